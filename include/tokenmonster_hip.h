@@ -1,0 +1,128 @@
+/* tokenmonster_hip.h — C ABI of libtokenmonster_hip.so: MI355X (gfx950) batch tokenizer for
+ * TokenMonster vocabularies.  This is the drop-in boundary for ONE path of the reference:
+ * the 6-branch ungreedy longest-match loop, go/tokenmonster.go:1017-1279 (Vocab.tokenize) and its
+ * copies (:1281 count, :1545/:1817/:2089 serialized, training/trainvocab.go:925-1176 scoring).
+ *
+ * The reference has no FFI of its own; the seams this library replaces are
+ *   (*Vocab).Tokenize / Count / TokenizeToSerialized      go/tokenmonster.go:959, :971, :986
+ *   tokenmonsterserver job 1 / job 20 goroutine fan-out   training/tokenmonsterserver.go:363-378, :773-787
+ *   trainvocab worker inner loop                          training/trainvocab.go:925-1176
+ *   Load (table upload; .vocab layout)                    go/tokenmonster.go:2656-2736
+ * INTEGRATION.md shows the cgo stub a maintainer adds on the Go side for each entry point.
+ *
+ * Conventions: extern "C", plain pointers and sizes.  Every host pointer is borrowed for the
+ * duration of the call only (cgo pointer-passing rule).  Every function returns TM_OK (0) or a
+ * negative TM_E_* code; tm_last_error() gives a thread-local message.  There is NO CPU fallback
+ * inside this library: if no gfx950 device is usable the call fails (TM_E_NODEVICE) and the Go
+ * side keeps using its own vocab.tokenize.
+ *
+ * Input text is ALREADY NORMALIZED bytes (what go/tokenmonster.go:963 `normalize` returns), unless
+ * stated otherwise.  The look-ahead pad byte is 0 (tokenmonster-cpp/src/tokenmonster.cpp:1724-1726).
+ */
+#ifndef TOKENMONSTER_HIP_H
+#define TOKENMONSTER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TM_OK 0
+#define TM_E_INVALID (-1)   /* bad argument / malformed .vocab */
+#define TM_E_NODEVICE (-2)  /* no usable gfx950 device */
+#define TM_E_HIP (-3)       /* a HIP runtime call failed */
+#define TM_E_NOSPACE (-4)   /* caller buffer too small; required size reported via out-params */
+#define TM_E_LIMIT (-5)     /* input exceeds a documented limit (batch bytes, trie nodes) */
+
+#define TM_NONE 0xFFFFFFu   /* go/tokenmonster.go:32 DOES_NOT_EXIST */
+
+typedef struct tm_vocab tm_vocab;     /* immutable device-resident vocabulary tables */
+typedef struct tm_batch tm_batch;     /* reusable device workspace for one batch of documents */
+typedef struct tm_dataset tm_dataset; /* device-resident normalized dataset for the scoring pass */
+
+const char* tm_last_error(void);
+int tm_device_count(void);
+/* Select the HIP device used by the calling thread's subsequent calls. */
+int tm_set_device(int device);
+
+/* ---- vocabulary: replaces Load's table construction (go/tokenmonster.go:2656-2736) ------------ */
+/* Parses the bytes of a .vocab file (layout: SURVEY.md Appendix A), builds the longest-match
+ * index and per-record rows, uploads them to the current device's HBM. */
+int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out);
+void tm_vocab_free(tm_vocab* v);
+uint32_t tm_vocab_size(const tm_vocab* v);             /* go :2477 Len()              */
+uint32_t tm_vocab_n_info(const tm_vocab* v);           /* index records incl. "D " duplicates */
+uint32_t tm_vocab_n_ids(const tm_vocab* v);            /* len(reverse) = highest ID + 1 */
+uint32_t tm_vocab_max_token_length(const tm_vocab* v); /* go :2498                    */
+uint32_t tm_vocab_capcode(const tm_vocab* v);          /* go :2390                    */
+uint32_t tm_vocab_charset(const tm_vocab* v);
+uint32_t tm_vocab_normalization(const tm_vocab* v);    /* normalizer flag byte        */
+uint32_t tm_vocab_unk(const tm_vocab* v);              /* unk id or TM_NONE           */
+uint32_t tm_vocab_delete_token(const tm_vocab* v);     /* deleteToken id or TM_NONE   */
+uint64_t tm_vocab_device_bytes(const tm_vocab* v);     /* HBM held by the tables      */
+
+/* ---- batch tokenize, host buffers: drop-in for the goroutine fan-out ------------------------- */
+/* Tokenizes `ndocs` independent documents.  Document d is text[offsets[d] .. offsets[d+1]).
+ * tokens_out receives all IDs, document after document; tok_offsets[ndocs+1] the prefix sums;
+ * missing[d] the count go/tokenmonster.go:1274 returns.  If tokens_cap is too small nothing is
+ * written to tokens_out, tok_offsets IS filled (so tok_offsets[ndocs] is the required capacity)
+ * and TM_E_NOSPACE is returned.  Equivalent of calling Vocab.tokenize on each document. */
+int tm_tokenize_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs,
+                      uint32_t* tokens_out, uint64_t tokens_cap, uint64_t* tok_offsets, uint32_t* missing);
+
+/* Same walk, counts only: go/tokenmonster.go:1281 tokenizeCount semantics (b-branches count 1,
+ * quirk Q2).  counts[ndocs], missing[ndocs]. */
+int tm_count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs,
+                   uint64_t* counts, uint32_t* missing);
+
+/* TokenizeToSerialized (go/tokenmonster.go:986): encoding_length 2, 3 or 4 bytes little-endian per
+ * ID (0 = auto: 2 if n_ids <= 65536 else 3, go :990-996).  bytes_out/byte_offsets as above. */
+int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs,
+                                 uint32_t encoding_length, uint8_t* bytes_out, uint64_t bytes_cap,
+                                 uint64_t* byte_offsets, uint32_t* missing, uint32_t* encoding_length_used);
+
+/* ---- batch tokenize, device-resident: what bench.py times ------------------------------------ */
+/* A tm_batch owns device buffers sized for up to max_bytes of text in up to max_docs documents. */
+int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm_batch** out);
+void tm_batch_free(tm_batch* b);
+/* H2D of packed text + offsets (synchronous). */
+int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs);
+/* Runs the whole device pipeline (match+branch, link, scan, emit) on `stream` (a hipStream_t, NULL =
+ * default stream).  Inputs and outputs stay in HBM.  Asynchronous with respect to the host. */
+int tm_batch_run(tm_batch* b, void* stream);
+/* As tm_batch_run but brackets every kernel with HIP events on `stream` and returns per-kernel
+ * milliseconds in ms[TM_NUM_KERNELS] (synchronizes). */
+#define TM_NUM_KERNELS 6
+int tm_batch_run_timed(tm_batch* b, void* stream, float* ms);
+const char* tm_kernel_name(int k);
+/* Totals of the last run (synchronizes the stream used by the last run). */
+int tm_batch_totals(tm_batch* b, uint64_t* total_tokens, uint64_t* total_missing);
+/* D2H of results of the last run. */
+int tm_batch_download(tm_batch* b, uint32_t* tokens_out, uint64_t tokens_cap, uint64_t* tok_offsets,
+                      uint32_t* missing);
+/* Raw device pointers of the last run's results (valid until the next run/free). */
+const uint32_t* tm_batch_device_tokens(const tm_batch* b);
+const uint64_t* tm_batch_device_tok_offsets(const tm_batch* b);
+uint64_t tm_batch_device_bytes(const tm_batch* b);
+
+/* ---- trainvocab scoring pass: replaces training/trainvocab.go:925-1176 ------------------------ */
+/* Upload the normalized dataset once (trainvocab.go:1660-1665 keeps it for the whole run). */
+int tm_dataset_upload(const uint8_t* normalized, uint64_t n, tm_dataset** out);
+void tm_dataset_free(tm_dataset* d);
+/* Walks each strip [strip_off[k], strip_off[k]+strip_len[k]) of the dataset exactly as the worker
+ * does and accumulates scores[id] += bytes covered, scores[deleteToken] += 1 per forward-delete,
+ * *tokens_in_text, and the 256-bit set of bytes that had no token.  scores has tm_vocab_n_ids()
+ * entries and is OVERWRITTEN.  n_strips == 0 means one strip = the whole dataset. */
+int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len,
+             uint32_t n_strips, uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]);
+/* Device-resident variant for multi-GPU reduction: leaves the histogram in HBM and returns its
+ * device pointer, *n_words = n_ids + 4 + 256 uint32: scores[n_ids] | tokens_in_text as four 16-bit limbs |
+ * missing[256] per-byte counters - every word is a plain sum over ranks, so ONE RCCL all-reduce(sum, uint32)
+ * merges the partial results of data-parallel ranks. */
+int tm_score_device(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len,
+                    uint32_t n_strips, void* stream, uint32_t** dev_hist, uint64_t* n_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

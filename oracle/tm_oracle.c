@@ -1,0 +1,290 @@
+/* oracle/tm_oracle.c — TEST INFRASTRUCTURE ONLY (the checker, never the product).
+ *
+ * Plain-C CPU restatement of TokenMonster's 6-branch ungreedy longest-match tokenization:
+ *   walk + scoring + select : go/tokenmonster.go:1017-1279  (== tokenmonster-cpp/src/tokenmonster.cpp:1723-1991)
+ *   count variant           : go/tokenmonster.go:1281-1543
+ *   trainvocab accumulation : training/trainvocab.go:925-1176
+ *   .vocab loader           : go/tokenmonster.go:2656-2736  (== tokenmonster.cpp:1287-1359)
+ *   longest-prefix index    : pansearch.Fast (third-party github.com/alasdairforsythe/pansearch, NOT in
+ *                             /root/reference and un-pinned: no go.mod).  Its published behaviour, as used at
+ *                             go/tokenmonster.go:1049 and translated at tokenmonster.cpp:491-1280, is
+ *                             "longest prefix that is a key; index = ordinal in (length, bytewise) order".
+ *                             Restated here in the most boring way possible: one binary search per length,
+ *                             longest first, over the records in file order.
+ *
+ * PINNING: (1) the reference's only known-answer vector, tokenmonster-cpp/tests/unit.cpp:87-112
+ * ("ab a z" -> {3,0,1,0}, missing 1, count {4,1}) — tests/test_oracle.py; (2) differential runs against
+ * oracle/_ref/libtmref.so, i.e. the reference's own C++ runtime compiled unmodified, on every fixture
+ * vocabulary and corpus in tests/ (IDs, missing, count).  The Go implementation itself cannot be run in
+ * this image (no Go toolchain, un-vendored deps); pad byte is 0 as in tokenmonster.cpp:1724-1726.
+ */
+#include "tm_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  uint8_t flag, n_words;     /* tokenInner, go/tokenmonster.go:79-83 */
+  uint8_t len, len1, len2;   /* own key length; alt lengths (0 = none) */
+  uint32_t index1, index2;   /* record ordinals of alternatives or TMO_NONE */
+  uint32_t id, id1, id2;
+  uint32_t key_off;          /* offset of key bytes in keys blob */
+} tmo_row;
+
+struct tmo_vocab {
+  uint8_t capcode, charset, norm_flag, level, reserve;
+  uint32_t unk, vocab_size, n_reverse, n_info, delete_id, max_len;
+  tmo_row* rows;
+  uint8_t* keys;             /* concatenated key bytes */
+  uint32_t len_start[42];    /* records of length L are [len_start[L], len_start[L+1]) */
+  uint8_t begin_byte[256];
+  uint32_t* rev_off;         /* reverse[id] -> (offset,len) of the LAST record with that id (go :2715) */
+  uint8_t* rev_len;
+};
+
+static _Thread_local char g_err[256];
+const char* tmo_last_error(void) { return g_err; }
+
+static uint32_t rd24(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+
+tmo_vocab* tmo_load(const uint8_t* f, size_t n) {
+  tmo_vocab* v = (tmo_vocab*)calloc(1, sizeof(*v));
+  size_t pos = 0;
+#define NEED(k) do { if (pos + (size_t)(k) > n) { snprintf(g_err, sizeof g_err, "truncated .vocab at %zu", pos); goto fail; } } while (0)
+  NEED(24);
+  v->capcode = f[0]; v->charset = f[1]; v->norm_flag = f[2]; v->level = f[3]; v->reserve = f[4];
+  if (v->charset > 2 || v->capcode > 2) { snprintf(g_err, sizeof g_err, "not a TokenMonster vocabulary"); goto fail; }
+  v->unk = rd24(f + 8); v->vocab_size = rd24(f + 11); v->n_reverse = rd24(f + 14); v->n_info = rd24(f + 17);
+  v->delete_id = rd24(f + 20); v->max_len = f[23];
+  pos = 24;
+  v->rows = (tmo_row*)calloc(v->n_info ? v->n_info : 1, sizeof(tmo_row));
+  v->keys = (uint8_t*)malloc((size_t)v->n_info * 40 + 1);
+  v->rev_off = (uint32_t*)calloc(v->n_reverse ? v->n_reverse : 1, 4);
+  v->rev_len = (uint8_t*)calloc(v->n_reverse ? v->n_reverse : 1, 1);
+  uint32_t koff = 0;
+  for (int L = 0; L < 42; L++) v->len_start[L] = 0;
+  uint32_t prev_len = 0;
+  for (uint32_t i = 0; i < v->n_info; i++) {
+    NEED(1);
+    uint32_t kl = f[pos++];
+    if (kl > 40 || kl == 0) { snprintf(g_err, sizeof g_err, "bad key length %u", kl); goto fail; }
+    NEED(kl + 15);
+    tmo_row* r = &v->rows[i];
+    r->len = (uint8_t)kl; r->key_off = koff;
+    memcpy(v->keys + koff, f + pos, kl); koff += kl; pos += kl;
+    if (kl < prev_len) { snprintf(g_err, sizeof g_err, "records not in length order at %u", i); goto fail; }
+    for (uint32_t L = prev_len + 1; L <= kl; L++) v->len_start[L] = i;
+    prev_len = kl;
+    r->flag = f[pos]; r->n_words = f[pos + 1];
+    r->index1 = rd24(f + pos + 2); r->index2 = rd24(f + pos + 5); r->id = rd24(f + pos + 8);
+    pos += 15; /* flag, nWords, index, index2, id, f32 score */
+    if (r->index1 != TMO_NONE) {            /* go/tokenmonster.go:2703-2706 */
+      if (r->index1 >= i) { snprintf(g_err, sizeof g_err, "alt index not earlier at %u", i); goto fail; }
+      r->len1 = v->rows[r->index1].len; r->id1 = v->rows[r->index1].id;
+    }
+    if (r->index2 != TMO_NONE) {            /* :2708-2711 */
+      if (r->index2 >= i) { snprintf(g_err, sizeof g_err, "alt index2 not earlier at %u", i); goto fail; }
+      r->len2 = v->rows[r->index2].len; r->id2 = v->rows[r->index2].id;
+    }
+    if (r->id >= v->n_reverse) { snprintf(g_err, sizeof g_err, "id out of range at %u", i); goto fail; }
+    v->rev_off[r->id] = r->key_off; v->rev_len[r->id] = r->len;   /* :2715 last writer wins */
+  }
+  for (uint32_t L = prev_len + 1; L < 42; L++) v->len_start[L] = v->n_info;
+  NEED(256);
+  memcpy(v->begin_byte, f + pos, 256); pos += 256;
+  NEED(3);
+  { uint32_t nd = rd24(f + pos); pos += 3;
+    for (uint32_t i = 0; i < nd; i++) { NEED(1); uint32_t l = f[pos++]; NEED(l + 7); pos += l + 7; } }
+  if (pos != n) { snprintf(g_err, sizeof g_err, "trailing bytes in .vocab"); goto fail; }  /* :2731 */
+  return v;
+fail:
+  tmo_free(v);
+  return NULL;
+#undef NEED
+}
+
+void tmo_free(tmo_vocab* v) {
+  if (!v) return;
+  free(v->rows); free(v->keys); free(v->rev_off); free(v->rev_len); free(v);
+}
+
+uint32_t tmo_vocab_size(const tmo_vocab* v) { return v->vocab_size; }
+uint32_t tmo_n_info(const tmo_vocab* v) { return v->n_info; }
+uint32_t tmo_max_token_length(const tmo_vocab* v) { return v->max_len; }
+uint32_t tmo_n_reverse(const tmo_vocab* v) { return v->n_reverse; }
+uint32_t tmo_capcode(const tmo_vocab* v) { return v->capcode; }
+
+int tmo_longest(const tmo_vocab* v, const uint8_t* key, size_t n, uint32_t* index, uint32_t* length) {
+  size_t L = n > 40 ? 40 : n;
+  for (; L >= 1; L--) {
+    uint32_t lo = v->len_start[L], hi = v->len_start[L + 1];
+    while (lo < hi) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      int c = memcmp(v->keys + v->rows[mid].key_off, key, L);
+      if (c == 0) { *index = mid; *length = (uint32_t)L; return 1; }
+      if (c < 0) lo = mid + 1; else hi = mid;
+    }
+  }
+  *index = 0; *length = 0;
+  return 0;
+}
+
+/* which exit of the walk was taken how often, so tests can prove every branch was exercised:
+ * 0 s1, 1 s2, 2 s3, 3 s1b, 4 s2b, 5 s3b, 6 fast-exit/end-of-text default emit, 7 all-NOSCORE default emit, 8 not found */
+static _Thread_local uint64_t g_stats[9];
+void tmo_stats(uint64_t out[9], int reset) {
+  for (int k = 0; k < 9; k++) { out[k] = g_stats[k]; if (reset) g_stats[k] = 0; }
+}
+
+#define NOSCORE (-1000000)
+static int max0(int x) { return x > 0 ? x : 0; }
+
+/* one walk, three sinks: mode 0 = ids (go :1017), 1 = count (go :1281), 2 = trainvocab histogram */
+typedef struct {
+  int mode;
+  uint32_t* out; size_t cap; long long ntok;      /* mode 0/1 */
+  uint32_t* scores; uint64_t tokens_in_text; uint8_t* missing_set; /* mode 2 */
+} sink_t;
+
+static void emit(const tmo_vocab* v, sink_t* s, uint32_t id, int adv, int with_delete) {
+  if (s->mode == 0) {
+    if ((size_t)s->ntok < s->cap) s->out[s->ntok] = id;
+    s->ntok++;
+    if (with_delete) { if ((size_t)s->ntok < s->cap) s->out[s->ntok] = v->delete_id; s->ntok++; }
+  } else if (s->mode == 1) {
+    s->ntok++;                        /* go/tokenmonster.go:1505-1521: +1 even for b-branches */
+  } else {
+    s->scores[id] += (uint32_t)adv;   /* trainvocab.go:1109..1162 */
+    if (with_delete) s->scores[v->delete_id]++;   /* :1134,1143,1152 (Q4: we use the ID) */
+    s->tokens_in_text += with_delete ? 2 : 1;
+  }
+}
+
+static long long walk(const tmo_vocab* v, const uint8_t* src, size_t n, sink_t* s) {
+  long long missing = 0;
+  if (v->max_len == 0) return 0;                  /* go :960 */
+  uint8_t* data = (uint8_t*)malloc(n + 1);
+  memcpy(data, src, n);
+  data[n] = 0;                                    /* go :1038-1046, pad 0 (tokenmonster.cpp:1726) */
+  const int lenData = (int)n, maxlen = (int)v->max_len;
+  const int off = v->charset == 2 ? 2 : 1;        /* go :1031-1034 */
+  const int maxlen_sp = maxlen - off;             /* go :1036 */
+  const int has_delete = v->delete_id != TMO_NONE;
+  const uint8_t* bb = v->begin_byte;
+  uint8_t lil[48];
+  memset(lil, 0, sizeof lil);
+  lil[0] = 32;                                    /* go :1030 */
+
+  int i = 0, fd = 0;
+  uint32_t index = 0, length = 0;
+  while (i < lenData) {
+    int rem = lenData - i;
+    if (!tmo_longest(v, data + i, (size_t)(rem < maxlen ? rem : maxlen), &index, &length)) {
+      /* go :1269-1276 */
+      if (s->mode == 2) { s->tokens_in_text++; if (s->missing_set) s->missing_set[data[i] >> 3] |= (uint8_t)(1u << (data[i] & 7)); }
+      else if (v->unk != TMO_NONE) { if (s->mode == 0) { if ((size_t)s->ntok < s->cap) s->out[s->ntok] = v->unk; } s->ntok++; }
+      i++; missing++; fd = 0; g_stats[8]++;
+      continue;
+    }
+  checkpoint:;
+    const tmo_row* O = &v->rows[index];
+    int len = (int)length;
+    int i1 = i + len;
+    int looked = 0;
+    if (i1 < lenData && ((O->flag & 32) == 0 || bb[data[i1]] != 12)) {       /* go :1057 */
+      looked = 1;
+      int s1 = NOSCORE, s2 = NOSCORE, s3 = NOSCORE, s1b = NOSCORE, s2b = NOSCORE, s3b = NOSCORE, best = NOSCORE;
+      uint32_t x1 = 0, l1 = 0, x2 = 0, l2 = 0, x3 = 0, l3 = 0, x1b = 0, l1b = 0, x2b = 0, l2b = 0, x3b = 0, l3b = 0;
+      /* candidate first tokens: k=0 greedy (go :1068), k=1 alt1 (:1111), k=2 alt2 (:1163, nested in alt1's test) */
+      for (int k = 0; k < 3; k++) {
+        int flen; const tmo_row* F;
+        if (k == 0) { flen = len; F = O; }
+        else if (k == 1) { if (O->index1 == TMO_NONE) break; flen = (int)O->len1 - fd; F = &v->rows[O->index1]; }
+        else { if (O->index2 == TMO_NONE) break; flen = (int)O->len2 - fd; F = &v->rows[O->index2]; }
+        int ik = i + flen;
+        int remk = lenData - ik;
+        uint32_t xk, lk;
+        if (!tmo_longest(v, data + ik, (size_t)(remk < maxlen ? remk : maxlen), &xk, &lk)) continue;
+        const tmo_row* S = &v->rows[xk];
+        int nw = (int)F->n_words - fd;                                      /* go :1071,1117,1169 */
+        int nb = bb[data[ik + (int)lk]];
+        int BL = flen + (int)lk;                                            /* :1075, :1120, :1172 */
+        int sc = (BL + (F->flag >> 7) + (S->flag >> 7) + max0(nw - 1) + max0((int)S->n_words - 1) +
+                  ((S->flag >> 2) & 1) + ((nb >> 2) & 1) + (nw + (int)S->n_words + (nb >> 3)) * 100) -
+                 ((F->flag & 1 & (S->flag >> 1)) * 103 + ((F->flag >> 3) & 1 & (S->flag >> 4)) * 100 +
+                  (S->flag & 1 & nb) * 3);
+        if (k > 0) sc -= (BL < len ? 100 : 0) + (BL == len ? 10000 : 0);   /* :1132-1133 */
+        if (sc > best) best = sc;
+        if (k == 0) { s1 = sc; x1 = xk; l1 = lk; } else if (k == 1) { s2 = sc; x2 = xk; l2 = lk; } else { s3 = sc; x3 = xk; l3 = lk; }
+        /* forward-delete variant, go :1088-1108 / :1137-1160 / :1189-1212 */
+        if (has_delete && (S->flag & 2) != 0 && nb == 1 && S->n_words == 0) {
+          int m = remk < maxlen_sp ? remk : maxlen_sp;
+          if (m < 0) m = 0;
+          memcpy(lil + off, data + ik, (size_t)m);
+          uint32_t xb, lb;
+          tmo_longest(v, lil, (size_t)(m + off), &xb, &lb);                 /* found ignored, Q9 */
+          if ((int)lb > (int)lk + 1) {
+            int lbb = (int)lb - off;
+            const tmo_row* Sb = &v->rows[xb];
+            int nbb = bb[data[ik + lbb]];
+            int BLb = flen + lbb;
+            int scb = (BLb + (F->flag >> 7) + (Sb->flag >> 7) + max0(nw - 1) + max0((int)Sb->n_words - 1) +
+                       ((nbb >> 2) & 1) + (nw + (int)Sb->n_words + (nbb >> 3)) * 100) -
+                      ((F->flag & 1) * 103 + ((F->flag >> 3) & 1 & (Sb->flag >> 4)) * 100 +
+                       (Sb->flag & 1 & nbb) * 3 + 1);
+            if (k > 0) scb -= (BLb < len ? 100 : 0) + (BLb == len ? 10000 : 0);
+            if (scb > best) best = scb;
+            if (k == 0) { s1b = scb; x1b = xb; l1b = (uint32_t)lbb; } else if (k == 1) { s2b = scb; x2b = xb; l2b = (uint32_t)lbb; } else { s3b = scb; x3b = xb; l3b = (uint32_t)lbb; }
+          }
+        }
+      }
+      /* go :1217-1262 — first equal wins in this order */
+      if (best != NOSCORE) {
+        if (best == s1)  { g_stats[0]++; emit(v, s, O->id,  len, 0);               i += len;               index = x1;  length = l1;  fd = 0; goto checkpoint; }
+        if (best == s2)  { g_stats[1]++; emit(v, s, O->id1, (int)O->len1 - fd, 0); i += (int)O->len1 - fd; index = x2;  length = l2;  fd = 0; goto checkpoint; }
+        if (best == s3)  { g_stats[2]++; emit(v, s, O->id2, (int)O->len2 - fd, 0); i += (int)O->len2 - fd; index = x3;  length = l3;  fd = 0; goto checkpoint; }
+        if (best == s1b) { g_stats[3]++; emit(v, s, O->id,  len, 1);               i += len;               index = x1b; length = l1b; fd = 1; goto checkpoint; }
+        if (best == s2b) { g_stats[4]++; emit(v, s, O->id1, (int)O->len1 - fd, 1); i += (int)O->len1 - fd; index = x2b; length = l2b; fd = 1; goto checkpoint; }
+        if (best == s3b) { g_stats[5]++; emit(v, s, O->id2, (int)O->len2 - fd, 1); i += (int)O->len2 - fd; index = x3b; length = l3b; fd = 1; goto checkpoint; }
+      }
+    }
+    g_stats[looked ? 7 : 6]++;
+    emit(v, s, O->id, len, 0);        /* go :1265-1267 */
+    i += len; fd = 0;
+  }
+  free(data);
+  return missing;
+}
+
+long long tmo_tokenize(const tmo_vocab* v, const uint8_t* data, size_t n, uint32_t* out, size_t cap, long long* missing) {
+  sink_t s; memset(&s, 0, sizeof s); s.mode = 0; s.out = out; s.cap = cap;
+  long long m = walk(v, data, n, &s);
+  if (missing) *missing = m;
+  return s.ntok;
+}
+
+long long tmo_count(const tmo_vocab* v, const uint8_t* data, size_t n, long long* missing) {
+  sink_t s; memset(&s, 0, sizeof s); s.mode = 1;
+  long long m = walk(v, data, n, &s);
+  if (missing) *missing = m;
+  return s.ntok;
+}
+
+void tmo_score(const tmo_vocab* v, const uint8_t* data, size_t n, uint32_t* scores, uint64_t* tokens_in_text,
+               uint8_t missing_set[32]) {
+  sink_t s; memset(&s, 0, sizeof s); s.mode = 2; s.scores = scores; s.missing_set = missing_set;
+  walk(v, data, n, &s);
+  if (tokens_in_text) *tokens_in_text += s.tokens_in_text;
+}
+
+long long tmo_decode_raw(const tmo_vocab* v, const uint32_t* toks, size_t n, uint8_t* out, size_t cap) {
+  size_t pos = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (toks[i] >= v->n_reverse) continue;       /* go decode skips ids out of range */
+    uint32_t l = v->rev_len[toks[i]];
+    if (pos + l <= cap) memcpy(out + pos, v->keys + v->rev_off[toks[i]], l);
+    pos += l;
+  }
+  return (long long)pos;
+}

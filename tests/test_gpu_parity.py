@@ -1,0 +1,80 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle, bit-exact token ids."""
+import numpy as np
+import pytest
+
+import tokenmonster_amd as tm
+from tokenmonster_amd import synth
+from conftest import fuzz_text, fuzz_vocab_tokens, unit_vocab_image
+from oracle_bind import Oracle, Reference, have_ref, oracle_stats
+
+pytestmark = pytest.mark.gpu
+
+
+def check_docs(vocab, orc, docs, what=""):
+    text, offs = tm.pack_documents(docs)
+    ids, toff, missing = vocab.tokenize_packed(text, offs)
+    assert toff[0] == 0 and toff[-1] == ids.size
+    for d, doc in enumerate(docs):
+        exp, miss = orc.tokenize(doc)
+        got = ids[int(toff[d]):int(toff[d + 1])]
+        assert got.size == exp.size and (got == exp).all(), "%s doc %d (len %d): ids differ\nexp %s\ngot %s" % (
+            what, d, len(doc), exp[:40], got[:40])
+        assert int(missing[d]) == miss, "%s doc %d: missing %d != %d" % (what, d, int(missing[d]), miss)
+    return ids, toff, missing
+
+
+def test_unit_golden_vector():
+    # tokenmonster-cpp/tests/unit.cpp:87-112
+    v = tm.Vocab(unit_vocab_image())
+    ids, missing = v.tokenize_normalized(b"ab a z")
+    assert ids.tolist() == [3, 0, 1, 0] and missing == 1
+    counts, miss = v.count_packed(*tm.pack_documents([b"ab a z"]))
+    assert int(counts[0]) == 4 and int(miss[0]) == 1
+    b, boff, _, enc = v.tokenize_serialized_packed(*tm.pack_documents([b"ab"]), encoding_length=2)
+    assert enc == 2 and b.tolist() == [3, 0]
+
+
+@pytest.mark.parametrize("capcode", [0, 2])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_fuzz_micro_vocab(capcode, seed):
+    rng = np.random.default_rng(1000 * capcode + seed)
+    toks = fuzz_vocab_tokens(rng, capcode, 60 + 40 * seed)
+    img = synth.build_vocab(toks, capcode=capcode, charset=1, with_unk=(seed % 2 == 0))
+    v = tm.Vocab(img)
+    orc = Oracle(img)
+    oracle_stats(reset=True)
+    docs = [fuzz_text(rng, capcode, int(n)) for n in rng.integers(0, 3000, size=120)]
+    docs += [b"", b"a", b" ", fuzz_text(rng, capcode, 511), fuzz_text(rng, capcode, 512), fuzz_text(rng, capcode, 513),
+             fuzz_text(rng, capcode, 1024), fuzz_text(rng, capcode, 1025), fuzz_text(rng, capcode, 70000)]
+    check_docs(v, orc, docs, "fuzz capcode=%d seed=%d" % (capcode, seed))
+    st = oracle_stats()
+    # the fuzz must actually have exercised the alternatives; with capcode 2 also the forward-delete branches
+    assert st["s1"] > 0 and st["s2"] > 0 and st["s3"] > 0 and st["not_found"] > 0, st
+    if capcode == 2:
+        assert st["s1b"] + st["s2b"] + st["s3b"] > 0, st
+
+
+@pytest.mark.parametrize("name", ["englishcode-32000-consistent", "code-4096-balanced-nocapcode"])
+def test_synthetic_config(name):
+    kind, size, capcode, norm_flag, level, seed = synth.CONFIGS[name]
+    img = synth.config_vocab(name)
+    v = tm.Vocab(img)
+    orc = Oracle(img)
+    raw, offs = synth.synth_corpus(kind, 400_000, seed=0x434F5250 + 2)
+    text, noff = synth.normalize_batch(raw, offs, capcode, norm_flag)
+    docs = [text[int(noff[d]):int(noff[d + 1])].tobytes() for d in range(noff.size - 1)]
+    oracle_stats(reset=True)
+    ids, toff, _ = check_docs(v, orc, docs, name)
+    st = oracle_stats()
+    assert st["s1"] > 0 and st["s2"] > 0
+    # Count(): b-branches count once (quirk Q2)
+    counts, _ = v.count_packed(text, noff)
+    for d in range(0, len(docs), 17):
+        assert int(counts[d]) == orc.count(docs[d])[0]
+    # reference's own runtime, when its prebuilt library travelled with the snapshot
+    if have_ref():
+        ref = Reference(img)
+        for d in range(0, len(docs), 7):
+            exp, _ = ref.tokenize_normalized(docs[d])
+            got = ids[int(toff[d]):int(toff[d + 1])]
+            assert got.size == exp.size and (got == exp).all()

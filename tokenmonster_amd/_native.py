@@ -1,0 +1,116 @@
+"""ctypes binding of libtokenmonster_hip.so (include/tokenmonster_hip.h, include/tm_build.h).
+
+The library is the product path.  If it is missing the import raises: there is no Python or CPU
+fallback for tokenization."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtokenmonster_hip.so")
+
+TM_OK, TM_E_INVALID, TM_E_NODEVICE, TM_E_HIP, TM_E_NOSPACE, TM_E_LIMIT = 0, -1, -2, -3, -4, -5
+TM_NONE = 0xFFFFFF
+TM_NUM_KERNELS = 6
+KIND_ENGLISH, KIND_ENGLISHCODE, KIND_CODE = 0, 1, 2
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+# name -> (restype, argtypes): every symbol the two public headers declare
+SIGNATURES = {
+    "tm_last_error": (C.c_char_p, []),
+    "tm_device_count": (C.c_int, []),
+    "tm_set_device": (C.c_int, [C.c_int]),
+    "tm_vocab_load": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "tm_vocab_free": (None, [vp]),
+    "tm_vocab_size": (C.c_uint32, [vp]),
+    "tm_vocab_n_info": (C.c_uint32, [vp]),
+    "tm_vocab_n_ids": (C.c_uint32, [vp]),
+    "tm_vocab_max_token_length": (C.c_uint32, [vp]),
+    "tm_vocab_capcode": (C.c_uint32, [vp]),
+    "tm_vocab_charset": (C.c_uint32, [vp]),
+    "tm_vocab_normalization": (C.c_uint32, [vp]),
+    "tm_vocab_unk": (C.c_uint32, [vp]),
+    "tm_vocab_delete_token": (C.c_uint32, [vp]),
+    "tm_vocab_device_bytes": (C.c_uint64, [vp]),
+    "tm_tokenize_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp]),
+    "tm_count_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp]),
+    "tm_tokenize_batch_serialized": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, u32p]),
+    "tm_batch_create": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
+    "tm_batch_free": (None, [vp]),
+    "tm_batch_upload": (C.c_int, [vp, vp, vp, C.c_uint32]),
+    "tm_batch_run": (C.c_int, [vp, vp]),
+    "tm_batch_run_timed": (C.c_int, [vp, vp, f32p]),
+    "tm_kernel_name": (C.c_char_p, [C.c_int]),
+    "tm_batch_totals": (C.c_int, [vp, u64p, u64p]),
+    "tm_batch_download": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
+    "tm_batch_device_tokens": (vp, [vp]),
+    "tm_batch_device_tok_offsets": (vp, [vp]),
+    "tm_batch_device_bytes": (C.c_uint64, [vp]),
+    "tm_dataset_upload": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
+    "tm_dataset_free": (None, [vp]),
+    "tm_score": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, u64p, vp]),
+    "tm_score_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.POINTER(vp), u64p]),
+    # tm_build.h
+    "tm_free": (None, [vp]),
+    "tm_build_vocab": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                 C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "tm_synth_corpus": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32, u32p, u64p]),
+    "tm_synth_vocab": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
+                                 C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "tm_normalize": (C.c_int, [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "tm_normalize_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp), vp]),
+}
+
+
+class TokenMonsterHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libtokenmonster_hip: error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the HIP tokenizer)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != TM_OK:
+        raise TokenMonsterHipError(rc, (lib.tm_last_error() or b"").decode(errors="replace"))
+
+
+def ptr(a):
+    """raw pointer of a contiguous numpy array (or None)"""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def take(p, n):
+    """copy a malloc'd buffer returned by the library into bytes and free it"""
+    try:
+        return C.string_at(p.value, n) if n else b""
+    finally:
+        lib.tm_free(p)
+
+
+def as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)

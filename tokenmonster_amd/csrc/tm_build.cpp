@@ -1,0 +1,360 @@
+// tm_build.cpp — vocabulary builder: per-token metadata rules of the reference restated in C++.
+//
+// Follows go/tokenmonster.go:3423-3793 (== training/trainvocab.go:548-907, the per-candidate table
+// build of the trainvocab worker) and writes go/tokenmonster.go:2602-2653's .vocab layout.
+// Unicode classes come from ICU (Go: unicode.IsLetter / IsNumber / Mn,Mc,Me / IsSpace).
+#include "tm_build.h"
+#include "tokenmonster_hip.h"
+#include "tm_internal.h"
+
+#include <unicode/uchar.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+namespace tmh {
+
+namespace {
+
+constexpr uint32_t kRuneError = 0xFFFD;
+
+// utf8.DecodeRune semantics: (RuneError,0) on empty, (RuneError,1) on invalid
+struct Rune { uint32_t r; int n; };
+
+Rune decode_utf8(const uint8_t* b, size_t len) {
+  if (len == 0) return {kRuneError, 0};
+  uint8_t b0 = b[0];
+  if (b0 < 0x80) return {b0, 1};
+  if (b0 < 0xC2 || b0 > 0xF4) return {kRuneError, 1};
+  int need = b0 < 0xE0 ? 1 : (b0 < 0xF0 ? 2 : 3);
+  if ((size_t)need + 1 > len) return {kRuneError, 1};
+  uint32_t cp = b0 & (need == 1 ? 0x1F : need == 2 ? 0x0F : 0x07);
+  for (int k = 1; k <= need; k++) {
+    if ((b[k] & 0xC0) != 0x80) return {kRuneError, 1};
+    cp = (cp << 6) | (b[k] & 0x3F);
+  }
+  if ((need == 2 && cp < 0x800) || (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) || (cp >= 0xD800 && cp <= 0xDFFF))
+    return {kRuneError, 1};
+  return {cp, need + 1};
+}
+
+// go/tokenmonster.go:371-400
+Rune decode_rune(const uint8_t* b, size_t len, uint32_t charset) {
+  if (charset != 2) return decode_utf8(b, len);
+  if (len < 2) return {kRuneError, 0};
+  uint32_t u = b[0] | (b[1] << 8);
+  if (u >= 0xD800 && u <= 0xDBFF) {
+    if (len < 4) return {kRuneError, 0};
+    uint32_t u2 = b[2] | (b[3] << 8);
+    if (u2 < 0xDC00 || u2 > 0xDFFF) return {kRuneError, 0};
+    return {0x10000 + ((u - 0xD800) << 10) + (u2 - 0xDC00), 4};
+  }
+  return {u, 2};
+}
+
+// go/tokenmonster.go:402-430 ; utf8.DecodeLastRune
+uint32_t decode_last_rune(const uint8_t* b, size_t len, uint32_t charset) {
+  if (charset == 2) {
+    if (len < 2) return kRuneError;
+    uint32_t u = b[len - 2] | (b[len - 1] << 8);
+    if (u >= 0xDC00 && u <= 0xDFFF) {
+      if (len < 4) return kRuneError;
+      uint32_t u2 = b[len - 4] | (b[len - 3] << 8);
+      if (u2 < 0xD800 || u2 > 0xDBFF) return kRuneError;
+      return 0x10000 + ((u2 - 0xD800) << 10) + (u - 0xDC00);
+    }
+    return u;
+  }
+  if (len == 0) return kRuneError;
+  size_t start = len - 1;
+  size_t lim = len >= 4 ? len - 4 : 0;
+  while (start > lim && (b[start] & 0xC0) == 0x80) start--;
+  Rune r = decode_utf8(b + start, len - start);
+  if (start + (size_t)r.n != len) return kRuneError;
+  return r.r;
+}
+
+bool uni_letter(uint32_t r) { return (U_GET_GC_MASK((UChar32)r) & U_GC_L_MASK) != 0; }
+bool uni_number(uint32_t r) { return (U_GET_GC_MASK((UChar32)r) & U_GC_N_MASK) != 0; }
+bool uni_mark(uint32_t r) { return (U_GET_GC_MASK((UChar32)r) & U_GC_M_MASK) != 0; }
+bool uni_space(uint32_t r) {
+  if (r < 0x100) return r == '\t' || r == '\n' || r == '\v' || r == '\f' || r == '\r' || r == ' ' || r == 0x85 || r == 0xA0;
+  return u_hasBinaryProperty((UChar32)r, UCHAR_WHITE_SPACE);
+}
+
+// go/tokenmonster.go:359-369
+bool is_letter(uint32_t r, uint32_t cc) {
+  return (uni_letter(r) && (cc != 2 || (r != 'W' && r != 'C' && r != 'D'))) || uni_mark(r);
+}
+bool is_alnum(uint32_t r, uint32_t cc) { return is_letter(r, cc) || uni_number(r); }
+bool is_capcode(uint32_t r, uint32_t cc) {
+  return (cc == 1 && r == 0x7F) || (cc == 2 && (r == 'C' || r == 'W' || r == 'D'));
+}
+
+struct Rec {
+  std::string key;
+  uint32_t id = 0;
+  float score = 1.0f;
+  bool special = false;
+  uint8_t flag = 0, n_words = 0;
+  uint32_t index1 = TM_NONE, index2 = TM_NONE;
+};
+
+bool key_less(const std::string& a, const std::string& b) {
+  if (a.size() != b.size()) return a.size() < b.size();
+  return std::memcmp(a.data(), b.data(), a.size()) < 0;
+}
+
+// go/tokenmonster.go:287-299 with ungreedySuffixes {"'s", "’s"} (:3157)
+int has_suffix_pos(const std::string& key, uint32_t charset, uint32_t cc) {
+  static const std::string sfx[2] = {"'s", "\xE2\x80\x99s"};
+  for (const auto& s : sfx) {
+    if (key.size() >= s.size() && key.compare(key.size() - s.size(), s.size(), s) == 0) {
+      if (s.size() < key.size()) {
+        uint32_t r = decode_last_rune((const uint8_t*)key.data(), key.size() - s.size(), charset);
+        if (is_letter(r, cc)) return (int)(key.size() - s.size());
+      }
+    }
+  }
+  return -1;
+}
+
+void w24(std::vector<uint8_t>& o, uint32_t v) { o.push_back(v); o.push_back(v >> 8); o.push_back(v >> 16); }
+void wf32(std::vector<uint8_t>& o, float f) {
+  uint32_t b; std::memcpy(&b, &f, 4);
+  o.push_back(b); o.push_back(b >> 8); o.push_back(b >> 16); o.push_back(b >> 24);
+}
+
+}  // namespace
+
+int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vector<uint8_t>& special_in,
+                      uint32_t capcode, uint32_t charset, uint32_t norm_flag, uint32_t level, bool with_unk,
+                      std::vector<uint8_t>& image) {
+  if (capcode > 2 || charset > 2) return set_error(TM_E_INVALID, "capcode/charset out of range");
+  // ---- dic1: unique tokens in (length, bytewise) order  (go :3364-3380) -------------------------
+  std::vector<std::pair<std::string, bool>> dic1;
+  dic1.reserve(tokens_in.size());
+  for (size_t k = 0; k < tokens_in.size(); k++) {
+    if (tokens_in[k].empty()) continue;
+    if (tokens_in[k].size() > 40) return set_error(TM_E_INVALID, "token longer than 40 bytes");
+    dic1.emplace_back(tokens_in[k], k < special_in.size() && special_in[k] != 0);
+  }
+  std::sort(dic1.begin(), dic1.end(), [](const auto& a, const auto& b) { return key_less(a.first, b.first); });
+  dic1.erase(std::unique(dic1.begin(), dic1.end(), [](const auto& a, const auto& b) { return a.first == b.first; }),
+             dic1.end());
+  if (dic1.size() >= TM_NONE - 2) return set_error(TM_E_LIMIT, "too many tokens");
+
+  // ---- IDs + "D "-duplicates  (go :3423-3470) ---------------------------------------------------
+  std::unordered_map<std::string, uint32_t> ids;       // idsMap
+  std::unordered_map<std::string, float> scores;       // scoresMap (only the -1 marker matters)
+  std::unordered_map<std::string, bool> specials;      // specialMap
+  ids.reserve(dic1.size() * 2);
+  std::vector<std::string> keys;
+  keys.reserve(dic1.size() * 2);
+  const std::string add = std::string(1, capcode == 1 ? (char)0x7F : 'D') + " ";
+  uint32_t next_id = 0;
+  size_t n_single = 0;
+  for (auto& [tok, sp] : dic1) {
+    if (tok.size() == 1) n_single++;
+    if (sp) specials[tok] = true;
+    uint32_t id;
+    auto it = ids.find(tok);
+    if (it != ids.end()) id = it->second;  // e.g. a real token equal to an earlier token's duplicate
+    else { id = next_id++; keys.push_back(tok); }
+    ids[tok] = id;
+    Rune r = decode_rune((const uint8_t*)tok.data(), tok.size(), charset);
+    if (capcode != 0 && is_alnum(r.r, capcode)) {
+      std::string s = add + tok;
+      if (sp) specials[s] = true;
+      if (s.size() <= 40) {
+        if (ids.find(s) == ids.end()) keys.push_back(s);
+        ids[s] = id;
+        scores[s] = -1.0f;
+      }
+    }
+  }
+  uint32_t n_tokens = next_id;
+  // unk: id = number of tokens (go :3382-3398); canHaveUnkToken (go :437-442)
+  uint32_t unk = TM_NONE;
+  if (with_unk && ((n_single < 256 && capcode != 2) || n_single < 233)) unk = n_tokens;
+  uint32_t vocab_size = n_tokens + (unk != TM_NONE ? 1 : 0);
+  uint32_t n_reverse = vocab_size;
+
+  std::sort(keys.begin(), keys.end(), key_less);      // dictionary.Build(): pansearch order
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  const uint32_t n_info = (uint32_t)keys.size();
+  std::unordered_map<std::string_view, uint32_t> find;  // dictionary.Find
+  find.reserve(n_info * 2);
+  for (uint32_t i = 0; i < n_info; i++) find.emplace(std::string_view(keys[i]), i);
+
+  // deleteToken index (go :3474-3483)
+  uint32_t delete_index = TM_NONE;
+  if (capcode == 2) { auto it = find.find(std::string_view("D", 1)); if (it != find.end()) delete_index = it->second; }
+  else if (capcode == 1) { auto it = find.find(std::string_view("\x7F", 1)); if (it != find.end()) delete_index = it->second; }
+
+  uint32_t max_len = 0;
+  for (auto& k : keys) max_len = std::max<uint32_t>(max_len, (uint32_t)k.size());
+
+  // ---- per-record metadata (go :3486-3777) ------------------------------------------------------
+  std::vector<Rec> recs(n_info);
+  uint32_t begin_count[256][4];
+  std::memset(begin_count, 0, sizeof begin_count);
+  for (uint32_t on = 0; on < n_info; on++) {
+    const std::string& token = keys[on];
+    const uint8_t* t = (const uint8_t*)token.data();
+    const size_t tl = token.size();
+    Rec& rec = recs[on];
+    rec.key = token;
+    rec.id = ids[token];
+    auto sit = scores.find(token);
+    rec.score = sit != scores.end() ? sit->second : 1.0f;
+    if (specials.count(token)) { rec.special = true; rec.flag = 64; continue; }   // go :3504-3511
+    uint8_t flag = 0, n_words = 0, priority1 = 0, priority2 = 0;
+    int min_alt = 1, alt_len1 = 0, alt_len2 = 0;
+    bool only_letter_space = false, only_number_space = false, only_punc = false;
+    Rune d1 = decode_rune(t, tl, charset);
+    Rune d2 = decode_rune(t + d1.n, tl - d1.n, charset);
+    uint32_t r = d1.r, r2 = d2.r;
+    int n = d1.n, n2 = d2.n;
+    // beginning of token (go :3522-3542)
+    if (r == ' ') {
+      flag = 4; begin_count[t[0]][0]++;
+      if (is_alnum(r2, capcode)) { n_words++; min_alt = 2; }
+    } else if (is_letter(r, capcode)) {
+      flag = 2; begin_count[t[0]][1]++;
+    } else if (is_capcode(r, capcode)) {
+      if (r == 'C' || r == 'W') flag = 4;
+      flag |= 16; begin_count[t[0]][3]++;
+    } else if (uni_number(r)) {
+      begin_count[t[0]][2]++;
+    } else {
+      begin_count[t[0]][3]++;
+    }
+    // words in token (go :3544-3572)
+    if (tl == 1) {
+      only_punc = true;
+    } else {
+      if ((r == ' ' || is_letter(r, capcode)) && is_letter(r2, capcode)) only_letter_space = true;
+      else if ((r == ' ' || uni_number(r)) && uni_number(r2)) only_number_space = true;
+      else if (!is_alnum(r, capcode) && !is_alnum(r2, capcode)) only_punc = true;
+      for (size_t i = (size_t)(n + n2); i < tl; i += (size_t)n2) {
+        r = r2; n = n2;
+        Rune d = decode_rune(t + i, tl - i, charset);
+        r2 = d.r; n2 = d.n;
+        if (n2 <= 0) break;  // (Go would spin on a malformed UTF-16 tail; nothing to classify)
+        if (r == ' ' && is_alnum(r2, capcode)) n_words++;
+        if (is_letter(r2, capcode)) { only_punc = false; only_number_space = false; }
+        else if (uni_number(r2)) { only_punc = false; only_letter_space = false; }
+        else if (r2 != ' ') { only_letter_space = false; only_number_space = false; }
+      }
+    }
+    // go :3575-3593
+    r = decode_last_rune(t, tl, charset);
+    if (min_alt == 2 && is_letter(r, capcode) && only_letter_space && n_words == 1) flag |= 32;
+    if (min_alt == 2 && n_words <= 1) min_alt = 1;
+    if (is_capcode(r, capcode)) flag |= 8;
+    if (is_letter(r, capcode)) flag |= 1;
+    if (only_letter_space || only_number_space || only_punc) flag |= 128;
+
+    const int has_suffix = has_suffix_pos(token, charset, capcode);
+    uint32_t index1 = TM_NONE, index2 = TM_NONE;
+    // slot choice shared by every rule: go :3606 etc.
+    auto offer = [&](uint8_t prio, uint32_t index, int length) {
+      if (priority1 < priority2 || (priority1 == priority2 && alt_len1 <= alt_len2)) {
+        if (priority1 < prio) { index1 = index; alt_len1 = length; priority1 = prio; }
+      } else {
+        if (priority2 < prio) { index2 = index; alt_len2 = length; priority2 = prio; }
+      }
+    };
+    for (int length = (int)tl - 1; length >= min_alt; length--) {      // go :3597
+      auto fit = find.find(std::string_view(token.data(), (size_t)length));
+      if (fit == find.end()) continue;
+      const uint32_t index = fit->second;
+      // anything | space + letter-or-number (go :3602-3621)
+      if (length <= (int)tl - 2 && t[length] == ' ') {
+        Rune d = decode_rune(t + length + 1, tl - (size_t)length - 1, charset);
+        if (is_letter(d.r, capcode) || uni_number(d.r)) { offer(10, index, length); continue; }
+      }
+      uint32_t ra = decode_last_rune(t, (size_t)length, charset);                     // go :3624
+      uint32_t rb = decode_rune(t + length, tl - (size_t)length, charset).r;         // go :3625
+      if (capcode == 0) {                                                              // go :3627-3647
+        if (((!is_letter(ra, capcode) && ra != '_') && (is_letter(rb, capcode) || rb == '_')) ||
+            (!uni_number(ra) && uni_number(rb))) { offer(9, index, length); continue; }
+      }
+      if (((is_letter(ra, capcode) || ra == '_') && (!is_letter(rb, capcode) && rb != '_')) ||
+          (uni_number(ra) && !uni_number(rb))) { offer(9, index, length); continue; }   // go :3651-3668
+      if (uni_space(ra) && !uni_space(rb)) { offer(7, index, length); continue; }        // go :3670
+      if (!uni_space(ra) && uni_space(rb)) { offer(8, index, length); continue; }        // go :3686
+      if (is_capcode(rb, capcode)) { offer(9, index, length); continue; }                // go :3702
+      if (length == has_suffix) { offer(8, index, length); break; }                      // go :3720-3735 (Q7: break)
+      offer(1, index, length);                                                           // go :3738-3750
+    }
+    // go :3761-3764
+    if (alt_len2 > 0 && (priority2 > priority1 || (priority2 == priority1 && alt_len2 > alt_len1))) {
+      std::swap(index1, index2); std::swap(alt_len1, alt_len2);
+    }
+    rec.flag = flag; rec.n_words = n_words;
+    rec.index1 = alt_len1 > 0 ? index1 : TM_NONE;
+    rec.index2 = alt_len2 > 0 ? index2 : TM_NONE;
+  }
+
+  // ---- beginByte (go :3779-3788) ----------------------------------------------------------------
+  uint8_t begin_byte[256];
+  for (int i = 0; i < 256; i++) {
+    const uint32_t* c = begin_count[i];
+    begin_byte[i] = 0;
+    if (c[1] > c[0] && c[1] > c[2] && c[1] > c[3] && c[1] > 2) begin_byte[i] = 1;
+    else if (c[0] > c[1] && c[0] > c[2] && c[0] > c[3] && c[0] > 2) begin_byte[i] = 12;
+    else if (c[3] > c[0] && c[3] > c[1] && c[3] > c[2] && c[3] > 2) begin_byte[i] = 10;
+  }
+  uint32_t delete_id = delete_index != TM_NONE ? recs[delete_index].id : TM_NONE;  // go :3791-3793
+
+  // ---- write (go :2602-2653) --------------------------------------------------------------------
+  image.clear();
+  image.reserve(24 + (size_t)n_info * 24 + 300);
+  image.push_back((uint8_t)capcode); image.push_back((uint8_t)charset); image.push_back((uint8_t)norm_flag);
+  image.push_back((uint8_t)level); image.push_back(0); image.push_back(0); image.push_back(0); image.push_back(0);
+  w24(image, unk); w24(image, vocab_size); w24(image, n_reverse); w24(image, n_info); w24(image, delete_id);
+  image.push_back((uint8_t)max_len);
+  for (auto& rec : recs) {
+    image.push_back((uint8_t)rec.key.size());
+    image.insert(image.end(), rec.key.begin(), rec.key.end());
+    image.push_back(rec.flag); image.push_back(rec.n_words);
+    w24(image, rec.index1); w24(image, rec.index2); w24(image, rec.id);
+    wf32(image, rec.score);
+  }
+  image.insert(image.end(), begin_byte, begin_byte + 256);
+  w24(image, 0);  // deleted tokens
+  return TM_OK;
+}
+
+}  // namespace tmh
+
+extern "C" {
+
+void tm_free(void* p) { std::free(p); }
+
+int tm_build_vocab(const uint8_t* blob, const uint32_t* off, uint32_t n_tokens, const uint8_t* special,
+                   uint32_t capcode, uint32_t charset, uint32_t norm_flag, uint32_t level, int with_unk,
+                   uint8_t** out, size_t* out_n) {
+  if (!out || !out_n || (n_tokens && (!blob || !off))) return tmh::set_error(TM_E_INVALID, "null argument");
+  std::vector<std::string> toks(n_tokens);
+  std::vector<uint8_t> sp(n_tokens, 0);
+  for (uint32_t k = 0; k < n_tokens; k++) {
+    toks[k].assign((const char*)blob + off[k], off[k + 1] - off[k]);
+    if (special) sp[k] = special[k];
+  }
+  std::vector<uint8_t> image;
+  int rc = tmh::build_vocab_image(toks, sp, capcode, charset, norm_flag, level, with_unk != 0, image);
+  if (rc != TM_OK) return rc;
+  *out = (uint8_t*)std::malloc(image.size());
+  std::memcpy(*out, image.data(), image.size());
+  *out_n = image.size();
+  return TM_OK;
+}
+
+}  // extern "C"

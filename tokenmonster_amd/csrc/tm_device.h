@@ -1,0 +1,42 @@
+// tm_device.h — host-side structures behind the opaque handles of tokenmonster_hip.h (HIP TUs only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "tokenmonster_hip.h"
+#include "tm_internal.h"
+#include "tm_tables.h"
+
+namespace tmh {
+
+int hip_fail(hipError_t e, const char* what);
+
+struct HostVocab {
+  uint8_t capcode = 0, charset = 0, norm_flag = 0, level = 0, reserve = 0;
+  uint32_t unk = TM_NONE, vocab_size = 0, n_ids = 0, n_info = 0, delete_id = TM_NONE, max_len = 0;
+  std::vector<uint8_t> keys;        // concatenated key bytes
+  std::vector<uint32_t> key_off;    // n_info + 1
+  std::vector<Row> rows;
+  uint8_t begin_byte[256];
+  std::vector<uint32_t> root, l2;
+  std::vector<uint2> edges;
+  uint32_t edge_mask = 0, edge_shift = 0, n_nodes = 0, off = 1, bstart = kNone;
+};
+
+int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv);
+
+}  // namespace tmh
+
+struct tm_vocab {
+  tmh::HostVocab host;
+  tmh::Tables tables{};
+  int device = 0;
+  uint64_t device_bytes = 0;
+  uint32_t* d_root = nullptr;
+  uint32_t* d_l2 = nullptr;
+  uint2* d_edges = nullptr;
+  tmh::Row* d_rows = nullptr;
+  uint8_t* d_begin_byte = nullptr;
+};

@@ -1,0 +1,46 @@
+// tm_internal.h — shared between the host translation units of libtokenmonster_hip.so.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace tmh {
+
+// thread-local error string behind tm_last_error()
+int set_error(int code, const char* fmt, ...);
+const char* last_error();
+
+// tm_build.cpp
+int build_vocab_image(const std::vector<std::string>& tokens, const std::vector<uint8_t>& special, uint32_t capcode,
+                      uint32_t charset, uint32_t norm_flag, uint32_t level, bool with_unk,
+                      std::vector<uint8_t>& image);
+
+// tm_normalize.cpp
+void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out);
+
+// small deterministic PRNG (splitmix64 seeding + xoshiro256**), used by the synthetic generators
+struct Rng {
+  uint64_t s[4];
+  explicit Rng(uint64_t seed) {
+    for (auto& x : s) {
+      seed += 0x9E3779B97F4A7C15ull;
+      uint64_t z = seed;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      x = z ^ (z >> 31);
+    }
+  }
+  static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+  uint64_t next() {
+    const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+    return r;
+  }
+  uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+  double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+  bool chance(double p) { return unit() < p; }
+};
+
+}  // namespace tmh

@@ -1,0 +1,998 @@
+// tm_kernels.hip — gfx950 kernels of the ungreedy tokenization path and the tm_batch pipeline.
+//
+// Reference path: go/tokenmonster.go:1017-1279 (Vocab.tokenize).  Restated as a specification in
+// SURVEY.md Appendix B; the property everything here rests on (derived from go :1051-1267) is that
+// the walk's whole carried state at a token boundary is (i, forwardDelete): `index/length` are always
+// the longest match at i (or of ' '+data[i:] when forwardDelete == 1).  Hence
+//     T(i, fd) -> (emitted id, advance, fd')
+// is a pure function of the text around i and can be evaluated for EVERY byte position independently.
+//
+// Pipeline (one wavefront owns one <=512-byte document segment; LDS holds its text and the per-position
+// second-token descriptors, i.e. the live cursors of all six branches of every position at once):
+//   K0 segments      doc -> segment table (binary search per segment)
+//   K1 match_branch  per position: longest match (trie walk) and forward-delete match -> descriptors in
+//                    LDS; then the 6-branch score/select of go :1068-1262 per (position, fd) -> R[p] = {T(p,0), T(p,1)}
+//   K2 link          per segment: follow T from each of the 80 possible entry states to the segment exit
+//                    -> exit map (next entry state, #tokens, #forward-deletes, #missing)
+//   K3 resolve       per document: chain the exit maps -> entry state + token base of every segment
+//   K4 emit          per segment: follow T from the true entry state, write token ids densely
+// All integer/byte work: no MFMA.  HBM-side traffic is streaming (text in, R out/in, ids out); the
+// vocabulary tables (<= a few MB) live in L2 / Infinity Cache and are the gather-bound part.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "tm_device.h"
+
+namespace tmh {
+
+constexpr int SEG = 512;                 // bytes of one document segment (one wavefront)
+constexpr int NPOS = SEG + 40;           // positions whose descriptors a segment needs (look-ahead <= 40)
+constexpr int NPOS_PAD = 576;            // 9 x 64
+constexpr int TEXT_LEN = SEG + 96;       // staged text: position i may read up to i + 40
+constexpr int ENT = 80;                  // entry states of a segment: 40 offsets x fd{0,1}
+constexpr int WAVES = 4;                 // wavefronts per workgroup in K1
+constexpr uint32_t R_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t ID_NONE = 0xFFFFFFu;
+constexpr int NOSCORE = -1000000;
+
+// R word: id[0..23] | advance[24..29] | fd'[30] | missing[31]
+
+// ------------------------------------------------------------------------------------------------
+// small utilities
+// ------------------------------------------------------------------------------------------------
+// Documents are given as doc_begin[d] .. doc_end[d] (for packed batches doc_end == doc_begin + 1 of the same
+// offsets array; for the scoring pass they are arbitrary disjoint strips of the dataset).
+__global__ void k_doc_nseg(const uint64_t* __restrict__ doc_begin, const uint64_t* __restrict__ doc_end, uint32_t ndocs,
+                           uint32_t* __restrict__ doc_nseg) {
+  uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < ndocs) {
+    uint64_t len = doc_end[d] - doc_begin[d];
+    doc_nseg[d] = (uint32_t)((len + SEG - 1) / SEG);
+  }
+}
+
+// exclusive scan u32 -> u64, three phases, CH elements per block
+constexpr int SCAN_T = 256, SCAN_PER = 16, SCAN_CH = SCAN_T * SCAN_PER;
+
+__global__ void k_scan_partial(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ block_sums) {
+  __shared__ uint64_t s[SCAN_T];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_CH + (uint64_t)threadIdx.x * SCAN_PER;
+  uint64_t acc = 0;
+  for (int k = 0; k < SCAN_PER; k++) if (base + k < n) acc += in[base + k];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = SCAN_T / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = s[0];
+}
+
+__global__ void k_scan_sums(uint64_t* __restrict__ block_sums, uint32_t nblocks, uint64_t* __restrict__ total) {
+  // single workgroup; serial over chunks of SCAN_T
+  __shared__ uint64_t s[SCAN_T];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nblocks; base += SCAN_T) {
+    uint32_t i = base + threadIdx.x;
+    uint64_t v = i < nblocks ? block_sums[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 1; st < SCAN_T; st <<= 1) {
+      uint64_t t = (int)threadIdx.x >= st ? s[threadIdx.x - st] : 0;
+      __syncthreads();
+      s[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblocks) block_sums[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += s[SCAN_T - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void k_scan_final(const uint32_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ block_sums,
+                             uint64_t* __restrict__ out) {
+  __shared__ uint64_t s[SCAN_T];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_CH + (uint64_t)threadIdx.x * SCAN_PER;
+  uint32_t v[SCAN_PER];
+  uint64_t acc = 0;
+  for (int k = 0; k < SCAN_PER; k++) { v[k] = base + k < n ? in[base + k] : 0; acc += v[k]; }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 1; st < SCAN_T; st <<= 1) {
+    uint64_t t = (int)threadIdx.x >= st ? s[threadIdx.x - st] : 0;
+    __syncthreads();
+    s[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint64_t run = block_sums[blockIdx.x] + s[threadIdx.x] - acc;
+  for (int k = 0; k < SCAN_PER; k++) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (base <= n && n < base + SCAN_PER) out[n] = run - 0;  // one-past-the-end = grand total (run == prefix up to n)
+}
+
+// K0: segment g belongs to the document d with doc_seg_start[d] <= g < doc_seg_start[d+1]
+__global__ void k_segments(const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs, uint64_t nseg,
+                           uint32_t* __restrict__ seg_doc) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nseg) return;
+  uint32_t lo = 0, hi = ndocs;   // invariant: start[lo] <= g < start[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = lo + (hi - lo) / 2;
+    if (doc_seg_start[mid] <= g) lo = mid; else hi = mid;
+  }
+  seg_doc[g] = lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: match + branch
+// ------------------------------------------------------------------------------------------------
+struct Match { uint32_t v; uint32_t len; };   // v = node value of the longest accepting prefix, len its length (0 = none)
+
+__device__ __forceinline__ uint32_t edge_lookup(const Tables& T, uint32_t parent, uint32_t byte) {
+  uint32_t key = (parent << 8) | byte;
+  uint32_t h = (key * 0x9E3779B1u) >> T.edge_shift;
+  for (;;) {
+    uint2 e = T.edges[h];
+    if (e.x == key) return e.y;
+    if (e.x == kNone) return kNone;
+    h = (h + 1) & T.edge_mask;
+  }
+}
+
+// continue a trie walk: `v` is the node value reached after `depth` bytes; text byte number k of the
+// string being matched is txt[k].  limit = number of bytes available.  (pansearch LongestSubstring,
+// call sites go/tokenmonster.go:1049,1068,1091,...; semantics tokenmonster.cpp:786-877)
+__device__ __forceinline__ void walk_tail(const Tables& T, const uint8_t* txt, uint32_t v, uint32_t depth, uint32_t limit,
+                                          Match& best) {
+  while (depth < limit && (v & kHasChildren)) {
+    uint32_t c = txt[depth];
+    v = edge_lookup(T, node_id(v), c);
+    if (v == kNone) break;
+    depth++;
+    if (node_id(v) < T.n_info) { best.v = v; best.len = depth; }
+  }
+}
+
+// descriptor word kept in LDS per position: len[0..5] | flag5[6..10] | nWords[11..15] | nextByteClass[16..19]
+__device__ __forceinline__ uint32_t make_desc(uint32_t len, uint32_t v, uint32_t nb) {
+  return len | (node_flag5(v) << 6) | (node_nwords(v) << 11) | (nb << 16);
+}
+
+struct First { int flen; int nw; uint32_t f3; };   // candidate first token: length consumed, nWords - fd, flag bits {1, 8>>3, 128>>7}
+
+// score of one branch, go/tokenmonster.go:1075-1084 (a), :1096-1105 (b); k > 0 adds :1132-1133
+__device__ __forceinline__ int branch_score(const First& F, uint32_t dS, bool bvariant, bool alt, int len) {
+  int l = (int)(dS & 63u);
+  uint32_t f5 = (dS >> 6) & 31u;
+  int snw = (int)((dS >> 11) & 31u);
+  int nb = (int)((dS >> 16) & 15u);
+  int BL = F.flen + l;
+  int fend = (int)(F.f3 & 1u), fcap = (int)((F.f3 >> 1) & 1u), fall = (int)((F.f3 >> 2) & 1u);
+  int send = (int)(f5 & 1u), sbegl = (int)((f5 >> 1) & 1u), sbegs = (int)((f5 >> 2) & 1u), sbegc = (int)((f5 >> 3) & 1u),
+      sall = (int)((f5 >> 4) & 1u);
+  int sc = BL + fall + sall + max(F.nw - 1, 0) + max(snw - 1, 0) + ((nb >> 2) & 1) + (F.nw + snw + (nb >> 3)) * 100;
+  if (!bvariant) sc += sbegs;
+  int pen = (fcap & sbegc) * 100 + (send & nb & 1) * 3;
+  pen += bvariant ? fend * 103 + 1 : (fend & sbegl) * 103;
+  if (alt) pen += (BL < len ? 100 : 0) + (BL == len ? 10000 : 0);
+  return sc - pen;
+}
+
+struct WaveLds {
+  uint8_t text[TEXT_LEN];
+  uint32_t D[NPOS_PAD];    // longest match at p                      (second-token descriptor)
+  uint32_t Db[NPOS_PAD];   // longest match of ' '+text[p:], if usable (forward-delete descriptor), 0 = none
+  uint32_t X[SEG];         // record ordinal of D's token
+  uint32_t Xb[SEG];        // record ordinal of Db's token
+};
+
+// T(p, fd): go/tokenmonster.go:1051-1276
+__device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w, const uint8_t* s_bb, int p, int dl,
+                                               uint32_t d, uint32_t x, int fd) {
+  if (d == 0) return (T.unk_id != TM_NONE ? T.unk_id : ID_NONE) | (1u << 24) | (1u << 31);   // go :1269-1276
+  const int len = (int)(d & 63u);
+  const Row O = T.rows[x];
+  const uint32_t id = O.x & ID_NONE, oflag = O.x >> 24;
+  const int i1 = p + len;
+  if (i1 < dl && ((oflag & 32u) == 0 || s_bb[w.text[i1]] != 12)) {                           // go :1057
+    const int len1 = (int)(O.z >> 24), len2 = (int)(O.w & 63u);
+    int s[6] = {NOSCORE, NOSCORE, NOSCORE, NOSCORE, NOSCORE, NOSCORE};   // s1 s2 s3 s1b s2b s3b
+    int best = NOSCORE;
+    First F[3];
+    F[0] = {len, (int)(O.y >> 24) - fd, (oflag & 1u) | (((oflag >> 3) & 1u) << 1) | (((oflag >> 7) & 1u) << 2)};
+    F[1] = {len1 - fd, (int)((O.w >> 6) & 31u) - fd, (O.w >> 16) & 7u};
+    F[2] = {len2 - fd, (int)((O.w >> 11) & 31u) - fd, (O.w >> 19) & 7u};
+    const int nk = len1 == 0 ? 1 : (len2 == 0 ? 2 : 3);                                      // go :1111, :1163
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (k < nk) {
+        const int ik = p + F[k].flen;
+        const uint32_t dS = w.D[ik];
+        if (dS != 0) {
+          s[k] = branch_score(F[k], dS, false, k > 0, len);
+          best = max(best, s[k]);
+          const uint32_t dB = w.Db[ik];
+          if (dB != 0) {
+            s[3 + k] = branch_score(F[k], dB, true, k > 0, len);
+            best = max(best, s[3 + k]);
+          }
+        }
+      }
+    }
+    if (best != NOSCORE) {                                                                     // go :1217-1262
+      if (best == s[0]) return id | ((uint32_t)len << 24);
+      if (best == s[1]) return (O.y & ID_NONE) | ((uint32_t)F[1].flen << 24);
+      if (best == s[2]) return (O.z & ID_NONE) | ((uint32_t)F[2].flen << 24);
+      if (best == s[3]) return id | ((uint32_t)len << 24) | (1u << 30);
+      if (best == s[4]) return (O.y & ID_NONE) | ((uint32_t)F[1].flen << 24) | (1u << 30);
+      return (O.z & ID_NONE) | ((uint32_t)F[2].flen << 24) | (1u << 30);
+    }
+  }
+  return id | ((uint32_t)len << 24);                                                           // go :1265-1267
+}
+
+__global__ __launch_bounds__(WAVES * 64) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
+                                                             const uint64_t* __restrict__ doc_begin,
+                                                             const uint64_t* __restrict__ doc_end,
+                                                             const uint32_t* __restrict__ seg_doc,
+                                                             const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
+                                                             uint2* __restrict__ R) {
+  __shared__ uint32_t s_root[256];
+  __shared__ uint8_t s_bb[256];
+  __shared__ WaveLds s_wave[WAVES];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  s_root[threadIdx.x] = T.root[threadIdx.x];
+  s_bb[threadIdx.x] = T.begin_byte[threadIdx.x];
+  __syncthreads();
+  const uint64_t g = (uint64_t)blockIdx.x * WAVES + wv;
+  if (g >= nseg) return;
+  WaveLds& w = s_wave[wv];
+  const uint32_t doc = seg_doc[g];
+  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
+  const uint64_t rem = doc_end[doc] - begin;
+  const int dl = rem > (uint64_t)(1 << 20) ? (1 << 20) : (int)rem;   // bytes of the document from `begin` on (clamped)
+  const int seglen = min(dl, SEG);
+  const int Lmax = (int)T.max_len;
+
+  for (int j = lane; j < TEXT_LEN; j += 64) w.text[j] = j < dl ? text[begin + j] : 0;   // pad byte 0 (go :1038-1046, Q1)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+
+  // ---- step A: descriptors for every position the segment can look at -----------------------------
+  for (int it = 0; it < NPOS_PAD / 64; it++) {
+    const int p = it * 64 + lane;
+    uint32_t d = 0, x = 0, db = 0, xb = 0;
+    if (p < NPOS && p < dl) {
+      const uint32_t m = (uint32_t)min(dl - p, Lmax);
+      Match best{0, 0};
+      const uint8_t* txt = &w.text[p];
+      uint32_t v = s_root[txt[0]];
+      if (v != kNone) {
+        if (node_id(v) < T.n_info) { best.v = v; best.len = 1; }
+        if (m >= 2 && (v & kHasChildren)) {
+          v = T.l2[((uint32_t)txt[0] << 8) | txt[1]];
+          if (v != kNone) {
+            if (node_id(v) < T.n_info) { best.v = v; best.len = 2; }
+            walk_tail(T, txt, v, 2, m, best);
+          }
+        }
+      }
+      if (best.len != 0) {
+        const uint32_t nb = s_bb[txt[best.len]];
+        d = make_desc(best.len, best.v, nb);
+        x = node_id(best.v);
+        // forward-delete probe, go :1088-1095: second token begins with a letter, has no word boundary,
+        // and the byte after it is letter-class -> look for ' '+text[p:] and accept it only if longer
+        if (T.has_delete && (node_flag5(best.v) & 2u) && nb == 1 && node_nwords(best.v) == 0 && T.bstart != kNone) {
+          const uint32_t off = T.off;
+          const int mb = min(dl - p, Lmax - (int)off);
+          if (mb > 0) {
+            Match bb{0, 0};
+            uint32_t vb = T.bstart;
+            uint32_t depth = off;
+            const uint32_t limit = (uint32_t)mb + off;
+            if (off == 1) {
+              // second byte of " x..." through the direct map
+              if (vb & kHasChildren) {
+                vb = T.l2[((uint32_t)' ' << 8) | txt[0]];
+                if (vb != kNone) {
+                  depth = 2;
+                  if (node_id(vb) < T.n_info) { bb.v = vb; bb.len = 2; }
+                  walk_tail(T, txt - 1, vb, depth, limit, bb);
+                }
+              }
+            } else {
+              walk_tail(T, txt - 2, vb, depth, limit, bb);
+            }
+            if (bb.len > best.len + 1) {                                   // go :1092
+              const uint32_t lb = bb.len - off;                            // go :1093
+              db = make_desc(lb, bb.v, s_bb[txt[lb]]);
+              xb = node_id(bb.v);
+            }
+          }
+        }
+      }
+    }
+    if (p < NPOS_PAD) { w.D[p] = d; w.Db[p] = db; }
+    if (p < SEG) { w.X[p] = x; w.Xb[p] = xb; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+
+  // ---- step B: T(p,0) and T(p,1) for every position of the segment --------------------------------
+  for (int it = 0; it < SEG / 64; it++) {
+    const int p = it * 64 + lane;
+    if (p < seglen) {
+      const uint32_t r0 = transition(T, w, s_bb, p, dl, w.D[p], w.X[p], 0);
+      const uint32_t dB = w.Db[p];
+      const uint32_t r1 = dB != 0 ? transition(T, w, s_bb, p, dl, dB, w.Xb[p], 1) : R_INVALID;
+      R[begin + p] = make_uint2(r0, r1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: link — exit map of every segment
+// ------------------------------------------------------------------------------------------------
+// exit map entry (uint2): x = next entry state [0..7] | #ids-events << 8 ; y = #forward-deletes | #missing << 16
+// (#tokens emitted = events + forward-deletes; Count() = events, quirk Q2).  x == 0xFFFFFFFF: entry unreachable.
+__global__ __launch_bounds__(256) void k_link(const uint2* __restrict__ R, const uint64_t* __restrict__ doc_begin,
+                                              const uint64_t* __restrict__ doc_end,
+                                              const uint32_t* __restrict__ seg_doc,
+                                              const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
+                                              uint2* __restrict__ exitmap) {
+  __shared__ uint32_t s_r[4][2][SEG];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
+  if (g >= nseg) return;
+  const uint32_t doc = seg_doc[g];
+  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
+  const uint64_t rem = doc_end[doc] - begin;
+  const int seglen = rem > SEG ? SEG : (int)rem;
+  for (int j = lane; j < seglen; j += 64) {
+    uint2 r = R[begin + j];
+    s_r[wv][0][j] = r.x;
+    s_r[wv][1][j] = r.y;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int e = lane; e < ENT; e += 64) {
+    int p = e >> 1, fd = e & 1;
+    uint32_t events = 0, nfd = 0, nmiss = 0;
+    uint32_t ox = R_INVALID, oy = 0;
+    if (p >= seglen) {
+      // only in a document's last segment: the chain entered exactly at (or is already past) the end of text
+      ox = 0; oy = 0;
+    } else {
+      bool ok = true;
+      for (int guard = 0; guard < 2 * SEG + 4; guard++) {
+        uint32_t r = s_r[wv][fd][p];
+        if (r == R_INVALID) { ok = false; break; }
+        events += (r & ID_NONE) != ID_NONE;
+        fd = (int)((r >> 30) & 1u);
+        nfd += (uint32_t)fd;
+        nmiss += r >> 31;
+        p += (int)((r >> 24) & 63u);
+        if (p >= seglen) break;
+      }
+      if (ok && p >= seglen) {
+        uint32_t ne = rem > SEG ? (uint32_t)((p - SEG) * 2 + fd) : 0u;
+        ox = ne | (events << 8);
+        oy = nfd | (nmiss << 16);
+      }
+    }
+    exitmap[g * ENT + e] = make_uint2(ox, oy);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: resolve — per document, chain the exit maps
+// ------------------------------------------------------------------------------------------------
+__global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs,
+                          uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
+                          uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ doc_events,
+                          uint32_t* __restrict__ doc_missing, uint32_t* __restrict__ error_flag) {
+  uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= ndocs) return;
+  uint64_t g0 = doc_seg_start[d], g1 = doc_seg_start[d + 1];
+  uint32_t e = 0, ntok = 0, events = 0, nmiss = 0;
+  for (uint64_t g = g0; g < g1; g++) {
+    seg_entry[g] = (uint8_t)e;
+    seg_tokbase[g] = ntok;
+    uint2 x = exitmap[g * ENT + e];
+    if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
+    e = x.x & 0xFFu;
+    uint32_t ev = x.x >> 8, nfd = x.y & 0xFFFFu;
+    events += ev;
+    ntok += ev + nfd;
+    nmiss += x.y >> 16;
+  }
+  doc_ntok[d] = ntok;
+  doc_events[d] = events;
+  doc_missing[d] = nmiss;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: emit
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit(const uint2* __restrict__ R, const uint64_t* __restrict__ doc_begin,
+                                              const uint64_t* __restrict__ doc_end,
+                                              const uint32_t* __restrict__ seg_doc,
+                                              const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
+                                              const uint8_t* __restrict__ seg_entry,
+                                              const uint32_t* __restrict__ seg_tokbase,
+                                              const uint64_t* __restrict__ tok_offsets, uint32_t delete_id,
+                                              uint64_t out_cap, uint32_t* __restrict__ out) {
+  __shared__ uint32_t s_r[4][2][SEG];
+  __shared__ uint32_t s_tok[4][2 * SEG + 8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
+  if (g >= nseg) return;
+  const uint32_t doc = seg_doc[g];
+  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
+  const uint64_t rem = doc_end[doc] - begin;
+  const int seglen = rem > SEG ? SEG : (int)rem;
+  for (int j = lane; j < seglen; j += 64) {
+    uint2 r = R[begin + j];
+    s_r[wv][0][j] = r.x;
+    s_r[wv][1][j] = r.y;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  int n = 0;
+  if (lane == 0) {
+    int e = seg_entry[g];
+    int p = e >> 1, fd = e & 1;
+    for (int guard = 0; guard < 2 * SEG + 4 && p < seglen; guard++) {
+      uint32_t r = s_r[wv][fd][p];
+      if (r == R_INVALID) break;
+      uint32_t id = r & ID_NONE;
+      if (id != ID_NONE) s_tok[wv][n++] = id;
+      fd = (int)((r >> 30) & 1u);
+      if (fd) s_tok[wv][n++] = delete_id;
+      p += (int)((r >> 24) & 63u);
+    }
+  }
+  n = __shfl(n, 0);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  const uint64_t base = tok_offsets[doc] + seg_tokbase[g];
+  for (int j = lane; j < n; j += 64)
+    if (base + j < out_cap) out[base + j] = s_tok[wv][j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4': trainvocab accumulation (training/trainvocab.go:1105-1174) instead of emitting ids
+// ------------------------------------------------------------------------------------------------
+// hist layout (all uint32, so that one RCCL all-reduce(sum) merges ranks): scores[n_ids] | tokens_in_text as
+// four 16-bit limbs | missing[256] (per-byte counters, > 0 = that byte had no token)
+__global__ __launch_bounds__(256) void k_hist(const uint2* __restrict__ R, const uint8_t* __restrict__ text,
+                                              const uint64_t* __restrict__ doc_begin,
+                                              const uint64_t* __restrict__ doc_end,
+                                              const uint32_t* __restrict__ seg_doc,
+                                              const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
+                                              const uint8_t* __restrict__ seg_entry, uint32_t delete_id,
+                                              uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
+                                              uint32_t* __restrict__ missing_bits) {
+  __shared__ uint32_t s_r[4][2][SEG];
+  __shared__ uint32_t s_tok[4][SEG + 8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
+  if (g >= nseg) return;
+  const uint32_t doc = seg_doc[g];
+  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
+  const uint64_t rem = doc_end[doc] - begin;
+  const int seglen = rem > SEG ? SEG : (int)rem;
+  for (int j = lane; j < seglen; j += 64) {
+    uint2 r = R[begin + j];
+    s_r[wv][0][j] = r.x;
+    s_r[wv][1][j] = r.y;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  int n = 0;
+  if (lane == 0) {
+    int e = seg_entry[g];
+    int p = e >> 1, fd = e & 1;
+    uint32_t nfd = 0, ntok = 0;
+    for (int guard = 0; guard < 2 * SEG + 4 && p < seglen; guard++) {
+      uint32_t r = s_r[wv][fd][p];
+      if (r == R_INVALID) break;
+      const uint32_t adv = (r >> 24) & 63u;
+      if (r >> 31) {                                     // trainvocab.go:1166-1173: no token for this byte
+        uint32_t byte = text[begin + p];
+        atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
+      } else {
+        s_tok[wv][n++] = (r & ID_NONE) | (adv << 24);   // scores[id] += bytes covered (:1109..1162)
+      }
+      ntok++;                                            // tokensInText++ (also for a missing byte, :1169)
+      fd = (int)((r >> 30) & 1u);
+      nfd += (uint32_t)fd;
+      p += (int)adv;
+    }
+    if (nfd) atomicAdd(&scores[delete_id], nfd);         // scores[deleteToken]++ per forward delete (:1134,1143,1152)
+    if (ntok + nfd) atomicAdd(tokens, (unsigned long long)(ntok + nfd));
+  }
+  n = __shfl(n, 0);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int j = lane; j < n; j += 64) {
+    uint32_t t = s_tok[wv][j];
+    atomicAdd(&scores[t & ID_NONE], t >> 24);
+  }
+}
+
+__global__ void k_hist_finish(const unsigned long long* __restrict__ tokens, const uint32_t* __restrict__ missing_bits,
+                              uint32_t* __restrict__ tail) {
+  uint32_t t = threadIdx.x;
+  if (t < 4) tail[t] = (uint32_t)((*tokens >> (16 * t)) & 0xFFFFull);
+  if (t < 256) tail[4 + t] = (missing_bits[t >> 5] >> (t & 31)) & 1u;
+}
+
+// pack u32 ids to 2/3/4 little-endian bytes (go/tokenmonster.go:1545, :1817, :2089)
+__global__ void k_serialize(const uint32_t* __restrict__ ids, uint64_t n, uint32_t enc, uint8_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t v = ids[i];
+  uint8_t* o = out + i * enc;
+  o[0] = (uint8_t)v;
+  o[1] = (uint8_t)(v >> 8);
+  if (enc >= 3) o[2] = (uint8_t)(v >> 16);
+  if (enc == 4) o[3] = 0;                     // go :2089 writes a zero high byte
+}
+
+}  // namespace tmh
+
+using namespace tmh;
+
+// ------------------------------------------------------------------------------------------------
+// tm_batch
+// ------------------------------------------------------------------------------------------------
+struct tm_batch {
+  const tm_vocab* vocab = nullptr;
+  uint64_t max_bytes = 0;
+  uint32_t max_docs = 0;
+  uint64_t max_segs = 0;
+  uint64_t nbytes = 0, nseg = 0;
+  uint32_t ndocs = 0;
+  uint64_t device_bytes = 0;
+  hipStream_t last_stream = nullptr;
+  // device buffers
+  uint8_t* d_text = nullptr;
+  bool text_borrowed = false;          // scoring pass: text belongs to a tm_dataset
+  uint64_t* d_offsets = nullptr;       // packed batches: doc_begin = d_offsets, doc_end = d_offsets + 1
+  const uint64_t* d_doc_begin = nullptr;
+  const uint64_t* d_doc_end = nullptr;
+  uint32_t* d_doc_nseg = nullptr;
+  uint64_t* d_doc_seg_start = nullptr;
+  uint32_t* d_seg_doc = nullptr;
+  uint2* d_R = nullptr;
+  uint2* d_exitmap = nullptr;
+  uint8_t* d_seg_entry = nullptr;
+  uint32_t* d_seg_tokbase = nullptr;
+  uint32_t* d_doc_ntok = nullptr;
+  uint32_t* d_doc_events = nullptr;
+  uint32_t* d_doc_missing = nullptr;
+  uint64_t* d_tok_offsets = nullptr;
+  uint64_t* d_scan_tmp = nullptr;   // block sums
+  uint64_t* d_totals = nullptr;     // [0] nseg total (device-computed), [1] token total, [2] missing total
+  uint32_t* d_error = nullptr;
+  uint32_t* d_out = nullptr;
+  uint64_t out_cap = 0;
+  hipEvent_t ev[TM_NUM_KERNELS + 1] = {};
+  bool have_events = false;
+};
+
+namespace {
+
+const char* kKernelNames[TM_NUM_KERNELS] = {"segments", "match_branch", "link", "resolve", "scan", "emit"};
+
+template <typename T>
+hipError_t dalloc(tm_batch* b, T** p, uint64_t count) {
+  uint64_t bytes = count * sizeof(T);
+  hipError_t e = hipMalloc((void**)p, bytes ? bytes : 16);
+  if (e == hipSuccess) b->device_bytes += bytes;
+  return e;
+}
+
+void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {
+  uint32_t nblocks = (uint32_t)((n + 1 + SCAN_CH - 1) / SCAN_CH);   // covers index n (the total slot)
+  k_scan_partial<<<nblocks, SCAN_T, 0, st>>>(in, n, block_sums);
+  k_scan_sums<<<1, SCAN_T, 0, st>>>(block_sums, nblocks, total);
+  k_scan_final<<<nblocks, SCAN_T, 0, st>>>(in, n, block_sums, out);
+}
+
+int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) {
+  const tm_vocab* v = b->vocab;
+  b->last_stream = st;
+  hipError_t e;
+  if (timed && !b->have_events) {
+    for (auto& ev : b->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    b->have_events = true;
+  }
+  auto mark = [&](int k) { if (timed) (void)hipEventRecord(b->ev[k], st); };
+  (void)hipMemsetAsync(b->d_error, 0, 4, st);
+  const uint32_t nd = b->ndocs;
+  const uint64_t nseg = b->nseg;
+  mark(0);
+  if (nd > 0) {
+    k_doc_nseg<<<(nd + 255) / 256, 256, 0, st>>>(b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nseg);
+    scan_u32(b->d_doc_nseg, nd, b->d_scan_tmp, b->d_totals + 0, b->d_doc_seg_start, st);
+    if (nseg > 0) k_segments<<<(uint32_t)((nseg + 255) / 256), 256, 0, st>>>(b->d_doc_seg_start, nd, nseg, b->d_seg_doc);
+  }
+  mark(1);
+  if (nseg > 0)
+    k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
+                                                                                b->d_doc_seg_start, nseg, b->d_R);
+  mark(2);
+  if (nseg > 0)
+    k_link<<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_exitmap);
+  mark(3);
+  if (nd > 0)
+    k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_seg_entry, b->d_seg_tokbase,
+                                                b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_error);
+  mark(4);
+  if (nd > 0) scan_u32(b->d_doc_ntok, nd, b->d_scan_tmp, b->d_totals + 1, b->d_tok_offsets, st);
+  else (void)hipMemsetAsync(b->d_tok_offsets, 0, 8, st);
+  mark(5);
+  if (emit && nseg > 0)
+    k_emit<<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry,
+                                                       b->d_seg_tokbase, b->d_tok_offsets, v->tables.delete_id, b->out_cap, b->d_out);
+  mark(6);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
+  if (timed) {
+    if ((e = hipEventSynchronize(b->ev[TM_NUM_KERNELS])) != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+    for (int k = 0; k < TM_NUM_KERNELS; k++) (void)hipEventElapsedTime(&ms[k], b->ev[k], b->ev[k + 1]);
+  }
+  return TM_OK;
+}
+
+// after a run: make sure the output buffer was large enough; if not, grow it and redo the emit stage
+int ensure_output(tm_batch* b) {
+  hipError_t e;
+  uint64_t totals[3];
+  uint32_t err = 0;
+  if ((e = hipStreamSynchronize(b->last_stream)) != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  if ((e = hipMemcpy(totals, b->d_totals, sizeof totals, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "hipMemcpy totals");
+  if ((e = hipMemcpy(&err, b->d_error, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "hipMemcpy error flag");
+  if (err != 0) return set_error(TM_E_HIP, "device pipeline inconsistency (unreachable segment entry state)");
+  uint64_t total = b->ndocs ? totals[1] : 0;
+  if (total > b->out_cap) {
+    (void)hipFree(b->d_out);
+    b->device_bytes -= b->out_cap * 4;
+    b->d_out = nullptr;
+    b->out_cap = total + 1024;
+    if ((e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc output");
+    hipStream_t st = b->last_stream;
+    k_emit<<<(uint32_t)((b->nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, b->nseg,
+                                                          b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
+                                                          b->vocab->tables.delete_id, b->out_cap, b->d_out);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "emit rerun");
+  }
+  return TM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tm_kernel_name(int k) { return k >= 0 && k < TM_NUM_KERNELS ? kKernelNames[k] : ""; }
+
+static int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, bool own_text, bool with_output, tm_batch** out) {
+  *out = nullptr;
+  auto* b = new tm_batch();
+  b->vocab = v;
+  b->max_bytes = max_bytes;
+  b->max_docs = max_docs;
+  b->max_segs = max_bytes / SEG + max_docs + 1;
+  b->out_cap = with_output ? max_bytes / 2 + 2ull * max_docs + 1024 : 0;   // grows on demand (worst case is 2 ids per byte)
+  b->text_borrowed = !own_text;
+  const uint64_t nd1 = (uint64_t)max_docs + 1;
+  const uint64_t scan_blocks = std::max<uint64_t>((nd1 + SCAN_CH) / SCAN_CH + 1, 16);
+  hipError_t e = hipSuccess;
+  if ((own_text && (e = dalloc(b, &b->d_text, max_bytes + 256)) != hipSuccess) || (e = dalloc(b, &b->d_offsets, 2 * nd1)) != hipSuccess ||
+      (e = dalloc(b, &b->d_doc_nseg, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_seg_start, nd1 + 1)) != hipSuccess ||
+      (e = dalloc(b, &b->d_seg_doc, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_R, max_bytes + 64)) != hipSuccess ||
+      (e = dalloc(b, &b->d_exitmap, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_seg_entry, b->max_segs)) != hipSuccess ||
+      (e = dalloc(b, &b->d_seg_tokbase, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_doc_ntok, nd1)) != hipSuccess ||
+      (e = dalloc(b, &b->d_doc_events, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_missing, nd1)) != hipSuccess ||
+      (e = dalloc(b, &b->d_tok_offsets, nd1 + 1)) != hipSuccess || (e = dalloc(b, &b->d_scan_tmp, scan_blocks)) != hipSuccess ||
+      (e = dalloc(b, &b->d_totals, 4)) != hipSuccess || (e = dalloc(b, &b->d_error, 4)) != hipSuccess ||
+      (e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) {
+    tm_batch_free(b);
+    return hip_fail(e, "hipMalloc (batch workspace)");
+  }
+  (void)hipMemset(b->d_totals, 0, 32);
+  *out = b;
+  return TM_OK;
+}
+
+int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm_batch** out) {
+  if (!v || !out) return set_error(TM_E_INVALID, "null argument");
+  return make_workspace(v, max_bytes, max_docs, true, true, out);
+}
+
+void tm_batch_free(tm_batch* b) {
+  if (!b) return;
+  void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R, b->d_exitmap, b->d_seg_entry,
+                  b->d_seg_tokbase, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
+                  b->d_error, b->d_out};
+  for (void* p : ptrs) (void)hipFree(p);
+  if (b->have_events) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
+  delete b;
+}
+
+int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs) {
+  if (!b || (ndocs && (!offsets))) return set_error(TM_E_INVALID, "null argument");
+  if (ndocs > b->max_docs) return set_error(TM_E_LIMIT, "batch has %u documents, workspace sized for %u", ndocs, b->max_docs);
+  uint64_t nbytes = ndocs ? offsets[ndocs] : 0;
+  if (ndocs && offsets[0] != 0) return set_error(TM_E_INVALID, "offsets[0] must be 0");
+  if (nbytes > b->max_bytes) return set_error(TM_E_LIMIT, "batch has %llu bytes, workspace sized for %llu", (unsigned long long)nbytes, (unsigned long long)b->max_bytes);
+  uint64_t nseg = 0;
+  for (uint32_t d = 0; d < ndocs; d++) {
+    if (offsets[d + 1] < offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
+    nseg += (offsets[d + 1] - offsets[d] + SEG - 1) / SEG;
+  }
+  hipError_t e;
+  if (nbytes && (e = hipMemcpy(b->d_text, text, nbytes, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D text");
+  if (ndocs && (e = hipMemcpy(b->d_offsets, offsets, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D offsets");
+  b->ndocs = ndocs;
+  b->nbytes = nbytes;
+  b->nseg = nseg;
+  b->d_doc_begin = b->d_offsets;
+  b->d_doc_end = b->d_offsets + 1;
+  return TM_OK;
+}
+
+int tm_batch_run(tm_batch* b, void* stream) {
+  if (!b) return set_error(TM_E_INVALID, "null argument");
+  return run_pipeline(b, (hipStream_t)stream, false, nullptr, true);
+}
+
+int tm_batch_run_timed(tm_batch* b, void* stream, float* ms) {
+  if (!b || !ms) return set_error(TM_E_INVALID, "null argument");
+  return run_pipeline(b, (hipStream_t)stream, true, ms, true);
+}
+
+int tm_batch_totals(tm_batch* b, uint64_t* total_tokens, uint64_t* total_missing) {
+  if (!b) return set_error(TM_E_INVALID, "null argument");
+  int rc = ensure_output(b);
+  if (rc != TM_OK) return rc;
+  hipError_t e;
+  uint64_t totals[3] = {0, 0, 0};
+  if ((e = hipMemcpy(totals, b->d_totals, sizeof totals, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "hipMemcpy totals");
+  if (total_tokens) *total_tokens = b->ndocs ? totals[1] : 0;
+  if (total_missing) {
+    std::vector<uint32_t> miss(b->ndocs);
+    if (b->ndocs && (e = hipMemcpy(miss.data(), b->d_doc_missing, (size_t)b->ndocs * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "hipMemcpy missing");
+    uint64_t m = 0;
+    for (auto x : miss) m += x;
+    *total_missing = m;
+  }
+  return TM_OK;
+}
+
+int tm_batch_download(tm_batch* b, uint32_t* tokens_out, uint64_t tokens_cap, uint64_t* tok_offsets, uint32_t* missing) {
+  if (!b) return set_error(TM_E_INVALID, "null argument");
+  int rc = ensure_output(b);
+  if (rc != TM_OK) return rc;
+  hipError_t e;
+  std::vector<uint64_t> offs((size_t)b->ndocs + 1, 0);
+  if (b->ndocs && (e = hipMemcpy(offs.data(), b->d_tok_offsets, offs.size() * 8, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H tok_offsets");
+  if (tok_offsets) std::memcpy(tok_offsets, offs.data(), offs.size() * 8);
+  if (missing && b->ndocs && (e = hipMemcpy(missing, b->d_doc_missing, (size_t)b->ndocs * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H missing");
+  uint64_t total = offs[b->ndocs];
+  if (total > tokens_cap) return set_error(TM_E_NOSPACE, "tokens_cap %llu < %llu required", (unsigned long long)tokens_cap, (unsigned long long)total);
+  if (total && (e = hipMemcpy(tokens_out, b->d_out, total * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H tokens");
+  return TM_OK;
+}
+
+const uint32_t* tm_batch_device_tokens(const tm_batch* b) { return b->d_out; }
+const uint64_t* tm_batch_device_tok_offsets(const tm_batch* b) { return b->d_tok_offsets; }
+uint64_t tm_batch_device_bytes(const tm_batch* b) { return b->device_bytes; }
+
+// ---- host-buffer entry points ---------------------------------------------------------------------
+static int with_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, tm_batch** pb, bool emit) {
+  if (!v || (ndocs && !offsets)) return set_error(TM_E_INVALID, "null argument");
+  uint64_t nbytes = ndocs ? offsets[ndocs] : 0;
+  int rc = tm_batch_create(v, nbytes, ndocs, pb);
+  if (rc != TM_OK) return rc;
+  if ((rc = tm_batch_upload(*pb, text, offsets, ndocs)) != TM_OK) return rc;
+  return run_pipeline(*pb, nullptr, false, nullptr, emit);
+}
+
+int tm_tokenize_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t* tokens_out,
+                      uint64_t tokens_cap, uint64_t* tok_offsets, uint32_t* missing) {
+  tm_batch* b = nullptr;
+  int rc = with_batch(v, text, offsets, ndocs, &b, true);
+  if (rc == TM_OK) rc = tm_batch_download(b, tokens_out, tokens_cap, tok_offsets, missing);
+  tm_batch_free(b);
+  return rc;
+}
+
+int tm_count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint64_t* counts,
+                   uint32_t* missing) {
+  tm_batch* b = nullptr;
+  int rc = with_batch(v, text, offsets, ndocs, &b, false);
+  if (rc == TM_OK && ndocs) {
+    hipError_t e;
+    std::vector<uint32_t> ev(ndocs);
+    uint32_t err = 0;
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) rc = hip_fail(e, "sync");
+    else if ((e = hipMemcpy(&err, b->d_error, 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H");
+    else if (err) rc = set_error(TM_E_HIP, "device pipeline inconsistency");
+    else if ((e = hipMemcpy(ev.data(), b->d_doc_events, (size_t)ndocs * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H counts");
+    else if (missing && (e = hipMemcpy(missing, b->d_doc_missing, (size_t)ndocs * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H missing");
+    if (rc == TM_OK && counts) for (uint32_t d = 0; d < ndocs; d++) counts[d] = ev[d];
+  }
+  tm_batch_free(b);
+  return rc;
+}
+
+int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs,
+                                 uint32_t encoding_length, uint8_t* bytes_out, uint64_t bytes_cap, uint64_t* byte_offsets,
+                                 uint32_t* missing, uint32_t* encoding_length_used) {
+  if (!v) return set_error(TM_E_INVALID, "null argument");
+  if (encoding_length <= 1) encoding_length = v->host.n_ids <= 65536 ? 2 : 3;          // go :990-996
+  if (encoding_length < 2 || encoding_length > 4) return set_error(TM_E_INVALID, "Invalid encoding length");   // go :1012
+  if (encoding_length_used) *encoding_length_used = encoding_length;
+  tm_batch* b = nullptr;
+  int rc = with_batch(v, text, offsets, ndocs, &b, true);
+  if (rc == TM_OK) rc = ensure_output(b);
+  if (rc == TM_OK) {
+    hipError_t e;
+    std::vector<uint64_t> offs((size_t)ndocs + 1, 0);
+    if (ndocs && (e = hipMemcpy(offs.data(), b->d_tok_offsets, offs.size() * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H tok_offsets");
+    if (rc == TM_OK) {
+      uint64_t total = offs[ndocs];
+      if (byte_offsets) for (size_t d = 0; d <= ndocs; d++) byte_offsets[d] = offs[d] * encoding_length;
+      if (missing && ndocs && (e = hipMemcpy(missing, b->d_doc_missing, (size_t)ndocs * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H missing");
+      if (rc == TM_OK && total * encoding_length > bytes_cap) rc = set_error(TM_E_NOSPACE, "bytes_cap too small");
+      if (rc == TM_OK && total) {
+        uint8_t* d_bytes = nullptr;
+        if ((e = hipMalloc((void**)&d_bytes, total * encoding_length)) != hipSuccess) rc = hip_fail(e, "hipMalloc");
+        else {
+          k_serialize<<<(uint32_t)((total + 255) / 256), 256>>>(b->d_out, total, encoding_length, d_bytes);
+          if ((e = hipMemcpy(bytes_out, d_bytes, total * encoding_length, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H bytes");
+          (void)hipFree(d_bytes);
+        }
+      }
+    }
+  }
+  tm_batch_free(b);
+  return rc;
+}
+
+// ---- trainvocab scoring pass ----------------------------------------------------------------------
+}  // extern "C"
+
+struct tm_dataset {
+  uint8_t* d_text = nullptr;
+  uint64_t n = 0;
+  tm_batch* ws = nullptr;          // workspace, created on first use and reused by every scoring pass
+  uint32_t ws_docs = 0;
+  uint32_t* d_hist = nullptr;      // scores | 4 token limbs | 256 missing counters
+  uint64_t hist_words = 0;
+  unsigned long long* d_tokens = nullptr;
+  uint32_t* d_missing_bits = nullptr;
+};
+
+static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+                     hipStream_t st) {
+  if (!v || !d) return set_error(TM_E_INVALID, "null argument");
+  std::vector<uint64_t> be;
+  uint64_t whole_off = 0, whole_len = d->n;
+  if (n_strips == 0) { strip_off = &whole_off; strip_len = &whole_len; n_strips = 1; }
+  be.resize(2ull * n_strips);
+  uint64_t nseg = 0;
+  for (uint32_t k = 0; k < n_strips; k++) {
+    if (strip_off[k] > d->n || strip_len[k] > d->n - strip_off[k]) return set_error(TM_E_INVALID, "strip %u outside the dataset", k);
+    be[k] = strip_off[k];
+    be[n_strips + k] = strip_off[k] + strip_len[k];
+    nseg += (strip_len[k] + SEG - 1) / SEG;
+  }
+  hipError_t e;
+  if (d->ws && (d->ws->vocab != v || d->ws_docs < n_strips)) { tm_batch_free(d->ws); d->ws = nullptr; }
+  if (!d->ws) {
+    int rc = make_workspace(v, d->n, n_strips, false, false, &d->ws);
+    if (rc != TM_OK) return rc;
+    d->ws_docs = n_strips;
+    d->ws->d_text = d->d_text;
+  }
+  tm_batch* b = d->ws;
+  b->vocab = v;
+  const uint64_t words = (uint64_t)v->host.n_ids + 4 + 256;
+  if (d->hist_words != words) {
+    (void)hipFree(d->d_hist);
+    d->d_hist = nullptr;
+    if ((e = hipMalloc((void**)&d->d_hist, words * 4)) != hipSuccess) return hip_fail(e, "hipMalloc histogram");
+    d->hist_words = words;
+  }
+  if ((e = hipMemcpyAsync(b->d_offsets, be.data(), be.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D strips");
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync");   // `be` is a host temporary
+  b->d_doc_begin = b->d_offsets;
+  b->d_doc_end = b->d_offsets + n_strips;
+  b->ndocs = n_strips;
+  b->nbytes = d->n;
+  b->nseg = nseg;
+  (void)hipMemsetAsync(d->d_hist, 0, words * 4, st);
+  (void)hipMemsetAsync(d->d_tokens, 0, 8, st);
+  (void)hipMemsetAsync(d->d_missing_bits, 0, 32, st);
+  int rc = run_pipeline(b, st, false, nullptr, false);
+  if (rc != TM_OK) return rc;
+  if (nseg > 0)
+    k_hist<<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+                                                       nseg, b->d_seg_entry, v->tables.has_delete ? v->tables.delete_id : 0,
+                                                       d->d_hist, d->d_tokens, d->d_missing_bits);
+  k_hist_finish<<<1, 256, 0, st>>>(d->d_tokens, d->d_missing_bits, d->d_hist + v->host.n_ids);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
+  return TM_OK;
+}
+
+extern "C" {
+
+int tm_dataset_upload(const uint8_t* normalized, uint64_t n, tm_dataset** out) {
+  if (!out || (n && !normalized)) return set_error(TM_E_INVALID, "null argument");
+  auto* d = new tm_dataset();
+  hipError_t e;
+  if ((e = hipMalloc((void**)&d->d_text, n + 256)) != hipSuccess || (e = hipMalloc((void**)&d->d_tokens, 8)) != hipSuccess ||
+      (e = hipMalloc((void**)&d->d_missing_bits, 32)) != hipSuccess ||
+      (n && (e = hipMemcpy(d->d_text, normalized, n, hipMemcpyHostToDevice)) != hipSuccess)) {
+    tm_dataset_free(d);
+    return hip_fail(e, "dataset upload");
+  }
+  d->n = n;
+  *out = d;
+  return TM_OK;
+}
+
+void tm_dataset_free(tm_dataset* d) {
+  if (!d) return;
+  tm_batch_free(d->ws);
+  (void)hipFree(d->d_text); (void)hipFree(d->d_hist); (void)hipFree(d->d_tokens); (void)hipFree(d->d_missing_bits);
+  delete d;
+}
+
+int tm_score_device(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+                    void* stream, uint32_t** dev_hist, uint64_t* n_words) {
+  int rc = score_run(v, d, strip_off, strip_len, n_strips, (hipStream_t)stream);
+  if (rc != TM_OK) return rc;
+  if (dev_hist) *dev_hist = d->d_hist;
+  if (n_words) *n_words = d->hist_words;
+  return TM_OK;
+}
+
+int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+             uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]) {
+  int rc = score_run(v, d, strip_off, strip_len, n_strips, nullptr);
+  if (rc != TM_OK) return rc;
+  hipError_t e;
+  std::vector<uint32_t> h(d->hist_words);
+  uint32_t err = 0;
+  if ((e = hipMemcpy(h.data(), d->d_hist, h.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H histogram");
+  if ((e = hipMemcpy(&err, d->ws->d_error, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H error flag");
+  if (err) return set_error(TM_E_HIP, "device pipeline inconsistency (unreachable segment entry state)");
+  const uint32_t n_ids = v->host.n_ids;
+  if (scores) std::memcpy(scores, h.data(), (size_t)n_ids * 4);
+  if (tokens_in_text) {
+    uint64_t t = 0;
+    for (int k = 0; k < 4; k++) t += (uint64_t)h[n_ids + k] << (16 * k);
+    *tokens_in_text = t;
+  }
+  if (missing_set) {
+    std::memset(missing_set, 0, 32);
+    for (int k = 0; k < 256; k++) if (h[n_ids + 4 + k]) missing_set[k >> 3] |= (uint8_t)(1u << (k & 7));
+  }
+  return TM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// tm_normalize.cpp — host-side pre-step of Tokenize: norm.Normalize then capcode.Encode
+// (go/tokenmonster.go:233-253).  Neither third-party module is in /root/reference; the byte
+// transforms follow tokenmonster-cpp/src/tokenmonster.cpp:190-475 (normalizer) and the only in-tree
+// statement of capcode level 2, javascript/tokenmonster.js:900-1005.  This implementation works on
+// the UTF-8 byte stream directly (ASCII classified by table, everything else through ICU).
+//
+// Scope this round: normalizer flags 0, 1 (NFD) and 2 (lowercase, with or without NFD); capcode 0 and 2.
+// Other flag combinations are rejected (TM_E_INVALID) instead of being approximated.
+#include "tm_build.h"
+#include "tokenmonster_hip.h"
+#include "tm_internal.h"
+
+#include <unicode/normalizer2.h>
+#include <unicode/uchar.h>
+#include <unicode/locid.h>
+#include <unicode/unistr.h>
+
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+namespace tmh {
+namespace {
+
+struct Cp { uint32_t r; int n; bool raw; };   // raw: undecodable byte carried through
+
+inline Cp next_cp(const uint8_t* b, size_t len) {
+  uint8_t b0 = b[0];
+  if (b0 < 0x80) return {b0, 1, false};
+  int need = 0; uint32_t cp = 0;
+  if (b0 >= 0xC2 && b0 < 0xE0) { need = 1; cp = b0 & 0x1F; }
+  else if (b0 >= 0xE0 && b0 < 0xF0) { need = 2; cp = b0 & 0x0F; }
+  else if (b0 >= 0xF0 && b0 < 0xF5) { need = 3; cp = b0 & 0x07; }
+  if (need == 0 || (size_t)need >= len) return {b0, 1, true};
+  for (int k = 1; k <= need; k++) {
+    if ((b[k] & 0xC0) != 0x80) return {b0, 1, true};
+    cp = (cp << 6) | (b[k] & 0x3F);
+  }
+  if ((need == 2 && cp < 0x800) || (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) || (cp >= 0xD800 && cp <= 0xDFFF))
+    return {b0, 1, true};
+  return {cp, need + 1, false};
+}
+
+enum : uint8_t { kUpper = 1, kLower = 2, kLetter = 4, kDigit = 8, kMark = 16 };
+
+inline uint8_t classify(const Cp& c) {
+  if (c.raw) return 0;
+  uint32_t r = c.r;
+  if (r < 0x80) {
+    if (r >= 'a' && r <= 'z') return kLower | kLetter;
+    if (r >= 'A' && r <= 'Z') return kUpper | kLetter;
+    if (r >= '0' && r <= '9') return kDigit;
+    return 0;
+  }
+  switch (u_charType((UChar32)r)) {
+    case U_UPPERCASE_LETTER: return kUpper | kLetter;
+    case U_LOWERCASE_LETTER: return kLower | kLetter;
+    case U_TITLECASE_LETTER: case U_MODIFIER_LETTER: case U_OTHER_LETTER: return kLetter;
+    case U_DECIMAL_DIGIT_NUMBER: return kDigit;
+    case U_NON_SPACING_MARK: case U_ENCLOSING_MARK: case U_COMBINING_SPACING_MARK: return kMark;
+    default: return 0;
+  }
+}
+
+inline void put_cp(std::vector<uint8_t>& o, uint32_t r) {
+  if (r < 0x80) o.push_back((uint8_t)r);
+  else if (r < 0x800) { o.push_back(0xC0 | (r >> 6)); o.push_back(0x80 | (r & 0x3F)); }
+  else if (r < 0x10000) { o.push_back(0xE0 | (r >> 12)); o.push_back(0x80 | ((r >> 6) & 0x3F)); o.push_back(0x80 | (r & 0x3F)); }
+  else { o.push_back(0xF0 | (r >> 18)); o.push_back(0x80 | ((r >> 12) & 0x3F)); o.push_back(0x80 | ((r >> 6) & 0x3F)); o.push_back(0x80 | (r & 0x3F)); }
+}
+inline void put_lower(std::vector<uint8_t>& o, const Cp& c) {
+  if (c.r < 0x80) o.push_back((uint8_t)(c.r | 0x20));
+  else put_cp(o, (uint32_t)u_tolower((UChar32)c.r));
+}
+
+// what the encoder remembers about the previous one/two input code points
+struct Last {
+  bool space = false, letter = false, apostrophe = false, mark = false, digit = false;
+  bool joiner() const { return letter || apostrophe || mark; }      // tokenmonster.js:915, :954
+};
+inline Last describe(const Cp& c, uint8_t cls) {
+  Last l;
+  l.space = !c.raw && c.r == ' ';
+  l.letter = (cls & kLetter) != 0;
+  l.apostrophe = !c.raw && (c.r == '\'' || c.r == 0x2019);
+  l.mark = (cls & kMark) != 0;
+  l.digit = (cls & kDigit) != 0;
+  return l;
+}
+
+// tokenmonster.js:924-951 — after a run of capitals turns out to be followed by lowercase, every
+// letter of the run after the first gets its own "DC " marker.  `from` is the byte offset just after
+// the first (lower-cased) letter of the run.
+void mark_run_letters(std::vector<uint8_t>& buf, size_t from) {
+  std::vector<uint8_t> tail(buf.begin() + (std::ptrdiff_t)from, buf.end());
+  buf.resize(from);
+  size_t i = 0, n = tail.size();
+  while (i < n) {
+    if (tail[i] == 'D' && i + 1 < n && tail[i + 1] == ' ') {
+      // an existing "D " (digit->letter or punctuation->letter inside the run)
+      bool lower_next = false; int ln = 0;
+      if (i + 2 < n) { Cp c = next_cp(&tail[i + 2], n - (i + 2)); lower_next = (classify(c) & kLower) != 0; ln = c.n; }
+      if (lower_next) {
+        buf.push_back('D'); buf.push_back('C'); buf.push_back(' ');
+        buf.insert(buf.end(), tail.begin() + (std::ptrdiff_t)(i + 2), tail.begin() + (std::ptrdiff_t)(i + 2 + ln));
+        i += 2 + (size_t)ln;
+      } else {
+        // JS skips "D ", and the element after it, unexamined
+        size_t skip = 2;
+        if (i + 2 < n) skip += (size_t)next_cp(&tail[i + 2], n - (i + 2)).n;
+        if (i + skip > n) skip = n - i;
+        buf.insert(buf.end(), tail.begin() + (std::ptrdiff_t)i, tail.begin() + (std::ptrdiff_t)(i + skip));
+        i += skip;
+      }
+      continue;
+    }
+    Cp c = next_cp(&tail[i], n - i);
+    if (classify(c) & kLower) { buf.push_back('D'); buf.push_back('C'); buf.push_back(' '); }
+    buf.insert(buf.end(), tail.begin() + (std::ptrdiff_t)i, tail.begin() + (std::ptrdiff_t)(i + (size_t)c.n));
+    i += (size_t)c.n;
+  }
+}
+
+// capcode level 2 encoder, tokenmonster.js:900-1005
+void capcode_encode(const uint8_t* in, size_t n, std::vector<uint8_t>& buf) {
+  buf.clear();
+  buf.reserve(n + n / 2 + 8);
+  size_t goback = 0, word_token_pos = 0;
+  Last last, last2;   // rlast = rlast2 = '.' initially: every predicate false
+  bool in_word = false, multi = false;
+  size_t i = 0;
+  while (i < n) {
+    // fast path: a stretch of lowercase ASCII / spaces outside a capital run needs no bookkeeping
+    Cp c = next_cp(in + i, n - i);
+    uint8_t cls = classify(c);
+    if (in_word) {
+      if (cls & kUpper) {                                           // :913-919
+        if (!last.joiner()) { buf.push_back('D'); buf.push_back(' '); }
+        multi = true;
+        put_lower(buf, c);
+      } else {
+        if (cls & kLower) {                                         // :921-955
+          in_word = false;
+          buf[word_token_pos] = 'C';
+          if (multi) mark_run_letters(buf, goback);
+          if (!last.joiner()) { buf.push_back('D'); buf.push_back(' '); }
+        } else if (cls & kDigit) {                                  // :957-961
+          if (!last.digit) { buf.push_back('D'); buf.push_back(' '); }
+        } else if (!((!c.raw && (c.r == '\'' || c.r == 0x2019)) || (cls & kMark))) {
+          in_word = false;                                          // :962-964
+        }
+        buf.insert(buf.end(), in + i, in + i + c.n);                // :966
+      }
+    } else {
+      if (cls & kLower) {                                           // :969-974
+        if (!(last.space || last.letter || (last2.letter && last.apostrophe) || last.mark)) {
+          buf.push_back('D'); buf.push_back(' ');
+        }
+        buf.insert(buf.end(), in + i, in + i + c.n);
+      } else if (cls & kUpper) {                                    // :975-990
+        if (last.space) {
+          word_token_pos = buf.size() - 1;
+          buf[word_token_pos] = 'W';
+          buf.push_back(' ');
+        } else {
+          buf.push_back('D');
+          word_token_pos = buf.size();
+          buf.push_back('W');
+          buf.push_back(' ');
+        }
+        put_lower(buf, c);
+        goback = buf.size();
+        multi = false;
+        in_word = true;
+      } else if (cls & kDigit) {                                    // :991-996
+        if (!(last.space || last.digit)) { buf.push_back('D'); buf.push_back(' '); }
+        buf.insert(buf.end(), in + i, in + i + c.n);
+      } else {
+        buf.insert(buf.end(), in + i, in + i + c.n);                // :997-999
+      }
+    }
+    last2 = last;
+    last = describe(c, cls);
+    i += (size_t)c.n;
+  }
+}
+
+bool is_ascii(const uint8_t* d, size_t n) {
+  for (size_t i = 0; i < n; i++) if (d[i] & 0x80) return false;
+  return true;
+}
+
+void nfd_bytes(std::vector<uint8_t>& b) {    // tokenmonster.cpp:190-212
+  if (is_ascii(b.data(), b.size())) return;
+  UErrorCode status = U_ZERO_ERROR;
+  const icu::Normalizer2* nz = icu::Normalizer2::getNFDInstance(status);
+  icu::UnicodeString u = icu::UnicodeString::fromUTF8(icu::StringPiece((const char*)b.data(), (int32_t)b.size()));
+  icu::UnicodeString out;
+  nz->normalize(u, out, status);
+  std::string s;
+  out.toUTF8String(s);
+  b.assign(s.begin(), s.end());
+}
+
+void lower_bytes(std::vector<uint8_t>& b) {  // tokenmonster.cpp:214-229
+  bool need = false;
+  for (auto x : b) if ((x & 0x80) || (x >= 'A' && x <= 'Z')) { need = true; break; }
+  if (!need) return;
+  icu::UnicodeString u = icu::UnicodeString::fromUTF8(icu::StringPiece((const char*)b.data(), (int32_t)b.size()));
+  u.toLower(icu::Locale::getRoot());
+  std::string s;
+  u.toUTF8String(s);
+  b.assign(s.begin(), s.end());
+}
+
+}  // namespace
+
+bool normalize_supported(uint32_t capcode, uint32_t norm_flag) {
+  return (capcode == 0 || capcode == 2) && (norm_flag & ~3u) == 0;
+}
+
+void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out) {
+  std::vector<uint8_t> tmp(data, data + n);
+  if (norm_flag & 2) { if (norm_flag & 1) nfd_bytes(tmp); lower_bytes(tmp); }   // tokenmonster.cpp:469-472
+  else if (norm_flag & 1) nfd_bytes(tmp);                                        // :473
+  if (capcode == 2) capcode_encode(tmp.data(), tmp.size(), out);
+  else out.swap(tmp);
+}
+
+}  // namespace tmh
+
+extern "C" {
+
+int tm_normalize(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, uint8_t** out, size_t* out_n) {
+  if (!out || !out_n || (n && !data)) return tmh::set_error(TM_E_INVALID, "null argument");
+  if (!tmh::normalize_supported(capcode, norm_flag))
+    return tmh::set_error(TM_E_INVALID, "normalization flags %u / capcode %u not supported by the host normalizer", norm_flag, capcode);
+  std::vector<uint8_t> o;
+  tmh::normalize_bytes(data, n, capcode, norm_flag, o);
+  *out = (uint8_t*)std::malloc(o.size() ? o.size() : 1);
+  if (!o.empty()) std::memcpy(*out, o.data(), o.size());
+  *out_n = o.size();
+  return TM_OK;
+}
+
+int tm_normalize_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode,
+                       uint32_t norm_flag, uint32_t threads, uint8_t** out_text, uint64_t* out_offsets) {
+  if (!out_text || !out_offsets || (ndocs && (!text || !offsets))) return tmh::set_error(TM_E_INVALID, "null argument");
+  if (!tmh::normalize_supported(capcode, norm_flag))
+    return tmh::set_error(TM_E_INVALID, "normalization flags %u / capcode %u not supported by the host normalizer", norm_flag, capcode);
+  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  threads = std::min<uint32_t>(threads, std::max(1u, ndocs));
+  std::vector<std::vector<uint8_t>> outs(ndocs);
+  std::atomic<uint32_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      uint32_t base = next.fetch_add(64);
+      if (base >= ndocs) break;
+      for (uint32_t d = base; d < std::min(ndocs, base + 64); d++)
+        tmh::normalize_bytes(text + offsets[d], (size_t)(offsets[d + 1] - offsets[d]), capcode, norm_flag, outs[d]);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (uint32_t t = 1; t < threads; t++) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+  uint64_t total = 0;
+  for (uint32_t d = 0; d < ndocs; d++) { out_offsets[d] = total; total += outs[d].size(); }
+  out_offsets[ndocs] = total;
+  uint8_t* o = (uint8_t*)std::malloc(total ? total : 1);
+  for (uint32_t d = 0; d < ndocs; d++) if (!outs[d].empty()) std::memcpy(o + out_offsets[d], outs[d].data(), outs[d].size());
+  *out_text = o;
+  return TM_OK;
+}
+
+}  // extern "C"

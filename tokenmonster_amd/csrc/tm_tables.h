@@ -1,0 +1,59 @@
+// tm_tables.h — device-resident vocabulary tables shared by host flattener and HIP kernels.
+//
+// The reference's longest-match index is pansearch.Fast (10 Bloom filters + hash maps + sorted arrays,
+// ~22-30 MB, tokenmonster-cpp/src/tokenmonster.cpp:491-1280): built for a CPU cache hierarchy and for
+// one lookup at a time.  Any structure is admissible as long as LongestSubstring returns the same
+// (index, length, found) with index = record ordinal in the .vocab file.
+// Here it is a byte trie whose accepting nodes ARE the record ordinals:
+//   depth 1   root[256]            (staged in LDS by every workgroup)
+//   depth 2   l2[65536]            direct map on the first two bytes (256 KiB, L2-resident)
+//   depth >=3 edges[]              open-addressing hash of (parent node, byte) -> child, 8 B per slot
+// A 32-bit node value carries everything a look-ahead needs about the token it accepts, so scoring a
+// branch never touches the row table:
+//   bits  0..20  node id; id < n_info  <=>  the prefix is a vocabulary key and id is its record ordinal
+//   bit   21     node has children (lets a walk stop without a failing probe)
+//   bits 22..26  nWords of the accepted token (go/tokenmonster.go:81)
+//   bits 27..31  the five flag bits a *second* token is asked for (go :1075-1084):
+//                b0 ends-with-letter(1) b1 begins-with-letter(2) b2 begins-with-space(4)
+//                b3 begins-on-capcode(16) b4 all-letters-or-all-punct(128)
+#pragma once
+#include <cstdint>
+
+namespace tmh {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kNodeBits = 21;
+constexpr uint32_t kNodeMask = (1u << kNodeBits) - 1;
+constexpr uint32_t kHasChildren = 1u << 21;
+constexpr uint32_t kMaxNodes = kNodeMask - 1;
+
+__host__ __device__ inline uint32_t node_id(uint32_t v) { return v & kNodeMask; }
+__host__ __device__ inline uint32_t node_nwords(uint32_t v) { return (v >> 22) & 31u; }
+__host__ __device__ inline uint32_t node_flag5(uint32_t v) { return v >> 27; }
+__host__ __device__ inline uint32_t flag8_to_flag5(uint32_t f) {
+  return (f & 1u) | (((f >> 1) & 1u) << 1) | (((f >> 2) & 1u) << 2) | (((f >> 4) & 1u) << 3) | (((f >> 7) & 1u) << 4);
+}
+
+// Row of record `index` (16 B): what the walk needs when the record is the FIRST token of a branch
+// (tokenOuter, go/tokenmonster.go:63-77, with id1/id2/length/length2 resolved as Load does, :2703-2712).
+//   x = id   | flag   << 24
+//   y = id1  | nWords << 24
+//   z = id2  | len1   << 24           len1 == 0  <=>  index  == DOES_NOT_EXIST
+//   w = len2 | nWords1 << 6 | nWords2 << 11 | f1 << 16 | f2 << 19     len2 == 0 <=> index2 == DOES_NOT_EXIST
+//       f1/f2: the three flag bits a FIRST token is asked for (b0 flag&1, b1 (flag>>3)&1, b2 flag>>7)
+struct alignas(16) Row { uint32_t x, y, z, w; };
+
+struct Tables {
+  const uint32_t* root;    // [256]
+  const uint32_t* l2;      // [65536]
+  const uint2* edges;      // [edge_mask+1]  x = parent<<8|byte (kNone = empty), y = node value
+  const Row* rows;         // [n_info]
+  const uint8_t* begin_byte;  // [256]  go/tokenmonster.go:43
+  uint32_t edge_mask, edge_shift;
+  uint32_t n_info, max_len;
+  uint32_t off;            // 1, or 2 for UTF-16 (lilbufOffset, go :1031-1034)
+  uint32_t bstart;         // node value after consuming ' ' (and 0x00 for UTF-16), kNone if absent
+  uint32_t has_delete, delete_id, unk_id;
+};
+
+}  // namespace tmh

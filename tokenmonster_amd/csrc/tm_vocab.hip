@@ -1,0 +1,231 @@
+// tm_vocab.hip — .vocab parser and device-table flattener (host side of tm_vocab_load).
+//
+// Replaces the table construction of Load, go/tokenmonster.go:2656-2736 (== tokenmonster-cpp
+// src/tokenmonster.cpp:1287-1359): reads the records in file order (= pansearch index order),
+// resolves alt lengths / ids from earlier records exactly as :2703-2712 does, and instead of
+// pansearch.Fast builds the byte trie described in tm_tables.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "tm_device.h"
+
+namespace tmh {
+
+namespace {
+thread_local char g_err[512];
+uint32_t rd24(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+}  // namespace
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+const char* last_error() { return g_err; }
+
+int hip_fail(hipError_t e, const char* what) {
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+    return set_error(TM_E_NODEVICE, "%s: %s", what, hipGetErrorString(e));
+  return set_error(TM_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
+  size_t pos = 0;
+#define NEED(k) do { if (pos + (size_t)(k) > n) return set_error(TM_E_INVALID, "truncated .vocab at byte %zu", pos); } while (0)
+  NEED(24);
+  hv.capcode = f[0]; hv.charset = f[1]; hv.norm_flag = f[2]; hv.level = f[3]; hv.reserve = f[4];
+  if (hv.charset > 2 || hv.capcode > 2) return set_error(TM_E_INVALID, "not a valid TokenMonster vocabulary");  // go :2675
+  hv.unk = rd24(f + 8); hv.vocab_size = rd24(f + 11); hv.n_ids = rd24(f + 14); hv.n_info = rd24(f + 17);
+  hv.delete_id = rd24(f + 20); hv.max_len = f[23];
+  pos = 24;
+  hv.keys.clear(); hv.key_off.assign(1, 0); hv.rows.resize(hv.n_info);
+  std::vector<uint8_t> lens(hv.n_info), flags(hv.n_info), nwords(hv.n_info);
+  std::vector<uint32_t> ids(hv.n_info);
+  uint32_t prev_len = 0;
+  for (uint32_t i = 0; i < hv.n_info; i++) {
+    NEED(1);
+    uint32_t kl = f[pos++];
+    if (kl == 0 || kl > 40) return set_error(TM_E_INVALID, "record %u: key length %u", i, kl);     // go :2695
+    NEED(kl + 15);
+    if (kl < prev_len || (kl == prev_len && i > 0 && std::memcmp(&hv.keys[hv.key_off[i - 1]], f + pos, kl) >= 0))
+      return set_error(TM_E_INVALID, "record %u out of (length, bytewise) order", i);               // tokenmonster.cpp:1352-1357
+    prev_len = kl;
+    hv.keys.insert(hv.keys.end(), f + pos, f + pos + kl);
+    hv.key_off.push_back((uint32_t)hv.keys.size());
+    pos += kl;
+    uint32_t flag = f[pos], nw = f[pos + 1], index1 = rd24(f + pos + 2), index2 = rd24(f + pos + 5), id = rd24(f + pos + 8);
+    pos += 15;
+    if (id >= hv.n_ids) return set_error(TM_E_INVALID, "record %u: id %u out of range", i, id);
+    if (nw > 31) return set_error(TM_E_LIMIT, "record %u: nWords %u > 31", i, nw);
+    lens[i] = (uint8_t)kl; flags[i] = (uint8_t)flag; nwords[i] = (uint8_t)nw; ids[i] = id;
+    uint32_t id1 = 0, id2 = 0, len1 = 0, len2 = 0, nw1 = 0, nw2 = 0, f1 = 0, f2 = 0;
+    auto first3 = [](uint32_t fl) { return (fl & 1u) | (((fl >> 3) & 1u) << 1) | (((fl >> 7) & 1u) << 2); };
+    if (index1 != TM_NONE) {                                   // go :2703-2706
+      if (index1 >= i) return set_error(TM_E_INVALID, "record %u: alternative does not precede it", i);
+      len1 = lens[index1]; id1 = ids[index1]; nw1 = nwords[index1]; f1 = first3(flags[index1]);
+    }
+    if (index2 != TM_NONE) {                                   // go :2708-2711
+      if (index2 >= i) return set_error(TM_E_INVALID, "record %u: alternative does not precede it", i);
+      len2 = lens[index2]; id2 = ids[index2]; nw2 = nwords[index2]; f2 = first3(flags[index2]);
+    }
+    Row& r = hv.rows[i];
+    r.x = id | (flag << 24);
+    r.y = id1 | (nw << 24);
+    r.z = id2 | (len1 << 24);
+    r.w = len2 | (nw1 << 6) | (nw2 << 11) | (f1 << 16) | (f2 << 19);
+  }
+  NEED(256);
+  std::memcpy(hv.begin_byte, f + pos, 256);
+  pos += 256;
+  NEED(3);
+  uint32_t nd = rd24(f + pos);
+  pos += 3;
+  for (uint32_t i = 0; i < nd; i++) { NEED(1); uint32_t l = f[pos++]; NEED(l + 7); pos += l + 7; }
+  if (pos != n) return set_error(TM_E_INVALID, "trailing bytes after .vocab payload");   // go :2731
+#undef NEED
+
+  // ---- trie: accepting node id == record ordinal; internal nodes numbered from n_info ------------
+  const uint32_t n_info = hv.n_info;
+  std::unordered_map<uint64_t, uint32_t> child;   // (parent id << 8 | byte) -> child id; parent kNodeMask = root
+  child.reserve((size_t)hv.keys.size() + 16);
+  std::vector<uint8_t> depth_of;                   // depth per node id
+  depth_of.assign(n_info, 0);
+  uint32_t next_internal = n_info;
+  const uint32_t kRoot = kNodeMask;
+  for (uint32_t i = 0; i < n_info; i++) {
+    const uint8_t* k = &hv.keys[hv.key_off[i]];
+    uint32_t kl = lens[i];
+    uint32_t node = kRoot;
+    for (uint32_t d = 0; d < kl; d++) {
+      uint64_t key = ((uint64_t)node << 8) | k[d];
+      if (d + 1 == kl) {
+        // keys arrive shortest first, so this node cannot exist yet (a proper prefix of a key is shorter)
+        child.emplace(key, i);
+        depth_of[i] = (uint8_t)kl;
+        node = i;
+      } else {
+        auto it = child.find(key);
+        if (it == child.end()) {
+          if (next_internal >= kMaxNodes) return set_error(TM_E_LIMIT, "vocabulary needs more than %u trie nodes", kMaxNodes);
+          it = child.emplace(key, next_internal++).first;
+          depth_of.push_back((uint8_t)(d + 1));
+        }
+        node = it->second;
+      }
+    }
+  }
+  const uint32_t n_nodes = next_internal;
+  std::vector<uint8_t> has_child(n_nodes, 0);
+  for (auto& kv : child) { uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) has_child[parent] = 1; }
+  auto value_of = [&](uint32_t id) {
+    uint32_t v = id | (has_child[id] ? kHasChildren : 0);
+    if (id < n_info) v |= ((uint32_t)nwords[id] << 22) | (flag8_to_flag5(flags[id]) << 27);
+    return v;
+  };
+  hv.root.assign(256, kNone);
+  hv.l2.assign(65536, kNone);
+  size_t n_edges = 0;
+  for (auto& kv : child) if (depth_of[kv.second] >= 3) n_edges++;
+  uint32_t bits = 4;
+  while ((1ull << bits) < n_edges * 5 / 2 + 8) bits++;
+  hv.edge_mask = (1u << bits) - 1;
+  hv.edge_shift = 32 - bits;
+  hv.edges.assign((size_t)1 << bits, uint2{kNone, kNone});
+  std::vector<uint32_t> first_byte(n_nodes, 0);   // for depth-1 nodes: their byte, to index l2
+  for (auto& kv : child) if (depth_of[kv.second] == 1) { hv.root[kv.first & 0xFF] = value_of(kv.second); first_byte[kv.second] = (uint32_t)(kv.first & 0xFF); }
+  for (auto& kv : child) {
+    uint32_t d = depth_of[kv.second], parent = (uint32_t)(kv.first >> 8), byte = (uint32_t)(kv.first & 0xFF);
+    if (d == 2) hv.l2[(first_byte[parent] << 8) | byte] = value_of(kv.second);
+    else if (d >= 3) {
+      uint32_t key = (parent << 8) | byte;
+      uint32_t h = (key * 0x9E3779B1u) >> hv.edge_shift;
+      while (hv.edges[h].x != kNone) h = (h + 1) & hv.edge_mask;
+      hv.edges[h] = uint2{key, value_of(kv.second)};
+    }
+  }
+  hv.n_nodes = n_nodes;
+  hv.off = hv.charset == 2 ? 2 : 1;
+  hv.bstart = hv.root[' '];
+  if (hv.off == 2 && hv.bstart != kNone) hv.bstart = (hv.bstart & kHasChildren) ? hv.l2[(' ' << 8) | 0] : kNone;
+  return TM_OK;
+}
+
+}  // namespace tmh
+
+using namespace tmh;
+
+extern "C" {
+
+const char* tm_last_error(void) { return tmh::last_error(); }
+
+int tm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int tm_set_device(int device) {
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  return TM_OK;
+}
+
+int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
+  if (!vocab_file || !out) return set_error(TM_E_INVALID, "null argument");
+  *out = nullptr;
+  auto* v = new tm_vocab();
+  int rc = parse_vocab(vocab_file, n, v->host);
+  if (rc != TM_OK) { delete v; return rc; }
+  HostVocab& hv = v->host;
+  hipError_t e;
+  int dev = 0;
+  if ((e = hipGetDevice(&dev)) != hipSuccess) { delete v; return hip_fail(e, "hipGetDevice"); }
+  v->device = dev;
+  auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t r = hipMalloc(dst, bytes ? bytes : 16);
+    if (r != hipSuccess) return r;
+    v->device_bytes += bytes;
+    return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  if ((e = up((void**)&v->d_root, hv.root.data(), 256 * 4)) != hipSuccess ||
+      (e = up((void**)&v->d_l2, hv.l2.data(), 65536 * 4)) != hipSuccess ||
+      (e = up((void**)&v->d_edges, hv.edges.data(), hv.edges.size() * sizeof(uint2))) != hipSuccess ||
+      (e = up((void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row))) != hipSuccess ||
+      (e = up((void**)&v->d_begin_byte, hv.begin_byte, 256)) != hipSuccess) {
+    tm_vocab_free(v);
+    return hip_fail(e, "vocabulary upload");
+  }
+  Tables& t = v->tables;
+  t.root = v->d_root; t.l2 = v->d_l2; t.edges = v->d_edges; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
+  t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
+  t.off = hv.off; t.bstart = hv.bstart;
+  t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
+  *out = v;
+  return TM_OK;
+}
+
+void tm_vocab_free(tm_vocab* v) {
+  if (!v) return;
+  (void)hipFree(v->d_root); (void)hipFree(v->d_l2); (void)hipFree(v->d_edges); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
+  delete v;
+}
+
+uint32_t tm_vocab_size(const tm_vocab* v) { return v->host.vocab_size; }
+uint32_t tm_vocab_n_info(const tm_vocab* v) { return v->host.n_info; }
+uint32_t tm_vocab_n_ids(const tm_vocab* v) { return v->host.n_ids; }
+uint32_t tm_vocab_max_token_length(const tm_vocab* v) { return v->host.max_len; }
+uint32_t tm_vocab_capcode(const tm_vocab* v) { return v->host.capcode; }
+uint32_t tm_vocab_charset(const tm_vocab* v) { return v->host.charset; }
+uint32_t tm_vocab_normalization(const tm_vocab* v) { return v->host.norm_flag; }
+uint32_t tm_vocab_unk(const tm_vocab* v) { return v->host.unk; }
+uint32_t tm_vocab_delete_token(const tm_vocab* v) { return v->host.delete_id; }
+uint64_t tm_vocab_device_bytes(const tm_vocab* v) { return v->device_bytes; }
+
+}  // extern "C"
