@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the HIP ungreedy-tokenization path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload (BASELINE.json configs[1]): englishcode-32000-consistent vocabulary shape, 1 GiB of synthetic mixed
+prose/code/log documents per GPU (weak scaling: every rank tokenizes its own shard, no data-path collective).
+A "step" is ONE pass of the whole device pipeline (segments, match_branch, link, resolve, scan, emit) over the
+resident batch.  Raw text is generated and normalized (NFD + capcode) on the host BEFORE the timed region; the
+timed region starts with the normalized bytes in HBM and ends with dense uint32 ids + offsets in HBM.
+`value` = raw UTF-8 bytes of all ranks x K / max-over-ranks wall time.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the roofline and cpu_baseline objects).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mbytes", type=int, default=1024, help="MiB of raw text per GPU (default 1024 = BASELINE configs[1])")
+    ap.add_argument("--config", default="englishcode-32000-consistent")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mb", type=float, default=64.0)
+    ap.add_argument("--verify", type=int, default=64, help="documents re-checked against the oracle after timing (rank 0)")
+    return ap.parse_args()
+
+
+def cpu_baseline(img, text, offs, sample_mb, log):
+    """the reference's own C++ runtime (oracle/_ref, kind 'reference') — or our C port when it is absent — timed
+    single-threaded on a bounded sample of the SAME normalized documents, the way benchmark/tokenmonster_bench.go
+    :41-55 times Go: wall clock around tokenize calls."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind as ob
+    kind = "reference" if ob.have_ref() else "port"
+    eng = ob.Reference(img) if kind == "reference" else ob.Oracle(img)
+    fn = eng.tokenize_normalized if kind == "reference" else eng.tokenize
+    budget = int(sample_mb * (1 << 20)) if kind == "reference" else int(sample_mb * (1 << 20) / 8)
+    nd = offs.size - 1
+    done = 0
+    d = 0
+    t0 = time.perf_counter()
+    ntok = 0
+    while d < nd and done < budget and time.perf_counter() - t0 < 40.0:
+        a, b = int(offs[d]), int(offs[d + 1])
+        ids, _ = fn(text[a:b])
+        ntok += ids.size
+        done += b - a
+        d += 1
+    dt = time.perf_counter() - t0
+    res = {"value": round(done / dt / 1e9, 6), "unit": "GB/s", "cores": 1, "kind": kind,
+           "sample": "first %d documents (%.1f MB normalized) of the same corpus, 1 thread, %.1f s" % (d, done / 1e6, dt),
+           "host_cores": os.cpu_count()}
+    log("cpu_baseline: %s" % res)
+    return res
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the tokenizer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if world > 1:
+        dist.barrier()
+    import tokenmonster_amd as tm
+    from tokenmonster_amd import _native as N, synth
+    N.check(N.lib.tm_set_device(local_rank))
+
+    kind, vsize, capcode, norm_flag, level, vseed = synth.CONFIGS[args.config]
+    t0 = time.time()
+    if rank == 0:
+        img = synth.config_vocab(args.config)
+    if world > 1:
+        dist.barrier()
+    img = synth.config_vocab(args.config)
+    vocab = tm.Vocab(img)
+    log("vocab %s: %d ids, %d index records, max token %d, tables %.1f MB (%.1fs)" % (
+        args.config, vocab.n_ids(), vocab.n_info(), vocab.max_token_length(), N.lib.tm_vocab_device_bytes(vocab.handle) / 1e6, time.time() - t0))
+
+    # ---- synthetic corpus shard of this rank ------------------------------------------------------------
+    t0 = time.time()
+    raw, roffs = synth.synth_corpus(kind, args.mbytes << 20, seed=0x434F5250 + 2 + 1000 * rank)
+    raw_bytes = int(raw.size)
+    text, offs = synth.normalize_batch(raw, roffs, capcode, norm_flag)
+    del raw
+    ndocs = offs.size - 1
+    log("corpus: %d docs, %.1f MB raw -> %.1f MB normalized (%.1fs host)" % (ndocs, raw_bytes / 1e6, text.size / 1e6, time.time() - t0))
+
+    batch = C.c_void_p()
+    N.check(N.lib.tm_batch_create(vocab.handle, int(text.size), ndocs, C.byref(batch)))
+    t0 = time.time()
+    N.check(N.lib.tm_batch_upload(batch, N.ptr(text), N.ptr(offs), ndocs))
+    h2d_s = time.time() - t0
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        N.check(N.lib.tm_batch_run(batch, C.c_void_p(stream)))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(raw_bytes), float(text.size)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        all_raw, all_norm = float(tot[0].item()), float(tot[1].item())
+    else:
+        all_raw, all_norm = float(raw_bytes), float(text.size)
+
+    ntok = C.c_uint64()
+    nmiss = C.c_uint64()
+    N.check(N.lib.tm_batch_totals(batch, C.byref(ntok), C.byref(nmiss)))
+
+    # ---- per-kernel time, HIP events on the launch stream (after the timed loop, a few extra passes) --------
+    ms = (C.c_float * N.TM_NUM_KERNELS)()
+    acc = np.zeros(N.TM_NUM_KERNELS)
+    reps = 3
+    for _ in range(reps):
+        N.check(N.lib.tm_batch_run_timed(batch, C.c_void_p(stream), ms))
+        acc += np.array(list(ms))
+    acc /= reps
+    names = [N.lib.tm_kernel_name(k).decode() for k in range(N.TM_NUM_KERNELS)]
+    kernel_ms = {n: round(float(v), 4) for n, v in zip(names, acc)}
+    dom = int(np.argmax(acc))
+    alg_bytes = float(text.size) + 4.0 * float(ntok.value)     # B_alg = N + 4T per pass
+    achieved = alg_bytes / (acc[dom] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("config") == args.config and tj.get("mbytes") == args.mbytes:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms}
+
+    # ---- verification of a sample against the oracle (rank 0; outside the timed region) -------------------
+    verified = None
+    if rank == 0 and args.verify > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_bind import Oracle
+        orc = Oracle(img)
+        cap = int(ntok.value)
+        ids = np.empty(max(cap, 1), dtype=np.uint32)
+        toff = np.empty(ndocs + 1, dtype=np.uint64)
+        miss = np.empty(max(ndocs, 1), dtype=np.uint32)
+        N.check(N.lib.tm_batch_download(batch, N.ptr(ids), cap, N.ptr(toff), N.ptr(miss)))
+        rng = np.random.default_rng(1)
+        verified = 0
+        for d in rng.choice(ndocs, size=min(args.verify, ndocs), replace=False):
+            exp, m = orc.tokenize(text[int(offs[d]):int(offs[d + 1])])
+            got = ids[int(toff[d]):int(toff[d + 1])]
+            if got.size != exp.size or (got != exp).any() or m != int(miss[d]):
+                raise SystemExit("bench.py: HIP ids differ from the oracle in document %d - number is INVALID" % d)
+            verified += 1
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(img, text, offs, args.cpu_sample_mb, log)
+
+    if rank == 0:
+        value = all_raw * args.steps / elapsed / 1e9
+        out = {
+            "metric": "GB/s raw UTF-8 tokenized, englishcode-32000 vocab", "value": round(value, 4), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s vocabulary shape (synthetic, %d ids / %d index records), %d MiB raw synthetic mixed "
+                                   "text per GPU in %d documents; hot path only: input = host-normalized (NFD+capcode) "
+                                   "bytes resident in HBM, output = uint32 ids + offsets in HBM" % (
+                                       args.config, vocab.n_ids(), vocab.n_info(), args.mbytes, ndocs),
+                       "raw_bytes_per_gpu": raw_bytes, "normalized_bytes_per_gpu": int(text.size), "tokens_per_gpu": int(ntok.value),
+                       "missing": int(nmiss.value), "normalized_GBps": round(all_norm * args.steps / elapsed / 1e9, 4),
+                       "h2d_seconds": round(h2d_s, 3), "parallelism": "documents sharded by rank, no collective",
+                       "verified_docs_vs_oracle": verified},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    N.lib.tm_batch_free(batch)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

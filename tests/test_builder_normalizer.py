@@ -1,0 +1,117 @@
+"""CPU: host logic — vocabulary builder (go/tokenmonster.go:3423-3793 rules) and the normalize+capcode pre-step."""
+import base64
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle_bind import Oracle, Reference, have_ref
+from tokenmonster_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def records(img):
+    """parse a .vocab image into {key: (flag, nWords, index1, index2, id)} + header"""
+    n_info = int.from_bytes(img[17:20], "little")
+    pos, recs, keys = 24, {}, []
+    for _ in range(n_info):
+        kl = img[pos]
+        key = img[pos + 1: pos + 1 + kl]
+        p = pos + 1 + kl
+        recs[key] = (img[p], img[p + 1], int.from_bytes(img[p + 2:p + 5], "little"), int.from_bytes(img[p + 5:p + 8], "little"),
+                     int.from_bytes(img[p + 8:p + 11], "little"))
+        keys.append(key)
+        pos = p + 15
+    bb = img[pos:pos + 256]
+    return recs, keys, bb, {"unk": int.from_bytes(img[8:11], "little"), "vocab_size": int.from_bytes(img[11:14], "little"),
+                            "delete": int.from_bytes(img[20:23], "little"), "max_len": img[23]}
+
+
+def test_flags_and_duplicates_capcode2():
+    toks = [bytes([c]) for c in b" abcdehlorstw.,D"] + [b" hello", b" hello world", b"hello", b" the", b"the", b"ell", b" he",
+                                                         b"C hello", b"ing", b"...", b" 12", b"12", b"e's", b"e"]
+    img = synth.build_vocab(toks, capcode=2, charset=1)
+    recs, keys, bb, hdr = records(img)
+    NONE = 0xFFFFFF
+    # "D "+token duplicates for tokens starting with a letter/digit share the id (go :3450-3462)
+    assert b"D hello" in recs and recs[b"D hello"][4] == recs[b"hello"][4]
+    assert b"D 12" in recs and b"D  the" not in recs and b"D ..." not in recs
+    # order = (length, bytewise) (Appendix D)
+    assert keys == sorted(keys, key=lambda k: (len(k), k))
+    f = recs[b" hello"][0]
+    assert f & 4 and f & 1 and f & 32 and f & 128 and recs[b" hello"][1] == 1         # begins space, ends letter, one whole word
+    f = recs[b" hello world"][0]
+    assert f & 4 and f & 1 and not f & 32 and recs[b" hello world"][1] == 2
+    assert keys[recs[b" hello world"][2]] == b" hello"                                 # best alternative: cut before " w" (priority 10)
+    assert recs[b"hello"][0] & 2 and recs[b"hello"][0] & 1 and recs[b"hello"][0] & 128
+    assert recs[b"C hello"][0] & 16 and recs[b"C hello"][0] & 4                        # begins on a capcode marker, counts as space
+    assert recs[b"..."][0] & 128 and not recs[b"..."][0] & 3
+    assert recs[b"D"][0] & 8 and hdr["delete"] == recs[b"D"][4]                        # ends on capcode marker; deleteToken id
+    assert recs[b"e's"][2] != NONE and keys[recs[b"e's"][2]] == b"e"                   # suffix rule (go :3720)
+    assert hdr["max_len"] == len(b" hello world") + 0 or hdr["max_len"] == max(len(k) for k in keys)
+    if have_ref():
+        Reference(img)   # the reference loader verifies order and backward alternative indices (tokenmonster.cpp:1352)
+    Oracle(img)
+
+
+def test_builder_capcode0_and_unk():
+    toks = [bytes([c]) for c in range(256)] + [b"foo", b"foo_bar", b"foo_", b"_bar", b"bar", b"Bar", b"fooBar", b"x1", b"x"]
+    img = synth.build_vocab(toks, capcode=0, charset=1, with_unk=True)
+    recs, keys, bb, hdr = records(img)
+    assert hdr["unk"] == 0xFFFFFF            # 256 single bytes: canHaveUnkToken false (go :437-442)
+    img = synth.build_vocab(toks[:200] + toks[256:], capcode=0, charset=1, with_unk=True)
+    recs, keys, bb, hdr = records(img)
+    assert hdr["unk"] == hdr["vocab_size"] - 1
+    assert b"D foo" not in recs and hdr["delete"] == 0xFFFFFF
+    assert keys[recs[b"foo_bar"][2]] in (b"foo", b"foo_")
+
+
+def test_builder_rejects_bad_input():
+    from tokenmonster_amd._native import TokenMonsterHipError
+    with pytest.raises(TokenMonsterHipError):
+        synth.build_vocab([b"x" * 41])
+
+
+def test_synthetic_vocab_shape_and_determinism():
+    a = synth.synth_vocab(synth.CODE, 1500, capcode=0, norm_flag=1, level=2, seed=42)
+    b = synth.synth_vocab(synth.CODE, 1500, capcode=0, norm_flag=1, level=2, seed=42)
+    assert a == b
+    recs, keys, bb, hdr = records(a)
+    assert hdr["vocab_size"] <= 1500 and hdr["vocab_size"] > 1400
+    assert sum(1 for k in keys if recs[k][2] != 0xFFFFFF) > 200      # alternatives exist
+    raw, offs = synth.synth_corpus(synth.CODE, 50_000, seed=1)
+    raw2, offs2 = synth.synth_corpus(synth.CODE, 50_000, seed=1)
+    assert (raw == raw2).all() and (offs == offs2).all() and offs[0] == 0 and offs[-1] == raw.size
+
+
+def test_normalizer_matches_golden_pairs():
+    g = json.load(open(os.path.join(GOLDEN, "normalize_capcode2_nfd.json")))
+    for p in g["pairs"]:
+        raw = base64.b64decode(p["raw_b64"])
+        assert synth.normalize(raw, g["capcode"], g["norm_flag"]) == base64.b64decode(p["norm_b64"]), raw
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+def test_normalizer_vs_reference_runtime_on_synthetic_text():
+    img = synth.synth_vocab(synth.ENGLISHCODE, 1200, capcode=2, norm_flag=1, level=3, seed=7)
+    ref = Reference(img)
+    raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 300_000, seed=9)
+    text, noff = synth.normalize_batch(raw, offs, 2, 1, threads=2)
+    for d in range(offs.size - 1):
+        exp = ref.normalize(raw[int(offs[d]):int(offs[d + 1])])
+        got = text[int(noff[d]):int(noff[d + 1])].tobytes()
+        assert got == exp, "doc %d" % d
+    rng = np.random.default_rng(3)
+    alphabet = list(b"aBcD eF'1.2-") + ["é", "É", "ß", "’", "́"]
+    for _ in range(400):
+        s = "".join(c if isinstance(c, str) else chr(c) for c in rng.choice(np.array(alphabet, dtype=object), size=int(rng.integers(0, 40))))
+        b = s.encode()
+        assert synth.normalize(b, 2, 1) == ref.normalize(b), s
+
+
+def test_unsupported_normalization_fails_loudly():
+    from tokenmonster_amd._native import TokenMonsterHipError
+    with pytest.raises(TokenMonsterHipError):
+        synth.normalize(b"abc", 2, 16)
