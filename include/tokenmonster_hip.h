@@ -87,12 +87,12 @@ int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm
 void tm_batch_free(tm_batch* b);
 /* H2D of packed text + offsets (synchronous). */
 int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs);
-/* Runs the whole device pipeline (match+branch, link, scan, emit) on `stream` (a hipStream_t, NULL =
+/* Runs the whole device pipeline (segments, match+branch+link, resolve, scan, emit) on `stream` (a hipStream_t, NULL =
  * default stream).  Inputs and outputs stay in HBM.  Asynchronous with respect to the host. */
 int tm_batch_run(tm_batch* b, void* stream);
 /* As tm_batch_run but brackets every kernel with HIP events on `stream` and returns per-kernel
  * milliseconds in ms[TM_NUM_KERNELS] (synchronizes). */
-#define TM_NUM_KERNELS 6
+#define TM_NUM_KERNELS 5
 int tm_batch_run_timed(tm_batch* b, void* stream, float* ms);
 const char* tm_kernel_name(int k);
 /* Totals of the last run (synchronizes the stream used by the last run). */

@@ -78,3 +78,61 @@ def test_synthetic_config(name):
             exp, _ = ref.tokenize_normalized(docs[d])
             got = ids[int(toff[d]):int(toff[d + 1])]
             assert got.size == exp.size and (got == exp).all()
+
+
+def _score(vocab, data, strips=None):
+    """tm_score on a freshly uploaded dataset -> (scores, tokens_in_text, missing_set)"""
+    import ctypes as C
+    from tokenmonster_amd import _native as N
+    d = np.frombuffer(bytes(data), dtype=np.uint8)
+    ds = C.c_void_p()
+    N.check(N.lib.tm_dataset_upload(N.ptr(d), d.size, C.byref(ds)))
+    try:
+        scores = np.zeros(vocab.n_ids(), dtype=np.uint32)
+        tit = C.c_uint64()
+        ms = np.zeros(32, dtype=np.uint8)
+        if strips is None:
+            N.check(N.lib.tm_score(vocab.handle, ds, None, None, 0, N.ptr(scores), C.byref(tit), N.ptr(ms)))
+        else:
+            so = np.array([a for a, _ in strips], dtype=np.uint64)
+            sl = np.array([l for _, l in strips], dtype=np.uint64)
+            N.check(N.lib.tm_score(vocab.handle, ds, N.ptr(so), N.ptr(sl), len(strips), N.ptr(scores), C.byref(tit), N.ptr(ms)))
+        return scores, tit.value, ms
+    finally:
+        N.lib.tm_dataset_free(ds)
+
+
+@pytest.mark.parametrize("capcode", [0, 2])
+def test_score_histogram_micro(capcode):
+    # training/trainvocab.go:925-1176: scores[id] += bytes covered, scores[deleteToken]++, tokensInText, missing bytes
+    rng = np.random.default_rng(300 + capcode)
+    toks = fuzz_vocab_tokens(rng, capcode, 150)
+    img = synth.build_vocab(toks, capcode=capcode, charset=1)
+    v, orc = tm.Vocab(img), Oracle(img)
+    data = fuzz_text(rng, capcode, 90_000)
+    exp_s, exp_t, exp_m = orc.score(data)
+    got_s, got_t, got_m = _score(v, data)
+    assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
+    # strips (the pre-"midway" mode, trainvocab.go:1668-1695): each strip is walked independently
+    strips = [(0, 10_000), (20_000, 4096), (50_000, 513), (70_000, 20_000), (89_999, 1), (5, 0)]
+    exp_s = np.zeros(orc.n_ids(), dtype=np.uint32)
+    exp_t = 0
+    exp_m = np.zeros(32, dtype=np.uint8)
+    for a, l in strips:
+        s, t, m = orc.score(data[a:a + l])
+        exp_s += s
+        exp_t += t
+        exp_m |= m
+    got_s, got_t, got_m = _score(v, data, strips)
+    assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
+
+
+def test_score_histogram_candidate_vocab():
+    img = synth.synth_vocab(synth.ENGLISHCODE, 8000, capcode=2, norm_flag=1, level=5, seed=0x544D0005)
+    v, orc = tm.Vocab(img), Oracle(img)
+    raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 600_000, seed=44)
+    text, _ = synth.normalize_batch(raw, offs, 2, 1)
+    exp_s, exp_t, exp_m = orc.score(text)
+    got_s, got_t, got_m = _score(v, text)
+    assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
+    assert int(got_s.sum()) >= text.size        # every byte covered once (+1 per forward delete)

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libtokenmonster_hip.so")
 
 TM_OK, TM_E_INVALID, TM_E_NODEVICE, TM_E_HIP, TM_E_NOSPACE, TM_E_LIMIT = 0, -1, -2, -3, -4, -5
 TM_NONE = 0xFFFFFF
-TM_NUM_KERNELS = 6
+TM_NUM_KERNELS = 5
 KIND_ENGLISH, KIND_ENGLISHCODE, KIND_CODE = 0, 1, 2
 
 u8p = C.POINTER(C.c_uint8)

@@ -20,8 +20,8 @@ struct HostVocab {
   std::vector<uint32_t> key_off;    // n_info + 1
   std::vector<Row> rows;
   uint8_t begin_byte[256];
-  std::vector<uint32_t> root, l2;
-  std::vector<uint2> edges;
+  std::vector<uint32_t> root;
+  std::vector<uint2> tab;           // direct depth-2 map followed by the edge hash (tm_tables.h)
   uint32_t edge_mask = 0, edge_shift = 0, n_nodes = 0, off = 1, bstart = kNone;
 };
 
@@ -35,8 +35,7 @@ struct tm_vocab {
   int device = 0;
   uint64_t device_bytes = 0;
   uint32_t* d_root = nullptr;
-  uint32_t* d_l2 = nullptr;
-  uint2* d_edges = nullptr;
+  uint2* d_tab = nullptr;
   tmh::Row* d_rows = nullptr;
   uint8_t* d_begin_byte = nullptr;
 };

@@ -34,7 +34,10 @@ constexpr int NPOS_PAD = 576;            // 9 x 64
 constexpr int TEXT_LEN = SEG + 96;       // staged text: position i may read up to i + 40
 constexpr int ENT = 80;                  // entry states of a segment: 40 offsets x fd{0,1}
 constexpr int WAVES = 4;                 // wavefronts per workgroup in K1
+constexpr int REFILL_THR = 40;           // K1 refills idle lanes when fewer than this many are still walking
 constexpr uint32_t R_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t J_EXIT = 1024;           // jump targets >= J_EXIT: left the segment; J_EXIT + next entry state
+constexpr uint32_t J_INVALID = 4095;        // state is not reachable (no forward-delete match there)
 constexpr uint32_t ID_NONE = 0xFFFFFFu;
 constexpr int NOSCORE = -1000000;
 
@@ -135,36 +138,10 @@ __global__ void k_segments(const uint64_t* __restrict__ doc_seg_start, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // K1: match + branch
 // ------------------------------------------------------------------------------------------------
-struct Match { uint32_t v; uint32_t len; };   // v = node value of the longest accepting prefix, len its length (0 = none)
-
-__device__ __forceinline__ uint32_t edge_lookup(const Tables& T, uint32_t parent, uint32_t byte) {
-  uint32_t key = (parent << 8) | byte;
-  uint32_t h = (key * 0x9E3779B1u) >> T.edge_shift;
-  for (;;) {
-    uint2 e = T.edges[h];
-    if (e.x == key) return e.y;
-    if (e.x == kNone) return kNone;
-    h = (h + 1) & T.edge_mask;
-  }
-}
-
-// continue a trie walk: `v` is the node value reached after `depth` bytes; text byte number k of the
-// string being matched is txt[k].  limit = number of bytes available.  (pansearch LongestSubstring,
-// call sites go/tokenmonster.go:1049,1068,1091,...; semantics tokenmonster.cpp:786-877)
-__device__ __forceinline__ void walk_tail(const Tables& T, const uint8_t* txt, uint32_t v, uint32_t depth, uint32_t limit,
-                                          Match& best) {
-  while (depth < limit && (v & kHasChildren)) {
-    uint32_t c = txt[depth];
-    v = edge_lookup(T, node_id(v), c);
-    if (v == kNone) break;
-    depth++;
-    if (node_id(v) < T.n_info) { best.v = v; best.len = depth; }
-  }
-}
-
-// descriptor word kept in LDS per position: len[0..5] | flag5[6..10] | nWords[11..15] | nextByteClass[16..19]
+// descriptor word kept in LDS per position: len[0..5] | nWords[6..10] | flag5[11..15] | nextByteClass[16..19]
+// (nWords|flag5 are bits 22..31 of the node value, so a descriptor is (v >> 22) << 6 | len)
 __device__ __forceinline__ uint32_t make_desc(uint32_t len, uint32_t v, uint32_t nb) {
-  return len | (node_flag5(v) << 6) | (node_nwords(v) << 11) | (nb << 16);
+  return len | ((v >> 22) << 6) | (nb << 16);
 }
 
 struct First { int flen; int nw; uint32_t f3; };   // candidate first token: length consumed, nWords - fd, flag bits {1, 8>>3, 128>>7}
@@ -172,8 +149,8 @@ struct First { int flen; int nw; uint32_t f3; };   // candidate first token: len
 // score of one branch, go/tokenmonster.go:1075-1084 (a), :1096-1105 (b); k > 0 adds :1132-1133
 __device__ __forceinline__ int branch_score(const First& F, uint32_t dS, bool bvariant, bool alt, int len) {
   int l = (int)(dS & 63u);
-  uint32_t f5 = (dS >> 6) & 31u;
-  int snw = (int)((dS >> 11) & 31u);
+  uint32_t f5 = (dS >> 11) & 31u;
+  int snw = (int)((dS >> 6) & 31u);
   int nb = (int)((dS >> 16) & 15u);
   int BL = F.flen + l;
   int fend = (int)(F.f3 & 1u), fcap = (int)((F.f3 >> 1) & 1u), fall = (int)((F.f3 >> 2) & 1u);
@@ -188,19 +165,19 @@ __device__ __forceinline__ int branch_score(const First& F, uint32_t dS, bool bv
 }
 
 struct WaveLds {
-  uint8_t text[TEXT_LEN];
+  alignas(16) uint8_t text[TEXT_LEN];
   uint32_t D[NPOS_PAD];    // longest match at p                      (second-token descriptor)
   uint32_t Db[NPOS_PAD];   // longest match of ' '+text[p:], if usable (forward-delete descriptor), 0 = none
-  uint32_t X[SEG];         // record ordinal of D's token
-  uint32_t Xb[SEG];        // record ordinal of Db's token
+  uint32_t X[SEG];         // node value of D's token (node id = record ordinal)
+  uint32_t Xb[SEG];        // node value of Db's token
+  uint8_t xchg[64];        // lane exchange scratch for handing out forward-delete tasks
 };
 
 // T(p, fd): go/tokenmonster.go:1051-1276
 __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w, const uint8_t* s_bb, int p, int dl,
-                                               uint32_t d, uint32_t x, int fd) {
+                                               uint32_t d, const Row& O, int fd) {
   if (d == 0) return (T.unk_id != TM_NONE ? T.unk_id : ID_NONE) | (1u << 24) | (1u << 31);   // go :1269-1276
   const int len = (int)(d & 63u);
-  const Row O = T.rows[x];
   const uint32_t id = O.x & ID_NONE, oflag = O.x >> 24;
   const int i1 = p + len;
   if (i1 < dl && ((oflag & 32u) == 0 || s_bb[w.text[i1]] != 12)) {                           // go :1057
@@ -245,7 +222,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_branch(Tables T, const uin
                                                              const uint64_t* __restrict__ doc_end,
                                                              const uint32_t* __restrict__ seg_doc,
                                                              const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
-                                                             uint2* __restrict__ R) {
+                                                             uint2* __restrict__ R, uint2* __restrict__ exitmap, int dbg) {
   __shared__ uint32_t s_root[256];
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
@@ -263,136 +240,286 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_branch(Tables T, const uin
   const int seglen = min(dl, SEG);
   const int Lmax = (int)T.max_len;
 
-  for (int j = lane; j < TEXT_LEN; j += 64) w.text[j] = j < dl ? text[begin + j] : 0;   // pad byte 0 (go :1038-1046, Q1)
+  // stage the text with (unaligned) dword loads; bytes at and after the end of the document read as 0: the pad
+  // byte of go/tokenmonster.go:1038-1046 (quirk Q1: we define it as 0 like tokenmonster.cpp:1724-1726)
+  for (int j = lane; j < TEXT_LEN / 4; j += 64) {
+    uint32_t wv = 0;
+    if (4 * j < dl) {
+      __builtin_memcpy(&wv, text + begin + 4 * j, 4);       // the text buffer has >= 256 bytes of slack
+      if (4 * j + 4 > dl) wv &= (1u << (8 * (dl - 4 * j))) - 1u;
+    }
+    reinterpret_cast<uint32_t*>(w.text)[j] = wv;
+  }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
 
   // ---- step A: descriptors for every position the segment can look at -----------------------------
-  for (int it = 0; it < NPOS_PAD / 64; it++) {
-    const int p = it * 64 + lane;
-    uint32_t d = 0, x = 0, db = 0, xb = 0;
-    if (p < NPOS && p < dl) {
-      const uint32_t m = (uint32_t)min(dl - p, Lmax);
-      Match best{0, 0};
-      const uint8_t* txt = &w.text[p];
-      uint32_t v = s_root[txt[0]];
-      if (v != kNone) {
-        if (node_id(v) < T.n_info) { best.v = v; best.len = 1; }
-        if (m >= 2 && (v & kHasChildren)) {
-          v = T.l2[((uint32_t)txt[0] << 8) | txt[1]];
-          if (v != kNone) {
-            if (node_id(v) < T.n_info) { best.v = v; best.len = 2; }
-            walk_tail(T, txt, v, 2, m, best);
+  // The pass is VALU-issue bound (profiles/r01_v1_pmc.txt), so the trie walks run as a TIGHT probe loop — one
+  // 8-byte hash probe per lane per round, ~20 instructions — and everything rare (taking the next position, the
+  // first two bytes through the direct map, storing a result) happens in a separate refill phase that runs only
+  // when fewer than REFILL_THR lanes are still walking.  Lanes take positions from a wave-wide counter, so no lane
+  // idles behind the longest walk of a block.  (pansearch LongestSubstring, call sites go/tokenmonster.go:1049..)
+  for (int j = lane; j < NPOS_PAD; j += 64) { w.D[j] = 0; w.Db[j] = 0; }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long lane_below = (1ull << lane) - 1ull;
+  const uint2* __restrict__ hash_tab = T.tab + kL2Size;
+  const int ntask = (dbg & 1) ? 0 : min(NPOS, dl);     // positions >= dl keep descriptor 0 (nothing there)
+  {
+    // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
+    int next_task = 0;                        // wave-uniform
+    int pos = 0, depth = 0, limit = 0, bestlen = 0;
+    uint32_t cur = 0, haddr = 0, key = 0, bestv = 0;
+    bool active = false;
+    for (;;) {
+      // refill: idle lanes take the next positions; the direct map answers the first two bytes
+      for (int rep = 0; rep < 2 && next_task < ntask; rep++) {
+        const unsigned long long wmask = __ballot(!active);
+        if (wmask == 0) break;
+        const int p = next_task + __popcll(wmask & lane_below);
+        next_task += __popcll(wmask);
+        if (!active && p < ntask) {
+          limit = min(dl - p, Lmax);
+          uint2 e;
+          if (limit >= 2) e = T.tab[((uint32_t)w.text[p] << 8) | w.text[p + 1]];
+          else { const uint32_t r = s_root[w.text[p]]; e = make_uint2((r != kNone && node_id(r) < T.n_info) ? 1u : 0u, r); }
+          bestlen = (int)(e.x & 3u);
+          bestv = e.y;
+          if ((e.x & 4u) && limit > 2) {
+            pos = p; depth = 2; active = true;
+            cur = (e.x >> 3) | kHasChildren;
+            key = ((e.x >> 3) << 8) | w.text[p + 2];
+            haddr = (key * 0x9E3779B1u) >> T.edge_shift;
+          } else if (bestlen != 0) {
+            w.D[p] = (uint32_t)bestlen | ((bestv >> 22) << 6);
+            if (p < SEG) w.X[p] = bestv;
           }
         }
       }
-      if (best.len != 0) {
-        const uint32_t nb = s_bb[txt[best.len]];
-        d = make_desc(best.len, best.v, nb);
-        x = node_id(best.v);
-        // forward-delete probe, go :1088-1095: second token begins with a letter, has no word boundary,
-        // and the byte after it is letter-class -> look for ' '+text[p:] and accept it only if longer
-        if (T.has_delete && (node_flag5(best.v) & 2u) && nb == 1 && node_nwords(best.v) == 0 && T.bstart != kNone) {
-          const uint32_t off = T.off;
-          const int mb = min(dl - p, Lmax - (int)off);
-          if (mb > 0) {
-            Match bb{0, 0};
-            uint32_t vb = T.bstart;
-            uint32_t depth = off;
-            const uint32_t limit = (uint32_t)mb + off;
-            if (off == 1) {
-              // second byte of " x..." through the direct map
-              if (vb & kHasChildren) {
-                vb = T.l2[((uint32_t)' ' << 8) | txt[0]];
-                if (vb != kNone) {
-                  depth = 2;
-                  if (node_id(vb) < T.n_info) { bb.v = vb; bb.len = 2; }
-                  walk_tail(T, txt - 1, vb, depth, limit, bb);
-                }
-              }
-            } else {
-              walk_tail(T, txt - 2, vb, depth, limit, bb);
-            }
-            if (bb.len > best.len + 1) {                                   // go :1092
-              const uint32_t lb = bb.len - off;                            // go :1093
-              db = make_desc(lb, bb.v, s_bb[txt[lb]]);
-              xb = node_id(bb.v);
-            }
+      int nactive = __popcll(__ballot(active));
+      if (nactive == 0) { if (next_task >= ntask) break; continue; }
+      // tight probe loop
+      const int thr = next_task < ntask ? REFILL_THR : 1;
+      do {
+        if (active) {
+          const uint2 e = hash_tab[haddr];
+          if (e.x == key) {
+            cur = e.y;
+            depth++;
+            if (node_id(cur) < T.n_info) { bestv = cur; bestlen = depth; }
+            if (depth < limit && (cur & kHasChildren)) {
+              key = (node_id(cur) << 8) | w.text[pos + depth];
+              haddr = (key * 0x9E3779B1u) >> T.edge_shift;
+            } else active = false;
+          } else if (e.x != kNone) {
+            haddr = (haddr + 1) & T.edge_mask;        // linear probing
+          } else active = false;
+          if (!active && bestlen != 0) {
+            w.D[pos] = (uint32_t)bestlen | ((bestv >> 22) << 6);
+            if (pos < SEG) w.X[pos] = bestv;
           }
         }
-      }
+        nactive = __popcll(__ballot(active));
+      } while (nactive >= thr);
     }
-    if (p < NPOS_PAD) { w.D[p] = d; w.Db[p] = db; }
-    if (p < SEG) { w.X[p] = x; w.Xb[p] = xb; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  // ---- A2: class of the byte after each match; which positions need the forward-delete probe (go :1088) ----------
+  // second token begins with a letter, has no word boundary and the byte after it is letter-class
+  unsigned long long elig[NPOS_PAD / 64];
+  {
+    const int off = (int)T.off;
+    const bool can_b = T.has_delete && T.bstart != kNone && (T.bstart & kHasChildren);
+#pragma unroll
+    for (int it = 0; it < NPOS_PAD / 64; it++) {
+      const int p = it * 64 + lane;
+      uint32_t d = w.D[p];
+      bool el = false;
+      if (d != 0) {
+        const uint32_t nb = s_bb[w.text[p + (d & 63u)]];
+        d |= nb << 16;
+        w.D[p] = d;
+        el = can_b && ((d >> 12) & 1u) && nb == 1 && ((d >> 6) & 31u) == 0 && min(dl - p, Lmax - off) > 0;
+      }
+      elig[it] = __ballot(el);
+    }
+  }
+  {
+    // ---- A3: longest match of ' '+text[p:] at the eligible positions -> Db[p], Xb[p] (accepted only if longer, go :1092)
+    const int off = (int)T.off;
+    int blk = 0;                              // wave-uniform: block of 64 positions tasks are taken from
+    unsigned long long avail = elig[0];
+    int pos = 0, depth = 0, limit = 0, bestlen = 0, mainlen = 0;
+    uint32_t cur = 0, haddr = 0, key = 0, bestv = 0;
+    bool active = false;
+    auto store_b = [&]() {
+      if (bestlen > mainlen + 1) {
+        const int lb = bestlen - off;                                      // go :1093
+        w.Db[pos] = make_desc((uint32_t)lb, bestv, s_bb[w.text[pos + lb]]);
+        if (pos < SEG) w.Xb[pos] = bestv;
+      }
+    };
+    for (;;) {
+      // refill from the eligibility masks
+      for (int rep = 0; rep < 2; rep++) {
+        while (avail == 0 && blk + 1 < NPOS_PAD / 64) { blk++; avail = 0;
+#pragma unroll
+          for (int k = 0; k < NPOS_PAD / 64; k++) if (k == blk) avail = elig[k];
+        }
+        if (avail == 0) break;
+        const unsigned long long wmask = __ballot(!active);
+        if (wmask == 0) break;
+        // the r-th idle lane takes the r-th available position of the block: exchange through the text tail of LDS
+        const int navail = __popcll(avail), nwant = __popcll(wmask);
+        const int n = min(navail, nwant);
+        const int prank = __popcll(avail & lane_below);                    // rank of MY position bit, if set
+        if (((avail >> lane) & 1ull) && prank < n) w.xchg[prank] = (uint8_t)lane;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0);
+        const int wrank = __popcll(wmask & lane_below);
+        const bool take = !active && wrank < n;
+        int p = 0;
+        if (take) p = blk * 64 + w.xchg[wrank];
+        // clear the n lowest available bits
+        avail = __ballot(((avail >> lane) & 1ull) && prank >= n);
+        __builtin_amdgcn_wave_barrier();
+        if (take) {
+          pos = p; bestlen = 0; bestv = 0;
+          mainlen = (int)(w.D[p] & 63u);
+          limit = min(dl - p, Lmax - off) + off;
+          if (off == 1) {
+            const uint2 e = T.tab[((uint32_t)' ' << 8) | w.text[p]];
+            if ((e.x & 4u) && limit > 2) {
+              depth = 2; active = true;
+              key = ((e.x >> 3) << 8) | w.text[p + 1];
+              haddr = (key * 0x9E3779B1u) >> T.edge_shift;
+            }
+          } else {
+            depth = 2; active = true;
+            key = (node_id(T.bstart) << 8) | w.text[p];
+            haddr = (key * 0x9E3779B1u) >> T.edge_shift;
+          }
+        }
+      }
+      int nactive = __popcll(__ballot(active));
+      bool more = avail != 0;
+#pragma unroll
+      for (int k = 0; k < NPOS_PAD / 64; k++) more |= (k > blk && elig[k] != 0);
+      if (nactive == 0) { if (!more) break; continue; }
+      const int thr = more ? REFILL_THR : 1;
+      const int tbase = pos - off;            // text[tbase + depth] is byte number `depth` of ' '+text[pos:]
+      do {
+        if (active) {
+          const uint2 e = hash_tab[haddr];
+          if (e.x == key) {
+            cur = e.y;
+            depth++;
+            if (node_id(cur) < T.n_info) { bestv = cur; bestlen = depth; }
+            if (depth < limit && (cur & kHasChildren)) {
+              key = (node_id(cur) << 8) | w.text[tbase + depth];
+              haddr = (key * 0x9E3779B1u) >> T.edge_shift;
+            } else active = false;
+          } else if (e.x != kNone) {
+            haddr = (haddr + 1) & T.edge_mask;
+          } else active = false;
+          if (!active) store_b();
+        }
+        nactive = __popcll(__ballot(active));
+      } while (nactive >= thr);
+    }
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
 
   // ---- step B: T(p,0) and T(p,1) for every position of the segment --------------------------------
-  for (int it = 0; it < SEG / 64; it++) {
-    const int p = it * 64 + lane;
-    if (p < seglen) {
-      const uint32_t r0 = transition(T, w, s_bb, p, dl, w.D[p], w.X[p], 0);
-      const uint32_t dB = w.Db[p];
-      const uint32_t r1 = dB != 0 ? transition(T, w, s_bb, p, dl, dB, w.Xb[p], 1) : R_INVALID;
-      R[begin + p] = make_uint2(r0, r1);
+  // all row gathers of the segment are issued first (independent), then the scoring runs out of registers + LDS
+  uint32_t r0[SEG / 64], r1[SEG / 64];
+  {
+    Row row0[SEG / 64], row1[SEG / 64];
+    uint32_t d0[SEG / 64], d1[SEG / 64];
+#pragma unroll
+    for (int it = 0; it < SEG / 64; it++) {
+      const int p = it * 64 + lane;
+      d0[it] = w.D[p];
+      d1[it] = w.Db[p];
+      if (p < seglen && d0[it] != 0) row0[it] = T.rows[node_id(w.X[p])];
+      if (p < seglen && d1[it] != 0) row1[it] = T.rows[node_id(w.Xb[p])];
+    }
+#pragma unroll
+    for (int it = 0; it < SEG / 64; it++) {
+      const int p = it * 64 + lane;
+      r0[it] = R_INVALID; r1[it] = R_INVALID;
+      if (p < seglen) {
+        r0[it] = transition(T, w, s_bb, p, dl, d0[it], row0[it], 0);
+        if (d1[it] != 0) r1[it] = transition(T, w, s_bb, p, dl, d1[it], row1[it], 1);
+        R[begin + p] = make_uint2(r0[it], r1[it]);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+
+  // ---- step C: exit map of the segment by pointer doubling over all (p, fd) states -------------------
+  // J[s] summarises the path from state s to where it currently points: {target, #id events, #forward deletes,
+  // #missing}.  Composing J[s] with J[target] doubles the path; after <= log2(chain length) rounds every state
+  // points at a segment exit.  Only the 80 possible entry states (offset < 40, fd) are written out, but their
+  // chains run through arbitrary states, so all 2 x 512 states take part.  In-place updates are safe: an entry is
+  // read and written as one 8-byte LDS access and always describes a valid prefix of its state's chain.
+  {
+    uint2* J = reinterpret_cast<uint2*>(w.D);            // overlays D, Db, X, Xb (dead after step B): 1024 x 8 B
+    static_assert(sizeof(uint32_t) * (2 * NPOS_PAD + 2 * SEG) >= 2 * SEG * sizeof(uint2), "J overlay does not fit");
+    const bool more_text = rem > (uint64_t)SEG;           // not the last segment of the document
+    auto first_hop = [&](uint32_t r, int p) -> uint2 {
+      if (p >= seglen) return make_uint2(J_EXIT, 0u);     // at/after the end of text: terminal, nothing emitted
+      if (r == R_INVALID) return make_uint2(J_INVALID, 0u);
+      const int pn = p + (int)((r >> 24) & 63u);
+      const uint32_t fdn = (r >> 30) & 1u;
+      const uint32_t ev = (r & ID_NONE) != ID_NONE ? 1u : 0u;
+      const uint32_t tgt = pn >= seglen ? J_EXIT + (more_text ? (uint32_t)((pn - SEG) * 2) + fdn : 0u) : fdn * SEG + (uint32_t)pn;
+      return make_uint2(tgt | (ev << 12), fdn | ((r >> 31) << 16));
+    };
+#pragma unroll
+    for (int it = 0; it < SEG / 64; it++) {
+      const int p = it * 64 + lane;
+      J[p] = first_hop(r0[it], p);
+      J[SEG + p] = first_hop(r1[it], p);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    // entry state e = offset*2 + fd  <->  state index fd*SEG + offset
+    const int e0 = lane, e1 = 64 + lane;
+    const int se0 = (e0 & 1) * SEG + (e0 >> 1), se1 = (e1 & 1) * SEG + (e1 >> 1);
+    for (int round = 0; round < 12; round++) {
+#pragma unroll
+      for (int k = 0; k < 2 * SEG / 64; k++) {
+        const int sidx = k * 64 + lane;
+        uint2 a = J[sidx];
+        const uint32_t t = a.x & 0xFFFu;
+        if (t < J_EXIT) {
+          const uint2 bnext = J[t];
+          a.x = (bnext.x & 0xFFFu) | (((a.x >> 12) + (bnext.x >> 12)) << 12);
+          a.y = a.y + bnext.y;                            // two 16-bit counters, neither can overflow (<= 512 each)
+          J[sidx] = a;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0);
+      bool pending = (J[se0].x & 0xFFFu) < J_EXIT;
+      if (lane < ENT - 64) pending |= (J[se1].x & 0xFFFu) < J_EXIT;
+      if (!__any(pending)) break;
+    }
+    for (int e = lane; e < ENT; e += 64) {
+      const uint2 a = J[(e & 1) * SEG + (e >> 1)];
+      const uint32_t t = a.x & 0xFFFu;
+      uint2 o = make_uint2(R_INVALID, 0u);
+      if (t >= J_EXIT && t != J_INVALID) o = make_uint2((t - J_EXIT) | ((a.x >> 12) << 8), a.y);
+      exitmap[g * ENT + e] = o;
     }
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K2: link — exit map of every segment
-// ------------------------------------------------------------------------------------------------
-// exit map entry (uint2): x = next entry state [0..7] | #ids-events << 8 ; y = #forward-deletes | #missing << 16
+// exit map entry (uint2): x = next entry state [0..7] | #id events << 8 ; y = #forward-deletes | #missing << 16
 // (#tokens emitted = events + forward-deletes; Count() = events, quirk Q2).  x == 0xFFFFFFFF: entry unreachable.
-__global__ __launch_bounds__(256) void k_link(const uint2* __restrict__ R, const uint64_t* __restrict__ doc_begin,
-                                              const uint64_t* __restrict__ doc_end,
-                                              const uint32_t* __restrict__ seg_doc,
-                                              const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
-                                              uint2* __restrict__ exitmap) {
-  __shared__ uint32_t s_r[4][2][SEG];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
-  if (g >= nseg) return;
-  const uint32_t doc = seg_doc[g];
-  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
-  const uint64_t rem = doc_end[doc] - begin;
-  const int seglen = rem > SEG ? SEG : (int)rem;
-  for (int j = lane; j < seglen; j += 64) {
-    uint2 r = R[begin + j];
-    s_r[wv][0][j] = r.x;
-    s_r[wv][1][j] = r.y;
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  for (int e = lane; e < ENT; e += 64) {
-    int p = e >> 1, fd = e & 1;
-    uint32_t events = 0, nfd = 0, nmiss = 0;
-    uint32_t ox = R_INVALID, oy = 0;
-    if (p >= seglen) {
-      // only in a document's last segment: the chain entered exactly at (or is already past) the end of text
-      ox = 0; oy = 0;
-    } else {
-      bool ok = true;
-      for (int guard = 0; guard < 2 * SEG + 4; guard++) {
-        uint32_t r = s_r[wv][fd][p];
-        if (r == R_INVALID) { ok = false; break; }
-        events += (r & ID_NONE) != ID_NONE;
-        fd = (int)((r >> 30) & 1u);
-        nfd += (uint32_t)fd;
-        nmiss += r >> 31;
-        p += (int)((r >> 24) & 63u);
-        if (p >= seglen) break;
-      }
-      if (ok && p >= seglen) {
-        uint32_t ne = rem > SEG ? (uint32_t)((p - SEG) * 2 + fd) : 0u;
-        ox = ne | (events << 8);
-        oy = nfd | (nmiss << 16);
-      }
-    }
-    exitmap[g * ENT + e] = make_uint2(ox, oy);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // K3: resolve — per document, chain the exit maps
@@ -422,112 +549,122 @@ __global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: emit
+// K4: emit ids (or, HIST, accumulate the trainvocab histogram, training/trainvocab.go:1105-1174)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emit(const uint2* __restrict__ R, const uint64_t* __restrict__ doc_begin,
-                                              const uint64_t* __restrict__ doc_end,
-                                              const uint32_t* __restrict__ seg_doc,
-                                              const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
-                                              const uint8_t* __restrict__ seg_entry,
-                                              const uint32_t* __restrict__ seg_tokbase,
-                                              const uint64_t* __restrict__ tok_offsets, uint32_t delete_id,
-                                              uint64_t out_cap, uint32_t* __restrict__ out) {
-  __shared__ uint32_t s_r[4][2][SEG];
-  __shared__ uint32_t s_tok[4][2 * SEG + 8];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
-  if (g >= nseg) return;
-  const uint32_t doc = seg_doc[g];
-  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
-  const uint64_t rem = doc_end[doc] - begin;
-  const int seglen = rem > SEG ? SEG : (int)rem;
-  for (int j = lane; j < seglen; j += 64) {
-    uint2 r = R[begin + j];
-    s_r[wv][0][j] = r.x;
-    s_r[wv][1][j] = r.y;
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  int n = 0;
-  if (lane == 0) {
-    int e = seg_entry[g];
-    int p = e >> 1, fd = e & 1;
-    for (int guard = 0; guard < 2 * SEG + 4 && p < seglen; guard++) {
-      uint32_t r = s_r[wv][fd][p];
-      if (r == R_INVALID) break;
-      uint32_t id = r & ID_NONE;
-      if (id != ID_NONE) s_tok[wv][n++] = id;
-      fd = (int)((r >> 30) & 1u);
-      if (fd) s_tok[wv][n++] = delete_id;
-      p += (int)((r >> 24) & 63u);
-    }
-  }
-  n = __shfl(n, 0);
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  const uint64_t base = tok_offsets[doc] + seg_tokbase[g];
-  for (int j = lane; j < n; j += 64)
-    if (base + j < out_cap) out[base + j] = s_tok[wv][j];
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4': trainvocab accumulation (training/trainvocab.go:1105-1174) instead of emitting ids
-// ------------------------------------------------------------------------------------------------
+// The chain of a segment from its true entry state is ranked in parallel instead of being chased by one lane:
+// J_k[s] = state 2^k steps after s (+ ids emitted on the way).  Round k marks, for every already-marked state s,
+// the state J_k[s] with rank[s] + ids(s -> J_k[s]); then J is squared.  After ceil(log2(chain length)) rounds all
+// chain states carry their output offset and write their ids independently.
 // hist layout (all uint32, so that one RCCL all-reduce(sum) merges ranks): scores[n_ids] | tokens_in_text as
 // four 16-bit limbs | missing[256] (per-byte counters, > 0 = that byte had no token)
-__global__ __launch_bounds__(256) void k_hist(const uint2* __restrict__ R, const uint8_t* __restrict__ text,
-                                              const uint64_t* __restrict__ doc_begin,
-                                              const uint64_t* __restrict__ doc_end,
-                                              const uint32_t* __restrict__ seg_doc,
-                                              const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
-                                              const uint8_t* __restrict__ seg_entry, uint32_t delete_id,
-                                              uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
-                                              uint32_t* __restrict__ missing_bits) {
-  __shared__ uint32_t s_r[4][2][SEG];
-  __shared__ uint32_t s_tok[4][SEG + 8];
+template <bool HIST>
+__global__ __launch_bounds__(256) void k_chain(const uint2* __restrict__ R, const uint8_t* __restrict__ text,
+                                               const uint64_t* __restrict__ doc_begin,
+                                               const uint64_t* __restrict__ doc_end,
+                                               const uint32_t* __restrict__ seg_doc,
+                                               const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
+                                               const uint8_t* __restrict__ seg_entry,
+                                               const uint32_t* __restrict__ seg_tokbase,
+                                               const uint64_t* __restrict__ tok_offsets, uint32_t delete_id,
+                                               uint64_t out_cap, uint32_t* __restrict__ out,
+                                               uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
+                                               uint32_t* __restrict__ missing_bits) {
+  __shared__ uint32_t s_j[4][2 * SEG];      // target[0..11] | ids on the path << 12
+  __shared__ uint16_t s_rk[4][2 * SEG];     // output rank of a chain state, 0xFFFF = not on the chain
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
   if (g >= nseg) return;
+  uint32_t* J = s_j[wv];
+  uint16_t* RK = s_rk[wv];
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
   const uint64_t rem = doc_end[doc] - begin;
   const int seglen = rem > SEG ? SEG : (int)rem;
-  for (int j = lane; j < seglen; j += 64) {
-    uint2 r = R[begin + j];
-    s_r[wv][0][j] = r.x;
-    s_r[wv][1][j] = r.y;
+  constexpr int NS = 2 * SEG / 64;          // states per lane: k < NS/2 -> (p = k*64+lane, fd 0), else fd 1
+  uint32_t r[NS], jr[NS];
+#pragma unroll
+  for (int it = 0; it < SEG / 64; it++) {
+    const int p = it * 64 + lane;
+    uint2 v = make_uint2(R_INVALID, R_INVALID);
+    if (p < seglen) v = R[begin + p];
+    r[it] = v.x;
+    r[SEG / 64 + it] = v.y;
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  int n = 0;
-  if (lane == 0) {
-    int e = seg_entry[g];
-    int p = e >> 1, fd = e & 1;
-    uint32_t nfd = 0, ntok = 0;
-    for (int guard = 0; guard < 2 * SEG + 4 && p < seglen; guard++) {
-      uint32_t r = s_r[wv][fd][p];
-      if (r == R_INVALID) break;
-      const uint32_t adv = (r >> 24) & 63u;
-      if (r >> 31) {                                     // trainvocab.go:1166-1173: no token for this byte
-        uint32_t byte = text[begin + p];
-        atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
-      } else {
-        s_tok[wv][n++] = (r & ID_NONE) | (adv << 24);   // scores[id] += bytes covered (:1109..1162)
-      }
-      ntok++;                                            // tokensInText++ (also for a missing byte, :1169)
-      fd = (int)((r >> 30) & 1u);
-      nfd += (uint32_t)fd;
-      p += (int)adv;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int p = (k % (SEG / 64)) * 64 + lane;
+    uint32_t j = J_EXIT;                                  // p >= seglen or unreachable: absorbing, emits nothing
+    if (r[k] != R_INVALID) {
+      const int pn = p + (int)((r[k] >> 24) & 63u);
+      const uint32_t fdn = (r[k] >> 30) & 1u;
+      const uint32_t nt = ((r[k] & ID_NONE) != ID_NONE ? 1u : 0u) + fdn;
+      j = (pn >= seglen ? J_EXIT : fdn * SEG + (uint32_t)pn) | (nt << 12);
     }
-    if (nfd) atomicAdd(&scores[delete_id], nfd);         // scores[deleteToken]++ per forward delete (:1134,1143,1152)
-    if (ntok + nfd) atomicAdd(tokens, (unsigned long long)(ntok + nfd));
+    jr[k] = j;
+    J[k * 64 + lane] = j;
+    RK[k * 64 + lane] = 0xFFFFu;
   }
-  n = __shfl(n, 0);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-  for (int j = lane; j < n; j += 64) {
-    uint32_t t = s_tok[wv][j];
-    atomicAdd(&scores[t & ID_NONE], t >> 24);
+  const int e = seg_entry[g];
+  const int se = (e & 1) * SEG + (e >> 1);
+  if (lane == 0) RK[se] = 0;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  uint32_t rk[NS];
+  for (int round = 0; round < 12; round++) {
+    uint32_t bn[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      rk[k] = RK[k * 64 + lane];
+      const uint32_t t = jr[k] & 0xFFFu;
+      bn[k] = t < J_EXIT ? J[t] : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      const uint32_t t = jr[k] & 0xFFFu;
+      if (t < J_EXIT) {
+        if (rk[k] != 0xFFFFu) RK[t] = (uint16_t)(rk[k] + (jr[k] >> 12));
+        jr[k] = (bn[k] & 0xFFFu) | (((jr[k] >> 12) + (bn[k] >> 12)) << 12);
+        J[k * 64 + lane] = jr[k];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    if ((J[se] & 0xFFFu) >= J_EXIT) break;                 // wave-uniform (same address in every lane)
+  }
+  const uint64_t base = HIST ? 0 : tok_offsets[doc] + seg_tokbase[g];
+  uint32_t ntok = 0, ndel = 0;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const uint32_t rank = RK[k * 64 + lane];
+    if (rank != 0xFFFFu && r[k] != R_INVALID) {
+      const uint32_t id = r[k] & ID_NONE, fdn = (r[k] >> 30) & 1u;
+      if (!HIST) {
+        uint64_t o = base + rank;
+        if (id != ID_NONE) { if (o < out_cap) out[o] = id; o++; }
+        if (fdn && o < out_cap) out[o] = delete_id;
+      } else {
+        const int p = (k % (SEG / 64)) * 64 + lane;
+        if (r[k] >> 31) {                                  // trainvocab.go:1166-1173: no token for this byte
+          const uint32_t byte = text[begin + p];
+          atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
+        } else {
+          atomicAdd(&scores[id], (r[k] >> 24) & 63u);      // scores[id] += bytes covered (:1109..1162)
+        }
+        ntok += 1 + fdn;                                   // tokensInText++ (also for a missing byte, :1169) / += 2
+        ndel += fdn;                                       // scores[deleteToken]++ (:1134,1143,1152)
+      }
+    }
+  }
+  if (HIST) {
+    for (int o = 32; o > 0; o >>= 1) { ntok += __shfl_xor(ntok, o); ndel += __shfl_xor(ndel, o); }
+    if (lane == 0) {
+      if (ndel) atomicAdd(&scores[delete_id], ndel);
+      if (ntok) atomicAdd(tokens, (unsigned long long)ntok);
+    }
   }
 }
 
@@ -594,7 +731,7 @@ struct tm_batch {
 
 namespace {
 
-const char* kKernelNames[TM_NUM_KERNELS] = {"segments", "match_branch", "link", "resolve", "scan", "emit"};
+const char* kKernelNames[TM_NUM_KERNELS] = {"segments", "match_branch", "resolve", "scan", "emit"};
 
 template <typename T>
 hipError_t dalloc(tm_batch* b, T** p, uint64_t count) {
@@ -632,22 +769,20 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   mark(1);
   if (nseg > 0)
     k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
-                                                                                b->d_doc_seg_start, nseg, b->d_R);
+                                                                                b->d_doc_seg_start, nseg, b->d_R, b->d_exitmap, getenv("TM_DBG") ? atoi(getenv("TM_DBG")) : 0);
   mark(2);
-  if (nseg > 0)
-    k_link<<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_exitmap);
-  mark(3);
   if (nd > 0)
     k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_seg_entry, b->d_seg_tokbase,
                                                 b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_error);
-  mark(4);
+  mark(3);
   if (nd > 0) scan_u32(b->d_doc_ntok, nd, b->d_scan_tmp, b->d_totals + 1, b->d_tok_offsets, st);
   else (void)hipMemsetAsync(b->d_tok_offsets, 0, 8, st);
-  mark(5);
+  mark(4);
   if (emit && nseg > 0)
-    k_emit<<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry,
-                                                       b->d_seg_tokbase, b->d_tok_offsets, v->tables.delete_id, b->out_cap, b->d_out);
-  mark(6);
+    k_chain<false><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+                                                               nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, v->tables.delete_id,
+                                                               b->out_cap, b->d_out, nullptr, nullptr, nullptr);
+  mark(5);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
   if (timed) {
     if ((e = hipEventSynchronize(b->ev[TM_NUM_KERNELS])) != hipSuccess) return hip_fail(e, "hipEventSynchronize");
@@ -673,9 +808,9 @@ int ensure_output(tm_batch* b) {
     b->out_cap = total + 1024;
     if ((e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc output");
     hipStream_t st = b->last_stream;
-    k_emit<<<(uint32_t)((b->nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, b->nseg,
-                                                          b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
-                                                          b->vocab->tables.delete_id, b->out_cap, b->d_out);
+    k_chain<false><<<(uint32_t)((b->nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+                                                                  b->nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
+                                                                  b->vocab->tables.delete_id, b->out_cap, b->d_out, nullptr, nullptr, nullptr);
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "emit rerun");
   }
   return TM_OK;
@@ -930,9 +1065,10 @@ static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off
   int rc = run_pipeline(b, st, false, nullptr, false);
   if (rc != TM_OK) return rc;
   if (nseg > 0)
-    k_hist<<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
-                                                       nseg, b->d_seg_entry, v->tables.has_delete ? v->tables.delete_id : 0,
-                                                       d->d_hist, d->d_tokens, d->d_missing_bits);
+    k_chain<true><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+                                                              nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
+                                                              v->tables.has_delete ? v->tables.delete_id : 0, 0, nullptr, d->d_hist, d->d_tokens,
+                                                              d->d_missing_bits);
   k_hist_finish<<<1, 256, 0, st>>>(d->d_tokens, d->d_missing_bits, d->d_hist + v->host.n_ids);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
   return TM_OK;

@@ -6,8 +6,9 @@
 // (index, length, found) with index = record ordinal in the .vocab file.
 // Here it is a byte trie whose accepting nodes ARE the record ordinals:
 //   depth 1   root[256]            (staged in LDS by every workgroup)
-//   depth 2   l2[65536]            direct map on the first two bytes (256 KiB, L2-resident)
-//   depth >=3 edges[]              open-addressing hash of (parent node, byte) -> child, 8 B per slot
+//   depth 2   tab[0..65535]        direct map on the first two bytes (512 KiB, L2-resident)
+//   depth >=3 tab[65536..]         open-addressing hash of (parent node, byte) -> child, 8 B per slot
+//             (one table, one 8-byte load per probe whatever the depth: every walk step is the same instruction)
 // A 32-bit node value carries everything a look-ahead needs about the token it accepts, so scoring a
 // branch never touches the row table:
 //   bits  0..20  node id; id < n_info  <=>  the prefix is a vocabulary key and id is its record ordinal
@@ -26,6 +27,7 @@ constexpr uint32_t kNodeBits = 21;
 constexpr uint32_t kNodeMask = (1u << kNodeBits) - 1;
 constexpr uint32_t kHasChildren = 1u << 21;
 constexpr uint32_t kMaxNodes = kNodeMask - 1;
+constexpr uint32_t kL2Size = 65536;
 
 __host__ __device__ inline uint32_t node_id(uint32_t v) { return v & kNodeMask; }
 __host__ __device__ inline uint32_t node_nwords(uint32_t v) { return (v >> 22) & 31u; }
@@ -45,8 +47,12 @@ struct alignas(16) Row { uint32_t x, y, z, w; };
 
 struct Tables {
   const uint32_t* root;    // [256]
-  const uint32_t* l2;      // [65536]
-  const uint2* edges;      // [edge_mask+1]  x = parent<<8|byte (kNone = empty), y = node value
+  const uint2* tab;        // one probe table, 8 B per slot, y = node value:
+                           //   [0, 65536)            direct map on the first two bytes b0<<8|b1: the whole answer for depth <= 2:
+                           //                         y = value of the longest accepting node among {b0, b0b1} (if any)
+                           //                         x = its length (0,1,2) | cont << 2 | depth-2 node id << 3, cont = the node
+                           //                         b0b1 exists and has children (the walk goes on in the hash)
+                           //   [65536, 65536+mask+1) depth>=3 hash, x = parent<<8|byte (kNone = empty slot)
   const Row* rows;         // [n_info]
   const uint8_t* begin_byte;  // [256]  go/tokenmonster.go:43
   uint32_t edge_mask, edge_shift;

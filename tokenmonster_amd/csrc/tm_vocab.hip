@@ -130,30 +130,52 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     return v;
   };
   hv.root.assign(256, kNone);
-  hv.l2.assign(65536, kNone);
   size_t n_edges = 0;
   for (auto& kv : child) if (depth_of[kv.second] >= 3) n_edges++;
   uint32_t bits = 4;
   while ((1ull << bits) < n_edges * 5 / 2 + 8) bits++;
   hv.edge_mask = (1u << bits) - 1;
   hv.edge_shift = 32 - bits;
-  hv.edges.assign((size_t)1 << bits, uint2{kNone, kNone});
+  hv.tab.assign((size_t)kL2Size + ((size_t)1 << bits), uint2{kNone, kNone});
+  uint2* l2 = hv.tab.data();
+  uint2* edges = hv.tab.data() + kL2Size;
   std::vector<uint32_t> first_byte(n_nodes, 0);   // for depth-1 nodes: their byte, to index l2
   for (auto& kv : child) if (depth_of[kv.second] == 1) { hv.root[kv.first & 0xFF] = value_of(kv.second); first_byte[kv.second] = (uint32_t)(kv.first & 0xFF); }
   for (auto& kv : child) {
     uint32_t d = depth_of[kv.second], parent = (uint32_t)(kv.first >> 8), byte = (uint32_t)(kv.first & 0xFF);
-    if (d == 2) hv.l2[(first_byte[parent] << 8) | byte] = value_of(kv.second);
+    if (d == 2) l2[(first_byte[parent] << 8) | byte] = uint2{0u, value_of(kv.second)};   // rewritten below
     else if (d >= 3) {
       uint32_t key = (parent << 8) | byte;
       uint32_t h = (key * 0x9E3779B1u) >> hv.edge_shift;
-      while (hv.edges[h].x != kNone) h = (h + 1) & hv.edge_mask;
-      hv.edges[h] = uint2{key, value_of(kv.second)};
+      while (edges[h].x != kNone) h = (h + 1) & hv.edge_mask;
+      edges[h] = uint2{key, value_of(kv.second)};
+    }
+  }
+  // direct map: fold the depth-1 answer in, so one 8-byte load resolves the first two bytes of any walk
+  for (uint32_t b0 = 0; b0 < 256; b0++) {
+    const uint32_t r = hv.root[b0];
+    for (uint32_t b1 = 0; b1 < 256; b1++) {
+      uint2& e = l2[(b0 << 8) | b1];
+      uint32_t bestlen = 0, bestv = 0, cont = 0, id2 = 0;
+      if (r != kNone) {
+        if (node_id(r) < n_info) { bestlen = 1; bestv = r; }
+        if (e.x != kNone) {                       // node b0b1 exists
+          const uint32_t v2 = e.y;
+          if (node_id(v2) < n_info) { bestlen = 2; bestv = v2; }
+          if (v2 & kHasChildren) { cont = 1; id2 = node_id(v2); }
+        }
+      }
+      e = uint2{bestlen | (cont << 2) | (id2 << 3), bestv};
     }
   }
   hv.n_nodes = n_nodes;
   hv.off = hv.charset == 2 ? 2 : 1;
   hv.bstart = hv.root[' '];
-  if (hv.off == 2 && hv.bstart != kNone) hv.bstart = (hv.bstart & kHasChildren) ? hv.l2[(' ' << 8) | 0] : kNone;
+  if (hv.off == 2 && hv.bstart != kNone) {
+    // UTF-16: the virtual prefix is ' ' 0x00 (lilbufOffset 2, go :1031-1034): start from that depth-2 node
+    const uint2 e = l2[(' ' << 8) | 0];
+    hv.bstart = (e.x & 4u) ? ((e.x >> 3) | kHasChildren) : kNone;
+  }
   return TM_OK;
 }
 
@@ -195,15 +217,14 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
     return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
   };
   if ((e = up((void**)&v->d_root, hv.root.data(), 256 * 4)) != hipSuccess ||
-      (e = up((void**)&v->d_l2, hv.l2.data(), 65536 * 4)) != hipSuccess ||
-      (e = up((void**)&v->d_edges, hv.edges.data(), hv.edges.size() * sizeof(uint2))) != hipSuccess ||
+      (e = up((void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2))) != hipSuccess ||
       (e = up((void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row))) != hipSuccess ||
       (e = up((void**)&v->d_begin_byte, hv.begin_byte, 256)) != hipSuccess) {
     tm_vocab_free(v);
     return hip_fail(e, "vocabulary upload");
   }
   Tables& t = v->tables;
-  t.root = v->d_root; t.l2 = v->d_l2; t.edges = v->d_edges; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
+  t.root = v->d_root; t.tab = v->d_tab; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
   t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
   t.off = hv.off; t.bstart = hv.bstart;
   t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
@@ -213,7 +234,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
 
 void tm_vocab_free(tm_vocab* v) {
   if (!v) return;
-  (void)hipFree(v->d_root); (void)hipFree(v->d_l2); (void)hipFree(v->d_edges); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
+  (void)hipFree(v->d_root); (void)hipFree(v->d_tab); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
   delete v;
 }
 
