@@ -44,8 +44,9 @@ def test_fuzz_micro_vocab(capcode, seed):
     orc = Oracle(img)
     oracle_stats(reset=True)
     docs = [fuzz_text(rng, capcode, int(n)) for n in rng.integers(0, 3000, size=120)]
-    docs += [b"", b"a", b" ", fuzz_text(rng, capcode, 511), fuzz_text(rng, capcode, 512), fuzz_text(rng, capcode, 513),
-             fuzz_text(rng, capcode, 1024), fuzz_text(rng, capcode, 1025), fuzz_text(rng, capcode, 70000)]
+    # empty / tiny documents, lengths around multiples of the segment size (whatever it is), one long document
+    docs += [b"", b"a", b" "] + [fuzz_text(rng, capcode, n) for n in (255, 256, 257, 319, 320, 321, 383, 384, 385, 511, 512, 513, 639, 640, 641,
+                                                                      1024, 1025, 70000)]
     check_docs(v, orc, docs, "fuzz capcode=%d seed=%d" % (capcode, seed))
     st = oracle_stats()
     # the fuzz must actually have exercised the alternatives; with capcode 2 also the forward-delete branches

@@ -28,13 +28,12 @@
 
 namespace tmh {
 
-constexpr int SEG = 512;                 // bytes of one document segment (one wavefront)
+constexpr int SEG = 320;                 // bytes of one document segment (one wavefront); 320 -> 24 wavefronts per CU
 constexpr int NPOS = SEG + 40;           // positions whose descriptors a segment needs (look-ahead <= 40)
-constexpr int NPOS_PAD = 576;            // 9 x 64
+constexpr int NPOS_PAD = (NPOS + 63) / 64 * 64;
 constexpr int TEXT_LEN = SEG + 96;       // staged text: position i may read up to i + 40
 constexpr int ENT = 80;                  // entry states of a segment: 40 offsets x fd{0,1}
-constexpr int WAVES = 4;                 // wavefronts per workgroup in K1
-constexpr int REFILL_THR = 40;           // K1 refills idle lanes when fewer than this many are still walking
+constexpr int WAVES = 4;                 // wavefronts per workgroup in K1 (plain variant)
 constexpr uint32_t R_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t J_EXIT = 1024;           // jump targets >= J_EXIT: left the segment; J_EXIT + next entry state
 constexpr uint32_t J_INVALID = 4095;        // state is not reachable (no forward-delete match there)
@@ -144,6 +143,35 @@ __device__ __forceinline__ uint32_t make_desc(uint32_t len, uint32_t v, uint32_t
   return len | ((v >> 22) << 6) | (nb << 16);
 }
 
+// one in-flight trie walk of a lane: text byte number d of the string being matched is text[tbase + d]
+struct Walk { int pos, tbase, depth, limit, bestlen; uint32_t haddr, key, bestv, h32; bool active; };
+
+// consume one hash probe: follow the edge, remember the deepest accepting node, arm the next probe or stop
+// (pansearch LongestSubstring semantics, tokenmonster.cpp:786-877: longest prefix that is a key).
+// Written without branches: every lane executes the same ~25 instructions, idle lanes probe slot 0 and ignore it,
+// so the NWALK loads of a round are issued back to back and the round has a single wait.
+// Returns true when the walk finished in this round.
+__device__ __forceinline__ bool walk_consume(const Tables& T, const uint8_t* text, Walk& k, const uint2 e) {
+  const bool was = k.active;
+  const bool hit = was && e.x == k.key;
+  const bool again = was && !hit && e.x != kNone;                 // occupied by another key: linear probing
+  const uint32_t cur = e.y;
+  k.depth += hit ? 1 : 0;
+  const bool acc = hit && node_id(cur) < T.n_info;
+  k.bestv = acc ? cur : k.bestv;
+  k.bestlen = acc ? k.depth : k.bestlen;
+  const bool cont = hit && k.depth < k.limit && (cur & kHasChildren) != 0;
+  const uint32_t c = text[k.tbase + k.depth];                     // always inside the staged text
+  const uint32_t nkey = (node_id(cur) << 8) | c;
+  k.key = cont ? nkey : k.key;
+  const uint32_t nh32 = nkey * 0x9E3779B1u;
+  const uint32_t lin = (k.haddr + 1) & T.edge_mask;
+  k.h32 = cont ? nh32 : k.h32;
+  k.haddr = cont ? (nh32 >> T.edge_shift) : (again ? lin : 0u);
+  k.active = cont || again;
+  return was && !k.active;
+}
+
 struct First { int flen; int nw; uint32_t f3; };   // candidate first token: length consumed, nWords - fd, flag bits {1, 8>>3, 128>>7}
 
 // score of one branch, go/tokenmonster.go:1075-1084 (a), :1096-1105 (b); k > 0 adds :1132-1133
@@ -217,38 +245,43 @@ __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w
   return id | ((uint32_t)len << 24);                                                           // go :1265-1267
 }
 
-__global__ __launch_bounds__(WAVES * 64) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
-                                                             const uint64_t* __restrict__ doc_begin,
-                                                             const uint64_t* __restrict__ doc_end,
-                                                             const uint32_t* __restrict__ seg_doc,
-                                                             const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
-                                                             uint2* __restrict__ R, uint2* __restrict__ exitmap, int dbg) {
+constexpr int NWALK = 2;                 // independent trie walks in flight per lane
+constexpr int REFILL_THR = 32;           // K1 refills idle lanes when fewer than this many (per walk slot) are still walking
+
+__global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
+                                                                const uint64_t* __restrict__ doc_begin,
+                                                                const uint64_t* __restrict__ doc_end,
+                                                                const uint32_t* __restrict__ seg_doc,
+                                                                const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
+                                                                uint2* __restrict__ R, uint2* __restrict__ exitmap, int dbg) {
   __shared__ uint32_t s_root[256];
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
   s_root[threadIdx.x] = T.root[threadIdx.x];
   s_bb[threadIdx.x] = T.begin_byte[threadIdx.x];
   __syncthreads();
-  const uint64_t g = (uint64_t)blockIdx.x * WAVES + wv;
+  const uint64_t g = (uint64_t)blockIdx.x * WAVES + wvi;
   if (g >= nseg) return;
-  WaveLds& w = s_wave[wv];
+  WaveLds& w = s_wave[wvi];
+  const int Lmax = (int)T.max_len;
+  const unsigned long long lane_below = (1ull << lane) - 1ull;
+  const uint2* __restrict__ hash_tab = T.tab + kL2Size;
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
   const uint64_t rem = doc_end[doc] - begin;
   const int dl = rem > (uint64_t)(1 << 20) ? (1 << 20) : (int)rem;   // bytes of the document from `begin` on (clamped)
   const int seglen = min(dl, SEG);
-  const int Lmax = (int)T.max_len;
 
   // stage the text with (unaligned) dword loads; bytes at and after the end of the document read as 0: the pad
   // byte of go/tokenmonster.go:1038-1046 (quirk Q1: we define it as 0 like tokenmonster.cpp:1724-1726)
   for (int j = lane; j < TEXT_LEN / 4; j += 64) {
-    uint32_t wv = 0;
+    uint32_t tw = 0;
     if (4 * j < dl) {
-      __builtin_memcpy(&wv, text + begin + 4 * j, 4);       // the text buffer has >= 256 bytes of slack
-      if (4 * j + 4 > dl) wv &= (1u << (8 * (dl - 4 * j))) - 1u;
+      __builtin_memcpy(&tw, text + begin + 4 * j, 4);       // the text buffer has >= 256 bytes of slack
+      if (4 * j + 4 > dl) tw &= (1u << (8 * (dl - 4 * j))) - 1u;
     }
-    reinterpret_cast<uint32_t*>(w.text)[j] = wv;
+    reinterpret_cast<uint32_t*>(w.text)[j] = tw;
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
@@ -261,64 +294,63 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_branch(Tables T, const uin
   // idles behind the longest walk of a block.  (pansearch LongestSubstring, call sites go/tokenmonster.go:1049..)
   for (int j = lane; j < NPOS_PAD; j += 64) { w.D[j] = 0; w.Db[j] = 0; }
   __builtin_amdgcn_wave_barrier();
-  const unsigned long long lane_below = (1ull << lane) - 1ull;
-  const uint2* __restrict__ hash_tab = T.tab + kL2Size;
   const int ntask = (dbg & 1) ? 0 : min(NPOS, dl);     // positions >= dl keep descriptor 0 (nothing there)
   {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
+    // The probe loop is latency bound (K1 time scales ~1/occupancy), so every lane keeps NWALK independent walks in
+    // flight: NWALK probes are issued back to back before any result is consumed.
     int next_task = 0;                        // wave-uniform
-    int pos = 0, depth = 0, limit = 0, bestlen = 0;
-    uint32_t cur = 0, haddr = 0, key = 0, bestv = 0;
-    bool active = false;
+    Walk k[NWALK];
+#pragma unroll
+    for (int s = 0; s < NWALK; s++) k[s] = Walk{0, 0, 0, 0, 0, 0u, 0u, 0u, 0u, false};
     for (;;) {
-      // refill: idle lanes take the next positions; the direct map answers the first two bytes
+      // refill: idle slots take the next positions; the direct map answers the first two bytes
       for (int rep = 0; rep < 2 && next_task < ntask; rep++) {
-        const unsigned long long wmask = __ballot(!active);
-        if (wmask == 0) break;
-        const int p = next_task + __popcll(wmask & lane_below);
-        next_task += __popcll(wmask);
-        if (!active && p < ntask) {
-          limit = min(dl - p, Lmax);
-          uint2 e;
-          if (limit >= 2) e = T.tab[((uint32_t)w.text[p] << 8) | w.text[p + 1]];
-          else { const uint32_t r = s_root[w.text[p]]; e = make_uint2((r != kNone && node_id(r) < T.n_info) ? 1u : 0u, r); }
-          bestlen = (int)(e.x & 3u);
-          bestv = e.y;
-          if ((e.x & 4u) && limit > 2) {
-            pos = p; depth = 2; active = true;
-            cur = (e.x >> 3) | kHasChildren;
-            key = ((e.x >> 3) << 8) | w.text[p + 2];
-            haddr = (key * 0x9E3779B1u) >> T.edge_shift;
-          } else if (bestlen != 0) {
-            w.D[p] = (uint32_t)bestlen | ((bestv >> 22) << 6);
-            if (p < SEG) w.X[p] = bestv;
+#pragma unroll
+        for (int s = 0; s < NWALK; s++) {
+          if (next_task >= ntask) break;
+          const unsigned long long wmask = __ballot(!k[s].active);
+          if (wmask == 0) continue;
+          const int p = next_task + __popcll(wmask & lane_below);
+          next_task += __popcll(wmask);
+          if (!k[s].active && p < ntask) {
+            const int limit = min(dl - p, Lmax);
+            uint2 e;
+            if (limit >= 2) e = T.tab[((uint32_t)w.text[p] << 8) | w.text[p + 1]];
+            else { const uint32_t r = s_root[w.text[p]]; e = make_uint2((r != kNone && node_id(r) < T.n_info) ? 1u : 0u, r); }
+            const int bestlen = (int)(e.x & 3u);
+            if ((e.x & 4u) && limit > 2 && !(dbg & 4)) {
+              k[s].pos = p; k[s].tbase = p; k[s].depth = 2; k[s].limit = limit; k[s].active = true;
+              k[s].bestlen = bestlen; k[s].bestv = e.y;
+              k[s].key = ((e.x >> 3) << 8) | w.text[p + 2];
+              k[s].h32 = k[s].key * 0x9E3779B1u;
+              k[s].haddr = k[s].h32 >> T.edge_shift;
+            } else if (bestlen != 0) {
+              w.D[p] = (uint32_t)bestlen | ((e.y >> 22) << 6);
+              if (p < SEG) w.X[p] = e.y;
+            }
           }
         }
       }
-      int nactive = __popcll(__ballot(active));
+      int nactive = 0;
+#pragma unroll
+      for (int s = 0; s < NWALK; s++) nactive += __popcll(__ballot(k[s].active));
       if (nactive == 0) { if (next_task >= ntask) break; continue; }
       // tight probe loop
-      const int thr = next_task < ntask ? REFILL_THR : 1;
+      const int thr = next_task < ntask ? NWALK * REFILL_THR : 1;
       do {
-        if (active) {
-          const uint2 e = hash_tab[haddr];
-          if (e.x == key) {
-            cur = e.y;
-            depth++;
-            if (node_id(cur) < T.n_info) { bestv = cur; bestlen = depth; }
-            if (depth < limit && (cur & kHasChildren)) {
-              key = (node_id(cur) << 8) | w.text[pos + depth];
-              haddr = (key * 0x9E3779B1u) >> T.edge_shift;
-            } else active = false;
-          } else if (e.x != kNone) {
-            haddr = (haddr + 1) & T.edge_mask;        // linear probing
-          } else active = false;
-          if (!active && bestlen != 0) {
-            w.D[pos] = (uint32_t)bestlen | ((bestv >> 22) << 6);
-            if (pos < SEG) w.X[pos] = bestv;
+        uint2 e[NWALK];
+#pragma unroll
+        for (int s = 0; s < NWALK; s++) e[s] = hash_tab[k[s].haddr];
+        nactive = 0;
+#pragma unroll
+        for (int s = 0; s < NWALK; s++) {
+          if (walk_consume(T, w.text, k[s], e[s]) && k[s].bestlen != 0) {
+            w.D[k[s].pos] = (uint32_t)k[s].bestlen | ((k[s].bestv >> 22) << 6);
+            if (k[s].pos < SEG) w.X[k[s].pos] = k[s].bestv;
           }
+          nactive += __popcll(__ballot(k[s].active));
         }
-        nactive = __popcll(__ballot(active));
       } while (nactive >= thr);
     }
   }
@@ -329,7 +361,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_branch(Tables T, const uin
   unsigned long long elig[NPOS_PAD / 64];
   {
     const int off = (int)T.off;
-    const bool can_b = T.has_delete && T.bstart != kNone && (T.bstart & kHasChildren);
+    const bool can_b = T.has_delete && T.bstart != kNone && (T.bstart & kHasChildren) && !(dbg & 8);
 #pragma unroll
     for (int it = 0; it < NPOS_PAD / 64; it++) {
       const int p = it * 64 + lane;
@@ -349,82 +381,78 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_branch(Tables T, const uin
     const int off = (int)T.off;
     int blk = 0;                              // wave-uniform: block of 64 positions tasks are taken from
     unsigned long long avail = elig[0];
-    int pos = 0, depth = 0, limit = 0, bestlen = 0, mainlen = 0;
-    uint32_t cur = 0, haddr = 0, key = 0, bestv = 0;
-    bool active = false;
-    auto store_b = [&]() {
-      if (bestlen > mainlen + 1) {
-        const int lb = bestlen - off;                                      // go :1093
-        w.Db[pos] = make_desc((uint32_t)lb, bestv, s_bb[w.text[pos + lb]]);
-        if (pos < SEG) w.Xb[pos] = bestv;
-      }
-    };
+    Walk k[NWALK];
+    int mainlen[NWALK];
+#pragma unroll
+    for (int s = 0; s < NWALK; s++) { k[s] = Walk{0, 0, 0, 0, 0, 0u, 0u, 0u, 0u, false}; mainlen[s] = 0; }
     for (;;) {
       // refill from the eligibility masks
       for (int rep = 0; rep < 2; rep++) {
-        while (avail == 0 && blk + 1 < NPOS_PAD / 64) { blk++; avail = 0;
 #pragma unroll
-          for (int k = 0; k < NPOS_PAD / 64; k++) if (k == blk) avail = elig[k];
-        }
-        if (avail == 0) break;
-        const unsigned long long wmask = __ballot(!active);
-        if (wmask == 0) break;
-        // the r-th idle lane takes the r-th available position of the block: exchange through the text tail of LDS
-        const int navail = __popcll(avail), nwant = __popcll(wmask);
-        const int n = min(navail, nwant);
-        const int prank = __popcll(avail & lane_below);                    // rank of MY position bit, if set
-        if (((avail >> lane) & 1ull) && prank < n) w.xchg[prank] = (uint8_t)lane;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0);
-        const int wrank = __popcll(wmask & lane_below);
-        const bool take = !active && wrank < n;
-        int p = 0;
-        if (take) p = blk * 64 + w.xchg[wrank];
-        // clear the n lowest available bits
-        avail = __ballot(((avail >> lane) & 1ull) && prank >= n);
-        __builtin_amdgcn_wave_barrier();
-        if (take) {
-          pos = p; bestlen = 0; bestv = 0;
-          mainlen = (int)(w.D[p] & 63u);
-          limit = min(dl - p, Lmax - off) + off;
-          if (off == 1) {
-            const uint2 e = T.tab[((uint32_t)' ' << 8) | w.text[p]];
-            if ((e.x & 4u) && limit > 2) {
-              depth = 2; active = true;
-              key = ((e.x >> 3) << 8) | w.text[p + 1];
-              haddr = (key * 0x9E3779B1u) >> T.edge_shift;
+        for (int s = 0; s < NWALK; s++) {
+          while (avail == 0 && blk + 1 < NPOS_PAD / 64) {
+            blk++;
+#pragma unroll
+            for (int q = 0; q < NPOS_PAD / 64; q++) if (q == blk) avail = elig[q];
+          }
+          if (avail == 0) break;
+          const unsigned long long wmask = __ballot(!k[s].active);
+          if (wmask == 0) continue;
+          // the r-th idle lane takes the r-th available position of the block: exchanged through LDS
+          const int n = min(__popcll(avail), __popcll(wmask));
+          const int prank = __popcll(avail & lane_below);                  // rank of MY position bit, if set
+          if (((avail >> lane) & 1ull) && prank < n) w.xchg[prank] = (uint8_t)lane;
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_s_waitcnt(0);
+          const int wrank = __popcll(wmask & lane_below);
+          const bool take = !k[s].active && wrank < n;
+          int p = 0;
+          if (take) p = blk * 64 + w.xchg[wrank];
+          avail = __ballot(((avail >> lane) & 1ull) && prank >= n);       // the n lowest positions are handed out
+          __builtin_amdgcn_wave_barrier();
+          if (take) {
+            k[s].pos = p; k[s].tbase = p - off; k[s].bestlen = 0; k[s].bestv = 0; k[s].depth = 2;
+            mainlen[s] = (int)(w.D[p] & 63u);
+            k[s].limit = min(dl - p, Lmax - off) + off;
+            if (off == 1) {
+              const uint2 e = T.tab[((uint32_t)' ' << 8) | w.text[p]];
+              if ((e.x & 4u) && k[s].limit > 2) {
+                k[s].active = true;
+                k[s].key = ((e.x >> 3) << 8) | w.text[p + 1];
+                k[s].h32 = k[s].key * 0x9E3779B1u;
+                k[s].haddr = k[s].h32 >> T.edge_shift;
+              }
+            } else {
+              k[s].active = true;
+              k[s].key = (node_id(T.bstart) << 8) | w.text[p];
+              k[s].h32 = k[s].key * 0x9E3779B1u;
+              k[s].haddr = k[s].h32 >> T.edge_shift;
             }
-          } else {
-            depth = 2; active = true;
-            key = (node_id(T.bstart) << 8) | w.text[p];
-            haddr = (key * 0x9E3779B1u) >> T.edge_shift;
           }
         }
       }
-      int nactive = __popcll(__ballot(active));
+      int nactive = 0;
+#pragma unroll
+      for (int s = 0; s < NWALK; s++) nactive += __popcll(__ballot(k[s].active));
       bool more = avail != 0;
 #pragma unroll
-      for (int k = 0; k < NPOS_PAD / 64; k++) more |= (k > blk && elig[k] != 0);
+      for (int q = 0; q < NPOS_PAD / 64; q++) more |= (q > blk && elig[q] != 0);
       if (nactive == 0) { if (!more) break; continue; }
-      const int thr = more ? REFILL_THR : 1;
-      const int tbase = pos - off;            // text[tbase + depth] is byte number `depth` of ' '+text[pos:]
+      const int thr = more ? NWALK * REFILL_THR : 1;
       do {
-        if (active) {
-          const uint2 e = hash_tab[haddr];
-          if (e.x == key) {
-            cur = e.y;
-            depth++;
-            if (node_id(cur) < T.n_info) { bestv = cur; bestlen = depth; }
-            if (depth < limit && (cur & kHasChildren)) {
-              key = (node_id(cur) << 8) | w.text[tbase + depth];
-              haddr = (key * 0x9E3779B1u) >> T.edge_shift;
-            } else active = false;
-          } else if (e.x != kNone) {
-            haddr = (haddr + 1) & T.edge_mask;
-          } else active = false;
-          if (!active) store_b();
+        uint2 e[NWALK];
+#pragma unroll
+        for (int s = 0; s < NWALK; s++) e[s] = hash_tab[k[s].haddr];
+        nactive = 0;
+#pragma unroll
+        for (int s = 0; s < NWALK; s++) {
+          if (walk_consume(T, w.text, k[s], e[s]) && k[s].bestlen > mainlen[s] + 1) {
+            const int lb = k[s].bestlen - off;                              // go :1093
+            w.Db[k[s].pos] = make_desc((uint32_t)lb, k[s].bestv, s_bb[w.text[k[s].pos + lb]]);
+            if (k[s].pos < SEG) w.Xb[k[s].pos] = k[s].bestv;
+          }
+          nactive += __popcll(__ballot(k[s].active));
         }
-        nactive = __popcll(__ballot(active));
       } while (nactive >= thr);
     }
   }
@@ -769,7 +797,8 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   mark(1);
   if (nseg > 0)
     k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
-                                                                                b->d_doc_seg_start, nseg, b->d_R, b->d_exitmap, getenv("TM_DBG") ? atoi(getenv("TM_DBG")) : 0);
+                                                                                b->d_doc_seg_start, nseg, b->d_R, b->d_exitmap,
+                                                                                getenv("TM_DBG") ? atoi(getenv("TM_DBG")) : 0);
   mark(2);
   if (nd > 0)
     k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_seg_entry, b->d_seg_tokbase,
