@@ -47,6 +47,8 @@ def test_fuzz_micro_vocab(capcode, seed):
     # empty / tiny documents, lengths around multiples of the segment size (whatever it is), one long document
     docs += [b"", b"a", b" "] + [fuzz_text(rng, capcode, n) for n in (255, 256, 257, 319, 320, 321, 383, 384, 385, 511, 512, 513, 639, 640, 641,
                                                                       1024, 1025, 70000)]
+    if seed == 1:
+        docs.append(fuzz_text(rng, capcode, 400_000))     # > LONG_SEGS segments: hierarchical resolve path
     check_docs(v, orc, docs, "fuzz capcode=%d seed=%d" % (capcode, seed))
     st = oracle_stats()
     # the fuzz must actually have exercised the alternatives; with capcode 2 also the forward-delete branches

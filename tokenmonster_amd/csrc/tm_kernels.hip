@@ -39,6 +39,7 @@ constexpr uint32_t J_EXIT = 1024;           // jump targets >= J_EXIT: left the 
 constexpr uint32_t J_INVALID = 4095;        // state is not reachable (no forward-delete match there)
 constexpr uint32_t ID_NONE = 0xFFFFFFu;
 constexpr int NOSCORE = -1000000;
+constexpr uint32_t LONG_SEGS = 512;        // documents with more segments than this are resolved hierarchically
 
 // R word: id[0..23] | advance[24..29] | fd'[30] | missing[31]
 
@@ -559,6 +560,7 @@ __global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __r
   uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ndocs) return;
   uint64_t g0 = doc_seg_start[d], g1 = doc_seg_start[d + 1];
+  if (g1 - g0 > LONG_SEGS) return;               // long documents: k_group_compose / k_long_top / k_group_expand
   uint32_t e = 0, ntok = 0, events = 0, nmiss = 0;
   for (uint64_t g = g0; g < g1; g++) {
     seg_entry[g] = (uint8_t)e;
@@ -574,6 +576,76 @@ __global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __r
   doc_ntok[d] = ntok;
   doc_events[d] = events;
   doc_missing[d] = nmiss;
+}
+
+// Long documents (more than LONG_SEGS segments: a multi-megabyte document, or a strip of the trainvocab dataset)
+// would make k_resolve a serial chain of millions of dependent loads.  Their segments are cut into ~sqrt(S)
+// groups (table built on the host at upload): k_group_compose composes the exit maps of a group for all 80 entry
+// states at once (one lane per entry state), k_long_top chains the ~sqrt(S) group maps per document, and
+// k_group_expand replays every group from its now known entry state.  Exit-map composition is associative, so the
+// result is the same as the serial chain.
+struct Group { uint32_t first_seg, nsegs, doc, pad; };
+struct LongDoc { uint32_t doc, first_group, ngroups, pad; };
+
+__global__ __launch_bounds__(128) void k_group_compose(const uint2* __restrict__ exitmap, const Group* __restrict__ groups,
+                                                       uint4* __restrict__ gmap) {
+  const Group gr = groups[blockIdx.x];
+  const uint32_t e0 = threadIdx.x;
+  if (e0 >= ENT) return;
+  uint32_t e = e0, events = 0, nfd = 0, nmiss = 0;
+  bool ok = true;
+  for (uint32_t k = 0; k < gr.nsegs; k++) {
+    const uint2 x = exitmap[(uint64_t)(gr.first_seg + k) * ENT + e];
+    if (x.x == R_INVALID) { ok = false; break; }
+    e = x.x & 0xFFu;
+    events += x.x >> 8;
+    nfd += x.y & 0xFFFFu;
+    nmiss += x.y >> 16;
+  }
+  gmap[(uint64_t)blockIdx.x * ENT + e0] = ok ? make_uint4(e, events, nfd, nmiss) : make_uint4(R_INVALID, 0u, 0u, 0u);
+}
+
+__global__ void k_long_top(const uint4* __restrict__ gmap, const LongDoc* __restrict__ longs, uint32_t nlong,
+                           uint8_t* __restrict__ group_entry, uint4* __restrict__ group_base,
+                           uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ doc_events,
+                           uint32_t* __restrict__ doc_missing, uint32_t* __restrict__ error_flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlong) return;
+  const LongDoc ld = longs[i];
+  uint32_t e = 0, ntok = 0, events = 0, nmiss = 0;
+  for (uint32_t k = 0; k < ld.ngroups; k++) {
+    const uint32_t gi = ld.first_group + k;
+    group_entry[gi] = (uint8_t)e;
+    group_base[gi] = make_uint4(ntok, events, nmiss, 0u);
+    const uint4 x = gmap[(uint64_t)gi * ENT + e];
+    if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
+    e = x.x;
+    events += x.y;
+    ntok += x.y + x.z;
+    nmiss += x.w;
+  }
+  doc_ntok[ld.doc] = ntok;
+  doc_events[ld.doc] = events;
+  doc_missing[ld.doc] = nmiss;
+}
+
+__global__ void k_group_expand(const uint2* __restrict__ exitmap, const Group* __restrict__ groups, uint32_t ngroups,
+                               const uint8_t* __restrict__ group_entry, const uint4* __restrict__ group_base,
+                               uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
+                               uint32_t* __restrict__ error_flag) {
+  const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= ngroups) return;
+  const Group gr = groups[gi];
+  uint32_t e = group_entry[gi], ntok = group_base[gi].x;
+  for (uint32_t k = 0; k < gr.nsegs; k++) {
+    const uint64_t g = (uint64_t)gr.first_seg + k;
+    seg_entry[g] = (uint8_t)e;
+    seg_tokbase[g] = ntok;
+    const uint2 x = exitmap[g * ENT + e];
+    if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
+    e = x.x & 0xFFu;
+    ntok += (x.x >> 8) + (x.y & 0xFFFFu);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -751,6 +823,13 @@ struct tm_batch {
   uint64_t* d_scan_tmp = nullptr;   // block sums
   uint64_t* d_totals = nullptr;     // [0] nseg total (device-computed), [1] token total, [2] missing total
   uint32_t* d_error = nullptr;
+  // long documents (hierarchical resolve)
+  uint32_t ngroups = 0, nlong = 0, cap_groups = 0, cap_long = 0;
+  Group* d_groups = nullptr;
+  LongDoc* d_longs = nullptr;
+  uint4* d_gmap = nullptr;
+  uint8_t* d_group_entry = nullptr;
+  uint4* d_group_base = nullptr;
   uint32_t* d_out = nullptr;
   uint64_t out_cap = 0;
   hipEvent_t ev[TM_NUM_KERNELS + 1] = {};
@@ -774,6 +853,50 @@ void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* to
   k_scan_partial<<<nblocks, SCAN_T, 0, st>>>(in, n, block_sums);
   k_scan_sums<<<1, SCAN_T, 0, st>>>(block_sums, nblocks, total);
   k_scan_final<<<nblocks, SCAN_T, 0, st>>>(in, n, block_sums, out);
+}
+
+// host: segment groups of the long documents.  doc d has lens[d] bytes; segments are numbered in document order.
+int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs) {
+  std::vector<Group> groups;
+  std::vector<LongDoc> longs;
+  uint64_t seg = 0;
+  for (uint32_t d = 0; d < ndocs; d++) {
+    const uint64_t S = (end[d] - begin[d] + SEG - 1) / SEG;
+    if (S > LONG_SEGS) {
+      uint64_t G = 64;
+      while (G * G < S) G++;                              // ~sqrt(S) segments per group -> ~sqrt(S) groups
+      LongDoc ld{d, (uint32_t)groups.size(), 0u, 0u};
+      for (uint64_t k = 0; k < S; k += G) groups.push_back(Group{(uint32_t)(seg + k), (uint32_t)std::min<uint64_t>(G, S - k), d, 0u});
+      ld.ngroups = (uint32_t)groups.size() - ld.first_group;
+      longs.push_back(ld);
+    }
+    seg += S;
+  }
+  if (seg >= (1ull << 32)) return set_error(TM_E_LIMIT, "batch has more than 2^32 segments");
+  b->ngroups = (uint32_t)groups.size();
+  b->nlong = (uint32_t)longs.size();
+  if (b->ngroups == 0) return TM_OK;
+  hipError_t e;
+  if (b->ngroups > b->cap_groups) {
+    (void)hipFree(b->d_groups); (void)hipFree(b->d_gmap); (void)hipFree(b->d_group_entry); (void)hipFree(b->d_group_base);
+    b->d_groups = nullptr; b->d_gmap = nullptr; b->d_group_entry = nullptr; b->d_group_base = nullptr;
+    b->cap_groups = b->ngroups + b->ngroups / 4 + 16;
+    if ((e = hipMalloc((void**)&b->d_groups, (size_t)b->cap_groups * sizeof(Group))) != hipSuccess ||
+        (e = hipMalloc((void**)&b->d_gmap, (size_t)b->cap_groups * ENT * sizeof(uint4))) != hipSuccess ||
+        (e = hipMalloc((void**)&b->d_group_entry, b->cap_groups)) != hipSuccess ||
+        (e = hipMalloc((void**)&b->d_group_base, (size_t)b->cap_groups * sizeof(uint4))) != hipSuccess)
+      return hip_fail(e, "hipMalloc (segment groups)");
+  }
+  if (b->nlong > b->cap_long) {
+    (void)hipFree(b->d_longs);
+    b->d_longs = nullptr;
+    b->cap_long = b->nlong + 16;
+    if ((e = hipMalloc((void**)&b->d_longs, (size_t)b->cap_long * sizeof(LongDoc))) != hipSuccess) return hip_fail(e, "hipMalloc (long documents)");
+  }
+  if ((e = hipMemcpy(b->d_groups, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(b->d_longs, longs.data(), longs.size() * sizeof(LongDoc), hipMemcpyHostToDevice)) != hipSuccess)
+    return hip_fail(e, "H2D segment groups");
+  return TM_OK;
 }
 
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) {
@@ -803,6 +926,13 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   if (nd > 0)
     k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_seg_entry, b->d_seg_tokbase,
                                                 b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_error);
+  if (b->ngroups > 0) {
+    k_group_compose<<<b->ngroups, 128, 0, st>>>(b->d_exitmap, b->d_groups, b->d_gmap);
+    k_long_top<<<(b->nlong + 63) / 64, 64, 0, st>>>(b->d_gmap, b->d_longs, b->nlong, b->d_group_entry, b->d_group_base, b->d_doc_ntok,
+                                                    b->d_doc_events, b->d_doc_missing, b->d_error);
+    k_group_expand<<<(b->ngroups + 63) / 64, 64, 0, st>>>(b->d_exitmap, b->d_groups, b->ngroups, b->d_group_entry, b->d_group_base,
+                                                          b->d_seg_entry, b->d_seg_tokbase, b->d_error);
+  }
   mark(3);
   if (nd > 0) scan_u32(b->d_doc_ntok, nd, b->d_scan_tmp, b->d_totals + 1, b->d_tok_offsets, st);
   else (void)hipMemsetAsync(b->d_tok_offsets, 0, 8, st);
@@ -889,7 +1019,7 @@ void tm_batch_free(tm_batch* b) {
   if (!b) return;
   void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R, b->d_exitmap, b->d_seg_entry,
                   b->d_seg_tokbase, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
-                  b->d_error, b->d_out};
+                  b->d_error, b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base};
   for (void* p : ptrs) (void)hipFree(p);
   if (b->have_events) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
   delete b;
@@ -914,7 +1044,7 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
   b->nseg = nseg;
   b->d_doc_begin = b->d_offsets;
   b->d_doc_end = b->d_offsets + 1;
-  return TM_OK;
+  return build_groups(b, offsets, offsets + 1, ndocs);
 }
 
 int tm_batch_run(tm_batch* b, void* stream) {
@@ -1088,6 +1218,7 @@ static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off
   b->ndocs = n_strips;
   b->nbytes = d->n;
   b->nseg = nseg;
+  { int grc = build_groups(b, be.data(), be.data() + n_strips, n_strips); if (grc != TM_OK) return grc; }
   (void)hipMemsetAsync(d->d_hist, 0, words * 4, st);
   (void)hipMemsetAsync(d->d_tokens, 0, 8, st);
   (void)hipMemsetAsync(d->d_missing_bits, 0, 32, st);
