@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mbytes", type=int, default=1024, help="MiB of raw text per GPU (default 1024 = BASELINE configs[1])")
-    ap.add_argument("--config", default="englishcode-32000-consistent")
+    ap.add_argument("--config", default=None, help="vocabulary shape (default: englishcode-32000-consistent; score: candidates-65536)")
+    ap.add_argument("--workload", default="tokenize", choices=["tokenize", "score"],
+                    help="tokenize = BASELINE configs[1] (default); score = trainvocab candidate-scoring pass, configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=64.0)
     ap.add_argument("--verify", type=int, default=64, help="documents re-checked against the oracle after timing (rank 0)")
@@ -70,6 +72,100 @@ def cpu_baseline(img, text, offs, sample_mb, log):
     return res
 
 
+def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_flag, log):
+    """trainvocab candidate-scoring pass (BASELINE configs[4], training/trainvocab.go:925-1176): ONE normalized dataset
+    of --mbytes MiB in total (strong scaling: every rank owns 1/N of it, uploaded once), a 65536-id candidate
+    vocabulary; a step = score the rank's range + ONE RCCL all-reduce(sum) of the (n_ids + 260)-word histogram."""
+    import torch
+    import torch.distributed as dist
+    import tokenmonster_amd as tm
+    from tokenmonster_amd import _native as N, synth, dist as tmdist
+    total_raw = args.mbytes << 20
+    t0 = time.time()
+    raw, roffs = synth.synth_corpus(kind, total_raw // world, seed=0x434F5250 + 5 + 1000 * rank)
+    raw_bytes = int(raw.size)
+    text, _ = synth.normalize_batch(raw, roffs, capcode, norm_flag)   # documents concatenated = the dataset range of this rank
+    del raw
+    log("dataset range of rank 0: %.1f MB raw -> %.1f MB normalized (%.1fs host)" % (raw_bytes / 1e6, text.size / 1e6, time.time() - t0))
+    ds = C.c_void_p()
+    N.check(N.lib.tm_dataset_upload(N.ptr(text), int(text.size), C.byref(ds)))
+    n_ids = vocab.n_ids()
+    words = n_ids + 4 + 256
+    hist = torch.zeros(words, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        N.check(N.lib.tm_score_device_into(vocab.handle, ds, None, None, 0, C.c_void_p(stream), C.c_void_p(hist.data_ptr()), words))
+        if world > 1:
+            tmdist.allreduce_histogram(hist)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([float(raw_bytes), float(text.size)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    all_raw, all_norm = float(tot[0].item()), float(tot[1].item())
+    scores, tokens, missing = tmdist.decode_histogram(hist.cpu().numpy(), n_ids)
+    verified = None
+    if rank == 0 and world == 1 and args.verify > 0:
+        # bit-exact check of a bounded prefix against the oracle's scoring mode (outside the timed region)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_bind import Oracle
+        orc = Oracle(img)
+        n = min(int(text.size), 2 << 20)
+        exp_s, exp_t, exp_m = orc.score(text[:n])
+        so, sl = np.array([0], dtype=np.uint64), np.array([n], dtype=np.uint64)
+        got = np.zeros(n_ids, dtype=np.uint32)
+        tit = C.c_uint64()
+        ms8 = np.zeros(32, dtype=np.uint8)
+        N.check(N.lib.tm_score(vocab.handle, ds, N.ptr(so), N.ptr(sl), 1, N.ptr(got), C.byref(tit), N.ptr(ms8)))
+        if not ((got == exp_s).all() and tit.value == exp_t and (ms8 == exp_m).all()):
+            raise SystemExit("bench.py: HIP score histogram differs from the oracle - number is INVALID")
+        verified = n
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        offs = np.array([0, min(int(text.size), int(args.cpu_sample_mb * (1 << 20)))], dtype=np.uint64)
+        cpu = cpu_baseline(img, text, offs, args.cpu_sample_mb, log)
+        cpu["sample"] += " (the reference runtime has no scoring mode: this times the identical walk, tokenize_normalized)"
+    if rank == 0:
+        value = all_raw * args.steps / elapsed / 1e9
+        alg = float(text.size)                       # SURVEY 8(d): scoring pass B_alg = N per rank
+        out = {
+            "metric": "GB/s raw UTF-8 scored, trainvocab candidate-scoring pass, 65536-id candidate vocabulary", "value": round(value, 4),
+            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s vocabulary shape (synthetic, %d ids / %d index records); ONE %d MiB synthetic mixed dataset in total, "
+                                   "normalized on the host and resident in HBM (1/N per rank); step = score + all-reduce(sum) of %d uint32" % (
+                                       args.config, n_ids, vocab.n_info(), args.mbytes, words),
+                       "raw_bytes_total": int(all_raw), "normalized_bytes_total": int(all_norm), "tokens_in_text": int(tokens),
+                       "normalized_GBps": round(all_norm * args.steps / elapsed / 1e9, 4),
+                       "parallelism": "dataset byte ranges per rank, RCCL all-reduce of the score histogram", "verified_bytes_vs_oracle": verified},
+            "roofline": {"bound": "hbm", "kernel": "whole scoring pass of one rank", "achieved": round(alg / (elapsed / args.steps) / 1e9, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": None, "algorithmic_bytes_per_launch": alg},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    N.lib.tm_dataset_free(ds)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +195,8 @@ def main():
     from tokenmonster_amd import _native as N, synth
     N.check(N.lib.tm_set_device(local_rank))
 
+    if args.config is None:
+        args.config = "englishcode-32000-consistent" if args.workload == "tokenize" else "candidates-65536"
     kind, vsize, capcode, norm_flag, level, vseed = synth.CONFIGS[args.config]
     t0 = time.time()
     if rank == 0:
@@ -109,6 +207,9 @@ def main():
     vocab = tm.Vocab(img)
     log("vocab %s: %d ids, %d index records, max token %d, tables %.1f MB (%.1fs)" % (
         args.config, vocab.n_ids(), vocab.n_info(), vocab.max_token_length(), N.lib.tm_vocab_device_bytes(vocab.handle) / 1e6, time.time() - t0))
+
+    if args.workload == "score":
+        return bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_flag, log)
 
     # ---- synthetic corpus shard of this rank ------------------------------------------------------------
     t0 = time.time()

@@ -122,6 +122,11 @@ int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const 
 int tm_score_device(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len,
                     uint32_t n_strips, void* stream, uint32_t** dev_hist, uint64_t* n_words);
 
+/* As tm_score_device, but also copies the histogram (device to device, on `stream`) into a caller-owned device
+ * buffer of dst_words >= n_ids + 4 + 256 uint32 — e.g. the storage of a torch tensor that is then all-reduced. */
+int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len,
+                         uint32_t n_strips, void* stream, uint32_t* dst_device, uint64_t dst_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,7 @@ SIGNATURES = {
     "tm_dataset_free": (None, [vp]),
     "tm_score": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, u64p, vp]),
     "tm_score_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.POINTER(vp), u64p]),
+    "tm_score_device_into": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64]),
     # tm_build.h
     "tm_free": (None, [vp]),
     "tm_build_vocab": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,

@@ -657,8 +657,13 @@ __global__ void k_group_expand(const uint2* __restrict__ exitmap, const Group* _
 // chain states carry their output offset and write their ids independently.
 // hist layout (all uint32, so that one RCCL all-reduce(sum) merges ranks): scores[n_ids] | tokens_in_text as
 // four 16-bit limbs | missing[256] (per-byte counters, > 0 = that byte had no token)
-template <bool HIST>
-__global__ __launch_bounds__(256) void k_chain(const uint2* __restrict__ R, const uint8_t* __restrict__ text,
+// HIST keeps most of the histogram traffic in LDS: persistent workgroups (one per CU, WV wavefronts) own a
+// direct-mapped table of HSLOTS {id, count} counters; an id that finds its slot free or already its own adds in
+// LDS, anything else falls through to a global atomic; slots are flushed once when the workgroup retires.  Without
+// this, the hot ids (" the", ",") serialise tens of millions of L2 atomics on a handful of addresses.
+constexpr int HSLOTS = 8192;
+template <bool HIST, int WV>
+__global__ __launch_bounds__(WV * 64) void k_chain(const uint2* __restrict__ R, const uint8_t* __restrict__ text,
                                                const uint64_t* __restrict__ doc_begin,
                                                const uint64_t* __restrict__ doc_end,
                                                const uint32_t* __restrict__ seg_doc,
@@ -669,13 +674,20 @@ __global__ __launch_bounds__(256) void k_chain(const uint2* __restrict__ R, cons
                                                uint64_t out_cap, uint32_t* __restrict__ out,
                                                uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
                                                uint32_t* __restrict__ missing_bits) {
-  __shared__ uint32_t s_j[4][2 * SEG];      // target[0..11] | ids on the path << 12
-  __shared__ uint16_t s_rk[4][2 * SEG];     // output rank of a chain state, 0xFFFF = not on the chain
+  __shared__ uint32_t s_j[WV][2 * SEG];     // target[0..11] | ids on the path << 12
+  __shared__ uint16_t s_rk[WV][2 * SEG];    // output rank of a chain state, 0xFFFF = not on the chain
+  __shared__ uint32_t s_tag[HIST ? HSLOTS : 1], s_cnt[HIST ? HSLOTS : 1];
+  __shared__ unsigned long long s_ntok;
+  __shared__ uint32_t s_ndel;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
-  if (g >= nseg) return;
+  if (HIST) {
+    for (int j = threadIdx.x; j < HSLOTS; j += WV * 64) { s_tag[j] = 0xFFFFFFFFu; s_cnt[j] = 0; }
+    if (threadIdx.x == 0) { s_ntok = 0; s_ndel = 0; }
+    __syncthreads();
+  }
   uint32_t* J = s_j[wv];
   uint16_t* RK = s_rk[wv];
+  for (uint64_t g = (uint64_t)blockIdx.x * WV + wv; g < nseg; g += (uint64_t)gridDim.x * WV) {
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
   const uint64_t rem = doc_end[doc] - begin;
@@ -752,7 +764,12 @@ __global__ __launch_bounds__(256) void k_chain(const uint2* __restrict__ R, cons
           const uint32_t byte = text[begin + p];
           atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
         } else {
-          atomicAdd(&scores[id], (r[k] >> 24) & 63u);      // scores[id] += bytes covered (:1109..1162)
+          const uint32_t adv = (r[k] >> 24) & 63u;         // scores[id] += bytes covered (:1109..1162)
+          const uint32_t slot = id & (HSLOTS - 1);
+          uint32_t owner = s_tag[slot];
+          if (owner == 0xFFFFFFFFu) { owner = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, id); if (owner == 0xFFFFFFFFu) owner = id; }
+          if (owner == id) atomicAdd(&s_cnt[slot], adv);
+          else atomicAdd(&scores[id], adv);
         }
         ntok += 1 + fdn;                                   // tokensInText++ (also for a missing byte, :1169) / += 2
         ndel += fdn;                                       // scores[deleteToken]++ (:1134,1143,1152)
@@ -762,8 +779,20 @@ __global__ __launch_bounds__(256) void k_chain(const uint2* __restrict__ R, cons
   if (HIST) {
     for (int o = 32; o > 0; o >>= 1) { ntok += __shfl_xor(ntok, o); ndel += __shfl_xor(ndel, o); }
     if (lane == 0) {
-      if (ndel) atomicAdd(&scores[delete_id], ndel);
-      if (ntok) atomicAdd(tokens, (unsigned long long)ntok);
+      if (ndel) atomicAdd(&s_ndel, ndel);
+      if (ntok) atomicAdd(&s_ntok, (unsigned long long)ntok);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  }  // segments of this wavefront
+  if (HIST) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < HSLOTS; j += WV * 64)
+      if (s_cnt[j] != 0) atomicAdd(&scores[s_tag[j]], s_cnt[j]);
+    if (threadIdx.x == 0) {
+      if (s_ndel) atomicAdd(&scores[delete_id], s_ndel);
+      if (s_ntok) atomicAdd(tokens, s_ntok);
     }
   }
 }
@@ -938,7 +967,7 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   else (void)hipMemsetAsync(b->d_tok_offsets, 0, 8, st);
   mark(4);
   if (emit && nseg > 0)
-    k_chain<false><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+    k_chain<false, 4><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
                                                                nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, v->tables.delete_id,
                                                                b->out_cap, b->d_out, nullptr, nullptr, nullptr);
   mark(5);
@@ -967,7 +996,7 @@ int ensure_output(tm_batch* b) {
     b->out_cap = total + 1024;
     if ((e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc output");
     hipStream_t st = b->last_stream;
-    k_chain<false><<<(uint32_t)((b->nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+    k_chain<false, 4><<<(uint32_t)((b->nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
                                                                   b->nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
                                                                   b->vocab->tables.delete_id, b->out_cap, b->d_out, nullptr, nullptr, nullptr);
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "emit rerun");
@@ -1178,6 +1207,7 @@ struct tm_dataset {
   uint64_t hist_words = 0;
   unsigned long long* d_tokens = nullptr;
   uint32_t* d_missing_bits = nullptr;
+  int n_cu = 256;
 };
 
 static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
@@ -1225,7 +1255,7 @@ static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off
   int rc = run_pipeline(b, st, false, nullptr, false);
   if (rc != TM_OK) return rc;
   if (nseg > 0)
-    k_chain<true><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+    k_chain<true, 16><<<(uint32_t)std::min<uint64_t>((nseg + 15) / 16, (uint64_t)d->n_cu), 1024, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
                                                               nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
                                                               v->tables.has_delete ? v->tables.delete_id : 0, 0, nullptr, d->d_hist, d->d_tokens,
                                                               d->d_missing_bits);
@@ -1247,6 +1277,7 @@ int tm_dataset_upload(const uint8_t* normalized, uint64_t n, tm_dataset** out) {
     return hip_fail(e, "dataset upload");
   }
   d->n = n;
+  { int dev = 0, cu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) d->n_cu = cu; }
   *out = d;
   return TM_OK;
 }
@@ -1264,6 +1295,17 @@ int tm_score_device(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off,
   if (rc != TM_OK) return rc;
   if (dev_hist) *dev_hist = d->d_hist;
   if (n_words) *n_words = d->hist_words;
+  return TM_OK;
+}
+
+int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+                         void* stream, uint32_t* dst_device, uint64_t dst_words) {
+  if (!dst_device) return set_error(TM_E_INVALID, "null argument");
+  int rc = score_run(v, d, strip_off, strip_len, n_strips, (hipStream_t)stream);
+  if (rc != TM_OK) return rc;
+  if (dst_words < d->hist_words) return set_error(TM_E_NOSPACE, "destination holds %llu words, histogram has %llu", (unsigned long long)dst_words, (unsigned long long)d->hist_words);
+  hipError_t e = hipMemcpyAsync(dst_device, d->d_hist, d->hist_words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "D2D histogram");
   return TM_OK;
 }
 
