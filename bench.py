@@ -6,10 +6,11 @@
 
 Workload (BASELINE.json configs[1]): englishcode-32000-consistent vocabulary shape, 1 GiB of synthetic mixed
 prose/code/log documents per GPU (weak scaling: every rank tokenizes its own shard, no data-path collective).
-A "step" is ONE pass of the whole device pipeline (segments, match_branch, link, resolve, scan, emit) over the
-resident batch.  Raw text is generated and normalized (NFD + capcode) on the host BEFORE the timed region; the
-timed region starts with the normalized bytes in HBM and ends with dense uint32 ids + offsets in HBM.
-`value` = raw UTF-8 bytes of all ranks x K / max-over-ranks wall time.
+A "step" is ONE pass of the whole device pipeline over the resident batch: normalize (NFD + capcode on the GPU,
+tm_batch_normalize; documents with other non-ASCII content go through the host normalizer inside that call), then
+segments, match_branch(+link), resolve, scan, emit.  The timed region starts with the RAW UTF-8 documents in HBM and
+ends with dense uint32 ids + offsets in HBM.  `value` = raw UTF-8 bytes of all ranks x K / max-over-ranks wall time.
+(--hot-path-only times the tokenize kernels alone on host-normalized input, as rounds before the GPU normalizer did.)
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the roofline and cpu_baseline objects).
 """
@@ -38,6 +39,7 @@ def parse():
     ap.add_argument("--workload", default="tokenize", choices=["tokenize", "score"],
                     help="tokenize = BASELINE configs[1] (default); score = trainvocab candidate-scoring pass, configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hot-path-only", action="store_true", help="input = host-normalized bytes; time only the tokenize pipeline")
     ap.add_argument("--cpu-sample-mb", type=float, default=64.0)
     ap.add_argument("--verify", type=int, default=64, help="documents re-checked against the oracle after timing (rank 0)")
     return ap.parse_args()
@@ -215,19 +217,23 @@ def main():
     t0 = time.time()
     raw, roffs = synth.synth_corpus(kind, args.mbytes << 20, seed=0x434F5250 + 2 + 1000 * rank)
     raw_bytes = int(raw.size)
-    text, offs = synth.normalize_batch(raw, roffs, capcode, norm_flag)
-    del raw
+    text, offs = synth.normalize_batch(raw, roffs, capcode, norm_flag)   # host normalizer: reference input for verification
     ndocs = offs.size - 1
     log("corpus: %d docs, %.1f MB raw -> %.1f MB normalized (%.1fs host)" % (ndocs, raw_bytes / 1e6, text.size / 1e6, time.time() - t0))
 
     batch = C.c_void_p()
-    N.check(N.lib.tm_batch_create(vocab.handle, int(text.size), ndocs, C.byref(batch)))
+    N.check(N.lib.tm_batch_create(vocab.handle, int(text.size) + (1 << 20), ndocs, C.byref(batch)))
     t0 = time.time()
-    N.check(N.lib.tm_batch_upload(batch, N.ptr(text), N.ptr(offs), ndocs))
+    if args.hot_path_only:
+        N.check(N.lib.tm_batch_upload(batch, N.ptr(text), N.ptr(offs), ndocs))
+    else:
+        N.check(N.lib.tm_batch_upload_raw(batch, N.ptr(raw), N.ptr(roffs), ndocs))
     h2d_s = time.time() - t0
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
+        if not args.hot_path_only:
+            N.check(N.lib.tm_batch_normalize(batch, C.c_void_p(stream)))
         N.check(N.lib.tm_batch_run(batch, C.c_void_p(stream)))
 
     for _ in range(args.warmup):
@@ -257,6 +263,24 @@ def main():
     ntok = C.c_uint64()
     nmiss = C.c_uint64()
     N.check(N.lib.tm_batch_totals(batch, C.byref(ntok), C.byref(nmiss)))
+
+    normalize_ms = None
+    fallback_docs = 0
+    if not args.hot_path_only:
+        tn = time.perf_counter()
+        for _ in range(3):
+            N.check(N.lib.tm_batch_normalize(batch, C.c_void_p(stream)))
+        torch.cuda.synchronize()
+        normalize_ms = (time.perf_counter() - tn) / 3 * 1e3
+        fallback_docs = int(N.lib.tm_batch_host_fallback_docs(batch))
+        # the device-normalized bytes must equal the host normalizer's
+        nb = int(N.lib.tm_batch_normalized_bytes(batch))
+        if rank == 0:
+            dtext = np.empty(max(nb, 1), dtype=np.uint8)
+            doffs = np.empty(ndocs + 1, dtype=np.uint64)
+            N.check(N.lib.tm_batch_download_text(batch, N.ptr(dtext), nb, N.ptr(doffs)))
+            if nb != text.size or not (doffs == offs).all() or not (dtext[:nb] == text).all():
+                raise SystemExit("bench.py: device-normalized text differs from the host normalizer - number is INVALID")
 
     # ---- per-kernel time, HIP events on the launch stream (after the timed loop, a few extra passes) --------
     ms = (C.c_float * N.TM_NUM_KERNELS)()
@@ -315,9 +339,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s vocabulary shape (synthetic, %d ids / %d index records), %d MiB raw synthetic mixed "
-                                   "text per GPU in %d documents; hot path only: input = host-normalized (NFD+capcode) "
-                                   "bytes resident in HBM, output = uint32 ids + offsets in HBM" % (
-                                       args.config, vocab.n_ids(), vocab.n_info(), args.mbytes, ndocs),
+                                   "text per GPU in %d documents; %s, output = uint32 ids + offsets in HBM" % (
+                                       args.config, vocab.n_ids(), vocab.n_info(), args.mbytes, ndocs,
+                                       "hot path only: input = host-normalized (NFD+capcode) bytes resident in HBM" if args.hot_path_only else
+                                       "end to end: input = RAW UTF-8 resident in HBM, normalized (NFD+capcode) on the GPU inside the timed step"),
+                       "normalize_ms_per_step": None if normalize_ms is None else round(normalize_ms, 3), "host_fallback_docs": fallback_docs,
                        "raw_bytes_per_gpu": raw_bytes, "normalized_bytes_per_gpu": int(text.size), "tokens_per_gpu": int(ntok.value),
                        "missing": int(nmiss.value), "normalized_GBps": round(all_norm * args.steps / elapsed / 1e9, 4),
                        "h2d_seconds": round(h2d_s, 3), "parallelism": "documents sharded by rank, no collective",

@@ -87,6 +87,18 @@ int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm
 void tm_batch_free(tm_batch* b);
 /* H2D of packed text + offsets (synchronous). */
 int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs);
+/* Raw (un-normalized) input: H2D of packed raw UTF-8 documents, then tm_batch_normalize runs the pre-step of
+ * Tokenize (go/tokenmonster.go:242-253: norm.Normalize + capcode.Encode) ON THE DEVICE into the batch's text buffer
+ * (max_bytes of tm_batch_create must cover the normalized size, about 1.1x raw with capcode 2).  Documents that
+ * contain non-ASCII characters other than NFD-stable general punctuation (U+2010..U+205E) are normalized by the
+ * host normalizer instead (they need ICU); tm_batch_host_fallback_docs reports how many.  Supported: capcode 0 and 2,
+ * normalization flags 0..3 (NFD, lowercase).  tm_batch_normalize synchronizes `stream`; afterwards tm_batch_run
+ * tokenizes the normalized documents. */
+int tm_batch_upload_raw(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs);
+int tm_batch_normalize(tm_batch* b, void* stream);
+uint64_t tm_batch_normalized_bytes(const tm_batch* b);
+uint32_t tm_batch_host_fallback_docs(const tm_batch* b);
+int tm_batch_download_text(tm_batch* b, uint8_t* text_out, uint64_t text_cap, uint64_t* offsets_out);
 /* Runs the whole device pipeline (segments, match+branch+link, resolve, scan, emit) on `stream` (a hipStream_t, NULL =
  * default stream).  Inputs and outputs stay in HBM.  Asynchronous with respect to the host. */
 int tm_batch_run(tm_batch* b, void* stream);

@@ -139,3 +139,37 @@ def test_score_histogram_candidate_vocab():
     got_s, got_t, got_m = _score(v, text)
     assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
     assert int(got_s.sum()) >= text.size        # every byte covered once (+1 per forward delete)
+
+
+def test_device_normalizer_matches_host_and_reference():
+    # go/tokenmonster.go:242-253 pre-step on the GPU vs the host normalizer (and the reference runtime's normalize)
+    img = synth.synth_vocab(synth.ENGLISHCODE, 1200, capcode=2, norm_flag=1, level=3, seed=7)
+    v = tm.Vocab(img)
+    raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 1_500_000, seed=21)
+    rng = np.random.default_rng(8)
+    alphabet = list(b"aBcDeFGhij XYZ'1234567890.,-_()\n\t") + ["’", "“", "”", "—", "…"]
+    extra = []
+    for _ in range(3000):
+        s = "".join(c if isinstance(c, str) else chr(c) for c in rng.choice(np.array(alphabet, dtype=object), size=int(rng.integers(0, 90))))
+        extra.append(s.encode())
+    extra += [b"", b"A", b"a", b"AB", b"Ab", b"aB", b"ABc", b"ABC", b" ABC d", b"HTTPServer2Go x", b"X's Y'S it's 'a' I'M", b"12AB34cd", b"A1B2c",
+              "X’s Y’S it’s".encode(), b"A" * 200 + b"b", b"A" * 200, b"a" + b"B" * 130 + b" " + b"C" * 70 + b"d", "café Über".encode(),
+              b"\xff\xfe bad bytes", "  en quad".encode()]
+    etext, eoffs = tm.pack_documents(extra)
+    for text_in, offs_in in ((raw, offs), (etext, eoffs)):
+        got, goff, nfb = v.normalize_packed_device(text_in, offs_in)
+        exp, eoff = synth.normalize_batch(text_in, offs_in, 2, 1)
+        assert (goff == eoff).all()
+        assert got.size == exp.size and (got == exp).all()
+        assert nfb < (offs_in.size - 1) // 5 + 8          # most documents are handled on the device
+    if have_ref():
+        ref = Reference(img)
+        for d in range(0, len(extra), 37):
+            a, b_ = int(goff[d]), int(goff[d + 1])
+            assert got[a:b_].tobytes() == ref.normalize(extra[d])
+    # capcode 0 + lowercase flag
+    img0 = synth.build_vocab([bytes([c]) for c in range(256)], capcode=0, charset=1, norm_flag=3)
+    v0 = tm.Vocab(img0)
+    got, goff, _ = v0.normalize_packed_device(etext, eoffs)
+    exp, eoff = synth.normalize_batch(etext, eoffs, 0, 3)
+    assert (goff == eoff).all() and (got == exp).all()

@@ -44,6 +44,11 @@ SIGNATURES = {
     "tm_batch_create": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
     "tm_batch_free": (None, [vp]),
     "tm_batch_upload": (C.c_int, [vp, vp, vp, C.c_uint32]),
+    "tm_batch_upload_raw": (C.c_int, [vp, vp, vp, C.c_uint32]),
+    "tm_batch_normalize": (C.c_int, [vp, vp]),
+    "tm_batch_normalized_bytes": (C.c_uint64, [vp]),
+    "tm_batch_host_fallback_docs": (C.c_uint32, [vp]),
+    "tm_batch_download_text": (C.c_int, [vp, vp, C.c_uint64, vp]),
     "tm_batch_run": (C.c_int, [vp, vp]),
     "tm_batch_run_timed": (C.c_int, [vp, vp, f32p]),
     "tm_kernel_name": (C.c_char_p, [C.c_int]),

@@ -130,7 +130,24 @@ void capcode_encode(const uint8_t* in, size_t n, std::vector<uint8_t>& buf) {
   bool in_word = false, multi = false;
   size_t i = 0;
   while (i < n) {
-    // fast path: a stretch of lowercase ASCII / spaces outside a capital run needs no bookkeeping
+    // fast path: outside a capital run, a stretch of lowercase ASCII words separated by single spaces needs no marker
+    // (every letter follows a letter or a space, :970) and is copied in bulk
+    if (!in_word && (last.space || last.letter) && in[i] - 'a' < 26u) {
+      size_t j = i;
+      while (j < n) {
+        const uint8_t x = in[j];
+        if (x - 'a' < 26u) j++;
+        else if (x == ' ' && j + 1 < n && in[j + 1] - 'a' < 26u) j++;
+        else break;
+      }
+      buf.insert(buf.end(), in + i, in + j);
+      Last letter; letter.letter = true;
+      Last space; space.space = true;
+      if (j - i >= 2) last2 = in[j - 2] == ' ' ? space : letter; else last2 = last;
+      last = letter;                                  // the stretch always ends on a letter
+      i = j;
+      continue;
+    }
     Cp c = next_cp(in + i, n - i);
     uint8_t cls = classify(c);
     if (in_word) {
@@ -192,14 +209,31 @@ bool is_ascii(const uint8_t* d, size_t n) {
 
 void nfd_bytes(std::vector<uint8_t>& b) {    // tokenmonster.cpp:190-212
   if (is_ascii(b.data(), b.size())) return;
+  // NFD is local: ASCII is inert (every ASCII character is a starter with no decomposition and composition is not
+  // involved), so only the maximal non-ASCII stretches need ICU; the ASCII in between is copied through.
   UErrorCode status = U_ZERO_ERROR;
   const icu::Normalizer2* nz = icu::Normalizer2::getNFDInstance(status);
-  icu::UnicodeString u = icu::UnicodeString::fromUTF8(icu::StringPiece((const char*)b.data(), (int32_t)b.size()));
-  icu::UnicodeString out;
-  nz->normalize(u, out, status);
-  std::string s;
-  out.toUTF8String(s);
-  b.assign(s.begin(), s.end());
+  std::vector<uint8_t> out;
+  out.reserve(b.size() + b.size() / 8 + 16);
+  const size_t n = b.size();
+  size_t i = 0;
+  std::string tmp;
+  while (i < n) {
+    size_t j = i;
+    while (j < n && !(b[j] & 0x80)) j++;
+    out.insert(out.end(), b.begin() + (std::ptrdiff_t)i, b.begin() + (std::ptrdiff_t)j);
+    if (j >= n) break;
+    size_t k = j;
+    while (k < n && (b[k] & 0x80)) k++;
+    icu::UnicodeString u = icu::UnicodeString::fromUTF8(icu::StringPiece((const char*)b.data() + j, (int32_t)(k - j)));
+    icu::UnicodeString o;
+    nz->normalize(u, o, status);
+    tmp.clear();
+    o.toUTF8String(tmp);
+    out.insert(out.end(), tmp.begin(), tmp.end());
+    i = k;
+  }
+  b.swap(out);
 }
 
 void lower_bytes(std::vector<uint8_t>& b) {  // tokenmonster.cpp:214-229
@@ -250,13 +284,14 @@ int tm_normalize_batch(const uint8_t* text, const uint64_t* offsets, uint32_t nd
     return tmh::set_error(TM_E_INVALID, "normalization flags %u / capcode %u not supported by the host normalizer", norm_flag, capcode);
   if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
   threads = std::min<uint32_t>(threads, std::max(1u, ndocs));
+  const uint32_t grab = std::max(1u, std::min(64u, ndocs / (threads * 4u)));
   std::vector<std::vector<uint8_t>> outs(ndocs);
   std::atomic<uint32_t> next{0};
   auto work = [&]() {
     for (;;) {
-      uint32_t base = next.fetch_add(64);
+      uint32_t base = next.fetch_add(grab);
       if (base >= ndocs) break;
-      for (uint32_t d = base; d < std::min(ndocs, base + 64); d++)
+      for (uint32_t d = base; d < std::min(ndocs, base + grab); d++)
         tmh::normalize_bytes(text + offsets[d], (size_t)(offsets[d + 1] - offsets[d]), capcode, norm_flag, outs[d]);
     }
   };

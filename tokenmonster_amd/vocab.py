@@ -79,6 +79,27 @@ class Vocab:
     def normalize(self, data):
         return _synth.normalize(data, self.capcode(), self.normalization_code())
 
+    def normalize_packed_device(self, raw_text, raw_offsets):
+        """norm.Normalize + capcode.Encode of packed raw documents ON THE GPU (tm_batch_normalize; documents with
+        other non-ASCII content fall back to the host normalizer inside the library)
+        -> (normalized text u8, offsets u64[D+1], number of host-fallback documents)"""
+        raw_text = N.as_u8(raw_text)
+        raw_offsets = np.ascontiguousarray(raw_offsets, dtype=np.uint64)
+        nd = raw_offsets.size - 1
+        cap = int(raw_text.size * 4 + 16 * nd + 1024)
+        b = C.c_void_p()
+        N.check(N.lib.tm_batch_create(self._h, cap, max(nd, 1), C.byref(b)))
+        try:
+            N.check(N.lib.tm_batch_upload_raw(b, N.ptr(raw_text), N.ptr(raw_offsets), nd))
+            N.check(N.lib.tm_batch_normalize(b, None))
+            n = int(N.lib.tm_batch_normalized_bytes(b))
+            text = np.empty(max(n, 1), dtype=np.uint8)
+            offs = np.zeros(nd + 1, dtype=np.uint64)
+            N.check(N.lib.tm_batch_download_text(b, N.ptr(text), n, N.ptr(offs)))
+            return text[:n], offs, int(N.lib.tm_batch_host_fallback_docs(b))
+        finally:
+            N.lib.tm_batch_free(b)
+
     # ---- tokenize ----
     def tokenize_packed(self, text, offsets):
         """normalized packed documents -> (ids u32[T], tok_offsets u64[D+1], missing u32[D])"""
