@@ -173,3 +173,62 @@ def test_device_normalizer_matches_host_and_reference():
     got, goff, _ = v0.normalize_packed_device(etext, eoffs)
     exp, eoff = synth.normalize_batch(etext, eoffs, 0, 3)
     assert (goff == eoff).all() and (got == exp).all()
+
+
+def _utf16(bs):
+    return b"".join(bytes([c, 0]) for c in bs)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_utf16_vocab(seed):
+    # charset 2: the forward-delete probe uses the two-byte prefix ' ' 0x00 (lilbufOffset 2, go :1031-1034, quirk Q8)
+    rng = np.random.default_rng(500 + seed)
+    toks8 = fuzz_vocab_tokens(rng, 2, 150)
+    toks = sorted(set(_utf16(t) for t in toks8 if len(t) <= 20) | {b"D", b" ", b"a"})     # plus a few odd-length keys
+    img = synth.build_vocab(toks, capcode=2, charset=2)
+    v, orc = tm.Vocab(img), Oracle(img)
+    assert v.charset() == 2
+    oracle_stats(reset=True)
+    docs = [_utf16(fuzz_text(rng, 2, int(n))) for n in rng.integers(0, 1500, size=60)]
+    docs += [_utf16(fuzz_text(rng, 2, 3000))[:-1], b"", _utf16(b" abc abc")]
+    ids, toff, _ = check_docs(v, orc, docs, "utf16 seed=%d" % seed)
+    st = oracle_stats()
+    assert st["s1"] > 0 and st["s2"] > 0
+    if have_ref():
+        ref = Reference(img)
+        for d in range(0, len(docs), 5):
+            exp, _ = ref.tokenize_normalized(docs[d])
+            got = ids[int(toff[d]):int(toff[d + 1])]
+            assert got.size == exp.size and (got == exp).all()
+
+
+def test_host_api_edge_cases():
+    from tokenmonster_amd import _native as N
+    import ctypes as C
+    v = tm.Vocab(unit_vocab_image())
+    # zero documents, empty documents
+    ids, toff, missing = v.tokenize_packed(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert ids.size == 0 and toff.tolist() == [0]
+    ids, toff, missing = v.tokenize_packed(*tm.pack_documents([b"", b"ab", b""]))
+    assert ids.tolist() == [3] and toff.tolist() == [0, 0, 1, 1]
+    # TM_E_NOSPACE reports the required capacity in tok_offsets[ndocs]
+    text, offs = tm.pack_documents([b"ab a z", b"abab"])
+    tok_off = np.zeros(3, dtype=np.uint64)
+    out = np.zeros(1, dtype=np.uint32)
+    miss = np.zeros(2, dtype=np.uint32)
+    rc = N.lib.tm_tokenize_batch(v.handle, N.ptr(text), N.ptr(offs), 2, N.ptr(out), 1, N.ptr(tok_off), N.ptr(miss))
+    assert rc == N.TM_E_NOSPACE and int(tok_off[2]) == 6
+    # serialized: encoding lengths 2, 3, 4 (go :1545/:1817/:2089) and the invalid one (go :1012)
+    for enc, exp in ((2, [3, 0]), (3, [3, 0, 0]), (4, [3, 0, 0, 0])):
+        b, boff, _, used = v.tokenize_serialized_packed(*tm.pack_documents([b"ab"]), encoding_length=enc)
+        assert used == enc and b.tolist() == exp
+    with pytest.raises(N.TokenMonsterHipError):
+        v.tokenize_serialized_packed(*tm.pack_documents([b"ab"]), encoding_length=5)
+    # raw-text entry point: normalize on the device, then tokenize
+    img = synth.synth_vocab(synth.ENGLISHCODE, 1500, capcode=2, norm_flag=1, level=3, seed=3)
+    v2, orc2 = tm.Vocab(img), Oracle(img)
+    raw_docs = [b"Hello World, this is A TEST of HTTPServer2Go!", "It’s “quoted” — naïve café".encode(), b""]
+    got = v2.tokenize(raw_docs)
+    for d, r in zip(got, raw_docs):
+        exp, _ = orc2.tokenize(synth.normalize(r, 2, 1))
+        assert d.tolist() == exp.tolist()

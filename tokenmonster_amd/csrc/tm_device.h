@@ -22,6 +22,7 @@ struct HostVocab {
   uint8_t begin_byte[256];
   std::vector<uint32_t> root;
   std::vector<uint2> tab;           // direct depth-2 map followed by the edge hash (tm_tables.h)
+  std::vector<uint2> spl;           // space-prefix links
   uint32_t edge_mask = 0, edge_shift = 0, n_nodes = 0, off = 1, bstart = kNone;
 };
 
@@ -36,6 +37,7 @@ struct tm_vocab {
   uint64_t device_bytes = 0;
   uint32_t* d_root = nullptr;
   uint2* d_tab = nullptr;
+  uint2* d_spl = nullptr;
   tmh::Row* d_rows = nullptr;
   uint8_t* d_begin_byte = nullptr;
 };

@@ -199,9 +199,8 @@ struct WaveLds {
   alignas(16) uint8_t text[TEXT_LEN];
   uint32_t D[NPOS_PAD];    // longest match at p                      (second-token descriptor)
   uint32_t Db[NPOS_PAD];   // longest match of ' '+text[p:], if usable (forward-delete descriptor), 0 = none
-  uint32_t X[SEG];         // node value of D's token (node id = record ordinal)
+  uint32_t X[NPOS_PAD];    // node value of D's token (node id = record ordinal)
   uint32_t Xb[SEG];        // node value of Db's token
-  uint8_t xchg[64];        // lane exchange scratch for handing out forward-delete tasks
 };
 
 // T(p, fd): go/tokenmonster.go:1051-1276
@@ -321,16 +320,18 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
             uint2 e;
             if (limit >= 2) e = T.tab[((uint32_t)w.text[p] << 8) | w.text[p + 1]];
             else { const uint32_t r = s_root[w.text[p]]; e = make_uint2((r != kNone && node_id(r) < T.n_info) ? 1u : 0u, r); }
-            const int bestlen = (int)(e.x & 3u);
-            if ((e.x & 4u) && limit > 2 && !(dbg & 4)) {
-              k[s].pos = p; k[s].tbase = p; k[s].depth = 2; k[s].limit = limit; k[s].active = true;
-              k[s].bestlen = bestlen; k[s].bestv = e.y;
-              k[s].key = ((e.x >> 3) << 8) | w.text[p + 2];
+            const int bestlen = (int)(e.x & 3u), depth = 2;
+            const uint32_t bestv = e.y, nid = e.x >> 3;
+            const bool cont = (e.x & 4u) != 0;
+            if (cont && limit > depth && !(dbg & 4)) {
+              k[s].pos = p; k[s].tbase = p; k[s].depth = depth; k[s].limit = limit; k[s].active = true;
+              k[s].bestlen = bestlen; k[s].bestv = bestv;
+              k[s].key = (nid << 8) | w.text[p + depth];
               k[s].h32 = k[s].key * 0x9E3779B1u;
               k[s].haddr = k[s].h32 >> T.edge_shift;
             } else if (bestlen != 0) {
-              w.D[p] = (uint32_t)bestlen | ((e.y >> 22) << 6);
-              if (p < SEG) w.X[p] = e.y;
+              w.D[p] = (uint32_t)bestlen | ((bestv >> 22) << 6);
+              w.X[p] = bestv;
             }
           }
         }
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
         for (int s = 0; s < NWALK; s++) {
           if (walk_consume(T, w.text, k[s], e[s]) && k[s].bestlen != 0) {
             w.D[k[s].pos] = (uint32_t)k[s].bestlen | ((k[s].bestv >> 22) << 6);
-            if (k[s].pos < SEG) w.X[k[s].pos] = k[s].bestv;
+            w.X[k[s].pos] = k[s].bestv;
           }
           nactive += __popcll(__ballot(k[s].active));
         }
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   unsigned long long elig[NPOS_PAD / 64];
   {
     const int off = (int)T.off;
-    const bool can_b = T.has_delete && T.bstart != kNone && (T.bstart & kHasChildren) && !(dbg & 8);
+    const bool can_b = T.has_delete && T.bstart != kNone && !(dbg & 8);
 #pragma unroll
     for (int it = 0; it < NPOS_PAD / 64; it++) {
       const int p = it * 64 + lane;
@@ -381,72 +382,45 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   }
   {
     // ---- A3: longest match of ' '+text[p:] at the eligible positions -> Db[p], Xb[p] (accepted only if longer, go :1092)
+    // The space-prefix link of the plain match (one gather) stands for the first mainlen+off bytes of that walk, so
+    // only the few walks that can still grow run the probe loop; positions are taken in place, NWALK blocks at a time.
     const int off = (int)T.off;
-    int blk = 0;                              // wave-uniform: block of 64 positions tasks are taken from
-    unsigned long long avail = elig[0];
-    Walk k[NWALK];
-    int mainlen[NWALK];
 #pragma unroll
-    for (int s = 0; s < NWALK; s++) { k[s] = Walk{0, 0, 0, 0, 0, 0u, 0u, 0u, 0u, false}; mainlen[s] = 0; }
-    for (;;) {
-      // refill from the eligibility masks
-      for (int rep = 0; rep < 2; rep++) {
+    for (int it = 0; it < NPOS_PAD / 64; it += NWALK) {
+      Walk k[NWALK];
+      int mainlen[NWALK];
+      bool any = false;
 #pragma unroll
-        for (int s = 0; s < NWALK; s++) {
-          while (avail == 0 && blk + 1 < NPOS_PAD / 64) {
-            blk++;
-#pragma unroll
-            for (int q = 0; q < NPOS_PAD / 64; q++) if (q == blk) avail = elig[q];
-          }
-          if (avail == 0) break;
-          const unsigned long long wmask = __ballot(!k[s].active);
-          if (wmask == 0) continue;
-          // the r-th idle lane takes the r-th available position of the block: exchanged through LDS
-          const int n = min(__popcll(avail), __popcll(wmask));
-          const int prank = __popcll(avail & lane_below);                  // rank of MY position bit, if set
-          if (((avail >> lane) & 1ull) && prank < n) w.xchg[prank] = (uint8_t)lane;
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_s_waitcnt(0);
-          const int wrank = __popcll(wmask & lane_below);
-          const bool take = !k[s].active && wrank < n;
-          int p = 0;
-          if (take) p = blk * 64 + w.xchg[wrank];
-          avail = __ballot(((avail >> lane) & 1ull) && prank >= n);       // the n lowest positions are handed out
-          __builtin_amdgcn_wave_barrier();
-          if (take) {
-            k[s].pos = p; k[s].tbase = p - off; k[s].bestlen = 0; k[s].bestv = 0; k[s].depth = 2;
-            mainlen[s] = (int)(w.D[p] & 63u);
-            k[s].limit = min(dl - p, Lmax - off) + off;
-            if (off == 1) {
-              const uint2 e = T.tab[((uint32_t)' ' << 8) | w.text[p]];
-              if ((e.x & 4u) && k[s].limit > 2) {
-                k[s].active = true;
-                k[s].key = ((e.x >> 3) << 8) | w.text[p + 1];
-                k[s].h32 = k[s].key * 0x9E3779B1u;
-                k[s].haddr = k[s].h32 >> T.edge_shift;
-              }
-            } else {
-              k[s].active = true;
-              k[s].key = (node_id(T.bstart) << 8) | w.text[p];
-              k[s].h32 = k[s].key * 0x9E3779B1u;
-              k[s].haddr = k[s].h32 >> T.edge_shift;
-            }
+      for (int s = 0; s < NWALK; s++) {
+        k[s] = Walk{0, 0, 0, 0, 0, 0u, 0u, 0u, 0u, false};
+        mainlen[s] = 0;
+        const int p = (it + s) * 64 + lane;
+        if (it + s < NPOS_PAD / 64 && ((elig[(it + s) < NPOS_PAD / 64 ? it + s : 0] >> lane) & 1ull)) {
+          const uint32_t ml = w.D[p] & 63u;
+          const uint2 e = T.spl[node_id(w.X[p])];
+          const int limit = min(dl - p, Lmax - off) + off;
+          const int depth = (int)ml + off;
+          const int bl = (int)((e.x >> 22) & 63u);
+          if (e.x != kNone && ((e.x >> 21) & 1u) && depth < limit) {
+            k[s].pos = p; k[s].tbase = p - off; k[s].bestlen = bl; k[s].bestv = e.y; k[s].depth = depth; k[s].limit = limit;
+            mainlen[s] = (int)ml;
+            k[s].active = true;
+            k[s].key = ((e.x & kNodeMask) << 8) | w.text[p + ml];
+            k[s].h32 = k[s].key * 0x9E3779B1u;
+            k[s].haddr = k[s].h32 >> T.edge_shift;
+          } else if (e.x != kNone && bl > (int)ml + 1) {               // (only possible with the two-byte UTF-16 prefix)
+            const int lb = bl - off;
+            w.Db[p] = make_desc((uint32_t)lb, e.y, s_bb[w.text[p + lb]]);
+            if (p < SEG) w.Xb[p] = e.y;
           }
         }
+        any |= k[s].active;
       }
-      int nactive = 0;
-#pragma unroll
-      for (int s = 0; s < NWALK; s++) nactive += __popcll(__ballot(k[s].active));
-      bool more = avail != 0;
-#pragma unroll
-      for (int q = 0; q < NPOS_PAD / 64; q++) more |= (q > blk && elig[q] != 0);
-      if (nactive == 0) { if (!more) break; continue; }
-      const int thr = more ? NWALK * REFILL_THR : 1;
-      do {
+      while (__any(any)) {
         uint2 e[NWALK];
 #pragma unroll
         for (int s = 0; s < NWALK; s++) e[s] = hash_tab[k[s].haddr];
-        nactive = 0;
+        any = false;
 #pragma unroll
         for (int s = 0; s < NWALK; s++) {
           if (walk_consume(T, w.text, k[s], e[s]) && k[s].bestlen > mainlen[s] + 1) {
@@ -454,9 +428,9 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
             w.Db[k[s].pos] = make_desc((uint32_t)lb, k[s].bestv, s_bb[w.text[k[s].pos + lb]]);
             if (k[s].pos < SEG) w.Xb[k[s].pos] = k[s].bestv;
           }
-          nactive += __popcll(__ballot(k[s].active));
+          any |= k[s].active;
         }
-      } while (nactive >= thr);
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -496,6 +470,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   // points at a segment exit.  Only the 80 possible entry states (offset < 40, fd) are written out, but their
   // chains run through arbitrary states, so all 2 x 512 states take part.  In-place updates are safe: an entry is
   // read and written as one 8-byte LDS access and always describes a valid prefix of its state's chain.
+  if (dbg & 16) { for (int e = lane; e < ENT; e += 64) exitmap[g * ENT + e] = make_uint2(0u, 0u); return; }   // (timing experiments only)
   {
     uint2* J = reinterpret_cast<uint2*>(w.D);            // overlays D, Db, X, Xb (dead after step B): 1024 x 8 B
     static_assert(sizeof(uint32_t) * (2 * NPOS_PAD + 2 * SEG) >= 2 * SEG * sizeof(uint2), "J overlay does not fit");

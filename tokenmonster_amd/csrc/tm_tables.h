@@ -53,6 +53,9 @@ struct Tables {
                            //                         x = its length (0,1,2) | cont << 2 | depth-2 node id << 3, cont = the node
                            //                         b0b1 exists and has children (the walk goes on in the hash)
                            //   [65536, 65536+mask+1) depth>=3 hash, x = parent<<8|byte (kNone = empty slot)
+  const uint2* spl;        // [n_info] "space-prefix link" of record s: where the walk of ' '+s (the forward-delete probe of
+                           //   go/tokenmonster.go:1088-1095; ' ' 0x00 + s for UTF-16) ends up, so that probe only has to CONTINUE:
+                           //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node
   const Row* rows;         // [n_info]
   const uint8_t* begin_byte;  // [256]  go/tokenmonster.go:43
   uint32_t edge_mask, edge_shift;

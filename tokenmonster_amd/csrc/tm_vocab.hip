@@ -151,6 +151,30 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       edges[h] = uint2{key, value_of(kv.second)};
     }
   }
+  // space-prefix links: walk ' ' (+ 0x00 for UTF-16) + key through the trie once per record
+  {
+    const uint32_t off = hv.charset == 2 ? 2u : 1u;
+    hv.spl.assign(n_info, uint2{kNone, 0u});
+    uint32_t start = kNone;
+    { auto it = child.find(((uint64_t)kRoot << 8) | ' '); if (it != child.end()) start = it->second; }
+    if (start != kNone && off == 2) { auto it = child.find(((uint64_t)start << 8) | 0u); start = it != child.end() ? it->second : kNone; }
+    if (start != kNone) {
+      for (uint32_t i = 0; i < n_info; i++) {
+        const uint8_t* k = &hv.keys[hv.key_off[i]];
+        const uint32_t kl = lens[i];
+        uint32_t node = start, depth = off, bestlen = 0, bestv = 0, used = 0;
+        if (node < n_info) { bestlen = depth; bestv = value_of(node); }
+        while (used < kl && depth < hv.max_len) {
+          auto it = child.find(((uint64_t)node << 8) | k[used]);
+          if (it == child.end()) break;
+          node = it->second; used++; depth++;
+          if (node < n_info) { bestlen = depth; bestv = value_of(node); }
+        }
+        const uint32_t cont = (used == kl && has_child[node] && depth < hv.max_len) ? 1u : 0u;
+        hv.spl[i] = uint2{node | (cont << 21) | (bestlen << 22), bestv};
+      }
+    }
+  }
   // direct map: fold the depth-1 answer in, so one 8-byte load resolves the first two bytes of any walk
   for (uint32_t b0 = 0; b0 < 256; b0++) {
     const uint32_t r = hv.root[b0];
@@ -219,12 +243,13 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   if ((e = up((void**)&v->d_root, hv.root.data(), 256 * 4)) != hipSuccess ||
       (e = up((void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2))) != hipSuccess ||
       (e = up((void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row))) != hipSuccess ||
+      (e = up((void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint2))) != hipSuccess ||
       (e = up((void**)&v->d_begin_byte, hv.begin_byte, 256)) != hipSuccess) {
     tm_vocab_free(v);
     return hip_fail(e, "vocabulary upload");
   }
   Tables& t = v->tables;
-  t.root = v->d_root; t.tab = v->d_tab; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
+  t.root = v->d_root; t.tab = v->d_tab; t.spl = v->d_spl; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
   t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
   t.off = hv.off; t.bstart = hv.bstart;
   t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
@@ -234,7 +259,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
 
 void tm_vocab_free(tm_vocab* v) {
   if (!v) return;
-  (void)hipFree(v->d_root); (void)hipFree(v->d_tab); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
+  (void)hipFree(v->d_root); (void)hipFree(v->d_tab); (void)hipFree(v->d_spl); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
   delete v;
 }
 

@@ -127,14 +127,27 @@ class Vocab:
         return (res[0], int(missing[0])) if single else (res, missing)
 
     def tokenize(self, docs):
-        """raw text -> ids (go :959 Tokenize = normalize + tokenize; python/tokenmonster.py:410)"""
+        """raw text -> ids (go :959 Tokenize = normalize + tokenize; python/tokenmonster.py:410).  The normalization
+        pre-step runs on the device too (tm_batch_upload_raw + tm_batch_normalize)."""
         single = isinstance(docs, (bytes, bytearray, str))
         lst = [docs] if single else list(docs)
         lst = [d.encode("utf-8") if isinstance(d, str) else d for d in lst]
         text, offsets = pack_documents(lst)
-        ntext, noff = _synth.normalize_batch(text, offsets, self.capcode(), self.normalization_code())
-        ids, off, _ = self.tokenize_packed(ntext, noff)
-        res = [ids[int(off[d]): int(off[d + 1])] for d in range(offsets.size - 1)]
+        nd = offsets.size - 1
+        b = C.c_void_p()
+        N.check(N.lib.tm_batch_create(self._h, int(text.size * 4 + 16 * nd + 1024), max(nd, 1), C.byref(b)))
+        try:
+            N.check(N.lib.tm_batch_upload_raw(b, N.ptr(text), N.ptr(offsets), nd))
+            N.check(N.lib.tm_batch_normalize(b, None))
+            N.check(N.lib.tm_batch_run(b, None))
+            ntok = C.c_uint64()
+            N.check(N.lib.tm_batch_totals(b, C.byref(ntok), None))
+            ids = np.empty(max(int(ntok.value), 1), dtype=np.uint32)
+            off = np.zeros(nd + 1, dtype=np.uint64)
+            N.check(N.lib.tm_batch_download(b, N.ptr(ids), int(ntok.value), N.ptr(off), None))
+        finally:
+            N.lib.tm_batch_free(b)
+        res = [ids[int(off[d]): int(off[d + 1])] for d in range(nd)]
         return res[0] if single else res
 
     def count_packed(self, text, offsets):
