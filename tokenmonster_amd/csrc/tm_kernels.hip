@@ -437,28 +437,54 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   __builtin_amdgcn_s_waitcnt(0);
 
   // ---- step B: T(p,0) and T(p,1) for every position of the segment --------------------------------
-  // all row gathers of the segment are issued first (independent), then the scoring runs out of registers + LDS
+  // The kernel is VALU-issue bound (profiles/r01_v3_pmc_k1.txt) and the six-branch scoring is its largest block of
+  // straight-line code, so it must not run on mostly idle lanes: T(p,0) is evaluated for all positions (row gathers
+  // issued first), but the few (p,1) states (forward-delete matches) are first compacted into a dense list — through
+  // the 64 halo slots of X, which step B does not read — and evaluated in as few full-width passes as possible.
   uint32_t r0[SEG / 64], r1[SEG / 64];
   {
-    Row row0[SEG / 64], row1[SEG / 64];
-    uint32_t d0[SEG / 64], d1[SEG / 64];
+    Row row0[SEG / 64];
+    uint32_t d0[SEG / 64];
+    unsigned long long m1[SEG / 64];
+    int n1 = 0;
 #pragma unroll
     for (int it = 0; it < SEG / 64; it++) {
       const int p = it * 64 + lane;
       d0[it] = w.D[p];
-      d1[it] = w.Db[p];
       if (p < seglen && d0[it] != 0) row0[it] = T.rows[node_id(w.X[p])];
-      if (p < seglen && d1[it] != 0) row1[it] = T.rows[node_id(w.Xb[p])];
+      m1[it] = __ballot(p < seglen && w.Db[p] != 0);
+      n1 += __popcll(m1[it]);
     }
 #pragma unroll
     for (int it = 0; it < SEG / 64; it++) {
       const int p = it * 64 + lane;
-      r0[it] = R_INVALID; r1[it] = R_INVALID;
-      if (p < seglen) {
-        r0[it] = transition(T, w, s_bb, p, dl, d0[it], row0[it], 0);
-        if (d1[it] != 0) r1[it] = transition(T, w, s_bb, p, dl, d1[it], row1[it], 1);
-        R[begin + p] = make_uint2(r0[it], r1[it]);
+      r0[it] = R_INVALID;
+      if (p < seglen) r0[it] = transition(T, w, s_bb, p, dl, d0[it], row0[it], 0);
+    }
+    for (int base = 0; base < n1; base += 64) {
+      int run = 0;
+#pragma unroll
+      for (int it = 0; it < SEG / 64; it++) {
+        const int dst = run + __popcll(m1[it] & lane_below) - base;
+        if (((m1[it] >> lane) & 1ull) && dst >= 0 && dst < 64) w.X[SEG + dst] = (uint32_t)(it * 64 + lane);
+        run += __popcll(m1[it]);
       }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0);
+      if (base + lane < n1) {
+        const int q = (int)w.X[SEG + lane];
+        const uint32_t dB = w.Db[q];
+        const Row row1 = T.rows[node_id(w.Xb[q])];
+        w.Xb[q] = transition(T, w, s_bb, q, dl, dB, row1, 1);     // Xb[q] is only ever read by this lane: reuse it for the result
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0);
+    }
+#pragma unroll
+    for (int it = 0; it < SEG / 64; it++) {
+      const int p = it * 64 + lane;
+      r1[it] = ((m1[it] >> lane) & 1ull) ? w.Xb[p] : R_INVALID;
+      if (p < seglen) R[begin + p] = make_uint2(r0[it], r1[it]);
     }
   }
   __builtin_amdgcn_wave_barrier();
