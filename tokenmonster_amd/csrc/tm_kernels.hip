@@ -510,35 +510,42 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       const uint32_t tgt = pn >= seglen ? J_EXIT + (more_text ? (uint32_t)((pn - SEG) * 2) + fdn : 0u) : fdn * SEG + (uint32_t)pn;
       return make_uint2(tgt | (ev << 12), fdn | ((r >> 31) << 16));
     };
+    // every lane keeps its own 2*SEG/64 states in registers and only touches LDS for states that still point inside
+    // the segment (most (p,1) states are unreachable and finished from the start)
+    constexpr int NS = 2 * SEG / 64;
+    uint2 ja[NS];
+    uint32_t pend = 0;
 #pragma unroll
     for (int it = 0; it < SEG / 64; it++) {
       const int p = it * 64 + lane;
-      J[p] = first_hop(r0[it], p);
-      J[SEG + p] = first_hop(r1[it], p);
+      ja[it] = first_hop(r0[it], p);
+      ja[SEG / 64 + it] = first_hop(r1[it], p);
+      J[p] = ja[it];
+      J[SEG + p] = ja[SEG / 64 + it];
     }
+#pragma unroll
+    for (int k = 0; k < NS; k++) if ((ja[k].x & 0xFFFu) < J_EXIT) pend |= 1u << k;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
     // entry state e = offset*2 + fd  <->  state index fd*SEG + offset
     const int e0 = lane, e1 = 64 + lane;
     const int se0 = (e0 & 1) * SEG + (e0 >> 1), se1 = (e1 & 1) * SEG + (e1 >> 1);
-    for (int round = 0; round < 12; round++) {
+    for (int round = 0; round < 12 && __any(pend != 0); round++) {
 #pragma unroll
-      for (int k = 0; k < 2 * SEG / 64; k++) {
-        const int sidx = k * 64 + lane;
-        uint2 a = J[sidx];
-        const uint32_t t = a.x & 0xFFFu;
-        if (t < J_EXIT) {
-          const uint2 bnext = J[t];
-          a.x = (bnext.x & 0xFFFu) | (((a.x >> 12) + (bnext.x >> 12)) << 12);
-          a.y = a.y + bnext.y;                            // two 16-bit counters, neither can overflow (<= 512 each)
-          J[sidx] = a;
+      for (int k = 0; k < NS; k++) {
+        if (pend & (1u << k)) {
+          const uint2 bnext = J[ja[k].x & 0xFFFu];
+          ja[k].x = (bnext.x & 0xFFFu) | (((ja[k].x >> 12) + (bnext.x >> 12)) << 12);
+          ja[k].y = ja[k].y + bnext.y;                    // two 16-bit counters, neither can overflow (<= 512 each)
+          J[k * 64 + lane] = ja[k];
+          if ((ja[k].x & 0xFFFu) >= J_EXIT) pend &= ~(1u << k);
         }
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0);
-      bool pending = (J[se0].x & 0xFFFu) < J_EXIT;
-      if (lane < ENT - 64) pending |= (J[se1].x & 0xFFFu) < J_EXIT;
-      if (!__any(pending)) break;
+      bool waiting = (J[se0].x & 0xFFFu) < J_EXIT;
+      if (lane < ENT - 64) waiting |= (J[se1].x & 0xFFFu) < J_EXIT;
+      if (!__any(waiting)) break;
     }
     for (int e = lane; e < ENT; e += 64) {
       const uint2 a = J[(e & 1) * SEG + (e >> 1)];
