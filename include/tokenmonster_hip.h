@@ -117,6 +117,14 @@ const uint32_t* tm_batch_device_tokens(const tm_batch* b);
 const uint64_t* tm_batch_device_tok_offsets(const tm_batch* b);
 uint64_t tm_batch_device_bytes(const tm_batch* b);
 
+/* ---- decode: Decode / decode_raw (go/tokenmonster.go:445-550; tokenmonster.cpp:1404-1425) ------------------------ */
+/* ids of document d = tokens[tok_offsets[d] .. tok_offsets[d+1]).  The gather of reverse[id] (lengths -> scan -> copy)
+ * runs on the device; ids >= tm_vocab_n_ids are skipped.  raw != 0: the concatenated token bytes as they are
+ * (decode_raw); raw == 0: capcode decoding is applied afterwards on the host (javascript/tokenmonster.js:1007-1065).
+ * out_offsets[ndocs+1] is always filled; TM_E_NOSPACE if out_cap is too small (required size in out_offsets[ndocs]). */
+int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* tok_offsets, uint32_t ndocs, int raw,
+                    uint8_t* out, uint64_t out_cap, uint64_t* out_offsets);
+
 /* ---- trainvocab scoring pass: replaces training/trainvocab.go:925-1176 ------------------------ */
 /* Upload the normalized dataset once (trainvocab.go:1660-1665 keeps it for the whole run). */
 int tm_dataset_upload(const uint8_t* normalized, uint64_t n, tm_dataset** out);

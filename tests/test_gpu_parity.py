@@ -232,3 +232,39 @@ def test_host_api_edge_cases():
     for d, r in zip(got, raw_docs):
         exp, _ = orc2.tokenize(synth.normalize(r, 2, 1))
         assert d.tolist() == exp.tolist()
+
+
+def test_decode_matches_reference_and_round_trips():
+    # go/tokenmonster.go:445-550 Decode; tokenmonster.cpp:1404-1425 decode_raw / decode
+    img = synth.synth_vocab(synth.ENGLISHCODE, 3000, capcode=2, norm_flag=1, level=3, seed=31)
+    v, orc = tm.Vocab(img), Oracle(img)
+    raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 300_000, seed=17)
+    text, noff = synth.normalize_batch(raw, offs, 2, 1)
+    ids, toff, _ = v.tokenize_packed(text, noff)
+    # decode_raw: concatenated token bytes.  reverse[id] is the LAST record with that id (quirk Q3), so the raw bytes
+    # are not always the normalized text, but they are exactly what the oracle/reference produce ...
+    out_raw, ooff = v.decode_packed(ids, toff, raw=True)
+    nd = noff.size - 1
+    ref = Reference(img) if have_ref() else None
+    for d in range(nd):
+        t = ids[int(toff[d]):int(toff[d + 1])]
+        got = out_raw[int(ooff[d]):int(ooff[d + 1])].tobytes()
+        assert got == orc.decode_raw(t)
+        if ref is not None and d % 5 == 0:
+            assert got == ref.decode_raw(t)
+    # ... and capcode-decoding them gives back the original text (NFD form), like the reference's decode()
+    out, ooff2 = v.decode_packed(ids, toff, raw=False)
+    for d in range(0, nd, 3):
+        got = out[int(ooff2[d]):int(ooff2[d + 1])].tobytes()
+        doc = raw[int(offs[d]):int(offs[d + 1])].tobytes()
+        if ref is not None:
+            import ctypes as C
+            t = np.ascontiguousarray(ids[int(toff[d]):int(toff[d + 1])])
+            buf = np.empty(t.size * 40 + 64, dtype=np.uint8)
+            n = ref.L.tmref_decode(ref.h, t.ctypes.data, t.size, buf.ctypes.data, buf.size)
+            assert got == buf[:n].tobytes()
+        if all(b < 0x80 for b in doc):          # ASCII documents: NFD is the identity, so decode(tokenize(x)) == x
+            assert got == doc
+    # out-of-range ids are skipped (tokenmonster.cpp:1407), empty documents, TM_E_NOSPACE handled by the wrapper
+    weird = np.array([0xFFFFFF, 5, v.n_ids() + 7, 6], dtype=np.uint32)
+    assert v.decode_packed(weird, np.array([0, 0, 4], dtype=np.uint64), raw=True)[0].tobytes() == orc.decode_raw(np.array([5, 6], dtype=np.uint32))

@@ -57,6 +57,7 @@ SIGNATURES = {
     "tm_batch_device_tokens": (vp, [vp]),
     "tm_batch_device_tok_offsets": (vp, [vp]),
     "tm_batch_device_bytes": (C.c_uint64, [vp]),
+    "tm_decode_batch": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint64, vp]),
     "tm_dataset_upload": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "tm_dataset_free": (None, [vp]),
     "tm_score": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, u64p, vp]),

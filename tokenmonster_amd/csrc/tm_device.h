@@ -23,6 +23,8 @@ struct HostVocab {
   std::vector<uint32_t> root;
   std::vector<uint2> tab;           // direct depth-2 map followed by the edge hash (tm_tables.h)
   std::vector<uint2> spl;           // space-prefix links
+  std::vector<uint32_t> rev_off;    // n_ids + 1: reverse[id] = rev_bytes[rev_off[id] .. rev_off[id+1])  (last record wins, go :2715)
+  std::vector<uint8_t> rev_bytes;
   uint32_t edge_mask = 0, edge_shift = 0, n_nodes = 0, off = 1, bstart = kNone;
 };
 
@@ -38,6 +40,8 @@ struct tm_vocab {
   uint32_t* d_root = nullptr;
   uint2* d_tab = nullptr;
   uint2* d_spl = nullptr;
+  uint32_t* d_rev_off = nullptr;
+  uint8_t* d_rev_bytes = nullptr;
   tmh::Row* d_rows = nullptr;
   uint8_t* d_begin_byte = nullptr;
 };

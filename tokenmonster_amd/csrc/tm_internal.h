@@ -20,6 +20,9 @@ int build_vocab_image(const std::vector<std::string>& tokens, const std::vector<
 // tm_normalize.cpp
 void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out);
 
+void capcode_decode_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t threads,
+                          std::vector<std::vector<uint8_t>>& outs);
+
 // small deterministic PRNG (splitmix64 seeding + xoshiro256**), used by the synthetic generators
 struct Rng {
   uint64_t s[4];

@@ -249,6 +249,49 @@ void lower_bytes(std::vector<uint8_t>& b) {  // tokenmonster.cpp:214-229
 
 }  // namespace
 
+// capcode level 2 decoder, javascript/tokenmonster.js:1007-1065 (one-shot form of capcode.Decoder, go/tokenmonster.go:451)
+void capcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+  out.clear();
+  out.reserve(n);
+  bool in_word = false, in_char = false, del = false, ignore = false;
+  size_t i = 0;
+  while (i < n) {
+    const Cp c = next_cp(in + i, n - i);
+    i += (size_t)c.n;
+    if (!c.raw && c.r == 'C') { in_char = true; in_word = false; continue; }
+    if (!c.raw && c.r == 'W') { in_word = true; in_char = false; ignore = true; continue; }
+    if (!c.raw && c.r == 'D') { del = true; continue; }
+    if (!c.raw && c.r == ' ') {
+      if (del) del = false;
+      else { out.push_back(' '); if (!ignore) in_word = false; }
+    } else {
+      const uint8_t cls = classify(c);
+      if (del) del = false;
+      else if (in_char) { in_char = false; if (c.raw) out.push_back((uint8_t)c.r); else put_cp(out, c.r < 0x80 && (cls & kLower) ? c.r - 32 : (uint32_t)u_toupper((UChar32)c.r)); }
+      else if (in_word) {
+        if (cls & (kLower | kUpper)) put_cp(out, c.r < 0x80 ? (cls & kLower ? c.r - 32 : c.r) : (uint32_t)u_toupper((UChar32)c.r));
+        else {
+          if (c.raw) out.push_back((uint8_t)c.r); else put_cp(out, c.r);
+          if (!((cls & kDigit) || (!c.raw && (c.r == '\'' || c.r == 0x2019)) || (cls & kMark))) in_word = false;
+        }
+      } else { if (c.raw) out.push_back((uint8_t)c.r); else put_cp(out, c.r); }
+    }
+    ignore = false;
+  }
+}
+
+// level 1 (marker 0x7F): no in-tree statement; delete the marker and the character after it
+void nocapcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+  out.clear();
+  out.reserve(n);
+  bool del = false;
+  for (size_t i = 0; i < n; i++) {
+    if (in[i] == 0x7F) { del = true; continue; }
+    if (del) { del = false; continue; }
+    out.push_back(in[i]);
+  }
+}
+
 bool normalize_supported(uint32_t capcode, uint32_t norm_flag) {
   return (capcode == 0 || capcode == 2) && (norm_flag & ~3u) == 0;
 }
@@ -259,6 +302,32 @@ void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t n
   else if (norm_flag & 1) nfd_bytes(tmp);                                        // :473
   if (capcode == 2) capcode_encode(tmp.data(), tmp.size(), out);
   else out.swap(tmp);
+}
+
+void capcode_decode_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t threads,
+                          std::vector<std::vector<uint8_t>>& outs) {
+  outs.assign(ndocs, {});
+  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  threads = std::min<uint32_t>(threads, std::max(1u, ndocs));
+  const uint32_t grab = std::max(1u, std::min(64u, ndocs / (threads * 4u)));
+  std::atomic<uint32_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      uint32_t base = next.fetch_add(grab);
+      if (base >= ndocs) break;
+      for (uint32_t d = base; d < std::min(ndocs, base + grab); d++) {
+        const uint8_t* p = text + offsets[d];
+        const size_t n = (size_t)(offsets[d + 1] - offsets[d]);
+        if (capcode == 2) capcode_decode(p, n, outs[d]);
+        else if (capcode == 1) nocapcode_decode(p, n, outs[d]);
+        else outs[d].assign(p, p + n);
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (uint32_t t = 1; t < threads; t++) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
 }
 
 }  // namespace tmh

@@ -151,6 +151,18 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       edges[h] = uint2{key, value_of(kv.second)};
     }
   }
+  // reverse table for decoding: reverse[id] = key of the LAST record carrying that id (go/tokenmonster.go:2715, quirk Q3)
+  {
+    std::vector<uint32_t> last(hv.n_ids, kNone);
+    for (uint32_t i = 0; i < n_info; i++) last[ids[i]] = i;
+    hv.rev_off.assign((size_t)hv.n_ids + 1, 0);
+    hv.rev_bytes.clear();
+    for (uint32_t id = 0; id < hv.n_ids; id++) {
+      hv.rev_off[id] = (uint32_t)hv.rev_bytes.size();
+      if (last[id] != kNone) hv.rev_bytes.insert(hv.rev_bytes.end(), hv.keys.begin() + hv.key_off[last[id]], hv.keys.begin() + hv.key_off[last[id] + 1]);
+    }
+    hv.rev_off[hv.n_ids] = (uint32_t)hv.rev_bytes.size();
+  }
   // space-prefix links: walk ' ' (+ 0x00 for UTF-16) + key through the trie once per record
   {
     const uint32_t off = hv.charset == 2 ? 2u : 1u;
@@ -244,6 +256,8 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
       (e = up((void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2))) != hipSuccess ||
       (e = up((void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row))) != hipSuccess ||
       (e = up((void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint2))) != hipSuccess ||
+      (e = up((void**)&v->d_rev_off, hv.rev_off.data(), hv.rev_off.size() * 4)) != hipSuccess ||
+      (e = up((void**)&v->d_rev_bytes, hv.rev_bytes.data(), hv.rev_bytes.size())) != hipSuccess ||
       (e = up((void**)&v->d_begin_byte, hv.begin_byte, 256)) != hipSuccess) {
     tm_vocab_free(v);
     return hip_fail(e, "vocabulary upload");
@@ -259,7 +273,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
 
 void tm_vocab_free(tm_vocab* v) {
   if (!v) return;
-  (void)hipFree(v->d_root); (void)hipFree(v->d_tab); (void)hipFree(v->d_spl); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
+  (void)hipFree(v->d_root); (void)hipFree(v->d_tab); (void)hipFree(v->d_spl); (void)hipFree(v->d_rev_off); (void)hipFree(v->d_rev_bytes); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
   delete v;
 }
 

@@ -150,6 +150,28 @@ class Vocab:
         res = [ids[int(off[d]): int(off[d + 1])] for d in range(nd)]
         return res[0] if single else res
 
+    def decode_packed(self, ids, tok_offsets, raw=False):
+        """Decode (go/tokenmonster.go:445) of packed id streams -> (bytes u8, offsets u64[D+1]); raw=True: decode_raw"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        tok_offsets = np.ascontiguousarray(tok_offsets, dtype=np.uint64)
+        nd = tok_offsets.size - 1
+        ooff = np.zeros(nd + 1, dtype=np.uint64)
+        cap = int(ids.size * 8 + 64)
+        while True:
+            out = np.empty(cap, dtype=np.uint8)
+            rc = N.lib.tm_decode_batch(self._h, N.ptr(ids), N.ptr(tok_offsets), nd, 1 if raw else 0, N.ptr(out), cap, N.ptr(ooff))
+            if rc == N.TM_E_NOSPACE:
+                cap = int(ooff[nd])
+                continue
+            N.check(rc)
+            return out[: int(ooff[nd])], ooff
+
+    def decode(self, ids):
+        """one id sequence -> bytes (python/tokenmonster.py:341 decode)"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out, _ = self.decode_packed(ids, np.array([0, ids.size], dtype=np.uint64))
+        return out.tobytes()
+
     def count_packed(self, text, offsets):
         """Count (go :971 / :1281): b-branches count once (quirk Q2) -> (counts u64[D], missing u32[D])"""
         text = N.as_u8(text)
