@@ -268,3 +268,39 @@ def test_decode_matches_reference_and_round_trips():
     # out-of-range ids are skipped (tokenmonster.cpp:1407), empty documents, TM_E_NOSPACE handled by the wrapper
     weird = np.array([0xFFFFFF, 5, v.n_ids() + 7, 6], dtype=np.uint32)
     assert v.decode_packed(weird, np.array([0, 0, 4], dtype=np.uint64), raw=True)[0].tobytes() == orc.decode_raw(np.array([5, 6], dtype=np.uint32))
+
+
+def test_full_size_properties():
+    """BASELINE-size shapes cannot be re-walked by the oracle in seconds; check size-independent properties instead:
+    batch-split invariance, decode round trip, a random sample against the oracle, end-to-end == host-normalized path."""
+    name = "englishcode-32000-consistent"
+    kind, size, capcode, norm_flag, level, seed = synth.CONFIGS[name]
+    v, orc = tm.Vocab(synth.config_vocab(name)), Oracle(synth.config_vocab(name))
+    raw, offs = synth.synth_corpus(kind, 256 << 20, seed=0x434F5250 + 77)
+    text, noff = synth.normalize_batch(raw, offs, capcode, norm_flag)
+    nd = noff.size - 1
+    ids, toff, missing = v.tokenize_packed(text, noff)
+    assert int(missing.sum()) == 0 and toff[-1] == ids.size
+    # (1) the same documents tokenized in two separate batches give the same ids (no cross-document / cross-segment leakage)
+    h = nd // 2
+    a_ids, a_off, _ = v.tokenize_packed(text[: int(noff[h])], noff[: h + 1])
+    b_ids, b_off, _ = v.tokenize_packed(text[int(noff[h]):], noff[h:] - noff[h])
+    assert a_ids.size + b_ids.size == ids.size and (np.concatenate([a_ids, b_ids]) == ids).all()
+    # (2) raw text through the device normalizer gives the same ids as the host-normalized path
+    got = v.tokenize([raw[int(offs[d]):int(offs[d + 1])].tobytes() for d in range(0, nd, 97)])
+    for k, d in enumerate(range(0, nd, 97)):
+        assert (got[k] == ids[int(toff[d]):int(toff[d + 1])]).all()
+    # (3) decode round trip on every ASCII document (NFD is the identity there): decode(tokenize(x)) == x
+    out, ooff = v.decode_packed(ids, toff, raw=False)
+    n_ascii = 0
+    for d in range(nd):
+        doc = raw[int(offs[d]):int(offs[d + 1])]
+        if doc.size and int(doc.max()) < 0x80:
+            n_ascii += 1
+            assert out[int(ooff[d]):int(ooff[d + 1])].tobytes() == doc.tobytes(), "document %d does not round-trip" % d
+    assert n_ascii > nd // 4
+    # (4) a random sample against the oracle
+    rng = np.random.default_rng(5)
+    for d in rng.choice(nd, size=150, replace=False):
+        exp, _ = orc.tokenize(text[int(noff[d]):int(noff[d + 1])])
+        assert (ids[int(toff[d]):int(toff[d + 1])] == exp).all()
