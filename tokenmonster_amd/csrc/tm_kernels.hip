@@ -248,7 +248,7 @@ __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w
 }
 
 constexpr int NWALK = 2;                 // independent trie walks in flight per lane
-constexpr int REFILL_THR = 32;           // K1 refills idle lanes when fewer than this many (per walk slot) are still walking
+constexpr int REFILL_THR = 24;           // K1 refills idle lanes when fewer than this many (per walk slot) are still walking
 
 __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
@@ -306,20 +306,28 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
 #pragma unroll
     for (int s = 0; s < NWALK; s++) k[s] = Walk{0, 0, 0, 0, 0, 0u, 0u, 0u, 0u, false};
     for (;;) {
-      // refill: idle slots take the next positions; the direct map answers the first two bytes
-      for (int rep = 0; rep < 2 && next_task < ntask; rep++) {
+      // refill: idle slots take the next positions; the direct map answers the first two bytes.  The gathers of all
+      // slots are issued together (one latency per refill phase).
+      if (next_task < ntask) {
+        int tp[NWALK], tlimit[NWALK];
+        bool take[NWALK];
+        uint2 te[NWALK];
 #pragma unroll
         for (int s = 0; s < NWALK; s++) {
-          if (next_task >= ntask) break;
           const unsigned long long wmask = __ballot(!k[s].active);
-          if (wmask == 0) continue;
-          const int p = next_task + __popcll(wmask & lane_below);
+          tp[s] = next_task + __popcll(wmask & lane_below);
           next_task += __popcll(wmask);
-          if (!k[s].active && p < ntask) {
-            const int limit = min(dl - p, Lmax);
-            uint2 e;
-            if (limit >= 2) e = T.tab[((uint32_t)w.text[p] << 8) | w.text[p + 1]];
-            else { const uint32_t r = s_root[w.text[p]]; e = make_uint2((r != kNone && node_id(r) < T.n_info) ? 1u : 0u, r); }
+          take[s] = !k[s].active && tp[s] < ntask;
+          tlimit[s] = take[s] ? min(dl - tp[s], Lmax) : 0;
+          te[s] = make_uint2(0u, 0u);
+          if (take[s] && tlimit[s] >= 2) te[s] = T.tab[((uint32_t)w.text[tp[s]] << 8) | w.text[tp[s] + 1]];
+        }
+#pragma unroll
+        for (int s = 0; s < NWALK; s++) {
+          if (take[s]) {
+            const int p = tp[s], limit = tlimit[s];
+            uint2 e = te[s];
+            if (limit < 2) { const uint32_t r = s_root[w.text[p]]; e = make_uint2((r != kNone && node_id(r) < T.n_info) ? 1u : 0u, r); }
             const int bestlen = (int)(e.x & 3u), depth = 2;
             const uint32_t bestv = e.y, nid = e.x >> 3;
             const bool cont = (e.x & 4u) != 0;
