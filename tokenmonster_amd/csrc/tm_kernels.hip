@@ -140,10 +140,20 @@ __global__ void k_segments(const uint64_t* __restrict__ doc_seg_start, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // K1: match + branch
 // ------------------------------------------------------------------------------------------------
-// descriptor word kept in LDS per position: len[0..5] | nWords[6..10] | flag5[11..15] | nextByteClass[16..19]
-// (nWords|flag5 are bits 22..31 of the node value, so a descriptor is (v >> 22) << 6 | len)
-__device__ __forceinline__ uint32_t make_desc(uint32_t len, uint32_t v, uint32_t nb) {
-  return len | ((v >> 22) << 6) | (nb << 16);
+// While the walks run, D[p] holds len[0..5] | nWords[6..10] | flag5[11..15] (bits 22..31 of the node value, shifted).
+// Step A2 then folds everything a *second* token contributes to a branch score (go/tokenmonster.go:1075-1084) into the
+// final descriptor, so that scoring a branch is a handful of adds instead of re-deriving it six times per state:
+//   len[0..5] | beginsWithLetter[6] | beginsOnCapcode[7] | S[8..19]
+//   S + 4 = len + allLetters/allPunct + max0(nWords-1) + beginsWithSpace (plain look-up only) + nextIsSpace
+//           + (nWords + nextIsNotLetter) * 100 - 3 * (endsWithLetter & nextIsLetter)
+// (the two cross terms of the penalty need the first token: begins-with-letter and begins-on-capcode stay as bits).
+__device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_t nb, bool bvariant) {
+  const uint32_t f5 = v >> 27, snw = (v >> 22) & 31u;
+  const int send = (int)(f5 & 1u), sbegl = (int)((f5 >> 1) & 1u), sbegs = (int)((f5 >> 2) & 1u), sbegc = (int)((f5 >> 3) & 1u),
+            sall = (int)((f5 >> 4) & 1u);
+  const int S = (int)len + sall + max((int)snw - 1, 0) + (bvariant ? 0 : sbegs) + (int)((nb >> 2) & 1u) + ((int)snw + (int)(nb >> 3)) * 100 -
+                (send & (int)(nb & 1u)) * 3;
+  return len | ((uint32_t)sbegl << 6) | ((uint32_t)sbegc << 7) | ((uint32_t)(S + 4) << 8);
 }
 
 // one in-flight trie walk of a lane: text byte number d of the string being matched is text[tbase + d]
@@ -175,24 +185,20 @@ __device__ __forceinline__ bool walk_consume(const Tables& T, const uint8_t* tex
   return was && !k.active;
 }
 
-struct First { int flen; int nw; uint32_t f3; };   // candidate first token: length consumed, nWords - fd, flag bits {1, 8>>3, 128>>7}
+// candidate first token of a branch: bytes consumed, and what it contributes to the score on its own:
+// fpart = flen + allLetters + max0(w-1) + w*100 with w = nWords - fd (go :1071,1117,1169)
+struct First { int flen; int fpart; int fend; int fcap; };
 
-// score of one branch, go/tokenmonster.go:1075-1084 (a), :1096-1105 (b); k > 0 adds :1132-1133
+__device__ __forceinline__ First make_first(int flen, int w, uint32_t f3) {
+  return First{flen, flen + (int)((f3 >> 2) & 1u) + max(w - 1, 0) + w * 100, (int)(f3 & 1u), (int)((f3 >> 1) & 1u)};
+}
+
+// score of one branch, go/tokenmonster.go:1075-1084 (plain), :1096-1105 (forward-delete variant); alternatives add :1132-1133
 __device__ __forceinline__ int branch_score(const First& F, uint32_t dS, bool bvariant, bool alt, int len) {
-  int l = (int)(dS & 63u);
-  uint32_t f5 = (dS >> 11) & 31u;
-  int snw = (int)((dS >> 6) & 31u);
-  int nb = (int)((dS >> 16) & 15u);
-  int BL = F.flen + l;
-  int fend = (int)(F.f3 & 1u), fcap = (int)((F.f3 >> 1) & 1u), fall = (int)((F.f3 >> 2) & 1u);
-  int send = (int)(f5 & 1u), sbegl = (int)((f5 >> 1) & 1u), sbegs = (int)((f5 >> 2) & 1u), sbegc = (int)((f5 >> 3) & 1u),
-      sall = (int)((f5 >> 4) & 1u);
-  int sc = BL + fall + sall + max(F.nw - 1, 0) + max(snw - 1, 0) + ((nb >> 2) & 1) + (F.nw + snw + (nb >> 3)) * 100;
-  if (!bvariant) sc += sbegs;
-  int pen = (fcap & sbegc) * 100 + (send & nb & 1) * 3;
-  pen += bvariant ? fend * 103 + 1 : (fend & sbegl) * 103;
-  if (alt) pen += (BL < len ? 100 : 0) + (BL == len ? 10000 : 0);
-  return sc - pen;
+  const int l = (int)(dS & 63u), sbegl = (int)((dS >> 6) & 1u), sbegc = (int)((dS >> 7) & 1u), S = (int)((dS >> 8) & 0xFFFu) - 4;
+  int sc = F.fpart + S - (F.fcap & sbegc) * 100 - (bvariant ? F.fend * 103 + 1 : (F.fend & sbegl) * 103);
+  if (alt) { const int BL = F.flen + l; sc -= (BL < len ? 100 : 0) + (BL == len ? 10000 : 0); }
+  return sc;
 }
 
 struct WaveLds {
@@ -215,9 +221,9 @@ __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w
     int s[6] = {NOSCORE, NOSCORE, NOSCORE, NOSCORE, NOSCORE, NOSCORE};   // s1 s2 s3 s1b s2b s3b
     int best = NOSCORE;
     First F[3];
-    F[0] = {len, (int)(O.y >> 24) - fd, (oflag & 1u) | (((oflag >> 3) & 1u) << 1) | (((oflag >> 7) & 1u) << 2)};
-    F[1] = {len1 - fd, (int)((O.w >> 6) & 31u) - fd, (O.w >> 16) & 7u};
-    F[2] = {len2 - fd, (int)((O.w >> 11) & 31u) - fd, (O.w >> 19) & 7u};
+    F[0] = make_first(len, (int)(O.y >> 24) - fd, (oflag & 1u) | (((oflag >> 3) & 1u) << 1) | (((oflag >> 7) & 1u) << 2));
+    F[1] = make_first(len1 - fd, (int)((O.w >> 6) & 31u) - fd, (O.w >> 16) & 7u);
+    F[2] = make_first(len2 - fd, (int)((O.w >> 11) & 31u) - fd, (O.w >> 19) & 7u);
     const int nk = len1 == 0 ? 1 : (len2 == 0 ? 2 : 3);                                      // go :1111, :1163
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -381,9 +387,8 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       bool el = false;
       if (d != 0) {
         const uint32_t nb = s_bb[w.text[p + (d & 63u)]];
-        d |= nb << 16;
-        w.D[p] = d;
         el = can_b && ((d >> 12) & 1u) && nb == 1 && ((d >> 6) & 31u) == 0 && min(dl - p, Lmax - off) > 0;
+        w.D[p] = make_sdesc(d & 63u, (d >> 6) << 22, nb, false);
       }
       elig[it] = __ballot(el);
     }
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
             k[s].haddr = k[s].h32 >> T.edge_shift;
           } else if (e.x != kNone && bl > (int)ml + 1) {               // (only possible with the two-byte UTF-16 prefix)
             const int lb = bl - off;
-            w.Db[p] = make_desc((uint32_t)lb, e.y, s_bb[w.text[p + lb]]);
+            w.Db[p] = make_sdesc((uint32_t)lb, e.y, s_bb[w.text[p + lb]], true);
             if (p < SEG) w.Xb[p] = e.y;
           }
         }
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
         for (int s = 0; s < NWALK; s++) {
           if (walk_consume(T, w.text, k[s], e[s]) && k[s].bestlen > mainlen[s] + 1) {
             const int lb = k[s].bestlen - off;                              // go :1093
-            w.Db[k[s].pos] = make_desc((uint32_t)lb, k[s].bestv, s_bb[w.text[k[s].pos + lb]]);
+            w.Db[k[s].pos] = make_sdesc((uint32_t)lb, k[s].bestv, s_bb[w.text[k[s].pos + lb]], true);
             if (k[s].pos < SEG) w.Xb[k[s].pos] = k[s].bestv;
           }
           any |= k[s].active;
