@@ -304,3 +304,39 @@ def test_full_size_properties():
     for d in rng.choice(nd, size=150, replace=False):
         exp, _ = orc.tokenize(text[int(noff[d]):int(noff[d + 1])])
         assert (ids[int(toff[d]):int(toff[d + 1])] == exp).all()
+
+
+def test_batch_workspace_reuse():
+    """one tm_batch reused for different uploads (normalized and raw), like a long-lived server worker would"""
+    import ctypes as C
+    from tokenmonster_amd import _native as N
+    img = synth.synth_vocab(synth.ENGLISHCODE, 2000, capcode=2, norm_flag=1, level=3, seed=12)
+    v, orc = tm.Vocab(img), Oracle(img)
+    b = C.c_void_p()
+    N.check(N.lib.tm_batch_create(v.handle, 4 << 20, 4096, C.byref(b)))
+    try:
+        for trial, nbytes in enumerate((300_000, 20_000, 900_000, 0, 150_000)):
+            raw, offs = synth.synth_corpus(synth.ENGLISHCODE, max(nbytes, 1), seed=100 + trial) if nbytes else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+            text, noff = synth.normalize_batch(raw, offs, 2, 1)
+            nd = noff.size - 1
+            if trial % 2 == 0:
+                N.check(N.lib.tm_batch_upload(b, N.ptr(text), N.ptr(noff), nd))
+            else:
+                N.check(N.lib.tm_batch_upload_raw(b, N.ptr(raw), N.ptr(offs), nd))
+                N.check(N.lib.tm_batch_normalize(b, None))
+            N.check(N.lib.tm_batch_run(b, None))
+            ntok, nmiss = C.c_uint64(), C.c_uint64()
+            N.check(N.lib.tm_batch_totals(b, C.byref(ntok), C.byref(nmiss)))
+            ids = np.empty(max(int(ntok.value), 1), dtype=np.uint32)
+            toff = np.zeros(nd + 1, dtype=np.uint64)
+            miss = np.zeros(max(nd, 1), dtype=np.uint32)
+            N.check(N.lib.tm_batch_download(b, N.ptr(ids), int(ntok.value), N.ptr(toff), N.ptr(miss)))
+            for d in range(nd):
+                exp, m = orc.tokenize(text[int(noff[d]):int(noff[d + 1])])
+                assert (ids[int(toff[d]):int(toff[d + 1])] == exp).all() and int(miss[d]) == m
+        # a batch larger than the workspace is refused, not truncated
+        raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 6 << 20, seed=9)
+        text, noff = synth.normalize_batch(raw, offs, 2, 1)
+        assert N.lib.tm_batch_upload(b, N.ptr(text), N.ptr(noff), noff.size - 1) == N.TM_E_LIMIT
+    finally:
+        N.lib.tm_batch_free(b)
