@@ -154,6 +154,7 @@ def test_device_normalizer_matches_host_and_reference():
         extra.append(s.encode())
     extra += [b"", b"A", b"a", b"AB", b"Ab", b"aB", b"ABc", b"ABC", b" ABC d", b"HTTPServer2Go x", b"X's Y'S it's 'a' I'M", b"12AB34cd", b"A1B2c",
               "X’s Y’S it’s".encode(), b"A" * 200 + b"b", b"A" * 200, b"a" + b"B" * 130 + b" " + b"C" * 70 + b"d", "café Über".encode(),
+              b"A" * 3000 + b"b", b"xY" * 2500, b"Q" * 5000,          # expand beyond a piece's 2 KiB slab: exact two-pass path
               b"\xff\xfe bad bytes", "  en quad".encode()]
     etext, eoffs = tm.pack_documents(extra)
     for text_in, offs_in in ((raw, offs), (etext, eoffs)):

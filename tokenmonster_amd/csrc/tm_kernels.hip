@@ -887,6 +887,8 @@ struct tm_batch {
   uint4* d_group_base = nullptr;
   // raw (un-normalized) input of tm_batch_upload_raw / tm_batch_normalize
   uint8_t* d_raw = nullptr;
+  uint8_t* d_slab = nullptr;            // normalizer: one 2 KiB slab per 1 KiB piece
+  uint64_t slab_cap = 0;
   uint64_t* d_raw_off = nullptr;
   uint64_t raw_cap = 0, raw_bytes = 0, raw_pieces = 0, piece_cap = 0;
   uint32_t raw_docs = 0, raw_docs_cap = 0;
@@ -1096,7 +1098,7 @@ void tm_batch_free(tm_batch* b) {
   void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R, b->d_exitmap, b->d_seg_entry,
                   b->d_seg_tokbase, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
                   b->d_error, b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
-                  b->d_raw, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,
+                  b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,
                   b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_raw, b->d_fb_norm, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids};
   for (void* p : ptrs) (void)hipFree(p);
   if (b->have_events) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
@@ -1538,27 +1540,32 @@ __global__ void k_norm_carry(const uint32_t* __restrict__ piece_sum, const uint6
   if (bad) atomicAdd(&ninfo[0], 1ull);
 }
 
-// WRITE == false: normalized length of every piece.  WRITE == true: the bytes.
-template <bool WRITE>
+// MODE 0: normalized length of every piece.  MODE 1: the bytes, packed at piece_off.  MODE 2: the bytes into the piece's
+// private slab (SLAB bytes apart; a piece that would not fit raises the overflow flag) and the length — the common
+// one-pass path; k_norm_compact then packs the slabs.
+constexpr int SLAB = 2 * PIECE;
+template <int MODE>
 __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rbegin,
                                                    const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
                                                    const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t capcode,
                                                    uint32_t lower_all, const uint8_t* __restrict__ piece_carry,
                                                    const uint8_t* __restrict__ need_host, uint32_t* __restrict__ piece_len,
-                                                   const uint64_t* __restrict__ piece_off, uint8_t* __restrict__ out) {
+                                                   const uint64_t* __restrict__ piece_off, uint8_t* __restrict__ out,
+                                                   unsigned long long* __restrict__ overflow) {
+  constexpr bool WRITE = MODE != 0;
   __shared__ PieceLds s_l[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
   if (k >= npieces) return;
   PieceLds& L = s_l[wv];
   const uint32_t d = piece_doc[k];
-  if (need_host[d]) { if (!WRITE && lane == 0) piece_len[k] = 0; return; }
+  if (need_host[d]) { if (MODE != 1 && lane == 0) piece_len[k] = 0; return; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
   const int m = norm_load_piece(L, raw, rb, re, pb, lane, lower_all != 0);
-  uint8_t* dst = WRITE ? out + piece_off[k] : nullptr;
+  uint8_t* dst = MODE == 1 ? out + piece_off[k] : (MODE == 2 ? out + k * (uint64_t)SLAB : nullptr);
   if (capcode != 2) {                                       // no capcode: same length, only the lower-case flag applies
-    if (!WRITE) { if (lane == 0) piece_len[k] = (uint32_t)m; }
-    else for (int i = lane; i < m; i += 64) { uint32_t b = L.raw[PMARGIN + i]; if (lower_all && b - 'A' < 26u) b |= 0x20u; dst[i] = (uint8_t)b; }
+    if (MODE != 1 && lane == 0) piece_len[k] = (uint32_t)m;
+    if (WRITE) for (int i = lane; i < m; i += 64) { uint32_t b = L.raw[PMARGIN + i]; if (lower_all && b - 'A' < 26u) b |= 0x20u; dst[i] = (uint8_t)b; }
     return;
   }
   const uint32_t carry = piece_carry[k];
@@ -1650,7 +1657,7 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
     }
     uint32_t incl = len;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (WRITE && in) {
+    if (WRITE && in && (MODE == 1 || pos + incl <= (uint32_t)SLAB)) {
       uint8_t* w = dst + pos + (incl - len);
       if (len == 4) { w[0] = (uint8_t)o0; w[1] = (uint8_t)o1; w[2] = (uint8_t)o2; w[3] = (uint8_t)o3; }
       else if (len == 3) { w[0] = (uint8_t)o1; w[1] = (uint8_t)o2; w[2] = (uint8_t)o3; }
@@ -1659,7 +1666,25 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
     }
     pos += __shfl(incl, 63);
   }
-  if (!WRITE && lane == 0) piece_len[k] = pos;
+  if (MODE != 1 && lane == 0) {
+    piece_len[k] = pos;
+    if (MODE == 2 && pos > (uint32_t)SLAB) atomicAdd(overflow, 1ull);
+  }
+}
+
+// pack the slabs: piece k's bytes go to out[piece_off[k] ..)
+__global__ __launch_bounds__(256) void k_norm_compact(const uint8_t* __restrict__ slab, const uint32_t* __restrict__ piece_len,
+                                                      const uint64_t* __restrict__ piece_off, uint64_t npieces, uint8_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= npieces) return;
+  const uint32_t len = piece_len[k];
+  const uint8_t* src = slab + k * (uint64_t)SLAB;
+  uint8_t* dst = out + piece_off[k];
+  for (uint32_t i = (uint32_t)lane * 16u; i < len; i += 64u * 16u) {
+    if (i + 16u <= len) { uint4 q; __builtin_memcpy(&q, src + i, 16); __builtin_memcpy(dst + i, &q, 16); }
+    else for (uint32_t j = i; j < len; j++) dst[j] = src[j];
+  }
 }
 
 // normalized range of every device-normalized document; segment / long-document counts
@@ -1743,6 +1768,7 @@ int tm_batch_upload_raw(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
         (e = hipMalloc((void**)&b->d_piece_off, (b->piece_cap + 1) * 8)) != hipSuccess)
       return hip_fail(e, "hipMalloc (pieces)");
   }
+  if ((e = grow(&b->d_slab, &b->slab_cap, (npieces + 1) * (uint64_t)SLAB)) != hipSuccess) return hip_fail(e, "hipMalloc (normalizer slabs)");
   if (nbytes && (e = hipMemcpy(b->d_raw, raw, nbytes, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D raw text");
   if (ndocs && (e = hipMemcpy(b->d_raw_off, raw_offsets, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D raw offsets");
   b->h_raw_off.assign(raw_offsets, raw_offsets + (ndocs ? ndocs + 1 : 0));
@@ -1782,19 +1808,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     k_norm_summary<<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_sum);
   }
   k_norm_carry<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo);
-  if (np > 0)
-    k_norm_emit<false><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                              b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, nullptr);
-  scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
-  unsigned long long h_info[3] = {0, 0, 0};
-  uint64_t gpu_bytes = 0;
-  if ((e = hipMemcpyAsync(h_info, ninfo, 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(&gpu_bytes, b->d_totals + 2, 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "normalize (lengths)");
-  if (gpu_bytes > b->max_bytes)
-    return set_error(TM_E_LIMIT, "normalized text needs %llu bytes, workspace sized for %llu", (unsigned long long)gpu_bytes, (unsigned long long)b->max_bytes);
+  unsigned long long h_info[4] = {0, 0, 0, 0};
+  if ((e = hipMemcpyAsync(h_info, ninfo, 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
+    return hip_fail(e, "normalize (summaries)");
   const double t1 = now();
-  uint64_t total = gpu_bytes;
   const uint32_t nf = (uint32_t)h_info[0];
   std::vector<uint32_t> ids;
   std::vector<uint64_t> roff;
@@ -1826,20 +1843,40 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
       return hip_fail(e, "D2H fallback documents");
     f2 = now();
   }
-  // the device writes its documents ...
+  // the device normalizes its documents (one pass into per-piece slabs, lengths on the side) ...
   if (np > 0)
-    k_norm_emit<true><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                             b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text);
-  k_norm_ranges<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);
+    k_norm_emit<2><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+                                          b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3);
+  scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
+  uint64_t gpu_bytes = 0;
+  // ... while the host normalizes the others; they are appended after the device part
+  uint8_t* hnorm = nullptr;
+  std::vector<uint64_t> noff(ids.size() + 1, 0);
   if (nf > 0) {
-    // ... while the host normalizes the others; they are appended after the device part
-    uint8_t* hnorm = nullptr;
-    std::vector<uint64_t> noff(ids.size() + 1);
-    const uint32_t threads = (uint32_t)std::min<size_t>(32, ids.size() / 8 + 1);
+    const uint32_t threads = (uint32_t)std::min<size_t>(64, ids.size() / 8 + 1);
     int rc = tm_normalize_batch(hraw.data(), roff.data(), (uint32_t)ids.size(), capcode, norm_flag, threads, &hnorm, noff.data());
     if (rc != TM_OK) return rc;
     f3 = now();
-    if (total + noff.back() > b->max_bytes) { tm_free(hnorm); return set_error(TM_E_LIMIT, "normalized text does not fit the workspace"); }
+  }
+  if ((e = hipMemcpyAsync(h_info, ninfo, 32, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(&gpu_bytes, b->d_totals + 2, 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipStreamSynchronize(st)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "normalize (device pass)"); }
+  if (gpu_bytes + noff.back() > b->max_bytes) {
+    tm_free(hnorm);
+    return set_error(TM_E_LIMIT, "normalized text needs %llu bytes, workspace sized for %llu", (unsigned long long)(gpu_bytes + noff.back()), (unsigned long long)b->max_bytes);
+  }
+  if (np > 0) {
+    if (h_info[3] == 0) {
+      k_norm_compact<<<pgrid, 256, 0, st>>>(b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text);
+    } else {
+      // some piece expands beyond its slab (long runs of capitals): exact two-pass path
+      k_norm_emit<1><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+                                            b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text, nullptr);
+    }
+  }
+  k_norm_ranges<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);
+  uint64_t total = gpu_bytes;
+  if (nf > 0) {
     if ((e = grow(&b->d_fb_norm, &b->fb_norm_cap, noff.back() + 16)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "hipMalloc (fallback output)"); }
     if ((e = hipMemcpyAsync(b->d_fb_norm, hnorm, noff.back(), hipMemcpyHostToDevice, st)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_fb_noff, noff.data(), noff.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "H2D fallback output"); }
@@ -1849,7 +1886,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     total += noff.back();
     b->host_fallback_docs = (uint32_t)ids.size();
     f4 = now();
-    if (trace) fprintf(stderr, "[fallback] flags+gather+D2H %.2f ms, host normalize %.2f ms, H2D+place (+wait for the write pass) %.2f ms\n", f2 - f1, f3 - f2, f4 - f3);
+    if (trace) fprintf(stderr, "[fallback] flags+gather+D2H %.2f ms, host normalize (overlaps the device pass) %.2f ms, wait + H2D + place %.2f ms\n", f2 - f1, f3 - f2, f4 - f3);
   }
   const double t2 = now();
   // ---- what the tokenize pipeline needs to know on the host: #segments, and the long documents if any ------------
@@ -1865,7 +1902,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
         (e = hipMemcpy(he.data(), b->d_nend, (size_t)nd * 8, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H ranges");
     rc = build_groups(b, hb.data(), he.data(), nd);
   }
-  if (trace) fprintf(stderr, "[tm_batch_normalize] lengths %.2f ms, write + host fallback (%u docs) %.2f ms, info %.2f ms\n", t1 - t0, nf, t2 - t1, now() - t2);
+  if (trace) fprintf(stderr, "[tm_batch_normalize] summaries %.2f ms, device pass + host fallback (%u docs) %.2f ms, info %.2f ms\n", t1 - t0, nf, t2 - t1, now() - t2);
   return rc;
 }
 
