@@ -45,7 +45,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(img, text, offs, sample_mb, log):
+def cpu_baseline(img, text, offs, sample_mb, log, raw_mode=False):
     """the reference's own C++ runtime (oracle/_ref, kind 'reference') — or our C port when it is absent — timed
     single-threaded on a bounded sample of the SAME normalized documents, the way benchmark/tokenmonster_bench.go
     :41-55 times Go: wall clock around tokenize calls."""
@@ -53,7 +53,8 @@ def cpu_baseline(img, text, offs, sample_mb, log):
     import oracle_bind as ob
     kind = "reference" if ob.have_ref() else "port"
     eng = ob.Reference(img) if kind == "reference" else ob.Oracle(img)
-    fn = eng.tokenize_normalized if kind == "reference" else eng.tokenize
+    # raw_mode: `text` is RAW UTF-8 and the reference's full Tokenize (normalize + capcode + walk) is timed
+    fn = (eng.tokenize if raw_mode else eng.tokenize_normalized) if kind == "reference" else eng.tokenize
     budget = int(sample_mb * (1 << 20)) if kind == "reference" else int(sample_mb * (1 << 20) / 8)
     nd = offs.size - 1
     done = 0
@@ -68,7 +69,8 @@ def cpu_baseline(img, text, offs, sample_mb, log):
         d += 1
     dt = time.perf_counter() - t0
     res = {"value": round(done / dt / 1e9, 6), "unit": "GB/s", "cores": 1, "kind": kind,
-           "sample": "first %d documents (%.1f MB normalized) of the same corpus, 1 thread, %.1f s" % (d, done / 1e6, dt),
+           "sample": "first %d documents (%.1f MB %s) of the same corpus, 1 thread, %.1f s" % (
+               d, done / 1e6, "raw, Tokenize = normalize + capcode + walk" if raw_mode else "normalized, tokenize_normalized", dt),
            "host_cores": os.cpu_count()}
     log("cpu_baseline: %s" % res)
     return res
@@ -330,7 +332,11 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(img, text, offs, args.cpu_sample_mb, log)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        if args.hot_path_only or not __import__("oracle_bind").have_ref():
+            cpu = cpu_baseline(img, text, offs, args.cpu_sample_mb, log)
+        else:
+            cpu = cpu_baseline(img, raw, roffs, args.cpu_sample_mb, log, raw_mode=True)
 
     if rank == 0:
         value = all_raw * args.steps / elapsed / 1e9
