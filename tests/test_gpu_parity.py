@@ -34,6 +34,24 @@ def test_unit_golden_vector():
     assert enc == 2 and b.tolist() == [3, 0]
 
 
+def test_fuzz_capcode1_vocab():
+    # capcode level 1: delete marker 0x7F only (go/tokenmonster.go:273, :3436, :3480); tokens "\x7F "+word exist
+    rng = np.random.default_rng(4242)
+    toks = [t.replace(b"D", b"\x7f").replace(b"C", b"c").replace(b"W", b"w") for t in fuzz_vocab_tokens(rng, 2, 160)] + [b"\x7f"]
+    img = synth.build_vocab(toks, capcode=1, charset=1)
+    v, orc = tm.Vocab(img), Oracle(img)
+    assert v.capcode() == 1 and v.delete_token_id() is not None
+    oracle_stats(reset=True)
+    docs = [fuzz_text(rng, 2, int(n)).replace(b"D", b"\x7f").replace(b"C", b"c").replace(b"W", b"w") for n in rng.integers(0, 2500, size=80)]
+    check_docs(v, orc, docs, "capcode 1")
+    st = oracle_stats()
+    assert st["s1"] > 0 and st["s2"] > 0 and st["s1b"] + st["s2b"] + st["s3b"] > 0, st
+    if have_ref():
+        ref = Reference(img)
+        for d in docs[::7]:
+            assert v.tokenize_normalized(d)[0].tolist() == ref.tokenize_normalized(d)[0].tolist()
+
+
 @pytest.mark.parametrize("capcode", [0, 2])
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_fuzz_micro_vocab(capcode, seed):
