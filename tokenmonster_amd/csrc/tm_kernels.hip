@@ -25,23 +25,9 @@
 #include <cstring>
 #include <vector>
 
-#include "tm_device.h"
-#include "tm_build.h"
+#include "tm_pipeline.h"
 
 namespace tmh {
-
-constexpr int SEG = 320;                 // bytes of one document segment (one wavefront); 320 -> 24 wavefronts per CU
-constexpr int NPOS = SEG + 40;           // positions whose descriptors a segment needs (look-ahead <= 40)
-constexpr int NPOS_PAD = (NPOS + 63) / 64 * 64;
-constexpr int TEXT_LEN = SEG + 96;       // staged text: position i may read up to i + 40
-constexpr int ENT = 80;                  // entry states of a segment: 40 offsets x fd{0,1}
-constexpr int WAVES = 4;                 // wavefronts per workgroup in K1 (plain variant)
-constexpr uint32_t R_INVALID = 0xFFFFFFFFu;
-constexpr uint32_t J_EXIT = 1024;           // jump targets >= J_EXIT: left the segment; J_EXIT + next entry state
-constexpr uint32_t J_INVALID = 4095;        // state is not reachable (no forward-delete match there)
-constexpr uint32_t ID_NONE = 0xFFFFFFu;
-constexpr int NOSCORE = -1000000;
-constexpr uint32_t LONG_SEGS = 512;        // documents with more segments than this are resolved hierarchically
 
 // R word: id[0..23] | advance[24..29] | fd'[30] | missing[31]
 
@@ -59,8 +45,7 @@ __global__ void k_doc_nseg(const uint64_t* __restrict__ doc_begin, const uint64_
   }
 }
 
-// exclusive scan u32 -> u64, three phases, CH elements per block
-constexpr int SCAN_T = 256, SCAN_PER = 16, SCAN_CH = SCAN_T * SCAN_PER;
+// exclusive scan u32 -> u64, three phases, SCAN_CH elements per block
 
 __global__ void k_scan_partial(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ block_sums) {
   __shared__ uint64_t s[SCAN_T];
@@ -607,8 +592,6 @@ __global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __r
 // states at once (one lane per entry state), k_long_top chains the ~sqrt(S) group maps per document, and
 // k_group_expand replays every group from its now known entry state.  Exit-map composition is associative, so the
 // result is the same as the serial chain.
-struct Group { uint32_t first_seg, nsegs, doc, pad; };
-struct LongDoc { uint32_t doc, first_group, ngroups, pad; };
 
 __global__ __launch_bounds__(128) void k_group_compose(const uint2* __restrict__ exitmap, const Group* __restrict__ groups,
                                                        uint4* __restrict__ gmap) {
@@ -841,89 +824,38 @@ __global__ void k_serialize(const uint32_t* __restrict__ ids, uint64_t n, uint32
 
 }  // namespace tmh
 
-namespace tmh {
-bool normalize_supported(uint32_t capcode, uint32_t norm_flag);
-}  // namespace tmh
 using namespace tmh;
 
 // ------------------------------------------------------------------------------------------------
 // tm_batch
 // ------------------------------------------------------------------------------------------------
-struct tm_batch {
-  const tm_vocab* vocab = nullptr;
-  uint64_t max_bytes = 0;
-  uint32_t max_docs = 0;
-  uint64_t max_segs = 0;
-  uint64_t nbytes = 0, nseg = 0;
-  uint32_t ndocs = 0;
-  uint64_t device_bytes = 0;
-  hipStream_t last_stream = nullptr;
-  // device buffers
-  uint8_t* d_text = nullptr;
-  bool text_borrowed = false;          // scoring pass: text belongs to a tm_dataset
-  uint64_t* d_offsets = nullptr;       // packed batches: doc_begin = d_offsets, doc_end = d_offsets + 1
-  const uint64_t* d_doc_begin = nullptr;
-  const uint64_t* d_doc_end = nullptr;
-  uint32_t* d_doc_nseg = nullptr;
-  uint64_t* d_doc_seg_start = nullptr;
-  uint32_t* d_seg_doc = nullptr;
-  uint2* d_R = nullptr;
-  uint2* d_exitmap = nullptr;
-  uint8_t* d_seg_entry = nullptr;
-  uint32_t* d_seg_tokbase = nullptr;
-  uint32_t* d_doc_ntok = nullptr;
-  uint32_t* d_doc_events = nullptr;
-  uint32_t* d_doc_missing = nullptr;
-  uint64_t* d_tok_offsets = nullptr;
-  uint64_t* d_scan_tmp = nullptr;   // block sums
-  uint64_t* d_totals = nullptr;     // [0] nseg total (device-computed), [1] token total, [2] missing total
-  uint32_t* d_error = nullptr;
-  // long documents (hierarchical resolve)
-  uint32_t ngroups = 0, nlong = 0, cap_groups = 0, cap_long = 0;
-  Group* d_groups = nullptr;
-  LongDoc* d_longs = nullptr;
-  uint4* d_gmap = nullptr;
-  uint8_t* d_group_entry = nullptr;
-  uint4* d_group_base = nullptr;
-  // raw (un-normalized) input of tm_batch_upload_raw / tm_batch_normalize
-  uint8_t* d_raw = nullptr;
-  uint8_t* d_slab = nullptr;            // normalizer: one 2 KiB slab per 1 KiB piece
-  uint64_t slab_cap = 0;
-  uint64_t* d_raw_off = nullptr;
-  uint64_t raw_cap = 0, raw_bytes = 0, raw_pieces = 0, piece_cap = 0;
-  uint32_t raw_docs = 0, raw_docs_cap = 0;
-  std::vector<uint64_t> h_raw_off;
-  uint32_t host_fallback_docs = 0;
-  uint32_t* d_doc_npiece = nullptr;     // pieces per raw document, then (scan) first piece of each document
-  uint64_t* d_doc_piece_start = nullptr;
-  uint32_t* d_piece_doc = nullptr;
-  uint32_t* d_piece_sum = nullptr;      // per-piece run summary (pass 1)
-  uint8_t* d_piece_carry = nullptr;     // per-piece carries (pass 2)
-  uint32_t* d_piece_len = nullptr;      // normalized bytes per piece (pass 3)
-  uint64_t* d_piece_off = nullptr;      // their exclusive scan
-  uint8_t* d_need_host = nullptr;       // per document: needs the host normalizer
-  uint64_t* d_nbegin = nullptr;         // normalized document ranges (GPU documents packed first, fallback documents after)
-  uint64_t* d_nend = nullptr;
-  uint64_t* d_ninfo = nullptr;          // [0] #fallback docs [1] #long docs [2] #segments (device-computed)
-  // grow-only staging for the host fallback
-  uint8_t* d_fb_raw = nullptr; uint8_t* d_fb_norm = nullptr; uint64_t* d_fb_roff = nullptr; uint64_t* d_fb_noff = nullptr; uint32_t* d_fb_ids = nullptr;
-  uint64_t fb_raw_cap = 0, fb_norm_cap = 0; uint32_t fb_docs_cap = 0;
-  uint32_t* d_out = nullptr;
-  uint64_t out_cap = 0;
-  hipEvent_t ev[TM_NUM_KERNELS + 1] = {};
-  bool have_events = false;
-};
 
-namespace {
+namespace tmh {
 
-const char* kKernelNames[TM_NUM_KERNELS] = {"segments", "match_branch", "resolve", "scan", "emit"};
+static const char* kKernelNames[TM_NUM_KERNELS] = {"segments", "match_branch", "resolve", "scan", "emit"};
 
-template <typename T>
-hipError_t dalloc(tm_batch* b, T** p, uint64_t count) {
-  uint64_t bytes = count * sizeof(T);
-  hipError_t e = hipMalloc((void**)p, bytes ? bytes : 16);
+hipError_t batch_alloc_bytes(tm_batch* b, void** p, uint64_t bytes) {
+  hipError_t e = hipMalloc(p, bytes ? bytes : 16);
   if (e == hipSuccess) b->device_bytes += bytes;
   return e;
+}
+template <typename T>
+static hipError_t dalloc(tm_batch* b, T** p, uint64_t count) { return batch_alloc_bytes(b, (void**)p, count * sizeof(T)); }
+
+void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32_t ndocs, uint32_t unit, uint32_t* doc_nunits, hipStream_t st) {
+  if (ndocs) k_doc_nseg<<<(ndocs + 255) / 256, 256, 0, st>>>(doc_begin, doc_end, ndocs, doc_nunits, unit);
+}
+void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st) {
+  if (nunits) k_segments<<<(uint32_t)((nunits + 255) / 256), 256, 0, st>>>(doc_unit_start, ndocs, nunits, unit_doc);
+}
+void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
+                       uint32_t n_ids, hipStream_t st) {
+  const uint64_t nseg = b->nseg;
+  if (nseg > 0)
+    k_chain<true, 16><<<(uint32_t)std::min<uint64_t>((nseg + 15) / 16, (uint64_t)n_cu), 1024, 0, st>>>(
+        b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
+        delete_id, 0, nullptr, d_hist, d_tokens, d_missing_bits);
+  k_hist_finish<<<1, 256, 0, st>>>(d_tokens, d_missing_bits, d_hist + n_ids);
 }
 
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {
@@ -1053,13 +985,15 @@ int ensure_output(tm_batch* b) {
   return TM_OK;
 }
 
-}  // namespace
+}  // namespace tmh
 
 extern "C" {
 
 const char* tm_kernel_name(int k) { return k >= 0 && k < TM_NUM_KERNELS ? kKernelNames[k] : ""; }
 
-static int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, bool own_text, bool with_output, tm_batch** out) {
+}  // extern "C"
+namespace tmh {
+int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, bool own_text, bool with_output, tm_batch** out) {
   *out = nullptr;
   auto* b = new tm_batch();
   b->vocab = v;
@@ -1087,6 +1021,8 @@ static int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_do
   *out = b;
   return TM_OK;
 }
+}  // namespace tmh
+extern "C" {
 
 int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm_batch** out) {
   if (!v || !out) return set_error(TM_E_INVALID, "null argument");
@@ -1246,772 +1182,4 @@ int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const u
   return rc;
 }
 
-// ---- trainvocab scoring pass ----------------------------------------------------------------------
 }  // extern "C"
-
-struct tm_dataset {
-  uint8_t* d_text = nullptr;
-  uint64_t n = 0;
-  tm_batch* ws = nullptr;          // workspace, created on first use and reused by every scoring pass
-  uint32_t ws_docs = 0;
-  uint32_t* d_hist = nullptr;      // scores | 4 token limbs | 256 missing counters
-  uint64_t hist_words = 0;
-  unsigned long long* d_tokens = nullptr;
-  uint32_t* d_missing_bits = nullptr;
-  int n_cu = 256;
-};
-
-static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
-                     hipStream_t st) {
-  if (!v || !d) return set_error(TM_E_INVALID, "null argument");
-  std::vector<uint64_t> be;
-  uint64_t whole_off = 0, whole_len = d->n;
-  if (n_strips == 0) { strip_off = &whole_off; strip_len = &whole_len; n_strips = 1; }
-  be.resize(2ull * n_strips);
-  uint64_t nseg = 0;
-  for (uint32_t k = 0; k < n_strips; k++) {
-    if (strip_off[k] > d->n || strip_len[k] > d->n - strip_off[k]) return set_error(TM_E_INVALID, "strip %u outside the dataset", k);
-    be[k] = strip_off[k];
-    be[n_strips + k] = strip_off[k] + strip_len[k];
-    nseg += (strip_len[k] + SEG - 1) / SEG;
-  }
-  hipError_t e;
-  if (d->ws && (d->ws->vocab != v || d->ws_docs < n_strips)) { tm_batch_free(d->ws); d->ws = nullptr; }
-  if (!d->ws) {
-    int rc = make_workspace(v, d->n, n_strips, false, false, &d->ws);
-    if (rc != TM_OK) return rc;
-    d->ws_docs = n_strips;
-    d->ws->d_text = d->d_text;
-  }
-  tm_batch* b = d->ws;
-  b->vocab = v;
-  const uint64_t words = (uint64_t)v->host.n_ids + 4 + 256;
-  if (d->hist_words != words) {
-    (void)hipFree(d->d_hist);
-    d->d_hist = nullptr;
-    if ((e = hipMalloc((void**)&d->d_hist, words * 4)) != hipSuccess) return hip_fail(e, "hipMalloc histogram");
-    d->hist_words = words;
-  }
-  if ((e = hipMemcpyAsync(b->d_offsets, be.data(), be.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D strips");
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync");   // `be` is a host temporary
-  b->d_doc_begin = b->d_offsets;
-  b->d_doc_end = b->d_offsets + n_strips;
-  b->ndocs = n_strips;
-  b->nbytes = d->n;
-  b->nseg = nseg;
-  { int grc = build_groups(b, be.data(), be.data() + n_strips, n_strips); if (grc != TM_OK) return grc; }
-  (void)hipMemsetAsync(d->d_hist, 0, words * 4, st);
-  (void)hipMemsetAsync(d->d_tokens, 0, 8, st);
-  (void)hipMemsetAsync(d->d_missing_bits, 0, 32, st);
-  int rc = run_pipeline(b, st, false, nullptr, false);
-  if (rc != TM_OK) return rc;
-  if (nseg > 0)
-    k_chain<true, 16><<<(uint32_t)std::min<uint64_t>((nseg + 15) / 16, (uint64_t)d->n_cu), 1024, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
-                                                              nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
-                                                              v->tables.has_delete ? v->tables.delete_id : 0, 0, nullptr, d->d_hist, d->d_tokens,
-                                                              d->d_missing_bits);
-  k_hist_finish<<<1, 256, 0, st>>>(d->d_tokens, d->d_missing_bits, d->d_hist + v->host.n_ids);
-  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
-  return TM_OK;
-}
-
-extern "C" {
-
-int tm_dataset_upload(const uint8_t* normalized, uint64_t n, tm_dataset** out) {
-  if (!out || (n && !normalized)) return set_error(TM_E_INVALID, "null argument");
-  auto* d = new tm_dataset();
-  hipError_t e;
-  if ((e = hipMalloc((void**)&d->d_text, n + 256)) != hipSuccess || (e = hipMalloc((void**)&d->d_tokens, 8)) != hipSuccess ||
-      (e = hipMalloc((void**)&d->d_missing_bits, 32)) != hipSuccess ||
-      (n && (e = hipMemcpy(d->d_text, normalized, n, hipMemcpyHostToDevice)) != hipSuccess)) {
-    tm_dataset_free(d);
-    return hip_fail(e, "dataset upload");
-  }
-  d->n = n;
-  { int dev = 0, cu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) d->n_cu = cu; }
-  *out = d;
-  return TM_OK;
-}
-
-void tm_dataset_free(tm_dataset* d) {
-  if (!d) return;
-  tm_batch_free(d->ws);
-  (void)hipFree(d->d_text); (void)hipFree(d->d_hist); (void)hipFree(d->d_tokens); (void)hipFree(d->d_missing_bits);
-  delete d;
-}
-
-int tm_score_device(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
-                    void* stream, uint32_t** dev_hist, uint64_t* n_words) {
-  int rc = score_run(v, d, strip_off, strip_len, n_strips, (hipStream_t)stream);
-  if (rc != TM_OK) return rc;
-  if (dev_hist) *dev_hist = d->d_hist;
-  if (n_words) *n_words = d->hist_words;
-  return TM_OK;
-}
-
-int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
-                         void* stream, uint32_t* dst_device, uint64_t dst_words) {
-  if (!dst_device) return set_error(TM_E_INVALID, "null argument");
-  int rc = score_run(v, d, strip_off, strip_len, n_strips, (hipStream_t)stream);
-  if (rc != TM_OK) return rc;
-  if (dst_words < d->hist_words) return set_error(TM_E_NOSPACE, "destination holds %llu words, histogram has %llu", (unsigned long long)dst_words, (unsigned long long)d->hist_words);
-  hipError_t e = hipMemcpyAsync(dst_device, d->d_hist, d->hist_words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "D2D histogram");
-  return TM_OK;
-}
-
-int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
-             uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]) {
-  int rc = score_run(v, d, strip_off, strip_len, n_strips, nullptr);
-  if (rc != TM_OK) return rc;
-  hipError_t e;
-  std::vector<uint32_t> h(d->hist_words);
-  uint32_t err = 0;
-  if ((e = hipMemcpy(h.data(), d->d_hist, h.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H histogram");
-  if ((e = hipMemcpy(&err, d->ws->d_error, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H error flag");
-  if (err) return set_error(TM_E_HIP, "device pipeline inconsistency (unreachable segment entry state)");
-  const uint32_t n_ids = v->host.n_ids;
-  if (scores) std::memcpy(scores, h.data(), (size_t)n_ids * 4);
-  if (tokens_in_text) {
-    uint64_t t = 0;
-    for (int k = 0; k < 4; k++) t += (uint64_t)h[n_ids + k] << (16 * k);
-    *tokens_in_text = t;
-  }
-  if (missing_set) {
-    std::memset(missing_set, 0, 32);
-    for (int k = 0; k < 256; k++) if (h[n_ids + 4 + k]) missing_set[k >> 3] |= (uint8_t)(1u << (k & 7));
-  }
-  return TM_OK;
-}
-
-}  // extern "C"
-
-// ================================================================================================
-// GPU normalizer: the pre-step of Tokenize (go/tokenmonster.go:242-253: norm.Normalize then capcode.Encode)
-// ================================================================================================
-// Handles, entirely on the device, documents made of ASCII plus the NFD-stable General Punctuation block
-// (U+2010..U+2027, U+2030..U+205E: curly quotes, dashes, ellipsis ...; U+2019 counts as an apostrophe exactly as in
-// javascript/tokenmonster.js:878).  For these NFD is the identity (tokenmonster.cpp:190-198) and capcode level 2
-// (javascript/tokenmonster.js:900-1005) becomes a LOCAL function of each character once three facts about its
-// "capital run" are known.  A run is what the encoder's inWord state covers: it starts at the first capital of a
-// maximal block of {capital, digit, apostrophe} characters and extends to the end of that block.  Needed per char:
-//   ub   capitals before it in its block (0 = it is the run's first letter; >= 1 = inside the run)
-//   ua   capitals after it in its block       (every later capital of a run is inside a run of several capitals)
-//   tL   the character right after the block is a lowercase letter ('C' mode: "Hello"; otherwise 'W' mode: "HELLO")
-// Documents are cut into 1 KiB pieces, one wavefront each (text staged in LDS):
-//   pass 1  k_norm_summary  per piece: leading / trailing block-run summary, unsupported-byte flag
-//   pass 2  k_norm_carry    per document: carries ub / ua / tL across piece boundaries (a few bits per piece)
-//   pass 3  k_norm_emit<0>  per piece: output length            -> scan -> where every piece goes
-//   pass 4  k_norm_emit<1>  per piece: the normalized bytes
-// Any other document (other non-ASCII bytes: needs ICU for NFD / Unicode case) is normalized by the host normalizer
-// (tm_normalize.cpp) and appended after the device-normalized documents; documents are (begin, end) ranges, so the
-// layout of the device part never waits for the host.
-namespace tmh {
-
-constexpr int PIECE = 1024, PMARGIN = 8, PLDS = PIECE + 2 * PMARGIN;
-enum : uint32_t { NC_O = 0, NC_L = 1, NC_U = 2, NC_N = 3, NC_AP = 4, NC_SP = 5 };
-constexpr uint32_t NF_CLASS = 7u, NF_CONT = 8u, NF_TERML = 16u, NF_UA_SHIFT = 5, NF_BAD = 0x80u;
-// piece summary bits
-constexpr uint32_t PS_WHOLE = 1u, PS_LEADU_SHIFT = 1, PS_LEADTL = 8u, PS_TRAILU_SHIFT = 5, PS_FIRSTBLOCK = 128u, PS_FIRSTL = 256u, PS_BAD = 512u;
-
-__device__ __forceinline__ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
-  if (c - 'a' < 26u) return NC_L;
-  if (c - 'A' < 26u) return lower_all ? NC_L : NC_U;
-  if (c - '0' < 10u) return NC_N;
-  if (c == '\'') return NC_AP;
-  if (c == ' ') return NC_SP;
-  return NC_O;
-}
-__device__ __forceinline__ bool npunct3(uint32_t b1, uint32_t b2) {   // E2 b1 b2 in the supported punctuation ranges
-  return (b1 == 0x80u && ((b2 >= 0x90u && b2 <= 0xA7u) || (b2 >= 0xB0u && b2 <= 0xBFu))) || (b1 == 0x81u && b2 >= 0x80u && b2 <= 0x9Eu);
-}
-__device__ __forceinline__ bool nblock(uint32_t cls) { return cls == NC_U || cls == NC_N || cls == NC_AP; }
-
-struct PieceLds { uint8_t raw[PLDS]; uint8_t f[PLDS]; };
-
-// stage the piece (+ margins) and classify every byte; continuation bytes inherit the class of their lead byte.
-// returns the piece length; LDS index of document byte (pb + i) is PMARGIN + i.
-__device__ __forceinline__ int norm_load_piece(PieceLds& L, const uint8_t* __restrict__ raw, uint64_t rb, uint64_t re, uint64_t pb, int lane,
-                                               bool lower_all) {
-  for (int i = lane; i < PLDS / 4; i += 64) {
-    const int64_t g = (int64_t)pb - PMARGIN + 4 * i;
-    uint32_t wv = 0;
-    if (g >= (int64_t)rb && g + 4 <= (int64_t)re) __builtin_memcpy(&wv, raw + g, 4);       // whole dword inside the document
-    else {
-#pragma unroll
-      for (int q = 0; q < 4; q++) if (g + q >= (int64_t)rb && g + q < (int64_t)re) wv |= (uint32_t)raw[g + q] << (8 * q);
-    }
-    reinterpret_cast<uint32_t*>(L.raw)[i] = wv;
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  for (int i = 2 + lane; i < PLDS - 2; i += 64) {
-    const uint32_t b = L.raw[i];
-    uint32_t fl;
-    if (b < 0x80u) fl = ncls_ascii(b, lower_all);
-    else {
-      const uint32_t m1 = L.raw[i - 1], m2 = L.raw[i - 2], p1 = L.raw[i + 1], p2 = L.raw[i + 2];
-      uint32_t b1 = 0, b2 = 0, cont = 0;
-      bool ok = false;
-      if (b == 0xE2u) { b1 = p1; b2 = p2; ok = true; }
-      else if (m1 == 0xE2u) { b1 = b; b2 = p1; cont = NF_CONT; ok = true; }
-      else if (m2 == 0xE2u) { b1 = m1; b2 = b; cont = NF_CONT; ok = true; }
-      ok = ok && npunct3(b1, b2);
-      fl = ok ? (((b1 == 0x80u && b2 == 0x99u) ? NC_AP : NC_O) | cont) : NF_BAD;
-    }
-    L.f[i] = (uint8_t)fl;
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  const uint64_t left = re - pb;
-  return left > (uint64_t)PIECE ? PIECE : (int)left;
-}
-
-__global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rbegin,
-                                                      const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
-                                                      const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t lower_all,
-                                                      uint32_t* __restrict__ piece_sum) {
-  __shared__ PieceLds s_l[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
-  if (k >= npieces) return;
-  PieceLds& L = s_l[wv];
-  const uint32_t d = piece_doc[k];
-  const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = norm_load_piece(L, raw, rb, re, pb, lane, lower_all != 0);
-  bool lead_open = true, lead_tl = false, bad = false;
-  uint32_t lead_u = 0, trail_u = 0;
-  for (int c = 0; c * 64 < m; c++) {
-    const int i = c * 64 + lane;
-    const bool in = i < m;
-    const uint32_t fl = in ? L.f[PMARGIN + i] : 0u, cls = fl & NF_CLASS;
-    bad |= in && fl == NF_BAD;
-    const unsigned long long V = __ballot(in), mB = __ballot(in && fl != NF_BAD && nblock(cls)), mU = __ballot(in && fl != NF_BAD && cls == NC_U),
-                             mL = __ballot(in && fl != NF_BAD && cls == NC_L);
-    const unsigned long long nonblock = V & ~mB;
-    if (lead_open) {
-      if (nonblock != 0) {
-        const int e = __ffsll((long long)nonblock) - 1;
-        lead_u = min(lead_u + (uint32_t)__popcll(mU & ((1ull << e) - 1ull)), 2u);
-        lead_tl = (mL >> e) & 1ull;
-        lead_open = false;
-      } else lead_u = min(lead_u + (uint32_t)__popcll(mU), 2u);
-    }
-    if (nonblock != 0) {
-      const int hi = 63 - __clzll((long long)nonblock);
-      trail_u = min((uint32_t)__popcll(hi == 63 ? 0ull : (mU & (~0ull << (hi + 1)))), 2u);
-    } else trail_u = min(trail_u + (uint32_t)__popcll(mU), 2u);
-  }
-  bad = __any(bad);
-  if (lane == 0) {
-    const uint32_t f0 = L.f[PMARGIN], c0 = f0 & NF_CLASS;
-    uint32_t s = (lead_open ? PS_WHOLE : 0u) | (lead_u << PS_LEADU_SHIFT) | (lead_tl ? PS_LEADTL : 0u) | (trail_u << PS_TRAILU_SHIFT);
-    if (m > 0 && f0 != NF_BAD && nblock(c0)) s |= PS_FIRSTBLOCK;
-    if (m > 0 && f0 != NF_BAD && c0 == NC_L) s |= PS_FIRSTL;
-    if (bad) s |= PS_BAD;
-    piece_sum[k] = s;
-  }
-}
-
-// carry byte of a piece: ub[0..1] | ua[2..3] | tL[4]
-__global__ void k_norm_carry(const uint32_t* __restrict__ piece_sum, const uint64_t* __restrict__ doc_piece_start, uint32_t ndocs,
-                             uint8_t* __restrict__ piece_carry, uint8_t* __restrict__ need_host, unsigned long long* __restrict__ ninfo) {
-  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= ndocs) return;
-  const uint64_t ps = doc_piece_start[d], pe = doc_piece_start[d + 1];
-  uint32_t ub = 0;
-  bool bad = false;
-  for (uint64_t k = ps; k < pe; k++) {
-    const uint32_t s = piece_sum[k];
-    piece_carry[k] = (uint8_t)ub;
-    bad |= (s & PS_BAD) != 0;
-    if (s & PS_WHOLE) ub = min(ub + ((s >> PS_LEADU_SHIFT) & 3u), 2u);
-    else ub = (s >> PS_TRAILU_SHIFT) & 3u;
-  }
-  uint32_t ua = 0, tl = 0;
-  for (uint64_t k = pe; k > ps; k--) {
-    const uint32_t s = piece_sum[k - 1];
-    piece_carry[k - 1] = (uint8_t)(piece_carry[k - 1] | (ua << 2) | (tl << 4));
-    if (s & PS_WHOLE) ua = min(ua + ((s >> PS_LEADU_SHIFT) & 3u), 2u);
-    else if (s & PS_FIRSTBLOCK) { ua = (s >> PS_LEADU_SHIFT) & 3u; tl = (s & PS_LEADTL) ? 1u : 0u; }
-    else { ua = 0; tl = (s & PS_FIRSTL) ? 1u : 0u; }
-  }
-  need_host[d] = bad ? 1 : 0;
-  if (bad) atomicAdd(&ninfo[0], 1ull);
-}
-
-// MODE 0: normalized length of every piece.  MODE 1: the bytes, packed at piece_off.  MODE 2: the bytes into the piece's
-// private slab (SLAB bytes apart; a piece that would not fit raises the overflow flag) and the length — the common
-// one-pass path; k_norm_compact then packs the slabs.
-constexpr int SLAB = 2 * PIECE;
-template <int MODE>
-__global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rbegin,
-                                                   const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
-                                                   const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t capcode,
-                                                   uint32_t lower_all, const uint8_t* __restrict__ piece_carry,
-                                                   const uint8_t* __restrict__ need_host, uint32_t* __restrict__ piece_len,
-                                                   const uint64_t* __restrict__ piece_off, uint8_t* __restrict__ out,
-                                                   unsigned long long* __restrict__ overflow) {
-  constexpr bool WRITE = MODE != 0;
-  __shared__ PieceLds s_l[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
-  if (k >= npieces) return;
-  PieceLds& L = s_l[wv];
-  const uint32_t d = piece_doc[k];
-  if (need_host[d]) { if (MODE != 1 && lane == 0) piece_len[k] = 0; return; }
-  const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = norm_load_piece(L, raw, rb, re, pb, lane, lower_all != 0);
-  uint8_t* dst = MODE == 1 ? out + piece_off[k] : (MODE == 2 ? out + k * (uint64_t)SLAB : nullptr);
-  if (capcode != 2) {                                       // no capcode: same length, only the lower-case flag applies
-    if (MODE != 1 && lane == 0) piece_len[k] = (uint32_t)m;
-    if (WRITE) for (int i = lane; i < m; i += 64) { uint32_t b = L.raw[PMARGIN + i]; if (lower_all && b - 'A' < 26u) b |= 0x20u; dst[i] = (uint8_t)b; }
-    return;
-  }
-  const uint32_t carry = piece_carry[k];
-  const unsigned long long below = (1ull << lane) - 1ull;
-  // ---- backward sweep: ua and tL of every block byte --------------------------------------------------------------
-  {
-    uint32_t carry_ua = (carry >> 2) & 3u;
-    bool carry_tl = (carry >> 4) & 1u;
-    for (int c = (m - 1) / 64; c >= 0; c--) {
-      const int i = c * 64 + lane;
-      const bool in = i < m;
-      const uint32_t fl = in ? L.f[PMARGIN + i] : 0u, cls = fl & NF_CLASS;
-      const unsigned long long V = __ballot(in), mB = __ballot(in && nblock(cls)), mU = __ballot(in && cls == NC_U), mL = __ballot(in && cls == NC_L);
-      const unsigned long long above = lane == 63 ? 0ull : (~0ull << (lane + 1));
-      const unsigned long long stop = V & ~mB & above;         // first non-block byte to my right inside the chunk
-      uint32_t ua;
-      bool tl;
-      if (stop != 0) {
-        const int e = __ffsll((long long)stop) - 1;
-        ua = (uint32_t)__popcll(mU & above & ((1ull << e) - 1ull));
-        tl = (mL >> e) & 1ull;
-      } else {
-        ua = (uint32_t)__popcll(mU & above) + carry_ua;
-        tl = carry_tl;
-      }
-      ua = min(ua, 2u);
-      if (in && nblock(cls)) L.f[PMARGIN + i] = (uint8_t)(fl | (tl ? NF_TERML : 0u) | (ua << NF_UA_SHIFT));
-      const uint32_t ua0 = __shfl(ua, 0), cls0 = __shfl(cls, 0);
-      const bool tl0 = __shfl((int)tl, 0) != 0;
-      if (nblock(cls0)) { carry_ua = min(ua0 + (cls0 == NC_U ? 1u : 0u), 2u); carry_tl = tl0; }
-      else { carry_ua = 0; carry_tl = cls0 == NC_L; }
-    }
-  }
-  // tL of the first byte of the NEXT piece (a space at the very end of this piece may turn into its marker)
-  const bool next_tl = (carry >> 4) & 1u;
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  // ---- forward sweep: ub, then every character's output ------------------------------------------------------------
-  uint32_t carry_ub = carry & 3u;
-  uint32_t pos = 0;
-  for (int c = 0; c * 64 < m; c++) {
-    const int i = c * 64 + lane, x = PMARGIN + i;
-    const bool in = i < m;
-    const uint32_t fl = in ? L.f[x] : 0u, cls = fl & NF_CLASS;
-    const unsigned long long mB = __ballot(in && nblock(cls)), mU = __ballot(in && cls == NC_U);
-    const unsigned long long gap = ~mB & below;                // non-block bytes to my left inside the chunk
-    uint32_t ub;
-    if (gap != 0) {
-      const int s = 64 - __clzll((long long)gap);
-      ub = (uint32_t)__popcll(mU & below & ~((1ull << s) - 1ull));
-    } else ub = (uint32_t)__popcll(mU & below) + carry_ub;
-    ub = min(ub, 2u);
-    {
-      const uint32_t ub63 = __shfl(ub, 63), cls63 = __shfl(cls, 63);
-      carry_ub = nblock(cls63) ? min(ub63 + (cls63 == NC_U ? 1u : 0u), 2u) : 0u;
-    }
-    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, len = 0;
-    if (in) {
-      const uint32_t b = L.raw[x];
-      o3 = b; len = 1;
-      if (!(fl & NF_CONT)) {
-        const uint32_t fm1 = L.f[x - 1], P = fm1 & NF_CLASS;
-        uint32_t P2 = NC_O;
-        if (P == NC_AP) P2 = L.f[(fm1 & NF_CONT) ? x - 4 : x - 2] & NF_CLASS;
-        const bool inword = ub >= 1;                           // javascript/tokenmonster.js `inWord` before this character
-        const bool tl = (fl & NF_TERML) != 0;
-        const uint32_t lowc = b | 0x20u;
-        if (cls == NC_U) {
-          o3 = lowc;
-          if (!inword) {                                       // first capital of a run  (:975-990)
-            if (P == NC_SP) { o2 = ' '; len = 2; }             // the space before it turns into the marker (below)
-            else { o0 = 'D'; o1 = tl ? 'C' : 'W'; o2 = ' '; len = 4; }
-          } else if (tl) { o0 = 'D'; o1 = 'C'; o2 = ' '; len = 4; }        // :924-951 every later capital of a 'C' run
-          else if (P == NC_N) { o1 = 'D'; o2 = ' '; len = 3; }              // :913-916
-        } else if (cls == NC_L) {
-          if (lower_all) o3 = lowc;
-          const bool joined = inword ? (P == NC_U || P == NC_AP)           // :952-955 (the letter that ends a run)
-                                     : (P == NC_SP || P == NC_L || P == NC_U || (P == NC_AP && (P2 == NC_L || P2 == NC_U)));   // :970
-          if (!joined) { o1 = 'D'; o2 = ' '; len = 3; }
-        } else if (cls == NC_N) {
-          const bool joined = inword ? (P == NC_N) : (P == NC_SP || P == NC_N);   // :958 / :992
-          if (!joined) { o1 = 'D'; o2 = ' '; len = 3; }
-        } else if (cls == NC_SP) {
-          const bool last = i + 1 == m;                        // the next byte lives in the next piece (or nowhere)
-          const uint32_t fp1 = L.f[x + 1];
-          if ((fp1 & NF_CLASS) == NC_U && fp1 != NF_BAD) o3 = (last ? next_tl : (fp1 & NF_TERML) != 0) ? 'C' : 'W';   // :976-979
-        }
-      }
-    }
-    uint32_t incl = len;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (WRITE && in && (MODE == 1 || pos + incl <= (uint32_t)SLAB)) {
-      uint8_t* w = dst + pos + (incl - len);
-      if (len == 4) { w[0] = (uint8_t)o0; w[1] = (uint8_t)o1; w[2] = (uint8_t)o2; w[3] = (uint8_t)o3; }
-      else if (len == 3) { w[0] = (uint8_t)o1; w[1] = (uint8_t)o2; w[2] = (uint8_t)o3; }
-      else if (len == 2) { w[0] = (uint8_t)o2; w[1] = (uint8_t)o3; }
-      else w[0] = (uint8_t)o3;
-    }
-    pos += __shfl(incl, 63);
-  }
-  if (MODE != 1 && lane == 0) {
-    piece_len[k] = pos;
-    if (MODE == 2 && pos > (uint32_t)SLAB) atomicAdd(overflow, 1ull);
-  }
-}
-
-// pack the slabs: piece k's bytes go to out[piece_off[k] ..)
-__global__ __launch_bounds__(256) void k_norm_compact(const uint8_t* __restrict__ slab, const uint32_t* __restrict__ piece_len,
-                                                      const uint64_t* __restrict__ piece_off, uint64_t npieces, uint8_t* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= npieces) return;
-  const uint32_t len = piece_len[k];
-  const uint8_t* src = slab + k * (uint64_t)SLAB;
-  uint8_t* dst = out + piece_off[k];
-  for (uint32_t i = (uint32_t)lane * 16u; i < len; i += 64u * 16u) {
-    if (i + 16u <= len) { uint4 q; __builtin_memcpy(&q, src + i, 16); __builtin_memcpy(dst + i, &q, 16); }
-    else for (uint32_t j = i; j < len; j++) dst[j] = src[j];
-  }
-}
-
-// normalized range of every device-normalized document; segment / long-document counts
-__global__ void k_norm_ranges(const uint64_t* __restrict__ piece_off, const uint64_t* __restrict__ doc_piece_start, const uint8_t* __restrict__ need_host,
-                              uint32_t ndocs, uint64_t* __restrict__ nbegin, uint64_t* __restrict__ nend) {
-  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= ndocs) return;
-  if (need_host[d]) { nbegin[d] = 0; nend[d] = 0; return; }
-  nbegin[d] = piece_off[doc_piece_start[d]];
-  nend[d] = piece_off[doc_piece_start[d + 1]];
-}
-__global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t* __restrict__ nend, uint32_t ndocs, unsigned long long* __restrict__ ninfo) {
-  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t nseg = 0;
-  if (d < ndocs) { nseg = (nend[d] - nbegin[d] + SEG - 1) / SEG; if (nseg > LONG_SEGS) atomicAdd(&ninfo[1], 1ull); }
-  for (int o = 32; o > 0; o >>= 1) nseg += __shfl_xor(nseg, o);
-  if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&ninfo[2], (unsigned long long)nseg);
-}
-__global__ void k_gather_docs(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ doc_ids,
-                              const uint64_t* __restrict__ dst_off, uint32_t n, uint8_t* __restrict__ staging) {
-  const uint32_t k = blockIdx.x;
-  if (k >= n) return;
-  const uint64_t s = raw_off[doc_ids[k]], len = raw_off[doc_ids[k] + 1] - s, o = dst_off[k];
-  for (uint64_t j = threadIdx.x; j < len; j += blockDim.x) staging[o + j] = raw[s + j];
-}
-// place the host-normalized documents after the device-normalized text and record their ranges
-__global__ void k_place_fallback(const uint8_t* __restrict__ staging, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ doc_ids,
-                                 uint32_t n, uint64_t base, uint8_t* __restrict__ out, uint64_t* __restrict__ nbegin, uint64_t* __restrict__ nend) {
-  const uint32_t k = blockIdx.x;
-  if (k >= n) return;
-  const uint64_t s = src_off[k], len = src_off[k + 1] - s;
-  if (threadIdx.x == 0) { nbegin[doc_ids[k]] = base + s; nend[doc_ids[k]] = base + s + len; }
-  for (uint64_t j = threadIdx.x; j < len; j += blockDim.x) out[base + s + j] = staging[s + j];
-}
-
-}  // namespace tmh
-
-namespace {
-template <typename T>
-hipError_t grow(T** p, uint64_t* cap, uint64_t need, uint64_t slack = 0) {
-  if (*p && *cap >= need) return hipSuccess;
-  (void)hipFree(*p);
-  *p = nullptr;
-  *cap = need + need / 4 + slack;
-  return hipMalloc((void**)p, *cap * sizeof(T));
-}
-}  // namespace
-
-extern "C" {
-
-int tm_batch_upload_raw(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs) {
-  if (!b || (ndocs && !raw_offsets)) return set_error(TM_E_INVALID, "null argument");
-  if (ndocs > b->max_docs) return set_error(TM_E_LIMIT, "batch has %u documents, workspace sized for %u", ndocs, b->max_docs);
-  const uint64_t nbytes = ndocs ? raw_offsets[ndocs] : 0;
-  if (ndocs && raw_offsets[0] != 0) return set_error(TM_E_INVALID, "offsets[0] must be 0");
-  uint64_t npieces = 0;
-  for (uint32_t d = 0; d < ndocs; d++) {
-    if (raw_offsets[d + 1] < raw_offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
-    npieces += (raw_offsets[d + 1] - raw_offsets[d] + PIECE - 1) / PIECE;
-  }
-  hipError_t e;
-  uint64_t docs_cap = b->raw_docs_cap;
-  if ((e = grow(&b->d_raw, &b->raw_cap, nbytes + 256)) != hipSuccess) return hip_fail(e, "hipMalloc (raw text)");
-  if (!b->d_raw_off || ndocs + 2 > docs_cap) {
-    void** ps[] = {(void**)&b->d_raw_off, (void**)&b->d_doc_npiece, (void**)&b->d_doc_piece_start, (void**)&b->d_need_host, (void**)&b->d_nbegin, (void**)&b->d_nend};
-    for (void** q : ps) { (void)hipFree(*q); *q = nullptr; }
-    docs_cap = (uint64_t)ndocs + ndocs / 4 + 16;
-    if ((e = hipMalloc((void**)&b->d_raw_off, docs_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_doc_npiece, docs_cap * 4)) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_doc_piece_start, (docs_cap + 1) * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_need_host, docs_cap)) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_nbegin, docs_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_nend, docs_cap * 8)) != hipSuccess)
-      return hip_fail(e, "hipMalloc (raw documents)");
-    b->raw_docs_cap = (uint32_t)std::min<uint64_t>(docs_cap - 2, 0xFFFFFFFFull);
-  }
-  if (!b->d_ninfo && (e = hipMalloc((void**)&b->d_ninfo, 64)) != hipSuccess) return hip_fail(e, "hipMalloc");
-  if (!b->d_piece_doc || npieces + 2 > b->piece_cap) {
-    void** ps[] = {(void**)&b->d_piece_doc, (void**)&b->d_piece_sum, (void**)&b->d_piece_carry, (void**)&b->d_piece_len, (void**)&b->d_piece_off};
-    for (void** q : ps) { (void)hipFree(*q); *q = nullptr; }
-    b->piece_cap = npieces + npieces / 4 + 16;
-    if ((e = hipMalloc((void**)&b->d_piece_doc, b->piece_cap * 4)) != hipSuccess || (e = hipMalloc((void**)&b->d_piece_sum, b->piece_cap * 4)) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_piece_carry, b->piece_cap)) != hipSuccess || (e = hipMalloc((void**)&b->d_piece_len, b->piece_cap * 4)) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_piece_off, (b->piece_cap + 1) * 8)) != hipSuccess)
-      return hip_fail(e, "hipMalloc (pieces)");
-  }
-  if ((e = grow(&b->d_slab, &b->slab_cap, (npieces + 1) * (uint64_t)SLAB)) != hipSuccess) return hip_fail(e, "hipMalloc (normalizer slabs)");
-  if (nbytes && (e = hipMemcpy(b->d_raw, raw, nbytes, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D raw text");
-  if (ndocs && (e = hipMemcpy(b->d_raw_off, raw_offsets, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D raw offsets");
-  b->h_raw_off.assign(raw_offsets, raw_offsets + (ndocs ? ndocs + 1 : 0));
-  b->raw_bytes = nbytes;
-  b->raw_docs = ndocs;
-  b->raw_pieces = npieces;
-  return TM_OK;
-}
-
-int tm_batch_normalize(tm_batch* b, void* stream) {
-  if (!b) return set_error(TM_E_INVALID, "null argument");
-  const tm_vocab* v = b->vocab;
-  const uint32_t capcode = v->host.capcode, norm_flag = v->host.norm_flag;
-  if (!normalize_supported(capcode, norm_flag))
-    return set_error(TM_E_INVALID, "normalization flags %u / capcode %u not supported by the normalizer", norm_flag, capcode);
-  hipStream_t st = (hipStream_t)stream;
-  const uint32_t nd = b->raw_docs;
-  const uint64_t np = b->raw_pieces;
-  hipError_t e;
-  b->host_fallback_docs = 0;
-  b->d_doc_begin = b->d_nbegin;
-  b->d_doc_end = b->d_nend;
-  b->ndocs = nd; b->nbytes = 0; b->nseg = 0; b->ngroups = 0; b->nlong = 0;
-  if (nd == 0) return TM_OK;
-  static const bool trace = getenv("TM_TRACE") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = now();
-  const uint32_t lower_all = (norm_flag & 2u) ? 1u : 0u;
-  unsigned long long* ninfo = (unsigned long long*)b->d_ninfo;
-  (void)hipMemsetAsync(ninfo, 0, 64, st);
-  // piece table
-  k_doc_nseg<<<(nd + 255) / 256, 256, 0, st>>>(b->d_raw_off, b->d_raw_off + 1, nd, b->d_doc_npiece, (uint32_t)PIECE);
-  scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
-  const uint32_t pgrid = (uint32_t)((np + 3) / 4);
-  if (np > 0) {
-    k_segments<<<(uint32_t)((np + 255) / 256), 256, 0, st>>>(b->d_doc_piece_start, nd, np, b->d_piece_doc);
-    k_norm_summary<<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_sum);
-  }
-  k_norm_carry<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo);
-  unsigned long long h_info[4] = {0, 0, 0, 0};
-  if ((e = hipMemcpyAsync(h_info, ninfo, 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
-    return hip_fail(e, "normalize (summaries)");
-  const double t1 = now();
-  const uint32_t nf = (uint32_t)h_info[0];
-  std::vector<uint32_t> ids;
-  std::vector<uint64_t> roff;
-  std::vector<uint8_t> hraw;
-  double f1 = now(), f2 = 0, f3 = 0, f4 = 0;
-  if (nf > 0) {
-    // fetch the documents the device cannot normalize (other non-ASCII content: NFD / Unicode case need ICU)
-    std::vector<uint8_t> need(nd);
-    if ((e = hipMemcpy(need.data(), b->d_need_host, nd, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H flags");
-    ids.reserve(nf);
-    for (uint32_t d = 0; d < nd; d++) if (need[d]) ids.push_back(d);
-    roff.assign(ids.size() + 1, 0);
-    for (size_t k = 0; k < ids.size(); k++) roff[k + 1] = roff[k] + (b->h_raw_off[ids[k] + 1] - b->h_raw_off[ids[k]]);
-    uint64_t docs_cap = b->fb_docs_cap;
-    if (!b->d_fb_ids || ids.size() + 1 > docs_cap) {
-      (void)hipFree(b->d_fb_ids); (void)hipFree(b->d_fb_roff); (void)hipFree(b->d_fb_noff);
-      b->d_fb_ids = nullptr; b->d_fb_roff = nullptr; b->d_fb_noff = nullptr;
-      docs_cap = ids.size() * 2 + 64;
-      if ((e = hipMalloc((void**)&b->d_fb_ids, docs_cap * 4)) != hipSuccess || (e = hipMalloc((void**)&b->d_fb_roff, (docs_cap + 1) * 8)) != hipSuccess ||
-          (e = hipMalloc((void**)&b->d_fb_noff, (docs_cap + 1) * 8)) != hipSuccess) return hip_fail(e, "hipMalloc (fallback lists)");
-      b->fb_docs_cap = (uint32_t)docs_cap;
-    }
-    if ((e = grow(&b->d_fb_raw, &b->fb_raw_cap, roff.back() + 16)) != hipSuccess) return hip_fail(e, "hipMalloc (fallback staging)");
-    if ((e = hipMemcpyAsync(b->d_fb_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_fb_roff, roff.data(), roff.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D fallback lists");
-    k_gather_docs<<<(uint32_t)ids.size(), 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_fb_ids, b->d_fb_roff, (uint32_t)ids.size(), b->d_fb_raw);
-    hraw.resize(roff.back());
-    if ((e = hipMemcpyAsync(hraw.data(), b->d_fb_raw, roff.back(), hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
-      return hip_fail(e, "D2H fallback documents");
-    f2 = now();
-  }
-  // the device normalizes its documents (one pass into per-piece slabs, lengths on the side) ...
-  if (np > 0)
-    k_norm_emit<2><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                          b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3);
-  scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
-  uint64_t gpu_bytes = 0;
-  // ... while the host normalizes the others; they are appended after the device part
-  uint8_t* hnorm = nullptr;
-  std::vector<uint64_t> noff(ids.size() + 1, 0);
-  if (nf > 0) {
-    const uint32_t threads = (uint32_t)std::min<size_t>(64, ids.size() / 8 + 1);
-    int rc = tm_normalize_batch(hraw.data(), roff.data(), (uint32_t)ids.size(), capcode, norm_flag, threads, &hnorm, noff.data());
-    if (rc != TM_OK) return rc;
-    f3 = now();
-  }
-  if ((e = hipMemcpyAsync(h_info, ninfo, 32, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(&gpu_bytes, b->d_totals + 2, 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipStreamSynchronize(st)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "normalize (device pass)"); }
-  if (gpu_bytes + noff.back() > b->max_bytes) {
-    tm_free(hnorm);
-    return set_error(TM_E_LIMIT, "normalized text needs %llu bytes, workspace sized for %llu", (unsigned long long)(gpu_bytes + noff.back()), (unsigned long long)b->max_bytes);
-  }
-  if (np > 0) {
-    if (h_info[3] == 0) {
-      k_norm_compact<<<pgrid, 256, 0, st>>>(b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text);
-    } else {
-      // some piece expands beyond its slab (long runs of capitals): exact two-pass path
-      k_norm_emit<1><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                            b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text, nullptr);
-    }
-  }
-  k_norm_ranges<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);
-  uint64_t total = gpu_bytes;
-  if (nf > 0) {
-    if ((e = grow(&b->d_fb_norm, &b->fb_norm_cap, noff.back() + 16)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "hipMalloc (fallback output)"); }
-    if ((e = hipMemcpyAsync(b->d_fb_norm, hnorm, noff.back(), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_fb_noff, noff.data(), noff.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "H2D fallback output"); }
-    k_place_fallback<<<(uint32_t)ids.size(), 256, 0, st>>>(b->d_fb_norm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), total, b->d_text, b->d_nbegin, b->d_nend);
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "fallback placement"); }
-    tm_free(hnorm);
-    total += noff.back();
-    b->host_fallback_docs = (uint32_t)ids.size();
-    f4 = now();
-    if (trace) fprintf(stderr, "[fallback] flags+gather+D2H %.2f ms, host normalize (overlaps the device pass) %.2f ms, wait + H2D + place %.2f ms\n", f2 - f1, f3 - f2, f4 - f3);
-  }
-  const double t2 = now();
-  // ---- what the tokenize pipeline needs to know on the host: #segments, and the long documents if any ------------
-  k_norm_info<<<(nd + 255) / 256, 256, 0, st>>>(b->d_nbegin, b->d_nend, nd, ninfo);
-  if ((e = hipMemcpyAsync(h_info, ninfo, 24, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
-    return hip_fail(e, "normalize (ranges)");
-  b->nbytes = total;
-  b->nseg = h_info[2];
-  int rc = TM_OK;
-  if (h_info[1] > 0) {
-    std::vector<uint64_t> hb(nd), he(nd);
-    if ((e = hipMemcpy(hb.data(), b->d_nbegin, (size_t)nd * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
-        (e = hipMemcpy(he.data(), b->d_nend, (size_t)nd * 8, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H ranges");
-    rc = build_groups(b, hb.data(), he.data(), nd);
-  }
-  if (trace) fprintf(stderr, "[tm_batch_normalize] summaries %.2f ms, device pass + host fallback (%u docs) %.2f ms, info %.2f ms\n", t1 - t0, nf, t2 - t1, now() - t2);
-  return rc;
-}
-
-uint64_t tm_batch_normalized_bytes(const tm_batch* b) { return b->nbytes; }
-uint32_t tm_batch_host_fallback_docs(const tm_batch* b) { return b->host_fallback_docs; }
-
-// D2H of the normalized text of the current batch in DOCUMENT ORDER (for tests): text_out[nbytes], offsets_out[ndocs+1]
-int tm_batch_download_text(tm_batch* b, uint8_t* text_out, uint64_t text_cap, uint64_t* offsets_out) {
-  if (!b) return set_error(TM_E_INVALID, "null argument");
-  hipError_t e;
-  if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "sync");
-  if (b->nbytes > text_cap) return set_error(TM_E_NOSPACE, "text_cap too small");
-  const uint32_t nd = b->ndocs;
-  std::vector<uint64_t> hb(nd), he(nd);
-  std::vector<uint8_t> all(b->nbytes);
-  if (nd && ((e = hipMemcpy(hb.data(), b->d_doc_begin, (size_t)nd * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
-             (e = hipMemcpy(he.data(), b->d_doc_end, (size_t)nd * 8, hipMemcpyDeviceToHost)) != hipSuccess)) return hip_fail(e, "D2H ranges");
-  if (b->nbytes && (e = hipMemcpy(all.data(), b->d_text, b->nbytes, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H text");
-  uint64_t o = 0;
-  for (uint32_t d = 0; d < nd; d++) {
-    if (offsets_out) offsets_out[d] = o;
-    if (he[d] > hb[d]) std::memcpy(text_out + o, all.data() + hb[d], he[d] - hb[d]);
-    o += he[d] - hb[d];
-  }
-  if (offsets_out) offsets_out[nd] = o;
-  return TM_OK;
-}
-
-}  // extern "C"
-
-// ================================================================================================
-// Decode (go/tokenmonster.go:445-550 Decode; tokenmonster.cpp:1404-1425): ids -> bytes
-// ================================================================================================
-// reverse[id] lengths -> exclusive scan -> copy.  Ids >= n_ids are skipped like the reference does.  Capcode decoding
-// (a per-document state machine, javascript/tokenmonster.js:1007-1065) runs on the host after the gather.
-namespace tmh {
-__global__ void k_dec_len(const uint32_t* __restrict__ tokens, uint64_t n, const uint32_t* __restrict__ rev_off, uint32_t n_ids,
-                          uint32_t* __restrict__ tok_len) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t id = tokens[i];
-  tok_len[i] = id < n_ids ? rev_off[id + 1] - rev_off[id] : 0u;
-}
-__global__ void k_dec_copy(const uint32_t* __restrict__ tokens, uint64_t n, const uint32_t* __restrict__ rev_off, const uint8_t* __restrict__ rev_bytes,
-                           uint32_t n_ids, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t id = tokens[i];
-  if (id >= n_ids) return;
-  const uint32_t s = rev_off[id], l = rev_off[id + 1] - s;
-  uint8_t* o = out + out_off[i];
-  for (uint32_t j = 0; j < l; j++) o[j] = rev_bytes[s + j];
-}
-__global__ void k_dec_doc_off(const uint64_t* __restrict__ out_off, const uint64_t* __restrict__ tok_offsets, uint32_t ndocs, uint64_t* __restrict__ doc_off) {
-  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d <= ndocs) doc_off[d] = out_off[tok_offsets[d]];
-}
-}  // namespace tmh
-
-extern "C" int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* tok_offsets, uint32_t ndocs, int raw,
-                               uint8_t* out, uint64_t out_cap, uint64_t* out_offsets) {
-  if (!v || !tok_offsets || !out_offsets) return set_error(TM_E_INVALID, "null argument");
-  const uint64_t n = tok_offsets[ndocs];
-  if (n && !tokens) return set_error(TM_E_INVALID, "null argument");
-  if (tok_offsets[0] != 0) return set_error(TM_E_INVALID, "tok_offsets[0] must be 0");
-  for (uint32_t d = 0; d < ndocs; d++) if (tok_offsets[d + 1] < tok_offsets[d]) return set_error(TM_E_INVALID, "tok_offsets not monotone");
-  hipError_t e = hipSuccess;
-  uint32_t *d_tok = nullptr, *d_len = nullptr;
-  uint64_t *d_off = nullptr, *d_sums = nullptr, *d_total = nullptr, *d_toff = nullptr, *d_doff = nullptr;
-  uint8_t* d_out = nullptr;
-  int rc = TM_OK;
-  const uint32_t sblocks = (uint32_t)((n + 1 + SCAN_CH - 1) / SCAN_CH) + 2;
-  std::vector<uint64_t> doff((size_t)ndocs + 1, 0);
-  std::vector<uint8_t> rawbytes;
-  if ((e = hipMalloc((void**)&d_tok, (n + 1) * 4)) != hipSuccess || (e = hipMalloc((void**)&d_len, (n + 1) * 4)) != hipSuccess ||
-      (e = hipMalloc((void**)&d_off, (n + 2) * 8)) != hipSuccess || (e = hipMalloc((void**)&d_sums, (uint64_t)sblocks * 8)) != hipSuccess ||
-      (e = hipMalloc((void**)&d_total, 8)) != hipSuccess || (e = hipMalloc((void**)&d_toff, ((uint64_t)ndocs + 1) * 8)) != hipSuccess ||
-      (e = hipMalloc((void**)&d_doff, ((uint64_t)ndocs + 1) * 8)) != hipSuccess) rc = hip_fail(e, "hipMalloc (decode)");
-  if (rc == TM_OK && ((n && (e = hipMemcpy(d_tok, tokens, n * 4, hipMemcpyHostToDevice)) != hipSuccess) ||
-                      (e = hipMemcpy(d_toff, tok_offsets, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess)) rc = hip_fail(e, "H2D tokens");
-  uint64_t total = 0;
-  if (rc == TM_OK) {
-    if (n) k_dec_len<<<(uint32_t)((n + 255) / 256), 256>>>(d_tok, n, v->d_rev_off, v->host.n_ids, d_len);
-    scan_u32(d_len, n, d_sums, d_total, d_off, nullptr);
-    k_dec_doc_off<<<(ndocs + 256) / 256, 256>>>(d_off, d_toff, ndocs, d_doff);
-    if ((e = hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost)) != hipSuccess ||
-        (e = hipMemcpy(doff.data(), d_doff, doff.size() * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "decode lengths");
-  }
-  if (rc == TM_OK && (e = hipMalloc((void**)&d_out, total + 16)) != hipSuccess) rc = hip_fail(e, "hipMalloc (decode output)");
-  if (rc == TM_OK) {
-    if (n) k_dec_copy<<<(uint32_t)((n + 255) / 256), 256>>>(d_tok, n, v->d_rev_off, v->d_rev_bytes, v->host.n_ids, d_off, d_out);
-    rawbytes.resize(total);
-    if (total && (e = hipMemcpy(rawbytes.data(), d_out, total, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H decoded bytes");
-  }
-  void* frees[] = {d_tok, d_len, d_off, d_sums, d_total, d_toff, d_doff, d_out};
-  for (void* q : frees) (void)hipFree(q);
-  if (rc != TM_OK) return rc;
-  if (raw || v->host.capcode == 0) {
-    std::memcpy(out_offsets, doff.data(), doff.size() * 8);
-    if (total > out_cap) return set_error(TM_E_NOSPACE, "out_cap %llu < %llu required", (unsigned long long)out_cap, (unsigned long long)total);
-    if (total) std::memcpy(out, rawbytes.data(), total);
-    return TM_OK;
-  }
-  std::vector<std::vector<uint8_t>> outs;
-  capcode_decode_batch(rawbytes.data(), doff.data(), ndocs, v->host.capcode, 0, outs);
-  uint64_t o = 0;
-  for (uint32_t d = 0; d < ndocs; d++) { out_offsets[d] = o; o += outs[d].size(); }
-  out_offsets[ndocs] = o;
-  if (o > out_cap) return set_error(TM_E_NOSPACE, "out_cap %llu < %llu required", (unsigned long long)out_cap, (unsigned long long)o);
-  for (uint32_t d = 0; d < ndocs; d++) if (!outs[d].empty()) std::memcpy(out + out_offsets[d], outs[d].data(), outs[d].size());
-  return TM_OK;
-}

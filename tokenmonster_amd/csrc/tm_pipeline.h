@@ -1,0 +1,115 @@
+// tm_pipeline.h — shared by the HIP translation units of libtokenmonster_hip.so: constants of the segment pipeline,
+// the tm_batch workspace behind the opaque handle, and the host-side entry points one unit offers the others.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "tm_device.h"
+
+namespace tmh {
+
+constexpr int SEG = 320;                 // bytes of one document segment (one wavefront); 320 -> 24 wavefronts per CU
+constexpr int NPOS = SEG + 40;           // positions whose descriptors a segment needs (look-ahead <= 40)
+constexpr int NPOS_PAD = (NPOS + 63) / 64 * 64;
+constexpr int TEXT_LEN = SEG + 96;       // staged text: position i may read up to i + 40
+constexpr int ENT = 80;                  // entry states of a segment: 40 offsets x fd{0,1}
+constexpr int WAVES = 4;                 // wavefronts per workgroup in K1 (plain variant)
+constexpr uint32_t R_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t J_EXIT = 1024;           // jump targets >= J_EXIT: left the segment; J_EXIT + next entry state
+constexpr uint32_t J_INVALID = 4095;        // state is not reachable (no forward-delete match there)
+constexpr uint32_t ID_NONE = 0xFFFFFFu;
+constexpr int NOSCORE = -1000000;
+constexpr uint32_t LONG_SEGS = 512;        // documents with more segments than this are resolved hierarchically
+
+constexpr int SCAN_T = 256, SCAN_PER = 16, SCAN_CH = SCAN_T * SCAN_PER;   // exclusive scan u32 -> u64: elements per workgroup
+
+// segment groups of long documents (hierarchical resolve, tm_kernels.hip)
+struct Group { uint32_t first_seg, nsegs, doc, pad; };
+struct LongDoc { uint32_t doc, first_group, ngroups, pad; };
+
+}  // namespace tmh
+
+struct tm_batch {
+  const tm_vocab* vocab = nullptr;
+  uint64_t max_bytes = 0;
+  uint32_t max_docs = 0;
+  uint64_t max_segs = 0;
+  uint64_t nbytes = 0, nseg = 0;
+  uint32_t ndocs = 0;
+  uint64_t device_bytes = 0;
+  hipStream_t last_stream = nullptr;
+  // device buffers
+  uint8_t* d_text = nullptr;
+  bool text_borrowed = false;          // scoring pass: text belongs to a tm_dataset
+  uint64_t* d_offsets = nullptr;       // packed batches: doc_begin = d_offsets, doc_end = d_offsets + 1
+  const uint64_t* d_doc_begin = nullptr;
+  const uint64_t* d_doc_end = nullptr;
+  uint32_t* d_doc_nseg = nullptr;
+  uint64_t* d_doc_seg_start = nullptr;
+  uint32_t* d_seg_doc = nullptr;
+  uint2* d_R = nullptr;
+  uint2* d_exitmap = nullptr;
+  uint8_t* d_seg_entry = nullptr;
+  uint32_t* d_seg_tokbase = nullptr;
+  uint32_t* d_doc_ntok = nullptr;
+  uint32_t* d_doc_events = nullptr;
+  uint32_t* d_doc_missing = nullptr;
+  uint64_t* d_tok_offsets = nullptr;
+  uint64_t* d_scan_tmp = nullptr;   // block sums
+  uint64_t* d_totals = nullptr;     // [0] nseg total (device-computed), [1] token total, [2] missing total
+  uint32_t* d_error = nullptr;
+  // long documents (hierarchical resolve)
+  uint32_t ngroups = 0, nlong = 0, cap_groups = 0, cap_long = 0;
+  tmh::Group* d_groups = nullptr;
+  tmh::LongDoc* d_longs = nullptr;
+  uint4* d_gmap = nullptr;
+  uint8_t* d_group_entry = nullptr;
+  uint4* d_group_base = nullptr;
+  // raw (un-normalized) input of tm_batch_upload_raw / tm_batch_normalize
+  uint8_t* d_raw = nullptr;
+  uint8_t* d_slab = nullptr;            // normalizer: one 2 KiB slab per 1 KiB piece
+  uint64_t slab_cap = 0;
+  uint64_t* d_raw_off = nullptr;
+  uint64_t raw_cap = 0, raw_bytes = 0, raw_pieces = 0, piece_cap = 0;
+  uint32_t raw_docs = 0, raw_docs_cap = 0;
+  std::vector<uint64_t> h_raw_off;
+  uint32_t host_fallback_docs = 0;
+  uint32_t* d_doc_npiece = nullptr;     // pieces per raw document, then (scan) first piece of each document
+  uint64_t* d_doc_piece_start = nullptr;
+  uint32_t* d_piece_doc = nullptr;
+  uint32_t* d_piece_sum = nullptr;      // per-piece run summary (pass 1)
+  uint8_t* d_piece_carry = nullptr;     // per-piece carries (pass 2)
+  uint32_t* d_piece_len = nullptr;      // normalized bytes per piece (pass 3)
+  uint64_t* d_piece_off = nullptr;      // their exclusive scan
+  uint8_t* d_need_host = nullptr;       // per document: needs the host normalizer
+  uint64_t* d_nbegin = nullptr;         // normalized document ranges (GPU documents packed first, fallback documents after)
+  uint64_t* d_nend = nullptr;
+  uint64_t* d_ninfo = nullptr;          // [0] #fallback docs [1] #long docs [2] #segments (device-computed)
+  // grow-only staging for the host fallback
+  uint8_t* d_fb_raw = nullptr; uint8_t* d_fb_norm = nullptr; uint64_t* d_fb_roff = nullptr; uint64_t* d_fb_noff = nullptr; uint32_t* d_fb_ids = nullptr;
+  uint64_t fb_raw_cap = 0, fb_norm_cap = 0; uint32_t fb_docs_cap = 0;
+  uint32_t* d_out = nullptr;
+  uint64_t out_cap = 0;
+  hipEvent_t ev[TM_NUM_KERNELS + 1] = {};
+  bool have_events = false;
+};
+
+namespace tmh {
+
+// tm_kernels.hip
+hipError_t batch_alloc_bytes(tm_batch* b, void** p, uint64_t bytes);
+int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, bool own_text, bool with_output, tm_batch** out);
+void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st);
+void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32_t ndocs, uint32_t unit, uint32_t* doc_nunits, hipStream_t st);
+void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st);
+int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs);
+int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit);
+// scoring variant of the chain kernel: histogram in HBM (scores | 4 limbs | 256 counters), see tm_score.hip
+void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
+                       uint32_t n_ids, hipStream_t st);
+// tm_normalize.cpp
+bool normalize_supported(uint32_t capcode, uint32_t norm_flag);
+
+}  // namespace tmh

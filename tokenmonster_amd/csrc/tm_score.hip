@@ -1,0 +1,148 @@
+// tm_score.hip — the trainvocab candidate-scoring pass behind tm_dataset_upload / tm_score* (include/tokenmonster_hip.h).
+//
+// Replaces the worker loop of training/trainvocab.go:925-1176: the SAME walk as tokenization (tm_kernels.hip: match_branch,
+// resolve) over strips of one device-resident normalized dataset, but instead of emitting ids the chain kernel accumulates
+// scores[id] += bytes covered, scores[deleteToken] += 1 per forward delete, tokensInText and the set of bytes that had no
+// token (trainvocab.go:1105-1174).  The histogram lives in HBM as plain uint32 sums so that data-parallel ranks merge it
+// with ONE RCCL all-reduce (tokenmonster_amd/dist.py).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "tm_pipeline.h"
+
+using namespace tmh;
+
+struct tm_dataset {
+  uint8_t* d_text = nullptr;
+  uint64_t n = 0;
+  tm_batch* ws = nullptr;          // workspace, created on first use and reused by every scoring pass
+  uint32_t ws_docs = 0;
+  uint32_t* d_hist = nullptr;      // scores | 4 token limbs | 256 missing counters
+  uint64_t hist_words = 0;
+  unsigned long long* d_tokens = nullptr;
+  uint32_t* d_missing_bits = nullptr;
+  int n_cu = 256;
+};
+
+static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+                     hipStream_t st) {
+  if (!v || !d) return set_error(TM_E_INVALID, "null argument");
+  std::vector<uint64_t> be;
+  uint64_t whole_off = 0, whole_len = d->n;
+  if (n_strips == 0) { strip_off = &whole_off; strip_len = &whole_len; n_strips = 1; }
+  be.resize(2ull * n_strips);
+  uint64_t nseg = 0;
+  for (uint32_t k = 0; k < n_strips; k++) {
+    if (strip_off[k] > d->n || strip_len[k] > d->n - strip_off[k]) return set_error(TM_E_INVALID, "strip %u outside the dataset", k);
+    be[k] = strip_off[k];
+    be[n_strips + k] = strip_off[k] + strip_len[k];
+    nseg += (strip_len[k] + SEG - 1) / SEG;
+  }
+  hipError_t e;
+  if (d->ws && (d->ws->vocab != v || d->ws_docs < n_strips)) { tm_batch_free(d->ws); d->ws = nullptr; }
+  if (!d->ws) {
+    int rc = make_workspace(v, d->n, n_strips, false, false, &d->ws);
+    if (rc != TM_OK) return rc;
+    d->ws_docs = n_strips;
+    d->ws->d_text = d->d_text;
+  }
+  tm_batch* b = d->ws;
+  b->vocab = v;
+  const uint64_t words = (uint64_t)v->host.n_ids + 4 + 256;
+  if (d->hist_words != words) {
+    (void)hipFree(d->d_hist);
+    d->d_hist = nullptr;
+    if ((e = hipMalloc((void**)&d->d_hist, words * 4)) != hipSuccess) return hip_fail(e, "hipMalloc histogram");
+    d->hist_words = words;
+  }
+  if ((e = hipMemcpyAsync(b->d_offsets, be.data(), be.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D strips");
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync");   // `be` is a host temporary
+  b->d_doc_begin = b->d_offsets;
+  b->d_doc_end = b->d_offsets + n_strips;
+  b->ndocs = n_strips;
+  b->nbytes = d->n;
+  b->nseg = nseg;
+  { int grc = build_groups(b, be.data(), be.data() + n_strips, n_strips); if (grc != TM_OK) return grc; }
+  (void)hipMemsetAsync(d->d_hist, 0, words * 4, st);
+  (void)hipMemsetAsync(d->d_tokens, 0, 8, st);
+  (void)hipMemsetAsync(d->d_missing_bits, 0, 32, st);
+  int rc = run_pipeline(b, st, false, nullptr, false);
+  if (rc != TM_OK) return rc;
+  launch_chain_hist(b, v->tables.has_delete ? v->tables.delete_id : 0, d->n_cu, d->d_hist, d->d_tokens, d->d_missing_bits, v->host.n_ids, st);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
+  return TM_OK;
+}
+
+extern "C" {
+
+int tm_dataset_upload(const uint8_t* normalized, uint64_t n, tm_dataset** out) {
+  if (!out || (n && !normalized)) return set_error(TM_E_INVALID, "null argument");
+  auto* d = new tm_dataset();
+  hipError_t e;
+  if ((e = hipMalloc((void**)&d->d_text, n + 256)) != hipSuccess || (e = hipMalloc((void**)&d->d_tokens, 8)) != hipSuccess ||
+      (e = hipMalloc((void**)&d->d_missing_bits, 32)) != hipSuccess ||
+      (n && (e = hipMemcpy(d->d_text, normalized, n, hipMemcpyHostToDevice)) != hipSuccess)) {
+    tm_dataset_free(d);
+    return hip_fail(e, "dataset upload");
+  }
+  d->n = n;
+  { int dev = 0, cu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) d->n_cu = cu; }
+  *out = d;
+  return TM_OK;
+}
+
+void tm_dataset_free(tm_dataset* d) {
+  if (!d) return;
+  tm_batch_free(d->ws);
+  (void)hipFree(d->d_text); (void)hipFree(d->d_hist); (void)hipFree(d->d_tokens); (void)hipFree(d->d_missing_bits);
+  delete d;
+}
+
+int tm_score_device(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+                    void* stream, uint32_t** dev_hist, uint64_t* n_words) {
+  int rc = score_run(v, d, strip_off, strip_len, n_strips, (hipStream_t)stream);
+  if (rc != TM_OK) return rc;
+  if (dev_hist) *dev_hist = d->d_hist;
+  if (n_words) *n_words = d->hist_words;
+  return TM_OK;
+}
+
+int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+                         void* stream, uint32_t* dst_device, uint64_t dst_words) {
+  if (!dst_device) return set_error(TM_E_INVALID, "null argument");
+  int rc = score_run(v, d, strip_off, strip_len, n_strips, (hipStream_t)stream);
+  if (rc != TM_OK) return rc;
+  if (dst_words < d->hist_words) return set_error(TM_E_NOSPACE, "destination holds %llu words, histogram has %llu", (unsigned long long)dst_words, (unsigned long long)d->hist_words);
+  hipError_t e = hipMemcpyAsync(dst_device, d->d_hist, d->hist_words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "D2D histogram");
+  return TM_OK;
+}
+
+int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+             uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]) {
+  int rc = score_run(v, d, strip_off, strip_len, n_strips, nullptr);
+  if (rc != TM_OK) return rc;
+  hipError_t e;
+  std::vector<uint32_t> h(d->hist_words);
+  uint32_t err = 0;
+  if ((e = hipMemcpy(h.data(), d->d_hist, h.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H histogram");
+  if ((e = hipMemcpy(&err, d->ws->d_error, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H error flag");
+  if (err) return set_error(TM_E_HIP, "device pipeline inconsistency (unreachable segment entry state)");
+  const uint32_t n_ids = v->host.n_ids;
+  if (scores) std::memcpy(scores, h.data(), (size_t)n_ids * 4);
+  if (tokens_in_text) {
+    uint64_t t = 0;
+    for (int k = 0; k < 4; k++) t += (uint64_t)h[n_ids + k] << (16 * k);
+    *tokens_in_text = t;
+  }
+  if (missing_set) {
+    std::memset(missing_set, 0, 32);
+    for (int k = 0; k < 256; k++) if (h[n_ids + 4 + k]) missing_set[k >> 3] |= (uint8_t)(1u << (k & 7));
+  }
+  return TM_OK;
+}
+
+}  // extern "C"
