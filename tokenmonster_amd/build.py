@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
     objs = []
     hipcc = _hipcc()
     common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-              "-Wall", "-Wno-unused-result"]
+              "-Wall", "-Wno-unused-result"] + os.environ.get("TM_EXTRA_FLAGS", "").split()
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     procs = []
     for s in srcs:

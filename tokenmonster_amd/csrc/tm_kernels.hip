@@ -132,9 +132,9 @@ __global__ void k_segments(const uint64_t* __restrict__ doc_seg_start, uint32_t 
 //   S + 4 = len + allLetters/allPunct + max0(nWords-1) + beginsWithSpace (plain look-up only) + nextIsSpace
 //           + (nWords + nextIsNotLetter) * 100 - 3 * (endsWithLetter & nextIsLetter)
 // (the two cross terms of the penalty need the first token: begins-with-letter and begins-on-capcode stay as bits).
-__device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_t nb, bool bvariant) {
+__device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_t nb, bool bvariant, uint32_t hint) {
   const uint32_t f5 = v >> 27, snw = (v >> 22) & 31u;
-  const int send = (int)(f5 & 1u), sbegl = (int)((f5 >> 1) & 1u), sbegs = (int)((f5 >> 2) & 1u), sbegc = (int)((f5 >> 3) & 1u),
+  const int send = (int)(f5 & 1u), sbegl = (int)((f5 >> 1) & 1u), sbegs = (int)((f5 >> 2) & 1u & ~((f5 >> 1) & hint)), sbegc = (int)((f5 >> 3) & 1u),
             sall = (int)((f5 >> 4) & 1u);
   const int S = (int)len + sall + max((int)snw - 1, 0) + (bvariant ? 0 : sbegs) + (int)((nb >> 2) & 1u) + ((int)snw + (int)(nb >> 3)) * 100 -
                 (send & (int)(nb & 1u)) * 3;
@@ -192,6 +192,7 @@ struct WaveLds {
   uint32_t Db[NPOS_PAD];   // longest match of ' '+text[p:], if usable (forward-delete descriptor), 0 = none
   uint32_t X[NPOS_PAD];    // node value of D's token (node id = record ordinal)
   uint32_t Xb[SEG];        // node value of Db's token
+  uint16_t xch[64];        // dense task list of the forward-delete walks (step A3), one batch at a time
 };
 
 // T(p, fd): go/tokenmonster.go:1051-1276
@@ -238,6 +239,22 @@ __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w
   return id | ((uint32_t)len << 24);                                                           // go :1265-1267
 }
 
+#ifdef TM_PHASE_TIMERS
+// development aid (never defined in the product build): per-phase wall cycles of one wavefront, summed over all of them
+__device__ unsigned long long g_phase[64 * 32];
+#define PH_INIT unsigned long long ph_t = __builtin_readcyclecounter(); unsigned long long ph_a[8] = {0}; int ph_c[16] = {0};
+#define PH(i) { const unsigned long long ph_n = __builtin_readcyclecounter(); ph_a[i] += ph_n - ph_t; ph_t = ph_n; }
+#define PH_COUNT(i, n) ph_c[i] += (int)(n);
+#define PH_INC(i) ph_c[i]++;
+#define PH_FLUSH { if (lane == 0) { unsigned long long* gp = g_phase + (blockIdx.x & 63) * 32; for (int q = 0; q < 8; q++) atomicAdd(&gp[q], ph_a[q]); for (int q = 8; q < 16; q++) atomicAdd(&gp[q], (unsigned long long)ph_c[q]); } }
+#else
+#define PH_INIT
+#define PH_INC(i)
+#define PH_FLUSH
+#define PH(i)
+#define PH_COUNT(i, n)
+#endif
+
 constexpr int NWALK = 2;                 // independent trie walks in flight per lane
 constexpr int REFILL_THR = 24;           // K1 refills idle lanes when fewer than this many (per walk slot) are still walking
 
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   const uint64_t rem = doc_end[doc] - begin;
   const int dl = rem > (uint64_t)(1 << 20) ? (1 << 20) : (int)rem;   // bytes of the document from `begin` on (clamped)
   const int seglen = min(dl, SEG);
+  PH_INIT
 
   // stage the text with (unaligned) dword loads; bytes at and after the end of the document read as 0: the pad
   // byte of go/tokenmonster.go:1038-1046 (quirk Q1: we define it as 0 like tokenmonster.cpp:1724-1726)
@@ -287,6 +305,8 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   // idles behind the longest walk of a block.  (pansearch LongestSubstring, call sites go/tokenmonster.go:1049..)
   for (int j = lane; j < NPOS_PAD; j += 64) { w.D[j] = 0; w.Db[j] = 0; }
   __builtin_amdgcn_wave_barrier();
+  PH(0)
+  PH_COUNT(12, 1)
   const int ntask = (dbg & 1) ? 0 : min(NPOS, dl);     // positions >= dl keep descriptor 0 (nothing there)
   {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
@@ -338,9 +358,12 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       int nactive = 0;
 #pragma unroll
       for (int s = 0; s < NWALK; s++) nactive += __popcll(__ballot(k[s].active));
+      PH(1)
+      PH_INC(10)
       if (nactive == 0) { if (next_task >= ntask) break; continue; }
-      // tight probe loop
-      const int thr = next_task < ntask ? NWALK * REFILL_THR : 1;
+      // tight probe loop; once the positions are used up it only runs while the walks still fill more than one slot per lane
+      const bool pool = next_task < ntask;
+      const int thr = pool ? NWALK * REFILL_THR : 65;
       do {
         uint2 e[NWALK];
 #pragma unroll
@@ -354,8 +377,41 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
           }
           nactive += __popcll(__ballot(k[s].active));
         }
+        PH_INC(8)
       } while (nactive >= thr);
+      PH(2)
+      if (!pool) break;
     }
+    // drain: at most 64 walks are left (typically a handful of long ones).  They are gathered into slot 0 — a lane's own
+    // second walk moves over in registers, the rest goes through LDS to idle lanes — so that the remaining rounds cost
+    // one probe per lane instead of NWALK.
+    static_assert(NWALK == 2, "the drain below moves slot 1 into slot 0");
+    if (!k[0].active && k[1].active) { k[0] = k[1]; k[1].active = false; }
+    const unsigned long long give = __ballot(k[1].active);
+    if (give != 0) {
+      const unsigned long long idle = __ballot(!k[0].active);
+      uint4* xw = reinterpret_cast<uint4*>(w.Xb);         // free until step A3; 64 x 16 B
+      if (k[1].active)
+        xw[__popcll(give & lane_below)] = make_uint4((uint32_t)k[1].pos | ((uint32_t)k[1].depth << 10) | ((uint32_t)k[1].limit << 16) | ((uint32_t)k[1].bestlen << 22),
+                                                     k[1].key, k[1].haddr, k[1].bestv);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0);
+      const int r = __popcll(idle & lane_below);
+      if (!k[0].active && r < __popcll(give)) {
+        const uint4 q = xw[r];
+        k[0].pos = k[0].tbase = (int)(q.x & 1023u); k[0].depth = (int)((q.x >> 10) & 63u); k[0].limit = (int)((q.x >> 16) & 63u);
+        k[0].bestlen = (int)(q.x >> 22); k[0].key = q.y; k[0].haddr = q.z; k[0].bestv = q.w; k[0].active = true;
+      }
+    }
+    while (__any(k[0].active)) {
+      const uint2 e = hash_tab[k[0].haddr];
+      if (walk_consume(T, w.text, k[0], e) && k[0].bestlen != 0) {
+        w.D[k[0].pos] = (uint32_t)k[0].bestlen | ((k[0].bestv >> 22) << 6);
+        w.X[k[0].pos] = k[0].bestv;
+      }
+      PH_INC(9)
+    }
+    PH(3)
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
@@ -372,65 +428,68 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       bool el = false;
       if (d != 0) {
         const uint32_t nb = s_bb[w.text[p + (d & 63u)]];
-        el = can_b && ((d >> 12) & 1u) && nb == 1 && ((d >> 6) & 31u) == 0 && min(dl - p, Lmax - off) > 0;
-        w.D[p] = make_sdesc(d & 63u, (d >> 6) << 22, nb, false);
+        el = can_b && ((d >> 12) & 1u) && (((d >> 13) & 1u) | (T.spl_hint ^ 1u)) && nb == 1 && ((d >> 6) & 31u) == 0 && min(dl - p, Lmax - off) > 0;
+        w.D[p] = make_sdesc(d & 63u, (d >> 6) << 22, nb, false, T.spl_hint);
       }
       elig[it] = __ballot(el);
     }
   }
+  PH(4)
   {
     // ---- A3: longest match of ' '+text[p:] at the eligible positions -> Db[p], Xb[p] (accepted only if longer, go :1092)
-    // The space-prefix link of the plain match (one gather) stands for the first mainlen+off bytes of that walk, so
-    // only the few walks that can still grow run the probe loop; positions are taken in place, NWALK blocks at a time.
+    // Eligible positions are few, so they are first compacted into a dense list (64 at a time) and every lane runs one
+    // walk.  The space-prefix link of the plain match (one gather) stands for the first mainlen+off bytes of that walk,
+    // so only the walks that can still grow enter the probe loop.
     const int off = (int)T.off;
+    int n_el = 0;
 #pragma unroll
-    for (int it = 0; it < NPOS_PAD / 64; it += NWALK) {
-      Walk k[NWALK];
-      int mainlen[NWALK];
-      bool any = false;
+    for (int it = 0; it < NPOS_PAD / 64; it++) n_el += __popcll(elig[it]);
+    for (int base = 0; base < n_el; base += 64) {
+      int run = 0;
 #pragma unroll
-      for (int s = 0; s < NWALK; s++) {
-        k[s] = Walk{0, 0, 0, 0, 0, 0u, 0u, 0u, 0u, false};
-        mainlen[s] = 0;
-        const int p = (it + s) * 64 + lane;
-        if (it + s < NPOS_PAD / 64 && ((elig[(it + s) < NPOS_PAD / 64 ? it + s : 0] >> lane) & 1ull)) {
-          const uint32_t ml = w.D[p] & 63u;
-          const uint2 e = T.spl[node_id(w.X[p])];
-          const int limit = min(dl - p, Lmax - off) + off;
-          const int depth = (int)ml + off;
-          const int bl = (int)((e.x >> 22) & 63u);
-          if (e.x != kNone && ((e.x >> 21) & 1u) && depth < limit) {
-            k[s].pos = p; k[s].tbase = p - off; k[s].bestlen = bl; k[s].bestv = e.y; k[s].depth = depth; k[s].limit = limit;
-            mainlen[s] = (int)ml;
-            k[s].active = true;
-            k[s].key = ((e.x & kNodeMask) << 8) | w.text[p + ml];
-            k[s].h32 = k[s].key * 0x9E3779B1u;
-            k[s].haddr = k[s].h32 >> T.edge_shift;
-          } else if (e.x != kNone && bl > (int)ml + 1) {               // (only possible with the two-byte UTF-16 prefix)
-            const int lb = bl - off;
-            w.Db[p] = make_sdesc((uint32_t)lb, e.y, s_bb[w.text[p + lb]], true);
-            if (p < SEG) w.Xb[p] = e.y;
-          }
-        }
-        any |= k[s].active;
+      for (int it = 0; it < NPOS_PAD / 64; it++) {
+        const int dst = run + __popcll(elig[it] & lane_below) - base;
+        if (((elig[it] >> lane) & 1ull) && dst >= 0 && dst < 64) w.xch[dst] = (uint16_t)(it * 64 + lane);
+        run += __popcll(elig[it]);
       }
-      while (__any(any)) {
-        uint2 e[NWALK];
-#pragma unroll
-        for (int s = 0; s < NWALK; s++) e[s] = hash_tab[k[s].haddr];
-        any = false;
-#pragma unroll
-        for (int s = 0; s < NWALK; s++) {
-          if (walk_consume(T, w.text, k[s], e[s]) && k[s].bestlen > mainlen[s] + 1) {
-            const int lb = k[s].bestlen - off;                              // go :1093
-            w.Db[k[s].pos] = make_sdesc((uint32_t)lb, k[s].bestv, s_bb[w.text[k[s].pos + lb]], true);
-            if (k[s].pos < SEG) w.Xb[k[s].pos] = k[s].bestv;
-          }
-          any |= k[s].active;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0);
+      Walk k = Walk{0, 0, 0, 0, 0, 0u, 0u, 0u, 0u, false};
+      int mainlen = 0;
+      if (base + lane < n_el) {
+        const int p = (int)w.xch[lane];
+        const uint32_t ml = w.D[p] & 63u;
+        const uint2 e = T.spl[node_id(w.X[p])];
+        const int limit = min(dl - p, Lmax - off) + off;
+        const int depth = (int)ml + off;
+        const int bl = (int)((e.x >> 22) & 63u);
+        if (e.x != kNone && ((e.x >> 21) & 1u) && depth < limit) {
+          k.pos = p; k.tbase = p - off; k.bestlen = bl; k.bestv = e.y; k.depth = depth; k.limit = limit;
+          mainlen = (int)ml;
+          k.active = true;
+          k.key = ((e.x & kNodeMask) << 8) | w.text[p + ml];
+          k.h32 = k.key * 0x9E3779B1u;
+          k.haddr = k.h32 >> T.edge_shift;
+        } else if (e.x != kNone && bl > (int)ml + 1) {               // (only possible with the two-byte UTF-16 prefix)
+          const int lb = bl - off;
+          w.Db[p] = make_sdesc((uint32_t)lb, e.y, s_bb[w.text[p + lb]], true, T.spl_hint);
+          if (p < SEG) w.Xb[p] = e.y;
         }
       }
+      while (__any(k.active)) {
+        const uint2 e = hash_tab[k.haddr];
+        if (walk_consume(T, w.text, k, e) && k.bestlen > mainlen + 1) {
+          const int lb = k.bestlen - off;                              // go :1093
+          w.Db[k.pos] = make_sdesc((uint32_t)lb, k.bestv, s_bb[w.text[k.pos + lb]], true, T.spl_hint);
+          if (k.pos < SEG) w.Xb[k.pos] = k.bestv;
+        }
+        PH_INC(11)
+      }
+      __builtin_amdgcn_wave_barrier();
     }
+    PH_COUNT(14, n_el)
   }
+  PH(5)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
 
@@ -484,7 +543,9 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       r1[it] = ((m1[it] >> lane) & 1ull) ? w.Xb[p] : R_INVALID;
       if (p < seglen) R[begin + p] = make_uint2(r0[it], r1[it]);
     }
+    PH_COUNT(15, n1)
   }
+  PH(6)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
 
@@ -525,25 +586,39 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     for (int k = 0; k < NS; k++) if ((ja[k].x & 0xFFFu) < J_EXIT) pend |= 1u << k;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
-    // entry state e = offset*2 + fd  <->  state index fd*SEG + offset
-    const int e0 = lane, e1 = 64 + lane;
-    const int se0 = (e0 & 1) * SEG + (e0 >> 1), se1 = (e1 & 1) * SEG + (e1 >> 1);
+    // One round: every pending state composes itself with the state it points at.  The (p,0) states — five per lane,
+    // nearly all pending — are handled without branches so that their LDS reads are issued back to back (one LDS
+    // latency per round instead of five); the rare pending (p,1) states take the generic path.  The entry states sit at
+    // the start of the segment and have the longest chains, so "nothing pending" is also when they are done.
+    constexpr int N0 = SEG / 64;
     for (int round = 0; round < 12 && __any(pend != 0); round++) {
+      uint2 bn[N0];
 #pragma unroll
-      for (int k = 0; k < NS; k++) {
-        if (pend & (1u << k)) {
-          const uint2 bnext = J[ja[k].x & 0xFFFu];
-          ja[k].x = (bnext.x & 0xFFFu) | (((ja[k].x >> 12) + (bnext.x >> 12)) << 12);
-          ja[k].y = ja[k].y + bnext.y;                    // two 16-bit counters, neither can overflow (<= 512 each)
-          J[k * 64 + lane] = ja[k];
-          if ((ja[k].x & 0xFFFu) >= J_EXIT) pend &= ~(1u << k);
+      for (int k = 0; k < N0; k++) bn[k] = J[((pend >> k) & 1u) ? (ja[k].x & 0xFFFu) : (uint32_t)(k * 64 + lane)];
+#pragma unroll
+      for (int k = 0; k < N0; k++) {
+        const bool pk = ((pend >> k) & 1u) != 0;
+        const uint32_t nx = (bn[k].x & 0xFFFu) | (((ja[k].x >> 12) + (bn[k].x >> 12)) << 12);
+        ja[k].x = pk ? nx : ja[k].x;
+        ja[k].y += pk ? bn[k].y : 0u;                     // two 16-bit counters, neither can overflow (<= 512 each)
+        if (pk) J[k * 64 + lane] = ja[k];
+        if ((ja[k].x & 0xFFFu) >= J_EXIT) pend &= ~(1u << k);
+      }
+      if (__any((pend >> N0) != 0)) {
+#pragma unroll
+        for (int k = N0; k < NS; k++) {
+          if (pend & (1u << k)) {
+            const uint2 bnext = J[ja[k].x & 0xFFFu];
+            ja[k].x = (bnext.x & 0xFFFu) | (((ja[k].x >> 12) + (bnext.x >> 12)) << 12);
+            ja[k].y = ja[k].y + bnext.y;
+            J[k * 64 + lane] = ja[k];
+            if ((ja[k].x & 0xFFFu) >= J_EXIT) pend &= ~(1u << k);
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0);
-      bool waiting = (J[se0].x & 0xFFFu) < J_EXIT;
-      if (lane < ENT - 64) waiting |= (J[se1].x & 0xFFFu) < J_EXIT;
-      if (!__any(waiting)) break;
+      PH_INC(13)
     }
     for (int e = lane; e < ENT; e += 64) {
       const uint2 a = J[(e & 1) * SEG + (e >> 1)];
@@ -553,6 +628,8 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       exitmap[g * ENT + e] = o;
     }
   }
+  PH(7)
+  PH_FLUSH
 }
 
 // exit map entry (uint2): x = next entry state [0..7] | #id events << 8 ; y = #forward-deletes | #missing << 16
@@ -1109,6 +1186,18 @@ int tm_batch_download(tm_batch* b, uint32_t* tokens_out, uint64_t tokens_cap, ui
 const uint32_t* tm_batch_device_tokens(const tm_batch* b) { return b->d_out; }
 const uint64_t* tm_batch_device_tok_offsets(const tm_batch* b) { return b->d_tok_offsets; }
 uint64_t tm_batch_device_bytes(const tm_batch* b) { return b->device_bytes; }
+
+#ifdef TM_PHASE_TIMERS
+int tm_debug_phases(unsigned long long* out, int reset) {
+  static unsigned long long z[64 * 32];
+  if (out) {
+    if (hipMemcpyFromSymbol(z, HIP_SYMBOL(tmh::g_phase), sizeof z) != hipSuccess) return -1;
+    for (int i = 0; i < 32; i++) { out[i] = 0; for (int b = 0; b < 64; b++) out[i] += z[b * 32 + i]; }
+  }
+  if (reset) { for (auto& x : z) x = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(tmh::g_phase), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 // ---- host-buffer entry points ---------------------------------------------------------------------
 static int with_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, tm_batch** pb, bool emit) {

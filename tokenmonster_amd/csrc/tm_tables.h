@@ -17,6 +17,8 @@
 //   bits 27..31  the five flag bits a *second* token is asked for (go :1075-1084):
 //                b0 ends-with-letter(1) b1 begins-with-letter(2) b2 begins-with-space(4)
 //                b3 begins-on-capcode(16) b4 all-letters-or-all-punct(128)
+//                When Tables::spl_hint is set, b2 of a token that begins with a letter (never also with a space) says
+//                instead whether its forward-delete probe can succeed at all (see Tables::spl).
 #pragma once
 #include <cstdint>
 
@@ -63,6 +65,7 @@ struct Tables {
   uint32_t off;            // 1, or 2 for UTF-16 (lilbufOffset, go :1031-1034)
   uint32_t bstart;         // node value after consuming ' ' (and 0x00 for UTF-16), kNone if absent
   uint32_t has_delete, delete_id, unk_id;
+  uint32_t spl_hint;       // b2 of letter-initial tokens is the forward-delete hint
 };
 
 }  // namespace tmh

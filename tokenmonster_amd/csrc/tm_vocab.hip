@@ -124,9 +124,43 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   const uint32_t n_nodes = next_internal;
   std::vector<uint8_t> has_child(n_nodes, 0);
   for (auto& kv : child) { uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) has_child[parent] = 1; }
+  // Forward-delete hint (tm_tables.h): can the walk of ' '+key (the probe of go :1088-1095) end on something longer than
+  // ' '+key itself?  Only then is the probe worth starting.  The hint rides in the begins-with-space bit of tokens that
+  // begin with a letter (the two are mutually exclusive in any vocabulary the reference's builder writes); if a file
+  // ever carries both bits on one record the hint is switched off and the kernels probe every eligible position.
+  const uint32_t spl_off = hv.charset == 2 ? 2u : 1u;
+  uint32_t spl_start = kNone;
+  { auto it = child.find(((uint64_t)kRoot << 8) | ' '); if (it != child.end()) spl_start = it->second; }
+  if (spl_start != kNone && spl_off == 2) { auto it = child.find(((uint64_t)spl_start << 8) | 0u); spl_start = it != child.end() ? it->second : kNone; }
+  struct Spl { uint32_t node, cont, bestlen, best; };
+  std::vector<Spl> splw(n_info, Spl{kNone, 0, 0, kNone});
+  std::vector<uint8_t> spl_hint(n_info, 0);
+  hv.spl_hint = 1;
+  for (uint32_t i = 0; i < n_info; i++) if ((flags[i] & 2u) && (flags[i] & 4u)) hv.spl_hint = 0;
+  if (spl_start != kNone) {
+    for (uint32_t i = 0; i < n_info; i++) {
+      const uint8_t* k = &hv.keys[hv.key_off[i]];
+      const uint32_t kl = lens[i];
+      uint32_t node = spl_start, depth = spl_off, bestlen = 0, best = kNone, used = 0;
+      if (node < n_info) { bestlen = depth; best = node; }
+      while (used < kl && depth < hv.max_len) {
+        auto it = child.find(((uint64_t)node << 8) | k[used]);
+        if (it == child.end()) break;
+        node = it->second; used++; depth++;
+        if (node < n_info) { bestlen = depth; best = node; }
+      }
+      const uint32_t cont = (used == kl && has_child[node] && depth < hv.max_len) ? 1u : 0u;
+      splw[i] = Spl{node, cont, bestlen, best};
+      spl_hint[i] = (cont || bestlen > kl + 1) ? 1 : 0;
+    }
+  }
   auto value_of = [&](uint32_t id) {
     uint32_t v = id | (has_child[id] ? kHasChildren : 0);
-    if (id < n_info) v |= ((uint32_t)nwords[id] << 22) | (flag8_to_flag5(flags[id]) << 27);
+    if (id < n_info) {
+      uint32_t f5 = flag8_to_flag5(flags[id]);
+      if (hv.spl_hint && (f5 & 2u)) f5 = (f5 & ~4u) | (spl_hint[id] ? 4u : 0u);
+      v |= ((uint32_t)nwords[id] << 22) | (f5 << 27);
+    }
     return v;
   };
   hv.root.assign(256, kNone);
@@ -163,30 +197,11 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     }
     hv.rev_off[hv.n_ids] = (uint32_t)hv.rev_bytes.size();
   }
-  // space-prefix links: walk ' ' (+ 0x00 for UTF-16) + key through the trie once per record
-  {
-    const uint32_t off = hv.charset == 2 ? 2u : 1u;
-    hv.spl.assign(n_info, uint2{kNone, 0u});
-    uint32_t start = kNone;
-    { auto it = child.find(((uint64_t)kRoot << 8) | ' '); if (it != child.end()) start = it->second; }
-    if (start != kNone && off == 2) { auto it = child.find(((uint64_t)start << 8) | 0u); start = it != child.end() ? it->second : kNone; }
-    if (start != kNone) {
-      for (uint32_t i = 0; i < n_info; i++) {
-        const uint8_t* k = &hv.keys[hv.key_off[i]];
-        const uint32_t kl = lens[i];
-        uint32_t node = start, depth = off, bestlen = 0, bestv = 0, used = 0;
-        if (node < n_info) { bestlen = depth; bestv = value_of(node); }
-        while (used < kl && depth < hv.max_len) {
-          auto it = child.find(((uint64_t)node << 8) | k[used]);
-          if (it == child.end()) break;
-          node = it->second; used++; depth++;
-          if (node < n_info) { bestlen = depth; bestv = value_of(node); }
-        }
-        const uint32_t cont = (used == kl && has_child[node] && depth < hv.max_len) ? 1u : 0u;
-        hv.spl[i] = uint2{node | (cont << 21) | (bestlen << 22), bestv};
-      }
-    }
-  }
+  // space-prefix links (walked above): x = node reached | continue << 21 | best accepting depth << 22, y = that node's value
+  hv.spl.assign(n_info, uint2{kNone, 0u});
+  if (spl_start != kNone)
+    for (uint32_t i = 0; i < n_info; i++)
+      hv.spl[i] = uint2{splw[i].node | (splw[i].cont << 21) | (splw[i].bestlen << 22), splw[i].best != kNone ? value_of(splw[i].best) : 0u};
   // direct map: fold the depth-1 answer in, so one 8-byte load resolves the first two bytes of any walk
   for (uint32_t b0 = 0; b0 < 256; b0++) {
     const uint32_t r = hv.root[b0];
@@ -265,7 +280,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   Tables& t = v->tables;
   t.root = v->d_root; t.tab = v->d_tab; t.spl = v->d_spl; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
   t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
-  t.off = hv.off; t.bstart = hv.bstart;
+  t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint;
   t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
   *out = v;
   return TM_OK;
