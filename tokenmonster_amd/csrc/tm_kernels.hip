@@ -141,33 +141,37 @@ __device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_
   return len | ((uint32_t)sbegl << 6) | ((uint32_t)sbegc << 7) | ((uint32_t)(S + 4) << 8);
 }
 
-// one in-flight trie walk of a lane: text byte number d of the string being matched is text[tbase + d]
-struct Walk { int pos, tbase, depth, limit, bestlen; uint32_t haddr, key, bestv, h32; bool active; };
+// one in-flight trie walk of a lane: text byte number d of the string being matched is text[tbase + d].
+// An idle slot has key == KEY_IDLE (never stored in the table) and probes the always-empty slot behind the table,
+// so it needs no flag of its own: it neither hits nor re-probes, and its bestlen of 0 keeps it from storing anything.
+struct Walk { int pos, tbase, depth, limit, bestlen; uint32_t hoff, key, bestv; };
+constexpr uint32_t KEY_IDLE = 0xFFFFFFFEu;
+__device__ __forceinline__ bool walk_idle(const Walk& k) { return k.key == KEY_IDLE; }
+__device__ __forceinline__ uint32_t edge_slot_offset(const Tables& T, uint32_t node, uint32_t byte) {
+  return (edge_hash(node, byte) >> T.edge_shift) << 3;     // byte offset of the home slot
+}
+__device__ __forceinline__ uint2 load_slot(const uint2* hash_tab, uint32_t hoff) {
+  return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hash_tab) + hoff);   // scalar base + 32-bit lane offset
+}
 
 // consume one hash probe: follow the edge, remember the deepest accepting node, arm the next probe or stop
 // (pansearch LongestSubstring semantics, tokenmonster.cpp:786-877: longest prefix that is a key).
-// Written without branches: every lane executes the same ~25 instructions, idle lanes probe slot 0 and ignore it,
-// so the NWALK loads of a round are issued back to back and the round has a single wait.
-// Returns true when the walk finished in this round.
-__device__ __forceinline__ bool walk_consume(const Tables& T, const uint8_t* text, Walk& k, const uint2 e) {
-  const bool was = k.active;
-  const bool hit = was && e.x == k.key;
-  const bool again = was && !hit && e.x != kNone;                 // occupied by another key: linear probing
-  const uint32_t cur = e.y;
+// Written without branches: every lane executes the same instructions, so the NWALK loads of a round are issued back
+// to back and the round has a single wait.  `c` is the text byte after the one being matched (text[tbase+depth+1]),
+// read from LDS while the probe was in flight.  Returns true when the slot is (or has become) idle.
+__device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uint2 e, const uint32_t c) {
+  const bool hit = e.x == k.key;
+  const bool again = !hit && e.x != kNone;                        // occupied by another key: linear probing
+  const uint32_t cur = e.y, nid = node_id(cur);
   k.depth += hit ? 1 : 0;
-  const bool acc = hit && node_id(cur) < T.n_info;
+  const bool acc = hit && nid < T.n_info;
   k.bestv = acc ? cur : k.bestv;
   k.bestlen = acc ? k.depth : k.bestlen;
   const bool cont = hit && k.depth < k.limit && (cur & kHasChildren) != 0;
-  const uint32_t c = text[k.tbase + k.depth];                     // always inside the staged text
-  const uint32_t nkey = (node_id(cur) << 8) | c;
-  k.key = cont ? nkey : k.key;
-  const uint32_t nh32 = nkey * 0x9E3779B1u;
-  const uint32_t lin = (k.haddr + 1) & T.edge_mask;
-  k.h32 = cont ? nh32 : k.h32;
-  k.haddr = cont ? (nh32 >> T.edge_shift) : (again ? lin : 0u);
-  k.active = cont || again;
-  return was && !k.active;
+  const uint32_t lin = (k.hoff + 8u) & (T.edge_mask << 3);
+  k.key = cont ? ((nid << 8) | c) : (again ? k.key : KEY_IDLE);
+  k.hoff = cont ? edge_slot_offset(T, nid, c) : (again ? lin : (T.edge_mask + 1u) << 3);
+  return !(cont || again);
 }
 
 // candidate first token of a branch: bytes consumed, and what it contributes to the score on its own:
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   const int Lmax = (int)T.max_len;
   const unsigned long long lane_below = (1ull << lane) - 1ull;
   const uint2* __restrict__ hash_tab = T.tab + kL2Size;
+  const uint32_t idle_off = (T.edge_mask + 1u) << 3;      // the always-empty slot behind the edge hash
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
   const uint64_t rem = doc_end[doc] - begin;
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     int next_task = 0;                        // wave-uniform
     Walk k[NWALK];
 #pragma unroll
-    for (int s = 0; s < NWALK; s++) k[s] = Walk{0, 0, 0, 0, 0, 0u, 0u, 0u, 0u, false};
+    for (int s = 0; s < NWALK; s++) k[s] = Walk{0, 0, 0, 0, 0, idle_off, KEY_IDLE, 0u};
     for (;;) {
       // refill: idle slots take the next positions; the direct map answers the first two bytes.  The gathers of all
       // slots are issued together (one latency per refill phase).
@@ -325,10 +330,10 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
         uint2 te[NWALK];
 #pragma unroll
         for (int s = 0; s < NWALK; s++) {
-          const unsigned long long wmask = __ballot(!k[s].active);
+          const unsigned long long wmask = __ballot(walk_idle(k[s]));
           tp[s] = next_task + __popcll(wmask & lane_below);
           next_task += __popcll(wmask);
-          take[s] = !k[s].active && tp[s] < ntask;
+          take[s] = walk_idle(k[s]) && tp[s] < ntask;
           tlimit[s] = take[s] ? min(dl - tp[s], Lmax) : 0;
           te[s] = make_uint2(0u, 0u);
           if (take[s] && tlimit[s] >= 2) te[s] = T.tab[((uint32_t)w.text[tp[s]] << 8) | w.text[tp[s] + 1]];
@@ -343,11 +348,11 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
             const uint32_t bestv = e.y, nid = e.x >> 3;
             const bool cont = (e.x & 4u) != 0;
             if (cont && limit > depth && !(dbg & 4)) {
-              k[s].pos = p; k[s].tbase = p; k[s].depth = depth; k[s].limit = limit; k[s].active = true;
+              k[s].pos = p; k[s].tbase = p; k[s].depth = depth; k[s].limit = limit;
               k[s].bestlen = bestlen; k[s].bestv = bestv;
-              k[s].key = (nid << 8) | w.text[p + depth];
-              k[s].h32 = k[s].key * 0x9E3779B1u;
-              k[s].haddr = k[s].h32 >> T.edge_shift;
+              const uint32_t c2 = w.text[p + depth];
+              k[s].key = (nid << 8) | c2;
+              k[s].hoff = edge_slot_offset(T, nid, c2);
             } else if (bestlen != 0) {
               w.D[p] = (uint32_t)bestlen | ((bestv >> 22) << 6);
               w.X[p] = bestv;
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       }
       int nactive = 0;
 #pragma unroll
-      for (int s = 0; s < NWALK; s++) nactive += __popcll(__ballot(k[s].active));
+      for (int s = 0; s < NWALK; s++) nactive += __popcll(__ballot(!walk_idle(k[s])));
       PH(1)
       PH_INC(10)
       if (nactive == 0) { if (next_task >= ntask) break; continue; }
@@ -366,16 +371,21 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       const int thr = pool ? NWALK * REFILL_THR : 65;
       do {
         uint2 e[NWALK];
+        uint32_t c[NWALK];
 #pragma unroll
-        for (int s = 0; s < NWALK; s++) e[s] = hash_tab[k[s].haddr];
+        for (int s = 0; s < NWALK; s++) e[s] = load_slot(hash_tab, k[s].hoff);
+#pragma unroll
+        for (int s = 0; s < NWALK; s++) c[s] = w.text[k[s].tbase + k[s].depth + 1];
         nactive = 0;
 #pragma unroll
         for (int s = 0; s < NWALK; s++) {
-          if (walk_consume(T, w.text, k[s], e[s]) && k[s].bestlen != 0) {
+          const bool fin = walk_consume(T, k[s], e[s], c[s]);
+          if (fin && k[s].bestlen != 0) {
             w.D[k[s].pos] = (uint32_t)k[s].bestlen | ((k[s].bestv >> 22) << 6);
             w.X[k[s].pos] = k[s].bestv;
+            k[s].bestlen = 0;
           }
-          nactive += __popcll(__ballot(k[s].active));
+          nactive += __popcll(__ballot(!fin));
         }
         PH_INC(8)
       } while (nactive >= thr);
@@ -386,28 +396,30 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     // second walk moves over in registers, the rest goes through LDS to idle lanes — so that the remaining rounds cost
     // one probe per lane instead of NWALK.
     static_assert(NWALK == 2, "the drain below moves slot 1 into slot 0");
-    if (!k[0].active && k[1].active) { k[0] = k[1]; k[1].active = false; }
-    const unsigned long long give = __ballot(k[1].active);
+    if (walk_idle(k[0]) && !walk_idle(k[1])) { k[0] = k[1]; k[1].key = KEY_IDLE; }
+    const unsigned long long give = __ballot(!walk_idle(k[1]));
     if (give != 0) {
-      const unsigned long long idle = __ballot(!k[0].active);
+      const unsigned long long idle = __ballot(walk_idle(k[0]));
       uint4* xw = reinterpret_cast<uint4*>(w.Xb);         // free until step A3; 64 x 16 B
-      if (k[1].active)
+      if (!walk_idle(k[1]))
         xw[__popcll(give & lane_below)] = make_uint4((uint32_t)k[1].pos | ((uint32_t)k[1].depth << 10) | ((uint32_t)k[1].limit << 16) | ((uint32_t)k[1].bestlen << 22),
-                                                     k[1].key, k[1].haddr, k[1].bestv);
+                                                     k[1].key, k[1].hoff, k[1].bestv);
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0);
       const int r = __popcll(idle & lane_below);
-      if (!k[0].active && r < __popcll(give)) {
+      if (walk_idle(k[0]) && r < __popcll(give)) {
         const uint4 q = xw[r];
         k[0].pos = k[0].tbase = (int)(q.x & 1023u); k[0].depth = (int)((q.x >> 10) & 63u); k[0].limit = (int)((q.x >> 16) & 63u);
-        k[0].bestlen = (int)(q.x >> 22); k[0].key = q.y; k[0].haddr = q.z; k[0].bestv = q.w; k[0].active = true;
+        k[0].bestlen = (int)(q.x >> 22); k[0].key = q.y; k[0].hoff = q.z; k[0].bestv = q.w;
       }
     }
-    while (__any(k[0].active)) {
-      const uint2 e = hash_tab[k[0].haddr];
-      if (walk_consume(T, w.text, k[0], e) && k[0].bestlen != 0) {
+    while (__any(!walk_idle(k[0]))) {
+      const uint2 e = load_slot(hash_tab, k[0].hoff);
+      const uint32_t c = w.text[k[0].tbase + k[0].depth + 1];
+      if (walk_consume(T, k[0], e, c) && k[0].bestlen != 0) {
         w.D[k[0].pos] = (uint32_t)k[0].bestlen | ((k[0].bestv >> 22) << 6);
         w.X[k[0].pos] = k[0].bestv;
+        k[0].bestlen = 0;
       }
       PH_INC(9)
     }
@@ -454,7 +466,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0);
-      Walk k = Walk{0, 0, 0, 0, 0, 0u, 0u, 0u, 0u, false};
+      Walk k = Walk{0, 0, 0, 0, 0, idle_off, KEY_IDLE, 0u};
       int mainlen = 0;
       if (base + lane < n_el) {
         const int p = (int)w.xch[lane];
@@ -466,23 +478,24 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
         if (e.x != kNone && ((e.x >> 21) & 1u) && depth < limit) {
           k.pos = p; k.tbase = p - off; k.bestlen = bl; k.bestv = e.y; k.depth = depth; k.limit = limit;
           mainlen = (int)ml;
-          k.active = true;
-          k.key = ((e.x & kNodeMask) << 8) | w.text[p + ml];
-          k.h32 = k.key * 0x9E3779B1u;
-          k.haddr = k.h32 >> T.edge_shift;
+          const uint32_t c0 = w.text[p + ml];
+          k.key = ((e.x & kNodeMask) << 8) | c0;
+          k.hoff = edge_slot_offset(T, e.x & kNodeMask, c0);
         } else if (e.x != kNone && bl > (int)ml + 1) {               // (only possible with the two-byte UTF-16 prefix)
           const int lb = bl - off;
           w.Db[p] = make_sdesc((uint32_t)lb, e.y, s_bb[w.text[p + lb]], true, T.spl_hint);
           if (p < SEG) w.Xb[p] = e.y;
         }
       }
-      while (__any(k.active)) {
-        const uint2 e = hash_tab[k.haddr];
-        if (walk_consume(T, w.text, k, e) && k.bestlen > mainlen + 1) {
+      while (__any(!walk_idle(k))) {
+        const uint2 e = load_slot(hash_tab, k.hoff);
+        const uint32_t c = w.text[k.tbase + k.depth + 1];
+        if (walk_consume(T, k, e, c) && k.bestlen > mainlen + 1) {
           const int lb = k.bestlen - off;                              // go :1093
           w.Db[k.pos] = make_sdesc((uint32_t)lb, k.bestv, s_bb[w.text[k.pos + lb]], true, T.spl_hint);
           if (k.pos < SEG) w.Xb[k.pos] = k.bestv;
         }
+        k.bestlen = walk_idle(k) ? 0 : k.bestlen;
         PH_INC(11)
       }
       __builtin_amdgcn_wave_barrier();

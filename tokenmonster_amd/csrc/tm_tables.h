@@ -32,6 +32,15 @@ constexpr uint32_t kMaxNodes = kNodeMask - 1;
 constexpr uint32_t kL2Size = 65536;
 
 __host__ __device__ inline uint32_t node_id(uint32_t v) { return v & kNodeMask; }
+// hash of the edge (parent node, byte): both factors fit 24 bits so the device computes it with two full-rate
+// v_mad_u32_u24 instead of a quarter-rate 32-bit multiply; the slot is the top bits
+__host__ __device__ inline uint32_t edge_hash(uint32_t node, uint32_t byte) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __umul24(node, 0x9E3779u) + __umul24(byte, 0x85EBCBu);
+#else
+  return node * 0x9E3779u + byte * 0x85EBCBu;
+#endif
+}
 __host__ __device__ inline uint32_t node_nwords(uint32_t v) { return (v >> 22) & 31u; }
 __host__ __device__ inline uint32_t node_flag5(uint32_t v) { return v >> 27; }
 __host__ __device__ inline uint32_t flag8_to_flag5(uint32_t f) {
@@ -54,7 +63,8 @@ struct Tables {
                            //                         y = value of the longest accepting node among {b0, b0b1} (if any)
                            //                         x = its length (0,1,2) | cont << 2 | depth-2 node id << 3, cont = the node
                            //                         b0b1 exists and has children (the walk goes on in the hash)
-                           //   [65536, 65536+mask+1) depth>=3 hash, x = parent<<8|byte (kNone = empty slot)
+                           //   [65536, 65536+mask+1) depth>=3 hash, x = parent<<8|byte (kNone = empty slot), home slot edge_hash >> edge_shift,
+                           //                         linear probing; one more slot behind it stays empty (idle walks probe it)
   const uint2* spl;        // [n_info] "space-prefix link" of record s: where the walk of ' '+s (the forward-delete probe of
                            //   go/tokenmonster.go:1088-1095; ' ' 0x00 + s for UTF-16) ends up, so that probe only has to CONTINUE:
                            //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node

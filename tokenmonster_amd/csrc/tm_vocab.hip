@@ -170,7 +170,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   while ((1ull << bits) < n_edges * 5 / 2 + 8) bits++;
   hv.edge_mask = (1u << bits) - 1;
   hv.edge_shift = 32 - bits;
-  hv.tab.assign((size_t)kL2Size + ((size_t)1 << bits), uint2{kNone, kNone});
+  hv.tab.assign((size_t)kL2Size + ((size_t)1 << bits) + 1, uint2{kNone, kNone});   // + the always-empty slot
   uint2* l2 = hv.tab.data();
   uint2* edges = hv.tab.data() + kL2Size;
   std::vector<uint32_t> first_byte(n_nodes, 0);   // for depth-1 nodes: their byte, to index l2
@@ -180,7 +180,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     if (d == 2) l2[(first_byte[parent] << 8) | byte] = uint2{0u, value_of(kv.second)};   // rewritten below
     else if (d >= 3) {
       uint32_t key = (parent << 8) | byte;
-      uint32_t h = (key * 0x9E3779B1u) >> hv.edge_shift;
+      uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;
       while (edges[h].x != kNone) h = (h + 1) & hv.edge_mask;
       edges[h] = uint2{key, value_of(kv.second)};
     }
