@@ -259,8 +259,6 @@ __device__ unsigned long long g_phase[64 * 32];
 #define PH_COUNT(i, n)
 #endif
 
-constexpr int NWALK = 2;                 // independent trie walks in flight per lane
-constexpr int REFILL_THR = 24;           // K1 refills idle lanes when fewer than this many (per walk slot) are still walking
 
 __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
@@ -280,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   WaveLds& w = s_wave[wvi];
   const int Lmax = (int)T.max_len;
   const unsigned long long lane_below = (1ull << lane) - 1ull;
-  const uint2* __restrict__ hash_tab = T.tab + kL2Size;
+  const uint2* __restrict__ hash_tab = T.tab + kDirectSlots;
   const uint32_t idle_off = (T.edge_mask + 1u) << 3;      // the always-empty slot behind the edge hash
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
@@ -303,11 +301,12 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   __builtin_amdgcn_s_waitcnt(0);
 
   // ---- step A: descriptors for every position the segment can look at -----------------------------
-  // The pass is VALU-issue bound (profiles/r01_v1_pmc.txt), so the trie walks run as a TIGHT probe loop — one
-  // 8-byte hash probe per lane per round, ~20 instructions — and everything rare (taking the next position, the
-  // first two bytes through the direct map, storing a result) happens in a separate refill phase that runs only
-  // when fewer than REFILL_THR lanes are still walking.  Lanes take positions from a wave-wide counter, so no lane
-  // idles behind the longest walk of a block.  (pansearch LongestSubstring, call sites go/tokenmonster.go:1049..)
+  // What bounds this kernel is the number of divergent gathers (every lane of a probe touches its own cache line; the
+  // vector memory pipeline retires about one line per clock per CU), so step A1 is built to issue as few of them as
+  // possible: a lane owns a RUN of consecutive positions, and once the walk at p has ended on trie node n it does not
+  // start over at p+1 but follows the suffix link of n (tm_tables.h) — the state of the walk of text[p+1:] after the
+  // bytes already known to match — and only probes for what may come after them.  ~3.1 gathers per position instead of
+  // ~4.9 (two-byte map + one probe per further byte).  (pansearch LongestSubstring, call sites go/tokenmonster.go:1049..)
   for (int j = lane; j < NPOS_PAD; j += 64) { w.D[j] = 0; w.Db[j] = 0; }
   __builtin_amdgcn_wave_barrier();
   PH(0)
@@ -315,115 +314,71 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   const int ntask = (dbg & 1) ? 0 : min(NPOS, dl);     // positions >= dl keep descriptor 0 (nothing there)
   {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
-    // The probe loop is latency bound (K1 time scales ~1/occupancy), so every lane keeps NWALK independent walks in
-    // flight: NWALK probes are issued back to back before any result is consumed.
-    int next_task = 0;                        // wave-uniform
-    Walk k[NWALK];
-#pragma unroll
-    for (int s = 0; s < NWALK; s++) k[s] = Walk{0, 0, 0, 0, 0, idle_off, KEY_IDLE, 0u};
-    for (;;) {
-      // refill: idle slots take the next positions; the direct map answers the first two bytes.  The gathers of all
-      // slots are issued together (one latency per refill phase).
-      if (next_task < ntask) {
-        int tp[NWALK], tlimit[NWALK];
-        bool take[NWALK];
-        uint2 te[NWALK];
-#pragma unroll
-        for (int s = 0; s < NWALK; s++) {
-          const unsigned long long wmask = __ballot(walk_idle(k[s]));
-          tp[s] = next_task + __popcll(wmask & lane_below);
-          next_task += __popcll(wmask);
-          take[s] = walk_idle(k[s]) && tp[s] < ntask;
-          tlimit[s] = take[s] ? min(dl - tp[s], Lmax) : 0;
-          te[s] = make_uint2(0u, 0u);
-          if (take[s] && tlimit[s] >= 2) te[s] = T.tab[((uint32_t)w.text[tp[s]] << 8) | w.text[tp[s] + 1]];
-        }
-#pragma unroll
-        for (int s = 0; s < NWALK; s++) {
-          if (take[s]) {
-            const int p = tp[s], limit = tlimit[s];
-            uint2 e = te[s];
-            if (limit < 2) { const uint32_t r = s_root[w.text[p]]; e = make_uint2((r != kNone && node_id(r) < T.n_info) ? 1u : 0u, r); }
-            const int bestlen = (int)(e.x & 3u), depth = 2;
-            const uint32_t bestv = e.y, nid = e.x >> 3;
-            const bool cont = (e.x & 4u) != 0;
-            if (cont && limit > depth && !(dbg & 4)) {
-              k[s].pos = p; k[s].tbase = p; k[s].depth = depth; k[s].limit = limit;
-              k[s].bestlen = bestlen; k[s].bestv = bestv;
-              const uint32_t c2 = w.text[p + depth];
-              k[s].key = (nid << 8) | c2;
-              k[s].hoff = edge_slot_offset(T, nid, c2);
-            } else if (bestlen != 0) {
-              w.D[p] = (uint32_t)bestlen | ((bestv >> 22) << 6);
-              w.X[p] = bestv;
-            }
-          }
-        }
-      }
-      int nactive = 0;
-#pragma unroll
-      for (int s = 0; s < NWALK; s++) nactive += __popcll(__ballot(!walk_idle(k[s])));
-      PH(1)
-      PH_INC(10)
-      if (nactive == 0) { if (next_task >= ntask) break; continue; }
-      // tight probe loop; once the positions are used up it only runs while the walks still fill more than one slot per lane
-      const bool pool = next_task < ntask;
-      const int thr = pool ? NWALK * REFILL_THR : 65;
-      do {
-        uint2 e[NWALK];
-        uint32_t c[NWALK];
-#pragma unroll
-        for (int s = 0; s < NWALK; s++) e[s] = load_slot(hash_tab, k[s].hoff);
-#pragma unroll
-        for (int s = 0; s < NWALK; s++) c[s] = w.text[k[s].tbase + k[s].depth + 1];
-        nactive = 0;
-#pragma unroll
-        for (int s = 0; s < NWALK; s++) {
-          const bool fin = walk_consume(T, k[s], e[s], c[s]);
-          if (fin && k[s].bestlen != 0) {
-            w.D[k[s].pos] = (uint32_t)k[s].bestlen | ((k[s].bestv >> 22) << 6);
-            w.X[k[s].pos] = k[s].bestv;
-            k[s].bestlen = 0;
-          }
-          nactive += __popcll(__ballot(!fin));
-        }
-        PH_INC(8)
-      } while (nactive >= thr);
-      PH(2)
-      if (!pool) break;
+    // A run is in one of two states.  SET: the gather is a link-format entry (a suffix link, or the direct map on the
+    // first two bytes when there is nothing to link from) that says where the walk stands — node, depth, best match so
+    // far — and whether it can go on.  PROBE: the gather is an edge-hash slot for the next byte.  The round is written
+    // as straight-line selects (one instruction costs about a third of a gather here, and branches cost more than the
+    // work they skip); the LDS bytes a round may need — the next key byte, the first two bytes of the next position —
+    // are read while the gather is in flight.
+    enum : uint32_t { M_IDLE = 0, M_SET = 1, M_PROBE = 2 };
+    const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
+    const uint32_t hash_base = kDirectSlots * 8u, mask8 = T.edge_mask << 3, idle_abs = hash_base + idle_off;
+    // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
+    const int nwalkpos = (dl <= NPOS) ? ntask - 1 : ntask;          // positions with at least two bytes of text left
+    if (lane == 0 && dl <= NPOS && ntask > 0) {
+      const uint32_t r = s_root[w.text[dl - 1]];
+      if (r != kNone && node_id(r) < T.n_info) { w.D[dl - 1] = 1u | ((r >> 22) << 6); w.X[dl - 1] = r; }
     }
-    // drain: at most 64 walks are left (typically a handful of long ones).  They are gathered into slot 0 — a lane's own
-    // second walk moves over in registers, the rest goes through LDS to idle lanes — so that the remaining rounds cost
-    // one probe per lane instead of NWALK.
-    static_assert(NWALK == 2, "the drain below moves slot 1 into slot 0");
-    if (walk_idle(k[0]) && !walk_idle(k[1])) { k[0] = k[1]; k[1].key = KEY_IDLE; }
-    const unsigned long long give = __ballot(!walk_idle(k[1]));
-    if (give != 0) {
-      const unsigned long long idle = __ballot(walk_idle(k[0]));
-      uint4* xw = reinterpret_cast<uint4*>(w.Xb);         // free until step A3; 64 x 16 B
-      if (!walk_idle(k[1]))
-        xw[__popcll(give & lane_below)] = make_uint4((uint32_t)k[1].pos | ((uint32_t)k[1].depth << 10) | ((uint32_t)k[1].limit << 16) | ((uint32_t)k[1].bestlen << 22),
-                                                     k[1].key, k[1].hoff, k[1].bestv);
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_s_waitcnt(0);
-      const int r = __popcll(idle & lane_below);
-      if (walk_idle(k[0]) && r < __popcll(give)) {
-        const uint4 q = xw[r];
-        k[0].pos = k[0].tbase = (int)(q.x & 1023u); k[0].depth = (int)((q.x >> 10) & 63u); k[0].limit = (int)((q.x >> 16) & 63u);
-        k[0].bestlen = (int)(q.x >> 22); k[0].key = q.y; k[0].hoff = q.z; k[0].bestv = q.w;
-      }
+    const int run = (max(nwalkpos, 0) + 63) >> 6;
+    int pos = lane * run;
+    const int end = min(pos + run, nwalkpos);
+    int depth = 0, limit = 0, bestlen = 0, pf = 0;
+    uint32_t off = idle_abs, key = 0u, bestv = 0u, node = 0u, mode = M_IDLE;
+    if (pos < end) {
+      mode = M_SET;
+      limit = min(dl - pos, Lmax);
+      off = (((uint32_t)w.text[pos] << 8) | w.text[pos + 1]) << 4;
+      pf = pos + 2;
     }
-    while (__any(!walk_idle(k[0]))) {
-      const uint2 e = load_slot(hash_tab, k[0].hoff);
-      const uint32_t c = w.text[k[0].tbase + k[0].depth + 1];
-      if (walk_consume(T, k[0], e, c) && k[0].bestlen != 0) {
-        w.D[k[0].pos] = (uint32_t)k[0].bestlen | ((k[0].bestv >> 22) << 6);
-        w.X[k[0].pos] = k[0].bestv;
-        k[0].bestlen = 0;
+    const bool nowalk = (dbg & 4) != 0;
+    while (__any(mode != M_IDLE)) {
+      const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // 8-byte slots: the upper half is ignored
+      const uint32_t c = w.text[pf], n0 = w.text[pos + 1], n1 = w.text[pos + 2];
+      const bool isP = mode == M_PROBE, isS = mode == M_SET;
+      const bool hit = isP && e.x == key;
+      const bool again = isP && !hit && e.x != kNone;                  // occupied by another key: linear probing
+      const bool adv = hit || isS;                                     // the walk state is (re)set this round
+      const uint32_t nid = hit ? node_id(e.y) : (e.x & kNodeMask);
+      depth = hit ? depth + 1 : (isS ? (int)((e.x >> 23) & 63u) : depth);
+      node = adv ? nid : node;
+      const bool accP = hit && nid < T.n_info;
+      bestv = (accP || isS) ? e.y : bestv;
+      bestlen = accP ? depth : (isS ? (int)e.z : bestlen);
+      const bool can = hit ? (e.y & kHasChildren) != 0 : ((e.x >> 21) & 3u) == 3u;
+      const bool go = adv && can && depth < limit && !nowalk;
+      const bool fin = (adv && !go) || (isP && !hit && !again);
+      // arm the next probe / step along the collision chain
+      key = go ? ((nid << 8) | c) : key;
+      const uint32_t lin = hash_base + ((off - hash_base + 8u) & mask8);
+      off = go ? hash_base + edge_slot_offset(T, nid, c) : (again ? lin : off);
+      pf = go ? pos + depth + 1 : pf;
+      mode = go ? (uint32_t)M_PROBE : mode;
+      // position done: store, move on — through the suffix link if the walk got deep enough, else from the direct map
+      if (fin && bestlen != 0) {
+        w.D[pos] = (uint32_t)bestlen | ((bestv >> 22) << 6);
+        w.X[pos] = bestv;
       }
-      PH_INC(9)
+      const int npos = pos + 1;
+      const bool more = npos < end, deep = depth >= 3;
+      const uint32_t noff = more ? (deep ? T.link_off + (node << 4) : ((n0 << 8) | n1) << 4) : idle_abs;
+      pos = fin ? npos : pos;
+      limit = fin ? min(dl - npos, Lmax) : limit;
+      off = fin ? noff : off;
+      pf = fin ? (deep ? npos + depth - 1 : npos + 2) : pf;
+      mode = fin ? (more ? (uint32_t)M_SET : (uint32_t)M_IDLE) : mode;
+      PH_INC(8)
     }
-    PH(3)
+    PH(2)
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
@@ -573,59 +528,68 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     uint2* J = reinterpret_cast<uint2*>(w.D);            // overlays D, Db, X, Xb (dead after step B): 1024 x 8 B
     static_assert(sizeof(uint32_t) * (2 * NPOS_PAD + 2 * SEG) >= 2 * SEG * sizeof(uint2), "J overlay does not fit");
     const bool more_text = rem > (uint64_t)SEG;           // not the last segment of the document
+    // J entry: x = #id events [0..17] | byte offset inside J of the entry it points at [18..31] — offsets >= 8192
+    // (index >= J_EXIT, i.e. the sign bit) mean "left the segment"; y = #forward-deletes | #missing << 16.
+    // Composing two entries is then (x & EV_MASK) + x', y + y': the kernel is VALU bound, and this loop runs ~7 times.
+    constexpr uint32_t EV_BITS = 18, EV_MASK = (1u << EV_BITS) - 1u;
+    static_assert(J_INVALID * 8u < (1u << 14) && J_EXIT * 8u == (1u << 13), "J target field");
     auto first_hop = [&](uint32_t r, int p) -> uint2 {
-      if (p >= seglen) return make_uint2(J_EXIT, 0u);     // at/after the end of text: terminal, nothing emitted
-      if (r == R_INVALID) return make_uint2(J_INVALID, 0u);
+      if (p >= seglen) return make_uint2((J_EXIT * 8u) << EV_BITS, 0u);     // at/after the end of text: terminal, nothing emitted
+      if (r == R_INVALID) return make_uint2((J_INVALID * 8u) << EV_BITS, 0u);
       const int pn = p + (int)((r >> 24) & 63u);
       const uint32_t fdn = (r >> 30) & 1u;
       const uint32_t ev = (r & ID_NONE) != ID_NONE ? 1u : 0u;
       const uint32_t tgt = pn >= seglen ? J_EXIT + (more_text ? (uint32_t)((pn - SEG) * 2) + fdn : 0u) : fdn * SEG + (uint32_t)pn;
-      return make_uint2(tgt | (ev << 12), fdn | ((r >> 31) << 16));
+      return make_uint2(((tgt * 8u) << EV_BITS) | ev, fdn | ((r >> 31) << 16));
     };
     // every lane keeps its own 2*SEG/64 states in registers and only touches LDS for states that still point inside
     // the segment (most (p,1) states are unreachable and finished from the start)
-    constexpr int NS = 2 * SEG / 64;
+    constexpr int NS = 2 * SEG / 64, N0 = SEG / 64;
     uint2 ja[NS];
-    uint32_t pend = 0;
+    bool pend[NS];
 #pragma unroll
-    for (int it = 0; it < SEG / 64; it++) {
+    for (int it = 0; it < N0; it++) {
       const int p = it * 64 + lane;
       ja[it] = first_hop(r0[it], p);
-      ja[SEG / 64 + it] = first_hop(r1[it], p);
+      ja[N0 + it] = first_hop(r1[it], p);
       J[p] = ja[it];
-      J[SEG + p] = ja[SEG / 64 + it];
+      J[SEG + p] = ja[N0 + it];
     }
+    bool any0 = false, any1 = false;
 #pragma unroll
-    for (int k = 0; k < NS; k++) if ((ja[k].x & 0xFFFu) < J_EXIT) pend |= 1u << k;
+    for (int k = 0; k < NS; k++) { pend[k] = (int)ja[k].x >= 0; if (k < N0) any0 |= pend[k]; else any1 |= pend[k]; }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
-    // One round: every pending state composes itself with the state it points at.  The (p,0) states — five per lane,
-    // nearly all pending — are handled without branches so that their LDS reads are issued back to back (one LDS
-    // latency per round instead of five); the rare pending (p,1) states take the generic path.  The entry states sit at
-    // the start of the segment and have the longest chains, so "nothing pending" is also when they are done.
-    constexpr int N0 = SEG / 64;
-    for (int round = 0; round < 12 && __any(pend != 0); round++) {
+    // One round: every pending state composes itself with the state it points at.  The LDS reads of a round are issued
+    // back to back (one LDS latency per round); the (p,1) states are rarely pending and skipped as a group.  The entry
+    // states sit at the start of the segment and have the longest chains, so "nothing pending" is also when they are done.
+    const char* Jb = reinterpret_cast<const char*>(J);
+    for (int round = 0; round < 12 && __any(any0 || any1); round++) {
       uint2 bn[N0];
 #pragma unroll
-      for (int k = 0; k < N0; k++) bn[k] = J[((pend >> k) & 1u) ? (ja[k].x & 0xFFFu) : (uint32_t)(k * 64 + lane)];
+      for (int k = 0; k < N0; k++) if (pend[k]) bn[k] = *reinterpret_cast<const uint2*>(Jb + (ja[k].x >> EV_BITS));
+      any0 = false;
 #pragma unroll
       for (int k = 0; k < N0; k++) {
-        const bool pk = ((pend >> k) & 1u) != 0;
-        const uint32_t nx = (bn[k].x & 0xFFFu) | (((ja[k].x >> 12) + (bn[k].x >> 12)) << 12);
-        ja[k].x = pk ? nx : ja[k].x;
-        ja[k].y += pk ? bn[k].y : 0u;                     // two 16-bit counters, neither can overflow (<= 512 each)
-        if (pk) J[k * 64 + lane] = ja[k];
-        if ((ja[k].x & 0xFFFu) >= J_EXIT) pend &= ~(1u << k);
+        if (pend[k]) {
+          ja[k].x = (ja[k].x & EV_MASK) + bn[k].x;
+          ja[k].y += bn[k].y;                              // two 16-bit counters, neither can overflow (<= 512 each)
+          J[k * 64 + lane] = ja[k];
+          pend[k] = (int)ja[k].x >= 0;
+          any0 |= pend[k];
+        }
       }
-      if (__any((pend >> N0) != 0)) {
+      if (__any(any1)) {
+        any1 = false;
 #pragma unroll
         for (int k = N0; k < NS; k++) {
-          if (pend & (1u << k)) {
-            const uint2 bnext = J[ja[k].x & 0xFFFu];
-            ja[k].x = (bnext.x & 0xFFFu) | (((ja[k].x >> 12) + (bnext.x >> 12)) << 12);
-            ja[k].y = ja[k].y + bnext.y;
+          if (pend[k]) {
+            const uint2 b1 = *reinterpret_cast<const uint2*>(Jb + (ja[k].x >> EV_BITS));
+            ja[k].x = (ja[k].x & EV_MASK) + b1.x;
+            ja[k].y += b1.y;
             J[k * 64 + lane] = ja[k];
-            if ((ja[k].x & 0xFFFu) >= J_EXIT) pend &= ~(1u << k);
+            pend[k] = (int)ja[k].x >= 0;
+            any1 |= pend[k];
           }
         }
       }
@@ -635,9 +599,9 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     }
     for (int e = lane; e < ENT; e += 64) {
       const uint2 a = J[(e & 1) * SEG + (e >> 1)];
-      const uint32_t t = a.x & 0xFFFu;
+      const uint32_t t = a.x >> (EV_BITS + 3);
       uint2 o = make_uint2(R_INVALID, 0u);
-      if (t >= J_EXIT && t != J_INVALID) o = make_uint2((t - J_EXIT) | ((a.x >> 12) << 8), a.y);
+      if (t >= J_EXIT && t != J_INVALID) o = make_uint2((t - J_EXIT) | ((a.x & EV_MASK) << 8), a.y);
       exitmap[g * ENT + e] = o;
     }
   }

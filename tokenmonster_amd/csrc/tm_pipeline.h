@@ -18,7 +18,7 @@ constexpr int ENT = 80;                  // entry states of a segment: 40 offset
 constexpr int WAVES = 4;                 // wavefronts per workgroup in K1 (plain variant)
 constexpr uint32_t R_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t J_EXIT = 1024;           // jump targets >= J_EXIT: left the segment; J_EXIT + next entry state
-constexpr uint32_t J_INVALID = 4095;        // state is not reachable (no forward-delete match there)
+constexpr uint32_t J_INVALID = 2047;        // state is not reachable (no forward-delete match there)
 constexpr uint32_t ID_NONE = 0xFFFFFFu;
 constexpr int NOSCORE = -1000000;
 constexpr uint32_t LONG_SEGS = 512;        // documents with more segments than this are resolved hierarchically

@@ -30,6 +30,7 @@ constexpr uint32_t kNodeMask = (1u << kNodeBits) - 1;
 constexpr uint32_t kHasChildren = 1u << 21;
 constexpr uint32_t kMaxNodes = kNodeMask - 1;
 constexpr uint32_t kL2Size = 65536;
+constexpr uint32_t kDirectSlots = 2 * kL2Size;   // the direct map in uint2 units (16-byte entries)
 
 __host__ __device__ inline uint32_t node_id(uint32_t v) { return v & kNodeMask; }
 // hash of the edge (parent node, byte): both factors fit 24 bits so the device computes it with two full-rate
@@ -58,13 +59,18 @@ struct alignas(16) Row { uint32_t x, y, z, w; };
 
 struct Tables {
   const uint32_t* root;    // [256]
-  const uint2* tab;        // one probe table, 8 B per slot, y = node value:
-                           //   [0, 65536)            direct map on the first two bytes b0<<8|b1: the whole answer for depth <= 2:
-                           //                         y = value of the longest accepting node among {b0, b0b1} (if any)
-                           //                         x = its length (0,1,2) | cont << 2 | depth-2 node id << 3, cont = the node
-                           //                         b0b1 exists and has children (the walk goes on in the hash)
-                           //   [65536, 65536+mask+1) depth>=3 hash, x = parent<<8|byte (kNone = empty slot), home slot edge_hash >> edge_shift,
-                           //                         linear probing; one more slot behind it stays empty (idle walks probe it)
+  const uint2* tab;        // one table for everything a walk gathers (uint2 units; link-format entries take two):
+                           //   [0, 2*65536)          direct map on the first two bytes b0<<8|b1, link format (below): the whole
+                           //                         answer for depth <= 2 and, if the node b0b1 has children, where to go on
+                           //   [2*65536, +mask+1)    depth>=3 edge hash, x = parent<<8|byte (kNone = empty slot), y = node value;
+                           //                         home slot edge_hash >> edge_shift, linear probing; one more slot behind it
+                           //                         stays empty (idle walks probe it)
+                           //   [link_off/8 ...)      suffix links, 16 B per trie node n (string s): where the walk of s[1:] ends up,
+                           //                         so the walk at text position p+1 CONTINUES from the walk at p instead of
+                           //                         starting over (Aho-Corasick failure links turned into longest-prefix state):
+                           //                         x = node m reached | full << 21 (all of s[1:] is in the trie) |
+                           //                             m has children << 22 | depth(m) << 23       (probe on iff both flags)
+                           //                         y = value of the deepest accepting node on the path to m (0: none), z = its depth
   const uint2* spl;        // [n_info] "space-prefix link" of record s: where the walk of ' '+s (the forward-delete probe of
                            //   go/tokenmonster.go:1088-1095; ' ' 0x00 + s for UTF-16) ends up, so that probe only has to CONTINUE:
                            //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node
@@ -76,6 +82,7 @@ struct Tables {
   uint32_t bstart;         // node value after consuming ' ' (and 0x00 for UTF-16), kNone if absent
   uint32_t has_delete, delete_id, unk_id;
   uint32_t spl_hint;       // b2 of letter-initial tokens is the forward-delete hint
+  uint32_t link_off;       // byte offset of the suffix links inside tab
 };
 
 }  // namespace tmh

@@ -97,6 +97,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   child.reserve((size_t)hv.keys.size() + 16);
   std::vector<uint8_t> depth_of;                   // depth per node id
   depth_of.assign(n_info, 0);
+  std::vector<uint32_t> parent_of(n_info, 0);      // parent node id (kRoot for depth 1) and the edge byte, per node id
+  std::vector<uint8_t> byte_of(n_info, 0);
   uint32_t next_internal = n_info;
   const uint32_t kRoot = kNodeMask;
   for (uint32_t i = 0; i < n_info; i++) {
@@ -109,6 +111,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
         // keys arrive shortest first, so this node cannot exist yet (a proper prefix of a key is shorter)
         child.emplace(key, i);
         depth_of[i] = (uint8_t)kl;
+        parent_of[i] = node; byte_of[i] = k[d];
         node = i;
       } else {
         auto it = child.find(key);
@@ -116,6 +119,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
           if (next_internal >= kMaxNodes) return set_error(TM_E_LIMIT, "vocabulary needs more than %u trie nodes", kMaxNodes);
           it = child.emplace(key, next_internal++).first;
           depth_of.push_back((uint8_t)(d + 1));
+          parent_of.push_back(node); byte_of.push_back(k[d]);
         }
         node = it->second;
       }
@@ -170,19 +174,50 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   while ((1ull << bits) < n_edges * 5 / 2 + 8) bits++;
   hv.edge_mask = (1u << bits) - 1;
   hv.edge_shift = 32 - bits;
-  hv.tab.assign((size_t)kL2Size + ((size_t)1 << bits) + 1, uint2{kNone, kNone});   // + the always-empty slot
-  uint2* l2 = hv.tab.data();
-  uint2* edges = hv.tab.data() + kL2Size;
+  const size_t link_base = ((size_t)kDirectSlots + ((size_t)1 << bits) + 1 + 1) & ~(size_t)1;   // + the always-empty slot, 16-byte aligned
+  hv.link_off = (uint32_t)(link_base * sizeof(uint2));
+  hv.tab.assign(link_base + 2 * (size_t)n_nodes, uint2{kNone, kNone});
+  std::vector<uint32_t> l2v(kL2Size, kNone);       // value of the depth-2 node b0b1
+  uint2* edges = hv.tab.data() + kDirectSlots;
   std::vector<uint32_t> first_byte(n_nodes, 0);   // for depth-1 nodes: their byte, to index l2
   for (auto& kv : child) if (depth_of[kv.second] == 1) { hv.root[kv.first & 0xFF] = value_of(kv.second); first_byte[kv.second] = (uint32_t)(kv.first & 0xFF); }
   for (auto& kv : child) {
     uint32_t d = depth_of[kv.second], parent = (uint32_t)(kv.first >> 8), byte = (uint32_t)(kv.first & 0xFF);
-    if (d == 2) l2[(first_byte[parent] << 8) | byte] = uint2{0u, value_of(kv.second)};   // rewritten below
+    if (d == 2) l2v[(first_byte[parent] << 8) | byte] = value_of(kv.second);
     else if (d >= 3) {
       uint32_t key = (parent << 8) | byte;
       uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;
       while (edges[h].x != kNone) h = (h + 1) & hv.edge_mask;
       edges[h] = uint2{key, value_of(kv.second)};
+    }
+  }
+  // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.
+  // link(n) follows from link(parent(n)) as in Aho-Corasick, in order of depth; best[m] = deepest accepting node on the
+  // path root..m.  Only links of nodes at depth >= 3 are ever read by the kernels.
+  {
+    std::vector<uint32_t> by_depth(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) by_depth[i] = i;
+    std::stable_sort(by_depth.begin(), by_depth.end(), [&](uint32_t a, uint32_t b) { return depth_of[a] < depth_of[b]; });
+    std::vector<uint32_t> best(n_nodes, kNone);          // best accepting ancestor-or-self
+    std::vector<uint32_t> lnode(n_nodes, kRoot);          // link target (kRoot = depth 0)
+    std::vector<uint8_t> lfull(n_nodes, 0);
+    auto depth_at = [&](uint32_t n) -> uint32_t { return n == kRoot ? 0u : depth_of[n]; };
+    for (uint32_t n : by_depth) {
+      const uint32_t par = parent_of[n];
+      best[n] = n < n_info ? n : (par == kRoot ? kNone : best[par]);
+      if (par == kRoot) { lnode[n] = kRoot; lfull[n] = 1; continue; }                 // s[1:] is empty
+      const uint32_t pm = lnode[par];
+      if (!lfull[par]) { lnode[n] = pm; lfull[n] = 0; continue; }                     // already fell off the trie
+      auto it = child.find(((uint64_t)pm << 8) | byte_of[n]);
+      if (it == child.end()) { lnode[n] = pm; lfull[n] = 0; } else { lnode[n] = it->second; lfull[n] = 1; }
+    }
+    uint2* lt = hv.tab.data() + link_base;
+    for (uint32_t n = 0; n < n_nodes; n++) {
+      const uint32_t m = lnode[n], dm = depth_at(m);
+      const uint32_t hc = (m != kRoot && has_child[m]) ? 1u : 0u;
+      const uint32_t b = m == kRoot ? kNone : best[m];
+      lt[2 * (size_t)n] = uint2{(m & kNodeMask) | ((uint32_t)lfull[n] << 21) | (hc << 22) | (dm << 23), b != kNone ? value_of(b) : 0u};
+      lt[2 * (size_t)n + 1] = uint2{b != kNone ? (uint32_t)depth_of[b] : 0u, 0u};
     }
   }
   // reverse table for decoding: reverse[id] = key of the LAST record carrying that id (go/tokenmonster.go:2715, quirk Q3)
@@ -202,21 +237,23 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   if (spl_start != kNone)
     for (uint32_t i = 0; i < n_info; i++)
       hv.spl[i] = uint2{splw[i].node | (splw[i].cont << 21) | (splw[i].bestlen << 22), splw[i].best != kNone ? value_of(splw[i].best) : 0u};
-  // direct map: fold the depth-1 answer in, so one 8-byte load resolves the first two bytes of any walk
+  // direct map: one 16-byte entry (same format as a suffix link) resolves the first two bytes of any walk, the
+  // depth-1 answer folded in
   for (uint32_t b0 = 0; b0 < 256; b0++) {
     const uint32_t r = hv.root[b0];
     for (uint32_t b1 = 0; b1 < 256; b1++) {
-      uint2& e = l2[(b0 << 8) | b1];
       uint32_t bestlen = 0, bestv = 0, cont = 0, id2 = 0;
+      const uint32_t v2 = l2v[(b0 << 8) | b1];
       if (r != kNone) {
         if (node_id(r) < n_info) { bestlen = 1; bestv = r; }
-        if (e.x != kNone) {                       // node b0b1 exists
-          const uint32_t v2 = e.y;
+        if (v2 != kNone) {                        // node b0b1 exists
           if (node_id(v2) < n_info) { bestlen = 2; bestv = v2; }
           if (v2 & kHasChildren) { cont = 1; id2 = node_id(v2); }
         }
       }
-      e = uint2{bestlen | (cont << 2) | (id2 << 3), bestv};
+      uint2* e = hv.tab.data() + 2 * (size_t)((b0 << 8) | b1);
+      e[0] = uint2{id2 | (cont << 21) | (cont << 22) | ((cont ? 2u : 0u) << 23), bestv};
+      e[1] = uint2{bestlen, 0u};
     }
   }
   hv.n_nodes = n_nodes;
@@ -224,8 +261,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   hv.bstart = hv.root[' '];
   if (hv.off == 2 && hv.bstart != kNone) {
     // UTF-16: the virtual prefix is ' ' 0x00 (lilbufOffset 2, go :1031-1034): start from that depth-2 node
-    const uint2 e = l2[(' ' << 8) | 0];
-    hv.bstart = (e.x & 4u) ? ((e.x >> 3) | kHasChildren) : kNone;
+    const uint32_t v2 = l2v[(' ' << 8) | 0];
+    hv.bstart = (v2 != kNone && (v2 & kHasChildren)) ? (node_id(v2) | kHasChildren) : kNone;
   }
   return TM_OK;
 }
@@ -280,7 +317,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   Tables& t = v->tables;
   t.root = v->d_root; t.tab = v->d_tab; t.spl = v->d_spl; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
   t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
-  t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint;
+  t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint; t.link_off = hv.link_off;
   t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
   *out = v;
   return TM_OK;
