@@ -278,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
   WaveLds& w = s_wave[wvi];
   const int Lmax = (int)T.max_len;
   const unsigned long long lane_below = (1ull << lane) - 1ull;
-  const uint2* __restrict__ hash_tab = T.tab + kDirectSlots;
+  const uint2* __restrict__ hash_tab = T.tab;
   const uint32_t idle_off = (T.edge_mask + 1u) << 3;      // the always-empty slot behind the edge hash
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
@@ -320,62 +320,66 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     // as straight-line selects (one instruction costs about a third of a gather here, and branches cost more than the
     // work they skip); the LDS bytes a round may need — the next key byte, the first two bytes of the next position —
     // are read while the gather is in flight.
-    enum : uint32_t { M_IDLE = 0, M_SET = 1, M_PROBE = 2 };
     const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
-    const uint32_t hash_base = kDirectSlots * 8u, mask8 = T.edge_mask << 3, idle_abs = hash_base + idle_off;
+    const uint32_t mask8 = T.edge_mask << 3;
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
     const int nwalkpos = (dl <= NPOS) ? ntask - 1 : ntask;          // positions with at least two bytes of text left
     if (lane == 0 && dl <= NPOS && ntask > 0) {
       const uint32_t r = s_root[w.text[dl - 1]];
       if (r != kNone && node_id(r) < T.n_info) { w.D[dl - 1] = 1u | ((r >> 22) << 6); w.X[dl - 1] = r; }
     }
+    // Positions are carried as LDS byte addresses of their text byte (one add less per use, and the kernel is VALU bound).
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef __attribute__((address_space(3), aligned(1))) uint16_t lds_u16u;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t tb = (uint32_t)(uintptr_t)(lds_u8*)w.text;                       // address of text[0]
+    const uint32_t dconst = (uint32_t)(uintptr_t)(lds_u8*)w.D - 4u * tb;              // &D[i] == dconst + 4 * (tb + i)
     const int run = (max(nwalkpos, 0) + 63) >> 6;
-    int pos = lane * run;
-    const int end = min(pos + run, nwalkpos);
-    int depth = 0, limit = 0, bestlen = 0, pf = 0;
-    uint32_t off = idle_abs, key = 0u, bestv = 0u, node = 0u, mode = M_IDLE;
-    if (pos < end) {
-      mode = M_SET;
-      limit = min(dl - pos, Lmax);
-      off = (((uint32_t)w.text[pos] << 8) | w.text[pos + 1]) << 4;
-      pf = pos + 2;
+    uint32_t posa = tb + (uint32_t)(lane * run);
+    const uint32_t enda = tb + (uint32_t)max(min(lane * run + run, nwalkpos), 0), dla = tb + (uint32_t)dl;
+    int depth = 0, limit = 0, bestlen = 0;
+    uint32_t pfa = tb, off = idle_off, key = 0u, bestv = 0u, node = 0u;
+    bool probing = false, setting = posa < enda;         // the state of the run; the compiler keeps these as lane masks
+    if (setting) {
+      limit = min((int)(dla - posa), Lmax);
+      off = T.direct_off + ((uint32_t)*(lds_u16u*)(uintptr_t)posa << 4);
+      pfa = posa + 2u;
     }
     const bool nowalk = (dbg & 4) != 0;
-    while (__any(mode != M_IDLE)) {
+    while (__builtin_amdgcn_ballot_w64(probing || setting) != 0ull) {
       const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // 8-byte slots: the upper half is ignored
-      const uint32_t c = w.text[pf], n0 = w.text[pos + 1], n1 = w.text[pos + 2];
-      const bool isP = mode == M_PROBE, isS = mode == M_SET;
-      const bool hit = isP && e.x == key;
-      const bool again = isP && !hit && e.x != kNone;                  // occupied by another key: linear probing
-      const bool adv = hit || isS;                                     // the walk state is (re)set this round
-      const uint32_t nid = hit ? node_id(e.y) : (e.x & kNodeMask);
-      depth = hit ? depth + 1 : (isS ? (int)((e.x >> 23) & 63u) : depth);
-      node = adv ? nid : node;
-      const bool accP = hit && nid < T.n_info;
-      bestv = (accP || isS) ? e.y : bestv;
-      bestlen = accP ? depth : (isS ? (int)e.z : bestlen);
-      const bool can = hit ? (e.y & kHasChildren) != 0 : ((e.x >> 21) & 3u) == 3u;
-      const bool go = adv && can && depth < limit && !nowalk;
-      const bool fin = (adv && !go) || (isP && !hit && !again);
-      // arm the next probe / step along the collision chain
-      key = go ? ((nid << 8) | c) : key;
-      const uint32_t lin = hash_base + ((off - hash_base + 8u) & mask8);
-      off = go ? hash_base + edge_slot_offset(T, nid, c) : (again ? lin : off);
-      pf = go ? pos + depth + 1 : pf;
-      mode = go ? (uint32_t)M_PROBE : mode;
-      // position done: store, move on — through the suffix link if the walk got deep enough, else from the direct map
-      if (fin && bestlen != 0) {
-        w.D[pos] = (uint32_t)bestlen | ((bestv >> 22) << 6);
-        w.X[pos] = bestv;
+      uint32_t c = *(lds_u8*)(uintptr_t)pfa;
+      uint32_t nn = *(lds_u16u*)(uintptr_t)(posa + 1u);                // the two bytes at the next position, as the direct map indexes them
+      asm volatile("" : "+v"(c), "+v"(nn));                            // both LDS reads are issued here, under the gather's latency
+      const bool hit = probing && e.x == key;
+      const bool again = probing && !hit && e.x != kNone;              // occupied by another key: linear probing
+      const bool adv = hit || setting;                                 // the walk state is (re)set this round
+      const uint32_t src = hit ? e.y : e.x;                            // bits 0..20 node, bit 21 "has children" / "go on"
+      const uint32_t nid = src & kNodeMask;
+      if (hit) depth++;
+      if (setting) { depth = (int)((e.x >> 23) & 63u); bestv = e.y; bestlen = (int)e.z; }
+      if (adv) node = nid;
+      if (hit && nid < T.n_info) { bestv = e.y; bestlen = depth; }
+      const bool go = adv && (src & kHasChildren) != 0 && depth < limit && !nowalk;
+      const bool fin = (adv && !go) || (probing && !hit && !again);
+      if (go) { key = (nid << 8) | c; off = edge_slot_offset(T, nid, c); pfa = posa + (uint32_t)depth + 1u; }
+      if (again) off = (off + 8u) & mask8;
+      probing = go || again;
+      setting = false;
+      if (fin) {
+        // position done: store, move on — through the suffix link if the walk got deep enough, else from the direct map
+        if (bestlen != 0) {
+          lds_u32* dp = (lds_u32*)(uintptr_t)(dconst + 4u * posa);
+          dp[0] = (uint32_t)bestlen | ((bestv >> 22) << 6);            // D[pos]
+          dp[2 * NPOS_PAD] = bestv;                                     // X[pos]
+        }
+        posa++;
+        setting = posa < enda;
+        limit = min((int)(dla - posa), Lmax);
+        if (depth >= 3) { off = T.link_off + (node << 4); pfa = posa + (uint32_t)depth - 1u; }
+        else { off = T.direct_off + (nn << 4); pfa = posa + 2u; }
+        if (!setting) off = idle_off;
       }
-      const int npos = pos + 1;
-      const bool more = npos < end, deep = depth >= 3;
-      const uint32_t noff = more ? (deep ? T.link_off + (node << 4) : ((n0 << 8) | n1) << 4) : idle_abs;
-      pos = fin ? npos : pos;
-      limit = fin ? min(dl - npos, Lmax) : limit;
-      off = fin ? noff : off;
-      pf = fin ? (deep ? npos + depth - 1 : npos + 2) : pf;
-      mode = fin ? (more ? (uint32_t)M_SET : (uint32_t)M_IDLE) : mode;
       PH_INC(8)
     }
     PH(2)

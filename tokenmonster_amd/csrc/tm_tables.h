@@ -59,18 +59,19 @@ struct alignas(16) Row { uint32_t x, y, z, w; };
 
 struct Tables {
   const uint32_t* root;    // [256]
-  const uint2* tab;        // one table for everything a walk gathers (uint2 units; link-format entries take two):
-                           //   [0, 2*65536)          direct map on the first two bytes b0<<8|b1, link format (below): the whole
-                           //                         answer for depth <= 2 and, if the node b0b1 has children, where to go on
-                           //   [2*65536, +mask+1)    depth>=3 edge hash, x = parent<<8|byte (kNone = empty slot), y = node value;
-                           //                         home slot edge_hash >> edge_shift, linear probing; one more slot behind it
-                           //                         stays empty (idle walks probe it)
-                           //   [link_off/8 ...)      suffix links, 16 B per trie node n (string s): where the walk of s[1:] ends up,
-                           //                         so the walk at text position p+1 CONTINUES from the walk at p instead of
-                           //                         starting over (Aho-Corasick failure links turned into longest-prefix state):
-                           //                         x = node m reached | full << 21 (all of s[1:] is in the trie) |
-                           //                             m has children << 22 | depth(m) << 23       (probe on iff both flags)
-                           //                         y = value of the deepest accepting node on the path to m (0: none), z = its depth
+  const uint2* tab;        // one table for everything a walk gathers (8-byte units; link-format entries take two):
+                           //   [0, mask+1]             depth>=3 edge hash, x = parent<<8|byte (kNone = empty slot), y = node value;
+                           //                           home slot edge_hash >> edge_shift, linear probing; the slot behind the
+                           //                           table stays empty (idle walks probe it)
+                           //   [direct_off/8, +2*65536) direct map on the first two bytes, index b0 | b1<<8 (the little-endian u16 at
+                           //                           the position), link format: the whole answer for depth <= 2 and, if the
+                           //                           node b0b1 has children, where to go on
+                           //   [link_off/8, +2*nodes)  suffix links, 16 B per trie node n (string s): where the walk of s[1:] ends up,
+                           //                           so the walk at text position p+1 CONTINUES from the walk at p instead of
+                           //                           starting over (Aho-Corasick failure links turned into longest-prefix state)
+                           //   link format:            x = node m reached | go << 21 (all of s[1:] is in the trie AND m has
+                           //                               children: probe on) | depth(m) << 23
+                           //                           y = value of the deepest accepting node on the path to m (0: none), z = its depth
   const uint2* spl;        // [n_info] "space-prefix link" of record s: where the walk of ' '+s (the forward-delete probe of
                            //   go/tokenmonster.go:1088-1095; ' ' 0x00 + s for UTF-16) ends up, so that probe only has to CONTINUE:
                            //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node
@@ -82,7 +83,7 @@ struct Tables {
   uint32_t bstart;         // node value after consuming ' ' (and 0x00 for UTF-16), kNone if absent
   uint32_t has_delete, delete_id, unk_id;
   uint32_t spl_hint;       // b2 of letter-initial tokens is the forward-delete hint
-  uint32_t link_off;       // byte offset of the suffix links inside tab
+  uint32_t link_off, direct_off;   // byte offsets of the suffix links / the direct map inside tab
 };
 
 }  // namespace tmh

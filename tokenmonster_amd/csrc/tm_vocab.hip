@@ -174,11 +174,14 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   while ((1ull << bits) < n_edges * 5 / 2 + 8) bits++;
   hv.edge_mask = (1u << bits) - 1;
   hv.edge_shift = 32 - bits;
-  const size_t link_base = ((size_t)kDirectSlots + ((size_t)1 << bits) + 1 + 1) & ~(size_t)1;   // + the always-empty slot, 16-byte aligned
+  // one allocation (tm_tables.h): edge hash | always-empty slot | direct map | suffix links
+  const size_t direct_base = (((size_t)1 << bits) + 1 + 1) & ~(size_t)1;      // 16-byte aligned
+  const size_t link_base = direct_base + kDirectSlots;
+  hv.direct_off = (uint32_t)(direct_base * sizeof(uint2));
   hv.link_off = (uint32_t)(link_base * sizeof(uint2));
   hv.tab.assign(link_base + 2 * (size_t)n_nodes, uint2{kNone, kNone});
   std::vector<uint32_t> l2v(kL2Size, kNone);       // value of the depth-2 node b0b1
-  uint2* edges = hv.tab.data() + kDirectSlots;
+  uint2* edges = hv.tab.data();
   std::vector<uint32_t> first_byte(n_nodes, 0);   // for depth-1 nodes: their byte, to index l2
   for (auto& kv : child) if (depth_of[kv.second] == 1) { hv.root[kv.first & 0xFF] = value_of(kv.second); first_byte[kv.second] = (uint32_t)(kv.first & 0xFF); }
   for (auto& kv : child) {
@@ -216,7 +219,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       const uint32_t m = lnode[n], dm = depth_at(m);
       const uint32_t hc = (m != kRoot && has_child[m]) ? 1u : 0u;
       const uint32_t b = m == kRoot ? kNone : best[m];
-      lt[2 * (size_t)n] = uint2{(m & kNodeMask) | ((uint32_t)lfull[n] << 21) | (hc << 22) | (dm << 23), b != kNone ? value_of(b) : 0u};
+      lt[2 * (size_t)n] = uint2{(m & kNodeMask) | (((uint32_t)lfull[n] & hc) << 21) | (dm << 23), b != kNone ? value_of(b) : 0u};
       lt[2 * (size_t)n + 1] = uint2{b != kNone ? (uint32_t)depth_of[b] : 0u, 0u};
     }
   }
@@ -251,8 +254,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
           if (v2 & kHasChildren) { cont = 1; id2 = node_id(v2); }
         }
       }
-      uint2* e = hv.tab.data() + 2 * (size_t)((b0 << 8) | b1);
-      e[0] = uint2{id2 | (cont << 21) | (cont << 22) | ((cont ? 2u : 0u) << 23), bestv};
+      uint2* e = hv.tab.data() + direct_base + 2 * (size_t)(b0 | (b1 << 8));      // indexed by the little-endian u16 at the position
+      e[0] = uint2{id2 | (cont << 21) | ((cont ? 2u : 0u) << 23), bestv};
       e[1] = uint2{bestlen, 0u};
     }
   }
@@ -317,7 +320,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   Tables& t = v->tables;
   t.root = v->d_root; t.tab = v->d_tab; t.spl = v->d_spl; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
   t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
-  t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint; t.link_off = hv.link_off;
+  t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint; t.link_off = hv.link_off; t.direct_off = hv.direct_off;
   t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
   *out = v;
   return TM_OK;
