@@ -532,19 +532,25 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     uint2* J = reinterpret_cast<uint2*>(w.D);            // overlays D, Db, X, Xb (dead after step B): 1024 x 8 B
     static_assert(sizeof(uint32_t) * (2 * NPOS_PAD + 2 * SEG) >= 2 * SEG * sizeof(uint2), "J overlay does not fit");
     const bool more_text = rem > (uint64_t)SEG;           // not the last segment of the document
-    // J entry: x = #id events [0..17] | byte offset inside J of the entry it points at [18..31] — offsets >= 8192
-    // (index >= J_EXIT, i.e. the sign bit) mean "left the segment"; y = #forward-deletes | #missing << 16.
-    // Composing two entries is then (x & EV_MASK) + x', y + y': the kernel is VALU bound, and this loop runs ~7 times.
-    constexpr uint32_t EV_BITS = 18, EV_MASK = (1u << EV_BITS) - 1u;
-    static_assert(J_INVALID * 8u < (1u << 14) && J_EXIT * 8u == (1u << 13), "J target field");
+    // J entry: x = #id events [0..15] | field [16..30] | left-the-segment [31]; the field is the LDS byte address of the
+    // entry it points at, or — once the chain has left the segment — the entry state of the next segment (0x7FFF: the
+    // state is unreachable); y = #forward-deletes | #missing << 16.  Composing two entries is (x & 0xFFFF) + x', y + y',
+    // and the address to read next is x >> 16: the kernel is VALU bound, and this loop runs ~7 times.
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) u32x2 lds_v2;
+    auto ld_j = [](uint32_t a) -> uint2 { const u32x2 t = *(lds_v2*)(uintptr_t)a; return make_uint2(t.x, t.y); };
+    const uint32_t jaddr = (uint32_t)(uintptr_t)(lds_u8*)w.D;
+    static_assert(sizeof(s_wave) + 2048 < 32768, "LDS addresses must fit the 15-bit field");
     auto first_hop = [&](uint32_t r, int p) -> uint2 {
-      if (p >= seglen) return make_uint2((J_EXIT * 8u) << EV_BITS, 0u);     // at/after the end of text: terminal, nothing emitted
-      if (r == R_INVALID) return make_uint2((J_INVALID * 8u) << EV_BITS, 0u);
+      if (p >= seglen) return make_uint2(0x80000000u, 0u);                    // at/after the end of text: terminal, nothing emitted
+      if (r == R_INVALID) return make_uint2(0x80000000u | (0x7FFFu << 16), 0u);
       const int pn = p + (int)((r >> 24) & 63u);
       const uint32_t fdn = (r >> 30) & 1u;
       const uint32_t ev = (r & ID_NONE) != ID_NONE ? 1u : 0u;
-      const uint32_t tgt = pn >= seglen ? J_EXIT + (more_text ? (uint32_t)((pn - SEG) * 2) + fdn : 0u) : fdn * SEG + (uint32_t)pn;
-      return make_uint2(((tgt * 8u) << EV_BITS) | ev, fdn | ((r >> 31) << 16));
+      const uint32_t x = pn >= seglen ? 0x80000000u | ((more_text ? (uint32_t)((pn - SEG) * 2) + fdn : 0u) << 16)
+                                      : (jaddr + 8u * (fdn * SEG + (uint32_t)pn)) << 16;
+      return make_uint2(x | ev, fdn | ((r >> 31) << 16));
     };
     // every lane keeps its own 2*SEG/64 states in registers and only touches LDS for states that still point inside
     // the segment (most (p,1) states are unreachable and finished from the start)
@@ -567,16 +573,15 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     // One round: every pending state composes itself with the state it points at.  The LDS reads of a round are issued
     // back to back (one LDS latency per round); the (p,1) states are rarely pending and skipped as a group.  The entry
     // states sit at the start of the segment and have the longest chains, so "nothing pending" is also when they are done.
-    const char* Jb = reinterpret_cast<const char*>(J);
     for (int round = 0; round < 12 && __any(any0 || any1); round++) {
       uint2 bn[N0];
 #pragma unroll
-      for (int k = 0; k < N0; k++) if (pend[k]) bn[k] = *reinterpret_cast<const uint2*>(Jb + (ja[k].x >> EV_BITS));
+      for (int k = 0; k < N0; k++) if (pend[k]) bn[k] = ld_j(ja[k].x >> 16);
       any0 = false;
 #pragma unroll
       for (int k = 0; k < N0; k++) {
         if (pend[k]) {
-          ja[k].x = (ja[k].x & EV_MASK) + bn[k].x;
+          ja[k].x = (ja[k].x & 0xFFFFu) + bn[k].x;
           ja[k].y += bn[k].y;                              // two 16-bit counters, neither can overflow (<= 512 each)
           J[k * 64 + lane] = ja[k];
           pend[k] = (int)ja[k].x >= 0;
@@ -588,8 +593,8 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
 #pragma unroll
         for (int k = N0; k < NS; k++) {
           if (pend[k]) {
-            const uint2 b1 = *reinterpret_cast<const uint2*>(Jb + (ja[k].x >> EV_BITS));
-            ja[k].x = (ja[k].x & EV_MASK) + b1.x;
+            const uint2 b1 = ld_j(ja[k].x >> 16);
+            ja[k].x = (ja[k].x & 0xFFFFu) + b1.x;
             ja[k].y += b1.y;
             J[k * 64 + lane] = ja[k];
             pend[k] = (int)ja[k].x >= 0;
@@ -603,9 +608,9 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     }
     for (int e = lane; e < ENT; e += 64) {
       const uint2 a = J[(e & 1) * SEG + (e >> 1)];
-      const uint32_t t = a.x >> (EV_BITS + 3);
+      const uint32_t t = (a.x >> 16) & 0x7FFFu;
       uint2 o = make_uint2(R_INVALID, 0u);
-      if (t >= J_EXIT && t != J_INVALID) o = make_uint2((t - J_EXIT) | ((a.x & EV_MASK) << 8), a.y);
+      if ((a.x >> 31) != 0 && t != 0x7FFFu) o = make_uint2(t | ((a.x & 0xFFFFu) << 8), a.y);
       exitmap[g * ENT + e] = o;
     }
   }
