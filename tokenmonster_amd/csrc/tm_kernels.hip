@@ -743,8 +743,11 @@ __global__ __launch_bounds__(WV * 64) void k_chain(const uint2* __restrict__ R, 
                                                uint64_t out_cap, uint32_t* __restrict__ out,
                                                uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
                                                uint32_t* __restrict__ missing_bits) {
-  __shared__ uint32_t s_j[WV][2 * SEG];     // target[0..11] | ids on the path << 12
-  __shared__ uint16_t s_rk[WV][2 * SEG];    // output rank of a chain state, 0xFFFF = not on the chain
+  // per wavefront: J[s] = ids on the path [0..15] | LDS address of the J word it points at [16..30] | left the segment [31]
+  // (composing two hops is (x & 0xFFFF) + x', the next read is x >> 16: this kernel is VALU bound like K1);
+  // RK[s] = output rank of a chain state, 0xFFFFFFFF = not (yet) known to be on the chain
+  struct ChainLds { uint32_t J[2 * SEG]; uint32_t RK[2 * SEG]; };
+  __shared__ ChainLds s_c[WV];
   __shared__ uint32_t s_tag[HIST ? HSLOTS : 1], s_cnt[HIST ? HSLOTS : 1];
   __shared__ unsigned long long s_ntok;
   __shared__ uint32_t s_ndel;
@@ -754,36 +757,47 @@ __global__ __launch_bounds__(WV * 64) void k_chain(const uint2* __restrict__ R, 
     if (threadIdx.x == 0) { s_ntok = 0; s_ndel = 0; }
     __syncthreads();
   }
-  uint32_t* J = s_j[wv];
-  uint16_t* RK = s_rk[wv];
+  uint32_t* J = s_c[wv].J;
+  uint32_t* RK = s_c[wv].RK;
+  typedef __attribute__((address_space(3))) uint8_t lds_u8;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  const uint32_t jaddr = (uint32_t)(uintptr_t)(lds_u8*)J;
+  static_assert(WV * sizeof(ChainLds) + 64 < 32768 || HIST, "LDS addresses must fit the 15-bit field");
+  // the persistent scoring variant owns more than 32 KB of LDS: its J words hold offsets from the wavefront's J instead
+  const uint32_t jbase = HIST ? 0u : jaddr, jrel = HIST ? jaddr : 0u;
+  constexpr uint32_t RKD = 2 * SEG;            // RK[s] sits RKD words behind J[s]
   for (uint64_t g = (uint64_t)blockIdx.x * WV + wv; g < nseg; g += (uint64_t)gridDim.x * WV) {
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
   const uint64_t rem = doc_end[doc] - begin;
   const int seglen = rem > SEG ? SEG : (int)rem;
-  constexpr int NS = 2 * SEG / 64;          // states per lane: k < NS/2 -> (p = k*64+lane, fd 0), else fd 1
+  constexpr int NS = 2 * SEG / 64, N0 = SEG / 64;   // states per lane: k < N0 -> (p = k*64+lane, fd 0), else fd 1
   uint32_t r[NS], jr[NS];
 #pragma unroll
-  for (int it = 0; it < SEG / 64; it++) {
+  for (int it = 0; it < N0; it++) {
     const int p = it * 64 + lane;
     uint2 v = make_uint2(R_INVALID, R_INVALID);
     if (p < seglen) v = R[begin + p];
     r[it] = v.x;
-    r[SEG / 64 + it] = v.y;
+    r[N0 + it] = v.y;
   }
+  bool pend[NS];
+  bool any0 = false, any1 = false;
 #pragma unroll
   for (int k = 0; k < NS; k++) {
-    const int p = (k % (SEG / 64)) * 64 + lane;
-    uint32_t j = J_EXIT;                                  // p >= seglen or unreachable: absorbing, emits nothing
+    const int p = (k % N0) * 64 + lane;
+    uint32_t j = 0x80000000u;                             // p >= seglen or unreachable: absorbing, emits nothing
     if (r[k] != R_INVALID) {
       const int pn = p + (int)((r[k] >> 24) & 63u);
       const uint32_t fdn = (r[k] >> 30) & 1u;
       const uint32_t nt = ((r[k] & ID_NONE) != ID_NONE ? 1u : 0u) + fdn;
-      j = (pn >= seglen ? J_EXIT : fdn * SEG + (uint32_t)pn) | (nt << 12);
+      j = (pn >= seglen ? 0x80000000u : (jbase + 4u * (fdn * SEG + (uint32_t)pn)) << 16) | nt;
     }
     jr[k] = j;
     J[k * 64 + lane] = j;
-    RK[k * 64 + lane] = 0xFFFFu;
+    RK[k * 64 + lane] = 0xFFFFFFFFu;
+    pend[k] = (int)j >= 0;
+    if (k < N0) any0 |= pend[k]; else any1 |= pend[k];
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
@@ -792,43 +806,55 @@ __global__ __launch_bounds__(WV * 64) void k_chain(const uint2* __restrict__ R, 
   if (lane == 0) RK[se] = 0;
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-  uint32_t rk[NS];
+  // One round, for every state that still points inside the segment: if it is known to be on the chain, tell the state
+  // it points at its rank; then double its own pointer.  Unlike the exit maps of K1 this needs every pointer of a round
+  // to be read before any is written (the marks only cover the chain if all pointers are the same power of two), hence
+  // the barrier in the middle.  The (p,1) states are rarely alive and skipped as a group.
   for (int round = 0; round < 12; round++) {
-    uint32_t bn[NS];
+    uint32_t bn[NS], rk[NS];
+    const bool g0 = __any(any0), g1 = __any(any1);
+    if (g0) {
 #pragma unroll
-    for (int k = 0; k < NS; k++) {
-      rk[k] = RK[k * 64 + lane];
-      const uint32_t t = jr[k] & 0xFFFu;
-      bn[k] = t < J_EXIT ? J[t] : 0u;
+      for (int k = 0; k < N0; k++) if (pend[k]) { bn[k] = *(lds_u32*)(uintptr_t)(jrel + (jr[k] >> 16)); rk[k] = RK[k * 64 + lane]; }
+    }
+    if (g1) {
+#pragma unroll
+      for (int k = N0; k < NS; k++) if (pend[k]) { bn[k] = *(lds_u32*)(uintptr_t)(jrel + (jr[k] >> 16)); rk[k] = RK[k * 64 + lane]; }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
+    auto update = [&](int k0, int k1, bool& any) {
+      any = false;
 #pragma unroll
-    for (int k = 0; k < NS; k++) {
-      const uint32_t t = jr[k] & 0xFFFu;
-      if (t < J_EXIT) {
-        if (rk[k] != 0xFFFFu) RK[t] = (uint16_t)(rk[k] + (jr[k] >> 12));
-        jr[k] = (bn[k] & 0xFFFu) | (((jr[k] >> 12) + (bn[k] >> 12)) << 12);
-        J[k * 64 + lane] = jr[k];
+      for (int k = k0; k < k1; k++) {
+        if (pend[k]) {
+          if (rk[k] != 0xFFFFFFFFu) ((lds_u32*)(uintptr_t)(jrel + (jr[k] >> 16)))[RKD] = rk[k] + (jr[k] & 0xFFFFu);
+          jr[k] = (jr[k] & 0xFFFFu) + bn[k];
+          J[k * 64 + lane] = jr[k];
+          pend[k] = (int)jr[k] >= 0;
+          any |= pend[k];
+        }
       }
-    }
+    };
+    if (g0) update(0, N0, any0);
+    if (g1) update(N0, NS, any1);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
-    if ((J[se] & 0xFFFu) >= J_EXIT) break;                 // wave-uniform (same address in every lane)
+    if ((int)J[se] < 0) break;                             // wave-uniform (same address in every lane): the entry's chain has left
   }
   const uint64_t base = HIST ? 0 : tok_offsets[doc] + seg_tokbase[g];
   uint32_t ntok = 0, ndel = 0;
 #pragma unroll
   for (int k = 0; k < NS; k++) {
     const uint32_t rank = RK[k * 64 + lane];
-    if (rank != 0xFFFFu && r[k] != R_INVALID) {
+    if (rank != 0xFFFFFFFFu && r[k] != R_INVALID) {
       const uint32_t id = r[k] & ID_NONE, fdn = (r[k] >> 30) & 1u;
       if (!HIST) {
         uint64_t o = base + rank;
         if (id != ID_NONE) { if (o < out_cap) out[o] = id; o++; }
         if (fdn && o < out_cap) out[o] = delete_id;
       } else {
-        const int p = (k % (SEG / 64)) * 64 + lane;
+        const int p = (k % N0) * 64 + lane;
         if (r[k] >> 31) {                                  // trainvocab.go:1166-1173: no token for this byte
           const uint32_t byte = text[begin + p];
           atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
