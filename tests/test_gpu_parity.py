@@ -75,6 +75,24 @@ def test_fuzz_micro_vocab(capcode, seed):
         assert st["s1b"] + st["s2b"] + st["s3b"] > 0, st
 
 
+def test_dense_forward_delete_path(monkeypatch):
+    """K1 hands the T(p,1) words to K4 as a short per-segment side list; segments with more forward-delete states than the
+    list holds use a dense array instead.  TM_DBG bit 6 forces that path for every segment."""
+    rng = np.random.default_rng(77)
+    toks = fuzz_vocab_tokens(rng, 2, 140)
+    img = synth.build_vocab(toks, capcode=2, charset=1, with_unk=True)
+    v = tm.Vocab(img)
+    orc = Oracle(img)
+    docs = [fuzz_text(rng, 2, int(n)) for n in rng.integers(0, 3000, size=60)] + [fuzz_text(rng, 2, 200_000)]
+    oracle_stats(reset=True)
+    monkeypatch.setenv("TM_DBG", "64")
+    check_docs(v, orc, docs, "dense (p,1) path")
+    monkeypatch.delenv("TM_DBG")
+    st = oracle_stats()
+    assert st["s1b"] + st["s2b"] + st["s3b"] > 0, st
+    check_docs(v, orc, docs[:10], "side-list path")
+
+
 @pytest.mark.parametrize("name", ["englishcode-32000-consistent", "code-4096-balanced-nocapcode"])
 def test_synthetic_config(name):
     kind, size, capcode, norm_flag, level, seed = synth.CONFIGS[name]

@@ -265,7 +265,8 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
                                                                 const uint64_t* __restrict__ doc_end,
                                                                 const uint32_t* __restrict__ seg_doc,
                                                                 const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
-                                                                uint2* __restrict__ R, uint2* __restrict__ exitmap, int dbg) {
+                                                                uint32_t* __restrict__ R0, uint2* __restrict__ side,
+                                                                uint32_t* __restrict__ R1, uint2* __restrict__ exitmap, int dbg) {
   __shared__ uint32_t s_root[256];
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
       r0[it] = R_INVALID;
       if (p < seglen) r0[it] = transition(T, w, s_bb, p, dl, d0[it], row0[it], 0);
     }
+    const bool side_ok = n1 < SIDE_STRIDE && !(dbg & 64);          // (dbg & 64: tests force the dense path)
     for (int base = 0; base < n1; base += 64) {
       int run = 0;
 #pragma unroll
@@ -504,7 +506,9 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
         const int q = (int)w.X[SEG + lane];
         const uint32_t dB = w.Db[q];
         const Row row1 = T.rows[node_id(w.Xb[q])];
-        w.Xb[q] = transition(T, w, s_bb, q, dl, dB, row1, 1);     // Xb[q] is only ever read by this lane: reuse it for the result
+        const uint32_t t1 = transition(T, w, s_bb, q, dl, dB, row1, 1);
+        w.Xb[q] = t1;                                              // Xb[q] is only ever read by this lane: reuse it for the result
+        if (side_ok) side[g * SIDE_STRIDE + 1 + lane] = make_uint2((uint32_t)q, t1);
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0);
@@ -513,8 +517,12 @@ __global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const 
     for (int it = 0; it < SEG / 64; it++) {
       const int p = it * 64 + lane;
       r1[it] = ((m1[it] >> lane) & 1ull) ? w.Xb[p] : R_INVALID;
-      if (p < seglen) R[begin + p] = make_uint2(r0[it], r1[it]);
+      if (p < seglen) {
+        R0[begin + p] = r0[it];
+        if (!side_ok) R1[begin + p] = r1[it];                      // (rare) too many forward-delete states for the side list
+      }
     }
+    if (lane == 0) side[g * SIDE_STRIDE] = make_uint2(side_ok ? (uint32_t)n1 : SIDE_DENSE, 0u);
     PH_COUNT(15, n1)
   }
   PH(6)
@@ -732,7 +740,8 @@ __global__ void k_group_expand(const uint2* __restrict__ exitmap, const Group* _
 // this, the hot ids (" the", ",") serialise tens of millions of L2 atomics on a handful of addresses.
 constexpr int HSLOTS = 8192;
 template <bool HIST, int WV>
-__global__ __launch_bounds__(WV * 64) void k_chain(const uint2* __restrict__ R, const uint8_t* __restrict__ text,
+__global__ __launch_bounds__(WV * 64) void k_chain(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
+                                               const uint32_t* __restrict__ R1, const uint8_t* __restrict__ text,
                                                const uint64_t* __restrict__ doc_begin,
                                                const uint64_t* __restrict__ doc_end,
                                                const uint32_t* __restrict__ seg_doc,
@@ -776,10 +785,28 @@ __global__ __launch_bounds__(WV * 64) void k_chain(const uint2* __restrict__ R, 
 #pragma unroll
   for (int it = 0; it < N0; it++) {
     const int p = it * 64 + lane;
-    uint2 v = make_uint2(R_INVALID, R_INVALID);
-    if (p < seglen) v = R[begin + p];
-    r[it] = v.x;
-    r[N0 + it] = v.y;
+    r[it] = p < seglen ? R0[begin + p] : R_INVALID;
+  }
+  // the few T(p,1) words of the segment come as a side list (scattered through LDS), or, if there were too many, densely
+  const uint32_t nside = side[g * SIDE_STRIDE].x;
+  if (nside == SIDE_DENSE) {
+#pragma unroll
+    for (int it = 0; it < N0; it++) { const int p = it * 64 + lane; r[N0 + it] = p < seglen ? R1[begin + p] : R_INVALID; }
+  } else if (nside == 0) {
+#pragma unroll
+    for (int it = 0; it < N0; it++) r[N0 + it] = R_INVALID;
+  } else {
+#pragma unroll
+    for (int it = 0; it < N0; it++) RK[it * 64 + lane] = R_INVALID;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    if ((uint32_t)lane < nside) { const uint2 sv = side[g * SIDE_STRIDE + 1 + lane]; RK[sv.x] = sv.y; }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for (int it = 0; it < N0; it++) r[N0 + it] = RK[it * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
   }
   bool pend[NS];
   bool any0 = false, any1 = false;
@@ -942,7 +969,7 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
   const uint64_t nseg = b->nseg;
   if (nseg > 0)
     k_chain<true, 16><<<(uint32_t)std::min<uint64_t>((nseg + 15) / 16, (uint64_t)n_cu), 1024, 0, st>>>(
-        b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
+        b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
         delete_id, 0, nullptr, d_hist, d_tokens, d_missing_bits);
   k_hist_finish<<<1, 256, 0, st>>>(d_tokens, d_missing_bits, d_hist + n_ids);
 }
@@ -1019,7 +1046,7 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   mark(1);
   if (nseg > 0)
     k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
-                                                                                b->d_doc_seg_start, nseg, b->d_R, b->d_exitmap,
+                                                                                b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
                                                                                 getenv("TM_DBG") ? atoi(getenv("TM_DBG")) : 0);
   mark(2);
   if (nd > 0)
@@ -1037,7 +1064,7 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   else (void)hipMemsetAsync(b->d_tok_offsets, 0, 8, st);
   mark(4);
   if (emit && nseg > 0)
-    k_chain<false, 4><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+    k_chain<false, 4><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
                                                                nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, v->tables.delete_id,
                                                                b->out_cap, b->d_out, nullptr, nullptr, nullptr);
   mark(5);
@@ -1066,7 +1093,7 @@ int ensure_output(tm_batch* b) {
     b->out_cap = total + 1024;
     if ((e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc output");
     hipStream_t st = b->last_stream;
-    k_chain<false, 4><<<(uint32_t)((b->nseg + 3) / 4), 256, 0, st>>>(b->d_R, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+    k_chain<false, 4><<<(uint32_t)((b->nseg + 3) / 4), 256, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
                                                                   b->nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
                                                                   b->vocab->tables.delete_id, b->out_cap, b->d_out, nullptr, nullptr, nullptr);
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "emit rerun");
@@ -1096,7 +1123,8 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
   hipError_t e = hipSuccess;
   if ((own_text && (e = dalloc(b, &b->d_text, max_bytes + 256)) != hipSuccess) || (e = dalloc(b, &b->d_offsets, 2 * nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_doc_nseg, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_seg_start, nd1 + 1)) != hipSuccess ||
-      (e = dalloc(b, &b->d_seg_doc, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_R, max_bytes + 64)) != hipSuccess ||
+      (e = dalloc(b, &b->d_seg_doc, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_R0, max_bytes + 64)) != hipSuccess || (e = dalloc(b, &b->d_R1, max_bytes + 64)) != hipSuccess ||
+      (e = dalloc(b, &b->d_side, b->max_segs * SIDE_STRIDE)) != hipSuccess ||
       (e = dalloc(b, &b->d_exitmap, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_seg_entry, b->max_segs)) != hipSuccess ||
       (e = dalloc(b, &b->d_seg_tokbase, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_doc_ntok, nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_doc_events, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_missing, nd1)) != hipSuccess ||
@@ -1120,7 +1148,7 @@ int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm
 
 void tm_batch_free(tm_batch* b) {
   if (!b) return;
-  void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R, b->d_exitmap, b->d_seg_entry,
+  void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R0, b->d_R1, b->d_side, b->d_exitmap, b->d_seg_entry,
                   b->d_seg_tokbase, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
                   b->d_error, b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
                   b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,

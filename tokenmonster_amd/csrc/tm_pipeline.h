@@ -21,6 +21,8 @@ constexpr uint32_t J_EXIT = 1024;           // jump targets >= J_EXIT: left the 
 constexpr uint32_t J_INVALID = 2047;        // state is not reachable (no forward-delete match there)
 constexpr uint32_t ID_NONE = 0xFFFFFFu;
 constexpr int NOSCORE = -1000000;
+constexpr int SIDE_STRIDE = 16;            // uint2 entries of a segment's side list: [0] = {count or SIDE_DENSE, 0}, then {position, T(p,1)}
+constexpr uint32_t SIDE_DENSE = 0xFFFFFFFFu;  // more (p,1) states than the list holds: they are in the dense R1 array instead
 constexpr uint32_t LONG_SEGS = 512;        // documents with more segments than this are resolved hierarchically
 
 constexpr int SCAN_T = 256, SCAN_PER = 16, SCAN_CH = SCAN_T * SCAN_PER;   // exclusive scan u32 -> u64: elements per workgroup
@@ -49,7 +51,9 @@ struct tm_batch {
   uint32_t* d_doc_nseg = nullptr;
   uint64_t* d_doc_seg_start = nullptr;
   uint32_t* d_seg_doc = nullptr;
-  uint2* d_R = nullptr;
+  uint32_t* d_R0 = nullptr;          // T(p,0) of every byte position
+  uint2* d_side = nullptr;           // per segment: its few T(p,1) words (SIDE_STRIDE entries: header + {position, word})
+  uint32_t* d_R1 = nullptr;          // T(p,1) per position, written only for segments whose side list overflows
   uint2* d_exitmap = nullptr;
   uint8_t* d_seg_entry = nullptr;
   uint32_t* d_seg_tokbase = nullptr;
