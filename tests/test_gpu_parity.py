@@ -63,7 +63,7 @@ def test_fuzz_micro_vocab(capcode, seed):
     oracle_stats(reset=True)
     docs = [fuzz_text(rng, capcode, int(n)) for n in rng.integers(0, 3000, size=120)]
     # empty / tiny documents, lengths around multiples of the segment size (whatever it is), one long document
-    docs += [b"", b"a", b" "] + [fuzz_text(rng, capcode, n) for n in (255, 256, 257, 319, 320, 321, 383, 384, 385, 511, 512, 513, 639, 640, 641,
+    docs += [b"", b"a", b" "] + [fuzz_text(rng, capcode, n) for n in (255, 256, 257, 319, 320, 321, 383, 384, 385, 511, 512, 513, 639, 640, 641, 767, 768, 769,
                                                                       1024, 1025, 70000)]
     if seed == 1:
         docs.append(fuzz_text(rng, capcode, 400_000))     # > LONG_SEGS segments: hierarchical resolve path

@@ -260,7 +260,7 @@ __device__ unsigned long long g_phase[64 * 32];
 #endif
 
 
-__global__ __launch_bounds__(WAVES * 64, 6) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
+__global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
                                                                 const uint64_t* __restrict__ doc_end,
                                                                 const uint32_t* __restrict__ seg_doc,

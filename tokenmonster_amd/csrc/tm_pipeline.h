@@ -10,7 +10,7 @@
 
 namespace tmh {
 
-constexpr int SEG = 320;                 // bytes of one document segment (one wavefront); 320 -> 24 wavefronts per CU
+constexpr int SEG = 256;                 // bytes of one document segment (one wavefront); 256 -> 28 wavefronts per CU (LDS)
 constexpr int NPOS = SEG + 40;           // positions whose descriptors a segment needs (look-ahead <= 40)
 constexpr int NPOS_PAD = (NPOS + 63) / 64 * 64;
 constexpr int TEXT_LEN = SEG + 96;       // staged text: position i may read up to i + 40
