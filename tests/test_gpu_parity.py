@@ -93,7 +93,8 @@ def test_dense_forward_delete_path(monkeypatch):
     check_docs(v, orc, docs[:10], "side-list path")
 
 
-@pytest.mark.parametrize("name", ["englishcode-32000-consistent", "code-4096-balanced-nocapcode"])
+@pytest.mark.parametrize("name", ["english-24000-consistent", "englishcode-32000-consistent", "englishcode-100256-clean",
+                                  "code-4096-balanced-nocapcode"])       # BASELINE.json configs[0..3] (shapes; synthetic)
 def test_synthetic_config(name):
     kind, size, capcode, norm_flag, level, seed = synth.CONFIGS[name]
     img = synth.config_vocab(name)
