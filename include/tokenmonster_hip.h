@@ -107,6 +107,9 @@ int tm_batch_run(tm_batch* b, void* stream);
 #define TM_NUM_KERNELS 5
 int tm_batch_run_timed(tm_batch* b, void* stream, float* ms);
 const char* tm_kernel_name(int k);
+/* Development aid: sets the debug switches of the match kernel (phases off for profiling; bit 6 = dense T(p,1) path, used by
+ * the tests) and returns the previous value; flags < 0 only queries.  0 in production: results with other bits are wrong. */
+int tm_debug_flags(int flags);
 /* Totals of the last run (synchronizes the stream used by the last run). */
 int tm_batch_totals(tm_batch* b, uint64_t* total_tokens, uint64_t* total_missing);
 /* D2H of results of the last run. */

@@ -75,9 +75,10 @@ def test_fuzz_micro_vocab(capcode, seed):
         assert st["s1b"] + st["s2b"] + st["s3b"] > 0, st
 
 
-def test_dense_forward_delete_path(monkeypatch):
+def test_dense_forward_delete_path():
     """K1 hands the T(p,1) words to K4 as a short per-segment side list; segments with more forward-delete states than the
-    list holds use a dense array instead.  TM_DBG bit 6 forces that path for every segment."""
+    list holds use a dense array instead.  Debug bit 6 forces that path for every segment."""
+    from tokenmonster_amd import _native as N
     rng = np.random.default_rng(77)
     toks = fuzz_vocab_tokens(rng, 2, 140)
     img = synth.build_vocab(toks, capcode=2, charset=1, with_unk=True)
@@ -85,9 +86,11 @@ def test_dense_forward_delete_path(monkeypatch):
     orc = Oracle(img)
     docs = [fuzz_text(rng, 2, int(n)) for n in rng.integers(0, 3000, size=60)] + [fuzz_text(rng, 2, 200_000)]
     oracle_stats(reset=True)
-    monkeypatch.setenv("TM_DBG", "64")
-    check_docs(v, orc, docs, "dense (p,1) path")
-    monkeypatch.delenv("TM_DBG")
+    old = N.lib.tm_debug_flags(64)
+    try:
+        check_docs(v, orc, docs, "dense (p,1) path")
+    finally:
+        N.lib.tm_debug_flags(old)
     st = oracle_stats()
     assert st["s1b"] + st["s2b"] + st["s3b"] > 0, st
     check_docs(v, orc, docs[:10], "side-list path")

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tm_batch_run": (C.c_int, [vp, vp]),
     "tm_batch_run_timed": (C.c_int, [vp, vp, f32p]),
     "tm_kernel_name": (C.c_char_p, [C.c_int]),
+    "tm_debug_flags": (C.c_int, [C.c_int]),
     "tm_batch_totals": (C.c_int, [vp, u64p, u64p]),
     "tm_batch_download": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
     "tm_batch_device_tokens": (vp, [vp]),

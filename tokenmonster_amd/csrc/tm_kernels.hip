@@ -948,6 +948,14 @@ using namespace tmh;
 
 namespace tmh {
 
+// K1 development switches (tm_debug_flags; TM_DBG in the environment sets the initial value): bit 0 no walks at all, 2 no hash
+// probes, 3 no forward-delete probes, 4 no exit maps, 6 dense T(p,1) array for every segment.  0 in production.
+int g_debug_flags = -1;
+int debug_flags() {
+  if (g_debug_flags < 0) { const char* e = getenv("TM_DBG"); g_debug_flags = e ? atoi(e) : 0; }
+  return g_debug_flags;
+}
+
 static const char* kKernelNames[TM_NUM_KERNELS] = {"segments", "match_branch", "resolve", "scan", "emit"};
 
 hipError_t batch_alloc_bytes(tm_batch* b, void** p, uint64_t bytes) {
@@ -1047,7 +1055,7 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   if (nseg > 0)
     k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
                                                                                 b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
-                                                                                getenv("TM_DBG") ? atoi(getenv("TM_DBG")) : 0);
+                                                                                debug_flags());
   mark(2);
   if (nd > 0)
     k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_seg_entry, b->d_seg_tokbase,
@@ -1106,6 +1114,12 @@ int ensure_output(tm_batch* b) {
 extern "C" {
 
 const char* tm_kernel_name(int k) { return k >= 0 && k < TM_NUM_KERNELS ? kKernelNames[k] : ""; }
+
+int tm_debug_flags(int flags) {
+  const int old = tmh::debug_flags();
+  if (flags >= 0) tmh::g_debug_flags = flags;
+  return old;
+}
 
 }  // extern "C"
 namespace tmh {

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc"))
     ap.add_argument("--kernel", default="")
     ap.add_argument("--extra", default="", help="extra bench.py flags")
+    ap.add_argument("--e2e", action="store_true", help="profile the end-to-end step (device normalizer included) instead of the hot path")
     ap.add_argument("--groups", default="", help="comma separated group numbers (default all)")
     args = ap.parse_args()
     args.out = os.path.abspath(args.out)
@@ -41,7 +42,7 @@ def main():
         d = os.path.join(args.out, "g%d" % gi)
         cmd = ["rocprofv3", "--pmc"] + grp + ["--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--mbytes", str(args.mbytes), "--steps", "2", "--warmup", "1",
-               "--hot-path-only", "--verify", "0", "--no-cpu-baseline"] + args.extra.split()
+               "--verify", "0", "--no-cpu-baseline"] + ([] if args.e2e else ["--hot-path-only"]) + args.extra.split()
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             print("group %d failed:\n%s" % (gi, r.stdout.decode(errors="replace")[-2000:]), file=sys.stderr)
