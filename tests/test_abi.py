@@ -41,3 +41,19 @@ def test_no_oracle_in_product():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_bind" not in src and "libtm_oracle" not in src and "libtmref" not in src, f
+
+
+def test_headers_are_plain_c_and_example_links(tmp_path):
+    """include/*.h must be usable from C (the cgo stub of INTEGRATION.md compiles them as C), and the library must link
+    into a program that knows nothing of Python or torch."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "tokenmonster_hip.h"\n#include "tm_build.h"\nint main(void) { return tm_device_count() < 0; }\n')
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                        "-L", os.path.join(root, "tokenmonster_amd"), "-ltokenmonster_hip",
+                        "-Wl,-rpath," + os.path.join(root, "tokenmonster_amd")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    r = subprocess.run(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")

@@ -1,4 +1,6 @@
 """-m gpu: the HIP path (through the C ABI) against the CPU oracle, bit-exact token ids."""
+import os
+
 import numpy as np
 import pytest
 
@@ -381,3 +383,25 @@ def test_batch_workspace_reuse():
         assert N.lib.tm_batch_upload(b, N.ptr(text), N.ptr(noff), noff.size - 1) == N.TM_E_LIMIT
     finally:
         N.lib.tm_batch_free(b)
+
+
+@pytest.mark.gpu
+def test_c_example_matches_python_path(tmp_path):
+    """examples/tokenize_file.c (plain C on the C ABI) prints the same ids as the Python mirror."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    rng = np.random.default_rng(5)
+    toks = fuzz_vocab_tokens(rng, 0, 120)
+    img = synth.build_vocab(toks, capcode=0, charset=1, with_unk=True)
+    lines = [fuzz_text(rng, 0, int(n)).replace(b"\n", b" ") + b"\n" for n in rng.integers(1, 900, size=40)]
+    (tmp_path / "v.vocab").write_bytes(bytes(img))
+    (tmp_path / "t.txt").write_bytes(b"".join(lines))
+    r = subprocess.run([os.path.join(root, "examples", "tokenize_file"), str(tmp_path / "v.vocab"), str(tmp_path / "t.txt"), "--lines"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")
+    got = [[int(x) for x in ln.split()] for ln in r.stdout.decode().split("\n")[:len(lines)]]
+    v = tm.Vocab(img)
+    for ln, g in zip(lines, got):
+        assert v.tokenize_normalized(ln)[0].tolist() == g
