@@ -57,7 +57,7 @@ struct PieceLds { uint8_t raw[PLDS]; uint8_t f[PLDS]; };
 // stage the piece (+ margins) and classify every byte; continuation bytes inherit the class of their lead byte.
 // returns the piece length; LDS index of document byte (pb + i) is PMARGIN + i.
 __device__ __forceinline__ int norm_load_piece(PieceLds& L, const uint8_t* __restrict__ raw, uint64_t rb, uint64_t re, uint64_t pb, int lane,
-                                               bool lower_all) {
+                                               const uint8_t* s_cls) {
   for (int i = lane; i < PLDS / 4; i += 64) {
     const int64_t g = (int64_t)pb - PMARGIN + 4 * i;
     uint32_t wv = 0;
@@ -73,7 +73,7 @@ __device__ __forceinline__ int norm_load_piece(PieceLds& L, const uint8_t* __res
   for (int i = 2 + lane; i < PLDS - 2; i += 64) {
     const uint32_t b = L.raw[i];
     uint32_t fl;
-    if (b < 0x80u) fl = ncls_ascii(b, lower_all);
+    if (b < 0x80u) fl = s_cls[b];                         // class of an ASCII byte: one LDS read instead of five range checks
     else {
       const uint32_t m1 = L.raw[i - 1], m2 = L.raw[i - 2], p1 = L.raw[i + 1], p2 = L.raw[i + 2];
       uint32_t b1 = 0, b2 = 0, cont = 0;
@@ -97,13 +97,16 @@ __global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict_
                                                       const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t lower_all,
                                                       uint32_t* __restrict__ piece_sum) {
   __shared__ PieceLds s_l[4];
+  __shared__ uint8_t s_cls[128];
+  if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
   if (k >= npieces) return;
   PieceLds& L = s_l[wv];
   const uint32_t d = piece_doc[k];
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = norm_load_piece(L, raw, rb, re, pb, lane, lower_all != 0);
+  const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls);
   bool lead_open = true, lead_tl = false, bad = false;
   uint32_t lead_u = 0, trail_u = 0;
   for (int c = 0; c * 64 < m; c++) {
@@ -179,6 +182,9 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
                                                    unsigned long long* __restrict__ overflow) {
   constexpr bool WRITE = MODE != 0;
   __shared__ PieceLds s_l[4];
+  __shared__ uint8_t s_cls[128];
+  if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
   if (k >= npieces) return;
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
   const uint32_t d = piece_doc[k];
   if (need_host[d]) { if (MODE != 1 && lane == 0) piece_len[k] = 0; return; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = norm_load_piece(L, raw, rb, re, pb, lane, lower_all != 0);
+  const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls);
   uint8_t* dst = MODE == 1 ? out + piece_off[k] : (MODE == 2 ? out + k * (uint64_t)SLAB : nullptr);
   if (capcode != 2) {                                       // no capcode: same length, only the lower-case flag applies
     if (MODE != 1 && lane == 0) piece_len[k] = (uint32_t)m;
@@ -280,8 +286,13 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
         }
       }
     }
+    // inclusive prefix sum of len (0..4) over the wavefront: bytes-with-len>=k ballots, counted below the lane
     uint32_t incl = len;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+#pragma unroll
+    for (uint32_t q = 1; q <= 4; q++) {
+      const unsigned long long bq = __ballot(len >= q);
+      incl = __builtin_amdgcn_mbcnt_hi((uint32_t)(bq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bq, incl));
+    }
     if (WRITE && in && (MODE == 1 || pos + incl <= (uint32_t)SLAB)) {
       uint8_t* w = dst + pos + (incl - len);
       if (len == 4) { w[0] = (uint8_t)o0; w[1] = (uint8_t)o1; w[2] = (uint8_t)o2; w[3] = (uint8_t)o3; }
