@@ -1169,6 +1169,7 @@ void tm_batch_free(tm_batch* b) {
                   b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_raw, b->d_fb_norm, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids};
   for (void* p : ptrs) (void)hipFree(p);
   if (b->have_events) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
+  if (b->aux_stream) (void)hipStreamDestroy(b->aux_stream);
   delete b;
 }
 

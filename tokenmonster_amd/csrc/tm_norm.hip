@@ -453,10 +453,19 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   std::vector<uint64_t> roff;
   std::vector<uint8_t> hraw;
   double f1 = now(), f2 = 0, f3 = 0, f4 = 0;
+  // the device normalizes its documents (one pass into per-piece slabs, lengths on the side) ...
+  if (np > 0)
+    k_norm_emit<2><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+                                          b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3);
+  scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
   if (nf > 0) {
-    // fetch the documents the device cannot normalize (other non-ASCII content: NFD / Unicode case need ICU)
+    // ... while the documents it cannot normalize (other non-ASCII content: NFD / Unicode case need ICU) are fetched on a
+    // second stream, so that the fetch does not hold up the pass above
+    if (!b->aux_stream && (e = hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    hipStream_t sx = b->aux_stream;
     std::vector<uint8_t> need(nd);
-    if ((e = hipMemcpy(need.data(), b->d_need_host, nd, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H flags");
+    if ((e = hipMemcpyAsync(need.data(), b->d_need_host, nd, hipMemcpyDeviceToHost, sx)) != hipSuccess || (e = hipStreamSynchronize(sx)) != hipSuccess)
+      return hip_fail(e, "D2H flags");
     ids.reserve(nf);
     for (uint32_t d = 0; d < nd; d++) if (need[d]) ids.push_back(d);
     roff.assign(ids.size() + 1, 0);
@@ -471,25 +480,20 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
       b->fb_docs_cap = (uint32_t)docs_cap;
     }
     if ((e = grow(&b->d_fb_raw, &b->fb_raw_cap, roff.back() + 16)) != hipSuccess) return hip_fail(e, "hipMalloc (fallback staging)");
-    if ((e = hipMemcpyAsync(b->d_fb_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_fb_roff, roff.data(), roff.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D fallback lists");
-    k_gather_docs<<<(uint32_t)ids.size(), 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_fb_ids, b->d_fb_roff, (uint32_t)ids.size(), b->d_fb_raw);
+    if ((e = hipMemcpyAsync(b->d_fb_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, sx)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_fb_roff, roff.data(), roff.size() * 8, hipMemcpyHostToDevice, sx)) != hipSuccess) return hip_fail(e, "H2D fallback lists");
+    k_gather_docs<<<(uint32_t)ids.size(), 256, 0, sx>>>(b->d_raw, b->d_raw_off, b->d_fb_ids, b->d_fb_roff, (uint32_t)ids.size(), b->d_fb_raw);
     hraw.resize(roff.back());
-    if ((e = hipMemcpyAsync(hraw.data(), b->d_fb_raw, roff.back(), hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
+    if ((e = hipMemcpyAsync(hraw.data(), b->d_fb_raw, roff.back(), hipMemcpyDeviceToHost, sx)) != hipSuccess || (e = hipStreamSynchronize(sx)) != hipSuccess)
       return hip_fail(e, "D2H fallback documents");
     f2 = now();
   }
-  // the device normalizes its documents (one pass into per-piece slabs, lengths on the side) ...
-  if (np > 0)
-    k_norm_emit<2><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                          b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3);
-  scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
   uint64_t gpu_bytes = 0;
-  // ... while the host normalizes the others; they are appended after the device part
+  // the host normalizes those; they are appended after the device part
   uint8_t* hnorm = nullptr;
   std::vector<uint64_t> noff(ids.size() + 1, 0);
   if (nf > 0) {
-    const uint32_t threads = (uint32_t)std::min<size_t>(64, ids.size() / 8 + 1);
+    const uint32_t threads = (uint32_t)std::min<size_t>(64, ids.size() / 8 + 1);   // measured: 32 and 128 threads are both slower (spawn cost)
     int rc = tm_normalize_batch(hraw.data(), roff.data(), (uint32_t)ids.size(), capcode, norm_flag, threads, &hnorm, noff.data());
     if (rc != TM_OK) return rc;
     f3 = now();

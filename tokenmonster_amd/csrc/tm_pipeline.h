@@ -42,6 +42,7 @@ struct tm_batch {
   uint32_t ndocs = 0;
   uint64_t device_bytes = 0;
   hipStream_t last_stream = nullptr;
+  hipStream_t aux_stream = nullptr;    // fetch of the host-fallback documents, beside the normalizer pass
   // device buffers
   uint8_t* d_text = nullptr;
   bool text_borrowed = false;          // scoring pass: text belongs to a tm_dataset
