@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,9 @@ void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t n
 
 void capcode_decode_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t threads,
                           std::vector<std::vector<uint8_t>>& outs);
+
+// runs `work` on the calling thread and on up to threads-1 pooled workers at once; `work` must pull from a shared queue
+void run_on_workers(uint32_t threads, const std::function<void()>& work);
 
 // small deterministic PRNG (splitmix64 seeding + xoshiro256**), used by the synthetic generators
 struct Rng {

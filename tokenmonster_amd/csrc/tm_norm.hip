@@ -493,7 +493,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   uint8_t* hnorm = nullptr;
   std::vector<uint64_t> noff(ids.size() + 1, 0);
   if (nf > 0) {
-    const uint32_t threads = (uint32_t)std::min<size_t>(64, ids.size() / 8 + 1);   // measured: 32 and 128 threads are both slower (spawn cost)
+    const uint32_t threads = (uint32_t)std::min<size_t>(64, ids.size() / 8 + 1);   // pooled workers; more of them gain little (the device pass is as long)
     int rc = tm_normalize_batch(hraw.data(), roff.data(), (uint32_t)ids.size(), capcode, norm_flag, threads, &hnorm, noff.data());
     if (rc != TM_OK) return rc;
     f3 = now();

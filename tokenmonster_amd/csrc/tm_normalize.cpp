@@ -16,8 +16,66 @@
 #include <unicode/unistr.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
+
+namespace tmh {
+
+// A small persistent worker pool: the host-fallback normalizer and the decode post-pass run once per batch on a few thousand
+// documents, and spawning their threads every time cost more than the work (64 fresh threads: 4 ms for 2 ms of work).
+// Workers are created on first use and never joined (the pool object is leaked on purpose: no destructor-order problems at
+// exit).  `work` must be a loop that pulls from a shared queue: helpers that do not wake up in time are simply not used.
+namespace {
+struct WorkerPool {
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  size_t nthreads = 0;
+  const std::function<void()>* job = nullptr;
+  uint64_t generation = 0;
+  uint32_t want = 0, started = 0, running = 0;
+  void worker() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_work.wait(lk, [&] { return generation != seen; });
+      seen = generation;
+      if (started >= want) continue;            // not needed for this job (or it is over already)
+      started++; running++;
+      const std::function<void()>* j = job;
+      lk.unlock();
+      (*j)();
+      lk.lock();
+      if (--running == 0) cv_done.notify_all();
+    }
+  }
+};
+WorkerPool* g_pool = nullptr;
+std::mutex g_pool_call;    // one job at a time
+}  // namespace
+
+void run_on_workers(uint32_t threads, const std::function<void()>& work) {
+  if (threads <= 1) { work(); return; }
+  std::lock_guard<std::mutex> call(g_pool_call);
+  if (!g_pool) g_pool = new WorkerPool();
+  WorkerPool& p = *g_pool;
+  const uint32_t helpers = threads - 1;
+  {
+    std::unique_lock<std::mutex> lk(p.mu);
+    while (p.nthreads < helpers) { std::thread([&p] { p.worker(); }).detach(); p.nthreads++; }
+    p.job = &work; p.want = helpers; p.started = 0; p.running = 0; p.generation++;
+  }
+  p.cv_work.notify_all();
+  work();                                       // the caller works too
+  std::unique_lock<std::mutex> lk(p.mu);
+  p.want = 0;                                   // late wakers find nothing to do
+  p.cv_done.wait(lk, [&] { return p.running == 0; });
+  p.job = nullptr;
+}
+
+}  // namespace tmh
 
 namespace tmh {
 namespace {
@@ -324,10 +382,7 @@ void capcode_decode_batch(const uint8_t* text, const uint64_t* offsets, uint32_t
       }
     }
   };
-  std::vector<std::thread> pool;
-  for (uint32_t t = 1; t < threads; t++) pool.emplace_back(work);
-  work();
-  for (auto& t : pool) t.join();
+  tmh::run_on_workers(threads, work);
 }
 
 }  // namespace tmh
@@ -364,10 +419,7 @@ int tm_normalize_batch(const uint8_t* text, const uint64_t* offsets, uint32_t nd
         tmh::normalize_bytes(text + offsets[d], (size_t)(offsets[d + 1] - offsets[d]), capcode, norm_flag, outs[d]);
     }
   };
-  std::vector<std::thread> pool;
-  for (uint32_t t = 1; t < threads; t++) pool.emplace_back(work);
-  work();
-  for (auto& t : pool) t.join();
+  tmh::run_on_workers(threads, work);
   uint64_t total = 0;
   for (uint32_t d = 0; d < ndocs; d++) { out_offsets[d] = total; total += outs[d].size(); }
   out_offsets[ndocs] = total;
