@@ -98,6 +98,30 @@ def test_dense_forward_delete_path():
     check_docs(v, orc, docs[:10], "side-list path")
 
 
+@pytest.mark.parametrize("flags", [128, 128 | 64])
+def test_list_ranking_emit_variant(flags):
+    """K4 is a lane-per-segment chain chase by default; debug bit 7 selects the list-ranking kernel (k_chain) for the emitting
+    entry points and for the scoring pass.  Both must give the oracle's ids / histogram (bit 6: dense T(p,1) array as well)."""
+    from tokenmonster_amd import _native as N
+    rng = np.random.default_rng(78)
+    toks = fuzz_vocab_tokens(rng, 2, 140)
+    img = synth.build_vocab(toks, capcode=2, charset=1, with_unk=True)
+    v = tm.Vocab(img)
+    orc = Oracle(img)
+    docs = [fuzz_text(rng, 2, int(n)) for n in rng.integers(0, 3000, size=60)] + [b"", b"a", fuzz_text(rng, 2, 200_000)]
+    data = fuzz_text(rng, 2, 120_000)
+    exp_s, exp_t, exp_m = orc.score(data)
+    old = N.lib.tm_debug_flags(flags)
+    try:
+        check_docs(v, orc, docs, "list-ranking emit, flags %d" % flags)
+        got_s, got_t, got_m = _score(v, data)
+    finally:
+        N.lib.tm_debug_flags(old)
+    assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
+    got_s, got_t, got_m = _score(v, data)              # and the default (chase) scoring kernel on the same data
+    assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
+
+
 @pytest.mark.parametrize("name", ["english-24000-consistent", "englishcode-32000-consistent", "englishcode-100256-clean",
                                   "code-4096-balanced-nocapcode"])       # BASELINE.json configs[0..3] (shapes; synthetic)
 def test_synthetic_config(name):

@@ -919,6 +919,117 @@ __global__ __launch_bounds__(WV * 64) void k_chain(const uint32_t* __restrict__ 
   }
 }
 
+// K4, emitting variant: one LANE per segment follows the chain from the segment's true entry state and writes the ids as it
+// goes.  The parallel ranking above spends ~500 vector instructions per segment to rank 512 states of which ~57 are on the
+// chain; here a wavefront spends ~15 per hop for 64 segments at once (~13 per segment) and the kernel is bound by the
+// dependent loads instead — of which hundreds of thousands are in flight on the chip, one per lane.  Every 128-byte line of
+// T(p,0) is still read once from HBM (a chain touches all of them), the hops after the first hit it in L2.
+// (p,1) states are rare: their words are looked up in the segment's side list (or the dense array) when one is entered.
+__global__ __launch_bounds__(256) void k_emit_chase(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
+                                                    const uint32_t* __restrict__ R1, const uint64_t* __restrict__ doc_begin,
+                                                    const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ seg_doc,
+                                                    const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
+                                                    const uint8_t* __restrict__ seg_entry, const uint32_t* __restrict__ seg_tokbase,
+                                                    const uint64_t* __restrict__ tok_offsets, uint32_t delete_id, uint64_t out_cap,
+                                                    uint32_t* __restrict__ out, uint32_t* __restrict__ error_flag) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nseg) return;
+  const uint32_t doc = seg_doc[g];
+  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
+  const uint64_t rem = doc_end[doc] - begin;
+  const uint32_t seglen = rem > (uint64_t)SEG ? (uint32_t)SEG : (uint32_t)rem;
+  const uint32_t e = seg_entry[g];
+  uint32_t p = e >> 1, fd = e & 1u;
+  uint64_t o = tok_offsets[doc] + seg_tokbase[g];
+  const uint32_t* __restrict__ r0 = R0 + begin;
+  const uint2* __restrict__ sl = side + g * SIDE_STRIDE;
+  for (int hop = 0; hop < 2 * SEG && p < seglen; hop++) {
+    uint32_t w;
+    if (fd == 0) w = r0[p];
+    else {
+      const uint32_t nside = sl[0].x;
+      w = R_INVALID;
+      if (nside == SIDE_DENSE) w = R1[begin + p];
+      else for (uint32_t k = 1; k <= nside && k < (uint32_t)SIDE_STRIDE; k++) { const uint2 sv = sl[k]; if (sv.x == p) w = sv.y; }
+    }
+    const uint32_t adv = (w >> 24) & 63u;
+    if (w == R_INVALID || adv == 0) { atomicOr(error_flag, 2u); break; }   // cannot happen on a chain K1/K3 produced
+    const uint32_t id = w & ID_NONE;
+    fd = (w >> 30) & 1u;
+    if (id != ID_NONE) { if (o < out_cap) out[o] = id; o++; }
+    if (fd) { if (o < out_cap) out[o] = delete_id; o++; }
+    p += adv;
+  }
+}
+
+// K4, scoring variant of the chase (training/trainvocab.go:1105-1174): persistent workgroups as in k_chain<true> (the
+// LDS-privatised histogram is what keeps the hot ids off the L2 atomics), every lane follows the chains of its segments.
+template <int WV>
+__global__ __launch_bounds__(WV * 64) void k_score_chase(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
+                                                        const uint32_t* __restrict__ R1, const uint8_t* __restrict__ text,
+                                                        const uint64_t* __restrict__ doc_begin, const uint64_t* __restrict__ doc_end,
+                                                        const uint32_t* __restrict__ seg_doc, const uint64_t* __restrict__ doc_seg_start,
+                                                        uint64_t nseg, const uint8_t* __restrict__ seg_entry, uint32_t delete_id,
+                                                        uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
+                                                        uint32_t* __restrict__ missing_bits, uint32_t* __restrict__ error_flag) {
+  __shared__ uint32_t s_tag[HSLOTS], s_cnt[HSLOTS];
+  __shared__ unsigned long long s_ntok;
+  __shared__ uint32_t s_ndel;
+  for (int j = threadIdx.x; j < HSLOTS; j += WV * 64) { s_tag[j] = 0xFFFFFFFFu; s_cnt[j] = 0; }
+  if (threadIdx.x == 0) { s_ntok = 0; s_ndel = 0; }
+  __syncthreads();
+  uint32_t ntok = 0, ndel = 0;
+  for (uint64_t g = (uint64_t)blockIdx.x * (WV * 64) + threadIdx.x; g < nseg; g += (uint64_t)gridDim.x * (WV * 64)) {
+    const uint32_t doc = seg_doc[g];
+    const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
+    const uint64_t rem = doc_end[doc] - begin;
+    const uint32_t seglen = rem > (uint64_t)SEG ? (uint32_t)SEG : (uint32_t)rem;
+    const uint32_t e = seg_entry[g];
+    uint32_t p = e >> 1, fd = e & 1u;
+    const uint32_t* __restrict__ r0 = R0 + begin;
+    const uint2* __restrict__ sl = side + g * SIDE_STRIDE;
+    for (int hop = 0; hop < 2 * SEG && p < seglen; hop++) {
+      uint32_t w;
+      if (fd == 0) w = r0[p];
+      else {
+        const uint32_t nside = sl[0].x;
+        w = R_INVALID;
+        if (nside == SIDE_DENSE) w = R1[begin + p];
+        else for (uint32_t k = 1; k <= nside && k < (uint32_t)SIDE_STRIDE; k++) { const uint2 sv = sl[k]; if (sv.x == p) w = sv.y; }
+      }
+      const uint32_t adv = (w >> 24) & 63u;
+      if (w == R_INVALID || adv == 0) { atomicOr(error_flag, 2u); break; }
+      const uint32_t id = w & ID_NONE;
+      fd = (w >> 30) & 1u;
+      if (w >> 31) {                                       // trainvocab.go:1166-1173: no token for this byte
+        const uint32_t byte = text[begin + p];
+        atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
+      } else {                                             // scores[id] += bytes covered (:1109..1162)
+        const uint32_t slot = id & (HSLOTS - 1);
+        uint32_t owner = s_tag[slot];
+        if (owner == 0xFFFFFFFFu) { owner = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, id); if (owner == 0xFFFFFFFFu) owner = id; }
+        if (owner == id) atomicAdd(&s_cnt[slot], adv);
+        else atomicAdd(&scores[id], adv);
+      }
+      ntok += 1 + fd;                                      // tokensInText++ (also for a missing byte, :1169) / += 2
+      ndel += fd;                                          // scores[deleteToken]++ (:1134,1143,1152)
+      p += adv;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { ntok += __shfl_xor(ntok, o); ndel += __shfl_xor(ndel, o); }
+  if ((threadIdx.x & 63) == 0) {
+    if (ndel) atomicAdd(&s_ndel, ndel);
+    if (ntok) atomicAdd(&s_ntok, (unsigned long long)ntok);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < HSLOTS; j += WV * 64)
+    if (s_cnt[j] != 0) atomicAdd(&scores[s_tag[j]], s_cnt[j]);
+  if (threadIdx.x == 0) {
+    if (s_ndel) atomicAdd(&scores[delete_id], s_ndel);
+    if (s_ntok) atomicAdd(tokens, s_ntok);
+  }
+}
+
 __global__ void k_hist_finish(const unsigned long long* __restrict__ tokens, const uint32_t* __restrict__ missing_bits,
                               uint32_t* __restrict__ tail) {
   uint32_t t = threadIdx.x;
@@ -975,11 +1086,29 @@ void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t 
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
                        uint32_t n_ids, hipStream_t st) {
   const uint64_t nseg = b->nseg;
-  if (nseg > 0)
+  if (nseg > 0 && !(debug_flags() & 128))
+    k_score_chase<16><<<(uint32_t)std::min<uint64_t>((nseg + 1023) / 1024, (uint64_t)n_cu), 1024, 0, st>>>(
+        b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry, delete_id, d_hist, d_tokens,
+        d_missing_bits, b->d_error);
+  else if (nseg > 0)
     k_chain<true, 16><<<(uint32_t)std::min<uint64_t>((nseg + 15) / 16, (uint64_t)n_cu), 1024, 0, st>>>(
         b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
         delete_id, 0, nullptr, d_hist, d_tokens, d_missing_bits);
   k_hist_finish<<<1, 256, 0, st>>>(d_tokens, d_missing_bits, d_hist + n_ids);
+}
+
+// K4 for the id-emitting entry points: the lane-per-segment chase; debug bit 7 selects the list-ranking kernel instead
+// (the scoring pass always uses the latter, its histogram lives in the LDS of persistent workgroups)
+static void launch_emit(tm_batch* b, hipStream_t st) {
+  const uint64_t nseg = b->nseg;
+  if (debug_flags() & 128)
+    k_chain<false, 4><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
+                                                               nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, b->vocab->tables.delete_id,
+                                                               b->out_cap, b->d_out, nullptr, nullptr, nullptr);
+  else
+    k_emit_chase<<<(uint32_t)((nseg + 255) / 256), 256, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg,
+                                                                b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, b->vocab->tables.delete_id, b->out_cap,
+                                                                b->d_out, b->d_error);
 }
 
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {
@@ -1071,10 +1200,7 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   if (nd > 0) scan_u32(b->d_doc_ntok, nd, b->d_scan_tmp, b->d_totals + 1, b->d_tok_offsets, st);
   else (void)hipMemsetAsync(b->d_tok_offsets, 0, 8, st);
   mark(4);
-  if (emit && nseg > 0)
-    k_chain<false, 4><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
-                                                               nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, v->tables.delete_id,
-                                                               b->out_cap, b->d_out, nullptr, nullptr, nullptr);
+  if (emit && nseg > 0) launch_emit(b, st);
   mark(5);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
   if (timed) {
@@ -1101,9 +1227,7 @@ int ensure_output(tm_batch* b) {
     b->out_cap = total + 1024;
     if ((e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc output");
     hipStream_t st = b->last_stream;
-    k_chain<false, 4><<<(uint32_t)((b->nseg + 3) / 4), 256, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
-                                                                  b->nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
-                                                                  b->vocab->tables.delete_id, b->out_cap, b->d_out, nullptr, nullptr, nullptr);
+    launch_emit(b, st);
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "emit rerun");
   }
   return TM_OK;
