@@ -115,3 +115,24 @@ def test_unsupported_normalization_fails_loudly():
     from tokenmonster_amd._native import TokenMonsterHipError
     with pytest.raises(TokenMonsterHipError):
         synth.normalize(b"abc", 2, 16)
+
+
+def test_device_normalizer_rule_table_and_flood_fills_on_cpu(tmp_path):
+    """The device normalizer (k_norm_emit2) takes its rule table and its run logic (inWord, 'C'/'W' lookahead as flood fills on
+    class ballots) from __host__ __device__ code in tm_norm_masks.h.  tools/norm_masks_check.cpp replays the kernel's per-piece /
+    per-chunk schedule around exactly that code on the CPU and compares every document with the host normalizer."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "norm_masks_check")
+    libdir = os.path.join(root, "tokenmonster_amd")
+    r = subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "include"), "-I", os.path.join(libdir, "csrc"),
+                        os.path.join(root, "tools", "norm_masks_check.cpp"), "-o", exe, "-L" + libdir, "-ltokenmonster_hip", "-Wl,-rpath," + libdir],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    r = subprocess.run([exe, "6000", "17"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and " 0 mismatches" in out, out[-3000:]

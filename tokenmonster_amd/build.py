@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtokenmonster_hip.so")
 SOURCES = ["tm_vocab.hip", "tm_kernels.hip", "tm_score.hip", "tm_norm.hip", "tm_decode.hip", "tm_build.cpp", "tm_normalize.cpp", "tm_synth.cpp"]
-HEADERS = ["tm_device.h", "tm_internal.h", "tm_tables.h", "tm_pipeline.h", "../../include/tokenmonster_hip.h", "../../include/tm_build.h"]
+HEADERS = ["tm_device.h", "tm_internal.h", "tm_tables.h", "tm_pipeline.h", "tm_norm_masks.h", "../../include/tokenmonster_hip.h", "../../include/tm_build.h"]
 
 
 def _hipcc():

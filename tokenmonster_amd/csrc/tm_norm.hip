@@ -8,6 +8,7 @@
 
 #include "tm_pipeline.h"
 #include "tm_build.h"
+#include "tm_norm_masks.h"
 
 using namespace tmh;
 
@@ -34,8 +35,7 @@ using namespace tmh;
 namespace tmh {
 
 constexpr int PIECE = 1024, PMARGIN = 8, PLDS = PIECE + 2 * PMARGIN;
-enum : uint32_t { NC_O = 0, NC_L = 1, NC_U = 2, NC_N = 3, NC_AP = 4, NC_SP = 5 };
-constexpr uint32_t NF_CLASS = 7u, NF_CONT = 8u, NF_TERML = 16u, NF_UA_SHIFT = 5, NF_BAD = 0x80u;
+// character classes NC_* and flag bits NF_*: tm_norm_masks.h
 // piece summary bits
 constexpr uint32_t PS_WHOLE = 1u, PS_LEADU_SHIFT = 1, PS_LEADTL = 8u, PS_TRAILU_SHIFT = 5, PS_FIRSTBLOCK = 128u, PS_FIRSTL = 256u, PS_BAD = 512u;
 
@@ -56,7 +56,8 @@ struct PieceLds { uint8_t raw[PLDS]; uint8_t f[PLDS]; };
 
 // stage the piece (+ margins) and classify every byte; continuation bytes inherit the class of their lead byte.
 // returns the piece length; LDS index of document byte (pb + i) is PMARGIN + i.
-__device__ __forceinline__ int norm_load_piece(PieceLds& L, const uint8_t* __restrict__ raw, uint64_t rb, uint64_t re, uint64_t pb, int lane,
+template <typename LDS>
+__device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict__ raw, uint64_t rb, uint64_t re, uint64_t pb, int lane,
                                                const uint8_t* s_cls) {
   for (int i = lane; i < PLDS / 4; i += 64) {
     const int64_t g = (int64_t)pb - PMARGIN + 4 * i;
@@ -308,6 +309,139 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
   }
 }
 
+// ---- capcode level 2, one pass into the slabs ------------------------------------------------------------------------------
+// Same rules as k_norm_emit (which stays for the exact two-pass path and for capcode 0) at ~40 % of its vector instructions
+// (the normalizer is bound by vector-instruction issue like the match kernel): the two run-dependent facts of a byte — inWord
+// and the 'C'/'W' lookahead — are flood fills on the chunk's class ballots, done by the scalar unit; the rule chain is a
+// 2048-entry table in LDS (tm_norm_masks.h; both checked on the CPU by tools/norm_masks_check.cpp); the output is assembled in
+// LDS and leaves for the slab in 16-byte stores.
+struct PieceLds2 { uint8_t raw[PLDS]; uint8_t f[PLDS]; alignas(16) uint8_t out[2 * PIECE + 64]; };   // out: slab image + one dump byte per lane
+
+__device__ const NmLut g_norm_lut = nm_make_lut();
+
+// per-lane select on a wave-uniform lane mask: bit set -> a, else b (one v_cndmask, the mask stays in scalar registers)
+__device__ __forceinline__ uint32_t sel_mask(unsigned long long mask, uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask, uint32_t acc) {      // acc + #set bits of mask below the lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, acc));
+}
+
+__global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rbegin,
+                                                    const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
+                                                    const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t lower_all,
+                                                    const uint8_t* __restrict__ piece_carry, const uint8_t* __restrict__ need_host,
+                                                    uint32_t* __restrict__ piece_len, uint8_t* __restrict__ slab,
+                                                    unsigned long long* __restrict__ overflow) {
+  constexpr int SLAB2 = 2 * PIECE, NCH = PIECE / 64;
+  __shared__ PieceLds2 s_l[4];
+  __shared__ uint8_t s_cls[128];
+  __shared__ alignas(16) uint16_t s_lut[NM_LUT_SIZE];
+  static_assert(NM_LUT_SIZE * sizeof(uint16_t) == 256 * sizeof(uint4), "one 16-byte load per thread stages the rule table");
+  if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
+  reinterpret_cast<uint4*>(s_lut)[threadIdx.x] = reinterpret_cast<const uint4*>(g_norm_lut.e[lower_all ? 1 : 0])[threadIdx.x];
+  __syncthreads();
+  // the wavefront index is made visibly wave-uniform: everything derived from it (piece, length, carries) then lives in scalar
+  // registers, and so does the mask algebra below
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+  if (k >= npieces) return;
+  PieceLds2& L = s_l[wv];
+  const uint32_t d = piece_doc[k];
+  if (need_host[d]) { if (lane == 0) piece_len[k] = 0; return; }
+  const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
+  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls));
+  const uint32_t carry = __builtin_amdgcn_readfirstlane((uint32_t)piece_carry[k]);
+  const unsigned long long carry_tl = (carry >> 4) & 1u;
+  const int nch = (m + 63) >> 6;
+  // all chunks but the last are whole; the piece boundary m lies in chunk m >> 6 (which is chunk nch when m is a multiple of 64)
+  const unsigned long long v_last = nm_valid(nch - 1, m);
+  const int c_bnd = m >> 6;
+  const unsigned long long bnd_bit = carry_tl << (m & 63);
+  const uint8_t* fl0 = L.f + PMARGIN + lane;       // class byte of byte (64 c + lane) of the piece = fl0[64 c]
+  // norm_load_piece has classified the LDS bytes from six before the piece to five after its 1024 (all the rules ever reach);
+  // a ballot over chunk c must not look at lanes outside that range
+  // ---- backward sweep: TX[c] = 'C'-lookahead of the block bytes of chunk c (+ the piece boundary bit) ------------------------
+  unsigned long long TX[NCH + 1];
+  {
+    unsigned long long tx_next = ((m & 63) == 0) ? carry_tl : 0ull, lx_next0 = tx_next;
+#pragma unroll
+    for (int c = NCH; c >= 0; c--) {
+      TX[c] = 0ull;
+      if (c == nch) TX[c] = tx_next;
+      if (c < nch && c < NCH) {
+        const uint32_t fl = fl0[64 * c];
+        uint64_t lx0;
+        TX[c] = nm_backward(__ballot((fl & NF_BLOCK) != 0), __ballot((fl & NF_CLASS) == NC_L), c == nch - 1 ? v_last : ~0ull, c == c_bnd ? bnd_bit : 0ull,
+                            tx_next, lx_next0, &lx0);
+        tx_next = TX[c];
+        lx_next0 = lx0;
+      }
+    }
+  }
+  // ---- forward sweep ---------------------------------------------------------------------------------------------------
+  typedef __attribute__((address_space(3))) uint8_t lds_u8;
+  const uint32_t out0 = (uint32_t)(uintptr_t)(lds_u8*)L.out;
+  const uint32_t dump = out0 + (uint32_t)SLAB2 + (uint32_t)lane;     // where a lane's "not this byte" stores go
+  unsigned long long w = (carry & 3u) ? 1ull : 0ull;
+  uint32_t pos = 0;
+  bool over = false;
+  unsigned long long Ucur = __ballot((fl0[0] & NF_CLASS) == NC_U);
+  uint32_t chC = 'C', chW = 'W', chSP = ' ', chD = 'D';
+  asm volatile("" : "+v"(chC), "+v"(chW), "+v"(chSP), "+v"(chD));      // four registers for the whole sweep, not four moves per chunk
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if (c < nch) {
+      // capitals of the next chunk (its first byte may be the capital a trailing space announces); chunk 16 is the six margin bytes
+      const uint32_t fnext = (c + 1 < NCH || lane <= 5) ? (uint32_t)fl0[64 * (c + 1)] : 0u;
+      const unsigned long long Unext = __ballot((fnext & NF_CLASS) == NC_U);
+      const uint32_t fl = fl0[64 * c], fp = fl0[64 * c - 1], f2 = fl0[64 * c - 2], f4 = fl0[64 * c - 4];
+      const uint32_t b = L.raw[PMARGIN + 64 * c + lane];
+      uint64_t w_out, spC, spW;
+      const unsigned long long V = c == nch - 1 ? v_last : ~0ull;
+      const unsigned long long W = nm_inword(__ballot((fl & NF_BLOCK) != 0), Ucur, V, w, &w_out);
+      nm_space_markers(__ballot((fl & NF_CLASS) == NC_SP), Ucur, Unext, V, TX[c], TX[c + 1], &spC, &spW);
+      w = w_out;
+      // the rule table: index = class | previous class << 3 | class before the apostrophe << 6 | W << 9 | T << 10
+      const uint32_t p2 = (fp & NF_CONT) ? f4 : f2;
+      uint32_t idx = (fl & 7u) | ((fp & 7u) << 3) | ((p2 & 7u) << 6);
+      idx = sel_mask(W, idx | 512u, idx);
+      idx = sel_mask(TX[c], idx | 1024u, idx);
+      const uint32_t code = s_lut[idx];
+      const uint32_t len1 = code & 3u;                                   // bytes emitted - 1
+      uint32_t o3 = b | ((code & 4u) << 3);
+      o3 = sel_mask(spC, chC, o3);
+      o3 = sel_mask(spW, chW, o3);
+      const unsigned long long ge2 = __ballot(len1 >= 1u) & V, ge3 = __ballot(len1 >= 2u) & V, ge4 = __ballot(len1 >= 3u) & V;
+      const uint32_t total = (uint32_t)(__builtin_popcountll(V) + __builtin_popcountll(ge2) + __builtin_popcountll(ge3) + __builtin_popcountll(ge4));
+      if (pos + total <= (uint32_t)SLAB2) {
+        // first output byte of the lane = out0 + pos + (bytes of the lanes below); its last byte is len1 further
+        const uint32_t first = mbcnt64(ge4, mbcnt64(ge3, mbcnt64(ge2, mbcnt64(V, out0 + pos))));
+        const uint32_t last = first + len1;
+        *(lds_u8*)(uintptr_t)sel_mask(V, last, dump) = (uint8_t)o3;
+        *(lds_u8*)(uintptr_t)sel_mask(ge2, last - 1u, dump) = (uint8_t)chSP;
+        *(lds_u8*)(uintptr_t)sel_mask(ge3, last - 2u, dump) = (uint8_t)(code >> 8);
+        *(lds_u8*)(uintptr_t)sel_mask(ge4, first, dump) = (uint8_t)chD;
+      } else over = true;                                   // wave-uniform: the piece does not fit its slab (exact two-pass path)
+      pos += total;
+      Ucur = Unext;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  if (!over) {
+    uint8_t* dst = slab + k * (uint64_t)SLAB2;
+    for (uint32_t j = (uint32_t)lane * 16u; j < pos; j += 64u * 16u)
+      *reinterpret_cast<uint4*>(dst + j) = *reinterpret_cast<const uint4*>(L.out + j);    // the slab is 16-byte aligned and 2 KiB long
+  }
+  if (lane == 0) {
+    piece_len[k] = pos;
+    if (pos > (uint32_t)SLAB2) atomicAdd(overflow, 1ull);
+  }
+}
+
 // pack the slabs: piece k's bytes go to out[piece_off[k] ..)
 __global__ __launch_bounds__(256) void k_norm_compact(const uint8_t* __restrict__ slab, const uint32_t* __restrict__ piece_len,
                                                       const uint64_t* __restrict__ piece_off, uint64_t npieces, uint8_t* __restrict__ out) {
@@ -454,7 +588,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   std::vector<uint8_t> hraw;
   double f1 = now(), f2 = 0, f3 = 0, f4 = 0;
   // the device normalizes its documents (one pass into per-piece slabs, lengths on the side) ...
-  if (np > 0)
+  if (np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
+    k_norm_emit2<<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
+                                        b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3);
+  else if (np > 0)                    // capcode 0, or debug bit 8: the per-lane version of the rules
     k_norm_emit<2><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                           b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3);
   scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);

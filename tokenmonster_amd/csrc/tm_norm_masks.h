@@ -1,0 +1,112 @@
+// tm_norm_masks.h — the parts of capcode level 2 (javascript/tokenmonster.js:900-1005) that the device normalizer
+// (tm_norm.hip, k_norm_emit2) does NOT evaluate lane by lane:
+//   * the two facts about a byte that depend on an unbounded stretch of text — W "inWord" and T "the block ends in a
+//     lower-case letter" — are flood fills on the 64-bit ballots of a chunk's character classes (a handful of scalar
+//     instructions per 64 bytes instead of per-lane popcount / find-first arithmetic);
+//   * the rule table itself: what a byte turns into is a function of (its class, the class before it, the class before an
+//     apostrophe before it, W, T) — 2048 cases, tabulated once at compile time (nm_lut_entry) and read from LDS.
+// Everything here is __host__ __device__ (and constexpr where it is a table) so that the exact code the kernel runs is
+// checked on the CPU against the host normalizer: tools/norm_masks_check.cpp, run by tests/test_builder_normalizer.py.
+//
+// Vocabulary (see tm_norm.hip): a *block* is a maximal run of {capital, digit, apostrophe} bytes;
+//   W[i]  there is a capital in the block bytes immediately before byte i            (the encoder's inWord state)
+//   T[i]  for a block byte: the first byte after its block is a lower-case letter   ('C' marker, else 'W')
+// Bit i of a mask is byte i of the chunk; carries between chunks are single bits.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIP__)
+#define TM_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define TM_HD inline
+#endif
+
+namespace tmh {
+
+// character classes (3 bits; bit 2 = member of a block) and flag bits of a classified byte
+enum : uint32_t { NC_O = 0, NC_L = 1, NC_SP = 2, NC_U = 4, NC_N = 5, NC_AP = 6 };
+constexpr uint32_t NF_CLASS = 7u, NF_BLOCK = 4u, NF_CONT = 8u, NF_TERML = 16u, NF_UA_SHIFT = 5, NF_BAD = 0x80u;
+
+TM_HD uint64_t nm_brev(uint64_t x) { return __builtin_bitreverse64(x); }   // s_brev_b64 on the device
+// every bit of M reachable upwards from a seed through consecutive set bits of M (seeds outside M are ignored):
+// the carry of M + S ripples from a seed to the end of its run
+TM_HD uint64_t nm_flood_up(uint64_t M, uint64_t S) { S &= M; return ((M ^ (M + S)) | S) & M; }
+TM_HD uint64_t nm_flood_down(uint64_t M, uint64_t S) { return nm_brev(nm_flood_up(nm_brev(M), nm_brev(S))); }
+// bit i = bit (i + 1) of the byte stream (next0 = bit 0 of the following chunk)
+TM_HD uint64_t nm_shr1(uint64_t cur, uint64_t next0) { return (cur >> 1) | (next0 << 63); }
+// valid-byte mask of chunk c of a piece of m bytes, and the bit of absolute position m inside chunk c (0 if elsewhere)
+TM_HD uint64_t nm_valid(int c, int m) { const int r = m - 64 * c; return r >= 64 ? ~0ull : (r <= 0 ? 0ull : ((1ull << r) - 1ull)); }
+TM_HD uint64_t nm_boundary(int c, int m) { const int r = m - 64 * c; return (r >= 0 && r < 64) ? (1ull << r) : 0ull; }
+
+// Backward sweep over a chunk.  B / L: ballots "byte is in a block" / "byte is a lower-case letter" of the chunk (any bytes; bytes
+// beyond the piece are masked here); V = nm_valid of the chunk; bnd = nm_boundary of the chunk if a block that reaches the end of
+// the piece ends in a lower-case letter (carry_tl from k_norm_carry), else 0.
+// Returns TX = T of the chunk's block bytes | bnd.
+// tx_next / lx_next0: TX of chunk c+1 and bit 0 of its boundary-augmented lower-case mask; *lx0: the same bit of this chunk.
+TM_HD uint64_t nm_backward(uint64_t B, uint64_t L, uint64_t V, uint64_t bnd, uint64_t tx_next, uint64_t lx_next0, uint64_t* lx0) {
+  const uint64_t Bv = B & V;
+  const uint64_t Lx = (L & V) | bnd;
+  const uint64_t succ = (lx_next0 | tx_next) & 1ull;              // what a block byte at bit 63 inherits from the next chunk
+  const uint64_t T = nm_flood_down(Bv, Bv & nm_shr1(Lx, succ));
+  *lx0 = Lx & 1ull;
+  return T | bnd;
+}
+
+// Forward sweep over a chunk: W of every byte.  B / U: ballots "in a block" / "capital" (masked to the piece here); w_in: W of byte 0
+// of the chunk; *w_out: W of byte 0 of the next chunk.
+TM_HD uint64_t nm_inword(uint64_t B, uint64_t U, uint64_t V, uint64_t w_in, uint64_t* w_out) {
+  const uint64_t G = nm_flood_up(B & V, (U & V) | (w_in & 1ull));   // block bytes with a capital at or before them in their run
+  *w_out = G >> 63;
+  return (G << 1) | (w_in & 1ull);
+}
+
+// A space right before a capital becomes that capital's marker (:976-979): 'C' if the capital's block ends in a lower-case
+// letter, else 'W'.  SP / U: ballots of the chunk (U unmasked: the capital may be the first byte after the piece); next_u0:
+// bit 0 of the capital ballot of chunk c+1; tx / tx_next0: TX of this chunk, bit 0 of TX of the next.
+TM_HD void nm_space_markers(uint64_t SP, uint64_t U, uint64_t next_u0, uint64_t V, uint64_t tx, uint64_t tx_next0, uint64_t* spC, uint64_t* spW) {
+  const uint64_t spM = SP & V & nm_shr1(U, next_u0 & 1ull);
+  const uint64_t nextT = nm_shr1(tx, tx_next0 & 1ull);
+  *spC = spM & nextT;
+  *spW = spM & ~nextT;
+}
+
+// ---- the rule table ------------------------------------------------------------------------------------------------------
+// index: class [0..2] | class of the previous byte [3..5] | class two characters back, looked at only behind an apostrophe
+//        [6..8] | W [9] | T [10]
+// entry: bytes emitted - 1 [0..1] | the byte itself is lower-cased [2] | the byte that precedes "' ' + byte" when three or four
+//        are emitted [8..15]: 'D' (three), 'C' or 'W' after a leading 'D' (four)
+constexpr int NM_LUT_SIZE = 2048;
+TM_HD constexpr uint32_t nm_lut_index(uint32_t cls, uint32_t prev, uint32_t prev2, uint32_t w, uint32_t t) {
+  return (cls & 7u) | ((prev & 7u) << 3) | ((prev2 & 7u) << 6) | ((w & 1u) << 9) | ((t & 1u) << 10);
+}
+TM_HD constexpr uint16_t nm_lut_entry(uint32_t idx, bool lower_all) {
+  const uint32_t cls = idx & 7u, P = (idx >> 3) & 7u, P2 = (idx >> 6) & 7u;
+  const bool W = (idx >> 9) & 1u, T = (idx >> 10) & 1u;
+  uint32_t len = 1, lower = 0, mark = 0;
+  if (cls == NC_U) {                                         // :913-916, :924-951, :975-990
+    lower = 1;
+    if (!W) {                                                // first capital of a run
+      if (P == NC_SP) len = 2;                               // the space before it has become the marker (nm_space_markers)
+      else { len = 4; mark = T ? 'C' : 'W'; }
+    } else if (T) { len = 4; mark = 'C'; }                   // every later capital of a 'C' run
+    else if (P == NC_N) { len = 3; mark = 'D'; }
+  } else if (cls == NC_L) {                                  // :952-955 (the letter that ends a run), :970
+    lower = lower_all ? 1 : 0;
+    const bool joined = W ? (P == NC_U || P == NC_AP)
+                          : (P == NC_SP || P == NC_L || P == NC_U || (P == NC_AP && (P2 == NC_L || P2 == NC_U)));
+    if (!joined) { len = 3; mark = 'D'; }
+  } else if (cls == NC_N) {                                  // :958 / :992
+    const bool joined = W ? (P == NC_N) : (P == NC_SP || P == NC_N);
+    if (!joined) { len = 3; mark = 'D'; }
+  }
+  return (uint16_t)((len - 1) | (lower << 2) | (mark << 8));
+}
+struct NmLut { uint16_t e[2][NM_LUT_SIZE]; };
+constexpr NmLut nm_make_lut() {
+  NmLut t{};
+  for (int la = 0; la < 2; la++)
+    for (int i = 0; i < NM_LUT_SIZE; i++) t.e[la][i] = nm_lut_entry((uint32_t)i, la != 0);
+  return t;
+}
+
+}  // namespace tmh

@@ -1,0 +1,209 @@
+// norm_masks_check.cpp — CPU check of the mask algebra the device normalizer runs (tokenmonster_amd/csrc/tm_norm_masks.h):
+// replays k_norm_emit2's per-piece / per-chunk schedule (class masks -> backward sweep -> forward sweep -> bytes) with the very
+// same __host__ __device__ functions and compares every document with the host normalizer (tm_normalize).
+//   hipcc -O2 -std=c++17 -I include -I tokenmonster_amd/csrc tools/norm_masks_check.cpp -o /tmp/norm_masks_check \
+//         -Ltokenmonster_amd -ltokenmonster_hip -Wl,-rpath,$PWD/tokenmonster_amd
+// usage: norm_masks_check [random documents] [seed]      exit code 0 = all documents equal
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tm_build.h"
+#include "tm_internal.h"
+#include "tm_norm_masks.h"
+
+using namespace tmh;
+
+namespace {
+constexpr int PIECE = 1024, SLAB = 2 * PIECE;
+
+uint32_t ncls_ascii(uint32_t c, bool lower_all) {
+  if (c - 'a' < 26u) return NC_L;
+  if (c - 'A' < 26u) return lower_all ? NC_L : NC_U;
+  if (c - '0' < 10u) return NC_N;
+  if (c == '\'') return NC_AP;
+  if (c == ' ') return NC_SP;
+  return NC_O;
+}
+bool npunct3(uint32_t b1, uint32_t b2) {
+  return (b1 == 0x80u && ((b2 >= 0x90u && b2 <= 0xA7u) || (b2 >= 0xB0u && b2 <= 0xBFu))) || (b1 == 0x81u && b2 >= 0x80u && b2 <= 0x9Eu);
+}
+// class byte of every byte of a document as norm_load_piece computes it (bytes outside the document read as 0)
+bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t>& f) {
+  const int n = (int)d.size();
+  auto at = [&](int i) -> uint32_t { return i >= 0 && i < n ? d[i] : 0u; };
+  f.assign(n, 0);
+  bool ok_all = true;
+  for (int i = 0; i < n; i++) {
+    const uint32_t b = d[i];
+    uint32_t fl;
+    if (b < 0x80u) fl = ncls_ascii(b, lower_all);
+    else {
+      const uint32_t m1 = at(i - 1), m2 = at(i - 2), p1 = at(i + 1), p2 = at(i + 2);
+      uint32_t b1 = 0, b2 = 0, cont = 0;
+      bool ok = false;
+      if (b == 0xE2u) { b1 = p1; b2 = p2; ok = true; }
+      else if (m1 == 0xE2u) { b1 = b; b2 = p1; cont = NF_CONT; ok = true; }
+      else if (m2 == 0xE2u) { b1 = m1; b2 = b; cont = NF_CONT; ok = true; }
+      ok = ok && npunct3(b1, b2);
+      fl = ok ? (((b1 == 0x80u && b2 == 0x99u) ? NC_AP : NC_O) | cont) : NF_BAD;
+    }
+    if (fl == NF_BAD) ok_all = false;
+    f[i] = (uint8_t)fl;
+  }
+  return ok_all;
+}
+bool is_block(uint32_t cls) { return (cls & NF_BLOCK) != 0; }
+
+// what k_norm_emit2 does for one piece: returns the bytes
+static const NmLut kLut = nm_make_lut();
+void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, int pb, int m, bool w_in, bool carry_tl, bool lower_all,
+                std::vector<uint8_t>& out) {
+  const int n = (int)d.size();
+  // class byte at piece-relative position rel, as the kernel's LDS holds it: classified from six bytes before the piece to five
+  // after its 1024; bytes outside the document read as class O
+  auto fat = [&](int rel) -> uint32_t {
+    const int p = pb + rel;
+    if (rel < -6 || rel > PIECE + 5) { fprintf(stderr, "harness: class byte %d outside the classified LDS range\n", rel); abort(); }
+    return (p < 0 || p >= n) ? (uint32_t)NC_O : (uint32_t)f[p];
+  };
+  auto ballot = [&](int c, auto pred) -> uint64_t {
+    uint64_t r = 0;
+    for (int i = 0; i < 64; i++) {
+      const int rel = 64 * c + i;
+      if (rel < -6 || rel > PIECE + 5) continue;             // lanes the kernel masks off
+      if (pred(fat(rel))) r |= 1ull << i;
+    }
+    return r;
+  };
+  auto is_b = [](uint32_t fl) { return (fl & NF_BLOCK) != 0; };
+  auto is_l = [](uint32_t fl) { return (fl & NF_CLASS) == NC_L; };
+  auto is_u = [](uint32_t fl) { return (fl & NF_CLASS) == NC_U; };
+  auto is_sp = [](uint32_t fl) { return (fl & NF_CLASS) == NC_SP; };
+  const int nch = (m + 63) / 64;
+  uint64_t TX[18] = {0};
+  {
+    uint64_t tx_next = (m % 64 == 0 && carry_tl) ? 1ull : 0ull, lx_next0 = tx_next;   // boundary exactly at the start of chunk nch
+    if (nch <= 16) TX[nch] = tx_next;
+    for (int c = nch - 1; c >= 0; c--) {
+      uint64_t lx0;
+      TX[c] = nm_backward(ballot(c, is_b), ballot(c, is_l), nm_valid(c, m), carry_tl ? nm_boundary(c, m) : 0ull, tx_next, lx_next0, &lx0);
+      tx_next = TX[c];
+      lx_next0 = lx0;
+    }
+  }
+  uint64_t w = w_in ? 1ull : 0ull;
+  uint64_t Ucur = ballot(0, is_u);
+  for (int c = 0; c < nch; c++) {
+    const uint64_t Unext = ballot(c + 1, is_u);
+    uint64_t w_out, spC, spW;
+    const uint64_t V = nm_valid(c, m);
+    const uint64_t W = nm_inword(ballot(c, is_b), Ucur, V, w, &w_out);
+    nm_space_markers(ballot(c, is_sp), Ucur, Unext, V, TX[c], TX[c + 1], &spC, &spW);
+    w = w_out;
+    for (int i = 0; i < 64; i++) {
+      const uint64_t bit = 1ull << i;
+      if (!(V & bit)) continue;
+      const int rel = 64 * c + i;
+      const uint32_t fl = fat(rel), fp = fat(rel - 1), f2 = fat(rel - 2), f4 = fat(rel - 4);
+      const uint32_t idx = nm_lut_index(fl, fp, (fp & NF_CONT) ? f4 : f2, (uint32_t)((W >> i) & 1ull), (uint32_t)((TX[c] >> i) & 1ull));
+      const uint32_t code = kLut.e[lower_all ? 1 : 0][idx];
+      const uint32_t len = (code & 3u) + 1u;
+      uint32_t o3 = d[pb + rel] | ((code & 4u) << 3);
+      if (spC & bit) o3 = 'C';
+      if (spW & bit) o3 = 'W';
+      if (len == 4) out.push_back('D');
+      if (len >= 3) out.push_back((uint8_t)(code >> 8));
+      if (len >= 2) out.push_back(' ');
+      out.push_back((uint8_t)o3);
+    }
+    Ucur = Unext;
+  }
+}
+
+bool check_doc(const std::vector<uint8_t>& d, uint32_t norm_flag, uint64_t* skipped) {
+  const bool lower_all = (norm_flag & 2u) != 0;
+  std::vector<uint8_t> f;
+  if (!classify(d, lower_all, f)) { (*skipped)++; return true; }     // host-fallback document on the device too
+  const int n = (int)d.size();
+  std::vector<uint8_t> got;
+  for (int pb = 0; pb < n; pb += PIECE) {
+    const int m = std::min(PIECE, n - pb);
+    bool w_in = false;
+    for (int j = pb - 1; j >= 0 && is_block(f[j] & 7u); j--) if ((f[j] & 7u) == NC_U) { w_in = true; break; }
+    bool carry_tl = false;
+    {
+      int j = pb + m;
+      while (j < n && is_block(f[j] & 7u)) j++;
+      carry_tl = j < n && (f[j] & 7u) == NC_L;
+    }
+    emit_piece(d, f, pb, m, w_in, carry_tl, lower_all, got);
+  }
+  uint8_t* exp = nullptr; size_t exp_n = 0;
+  if (tm_normalize(d.data(), d.size(), 2, norm_flag, &exp, &exp_n) != 0) { fprintf(stderr, "tm_normalize failed\n"); return false; }
+  const bool same = exp_n == got.size() && (exp_n == 0 || memcmp(exp, got.data(), exp_n) == 0);
+  if (!same) {
+    size_t k = 0;
+    while (k < exp_n && k < got.size() && exp[k] == got[k]) k++;
+    fprintf(stderr, "MISMATCH (flag %u, %zu bytes): expected %zu bytes, got %zu; first difference at output byte %zu\n  input : %.*s\n", norm_flag, d.size(),
+            exp_n, got.size(), k, (int)std::min<size_t>(d.size(), 200), (const char*)d.data());
+    const size_t a = k > 20 ? k - 20 : 0;
+    fprintf(stderr, "  expect: ...%.*s\n  got   : ...%.*s\n", (int)std::min<size_t>(exp_n - a, 60), (const char*)exp + a, (int)std::min<size_t>(got.size() - a, 60),
+            (const char*)got.data() + a);
+  }
+  tm_free(exp);
+  return same;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  const int ndocs = argc > 1 ? atoi(argv[1]) : 20000;
+  const uint64_t seed = argc > 2 ? strtoull(argv[2], nullptr, 10) : 1;
+  Rng rng(seed);
+  uint64_t bad = 0, skipped = 0, total = 0;
+  const char* ascii = "aBcDeFGhijKLMnop XYZ  '''1234567890.,-_()\n\tQ";
+  const char* multi[] = {"\xE2\x80\x99", "\xE2\x80\x9C", "\xE2\x80\x9D", "\xE2\x80\x94", "\xE2\x80\xA6", "\xE2\x81\x80"};
+  std::vector<std::string> fixed = {"", "A", "a", "AB", "Ab", "aB", "ABc", "ABC", " ABC d", "HTTPServer2Go x", "X's Y'S it's 'a' I'M", "12AB34cd", "A1B2c",
+                                    "X\xE2\x80\x99s Y\xE2\x80\x99S it\xE2\x80\x99s", std::string(200, 'A') + "b", std::string(200, 'A'),
+                                    "a" + std::string(130, 'B') + " " + std::string(70, 'C') + "d", std::string(3000, 'A') + "b", std::string(5000, 'Q'),
+                                    std::string(1023, 'x') + " Abc", std::string(1023, 'x') + "A" + "bc", std::string(1022, 'x') + " A" + std::string(1100, 'B') + "c",
+                                    std::string(1024, 'A') + std::string(1024, '1') + "z", std::string(1020, ' ') + "AB'\xE2\x80\x99" + "cD"};
+  for (int lower = 0; lower < 2; lower++) {
+    const uint32_t flag = lower ? 3u : 1u;
+    for (const auto& s : fixed) { std::vector<uint8_t> d(s.begin(), s.end()); total++; if (!check_doc(d, flag, &skipped)) bad++; }
+    for (int k = 0; k < ndocs; k++) {
+      // lengths cluster around the piece and chunk boundaries
+      const uint32_t mode = rng.below(4);
+      size_t len = mode == 0 ? rng.below(200) : mode == 1 ? 1024u * (1 + rng.below(3)) - 40 + rng.below(80) : mode == 2 ? 64u * (1 + rng.below(40)) - 4 + rng.below(8) : rng.below(5000);
+      std::vector<uint8_t> d;
+      const uint32_t style = rng.below(5);      // 0 mixed, 1 capitals-heavy, 2 digits/apostrophes-heavy, 3 spaces + capitals, 4 long runs
+      while (d.size() < len) {
+        const uint32_t r = rng.below(100);
+        if (style == 4 && r < 30) { const char ch = "AB1'a "[rng.below(6)]; const uint32_t rep = 1 + rng.below(150); for (uint32_t q = 0; q < rep; q++) d.push_back((uint8_t)ch); continue; }
+        if (r < 4) { const char* mchar = multi[rng.below(6)]; d.insert(d.end(), mchar, mchar + 3); continue; }
+        if (style == 1 && r < 60) { d.push_back((uint8_t)('A' + rng.below(26))); continue; }
+        if (style == 2 && r < 60) { d.push_back((uint8_t)("0123456789''"[rng.below(12)])); continue; }
+        if (style == 3 && r < 50) { d.push_back(rng.below(2) ? ' ' : (uint8_t)('A' + rng.below(26))); continue; }
+        d.push_back((uint8_t)ascii[rng.below((uint32_t)strlen(ascii))]);
+      }
+      total++;
+      if (!check_doc(d, flag, &skipped)) { bad++; if (bad > 5) break; }
+    }
+  }
+  // documents of the synthetic bench corpus
+  {
+    std::vector<uint8_t> raw((4u << 20) + 70000);
+    std::vector<uint64_t> off(70000);
+    uint32_t nd = 0; uint64_t nb = 0;
+    tm_synth_corpus(TM_KIND_ENGLISHCODE, 99, 4u << 20, 2048, raw.data(), off.data(), (uint32_t)off.size() - 1, &nd, &nb);
+    for (uint32_t k = 0; k < nd && bad <= 5; k++) {
+      std::vector<uint8_t> d(raw.begin() + off[k], raw.begin() + off[k + 1]);
+      total++;
+      if (!check_doc(d, 1, &skipped)) bad++;
+    }
+  }
+  printf("%llu documents, %llu skipped (host-fallback class), %llu mismatches\n", (unsigned long long)total, (unsigned long long)skipped, (unsigned long long)bad);
+  return bad ? 1 : 0;
+}
