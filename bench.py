@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--hot-path-only", action="store_true", help="input = host-normalized bytes; time only the tokenize pipeline")
     ap.add_argument("--cpu-sample-mb", type=float, default=64.0)
     ap.add_argument("--verify", type=int, default=64, help="documents re-checked against the oracle after timing (rank 0)")
+    ap.add_argument("--also-flags", default="", help="development aid: comma separated tm_debug_flags values; the same step is timed again under each "
+                                                      "(kernel variants) and reported on stderr, its ids compared with the default's")
     return ap.parse_args()
 
 
@@ -329,6 +331,35 @@ def main():
             if got.size != exp.size or (got != exp).any() or m != int(miss[d]):
                 raise SystemExit("bench.py: HIP ids differ from the oracle in document %d - number is INVALID" % d)
             verified += 1
+
+    if args.also_flags and rank == 0:
+        cap = int(ntok.value)
+        ref_ids = np.empty(max(cap, 1), dtype=np.uint32)
+        ref_toff = np.empty(ndocs + 1, dtype=np.uint64)
+        N.check(N.lib.tm_batch_download(batch, N.ptr(ref_ids), cap, N.ptr(ref_toff), None))
+        for f in [int(x) for x in args.also_flags.split(",") if x.strip()]:
+            old = N.lib.tm_debug_flags(f)
+            try:
+                step()
+                torch.cuda.synchronize()
+                tv = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                dtv = (time.perf_counter() - tv) / args.steps
+                N.check(N.lib.tm_batch_run_timed(batch, C.c_void_p(stream), ms))
+                ids2 = np.empty(max(cap, 1), dtype=np.uint32)
+                toff2 = np.empty(ndocs + 1, dtype=np.uint64)
+                nt2 = C.c_uint64()
+                N.check(N.lib.tm_batch_totals(batch, C.byref(nt2), None))
+                same = nt2.value == ntok.value
+                if same:
+                    N.check(N.lib.tm_batch_download(batch, N.ptr(ids2), cap, N.ptr(toff2), None))
+                    same = bool((toff2 == ref_toff).all() and (ids2[:cap] == ref_ids[:cap]).all())
+                log("variant flags=%d: %.3f ms/step = %.2f GB/s raw, kernels %s, ids %s the default's" % (
+                    f, dtv * 1e3, raw_bytes / dtv / 1e9, {n: round(float(v), 3) for n, v in zip(names, list(ms))}, "EQUAL" if same else "DIFFER FROM"))
+            finally:
+                N.lib.tm_debug_flags(old)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -222,13 +222,28 @@ def test_device_normalizer_matches_host_and_reference():
               "X’s Y’S it’s".encode(), b"A" * 200 + b"b", b"A" * 200, b"a" + b"B" * 130 + b" " + b"C" * 70 + b"d", "café Über".encode(),
               b"A" * 3000 + b"b", b"xY" * 2500, b"Q" * 5000,          # expand beyond a piece's 2 KiB slab: exact two-pass path
               b"\xff\xfe bad bytes", "  en quad".encode()]
+    # documents whose capital / digit / apostrophe runs straddle the 64-byte chunks and 1 KiB pieces of the device pass
+    for n in (60, 63, 64, 65, 1020, 1023, 1024, 1025, 2047, 2048, 2049):
+        extra += [b"x" * n + b" Abc " + b"DEF'S 12a", b"x" * (n - 2) + b"AB" + b"C" * 70 + b"d", b"x" * (n - 1) + b" " + b"Q" * 130,
+                  b"y" * (n - 3) + "I’M".encode() + b" OK", b"1" * n + b"a", b"z" * n + b" " + b"A" * 1100 + b"b"]
     etext, eoffs = tm.pack_documents(extra)
-    for text_in, offs_in in ((raw, offs), (etext, eoffs)):
-        got, goff, nfb = v.normalize_packed_device(text_in, offs_in)
-        exp, eoff = synth.normalize_batch(text_in, offs_in, 2, 1)
-        assert (goff == eoff).all()
-        assert got.size == exp.size and (got == exp).all()
-        assert nfb < (offs_in.size - 1) // 5 + 8          # most documents are handled on the device
+    from tokenmonster_amd import _native as N
+    for flags in (0, 256):       # debug bit 8: the per-lane kernel (k_norm_emit<2>) instead of k_norm_emit2
+        old = N.lib.tm_debug_flags(flags)
+        try:
+            for text_in, offs_in in ((raw, offs), (etext, eoffs)):
+                got, goff, nfb = v.normalize_packed_device(text_in, offs_in)
+                exp, eoff = synth.normalize_batch(text_in, offs_in, 2, 1)
+                assert (goff == eoff).all(), "flags %d" % flags
+                assert got.size == exp.size and (got == exp).all(), "flags %d" % flags
+                assert nfb < (offs_in.size - 1) // 5 + 8          # most documents are handled on the device
+        finally:
+            N.lib.tm_debug_flags(old)
+    # lower-case-everything flag with capcode 2 (capitals are classified as letters)
+    img3 = synth.synth_vocab(synth.ENGLISHCODE, 1200, capcode=2, norm_flag=3, level=3, seed=7)
+    got3, goff3, _ = tm.Vocab(img3).normalize_packed_device(etext, eoffs)
+    exp3, eoff3 = synth.normalize_batch(etext, eoffs, 2, 3)
+    assert (goff3 == eoff3).all() and got3.size == exp3.size and (got3 == exp3).all()
     if have_ref():
         ref = Reference(img)
         for d in range(0, len(extra), 37):
