@@ -919,105 +919,163 @@ __global__ __launch_bounds__(WV * 64) void k_chain(const uint32_t* __restrict__ 
   }
 }
 
-// K4, emitting variant: one LANE per segment follows the chain from the segment's true entry state and writes the ids as it
-// goes.  The parallel ranking above spends ~500 vector instructions per segment to rank 512 states of which ~57 are on the
-// chain; here a wavefront spends ~15 per hop for 64 segments at once (~13 per segment) and the kernel is bound by the
-// dependent loads instead — of which hundreds of thousands are in flight on the chip, one per lane.  Every 128-byte line of
-// T(p,0) is still read once from HBM (a chain touches all of them), the hops after the first hit it in L2.
+// K4 as a chain walk through LDS tiles.  The parallel ranking above spends ~500 vector instructions per segment to rank 512
+// states of which ~60 are on the chain.  Here a wavefront takes TS consecutive segments: their T(p,0) words are streamed into LDS
+// with full-width 16-byte loads, then lane s simply follows the chain of segment s through its tile (one dependent LDS read and
+// ~15 instructions per token, for 16 segments at once), and because consecutive segments write consecutive ranges of the output
+// stream, the ids are staged in LDS at their final relative position and leave in coalesced stores.
 // (p,1) states are rare: their words are looked up in the segment's side list (or the dense array) when one is entered.
-__global__ __launch_bounds__(256) void k_emit_chase(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
-                                                    const uint32_t* __restrict__ R1, const uint64_t* __restrict__ doc_begin,
-                                                    const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ seg_doc,
-                                                    const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
-                                                    const uint8_t* __restrict__ seg_entry, const uint32_t* __restrict__ seg_tokbase,
-                                                    const uint64_t* __restrict__ tok_offsets, uint32_t delete_id, uint64_t out_cap,
-                                                    uint32_t* __restrict__ out, uint32_t* __restrict__ error_flag) {
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= nseg) return;
-  const uint32_t doc = seg_doc[g];
-  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
-  const uint64_t rem = doc_end[doc] - begin;
-  const uint32_t seglen = rem > (uint64_t)SEG ? (uint32_t)SEG : (uint32_t)rem;
-  const uint32_t e = seg_entry[g];
-  uint32_t p = e >> 1, fd = e & 1u;
-  uint64_t o = tok_offsets[doc] + seg_tokbase[g];
-  const uint32_t* __restrict__ r0 = R0 + begin;
-  const uint2* __restrict__ sl = side + g * SIDE_STRIDE;
-  for (int hop = 0; hop < 2 * SEG && p < seglen; hop++) {
-    uint32_t w;
-    if (fd == 0) w = r0[p];
-    else {
-      const uint32_t nside = sl[0].x;
-      w = R_INVALID;
-      if (nside == SIDE_DENSE) w = R1[begin + p];
-      else for (uint32_t k = 1; k <= nside && k < (uint32_t)SIDE_STRIDE; k++) { const uint2 sv = sl[k]; if (sv.x == p) w = sv.y; }
+// (Letting every lane walk its segment straight from HBM — no tiles — was measured at 8.5 ms per GiB against 5.5 for the
+// ranking kernel: ~0.6 G scattered 4-byte accesses cost ~8 cycles each per CU.)
+constexpr int TS = 16;                  // segments per wavefront
+constexpr int TROW = SEG + 4;           // words per tile row (16-byte multiple; the 4 spread the rows over the LDS banks)
+constexpr int TOUT = 2048;              // ids staged per wavefront (a tile with more falls back to direct stores)
+struct TileSegs {                       // the tile's segments, one per lane (lanes >= TS and segments >= nseg: have == false)
+  bool have; uint64_t begin, base, end; uint32_t seglen, entry;
+};
+__device__ __forceinline__ TileSegs tile_segments(uint64_t g, bool lane_ok, uint64_t nseg, const uint64_t* __restrict__ doc_begin,
+                                                  const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ seg_doc,
+                                                  const uint64_t* __restrict__ doc_seg_start, const uint8_t* __restrict__ seg_entry,
+                                                  const uint32_t* __restrict__ seg_tokbase, const uint64_t* __restrict__ tok_offsets) {
+  TileSegs t{lane_ok && g < nseg, 0, 0, 0, 0, 0};
+  if (t.have) {
+    const uint32_t doc = seg_doc[g];
+    t.begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
+    const uint64_t rem = doc_end[doc] - t.begin;
+    t.seglen = rem > (uint64_t)SEG ? (uint32_t)SEG : (uint32_t)rem;
+    t.entry = seg_entry[g];
+    if (tok_offsets) {
+      // the output stream is contiguous over segments in order: segment g owns [base, end), end = base of the next segment
+      t.base = tok_offsets[doc] + seg_tokbase[g];
+      t.end = (g + 1 < nseg && seg_doc[g + 1] == doc) ? tok_offsets[doc] + seg_tokbase[g + 1] : tok_offsets[doc + 1];
     }
-    const uint32_t adv = (w >> 24) & 63u;
-    if (w == R_INVALID || adv == 0) { atomicOr(error_flag, 2u); break; }   // cannot happen on a chain K1/K3 produced
-    const uint32_t id = w & ID_NONE;
-    fd = (w >> 30) & 1u;
-    if (id != ID_NONE) { if (o < out_cap) out[o] = id; o++; }
-    if (fd) { if (o < out_cap) out[o] = delete_id; o++; }
-    p += adv;
+  }
+  return t;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+  return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32);
+}
+// stream the T(p,0) words of the tile's segments into LDS, position p of segment s at tile[s][p]: lane l fetches words 4l..4l+3
+// of a row with one 16-byte load (R0 + begin is only 4-byte aligned: gfx950 global loads do not ask for more).  All loads are
+// issued before the first LDS write, so a tile costs one HBM latency, not sixteen.
+__device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSegs& t, int nv, int lane, const uint32_t* __restrict__ R0) {
+  uint4 v[TS];
+#pragma unroll
+  for (int s = 0; s < TS; s++) {
+    const int ss = s < nv ? s : nv - 1;                                // rows beyond the last segment: nothing is fetched
+    const uint64_t b = shfl_u64(t.begin, ss);
+    const uint32_t need = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;
+    v[s] = make_uint4(0u, 0u, 0u, 0u);
+    if (4u * (uint32_t)lane < need) __builtin_memcpy(&v[s], R0 + b + 4 * lane, 16);   // at most 3 words past the segment: R0 has 64 of slack
+  }
+#pragma unroll
+  for (int s = 0; s < TS; s++) *reinterpret_cast<uint4*>(&tile[s][4 * lane]) = v[s];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+}
+// T(p,1) of a segment: from its side list, or from the dense array when the list overflowed
+__device__ __forceinline__ uint32_t side_word(const uint2* __restrict__ sl, const uint32_t* __restrict__ R1, uint64_t begin, uint32_t p) {
+  const uint32_t nside = sl[0].x;
+  if (nside == SIDE_DENSE) return R1[begin + p];
+  uint32_t w = R_INVALID;
+  for (uint32_t k = 1; k <= nside && k < (uint32_t)SIDE_STRIDE; k++) { const uint2 sv = sl[k]; if (sv.x == p) w = sv.y; }
+  return w;
+}
+
+struct TileLds { alignas(16) uint32_t r[TS][TROW]; uint32_t out[TOUT]; };
+
+__global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
+                                                   const uint32_t* __restrict__ R1, const uint64_t* __restrict__ doc_begin,
+                                                   const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ seg_doc,
+                                                   const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
+                                                   const uint8_t* __restrict__ seg_entry, const uint32_t* __restrict__ seg_tokbase,
+                                                   const uint64_t* __restrict__ tok_offsets, uint32_t delete_id, uint64_t out_cap,
+                                                   uint32_t* __restrict__ out, uint32_t* __restrict__ error_flag) {
+  __shared__ TileLds L;
+  const int lane = threadIdx.x;
+  const uint64_t g0 = (uint64_t)blockIdx.x * TS;
+  const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
+  const TileSegs t = tile_segments(g0 + lane, lane < TS, nseg, doc_begin, doc_end, seg_doc, doc_seg_start, seg_entry, seg_tokbase, tok_offsets);
+  tile_load(L.r, t, nv, lane, R0);
+  const uint64_t base0 = shfl_u64(t.base, 0), end_last = shfl_u64(t.end, nv - 1);
+  const bool staged = end_last >= base0 && end_last - base0 <= (uint64_t)TOUT;      // (anything else: an inconsistent batch, or > 128 ids per segment)
+  if (t.have) {
+    uint32_t p = t.entry >> 1, fd = t.entry & 1u;
+    uint64_t o = staged ? t.base - base0 : t.base;
+    const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
+    int hop = 0;
+    for (; hop <= 2 * SEG && p < t.seglen; hop++) {                   // a chain visits a state (p, fd) at most once
+      const uint32_t w = fd == 0 ? L.r[lane][p] : side_word(sl, R1, t.begin, p);
+      if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }         // cannot happen on a chain K1/K3 produced
+      const uint32_t id = w & ID_NONE;
+      fd = (w >> 30) & 1u;
+      if (id != ID_NONE) { if (staged) { if (o < (uint64_t)TOUT) L.out[o] = id; } else if (o < out_cap) out[o] = id; o++; }
+      if (fd) { if (staged) { if (o < (uint64_t)TOUT) L.out[o] = delete_id; } else if (o < out_cap) out[o] = delete_id; o++; }
+      p += (w >> 24) & 63u;                                            // (0 is possible: a one-byte alternative of a forward-delete state)
+    }
+    if (hop > 2 * SEG) atomicOr(error_flag, 2u);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  if (staged) {
+    const uint32_t total = (uint32_t)(end_last - base0);
+    for (uint32_t j = (uint32_t)lane; j < total; j += 64u) { const uint64_t o = base0 + j; if (o < out_cap) out[o] = L.out[j]; }
   }
 }
 
-// K4, scoring variant of the chase (training/trainvocab.go:1105-1174): persistent workgroups as in k_chain<true> (the
-// LDS-privatised histogram is what keeps the hot ids off the L2 atomics), every lane follows the chains of its segments.
+// K4, scoring variant of the tile walk (training/trainvocab.go:1105-1174): persistent workgroups as in k_chain<true> (the
+// LDS-privatised histogram is what keeps the hot ids off the L2 atomics), every wavefront walks tiles of TS segments.
 template <int WV>
-__global__ __launch_bounds__(WV * 64) void k_score_chase(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
+__global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
                                                         const uint32_t* __restrict__ R1, const uint8_t* __restrict__ text,
                                                         const uint64_t* __restrict__ doc_begin, const uint64_t* __restrict__ doc_end,
                                                         const uint32_t* __restrict__ seg_doc, const uint64_t* __restrict__ doc_seg_start,
                                                         uint64_t nseg, const uint8_t* __restrict__ seg_entry, uint32_t delete_id,
                                                         uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
                                                         uint32_t* __restrict__ missing_bits, uint32_t* __restrict__ error_flag) {
+  __shared__ alignas(16) uint32_t s_tile[WV][TS][TROW];
   __shared__ uint32_t s_tag[HSLOTS], s_cnt[HSLOTS];
   __shared__ unsigned long long s_ntok;
   __shared__ uint32_t s_ndel;
   for (int j = threadIdx.x; j < HSLOTS; j += WV * 64) { s_tag[j] = 0xFFFFFFFFu; s_cnt[j] = 0; }
   if (threadIdx.x == 0) { s_ntok = 0; s_ndel = 0; }
   __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t ntok = 0, ndel = 0;
-  for (uint64_t g = (uint64_t)blockIdx.x * (WV * 64) + threadIdx.x; g < nseg; g += (uint64_t)gridDim.x * (WV * 64)) {
-    const uint32_t doc = seg_doc[g];
-    const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
-    const uint64_t rem = doc_end[doc] - begin;
-    const uint32_t seglen = rem > (uint64_t)SEG ? (uint32_t)SEG : (uint32_t)rem;
-    const uint32_t e = seg_entry[g];
-    uint32_t p = e >> 1, fd = e & 1u;
-    const uint32_t* __restrict__ r0 = R0 + begin;
-    const uint2* __restrict__ sl = side + g * SIDE_STRIDE;
-    for (int hop = 0; hop < 2 * SEG && p < seglen; hop++) {
-      uint32_t w;
-      if (fd == 0) w = r0[p];
-      else {
-        const uint32_t nside = sl[0].x;
-        w = R_INVALID;
-        if (nside == SIDE_DENSE) w = R1[begin + p];
-        else for (uint32_t k = 1; k <= nside && k < (uint32_t)SIDE_STRIDE; k++) { const uint2 sv = sl[k]; if (sv.x == p) w = sv.y; }
+  for (uint64_t g0 = ((uint64_t)blockIdx.x * WV + wv) * TS; g0 < nseg; g0 += (uint64_t)gridDim.x * WV * TS) {
+    const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
+    const TileSegs t = tile_segments(g0 + lane, lane < TS, nseg, doc_begin, doc_end, seg_doc, doc_seg_start, seg_entry, nullptr, nullptr);
+    tile_load(s_tile[wv], t, nv, lane, R0);
+    if (t.have) {
+      uint32_t p = t.entry >> 1, fd = t.entry & 1u;
+      const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
+      int hop = 0;
+      for (; hop <= 2 * SEG && p < t.seglen; hop++) {
+        const uint32_t w = fd == 0 ? s_tile[wv][lane][p] : side_word(sl, R1, t.begin, p);
+        if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }
+        const uint32_t id = w & ID_NONE, adv = (w >> 24) & 63u;
+        fd = (w >> 30) & 1u;
+        if (w >> 31) {                                       // trainvocab.go:1166-1173: no token for this byte
+          const uint32_t byte = text[t.begin + p];
+          atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
+        } else {                                             // scores[id] += bytes covered (:1109..1162)
+          const uint32_t slot = id & (HSLOTS - 1);
+          uint32_t owner = s_tag[slot];
+          if (owner == 0xFFFFFFFFu) { owner = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, id); if (owner == 0xFFFFFFFFu) owner = id; }
+          if (owner == id) atomicAdd(&s_cnt[slot], adv);
+          else atomicAdd(&scores[id], adv);
+        }
+        ntok += 1 + fd;                                      // tokensInText++ (also for a missing byte, :1169) / += 2
+        ndel += fd;                                          // scores[deleteToken]++ (:1134,1143,1152)
+        p += adv;
       }
-      const uint32_t adv = (w >> 24) & 63u;
-      if (w == R_INVALID || adv == 0) { atomicOr(error_flag, 2u); break; }
-      const uint32_t id = w & ID_NONE;
-      fd = (w >> 30) & 1u;
-      if (w >> 31) {                                       // trainvocab.go:1166-1173: no token for this byte
-        const uint32_t byte = text[begin + p];
-        atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
-      } else {                                             // scores[id] += bytes covered (:1109..1162)
-        const uint32_t slot = id & (HSLOTS - 1);
-        uint32_t owner = s_tag[slot];
-        if (owner == 0xFFFFFFFFu) { owner = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, id); if (owner == 0xFFFFFFFFu) owner = id; }
-        if (owner == id) atomicAdd(&s_cnt[slot], adv);
-        else atomicAdd(&scores[id], adv);
-      }
-      ntok += 1 + fd;                                      // tokensInText++ (also for a missing byte, :1169) / += 2
-      ndel += fd;                                          // scores[deleteToken]++ (:1134,1143,1152)
-      p += adv;
+      if (hop > 2 * SEG) atomicOr(error_flag, 2u);
     }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
   }
   for (int o = 32; o > 0; o >>= 1) { ntok += __shfl_xor(ntok, o); ndel += __shfl_xor(ndel, o); }
-  if ((threadIdx.x & 63) == 0) {
+  if (lane == 0) {
     if (ndel) atomicAdd(&s_ndel, ndel);
     if (ntok) atomicAdd(&s_ntok, (unsigned long long)ntok);
   }
@@ -1087,7 +1145,7 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
                        uint32_t n_ids, hipStream_t st) {
   const uint64_t nseg = b->nseg;
   if (nseg > 0 && !(debug_flags() & 128))
-    k_score_chase<16><<<(uint32_t)std::min<uint64_t>((nseg + 1023) / 1024, (uint64_t)n_cu), 1024, 0, st>>>(
+    k_score_tiles<5><<<(uint32_t)std::min<uint64_t>((nseg + 5 * TS - 1) / (5 * TS), (uint64_t)n_cu), 5 * 64, 0, st>>>(
         b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry, delete_id, d_hist, d_tokens,
         d_missing_bits, b->d_error);
   else if (nseg > 0)
@@ -1097,8 +1155,7 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
   k_hist_finish<<<1, 256, 0, st>>>(d_tokens, d_missing_bits, d_hist + n_ids);
 }
 
-// K4 for the id-emitting entry points: the lane-per-segment chase; debug bit 7 selects the list-ranking kernel instead
-// (the scoring pass always uses the latter, its histogram lives in the LDS of persistent workgroups)
+// K4 for the id-emitting entry points: the tile walk; debug bit 7 selects the list-ranking kernel instead
 static void launch_emit(tm_batch* b, hipStream_t st) {
   const uint64_t nseg = b->nseg;
   if (debug_flags() & 128)
@@ -1106,9 +1163,9 @@ static void launch_emit(tm_batch* b, hipStream_t st) {
                                                                nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, b->vocab->tables.delete_id,
                                                                b->out_cap, b->d_out, nullptr, nullptr, nullptr);
   else
-    k_emit_chase<<<(uint32_t)((nseg + 255) / 256), 256, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg,
-                                                                b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, b->vocab->tables.delete_id, b->out_cap,
-                                                                b->d_out, b->d_error);
+    k_emit_tiles<<<(uint32_t)((nseg + TS - 1) / TS), 64, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg,
+                                                                 b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, b->vocab->tables.delete_id, b->out_cap,
+                                                                 b->d_out, b->d_error);
 }
 
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {

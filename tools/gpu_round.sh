@@ -12,3 +12,7 @@ echo "bench exit $?" >> $OUT/bench_e2e_1g.err
 tail -15 $OUT/pytest_gpu.log
 cat $OUT/bench_e2e_1g.json
 grep -E "variant|exit|normalize|INVALID|Error|error" $OUT/bench_e2e_1g.err | tail -20
+# per-kernel times of the same step (rocprofv3 kernel trace)
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/stats_e2e -o e2e --output-format csv -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --verify 0 > $OLDPWD/$OUT/bench_under_rocprof.json 2> $OLDPWD/$OUT/stats_e2e.err)
+f=$(find $OUT/stats_e2e -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cut -d, -f1-4 "$f" | cut -c1-60,200- | head -14
