@@ -921,55 +921,73 @@ __global__ __launch_bounds__(WV * 64) void k_chain(const uint32_t* __restrict__ 
 
 // K4 as a chain walk through LDS tiles.  The parallel ranking above spends ~500 vector instructions per segment to rank 512
 // states of which ~60 are on the chain.  Here a wavefront takes TS consecutive segments: their T(p,0) words are streamed into LDS
-// with full-width 16-byte loads, then lane s simply follows the chain of segment s through its tile (one dependent LDS read and
-// ~15 instructions per token, for 16 segments at once), and because consecutive segments write consecutive ranges of the output
-// stream, the ids are staged in LDS at their final relative position and leave in coalesced stores.
+// with full-width 16-byte loads, then lane s simply follows the chain of segment s through its row (one dependent LDS read and
+// ~15 instructions per token, for 16 segments at once).  The ids are staged in the part of the row the walk has already left
+// and leave in coalesced stores.  The kernel is bound by the latency of the walk, i.e. by how many rows fit the LDS of a CU.
 // (p,1) states are rare: their words are looked up in the segment's side list (or the dense array) when one is entered.
 // (Letting every lane walk its segment straight from HBM — no tiles — was measured at 8.5 ms per GiB against 5.5 for the
 // ranking kernel: ~0.6 G scattered 4-byte accesses cost ~8 cycles each per CU.)
 constexpr int TS = 16;                  // segments per wavefront
-constexpr int TROW = SEG + 4;           // words per tile row (16-byte multiple; the 4 spread the rows over the LDS banks)
-constexpr int TOUT = 2048;              // ids staged per wavefront (a tile with more falls back to direct stores)
-struct TileSegs {                       // the tile's segments, one per lane (lanes >= TS and segments >= nseg: have == false)
-  bool have; uint64_t begin, base, end; uint32_t seglen, entry;
-};
-__device__ __forceinline__ TileSegs tile_segments(uint64_t g, bool lane_ok, uint64_t nseg, const uint64_t* __restrict__ doc_begin,
-                                                  const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ seg_doc,
-                                                  const uint64_t* __restrict__ doc_seg_start, const uint8_t* __restrict__ seg_entry,
-                                                  const uint32_t* __restrict__ seg_tokbase, const uint64_t* __restrict__ tok_offsets) {
-  TileSegs t{lane_ok && g < nseg, 0, 0, 0, 0, 0};
+constexpr int TSLACK = 2;               // position p of a row is word TSLACK + p: the two ids of a first token fit in front of it
+constexpr int TROW = SEG + 8;           // words per tile row (16-byte multiple; the odd multiple of 8 spreads the rows over the LDS banks)
+
+// k_seg_params: everything K4 needs to know about a segment in one 16-byte record, so that a tile starts with ONE round of loads
+// instead of a chain of three (segment -> document -> offsets):
+//   x = begin[0..31]   y = begin[32..39] | seglen << 8 (9 bits) | entry state << 20 (7 bits)   z, w = first output index (64 bit)
+// Record nseg holds the end of the output stream.
+__global__ void k_seg_params(const uint64_t* __restrict__ doc_begin, const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ seg_doc,
+                             const uint64_t* __restrict__ doc_seg_start, uint64_t nseg, uint32_t ndocs, const uint8_t* __restrict__ seg_entry,
+                             const uint32_t* __restrict__ seg_tokbase, const uint64_t* __restrict__ tok_offsets, uint4* __restrict__ par) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > nseg) return;
+  if (g == nseg) { const uint64_t total = tok_offsets[ndocs]; par[g] = make_uint4(0u, 0u, (uint32_t)total, (uint32_t)(total >> 32)); return; }
+  const uint32_t doc = seg_doc[g];
+  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
+  const uint64_t rem = doc_end[doc] - begin;
+  const uint32_t seglen = rem > (uint64_t)SEG ? (uint32_t)SEG : (uint32_t)rem;
+  const uint64_t base = tok_offsets[doc] + seg_tokbase[g];
+  par[g] = make_uint4((uint32_t)begin, (uint32_t)((begin >> 32) & 0xFFu) | (seglen << 8) | ((uint32_t)seg_entry[g] << 20), (uint32_t)base, (uint32_t)(base >> 32));
+}
+
+struct TileSeg { bool have; uint64_t begin, base; uint32_t seglen, entry; };   // one segment of the tile per lane (lanes >= TS: have == false)
+__device__ __forceinline__ TileSeg tile_segment(const uint4* __restrict__ par, uint64_t g, bool lane_ok, uint64_t nseg) {
+  TileSeg t{lane_ok && g < nseg, 0, 0, 0, 0};
   if (t.have) {
-    const uint32_t doc = seg_doc[g];
-    t.begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
-    const uint64_t rem = doc_end[doc] - t.begin;
-    t.seglen = rem > (uint64_t)SEG ? (uint32_t)SEG : (uint32_t)rem;
-    t.entry = seg_entry[g];
-    if (tok_offsets) {
-      // the output stream is contiguous over segments in order: segment g owns [base, end), end = base of the next segment
-      t.base = tok_offsets[doc] + seg_tokbase[g];
-      t.end = (g + 1 < nseg && seg_doc[g + 1] == doc) ? tok_offsets[doc] + seg_tokbase[g + 1] : tok_offsets[doc + 1];
-    }
+    const uint4 q = par[g];
+    t.begin = (uint64_t)q.x | ((uint64_t)(q.y & 0xFFu) << 32);
+    t.seglen = (q.y >> 8) & 0x1FFu;
+    t.entry = (q.y >> 20) & 0x7Fu;
+    t.base = (uint64_t)q.z | ((uint64_t)q.w << 32);
   }
   return t;
 }
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
   return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32);
 }
-// stream the T(p,0) words of the tile's segments into LDS, position p of segment s at tile[s][p]: lane l fetches words 4l..4l+3
-// of a row with one 16-byte load (R0 + begin is only 4-byte aligned: gfx950 global loads do not ask for more).  All loads are
-// issued before the first LDS write, so a tile costs one HBM latency, not sixteen.
-__device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSegs& t, int nv, int lane, const uint32_t* __restrict__ R0) {
+// stream the T(p,0) words of the tile's segments into LDS, position p of segment s at tile[s][TSLACK + p]: lane l fetches words
+// 4l..4l+3 of a row with one 16-byte load (R0 + begin is only 4-byte aligned: gfx950 global loads do not ask for more).  All
+// loads are issued before the first LDS write, so a tile costs one HBM latency, not sixteen.
+__device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg& t, int nv, int lane, const uint32_t* __restrict__ R0) {
   uint4 v[TS];
+  const uint32_t* src[TS];
+  bool want[TS];
 #pragma unroll
   for (int s = 0; s < TS; s++) {
     const int ss = s < nv ? s : nv - 1;                                // rows beyond the last segment: nothing is fetched
-    const uint64_t b = shfl_u64(t.begin, ss);
-    const uint32_t need = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;
-    v[s] = make_uint4(0u, 0u, 0u, 0u);
-    if (4u * (uint32_t)lane < need) __builtin_memcpy(&v[s], R0 + b + 4 * lane, 16);   // at most 3 words past the segment: R0 has 64 of slack
+    src[s] = R0 + shfl_u64(t.begin, ss) + 4 * lane;
+    want[s] = s < nv && 4u * (uint32_t)lane < (uint32_t)__shfl((int)t.seglen, ss);   // at most 3 words past the segment: R0 has 64 of slack
   }
 #pragma unroll
-  for (int s = 0; s < TS; s++) *reinterpret_cast<uint4*>(&tile[s][4 * lane]) = v[s];
+  for (int s = 0; s < TS; s++) {
+    v[s] = make_uint4(0u, 0u, 0u, 0u);
+    if (want[s]) __builtin_memcpy(&v[s], src[s], 16);
+  }
+#pragma unroll
+  for (int s = 0; s < TS; s++) {                                       // TSLACK = 2: the row is 8-byte, not 16-byte, aligned
+    uint2* dst = reinterpret_cast<uint2*>(&tile[s][TSLACK + 4 * lane]);
+    dst[0] = make_uint2(v[s].x, v[s].y);
+    dst[1] = make_uint2(v[s].z, v[s].w);
+  }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
 }
@@ -982,44 +1000,49 @@ __device__ __forceinline__ uint32_t side_word(const uint2* __restrict__ sl, cons
   return w;
 }
 
-struct TileLds { alignas(16) uint32_t r[TS][TROW]; uint32_t out[TOUT]; };
-
 __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
-                                                   const uint32_t* __restrict__ R1, const uint64_t* __restrict__ doc_begin,
-                                                   const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ seg_doc,
-                                                   const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
-                                                   const uint8_t* __restrict__ seg_entry, const uint32_t* __restrict__ seg_tokbase,
-                                                   const uint64_t* __restrict__ tok_offsets, uint32_t delete_id, uint64_t out_cap,
-                                                   uint32_t* __restrict__ out, uint32_t* __restrict__ error_flag) {
-  __shared__ TileLds L;
+                                                   const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
+                                                   uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
+                                                   uint32_t* __restrict__ error_flag) {
+  __shared__ alignas(16) uint32_t s_tile[TS][TROW];
   const int lane = threadIdx.x;
   const uint64_t g0 = (uint64_t)blockIdx.x * TS;
   const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
-  const TileSegs t = tile_segments(g0 + lane, lane < TS, nseg, doc_begin, doc_end, seg_doc, doc_seg_start, seg_entry, seg_tokbase, tok_offsets);
-  tile_load(L.r, t, nv, lane, R0);
-  const uint64_t base0 = shfl_u64(t.base, 0), end_last = shfl_u64(t.end, nv - 1);
-  const bool staged = end_last >= base0 && end_last - base0 <= (uint64_t)TOUT;      // (anything else: an inconsistent batch, or > 128 ids per segment)
+  const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
+  tile_load(s_tile, t, nv, lane, R0);
+  // Walk.  Id number E of the segment is staged in word E of its own row while that word lies before the position being read
+  // (E < TSLACK + p: true unless the text averages more than one id per byte); from the first id that does not fit, the rest of
+  // the segment's ids go straight to HBM.
+  uint32_t staged = 0;
   if (t.have) {
-    uint32_t p = t.entry >> 1, fd = t.entry & 1u;
-    uint64_t o = staged ? t.base - base0 : t.base;
+    uint32_t* row = s_tile[lane];
+    uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0;
+    bool direct = false;
     const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
+    auto put = [&](uint32_t id) {
+      if (!direct && E < (uint32_t)TSLACK + p) { row[E] = id; staged = E + 1; }
+      else { direct = true; if (t.base + E < out_cap) out[t.base + E] = id; }
+      E++;
+    };
     int hop = 0;
     for (; hop <= 2 * SEG && p < t.seglen; hop++) {                   // a chain visits a state (p, fd) at most once
-      const uint32_t w = fd == 0 ? L.r[lane][p] : side_word(sl, R1, t.begin, p);
+      const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, t.begin, p);
       if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }         // cannot happen on a chain K1/K3 produced
       const uint32_t id = w & ID_NONE;
       fd = (w >> 30) & 1u;
-      if (id != ID_NONE) { if (staged) { if (o < (uint64_t)TOUT) L.out[o] = id; } else if (o < out_cap) out[o] = id; o++; }
-      if (fd) { if (staged) { if (o < (uint64_t)TOUT) L.out[o] = delete_id; } else if (o < out_cap) out[o] = delete_id; o++; }
+      if (id != ID_NONE) put(id);
+      if (fd) put(delete_id);
       p += (w >> 24) & 63u;                                            // (0 is possible: a one-byte alternative of a forward-delete state)
     }
     if (hop > 2 * SEG) atomicOr(error_flag, 2u);
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-  if (staged) {
-    const uint32_t total = (uint32_t)(end_last - base0);
-    for (uint32_t j = (uint32_t)lane; j < total; j += 64u) { const uint64_t o = base0 + j; if (o < out_cap) out[o] = L.out[j]; }
+#pragma unroll 4
+  for (int s = 0; s < nv; s++) {
+    const uint32_t n = (uint32_t)__shfl((int)staged, s);
+    const uint64_t base = shfl_u64(t.base, s);
+    for (uint32_t j = (uint32_t)lane; j < n; j += 64u) if (base + j < out_cap) out[base + j] = s_tile[s][j];
   }
 }
 
@@ -1028,9 +1051,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
 template <int WV>
 __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
                                                         const uint32_t* __restrict__ R1, const uint8_t* __restrict__ text,
-                                                        const uint64_t* __restrict__ doc_begin, const uint64_t* __restrict__ doc_end,
-                                                        const uint32_t* __restrict__ seg_doc, const uint64_t* __restrict__ doc_seg_start,
-                                                        uint64_t nseg, const uint8_t* __restrict__ seg_entry, uint32_t delete_id,
+                                                        const uint4* __restrict__ par, uint64_t nseg, uint32_t delete_id,
                                                         uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
                                                         uint32_t* __restrict__ missing_bits, uint32_t* __restrict__ error_flag) {
   __shared__ alignas(16) uint32_t s_tile[WV][TS][TROW];
@@ -1044,14 +1065,15 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
   uint32_t ntok = 0, ndel = 0;
   for (uint64_t g0 = ((uint64_t)blockIdx.x * WV + wv) * TS; g0 < nseg; g0 += (uint64_t)gridDim.x * WV * TS) {
     const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
-    const TileSegs t = tile_segments(g0 + lane, lane < TS, nseg, doc_begin, doc_end, seg_doc, doc_seg_start, seg_entry, nullptr, nullptr);
+    const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
     tile_load(s_tile[wv], t, nv, lane, R0);
     if (t.have) {
+      const uint32_t* row = s_tile[wv][lane];
       uint32_t p = t.entry >> 1, fd = t.entry & 1u;
       const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
       int hop = 0;
       for (; hop <= 2 * SEG && p < t.seglen; hop++) {
-        const uint32_t w = fd == 0 ? s_tile[wv][lane][p] : side_word(sl, R1, t.begin, p);
+        const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, t.begin, p);
         if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }
         const uint32_t id = w & ID_NONE, adv = (w >> 24) & 63u;
         fd = (w >> 30) & 1u;
@@ -1141,13 +1163,15 @@ void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32
 void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st) {
   if (nunits) k_segments<<<(uint32_t)((nunits + 255) / 256), 256, 0, st>>>(doc_unit_start, ndocs, nunits, unit_doc);
 }
+static void launch_seg_params(tm_batch* b, hipStream_t st);
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
                        uint32_t n_ids, hipStream_t st) {
   const uint64_t nseg = b->nseg;
-  if (nseg > 0 && !(debug_flags() & 128))
+  if (nseg > 0 && !(debug_flags() & 128)) {
+    launch_seg_params(b, st);
     k_score_tiles<5><<<(uint32_t)std::min<uint64_t>((nseg + 5 * TS - 1) / (5 * TS), (uint64_t)n_cu), 5 * 64, 0, st>>>(
-        b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry, delete_id, d_hist, d_tokens,
-        d_missing_bits, b->d_error);
+        b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_seg_par, nseg, delete_id, d_hist, d_tokens, d_missing_bits, b->d_error);
+  }
   else if (nseg > 0)
     k_chain<true, 16><<<(uint32_t)std::min<uint64_t>((nseg + 15) / 16, (uint64_t)n_cu), 1024, 0, st>>>(
         b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
@@ -1155,6 +1179,11 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
   k_hist_finish<<<1, 256, 0, st>>>(d_tokens, d_missing_bits, d_hist + n_ids);
 }
 
+// the per-segment records of k_seg_params (after the token-offset scan)
+static void launch_seg_params(tm_batch* b, hipStream_t st) {
+  k_seg_params<<<(uint32_t)((b->nseg + 1 + 255) / 256), 256, 0, st>>>(b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, b->nseg, b->ndocs, b->d_seg_entry,
+                                                                      b->d_seg_tokbase, b->d_tok_offsets, b->d_seg_par);
+}
 // K4 for the id-emitting entry points: the tile walk; debug bit 7 selects the list-ranking kernel instead
 static void launch_emit(tm_batch* b, hipStream_t st) {
   const uint64_t nseg = b->nseg;
@@ -1162,10 +1191,11 @@ static void launch_emit(tm_batch* b, hipStream_t st) {
     k_chain<false, 4><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
                                                                nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, b->vocab->tables.delete_id,
                                                                b->out_cap, b->d_out, nullptr, nullptr, nullptr);
-  else
-    k_emit_tiles<<<(uint32_t)((nseg + TS - 1) / TS), 64, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg,
-                                                                 b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, b->vocab->tables.delete_id, b->out_cap,
-                                                                 b->d_out, b->d_error);
+  else {
+    launch_seg_params(b, st);
+    k_emit_tiles<<<(uint32_t)((nseg + TS - 1) / TS), 64, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, b->out_cap, b->d_out,
+                                                                 b->d_error);
+  }
 }
 
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {
@@ -1321,7 +1351,7 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
       (e = dalloc(b, &b->d_seg_doc, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_R0, max_bytes + 64)) != hipSuccess || (e = dalloc(b, &b->d_R1, max_bytes + 64)) != hipSuccess ||
       (e = dalloc(b, &b->d_side, b->max_segs * SIDE_STRIDE)) != hipSuccess ||
       (e = dalloc(b, &b->d_exitmap, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_seg_entry, b->max_segs)) != hipSuccess ||
-      (e = dalloc(b, &b->d_seg_tokbase, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_doc_ntok, nd1)) != hipSuccess ||
+      (e = dalloc(b, &b->d_seg_tokbase, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_seg_par, b->max_segs + 1)) != hipSuccess || (e = dalloc(b, &b->d_doc_ntok, nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_doc_events, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_missing, nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_tok_offsets, nd1 + 1)) != hipSuccess || (e = dalloc(b, &b->d_scan_tmp, scan_blocks)) != hipSuccess ||
       (e = dalloc(b, &b->d_totals, 4)) != hipSuccess || (e = dalloc(b, &b->d_error, 4)) != hipSuccess ||
@@ -1344,7 +1374,7 @@ int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm
 void tm_batch_free(tm_batch* b) {
   if (!b) return;
   void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R0, b->d_R1, b->d_side, b->d_exitmap, b->d_seg_entry,
-                  b->d_seg_tokbase, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
+                  b->d_seg_tokbase, b->d_seg_par, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
                   b->d_error, b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
                   b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,
                   b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_raw, b->d_fb_norm, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids};

@@ -58,6 +58,7 @@ struct tm_batch {
   uint2* d_exitmap = nullptr;
   uint8_t* d_seg_entry = nullptr;
   uint32_t* d_seg_tokbase = nullptr;
+  uint4* d_seg_par = nullptr;          // per segment: begin | length | entry state | first output index (k_seg_params)
   uint32_t* d_doc_ntok = nullptr;
   uint32_t* d_doc_events = nullptr;
   uint32_t* d_doc_missing = nullptr;
