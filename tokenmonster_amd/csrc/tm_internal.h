@@ -21,6 +21,9 @@ int build_vocab_image(const std::vector<std::string>& tokens, const std::vector<
 // tm_normalize.cpp
 void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out);
 
+int normalize_batch_into(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t norm_flag,
+                         uint32_t threads, uint64_t* out_offsets, const std::function<uint8_t*(uint64_t)>& alloc);
+
 void capcode_decode_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t threads,
                           std::vector<std::vector<uint8_t>>& outs);
 

@@ -1381,6 +1381,7 @@ void tm_batch_free(tm_batch* b) {
   for (void* p : ptrs) (void)hipFree(p);
   if (b->have_events) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
   if (b->aux_stream) (void)hipStreamDestroy(b->aux_stream);
+  (void)hipHostFree(b->h_fb_raw); (void)hipHostFree(b->h_fb_norm);
   delete b;
 }
 

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict_
 
 // carry byte of a piece: ub[0..1] | ua[2..3] | tL[4]
 __global__ void k_norm_carry(const uint32_t* __restrict__ piece_sum, const uint64_t* __restrict__ doc_piece_start, uint32_t ndocs,
-                             uint8_t* __restrict__ piece_carry, uint8_t* __restrict__ need_host, unsigned long long* __restrict__ ninfo) {
+                             uint8_t* __restrict__ piece_carry, uint8_t* __restrict__ need_host, unsigned long long* __restrict__ ninfo,
+                             uint32_t* __restrict__ fb_ids) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ndocs) return;
   const uint64_t ps = doc_piece_start[d], pe = doc_piece_start[d + 1];
@@ -166,7 +167,7 @@ __global__ void k_norm_carry(const uint32_t* __restrict__ piece_sum, const uint6
     else { ua = 0; tl = (s & PS_FIRSTL) ? 1u : 0u; }
   }
   need_host[d] = bad ? 1 : 0;
-  if (bad) atomicAdd(&ninfo[0], 1ull);
+  if (bad) fb_ids[atomicAdd(&ninfo[0], 1ull)] = d;           // the documents the host has to normalize, in no particular order
 }
 
 // MODE 0: normalized length of every piece.  MODE 1: the bytes, packed at piece_off.  MODE 2: the bytes into the piece's
@@ -519,12 +520,15 @@ int tm_batch_upload_raw(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
   uint64_t docs_cap = b->raw_docs_cap;
   if ((e = grow(&b->d_raw, &b->raw_cap, nbytes + 256)) != hipSuccess) return hip_fail(e, "hipMalloc (raw text)");
   if (!b->d_raw_off || ndocs + 2 > docs_cap) {
-    void** ps[] = {(void**)&b->d_raw_off, (void**)&b->d_doc_npiece, (void**)&b->d_doc_piece_start, (void**)&b->d_need_host, (void**)&b->d_nbegin, (void**)&b->d_nend};
+    void** ps[] = {(void**)&b->d_raw_off, (void**)&b->d_doc_npiece, (void**)&b->d_doc_piece_start, (void**)&b->d_need_host, (void**)&b->d_nbegin, (void**)&b->d_nend,
+                   (void**)&b->d_fb_ids, (void**)&b->d_fb_roff, (void**)&b->d_fb_noff};
     for (void** q : ps) { (void)hipFree(*q); *q = nullptr; }
     docs_cap = (uint64_t)ndocs + ndocs / 4 + 16;
     if ((e = hipMalloc((void**)&b->d_raw_off, docs_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_doc_npiece, docs_cap * 4)) != hipSuccess ||
         (e = hipMalloc((void**)&b->d_doc_piece_start, (docs_cap + 1) * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_need_host, docs_cap)) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_nbegin, docs_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_nend, docs_cap * 8)) != hipSuccess)
+        (e = hipMalloc((void**)&b->d_nbegin, docs_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_nend, docs_cap * 8)) != hipSuccess ||
+        (e = hipMalloc((void**)&b->d_fb_ids, docs_cap * 4)) != hipSuccess || (e = hipMalloc((void**)&b->d_fb_roff, (docs_cap + 1) * 8)) != hipSuccess ||
+        (e = hipMalloc((void**)&b->d_fb_noff, (docs_cap + 1) * 8)) != hipSuccess)
       return hip_fail(e, "hipMalloc (raw documents)");
     b->raw_docs_cap = (uint32_t)std::min<uint64_t>(docs_cap - 2, 0xFFFFFFFFull);
   }
@@ -577,7 +581,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
     k_norm_summary<<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_sum);
   }
-  k_norm_carry<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo);
+  k_norm_carry<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids);
   unsigned long long h_info[4] = {0, 0, 0, 0};
   if ((e = hipMemcpyAsync(h_info, ninfo, 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
     return hip_fail(e, "normalize (summaries)");
@@ -585,7 +589,6 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   const uint32_t nf = (uint32_t)h_info[0];
   std::vector<uint32_t> ids;
   std::vector<uint64_t> roff;
-  std::vector<uint8_t> hraw;
   double f1 = now(), f2 = 0, f3 = 0, f4 = 0;
   // the device normalizes its documents (one pass into per-piece slabs, lengths on the side) ...
   if (np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
@@ -600,28 +603,24 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     // second stream, so that the fetch does not hold up the pass above
     if (!b->aux_stream && (e = hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
     hipStream_t sx = b->aux_stream;
-    std::vector<uint8_t> need(nd);
-    if ((e = hipMemcpyAsync(need.data(), b->d_need_host, nd, hipMemcpyDeviceToHost, sx)) != hipSuccess || (e = hipStreamSynchronize(sx)) != hipSuccess)
-      return hip_fail(e, "D2H flags");
-    ids.reserve(nf);
-    for (uint32_t d = 0; d < nd; d++) if (need[d]) ids.push_back(d);
+    // the (unordered) list k_norm_carry has left on the device, put into document order
+    ids.resize(nf);
+    if ((e = hipMemcpyAsync(ids.data(), b->d_fb_ids, (size_t)nf * 4, hipMemcpyDeviceToHost, sx)) != hipSuccess || (e = hipStreamSynchronize(sx)) != hipSuccess)
+      return hip_fail(e, "D2H fallback list");
+    std::sort(ids.begin(), ids.end());
     roff.assign(ids.size() + 1, 0);
     for (size_t k = 0; k < ids.size(); k++) roff[k + 1] = roff[k] + (b->h_raw_off[ids[k] + 1] - b->h_raw_off[ids[k]]);
-    uint64_t docs_cap = b->fb_docs_cap;
-    if (!b->d_fb_ids || ids.size() + 1 > docs_cap) {
-      (void)hipFree(b->d_fb_ids); (void)hipFree(b->d_fb_roff); (void)hipFree(b->d_fb_noff);
-      b->d_fb_ids = nullptr; b->d_fb_roff = nullptr; b->d_fb_noff = nullptr;
-      docs_cap = ids.size() * 2 + 64;
-      if ((e = hipMalloc((void**)&b->d_fb_ids, docs_cap * 4)) != hipSuccess || (e = hipMalloc((void**)&b->d_fb_roff, (docs_cap + 1) * 8)) != hipSuccess ||
-          (e = hipMalloc((void**)&b->d_fb_noff, (docs_cap + 1) * 8)) != hipSuccess) return hip_fail(e, "hipMalloc (fallback lists)");
-      b->fb_docs_cap = (uint32_t)docs_cap;
-    }
     if ((e = grow(&b->d_fb_raw, &b->fb_raw_cap, roff.back() + 16)) != hipSuccess) return hip_fail(e, "hipMalloc (fallback staging)");
+    if (!b->h_fb_raw || b->h_fb_raw_cap < roff.back() + 16) {
+      (void)hipHostFree(b->h_fb_raw);
+      b->h_fb_raw = nullptr;
+      b->h_fb_raw_cap = roff.back() + roff.back() / 4 + 4096;
+      if ((e = hipHostMalloc((void**)&b->h_fb_raw, b->h_fb_raw_cap, hipHostMallocDefault)) != hipSuccess) return hip_fail(e, "hipHostMalloc (fallback staging)");
+    }
     if ((e = hipMemcpyAsync(b->d_fb_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, sx)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_fb_roff, roff.data(), roff.size() * 8, hipMemcpyHostToDevice, sx)) != hipSuccess) return hip_fail(e, "H2D fallback lists");
     k_gather_docs<<<(uint32_t)ids.size(), 256, 0, sx>>>(b->d_raw, b->d_raw_off, b->d_fb_ids, b->d_fb_roff, (uint32_t)ids.size(), b->d_fb_raw);
-    hraw.resize(roff.back());
-    if ((e = hipMemcpyAsync(hraw.data(), b->d_fb_raw, roff.back(), hipMemcpyDeviceToHost, sx)) != hipSuccess || (e = hipStreamSynchronize(sx)) != hipSuccess)
+    if ((e = hipMemcpyAsync(b->h_fb_raw, b->d_fb_raw, roff.back(), hipMemcpyDeviceToHost, sx)) != hipSuccess || (e = hipStreamSynchronize(sx)) != hipSuccess)
       return hip_fail(e, "D2H fallback documents");
     f2 = now();
   }
@@ -630,16 +629,26 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   uint8_t* hnorm = nullptr;
   std::vector<uint64_t> noff(ids.size() + 1, 0);
   if (nf > 0) {
-    const uint32_t threads = (uint32_t)std::min<size_t>(64, ids.size() / 8 + 1);   // pooled workers; more of them gain little (the device pass is as long)
-    int rc = tm_normalize_batch(hraw.data(), roff.data(), (uint32_t)ids.size(), capcode, norm_flag, threads, &hnorm, noff.data());
+    const uint32_t threads = (uint32_t)std::min<size_t>(128, ids.size() / 8 + 1);   // pooled workers
+    hipError_t he = hipSuccess;
+    int rc = normalize_batch_into(b->h_fb_raw, roff.data(), (uint32_t)ids.size(), capcode, norm_flag, threads, noff.data(), [&](uint64_t total) -> uint8_t* {
+      if (!b->h_fb_norm || b->h_fb_norm_cap < total + 16) {                         // pinned: the H2D below then runs at link speed
+        (void)hipHostFree(b->h_fb_norm);
+        b->h_fb_norm = nullptr;
+        b->h_fb_norm_cap = total + total / 4 + 4096;
+        if ((he = hipHostMalloc((void**)&b->h_fb_norm, b->h_fb_norm_cap, hipHostMallocDefault)) != hipSuccess) return nullptr;
+      }
+      return b->h_fb_norm;
+    });
+    if (he != hipSuccess) return hip_fail(he, "hipHostMalloc (fallback output)");
     if (rc != TM_OK) return rc;
+    hnorm = b->h_fb_norm;
     f3 = now();
   }
   if ((e = hipMemcpyAsync(h_info, ninfo, 32, hipMemcpyDeviceToHost, st)) != hipSuccess ||
       (e = hipMemcpyAsync(&gpu_bytes, b->d_totals + 2, 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipStreamSynchronize(st)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "normalize (device pass)"); }
+      (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "normalize (device pass)");
   if (gpu_bytes + noff.back() > b->max_bytes) {
-    tm_free(hnorm);
     return set_error(TM_E_LIMIT, "normalized text needs %llu bytes, workspace sized for %llu", (unsigned long long)(gpu_bytes + noff.back()), (unsigned long long)b->max_bytes);
   }
   if (np > 0) {
@@ -654,12 +663,11 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   k_norm_ranges<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);
   uint64_t total = gpu_bytes;
   if (nf > 0) {
-    if ((e = grow(&b->d_fb_norm, &b->fb_norm_cap, noff.back() + 16)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "hipMalloc (fallback output)"); }
+    if ((e = grow(&b->d_fb_norm, &b->fb_norm_cap, noff.back() + 16)) != hipSuccess) return hip_fail(e, "hipMalloc (fallback output)");
     if ((e = hipMemcpyAsync(b->d_fb_norm, hnorm, noff.back(), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_fb_noff, noff.data(), noff.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "H2D fallback output"); }
+        (e = hipMemcpyAsync(b->d_fb_noff, noff.data(), noff.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D fallback output");
     k_place_fallback<<<(uint32_t)ids.size(), 256, 0, st>>>(b->d_fb_norm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), total, b->d_text, b->d_nbegin, b->d_nend);
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) { tm_free(hnorm); return hip_fail(e, "fallback placement"); }
-    tm_free(hnorm);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "fallback placement");
     total += noff.back();
     b->host_fallback_docs = (uint32_t)ids.size();
     f4 = now();

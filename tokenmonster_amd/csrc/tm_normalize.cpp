@@ -387,6 +387,47 @@ void capcode_decode_batch(const uint8_t* text, const uint64_t* offsets, uint32_t
 
 }  // namespace tmh
 
+namespace tmh {
+
+// Normalizes every document on up to `threads` pooled workers (0 = one per hardware thread), fills out_offsets[ndocs+1], asks
+// `alloc` for a destination of the total size (a malloc'd block, a pinned staging buffer ...) and places the documents there,
+// also in parallel.
+int normalize_batch_into(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t norm_flag,
+                         uint32_t threads, uint64_t* out_offsets, const std::function<uint8_t*(uint64_t)>& alloc) {
+  if (!normalize_supported(capcode, norm_flag))
+    return set_error(TM_E_INVALID, "normalization flags %u / capcode %u not supported by the host normalizer", norm_flag, capcode);
+  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  threads = std::min<uint32_t>(threads, std::max(1u, ndocs));
+  const uint32_t grab = std::max(1u, std::min(64u, ndocs / (threads * 4u)));
+  std::vector<std::vector<uint8_t>> outs(ndocs);
+  std::atomic<uint32_t> next{0};
+  run_on_workers(threads, [&]() {
+    for (;;) {
+      const uint32_t base = next.fetch_add(grab);
+      if (base >= ndocs) break;
+      for (uint32_t d = base; d < std::min(ndocs, base + grab); d++)
+        normalize_bytes(text + offsets[d], (size_t)(offsets[d + 1] - offsets[d]), capcode, norm_flag, outs[d]);
+    }
+  });
+  uint64_t total = 0;
+  for (uint32_t d = 0; d < ndocs; d++) { out_offsets[d] = total; total += outs[d].size(); }
+  out_offsets[ndocs] = total;
+  uint8_t* o = alloc(total);
+  if (!o) return set_error(TM_E_INVALID, "no destination for %llu normalized bytes", (unsigned long long)total);
+  next = 0;
+  run_on_workers(total > (1u << 20) ? threads : 1u, [&]() {
+    for (;;) {
+      const uint32_t base = next.fetch_add(grab);
+      if (base >= ndocs) break;
+      for (uint32_t d = base; d < std::min(ndocs, base + grab); d++)
+        if (!outs[d].empty()) std::memcpy(o + out_offsets[d], outs[d].data(), outs[d].size());
+    }
+  });
+  return TM_OK;
+}
+
+}  // namespace tmh
+
 extern "C" {
 
 int tm_normalize(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, uint8_t** out, size_t* out_n) {
@@ -404,27 +445,10 @@ int tm_normalize(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_
 int tm_normalize_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode,
                        uint32_t norm_flag, uint32_t threads, uint8_t** out_text, uint64_t* out_offsets) {
   if (!out_text || !out_offsets || (ndocs && (!text || !offsets))) return tmh::set_error(TM_E_INVALID, "null argument");
-  if (!tmh::normalize_supported(capcode, norm_flag))
-    return tmh::set_error(TM_E_INVALID, "normalization flags %u / capcode %u not supported by the host normalizer", norm_flag, capcode);
-  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
-  threads = std::min<uint32_t>(threads, std::max(1u, ndocs));
-  const uint32_t grab = std::max(1u, std::min(64u, ndocs / (threads * 4u)));
-  std::vector<std::vector<uint8_t>> outs(ndocs);
-  std::atomic<uint32_t> next{0};
-  auto work = [&]() {
-    for (;;) {
-      uint32_t base = next.fetch_add(grab);
-      if (base >= ndocs) break;
-      for (uint32_t d = base; d < std::min(ndocs, base + grab); d++)
-        tmh::normalize_bytes(text + offsets[d], (size_t)(offsets[d + 1] - offsets[d]), capcode, norm_flag, outs[d]);
-    }
-  };
-  tmh::run_on_workers(threads, work);
-  uint64_t total = 0;
-  for (uint32_t d = 0; d < ndocs; d++) { out_offsets[d] = total; total += outs[d].size(); }
-  out_offsets[ndocs] = total;
-  uint8_t* o = (uint8_t*)std::malloc(total ? total : 1);
-  for (uint32_t d = 0; d < ndocs; d++) if (!outs[d].empty()) std::memcpy(o + out_offsets[d], outs[d].data(), outs[d].size());
+  uint8_t* o = nullptr;
+  int rc = tmh::normalize_batch_into(text, offsets, ndocs, capcode, norm_flag, threads, out_offsets,
+                                     [&](uint64_t total) { o = (uint8_t*)std::malloc(total ? total : 1); return o; });
+  if (rc != TM_OK) { std::free(o); return rc; }
   *out_text = o;
   return TM_OK;
 }
