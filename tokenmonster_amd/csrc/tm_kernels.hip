@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "tm_pipeline.h"
@@ -347,42 +348,48 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
       pfa = posa + 2u;
     }
     const bool nowalk = (dbg & 4) != 0;
-    while (__builtin_amdgcn_ballot_w64(probing || setting) != 0ull) {
-      const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // 8-byte slots: the upper half is ignored
-      uint32_t c = *(lds_u8*)(uintptr_t)pfa;
-      uint32_t nn = *(lds_u16u*)(uintptr_t)(posa + 1u);                // the two bytes at the next position, as the direct map indexes them
-      asm volatile("" : "+v"(c), "+v"(nn));                            // both LDS reads are issued here, under the gather's latency
-      const bool hit = probing && e.x == key;
-      const bool again = probing && !hit && e.x != kNone;              // occupied by another key: linear probing
-      const bool adv = hit || setting;                                 // the walk state is (re)set this round
-      const uint32_t src = hit ? e.y : e.x;                            // bits 0..20 node, bit 21 "has children" / "go on"
-      const uint32_t nid = src & kNodeMask;
-      if (hit) depth++;
-      if (setting) { depth = (int)((e.x >> 23) & 63u); bestv = e.y; bestlen = (int)e.z; }
-      if (adv) node = nid;
-      if (hit && nid < T.n_info) { bestv = e.y; bestlen = depth; }
-      const bool go = adv && (src & kHasChildren) != 0 && depth < limit && !nowalk;
-      const bool fin = (adv && !go) || (probing && !hit && !again);
-      if (go) { key = (nid << 8) | c; off = edge_slot_offset(T, nid, c); pfa = posa + (uint32_t)depth + 1u; }
-      if (again) off = (off + 8u) & mask8;
-      probing = go || again;
-      setting = false;
-      if (fin) {
-        // position done: store, move on — through the suffix link if the walk got deep enough, else from the direct map
-        if (bestlen != 0) {
+    // The loop exists twice: when the document goes on for at least Lmax bytes behind the last position of the segment, no walk
+    // is cut short by the end of the text and `limit` is the constant Lmax (two instructions less per round).
+    auto rounds = [&](auto tail_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      // a lane is busy exactly as long as its gather address is not the idle slot
+      while (__builtin_amdgcn_ballot_w64(off != idle_off) != 0ull) {
+        const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // 8-byte slots: the upper half is ignored
+        uint32_t c = *(lds_u8*)(uintptr_t)pfa;
+        uint32_t nn = *(lds_u16u*)(uintptr_t)(posa + 1u);                // the two bytes at the next position, as the direct map indexes them
+        asm volatile("" : "+v"(c), "+v"(nn));                            // both LDS reads are issued here, under the gather's latency
+        const bool hit = probing && e.x == key;
+        const bool again = probing && !hit && e.x != kNone;              // occupied by another key: linear probing
+        const bool adv = hit || setting;                                 // the walk state is (re)set this round
+        const uint32_t src = hit ? e.y : e.x;                            // bits 0..20 node, bit 21 "has children" / "go on"
+        const uint32_t nid = src & kNodeMask;
+        if (hit) depth++;
+        if (setting) { depth = (int)((e.x >> 23) & 63u); bestv = e.y; bestlen = (int)e.z; }
+        if (adv) node = nid;
+        if (hit && nid < T.n_info) { bestv = e.y; bestlen = depth; }
+        const bool go = adv && (src & kHasChildren) != 0 && depth < (TAIL ? limit : Lmax) && !nowalk;
+        const bool fin = (adv && !go) || (probing && !hit && !again);
+        if (go) { key = (nid << 8) | c; off = edge_slot_offset(T, nid, c); pfa = posa + (uint32_t)depth + 1u; }
+        if (again) off = (off + 8u) & mask8;
+        probing = go || again;
+        setting = false;
+        if (fin) {
+          // position done: store (no match: bestlen == 0 and the link formats give bestv == 0, so the descriptor written is the
+          // 0 that is there already), move on — through the suffix link if the walk got deep enough, else from the direct map
           lds_u32* dp = (lds_u32*)(uintptr_t)(dconst + 4u * posa);
-          dp[0] = (uint32_t)bestlen | ((bestv >> 22) << 6);            // D[pos]
-          dp[2 * NPOS_PAD] = bestv;                                     // X[pos]
+          dp[0] = (uint32_t)bestlen | ((bestv >> 22) << 6);              // D[pos]
+          dp[2 * NPOS_PAD] = bestv;                                       // X[pos]
+          posa++;
+          setting = posa < enda;
+          if (TAIL) limit = min((int)(dla - posa), Lmax);
+          if (depth >= 3) { off = T.link_off + (node << 4); pfa = posa + (uint32_t)depth - 1u; }
+          else { off = T.direct_off + (nn << 4); pfa = posa + 2u; }
+          if (!setting) off = idle_off;
         }
-        posa++;
-        setting = posa < enda;
-        limit = min((int)(dla - posa), Lmax);
-        if (depth >= 3) { off = T.link_off + (node << 4); pfa = posa + (uint32_t)depth - 1u; }
-        else { off = T.direct_off + (nn << 4); pfa = posa + 2u; }
-        if (!setting) off = idle_off;
+        PH_INC(8)
       }
-      PH_INC(8)
-    }
+    };
+    if (dl >= NPOS + Lmax) rounds(std::false_type{}); else rounds(std::true_type{});
     PH(2)
   }
   __builtin_amdgcn_wave_barrier();
