@@ -174,8 +174,13 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   while ((1ull << bits) < n_edges * 5 / 2 + 8) bits++;
   hv.edge_mask = (1u << bits) - 1;
   hv.edge_shift = 32 - bits;
-  // one allocation (tm_tables.h): edge hash | always-empty slot | direct map | suffix links
-  const size_t direct_base = (((size_t)1 << bits) + 1 + 1) & ~(size_t)1;      // 16-byte aligned
+  // child-byte filter of every node: bit (b & 31) is set if the node has a child over byte b.  A walk only probes the edge hash
+  // for a byte whose bit is set, so a probe that cannot hit (half of all positions end on one, and with linear probing it is
+  // ~1.5 gathers) is almost never issued: most nodes have one child.
+  std::vector<uint32_t> cmask(n_nodes, 0);
+  for (auto& kv : child) { const uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) cmask[parent] |= 1u << (kv.first & 31u); }
+  // one allocation (tm_tables.h): edge hash (16-byte slots) | always-empty slot | direct map | suffix links
+  const size_t direct_base = 2 * (((size_t)1 << bits) + 1);                   // in 8-byte units; 16-byte aligned
   const size_t link_base = direct_base + kDirectSlots;
   hv.direct_off = (uint32_t)(direct_base * sizeof(uint2));
   hv.link_off = (uint32_t)(link_base * sizeof(uint2));
@@ -190,8 +195,9 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     else if (d >= 3) {
       uint32_t key = (parent << 8) | byte;
       uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;
-      while (edges[h].x != kNone) h = (h + 1) & hv.edge_mask;
-      edges[h] = uint2{key, value_of(kv.second)};
+      while (edges[2 * (size_t)h].x != kNone) h = (h + 1) & hv.edge_mask;
+      edges[2 * (size_t)h] = uint2{key, value_of(kv.second)};
+      edges[2 * (size_t)h + 1] = uint2{cmask[kv.second], 0u};                   // the filter of the node the edge leads to
     }
   }
   // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.
@@ -220,7 +226,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       const uint32_t hc = (m != kRoot && has_child[m]) ? 1u : 0u;
       const uint32_t b = m == kRoot ? kNone : best[m];
       lt[2 * (size_t)n] = uint2{(m & kNodeMask) | (((uint32_t)lfull[n] & hc) << 21) | (dm << 23), b != kNone ? value_of(b) : 0u};
-      lt[2 * (size_t)n + 1] = uint2{b != kNone ? (uint32_t)depth_of[b] : 0u, 0u};
+      lt[2 * (size_t)n + 1] = uint2{(lfull[n] && hc) ? cmask[m] : 0u, b != kNone ? (uint32_t)depth_of[b] : 0u};
     }
   }
   // reverse table for decoding: reverse[id] = key of the LAST record carrying that id (go/tokenmonster.go:2715, quirk Q3)
@@ -256,7 +262,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       }
       uint2* e = hv.tab.data() + direct_base + 2 * (size_t)(b0 | (b1 << 8));      // indexed by the little-endian u16 at the position
       e[0] = uint2{id2 | (cont << 21) | ((cont ? 2u : 0u) << 23), bestv};
-      e[1] = uint2{bestlen, 0u};
+      e[1] = uint2{cont ? cmask[id2] : 0u, bestlen};
     }
   }
   hv.n_nodes = n_nodes;

@@ -35,13 +35,14 @@ int main(int argc, char** argv) {
   const uint64_t N = off[nd];
   printf("vocab: n_info %u nodes %u edge slots %u (mask %x) tab bytes %zu; corpus %llu docs %u\n", hv.n_info, hv.n_nodes, hv.edge_mask + 1,
          hv.edge_mask, hv.tab.size() * 8, (unsigned long long)N, nd);
+  // NOTE: 16-byte hash slots {key, value | child filter, -}; link format {x, y | child filter, best depth}
 
   // child-byte masks per node (from the edge hash: all edges into depth >= 3)
   std::vector<uint64_t> cmask(hv.n_nodes, 0);
   std::vector<uint32_t> nchild(hv.n_nodes, 0);
   uint64_t nedges = 0;
   for (uint32_t s = 0; s <= hv.edge_mask; s++) {
-    const uint2 e = hv.tab[s];
+    const uint2 e = hv.tab[2 * (size_t)s];
     if (e.x == kNone) continue;
     cmask[e.x >> 8] |= 1ull << (e.x & 63u);
     nchild[e.x >> 8]++;
@@ -59,7 +60,8 @@ int main(int argc, char** argv) {
   const uint2* link = tab + hv.link_off / 8;
   const int Lmax = (int)hv.max_len;
 
-  // variants: 0 = as built (has-children bit only); 1 = 32-bit filter (byte & 31); 2 = 64-bit filter (byte & 63)
+  // variants: 0 = has-children bit only (no filter); 1 = the 32-bit filter words stored in the tables (what the kernel does); 2 = ideal 64-bit filter
+  std::vector<uint64_t> sigs; uint64_t sig_bad = 0;
   for (int variant = 0; variant < 3; variant++) {
     Stats st;
     std::vector<uint32_t> round_hist(128, 0);
@@ -89,23 +91,22 @@ int main(int argc, char** argv) {
             // note: the kernel takes the link of the node the previous walk ENDED on and its depth-1
             rounds++; st.set++;
             uint32_t src = e[0].x;
+            uint32_t filt = e[1].x;                                  // child filter of the node the entry leads to
             depth = (int)((src >> 23) & 63u);
             node = src & kNodeMask;
+            int bestlen = (int)e[1].y;
             bool go = (src & kHasChildren) != 0 && depth < limit;
             while (go) {
               const uint32_t c = at(pos + depth);
-              if (variant != 0) {
-                const uint64_t m = cmask[node];
-                const bool pass = variant == 1 ? (((uint32_t)(m | (m >> 32)) >> (c & 31u)) & 1u) != 0 : ((m >> (c & 63u)) & 1ull) != 0;
-                if (!pass) { st.filtered++; break; }
-              }
+              if (variant == 1) { if (!((filt >> (c & 31u)) & 1u)) { st.filtered++; break; } }
+              else if (variant == 2) { if (!((cmask[node] >> (c & 63u)) & 1ull)) { st.filtered++; break; } }
               const uint32_t key = (node << 8) | c;
               uint32_t h = edge_hash(node, c) >> hv.edge_shift;
               bool hit = false;
               for (;;) {
                 rounds++;
-                const uint2 s = tab[h];
-                if (s.x == key) { hit = true; st.hit++; src = s.y; break; }
+                const uint2 s = tab[2 * (size_t)h];
+                if (s.x == key) { hit = true; st.hit++; src = s.y; filt = tab[2 * (size_t)h + 1].x; break; }
                 if (s.x == kNone) { st.miss++; break; }
                 st.again++;
                 h = (h + 1) & hv.edge_mask;
@@ -113,8 +114,11 @@ int main(int argc, char** argv) {
               if (!hit) break;
               depth++;
               node = src & kNodeMask;
+              if (node < hv.n_info) bestlen = depth;
               go = (src & kHasChildren) != 0 && depth < limit;
             }
+            // every variant must end every position in the same state (the filter only suppresses probes that cannot hit)
+            { const uint64_t sig = ((uint64_t)node << 16) | ((uint64_t)depth << 8) | (uint64_t)bestlen; if (variant == 0) sigs.push_back(sig); else if (sigs[st.pos] != sig) { if (++sig_bad < 5) fprintf(stderr, "STATE MISMATCH variant %d position %llu\n", variant, (unsigned long long)st.pos); } }
             if (first) { st.first_n++; st.first_g += rounds - rounds_before; }
             first = false;
             pos++;
@@ -133,6 +137,7 @@ int main(int argc, char** argv) {
            variant, (unsigned long long)st.pos, g / st.pos, (double)st.set / st.pos, (double)st.hit / st.pos, (double)st.again / st.pos,
            (double)st.miss / st.pos, (double)st.filtered / st.pos, (double)st.rounds / st.waves, (double)st.lane_sum / st.waves / 64.0,
            (double)st.lane_sum / 64.0 / st.rounds);
+    printf("   state mismatches vs variant 0: %llu\n", (unsigned long long)sig_bad);
     printf("   first position of a run: %.2f gathers (others %.2f)\n", (double)st.first_g / st.first_n, (g - st.first_g) / (st.pos - st.first_n));
   }
 
@@ -164,7 +169,7 @@ int main(int argc, char** argv) {
               const uint32_t key = (node << 8) | c;
               uint32_t h = edge_hash(node, c) >> hv.edge_shift;
               bool hit = false;
-              for (;;) { rounds++; const uint2 sl = tab[h]; if (sl.x == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
+              for (;;) { rounds++; const uint2 sl = tab[2 * (size_t)h]; if (sl.x == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
               if (!hit) break;
               depth++; node = src & kNodeMask; go = (src & kHasChildren) != 0 && depth < limit;
             }
@@ -221,7 +226,7 @@ int main(int argc, char** argv) {
               const uint32_t key = (node << 8) | c;
               uint32_t h = edge_hash(node, c) >> hv.edge_shift;
               bool hit = false;
-              for (;;) { rounds++; const uint2 sl = tab[h]; if (sl.x == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
+              for (;;) { rounds++; const uint2 sl = tab[2 * (size_t)h]; if (sl.x == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
               if (!hit) break;
               depth++; node = src & kNodeMask; go = (src & kHasChildren) != 0 && depth < limit;
             }
