@@ -936,7 +936,7 @@ __global__ __launch_bounds__(WV * 64) void k_chain(const uint32_t* __restrict__ 
 // (p,1) states are rare: their words are looked up in the segment's side list (or the dense array) when one is entered.
 // (Letting every lane walk its segment straight from HBM — no tiles — was measured at 8.5 ms per GiB against 5.5 for the
 // ranking kernel: ~0.6 G scattered 4-byte accesses cost ~8 cycles each per CU.)
-constexpr int TS = 16;                  // segments per wavefront
+constexpr int TS = 8;                   // segments per wavefront (8: 18 wavefronts per CU; 16 was 8 % slower, the phases of a tile overlap less)
 constexpr int TSLACK = 2;               // position p of a row is word TSLACK + p: the two ids of a first token fit in front of it
 constexpr int TROW = SEG + 8;           // words per tile row (16-byte multiple; the odd multiple of 8 spreads the rows over the LDS banks)
 
@@ -1178,7 +1178,7 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
   const uint64_t nseg = b->nseg;
   if (nseg > 0 && !(debug_flags() & 128)) {
     launch_seg_params(b, st);
-    k_score_tiles<5><<<(uint32_t)std::min<uint64_t>((nseg + 5 * TS - 1) / (5 * TS), (uint64_t)n_cu), 5 * 64, 0, st>>>(
+    k_score_tiles<10><<<(uint32_t)std::min<uint64_t>((nseg + 10 * TS - 1) / (10 * TS), (uint64_t)n_cu), 10 * 64, 0, st>>>(
         b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_seg_par, nseg, delete_id, d_hist, d_tokens, d_missing_bits, b->d_error);
   }
   else if (nseg > 0)
