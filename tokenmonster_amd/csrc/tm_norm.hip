@@ -52,7 +52,7 @@ __device__ __forceinline__ bool npunct3(uint32_t b1, uint32_t b2) {   // E2 b1 b
 }
 __device__ __forceinline__ bool nblock(uint32_t cls) { return cls == NC_U || cls == NC_N || cls == NC_AP; }
 
-struct PieceLds { uint8_t raw[PLDS]; uint8_t f[PLDS]; };
+struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
 
 // stage the piece (+ margins) and classify every byte; continuation bytes inherit the class of their lead byte.
 // returns the piece length; LDS index of document byte (pb + i) is PMARGIN + i.
@@ -71,21 +71,34 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-  for (int i = 2 + lane; i < PLDS - 2; i += 64) {
-    const uint32_t b = L.raw[i];
-    uint32_t fl;
-    if (b < 0x80u) fl = s_cls[b];                         // class of an ASCII byte: one LDS read instead of five range checks
-    else {
-      const uint32_t m1 = L.raw[i - 1], m2 = L.raw[i - 2], p1 = L.raw[i + 1], p2 = L.raw[i + 2];
-      uint32_t b1 = 0, b2 = 0, cont = 0;
-      bool ok = false;
-      if (b == 0xE2u) { b1 = p1; b2 = p2; ok = true; }
-      else if (m1 == 0xE2u) { b1 = b; b2 = p1; cont = NF_CONT; ok = true; }
-      else if (m2 == 0xE2u) { b1 = m1; b2 = b; cont = NF_CONT; ok = true; }
-      ok = ok && npunct3(b1, b2);
-      fl = ok ? (((b1 == 0x80u && b2 == 0x99u) ? NC_AP : NC_O) | cont) : NF_BAD;
+  // four bytes per lane and step; a dword of plain ASCII (nearly all of them) is four table reads, anything else goes byte by byte
+  for (int i = lane; i < PLDS / 4; i += 64) {
+    const uint32_t w4 = reinterpret_cast<const uint32_t*>(L.raw)[i];
+    uint32_t f4;
+    if ((w4 & 0x80808080u) == 0u) {
+      f4 = (uint32_t)s_cls[w4 & 0xFFu] | ((uint32_t)s_cls[(w4 >> 8) & 0xFFu] << 8) | ((uint32_t)s_cls[(w4 >> 16) & 0xFFu] << 16) | ((uint32_t)s_cls[w4 >> 24] << 24);
+    } else {
+      f4 = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int x = 4 * i + q;
+        const uint32_t b = (w4 >> (8 * q)) & 0xFFu;
+        uint32_t fl = 0;                                    // (the two bytes at either end of the staged range are never looked at)
+        if (b < 0x80u) fl = s_cls[b];                       // class of an ASCII byte: one LDS read instead of five range checks
+        else if (x >= 2 && x < PLDS - 2) {
+          const uint32_t m1 = L.raw[x - 1], m2 = L.raw[x - 2], p1 = L.raw[x + 1], p2 = L.raw[x + 2];
+          uint32_t b1 = 0, b2 = 0, cont = 0;
+          bool ok = false;
+          if (b == 0xE2u) { b1 = p1; b2 = p2; ok = true; }
+          else if (m1 == 0xE2u) { b1 = b; b2 = p1; cont = NF_CONT; ok = true; }
+          else if (m2 == 0xE2u) { b1 = m1; b2 = b; cont = NF_CONT; ok = true; }
+          ok = ok && npunct3(b1, b2);
+          fl = ok ? (((b1 == 0x80u && b2 == 0x99u) ? NC_AP : NC_O) | cont) : NF_BAD;
+        }
+        f4 |= fl << (8 * q);
+      }
     }
-    L.f[i] = (uint8_t)fl;
+    reinterpret_cast<uint32_t*>(L.f)[i] = f4;
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
@@ -101,13 +114,14 @@ __global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict_
   __shared__ uint8_t s_cls[128];
   if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // (wave-uniform wavefront index: the run bookkeeping below is arithmetic on ballots and then runs on the scalar unit)
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
   if (k >= npieces) return;
   PieceLds& L = s_l[wv];
   const uint32_t d = piece_doc[k];
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls);
+  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls));
   bool lead_open = true, lead_tl = false, bad = false;
   uint32_t lead_u = 0, trail_u = 0;
   for (int c = 0; c * 64 < m; c++) {
