@@ -7,13 +7,15 @@
 // Here it is a byte trie whose accepting nodes ARE the record ordinals:
 //   depth 1   root[256]            (staged in LDS by every workgroup)
 //   depth 2   tab[0..65535]        direct map on the first two bytes (512 KiB, L2-resident)
-//   depth >=3 tab[..]              open-addressing hash of (parent node, byte) -> child, 16 B per slot
-//             (one table, one 16-byte load per probe whatever the depth: every walk step is the same instruction)
-// Every entry a walk can stand on carries the 32-bit CHILD FILTER of its node (bit b & 31 set <=> the node has a child over some
-// byte congruent to b): the next probe is only issued if the bit of the next text byte is set.  Half of all positions end on a
-// probe that cannot hit, and with linear probing such a probe is ~1.5 gathers; most nodes have a single child, so the filter
-// removes 97 % of them (tools/a1_sim.cpp: 3.44 -> 2.76 gathers per position).  The match kernel is bound by the rate at which
-// the L2 of an XCD serves these 16-byte gathers, so a gather not issued is time saved.
+//   depth >=3 tab[..]              open-addressing hash of (parent node, byte) -> child, 8 B per slot
+//             (one table, one load per probe whatever the depth: every walk step is the same instruction)
+// Every entry a walk can stand on carries a CHILD FILTER of its node: the next probe is only issued if the bit of the next text
+// byte is set.  Half of all positions end on a probe that cannot hit, and with linear probing such a probe is ~1.5 gathers.
+// Link-format entries (16 B) have room for 32 bits (bit b & 31: the node has a child over some byte congruent to b); a hash
+// slot keeps 4 bits (bit b & 3) in the top of its key word, so that the table stays 8 B per slot: with 16-byte slots and 32 bits
+// everywhere the walk needs 2.76 instead of 3.44 gathers per position (tools/a1_sim.cpp) but the tables of the 32 000-id
+// vocabulary grow from 4.3 to 6.4 MB, past the 4 MB L2 of an XCD — measured: HBM fetches of the match kernel x5 and the time
+// unchanged.  With 4 bits in the slots it is 2.89 gathers per position at the old size.
 // A 32-bit node value carries everything a look-ahead needs about the token it accepts, so scoring a
 // branch never touches the row table:
 //   bits  0..20  node id; id < n_info  <=>  the prefix is a vocabulary key and id is its record ordinal
@@ -33,7 +35,8 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kNodeBits = 21;
 constexpr uint32_t kNodeMask = (1u << kNodeBits) - 1;
 constexpr uint32_t kHasChildren = 1u << 21;
-constexpr uint32_t kMaxNodes = kNodeMask - 1;
+constexpr uint32_t kMaxNodes = (1u << 20) - 2;       // 20 bits: the top four bits of a hash slot's key word hold its child filter
+constexpr uint32_t kKeyMask = 0x0FFFFFFFu;          // parent node << 8 | byte
 constexpr uint32_t kL2Size = 65536;
 constexpr uint32_t kDirectSlots = 2 * kL2Size;   // the direct map in uint2 units (16-byte entries)
 
@@ -64,10 +67,10 @@ struct alignas(16) Row { uint32_t x, y, z, w; };
 
 struct Tables {
   const uint32_t* root;    // [256]
-  const uint2* tab;        // one table for everything a walk gathers (8-byte units; every entry takes two = one 16-byte load):
-                           //   [0, 2*(mask+2))         depth>=3 edge hash, slot = {parent<<8|byte (kNone = empty slot), node value,
-                           //                           child filter of that node, -}; home slot edge_hash >> edge_shift, linear
-                           //                           probing; the slot behind the table stays empty (idle walks probe it)
+  const uint2* tab;        // one table for everything a walk gathers (8-byte units; link-format entries take two):
+                           //   [0, mask+1]             depth>=3 edge hash, x = parent<<8|byte | 4-bit child filter of the child << 28
+                           //                           (kNone = empty slot), y = node value; home slot edge_hash >> edge_shift,
+                           //                           linear probing; the slot behind the table stays empty (idle walks probe it)
                            //   [direct_off/8, +2*65536) direct map on the first two bytes, index b0 | b1<<8 (the little-endian u16 at
                            //                           the position), link format: the whole answer for depth <= 2 and, if the
                            //                           node b0b1 has children, where to go on

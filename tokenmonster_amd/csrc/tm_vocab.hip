@@ -179,8 +179,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   // ~1.5 gathers) is almost never issued: most nodes have one child.
   std::vector<uint32_t> cmask(n_nodes, 0);
   for (auto& kv : child) { const uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) cmask[parent] |= 1u << (kv.first & 31u); }
-  // one allocation (tm_tables.h): edge hash (16-byte slots) | always-empty slot | direct map | suffix links
-  const size_t direct_base = 2 * (((size_t)1 << bits) + 1);                   // in 8-byte units; 16-byte aligned
+  // one allocation (tm_tables.h): edge hash | always-empty slot | direct map | suffix links
+  const size_t direct_base = (((size_t)1 << bits) + 1 + 1) & ~(size_t)1;      // 16-byte aligned
   const size_t link_base = direct_base + kDirectSlots;
   hv.direct_off = (uint32_t)(direct_base * sizeof(uint2));
   hv.link_off = (uint32_t)(link_base * sizeof(uint2));
@@ -195,9 +195,10 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     else if (d >= 3) {
       uint32_t key = (parent << 8) | byte;
       uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;
-      while (edges[2 * (size_t)h].x != kNone) h = (h + 1) & hv.edge_mask;
-      edges[2 * (size_t)h] = uint2{key, value_of(kv.second)};
-      edges[2 * (size_t)h + 1] = uint2{cmask[kv.second], 0u};                   // the filter of the node the edge leads to
+      while (edges[h].x != kNone) h = (h + 1) & hv.edge_mask;
+      uint32_t f4 = 0;                                                           // 4-bit filter of the node the edge leads to
+      for (uint32_t q = 0; q < 32; q++) if ((cmask[kv.second] >> q) & 1u) f4 |= 1u << (q & 3u);
+      edges[h] = uint2{key | (f4 << 28), value_of(kv.second)};
     }
   }
   // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.

@@ -35,17 +35,17 @@ int main(int argc, char** argv) {
   const uint64_t N = off[nd];
   printf("vocab: n_info %u nodes %u edge slots %u (mask %x) tab bytes %zu; corpus %llu docs %u\n", hv.n_info, hv.n_nodes, hv.edge_mask + 1,
          hv.edge_mask, hv.tab.size() * 8, (unsigned long long)N, nd);
-  // NOTE: 16-byte hash slots {key, value | child filter, -}; link format {x, y | child filter, best depth}
+  // hash slots {key | 4-bit child filter << 28, value}; link format {x, y | child filter, best depth}
 
   // child-byte masks per node (from the edge hash: all edges into depth >= 3)
   std::vector<uint64_t> cmask(hv.n_nodes, 0);
   std::vector<uint32_t> nchild(hv.n_nodes, 0);
   uint64_t nedges = 0;
   for (uint32_t s = 0; s <= hv.edge_mask; s++) {
-    const uint2 e = hv.tab[2 * (size_t)s];
+    const uint2 e = hv.tab[s];
     if (e.x == kNone) continue;
-    cmask[e.x >> 8] |= 1ull << (e.x & 63u);
-    nchild[e.x >> 8]++;
+    cmask[(e.x & kKeyMask) >> 8] |= 1ull << (e.x & 63u);
+    nchild[(e.x & kKeyMask) >> 8]++;
     nedges++;
   }
   {
@@ -60,9 +60,10 @@ int main(int argc, char** argv) {
   const uint2* link = tab + hv.link_off / 8;
   const int Lmax = (int)hv.max_len;
 
-  // variants: 0 = has-children bit only (no filter); 1 = the 32-bit filter words stored in the tables (what the kernel does); 2 = ideal 64-bit filter
+  // variants: 0 = has-children bit only (no filter); 1 = the filters stored in the tables (what the kernel does: 32 bits behind a
+  // link-format entry, 4 bits in a hash slot); 2 = ideal 64-bit filter everywhere
   std::vector<uint64_t> sigs; uint64_t sig_bad = 0;
-  for (int variant = 0; variant < 3; variant++) {
+  for (int variant = 0; variant < 4; variant++) {   // 3: filter only in the link-format entries
     Stats st;
     std::vector<uint32_t> round_hist(128, 0);
     for (uint32_t d = 0; d < nd; d++) {
@@ -95,18 +96,20 @@ int main(int argc, char** argv) {
             depth = (int)((src >> 23) & 63u);
             node = src & kNodeMask;
             int bestlen = (int)e[1].y;
+            bool from_set = true;
             bool go = (src & kHasChildren) != 0 && depth < limit;
             while (go) {
               const uint32_t c = at(pos + depth);
-              if (variant == 1) { if (!((filt >> (c & 31u)) & 1u)) { st.filtered++; break; } }
+              if (variant == 1) { if (from_set ? !((filt >> (c & 31u)) & 1u) : !((filt >> (c & 3u)) & 1u)) { st.filtered++; break; } }
+              else if (variant == 3) { if (from_set && !((filt >> (c & 31u)) & 1u)) { st.filtered++; break; } }
               else if (variant == 2) { if (!((cmask[node] >> (c & 63u)) & 1ull)) { st.filtered++; break; } }
               const uint32_t key = (node << 8) | c;
               uint32_t h = edge_hash(node, c) >> hv.edge_shift;
               bool hit = false;
               for (;;) {
                 rounds++;
-                const uint2 s = tab[2 * (size_t)h];
-                if (s.x == key) { hit = true; st.hit++; src = s.y; filt = tab[2 * (size_t)h + 1].x; break; }
+                const uint2 s = tab[h];
+                if ((s.x & kKeyMask) == key) { hit = true; st.hit++; src = s.y; filt = (tab[h].x >> 28); from_set = false; break; }
                 if (s.x == kNone) { st.miss++; break; }
                 st.again++;
                 h = (h + 1) & hv.edge_mask;
@@ -169,7 +172,7 @@ int main(int argc, char** argv) {
               const uint32_t key = (node << 8) | c;
               uint32_t h = edge_hash(node, c) >> hv.edge_shift;
               bool hit = false;
-              for (;;) { rounds++; const uint2 sl = tab[2 * (size_t)h]; if (sl.x == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
+              for (;;) { rounds++; const uint2 sl = tab[h]; if ((sl.x & kKeyMask) == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
               if (!hit) break;
               depth++; node = src & kNodeMask; go = (src & kHasChildren) != 0 && depth < limit;
             }
@@ -226,7 +229,7 @@ int main(int argc, char** argv) {
               const uint32_t key = (node << 8) | c;
               uint32_t h = edge_hash(node, c) >> hv.edge_shift;
               bool hit = false;
-              for (;;) { rounds++; const uint2 sl = tab[2 * (size_t)h]; if (sl.x == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
+              for (;;) { rounds++; const uint2 sl = tab[h]; if ((sl.x & kKeyMask) == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
               if (!hit) break;
               depth++; node = src & kNodeMask; go = (src & kHasChildren) != 0 && depth < limit;
             }
