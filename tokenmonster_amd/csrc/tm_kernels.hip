@@ -1150,8 +1150,10 @@ using namespace tmh;
 
 namespace tmh {
 
-// K1 development switches (tm_debug_flags; TM_DBG in the environment sets the initial value): bit 0 no walks at all, 2 no hash
-// probes, 3 no forward-delete probes, 4 no exit maps, 6 dense T(p,1) array for every segment.  0 in production.
+// development switches (tm_debug_flags; TM_DBG in the environment sets the initial value).  K1 phases off (wrong results, for
+// profiling): bit 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps; bit 9: 4 KB of dummy LDS per K1
+// workgroup (24 instead of 28 wavefronts per CU).  Alternative implementations with the same results: bit 6 dense T(p,1) array for
+// every segment, 7 list-ranking K4, 8 per-lane normalizer kernel.  0 in production.
 int g_debug_flags = -1;
 int debug_flags() {
   if (g_debug_flags < 0) { const char* e = getenv("TM_DBG"); g_debug_flags = e ? atoi(e) : 0; }
