@@ -149,10 +149,10 @@ struct Walk { int pos, tbase, depth, limit, bestlen; uint32_t hoff, key, bestv; 
 constexpr uint32_t KEY_IDLE = 0xFFFFFFFEu;
 __device__ __forceinline__ bool walk_idle(const Walk& k) { return k.key == KEY_IDLE; }
 __device__ __forceinline__ uint32_t edge_slot_offset(const Tables& T, uint32_t node, uint32_t byte) {
-  return (edge_hash(node, byte) >> T.edge_shift) << 3;     // byte offset of the home slot
+  return (edge_hash(node, byte) >> T.edge_shift) << 4;     // byte offset of the home bucket (two 8-byte slots)
 }
-__device__ __forceinline__ uint2 load_slot(const uint2* hash_tab, uint32_t hoff) {
-  return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hash_tab) + hoff);   // scalar base + 32-bit lane offset
+__device__ __forceinline__ uint4 load_slot(const uint2* hash_tab, uint32_t hoff) {          // a bucket: {key0, value0, key1, value1}
+  return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hash_tab) + hoff);   // scalar base + 32-bit lane offset
 }
 // child filter (tm_tables.h): can the node have a child over byte c?  32 bits in a link-format entry, 4 in the key word of a slot
 __device__ __forceinline__ bool child_possible32(uint32_t m, uint32_t c) { return ((m >> (c & 31u)) & 1u) != 0; }
@@ -163,18 +163,19 @@ __device__ __forceinline__ bool child_possible4(uint32_t key_word, uint32_t c) {
 // Written without branches: every lane executes the same instructions, so the NWALK loads of a round are issued back
 // to back and the round has a single wait.  `c` is the text byte after the one being matched (text[tbase+depth+1]),
 // read from LDS while the probe was in flight.  Returns true when the slot is (or has become) idle.
-__device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uint2 e, const uint32_t c) {
-  const bool hit = (e.x & kKeyMask) == k.key;
-  const bool again = !hit && e.x != kNone;                        // occupied by another key: linear probing
-  const uint32_t cur = e.y, nid = node_id(cur);
+__device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uint4 e, const uint32_t c) {
+  const bool hit1 = (e.z & kKeyMask) == k.key;
+  const bool hit = hit1 || (e.x & kKeyMask) == k.key;
+  const bool again = !hit && e.z != kNone;                        // both slots taken by other keys: the next bucket
+  const uint32_t cur = hit1 ? e.w : e.y, kw = hit1 ? e.z : e.x, nid = node_id(cur);
   k.depth += hit ? 1 : 0;
   const bool acc = hit && nid < T.n_info;
   k.bestv = acc ? cur : k.bestv;
   k.bestlen = acc ? k.depth : k.bestlen;
-  const bool cont = hit && k.depth < k.limit && child_possible4(e.x, c);
-  const uint32_t lin = (k.hoff + 8u) & (T.edge_mask << 3);
+  const bool cont = hit && k.depth < k.limit && child_possible4(kw, c);
+  const uint32_t lin = (k.hoff + 16u) & (T.edge_mask << 4);
   k.key = cont ? ((nid << 8) | c) : (again ? k.key : KEY_IDLE);
-  k.hoff = cont ? edge_slot_offset(T, nid, c) : (again ? lin : (T.edge_mask + 1u) << 3);
+  k.hoff = cont ? edge_slot_offset(T, nid, c) : (again ? lin : (T.edge_mask + 1u) << 4);
   return !(cont || again);
 }
 
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
   const int Lmax = (int)T.max_len;
   const unsigned long long lane_below = (1ull << lane) - 1ull;
   const uint2* __restrict__ hash_tab = T.tab;
-  const uint32_t idle_off = (T.edge_mask + 1u) << 3;      // the always-empty slot behind the edge hash
+  const uint32_t idle_off = (T.edge_mask + 1u) << 4;      // the always-empty bucket behind the edge hash
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
   const uint64_t rem = doc_end[doc] - begin;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
     // work they skip); the LDS bytes a round may need — the next key byte, the first two bytes of the next position —
     // are read while the gather is in flight.
     const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
-    const uint32_t mask8 = T.edge_mask << 3;
+    const uint32_t mask16 = T.edge_mask << 4;
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
     const int nwalkpos = (dl <= NPOS) ? ntask - 1 : ntask;          // positions with at least two bytes of text left
     if (lane == 0 && dl <= NPOS && ntask > 0) {
@@ -357,24 +358,26 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
       constexpr bool TAIL = decltype(tail_tag)::value;
       // a lane is busy exactly as long as its gather address is not the idle slot
       while (__builtin_amdgcn_ballot_w64(off != idle_off) != 0ull) {
-        const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // link format {x, y, child filter, best depth}, or a hash slot {key | filter, value} (upper half ignored)
+        const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // link format {x, y, child filter, best depth}, or a hash bucket {key0 | filter, value0, key1 | filter, value1}
         uint32_t c = *(lds_u8*)(uintptr_t)pfa;
         uint32_t nn = *(lds_u16u*)(uintptr_t)(posa + 1u);                // the two bytes at the next position, as the direct map indexes them
         asm volatile("" : "+v"(c), "+v"(nn));                            // both LDS reads are issued here, under the gather's latency
-        const bool hit = probing && (e.x & kKeyMask) == key;
-        const bool again = probing && !hit && e.x != kNone;              // occupied by another key: linear probing
+        const bool hit1 = probing && (e.z & kKeyMask) == key;
+        const bool hit = hit1 || (probing && (e.x & kKeyMask) == key);
+        const bool again = probing && !hit && e.z != kNone;              // both slots of the bucket hold other keys: next bucket
         const bool adv = hit || setting;                                 // the walk state is (re)set this round
-        const uint32_t src = hit ? e.y : e.x;                            // bits 0..20 node, bit 21 "has children" / "go on"
+        const uint32_t hv = hit1 ? e.w : e.y, hk = hit1 ? e.z : e.x;     // the slot that hit
+        const uint32_t src = hit ? hv : e.x;                             // bits 0..20 node
         const uint32_t nid = src & kNodeMask;
         if (hit) depth++;
         if (setting) { depth = (int)((e.x >> 23) & 63u); bestv = e.y; bestlen = (int)e.w; }
         if (adv) node = nid;
-        if (hit && nid < T.n_info) { bestv = e.y; bestlen = depth; }
+        if (hit && nid < T.n_info) { bestv = hv; bestlen = depth; }
         // probe only for a byte the node can continue with (32-bit filter behind a link, 4 bits in the key word of a slot)
-        const bool go = adv && (setting ? child_possible32(e.z, c) : child_possible4(e.x, c)) && depth < (TAIL ? limit : Lmax) && !nowalk;
+        const bool go = adv && (setting ? child_possible32(e.z, c) : child_possible4(hk, c)) && depth < (TAIL ? limit : Lmax) && !nowalk;
         const bool fin = (adv && !go) || (probing && !hit && !again);
         if (go) { key = (nid << 8) | c; off = edge_slot_offset(T, nid, c); pfa = posa + (uint32_t)depth + 1u; }
-        if (again) off = (off + 8u) & mask8;
+        if (again) off = (off + 16u) & mask16;
         probing = go || again;
         setting = false;
         if (fin) {
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
         }
       }
       while (__any(!walk_idle(k))) {
-        const uint2 e = load_slot(hash_tab, k.hoff);
+        const uint4 e = load_slot(hash_tab, k.hoff);
         const uint32_t c = w.text[k.tbase + k.depth + 1];
         if (walk_consume(T, k, e, c) && k.bestlen > mainlen + 1) {
           const int lb = k.bestlen - off;                              // go :1093

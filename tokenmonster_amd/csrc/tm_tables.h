@@ -7,8 +7,9 @@
 // Here it is a byte trie whose accepting nodes ARE the record ordinals:
 //   depth 1   root[256]            (staged in LDS by every workgroup)
 //   depth 2   tab[0..65535]        direct map on the first two bytes (512 KiB, L2-resident)
-//   depth >=3 tab[..]              open-addressing hash of (parent node, byte) -> child, 8 B per slot
-//             (one table, one load per probe whatever the depth: every walk step is the same instruction)
+//   depth >=3 tab[..]              open-addressing hash of (parent node, byte) -> child: 16-byte buckets of two 8-byte slots
+//             (one table, one 16-byte load per probe whatever the depth: every walk step is the same instruction; the load
+//             sees both slots of the bucket, so at load 0.3 a key is almost always found — or known absent — in one gather)
 // Every entry a walk can stand on carries a CHILD FILTER of its node: the next probe is only issued if the bit of the next text
 // byte is set.  Half of all positions end on a probe that cannot hit, and with linear probing such a probe is ~1.5 gathers.
 // Link-format entries (16 B) have room for 32 bits (bit b & 31: the node has a child over some byte congruent to b); a hash
@@ -68,9 +69,10 @@ struct alignas(16) Row { uint32_t x, y, z, w; };
 struct Tables {
   const uint32_t* root;    // [256]
   const uint2* tab;        // one table for everything a walk gathers (8-byte units; link-format entries take two):
-                           //   [0, mask+1]             depth>=3 edge hash, x = parent<<8|byte | 4-bit child filter of the child << 28
-                           //                           (kNone = empty slot), y = node value; home slot edge_hash >> edge_shift,
-                           //                           linear probing; the slot behind the table stays empty (idle walks probe it)
+                           //   [0, 2*(mask+2))         depth>=3 edge hash, bucket b = slots 2b, 2b+1 (slot 0 fills first); slot x = parent<<8|byte
+                           //                           | 4-bit child filter of the child << 28 (kNone = empty), y = node value; home
+                           //                           bucket edge_hash >> edge_shift, a full bucket overflows into the next one; the
+                           //                           bucket behind the table stays empty (idle walks probe it)
                            //   [direct_off/8, +2*65536) direct map on the first two bytes, index b0 | b1<<8 (the little-endian u16 at
                            //                           the position), link format: the whole answer for depth <= 2 and, if the
                            //                           node b0b1 has children, where to go on
@@ -86,7 +88,7 @@ struct Tables {
                            //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node
   const Row* rows;         // [n_info]
   const uint8_t* begin_byte;  // [256]  go/tokenmonster.go:43
-  uint32_t edge_mask, edge_shift;
+  uint32_t edge_mask, edge_shift;     // bucket mask / hash shift
   uint32_t n_info, max_len;
   uint32_t off;            // 1, or 2 for UTF-16 (lilbufOffset, go :1031-1034)
   uint32_t bstart;         // node value after consuming ' ' (and 0x00 for UTF-16), kNone if absent

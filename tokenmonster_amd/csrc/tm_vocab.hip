@@ -172,15 +172,17 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   for (auto& kv : child) if (depth_of[kv.second] >= 3) n_edges++;
   uint32_t bits = 4;
   while ((1ull << bits) < n_edges * 5 / 2 + 8) bits++;
-  hv.edge_mask = (1u << bits) - 1;
-  hv.edge_shift = 32 - bits;
+  // two slots per 16-byte bucket: a probe is one 16-byte gather and sees both, so at this load nearly every key sits in the
+  // bucket it hashes to (the walk's "occupied by another key, try the next slot" rounds all but disappear)
+  hv.edge_mask = (1u << (bits - 1)) - 1;           // bucket mask
+  hv.edge_shift = 32 - (bits - 1);
   // child-byte filter of every node: bit (b & 31) is set if the node has a child over byte b.  A walk only probes the edge hash
   // for a byte whose bit is set, so a probe that cannot hit (half of all positions end on one, and with linear probing it is
   // ~1.5 gathers) is almost never issued: most nodes have one child.
   std::vector<uint32_t> cmask(n_nodes, 0);
   for (auto& kv : child) { const uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) cmask[parent] |= 1u << (kv.first & 31u); }
   // one allocation (tm_tables.h): edge hash | always-empty slot | direct map | suffix links
-  const size_t direct_base = (((size_t)1 << bits) + 1 + 1) & ~(size_t)1;      // 16-byte aligned
+  const size_t direct_base = 2 * (((size_t)hv.edge_mask + 1) + 1);            // buckets + the always-empty one, in 8-byte units
   const size_t link_base = direct_base + kDirectSlots;
   hv.direct_off = (uint32_t)(direct_base * sizeof(uint2));
   hv.link_off = (uint32_t)(link_base * sizeof(uint2));
@@ -194,11 +196,11 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     if (d == 2) l2v[(first_byte[parent] << 8) | byte] = value_of(kv.second);
     else if (d >= 3) {
       uint32_t key = (parent << 8) | byte;
-      uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;
-      while (edges[h].x != kNone) h = (h + 1) & hv.edge_mask;
+      uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;                     // home bucket; slot 0 fills before slot 1
+      while (edges[2 * (size_t)h + 1].x != kNone) h = (h + 1) & hv.edge_mask;
       uint32_t f4 = 0;                                                           // 4-bit filter of the node the edge leads to
       for (uint32_t q = 0; q < 32; q++) if ((cmask[kv.second] >> q) & 1u) f4 |= 1u << (q & 3u);
-      edges[h] = uint2{key | (f4 << 28), value_of(kv.second)};
+      edges[2 * (size_t)h + (edges[2 * (size_t)h].x != kNone ? 1 : 0)] = uint2{key | (f4 << 28), value_of(kv.second)};
     }
   }
   // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.

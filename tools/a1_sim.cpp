@@ -33,15 +33,15 @@ int main(int argc, char** argv) {
   uint8_t* text = nullptr; std::vector<uint64_t> off(nd + 1);
   if (tm_normalize_batch(raw.data(), roff.data(), nd, capcode, 1, 0, &text, off.data()) != 0) { fprintf(stderr, "normalize failed\n"); return 1; }
   const uint64_t N = off[nd];
-  printf("vocab: n_info %u nodes %u edge slots %u (mask %x) tab bytes %zu; corpus %llu docs %u\n", hv.n_info, hv.n_nodes, hv.edge_mask + 1,
+  printf("vocab: n_info %u nodes %u edge buckets (2 slots each) %u (mask %x) tab bytes %zu; corpus %llu docs %u\n", hv.n_info, hv.n_nodes, hv.edge_mask + 1,
          hv.edge_mask, hv.tab.size() * 8, (unsigned long long)N, nd);
-  // hash slots {key | 4-bit child filter << 28, value}; link format {x, y | child filter, best depth}
+  // hash buckets of two slots {key | 4-bit child filter << 28, value}; link format {x, y | child filter, best depth}
 
   // child-byte masks per node (from the edge hash: all edges into depth >= 3)
   std::vector<uint64_t> cmask(hv.n_nodes, 0);
   std::vector<uint32_t> nchild(hv.n_nodes, 0);
   uint64_t nedges = 0;
-  for (uint32_t s = 0; s <= hv.edge_mask; s++) {
+  for (uint32_t s = 0; s < 2 * (hv.edge_mask + 1); s++) {
     const uint2 e = hv.tab[s];
     if (e.x == kNone) continue;
     cmask[(e.x & kKeyMask) >> 8] |= 1ull << (e.x & 63u);
@@ -106,11 +106,12 @@ int main(int argc, char** argv) {
               const uint32_t key = (node << 8) | c;
               uint32_t h = edge_hash(node, c) >> hv.edge_shift;
               bool hit = false;
-              for (;;) {
+              for (;;) {                                                  // one gather = one bucket of two slots
                 rounds++;
-                const uint2 s = tab[h];
-                if ((s.x & kKeyMask) == key) { hit = true; st.hit++; src = s.y; filt = (tab[h].x >> 28); from_set = false; break; }
-                if (s.x == kNone) { st.miss++; break; }
+                const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1];
+                if ((s0.x & kKeyMask) == key) { hit = true; st.hit++; src = s0.y; filt = s0.x >> 28; from_set = false; break; }
+                if ((s1.x & kKeyMask) == key) { hit = true; st.hit++; src = s1.y; filt = s1.x >> 28; from_set = false; break; }
+                if (s1.x == kNone) { st.miss++; break; }
                 st.again++;
                 h = (h + 1) & hv.edge_mask;
               }
@@ -172,7 +173,7 @@ int main(int argc, char** argv) {
               const uint32_t key = (node << 8) | c;
               uint32_t h = edge_hash(node, c) >> hv.edge_shift;
               bool hit = false;
-              for (;;) { rounds++; const uint2 sl = tab[h]; if ((sl.x & kKeyMask) == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
+              for (;;) { rounds++; const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1]; if ((s0.x & kKeyMask) == key) { hit = true; src = s0.y; break; } if ((s1.x & kKeyMask) == key) { hit = true; src = s1.y; break; } if (s1.x == kNone) break; h = (h + 1) & hv.edge_mask; }
               if (!hit) break;
               depth++; node = src & kNodeMask; go = (src & kHasChildren) != 0 && depth < limit;
             }
@@ -229,7 +230,7 @@ int main(int argc, char** argv) {
               const uint32_t key = (node << 8) | c;
               uint32_t h = edge_hash(node, c) >> hv.edge_shift;
               bool hit = false;
-              for (;;) { rounds++; const uint2 sl = tab[h]; if ((sl.x & kKeyMask) == key) { hit = true; src = sl.y; break; } if (sl.x == kNone) break; h = (h + 1) & hv.edge_mask; }
+              for (;;) { rounds++; const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1]; if ((s0.x & kKeyMask) == key) { hit = true; src = s0.y; break; } if ((s1.x & kKeyMask) == key) { hit = true; src = s1.y; break; } if (s1.x == kNone) break; h = (h + 1) & hv.edge_mask; }
               if (!hit) break;
               depth++; node = src & kNodeMask; go = (src & kHasChildren) != 0 && depth < limit;
             }
