@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "tm_pipeline.h"
@@ -643,7 +644,9 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   uint8_t* hnorm = nullptr;
   std::vector<uint64_t> noff(ids.size() + 1, 0);
   if (nf > 0) {
-    const uint32_t threads = (uint32_t)std::min<size_t>(128, ids.size() / 8 + 1);   // pooled workers
+    // pooled workers: up to 128, but only this process's share of the host when there is one process per GPU of the node
+    static const uint32_t host_share = std::max(8u, std::max(1u, std::thread::hardware_concurrency()) / (uint32_t)std::max(1, tm_device_count()));
+    const uint32_t threads = (uint32_t)std::min<size_t>(std::min<uint32_t>(128u, host_share), ids.size() / 8 + 1);
     hipError_t he = hipSuccess;
     int rc = normalize_batch_into(b->h_fb_raw, roff.data(), (uint32_t)ids.size(), capcode, norm_flag, threads, noff.data(), [&](uint64_t total) -> uint8_t* {
       if (!b->h_fb_norm || b->h_fb_norm_cap < total + 16) {                         // pinned: the H2D below then runs at link speed

@@ -95,7 +95,7 @@ struct tm_batch {
   uint64_t* d_ninfo = nullptr;          // [0] #fallback docs [1] #long docs [2] #segments (device-computed)
   // grow-only staging for the host fallback
   uint8_t* d_fb_raw = nullptr; uint8_t* d_fb_norm = nullptr; uint64_t* d_fb_roff = nullptr; uint64_t* d_fb_noff = nullptr; uint32_t* d_fb_ids = nullptr;
-  uint64_t fb_raw_cap = 0, fb_norm_cap = 0; uint32_t fb_docs_cap = 0;
+  uint64_t fb_raw_cap = 0, fb_norm_cap = 0;
   uint8_t* h_fb_raw = nullptr; uint8_t* h_fb_norm = nullptr;     // pinned host staging of the fallback documents (raw in, normalized out)
   uint64_t h_fb_raw_cap = 0, h_fb_norm_cap = 0;
   uint32_t* d_out = nullptr;
