@@ -1017,7 +1017,7 @@ __device__ __forceinline__ uint32_t side_word(const uint2* __restrict__ sl, cons
 __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
                                                    const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
                                                    uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
-                                                   uint32_t* __restrict__ error_flag) {
+                                                   uint32_t* __restrict__ error_flag, uint32_t stage_after) {
   __shared__ alignas(16) uint32_t s_tile[TS][TROW];
   const int lane = threadIdx.x;
   const uint64_t g0 = (uint64_t)blockIdx.x * TS;
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
   tile_load(s_tile, t, nv, lane, R0);
   // Walk.  Id number E of the segment is staged in word E of its own row while that word lies before the position being read
   // (E < TSLACK + p: true unless the text averages more than one id per byte); from the first id that does not fit, the rest of
-  // the segment's ids go straight to HBM.
+  // the segment's ids go straight to HBM.  (stage_after = 0; the tests pass 512 so that nothing is staged: debug bit 10.)
   uint32_t staged = 0;
   if (t.have) {
     uint32_t* row = s_tile[lane];
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
     bool direct = false;
     const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
     auto put = [&](uint32_t id) {
-      if (!direct && E < (uint32_t)TSLACK + p) { row[E] = id; staged = E + 1; }
+      if (!direct && E + stage_after < (uint32_t)TSLACK + p) { row[E] = id; staged = E + 1; }
       else { direct = true; if (t.base + E < out_cap) out[t.base + E] = id; }
       E++;
     };
@@ -1156,7 +1156,7 @@ namespace tmh {
 // development switches (tm_debug_flags; TM_DBG in the environment sets the initial value).  K1 phases off (wrong results, for
 // profiling): bit 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps; bit 9: 4 KB of dummy LDS per K1
 // workgroup (24 instead of 28 wavefronts per CU).  Alternative implementations with the same results: bit 6 dense T(p,1) array for
-// every segment, 7 list-ranking K4, 8 per-lane normalizer kernel.  0 in production.
+// every segment, 7 list-ranking K4, 8 per-lane normalizer kernel, 10 K4 tile walk without staging (every id stored directly).  0 in production.
 int g_debug_flags = -1;
 int debug_flags() {
   if (g_debug_flags < 0) { const char* e = getenv("TM_DBG"); g_debug_flags = e ? atoi(e) : 0; }
@@ -1210,7 +1210,7 @@ static void launch_emit(tm_batch* b, hipStream_t st) {
   else {
     launch_seg_params(b, st);
     k_emit_tiles<<<(uint32_t)((nseg + TS - 1) / TS), 64, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, b->out_cap, b->d_out,
-                                                                 b->d_error);
+                                                                 b->d_error, (debug_flags() & 1024) ? 512u : 0u);
   }
 }
 
