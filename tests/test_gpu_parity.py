@@ -98,11 +98,11 @@ def test_dense_forward_delete_path():
     check_docs(v, orc, docs[:10], "side-list path")
 
 
-@pytest.mark.parametrize("flags", [128, 128 | 64, 1024, 1024 | 64])
+@pytest.mark.parametrize("flags", [128, 128 | 64, 1024, 1024 | 64, 2048])
 def test_list_ranking_emit_variant(flags):
     """K4 is a chain walk through LDS tiles by default; debug bit 7 selects the list-ranking kernel (k_chain) for the emitting
     entry points and for the scoring pass, bit 10 makes the tile walk store every id directly (the path it takes when a text
-    averages more than one id per byte).  All must give the oracle's ids / histogram (bit 6: dense T(p,1) array as well)."""
+    averages more than one id per byte), bit 11 selects the experimental split pipeline (k_match_runs + k_match_branch<true>).  All must give the oracle's ids / histogram (bit 6: dense T(p,1) array as well)."""
     from tokenmonster_amd import _native as N
     rng = np.random.default_rng(78)
     toks = fuzz_vocab_tokens(rng, 2, 140)

@@ -265,13 +265,16 @@ __device__ unsigned long long g_phase[64 * 32];
 #endif
 
 
+// SPLIT (experimental, debug bit 11): step A1 has been done by k_match_runs; A[] holds len | record ordinal << 6 per position.
+template <bool SPLIT>
 __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
                                                                 const uint64_t* __restrict__ doc_end,
                                                                 const uint32_t* __restrict__ seg_doc,
                                                                 const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
                                                                 uint32_t* __restrict__ R0, uint2* __restrict__ side,
-                                                                uint32_t* __restrict__ R1, uint2* __restrict__ exitmap, int dbg) {
+                                                                uint32_t* __restrict__ R1, uint2* __restrict__ exitmap, int dbg,
+                                                                const uint32_t* __restrict__ A) {
   __shared__ uint32_t s_root[256];
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
@@ -318,7 +321,18 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
   PH(0)
   PH_COUNT(12, 1)
   const int ntask = (dbg & 1) ? 0 : min(NPOS, dl);     // positions >= dl keep descriptor 0 (nothing there)
-  {
+  if constexpr (SPLIT) {
+    // ---- A1 was done by k_match_runs: fetch the positions' words (coalesced) and the node values of the records (one dense
+    // gather per position, no dependency chain) -> D[p], X[p] exactly as the walk below leaves them
+    for (int p = lane; p < ntask; p += 64) {
+      const uint32_t wd = A[begin + p];
+      if (wd != 0) {
+        const uint32_t v = T.vals[wd >> 6];
+        w.D[p] = (wd & 63u) | ((v >> 22) << 6);
+        w.X[p] = v;
+      }
+    }
+  } else {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
     // A run is in one of two states.  SET: the gather is a link-format entry (a suffix link, or the direct map on the
     // first two bytes when there is nothing to link from) that says where the walk stands — node, depth, best match so
@@ -638,6 +652,105 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
   }
   PH(7)
   PH_FLUSH
+}
+
+// ---- split pipeline, experimental (debug bit 11; built and modelled in tools/a1_sim.cpp, see DESIGN.md "what comes next") ----
+// Step A1 alone: one wavefront walks a CHUNK of 1024 consecutive positions of one document, 16 per lane instead of 5, every
+// position of the document exactly once (no 40-position look-ahead walked twice).  The round is the one of k_match_branch;
+// a position's result, len | record ordinal << 6 (0: no match), is staged in LDS and leaves in coalesced stores.
+struct RunLds { alignas(16) uint8_t text[CHUNK + 96]; uint32_t out[CHUNK]; };
+
+__global__ __launch_bounds__(WAVES * 64, 7) void k_match_runs(Tables T, const uint8_t* __restrict__ text, const uint64_t* __restrict__ doc_begin,
+                                                              const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ chunk_doc,
+                                                              const uint64_t* __restrict__ doc_chunk_start, const uint64_t* __restrict__ nchunks,
+                                                              uint32_t* __restrict__ A) {
+  __shared__ uint32_t s_root[256];
+  __shared__ RunLds s_run[WAVES];
+  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+  s_root[threadIdx.x] = T.root[threadIdx.x];
+  __syncthreads();
+  const uint64_t k = (uint64_t)blockIdx.x * WAVES + wvi;
+  if (k >= *nchunks) return;
+  RunLds& w = s_run[wvi];
+  const int Lmax = (int)T.max_len;
+  const uint32_t idle_off = (T.edge_mask + 1u) << 4;
+  const uint32_t doc = chunk_doc[k];
+  const uint64_t begin = doc_begin[doc] + (k - doc_chunk_start[doc]) * CHUNK;
+  const uint64_t rem = doc_end[doc] - begin;
+  const int dl = rem > (uint64_t)(1 << 20) ? (1 << 20) : (int)rem;   // bytes of the document from `begin` on (clamped)
+  const int n = min(dl, CHUNK);                                       // positions of this chunk
+  for (int j = lane; j < (CHUNK + 96) / 4; j += 64) {                 // text + look-ahead; bytes behind the document read as 0 (quirk Q1)
+    uint32_t tw = 0;
+    if (4 * j < dl) {
+      __builtin_memcpy(&tw, text + begin + 4 * j, 4);
+      if (4 * j + 4 > dl) tw &= (1u << (8 * (dl - 4 * j))) - 1u;
+    }
+    reinterpret_cast<uint32_t*>(w.text)[j] = tw;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
+  const uint32_t mask16 = T.edge_mask << 4;
+  const int nwalkpos = (dl <= CHUNK) ? n - 1 : n;                     // the last byte of a document is looked up in root[], not walked
+  if (lane == 0 && dl <= CHUNK && n > 0) {
+    const uint32_t r = s_root[w.text[dl - 1]];
+    w.out[dl - 1] = (r != kNone && node_id(r) < T.n_info) ? (1u | (node_id(r) << 6)) : 0u;
+  }
+  typedef __attribute__((address_space(3))) uint8_t lds_u8;
+  typedef __attribute__((address_space(3), aligned(1))) uint16_t lds_u16u;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  const uint32_t tb = (uint32_t)(uintptr_t)(lds_u8*)w.text;
+  const uint32_t oconst = (uint32_t)(uintptr_t)(lds_u8*)w.out - 4u * tb;             // &out[i] == oconst + 4 * (tb + i)
+  const int run = (max(nwalkpos, 0) + 63) >> 6;
+  uint32_t posa = tb + (uint32_t)(lane * run);
+  const uint32_t enda = tb + (uint32_t)max(min(lane * run + run, nwalkpos), 0), dla = tb + (uint32_t)dl;
+  int depth = 0, limit = 0, bestlen = 0;
+  uint32_t pfa = tb, off = idle_off, key = 0u, bestv = 0u, node = 0u;
+  bool probing = false, setting = posa < enda;
+  if (setting) {
+    limit = min((int)(dla - posa), Lmax);
+    off = T.direct_off + ((uint32_t)*(lds_u16u*)(uintptr_t)posa << 4);
+    pfa = posa + 2u;
+  }
+  auto rounds = [&](auto tail_tag) {                                   // (the round of k_match_branch step A1, see there)
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    while (__builtin_amdgcn_ballot_w64(off != idle_off) != 0ull) {
+      const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);
+      uint32_t c = *(lds_u8*)(uintptr_t)pfa;
+      uint32_t nn = *(lds_u16u*)(uintptr_t)(posa + 1u);
+      asm volatile("" : "+v"(c), "+v"(nn));
+      const bool hit1 = probing && (e.z & kKeyMask) == key;
+      const bool hit = hit1 || (probing && (e.x & kKeyMask) == key);
+      const bool again = probing && !hit && e.z != kNone;
+      const bool adv = hit || setting;
+      const uint32_t hv = hit1 ? e.w : e.y, hk = hit1 ? e.z : e.x;
+      const uint32_t src = hit ? hv : e.x;
+      const uint32_t nid = src & kNodeMask;
+      if (hit) depth++;
+      if (setting) { depth = (int)((e.x >> 23) & 63u); bestv = e.y; bestlen = (int)e.w; }
+      if (adv) node = nid;
+      if (hit && nid < T.n_info) { bestv = hv; bestlen = depth; }
+      const bool go = adv && (setting ? child_possible32(e.z, c) : child_possible4(hk, c)) && depth < (TAIL ? limit : Lmax);
+      const bool fin = (adv && !go) || (probing && !hit && !again);
+      if (go) { key = (nid << 8) | c; off = edge_slot_offset(T, nid, c); pfa = posa + (uint32_t)depth + 1u; }
+      if (again) off = (off + 16u) & mask16;
+      probing = go || again;
+      setting = false;
+      if (fin) {
+        *(lds_u32*)(uintptr_t)(oconst + 4u * posa) = (uint32_t)bestlen | (node_id(bestv) << 6);   // no match: bestlen == 0 and bestv == 0
+        posa++;
+        setting = posa < enda;
+        if (TAIL) limit = min((int)(dla - posa), Lmax);
+        if (depth >= 3) { off = T.link_off + (node << 4); pfa = posa + (uint32_t)depth - 1u; }
+        else { off = T.direct_off + (nn << 4); pfa = posa + 2u; }
+        if (!setting) off = idle_off;
+      }
+    }
+  };
+  if (dl >= CHUNK + Lmax) rounds(std::false_type{}); else rounds(std::true_type{});
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int j = lane; j < n; j += 64) A[begin + j] = w.out[j];
 }
 
 // exit map entry (uint2): x = next entry state [0..7] | #id events << 8 ; y = #forward-deletes | #missing << 16
@@ -1156,7 +1269,8 @@ namespace tmh {
 // development switches (tm_debug_flags; TM_DBG in the environment sets the initial value).  K1 phases off (wrong results, for
 // profiling): bit 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps; bit 9: 4 KB of dummy LDS per K1
 // workgroup (24 instead of 28 wavefronts per CU).  Alternative implementations with the same results: bit 6 dense T(p,1) array for
-// every segment, 7 list-ranking K4, 8 per-lane normalizer kernel, 10 K4 tile walk without staging (every id stored directly).  0 in production.
+// every segment, 7 list-ranking K4, 8 per-lane normalizer kernel, 10 K4 tile walk without staging (every id stored directly),
+// 11 experimental split pipeline (k_match_runs + k_match_branch<true>).  0 in production.
 int g_debug_flags = -1;
 int debug_flags() {
   if (g_debug_flags < 0) { const char* e = getenv("TM_DBG"); g_debug_flags = e ? atoi(e) : 0; }
@@ -1284,11 +1398,28 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
     if (nseg > 0) k_segments<<<(uint32_t)((nseg + 255) / 256), 256, 0, st>>>(b->d_doc_seg_start, nd, nseg, b->d_seg_doc);
   }
   mark(1);
-  if (nseg > 0)
+  if (nseg > 0 && (debug_flags() & 2048)) {
+    // experimental split pipeline: k_match_runs (step A1 over 1 KiB chunks) + k_match_branch<true>
+    const uint64_t max_chunks = b->max_bytes / CHUNK + (uint64_t)b->max_docs + 2;
+    if (!b->d_A) {
+      if ((e = dalloc(b, &b->d_A, b->max_bytes + 64)) != hipSuccess || (e = dalloc(b, &b->d_doc_nchunk, (uint64_t)b->max_docs + 1)) != hipSuccess ||
+          (e = dalloc(b, &b->d_doc_chunk_start, (uint64_t)b->max_docs + 2)) != hipSuccess || (e = dalloc(b, &b->d_chunk_doc, max_chunks)) != hipSuccess)
+        return hip_fail(e, "hipMalloc (split pipeline)");
+    }
+    const uint64_t chunk_bound = b->nbytes / CHUNK + (uint64_t)nd + 1;       // the exact number is only on the device (d_totals[3])
+    k_doc_nseg<<<(nd + 255) / 256, 256, 0, st>>>(b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nchunk, (uint32_t)CHUNK);
+    scan_u32(b->d_doc_nchunk, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_chunk_start, st);
+    k_segments<<<(uint32_t)((chunk_bound + 255) / 256), 256, 0, st>>>(b->d_doc_chunk_start, nd, chunk_bound, b->d_chunk_doc);
+    k_match_runs<<<(uint32_t)((chunk_bound + WAVES - 1) / WAVES), WAVES * 64, 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_chunk_doc,
+                                                                                       b->d_doc_chunk_start, b->d_totals + 3, b->d_A);
+    k_match_branch<true><<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
+                                                                                      b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
+                                                                                      debug_flags(), b->d_A);
+  } else if (nseg > 0)
     // (debug bit 9: 4 KB of unused dynamic LDS per workgroup = 6 instead of 7 workgroups per CU, to measure what occupancy is worth)
-    k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, (debug_flags() & 512) ? 4096 : 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
+    k_match_branch<false><<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, (debug_flags() & 512) ? 4096 : 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
                                                                                 b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
-                                                                                debug_flags());
+                                                                                debug_flags(), nullptr);
   mark(2);
   if (nd > 0)
     k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_seg_entry, b->d_seg_tokbase,
@@ -1391,7 +1522,7 @@ int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm
 void tm_batch_free(tm_batch* b) {
   if (!b) return;
   void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R0, b->d_R1, b->d_side, b->d_exitmap, b->d_seg_entry,
-                  b->d_seg_tokbase, b->d_seg_par, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
+                  b->d_seg_tokbase, b->d_seg_par, b->d_A, b->d_doc_nchunk, b->d_doc_chunk_start, b->d_chunk_doc, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
                   b->d_error, b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
                   b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,
                   b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_raw, b->d_fb_norm, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids};

@@ -86,6 +86,7 @@ struct Tables {
   const uint2* spl;        // [n_info] "space-prefix link" of record s: where the walk of ' '+s (the forward-delete probe of
                            //   go/tokenmonster.go:1088-1095; ' ' 0x00 + s for UTF-16) ends up, so that probe only has to CONTINUE:
                            //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node
+  const uint32_t* vals;    // [n_info] node value of every record (the split pipeline hands positions over as record ordinals)
   const Row* rows;         // [n_info]
   const uint8_t* begin_byte;  // [256]  go/tokenmonster.go:43
   uint32_t edge_mask, edge_shift;     // bucket mask / hash shift

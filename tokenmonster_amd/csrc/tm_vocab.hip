@@ -245,6 +245,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     hv.rev_off[hv.n_ids] = (uint32_t)hv.rev_bytes.size();
   }
   // space-prefix links (walked above): x = node reached | continue << 21 | best accepting depth << 22, y = that node's value
+  hv.vals.resize(n_info);
+  for (uint32_t i = 0; i < n_info; i++) hv.vals[i] = value_of(i);
   hv.spl.assign(n_info, uint2{kNone, 0u});
   if (spl_start != kNone)
     for (uint32_t i = 0; i < n_info; i++)
@@ -320,6 +322,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
       (e = up((void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2))) != hipSuccess ||
       (e = up((void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row))) != hipSuccess ||
       (e = up((void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint2))) != hipSuccess ||
+      (e = up((void**)&v->d_vals, hv.vals.data(), hv.vals.size() * 4)) != hipSuccess ||
       (e = up((void**)&v->d_rev_off, hv.rev_off.data(), hv.rev_off.size() * 4)) != hipSuccess ||
       (e = up((void**)&v->d_rev_bytes, hv.rev_bytes.data(), hv.rev_bytes.size())) != hipSuccess ||
       (e = up((void**)&v->d_begin_byte, hv.begin_byte, 256)) != hipSuccess) {
@@ -327,7 +330,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
     return hip_fail(e, "vocabulary upload");
   }
   Tables& t = v->tables;
-  t.root = v->d_root; t.tab = v->d_tab; t.spl = v->d_spl; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
+  t.root = v->d_root; t.tab = v->d_tab; t.spl = v->d_spl; t.vals = v->d_vals; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
   t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
   t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint; t.link_off = hv.link_off; t.direct_off = hv.direct_off;
   t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
@@ -337,7 +340,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
 
 void tm_vocab_free(tm_vocab* v) {
   if (!v) return;
-  (void)hipFree(v->d_root); (void)hipFree(v->d_tab); (void)hipFree(v->d_spl); (void)hipFree(v->d_rev_off); (void)hipFree(v->d_rev_bytes); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
+  (void)hipFree(v->d_root); (void)hipFree(v->d_tab); (void)hipFree(v->d_spl); (void)hipFree(v->d_vals); (void)hipFree(v->d_rev_off); (void)hipFree(v->d_rev_bytes); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
   delete v;
 }
 
