@@ -324,13 +324,16 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
   if constexpr (SPLIT) {
     // ---- A1 was done by k_match_runs: fetch the positions' words (coalesced) and the node values of the records (one dense
     // gather per position, no dependency chain) -> D[p], X[p] exactly as the walk below leaves them
-    for (int p = lane; p < ntask; p += 64) {
-      const uint32_t wd = A[begin + p];
-      if (wd != 0) {
-        const uint32_t v = T.vals[wd >> 6];
-        w.D[p] = (wd & 63u) | ((v >> 22) << 6);
-        w.X[p] = v;
-      }
+    // (all loads of a kind issued back to back: two memory latencies for the segment, not ten)
+    uint32_t wd[NPOS_PAD / 64], vv[NPOS_PAD / 64];
+#pragma unroll
+    for (int it = 0; it < NPOS_PAD / 64; it++) { const int p = it * 64 + lane; wd[it] = p < ntask ? A[begin + p] : 0u; }
+#pragma unroll
+    for (int it = 0; it < NPOS_PAD / 64; it++) vv[it] = wd[it] != 0 ? T.vals[wd[it] >> 6] : 0u;
+#pragma unroll
+    for (int it = 0; it < NPOS_PAD / 64; it++) {
+      const int p = it * 64 + lane;
+      if (wd[it] != 0) { w.D[p] = (wd[it] & 63u) | ((vv[it] >> 22) << 6); w.X[p] = vv[it]; }
     }
   } else {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
