@@ -1,0 +1,76 @@
+// make_capcode_golden.js — pins capcode level 2 to the reference's OWN statement of it.
+//
+//   node tests/golden/make_capcode_golden.js > /tmp/capcode_js.json && gzip -9n -c /tmp/capcode_js.json > tests/golden/capcode_js.json.gz
+//
+// Evaluates /root/reference/javascript/tokenmonster.js from its "// ---- capcode.js ----" marker on, WHERE IT LIES
+// (nothing is copied into this repository), and runs the reference's capcode_encode (:900-1005) and CapcodeDecoder
+// (:1007-1065) on a seeded set of strings.  Runs in this container only (node 12 + /root/reference); the JSON it
+// prints is the committed fixture the CPU and -m gpu tests replay.
+//
+// Per string: in = UTF-8 of the raw string, nfd = UTF-8 of String.prototype.normalize('NFD') (what the pipeline feeds
+// capcode after go/tokenmonster.go:243), enc = capcode_encode(nfd), dec = CapcodeDecoder.decode(enc).  All base64.
+'use strict';
+const fs = require('fs');
+const vm = require('vm');
+
+const REF = '/root/reference/javascript/tokenmonster.js';
+const src = fs.readFileSync(REF, 'utf8');
+const at = src.indexOf('// ---- capcode.js ----');
+if (at < 0) throw new Error('capcode section not found in ' + REF);
+const ctx = {};
+vm.createContext(ctx);
+vm.runInContext(src.slice(at) + '\nthis.capcode_encode = capcode_encode; this.CapcodeDecoder = CapcodeDecoder;', ctx, { filename: REF });
+
+// xorshift32, seeded
+let state = 0x43415043;
+function rnd(n) { state ^= state << 13; state >>>= 0; state ^= state >>> 17; state ^= state << 5; state >>>= 0; return state % n; }
+function pick(a) { return a[rnd(a.length)]; }
+
+const lower = 'abcdefghijklmnopqrstuvwxyz'.split('');
+const upper = 'ABCDEFGHIJKLMNOPQRSTUVWXYZ'.split('');
+const digits = '0123456789'.split('');
+const punct = ' .,;:-_()[]{}<>/\\"!?@#$%^&*+=|~`\n\t'.split('');
+const apos = ["'", '’'];
+const gpunct = ['‘', '“', '”', '—', '–', '…', '•', ' ', ' '];
+const marks = ['́', '̀', '̈', '̧', '̃'];                 // combining marks (\p{M})
+const accented = ['é', 'É', 'ü', 'Ü', 'ñ', 'Ñ', 'ç', 'Ç', 'å', 'Å', 'ö', 'Ö', 'ß', 'ø', 'Ø', 'š', 'Š', 'ž', 'Ž', 'ő', 'Ő'];
+const other = ['中', '文', '日', '本', 'あ', 'カ', '한', 'д', 'Д', 'ж', 'Ж', 'λ', 'Λ', 'ω', 'Ω', 'ا', 'ב', '😀', '🚀', 'ǅ', 'ʰ', '٣', '५', '½', 'Ⅷ', 'ª'];
+const words = ['the', 'HTTP', 'Server', 'iPhone', 'McDonald', 'NASA', 'it', 'don', 't', 's', 'I', 'M', 'x86', 'USA', 'e', 'Go', 'API', 'v2', 'a', 'B'];
+
+// alphabets by flavour; every flavour keeps the characters capcode's state machine looks at (caps, digits, apostrophes, marks)
+const flavours = [
+  () => pick([lower, upper, digits, punct, apos, [' '], [' ']]),                                   // ASCII, all classes
+  () => pick([lower, upper, upper, [' '], apos, digits]),                                            // capital heavy
+  () => pick([lower, upper, digits, punct, apos, gpunct, [' ']]),                                    // + general punctuation (NFD stable)
+  () => pick([lower, upper, marks, apos, [' '], accented, digits]),                                  // marks and accents (NFD changes these)
+  () => pick([lower, upper, other, digits, apos, [' '], punct, marks]),                              // CJK, Cyrillic, Greek, emoji, titlecase, other digits
+  () => pick([words, words, [' '], [' '], apos, punct, digits, upper]),                              // word pieces
+];
+
+const inputs = [];
+// the strings tests/test_gpu_parity.py feeds the device normalizer by hand
+['', 'A', 'a', 'AB', 'Ab', 'aB', 'ABc', 'ABC', ' ABC d', 'HTTPServer2Go x', "X's Y'S it's 'a' I'M", '12AB34cd', 'A1B2c', 'X’s Y’S it’s',
+ 'A'.repeat(200) + 'b', 'A'.repeat(200), 'a' + 'B'.repeat(130) + ' ' + 'C'.repeat(70) + 'd', 'café Über', ' en quad',
+ 'Hello World', 'HELLO WORLD', 'hello WORLD again', 'THE QUICK brown FOX', "DON'T STOP", "I'M OK", 'O’NEIL', "ROCK'N'ROLL", 'A-B', 'A.B.C.',
+ 'MiXeD cAsE', 'x1Y2z3', '3D', '2ND', 'ÉCOLE', 'École', 'ÜBER', 'İ', 'İstanbul', 'ǅ', 'STRASSE', 'Ⅷ', 'ΑΒΓ αβγ', 'ДА нет', '1st 2ND 3Rd',
+ ' W', 'C D W', 'DW', ' D', 'a  B', 'a\tB', 'a\nB', "'A", "'a", "1'a", "a'1", 'áB', 'Áb', 'ÁB', 'Á', 'ÁB', 'Áb',
+].forEach(s => inputs.push(s));
+for (let i = 0; i < 5200; i++) {
+  const f = flavours[i % flavours.length];
+  const n = rnd(rnd(4) === 0 ? 90 : 28);
+  let s = '';
+  for (let k = 0; k < n; k++) s += pick(f());
+  inputs.push(s);
+}
+
+const b64 = s => Buffer.from(s, 'utf8').toString('base64');
+const cases = inputs.map(s => {
+  const nfd = s.normalize('NFD');
+  const enc = ctx.capcode_encode(nfd);
+  const dec = new ctx.CapcodeDecoder().decode(enc);
+  return { in: b64(s), nfd: b64(nfd), enc: b64(enc), dec: b64(dec) };
+});
+process.stdout.write(JSON.stringify({
+  source: 'javascript/tokenmonster.js:872-1065 evaluated in place by node ' + process.version + ' (tests/golden/make_capcode_golden.js)',
+  unicode: process.versions.unicode, icu: process.versions.icu, n: cases.length, cases,
+}));

@@ -184,6 +184,16 @@ class Reference:
         n = self.L.tmref_decode_raw(self.h, t.ctypes.data, t.size, out.ctypes.data, cap)
         return out[:n].tobytes()
 
+    def decode(self, toks):
+        """Vocab::decode (tokenmonster.cpp:1404-1425): decode_raw + capcode / charset post-processing"""
+        t = np.ascontiguousarray(toks, dtype=np.uint32)
+        cap = 40 * t.size + 8
+        out = np.empty(cap, dtype=np.uint8)
+        n = self.L.tmref_decode(self.h, t.ctypes.data, t.size, out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("reference decode failed")
+        return out[:n].tobytes()
+
 
 STAT_NAMES = ["s1", "s2", "s3", "s1b", "s2b", "s3b", "fast_exit", "no_lookahead_match", "not_found"]
 

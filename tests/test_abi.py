@@ -23,6 +23,11 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert n in N.SIGNATURES, "%s is declared in a header but not bound in _native.SIGNATURES" % n
     for n in N.SIGNATURES:
         assert n in names, "%s is bound but not declared in a public header" % n
+    # the synthetic generators are test / benchmark support: their own library, absent from the product's
+    sup = C.CDLL(N.SUPPORT_LIB_PATH)
+    for n in declared_symbols("tm_testsupport.h"):
+        assert hasattr(sup, n) and n in N.SUPPORT_SIGNATURES and n not in N.SIGNATURES
+        assert not hasattr(lib, n), "libtokenmonster_hip.so still exports the test-support symbol %s" % n
 
 
 def test_error_path_without_compute():

@@ -130,7 +130,7 @@ def test_device_normalizer_rule_table_and_flood_fills_on_cpu(tmp_path):
     exe = str(tmp_path / "norm_masks_check")
     libdir = os.path.join(root, "tokenmonster_amd")
     r = subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "include"), "-I", os.path.join(libdir, "csrc"),
-                        os.path.join(root, "tools", "norm_masks_check.cpp"), "-o", exe, "-L" + libdir, "-ltokenmonster_hip", "-Wl,-rpath," + libdir],
+                        os.path.join(root, "tools", "norm_masks_check.cpp"), "-o", exe, "-L" + libdir, "-ltokenmonster_hip", "-ltm_testsupport", "-Wl,-rpath," + libdir],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
     r = subprocess.run([exe, "6000", "17"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)

@@ -208,6 +208,51 @@ def test_score_histogram_candidate_vocab():
     assert int(got_s.sum()) >= text.size        # every byte covered once (+1 per forward delete)
 
 
+def test_score_histogram_full_candidate_shape():
+    """BASELINE.json configs[4] at its full vocabulary shape: 65 536 candidate ids (~113 000 index records), one 8 MiB strip
+    (training/trainvocab.go:909-922 post-midway mode) against the oracle's scoring mode."""
+    img = synth.config_vocab("candidates-65536")
+    v, orc = tm.Vocab(img), Oracle(img)
+    assert v.n_ids() == 65536
+    raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 8 << 20, seed=0x434F5250 + 5)
+    text, _ = synth.normalize_batch(raw, offs, 2, 1)
+    assert text.size >= 8 << 20
+    exp_s, exp_t, exp_m = orc.score(text)
+    got_s, got_t, got_m = _score(v, text)
+    assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
+    # strips that cut the dataset at arbitrary bytes are walked independently (pre-midway mode, :1668-1695)
+    strips = [(0, 1 << 20), (3 << 20, (2 << 20) + 77), ((6 << 20) + 13, 1 << 19)]
+    es = np.zeros(orc.n_ids(), dtype=np.uint32)
+    et, em = 0, np.zeros(32, dtype=np.uint8)
+    for a, l in strips:
+        s_, t_, m_ = orc.score(text[a:a + l])
+        es += s_
+        et += t_
+        em |= m_
+    got_s, got_t, got_m = _score(v, text, strips)
+    assert (got_s == es).all() and got_t == et and (got_m == em).all()
+
+
+def test_serialized_auto_width_large_vocab():
+    """go/tokenmonster.go:990-996: encoding_length 0 picks 3 bytes per id once the vocabulary has more than 65 536 ids
+    (englishcode-100256 shape); 2- and 4-byte requests are honoured as given (:1545, :2089; 2 bytes truncates, as Go's does)."""
+    img = synth.config_vocab("englishcode-100256-clean")
+    v = tm.Vocab(img)
+    assert v.n_ids() == 100256
+    raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 600_000, seed=0x434F5250 + 3)
+    text, noff = synth.normalize_batch(raw, offs, 2, 1)
+    ids, toff, miss = v.tokenize_packed(text, noff)
+    assert int(ids.max()) > 65535            # the high ids are really in use
+    for enc_req, enc_exp in ((0, 3), (3, 3), (4, 4), (2, 2)):
+        blob, boff, bmiss, enc = v.tokenize_serialized_packed(text, noff, enc_req)
+        assert enc == enc_exp and (bmiss == miss).all()
+        assert (boff == toff * np.uint64(enc)).all()
+        exp = np.zeros((ids.size, enc), dtype=np.uint8)
+        for b in range(min(enc, 3)):
+            exp[:, b] = (ids >> (8 * b)) & 0xFF
+        assert blob.tobytes() == exp.tobytes()
+
+
 def test_device_normalizer_matches_host_and_reference():
     # go/tokenmonster.go:242-253 pre-step on the GPU vs the host normalizer (and the reference runtime's normalize)
     img = synth.synth_vocab(synth.ENGLISHCODE, 1200, capcode=2, norm_flag=1, level=3, seed=7)

@@ -18,7 +18,7 @@ def test_walk_tables_against_brute_force(tmp_path):
     exe = str(tmp_path / "tables_check")
     libdir = os.path.join(ROOT, "tokenmonster_amd")
     r = subprocess.run([hipcc, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "csrc"),
-                        os.path.join(ROOT, "tools", "tables_check.cpp"), "-o", exe, "-L" + libdir, "-ltokenmonster_hip", "-Wl,-rpath," + libdir],
+                        os.path.join(ROOT, "tools", "tables_check.cpp"), "-o", exe, "-L" + libdir, "-ltokenmonster_hip", "-ltm_testsupport", "-Wl,-rpath," + libdir],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
     r = subprocess.run([exe, str(384 * 1024)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)

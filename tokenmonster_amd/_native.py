@@ -68,11 +68,17 @@ SIGNATURES = {
     "tm_free": (None, [vp]),
     "tm_build_vocab": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                  C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "tm_normalize": (C.c_int, [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "tm_normalize_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp), vp]),
+}
+
+
+# include/tm_testsupport.h: libtm_testsupport.so (synthetic vocabularies / corpora for tests and bench.py; not the product)
+SUPPORT_LIB_PATH = os.path.join(_HERE, "libtm_testsupport.so")
+SUPPORT_SIGNATURES = {
     "tm_synth_corpus": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32, u32p, u64p]),
     "tm_synth_vocab": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
                                  C.POINTER(vp), C.POINTER(C.c_size_t)]),
-    "tm_normalize": (C.c_int, [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
-    "tm_normalize_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp), vp]),
 }
 
 
@@ -95,6 +101,22 @@ def _load():
 
 
 lib = _load()
+_support = None
+
+
+def support_lib():
+    """libtm_testsupport.so, loaded on first use (tests, tools and bench.py only)"""
+    global _support
+    if _support is None:
+        if not os.path.exists(SUPPORT_LIB_PATH):
+            raise ImportError("%s is missing - run `python -c 'import __graft_entry__ as g; g.build()'`" % SUPPORT_LIB_PATH)
+        sl = C.CDLL(SUPPORT_LIB_PATH)
+        for name, (res, args) in SUPPORT_SIGNATURES.items():
+            fn = getattr(sl, name)
+            fn.restype = res
+            fn.argtypes = args
+        _support = sl
+    return _support
 
 
 def check(rc):

@@ -10,7 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtokenmonster_hip.so")
-SOURCES = ["tm_vocab.hip", "tm_kernels.hip", "tm_score.hip", "tm_norm.hip", "tm_decode.hip", "tm_build.cpp", "tm_normalize.cpp", "tm_synth.cpp"]
+# test / benchmark support (synthetic vocabularies and corpora): its own library, not part of the product
+SUPPORT_LIB = os.path.join(HERE, "libtm_testsupport.so")
+SUPPORT_SOURCES = [os.path.join(HERE, "testsupport", "tm_synth.cpp")]
+SOURCES = ["tm_vocab.hip", "tm_kernels.hip", "tm_score.hip", "tm_norm.hip", "tm_decode.hip", "tm_build.cpp", "tm_normalize.cpp"]
 HEADERS = ["tm_device.h", "tm_internal.h", "tm_tables.h", "tm_pipeline.h", "tm_norm_masks.h", "../../include/tokenmonster_hip.h", "../../include/tm_build.h"]
 
 
@@ -56,6 +59,12 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    if force or _stale(SUPPORT_LIB, SUPPORT_SOURCES + [LIB, os.path.join(CSRC, "tm_internal.h"), os.path.join(ROOT, "include", "tm_testsupport.h")]):
+        cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall"] + SUPPORT_SOURCES + [
+            "-o", SUPPORT_LIB, "-L" + HERE, "-ltokenmonster_hip", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("test-support library failed to build:\n" + r.stdout.decode(errors="replace"))
     return LIB
 
 

@@ -133,15 +133,17 @@ void wf32(std::vector<uint8_t>& o, float f) {
 
 int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vector<uint8_t>& special_in,
                       uint32_t capcode, uint32_t charset, uint32_t norm_flag, uint32_t level, bool with_unk,
-                      std::vector<uint8_t>& image) {
+                      std::vector<uint8_t>& image, const std::vector<float>* token_scores) {
   if (capcode > 2 || charset > 2) return set_error(TM_E_INVALID, "capcode/charset out of range");
   // ---- dic1: unique tokens in (length, bytewise) order  (go :3364-3380) -------------------------
   std::vector<std::pair<std::string, bool>> dic1;
   dic1.reserve(tokens_in.size());
+  std::unordered_map<std::string, float> given_scores;   // the score column of the .vocab records (go :2636); 1.0 when not given
   for (size_t k = 0; k < tokens_in.size(); k++) {
     if (tokens_in[k].empty()) continue;
     if (tokens_in[k].size() > 40) return set_error(TM_E_INVALID, "token longer than 40 bytes");
     dic1.emplace_back(tokens_in[k], k < special_in.size() && special_in[k] != 0);
+    if (token_scores && k < token_scores->size()) given_scores[tokens_in[k]] = std::max(0.0f, (*token_scores)[k]);
   }
   std::sort(dic1.begin(), dic1.end(), [](const auto& a, const auto& b) { return key_less(a.first, b.first); });
   dic1.erase(std::unique(dic1.begin(), dic1.end(), [](const auto& a, const auto& b) { return a.first == b.first; }),
@@ -212,6 +214,7 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
     rec.id = ids[token];
     auto sit = scores.find(token);
     rec.score = sit != scores.end() ? sit->second : 1.0f;
+    if (sit == scores.end() && token_scores) { auto g = given_scores.find(token); if (g != given_scores.end()) rec.score = g->second; }
     if (specials.count(token)) { rec.special = true; rec.flag = 64; continue; }   // go :3504-3511
     uint8_t flag = 0, n_words = 0, priority1 = 0, priority2 = 0;
     int min_alt = 1, alt_len1 = 0, alt_len2 = 0;

@@ -33,6 +33,13 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv);
 
 }  // namespace tmh
 
+struct tm_vocab;
+namespace tmh {
+// Every entry point that takes a vocabulary (or a batch / dataset bound to one) runs on the device the vocabulary's tables live
+// on, whatever device is current for the calling OS thread (cgo moves goroutines between threads): makes it current.
+int enter_device(const tm_vocab* v);
+}  // namespace tmh
+
 struct tm_vocab {
   tmh::HostVocab host;
   tmh::Tables tables{};

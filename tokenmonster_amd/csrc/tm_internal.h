@@ -16,7 +16,7 @@ const char* last_error();
 // tm_build.cpp
 int build_vocab_image(const std::vector<std::string>& tokens, const std::vector<uint8_t>& special, uint32_t capcode,
                       uint32_t charset, uint32_t norm_flag, uint32_t level, bool with_unk,
-                      std::vector<uint8_t>& image);
+                      std::vector<uint8_t>& image, const std::vector<float>* token_scores = nullptr);
 
 // tm_normalize.cpp
 void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out);

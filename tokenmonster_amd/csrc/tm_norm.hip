@@ -531,6 +531,10 @@ int tm_batch_upload_raw(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
     if (raw_offsets[d + 1] < raw_offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
     npieces += (raw_offsets[d + 1] - raw_offsets[d] + PIECE - 1) / PIECE;
   }
+  // the normalized text cannot be shorter than what capcode leaves of the raw text, and the scans of tm_batch_normalize run over
+  // one entry per piece with block sums sized (make_workspace) for max_bytes / 256 + max_docs entries
+  if (nbytes > b->max_bytes) return set_error(TM_E_LIMIT, "raw batch has %llu bytes, workspace sized for %llu", (unsigned long long)nbytes, (unsigned long long)b->max_bytes);
+  if (npieces > b->max_bytes / 256 + (uint64_t)b->max_docs) return set_error(TM_E_LIMIT, "raw batch has %llu pieces, workspace scans hold %llu", (unsigned long long)npieces, (unsigned long long)(b->max_bytes / 256 + b->max_docs));
   hipError_t e;
   uint64_t docs_cap = b->raw_docs_cap;
   if ((e = grow(&b->d_raw, &b->raw_cap, nbytes + 256)) != hipSuccess) return hip_fail(e, "hipMalloc (raw text)");

@@ -41,6 +41,17 @@ static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off
     be[n_strips + k] = strip_off[k] + strip_len[k];
     nseg += (strip_len[k] + SEG - 1) / SEG;
   }
+  // Strips must be disjoint: the per-position words of the walk (R0, R1) are indexed by absolute dataset position, so two
+  // strips that share a byte would race on them, and the workspace (max_bytes / SEG + n_strips + 1 segments) is sized for
+  // strips that together cover the dataset at most once.  (The trainvocab worker's strips are disjoint: trainvocab.go:1668-1695.)
+  if (n_strips > 1) {
+    std::vector<std::pair<uint64_t, uint64_t>> iv;
+    iv.reserve(n_strips);
+    for (uint32_t k = 0; k < n_strips; k++) if (strip_len[k]) iv.emplace_back(strip_off[k], strip_off[k] + strip_len[k]);
+    std::sort(iv.begin(), iv.end());
+    for (size_t k = 1; k < iv.size(); k++)
+      if (iv[k].first < iv[k - 1].second) return set_error(TM_E_INVALID, "strips overlap at dataset byte %llu", (unsigned long long)iv[k].first);
+  }
   hipError_t e;
   if (d->ws && (d->ws->vocab != v || d->ws_docs < n_strips)) { tm_batch_free(d->ws); d->ws = nullptr; }
   if (!d->ws) {
@@ -51,6 +62,7 @@ static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off
   }
   tm_batch* b = d->ws;
   b->vocab = v;
+  if (nseg > b->max_segs) return set_error(TM_E_LIMIT, "%llu segments, workspace holds %llu", (unsigned long long)nseg, (unsigned long long)b->max_segs);
   const uint64_t words = (uint64_t)v->host.n_ids + 4 + 256;
   if (d->hist_words != words) {
     (void)hipFree(d->d_hist);

@@ -36,6 +36,14 @@ int hip_fail(hipError_t e, const char* what) {
   return set_error(TM_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
+int enter_device(const tm_vocab* v) {
+  if (!v) return set_error(TM_E_INVALID, "null argument");
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == v->device) return TM_OK;
+  const hipError_t e = hipSetDevice(v->device);
+  return e == hipSuccess ? TM_OK : hip_fail(e, "hipSetDevice (device of the vocabulary)");
+}
+
 int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   size_t pos = 0;
 #define NEED(k) do { if (pos + (size_t)(k) > n) return set_error(TM_E_INVALID, "truncated .vocab at byte %zu", pos); } while (0)
@@ -45,6 +53,12 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   hv.unk = rd24(f + 8); hv.vocab_size = rd24(f + 11); hv.n_ids = rd24(f + 14); hv.n_info = rd24(f + 17);
   hv.delete_id = rd24(f + 20); hv.max_len = f[23];
   pos = 24;
+  // header fields the kernels later use as indices or bit fields are checked here, before anything is allocated from them
+  if (hv.unk != TM_NONE && hv.unk >= hv.n_ids) return set_error(TM_E_INVALID, "unk token id %u out of range (%u ids)", hv.unk, hv.n_ids);
+  if (hv.delete_id != TM_NONE && hv.delete_id >= hv.n_ids) return set_error(TM_E_INVALID, "deleteToken id %u out of range (%u ids)", hv.delete_id, hv.n_ids);
+  if (hv.max_len > 40) return set_error(TM_E_INVALID, "maxTokenLength %u > 40", hv.max_len);                      // go :2695
+  if (hv.n_info >= kMaxNodes) return set_error(TM_E_LIMIT, "%u index records: the walk tables hold fewer than %u trie nodes", hv.n_info, kMaxNodes);
+  if ((uint64_t)hv.n_info * 16 > n) return set_error(TM_E_INVALID, "truncated .vocab: %u records do not fit %zu bytes", hv.n_info, n);
   hv.keys.clear(); hv.key_off.assign(1, 0); hv.rows.resize(hv.n_info);
   std::vector<uint8_t> lens(hv.n_info), flags(hv.n_info), nwords(hv.n_info);
   std::vector<uint32_t> ids(hv.n_info);

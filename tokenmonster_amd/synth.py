@@ -1,4 +1,5 @@
-"""Synthetic vocabularies / corpora of the BASELINE.json shapes (include/tm_build.h) and the vocab builder."""
+"""Synthetic vocabularies / corpora of the BASELINE.json shapes (include/tm_testsupport.h, libtm_testsupport.so: test and
+benchmark support, not the product) and thin wrappers of the vocabulary builder / host normalizer (include/tm_build.h)."""
 import ctypes as C
 import os
 
@@ -38,7 +39,7 @@ def build_vocab(tokens, capcode=0, charset=1, norm_flag=0, level=5, with_unk=Fal
 def synth_vocab(kind, vocab_size, capcode=2, norm_flag=1, level=3, seed=1, with_unk=False):
     out = C.c_void_p()
     n = C.c_size_t()
-    N.check(N.lib.tm_synth_vocab(kind, vocab_size, capcode, norm_flag, level, seed, 1 if with_unk else 0, C.byref(out),
+    N.check(N.support_lib().tm_synth_vocab(kind, vocab_size, capcode, norm_flag, level, seed, 1 if with_unk else 0, C.byref(out),
                                  C.byref(n)))
     return N.take(out, n.value)
 
@@ -67,7 +68,7 @@ def synth_corpus(kind, nbytes, seed=1, median_doc=2048, max_docs=None):
     offsets = np.empty(max_docs + 1, dtype=np.uint64)
     nd = C.c_uint32()
     nb = C.c_uint64()
-    N.check(N.lib.tm_synth_corpus(kind, seed, int(nbytes), median_doc, N.ptr(text), N.ptr(offsets), max_docs, C.byref(nd),
+    N.check(N.support_lib().tm_synth_corpus(kind, seed, int(nbytes), median_doc, N.ptr(text), N.ptr(offsets), max_docs, C.byref(nd),
                                   C.byref(nb)))
     return text[: nb.value], offsets[: nd.value + 1].copy()
 

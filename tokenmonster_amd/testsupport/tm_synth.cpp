@@ -1,16 +1,23 @@
 // tm_synth.cpp — deterministic synthetic lexicon, corpora and vocabularies of the BASELINE.json shapes.
+// TEST / BENCHMARK SUPPORT: built into libtm_testsupport.so (include/tm_testsupport.h), not into the product library.
 //
 // No pretrained .vocab and no dataset exists in /root/reference or in this image, and
 // there is no network, so the named configurations (english-24000, englishcode-32000,
 // englishcode-100256, code-4096-nocapcode, 65536-token candidate set) are reproduced as *shapes*:
 //   corpus   raw UTF-8 documents: English-like prose (Zipf over a fixed function-word list + generated
-//            syllable words, sentence case, ~4% Title/ALL-CAPS words, punctuation, numbers), source
-//            code (keywords, camelCase / snake_case identifiers, operators, indentation) and log/JSON lines.
+//            syllable words and a Zipf-weighted set of multi-word collocations, sentence case, ~4% Title/ALL-CAPS
+//            words, punctuation, numbers), source code (keywords, camelCase / snake_case identifiers, operators,
+//            indentation, recurring idioms) and log/JSON lines.
 //   vocab    the most valuable substrings of a normalized sample of that corpus (count x (length-1)),
 //            in the spirit of getalltokens+trainvocab (training/getalltokens.go, trainvocab.go) but
 //            selected in one greedy pass; then tm_build_vocab computes flags/alternatives exactly as
-//            the reference's builder does.
+//            the reference's builder does.  The reference trains with -max-token-length 40 and says the algorithm
+//            "is optimized for" it (training/README.md:151-153): the collocations and idioms are what gives these
+//            vocabularies the multi-word tail (keys up to 40 bytes) real ones have.  The number of IDs is exactly the
+//            size asked for; record scores are the fraction of sample bytes a token's occurrences cover
+//            (trainvocab.go:438-442).
 #include "tm_build.h"
+#include "tm_testsupport.h"
 #include "tokenmonster_hip.h"
 #include "tm_internal.h"
 
@@ -50,12 +57,19 @@ const char* kOps[] = {" = ", " == ", " != ", " + ", " - ", " * ", " / ", " < ", 
 const char* kJsonKeys[] = {"id", "name", "type", "value", "status", "ts", "level", "msg", "user", "host", "path",
                            "code", "count", "items", "error", "data", "time", "size", "tags", "url"};
 const char* kLogLevels[] = {"INFO", "WARN", "ERROR", "DEBUG", "TRACE"};
+const char* kIdioms[] = {"for (int i = 0; i < n; i++) {\n", "if (err != nil) {\n", "return nil, err\n", "import numpy as np\n", "def __init__(self, ",
+                         "public static void main(String[] args) {\n", "#include <stdio.h>\n", "console.log(", "from typing import List, Optional\n",
+                         "if __name__ == \"__main__\":\n", "} else if (", "for i in range(len(", "std::vector<std::string> ", "return false;\n",
+                         "return true;\n", "self.assertEqual(", "throw new IllegalArgumentException(", "fmt.Println(", "const result = await ",
+                         "} catch (Exception e) {\n", "static const unsigned int ", "print(f\"", "using namespace std;\n", "package main\n\nimport (\n"};
 
 template <size_t N> constexpr size_t countof(const char* (&)[N]) { return N; }
 
 struct Lexicon {
   std::vector<std::string> words;     // rank order
   std::vector<double> cdf;            // Zipf cumulative
+  std::vector<std::string> phrases;   // collocations of 2..6 words, rank order ("of the", "as well as the", ...)
+  std::vector<double> pcdf;
   explicit Lexicon(uint64_t seed, size_t n_words = 50000) {
     Rng rng(seed ^ 0x4C455849434F4Eull);
     std::unordered_map<std::string, int> seen;
@@ -78,6 +92,28 @@ struct Lexicon {
     double acc = 0;
     for (size_t k = 0; k < words.size(); k++) { acc += 1.0 / std::pow((double)k + 2.7, 1.05); cdf[k] = acc; }
     for (auto& c : cdf) c /= acc;
+    // collocations: mostly frequent words, the frequent ones short
+    const size_t n_phrases = 6000;
+    std::unordered_map<std::string, int> pseen;
+    while (phrases.size() < n_phrases) {
+      const size_t rank = phrases.size();
+      const int nw = 2 + (int)rng.below(rank < 200 ? 2 : (rank < 2000 ? 4 : 5));
+      std::string ph;
+      for (int k = 0; k < nw; k++) { if (k) ph.push_back(' '); ph += sample(rng); }
+      if (ph.size() > 60 || pseen.count(ph)) continue;
+      pseen[ph] = 1;
+      phrases.push_back(ph);
+    }
+    pcdf.resize(phrases.size());
+    acc = 0;
+    for (size_t k = 0; k < phrases.size(); k++) { acc += 1.0 / std::pow((double)k + 4.0, 0.95); pcdf[k] = acc; }
+    for (auto& c : pcdf) c /= acc;
+  }
+  const std::string& sample_phrase(Rng& rng) const {
+    double u = rng.unit();
+    size_t k = (size_t)(std::lower_bound(pcdf.begin(), pcdf.end(), u) - pcdf.begin());
+    if (k >= phrases.size()) k = phrases.size() - 1;
+    return phrases[k];
   }
   const std::string& sample(Rng& rng) const {
     double u = rng.unit();
@@ -105,7 +141,7 @@ void gen_prose(const Lexicon& lex, Rng& rng, size_t target, std::string& out) {
       bool quoted = rng.chance(0.06);
       if (quoted) out += rng.chance(0.5) ? "\"" : "\xE2\x80\x9C";
       for (int w = 0; w < n_words; w++) {
-        std::string word = lex.sample(rng);
+        std::string word = rng.chance(0.10) ? lex.sample_phrase(rng) : lex.sample(rng);
         if (w == 0) cap_first(word);
         else if (rng.chance(0.03)) cap_first(word);
         else if (rng.chance(0.008)) cap_all(word);
@@ -165,6 +201,7 @@ void gen_code(const Lexicon& lex, Rng& rng, size_t target, std::string& out) {
     auto ind = [&]() { for (int k = 0; k < indent; k++) out += tabs ? "\t" : "    "; };
     uint32_t k = rng.below(20);
     ind();
+    if (rng.chance(0.06)) { const char* idiom = kIdioms[rng.below((uint32_t)countof(kIdioms))]; out += idiom; if (out.back() != '\n') { gen_expr(lex, rng, out, 1); out += ")\n"; } continue; }
     if (k < 2) { out += rng.chance(0.5) ? "// " : "# "; int nw = 2 + (int)rng.below(8); for (int w = 0; w < nw; w++) { if (w) out.push_back(' '); out += lex.sample(rng); } out.push_back('\n'); }
     else if (k < 5 && indent < 5) { out += kKeywords[rng.below(5)]; out += " ("; gen_expr(lex, rng, out, 0); out += ") {\n"; indent++; }
     else if (k < 7 && indent > 0) { indent--; out.resize(out.size() - (tabs ? 1 : 4)); out += "}\n"; }
@@ -327,6 +364,7 @@ int synth_vocab_image(uint32_t kind, uint32_t vocab_size, uint32_t capcode, uint
     return std::memcmp(&norm[a.pos], &norm[b.pos], a.len) < 0;
   });
   std::vector<std::string> tokens;
+  std::vector<float> tok_scores;
   std::vector<uint8_t> special;
   // single bytes (go/tokenmonster.go:200-232): capcode 2 / UTF-8 -> genUTF8bytes; capcode 0 -> all 256
   bool single[256];
@@ -338,18 +376,30 @@ int synth_vocab_image(uint32_t kind, uint32_t vocab_size, uint32_t capcode, uint
     for (int i = 0x80; i <= 0xBF; i++) single[i] = true;
     for (int i = 0xC2; i <= 0xF4; i++) single[i] = true;
   }
-  for (int i = 0; i < 256; i++) if (single[i]) tokens.push_back(std::string(1, (char)i));
-  size_t n_single = tokens.size();
-  uint32_t budget = vocab_size > n_single + (with_unk ? 1u : 0u) ? vocab_size - (uint32_t)n_single - (with_unk ? 1u : 0u) : 0;
+  uint64_t byte_count[256] = {0};
+  for (uint8_t b : norm) byte_count[b]++;
+  const double total = (double)std::max<size_t>(norm.size(), 1);
+  for (int i = 0; i < 256; i++) if (single[i]) { tokens.push_back(std::string(1, (char)i)); tok_scores.push_back((float)((double)byte_count[i] / total)); }
+  const size_t n_single = tokens.size();
+  // A chosen token that equals the "D "-duplicate of another one shares its ID (go/tokenmonster.go:3450-3462), so the number of
+  // IDs is only known after the build: take candidates in value order until the image has exactly vocab_size IDs.
   std::unordered_map<std::string, int> chosen;
-  for (auto& c : cands) {
-    if (chosen.size() >= budget) break;
-    std::string s((const char*)&norm[c.pos], c.len);
-    chosen.emplace(std::move(s), 1);
+  size_t next_cand = 0;
+  uint32_t want = vocab_size > n_single + (with_unk ? 1u : 0u) ? vocab_size - (uint32_t)n_single - (with_unk ? 1u : 0u) : 0;
+  for (int pass = 0; pass < 12; pass++) {
+    while (chosen.size() < want && next_cand < cands.size()) {
+      const Cand& c = cands[next_cand++];
+      std::string s((const char*)&norm[c.pos], c.len);
+      if (chosen.emplace(s, 1).second) { tokens.push_back(std::move(s)); tok_scores.push_back((float)(c.value / (double)(c.len - 1) * (double)c.len / total)); }
+    }
+    special.assign(tokens.size(), 0);
+    int rc = build_vocab_image(tokens, special, capcode, /*charset=*/1, norm_flag, level, with_unk, image, &tok_scores);
+    if (rc != TM_OK) return rc;
+    const uint32_t got = (uint32_t)image[11] | ((uint32_t)image[12] << 8) | ((uint32_t)image[13] << 16);   // vocabSize, Appendix A
+    if (got >= vocab_size || next_cand >= cands.size()) break;
+    want += vocab_size - got;
   }
-  for (auto& kv : chosen) tokens.push_back(kv.first);
-  special.assign(tokens.size(), 0);
-  return build_vocab_image(tokens, special, capcode, /*charset=*/1, norm_flag, level, with_unk, image);
+  return TM_OK;
 }
 
 }  // namespace tmh

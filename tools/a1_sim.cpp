@@ -2,7 +2,7 @@
 // rounds a wavefront needs (max over its lanes), for the table layout as built by parse_vocab and for candidate layouts
 // (child-byte filters that suppress probes which cannot hit).  Development aid: the kernel is bound by vector-instruction
 // issue, rounds x instructions per round is its cost model, and this runs without a GPU.
-//   hipcc -O2 -std=c++17 -I include -I tokenmonster_amd/csrc tools/a1_sim.cpp -o /tmp/a1_sim -Ltokenmonster_amd -ltokenmonster_hip -Wl,-rpath,$PWD/tokenmonster_amd
+//   hipcc -O2 -std=c++17 -I include -I tokenmonster_amd/csrc tools/a1_sim.cpp -o /tmp/a1_sim -Ltokenmonster_amd -ltokenmonster_hip -ltm_testsupport -Wl,-rpath,$PWD/tokenmonster_amd
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "tm_build.h"
+#include "tm_testsupport.h"
 #include "tm_device.h"
 #include "tm_pipeline.h"
 

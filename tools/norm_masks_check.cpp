@@ -2,7 +2,7 @@
 // replays k_norm_emit2's per-piece / per-chunk schedule (class masks -> backward sweep -> forward sweep -> bytes) with the very
 // same __host__ __device__ functions and compares every document with the host normalizer (tm_normalize).
 //   hipcc -O2 -std=c++17 -I include -I tokenmonster_amd/csrc tools/norm_masks_check.cpp -o /tmp/norm_masks_check \
-//         -Ltokenmonster_amd -ltokenmonster_hip -Wl,-rpath,$PWD/tokenmonster_amd
+//         -Ltokenmonster_amd -ltokenmonster_hip -ltm_testsupport -Wl,-rpath,$PWD/tokenmonster_amd
 // usage: norm_masks_check [random documents] [seed]      exit code 0 = all documents equal
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "tm_build.h"
+#include "tm_testsupport.h"
 #include "tm_internal.h"
 #include "tm_norm_masks.h"
 

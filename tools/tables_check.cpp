@@ -7,7 +7,7 @@
 //      the .vocab file: same (length, record ordinal) at every position (pansearch LongestSubstring semantics,
 //      tokenmonster-cpp/src/tokenmonster.cpp:786-877).
 //   hipcc -O2 -std=c++17 -I include -I tokenmonster_amd/csrc tools/tables_check.cpp -o /tmp/tables_check \
-//         -Ltokenmonster_amd -ltokenmonster_hip -Wl,-rpath,$PWD/tokenmonster_amd
+//         -Ltokenmonster_amd -ltokenmonster_hip -ltm_testsupport -Wl,-rpath,$PWD/tokenmonster_amd
 // exit code 0 = all checks passed
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "tm_build.h"
+#include "tm_testsupport.h"
 #include "tm_device.h"
 
 using namespace tmh;
