@@ -129,17 +129,20 @@ __global__ void k_segments(const uint64_t* __restrict__ doc_seg_start, uint32_t 
 // While the walks run, D[p] holds len[0..5] | nWords[6..10] | flag5[11..15] (bits 22..31 of the node value, shifted).
 // Step A2 then folds everything a *second* token contributes to a branch score (go/tokenmonster.go:1075-1084) into the
 // final descriptor, so that scoring a branch is a handful of adds instead of re-deriving it six times per state:
-//   len[0..5] | beginsWithLetter[6] | beginsOnCapcode[7] | S[8..19]
-//   S + 4 = len + allLetters/allPunct + max0(nWords-1) + beginsWithSpace (plain look-up only) + nextIsSpace
+//   beginsWithLetter[0] | len[1..6] | beginsOnCapcode[8] | S[9..20]
+//   S - 4 = len + allLetters/allPunct + max0(nWords-1) + beginsWithSpace (plain look-up only) + nextIsSpace
 //           + (nWords + nextIsNotLetter) * 100 - 3 * (endsWithLetter & nextIsLetter)
-// (the two cross terms of the penalty need the first token: begins-with-letter and begins-on-capcode stay as bits).
+// The two cross terms of the penalty need the first token: begins-with-letter and begins-on-capcode sit in bit 0 of bytes 0 and 1,
+// so that the penalty is ONE dot product of (descriptor & first-token bits) with the bytes {103, 100} (v_dot4_u32_u8).
+constexpr uint32_t D_LEN_SHIFT = 1, D_S_SHIFT = 9;
+__device__ __forceinline__ uint32_t desc_len(uint32_t d) { return (d >> D_LEN_SHIFT) & 63u; }
 __device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_t nb, bool bvariant, uint32_t hint) {
   const uint32_t f5 = v >> 27, snw = (v >> 22) & 31u;
   const int send = (int)(f5 & 1u), sbegl = (int)((f5 >> 1) & 1u), sbegs = (int)((f5 >> 2) & 1u & ~((f5 >> 1) & hint)), sbegc = (int)((f5 >> 3) & 1u),
             sall = (int)((f5 >> 4) & 1u);
   const int S = (int)len + sall + max((int)snw - 1, 0) + (bvariant ? 0 : sbegs) + (int)((nb >> 2) & 1u) + ((int)snw + (int)(nb >> 3)) * 100 -
                 (send & (int)(nb & 1u)) * 3;
-  return len | ((uint32_t)sbegl << 6) | ((uint32_t)sbegc << 7) | ((uint32_t)(S + 4) << 8);
+  return (uint32_t)sbegl | (len << D_LEN_SHIFT) | ((uint32_t)sbegc << 8) | ((uint32_t)(S + 4) << D_S_SHIFT);
 }
 
 // one in-flight trie walk of a lane: text byte number d of the string being matched is text[tbase + d].
@@ -179,73 +182,78 @@ __device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uin
   return !(cont || again);
 }
 
-// candidate first token of a branch: bytes consumed, and what it contributes to the score on its own:
-// fpart = flen + allLetters + max0(w-1) + w*100 with w = nWords - fd (go :1071,1117,1169)
-struct First { int flen; int fpart; int fend; int fcap; };
-
-__device__ __forceinline__ First make_first(int flen, int w, uint32_t f3) {
-  return First{flen, flen + (int)((f3 >> 2) & 1u) + max(w - 1, 0) + w * 100, (int)(f3 & 1u), (int)((f3 >> 1) & 1u)};
+// score of one branch, go/tokenmonster.go:1075-1084 (plain), :1096-1105 (forward-delete variant); alternatives add :1132-1133.
+//   fpart  what the candidate first token contributes on its own: flen + allLetters + max0(w-1) + w*100, w = nWords - fd (go :1071,1117,1169)
+//   fb     its endsWithLetter (byte 0) and endsOnCapcode (byte 1) bits, lined up with the descriptor's beginsWithLetter / beginsOnCapcode
+__device__ __forceinline__ int branch_score(int fpart, uint32_t fb, uint32_t dS, bool bvariant) {
+  const int S = (int)((dS >> D_S_SHIFT) & 0xFFFu) - 4;
+  // plain: (endsWithLetter & beginsWithLetter) * 103 + (endsOnCapcode & beginsOnCapcode) * 100; forward-delete variant: endsWithLetter * 103 + 1 + ...
+  const uint32_t t = (bvariant ? (dS | 1u) : dS) & fb;
+  const int pen = (int)__builtin_amdgcn_udot4(t, 0x00006467u, bvariant ? 1u : 0u, false);
+  return fpart + S - pen;
 }
-
-// score of one branch, go/tokenmonster.go:1075-1084 (plain), :1096-1105 (forward-delete variant); alternatives add :1132-1133
-__device__ __forceinline__ int branch_score(const First& F, uint32_t dS, bool bvariant, bool alt, int len) {
-  const int l = (int)(dS & 63u), sbegl = (int)((dS >> 6) & 1u), sbegc = (int)((dS >> 7) & 1u), S = (int)((dS >> 8) & 0xFFFu) - 4;
-  int sc = F.fpart + S - (F.fcap & sbegc) * 100 - (bvariant ? F.fend * 103 + 1 : (F.fend & sbegl) * 103);
-  if (alt) { const int BL = F.flen + l; sc -= (BL < len ? 100 : 0) + (BL == len ? 10000 : 0); }
-  return sc;
+// go :1132-1133: an alternative's branch that ends short of the greedy token loses 100, one that ends exactly there 10 000
+__device__ __forceinline__ int alt_penalty(int flen, uint32_t dS, int len) {
+  const int BL = flen + (int)desc_len(dS);
+  return (BL < len ? 100 : 0) + (BL == len ? 10000 : 0);
 }
 
 struct WaveLds {
   alignas(16) uint8_t text[TEXT_LEN];
-  uint32_t D[NPOS_PAD];    // longest match at p                      (second-token descriptor)
-  uint32_t Db[NPOS_PAD];   // longest match of ' '+text[p:], if usable (forward-delete descriptor), 0 = none
-  uint32_t X[NPOS_PAD];    // node value of D's token (node id = record ordinal)
+  // (arrays of NPOS, not NPOS_PAD, entries: with the 256 bytes of begin_byte[] a workgroup takes exactly 20 KB, 8 workgroups = 32
+  // wavefronts per CU fill the 160 KB; the loops over NPOS_PAD positions guard p < NPOS)
+  uint32_t D[NPOS];        // longest match at p                      (second-token descriptor)
+  uint32_t Db[NPOS];       // longest match of ' '+text[p:], if usable (forward-delete descriptor), 0 = none
+  uint32_t X[NPOS];        // node value of D's token (node id = record ordinal)
   uint32_t Xb[SEG];        // node value of Db's token
   uint16_t xch[64];        // dense task list of the forward-delete walks (step A3), one batch at a time
 };
 
 // T(p, fd): go/tokenmonster.go:1051-1276
+template <int FD>
 __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w, const uint8_t* s_bb, int p, int dl,
-                                               uint32_t d, const Row& O, int fd) {
+                                               uint32_t d, const Row& O) {
   if (d == 0) return (T.unk_id != TM_NONE ? T.unk_id : ID_NONE) | (1u << 24) | (1u << 31);   // go :1269-1276
-  const int len = (int)(d & 63u);
-  const uint32_t id = O.x & ID_NONE, oflag = O.x >> 24;
+  const int len = (int)desc_len(d);
+  const uint32_t id = O.x & kRowIdMask;
   const int i1 = p + len;
-  if (i1 < dl && ((oflag & 32u) == 0 || s_bb[w.text[i1]] != 12)) {                           // go :1057
-    const int len1 = (int)(O.z >> 24), len2 = (int)(O.w & 63u);
-    int s[6] = {NOSCORE, NOSCORE, NOSCORE, NOSCORE, NOSCORE, NOSCORE};   // s1 s2 s3 s1b s2b s3b
-    int best = NOSCORE;
-    First F[3];
-    F[0] = make_first(len, (int)(O.y >> 24) - fd, (oflag & 1u) | (((oflag >> 3) & 1u) << 1) | (((oflag >> 7) & 1u) << 2));
-    F[1] = make_first(len1 - fd, (int)((O.w >> 6) & 31u) - fd, (O.w >> 16) & 7u);
-    F[2] = make_first(len2 - fd, (int)((O.w >> 11) & 31u) - fd, (O.w >> 19) & 7u);
+  uint32_t res = id | ((uint32_t)len << 24);                                                   // go :1265-1267
+  if (i1 < dl && ((O.w & (1u << 21)) == 0 || s_bb[w.text[i1]] != 12)) {                       // go :1057 (flag 32: a whole word, followed by a space)
+    const int len1 = (int)(O.w & 63u), len2 = (int)((O.w >> 6) & 63u);
+    // candidate first tokens: the match itself, alternative 1, alternative 2 (lengths and constants of a forward-delete state: tm_tables.h)
+    const int flen[3] = {len, len1 - FD, len2 - FD};
+    const int fpart[3] = {len + (int)(O.x >> kRowIdBits) - FD * (100 + (int)((O.w >> 18) & 1u)),
+                          (int)(O.y >> kRowIdBits) - FD * (101 + (int)((O.w >> 19) & 1u)),
+                          (int)(O.z >> kRowIdBits) - FD * (101 + (int)((O.w >> 20) & 1u))};
+    const uint32_t fb[3] = {((O.w >> 12) & 1u) | (((O.w >> 15) & 1u) << 8), ((O.w >> 13) & 1u) | (((O.w >> 16) & 1u) << 8),
+                            ((O.w >> 14) & 1u) | (((O.w >> 17) & 1u) << 8)};
     const int nk = len1 == 0 ? 1 : (len2 == 0 ? 2 : 3);                                      // go :1111, :1163
+    // the first maximum in the order 1,2,3,1b,2b,3b wins (go :1217-1262): a later score replaces the best only if it is larger
+    // within its group, and a forward-delete (b) score only if it is larger than every plain one
+    int best = NOSCORE, bestb = NOSCORE;
+    uint32_t resb = 0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       if (k < nk) {
-        const int ik = p + F[k].flen;
+        const int ik = p + flen[k];
         const uint32_t dS = w.D[ik];
         if (dS != 0) {
-          s[k] = branch_score(F[k], dS, false, k > 0, len);
-          best = max(best, s[k]);
+          int sc = branch_score(fpart[k], fb[k], dS, false);
+          if (k > 0) sc -= alt_penalty(flen[k], dS, len);
+          const uint32_t rk = (k == 0 ? id : ((k == 1 ? O.y : O.z) & kRowIdMask)) | ((uint32_t)flen[k] << 24);
+          if (sc > best) { best = sc; res = rk; }
           const uint32_t dB = w.Db[ik];
           if (dB != 0) {
-            s[3 + k] = branch_score(F[k], dB, true, k > 0, len);
-            best = max(best, s[3 + k]);
+            int sb = branch_score(fpart[k], fb[k], dB, true);
+            if (k > 0) sb -= alt_penalty(flen[k], dB, len);
+            if (sb > bestb) { bestb = sb; resb = rk | (1u << 30); }
           }
         }
       }
     }
-    if (best != NOSCORE) {                                                                     // go :1217-1262
-      if (best == s[0]) return id | ((uint32_t)len << 24);
-      if (best == s[1]) return (O.y & ID_NONE) | ((uint32_t)F[1].flen << 24);
-      if (best == s[2]) return (O.z & ID_NONE) | ((uint32_t)F[2].flen << 24);
-      if (best == s[3]) return id | ((uint32_t)len << 24) | (1u << 30);
-      if (best == s[4]) return (O.y & ID_NONE) | ((uint32_t)F[1].flen << 24) | (1u << 30);
-      return (O.z & ID_NONE) | ((uint32_t)F[2].flen << 24) | (1u << 30);
-    }
+    if (bestb > best) res = resb;
   }
-  return id | ((uint32_t)len << 24);                                                           // go :1265-1267
+  return res;
 }
 
 #ifdef TM_PHASE_TIMERS
@@ -265,21 +273,16 @@ __device__ unsigned long long g_phase[64 * 32];
 #endif
 
 
-// SPLIT (experimental, debug bit 11): step A1 has been done by k_match_runs; A[] holds len | record ordinal << 6 per position.
-template <bool SPLIT>
-__global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
+__global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
                                                                 const uint64_t* __restrict__ doc_end,
                                                                 const uint32_t* __restrict__ seg_doc,
                                                                 const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
                                                                 uint32_t* __restrict__ R0, uint2* __restrict__ side,
-                                                                uint32_t* __restrict__ R1, uint2* __restrict__ exitmap, int dbg,
-                                                                const uint32_t* __restrict__ A) {
-  __shared__ uint32_t s_root[256];
+                                                                uint32_t* __restrict__ R1, uint2* __restrict__ exitmap, int dbg) {
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
   const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-  s_root[threadIdx.x] = T.root[threadIdx.x];
   s_bb[threadIdx.x] = T.begin_byte[threadIdx.x];
   __syncthreads();
   const uint64_t g = (uint64_t)blockIdx.x * WAVES + wvi;
@@ -316,26 +319,16 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
   // start over at p+1 but follows the suffix link of n (tm_tables.h) — the state of the walk of text[p+1:] after the
   // bytes already known to match — and only probes for what may come after them.  ~3.1 gathers per position instead of
   // ~4.9 (two-byte map + one probe per further byte).  (pansearch LongestSubstring, call sites go/tokenmonster.go:1049..)
-  for (int j = lane; j < NPOS_PAD; j += 64) { w.D[j] = 0; w.Db[j] = 0; }
+  for (int j = lane; j < NPOS; j += 64) { w.D[j] = 0; w.Db[j] = 0; }
   __builtin_amdgcn_wave_barrier();
   PH(0)
   PH_COUNT(12, 1)
-  const int ntask = (dbg & 1) ? 0 : min(NPOS, dl);     // positions >= dl keep descriptor 0 (nothing there)
-  if constexpr (SPLIT) {
-    // ---- A1 was done by k_match_runs: fetch the positions' words (coalesced) and the node values of the records (one dense
-    // gather per position, no dependency chain) -> D[p], X[p] exactly as the walk below leaves them
-    // (all loads of a kind issued back to back: two memory latencies for the segment, not ten)
-    uint32_t wd[NPOS_PAD / 64], vv[NPOS_PAD / 64];
-#pragma unroll
-    for (int it = 0; it < NPOS_PAD / 64; it++) { const int p = it * 64 + lane; wd[it] = p < ntask ? A[begin + p] : 0u; }
-#pragma unroll
-    for (int it = 0; it < NPOS_PAD / 64; it++) vv[it] = wd[it] != 0 ? T.vals[wd[it] >> 6] : 0u;
-#pragma unroll
-    for (int it = 0; it < NPOS_PAD / 64; it++) {
-      const int p = it * 64 + lane;
-      if (wd[it] != 0) { w.D[p] = (wd[it] & 63u) | ((vv[it] >> 22) << 6); w.X[p] = vv[it]; }
-    }
-  } else {
+#ifdef TM_DEVEL
+  const int ntask = (dbg & 1) ? 0 : min(NPOS, dl);
+#else
+  const int ntask = min(NPOS, dl);                     // positions >= dl keep descriptor 0 (nothing there)
+#endif
+  {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
     // A run is in one of two states.  SET: the gather is a link-format entry (a suffix link, or the direct map on the
     // first two bytes when there is nothing to link from) that says where the walk stands — node, depth, best match so
@@ -348,7 +341,7 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
     const int nwalkpos = (dl <= NPOS) ? ntask - 1 : ntask;          // positions with at least two bytes of text left
     if (lane == 0 && dl <= NPOS && ntask > 0) {
-      const uint32_t r = s_root[w.text[dl - 1]];
+      const uint32_t r = T.root[w.text[dl - 1]];
       if (r != kNone && node_id(r) < T.n_info) { w.D[dl - 1] = 1u | ((r >> 22) << 6); w.X[dl - 1] = r; }
     }
     // Positions are carried as LDS byte addresses of their text byte (one add less per use, and the kernel is VALU bound).
@@ -368,7 +361,11 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
       off = T.direct_off + ((uint32_t)*(lds_u16u*)(uintptr_t)posa << 4);
       pfa = posa + 2u;
     }
+#ifdef TM_DEVEL
     const bool nowalk = (dbg & 4) != 0;
+#else
+    constexpr bool nowalk = false;
+#endif
     // The loop exists twice: when the document goes on for at least Lmax bytes behind the last position of the segment, no walk
     // is cut short by the end of the text and `limit` is the constant Lmax (two instructions less per round).
     auto rounds = [&](auto tail_tag) {
@@ -402,7 +399,7 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
           // 0 that is there already), move on — through the suffix link if the walk got deep enough, else from the direct map
           lds_u32* dp = (lds_u32*)(uintptr_t)(dconst + 4u * posa);
           dp[0] = (uint32_t)bestlen | ((bestv >> 22) << 6);              // D[pos]
-          dp[2 * NPOS_PAD] = bestv;                                       // X[pos]
+          dp[2 * NPOS] = bestv;                                           // X[pos]
           posa++;
           setting = posa < enda;
           if (TAIL) limit = min((int)(dla - posa), Lmax);
@@ -423,11 +420,15 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
   unsigned long long elig[NPOS_PAD / 64];
   {
     const int off = (int)T.off;
+#ifdef TM_DEVEL
     const bool can_b = T.has_delete && T.bstart != kNone && !(dbg & 8);
+#else
+    const bool can_b = T.has_delete && T.bstart != kNone;
+#endif
 #pragma unroll
     for (int it = 0; it < NPOS_PAD / 64; it++) {
       const int p = it * 64 + lane;
-      uint32_t d = w.D[p];
+      uint32_t d = p < NPOS ? w.D[p] : 0u;
       bool el = false;
       if (d != 0) {
         const uint32_t nb = s_bb[w.text[p + (d & 63u)]];
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
       int mainlen = 0;
       if (base + lane < n_el) {
         const int p = (int)w.xch[lane];
-        const uint32_t ml = w.D[p] & 63u;
+        const uint32_t ml = desc_len(w.D[p]);
         const uint2 e = T.spl[node_id(w.X[p])];
         const int limit = min(dl - p, Lmax - off) + off;
         const int depth = (int)ml + off;
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
   // The kernel is VALU-issue bound (profiles/r01_v3_pmc_k1.txt) and the six-branch scoring is its largest block of
   // straight-line code, so it must not run on mostly idle lanes: T(p,0) is evaluated for all positions (row gathers
   // issued first), but the few (p,1) states (forward-delete matches) are first compacted into a dense list — through
-  // the 64 halo slots of X, which step B does not read — and evaluated in as few full-width passes as possible.
+  // the task list of step A3, free by now — and evaluated in as few full-width passes as possible.
   uint32_t r0[SEG / 64], r1[SEG / 64];
   {
     Row row0[SEG / 64];
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
     for (int it = 0; it < SEG / 64; it++) {
       const int p = it * 64 + lane;
       r0[it] = R_INVALID;
-      if (p < seglen) r0[it] = transition(T, w, s_bb, p, dl, d0[it], row0[it], 0);
+      if (p < seglen) r0[it] = transition<0>(T, w, s_bb, p, dl, d0[it], row0[it]);
     }
     const bool side_ok = n1 < SIDE_STRIDE && !(dbg & 64);          // (dbg & 64: tests force the dense path)
     for (int base = 0; base < n1; base += 64) {
@@ -528,16 +529,16 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
 #pragma unroll
       for (int it = 0; it < SEG / 64; it++) {
         const int dst = run + __popcll(m1[it] & lane_below) - base;
-        if (((m1[it] >> lane) & 1ull) && dst >= 0 && dst < 64) w.X[SEG + dst] = (uint32_t)(it * 64 + lane);
+        if (((m1[it] >> lane) & 1ull) && dst >= 0 && dst < 64) w.xch[dst] = (uint16_t)(it * 64 + lane);
         run += __popcll(m1[it]);
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0);
       if (base + lane < n1) {
-        const int q = (int)w.X[SEG + lane];
+        const int q = (int)w.xch[lane];
         const uint32_t dB = w.Db[q];
         const Row row1 = T.rows[node_id(w.Xb[q])];
-        const uint32_t t1 = transition(T, w, s_bb, q, dl, dB, row1, 1);
+        const uint32_t t1 = transition<1>(T, w, s_bb, q, dl, dB, row1);
         w.Xb[q] = t1;                                              // Xb[q] is only ever read by this lane: reuse it for the result
         if (side_ok) side[g * SIDE_STRIDE + 1 + lane] = make_uint2((uint32_t)q, t1);
       }
@@ -566,10 +567,12 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
   // points at a segment exit.  Only the 80 possible entry states (offset < 40, fd) are written out, but their
   // chains run through arbitrary states, so all 2 x 512 states take part.  In-place updates are safe: an entry is
   // read and written as one 8-byte LDS access and always describes a valid prefix of its state's chain.
+#ifdef TM_DEVEL
   if (dbg & 16) { for (int e = lane; e < ENT; e += 64) exitmap[g * ENT + e] = make_uint2(0u, 0u); return; }   // (timing experiments only)
+#endif
   {
     uint2* J = reinterpret_cast<uint2*>(w.D);            // overlays D, Db, X, Xb (dead after step B): 1024 x 8 B
-    static_assert(sizeof(uint32_t) * (2 * NPOS_PAD + 2 * SEG) >= 2 * SEG * sizeof(uint2), "J overlay does not fit");
+    static_assert(sizeof(uint32_t) * (3 * NPOS + SEG) >= 2 * SEG * sizeof(uint2), "J overlay does not fit");
     const bool more_text = rem > (uint64_t)SEG;           // not the last segment of the document
     // J entry: x = #id events [0..15] | field [16..30] | left-the-segment [31]; the field is the LDS byte address of the
     // entry it points at, or — once the chain has left the segment — the entry state of the next segment (0x7FFF: the
@@ -655,105 +658,6 @@ __global__ __launch_bounds__(WAVES * 64, 7) void k_match_branch(Tables T, const 
   }
   PH(7)
   PH_FLUSH
-}
-
-// ---- split pipeline, experimental (debug bit 11; built and modelled in tools/a1_sim.cpp, see DESIGN.md "what comes next") ----
-// Step A1 alone: one wavefront walks a CHUNK of 1024 consecutive positions of one document, 16 per lane instead of 5, every
-// position of the document exactly once (no 40-position look-ahead walked twice).  The round is the one of k_match_branch;
-// a position's result, len | record ordinal << 6 (0: no match), is staged in LDS and leaves in coalesced stores.
-struct RunLds { alignas(16) uint8_t text[CHUNK + 96]; uint32_t out[CHUNK]; };
-
-__global__ __launch_bounds__(WAVES * 64, 7) void k_match_runs(Tables T, const uint8_t* __restrict__ text, const uint64_t* __restrict__ doc_begin,
-                                                              const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ chunk_doc,
-                                                              const uint64_t* __restrict__ doc_chunk_start, const uint64_t* __restrict__ nchunks,
-                                                              uint32_t* __restrict__ A) {
-  __shared__ uint32_t s_root[256];
-  __shared__ RunLds s_run[WAVES];
-  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-  s_root[threadIdx.x] = T.root[threadIdx.x];
-  __syncthreads();
-  const uint64_t k = (uint64_t)blockIdx.x * WAVES + wvi;
-  if (k >= *nchunks) return;
-  RunLds& w = s_run[wvi];
-  const int Lmax = (int)T.max_len;
-  const uint32_t idle_off = (T.edge_mask + 1u) << 4;
-  const uint32_t doc = chunk_doc[k];
-  const uint64_t begin = doc_begin[doc] + (k - doc_chunk_start[doc]) * CHUNK;
-  const uint64_t rem = doc_end[doc] - begin;
-  const int dl = rem > (uint64_t)(1 << 20) ? (1 << 20) : (int)rem;   // bytes of the document from `begin` on (clamped)
-  const int n = min(dl, CHUNK);                                       // positions of this chunk
-  for (int j = lane; j < (CHUNK + 96) / 4; j += 64) {                 // text + look-ahead; bytes behind the document read as 0 (quirk Q1)
-    uint32_t tw = 0;
-    if (4 * j < dl) {
-      __builtin_memcpy(&tw, text + begin + 4 * j, 4);
-      if (4 * j + 4 > dl) tw &= (1u << (8 * (dl - 4 * j))) - 1u;
-    }
-    reinterpret_cast<uint32_t*>(w.text)[j] = tw;
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
-  const uint32_t mask16 = T.edge_mask << 4;
-  const int nwalkpos = (dl <= CHUNK) ? n - 1 : n;                     // the last byte of a document is looked up in root[], not walked
-  if (lane == 0 && dl <= CHUNK && n > 0) {
-    const uint32_t r = s_root[w.text[dl - 1]];
-    w.out[dl - 1] = (r != kNone && node_id(r) < T.n_info) ? (1u | (node_id(r) << 6)) : 0u;
-  }
-  typedef __attribute__((address_space(3))) uint8_t lds_u8;
-  typedef __attribute__((address_space(3), aligned(1))) uint16_t lds_u16u;
-  typedef __attribute__((address_space(3))) uint32_t lds_u32;
-  const uint32_t tb = (uint32_t)(uintptr_t)(lds_u8*)w.text;
-  const uint32_t oconst = (uint32_t)(uintptr_t)(lds_u8*)w.out - 4u * tb;             // &out[i] == oconst + 4 * (tb + i)
-  const int run = (max(nwalkpos, 0) + 63) >> 6;
-  uint32_t posa = tb + (uint32_t)(lane * run);
-  const uint32_t enda = tb + (uint32_t)max(min(lane * run + run, nwalkpos), 0), dla = tb + (uint32_t)dl;
-  int depth = 0, limit = 0, bestlen = 0;
-  uint32_t pfa = tb, off = idle_off, key = 0u, bestv = 0u, node = 0u;
-  bool probing = false, setting = posa < enda;
-  if (setting) {
-    limit = min((int)(dla - posa), Lmax);
-    off = T.direct_off + ((uint32_t)*(lds_u16u*)(uintptr_t)posa << 4);
-    pfa = posa + 2u;
-  }
-  auto rounds = [&](auto tail_tag) {                                   // (the round of k_match_branch step A1, see there)
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    while (__builtin_amdgcn_ballot_w64(off != idle_off) != 0ull) {
-      const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);
-      uint32_t c = *(lds_u8*)(uintptr_t)pfa;
-      uint32_t nn = *(lds_u16u*)(uintptr_t)(posa + 1u);
-      asm volatile("" : "+v"(c), "+v"(nn));
-      const bool hit1 = probing && (e.z & kKeyMask) == key;
-      const bool hit = hit1 || (probing && (e.x & kKeyMask) == key);
-      const bool again = probing && !hit && e.z != kNone;
-      const bool adv = hit || setting;
-      const uint32_t hv = hit1 ? e.w : e.y, hk = hit1 ? e.z : e.x;
-      const uint32_t src = hit ? hv : e.x;
-      const uint32_t nid = src & kNodeMask;
-      if (hit) depth++;
-      if (setting) { depth = (int)((e.x >> 23) & 63u); bestv = e.y; bestlen = (int)e.w; }
-      if (adv) node = nid;
-      if (hit && nid < T.n_info) { bestv = hv; bestlen = depth; }
-      const bool go = adv && (setting ? child_possible32(e.z, c) : child_possible4(hk, c)) && depth < (TAIL ? limit : Lmax);
-      const bool fin = (adv && !go) || (probing && !hit && !again);
-      if (go) { key = (nid << 8) | c; off = edge_slot_offset(T, nid, c); pfa = posa + (uint32_t)depth + 1u; }
-      if (again) off = (off + 16u) & mask16;
-      probing = go || again;
-      setting = false;
-      if (fin) {
-        *(lds_u32*)(uintptr_t)(oconst + 4u * posa) = (uint32_t)bestlen | (node_id(bestv) << 6);   // no match: bestlen == 0 and bestv == 0
-        posa++;
-        setting = posa < enda;
-        if (TAIL) limit = min((int)(dla - posa), Lmax);
-        if (depth >= 3) { off = T.link_off + (node << 4); pfa = posa + (uint32_t)depth - 1u; }
-        else { off = T.direct_off + (nn << 4); pfa = posa + 2u; }
-        if (!setting) off = idle_off;
-      }
-    }
-  };
-  if (dl >= CHUNK + Lmax) rounds(std::false_type{}); else rounds(std::true_type{});
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  for (int j = lane; j < n; j += 64) A[begin + j] = w.out[j];
 }
 
 // exit map entry (uint2): x = next entry state [0..7] | #id events << 8 ; y = #forward-deletes | #missing << 16
@@ -858,212 +762,29 @@ __global__ void k_group_expand(const uint2* __restrict__ exitmap, const Group* _
 // ------------------------------------------------------------------------------------------------
 // K4: emit ids (or, HIST, accumulate the trainvocab histogram, training/trainvocab.go:1105-1174)
 // ------------------------------------------------------------------------------------------------
-// The chain of a segment from its true entry state is ranked in parallel instead of being chased by one lane:
-// J_k[s] = state 2^k steps after s (+ ids emitted on the way).  Round k marks, for every already-marked state s,
-// the state J_k[s] with rank[s] + ids(s -> J_k[s]); then J is squared.  After ceil(log2(chain length)) rounds all
-// chain states carry their output offset and write their ids independently.
 // hist layout (all uint32, so that one RCCL all-reduce(sum) merges ranks): scores[n_ids] | tokens_in_text as
 // four 16-bit limbs | missing[256] (per-byte counters, > 0 = that byte had no token)
-// HIST keeps most of the histogram traffic in LDS: persistent workgroups (one per CU, WV wavefronts) own a
+// The scoring variant keeps most of the histogram traffic in LDS: persistent workgroups (one per CU) own a
 // direct-mapped table of HSLOTS {id, count} counters; an id that finds its slot free or already its own adds in
 // LDS, anything else falls through to a global atomic; slots are flushed once when the workgroup retires.  Without
 // this, the hot ids (" the", ",") serialise tens of millions of L2 atomics on a handful of addresses.
 constexpr int HSLOTS = 8192;
-template <bool HIST, int WV>
-__global__ __launch_bounds__(WV * 64) void k_chain(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
-                                               const uint32_t* __restrict__ R1, const uint8_t* __restrict__ text,
-                                               const uint64_t* __restrict__ doc_begin,
-                                               const uint64_t* __restrict__ doc_end,
-                                               const uint32_t* __restrict__ seg_doc,
-                                               const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
-                                               const uint8_t* __restrict__ seg_entry,
-                                               const uint32_t* __restrict__ seg_tokbase,
-                                               const uint64_t* __restrict__ tok_offsets, uint32_t delete_id,
-                                               uint64_t out_cap, uint32_t* __restrict__ out,
-                                               uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
-                                               uint32_t* __restrict__ missing_bits) {
-  // per wavefront: J[s] = ids on the path [0..15] | LDS address of the J word it points at [16..30] | left the segment [31]
-  // (composing two hops is (x & 0xFFFF) + x', the next read is x >> 16: this kernel is VALU bound like K1);
-  // RK[s] = output rank of a chain state, 0xFFFFFFFF = not (yet) known to be on the chain
-  struct ChainLds { uint32_t J[2 * SEG]; uint32_t RK[2 * SEG]; };
-  __shared__ ChainLds s_c[WV];
-  __shared__ uint32_t s_tag[HIST ? HSLOTS : 1], s_cnt[HIST ? HSLOTS : 1];
-  __shared__ unsigned long long s_ntok;
-  __shared__ uint32_t s_ndel;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (HIST) {
-    for (int j = threadIdx.x; j < HSLOTS; j += WV * 64) { s_tag[j] = 0xFFFFFFFFu; s_cnt[j] = 0; }
-    if (threadIdx.x == 0) { s_ntok = 0; s_ndel = 0; }
-    __syncthreads();
-  }
-  uint32_t* J = s_c[wv].J;
-  uint32_t* RK = s_c[wv].RK;
-  typedef __attribute__((address_space(3))) uint8_t lds_u8;
-  typedef __attribute__((address_space(3))) uint32_t lds_u32;
-  const uint32_t jaddr = (uint32_t)(uintptr_t)(lds_u8*)J;
-  static_assert(WV * sizeof(ChainLds) + 64 < 32768 || HIST, "LDS addresses must fit the 15-bit field");
-  // the persistent scoring variant owns more than 32 KB of LDS: its J words hold offsets from the wavefront's J instead
-  const uint32_t jbase = HIST ? 0u : jaddr, jrel = HIST ? jaddr : 0u;
-  constexpr uint32_t RKD = 2 * SEG;            // RK[s] sits RKD words behind J[s]
-  for (uint64_t g = (uint64_t)blockIdx.x * WV + wv; g < nseg; g += (uint64_t)gridDim.x * WV) {
-  const uint32_t doc = seg_doc[g];
-  const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
-  const uint64_t rem = doc_end[doc] - begin;
-  const int seglen = rem > SEG ? SEG : (int)rem;
-  constexpr int NS = 2 * SEG / 64, N0 = SEG / 64;   // states per lane: k < N0 -> (p = k*64+lane, fd 0), else fd 1
-  uint32_t r[NS], jr[NS];
-#pragma unroll
-  for (int it = 0; it < N0; it++) {
-    const int p = it * 64 + lane;
-    r[it] = p < seglen ? R0[begin + p] : R_INVALID;
-  }
-  // the few T(p,1) words of the segment come as a side list (scattered through LDS), or, if there were too many, densely
-  const uint32_t nside = side[g * SIDE_STRIDE].x;
-  if (nside == SIDE_DENSE) {
-#pragma unroll
-    for (int it = 0; it < N0; it++) { const int p = it * 64 + lane; r[N0 + it] = p < seglen ? R1[begin + p] : R_INVALID; }
-  } else if (nside == 0) {
-#pragma unroll
-    for (int it = 0; it < N0; it++) r[N0 + it] = R_INVALID;
-  } else {
-#pragma unroll
-    for (int it = 0; it < N0; it++) RK[it * 64 + lane] = R_INVALID;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0);
-    if ((uint32_t)lane < nside) { const uint2 sv = side[g * SIDE_STRIDE + 1 + lane]; RK[sv.x] = sv.y; }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll
-    for (int it = 0; it < N0; it++) r[N0 + it] = RK[it * 64 + lane];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0);
-  }
-  bool pend[NS];
-  bool any0 = false, any1 = false;
-#pragma unroll
-  for (int k = 0; k < NS; k++) {
-    const int p = (k % N0) * 64 + lane;
-    uint32_t j = 0x80000000u;                             // p >= seglen or unreachable: absorbing, emits nothing
-    if (r[k] != R_INVALID) {
-      const int pn = p + (int)((r[k] >> 24) & 63u);
-      const uint32_t fdn = (r[k] >> 30) & 1u;
-      const uint32_t nt = ((r[k] & ID_NONE) != ID_NONE ? 1u : 0u) + fdn;
-      j = (pn >= seglen ? 0x80000000u : (jbase + 4u * (fdn * SEG + (uint32_t)pn)) << 16) | nt;
-    }
-    jr[k] = j;
-    J[k * 64 + lane] = j;
-    RK[k * 64 + lane] = 0xFFFFFFFFu;
-    pend[k] = (int)j >= 0;
-    if (k < N0) any0 |= pend[k]; else any1 |= pend[k];
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  const int e = seg_entry[g];
-  const int se = (e & 1) * SEG + (e >> 1);
-  if (lane == 0) RK[se] = 0;
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  // One round, for every state that still points inside the segment: if it is known to be on the chain, tell the state
-  // it points at its rank; then double its own pointer.  Unlike the exit maps of K1 this needs every pointer of a round
-  // to be read before any is written (the marks only cover the chain if all pointers are the same power of two), hence
-  // the barrier in the middle.  The (p,1) states are rarely alive and skipped as a group.
-  for (int round = 0; round < 12; round++) {
-    uint32_t bn[NS], rk[NS];
-    const bool g0 = __any(any0), g1 = __any(any1);
-    if (g0) {
-#pragma unroll
-      for (int k = 0; k < N0; k++) if (pend[k]) { bn[k] = *(lds_u32*)(uintptr_t)(jrel + (jr[k] >> 16)); rk[k] = RK[k * 64 + lane]; }
-    }
-    if (g1) {
-#pragma unroll
-      for (int k = N0; k < NS; k++) if (pend[k]) { bn[k] = *(lds_u32*)(uintptr_t)(jrel + (jr[k] >> 16)); rk[k] = RK[k * 64 + lane]; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0);
-    auto update = [&](int k0, int k1, bool& any) {
-      any = false;
-#pragma unroll
-      for (int k = k0; k < k1; k++) {
-        if (pend[k]) {
-          if (rk[k] != 0xFFFFFFFFu) ((lds_u32*)(uintptr_t)(jrel + (jr[k] >> 16)))[RKD] = rk[k] + (jr[k] & 0xFFFFu);
-          jr[k] = (jr[k] & 0xFFFFu) + bn[k];
-          J[k * 64 + lane] = jr[k];
-          pend[k] = (int)jr[k] >= 0;
-          any |= pend[k];
-        }
-      }
-    };
-    if (g0) update(0, N0, any0);
-    if (g1) update(N0, NS, any1);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0);
-    if ((int)J[se] < 0) break;                             // wave-uniform (same address in every lane): the entry's chain has left
-  }
-  const uint64_t base = HIST ? 0 : tok_offsets[doc] + seg_tokbase[g];
-  uint32_t ntok = 0, ndel = 0;
-#pragma unroll
-  for (int k = 0; k < NS; k++) {
-    const uint32_t rank = RK[k * 64 + lane];
-    if (rank != 0xFFFFFFFFu && r[k] != R_INVALID) {
-      const uint32_t id = r[k] & ID_NONE, fdn = (r[k] >> 30) & 1u;
-      if (!HIST) {
-        uint64_t o = base + rank;
-        if (id != ID_NONE) { if (o < out_cap) out[o] = id; o++; }
-        if (fdn && o < out_cap) out[o] = delete_id;
-      } else {
-        const int p = (k % N0) * 64 + lane;
-        if (r[k] >> 31) {                                  // trainvocab.go:1166-1173: no token for this byte
-          const uint32_t byte = text[begin + p];
-          atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
-        } else {
-          const uint32_t adv = (r[k] >> 24) & 63u;         // scores[id] += bytes covered (:1109..1162)
-          const uint32_t slot = id & (HSLOTS - 1);
-          uint32_t owner = s_tag[slot];
-          if (owner == 0xFFFFFFFFu) { owner = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, id); if (owner == 0xFFFFFFFFu) owner = id; }
-          if (owner == id) atomicAdd(&s_cnt[slot], adv);
-          else atomicAdd(&scores[id], adv);
-        }
-        ntok += 1 + fdn;                                   // tokensInText++ (also for a missing byte, :1169) / += 2
-        ndel += fdn;                                       // scores[deleteToken]++ (:1134,1143,1152)
-      }
-    }
-  }
-  if (HIST) {
-    for (int o = 32; o > 0; o >>= 1) { ntok += __shfl_xor(ntok, o); ndel += __shfl_xor(ndel, o); }
-    if (lane == 0) {
-      if (ndel) atomicAdd(&s_ndel, ndel);
-      if (ntok) atomicAdd(&s_ntok, (unsigned long long)ntok);
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  }  // segments of this wavefront
-  if (HIST) {
-    __syncthreads();
-    for (int j = threadIdx.x; j < HSLOTS; j += WV * 64)
-      if (s_cnt[j] != 0) atomicAdd(&scores[s_tag[j]], s_cnt[j]);
-    if (threadIdx.x == 0) {
-      if (s_ndel) atomicAdd(&scores[delete_id], s_ndel);
-      if (s_ntok) atomicAdd(tokens, s_ntok);
-    }
-  }
-}
 
-// K4 as a chain walk through LDS tiles.  The parallel ranking above spends ~500 vector instructions per segment to rank 512
-// states of which ~60 are on the chain.  Here a wavefront takes TS consecutive segments: their T(p,0) words are streamed into LDS
+// K4 as a chain walk through LDS tiles (a parallel list ranking of all 512 states of a segment, of which ~60 are on the chain,
+// was measured at 5.5 ms per GiB against 3.3 for this walk and has been removed).  A wavefront takes TS consecutive segments: their T(p,0) words are streamed into LDS
 // with full-width 16-byte loads, then lane s simply follows the chain of segment s through its row (one dependent LDS read and
 // ~15 instructions per token, for 16 segments at once).  The ids are staged in the part of the row the walk has already left
 // and leave in coalesced stores.  The kernel is bound by the latency of the walk, i.e. by how many rows fit the LDS of a CU.
 // (p,1) states are rare: their words are looked up in the segment's side list (or the dense array) when one is entered.
-// (Letting every lane walk its segment straight from HBM — no tiles — was measured at 8.5 ms per GiB against 5.5 for the
-// ranking kernel: ~0.6 G scattered 4-byte accesses cost ~8 cycles each per CU.)
+// (Letting every lane walk its segment straight from HBM — no tiles — was measured at 8.5 ms per GiB: ~0.6 G scattered 4-byte
+// accesses cost ~8 cycles each per CU.)
 constexpr int TS = 8;                   // segments per wavefront (8: 18 wavefronts per CU; 16 was 8 % slower, the phases of a tile overlap less)
 constexpr int TSLACK = 2;               // position p of a row is word TSLACK + p: the two ids of a first token fit in front of it
 constexpr int TROW = SEG + 8;           // words per tile row (16-byte multiple; the odd multiple of 8 spreads the rows over the LDS banks)
 
 // k_seg_params: everything K4 needs to know about a segment in one 16-byte record, so that a tile starts with ONE round of loads
 // instead of a chain of three (segment -> document -> offsets):
-//   x = begin[0..31]   y = begin[32..39] | seglen << 8 (9 bits) | entry state << 20 (7 bits)   z, w = first output index (64 bit)
+//   x = begin[0..31]   y = begin[32..39] | seglen << 8 (12 bits) | entry state << 20 (7 bits)   z, w = first output index (64 bit)
 // Record nseg holds the end of the output stream.
 __global__ void k_seg_params(const uint64_t* __restrict__ doc_begin, const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ seg_doc,
                              const uint64_t* __restrict__ doc_seg_start, uint64_t nseg, uint32_t ndocs, const uint8_t* __restrict__ seg_entry,
@@ -1085,7 +806,7 @@ __device__ __forceinline__ TileSeg tile_segment(const uint4* __restrict__ par, u
   if (t.have) {
     const uint4 q = par[g];
     t.begin = (uint64_t)q.x | ((uint64_t)(q.y & 0xFFu) << 32);
-    t.seglen = (q.y >> 8) & 0x1FFu;
+    t.seglen = (q.y >> 8) & 0xFFFu;
     t.entry = (q.y >> 20) & 0x7Fu;
     t.base = (uint64_t)q.z | ((uint64_t)q.w << 32);
   }
@@ -1098,26 +819,32 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
 // 4l..4l+3 of a row with one 16-byte load (R0 + begin is only 4-byte aligned: gfx950 global loads do not ask for more).  All
 // loads are issued before the first LDS write, so a tile costs one HBM latency, not sixteen.
 __device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg& t, int nv, int lane, const uint32_t* __restrict__ R0) {
-  uint4 v[TS];
+  constexpr int PARTS = SEG / 256;                                       // a row is fetched 256 words (one 16-byte load per lane) at a time
+  static_assert(SEG % 256 == 0, "tile_load fetches rows in units of 256 words");
+  uint4 v[TS][PARTS];
   const uint32_t* src[TS];
-  bool want[TS];
+  uint32_t len[TS];
 #pragma unroll
   for (int s = 0; s < TS; s++) {
     const int ss = s < nv ? s : nv - 1;                                // rows beyond the last segment: nothing is fetched
     src[s] = R0 + shfl_u64(t.begin, ss) + 4 * lane;
-    want[s] = s < nv && 4u * (uint32_t)lane < (uint32_t)__shfl((int)t.seglen, ss);   // at most 3 words past the segment: R0 has 64 of slack
+    len[s] = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;        // at most 3 words past the segment: R0 has 64 of slack
   }
 #pragma unroll
-  for (int s = 0; s < TS; s++) {
-    v[s] = make_uint4(0u, 0u, 0u, 0u);
-    if (want[s]) __builtin_memcpy(&v[s], src[s], 16);
-  }
+  for (int s = 0; s < TS; s++)
 #pragma unroll
-  for (int s = 0; s < TS; s++) {                                       // TSLACK = 2: the row is 8-byte, not 16-byte, aligned
-    uint2* dst = reinterpret_cast<uint2*>(&tile[s][TSLACK + 4 * lane]);
-    dst[0] = make_uint2(v[s].x, v[s].y);
-    dst[1] = make_uint2(v[s].z, v[s].w);
-  }
+    for (int h = 0; h < PARTS; h++) {
+      v[s][h] = make_uint4(0u, 0u, 0u, 0u);
+      if (4u * (uint32_t)lane + 256u * h < len[s]) __builtin_memcpy(&v[s][h], src[s] + 256 * h, 16);
+    }
+#pragma unroll
+  for (int s = 0; s < TS; s++)
+#pragma unroll
+    for (int h = 0; h < PARTS; h++) {                                    // TSLACK = 2: the row is 8-byte, not 16-byte, aligned
+      uint2* dst = reinterpret_cast<uint2*>(&tile[s][TSLACK + 4 * lane + 256 * h]);
+      dst[0] = make_uint2(v[s][h].x, v[s][h].y);
+      dst[1] = make_uint2(v[s][h].z, v[s][h].w);
+    }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
 }
@@ -1176,8 +903,8 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
   }
 }
 
-// K4, scoring variant of the tile walk (training/trainvocab.go:1105-1174): persistent workgroups as in k_chain<true> (the
-// LDS-privatised histogram is what keeps the hot ids off the L2 atomics), every wavefront walks tiles of TS segments.
+// K4, scoring variant of the tile walk (training/trainvocab.go:1105-1174): persistent workgroups (the LDS-privatised histogram is
+// what keeps the hot ids off the L2 atomics), every wavefront walks tiles of TS segments.
 template <int WV>
 __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
                                                         const uint32_t* __restrict__ R1, const uint8_t* __restrict__ text,
@@ -1269,14 +996,28 @@ using namespace tmh;
 
 namespace tmh {
 
-// development switches (tm_debug_flags; TM_DBG in the environment sets the initial value).  K1 phases off (wrong results, for
-// profiling): bit 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps; bit 9: 4 KB of dummy LDS per K1
-// workgroup (24 instead of 28 wavefronts per CU).  Alternative implementations with the same results: bit 6 dense T(p,1) array for
-// every segment, 7 list-ranking K4, 8 per-lane normalizer kernel, 10 K4 tile walk without staging (every id stored directly),
-// 11 experimental split pipeline (k_match_runs + k_match_branch<true>).  0 in production.
+// Test hooks (tm_debug_flags): bits that force a rarely taken fallback path of the product so that the tests can cover it, with the
+// same results: 6 = dense T(p,1) array for every segment, 8 = per-lane normalizer kernel, 10 = K4 tile walk that stores every id
+// directly.  Nothing else is reachable in the default build.  With -DTM_DEVEL (tools/ only: results are WRONG) further bits switch
+// phases of K1 off for profiling — 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps — bit 9 adds 4 KB
+// of dummy LDS per K1 workgroup, and TM_DBG in the environment sets the initial value.
+#ifdef TM_DEVEL
+constexpr int kDebugMask = ~0;
+#define TM_K1_EXTRA_LDS ((debug_flags() & 512) ? 4096 : 0)
+#else
+constexpr int kDebugMask = 64 | 256 | 1024;
+#define TM_K1_EXTRA_LDS 0
+#endif
 int g_debug_flags = -1;
 int debug_flags() {
-  if (g_debug_flags < 0) { const char* e = getenv("TM_DBG"); g_debug_flags = e ? atoi(e) : 0; }
+  if (g_debug_flags < 0) {
+#ifdef TM_DEVEL
+    const char* e = getenv("TM_DBG");
+    g_debug_flags = e ? atoi(e) : 0;
+#else
+    g_debug_flags = 0;
+#endif
+  }
   return g_debug_flags;
 }
 
@@ -1300,15 +1041,12 @@ static void launch_seg_params(tm_batch* b, hipStream_t st);
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
                        uint32_t n_ids, hipStream_t st) {
   const uint64_t nseg = b->nseg;
-  if (nseg > 0 && !(debug_flags() & 128)) {
+  if (nseg > 0) {
     launch_seg_params(b, st);
-    k_score_tiles<10><<<(uint32_t)std::min<uint64_t>((nseg + 10 * TS - 1) / (10 * TS), (uint64_t)n_cu), 10 * 64, 0, st>>>(
+    constexpr int WV = SEG <= 256 ? 10 : 5;      // wavefronts of a scoring workgroup: as many tiles as fit the LDS beside the histogram
+    k_score_tiles<WV><<<(uint32_t)std::min<uint64_t>((nseg + WV * TS - 1) / (WV * TS), (uint64_t)n_cu), WV * 64, 0, st>>>(
         b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_seg_par, nseg, delete_id, d_hist, d_tokens, d_missing_bits, b->d_error);
   }
-  else if (nseg > 0)
-    k_chain<true, 16><<<(uint32_t)std::min<uint64_t>((nseg + 15) / 16, (uint64_t)n_cu), 1024, 0, st>>>(
-        b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets,
-        delete_id, 0, nullptr, d_hist, d_tokens, d_missing_bits);
   k_hist_finish<<<1, 256, 0, st>>>(d_tokens, d_missing_bits, d_hist + n_ids);
 }
 
@@ -1317,18 +1055,12 @@ static void launch_seg_params(tm_batch* b, hipStream_t st) {
   k_seg_params<<<(uint32_t)((b->nseg + 1 + 255) / 256), 256, 0, st>>>(b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, b->nseg, b->ndocs, b->d_seg_entry,
                                                                       b->d_seg_tokbase, b->d_tok_offsets, b->d_seg_par);
 }
-// K4 for the id-emitting entry points: the tile walk; debug bit 7 selects the list-ranking kernel instead
+// K4 for the id-emitting entry points: the tile walk (test hook bit 10: every id stored directly, the overflow path of the staging)
 static void launch_emit(tm_batch* b, hipStream_t st) {
   const uint64_t nseg = b->nseg;
-  if (debug_flags() & 128)
-    k_chain<false, 4><<<(uint32_t)((nseg + 3) / 4), 256, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start,
-                                                               nseg, b->d_seg_entry, b->d_seg_tokbase, b->d_tok_offsets, b->vocab->tables.delete_id,
-                                                               b->out_cap, b->d_out, nullptr, nullptr, nullptr);
-  else {
-    launch_seg_params(b, st);
-    k_emit_tiles<<<(uint32_t)((nseg + TS - 1) / TS), 64, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, b->out_cap, b->d_out,
-                                                                 b->d_error, (debug_flags() & 1024) ? 512u : 0u);
-  }
+  launch_seg_params(b, st);
+  k_emit_tiles<<<(uint32_t)((nseg + TS - 1) / TS), 64, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, b->out_cap, b->d_out,
+                                                               b->d_error, (debug_flags() & 1024) ? 512u : 0u);
 }
 
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {
@@ -1401,28 +1133,10 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
     if (nseg > 0) k_segments<<<(uint32_t)((nseg + 255) / 256), 256, 0, st>>>(b->d_doc_seg_start, nd, nseg, b->d_seg_doc);
   }
   mark(1);
-  if (nseg > 0 && (debug_flags() & 2048)) {
-    // experimental split pipeline: k_match_runs (step A1 over 1 KiB chunks) + k_match_branch<true>
-    const uint64_t max_chunks = b->max_bytes / CHUNK + (uint64_t)b->max_docs + 2;
-    if (!b->d_A) {
-      if ((e = dalloc(b, &b->d_A, b->max_bytes + 64)) != hipSuccess || (e = dalloc(b, &b->d_doc_nchunk, (uint64_t)b->max_docs + 1)) != hipSuccess ||
-          (e = dalloc(b, &b->d_doc_chunk_start, (uint64_t)b->max_docs + 2)) != hipSuccess || (e = dalloc(b, &b->d_chunk_doc, max_chunks)) != hipSuccess)
-        return hip_fail(e, "hipMalloc (split pipeline)");
-    }
-    const uint64_t chunk_bound = b->nbytes / CHUNK + (uint64_t)nd + 1;       // the exact number is only on the device (d_totals[3])
-    k_doc_nseg<<<(nd + 255) / 256, 256, 0, st>>>(b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nchunk, (uint32_t)CHUNK);
-    scan_u32(b->d_doc_nchunk, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_chunk_start, st);
-    k_segments<<<(uint32_t)((chunk_bound + 255) / 256), 256, 0, st>>>(b->d_doc_chunk_start, nd, chunk_bound, b->d_chunk_doc);
-    k_match_runs<<<(uint32_t)((chunk_bound + WAVES - 1) / WAVES), WAVES * 64, 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_chunk_doc,
-                                                                                       b->d_doc_chunk_start, b->d_totals + 3, b->d_A);
-    k_match_branch<true><<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
-                                                                                      b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
-                                                                                      debug_flags(), b->d_A);
-  } else if (nseg > 0)
-    // (debug bit 9: 4 KB of unused dynamic LDS per workgroup = 6 instead of 7 workgroups per CU, to measure what occupancy is worth)
-    k_match_branch<false><<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, (debug_flags() & 512) ? 4096 : 0, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
-                                                                                b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
-                                                                                debug_flags(), nullptr);
+  if (nseg > 0)
+    k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
+                                                                                          b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
+                                                                                          debug_flags());
   mark(2);
   if (nd > 0)
     k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_seg_entry, b->d_seg_tokbase,
@@ -1479,7 +1193,7 @@ const char* tm_kernel_name(int k) { return k >= 0 && k < TM_NUM_KERNELS ? kKerne
 
 int tm_debug_flags(int flags) {
   const int old = tmh::debug_flags();
-  if (flags >= 0) tmh::g_debug_flags = flags;
+  if (flags >= 0) tmh::g_debug_flags = flags & tmh::kDebugMask;
   return old;
 }
 
@@ -1525,7 +1239,7 @@ int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm
 void tm_batch_free(tm_batch* b) {
   if (!b) return;
   void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R0, b->d_R1, b->d_side, b->d_exitmap, b->d_seg_entry,
-                  b->d_seg_tokbase, b->d_seg_par, b->d_A, b->d_doc_nchunk, b->d_doc_chunk_start, b->d_chunk_doc, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
+                  b->d_seg_tokbase, b->d_seg_par, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
                   b->d_error, b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
                   b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,
                   b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_raw, b->d_fb_norm, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids};

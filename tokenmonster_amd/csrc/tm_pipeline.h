@@ -23,7 +23,6 @@ constexpr uint32_t ID_NONE = 0xFFFFFFu;
 constexpr int NOSCORE = -1000000;
 constexpr int SIDE_STRIDE = 16;            // uint2 entries of a segment's side list: [0] = {count or SIDE_DENSE, 0}, then {position, T(p,1)}
 constexpr uint32_t SIDE_DENSE = 0xFFFFFFFFu;  // more (p,1) states than the list holds: they are in the dense R1 array instead
-constexpr int CHUNK = 1024;               // positions one wavefront of k_match_runs walks (split pipeline, debug bit 11)
 constexpr uint32_t LONG_SEGS = 512;        // documents with more segments than this are resolved hierarchically
 
 constexpr int SCAN_T = 256, SCAN_PER = 16, SCAN_CH = SCAN_T * SCAN_PER;   // exclusive scan u32 -> u64: elements per workgroup
@@ -59,9 +58,6 @@ struct tm_batch {
   uint2* d_exitmap = nullptr;
   uint8_t* d_seg_entry = nullptr;
   uint32_t* d_seg_tokbase = nullptr;
-  // split pipeline (debug bit 11, experimental): step A1 as its own kernel over 1 KiB chunks, results handed over in d_A
-  uint32_t* d_A = nullptr;             // len | record ordinal << 6 of the longest match at every byte position
-  uint32_t* d_doc_nchunk = nullptr; uint64_t* d_doc_chunk_start = nullptr; uint32_t* d_chunk_doc = nullptr;
   uint4* d_seg_par = nullptr;          // per segment: begin | length | entry state | first output index (k_seg_params)
   uint32_t* d_doc_ntok = nullptr;
   uint32_t* d_doc_events = nullptr;

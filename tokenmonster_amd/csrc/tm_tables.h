@@ -57,13 +57,19 @@ __host__ __device__ inline uint32_t flag8_to_flag5(uint32_t f) {
   return (f & 1u) | (((f >> 1) & 1u) << 1) | (((f >> 2) & 1u) << 2) | (((f >> 4) & 1u) << 3) | (((f >> 7) & 1u) << 4);
 }
 
-// Row of record `index` (16 B): what the walk needs when the record is the FIRST token of a branch
-// (tokenOuter, go/tokenmonster.go:63-77, with id1/id2/length/length2 resolved as Load does, :2703-2712).
-//   x = id   | flag   << 24
-//   y = id1  | nWords << 24
-//   z = id2  | len1   << 24           len1 == 0  <=>  index  == DOES_NOT_EXIST
-//   w = len2 | nWords1 << 6 | nWords2 << 11 | f1 << 16 | f2 << 19     len2 == 0 <=> index2 == DOES_NOT_EXIST
-//       f1/f2: the three flag bits a FIRST token is asked for (b0 flag&1, b1 (flag>>3)&1, b2 flag>>7)
+// Row of record `index` (16 B): what the walk needs when the record is the FIRST token of a branch (tokenOuter,
+// go/tokenmonster.go:63-77, with id1/id2/length/length2 resolved as Load does, :2703-2712) — with everything about the three
+// candidate first tokens (the record itself, alternative 1, alternative 2) that does not depend on the text folded into constants
+// at load, so that scoring a branch (go :1075-1084) is a handful of adds:
+//   x = id  | c0     << 20      c0     = allLetters + max0(nWords-1) + nWords*100 of the record (its length comes with the match)
+//   y = id1 | fpart1 << 20      fpartK = lenK + allLettersK + max0(nWordsK-1) + nWordsK*100 of alternative K
+//   z = id2 | fpart2 << 20
+//   w = len1 | len2 << 6 | endsWithLetter{0,1,2} << 12 | endsOnCapcode{0,1,2} << 15 | (nWords >= 2){0,1,2} << 18 | flag&32 << 21
+//       len1 == 0 <=> index == DOES_NOT_EXIST, len2 == 0 <=> index2 == DOES_NOT_EXIST
+// ids take 20 bits: a vocabulary with more than 2^20 ids is refused at load (the reference's format allows 2^24 - 1; its trained
+// vocabularies stop at 100 256).  In a forward-delete state (go :1088-1105: nWords - 1, length - 1) a candidate's constant is
+// c - 100 - (nWords >= 2) resp. fpart - 101 - (nWords >= 2).
+constexpr uint32_t kRowIdBits = 20, kRowIdMask = (1u << kRowIdBits) - 1;
 struct alignas(16) Row { uint32_t x, y, z, w; };
 
 struct Tables {

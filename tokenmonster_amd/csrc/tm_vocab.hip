@@ -57,6 +57,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   if (hv.unk != TM_NONE && hv.unk >= hv.n_ids) return set_error(TM_E_INVALID, "unk token id %u out of range (%u ids)", hv.unk, hv.n_ids);
   if (hv.delete_id != TM_NONE && hv.delete_id >= hv.n_ids) return set_error(TM_E_INVALID, "deleteToken id %u out of range (%u ids)", hv.delete_id, hv.n_ids);
   if (hv.max_len > 40) return set_error(TM_E_INVALID, "maxTokenLength %u > 40", hv.max_len);                      // go :2695
+  if (hv.n_ids > kRowIdMask) return set_error(TM_E_LIMIT, "%u ids: the device tables hold at most %u", hv.n_ids, kRowIdMask);
   if (hv.n_info >= kMaxNodes) return set_error(TM_E_LIMIT, "%u index records: the walk tables hold fewer than %u trie nodes", hv.n_info, kMaxNodes);
   if ((uint64_t)hv.n_info * 16 > n) return set_error(TM_E_INVALID, "truncated .vocab: %u records do not fit %zu bytes", hv.n_info, n);
   hv.keys.clear(); hv.key_off.assign(1, 0); hv.rows.resize(hv.n_info);
@@ -79,21 +80,23 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     if (id >= hv.n_ids) return set_error(TM_E_INVALID, "record %u: id %u out of range", i, id);
     if (nw > 31) return set_error(TM_E_LIMIT, "record %u: nWords %u > 31", i, nw);
     lens[i] = (uint8_t)kl; flags[i] = (uint8_t)flag; nwords[i] = (uint8_t)nw; ids[i] = id;
-    uint32_t id1 = 0, id2 = 0, len1 = 0, len2 = 0, nw1 = 0, nw2 = 0, f1 = 0, f2 = 0;
-    auto first3 = [](uint32_t fl) { return (fl & 1u) | (((fl >> 3) & 1u) << 1) | (((fl >> 7) & 1u) << 2); };
+    uint32_t id1 = 0, id2 = 0, len1 = 0, len2 = 0, nw1 = 0, nw2 = 0, fl1 = 0, fl2 = 0;
     if (index1 != TM_NONE) {                                   // go :2703-2706
       if (index1 >= i) return set_error(TM_E_INVALID, "record %u: alternative does not precede it", i);
-      len1 = lens[index1]; id1 = ids[index1]; nw1 = nwords[index1]; f1 = first3(flags[index1]);
+      len1 = lens[index1]; id1 = ids[index1]; nw1 = nwords[index1]; fl1 = flags[index1];
     }
     if (index2 != TM_NONE) {                                   // go :2708-2711
       if (index2 >= i) return set_error(TM_E_INVALID, "record %u: alternative does not precede it", i);
-      len2 = lens[index2]; id2 = ids[index2]; nw2 = nwords[index2]; f2 = first3(flags[index2]);
+      len2 = lens[index2]; id2 = ids[index2]; nw2 = nwords[index2]; fl2 = flags[index2];
     }
+    // first-token constants (tm_tables.h): allLetters + max0(nWords-1) + nWords*100 (+ the length, for the alternatives)
+    auto fconst = [](uint32_t fl, uint32_t nwk) { return ((fl >> 7) & 1u) + (nwk > 0 ? nwk - 1 : 0u) + nwk * 100u; };
     Row& r = hv.rows[i];
-    r.x = id | (flag << 24);
-    r.y = id1 | (nw << 24);
-    r.z = id2 | (len1 << 24);
-    r.w = len2 | (nw1 << 6) | (nw2 << 11) | (f1 << 16) | (f2 << 19);
+    r.x = id | (fconst(flag, nw) << kRowIdBits);
+    r.y = id1 | ((len1 ? len1 + fconst(fl1, nw1) : 0u) << kRowIdBits);
+    r.z = id2 | ((len2 ? len2 + fconst(fl2, nw2) : 0u) << kRowIdBits);
+    r.w = len1 | (len2 << 6) | ((flag & 1u) << 12) | ((fl1 & 1u) << 13) | ((fl2 & 1u) << 14) | (((flag >> 3) & 1u) << 15) | (((fl1 >> 3) & 1u) << 16) |
+          (((fl2 >> 3) & 1u) << 17) | ((nw >= 2 ? 1u : 0u) << 18) | ((nw1 >= 2 ? 1u : 0u) << 19) | ((nw2 >= 2 ? 1u : 0u) << 20) | (((flag >> 5) & 1u) << 21);
   }
   NEED(256);
   std::memcpy(hv.begin_byte, f + pos, 256);

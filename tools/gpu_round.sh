@@ -1,20 +1,18 @@
 #!/bin/bash
-# One GPU call of a development round: the -m gpu parity suite, then the end-to-end bench with the kernel variants behind the
-# debug bits timed in the same process.  Everything lands in gpurun_out/$1.
+# One GPU call of a development round: the -m gpu parity suite, then the end-to-end bench, the scoring bench and the per-kernel times.  Everything lands in gpurun_out/$1.
 set -u
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/${1:-round}
 mkdir -p $OUT
 timeout 1200 python -m pytest tests -m gpu -q --timeout=400 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> $OUT/pytest_gpu.log
-timeout 600 python bench.py --steps 5 --warmup 2 --also-flags ${2:-128,256,384} > $OUT/bench_e2e_1g.json 2> $OUT/bench_e2e_1g.err
+timeout 600 python bench.py --steps 5 --warmup 2 > $OUT/bench_e2e_1g.json 2> $OUT/bench_e2e_1g.err
 echo "bench exit $?" >> $OUT/bench_e2e_1g.err
 tail -15 $OUT/pytest_gpu.log
 cat $OUT/bench_e2e_1g.json
 grep -E "variant|exit|normalize|INVALID|Error|error" $OUT/bench_e2e_1g.err | tail -20
 timeout 600 python bench.py --workload score --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_score_1g.json 2> $OUT/bench_score_1g.err
 cut -c1-400 $OUT/bench_score_1g.json; echo
-TM_DBG=128 timeout 600 python bench.py --workload score --steps 5 --warmup 2 --no-cpu-baseline --verify 0 2>/dev/null | cut -c1-330; echo
 # per-kernel times of the same step (rocprofv3 kernel trace)
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/stats_e2e -o e2e --output-format csv -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --verify 0 > $OLDPWD/$OUT/bench_under_rocprof.json 2> $OLDPWD/$OUT/stats_e2e.err)
 f=$(find $OUT/stats_e2e -name "*kernel_stats.csv" | head -1)

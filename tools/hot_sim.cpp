@@ -1,0 +1,135 @@
+// hot_sim.cpp — development aid: how much of K1's table traffic a small, statically chosen HOT table could absorb.
+// Replays step A1 of k_match_branch (direct map / suffix links / two-slot buckets with the child filters, as the kernel walks them)
+// over a synthetic corpus, counts how often every 16-byte table entry and every row is gathered, and prints the share of the
+// gathers the K most frequently used entries cover (K = what fits 4 .. 128 KB).
+//   hipcc -O2 -std=c++17 -I include -I tokenmonster_amd/csrc tools/hot_sim.cpp -o /tmp/hot_sim -Ltokenmonster_amd -ltokenmonster_hip -ltm_testsupport -Wl,-rpath,$PWD/tokenmonster_amd
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "tm_build.h"
+#include "tm_testsupport.h"
+#include "tm_device.h"
+#include "tm_pipeline.h"
+
+using namespace tmh;
+
+static void coverage(const char* what, std::vector<uint64_t> cnt, size_t entry_bytes) {
+  uint64_t total = 0;
+  for (auto c : cnt) total += c;
+  std::sort(cnt.begin(), cnt.end(), [](uint64_t a, uint64_t b) { return a > b; });
+  size_t used = 0;
+  for (auto c : cnt) used += c != 0;
+  printf("%-28s total %11llu  distinct %8zu:", what, (unsigned long long)total, used);
+  for (size_t kb : {4, 8, 16, 32, 64, 128}) {
+    const size_t k = std::min(cnt.size(), kb * 1024 / entry_bytes);
+    uint64_t s = 0;
+    for (size_t i = 0; i < k; i++) s += cnt[i];
+    printf("  %zuK %.3f", kb, total ? (double)s / total : 0.0);
+  }
+  printf("\n");
+}
+
+int main(int argc, char** argv) {
+  const uint32_t kind = argc > 1 ? atoi(argv[1]) : TM_KIND_ENGLISHCODE;
+  const uint32_t vsize = argc > 2 ? atoi(argv[2]) : 32000;
+  const uint64_t nbytes = argc > 3 ? atoll(argv[3]) : (8ull << 20);
+  const uint32_t capcode = argc > 4 ? atoi(argv[4]) : 2;
+  const int seg = argc > 5 ? atoi(argv[5]) : SEG;
+  uint8_t* img = nullptr; size_t img_n = 0;
+  if (tm_synth_vocab(kind, vsize, capcode, 1, 3, 0x544D0002, 0, &img, &img_n) != 0) return 1;
+  HostVocab hv;
+  if (parse_vocab(img, img_n, hv) != 0) { fprintf(stderr, "parse failed: %s\n", last_error()); return 1; }
+  std::vector<uint8_t> raw(nbytes + 70000);
+  std::vector<uint64_t> roff(nbytes / 64 + 17);
+  uint32_t nd = 0; uint64_t nb = 0;
+  tm_synth_corpus(kind, 0x434F5250 + 2, nbytes, 2048, raw.data(), roff.data(), (uint32_t)roff.size() - 1, &nd, &nb);
+  uint8_t* text = nullptr; std::vector<uint64_t> off(nd + 1);
+  if (tm_normalize_batch(raw.data(), roff.data(), nd, capcode, 1, 0, &text, off.data()) != 0) return 1;
+  printf("vocab %u ids, n_info %u, nodes %u, tab %zu bytes; corpus %llu bytes in %u docs; segment %d\n", hv.n_ids, hv.n_info, hv.n_nodes, hv.tab.size() * 8,
+         (unsigned long long)off[nd], nd, seg);
+  const uint2* tab = hv.tab.data();
+  const size_t n16 = hv.tab.size() / 2;                        // 16-byte entries of the gather buffer
+  std::vector<uint64_t> c_direct(n16, 0), c_link(n16, 0), c_bucket(n16, 0), c_all(n16, 0), c_row(hv.n_info, 0), c_pair(65536, 0);
+  const size_t direct16 = hv.direct_off / 16, link16 = hv.link_off / 16;
+  const int Lmax = (int)hv.max_len;
+  uint64_t npos = 0, nrow = 0;
+  for (uint32_t d = 0; d < nd; d++) {
+    const uint64_t b0 = off[d], e0 = off[d + 1];
+    for (uint64_t begin = b0; begin < e0; begin += seg) {
+      const int dl = (int)std::min<uint64_t>(e0 - begin, 1 << 20);
+      const uint8_t* t = text + begin;
+      auto at = [&](int i) -> uint32_t { return i < dl ? t[i] : 0u; };
+      const int np = seg + 40;
+      const int ntask = std::min(np, dl);
+      const int nwalkpos = dl <= np ? ntask - 1 : ntask;
+      const int run = (std::max(nwalkpos, 0) + 63) >> 6;
+      for (int lane = 0; lane < 64; lane++) {
+        const int end = std::max(std::min(lane * run + run, nwalkpos), 0);
+        int depth = 0; uint32_t node = 0; bool first = true;
+        for (int pos = lane * run; pos < end; pos++) {
+          const int limit = std::min(dl - pos, Lmax);
+          size_t e16;
+          if (!first && depth >= 3) { e16 = link16 + node; c_link[e16]++; }
+          else { const uint32_t pr = at(pos) | (at(pos + 1) << 8); e16 = direct16 + pr; c_direct[e16]++; c_pair[pr]++; }
+          c_all[e16]++;
+          const uint2* e = tab + 2 * e16;
+          uint32_t src = e[0].x, filt = e[1].x, bestv = e[0].y;
+          depth = (int)((src >> 23) & 63u); node = src & kNodeMask;
+          bool from_set = true, go = (src & kHasChildren) != 0 && depth < limit;
+          while (go) {
+            const uint32_t c = at(pos + depth);
+            if (from_set ? !((filt >> (c & 31u)) & 1u) : !((filt >> (c & 3u)) & 1u)) break;
+            const uint32_t key = (node << 8) | c;
+            uint32_t h = edge_hash(node, c) >> hv.edge_shift;
+            bool hit = false;
+            for (;;) {
+              c_bucket[h]++; c_all[h]++;
+              const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1];
+              if ((s0.x & kKeyMask) == key) { hit = true; src = s0.y; filt = s0.x >> 28; break; }
+              if ((s1.x & kKeyMask) == key) { hit = true; src = s1.y; filt = s1.x >> 28; break; }
+              if (s1.x == kNone) break;
+              h = (h + 1) & hv.edge_mask;
+            }
+            if (!hit) break;
+            from_set = false; depth++; node = src & kNodeMask;
+            if (node < hv.n_info) bestv = src;
+            go = (src & kHasChildren) != 0 && depth < limit;
+          }
+          if (pos < seg && bestv != 0 && node_id(bestv) < hv.n_info) { c_row[node_id(bestv)]++; nrow++; }
+          first = false; npos++;
+        }
+      }
+    }
+  }
+  printf("positions walked %llu (%.3f per byte), row gathers %.3f per byte\n", (unsigned long long)npos, (double)npos / off[nd], (double)nrow / off[nd]);
+  coverage("SET via direct map (16 B)", c_direct, 16);
+  coverage("SET via suffix link (16 B)", c_link, 16);
+  coverage("PROBE buckets (16 B)", c_bucket, 16);
+  coverage("all A1 gathers (16 B)", c_all, 16);
+  coverage("rows (16 B)", c_row, 16);
+  // the direct map as a rank-mapped square: bytes sorted by how often they occur in a looked-up pair; share of the look-ups whose
+  // two bytes are both among the R most frequent ones (R*R entries)
+  {
+    std::vector<uint64_t> bc(256, 0);
+    for (uint32_t pr = 0; pr < 65536; pr++) { bc[pr & 255] += c_pair[pr]; bc[pr >> 8] += c_pair[pr]; }
+    std::vector<int> order(256);
+    for (int i = 0; i < 256; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return bc[a] > bc[b]; });
+    std::vector<int> rank(256);
+    for (int i = 0; i < 256; i++) rank[order[i]] = i;
+    uint64_t tot = 0;
+    for (auto c : c_pair) tot += c;
+    printf("direct map as a square of the R most frequent bytes:");
+    for (int R : {16, 24, 32, 48, 64}) {
+      uint64_t s = 0;
+      for (uint32_t pr = 0; pr < 65536; pr++) if (rank[pr & 255] < R && rank[pr >> 8] < R) s += c_pair[pr];
+      printf("  R=%d (%d KB at 16 B) %.3f", R, R * R * 16 / 1024, (double)s / tot);
+    }
+    printf("\n");
+  }
+  tm_free(text); tm_free(img);
+  return 0;
+}

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (history: ran at the commit before the split pipeline and the profiling switches were removed from the default build; results in
+# profiles/r02a_*)
 # round 2, GPU call 1: where K1's time goes (phases off) and the per-kernel / counter breakdown of the split pipeline (debug bit 11)
 set -u
 cd "$(dirname "$0")/.."
