@@ -172,13 +172,31 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
         dist.destroy_process_group()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1 (the container hostname may not resolve).  The children see WORLD_SIZE and take the normal path."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if world != args.gpus:      # never print a line whose n_gpus differs from what was asked for
+        raise SystemExit("WORLD_SIZE %d != --gpus %d (launch with --nproc-per-node equal to --gpus, or without a launcher)" % (world, args.gpus))
 
     def log(msg):
         if rank == 0:

@@ -81,6 +81,33 @@ int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const u
                                  uint32_t encoding_length, uint8_t* bytes_out, uint64_t bytes_cap,
                                  uint64_t* byte_offsets, uint32_t* missing, uint32_t* encoding_length_used);
 
+/* ---- large batches, host to host --------------------------------------------------------------------------------- */
+/* The three calls above borrow one LANE of the vocabulary (a HIP stream + a grow-only device workspace): steady state does
+ * no allocation and never touches the NULL stream, and concurrent callers (cgo calls run on distinct OS threads) take
+ * different lanes and overlap on the device; at most TM_LANES (environment, default 8) calls run at once, further callers wait.
+ *
+ * tm_tokenize_pipeline is the large-batch form of Vocab.TokenizeToSerialized over many documents: the corpus is cut into
+ * chunks of whole documents (about chunk_bytes, 0 = 64 MiB) that run H2D | normalize + tokenize + serialize | D2H on `lanes`
+ * lanes at once (0 = 3), so that PCIe moves the next chunk in and the previous one out while a chunk computes.  raw != 0: text is
+ * RAW UTF-8 and is normalized on the device (go/tokenmonster.go:242-253); raw == 0: already normalized.  Output: ids of all
+ * documents back to back, encoding_length bytes each, little-endian (0 = automatic, go :990-996); byte_offsets[ndocs+1] is
+ * always filled, so on TM_E_NOSPACE byte_offsets[ndocs] is the capacity required.  Buffers from tm_host_alloc (or registered
+ * with tm_host_register) are DMA'd directly; pageable buffers go through pinned staging at memcpy speed. */
+typedef struct tm_pipeline_stats {
+  uint32_t chunks, lanes;
+  int input_pinned, output_pinned;
+  uint64_t normalized_bytes;
+  uint32_t host_fallback_docs;
+} tm_pipeline_stats;
+int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, int raw,
+                         uint32_t encoding_length, uint64_t chunk_bytes, uint32_t lanes, uint8_t* bytes_out, uint64_t bytes_cap,
+                         uint64_t* byte_offsets, uint32_t* missing, uint32_t* encoding_length_used, tm_pipeline_stats* stats);
+/* Page-locked host memory for the buffers of tm_tokenize_pipeline (hipHostMalloc / hipHostRegister). */
+void* tm_host_alloc(size_t bytes);
+void tm_host_free(void* p);
+int tm_host_register(void* p, size_t bytes);
+int tm_host_unregister(void* p);
+
 /* ---- batch tokenize, device-resident: what bench.py times ------------------------------------ */
 /* A tm_batch owns device buffers sized for up to max_bytes of text in up to max_docs documents. */
 int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm_batch** out);

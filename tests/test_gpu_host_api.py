@@ -1,0 +1,94 @@
+"""-m gpu: the host-buffer entry points a Go caller binds (tokenmonster_amd/csrc/tm_host.hip): lanes (stream + grow-only workspace
+per concurrent caller, training/tokenmonsterserver.go:363-378 calls Tokenize from many goroutines at once) and the chunked
+host-to-host pipeline tm_tokenize_pipeline."""
+import threading
+
+import numpy as np
+import pytest
+
+import tokenmonster_amd as tm
+from oracle_bind import Oracle
+from tokenmonster_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _ids_from_bytes(blob, enc):
+    b = blob.reshape(-1, enc).astype(np.uint32)
+    out = b[:, 0] | (b[:, 1] << 8)
+    if enc >= 3:
+        out |= b[:, 2] << 16
+    return out
+
+
+@pytest.fixture(scope="module")
+def setup():
+    img = synth.synth_vocab(synth.ENGLISHCODE, 6000, capcode=2, norm_flag=1, level=3, seed=0x484F5354)
+    raw, roffs = synth.synth_corpus(synth.ENGLISHCODE, 3_000_000, seed=71)
+    text, offs = synth.normalize_batch(raw, roffs, 2, 1)
+    return img, raw, roffs, text, offs
+
+
+@pytest.mark.parametrize("raw_mode", [False, True])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_pipeline_equals_single_batch(setup, raw_mode, pinned):
+    img, raw, roffs, text, offs = setup
+    v = tm.Vocab(img)
+    ids, toff, miss = v.tokenize_packed(text, offs)
+    src, soff = (raw, roffs) if raw_mode else (text, offs)
+    keep = []
+    out = None
+    if pinned:
+        pin = tm.PinnedBuffer(src.size)
+        pin.array[:] = src
+        pout = tm.PinnedBuffer(2 * ids.size + 64)
+        keep += [pin, pout]
+        src, out = pin.array, pout.array
+    # small chunks: many chunks per lane, chunk boundaries everywhere, one document longer than a chunk
+    for chunk, lanes in ((200_000, 3), (40_000, 4), (1 << 30, 1)):
+        blob, boff, bmiss, enc, st = v.tokenize_pipeline(src, soff, raw=raw_mode, chunk_bytes=chunk, lanes=lanes, out=out)
+        assert enc == 2 and (bmiss == miss).all()
+        assert (boff == toff * np.uint64(2)).all()
+        assert (_ids_from_bytes(np.asarray(blob), 2) == ids).all()
+        assert st["input_pinned"] == int(pinned) and st["chunks"] >= 1
+    # 4-byte form, TM_E_NOSPACE path (out=None starts with a guess), empty corpus
+    blob, boff, _, enc, _ = v.tokenize_pipeline(src, soff, raw=raw_mode, encoding_length=4, chunk_bytes=300_000, out=np.empty(16, np.uint8))
+    assert enc == 4 and (_ids_from_bytes(np.asarray(blob), 4) == ids).all() and int(boff[-1]) == 4 * ids.size
+    blob, boff, _, _, _ = v.tokenize_pipeline(np.zeros(0, np.uint8), np.zeros(1, np.uint64), raw=raw_mode)
+    assert blob.size == 0 and boff.tolist() == [0]
+    del keep
+
+
+def test_concurrent_callers_take_lanes(setup):
+    """8 threads tokenize different batches on ONE vocabulary at once (cgo calls run on distinct OS threads): every result is
+    bit-exact, repeated calls reuse the lane workspaces (no growth of device memory after the first round)."""
+    img, raw, roffs, text, offs = setup
+    v, orc = tm.Vocab(img), Oracle(img)
+    nd = offs.size - 1
+    parts = []
+    for t in range(8):
+        d0, d1 = nd * t // 8, nd * (t + 1) // 8
+        sub_off = offs[d0:d1 + 1] - offs[d0]
+        parts.append((text[int(offs[d0]):int(offs[d1])], sub_off))
+    expect = [[orc.tokenize(p[int(o[d]):int(o[d + 1])])[0] for d in range(0, o.size - 1, 9)] for p, o in parts]
+    errors = []
+
+    def work(t):
+        try:
+            p, o = parts[t]
+            for _ in range(6):
+                ids, toff, _ = v.tokenize_packed(p, o)
+                counts, _ = v.count_packed(p, o)
+                for k, d in enumerate(range(0, o.size - 1, 9)):
+                    got = ids[int(toff[d]):int(toff[d + 1])]
+                    if got.size != expect[t][k].size or (got != expect[t][k]).any():
+                        raise AssertionError("thread %d doc %d differs" % (t, d))
+        except Exception as e:     # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors[:2]

@@ -41,6 +41,11 @@ SIGNATURES = {
     "tm_tokenize_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp]),
     "tm_count_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp]),
     "tm_tokenize_batch_serialized": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, u32p]),
+    "tm_tokenize_pipeline": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_uint64, vp, vp, u32p, vp]),
+    "tm_host_alloc": (vp, [C.c_size_t]),
+    "tm_host_free": (None, [vp]),
+    "tm_host_register": (C.c_int, [vp, C.c_size_t]),
+    "tm_host_unregister": (C.c_int, [vp]),
     "tm_batch_create": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
     "tm_batch_free": (None, [vp]),
     "tm_batch_upload": (C.c_int, [vp, vp, vp, C.c_uint32]),

@@ -35,6 +35,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv);
 
 struct tm_vocab;
 namespace tmh {
+struct LanePool;                       // tm_host.hip: streams + workspaces the host-buffer entry points borrow
+void pool_destroy(LanePool* p);
 // Every entry point that takes a vocabulary (or a batch / dataset bound to one) runs on the device the vocabulary's tables live
 // on, whatever device is current for the calling OS thread (cgo moves goroutines between threads): makes it current.
 int enter_device(const tm_vocab* v);
@@ -53,4 +55,5 @@ struct tm_vocab {
   uint8_t* d_rev_bytes = nullptr;
   tmh::Row* d_rows = nullptr;
   uint8_t* d_begin_byte = nullptr;
+  mutable tmh::LanePool* pool = nullptr;   // created on first use; the tables themselves are immutable
 };

@@ -1,0 +1,377 @@
+// tm_host.hip — the host-buffer entry points of the C ABI (include/tokenmonster_hip.h): what a Go caller binds.
+//
+// The reference fans documents out over goroutines, each calling Vocab.tokenize (training/tokenmonsterserver.go:363-378,
+// :773-787), and is reentrant: many callers tokenize at once on one read-only Vocab.  Here every call borrows a LANE of the
+// vocabulary: a HIP stream + a grow-only device workspace (tm_batch) + grow-only pinned staging.  Steady state does no
+// hipMalloc / hipFree and never touches the NULL stream; concurrent callers (cgo calls run on distinct OS threads) take
+// different lanes and overlap on the device.  tm_tokenize_pipeline is the large-batch form: the corpus is cut into chunks that
+// run H2D | normalize + tokenize (+ serialize) | D2H on several lanes at once, so that PCIe moves chunk k+1 in and chunk k-1 out
+// while chunk k computes — the host-to-host number of bench.py.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "tm_pipeline.h"
+
+namespace tmh {
+
+struct Lane {
+  hipStream_t stream = nullptr;
+  tm_batch* ws = nullptr;
+  uint8_t* h_stage = nullptr;     // pinned staging (input, then output), grow-only
+  uint64_t h_cap = 0;
+  uint8_t* d_bytes = nullptr;     // serialized ids on the device, grow-only
+  uint64_t d_bytes_cap = 0;
+  bool busy = false;
+};
+
+struct LanePool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Lane*> lanes;
+  size_t max_lanes = 8;
+};
+
+static void lane_destroy(Lane* l) {
+  if (!l) return;
+  tm_batch_free(l->ws);
+  if (l->stream) (void)hipStreamDestroy(l->stream);
+  (void)hipHostFree(l->h_stage);
+  (void)hipFree(l->d_bytes);
+  delete l;
+}
+
+void pool_destroy(LanePool* p) {
+  if (!p) return;
+  for (Lane* l : p->lanes) lane_destroy(l);
+  delete p;
+}
+
+static LanePool* pool_of(const tm_vocab* v) {
+  static std::mutex create_mu;
+  std::lock_guard<std::mutex> g(create_mu);
+  if (!v->pool) {
+    v->pool = new LanePool();
+    if (const char* e = getenv("TM_LANES")) { int n = atoi(e); if (n >= 1 && n <= 64) v->pool->max_lanes = (size_t)n; }
+  }
+  return v->pool;
+}
+
+// borrow a lane (blocks while all max_lanes are busy); *out is returned with busy == true
+static int lane_acquire(const tm_vocab* v, Lane** out) {
+  int rc = enter_device(v);
+  if (rc != TM_OK) return rc;
+  LanePool* p = pool_of(v);
+  std::unique_lock<std::mutex> lk(p->mu);
+  for (;;) {
+    for (Lane* l : p->lanes) if (!l->busy) { l->busy = true; *out = l; return TM_OK; }
+    if (p->lanes.size() < p->max_lanes) {
+      Lane* l = new Lane();
+      hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
+      if (e != hipSuccess) { delete l; return hip_fail(e, "hipStreamCreate (lane)"); }
+      l->busy = true;
+      p->lanes.push_back(l);
+      *out = l;
+      return TM_OK;
+    }
+    p->cv.wait(lk);
+  }
+}
+
+static void lane_release(const tm_vocab* v, Lane* l) {
+  LanePool* p = v->pool;
+  { std::lock_guard<std::mutex> g(p->mu); l->busy = false; }
+  p->cv.notify_one();
+}
+
+// grow-only: a workspace that is too small is replaced by one with headroom, so that a server converges to zero allocations
+static int lane_workspace(Lane* l, const tm_vocab* v, uint64_t bytes, uint32_t docs) {
+  if (l->ws && l->ws->vocab == v && l->ws->max_bytes >= bytes && l->ws->max_docs >= docs) return TM_OK;
+  uint64_t want_b = std::max<uint64_t>(bytes + bytes / 4 + (1u << 20), l->ws ? l->ws->max_bytes : 0);
+  uint64_t want_d = std::max<uint64_t>((uint64_t)docs + docs / 4 + 64, l->ws ? l->ws->max_docs : 0);
+  tm_batch_free(l->ws);
+  l->ws = nullptr;
+  return tm_batch_create(v, want_b, (uint32_t)std::min<uint64_t>(want_d, 0xFFFFFFF0ull), &l->ws);
+}
+
+static int lane_stage(Lane* l, uint64_t bytes) {
+  if (l->h_cap >= bytes) return TM_OK;
+  (void)hipHostFree(l->h_stage);
+  l->h_stage = nullptr;
+  l->h_cap = bytes + bytes / 4 + 4096;
+  hipError_t e = hipHostMalloc((void**)&l->h_stage, l->h_cap, hipHostMallocDefault);
+  if (e != hipSuccess) { l->h_cap = 0; return hip_fail(e, "hipHostMalloc (lane staging)"); }
+  return TM_OK;
+}
+
+static int lane_dbytes(Lane* l, uint64_t bytes) {
+  if (l->d_bytes_cap >= bytes) return TM_OK;
+  (void)hipFree(l->d_bytes);
+  l->d_bytes = nullptr;
+  l->d_bytes_cap = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc((void**)&l->d_bytes, l->d_bytes_cap);
+  if (e != hipSuccess) { l->d_bytes_cap = 0; return hip_fail(e, "hipMalloc (serialized ids)"); }
+  return TM_OK;
+}
+
+static bool is_pinned(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+struct RunOut { uint64_t total_tokens = 0; };
+
+// upload + run one batch on a lane; the ids stay on the device (l->ws->d_out)
+static int lane_run(Lane* l, const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, bool raw, bool emit, RunOut* ro) {
+  const uint64_t nbytes = ndocs ? offsets[ndocs] : 0;
+  // raw text grows under capcode (about 1.1x; worst case every byte a capital: "DC x" = 4x)
+  int rc = lane_workspace(l, v, raw ? nbytes + nbytes / 2 + 4096 : nbytes, ndocs);
+  if (rc != TM_OK) return rc;
+  tm_batch* b = l->ws;
+  if (raw) {
+    rc = batch_upload_raw_on(b, text, offsets, ndocs, l->stream);
+    if (rc == TM_OK) rc = tm_batch_normalize(b, l->stream);
+    if (rc == TM_E_LIMIT) {      // capital-heavy text: retry once with the worst-case workspace
+      if ((rc = lane_workspace(l, v, 4 * nbytes + 4096, ndocs)) != TM_OK) return rc;
+      b = l->ws;
+      if ((rc = batch_upload_raw_on(b, text, offsets, ndocs, l->stream)) != TM_OK) return rc;
+      rc = tm_batch_normalize(b, l->stream);
+    }
+  } else {
+    rc = batch_upload_on(b, text, offsets, ndocs, l->stream);
+  }
+  if (rc != TM_OK) return rc;
+  if ((rc = run_pipeline(b, l->stream, false, nullptr, emit)) != TM_OK) return rc;
+  if (emit) {
+    if ((rc = ensure_output(b)) != TM_OK) return rc;
+  } else {
+    hipError_t e = hipStreamSynchronize(l->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  }
+  if (ro) {
+    uint64_t totals[3] = {0, 0, 0};
+    hipError_t e = hipMemcpyAsync(totals, b->d_totals, sizeof totals, hipMemcpyDeviceToHost, l->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(l->stream);
+    if (e != hipSuccess) return hip_fail(e, "D2H totals");
+    ro->total_tokens = ndocs ? totals[1] : 0;
+  }
+  return TM_OK;
+}
+
+static int d2h(void* dst, const void* src, uint64_t bytes, hipStream_t st, const char* what) {
+  if (!bytes) return TM_OK;
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+  return e == hipSuccess ? TM_OK : hip_fail(e, what);
+}
+
+}  // namespace tmh
+
+using namespace tmh;
+
+extern "C" {
+
+void* tm_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void tm_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int tm_host_register(void* p, size_t bytes) {
+  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  return e == hipSuccess ? TM_OK : hip_fail(e, "hipHostRegister");
+}
+int tm_host_unregister(void* p) {
+  hipError_t e = hipHostUnregister(p);
+  return e == hipSuccess ? TM_OK : hip_fail(e, "hipHostUnregister");
+}
+
+int tm_tokenize_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t* tokens_out,
+                      uint64_t tokens_cap, uint64_t* tok_offsets, uint32_t* missing) {
+  if (!v || (ndocs && !offsets)) return set_error(TM_E_INVALID, "null argument");
+  Lane* l = nullptr;
+  int rc = lane_acquire(v, &l);
+  if (rc != TM_OK) return rc;
+  RunOut ro;
+  rc = lane_run(l, v, text, offsets, ndocs, false, true, &ro);
+  if (rc == TM_OK) {
+    tm_batch* b = l->ws;
+    if (tok_offsets) rc = d2h(tok_offsets, b->d_tok_offsets, ((uint64_t)ndocs + 1) * 8, l->stream, "D2H tok_offsets");
+    if (rc == TM_OK && missing && ndocs) rc = d2h(missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream, "D2H missing");
+    if (rc == TM_OK && ro.total_tokens > tokens_cap) {
+      (void)hipStreamSynchronize(l->stream);
+      rc = set_error(TM_E_NOSPACE, "tokens_cap %llu < %llu required", (unsigned long long)tokens_cap, (unsigned long long)ro.total_tokens);
+    }
+    if (rc == TM_OK) rc = d2h(tokens_out, b->d_out, ro.total_tokens * 4, l->stream, "D2H tokens");
+    if (rc == TM_OK) { hipError_t e = hipStreamSynchronize(l->stream); if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize"); }
+    if (ndocs == 0 && tok_offsets) tok_offsets[0] = 0;
+  }
+  lane_release(v, l);
+  return rc;
+}
+
+int tm_count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint64_t* counts, uint32_t* missing) {
+  if (!v || (ndocs && !offsets)) return set_error(TM_E_INVALID, "null argument");
+  Lane* l = nullptr;
+  int rc = lane_acquire(v, &l);
+  if (rc != TM_OK) return rc;
+  rc = lane_run(l, v, text, offsets, ndocs, false, false, nullptr);
+  if (rc == TM_OK && ndocs) {
+    tm_batch* b = l->ws;
+    std::vector<uint32_t> ev(ndocs);
+    uint32_t err = 0;
+    rc = d2h(&err, b->d_error, 4, l->stream, "D2H error flag");
+    if (rc == TM_OK) rc = d2h(ev.data(), b->d_doc_events, (uint64_t)ndocs * 4, l->stream, "D2H counts");
+    if (rc == TM_OK && missing) rc = d2h(missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream, "D2H missing");
+    if (rc == TM_OK) { hipError_t e = hipStreamSynchronize(l->stream); if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize"); }
+    if (rc == TM_OK && err) rc = set_error(TM_E_HIP, "device pipeline inconsistency");
+    if (rc == TM_OK && counts) for (uint32_t d = 0; d < ndocs; d++) counts[d] = ev[d];
+  }
+  lane_release(v, l);
+  return rc;
+}
+
+int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t encoding_length,
+                                 uint8_t* bytes_out, uint64_t bytes_cap, uint64_t* byte_offsets, uint32_t* missing, uint32_t* encoding_length_used) {
+  if (!v || (ndocs && !offsets)) return set_error(TM_E_INVALID, "null argument");
+  if (encoding_length <= 1) encoding_length = v->host.n_ids <= 65536 ? 2 : 3;          // go :990-996
+  if (encoding_length < 2 || encoding_length > 4) return set_error(TM_E_INVALID, "Invalid encoding length");   // go :1012
+  if (encoding_length_used) *encoding_length_used = encoding_length;
+  Lane* l = nullptr;
+  int rc = lane_acquire(v, &l);
+  if (rc != TM_OK) return rc;
+  RunOut ro;
+  rc = lane_run(l, v, text, offsets, ndocs, false, true, &ro);
+  if (rc == TM_OK) {
+    tm_batch* b = l->ws;
+    const uint64_t nb = ro.total_tokens * encoding_length;
+    std::vector<uint64_t> offs((size_t)ndocs + 1, 0);
+    if (ndocs) rc = d2h(offs.data(), b->d_tok_offsets, offs.size() * 8, l->stream, "D2H tok_offsets");
+    if (rc == TM_OK && missing && ndocs) rc = d2h(missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream, "D2H missing");
+    if (rc == TM_OK && nb <= bytes_cap && nb) {
+      if ((rc = lane_dbytes(l, nb)) == TM_OK) {
+        launch_serialize(b->d_out, ro.total_tokens, encoding_length, l->d_bytes, l->stream);
+        rc = d2h(bytes_out, l->d_bytes, nb, l->stream, "D2H bytes");
+      }
+    }
+    { hipError_t e = hipStreamSynchronize(l->stream); if (rc == TM_OK && e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize"); }
+    if (rc == TM_OK && byte_offsets) for (size_t d = 0; d <= ndocs; d++) byte_offsets[d] = offs[d] * encoding_length;
+    if (rc == TM_OK && nb > bytes_cap) rc = set_error(TM_E_NOSPACE, "bytes_cap too small");
+  }
+  lane_release(v, l);
+  return rc;
+}
+
+// ---- large batches, host to host -------------------------------------------------------------------------------------------------
+int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, int raw, uint32_t encoding_length,
+                         uint64_t chunk_bytes, uint32_t lanes, uint8_t* bytes_out, uint64_t bytes_cap, uint64_t* byte_offsets, uint32_t* missing,
+                         uint32_t* encoding_length_used, tm_pipeline_stats* stats) {
+  if (!v || (ndocs && (!offsets || !text)) || !byte_offsets) return set_error(TM_E_INVALID, "null argument");
+  if (encoding_length <= 1) encoding_length = v->host.n_ids <= 65536 ? 2 : 3;
+  if (encoding_length < 2 || encoding_length > 4) return set_error(TM_E_INVALID, "Invalid encoding length");
+  if (encoding_length_used) *encoding_length_used = encoding_length;
+  if (ndocs && offsets[0] != 0) return set_error(TM_E_INVALID, "offsets[0] must be 0");
+  if (chunk_bytes == 0) chunk_bytes = 64ull << 20;
+  if (lanes == 0) lanes = 3;
+  lanes = std::min<uint32_t>(lanes, 8);
+  // chunks = maximal runs of whole documents of at most chunk_bytes (a longer document is a chunk of its own)
+  std::vector<uint32_t> first;     // first document of every chunk, + ndocs
+  for (uint32_t d = 0; d < ndocs;) {
+    first.push_back(d);
+    uint32_t e = d + 1;
+    if (offsets[e] < offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
+    while (e < ndocs && offsets[e + 1] >= offsets[e] && offsets[e + 1] - offsets[d] <= chunk_bytes) e++;
+    d = e;
+  }
+  first.push_back(ndocs);
+  const size_t nchunks = first.size() - 1;
+  byte_offsets[0] = 0;
+  if (stats) *stats = tm_pipeline_stats{};
+  if (nchunks == 0) return TM_OK;
+  const bool in_pinned = is_pinned(text), out_pinned = is_pinned(bytes_out);
+  // chunk k's ids go behind those of chunks 0..k-1: a chunk publishes its token count as soon as its kernels have run, and the
+  // next one waits for it only before its own D2H
+  std::vector<uint64_t> tok_base(nchunks + 1, 0);
+  std::vector<char> known(nchunks + 1, 0);
+  known[0] = 1;
+  std::mutex mu;
+  std::condition_variable cv;
+  int first_error = TM_OK;
+  std::string first_msg;
+  std::atomic<size_t> next{0};
+  lanes = (uint32_t)std::min<size_t>(lanes, nchunks);
+  auto worker = [&]() {
+    Lane* l = nullptr;
+    int rc = lane_acquire(v, &l);
+    std::vector<uint64_t> loc, toff;
+    while (rc == TM_OK) {
+      const size_t k = next.fetch_add(1);
+      if (k >= nchunks) break;
+      { std::lock_guard<std::mutex> g(mu); if (first_error != TM_OK) { break; } }
+      const uint32_t d0 = first[k], d1 = first[k + 1], nd = d1 - d0;
+      const uint64_t b0 = offsets[d0], nb = offsets[d1] - b0;
+      loc.resize((size_t)nd + 1);
+      for (uint32_t d = 0; d <= nd; d++) loc[d] = offsets[d0 + d] - b0;
+      const uint8_t* src = text + b0;
+      if (!in_pinned) {                       // pageable input: through the lane's pinned staging, so that the H2D runs at link speed
+        if ((rc = lane_stage(l, nb)) != TM_OK) break;
+        std::memcpy(l->h_stage, src, nb);
+        src = l->h_stage;
+      }
+      RunOut ro;
+      if ((rc = lane_run(l, v, src, loc.data(), nd, raw != 0, true, &ro)) != TM_OK) break;
+      {   // publish this chunk's count, learn where its ids go
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return known[k] || first_error != TM_OK; });
+        if (first_error != TM_OK) break;
+        tok_base[k + 1] = tok_base[k] + ro.total_tokens;
+        known[k + 1] = 1;
+      }
+      cv.notify_all();
+      tm_batch* b = l->ws;
+      const uint64_t base = tok_base[k], out_b = ro.total_tokens * encoding_length;
+      toff.resize((size_t)nd + 1);
+      if ((rc = d2h(toff.data(), b->d_tok_offsets, toff.size() * 8, l->stream, "D2H tok_offsets")) != TM_OK) break;
+      if (missing && nd && (rc = d2h(missing + d0, b->d_doc_missing, (uint64_t)nd * 4, l->stream, "D2H missing")) != TM_OK) break;
+      const bool fits = (base + ro.total_tokens) * encoding_length <= bytes_cap && bytes_out;
+      if (fits && out_b) {
+        if ((rc = lane_dbytes(l, out_b)) != TM_OK) break;
+        launch_serialize(b->d_out, ro.total_tokens, encoding_length, l->d_bytes, l->stream);
+        uint8_t* dst = bytes_out + base * encoding_length;
+        if (out_pinned) rc = d2h(dst, l->d_bytes, out_b, l->stream, "D2H ids");
+        else {
+          if ((rc = lane_stage(l, out_b)) != TM_OK) break;
+          rc = d2h(l->h_stage, l->d_bytes, out_b, l->stream, "D2H ids");
+        }
+        if (rc != TM_OK) break;
+      }
+      { hipError_t e = hipStreamSynchronize(l->stream); if (e != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; } }
+      if (fits && out_b && !out_pinned) std::memcpy(bytes_out + base * encoding_length, l->h_stage, out_b);
+      for (uint32_t d = 1; d <= nd; d++) byte_offsets[d0 + d] = (base + toff[d]) * encoding_length;
+      if (stats) { std::lock_guard<std::mutex> g(mu); stats->host_fallback_docs += raw ? b->host_fallback_docs : 0; stats->normalized_bytes += b->nbytes; }
+    }
+    if (rc != TM_OK) {
+      { std::lock_guard<std::mutex> g(mu); if (first_error == TM_OK) { first_error = rc; first_msg = last_error(); } }
+      cv.notify_all();
+    }
+    if (l) lane_release(v, l);
+  };
+  std::vector<std::thread> th;
+  for (uint32_t t = 1; t < lanes; t++) th.emplace_back(worker);
+  worker();
+  for (auto& t : th) t.join();
+  if (first_error != TM_OK) return set_error(first_error, "%s", first_msg.c_str());
+  if (stats) { stats->chunks = (uint32_t)nchunks; stats->lanes = lanes; stats->input_pinned = in_pinned; stats->output_pinned = out_pinned; }
+  if (byte_offsets[ndocs] > bytes_cap || !bytes_out) return set_error(TM_E_NOSPACE, "bytes_cap %llu < %llu required", (unsigned long long)bytes_cap, (unsigned long long)byte_offsets[ndocs]);
+  return TM_OK;
+}
+
+}  // extern "C"

@@ -1116,6 +1116,7 @@ int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32
 
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) {
   const tm_vocab* v = b->vocab;
+  { int rc = enter_device(v); if (rc != TM_OK) return rc; }
   b->last_stream = st;
   hipError_t e;
   if (timed && !b->have_events) {
@@ -1164,6 +1165,7 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
 
 // after a run: make sure the output buffer was large enough; if not, grow it and redo the emit stage
 int ensure_output(tm_batch* b) {
+  { int rc = enter_device(b->vocab); if (rc != TM_OK) return rc; }
   hipError_t e;
   uint64_t totals[3];
   uint32_t err = 0;
@@ -1201,6 +1203,7 @@ int tm_debug_flags(int flags) {
 namespace tmh {
 int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, bool own_text, bool with_output, tm_batch** out) {
   *out = nullptr;
+  { int rc = enter_device(v); if (rc != TM_OK) return rc; }
   auto* b = new tm_batch();
   b->vocab = v;
   b->max_bytes = max_bytes;
@@ -1251,7 +1254,17 @@ void tm_batch_free(tm_batch* b) {
 }
 
 int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs) {
+  int rc = tmh::batch_upload_on(b, text, offsets, ndocs, nullptr);
+  if (rc == TM_OK) { hipError_t e = hipStreamSynchronize(nullptr); if (e != hipSuccess) rc = hip_fail(e, "H2D text"); }
+  return rc;
+}
+
+}  // extern "C"
+namespace tmh {
+// H2D of packed text + offsets on `st` (asynchronous when the source is pinned); the batch is then ready for run_pipeline on `st`
+int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, hipStream_t st) {
   if (!b || (ndocs && (!offsets))) return set_error(TM_E_INVALID, "null argument");
+  { int rc = enter_device(b->vocab); if (rc != TM_OK) return rc; }
   if (ndocs > b->max_docs) return set_error(TM_E_LIMIT, "batch has %u documents, workspace sized for %u", ndocs, b->max_docs);
   uint64_t nbytes = ndocs ? offsets[ndocs] : 0;
   if (ndocs && offsets[0] != 0) return set_error(TM_E_INVALID, "offsets[0] must be 0");
@@ -1262,8 +1275,8 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
     nseg += (offsets[d + 1] - offsets[d] + SEG - 1) / SEG;
   }
   hipError_t e;
-  if (nbytes && (e = hipMemcpy(b->d_text, text, nbytes, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D text");
-  if (ndocs && (e = hipMemcpy(b->d_offsets, offsets, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D offsets");
+  if (nbytes && (e = hipMemcpyAsync(b->d_text, text, nbytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D text");
+  if (ndocs && (e = hipMemcpyAsync(b->d_offsets, offsets, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D offsets");
   b->ndocs = ndocs;
   b->nbytes = nbytes;
   b->nseg = nseg;
@@ -1271,6 +1284,11 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
   b->d_doc_end = b->d_offsets + 1;
   return build_groups(b, offsets, offsets + 1, ndocs);
 }
+void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* out, hipStream_t st) {
+  if (n) k_serialize<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(ids, n, enc, out);
+}
+}  // namespace tmh
+extern "C" {
 
 int tm_batch_run(tm_batch* b, void* stream) {
   if (!b) return set_error(TM_E_INVALID, "null argument");
@@ -1330,77 +1348,5 @@ int tm_debug_phases(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
-
-// ---- host-buffer entry points ---------------------------------------------------------------------
-static int with_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, tm_batch** pb, bool emit) {
-  if (!v || (ndocs && !offsets)) return set_error(TM_E_INVALID, "null argument");
-  uint64_t nbytes = ndocs ? offsets[ndocs] : 0;
-  int rc = tm_batch_create(v, nbytes, ndocs, pb);
-  if (rc != TM_OK) return rc;
-  if ((rc = tm_batch_upload(*pb, text, offsets, ndocs)) != TM_OK) return rc;
-  return run_pipeline(*pb, nullptr, false, nullptr, emit);
-}
-
-int tm_tokenize_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t* tokens_out,
-                      uint64_t tokens_cap, uint64_t* tok_offsets, uint32_t* missing) {
-  tm_batch* b = nullptr;
-  int rc = with_batch(v, text, offsets, ndocs, &b, true);
-  if (rc == TM_OK) rc = tm_batch_download(b, tokens_out, tokens_cap, tok_offsets, missing);
-  tm_batch_free(b);
-  return rc;
-}
-
-int tm_count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint64_t* counts,
-                   uint32_t* missing) {
-  tm_batch* b = nullptr;
-  int rc = with_batch(v, text, offsets, ndocs, &b, false);
-  if (rc == TM_OK && ndocs) {
-    hipError_t e;
-    std::vector<uint32_t> ev(ndocs);
-    uint32_t err = 0;
-    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) rc = hip_fail(e, "sync");
-    else if ((e = hipMemcpy(&err, b->d_error, 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H");
-    else if (err) rc = set_error(TM_E_HIP, "device pipeline inconsistency");
-    else if ((e = hipMemcpy(ev.data(), b->d_doc_events, (size_t)ndocs * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H counts");
-    else if (missing && (e = hipMemcpy(missing, b->d_doc_missing, (size_t)ndocs * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H missing");
-    if (rc == TM_OK && counts) for (uint32_t d = 0; d < ndocs; d++) counts[d] = ev[d];
-  }
-  tm_batch_free(b);
-  return rc;
-}
-
-int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs,
-                                 uint32_t encoding_length, uint8_t* bytes_out, uint64_t bytes_cap, uint64_t* byte_offsets,
-                                 uint32_t* missing, uint32_t* encoding_length_used) {
-  if (!v) return set_error(TM_E_INVALID, "null argument");
-  if (encoding_length <= 1) encoding_length = v->host.n_ids <= 65536 ? 2 : 3;          // go :990-996
-  if (encoding_length < 2 || encoding_length > 4) return set_error(TM_E_INVALID, "Invalid encoding length");   // go :1012
-  if (encoding_length_used) *encoding_length_used = encoding_length;
-  tm_batch* b = nullptr;
-  int rc = with_batch(v, text, offsets, ndocs, &b, true);
-  if (rc == TM_OK) rc = ensure_output(b);
-  if (rc == TM_OK) {
-    hipError_t e;
-    std::vector<uint64_t> offs((size_t)ndocs + 1, 0);
-    if (ndocs && (e = hipMemcpy(offs.data(), b->d_tok_offsets, offs.size() * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H tok_offsets");
-    if (rc == TM_OK) {
-      uint64_t total = offs[ndocs];
-      if (byte_offsets) for (size_t d = 0; d <= ndocs; d++) byte_offsets[d] = offs[d] * encoding_length;
-      if (missing && ndocs && (e = hipMemcpy(missing, b->d_doc_missing, (size_t)ndocs * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H missing");
-      if (rc == TM_OK && total * encoding_length > bytes_cap) rc = set_error(TM_E_NOSPACE, "bytes_cap too small");
-      if (rc == TM_OK && total) {
-        uint8_t* d_bytes = nullptr;
-        if ((e = hipMalloc((void**)&d_bytes, total * encoding_length)) != hipSuccess) rc = hip_fail(e, "hipMalloc");
-        else {
-          k_serialize<<<(uint32_t)((total + 255) / 256), 256>>>(b->d_out, total, encoding_length, d_bytes);
-          if ((e = hipMemcpy(bytes_out, d_bytes, total * encoding_length, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H bytes");
-          (void)hipFree(d_bytes);
-        }
-      }
-    }
-  }
-  tm_batch_free(b);
-  return rc;
-}
 
 }  // extern "C"

@@ -522,7 +522,16 @@ hipError_t grow(T** p, uint64_t* cap, uint64_t need, uint64_t slack = 0) {
 extern "C" {
 
 int tm_batch_upload_raw(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs) {
+  int rc = tmh::batch_upload_raw_on(b, raw, raw_offsets, ndocs, nullptr);
+  if (rc == TM_OK) { hipError_t e = hipStreamSynchronize(nullptr); if (e != hipSuccess) rc = hip_fail(e, "H2D raw text"); }
+  return rc;
+}
+
+}  // extern "C"
+namespace tmh {
+int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs, hipStream_t st) {
   if (!b || (ndocs && !raw_offsets)) return set_error(TM_E_INVALID, "null argument");
+  { int rc = enter_device(b->vocab); if (rc != TM_OK) return rc; }
   if (ndocs > b->max_docs) return set_error(TM_E_LIMIT, "batch has %u documents, workspace sized for %u", ndocs, b->max_docs);
   const uint64_t nbytes = ndocs ? raw_offsets[ndocs] : 0;
   if (ndocs && raw_offsets[0] != 0) return set_error(TM_E_INVALID, "offsets[0] must be 0");
@@ -562,18 +571,21 @@ int tm_batch_upload_raw(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
       return hip_fail(e, "hipMalloc (pieces)");
   }
   if ((e = grow(&b->d_slab, &b->slab_cap, (npieces + 1) * (uint64_t)SLAB)) != hipSuccess) return hip_fail(e, "hipMalloc (normalizer slabs)");
-  if (nbytes && (e = hipMemcpy(b->d_raw, raw, nbytes, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D raw text");
-  if (ndocs && (e = hipMemcpy(b->d_raw_off, raw_offsets, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "H2D raw offsets");
-  b->h_raw_off.assign(raw_offsets, raw_offsets + (ndocs ? ndocs + 1 : 0));
+  if (nbytes && (e = hipMemcpyAsync(b->d_raw, raw, nbytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D raw text");
+  b->h_raw_off.assign(raw_offsets, raw_offsets + (ndocs ? ndocs + 1 : 0));      // (the batch's own copy: it outlives the caller's array)
+  if (ndocs && (e = hipMemcpyAsync(b->d_raw_off, b->h_raw_off.data(), ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D raw offsets");
   b->raw_bytes = nbytes;
   b->raw_docs = ndocs;
   b->raw_pieces = npieces;
   return TM_OK;
 }
+}  // namespace tmh
+extern "C" {
 
 int tm_batch_normalize(tm_batch* b, void* stream) {
   if (!b) return set_error(TM_E_INVALID, "null argument");
   const tm_vocab* v = b->vocab;
+  { int rc = enter_device(v); if (rc != TM_OK) return rc; }
   const uint32_t capcode = v->host.capcode, norm_flag = v->host.norm_flag;
   if (!normalize_supported(capcode, norm_flag))
     return set_error(TM_E_INVALID, "normalization flags %u / capcode %u not supported by the normalizer", norm_flag, capcode);

@@ -117,6 +117,11 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit);
 // scoring variant of the chain kernel: histogram in HBM (scores | 4 limbs | 256 counters), see tm_score.hip
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
                        uint32_t n_ids, hipStream_t st);
+int ensure_output(tm_batch* b);
+int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, hipStream_t st);
+void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* out, hipStream_t st);
+// tm_norm.hip
+int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs, hipStream_t st);
 // tm_normalize.cpp
 bool normalize_supported(uint32_t capcode, uint32_t norm_flag);
 

@@ -25,11 +25,14 @@ struct tm_dataset {
   unsigned long long* d_tokens = nullptr;
   uint32_t* d_missing_bits = nullptr;
   int n_cu = 256;
+  int device = 0;
 };
 
 static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
                      hipStream_t st) {
   if (!v || !d) return set_error(TM_E_INVALID, "null argument");
+  { int rc = enter_device(v); if (rc != TM_OK) return rc; }
+  if (d->device != v->device) return set_error(TM_E_INVALID, "dataset lives on device %d, vocabulary on device %d", d->device, v->device);
   std::vector<uint64_t> be;
   uint64_t whole_off = 0, whole_len = d->n;
   if (n_strips == 0) { strip_off = &whole_off; strip_len = &whole_len; n_strips = 1; }
@@ -101,6 +104,7 @@ int tm_dataset_upload(const uint8_t* normalized, uint64_t n, tm_dataset** out) {
     return hip_fail(e, "dataset upload");
   }
   d->n = n;
+  (void)hipGetDevice(&d->device);
   { int dev = 0, cu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) d->n_cu = cu; }
   *out = d;
   return TM_OK;

@@ -357,6 +357,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
 
 void tm_vocab_free(tm_vocab* v) {
   if (!v) return;
+  tmh::pool_destroy(v->pool);
   (void)hipFree(v->d_root); (void)hipFree(v->d_tab); (void)hipFree(v->d_spl); (void)hipFree(v->d_vals); (void)hipFree(v->d_rev_off); (void)hipFree(v->d_rev_bytes); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
   delete v;
 }

@@ -211,6 +211,51 @@ class Vocab:
             return out[: int(boff[nd])], boff, missing[:nd], enc.value
 
 
+    def tokenize_pipeline(self, text, offsets, raw=True, encoding_length=0, chunk_bytes=0, lanes=0, out=None):
+        """host-to-host tokenization of a large packed corpus (tm_tokenize_pipeline): chunks of documents run
+        H2D | normalize + tokenize + serialize | D2H on several lanes at once.  -> (serialized ids u8, byte_offsets u64[D+1],
+        missing u32[D], encoding length, stats dict).  `text` / `out` may be pinned arrays from pinned_empty()."""
+        text = N.as_u8(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nd = offsets.size - 1
+        boff = np.zeros(nd + 1, dtype=np.uint64)
+        missing = np.zeros(max(nd, 1), dtype=np.uint32)
+        enc = C.c_uint32()
+        stats = PipelineStats()
+        if out is None:
+            out = np.empty(int(text.size) + 8 * nd + 64, dtype=np.uint8)
+        while True:
+            rc = N.lib.tm_tokenize_pipeline(self._h, N.ptr(text), N.ptr(offsets), nd, 1 if raw else 0, encoding_length, chunk_bytes, lanes,
+                                            N.ptr(out), out.size, N.ptr(boff), N.ptr(missing), C.byref(enc), C.byref(stats))
+            if rc == N.TM_E_NOSPACE:
+                out = np.empty(int(boff[nd]), dtype=np.uint8)
+                continue
+            N.check(rc)
+            st = {k: getattr(stats, k) for k, _ in PipelineStats._fields_}
+            return out[: int(boff[nd])], boff, missing[:nd], enc.value, st
+
+
+class PipelineStats(C.Structure):
+    _fields_ = [("chunks", C.c_uint32), ("lanes", C.c_uint32), ("input_pinned", C.c_int), ("output_pinned", C.c_int),
+                ("normalized_bytes", C.c_uint64), ("host_fallback_docs", C.c_uint32)]
+
+
+class PinnedBuffer:
+    """page-locked host memory (tm_host_alloc) viewed as a numpy uint8 array; freed with the object"""
+
+    def __init__(self, nbytes):
+        self._p = N.lib.tm_host_alloc(max(int(nbytes), 16))
+        if not self._p:
+            raise MemoryError("tm_host_alloc(%d) failed" % nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(int(nbytes), 16)).from_address(self._p))[: int(nbytes)]
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            N.lib.tm_host_free(self._p)
+            self._p = None
+
+
 def load(path_or_bytes):
     """load a .vocab file (go/tokenmonster.go:2656 Load; python/tokenmonster.py load) onto the current GPU"""
     if isinstance(path_or_bytes, (bytes, bytearray)):
