@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--verify", type=int, default=64, help="documents re-checked against the oracle after timing (rank 0)")
     ap.add_argument("--also-flags", default="", help="development aid: comma separated tm_debug_flags values; the same step is timed again under each "
                                                       "(kernel variants) and reported on stderr, its ids compared with the default's")
+    ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-to-host pipeline and small-batch latency figures")
     return ap.parse_args()
 
 
@@ -74,7 +75,85 @@ def cpu_baseline(img, text, offs, sample_mb, log, raw_mode=False):
            "sample": "first %d documents (%.1f MB %s) of the same corpus, 1 thread, %.1f s" % (
                d, done / 1e6, "raw, Tokenize = normalize + capcode + walk" if raw_mode else "normalized, tokenize_normalized", dt),
            "host_cores": os.cpu_count()}
+    if kind == "reference":
+        # all host cores, one document per call like the server's goroutines (training/tokenmonsterserver.go:363-378); the sample
+        # grows with the core count so that every thread has about a second of work
+        ncores = os.cpu_count() or 1
+        want = min(int(offs[nd]), int(16e6 * ncores))
+        d2 = int(np.searchsorted(offs, want, side="right")) - 1
+        d2 = max(1, min(nd, d2))
+        t0 = time.perf_counter()
+        eng.tokenize_docs_mt(text[: int(offs[d2])], offs[: d2 + 1], raw_mode, ncores)
+        dt2 = time.perf_counter() - t0
+        res["all_cores"] = {"value": round(int(offs[d2]) / dt2 / 1e9, 6), "unit": "GB/s", "cores": ncores,
+                            "sample": "first %d documents (%.1f MB) of the same corpus, %d threads, %.1f s" % (d2, int(offs[d2]) / 1e6, ncores, dt2)}
+        # the reference's own micro-benchmark on its own 1 MiB micro-corpus (tokenmonster-cpp/tests/bench.cpp:39-55), 1 thread
+        if os.path.exists(ob.REF_BENCH):
+            import subprocess
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix=".vocab", delete=False) as f:
+                f.write(bytes(img))
+            try:
+                r = subprocess.run([ob.REF_BENCH, f.name, "1.0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60)
+                rows = {ln.split("\t")[0]: ln.split("\t") for ln in r.stdout.decode(errors="replace").splitlines() if "\t" in ln}
+                res["reference_micro_corpus"] = {k: {"MB_per_s": float(rows[k][4])} for k in ("normalize", "tokenize_normalized", "encode_tokenize", "decode_tokens")
+                                                 if k in rows and len(rows[k]) > 4}
+                res["reference_micro_corpus"]["note"] = "tokenmonster-cpp/tests/bench.cpp run as is: 1 MiB micro-corpus, 1 thread, this vocabulary"
+            except Exception as ex:     # noqa: BLE001
+                res["reference_micro_corpus"] = {"error": str(ex)}
+            finally:
+                os.unlink(f.name)
     log("cpu_baseline: %s" % res)
+    return res
+
+
+def host_to_host(vocab, raw, roffs, text, offs, ids_expected, log, tm, steps=3):
+    """RAW UTF-8 in (pinned) host memory -> 2-byte serialized ids in (pinned) host memory, through tm_tokenize_pipeline:
+    chunks run H2D | normalize + tokenize + serialize | D2H on several lanes.  This is SURVEY 8(d)'s 'first H2D to last D2H'
+    figure; `value` stays the HBM-resident rate.  Also the latency of a small batch (64 documents of 2 KiB, already normalized)
+    through tm_tokenize_batch on a warm lane: the job-1 case of the server."""
+    import ctypes as C
+    from tokenmonster_amd import _native as N
+    pin_in = tm.PinnedBuffer(raw.size)
+    pin_in.array[:] = raw
+    pin_out = tm.PinnedBuffer(4 * ids_expected + 4096)
+    res = {}
+    for label, src, dst in (("pinned", pin_in.array, pin_out.array), ("pageable", raw, np.empty(4 * ids_expected + 4096, dtype=np.uint8))):
+        best = None
+        for lanes, chunk in ((3, 64 << 20), (4, 32 << 20)):
+            vocab.tokenize_pipeline(src, roffs, raw=True, chunk_bytes=chunk, lanes=lanes, out=dst)      # warm the lanes
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                blob, boff, _, enc, st = vocab.tokenize_pipeline(src, roffs, raw=True, chunk_bytes=chunk, lanes=lanes, out=dst)
+            dt = (time.perf_counter() - t0) / steps
+            if best is None or dt < best[0]:
+                best = (dt, lanes, chunk, enc, int(boff[-1]) // enc, st)
+        dt, lanes, chunk, enc, ntok, st = best
+        res[label] = {"value": round(raw.size / dt / 1e9, 4), "unit": "GB/s raw UTF-8, host to host", "ms": round(dt * 1e3, 3), "lanes": lanes,
+                      "chunk_MiB": chunk >> 20, "id_bytes": enc, "tokens": ntok}
+        if ntok != ids_expected:
+            raise SystemExit("bench.py: host-to-host pipeline produced %d tokens, the resident pass %d - number is INVALID" % (ntok, ids_expected))
+    # small batch latency
+    nd = 64
+    small_off = np.zeros(nd + 1, dtype=np.uint64)
+    pos, k = 0, 0
+    chunks = []
+    while k < nd:
+        a = int(offs[k % (offs.size - 1)])
+        chunks.append(text[a:a + 2048])
+        pos += chunks[-1].size
+        k += 1
+        small_off[k] = pos
+    small = np.ascontiguousarray(np.concatenate(chunks))
+    lat = []
+    for it in range(220):
+        t0 = time.perf_counter()
+        vocab.tokenize_packed(small, small_off)
+        lat.append(time.perf_counter() - t0)
+    lat = np.sort(np.array(lat[20:]))
+    res["small_batch_latency"] = {"docs": nd, "bytes": int(small.size), "p50_ms": round(float(lat[lat.size // 2]) * 1e3, 3),
+                                  "p99_ms": round(float(lat[int(lat.size * 0.99)]) * 1e3, 3), "api": "tm_tokenize_batch (host buffers, warm lane)"}
+    log("host_to_host: %s" % res)
     return res
 
 
@@ -206,6 +285,8 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the tokenizer has no CPU fallback")
+    if args.gpus > torch.cuda.device_count():
+        raise SystemExit("--gpus %d but only %d device(s) visible" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -317,17 +398,22 @@ def main():
     dom = int(np.argmax(acc))
     alg_bytes = float(text.size) + 4.0 * float(ntok.value)     # B_alg = N + 4T per pass
     achieved = alg_bytes / (acc[dom] * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is the one
+    # tools/pmc_profile.py measured under rocprofv3 for the same configuration and size (FETCH_SIZE x2 + WRITE_SIZE, separate passes,
+    # as /opt/skills/guides/MI355X_MICROARCH.md prescribes) and wrote to profiles/traffic_latest.json; null when that file is for
+    # another configuration.  `traffic_source` says so in the line itself.
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("config") == args.config and tj.get("mbytes") == args.mbytes:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "static: profiles/traffic_latest.json (%s), not measured in this run" % tj.get("measured", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms}
 
     # ---- verification of a sample against the oracle (rank 0; outside the timed region) -------------------
@@ -379,6 +465,12 @@ def main():
             finally:
                 N.lib.tm_debug_flags(old)
 
+    # host to host before the CPU baseline: its 256 threads leave this process's threads (and the pinned buffers it allocates next)
+    # wherever the scheduler put them last, and pinned memory on the far socket halves the PCIe rate
+    h2h = None
+    if rank == 0 and world == 1 and not args.hot_path_only and not args.no_host_to_host:
+        h2h = host_to_host(vocab, raw, roffs, text, offs, int(ntok.value), log, tm)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -390,7 +482,7 @@ def main():
     if rank == 0:
         value = all_raw * args.steps / elapsed / 1e9
         out = {
-            "metric": "GB/s raw UTF-8 tokenized, englishcode-32000 vocab", "value": round(value, 4), "unit": "GB/s",
+            "metric": "GB/s raw UTF-8 tokenized, %s vocab" % args.config.split("-consistent")[0].split("-clean")[0].split("-balanced")[0], "value": round(value, 4), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s vocabulary shape (synthetic, %d ids / %d index records), %d MiB raw synthetic mixed "
@@ -405,6 +497,8 @@ def main():
                        "verified_docs_vs_oracle": verified},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "value_host_to_host": None if h2h is None else h2h["pinned"]["value"],
+            "host_to_host": h2h,
         }
         print(json.dumps(out), flush=True)
     N.lib.tm_batch_free(batch)

@@ -17,7 +17,9 @@
 #include <span>
 #include <stdexcept>
 #include <string>
+#include <atomic>
 #include <string_view>
+#include <thread>
 #include <utility>
 #include <vector>
 #include <capcode/capcode.hpp>
@@ -127,6 +129,43 @@ long long tmref_decode_raw(void* v, const std::uint32_t* toks, std::size_t n, st
     if (r.size() > cap) return -(long long)r.size();
     if (!r.empty()) std::memcpy(out, r.data(), r.size());
     return (long long)r.size();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// All-core baseline for bench.py (the reference server's model: documents are independent, one goroutine each,
+// training/tokenmonsterserver.go:363-378): `threads` std::threads pull documents from a shared counter and call
+// Vocab::tokenize (raw != 0: normalize + capcode + walk) or Vocab::tokenize_normalized.  Returns the number of tokens.
+long long tmref_tokenize_docs_mt(void* v, const std::uint8_t* text, const std::uint64_t* offsets, std::uint32_t ndocs, int raw,
+                                 std::uint32_t threads) {
+  try {
+    auto* vocab = static_cast<Vocab*>(v);
+    if (threads == 0) threads = 1;
+    std::atomic<std::uint32_t> next{0};
+    std::atomic<long long> total{0};
+    std::atomic<bool> failed{false};
+    auto work = [&]() {
+      long long mine = 0;
+      try {
+        for (;;) {
+          const std::uint32_t base = next.fetch_add(16);
+          if (base >= ndocs) break;
+          for (std::uint32_t d = base; d < ndocs && d < base + 16; d++) {
+            auto doc = sp(text + offsets[d], (std::size_t)(offsets[d + 1] - offsets[d]));
+            mine += (long long)(raw ? vocab->tokenize(doc) : vocab->tokenize_normalized(doc)).tokens.size();
+          }
+        }
+      } catch (...) { failed = true; }
+      total += mine;
+    };
+    std::vector<std::thread> th;
+    for (std::uint32_t t = 1; t < threads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (failed) { g_err = "a worker thread failed"; return -1; }
+    return total.load();
   } catch (const std::exception& e) {
     g_err = e.what();
     return -1;

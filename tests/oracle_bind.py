@@ -17,6 +17,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libtm_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libtmref.so")
 REF_UNIT = os.path.join(ORACLE_DIR, "_ref", "unit")
+REF_BENCH = os.path.join(ORACLE_DIR, "_ref", "bench")      # the reference's own tests/bench.cpp
 
 
 def build_oracles():
@@ -183,6 +184,17 @@ class Reference:
         out = np.empty(cap, dtype=np.uint8)
         n = self.L.tmref_decode_raw(self.h, t.ctypes.data, t.size, out.ctypes.data, cap)
         return out[:n].tobytes()
+
+    def tokenize_docs_mt(self, text, offsets, raw, threads):
+        """all documents, `threads` std::threads inside the shim (one document per call, like the server's goroutines) -> #tokens"""
+        t = _u8(text)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.L.tmref_tokenize_docs_mt.restype = C.c_longlong
+        self.L.tmref_tokenize_docs_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
+        n = self.L.tmref_tokenize_docs_mt(self.h, t.ctypes.data, o.ctypes.data, o.size - 1, 1 if raw else 0, threads)
+        if n < 0:
+            raise RuntimeError("reference tokenize (multi-threaded) failed")
+        return int(n)
 
     def decode(self, toks):
         """Vocab::decode (tokenmonster.cpp:1404-1425): decode_raw + capcode / charset post-processing"""

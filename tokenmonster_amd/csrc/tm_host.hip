@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -131,7 +132,11 @@ static bool is_pinned(const void* p) {
 struct RunOut { uint64_t total_tokens = 0; };
 
 // upload + run one batch on a lane; the ids stay on the device (l->ws->d_out)
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int lane_run(Lane* l, const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, bool raw, bool emit, RunOut* ro) {
+  static const bool trace = getenv("TM_TRACE") != nullptr;
+  const double t0 = trace ? now_ms() : 0;
+  double t1 = 0, t2 = 0;
   const uint64_t nbytes = ndocs ? offsets[ndocs] : 0;
   // raw text grows under capcode (about 1.1x; worst case every byte a capital: "DC x" = 4x)
   int rc = lane_workspace(l, v, raw ? nbytes + nbytes / 2 + 4096 : nbytes, ndocs);
@@ -150,7 +155,9 @@ static int lane_run(Lane* l, const tm_vocab* v, const uint8_t* text, const uint6
     rc = batch_upload_on(b, text, offsets, ndocs, l->stream);
   }
   if (rc != TM_OK) return rc;
+  if (trace) t1 = now_ms();
   if ((rc = run_pipeline(b, l->stream, false, nullptr, emit)) != TM_OK) return rc;
+  if (trace) t2 = now_ms();
   if (emit) {
     if ((rc = ensure_output(b)) != TM_OK) return rc;
   } else {
@@ -164,6 +171,7 @@ static int lane_run(Lane* l, const tm_vocab* v, const uint8_t* text, const uint6
     if (e != hipSuccess) return hip_fail(e, "D2H totals");
     ro->total_tokens = ndocs ? totals[1] : 0;
   }
+  if (trace) fprintf(stderr, "[lane %p] %llu bytes: upload%s %.2f ms, launch %.2f ms, wait %.2f ms\n", (void*)l, (unsigned long long)nbytes, raw ? "+normalize" : "", t1 - t0, t2 - t1, now_ms() - t2);
   return TM_OK;
 }
 
