@@ -172,15 +172,24 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
     text, _ = synth.normalize_batch(raw, roffs, capcode, norm_flag)   # documents concatenated = the dataset range of this rank
     del raw
     log("dataset range of rank 0: %.1f MB raw -> %.1f MB normalized (%.1fs host)" % (raw_bytes / 1e6, text.size / 1e6, time.time() - t0))
+    # ONE whole-buffer walk (training/trainvocab.go:909-922) cut into a byte range per rank: every rank uploads its range followed by
+    # the first bytes of the next rank's (the halo a token that straddles the boundary needs), and a pass is: match kernel -> 80 exit
+    # states per rank, all-gathered -> finish from the true entry state -> ONE all-reduce of the histogram (tokenmonster_amd/dist.py)
+    own_len = int(text.size)
+    if world > 1:
+        halo = tmdist.exchange_halo(text, rank, world, backend_device="cuda")
+        text = np.concatenate([text, halo])
     ds = C.c_void_p()
-    N.check(N.lib.tm_dataset_upload(N.ptr(text), int(text.size), C.byref(ds)))
+    N.check(N.lib.tm_dataset_upload(N.ptr(np.ascontiguousarray(text)), int(text.size), C.byref(ds)))
+    text = text[:own_len]
     n_ids = vocab.n_ids()
     words = n_ids + 4 + 256
     hist = torch.zeros(words, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    engine = tmdist.HipRange(vocab, ds, own_len, continues=rank + 1 < world, stream=stream, dst=hist.data_ptr(), dst_words=words)
 
     def step():
-        N.check(N.lib.tm_score_device_into(vocab.handle, ds, None, None, 0, C.c_void_p(stream), C.c_void_p(hist.data_ptr()), words))
+        tmdist.score_ranges_exact(engine, rank, world, backend_device="cuda")
         if world > 1:
             tmdist.allreduce_histogram(hist)
 
@@ -239,7 +248,8 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
                                        args.config, n_ids, vocab.n_info(), args.mbytes, words),
                        "raw_bytes_total": int(all_raw), "normalized_bytes_total": int(all_norm), "tokens_in_text": int(tokens),
                        "normalized_GBps": round(all_norm * args.steps / elapsed / 1e9, 4),
-                       "parallelism": "dataset byte ranges per rank, RCCL all-reduce of the score histogram", "verified_bytes_vs_oracle": verified},
+                       "parallelism": "one whole-buffer walk cut into a byte range per rank (halo + all-gather of 80 exit states per rank), RCCL all-reduce of the score histogram",
+                       "verified_bytes_vs_oracle": verified},
             "roofline": {"bound": "hbm", "kernel": "whole scoring pass of one rank", "achieved": round(alg / (elapsed / args.steps) / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": None, "algorithmic_bytes_per_launch": alg},

@@ -180,6 +180,22 @@ int tm_score_device(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off,
 int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len,
                          uint32_t n_strips, void* stream, uint32_t* dst_device, uint64_t dst_words);
 
+/* ---- one whole-buffer walk over several GPUs (training/trainvocab.go:909-922: after "midway" the worker walks the dataset as ONE
+ * strip) --------------------------------------------------------------------------------------------------------------------
+ * Rank r owns the bytes [off, off+len) of the dataset and has uploaded them followed by a halo of >= 128 bytes of the text that
+ * comes next (continues != 0; the last rank has none).  The walk's state at a byte is (offset of the next token start, pending
+ * forward-delete flag) = one of 80 ENTRY STATES (2 * offset + flag, offset < 40), and what a range does to it is a map of 80 entries:
+ *   tm_score_begin   runs the match kernel over the range and returns exits[80]: exits[e] = the entry state of the NEXT range if this
+ *                    one is entered in state e (0xFF: e cannot occur).  Ranks all-gather their 80 bytes; rank r's true entry state is
+ *                    exits[r-1][ exits[r-2][ ... exits[0][0] ] ].
+ *   tm_score_finish  completes the pass from that entry state: histogram exactly as tm_score_device[_into] leaves it (dst_device may be
+ *                    NULL).  A token that begins inside the range is counted by this rank even if it ends in the halo.
+ * Summed over the ranks (one all-reduce) the histograms equal tm_score of the whole dataset as one strip, bit for bit.
+ * tm_score_read copies the histogram of the last pass to the host in tm_score's form. */
+int tm_score_begin(const tm_vocab* v, tm_dataset* d, uint64_t off, uint64_t len, int continues, void* stream, uint8_t* exits);
+int tm_score_finish(const tm_vocab* v, tm_dataset* d, uint32_t entry_state, void* stream, uint32_t* dst_device, uint64_t dst_words);
+int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,8 +161,14 @@ static void emit(const tmo_vocab* v, sink_t* s, uint32_t id, int adv, int with_d
   }
 }
 
-static long long walk(const tmo_vocab* v, const uint8_t* src, size_t n, sink_t* s) {
+/* The walk over data[start .. stop) of a text of n bytes (all of it can be looked at), entered with forwardDelete = fd0: what one
+ * goroutine of the reference does for start = 0, fd0 = 0, stop = n.  The general form restates the one property the multi-GPU scoring
+ * pass rests on: the walk's whole state at a token boundary is (i, forwardDelete) — index/length are recomputed from the text — so a
+ * range of the whole-buffer walk (training/trainvocab.go:909-922) can be entered at start with fd0 and left where the first token
+ * begins at or behind `stop`.  *exit_state = 2 * (i - stop) + forwardDelete at that point. */
+static long long walk_range(const tmo_vocab* v, const uint8_t* src, size_t n, size_t start, int fd0, size_t stop, sink_t* s, uint32_t* exit_state) {
   long long missing = 0;
+  if (exit_state) *exit_state = 0;
   if (v->max_len == 0) return 0;                  /* go :960 */
   uint8_t* data = (uint8_t*)malloc(n + 1);
   memcpy(data, src, n);
@@ -176,9 +182,22 @@ static long long walk(const tmo_vocab* v, const uint8_t* src, size_t n, sink_t* 
   memset(lil, 0, sizeof lil);
   lil[0] = 32;                                    /* go :1030 */
 
-  int i = 0, fd = 0;
+  int i = (int)start, fd = 0;
+  const int stopi = (int)stop;
   uint32_t index = 0, length = 0;
-  while (i < lenData) {
+  if (fd0 && i < stopi) {
+    /* entered in a forward-delete state: index/length are the longest match of ' ' + data[i:] (go :1088-1095) */
+    int rem0 = lenData - i;
+    int m = rem0 < maxlen_sp ? rem0 : maxlen_sp;
+    if (m < 0) m = 0;
+    memcpy(lil + off, data + i, (size_t)m);
+    uint32_t lb = 0;
+    tmo_longest(v, lil, (size_t)(m + off), &index, &lb);
+    length = lb - (uint32_t)off;
+    fd = 1;
+    goto checkpoint;
+  }
+  while (i < stopi) {
     int rem = lenData - i;
     if (!tmo_longest(v, data + i, (size_t)(rem < maxlen ? rem : maxlen), &index, &length)) {
       /* go :1269-1276 */
@@ -188,6 +207,7 @@ static long long walk(const tmo_vocab* v, const uint8_t* src, size_t n, sink_t* 
       continue;
     }
   checkpoint:;
+    if (i >= stopi) break;                        /* (never taken when stop == n: a second token is only found inside the text) */
     const tmo_row* O = &v->rows[index];
     int len = (int)length;
     int i1 = i + len;
@@ -253,9 +273,12 @@ static long long walk(const tmo_vocab* v, const uint8_t* src, size_t n, sink_t* 
     emit(v, s, O->id, len, 0);        /* go :1265-1267 */
     i += len; fd = 0;
   }
+  if (exit_state) *exit_state = (uint32_t)(2 * (i - stopi) + fd);
   free(data);
   return missing;
 }
+
+static long long walk(const tmo_vocab* v, const uint8_t* src, size_t n, sink_t* s) { return walk_range(v, src, n, 0, 0, n, s, NULL); }
 
 long long tmo_tokenize(const tmo_vocab* v, const uint8_t* data, size_t n, uint32_t* out, size_t cap, long long* missing) {
   sink_t s; memset(&s, 0, sizeof s); s.mode = 0; s.out = out; s.cap = cap;
@@ -275,6 +298,15 @@ void tmo_score(const tmo_vocab* v, const uint8_t* data, size_t n, uint32_t* scor
                uint8_t missing_set[32]) {
   sink_t s; memset(&s, 0, sizeof s); s.mode = 2; s.scores = scores; s.missing_set = missing_set;
   walk(v, data, n, &s);
+  if (tokens_in_text) *tokens_in_text += s.tokens_in_text;
+}
+
+/* scoring mode over the byte range [start, stop) of a text of n bytes, entered in state (start offset already applied by the caller,
+ * fd0); see walk_range */
+void tmo_score_range(const tmo_vocab* v, const uint8_t* data, size_t n, size_t start, int fd0, size_t stop, uint32_t* scores,
+                     uint64_t* tokens_in_text, uint8_t missing_set[32], uint32_t* exit_state) {
+  sink_t s; memset(&s, 0, sizeof s); s.mode = 2; s.scores = scores; s.missing_set = missing_set;
+  walk_range(v, data, n, start, fd0, stop, &s, exit_state);
   if (tokens_in_text) *tokens_in_text += s.tokens_in_text;
 }
 

@@ -43,6 +43,13 @@ long long tmo_count(const tmo_vocab* v, const uint8_t* data, size_t n, long long
 void tmo_score(const tmo_vocab* v, const uint8_t* data, size_t n, uint32_t* scores, uint64_t* tokens_in_text,
                uint8_t missing_set[32]);
 
+/* The same accumulation over the byte range [start, stop) of ONE walk over a text of n bytes (training/trainvocab.go:909-922: after
+ * "midway" the worker walks the whole dataset as one strip): entered at `start` with forwardDelete = fd0, left at the first token
+ * boundary >= stop; *exit_state = 2 * (boundary - stop) + forwardDelete there.  A token that begins before `stop` is counted in
+ * full.  Chaining ranges through their exit states reproduces tmo_score of the whole text (tests/test_dist_gloo.py). */
+void tmo_score_range(const tmo_vocab* v, const uint8_t* data, size_t n, size_t start, int fd0, size_t stop, uint32_t* scores,
+                     uint64_t* tokens_in_text, uint8_t missing_set[32], uint32_t* exit_state);
+
 /* go/tokenmonster.go:445-...(decode of raw token bytes, no capcode decoding): concatenates reverse[id] */
 long long tmo_decode_raw(const tmo_vocab* v, const uint32_t* toks, size_t n, uint8_t* out, size_t cap);
 

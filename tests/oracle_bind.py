@@ -94,6 +94,21 @@ class Oracle:
         self.L.tmo_score(self.h, d.ctypes.data, d.size, scores.ctypes.data, C.byref(tit), ms.ctypes.data)
         return scores, tit.value, ms
 
+    def score_range(self, data, lo, hi, entry_state=0):
+        """scoring mode over bytes [lo, hi) of ONE walk over `data`, entered in `entry_state` (2 * offset + forwardDelete)
+        -> (scores, tokens_in_text, missing_set, exit_state)"""
+        d = _u8(data)
+        self.L.tmo_score_range.restype = None
+        self.L.tmo_score_range.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64),
+                                           C.c_void_p, C.POINTER(C.c_uint32)]
+        scores = np.zeros(self.n_ids(), dtype=np.uint32)
+        tit = C.c_uint64(0)
+        ms = np.zeros(32, dtype=np.uint8)
+        ex = C.c_uint32(0)
+        self.L.tmo_score_range(self.h, d.ctypes.data, d.size, lo + (entry_state >> 1), entry_state & 1, hi, scores.ctypes.data, C.byref(tit),
+                               ms.ctypes.data, C.byref(ex))
+        return scores, tit.value, ms, ex.value
+
     def decode_raw(self, toks):
         t = np.ascontiguousarray(toks, dtype=np.uint32)
         cap = 40 * t.size + 8

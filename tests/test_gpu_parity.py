@@ -234,6 +234,59 @@ def test_score_histogram_full_candidate_shape():
     assert (got_s == es).all() and got_t == et and (got_m == em).all()
 
 
+@pytest.mark.parametrize("shape", ["micro", "candidates"])
+def test_score_ranges_of_one_walk(shape):
+    """tm_score_begin / tm_score_finish: a dataset cut into byte ranges, each uploaded with a halo of the following text and scored as a
+    piece of ONE whole-buffer walk (training/trainvocab.go:909-922), the ranges chained through their 80-entry exit maps exactly as
+    N ranks do (tokenmonster_amd/dist.py).  The summed histogram must equal the oracle's walk over the whole buffer."""
+    import ctypes as C
+    from tokenmonster_amd import _native as N
+    from tokenmonster_amd import dist as tmdist
+    if shape == "micro":
+        rng = np.random.default_rng(91)
+        img = synth.build_vocab(fuzz_vocab_tokens(rng, 2, 150), capcode=2, charset=1)
+        data = np.frombuffer(fuzz_text(rng, 2, 300_000), dtype=np.uint8)
+        cuts = [0, 64, 200, 70_001, 70_100, 150_000, 299_900, 300_000]
+    else:
+        img = synth.config_vocab("candidates-65536")
+        raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 3 << 20, seed=0x434F5250 + 5)
+        data, _ = synth.normalize_batch(raw, offs, 2, 1)
+        n = int(data.size)
+        cuts = [0, n // 3 + 1, 2 * n // 3 + 2, n]          # a long range each: the group maps (k_group_compose) carry the exit map
+    v, orc = tm.Vocab(img), Oracle(img)
+    exp_s, exp_t, exp_m = orc.score(data)
+    n_ids = v.n_ids()
+    all_exits, hists = [], []
+    handles = []
+    for a, b in zip(cuts, cuts[1:]):
+        own = data[a:min(b + tmdist.HALO, data.size)]       # the rank's bytes + halo: all it ever sees
+        ds = C.c_void_p()
+        N.check(N.lib.tm_dataset_upload(N.ptr(np.ascontiguousarray(own)), own.size, C.byref(ds)))
+        handles.append(ds)
+        eng = tmdist.HipRange(v, ds, b - a, continues=b < data.size)
+        ex = eng.begin()
+        # the device's exit map agrees with the oracle's range walk on every entry state the walk can be in
+        for e in (0, 2, 7, 21):
+            if ex[e] != tmdist.UNREACHABLE and e % 2 == 0:
+                assert int(ex[e]) == orc.score_range(data, a, b, e)[3], (a, b, e)
+        all_exits.append(ex)
+        entry = tmdist.resolve_entry(all_exits, len(all_exits) - 1)
+        eng.finish(entry)
+        s_ = np.zeros(n_ids, dtype=np.uint32)
+        t_ = C.c_uint64()
+        m_ = np.zeros(32, dtype=np.uint8)
+        N.check(N.lib.tm_score_read(v.handle, ds, N.ptr(s_), C.byref(t_), N.ptr(m_)))
+        hists.append((s_, t_.value, m_))
+    got_s = sum(h[0].astype(np.uint64) for h in hists)
+    got_t = sum(h[1] for h in hists)
+    got_m = np.bitwise_or.reduce(np.stack([h[2] for h in hists]))
+    for ds in handles:
+        N.lib.tm_dataset_free(ds)
+    assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
+    assert tmdist.resolve_entry(all_exits, len(all_exits)) == 0     # the walk ends at the end of the text
+    assert any(tmdist.resolve_entry(all_exits, r) != 0 for r in range(1, len(all_exits)))    # some cut fell inside a token
+
+
 def test_serialized_auto_width_large_vocab():
     """go/tokenmonster.go:990-996: encoding_length 0 picks 3 bytes per id once the vocabulary has more than 65 536 ids
     (englishcode-100256 shape); 2- and 4-byte requests are honoured as given (:1545, :2089; 2 bytes truncates, as Go's does)."""

@@ -69,6 +69,9 @@ SIGNATURES = {
     "tm_score": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, u64p, vp]),
     "tm_score_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.POINTER(vp), u64p]),
     "tm_score_device_into": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64]),
+    "tm_score_begin": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp]),
+    "tm_score_finish": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint64]),
+    "tm_score_read": (C.c_int, [vp, vp, vp, u64p, vp]),
     # tm_build.h
     "tm_free": (None, [vp]),
     "tm_build_vocab": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,

@@ -276,6 +276,7 @@ __device__ unsigned long long g_phase[64 * 32];
 __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
                                                                 const uint64_t* __restrict__ doc_end,
+                                                                const uint64_t* __restrict__ doc_vis,
                                                                 const uint32_t* __restrict__ seg_doc,
                                                                 const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
                                                                 uint32_t* __restrict__ R0, uint2* __restrict__ side,
@@ -294,9 +295,12 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   const uint32_t idle_off = (T.edge_mask + 1u) << 4;      // the always-empty bucket behind the edge hash
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
-  const uint64_t rem = doc_end[doc] - begin;
-  const int dl = rem > (uint64_t)(1 << 20) ? (1 << 20) : (int)rem;   // bytes of the document from `begin` on (clamped)
-  const int seglen = min(dl, SEG);
+  // A document owns the positions [doc_begin, doc_end) but may LOOK at text up to doc_vis >= doc_end: a byte range of a dataset
+  // that is scored as part of the whole-buffer walk (training/trainvocab.go:909-922) sees the text that follows it, and tokens that
+  // begin inside the range may end behind it.  For ordinary documents doc_vis == doc_end: the text ends with the document.
+  const uint64_t rem = doc_end[doc] - begin, remv = doc_vis[doc] - begin;
+  const int dl = remv > (uint64_t)(1 << 20) ? (1 << 20) : (int)remv;   // bytes of text from `begin` on that can be looked at (clamped)
+  const int seglen = (int)(rem < (uint64_t)SEG ? rem : (uint64_t)SEG);  // positions of this segment
   PH_INIT
 
   // stage the text with (unaligned) dword loads; bytes at and after the end of the document read as 0: the pad
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   {
     uint2* J = reinterpret_cast<uint2*>(w.D);            // overlays D, Db, X, Xb (dead after step B): 1024 x 8 B
     static_assert(sizeof(uint32_t) * (3 * NPOS + SEG) >= 2 * SEG * sizeof(uint2), "J overlay does not fit");
-    const bool more_text = rem > (uint64_t)SEG;           // not the last segment of the document
+    const bool more_text = remv > (uint64_t)seglen;       // text follows the segment: the chain leaves it into an entry state
     // J entry: x = #id events [0..15] | field [16..30] | left-the-segment [31]; the field is the LDS byte address of the
     // entry it points at, or — once the chain has left the segment — the entry state of the next segment (0x7FFF: the
     // state is unreachable); y = #forward-deletes | #missing << 16.  Composing two entries is (x & 0xFFFF) + x', y + y',
@@ -584,13 +588,15 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     auto ld_j = [](uint32_t a) -> uint2 { const u32x2 t = *(lds_v2*)(uintptr_t)a; return make_uint2(t.x, t.y); };
     const uint32_t jaddr = (uint32_t)(uintptr_t)(lds_u8*)w.D;
     static_assert(sizeof(s_wave) + 2048 < 32768, "LDS addresses must fit the 15-bit field");
-    auto first_hop = [&](uint32_t r, int p) -> uint2 {
-      if (p >= seglen) return make_uint2(0x80000000u, 0u);                    // at/after the end of text: terminal, nothing emitted
+    auto first_hop = [&](uint32_t r, int p, uint32_t fd) -> uint2 {
+      // at/after the end of the segment: nothing is emitted here.  At the end of the text that is the terminal state; in a byte
+      // range that is followed by more text, a token of the range before may cover this whole (short, last) segment: pass through
+      if (p >= seglen) return make_uint2(0x80000000u | ((more_text ? (uint32_t)((p - seglen) * 2) + fd : 0u) << 16), 0u);
       if (r == R_INVALID) return make_uint2(0x80000000u | (0x7FFFu << 16), 0u);
       const int pn = p + (int)((r >> 24) & 63u);
       const uint32_t fdn = (r >> 30) & 1u;
       const uint32_t ev = (r & ID_NONE) != ID_NONE ? 1u : 0u;
-      const uint32_t x = pn >= seglen ? 0x80000000u | ((more_text ? (uint32_t)((pn - SEG) * 2) + fdn : 0u) << 16)
+      const uint32_t x = pn >= seglen ? 0x80000000u | ((more_text ? (uint32_t)((pn - seglen) * 2) + fdn : 0u) << 16)
                                       : (jaddr + 8u * (fdn * SEG + (uint32_t)pn)) << 16;
       return make_uint2(x | ev, fdn | ((r >> 31) << 16));
     };
@@ -602,8 +608,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 #pragma unroll
     for (int it = 0; it < N0; it++) {
       const int p = it * 64 + lane;
-      ja[it] = first_hop(r0[it], p);
-      ja[N0 + it] = first_hop(r1[it], p);
+      ja[it] = first_hop(r0[it], p, 0u);
+      ja[N0 + it] = first_hop(r1[it], p, 1u);
       J[p] = ja[it];
       J[SEG + p] = ja[N0 + it];
     }
@@ -666,15 +672,17 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 // ------------------------------------------------------------------------------------------------
 // K3: resolve — per document, chain the exit maps
 // ------------------------------------------------------------------------------------------------
+// doc_entry (may be null = all 0): the entry state of a document's first segment.  It is 0 for a document; a byte range of a
+// dataset that continues the whole-buffer walk of the range before it enters in the state that walk left (tm_score_begin/finish).
 __global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs,
-                          uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
+                          const uint8_t* __restrict__ doc_entry, uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
                           uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ doc_events,
                           uint32_t* __restrict__ doc_missing, uint32_t* __restrict__ error_flag) {
   uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ndocs) return;
   uint64_t g0 = doc_seg_start[d], g1 = doc_seg_start[d + 1];
   if (g1 - g0 > LONG_SEGS) return;               // long documents: k_group_compose / k_long_top / k_group_expand
-  uint32_t e = 0, ntok = 0, events = 0, nmiss = 0;
+  uint32_t e = doc_entry ? doc_entry[d] : 0u, ntok = 0, events = 0, nmiss = 0;
   for (uint64_t g = g0; g < g1; g++) {
     seg_entry[g] = (uint8_t)e;
     seg_tokbase[g] = ntok;
@@ -716,14 +724,14 @@ __global__ __launch_bounds__(128) void k_group_compose(const uint2* __restrict__
   gmap[(uint64_t)blockIdx.x * ENT + e0] = ok ? make_uint4(e, events, nfd, nmiss) : make_uint4(R_INVALID, 0u, 0u, 0u);
 }
 
-__global__ void k_long_top(const uint4* __restrict__ gmap, const LongDoc* __restrict__ longs, uint32_t nlong,
+__global__ void k_long_top(const uint4* __restrict__ gmap, const LongDoc* __restrict__ longs, uint32_t nlong, const uint8_t* __restrict__ doc_entry,
                            uint8_t* __restrict__ group_entry, uint4* __restrict__ group_base,
                            uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ doc_events,
                            uint32_t* __restrict__ doc_missing, uint32_t* __restrict__ error_flag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nlong) return;
   const LongDoc ld = longs[i];
-  uint32_t e = 0, ntok = 0, events = 0, nmiss = 0;
+  uint32_t e = doc_entry ? doc_entry[ld.doc] : 0u, ntok = 0, events = 0, nmiss = 0;
   for (uint32_t k = 0; k < ld.ngroups; k++) {
     const uint32_t gi = ld.first_group + k;
     group_entry[gi] = (uint8_t)e;
@@ -757,6 +765,36 @@ __global__ void k_group_expand(const uint2* __restrict__ exitmap, const Group* _
     e = x.x & 0xFFu;
     ntok += (x.x >> 8) + (x.y & 0xFFFFu);
   }
+}
+
+// Exit state of a document for EVERY entry state (one thread per entry state): what a rank hands to its neighbours when a dataset is
+// scored as byte ranges of ONE whole-buffer walk.  Short documents chain their segments' exit maps, long ones their groups' maps
+// (k_group_compose has composed those for all 80 entry states already).  0xFF: the entry state cannot occur.
+__global__ __launch_bounds__(128) void k_doc_exits(const uint2* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, const uint4* __restrict__ gmap,
+                                                   const LongDoc* __restrict__ longs, uint32_t nlong, uint8_t* __restrict__ exits) {
+  const uint32_t d = blockIdx.x, e0 = threadIdx.x;
+  if (e0 >= ENT) return;
+  const uint64_t g0 = doc_seg_start[d], g1 = doc_seg_start[d + 1];
+  uint32_t e = e0;
+  bool ok = true;
+  if (g1 - g0 > LONG_SEGS) {
+    uint32_t li = 0;
+    while (li < nlong && longs[li].doc != d) li++;
+    if (li == nlong) ok = false;
+    else {
+      const LongDoc ld = longs[li];
+      for (uint32_t k = 0; k < ld.ngroups && ok; k++) {
+        const uint4 x = gmap[(uint64_t)(ld.first_group + k) * ENT + e];
+        if (x.x == R_INVALID) ok = false; else e = x.x;
+      }
+    }
+  } else {
+    for (uint64_t g = g0; g < g1 && ok; g++) {
+      const uint2 x = exitmap[g * ENT + e];
+      if (x.x == R_INVALID) ok = false; else e = x.x & 0xFFu;
+    }
+  }
+  exits[(uint64_t)d * ENT + e0] = ok ? (uint8_t)e : (uint8_t)0xFF;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1114,16 +1152,13 @@ int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32
   return TM_OK;
 }
 
-int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) {
+// The pipeline in two halves, so that the scoring pass can look at the exit maps (tm_score_begin) before the entry states of its byte
+// ranges are known (tm_score_finish): pipeline_match = K0 + K1 (+ the group maps of long documents), pipeline_resolve = K3 + scan (+ K4).
+int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   const tm_vocab* v = b->vocab;
   { int rc = enter_device(v); if (rc != TM_OK) return rc; }
   b->last_stream = st;
-  hipError_t e;
-  if (timed && !b->have_events) {
-    for (auto& ev : b->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-    b->have_events = true;
-  }
-  auto mark = [&](int k) { if (timed) (void)hipEventRecord(b->ev[k], st); };
+  auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   (void)hipMemsetAsync(b->d_error, 0, 4, st);
   const uint32_t nd = b->ndocs;
   const uint64_t nseg = b->nseg;
@@ -1135,16 +1170,24 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   }
   mark(1);
   if (nseg > 0)
-    k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end, b->d_seg_doc,
+    k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end,
+                                                                                          b->d_doc_vis ? b->d_doc_vis : b->d_doc_end, b->d_seg_doc,
                                                                                           b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
                                                                                           debug_flags());
   mark(2);
+  if (b->ngroups > 0) k_group_compose<<<b->ngroups, 128, 0, st>>>(b->d_exitmap, b->d_groups, b->d_gmap);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
+}
+
+int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, bool emit) {
+  const uint32_t nd = b->ndocs;
+  auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   if (nd > 0)
-    k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_seg_entry, b->d_seg_tokbase,
+    k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_doc_entry, b->d_seg_entry, b->d_seg_tokbase,
                                                 b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_error);
   if (b->ngroups > 0) {
-    k_group_compose<<<b->ngroups, 128, 0, st>>>(b->d_exitmap, b->d_groups, b->d_gmap);
-    k_long_top<<<(b->nlong + 63) / 64, 64, 0, st>>>(b->d_gmap, b->d_longs, b->nlong, b->d_group_entry, b->d_group_base, b->d_doc_ntok,
+    k_long_top<<<(b->nlong + 63) / 64, 64, 0, st>>>(b->d_gmap, b->d_longs, b->nlong, b->d_doc_entry, b->d_group_entry, b->d_group_base, b->d_doc_ntok,
                                                     b->d_doc_events, b->d_doc_missing, b->d_error);
     k_group_expand<<<(b->ngroups + 63) / 64, 64, 0, st>>>(b->d_exitmap, b->d_groups, b->ngroups, b->d_group_entry, b->d_group_base,
                                                           b->d_seg_entry, b->d_seg_tokbase, b->d_error);
@@ -1153,9 +1196,26 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
   if (nd > 0) scan_u32(b->d_doc_ntok, nd, b->d_scan_tmp, b->d_totals + 1, b->d_tok_offsets, st);
   else (void)hipMemsetAsync(b->d_tok_offsets, 0, 8, st);
   mark(4);
-  if (emit && nseg > 0) launch_emit(b, st);
+  if (emit && b->nseg > 0) launch_emit(b, st);
   mark(5);
-  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
+}
+
+// exit state of every document for every entry state -> exits[ndocs * ENT] (device); needs pipeline_match
+void launch_doc_exits(tm_batch* b, uint8_t* d_exits, hipStream_t st) {
+  if (b->ndocs) k_doc_exits<<<b->ndocs, 128, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, b->d_gmap, b->d_longs, b->nlong, d_exits);
+}
+
+int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) {
+  hipError_t e;
+  if (timed && !b->have_events) {
+    for (auto& ev : b->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    b->have_events = true;
+  }
+  int rc = pipeline_match(b, st, timed ? b->ev : nullptr);
+  if (rc == TM_OK) rc = pipeline_resolve(b, st, timed ? b->ev : nullptr, emit);
+  if (rc != TM_OK) return rc;
   if (timed) {
     if ((e = hipEventSynchronize(b->ev[TM_NUM_KERNELS])) != hipSuccess) return hip_fail(e, "hipEventSynchronize");
     for (int k = 0; k < TM_NUM_KERNELS; k++) (void)hipEventElapsedTime(&ms[k], b->ev[k], b->ev[k + 1]);

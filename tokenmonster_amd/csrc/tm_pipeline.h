@@ -49,6 +49,8 @@ struct tm_batch {
   uint64_t* d_offsets = nullptr;       // packed batches: doc_begin = d_offsets, doc_end = d_offsets + 1
   const uint64_t* d_doc_begin = nullptr;
   const uint64_t* d_doc_end = nullptr;
+  const uint64_t* d_doc_vis = nullptr;   // how far a document may look at the text (null: its end); see k_match_branch
+  const uint8_t* d_doc_entry = nullptr;  // entry state of a document's first segment (null: 0); see k_resolve
   uint32_t* d_doc_nseg = nullptr;
   uint64_t* d_doc_seg_start = nullptr;
   uint32_t* d_seg_doc = nullptr;
@@ -114,6 +116,9 @@ void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32
 void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st);
 int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs);
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit);
+int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev);
+int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, bool emit);
+void launch_doc_exits(tm_batch* b, uint8_t* d_exits, hipStream_t st);
 // scoring variant of the chain kernel: histogram in HBM (scores | 4 limbs | 256 counters), see tm_score.hip
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
                        uint32_t n_ids, hipStream_t st);

@@ -26,22 +26,33 @@ struct tm_dataset {
   uint32_t* d_missing_bits = nullptr;
   int n_cu = 256;
   int device = 0;
+  // byte ranges of a whole-buffer walk (tm_score_begin / tm_score_finish)
+  uint64_t* d_vis = nullptr;       // per strip: how far it may look at the text
+  uint8_t* d_entry = nullptr;      // per strip: entry state
+  uint8_t* d_exits = nullptr;      // per strip: exit state for each of the ENT entry states
+  uint32_t strip_cap = 0;
+  bool prepared = false;
 };
 
-static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
-                     hipStream_t st) {
+// One scoring pass in two halves.  score_prepare: the strips become the documents of the workspace, K0 + K1 run (and the group maps
+// of long strips).  score_complete: K3 from the strips' entry states + the histogram walk.  Between the two a caller that scores
+// ONE byte range of a whole-buffer walk (tm_score_begin / tm_score_finish) reads the range's exit map and learns its entry state.
+static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+                         bool continues, hipStream_t st) {
   if (!v || !d) return set_error(TM_E_INVALID, "null argument");
   { int rc = enter_device(v); if (rc != TM_OK) return rc; }
   if (d->device != v->device) return set_error(TM_E_INVALID, "dataset lives on device %d, vocabulary on device %d", d->device, v->device);
+  d->prepared = false;
   std::vector<uint64_t> be;
   uint64_t whole_off = 0, whole_len = d->n;
   if (n_strips == 0) { strip_off = &whole_off; strip_len = &whole_len; n_strips = 1; }
-  be.resize(2ull * n_strips);
+  be.resize(3ull * n_strips);
   uint64_t nseg = 0;
   for (uint32_t k = 0; k < n_strips; k++) {
     if (strip_off[k] > d->n || strip_len[k] > d->n - strip_off[k]) return set_error(TM_E_INVALID, "strip %u outside the dataset", k);
     be[k] = strip_off[k];
     be[n_strips + k] = strip_off[k] + strip_len[k];
+    be[2ull * n_strips + k] = continues ? d->n : strip_off[k] + strip_len[k];     // how far the strip may look (k_match_branch)
     nseg += (strip_len[k] + SEG - 1) / SEG;
   }
   // Strips must be disjoint: the per-position words of the walk (R0, R1) are indexed by absolute dataset position, so two
@@ -73,22 +84,53 @@ static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off
     if ((e = hipMalloc((void**)&d->d_hist, words * 4)) != hipSuccess) return hip_fail(e, "hipMalloc histogram");
     d->hist_words = words;
   }
-  if ((e = hipMemcpyAsync(b->d_offsets, be.data(), be.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D strips");
+  if (d->strip_cap < n_strips) {
+    (void)hipFree(d->d_vis); (void)hipFree(d->d_entry); (void)hipFree(d->d_exits);
+    d->d_vis = nullptr; d->d_entry = nullptr; d->d_exits = nullptr;
+    d->strip_cap = n_strips + 16;
+    if ((e = hipMalloc((void**)&d->d_vis, (size_t)d->strip_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&d->d_entry, d->strip_cap)) != hipSuccess ||
+        (e = hipMalloc((void**)&d->d_exits, (size_t)d->strip_cap * ENT)) != hipSuccess) { d->strip_cap = 0; return hip_fail(e, "hipMalloc (strips)"); }
+  }
+  if ((e = hipMemcpyAsync(b->d_offsets, be.data(), 2ull * n_strips * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(d->d_vis, be.data() + 2ull * n_strips, (size_t)n_strips * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D strips");
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync");   // `be` is a host temporary
   b->d_doc_begin = b->d_offsets;
   b->d_doc_end = b->d_offsets + n_strips;
+  b->d_doc_vis = d->d_vis;
+  b->d_doc_entry = nullptr;
   b->ndocs = n_strips;
   b->nbytes = d->n;
   b->nseg = nseg;
   { int grc = build_groups(b, be.data(), be.data() + n_strips, n_strips); if (grc != TM_OK) return grc; }
+  int rc = pipeline_match(b, st, nullptr);
+  if (rc == TM_OK) d->prepared = true;
+  return rc;
+}
+
+static int score_complete(const tm_vocab* v, tm_dataset* d, const uint8_t* entry_states, hipStream_t st) {
+  if (!d->prepared) return set_error(TM_E_INVALID, "tm_score_finish without tm_score_begin");
+  d->prepared = false;
+  tm_batch* b = d->ws;
+  hipError_t e;
+  if (entry_states) {
+    if ((e = hipMemcpyAsync(d->d_entry, entry_states, b->ndocs, hipMemcpyHostToDevice, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
+      return hip_fail(e, "H2D entry states");
+    b->d_doc_entry = d->d_entry;
+  }
+  const uint64_t words = d->hist_words;
   (void)hipMemsetAsync(d->d_hist, 0, words * 4, st);
   (void)hipMemsetAsync(d->d_tokens, 0, 8, st);
   (void)hipMemsetAsync(d->d_missing_bits, 0, 32, st);
-  int rc = run_pipeline(b, st, false, nullptr, false);
+  int rc = pipeline_resolve(b, st, nullptr, false);
   if (rc != TM_OK) return rc;
   launch_chain_hist(b, v->tables.has_delete ? v->tables.delete_id : 0, d->n_cu, d->d_hist, d->d_tokens, d->d_missing_bits, v->host.n_ids, st);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
   return TM_OK;
+}
+
+static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips, hipStream_t st) {
+  int rc = score_prepare(v, d, strip_off, strip_len, n_strips, false, st);
+  return rc == TM_OK ? score_complete(v, d, nullptr, st) : rc;
 }
 
 extern "C" {
@@ -114,6 +156,7 @@ void tm_dataset_free(tm_dataset* d) {
   if (!d) return;
   tm_batch_free(d->ws);
   (void)hipFree(d->d_text); (void)hipFree(d->d_hist); (void)hipFree(d->d_tokens); (void)hipFree(d->d_missing_bits);
+  (void)hipFree(d->d_vis); (void)hipFree(d->d_entry); (void)hipFree(d->d_exits);
   delete d;
 }
 
@@ -137,10 +180,34 @@ int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
   return TM_OK;
 }
 
-int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
-             uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]) {
-  int rc = score_run(v, d, strip_off, strip_len, n_strips, nullptr);
+int tm_score_begin(const tm_vocab* v, tm_dataset* d, uint64_t off, uint64_t len, int continues, void* stream, uint8_t* exits) {
+  if (!exits) return set_error(TM_E_INVALID, "null argument");
+  if (continues && len < 64 && off + len < (d ? d->n : 0)) return set_error(TM_E_INVALID, "a byte range that is followed by more text must be at least 64 bytes long");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = score_prepare(v, d, &off, &len, 1, continues != 0, st);
   if (rc != TM_OK) return rc;
+  launch_doc_exits(d->ws, d->d_exits, st);
+  hipError_t e;
+  if ((e = hipMemcpyAsync(exits, d->d_exits, ENT, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) {
+    d->prepared = false;
+    return hip_fail(e, "D2H exit map");
+  }
+  return TM_OK;
+}
+
+int tm_score_finish(const tm_vocab* v, tm_dataset* d, uint32_t entry_state, void* stream, uint32_t* dst_device, uint64_t dst_words) {
+  if (!v || !d) return set_error(TM_E_INVALID, "null argument");
+  if (entry_state >= (uint32_t)ENT) return set_error(TM_E_INVALID, "entry state %u out of range", entry_state);
+  const uint8_t es = (uint8_t)entry_state;
+  int rc = score_complete(v, d, &es, (hipStream_t)stream);
+  if (rc != TM_OK || !dst_device) return rc;
+  if (dst_words < d->hist_words) return set_error(TM_E_NOSPACE, "destination holds %llu words, histogram has %llu", (unsigned long long)dst_words, (unsigned long long)d->hist_words);
+  hipError_t e = hipMemcpyAsync(dst_device, d->d_hist, d->hist_words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  return e == hipSuccess ? TM_OK : hip_fail(e, "D2D histogram");
+}
+
+int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]) {
+  if (!v || !d || !d->d_hist || !d->ws) return set_error(TM_E_INVALID, "no scoring pass to read");
   hipError_t e;
   std::vector<uint32_t> h(d->hist_words);
   uint32_t err = 0;
@@ -159,6 +226,12 @@ int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const 
     for (int k = 0; k < 256; k++) if (h[n_ids + 4 + k]) missing_set[k >> 3] |= (uint8_t)(1u << (k & 7));
   }
   return TM_OK;
+}
+
+int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
+             uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]) {
+  int rc = score_run(v, d, strip_off, strip_len, n_strips, nullptr);
+  return rc == TM_OK ? tm_score_read(v, d, scores, tokens_in_text, missing_set) : rc;
 }
 
 }  // extern "C"

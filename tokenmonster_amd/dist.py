@@ -18,10 +18,15 @@ def shard_documents(offsets, rank, world):
     return cuts[rank], cuts[rank + 1]
 
 
+ENTRY_STATES = 80        # 40 offsets x forwardDelete {0, 1}: tmh::ENT
+HALO = 128               # bytes of the following text a rank must see: longest token (40) + look-ahead (41), rounded up
+UNREACHABLE = 0xFF
+
+
 def shard_strips(n_bytes, rank, world, align=4):
     """byte range of one contiguous dataset for `rank` (trainvocab cuts strips on multiples of 4, trainvocab.go:1674).
-    Each rank walks its range as an independent strip - the same approximation the reference makes at strip
-    boundaries; world == 1 is exact."""
+    With score_ranges_exact below the ranges are pieces of ONE whole-buffer walk (exact); walked as independent strips
+    they are the approximation the reference makes at its strip boundaries before "midway"."""
     per = (n_bytes // world) // align * align
     lo = per * rank
     hi = n_bytes if rank == world - 1 else per * (rank + 1)
@@ -59,3 +64,78 @@ def encode_histogram(scores, tokens, missing_set):
         if missing_set[b >> 3] & (1 << (b & 7)):
             w[n_ids + 4 + b] = 1
     return w
+
+
+# ---- exact data-parallel scoring: ONE whole-buffer walk (training/trainvocab.go:909-922) cut into one byte range per rank ------------
+# The walk's whole state at a token boundary is (position, forwardDelete): at a range boundary that is one of 80 entry states
+# (2 * offset-into-the-next-range + forwardDelete, offset < 40).  What a range does to the state is a map of 80 entries that the match
+# kernel produces anyway (exit maps, composed per range by k_group_compose / k_doc_exits).  Protocol, per scoring pass:
+#   1. every rank runs the match kernel over its range (which looks HALO bytes into the next rank's text) -> exits[80]
+#   2. all-gather 80 bytes per rank; rank r chains exits[0][0] -> exits[1][.] -> ... -> its own entry state
+#   3. every rank finishes its pass from that state; ONE all-reduce(sum) of the histogram words
+# Engines: HipRange (tm_score_begin / tm_score_finish on this rank's GPU); the CPU tests use an oracle-backed engine with the same
+# two methods.
+
+
+def exchange_halo(own, rank, world, group=None, backend_device="cpu"):
+    """the first HALO bytes of rank+1's range (empty for the last rank).  `own`: uint8 numpy array, every rank >= HALO bytes."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return np.zeros(0, dtype=np.uint8)
+    if own.size < HALO:
+        raise ValueError("every rank's range must hold at least %d bytes" % HALO)
+    mine = torch.from_numpy(np.ascontiguousarray(own[:HALO]).copy()).to(backend_device)
+    heads = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(heads, mine, group=group)
+    return heads[rank + 1].cpu().numpy() if rank + 1 < world else np.zeros(0, dtype=np.uint8)
+
+
+def resolve_entry(all_exits, rank):
+    """all_exits[r][e] = exit state of rank r's range when entered in state e -> entry state of `rank` (rank 0 enters in 0)"""
+    e = 0
+    for r in range(rank):
+        e = int(all_exits[r][e])
+        if e == UNREACHABLE or e >= ENTRY_STATES:
+            raise RuntimeError("range of rank %d cannot be entered in the state the walk reaches it in" % r)
+    return e
+
+
+def score_ranges_exact(engine, rank, world, group=None, backend_device="cpu"):
+    """one scoring pass over this rank's range as a piece of the whole-buffer walk; returns what engine.finish returns (for HipRange the
+    device histogram is already all-reduced in place by the caller's choice: see bench.py).  engine.begin() -> 80 exit states;
+    engine.finish(entry_state) -> result."""
+    import torch
+    import torch.distributed as dist
+    exits = np.asarray(engine.begin(), dtype=np.uint8)
+    assert exits.size == ENTRY_STATES
+    if world > 1:
+        mine = torch.from_numpy(exits.copy()).to(backend_device)
+        allx = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allx, mine, group=group)
+        entry = resolve_entry([t.cpu().numpy() for t in allx], rank)
+    else:
+        entry = 0
+    return engine.finish(entry)
+
+
+class HipRange:
+    """engine for score_ranges_exact on this rank's GPU.  `dataset` holds the rank's bytes followed by the halo; the range is
+    [0, own_len) of it."""
+
+    def __init__(self, vocab, dataset, own_len, continues, stream=None, dst=None, dst_words=0):
+        self.vocab, self.ds, self.own_len, self.continues = vocab, dataset, int(own_len), bool(continues)
+        self.stream, self.dst, self.dst_words = stream, dst, dst_words
+
+    def begin(self):
+        import ctypes as C
+        from . import _native as N
+        ex = np.zeros(ENTRY_STATES, dtype=np.uint8)
+        N.check(N.lib.tm_score_begin(self.vocab.handle, self.ds, 0, self.own_len, 1 if self.continues else 0, C.c_void_p(self.stream or 0), N.ptr(ex)))
+        return ex
+
+    def finish(self, entry):
+        import ctypes as C
+        from . import _native as N
+        N.check(N.lib.tm_score_finish(self.vocab.handle, self.ds, int(entry), C.c_void_p(self.stream or 0), C.c_void_p(self.dst or 0), self.dst_words))
+        return entry
