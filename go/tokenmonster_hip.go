@@ -1,0 +1,226 @@
+//go:build hip
+
+// tokenmonster_hip.go — the cgo binding a maintainer drops next to go/tokenmonster.go to run the tokenize path on an
+// MI355X through libtokenmonster_hip.so (include/tokenmonster_hip.h).  Build with `-tags hip`; without the tag nothing
+// changes.  The Go toolchain is not part of the image this library was developed in, so this file is compiled by nobody
+// there: every call it makes is exercised through the same C ABI by examples/server_jobs.c (the job-1 / job-20 framing
+// of training/tokenmonsterserver.go), examples/tokenize_file.c and the ctypes tests.
+//
+// Seams replaced (nothing else in the reference changes):
+//   (*Vocab).Tokenize / Count / TokenizeToSerialized over many documents   go/tokenmonster.go:959, :971, :986
+//   the goroutine fan-out of tokenmonsterserver jobs 1 and 20              training/tokenmonsterserver.go:363-378, :773-787
+//   the scoring loop of the trainvocab worker                              training/trainvocab.go:925-1176
+// Every call borrows Go memory for its duration only (cgo pointer rule).  Any error means: use the existing CPU path.
+// Goroutines may call concurrently: each call takes a lane (stream + workspace) of the vocabulary and makes the
+// vocabulary's device current on whatever OS thread the goroutine is on; no runtime.LockOSThread is needed.
+package tokenmonster
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../include
+#cgo LDFLAGS: -ltokenmonster_hip
+#include <stdlib.h>
+#include "tokenmonster_hip.h"
+#include "tm_build.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"os"
+	"unsafe"
+)
+
+// HipVocab is the device-resident twin of a *Vocab: the same .vocab bytes, flattened into the walk tables in HBM.
+type HipVocab struct {
+	h   *C.tm_vocab
+	len int // vocab.Len(): decides 2- or 4-byte ids on the server wire (tokenmonsterserver.go:350-353)
+}
+
+func hipErr() error { return errors.New("tokenmonster_hip: " + C.GoString(C.tm_last_error())) }
+
+// HipDeviceCount reports the usable gfx950 devices (0: keep using the CPU path).
+func HipDeviceCount() int { return int(C.tm_device_count()) }
+
+// LoadHip uploads the vocabulary file that Load (go/tokenmonster.go:2656) reads to the current device.
+func LoadHip(filename string, device int) (*HipVocab, error) {
+	b, err := os.ReadFile(filename)
+	if err != nil {
+		return nil, err
+	}
+	if len(b) == 0 {
+		return nil, errors.New("tokenmonster_hip: empty vocabulary file")
+	}
+	if C.tm_set_device(C.int(device)) != C.TM_OK {
+		return nil, hipErr()
+	}
+	var h *C.tm_vocab
+	if C.tm_vocab_load((*C.uint8_t)(unsafe.Pointer(&b[0])), C.size_t(len(b)), &h) != C.TM_OK {
+		return nil, hipErr()
+	}
+	return &HipVocab{h: h, len: int(C.tm_vocab_size(h))}, nil
+}
+
+func (hv *HipVocab) Close() {
+	if hv.h != nil {
+		C.tm_vocab_free(hv.h)
+		hv.h = nil
+	}
+}
+
+// pack lays documents out the way the kernels read them: one contiguous buffer + offsets.
+func pack(docs [][]byte) ([]byte, []uint64) {
+	offsets := make([]uint64, len(docs)+1)
+	total := 0
+	for i, d := range docs {
+		total += len(d)
+		offsets[i+1] = uint64(total)
+	}
+	text := make([]byte, total+1)
+	for i, d := range docs {
+		copy(text[offsets[i]:], d)
+	}
+	return text, offsets
+}
+
+// TokenizeSerializedBatch is TokenizeToSerialized (go/tokenmonster.go:986) over many RAW documents in one call: the
+// normalization pre-step (go :242-253), the walk and the packing to encodingLength bytes per id all run on the device,
+// chunks of documents overlap their PCIe transfers with the kernels of other chunks.  encodingLength 0 picks 2 or 3 by
+// len(reverse) like go :990-996.  Returns the serialized ids per document and the count of characters without a token.
+func (hv *HipVocab) TokenizeSerializedBatch(docs [][]byte, encodingLength uint8) ([][]byte, []int, uint8, error) {
+	n := len(docs)
+	text, offsets := pack(docs)
+	byteOff := make([]uint64, n+1)
+	missing := make([]uint32, n+1)
+	capBytes := uint64(len(text))*2 + 64
+	var used C.uint32_t
+	for {
+		out := make([]byte, capBytes+1)
+		rc := C.tm_tokenize_pipeline(hv.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])),
+			C.uint32_t(n), 1, C.uint32_t(encodingLength), 0, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(capBytes),
+			(*C.uint64_t)(unsafe.Pointer(&byteOff[0])), (*C.uint32_t)(unsafe.Pointer(&missing[0])), &used, nil)
+		if rc == C.TM_E_NOSPACE { // the capacity required is reported in byteOff[n]
+			capBytes = byteOff[n]
+			continue
+		}
+		if rc != C.TM_OK {
+			return nil, nil, 0, hipErr()
+		}
+		res := make([][]byte, n)
+		miss := make([]int, n)
+		for i := range docs {
+			res[i] = out[byteOff[i]:byteOff[i+1]]
+			miss[i] = int(missing[i])
+		}
+		return res, miss, uint8(used), nil
+	}
+}
+
+// TokenizeBatch returns uint32 ids of ALREADY NORMALIZED documents (what vocab.tokenize, go :1017, takes).
+func (hv *HipVocab) TokenizeBatch(normalized [][]byte) ([][]uint32, []int, error) {
+	n := len(normalized)
+	text, offsets := pack(normalized)
+	capTok := uint64(len(text)/2 + 2*n + 64)
+	tokOff := make([]uint64, n+1)
+	missing := make([]uint32, n+1)
+	for {
+		out := make([]uint32, capTok+1)
+		rc := C.tm_tokenize_batch(hv.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])),
+			C.uint32_t(n), (*C.uint32_t)(unsafe.Pointer(&out[0])), C.uint64_t(capTok),
+			(*C.uint64_t)(unsafe.Pointer(&tokOff[0])), (*C.uint32_t)(unsafe.Pointer(&missing[0])))
+		if rc == C.TM_E_NOSPACE {
+			capTok = tokOff[n]
+			continue
+		}
+		if rc != C.TM_OK {
+			return nil, nil, hipErr()
+		}
+		res := make([][]uint32, n)
+		miss := make([]int, n)
+		for i := range normalized {
+			res[i] = out[tokOff[i]:tokOff[i+1]]
+			miss[i] = int(missing[i])
+		}
+		return res, miss, nil
+	}
+}
+
+// CountBatch is Count (go :971) over many RAW documents: server job 20.
+func (hv *HipVocab) CountBatch(docs [][]byte) ([]int, error) {
+	n := len(docs)
+	text, offsets := pack(docs)
+	counts := make([]uint64, n+1)
+	if C.tm_count_batch_raw(hv.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])), C.uint32_t(n),
+		(*C.uint64_t)(unsafe.Pointer(&counts[0])), nil) != C.TM_OK {
+		return nil, hipErr()
+	}
+	res := make([]int, n)
+	for i := range res {
+		res[i] = int(counts[i])
+	}
+	return res, nil
+}
+
+// ServerEncodingLength is the rule of tokenmonsterserver job 1 (training/tokenmonsterserver.go:350-353): 2 bytes per
+// id unless vocab.Len() > 65536, then 4 (not the 2/3 rule of TokenizeToSerialized's automatic mode).
+func (hv *HipVocab) ServerEncodingLength() uint8 {
+	if hv.len > 65536 {
+		return 4
+	}
+	return 2
+}
+
+// In tokenmonsterserver.go job 1 (:355-383) the whole `if numBatches == 1 { ... } else { goroutines }` block becomes
+//
+//	bodies := splitBatches(data, numBatches)                    // the same length-prefixed parsing as :356-369
+//	enc, _, _, err := hipVocab.TokenizeSerializedBatch(bodies, hipVocab.ServerEncodingLength())
+//	for i := range results { results[i] = work{enc[i], err} }
+//
+// and job 20 (:767-787) `counts, err := hipVocab.CountBatch(bodies)`.  The response framing below them is unchanged.
+
+// HipDataset is the normalized training dataset of trainvocab, resident in HBM for the whole run (trainvocab.go:1660-1665).
+type HipDataset struct{ h *C.tm_dataset }
+
+func UploadDataset(normalized []byte) (*HipDataset, error) {
+	var d *C.tm_dataset
+	if C.tm_dataset_upload((*C.uint8_t)(unsafe.Pointer(&normalized[0])), C.uint64_t(len(normalized)), &d) != C.TM_OK {
+		return nil, hipErr()
+	}
+	return &HipDataset{d}, nil
+}
+func (d *HipDataset) Close() { C.tm_dataset_free(d.h) }
+
+// ScoreCandidate replaces the worker loop of training/trainvocab.go:925-1176 for one candidate vocabulary: tokens are the
+// candidate's byte strings (single bytes included, as the worker's testVocab has them).  Tables are built with the rules
+// of trainvocab.go:548-907 (tm_build_vocab), uploaded, and the strips are walked; stripOff == nil walks the whole dataset
+// as one strip (:909-922).  scores[id] is scores[index].V of :1109-1162.
+func ScoreCandidate(d *HipDataset, tokens [][]byte, capcode, charset uint8, stripOff, stripLen []uint64) (scores []uint32, tokensInText uint64, missing [32]byte, err error) {
+	blob, off64 := pack(tokens)
+	off := make([]uint32, len(off64))
+	for i, o := range off64 {
+		off[i] = uint32(o)
+	}
+	var img *C.uint8_t
+	var imgLen C.size_t
+	if C.tm_build_vocab((*C.uint8_t)(unsafe.Pointer(&blob[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(tokens)), nil,
+		C.uint32_t(capcode), C.uint32_t(charset), 0, 5, 0, &img, &imgLen) != C.TM_OK {
+		return nil, 0, missing, hipErr()
+	}
+	defer C.tm_free(unsafe.Pointer(img))
+	var cand *C.tm_vocab
+	if C.tm_vocab_load(img, imgLen, &cand) != C.TM_OK {
+		return nil, 0, missing, hipErr()
+	}
+	defer C.tm_vocab_free(cand)
+	scores = make([]uint32, int(C.tm_vocab_n_ids(cand))+1)
+	var so, sl *C.uint64_t
+	if len(stripOff) > 0 {
+		so = (*C.uint64_t)(unsafe.Pointer(&stripOff[0]))
+		sl = (*C.uint64_t)(unsafe.Pointer(&stripLen[0]))
+	}
+	var tit C.uint64_t
+	if C.tm_score(cand, d.h, so, sl, C.uint32_t(len(stripOff)), (*C.uint32_t)(unsafe.Pointer(&scores[0])), &tit,
+		(*C.uint8_t)(unsafe.Pointer(&missing[0]))) != C.TM_OK {
+		return nil, 0, missing, hipErr()
+	}
+	return scores[:len(scores)-1], uint64(tit), missing, nil
+}

@@ -75,6 +75,11 @@ int tm_tokenize_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* of
 int tm_count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs,
                    uint64_t* counts, uint32_t* missing);
 
+/* Vocab.Count on RAW text (go :971: normalize, then tokenizeCount): what tokenmonsterserver job 20 calls per document
+ * (training/tokenmonsterserver.go:753-800).  The normalization runs on the device. */
+int tm_count_batch_raw(const tm_vocab* v, const uint8_t* raw, const uint64_t* offsets, uint32_t ndocs,
+                       uint64_t* counts, uint32_t* missing);
+
 /* TokenizeToSerialized (go/tokenmonster.go:986): encoding_length 2, 3 or 4 bytes little-endian per
  * ID (0 = auto: 2 if n_ids <= 65536 else 3, go :990-996).  bytes_out/byte_offsets as above. */
 int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs,

@@ -40,6 +40,7 @@ SIGNATURES = {
     "tm_vocab_device_bytes": (C.c_uint64, [vp]),
     "tm_tokenize_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp]),
     "tm_count_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp]),
+    "tm_count_batch_raw": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp]),
     "tm_tokenize_batch_serialized": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, u32p]),
     "tm_tokenize_pipeline": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_uint64, vp, vp, u32p, vp]),
     "tm_host_alloc": (vp, [C.c_size_t]),

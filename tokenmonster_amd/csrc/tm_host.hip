@@ -226,12 +226,12 @@ int tm_tokenize_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* of
   return rc;
 }
 
-int tm_count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint64_t* counts, uint32_t* missing) {
+static int count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, bool raw, uint64_t* counts, uint32_t* missing) {
   if (!v || (ndocs && !offsets)) return set_error(TM_E_INVALID, "null argument");
   Lane* l = nullptr;
   int rc = lane_acquire(v, &l);
   if (rc != TM_OK) return rc;
-  rc = lane_run(l, v, text, offsets, ndocs, false, false, nullptr);
+  rc = lane_run(l, v, text, offsets, ndocs, raw, false, nullptr);
   if (rc == TM_OK && ndocs) {
     tm_batch* b = l->ws;
     std::vector<uint32_t> ev(ndocs);
@@ -245,6 +245,13 @@ int tm_count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offse
   }
   lane_release(v, l);
   return rc;
+}
+
+int tm_count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint64_t* counts, uint32_t* missing) {
+  return count_batch(v, text, offsets, ndocs, false, counts, missing);
+}
+int tm_count_batch_raw(const tm_vocab* v, const uint8_t* raw, const uint64_t* offsets, uint32_t ndocs, uint64_t* counts, uint32_t* missing) {
+  return count_batch(v, raw, offsets, ndocs, true, counts, missing);
 }
 
 int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t encoding_length,
