@@ -39,6 +39,7 @@ extern "C" {
 typedef struct tm_vocab tm_vocab;     /* immutable device-resident vocabulary tables */
 typedef struct tm_batch tm_batch;     /* reusable device workspace for one batch of documents */
 typedef struct tm_dataset tm_dataset; /* device-resident normalized dataset for the scoring pass */
+typedef struct tm_decoder tm_decoder; /* streaming Decoder: per-connection host state */
 
 const char* tm_last_error(void);
 int tm_device_count(void);
@@ -162,6 +163,22 @@ uint64_t tm_batch_device_bytes(const tm_batch* b);
  * out_offsets[ndocs+1] is always filled; TM_E_NOSPACE if out_cap is too small (required size in out_offsets[ndocs]). */
 int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* tok_offsets, uint32_t ndocs, int raw,
                     uint8_t* out, uint64_t out_cap, uint64_t* out_offsets);
+
+/* Streaming Decoder (go/tokenmonster.go:552-700 NewDecoder / Decode / DecodeSerialized / Flush; server jobs 5-9): ids arrive a few
+ * at a time, a call returns the text that is COMPLETE so far; the bytes of a character that is not (a token may end in the middle of a
+ * UTF-8 sequence) and the state of the capcode decoder are carried to the next call.  Per-connection host state: the gather of a
+ * handful of ids runs on the host copy of the reverse table.  out_len receives the number of bytes decoded; on TM_E_NOSPACE
+ * (out_cap too small) the ids HAVE been consumed and the text is kept: call again with n = 0 and a buffer of *out_len bytes.
+ * tm_decoder_flush returns (and forgets) the held-back bytes.
+ * Quirk kept from the reference: the number of bytes held back is incompleteUTF8Bytes' return value, which for a character that
+ * is cut is the number of bytes still MISSING (go/tokenmonster.go:183-185), not the number present; where that exceeds the
+ * buffer (Go panics there) the whole buffer is held back. */
+int tm_decoder_new(const tm_vocab* v, tm_decoder** out);
+void tm_decoder_free(tm_decoder* d);
+int tm_decoder_decode(tm_decoder* d, const uint32_t* tokens, uint64_t n, uint8_t* out, uint64_t out_cap, uint64_t* out_len);
+int tm_decoder_decode_serialized(tm_decoder* d, const uint8_t* data, uint64_t nbytes, uint32_t encoding_length, uint8_t* out,
+                                 uint64_t out_cap, uint64_t* out_len);
+int tm_decoder_flush(tm_decoder* d, uint8_t* out, uint64_t out_cap, uint64_t* out_len);
 
 /* ---- trainvocab scoring pass: replaces training/trainvocab.go:925-1176 ------------------------ */
 /* Upload the normalized dataset once (trainvocab.go:1660-1665 keeps it for the whole run). */

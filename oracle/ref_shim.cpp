@@ -135,6 +135,36 @@ long long tmref_decode_raw(void* v, const std::uint32_t* toks, std::size_t n, st
   }
 }
 
+// the reference's streaming Decoder (tokenmonster.cpp:1509-1721)
+void* tmref_decoder_new(void* v) {
+  try { return new tokenmonster::Decoder(static_cast<Vocab*>(v)->new_decoder()); } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void tmref_decoder_free(void* d) { delete static_cast<tokenmonster::Decoder*>(d); }
+long long tmref_decoder_decode(void* d, const std::uint32_t* toks, std::size_t n, std::uint8_t* out, std::size_t cap) {
+  try {
+    auto r = static_cast<tokenmonster::Decoder*>(d)->decode(std::span<const std::uint32_t>(toks, n));
+    if (r.size() > cap) return -(long long)r.size();
+    if (!r.empty()) std::memcpy(out, r.data(), r.size());
+    return (long long)r.size();
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+long long tmref_decoder_decode_serialized(void* d, const std::uint8_t* data, std::size_t n, int enc, std::uint8_t* out, std::size_t cap) {
+  try {
+    auto r = static_cast<tokenmonster::Decoder*>(d)->decode_serialized(sp(data, n), (std::uint8_t)enc);
+    if (r.size() > cap) return -(long long)r.size();
+    if (!r.empty()) std::memcpy(out, r.data(), r.size());
+    return (long long)r.size();
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+long long tmref_decoder_flush(void* d, std::uint8_t* out, std::size_t cap) {
+  try {
+    auto r = static_cast<tokenmonster::Decoder*>(d)->flush();
+    if (r.size() > cap) return -(long long)r.size();
+    if (!r.empty()) std::memcpy(out, r.data(), r.size());
+    return (long long)r.size();
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
 // All-core baseline for bench.py (the reference server's model: documents are independent, one goroutine each,
 // training/tokenmonsterserver.go:363-378): `threads` std::threads pull documents from a shared counter and call
 // Vocab::tokenize (raw != 0: normalize + capcode + walk) or Vocab::tokenize_normalized.  Returns the number of tokens.

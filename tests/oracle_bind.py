@@ -222,6 +222,48 @@ class Reference:
         return out[:n].tobytes()
 
 
+class ReferenceDecoder:
+    """the reference's streaming Decoder (tokenmonster.cpp:1509-1721) on a Reference vocabulary"""
+
+    def __init__(self, ref):
+        self.ref, L = ref, ref.L
+        L.tmref_decoder_new.restype = C.c_void_p
+        L.tmref_decoder_new.argtypes = [C.c_void_p]
+        L.tmref_decoder_free.argtypes = [C.c_void_p]
+        L.tmref_decoder_decode.restype = C.c_longlong
+        L.tmref_decoder_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.tmref_decoder_decode_serialized.restype = C.c_longlong
+        L.tmref_decoder_decode_serialized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+        L.tmref_decoder_flush.restype = C.c_longlong
+        L.tmref_decoder_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.h = L.tmref_decoder_new(ref.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.ref.L.tmref_decoder_free(self.h)
+            self.h = None
+
+    def decode(self, toks):
+        t = np.ascontiguousarray(toks, dtype=np.uint32)
+        out = np.empty(40 * t.size + 64, dtype=np.uint8)
+        n = self.ref.L.tmref_decoder_decode(self.h, t.ctypes.data, t.size, out.ctypes.data, out.size)
+        assert n >= 0
+        return out[:n].tobytes()
+
+    def decode_serialized(self, data, enc):
+        d = _u8(data)
+        out = np.empty(40 * d.size + 64, dtype=np.uint8)
+        n = self.ref.L.tmref_decoder_decode_serialized(self.h, d.ctypes.data, d.size, enc, out.ctypes.data, out.size)
+        assert n >= 0
+        return out[:n].tobytes()
+
+    def flush(self):
+        out = np.empty(64, dtype=np.uint8)
+        n = self.ref.L.tmref_decoder_flush(self.h, out.ctypes.data, out.size)
+        assert n >= 0
+        return out[:n].tobytes()
+
+
 STAT_NAMES = ["s1", "s2", "s3", "s1b", "s2b", "s3b", "fast_exit", "no_lookahead_match", "not_found"]
 
 

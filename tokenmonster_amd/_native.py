@@ -65,6 +65,11 @@ SIGNATURES = {
     "tm_batch_device_tok_offsets": (vp, [vp]),
     "tm_batch_device_bytes": (C.c_uint64, [vp]),
     "tm_decode_batch": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint64, vp]),
+    "tm_decoder_new": (C.c_int, [vp, C.POINTER(vp)]),
+    "tm_decoder_free": (None, [vp]),
+    "tm_decoder_decode": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]),
+    "tm_decoder_decode_serialized": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_uint64, u64p]),
+    "tm_decoder_flush": (C.c_int, [vp, vp, C.c_uint64, u64p]),
     "tm_dataset_upload": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "tm_dataset_free": (None, [vp]),
     "tm_score": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, u64p, vp]),

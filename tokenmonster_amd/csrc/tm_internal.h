@@ -24,6 +24,11 @@ void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t n
 int normalize_batch_into(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t norm_flag,
                          uint32_t threads, uint64_t* out_offsets, const std::function<uint8_t*(uint64_t)>& alloc);
 
+// state of a capcode decoder between two calls (javascript/tokenmonster.js:1008-1013)
+struct CapcodeState { bool in_word = false, in_char = false, del = false, ignore = false; };
+void capcode_decode_stream(CapcodeState& st, const uint8_t* in, size_t n, std::vector<uint8_t>& out);     // appends
+void nocapcode_decode_stream(CapcodeState& st, const uint8_t* in, size_t n, std::vector<uint8_t>& out);   // appends
+
 void capcode_decode_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t threads,
                           std::vector<std::vector<uint8_t>>& outs);
 

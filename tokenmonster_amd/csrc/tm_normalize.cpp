@@ -307,11 +307,11 @@ void lower_bytes(std::vector<uint8_t>& b) {  // tokenmonster.cpp:214-229
 
 }  // namespace
 
-// capcode level 2 decoder, javascript/tokenmonster.js:1007-1065 (one-shot form of capcode.Decoder, go/tokenmonster.go:451)
-void capcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
-  out.clear();
-  out.reserve(n);
-  bool in_word = false, in_char = false, del = false, ignore = false;
+// capcode level 2 decoder, javascript/tokenmonster.js:1007-1065: the four flags of CapcodeDecoder live in `st` (tm_internal.h), so
+// that a streaming Decoder (go/tokenmonster.go:552-700) carries them from call to call; appends to `out`
+void capcode_decode_stream(CapcodeState& st, const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+  out.reserve(out.size() + n);
+  bool in_word = st.in_word, in_char = st.in_char, del = st.del, ignore = st.ignore;
   size_t i = 0;
   while (i < n) {
     const Cp c = next_cp(in + i, n - i);
@@ -336,18 +336,29 @@ void capcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
     }
     ignore = false;
   }
+  st.in_word = in_word; st.in_char = in_char; st.del = del; st.ignore = ignore;
+}
+void capcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+  out.clear();
+  CapcodeState st;
+  capcode_decode_stream(st, in, n, out);
 }
 
 // level 1 (marker 0x7F): no in-tree statement; delete the marker and the character after it
-void nocapcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
-  out.clear();
-  out.reserve(n);
-  bool del = false;
+void nocapcode_decode_stream(CapcodeState& st, const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+  out.reserve(out.size() + n);
+  bool del = st.del;
   for (size_t i = 0; i < n; i++) {
     if (in[i] == 0x7F) { del = true; continue; }
     if (del) { del = false; continue; }
     out.push_back(in[i]);
   }
+  st.del = del;
+}
+void nocapcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+  out.clear();
+  CapcodeState st;
+  nocapcode_decode_stream(st, in, n, out);
 }
 
 bool normalize_supported(uint32_t capcode, uint32_t norm_flag) {

@@ -172,6 +172,9 @@ class Vocab:
         out, _ = self.decode_packed(ids, np.array([0, ids.size], dtype=np.uint64))
         return out.tobytes()
 
+    def decoder(self):
+        return Decoder(self)
+
     def count_packed(self, text, offsets):
         """Count (go :971 / :1281): b-branches count once (quirk Q2) -> (counts u64[D], missing u32[D])"""
         text = N.as_u8(text)
@@ -233,6 +236,45 @@ class Vocab:
             N.check(rc)
             st = {k: getattr(stats, k) for k, _ in PipelineStats._fields_}
             return out[: int(boff[nd])], boff, missing[:nd], enc.value, st
+
+
+class Decoder:
+    """streaming decoder (go/tokenmonster.go:552-700 NewDecoder; python/tokenmonster.py Decoder): feed ids a few at a time, get the
+    text that is complete so far; partial UTF-8 sequences and the capcode state carry over to the next call"""
+
+    def __init__(self, vocab):
+        self._vocab = vocab
+        self._h = C.c_void_p()
+        N.check(N.lib.tm_decoder_new(vocab.handle, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib.tm_decoder_free(self._h)
+            self._h = None
+
+    def _call(self, fn, *args):
+        n = C.c_uint64()
+        out = np.empty(4096, dtype=np.uint8)
+        rc = fn(self._h, *args, N.ptr(out), out.size, C.byref(n))
+        if rc == N.TM_E_NOSPACE:         # the ids were consumed; fetch the text with a buffer of the reported size
+            out = np.empty(int(n.value), dtype=np.uint8)
+            rc = N.lib.tm_decoder_decode(self._h, None, 0, N.ptr(out), out.size, C.byref(n))
+        N.check(rc)
+        return out[: int(n.value)].tobytes()
+
+    def decode(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        return self._call(N.lib.tm_decoder_decode, N.ptr(ids), ids.size)
+
+    def decode_serialized(self, data, encoding_length=0):
+        d = N.as_u8(data)
+        return self._call(N.lib.tm_decoder_decode_serialized, N.ptr(d), d.size, encoding_length)
+
+    def flush(self):
+        n = C.c_uint64()
+        out = np.empty(64, dtype=np.uint8)
+        N.check(N.lib.tm_decoder_flush(self._h, N.ptr(out), out.size, C.byref(n)))
+        return out[: int(n.value)].tobytes()
 
 
 class PipelineStats(C.Structure):
