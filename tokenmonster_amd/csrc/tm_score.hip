@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "tm_pipeline.h"
@@ -32,6 +33,10 @@ struct tm_dataset {
   uint8_t* d_exits = nullptr;      // per strip: exit state for each of the ENT entry states
   uint32_t strip_cap = 0;
   bool prepared = false;
+  // one scoring pass at a time per dataset (it owns ONE workspace); host threads that build and load the next candidates
+  // (tm_build_vocab, tm_vocab_load) run beside the pass of the current one
+  std::mutex mu;
+  hipStream_t stream = nullptr;    // tm_score's own stream
 };
 
 // One scoring pass in two halves.  score_prepare: the strips become the documents of the workspace, K0 + K1 run (and the group maps
@@ -67,7 +72,8 @@ static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
       if (iv[k].first < iv[k - 1].second) return set_error(TM_E_INVALID, "strips overlap at dataset byte %llu", (unsigned long long)iv[k].first);
   }
   hipError_t e;
-  if (d->ws && (d->ws->vocab != v || d->ws_docs < n_strips)) { tm_batch_free(d->ws); d->ws = nullptr; }
+  // (the workspace does not depend on the vocabulary: a new candidate reuses it as it is)
+  if (d->ws && d->ws_docs < n_strips) { tm_batch_free(d->ws); d->ws = nullptr; }
   if (!d->ws) {
     int rc = make_workspace(v, d->n, n_strips, false, false, &d->ws);
     if (rc != TM_OK) return rc;
@@ -157,11 +163,14 @@ void tm_dataset_free(tm_dataset* d) {
   tm_batch_free(d->ws);
   (void)hipFree(d->d_text); (void)hipFree(d->d_hist); (void)hipFree(d->d_tokens); (void)hipFree(d->d_missing_bits);
   (void)hipFree(d->d_vis); (void)hipFree(d->d_entry); (void)hipFree(d->d_exits);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
 }
 
 int tm_score_device(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
                     void* stream, uint32_t** dev_hist, uint64_t* n_words) {
+  if (!d) return set_error(TM_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> g(d->mu);
   int rc = score_run(v, d, strip_off, strip_len, n_strips, (hipStream_t)stream);
   if (rc != TM_OK) return rc;
   if (dev_hist) *dev_hist = d->d_hist;
@@ -171,7 +180,8 @@ int tm_score_device(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off,
 
 int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
                          void* stream, uint32_t* dst_device, uint64_t dst_words) {
-  if (!dst_device) return set_error(TM_E_INVALID, "null argument");
+  if (!dst_device || !d) return set_error(TM_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> g(d->mu);
   int rc = score_run(v, d, strip_off, strip_len, n_strips, (hipStream_t)stream);
   if (rc != TM_OK) return rc;
   if (dst_words < d->hist_words) return set_error(TM_E_NOSPACE, "destination holds %llu words, histogram has %llu", (unsigned long long)dst_words, (unsigned long long)d->hist_words);
@@ -230,7 +240,13 @@ int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* 
 
 int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
              uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]) {
-  int rc = score_run(v, d, strip_off, strip_len, n_strips, nullptr);
+  if (!d) return set_error(TM_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> g(d->mu);
+  hipStream_t st = nullptr;
+  if (!d->stream && hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) d->stream = nullptr;
+  st = d->stream;          // (not the NULL stream: the table uploads of other threads' tm_vocab_load must not order behind this pass)
+  int rc = score_run(v, d, strip_off, strip_len, n_strips, st);
+  if (rc == TM_OK) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize"); }
   return rc == TM_OK ? tm_score_read(v, d, scores, tokens_in_text, missing_set) : rc;
 }
 
