@@ -34,8 +34,9 @@ int tm_normalize(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_
                  size_t* out_n);
 /* Batch form: normalizes each document independently on `threads` host threads and re-packs into a
  * malloc'd buffer (*out_text, free with tm_free); out_offsets has ndocs+1 entries (caller-allocated).
- * Supported in this round: norm_flag in {0, 1 (NFD), 2|1 (lowercase)}, capcode in {0, 2}; anything
- * else fails with TM_E_INVALID rather than producing approximately-right bytes. */
+ * Every normalizer flag bit is implemented (tokenmonster-cpp/src/tokenmonster.cpp:428-475: 1 NFD, 2 lowercase, 4 accents,
+ * 8 quotemarks, 16 collapse, 32 trim, 64 leadingspace, 128 unixlines); capcode in {0, 2} — level 1 has no statement in the
+ * reference tree and fails with TM_E_INVALID rather than producing approximately-right bytes. */
 int tm_normalize_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode,
                        uint32_t norm_flag, uint32_t threads, uint8_t** out_text, uint64_t* out_offsets);
 

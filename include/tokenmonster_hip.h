@@ -124,9 +124,12 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
  * Tokenize (go/tokenmonster.go:242-253: norm.Normalize + capcode.Encode) ON THE DEVICE into the batch's text buffer
  * (max_bytes of tm_batch_create must cover the normalized size, about 1.1x raw with capcode 2).  Documents that
  * contain non-ASCII characters other than NFD-stable general punctuation (U+2010..U+205E) are normalized by the
- * host normalizer instead (they need ICU); tm_batch_host_fallback_docs reports how many.  Supported: capcode 0 and 2,
- * normalization flags 0..3 (NFD, lowercase).  tm_batch_normalize synchronizes `stream`; afterwards tm_batch_run
- * tokenizes the normalized documents. */
+ * host normalizer instead (they need ICU); tm_batch_host_fallback_docs reports how many.  Supported: capcode 0 and 2 (level 1
+ * has no statement in the reference tree and is refused), every normalization flag (training/README.md:110-123); the device
+ * pass itself implements NFD and lowercase (what the reference's pretrained vocabularies use), a vocabulary with any of the
+ * lossy flags accents / quotemarks / collapse / trim / leadingspace / unixlines sends ALL its documents through the (multi-threaded)
+ * host normalizer inside this call.  tm_batch_normalize synchronizes `stream`; afterwards tm_batch_run tokenizes the normalized
+ * documents. */
 int tm_batch_upload_raw(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs);
 int tm_batch_normalize(tm_batch* b, void* stream);
 uint64_t tm_batch_normalized_bytes(const tm_batch* b);

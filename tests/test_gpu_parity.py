@@ -357,6 +357,27 @@ def test_device_normalizer_matches_host_and_reference():
     assert (goff == eoff).all() and (got == exp).all()
 
 
+def test_lossy_normalizer_flags_take_the_host_path_inside_the_device_call():
+    """a vocabulary with accents / quotemarks / collapse / trim / leadingspace / unixlines (training/README.md:110-123): the device
+    normalizer implements NFD and lowercase only, so tm_batch_normalize sends every document through the host normalizer (same
+    call, same outputs) and the raw-text entry points keep working"""
+    for flag in (1 | 8 | 16 | 32 | 128, 2 | 4 | 64):
+        img = synth.synth_vocab(synth.ENGLISHCODE, 1500, capcode=2, norm_flag=1, level=3, seed=3)
+        img = bytes(img[:2]) + bytes([flag]) + bytes(img[3:])
+        v, orc = tm.Vocab(img), Oracle(img)
+        docs = [b"  Hello   World \r\n", "\u201cQuoted\u201d  caf\u00e9  \u2018x\u2019 ".encode(), b"", b"a", b" \t ", b"No leading blank  here"]
+        raw, roffs = synth.synth_corpus(synth.ENGLISHCODE, 100_000, seed=5)
+        docs += [raw[int(roffs[d]):int(roffs[d + 1])].tobytes() for d in range(roffs.size - 1)]
+        text, offs = tm.pack_documents(docs)
+        got, goff, nfb = v.normalize_packed_device(text, offs)
+        assert nfb == len(docs)
+        for d, doc in enumerate(docs):
+            assert got[int(goff[d]):int(goff[d + 1])].tobytes() == synth.normalize(doc, 2, flag)
+        ids = v.tokenize(docs)
+        for d, doc in enumerate(docs):
+            assert ids[d].tolist() == orc.tokenize(synth.normalize(doc, 2, flag))[0].tolist()
+
+
 def _utf16(bs):
     return b"".join(bytes([c, 0]) for c in bs)
 

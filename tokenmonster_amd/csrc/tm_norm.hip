@@ -160,12 +160,12 @@ __global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict_
 // carry byte of a piece: ub[0..1] | ua[2..3] | tL[4]
 __global__ void k_norm_carry(const uint32_t* __restrict__ piece_sum, const uint64_t* __restrict__ doc_piece_start, uint32_t ndocs,
                              uint8_t* __restrict__ piece_carry, uint8_t* __restrict__ need_host, unsigned long long* __restrict__ ninfo,
-                             uint32_t* __restrict__ fb_ids) {
+                             uint32_t* __restrict__ fb_ids, uint32_t all_host) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ndocs) return;
   const uint64_t ps = doc_piece_start[d], pe = doc_piece_start[d + 1];
   uint32_t ub = 0;
-  bool bad = false;
+  bool bad = all_host != 0;        // normalizer flags the device pass does not implement: every document takes the host path
   for (uint64_t k = ps; k < pe; k++) {
     const uint32_t s = piece_sum[k];
     piece_carry[k] = (uint8_t)ub;
@@ -612,7 +612,8 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
     k_norm_summary<<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_sum);
   }
-  k_norm_carry<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids);
+  k_norm_carry<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids,
+                                                  normalize_on_device(capcode, norm_flag) ? 0u : 1u);
   unsigned long long h_info[4] = {0, 0, 0, 0};
   if ((e = hipMemcpyAsync(h_info, ninfo, 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
     return hip_fail(e, "normalize (summaries)");

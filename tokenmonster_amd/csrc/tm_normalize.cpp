@@ -361,14 +361,94 @@ void nocapcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
   nocapcode_decode_stream(st, in, n, out);
 }
 
-bool normalize_supported(uint32_t capcode, uint32_t norm_flag) {
-  return (capcode == 0 || capcode == 2) && (norm_flag & ~3u) == 0;
+// capcode level 1 has no statement in the reference tree: refused rather than guessed
+bool normalize_supported(uint32_t capcode, uint32_t norm_flag) { return (capcode == 0 || capcode == 2) && norm_flag < 256; }
+// what the DEVICE normalizer (tm_norm.hip) does itself; documents of vocabularies with further flags take the host path below
+bool normalize_on_device(uint32_t capcode, uint32_t norm_flag) { return (capcode == 0 || capcode == 2) && (norm_flag & ~3u) == 0; }
+
+namespace {
+
+// The byte-level flags 8 quotemarks, 16 collapse, 128 unixlines (training/README.md:110-123), as ONE left-to-right pass with the
+// semantics of the reference's fused loops (tokenmonster.cpp:285-425): a space is dropped when the byte before it in the INPUT was a
+// space; with `fused_unix` a '\n' that follows '\r' overwrites it; a curly quote E2 80 {98,99 | 9C,9D} collapses to ' or ".
+void squeeze(std::vector<uint8_t>& b, bool quotes, bool collapse, bool fused_unix) {
+  // IN PLACE, like the reference, and that is part of the behaviour: the two bytes in front of a quote byte are read from the buffer
+  // that is being compacted, so after exactly one dropped byte the look-behind sees a byte that was already moved and the quote is
+  // left alone (tests/test_builder_normalizer.py fuzzes this against the reference runtime)
+  const size_t n = b.size();
+  size_t on = 0;
+  uint8_t last = 0;
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t c = b[i];
+    if (collapse && c == ' ') { if (last != ' ') b[on++] = ' '; last = ' '; continue; }
+    if (fused_unix && c == '\n' && last == '\r') { b[on - 1] = '\n'; last = '\n'; continue; }
+    last = c;
+    if (quotes && (c == 0x98 || c == 0x99 || c == 0x9C || c == 0x9D) && i > 1 && b[i - 1] == 0x80 && b[i - 2] == 0xE2) {
+      b[on - 2] = c < 0x9C ? '\'' : '"';
+      on--;
+      continue;
+    }
+    b[on++] = c;
+  }
+  b.resize(on);
+}
+// flag 128 on its own (tokenmonster.cpp:302-314): a '\r' directly before '\n' is dropped
+void unix_lines(std::vector<uint8_t>& b) {
+  const size_t n = b.size();
+  if (n < 2) return;
+  size_t on = 0;
+  for (size_t i = 0; i + 1 < n; i++) if (!(b[i] == '\r' && b[i + 1] == '\n')) b[on++] = b[i];
+  b[on++] = b[n - 1];
+  b.resize(on);
+}
+// flags 32 trim / 64 leadingspace (tokenmonster.cpp:245-283), including what trim+leadingspace does to a text WITHOUT leading
+// whitespace: its last non-blank byte goes as well (:274-277 cut at i2, not i2 + 1)
+void trim_and_lead(std::vector<uint8_t>& b, bool trim, bool lead) {
+  const ptrdiff_t n = (ptrdiff_t)b.size();
+  auto add_lead = [](std::vector<uint8_t>& x) { if (!x.empty() && x[0] != ' ') x.insert(x.begin(), ' '); };
+  if (!trim) { if (lead) add_lead(b); return; }
+  ptrdiff_t i = 0, i2 = n - 1;
+  while (i < n && b[(size_t)i] <= 32) i++;
+  while (i2 >= 0 && b[(size_t)i2] <= 32) i2--;
+  if (i2 < 0) { b.clear(); return; }
+  if (!lead) { b = std::vector<uint8_t>(b.begin() + i, b.begin() + i2 + 1); return; }
+  if (i == 0) { b.resize((size_t)i2); add_lead(b); return; }
+  b[(size_t)(i - 1)] = ' ';
+  b = std::vector<uint8_t>(b.begin() + (i - 1), b.begin() + i2 + 1);
+}
+// flag 4 accents (tokenmonster.cpp:231-243): NFD, then every non-spacing mark (Mn) goes
+void remove_marks(std::vector<uint8_t>& b) {
+  nfd_bytes(b);
+  bool any = false;
+  for (auto x : b) if (x & 0x80) { any = true; break; }
+  if (!any) return;
+  std::vector<uint8_t> out;
+  out.reserve(b.size());
+  for (size_t i = 0; i < b.size();) {
+    const Cp c = next_cp(b.data() + i, b.size() - i);
+    if (c.raw || u_charType((UChar32)c.r) != U_NON_SPACING_MARK) out.insert(out.end(), b.begin() + (ptrdiff_t)i, b.begin() + (ptrdiff_t)i + c.n);
+    i += (size_t)c.n;
+  }
+  b.swap(out);
 }
 
+}  // namespace
+
+// norm.Normalize + capcode.Encode (go/tokenmonster.go:242-253); flag order as tokenmonster.cpp:428-475
 void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out) {
   std::vector<uint8_t> tmp(data, data + n);
-  if (norm_flag & 2) { if (norm_flag & 1) nfd_bytes(tmp); lower_bytes(tmp); }   // tokenmonster.cpp:469-472
-  else if (norm_flag & 1) nfd_bytes(tmp);                                        // :473
+  if (norm_flag > 1) {
+    const bool q = norm_flag & 8, c = norm_flag & 16, u = norm_flag & 128;
+    if (u && c) squeeze(tmp, q, true, true);                       // :433-441
+    else {
+      if (u) unix_lines(tmp);                                      // :443
+      if (q || c) squeeze(tmp, q, c, false);                       // :445-453
+    }
+    if (norm_flag & (32 | 64)) trim_and_lead(tmp, norm_flag & 32, norm_flag & 64);   // :454-462
+  }
+  if (norm_flag & 4) { remove_marks(tmp); if (norm_flag & 2) lower_bytes(tmp); }     // :464-468
+  else if (norm_flag & 2) { if (norm_flag & 1) nfd_bytes(tmp); lower_bytes(tmp); }   // :469-472
+  else if (norm_flag & 1) nfd_bytes(tmp);                                            // :473
   if (capcode == 2) capcode_encode(tmp.data(), tmp.size(), out);
   else out.swap(tmp);
 }

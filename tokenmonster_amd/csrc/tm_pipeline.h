@@ -129,5 +129,6 @@ void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* ou
 int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs, hipStream_t st);
 // tm_normalize.cpp
 bool normalize_supported(uint32_t capcode, uint32_t norm_flag);
+bool normalize_on_device(uint32_t capcode, uint32_t norm_flag);
 
 }  // namespace tmh
