@@ -42,7 +42,7 @@ def main():
         d = os.path.join(args.out, "g%d" % gi)
         cmd = ["rocprofv3", "--pmc"] + grp + ["--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--mbytes", str(args.mbytes), "--steps", "2", "--warmup", "1",
-               "--verify", "0", "--no-cpu-baseline"] + ([] if args.e2e else ["--hot-path-only"]) + args.extra.split()
+               "--verify", "0", "--no-cpu-baseline", "--no-host-to-host"] + ([] if args.e2e else ["--hot-path-only"]) + args.extra.split()
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             print("group %d failed:\n%s" % (gi, r.stdout.decode(errors="replace")[-2000:]), file=sys.stderr)
