@@ -663,7 +663,9 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   if (nf > 0) {
     // pooled workers: up to 128, but only this process's share of the host when there is one process per GPU of the node
     static const uint32_t host_share = std::max(8u, std::max(1u, std::thread::hardware_concurrency()) / (uint32_t)std::max(1, tm_device_count()));
-    const uint32_t threads = (uint32_t)std::min<size_t>(std::min<uint32_t>(128u, host_share), ids.size() / 8 + 1);
+    // ... and only as many as the bytes are worth: the pool runs one job at a time, so a chunk of the host-to-host pipeline (a few
+    // dozen fallback documents) normalizes them on its own lane thread and leaves the pool to batches that need it
+    const uint32_t threads = (uint32_t)std::min<size_t>(std::min<size_t>(std::min<uint32_t>(128u, host_share), ids.size() / 8 + 1), (size_t)(roff.back() >> 18) + 1);
     hipError_t he = hipSuccess;
     int rc = normalize_batch_into(b->h_fb_raw, roff.data(), (uint32_t)ids.size(), capcode, norm_flag, threads, noff.data(), [&](uint64_t total) -> uint8_t* {
       if (!b->h_fb_norm || b->h_fb_norm_cap < total + 16) {                         // pinned: the H2D below then runs at link speed

@@ -67,7 +67,8 @@ void run_on_workers(uint32_t threads, const std::function<void()>& work) {
     while (p.nthreads < helpers) { std::thread([&p] { p.worker(); }).detach(); p.nthreads++; }
     p.job = &work; p.want = helpers; p.started = 0; p.running = 0; p.generation++;
   }
-  p.cv_work.notify_all();
+  if (helpers >= p.nthreads) p.cv_work.notify_all();
+  else for (uint32_t k = 0; k < helpers; k++) p.cv_work.notify_one();   // (a pool that once served 256 threads is not woken for a job of 4)
   work();                                       // the caller works too
   std::unique_lock<std::mutex> lk(p.mu);
   p.want = 0;                                   // late wakers find nothing to do
