@@ -23,7 +23,7 @@ struct HostVocab {
   std::vector<uint32_t> root;
   std::vector<uint2> tab;           // direct depth-2 map, edge hash, suffix links (tm_tables.h)
   std::vector<uint32_t> vals;       // node value per record ordinal
-  std::vector<uint2> spl;           // space-prefix links
+  std::vector<uint4> spl;           // space-prefix links
   std::vector<uint32_t> rev_off;    // n_ids + 1: reverse[id] = rev_bytes[rev_off[id] .. rev_off[id+1])  (last record wins, go :2715)
   std::vector<uint8_t> rev_bytes;
   uint32_t edge_mask = 0, edge_shift = 0, n_nodes = 0, off = 1, bstart = kNone, spl_hint = 0, link_off = 0, direct_off = 0;
@@ -49,7 +49,7 @@ struct tm_vocab {
   uint64_t device_bytes = 0;
   uint32_t* d_root = nullptr;
   uint2* d_tab = nullptr;
-  uint2* d_spl = nullptr;
+  uint4* d_spl = nullptr;
   uint32_t* d_vals = nullptr;
   uint32_t* d_rev_off = nullptr;
   uint8_t* d_rev_bytes = nullptr;

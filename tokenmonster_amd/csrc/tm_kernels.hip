@@ -467,14 +467,15 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       if (base + lane < n_el) {
         const int p = (int)w.xch[lane];
         const uint32_t ml = desc_len(w.D[p]);
-        const uint2 e = T.spl[node_id(w.X[p])];
+        const uint4 e = T.spl[node_id(w.X[p])];
         const int limit = min(dl - p, Lmax - off) + off;
         const int depth = (int)ml + off;
         const int bl = (int)((e.x >> 22) & 63u);
-        if (e.x != kNone && ((e.x >> 21) & 1u) && depth < limit) {
+        const uint32_t c0 = w.text[p + ml];
+        // the probe is only walked if the node of ' '+match can go on over the next text byte at all (its child filter): most cannot
+        if (e.x != kNone && ((e.x >> 21) & 1u) && depth < limit && child_possible32(e.z, c0)) {
           k.pos = p; k.tbase = p - off; k.bestlen = bl; k.bestv = e.y; k.depth = depth; k.limit = limit;
           mainlen = (int)ml;
-          const uint32_t c0 = w.text[p + ml];
           k.key = ((e.x & kNodeMask) << 8) | c0;
           k.hoff = edge_slot_offset(T, e.x & kNodeMask, c0);
         } else if (e.x != kNone && bl > (int)ml + 1) {               // (only possible with the two-byte UTF-16 prefix)
@@ -677,11 +678,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 __global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs,
                           const uint8_t* __restrict__ doc_entry, uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
                           uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ doc_events,
-                          uint32_t* __restrict__ doc_missing, uint32_t* __restrict__ error_flag) {
+                          uint32_t* __restrict__ doc_missing, uint32_t* __restrict__ error_flag, uint32_t long_segs) {
   uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ndocs) return;
   uint64_t g0 = doc_seg_start[d], g1 = doc_seg_start[d + 1];
-  if (g1 - g0 > LONG_SEGS) return;               // long documents: k_group_compose / k_long_top / k_group_expand
+  if (g1 - g0 > long_segs) return;               // long documents: k_group_compose / k_long_top / k_group_expand
   uint32_t e = doc_entry ? doc_entry[d] : 0u, ntok = 0, events = 0, nmiss = 0;
   for (uint64_t g = g0; g < g1; g++) {
     seg_entry[g] = (uint8_t)e;
@@ -699,29 +700,42 @@ __global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __r
   doc_missing[d] = nmiss;
 }
 
-// Long documents (more than LONG_SEGS segments: a multi-megabyte document, or a strip of the trainvocab dataset)
-// would make k_resolve a serial chain of millions of dependent loads.  Their segments are cut into ~sqrt(S)
-// groups (table built on the host at upload): k_group_compose composes the exit maps of a group for all 80 entry
-// states at once (one lane per entry state), k_long_top chains the ~sqrt(S) group maps per document, and
-// k_group_expand replays every group from its now known entry state.  Exit-map composition is associative, so the
-// result is the same as the serial chain.
+// Long documents (more than LONG_SEGS segments: a multi-megabyte document, or a strip of the trainvocab dataset) would make
+// k_resolve a serial chain of millions of dependent loads.  Their segments hang under a TREE of groups with fan-out GROUP_FAN
+// (table built on the host at upload): level-1 groups hold segments, level-k groups hold level-(k-1) groups, until a document has
+// at most GROUP_FAN groups at the top.  k_group_compose composes the maps of a group's children for all 80 entry states at once (one
+// lane per entry state), level by level; k_long_top chains a document's few top groups; k_group_expand replays every group from its
+// now known entry state, top level first.  Every serial chain is GROUP_FAN steps long: a 1 GiB strip (4.5 M segments, 4 levels)
+// resolves in well under a millisecond.  Exit-map composition is associative, so the result is the same as the serial chain.
+// group map entry (uint4): x = next entry state, y = #id events, z = #forward-deletes, w = #missing; x == R_INVALID: unreachable
 
-__global__ __launch_bounds__(128) void k_group_compose(const uint2* __restrict__ exitmap, const Group* __restrict__ groups,
-                                                       uint4* __restrict__ gmap) {
-  const Group gr = groups[blockIdx.x];
+template <bool LEAF>     // LEAF: the children are segments (exit maps, uint2); otherwise groups of the level below (group maps, uint4)
+__global__ __launch_bounds__(128) void k_group_compose(const uint2* __restrict__ exitmap, const uint4* __restrict__ gmap_in, const Group* __restrict__ groups,
+                                                       uint32_t first_group, uint4* __restrict__ gmap) {
+  const uint32_t gi = first_group + blockIdx.x;
+  const Group gr = groups[gi];
   const uint32_t e0 = threadIdx.x;
   if (e0 >= ENT) return;
   uint32_t e = e0, events = 0, nfd = 0, nmiss = 0;
   bool ok = true;
-  for (uint32_t k = 0; k < gr.nsegs; k++) {
-    const uint2 x = exitmap[(uint64_t)(gr.first_seg + k) * ENT + e];
-    if (x.x == R_INVALID) { ok = false; break; }
-    e = x.x & 0xFFu;
-    events += x.x >> 8;
-    nfd += x.y & 0xFFFFu;
-    nmiss += x.y >> 16;
+  for (uint32_t k = 0; k < gr.nchildren; k++) {
+    if (LEAF) {
+      const uint2 x = exitmap[(uint64_t)(gr.first_child + k) * ENT + e];
+      if (x.x == R_INVALID) { ok = false; break; }
+      e = x.x & 0xFFu;
+      events += x.x >> 8;
+      nfd += x.y & 0xFFFFu;
+      nmiss += x.y >> 16;
+    } else {
+      const uint4 x = gmap_in[(uint64_t)(gr.first_child + k) * ENT + e];
+      if (x.x == R_INVALID) { ok = false; break; }
+      e = x.x;
+      events += x.y;
+      nfd += x.z;
+      nmiss += x.w;
+    }
   }
-  gmap[(uint64_t)blockIdx.x * ENT + e0] = ok ? make_uint4(e, events, nfd, nmiss) : make_uint4(R_INVALID, 0u, 0u, 0u);
+  gmap[(uint64_t)gi * ENT + e0] = ok ? make_uint4(e, events, nfd, nmiss) : make_uint4(R_INVALID, 0u, 0u, 0u);
 }
 
 __global__ void k_long_top(const uint4* __restrict__ gmap, const LongDoc* __restrict__ longs, uint32_t nlong, const uint8_t* __restrict__ doc_entry,
@@ -748,22 +762,35 @@ __global__ void k_long_top(const uint4* __restrict__ gmap, const LongDoc* __rest
   doc_missing[ld.doc] = nmiss;
 }
 
-__global__ void k_group_expand(const uint2* __restrict__ exitmap, const Group* __restrict__ groups, uint32_t ngroups,
-                               const uint8_t* __restrict__ group_entry, const uint4* __restrict__ group_base,
-                               uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
-                               uint32_t* __restrict__ error_flag) {
-  const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gi >= ngroups) return;
+template <bool LEAF>     // one thread per group of the level: hands its entry state and token base down to its children
+__global__ void k_group_expand(const uint2* __restrict__ exitmap, const uint4* __restrict__ gmap, const Group* __restrict__ groups, uint32_t first_group,
+                               uint32_t ngroups, uint8_t* __restrict__ group_entry, uint4* __restrict__ group_base,
+                               uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase, uint32_t* __restrict__ error_flag) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ngroups) return;
+  const uint32_t gi = first_group + t;
   const Group gr = groups[gi];
-  uint32_t e = group_entry[gi], ntok = group_base[gi].x;
-  for (uint32_t k = 0; k < gr.nsegs; k++) {
-    const uint64_t g = (uint64_t)gr.first_seg + k;
-    seg_entry[g] = (uint8_t)e;
-    seg_tokbase[g] = ntok;
-    const uint2 x = exitmap[g * ENT + e];
-    if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
-    e = x.x & 0xFFu;
-    ntok += (x.x >> 8) + (x.y & 0xFFFFu);
+  const uint4 base = group_base[gi];
+  uint32_t e = group_entry[gi], ntok = base.x, events = base.y, nmiss = base.z;
+  for (uint32_t k = 0; k < gr.nchildren; k++) {
+    const uint64_t c = (uint64_t)gr.first_child + k;
+    if (LEAF) {
+      seg_entry[c] = (uint8_t)e;
+      seg_tokbase[c] = ntok;
+      const uint2 x = exitmap[c * ENT + e];
+      if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
+      e = x.x & 0xFFu;
+      ntok += (x.x >> 8) + (x.y & 0xFFFFu);
+    } else {
+      group_entry[c] = (uint8_t)e;
+      group_base[c] = make_uint4(ntok, events, nmiss, 0u);
+      const uint4 x = gmap[c * ENT + e];
+      if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
+      e = x.x;
+      events += x.y;
+      ntok += x.y + x.z;
+      nmiss += x.w;
+    }
   }
 }
 
@@ -771,13 +798,13 @@ __global__ void k_group_expand(const uint2* __restrict__ exitmap, const Group* _
 // scored as byte ranges of ONE whole-buffer walk.  Short documents chain their segments' exit maps, long ones their groups' maps
 // (k_group_compose has composed those for all 80 entry states already).  0xFF: the entry state cannot occur.
 __global__ __launch_bounds__(128) void k_doc_exits(const uint2* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, const uint4* __restrict__ gmap,
-                                                   const LongDoc* __restrict__ longs, uint32_t nlong, uint8_t* __restrict__ exits) {
+                                                   const LongDoc* __restrict__ longs, uint32_t nlong, uint8_t* __restrict__ exits, uint32_t long_segs) {
   const uint32_t d = blockIdx.x, e0 = threadIdx.x;
   if (e0 >= ENT) return;
   const uint64_t g0 = doc_seg_start[d], g1 = doc_seg_start[d + 1];
   uint32_t e = e0;
   bool ok = true;
-  if (g1 - g0 > LONG_SEGS) {
+  if (g1 - g0 > long_segs) {
     uint32_t li = 0;
     while (li < nlong && longs[li].doc != d) li++;
     if (li == nlong) ok = false;
@@ -1036,14 +1063,15 @@ namespace tmh {
 
 // Test hooks (tm_debug_flags): bits that force a rarely taken fallback path of the product so that the tests can cover it, with the
 // same results: 6 = dense T(p,1) array for every segment, 8 = per-lane normalizer kernel, 10 = K4 tile walk that stores every id
-// directly.  Nothing else is reachable in the default build.  With -DTM_DEVEL (tools/ only: results are WRONG) further bits switch
+// directly, 12 = group tree of long documents with fan-out 4 from 9 segments on (a deep tree on a small document).  Nothing else is
+// reachable in the default build.  With -DTM_DEVEL (tools/ only: results are WRONG) further bits switch
 // phases of K1 off for profiling — 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps — bit 9 adds 4 KB
 // of dummy LDS per K1 workgroup, and TM_DBG in the environment sets the initial value.
 #ifdef TM_DEVEL
 constexpr int kDebugMask = ~0;
 #define TM_K1_EXTRA_LDS ((debug_flags() & 512) ? 4096 : 0)
 #else
-constexpr int kDebugMask = 64 | 256 | 1024;
+constexpr int kDebugMask = 64 | 256 | 1024 | 4096;
 #define TM_K1_EXTRA_LDS 0
 #endif
 int g_debug_flags = -1;
@@ -1058,6 +1086,8 @@ int debug_flags() {
   }
   return g_debug_flags;
 }
+
+uint32_t long_segs() { return (debug_flags() & 4096) ? 8u : LONG_SEGS; }
 
 static const char* kKernelNames[TM_NUM_KERNELS] = {"segments", "match_branch", "resolve", "scan", "emit"};
 
@@ -1108,24 +1138,39 @@ void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* to
   k_scan_final<<<nblocks, SCAN_T, 0, st>>>(in, n, block_sums, out);
 }
 
-// host: segment groups of the long documents.  doc d has lens[d] bytes; segments are numbered in document order.
+// host: the group tree of the long documents.  doc d has lens[d] bytes; segments are numbered in document order.  groups[] holds
+// level 1 first (children = segments), then level 2 (children = level-1 groups), ...; b->level_first[k] is where level k+1 begins.
 int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs) {
-  std::vector<Group> groups;
+  std::vector<std::vector<Group>> levels;        // levels[k]: groups of level k+1, all long documents, in document order
   std::vector<LongDoc> longs;
+  struct Top { uint32_t level, first, count; };  // a long document's top groups: index range within its top level
+  std::vector<Top> tops;
   uint64_t seg = 0;
+  const uint64_t FAN = (debug_flags() & 4096) ? 4u : GROUP_FAN;      // (test hook bit 12: a deep tree on a small document)
+  const uint64_t LONG = long_segs();
   for (uint32_t d = 0; d < ndocs; d++) {
     const uint64_t S = (end[d] - begin[d] + SEG - 1) / SEG;
-    if (S > LONG_SEGS) {
-      uint64_t G = 64;
-      while (G * G < S) G++;                              // ~sqrt(S) segments per group -> ~sqrt(S) groups
-      LongDoc ld{d, (uint32_t)groups.size(), 0u, 0u};
-      for (uint64_t k = 0; k < S; k += G) groups.push_back(Group{(uint32_t)(seg + k), (uint32_t)std::min<uint64_t>(G, S - k), d, 0u});
-      ld.ngroups = (uint32_t)groups.size() - ld.first_group;
-      longs.push_back(ld);
+    if (S > LONG) {
+      uint64_t first = seg, count = S;             // children of the level being built: segments, then groups of the level below
+      for (uint32_t lvl = 0;; lvl++) {
+        if (levels.size() <= lvl) levels.emplace_back();
+        const uint32_t g0 = (uint32_t)levels[lvl].size();
+        for (uint64_t k = 0; k < count; k += FAN)
+          levels[lvl].push_back(Group{(uint32_t)(first + k), (uint32_t)std::min<uint64_t>(FAN, count - k), d, lvl});
+        const uint32_t ng = (uint32_t)levels[lvl].size() - g0;
+        if (ng <= FAN) { tops.push_back(Top{lvl, g0, ng}); longs.push_back(LongDoc{d, 0u, ng, 0u}); break; }
+        first = g0; count = ng;                    // (indices within the level: rebased below once the level offsets are known)
+      }
     }
     seg += S;
   }
   if (seg >= (1ull << 32)) return set_error(TM_E_LIMIT, "batch has more than 2^32 segments");
+  std::vector<Group> groups;
+  b->level_first.assign(1, 0u);
+  for (auto& lv : levels) { groups.insert(groups.end(), lv.begin(), lv.end()); b->level_first.push_back((uint32_t)groups.size()); }
+  for (size_t lvl = 1; lvl < levels.size(); lvl++)                       // children of a level >= 2 group are groups of the level below
+    for (uint32_t g = b->level_first[lvl]; g < b->level_first[lvl + 1]; g++) groups[g].first_child += b->level_first[lvl - 1];
+  for (size_t i = 0; i < longs.size(); i++) longs[i].first_group = b->level_first[tops[i].level] + tops[i].first;
   b->ngroups = (uint32_t)groups.size();
   b->nlong = (uint32_t)longs.size();
   if (b->ngroups == 0) return TM_OK;
@@ -1175,7 +1220,11 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
                                                                                           b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
                                                                                           debug_flags());
   mark(2);
-  if (b->ngroups > 0) k_group_compose<<<b->ngroups, 128, 0, st>>>(b->d_exitmap, b->d_groups, b->d_gmap);
+  for (size_t lvl = 0; lvl + 1 < b->level_first.size() && b->ngroups > 0; lvl++) {     // bottom up: a level reads the maps of the one below
+    const uint32_t g0 = b->level_first[lvl], ng = b->level_first[lvl + 1] - g0;
+    if (lvl == 0) k_group_compose<true><<<ng, 128, 0, st>>>(b->d_exitmap, b->d_gmap, b->d_groups, g0, b->d_gmap);
+    else k_group_compose<false><<<ng, 128, 0, st>>>(b->d_exitmap, b->d_gmap, b->d_groups, g0, b->d_gmap);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
 }
@@ -1185,12 +1234,17 @@ int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, bool emit) {
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   if (nd > 0)
     k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_doc_entry, b->d_seg_entry, b->d_seg_tokbase,
-                                                b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_error);
+                                                b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_error, long_segs());
   if (b->ngroups > 0) {
     k_long_top<<<(b->nlong + 63) / 64, 64, 0, st>>>(b->d_gmap, b->d_longs, b->nlong, b->d_doc_entry, b->d_group_entry, b->d_group_base, b->d_doc_ntok,
                                                     b->d_doc_events, b->d_doc_missing, b->d_error);
-    k_group_expand<<<(b->ngroups + 63) / 64, 64, 0, st>>>(b->d_exitmap, b->d_groups, b->ngroups, b->d_group_entry, b->d_group_base,
-                                                          b->d_seg_entry, b->d_seg_tokbase, b->d_error);
+    for (size_t lvl = b->level_first.size() - 1; lvl-- > 0;) {                           // top down
+      const uint32_t g0 = b->level_first[lvl], ng = b->level_first[lvl + 1] - g0;
+      if (lvl == 0) k_group_expand<true><<<(ng + 63) / 64, 64, 0, st>>>(b->d_exitmap, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
+                                                                         b->d_seg_entry, b->d_seg_tokbase, b->d_error);
+      else k_group_expand<false><<<(ng + 63) / 64, 64, 0, st>>>(b->d_exitmap, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
+                                                                 b->d_seg_entry, b->d_seg_tokbase, b->d_error);
+    }
   }
   mark(3);
   if (nd > 0) scan_u32(b->d_doc_ntok, nd, b->d_scan_tmp, b->d_totals + 1, b->d_tok_offsets, st);
@@ -1204,7 +1258,7 @@ int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, bool emit) {
 
 // exit state of every document for every entry state -> exits[ndocs * ENT] (device); needs pipeline_match
 void launch_doc_exits(tm_batch* b, uint8_t* d_exits, hipStream_t st) {
-  if (b->ndocs) k_doc_exits<<<b->ndocs, 128, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, b->d_gmap, b->d_longs, b->nlong, d_exits);
+  if (b->ndocs) k_doc_exits<<<b->ndocs, 128, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, b->d_gmap, b->d_longs, b->nlong, d_exits, long_segs());
 }
 
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) {

@@ -482,10 +482,11 @@ __global__ void k_norm_ranges(const uint64_t* __restrict__ piece_off, const uint
   nbegin[d] = piece_off[doc_piece_start[d]];
   nend[d] = piece_off[doc_piece_start[d + 1]];
 }
-__global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t* __restrict__ nend, uint32_t ndocs, unsigned long long* __restrict__ ninfo) {
+__global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t* __restrict__ nend, uint32_t ndocs, unsigned long long* __restrict__ ninfo,
+                            uint32_t long_segs) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t nseg = 0;
-  if (d < ndocs) { nseg = (nend[d] - nbegin[d] + SEG - 1) / SEG; if (nseg > LONG_SEGS) atomicAdd(&ninfo[1], 1ull); }
+  if (d < ndocs) { nseg = (nend[d] - nbegin[d] + SEG - 1) / SEG; if (nseg > long_segs) atomicAdd(&ninfo[1], 1ull); }
   for (int o = 32; o > 0; o >>= 1) nseg += __shfl_xor(nseg, o);
   if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&ninfo[2], (unsigned long long)nseg);
 }
@@ -711,7 +712,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   }
   const double t2 = now();
   // ---- what the tokenize pipeline needs to know on the host: #segments, and the long documents if any ------------
-  k_norm_info<<<(nd + 255) / 256, 256, 0, st>>>(b->d_nbegin, b->d_nend, nd, ninfo);
+  k_norm_info<<<(nd + 255) / 256, 256, 0, st>>>(b->d_nbegin, b->d_nend, nd, ninfo, long_segs());
   if ((e = hipMemcpyAsync(h_info, ninfo, 24, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
     return hip_fail(e, "normalize (ranges)");
   b->nbytes = total;

@@ -28,7 +28,8 @@ constexpr uint32_t LONG_SEGS = 512;        // documents with more segments than 
 constexpr int SCAN_T = 256, SCAN_PER = 16, SCAN_CH = SCAN_T * SCAN_PER;   // exclusive scan u32 -> u64: elements per workgroup
 
 // segment groups of long documents (hierarchical resolve, tm_kernels.hip)
-struct Group { uint32_t first_seg, nsegs, doc, pad; };
+constexpr uint32_t GROUP_FAN = 64;         // children per group of the tree over a long document's segments
+struct Group { uint32_t first_child, nchildren, doc, level; };   // children: segments (level 0 = leaf groups) or groups of the level below
 struct LongDoc { uint32_t doc, first_group, ngroups, pad; };
 
 }  // namespace tmh
@@ -70,6 +71,7 @@ struct tm_batch {
   uint32_t* d_error = nullptr;
   // long documents (hierarchical resolve)
   uint32_t ngroups = 0, nlong = 0, cap_groups = 0, cap_long = 0;
+  std::vector<uint32_t> level_first;   // groups of level k+1 are d_groups[level_first[k] .. level_first[k+1])
   tmh::Group* d_groups = nullptr;
   tmh::LongDoc* d_longs = nullptr;
   uint4* d_gmap = nullptr;
@@ -114,6 +116,7 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st);
 void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32_t ndocs, uint32_t unit, uint32_t* doc_nunits, hipStream_t st);
 void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st);
+uint32_t long_segs();    // documents with more segments than this hang under the group tree (LONG_SEGS; 8 under test hook bit 12)
 int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs);
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit);
 int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev);

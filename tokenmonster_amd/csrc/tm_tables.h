@@ -89,9 +89,10 @@ struct Tables {
                            //                               children: probe on) | depth(m) << 23
                            //                           y = value of the deepest accepting node on the path to m (0: none)
                            //                           z = child filter of m (0 unless go), w = depth of that accepting node
-  const uint2* spl;        // [n_info] "space-prefix link" of record s: where the walk of ' '+s (the forward-delete probe of
+  const uint4* spl;        // [n_info] "space-prefix link" of record s: where the walk of ' '+s (the forward-delete probe of
                            //   go/tokenmonster.go:1088-1095; ' ' 0x00 + s for UTF-16) ends up, so that probe only has to CONTINUE:
-                           //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node
+                           //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node;
+                           //   z = 32-bit child filter of the node reached (0 unless the continue flag is set): most probes end here
   const uint32_t* vals;    // [n_info] node value of every record (the split pipeline hands positions over as record ordinals)
   const Row* rows;         // [n_info]
   const uint8_t* begin_byte;  // [256]  go/tokenmonster.go:43

@@ -264,10 +264,11 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   // space-prefix links (walked above): x = node reached | continue << 21 | best accepting depth << 22, y = that node's value
   hv.vals.resize(n_info);
   for (uint32_t i = 0; i < n_info; i++) hv.vals[i] = value_of(i);
-  hv.spl.assign(n_info, uint2{kNone, 0u});
+  hv.spl.assign(n_info, uint4{kNone, 0u, 0u, 0u});
   if (spl_start != kNone)
     for (uint32_t i = 0; i < n_info; i++)
-      hv.spl[i] = uint2{splw[i].node | (splw[i].cont << 21) | (splw[i].bestlen << 22), splw[i].best != kNone ? value_of(splw[i].best) : 0u};
+      hv.spl[i] = uint4{splw[i].node | (splw[i].cont << 21) | (splw[i].bestlen << 22), splw[i].best != kNone ? value_of(splw[i].best) : 0u,
+                        splw[i].cont ? cmask[splw[i].node] : 0u, 0u};
   // direct map: one 16-byte entry (same format as a suffix link) resolves the first two bytes of any walk, the
   // depth-1 answer folded in
   for (uint32_t b0 = 0; b0 < 256; b0++) {
@@ -338,7 +339,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   if ((e = up((void**)&v->d_root, hv.root.data(), 256 * 4)) != hipSuccess ||
       (e = up((void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2))) != hipSuccess ||
       (e = up((void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row))) != hipSuccess ||
-      (e = up((void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint2))) != hipSuccess ||
+      (e = up((void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint4))) != hipSuccess ||
       (e = up((void**)&v->d_vals, hv.vals.data(), hv.vals.size() * 4)) != hipSuccess ||
       (e = up((void**)&v->d_rev_off, hv.rev_off.data(), hv.rev_off.size() * 4)) != hipSuccess ||
       (e = up((void**)&v->d_rev_bytes, hv.rev_bytes.data(), hv.rev_bytes.size())) != hipSuccess ||
