@@ -280,7 +280,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
                                                                 const uint32_t* __restrict__ seg_doc,
                                                                 const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
                                                                 uint32_t* __restrict__ R0, uint2* __restrict__ side,
-                                                                uint32_t* __restrict__ R1, uint2* __restrict__ exitmap, int dbg) {
+                                                                uint32_t* __restrict__ R1, uint32_t* __restrict__ exitmap, int dbg) {
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
   const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
@@ -567,44 +567,43 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   __builtin_amdgcn_s_waitcnt(0);
 
   // ---- step C: exit map of the segment by pointer doubling over all (p, fd) states -------------------
-  // J[s] summarises the path from state s to where it currently points: {target, #id events, #forward deletes,
-  // #missing}.  Composing J[s] with J[target] doubles the path; after <= log2(chain length) rounds every state
-  // points at a segment exit.  Only the 80 possible entry states (offset < 40, fd) are written out, but their
-  // chains run through arbitrary states, so all 2 x 512 states take part.  In-place updates are safe: an entry is
-  // read and written as one 8-byte LDS access and always describes a valid prefix of its state's chain.
+  // J[s] summarises the path from state s to where it currently points: {target, #tokens emitted on the way}.  Composing J[s] with
+  // J[target] doubles the path; after <= log2(chain length) rounds every state points at a segment exit.  Only the 80 possible entry
+  // states (offset < 40, fd) are written out, but their chains run through arbitrary states, so all 2 x 256 states take part.
+  // In-place updates are safe: an entry is read and written as one 4-byte LDS access and always describes a valid prefix of its
+  // state's chain.  (What a chain emits besides its count — forward-deletes, missing characters — is counted by K4, which walks
+  // the one chain that is real.)
 #ifdef TM_DEVEL
-  if (dbg & 16) { for (int e = lane; e < ENT; e += 64) exitmap[g * ENT + e] = make_uint2(0u, 0u); return; }   // (timing experiments only)
+  if (dbg & 16) { for (int e = lane; e < ENT; e += 64) exitmap[g * ENT + e] = 0u; return; }   // (timing experiments only)
 #endif
   {
-    uint2* J = reinterpret_cast<uint2*>(w.D);            // overlays D, Db, X, Xb (dead after step B): 1024 x 8 B
-    static_assert(sizeof(uint32_t) * (3 * NPOS + SEG) >= 2 * SEG * sizeof(uint2), "J overlay does not fit");
+    uint32_t* J = reinterpret_cast<uint32_t*>(w.D);       // overlays D, Db (dead after step B): 512 x 4 B
+    static_assert(sizeof(uint32_t) * 2 * NPOS >= 2 * SEG * sizeof(uint32_t), "J overlay does not fit");
     const bool more_text = remv > (uint64_t)seglen;       // text follows the segment: the chain leaves it into an entry state
-    // J entry: x = #id events [0..15] | field [16..30] | left-the-segment [31]; the field is the LDS byte address of the
-    // entry it points at, or — once the chain has left the segment — the entry state of the next segment (0x7FFF: the
-    // state is unreachable); y = #forward-deletes | #missing << 16.  Composing two entries is (x & 0xFFFF) + x', y + y',
-    // and the address to read next is x >> 16: the kernel is VALU bound, and this loop runs ~7 times.
+    // J entry: #tokens [0..15] | field [16..30] | left-the-segment [31]; the field is the LDS byte address of the entry it points
+    // at, or — once the chain has left the segment — the entry state of the next segment (0x7FFF: the state is unreachable).
+    // Composing two entries is (x & 0xFFFF) + x', and the address to read next is x >> 16.
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(3))) u32x2 lds_v2;
-    auto ld_j = [](uint32_t a) -> uint2 { const u32x2 t = *(lds_v2*)(uintptr_t)a; return make_uint2(t.x, t.y); };
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    auto ld_j = [](uint32_t a) -> uint32_t { return *(lds_u32*)(uintptr_t)a; };
     const uint32_t jaddr = (uint32_t)(uintptr_t)(lds_u8*)w.D;
     static_assert(sizeof(s_wave) + 2048 < 32768, "LDS addresses must fit the 15-bit field");
-    auto first_hop = [&](uint32_t r, int p, uint32_t fd) -> uint2 {
+    auto first_hop = [&](uint32_t r, int p, uint32_t fd) -> uint32_t {
       // at/after the end of the segment: nothing is emitted here.  At the end of the text that is the terminal state; in a byte
       // range that is followed by more text, a token of the range before may cover this whole (short, last) segment: pass through
-      if (p >= seglen) return make_uint2(0x80000000u | ((more_text ? (uint32_t)((p - seglen) * 2) + fd : 0u) << 16), 0u);
-      if (r == R_INVALID) return make_uint2(0x80000000u | (0x7FFFu << 16), 0u);
+      if (p >= seglen) return 0x80000000u | ((more_text ? (uint32_t)((p - seglen) * 2) + fd : 0u) << 16);
+      if (r == R_INVALID) return 0x80000000u | (0x7FFFu << 16);
       const int pn = p + (int)((r >> 24) & 63u);
       const uint32_t fdn = (r >> 30) & 1u;
-      const uint32_t ev = (r & ID_NONE) != ID_NONE ? 1u : 0u;
+      const uint32_t nt = ((r & ID_NONE) != ID_NONE ? 1u : 0u) + fdn;          // ids this step emits: the token (unless it is "none") + the delete token
       const uint32_t x = pn >= seglen ? 0x80000000u | ((more_text ? (uint32_t)((pn - seglen) * 2) + fdn : 0u) << 16)
-                                      : (jaddr + 8u * (fdn * SEG + (uint32_t)pn)) << 16;
-      return make_uint2(x | ev, fdn | ((r >> 31) << 16));
+                                      : (jaddr + 4u * (fdn * SEG + (uint32_t)pn)) << 16;
+      return x | nt;
     };
     // every lane keeps its own 2*SEG/64 states in registers and only touches LDS for states that still point inside
     // the segment (most (p,1) states are unreachable and finished from the start)
     constexpr int NS = 2 * SEG / 64, N0 = SEG / 64;
-    uint2 ja[NS];
+    uint32_t ja[NS];
     bool pend[NS];
 #pragma unroll
     for (int it = 0; it < N0; it++) {
@@ -616,24 +615,23 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     }
     bool any0 = false, any1 = false;
 #pragma unroll
-    for (int k = 0; k < NS; k++) { pend[k] = (int)ja[k].x >= 0; if (k < N0) any0 |= pend[k]; else any1 |= pend[k]; }
+    for (int k = 0; k < NS; k++) { pend[k] = (int)ja[k] >= 0; if (k < N0) any0 |= pend[k]; else any1 |= pend[k]; }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
     // One round: every pending state composes itself with the state it points at.  The LDS reads of a round are issued
     // back to back (one LDS latency per round); the (p,1) states are rarely pending and skipped as a group.  The entry
     // states sit at the start of the segment and have the longest chains, so "nothing pending" is also when they are done.
     for (int round = 0; round < 12 && __any(any0 || any1); round++) {
-      uint2 bn[N0];
+      uint32_t bn[N0];
 #pragma unroll
-      for (int k = 0; k < N0; k++) if (pend[k]) bn[k] = ld_j(ja[k].x >> 16);
+      for (int k = 0; k < N0; k++) if (pend[k]) bn[k] = ld_j(ja[k] >> 16);
       any0 = false;
 #pragma unroll
       for (int k = 0; k < N0; k++) {
         if (pend[k]) {
-          ja[k].x = (ja[k].x & 0xFFFFu) + bn[k].x;
-          ja[k].y += bn[k].y;                              // two 16-bit counters, neither can overflow (<= 512 each)
+          ja[k] = (ja[k] & 0xFFFFu) + bn[k];              // (a 16-bit count cannot overflow: <= 512 ids per segment)
           J[k * 64 + lane] = ja[k];
-          pend[k] = (int)ja[k].x >= 0;
+          pend[k] = (int)ja[k] >= 0;
           any0 |= pend[k];
         }
       }
@@ -642,11 +640,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 #pragma unroll
         for (int k = N0; k < NS; k++) {
           if (pend[k]) {
-            const uint2 b1 = ld_j(ja[k].x >> 16);
-            ja[k].x = (ja[k].x & 0xFFFFu) + b1.x;
-            ja[k].y += b1.y;
+            const uint32_t b1 = ld_j(ja[k] >> 16);
+            ja[k] = (ja[k] & 0xFFFFu) + b1;
             J[k * 64 + lane] = ja[k];
-            pend[k] = (int)ja[k].x >= 0;
+            pend[k] = (int)ja[k] >= 0;
             any1 |= pend[k];
           }
         }
@@ -655,49 +652,42 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       __builtin_amdgcn_s_waitcnt(0);
       PH_INC(13)
     }
+    // exit map entry: next entry state [0..7] | #ids << 8; 0xFFFFFFFF: the entry state cannot occur
     for (int e = lane; e < ENT; e += 64) {
-      const uint2 a = J[(e & 1) * SEG + (e >> 1)];
-      const uint32_t t = (a.x >> 16) & 0x7FFFu;
-      uint2 o = make_uint2(R_INVALID, 0u);
-      if ((a.x >> 31) != 0 && t != 0x7FFFu) o = make_uint2(t | ((a.x & 0xFFFFu) << 8), a.y);
-      exitmap[g * ENT + e] = o;
+      const uint32_t a = J[(e & 1) * SEG + (e >> 1)];
+      const uint32_t t = (a >> 16) & 0x7FFFu;
+      exitmap[g * ENT + e] = ((a >> 31) != 0 && t != 0x7FFFu) ? (t | ((a & 0xFFFFu) << 8)) : R_INVALID;
     }
   }
   PH(7)
   PH_FLUSH
 }
 
-// exit map entry (uint2): x = next entry state [0..7] | #id events << 8 ; y = #forward-deletes | #missing << 16
-// (#tokens emitted = events + forward-deletes; Count() = events, quirk Q2).  x == 0xFFFFFFFF: entry unreachable.
+// exit map entry (uint32): next entry state [0..7] | #ids emitted << 8 (delete tokens included).  0xFFFFFFFF: entry unreachable.
+// Count() (= ids without the delete tokens, quirk Q2) and the missing characters of a document are counted by K4.
 
 // ------------------------------------------------------------------------------------------------
 // K3: resolve — per document, chain the exit maps
 // ------------------------------------------------------------------------------------------------
 // doc_entry (may be null = all 0): the entry state of a document's first segment.  It is 0 for a document; a byte range of a
 // dataset that continues the whole-buffer walk of the range before it enters in the state that walk left (tm_score_begin/finish).
-__global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs,
+__global__ void k_resolve(const uint32_t* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs,
                           const uint8_t* __restrict__ doc_entry, uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
-                          uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ doc_events,
-                          uint32_t* __restrict__ doc_missing, uint32_t* __restrict__ error_flag, uint32_t long_segs) {
+                          uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ error_flag, uint32_t long_segs) {
   uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ndocs) return;
   uint64_t g0 = doc_seg_start[d], g1 = doc_seg_start[d + 1];
   if (g1 - g0 > long_segs) return;               // long documents: k_group_compose / k_long_top / k_group_expand
-  uint32_t e = doc_entry ? doc_entry[d] : 0u, ntok = 0, events = 0, nmiss = 0;
+  uint32_t e = doc_entry ? doc_entry[d] : 0u, ntok = 0;
   for (uint64_t g = g0; g < g1; g++) {
     seg_entry[g] = (uint8_t)e;
     seg_tokbase[g] = ntok;
-    uint2 x = exitmap[g * ENT + e];
-    if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
-    e = x.x & 0xFFu;
-    uint32_t ev = x.x >> 8, nfd = x.y & 0xFFFFu;
-    events += ev;
-    ntok += ev + nfd;
-    nmiss += x.y >> 16;
+    const uint32_t x = exitmap[g * ENT + e];
+    if (x == R_INVALID) { atomicOr(error_flag, 1u); break; }
+    e = x & 0xFFu;
+    ntok += x >> 8;
   }
   doc_ntok[d] = ntok;
-  doc_events[d] = events;
-  doc_missing[d] = nmiss;
 }
 
 // Long documents (more than LONG_SEGS segments: a multi-megabyte document, or a strip of the trainvocab dataset) would make
@@ -707,97 +697,85 @@ __global__ void k_resolve(const uint2* __restrict__ exitmap, const uint64_t* __r
 // lane per entry state), level by level; k_long_top chains a document's few top groups; k_group_expand replays every group from its
 // now known entry state, top level first.  Every serial chain is GROUP_FAN steps long: a 1 GiB strip (4.5 M segments, 4 levels)
 // resolves in well under a millisecond.  Exit-map composition is associative, so the result is the same as the serial chain.
-// group map entry (uint4): x = next entry state, y = #id events, z = #forward-deletes, w = #missing; x == R_INVALID: unreachable
+// group map entry (uint2): x = next entry state, y = #ids; x == R_INVALID: unreachable
 
-template <bool LEAF>     // LEAF: the children are segments (exit maps, uint2); otherwise groups of the level below (group maps, uint4)
-__global__ __launch_bounds__(128) void k_group_compose(const uint2* __restrict__ exitmap, const uint4* __restrict__ gmap_in, const Group* __restrict__ groups,
-                                                       uint32_t first_group, uint4* __restrict__ gmap) {
+template <bool LEAF>     // LEAF: the children are segments (exit maps, uint32); otherwise groups of the level below (group maps, uint2)
+__global__ __launch_bounds__(128) void k_group_compose(const uint32_t* __restrict__ exitmap, const uint2* __restrict__ gmap_in, const Group* __restrict__ groups,
+                                                       uint32_t first_group, uint2* __restrict__ gmap) {
   const uint32_t gi = first_group + blockIdx.x;
   const Group gr = groups[gi];
   const uint32_t e0 = threadIdx.x;
   if (e0 >= ENT) return;
-  uint32_t e = e0, events = 0, nfd = 0, nmiss = 0;
+  uint32_t e = e0, ntok = 0;
   bool ok = true;
   for (uint32_t k = 0; k < gr.nchildren; k++) {
     if (LEAF) {
-      const uint2 x = exitmap[(uint64_t)(gr.first_child + k) * ENT + e];
-      if (x.x == R_INVALID) { ok = false; break; }
-      e = x.x & 0xFFu;
-      events += x.x >> 8;
-      nfd += x.y & 0xFFFFu;
-      nmiss += x.y >> 16;
+      const uint32_t x = exitmap[(uint64_t)(gr.first_child + k) * ENT + e];
+      if (x == R_INVALID) { ok = false; break; }
+      e = x & 0xFFu;
+      ntok += x >> 8;
     } else {
-      const uint4 x = gmap_in[(uint64_t)(gr.first_child + k) * ENT + e];
+      const uint2 x = gmap_in[(uint64_t)(gr.first_child + k) * ENT + e];
       if (x.x == R_INVALID) { ok = false; break; }
       e = x.x;
-      events += x.y;
-      nfd += x.z;
-      nmiss += x.w;
+      ntok += x.y;
     }
   }
-  gmap[(uint64_t)gi * ENT + e0] = ok ? make_uint4(e, events, nfd, nmiss) : make_uint4(R_INVALID, 0u, 0u, 0u);
+  gmap[(uint64_t)gi * ENT + e0] = ok ? make_uint2(e, ntok) : make_uint2(R_INVALID, 0u);
 }
 
-__global__ void k_long_top(const uint4* __restrict__ gmap, const LongDoc* __restrict__ longs, uint32_t nlong, const uint8_t* __restrict__ doc_entry,
-                           uint8_t* __restrict__ group_entry, uint4* __restrict__ group_base,
-                           uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ doc_events,
-                           uint32_t* __restrict__ doc_missing, uint32_t* __restrict__ error_flag) {
+__global__ void k_long_top(const uint2* __restrict__ gmap, const LongDoc* __restrict__ longs, uint32_t nlong, const uint8_t* __restrict__ doc_entry,
+                           uint8_t* __restrict__ group_entry, uint32_t* __restrict__ group_base, uint32_t* __restrict__ doc_ntok,
+                           uint32_t* __restrict__ error_flag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nlong) return;
   const LongDoc ld = longs[i];
-  uint32_t e = doc_entry ? doc_entry[ld.doc] : 0u, ntok = 0, events = 0, nmiss = 0;
+  uint32_t e = doc_entry ? doc_entry[ld.doc] : 0u, ntok = 0;
   for (uint32_t k = 0; k < ld.ngroups; k++) {
     const uint32_t gi = ld.first_group + k;
     group_entry[gi] = (uint8_t)e;
-    group_base[gi] = make_uint4(ntok, events, nmiss, 0u);
-    const uint4 x = gmap[(uint64_t)gi * ENT + e];
+    group_base[gi] = ntok;
+    const uint2 x = gmap[(uint64_t)gi * ENT + e];
     if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
     e = x.x;
-    events += x.y;
-    ntok += x.y + x.z;
-    nmiss += x.w;
+    ntok += x.y;
   }
   doc_ntok[ld.doc] = ntok;
-  doc_events[ld.doc] = events;
-  doc_missing[ld.doc] = nmiss;
 }
 
 template <bool LEAF>     // one thread per group of the level: hands its entry state and token base down to its children
-__global__ void k_group_expand(const uint2* __restrict__ exitmap, const uint4* __restrict__ gmap, const Group* __restrict__ groups, uint32_t first_group,
-                               uint32_t ngroups, uint8_t* __restrict__ group_entry, uint4* __restrict__ group_base,
+__global__ void k_group_expand(const uint32_t* __restrict__ exitmap, const uint2* __restrict__ gmap, const Group* __restrict__ groups, uint32_t first_group,
+                               uint32_t ngroups, uint8_t* __restrict__ group_entry, uint32_t* __restrict__ group_base,
                                uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase, uint32_t* __restrict__ error_flag) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ngroups) return;
   const uint32_t gi = first_group + t;
   const Group gr = groups[gi];
-  const uint4 base = group_base[gi];
-  uint32_t e = group_entry[gi], ntok = base.x, events = base.y, nmiss = base.z;
+  uint32_t e = group_entry[gi], ntok = group_base[gi];
   for (uint32_t k = 0; k < gr.nchildren; k++) {
     const uint64_t c = (uint64_t)gr.first_child + k;
     if (LEAF) {
       seg_entry[c] = (uint8_t)e;
       seg_tokbase[c] = ntok;
-      const uint2 x = exitmap[c * ENT + e];
-      if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
-      e = x.x & 0xFFu;
-      ntok += (x.x >> 8) + (x.y & 0xFFFFu);
+      const uint32_t x = exitmap[c * ENT + e];
+      if (x == R_INVALID) { atomicOr(error_flag, 1u); break; }
+      e = x & 0xFFu;
+      ntok += x >> 8;
     } else {
       group_entry[c] = (uint8_t)e;
-      group_base[c] = make_uint4(ntok, events, nmiss, 0u);
-      const uint4 x = gmap[c * ENT + e];
+      group_base[c] = ntok;
+      const uint2 x = gmap[c * ENT + e];
       if (x.x == R_INVALID) { atomicOr(error_flag, 1u); break; }
       e = x.x;
-      events += x.y;
-      ntok += x.y + x.z;
-      nmiss += x.w;
+      ntok += x.y;
     }
   }
 }
 
 // Exit state of a document for EVERY entry state (one thread per entry state): what a rank hands to its neighbours when a dataset is
-// scored as byte ranges of ONE whole-buffer walk.  Short documents chain their segments' exit maps, long ones their groups' maps
+// scored as byte ranges of ONE whole-buffer walk.  Short documents chain their segments' exit maps, long ones their top groups' maps
 // (k_group_compose has composed those for all 80 entry states already).  0xFF: the entry state cannot occur.
-__global__ __launch_bounds__(128) void k_doc_exits(const uint2* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, const uint4* __restrict__ gmap,
+__global__ __launch_bounds__(128) void k_doc_exits(const uint32_t* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, const uint2* __restrict__ gmap,
                                                    const LongDoc* __restrict__ longs, uint32_t nlong, uint8_t* __restrict__ exits, uint32_t long_segs) {
   const uint32_t d = blockIdx.x, e0 = threadIdx.x;
   if (e0 >= ENT) return;
@@ -811,17 +789,23 @@ __global__ __launch_bounds__(128) void k_doc_exits(const uint2* __restrict__ exi
     else {
       const LongDoc ld = longs[li];
       for (uint32_t k = 0; k < ld.ngroups && ok; k++) {
-        const uint4 x = gmap[(uint64_t)(ld.first_group + k) * ENT + e];
+        const uint2 x = gmap[(uint64_t)(ld.first_group + k) * ENT + e];
         if (x.x == R_INVALID) ok = false; else e = x.x;
       }
     }
   } else {
     for (uint64_t g = g0; g < g1 && ok; g++) {
-      const uint2 x = exitmap[g * ENT + e];
-      if (x.x == R_INVALID) ok = false; else e = x.x & 0xFFu;
+      const uint32_t x = exitmap[g * ENT + e];
+      if (x == R_INVALID) ok = false; else e = x & 0xFFu;
     }
   }
   exits[(uint64_t)d * ENT + e0] = ok ? (uint8_t)e : (uint8_t)0xFF;
+}
+
+// Count() of a document = its ids without the delete tokens (go/tokenmonster.go:1281, quirk Q2): K3 knows the ids, K4 the delete tokens
+__global__ void k_doc_events(const uint32_t* __restrict__ doc_ntok, const uint32_t* __restrict__ doc_fd, uint32_t ndocs, uint32_t* __restrict__ doc_events) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < ndocs) doc_events[d] = doc_ntok[d] - doc_fd[d];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -925,7 +909,8 @@ __device__ __forceinline__ uint32_t side_word(const uint2* __restrict__ sl, cons
 __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
                                                    const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
                                                    uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
-                                                   uint32_t* __restrict__ error_flag, uint32_t stage_after) {
+                                                   uint32_t* __restrict__ error_flag, uint32_t stage_after, const uint32_t* __restrict__ seg_doc,
+                                                   uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing) {
   __shared__ alignas(16) uint32_t s_tile[TS][TROW];
   const int lane = threadIdx.x;
   const uint64_t g0 = (uint64_t)blockIdx.x * TS;
@@ -947,16 +932,25 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
       E++;
     };
     int hop = 0;
+    uint32_t nfd = 0, nmiss = 0;                                       // delete tokens emitted / characters without a token (go :1274)
     for (; hop <= 2 * SEG && p < t.seglen; hop++) {                   // a chain visits a state (p, fd) at most once
       const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, t.begin, p);
       if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }         // cannot happen on a chain K1/K3 produced
       const uint32_t id = w & ID_NONE;
       fd = (w >> 30) & 1u;
+      nfd += fd;
+      nmiss += w >> 31;
       if (id != ID_NONE) put(id);
       if (fd) put(delete_id);
       p += (w >> 24) & 63u;                                            // (0 is possible: a one-byte alternative of a forward-delete state)
     }
     if (hop > 2 * SEG) atomicOr(error_flag, 2u);
+    // what the document's Count() and `missing` need beyond the id count of K3 (rare: the document is only looked up when there is something to add)
+    if (nfd | nmiss) {
+      const uint32_t doc = seg_doc[g0 + lane];
+      if (nfd) atomicAdd(&doc_fd[doc], nfd);
+      if (nmiss) atomicAdd(&doc_missing[doc], nmiss);
+    }
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
@@ -1124,11 +1118,18 @@ static void launch_seg_params(tm_batch* b, hipStream_t st) {
                                                                       b->d_seg_tokbase, b->d_tok_offsets, b->d_seg_par);
 }
 // K4 for the id-emitting entry points: the tile walk (test hook bit 10: every id stored directly, the overflow path of the staging)
-static void launch_emit(tm_batch* b, hipStream_t st) {
+// store == false (Count): the same walk with an output capacity of 0 — it is there for the delete tokens and missing characters it counts
+static void launch_emit(tm_batch* b, hipStream_t st, bool store) {
   const uint64_t nseg = b->nseg;
-  launch_seg_params(b, st);
-  k_emit_tiles<<<(uint32_t)((nseg + TS - 1) / TS), 64, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, b->out_cap, b->d_out,
-                                                               b->d_error, (debug_flags() & 1024) ? 512u : 0u);
+  const uint32_t nd = b->ndocs;
+  (void)hipMemsetAsync(b->d_doc_fd, 0, (size_t)nd * 4, st);
+  (void)hipMemsetAsync(b->d_doc_missing, 0, (size_t)nd * 4, st);
+  if (nseg > 0) {
+    launch_seg_params(b, st);
+    k_emit_tiles<<<(uint32_t)((nseg + TS - 1) / TS), 64, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
+                                                                 b->d_error, (debug_flags() & 1024) ? 512u : 0u, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing);
+  }
+  if (nd) k_doc_events<<<(nd + 255) / 256, 256, 0, st>>>(b->d_doc_ntok, b->d_doc_fd, nd, b->d_doc_events);
 }
 
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {
@@ -1180,9 +1181,9 @@ int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32
     b->d_groups = nullptr; b->d_gmap = nullptr; b->d_group_entry = nullptr; b->d_group_base = nullptr;
     b->cap_groups = b->ngroups + b->ngroups / 4 + 16;
     if ((e = hipMalloc((void**)&b->d_groups, (size_t)b->cap_groups * sizeof(Group))) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_gmap, (size_t)b->cap_groups * ENT * sizeof(uint4))) != hipSuccess ||
+        (e = hipMalloc((void**)&b->d_gmap, (size_t)b->cap_groups * ENT * sizeof(uint2))) != hipSuccess ||
         (e = hipMalloc((void**)&b->d_group_entry, b->cap_groups)) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_group_base, (size_t)b->cap_groups * sizeof(uint4))) != hipSuccess)
+        (e = hipMalloc((void**)&b->d_group_base, (size_t)b->cap_groups * sizeof(uint32_t))) != hipSuccess)
       return hip_fail(e, "hipMalloc (segment groups)");
   }
   if (b->nlong > b->cap_long) {
@@ -1229,15 +1230,15 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
 }
 
-int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, bool emit) {
+// mode: 0 = resolve only (the scoring pass walks the chains itself), 1 = + K4 counting only (Count), 2 = + K4 writing the ids
+int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode) {
   const uint32_t nd = b->ndocs;
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   if (nd > 0)
     k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_doc_entry, b->d_seg_entry, b->d_seg_tokbase,
-                                                b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_error, long_segs());
+                                                b->d_doc_ntok, b->d_error, long_segs());
   if (b->ngroups > 0) {
-    k_long_top<<<(b->nlong + 63) / 64, 64, 0, st>>>(b->d_gmap, b->d_longs, b->nlong, b->d_doc_entry, b->d_group_entry, b->d_group_base, b->d_doc_ntok,
-                                                    b->d_doc_events, b->d_doc_missing, b->d_error);
+    k_long_top<<<(b->nlong + 63) / 64, 64, 0, st>>>(b->d_gmap, b->d_longs, b->nlong, b->d_doc_entry, b->d_group_entry, b->d_group_base, b->d_doc_ntok, b->d_error);
     for (size_t lvl = b->level_first.size() - 1; lvl-- > 0;) {                           // top down
       const uint32_t g0 = b->level_first[lvl], ng = b->level_first[lvl + 1] - g0;
       if (lvl == 0) k_group_expand<true><<<(ng + 63) / 64, 64, 0, st>>>(b->d_exitmap, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
@@ -1250,7 +1251,7 @@ int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, bool emit) {
   if (nd > 0) scan_u32(b->d_doc_ntok, nd, b->d_scan_tmp, b->d_totals + 1, b->d_tok_offsets, st);
   else (void)hipMemsetAsync(b->d_tok_offsets, 0, 8, st);
   mark(4);
-  if (emit && b->nseg > 0) launch_emit(b, st);
+  if (mode > 0) launch_emit(b, st, mode == 2);
   mark(5);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
@@ -1268,7 +1269,7 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
     b->have_events = true;
   }
   int rc = pipeline_match(b, st, timed ? b->ev : nullptr);
-  if (rc == TM_OK) rc = pipeline_resolve(b, st, timed ? b->ev : nullptr, emit);
+  if (rc == TM_OK) rc = pipeline_resolve(b, st, timed ? b->ev : nullptr, emit ? 2 : 1);
   if (rc != TM_OK) return rc;
   if (timed) {
     if ((e = hipEventSynchronize(b->ev[TM_NUM_KERNELS])) != hipSuccess) return hip_fail(e, "hipEventSynchronize");
@@ -1295,7 +1296,7 @@ int ensure_output(tm_batch* b) {
     b->out_cap = total + 1024;
     if ((e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc output");
     hipStream_t st = b->last_stream;
-    launch_emit(b, st);
+    launch_emit(b, st, true);
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "emit rerun");
   }
   return TM_OK;
@@ -1334,7 +1335,7 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
       (e = dalloc(b, &b->d_side, b->max_segs * SIDE_STRIDE)) != hipSuccess ||
       (e = dalloc(b, &b->d_exitmap, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_seg_entry, b->max_segs)) != hipSuccess ||
       (e = dalloc(b, &b->d_seg_tokbase, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_seg_par, b->max_segs + 1)) != hipSuccess || (e = dalloc(b, &b->d_doc_ntok, nd1)) != hipSuccess ||
-      (e = dalloc(b, &b->d_doc_events, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_missing, nd1)) != hipSuccess ||
+      (e = dalloc(b, &b->d_doc_events, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_missing, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_fd, nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_tok_offsets, nd1 + 1)) != hipSuccess || (e = dalloc(b, &b->d_scan_tmp, scan_blocks)) != hipSuccess ||
       (e = dalloc(b, &b->d_totals, 4)) != hipSuccess || (e = dalloc(b, &b->d_error, 4)) != hipSuccess ||
       (e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) {
@@ -1356,7 +1357,7 @@ int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm
 void tm_batch_free(tm_batch* b) {
   if (!b) return;
   void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R0, b->d_R1, b->d_side, b->d_exitmap, b->d_seg_entry,
-                  b->d_seg_tokbase, b->d_seg_par, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
+                  b->d_seg_tokbase, b->d_seg_par, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_doc_fd, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
                   b->d_error, b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
                   b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,
                   b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_raw, b->d_fb_norm, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids};

@@ -58,13 +58,14 @@ struct tm_batch {
   uint32_t* d_R0 = nullptr;          // T(p,0) of every byte position
   uint2* d_side = nullptr;           // per segment: its few T(p,1) words (SIDE_STRIDE entries: header + {position, word})
   uint32_t* d_R1 = nullptr;          // T(p,1) per position, written only for segments whose side list overflows
-  uint2* d_exitmap = nullptr;
+  uint32_t* d_exitmap = nullptr;       // per segment: 80 entries {next entry state | #ids << 8}
   uint8_t* d_seg_entry = nullptr;
   uint32_t* d_seg_tokbase = nullptr;
   uint4* d_seg_par = nullptr;          // per segment: begin | length | entry state | first output index (k_seg_params)
   uint32_t* d_doc_ntok = nullptr;
   uint32_t* d_doc_events = nullptr;
   uint32_t* d_doc_missing = nullptr;
+  uint32_t* d_doc_fd = nullptr;        // delete tokens emitted per document (K4)
   uint64_t* d_tok_offsets = nullptr;
   uint64_t* d_scan_tmp = nullptr;   // block sums
   uint64_t* d_totals = nullptr;     // [0] nseg total (device-computed), [1] token total, [2] missing total
@@ -74,9 +75,9 @@ struct tm_batch {
   std::vector<uint32_t> level_first;   // groups of level k+1 are d_groups[level_first[k] .. level_first[k+1])
   tmh::Group* d_groups = nullptr;
   tmh::LongDoc* d_longs = nullptr;
-  uint4* d_gmap = nullptr;
+  uint2* d_gmap = nullptr;
   uint8_t* d_group_entry = nullptr;
-  uint4* d_group_base = nullptr;
+  uint32_t* d_group_base = nullptr;
   // raw (un-normalized) input of tm_batch_upload_raw / tm_batch_normalize
   uint8_t* d_raw = nullptr;
   uint8_t* d_slab = nullptr;            // normalizer: one 2 KiB slab per 1 KiB piece
@@ -120,7 +121,7 @@ uint32_t long_segs();    // documents with more segments than this hang under th
 int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs);
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit);
 int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev);
-int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, bool emit);
+int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode);
 void launch_doc_exits(tm_batch* b, uint8_t* d_exits, hipStream_t st);
 // scoring variant of the chain kernel: histogram in HBM (scores | 4 limbs | 256 counters), see tm_score.hip
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,

@@ -127,7 +127,7 @@ static int score_complete(const tm_vocab* v, tm_dataset* d, const uint8_t* entry
   (void)hipMemsetAsync(d->d_hist, 0, words * 4, st);
   (void)hipMemsetAsync(d->d_tokens, 0, 8, st);
   (void)hipMemsetAsync(d->d_missing_bits, 0, 32, st);
-  int rc = pipeline_resolve(b, st, nullptr, false);
+  int rc = pipeline_resolve(b, st, nullptr, 0);
   if (rc != TM_OK) return rc;
   launch_chain_hist(b, v->tables.has_delete ? v->tables.delete_id : 0, d->n_cu, d->d_hist, d->d_tokens, d->d_missing_bits, v->host.n_ids, st);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "kernel launch");
