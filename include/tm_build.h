@@ -40,6 +40,22 @@ int tm_normalize(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_
 int tm_normalize_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode,
                        uint32_t norm_flag, uint32_t threads, uint8_t** out_text, uint64_t* out_offsets);
 
+/* ---- on-disk formats either side of the path (host only) --------------------------------------------------------------------------
+ * .vocab (go/tokenmonster.go:2602-2653 Save): this library never mutates a vocabulary, so saving one is writing back the image it was
+ * loaded from.  *image stays valid until tm_vocab_free. */
+struct tm_vocab;
+int tm_vocab_image(const struct tm_vocab* v, const uint8_t** image, size_t* n);
+int tm_vocab_save(const struct tm_vocab* v, const char* path);
+/* .tok token dictionaries (training/trainvocab.go:412-480: what getalltokens writes and trainvocab reads and writes): a zlib stream of
+ * header[5] = {capcode, charset, normalization flag, level, reserve} + 3 reserved bytes, u64 count, count x {u8 length, bytes}, optionally
+ * count x f32 score, optionally u32 nSpecial + nSpecial x {u8 length, bytes}.  tm_tok_read inflates and parses a whole file: tokens as
+ * blob + offsets[count+1] (the layout tm_build_vocab takes), *scores NULL when the file has none; every returned buffer is malloc'd
+ * (tm_free).  tm_tok_write produces the file bytes (scores / special tokens optional, NULL / 0). */
+int tm_tok_read(const uint8_t* file, size_t n, uint8_t header[5], uint8_t** blob, uint32_t** offsets, uint32_t* count, float** scores,
+                uint8_t** special_blob, uint32_t** special_offsets, uint32_t* n_special);
+int tm_tok_write(const uint8_t header[5], const uint8_t* blob, const uint32_t* offsets, uint32_t count, const float* scores,
+                 const uint8_t* special_blob, const uint32_t* special_offsets, uint32_t n_special, uint8_t** out, size_t* out_n);
+
 #ifdef __cplusplus
 }
 #endif

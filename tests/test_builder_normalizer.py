@@ -165,3 +165,63 @@ def test_device_normalizer_rule_table_and_flood_fills_on_cpu(tmp_path):
     r = subprocess.run([exe, "6000", "17"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and " 0 mismatches" in out, out[-3000:]
+
+
+def test_tok_dictionary_format_round_trip_and_layout():
+    """.tok token dictionaries (training/trainvocab.go:412-480): zlib stream of 8 header bytes, u64 count, count x {u8 len, bytes},
+    optional f32 scores, optional u32 nSpecial + special tokens.  tm_tok_write's bytes are checked against the layout built
+    independently with Python's zlib/struct, and tm_tok_read reads both back."""
+    import ctypes as C
+    import struct
+    import zlib
+    from tokenmonster_amd import _native as N
+    toks = [b"a", b" the", b"hello world", bytes(range(200, 240)), b""]
+    scores = np.array([0.5, 0.25, 0.125, 0.0, 1.0], dtype=np.float32)
+    special = [b"<eos>", b"<pad>"]
+    header = bytes([2, 1, 1, 3, 0])
+
+    def pack(ts):
+        off = np.zeros(len(ts) + 1, dtype=np.uint32)
+        np.cumsum([len(t) for t in ts], out=off[1:])
+        return np.frombuffer(b"".join(ts) or b"\0", dtype=np.uint8).copy(), off
+
+    def layout(with_scores, with_special):
+        raw = header + b"\0\0\0" + struct.pack("<Q", len(toks)) + b"".join(bytes([len(t)]) + t for t in toks)
+        if with_scores:
+            raw += scores.tobytes()
+            if with_special:
+                raw += struct.pack("<I", len(special)) + b"".join(bytes([len(t)]) + t for t in special)
+        return raw
+
+    blob, off = pack(toks)
+    sblob, soff = pack(special)
+    for with_scores, with_special in ((False, False), (True, False), (True, True)):
+        out, n = C.c_void_p(), C.c_size_t()
+        N.check(N.lib.tm_tok_write(header, N.ptr(blob), N.ptr(off), len(toks), N.ptr(scores) if with_scores else None,
+                                   N.ptr(sblob) if with_special else None, N.ptr(soff) if with_special else None, len(special) if with_special else 0,
+                                   C.byref(out), C.byref(n)))
+        written = N.take(out, n.value)
+        assert zlib.decompress(written) == layout(with_scores, with_special)
+        for filedata in (written, zlib.compress(layout(with_scores, with_special), 9)):      # ours, and one a foreign zlib wrote
+            hdr = (C.c_uint8 * 5)()
+            b, o, cnt, sc, sb, so, ns = C.c_void_p(), C.c_void_p(), C.c_uint32(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+            N.check(N.lib.tm_tok_read(filedata, len(filedata), hdr, C.byref(b), C.byref(o), C.byref(cnt), C.byref(sc), C.byref(sb), C.byref(so), C.byref(ns)))
+            assert bytes(hdr) == header and cnt.value == len(toks)
+            offs = np.frombuffer(C.string_at(o.value, 4 * (cnt.value + 1)), dtype=np.uint32)
+            data = C.string_at(b.value, int(offs[-1]))
+            assert [data[int(offs[i]):int(offs[i + 1])] for i in range(cnt.value)] == toks
+            assert (sc.value is not None) == with_scores
+            if with_scores:
+                assert (np.frombuffer(C.string_at(sc.value, 4 * cnt.value), dtype=np.float32) == scores).all()
+            assert ns.value == (len(special) if with_special else 0)
+            if with_special:
+                so_ = np.frombuffer(C.string_at(so.value, 4 * (ns.value + 1)), dtype=np.uint32)
+                sd = C.string_at(sb.value, int(so_[-1]))
+                assert [sd[int(so_[i]):int(so_[i + 1])] for i in range(ns.value)] == special
+            for p_ in (b, o, sc, sb, so):
+                if p_.value:
+                    N.lib.tm_free(p_)
+    with pytest.raises(N.TokenMonsterHipError):
+        hdr = (C.c_uint8 * 5)()
+        b, o, cnt = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        N.check(N.lib.tm_tok_read(b"not zlib", 8, hdr, C.byref(b), C.byref(o), C.byref(cnt), None, None, None, None))

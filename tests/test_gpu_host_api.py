@@ -92,3 +92,20 @@ def test_concurrent_callers_take_lanes(setup):
     for th in ths:
         th.join()
     assert not errors, errors[:2]
+
+
+def test_vocab_save_writes_back_the_loaded_image(setup, tmp_path):
+    """Save (go/tokenmonster.go:2602-2653): the library never mutates a vocabulary, so the saved file is the loaded image, byte for byte,
+    and loads again"""
+    import ctypes as C
+    from tokenmonster_amd import _native as N
+    img = setup[0]
+    v = tm.Vocab(img)
+    p, n = C.c_void_p(), C.c_size_t()
+    N.check(N.lib.tm_vocab_image(v.handle, C.byref(p), C.byref(n)))
+    assert C.string_at(p.value, n.value) == bytes(img)
+    path = str(tmp_path / "saved.vocab")
+    N.check(N.lib.tm_vocab_save(v.handle, path.encode()))
+    assert open(path, "rb").read() == bytes(img)
+    v2 = tm.load(path)
+    assert v2.n_ids() == v.n_ids() and v2.n_info() == v.n_info()

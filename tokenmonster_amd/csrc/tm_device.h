@@ -16,6 +16,7 @@ int hip_fail(hipError_t e, const char* what);
 struct HostVocab {
   uint8_t capcode = 0, charset = 0, norm_flag = 0, level = 0, reserve = 0;
   uint32_t unk = TM_NONE, vocab_size = 0, n_ids = 0, n_info = 0, delete_id = TM_NONE, max_len = 0;
+  std::vector<uint8_t> image;       // the .vocab bytes the vocabulary was loaded from (tm_vocab_image / tm_vocab_save)
   std::vector<uint8_t> keys;        // concatenated key bytes
   std::vector<uint32_t> key_off;    // n_info + 1
   std::vector<Row> rows;

@@ -325,6 +325,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   auto* v = new tm_vocab();
   int rc = parse_vocab(vocab_file, n, v->host);
   if (rc != TM_OK) { delete v; return rc; }
+  v->host.image.assign(vocab_file, vocab_file + n);
   HostVocab& hv = v->host;
   hipError_t e;
   int dev = 0;
