@@ -827,7 +827,10 @@ constexpr int HSLOTS = 8192;
 // (p,1) states are rare: their words are looked up in the segment's side list (or the dense array) when one is entered.
 // (Letting every lane walk its segment straight from HBM — no tiles — was measured at 8.5 ms per GiB: ~0.6 G scattered 4-byte
 // accesses cost ~8 cycles each per CU.)
-constexpr int TS = 8;                   // segments per wavefront (8: 18 wavefronts per CU; 16 was 8 % slower, the phases of a tile overlap less)
+#ifndef TM_TS
+#define TM_TS 8
+#endif
+constexpr int TS = TM_TS;                   // segments per wavefront (8: 18 wavefronts per CU; 16 was 8 % slower, the phases of a tile overlap less)
 constexpr int TSLACK = 2;               // position p of a row is word TSLACK + p: the two ids of a first token fit in front of it
 constexpr int TROW = SEG + 8;           // words per tile row (16-byte multiple; the odd multiple of 8 spreads the rows over the LDS banks)
 
@@ -924,25 +927,33 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
   if (t.have) {
     uint32_t* row = s_tile[lane];
     uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0;
-    bool direct = false;
     const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
-    auto put = [&](uint32_t id) {
-      if (!direct && E + stage_after < (uint32_t)TSLACK + p) { row[E] = id; staged = E + 1; }
-      else { direct = true; if (t.base + E < out_cap) out[t.base + E] = id; }
-      E++;
-    };
-    int hop = 0;
     uint32_t nfd = 0, nmiss = 0;                                       // delete tokens emitted / characters without a token (go :1274)
-    for (; hop <= 2 * SEG && p < t.seglen; hop++) {                   // a chain visits a state (p, fd) at most once
+    int hop = 0;
+    // fast loop: both ids a step can emit still fit in front of the word being read (stage_after = 0; the test hook passes 512: never)
+    for (; hop <= 2 * SEG && p < t.seglen && E + 2u + stage_after <= (uint32_t)TSLACK + p; hop++) {      // a chain visits a state (p, fd) at most once
       const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, t.begin, p);
-      if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }         // cannot happen on a chain K1/K3 produced
+      if (w == R_INVALID) { atomicOr(error_flag, 2u); p = t.seglen; break; }     // cannot happen on a chain K1/K3 produced
       const uint32_t id = w & ID_NONE;
       fd = (w >> 30) & 1u;
       nfd += fd;
       nmiss += w >> 31;
-      if (id != ID_NONE) put(id);
-      if (fd) put(delete_id);
+      if (id != ID_NONE) row[E++] = id;
+      if (fd) row[E++] = delete_id;
       p += (w >> 24) & 63u;                                            // (0 is possible: a one-byte alternative of a forward-delete state)
+    }
+    staged = E;
+    // the rest of a segment whose ids have caught up with its words (more than one id per byte of text) goes straight to HBM
+    for (; hop <= 2 * SEG && p < t.seglen; hop++) {
+      const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, t.begin, p);
+      if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }
+      const uint32_t id = w & ID_NONE;
+      fd = (w >> 30) & 1u;
+      nfd += fd;
+      nmiss += w >> 31;
+      if (id != ID_NONE) { if (t.base + E < out_cap) out[t.base + E] = id; E++; }
+      if (fd) { if (t.base + E < out_cap) out[t.base + E] = delete_id; E++; }
+      p += (w >> 24) & 63u;
     }
     if (hop > 2 * SEG) atomicOr(error_flag, 2u);
     // what the document's Count() and `missing` need beyond the id count of K3 (rare: the document is only looked up when there is something to add)
