@@ -154,7 +154,10 @@ int tm_batch_totals(tm_batch* b, uint64_t* total_tokens, uint64_t* total_missing
 /* D2H of results of the last run. */
 int tm_batch_download(tm_batch* b, uint32_t* tokens_out, uint64_t tokens_cap, uint64_t* tok_offsets,
                       uint32_t* missing);
-/* Raw device pointers of the last run's results (valid until the next run/free). */
+/* Raw device pointers of the last run's results (valid until the next run/free).  The id buffer starts at max_bytes / 2 + 2 * max_docs
+ * + 1024 ids and grows on demand: call tm_batch_totals (or tm_batch_download) after tm_batch_run and BEFORE fetching these pointers —
+ * it synchronizes, and if the run produced more ids than the buffer held it reallocates the buffer and repeats the emit stage, so a
+ * pointer fetched earlier may dangle and ids beyond the old capacity were not written. */
 const uint32_t* tm_batch_device_tokens(const tm_batch* b);
 const uint64_t* tm_batch_device_tok_offsets(const tm_batch* b);
 uint64_t tm_batch_device_bytes(const tm_batch* b);

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
                                                                 uint32_t* __restrict__ R1, uint32_t* __restrict__ exitmap, int dbg) {
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
-  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wvi = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the segment, its document and lengths live in SGPRs
   s_bb[threadIdx.x] = T.begin_byte[threadIdx.x];
   __syncthreads();
   const uint64_t g = (uint64_t)blockIdx.x * WAVES + wvi;
@@ -555,8 +555,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       const int p = it * 64 + lane;
       r1[it] = ((m1[it] >> lane) & 1ull) ? w.Xb[p] : R_INVALID;
       if (p < seglen) {
-        R0[begin + p] = r0[it];
-        if (!side_ok) R1[begin + p] = r1[it];                      // (rare) too many forward-delete states for the side list
+        R0[g * SEG + p] = r0[it];                                  // rows of SEG words per SEGMENT (not per text position): every store is whole aligned lines
+        if (!side_ok) R1[g * SEG + p] = r1[it];                    // (rare) too many forward-delete states for the side list
       }
     }
     if (lane == 0) side[g * SIDE_STRIDE] = make_uint2(side_ok ? (uint32_t)n1 : SIDE_DENSE, 0u);
@@ -868,9 +868,9 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
   return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32);
 }
 // stream the T(p,0) words of the tile's segments into LDS, position p of segment s at tile[s][TSLACK + p]: lane l fetches words
-// 4l..4l+3 of a row with one 16-byte load (R0 + begin is only 4-byte aligned: gfx950 global loads do not ask for more).  All
-// loads are issued before the first LDS write, so a tile costs one HBM latency, not sixteen.
-__device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg& t, int nv, int lane, const uint32_t* __restrict__ R0) {
+// 4l..4l+3 of a row with one aligned 16-byte load (segment g owns words [g * SEG, (g + 1) * SEG) of R0, so a tile is one contiguous
+// block).  All loads are issued before the first LDS write, so a tile costs one HBM latency, not sixteen.
+__device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg& t, uint64_t g0, int nv, int lane, const uint32_t* __restrict__ R0) {
   constexpr int PARTS = SEG / 256;                                       // a row is fetched 256 words (one 16-byte load per lane) at a time
   static_assert(SEG % 256 == 0, "tile_load fetches rows in units of 256 words");
   uint4 v[TS][PARTS];
@@ -879,8 +879,8 @@ __device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg&
 #pragma unroll
   for (int s = 0; s < TS; s++) {
     const int ss = s < nv ? s : nv - 1;                                // rows beyond the last segment: nothing is fetched
-    src[s] = R0 + shfl_u64(t.begin, ss) + 4 * lane;
-    len[s] = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;        // at most 3 words past the segment: R0 has 64 of slack
+    src[s] = R0 + (g0 + (uint64_t)ss) * SEG + 4 * lane;
+    len[s] = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;
   }
 #pragma unroll
   for (int s = 0; s < TS; s++)
@@ -901,9 +901,9 @@ __device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg&
   __builtin_amdgcn_s_waitcnt(0);
 }
 // T(p,1) of a segment: from its side list, or from the dense array when the list overflowed
-__device__ __forceinline__ uint32_t side_word(const uint2* __restrict__ sl, const uint32_t* __restrict__ R1, uint64_t begin, uint32_t p) {
+__device__ __forceinline__ uint32_t side_word(const uint2* __restrict__ sl, const uint32_t* __restrict__ R1, uint64_t g, uint32_t p) {
   const uint32_t nside = sl[0].x;
-  if (nside == SIDE_DENSE) return R1[begin + p];
+  if (nside == SIDE_DENSE) return R1[g * SEG + p];
   uint32_t w = R_INVALID;
   for (uint32_t k = 1; k <= nside && k < (uint32_t)SIDE_STRIDE; k++) { const uint2 sv = sl[k]; if (sv.x == p) w = sv.y; }
   return w;
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
   const uint64_t g0 = (uint64_t)blockIdx.x * TS;
   const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
   const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
-  tile_load(s_tile, t, nv, lane, R0);
+  tile_load(s_tile, t, g0, nv, lane, R0);
   // Walk.  Id number E of the segment is staged in word E of its own row while that word lies before the position being read
   // (E < TSLACK + p: true unless the text averages more than one id per byte); from the first id that does not fit, the rest of
   // the segment's ids go straight to HBM.  (stage_after = 0; the tests pass 512 so that nothing is staged: debug bit 10.)
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
     int hop = 0;
     // fast loop: both ids a step can emit still fit in front of the word being read (stage_after = 0; the test hook passes 512: never)
     for (; hop <= 2 * SEG && p < t.seglen && E + 2u + stage_after <= (uint32_t)TSLACK + p; hop++) {      // a chain visits a state (p, fd) at most once
-      const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, t.begin, p);
+      const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, g0 + lane, p);
       if (w == R_INVALID) { atomicOr(error_flag, 2u); p = t.seglen; break; }     // cannot happen on a chain K1/K3 produced
       const uint32_t id = w & ID_NONE;
       fd = (w >> 30) & 1u;
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
     staged = E;
     // the rest of a segment whose ids have caught up with its words (more than one id per byte of text) goes straight to HBM
     for (; hop <= 2 * SEG && p < t.seglen; hop++) {
-      const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, t.begin, p);
+      const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, g0 + lane, p);
       if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }
       const uint32_t id = w & ID_NONE;
       fd = (w >> 30) & 1u;
@@ -988,19 +988,19 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
   for (int j = threadIdx.x; j < HSLOTS; j += WV * 64) { s_tag[j] = 0xFFFFFFFFu; s_cnt[j] = 0; }
   if (threadIdx.x == 0) { s_ntok = 0; s_ndel = 0; }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t ntok = 0, ndel = 0;
   for (uint64_t g0 = ((uint64_t)blockIdx.x * WV + wv) * TS; g0 < nseg; g0 += (uint64_t)gridDim.x * WV * TS) {
     const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
     const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
-    tile_load(s_tile[wv], t, nv, lane, R0);
+    tile_load(s_tile[wv], t, g0, nv, lane, R0);
     if (t.have) {
       const uint32_t* row = s_tile[wv][lane];
       uint32_t p = t.entry >> 1, fd = t.entry & 1u;
       const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
       int hop = 0;
       for (; hop <= 2 * SEG && p < t.seglen; hop++) {
-        const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, t.begin, p);
+        const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, g0 + lane, p);
         if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }
         const uint32_t id = w & ID_NONE, adv = (w >> 24) & 63u;
         fd = (w >> 30) & 1u;
@@ -1342,7 +1342,7 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
   hipError_t e = hipSuccess;
   if ((own_text && (e = dalloc(b, &b->d_text, max_bytes + 256)) != hipSuccess) || (e = dalloc(b, &b->d_offsets, 2 * nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_doc_nseg, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_seg_start, nd1 + 1)) != hipSuccess ||
-      (e = dalloc(b, &b->d_seg_doc, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_R0, max_bytes + 64)) != hipSuccess || (e = dalloc(b, &b->d_R1, max_bytes + 64)) != hipSuccess ||
+      (e = dalloc(b, &b->d_seg_doc, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_R0, b->max_segs * SEG)) != hipSuccess || (e = dalloc(b, &b->d_R1, b->max_segs * SEG)) != hipSuccess ||
       (e = dalloc(b, &b->d_side, b->max_segs * SIDE_STRIDE)) != hipSuccess ||
       (e = dalloc(b, &b->d_exitmap, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_seg_entry, b->max_segs)) != hipSuccess ||
       (e = dalloc(b, &b->d_seg_tokbase, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_seg_par, b->max_segs + 1)) != hipSuccess || (e = dalloc(b, &b->d_doc_ntok, nd1)) != hipSuccess ||

@@ -55,7 +55,7 @@ struct tm_batch {
   uint32_t* d_doc_nseg = nullptr;
   uint64_t* d_doc_seg_start = nullptr;
   uint32_t* d_seg_doc = nullptr;
-  uint32_t* d_R0 = nullptr;          // T(p,0) of every byte position
+  uint32_t* d_R0 = nullptr;          // T(p,0): SEG words per segment (position p of segment g at g * SEG + p)
   uint2* d_side = nullptr;           // per segment: its few T(p,1) words (SIDE_STRIDE entries: header + {position, word})
   uint32_t* d_R1 = nullptr;          // T(p,1) per position, written only for segments whose side list overflows
   uint32_t* d_exitmap = nullptr;       // per segment: 80 entries {next entry state | #ids << 8}

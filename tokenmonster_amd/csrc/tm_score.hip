@@ -60,9 +60,8 @@ static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
     be[2ull * n_strips + k] = continues ? d->n : strip_off[k] + strip_len[k];     // how far the strip may look (k_match_branch)
     nseg += (strip_len[k] + SEG - 1) / SEG;
   }
-  // Strips must be disjoint: the per-position words of the walk (R0, R1) are indexed by absolute dataset position, so two
-  // strips that share a byte would race on them, and the workspace (max_bytes / SEG + n_strips + 1 segments) is sized for
-  // strips that together cover the dataset at most once.  (The trainvocab worker's strips are disjoint: trainvocab.go:1668-1695.)
+  // Strips must be disjoint: the workspace (max_bytes / SEG + n_strips + 1 segments) is sized for strips that together cover
+  // the dataset at most once, and a byte that two strips share would be counted twice.  (The trainvocab worker's strips are disjoint: trainvocab.go:1668-1695.)
   if (n_strips > 1) {
     std::vector<std::pair<uint64_t, uint64_t>> iv;
     iv.reserve(n_strips);

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Host-to-host pipeline under a timeline: run as
+    rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d DIR -o t -- python tools/h2h_trace.py [--lanes L --chunk-mib C]
+and feed DIR to `tools/h2h_trace.py --analyze DIR`: GPU-busy time (union of kernel intervals), copy-engine busy time per
+direction, and the wall span of the last pipeline pass.  Development aid for tm_tokenize_pipeline (tm_host.hip)."""
+import argparse
+import csv
+import glob
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def union(iv):
+    iv.sort()
+    tot, cur_a, cur_b = 0, None, None
+    for a, b in iv:
+        if cur_b is None or a > cur_b:
+            if cur_b is not None:
+                tot += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    if cur_b is not None:
+        tot += cur_b - cur_a
+    return tot
+
+
+def analyze(d):
+    kf = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    mf = glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True)
+    ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]) for f in kf for r in csv.DictReader(open(f))]
+    ms = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Direction"], int(r.get("Bytes", 0) or 0)) for f in mf for r in csv.DictReader(open(f))]
+    if not ks:
+        print("no kernel trace under", d)
+        return
+    # the last pass = everything after the last gap of > 20 ms without any kernel
+    ks.sort()
+    cut = ks[0][0]
+    for (a0, b0, _), (a1, b1, _) in zip(ks, ks[1:]):
+        if a1 - b0 > 20_000_000:
+            cut = a1
+    kl = [k for k in ks if k[0] >= cut]
+    lo, hi = kl[0][0], max(k[1] for k in kl)
+    ml = [m for m in ms if m[1] >= lo - 30_000_000 and m[0] <= hi + 30_000_000]
+    if ml:
+        lo = min(lo, min(m[0] for m in ml if m[0] >= lo - 30_000_000))
+        hi = max(hi, max(m[1] for m in ml))
+    print("last pass: span %.2f ms, %d kernels, %d copies" % ((hi - lo) / 1e6, len(kl), len(ml)))
+    print("  GPU busy (union of kernels)  %.2f ms ; sum of kernel durations %.2f ms" % (union([(a, b) for a, b, _ in kl]) / 1e6, sum(b - a for a, b, _ in kl) / 1e6))
+    for dirn in sorted(set(m[2] for m in ml)):
+        sel = [m for m in ml if m[2] == dirn]
+        big = [m for m in sel if m[3] >= 1 << 20]
+        by = sum(m[3] for m in sel)
+        print("  copies %-22s n %4d  bytes %8.1f MB  busy %.2f ms  (>=1 MiB: n %d, %.1f GB/s while active)" % (
+            dirn, len(sel), by / 1e6, union([(m[0], m[1]) for m in sel]) / 1e6, len(big),
+            (sum(m[3] for m in big) / max(1, union([(m[0], m[1]) for m in big]))) if big else 0.0))
+    agg = {}
+    for a, b, n in kl:
+        t = agg.setdefault(n, [0, 0])
+        t[0] += 1
+        t[1] += b - a
+    for n, (c, t) in sorted(agg.items(), key=lambda x: -x[1][1])[:12]:
+        print("    %-40s calls %4d  total %8.2f ms" % (n[-40:], c, t / 1e6))
+    # idle gaps of the compute queue inside the span
+    iv = sorted((a, b) for a, b, _ in kl)
+    gaps, cur = [], iv[0][1]
+    for a, b in iv[1:]:
+        if a > cur:
+            gaps.append(a - cur)
+        cur = max(cur, b)
+    gaps.sort(reverse=True)
+    print("  idle gaps between kernels: total %.2f ms, largest %s ms" % (sum(gaps) / 1e6, [round(g / 1e6, 2) for g in gaps[:8]]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--analyze")
+    ap.add_argument("--lanes", type=int, default=3)
+    ap.add_argument("--chunk-mib", type=int, default=64)
+    ap.add_argument("--mbytes", type=int, default=1024)
+    ap.add_argument("--passes", type=int, default=3)
+    a = ap.parse_args()
+    if a.analyze:
+        return analyze(a.analyze)
+    import numpy as np
+    import tokenmonster_amd as tm
+    from tokenmonster_amd import synth
+    cfg = "englishcode-32000-consistent"
+    kind, vsize, capcode, norm_flag, level, vseed = synth.CONFIGS[cfg]
+    vocab = tm.Vocab(synth.config_vocab(cfg))
+    raw, roffs = synth.synth_corpus(kind, a.mbytes << 20, seed=0x434F5250 + 2)
+    pin_in = tm.PinnedBuffer(raw.size)
+    pin_in.array[:] = raw
+    pin_out = tm.PinnedBuffer(raw.size + 4096)
+    for i in range(a.passes):
+        if i == a.passes - 1:
+            time.sleep(0.1)          # a gap the analysis can find
+        t0 = time.perf_counter()
+        blob, boff, _, enc, st = vocab.tokenize_pipeline(pin_in.array, roffs, raw=True, chunk_bytes=a.chunk_mib << 20, lanes=a.lanes, out=pin_out.array)
+        dt = time.perf_counter() - t0
+        print("pass %d: %.2f ms  %.2f GB/s  (%d ids, lanes %d, chunk %d MiB)" % (i, dt * 1e3, raw.size / dt / 1e9, int(boff[-1]) // enc, a.lanes, a.chunk_mib), flush=True)
+
+
+if __name__ == "__main__":
+    main()
