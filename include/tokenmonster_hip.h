@@ -93,8 +93,8 @@ int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const u
  * different lanes and overlap on the device; at most TM_LANES (environment, default 8) calls run at once, further callers wait.
  *
  * tm_tokenize_pipeline is the large-batch form of Vocab.TokenizeToSerialized over many documents: the corpus is cut into
- * chunks of whole documents (about chunk_bytes, 0 = 64 MiB) that run H2D | normalize + tokenize + serialize | D2H on `lanes`
- * lanes at once (0 = 3), so that PCIe moves the next chunk in and the previous one out while a chunk computes.  raw != 0: text is
+ * chunks of whole documents (about chunk_bytes, 0 = 32 MiB; the first two are smaller) that run H2D | normalize + tokenize + serialize | D2H on `lanes`
+ * lanes at once (0 = 4): a lane uploads its next chunk while the current one computes, so that PCIe moves text in and ids out behind the kernels.  raw != 0: text is
  * RAW UTF-8 and is normalized on the device (go/tokenmonster.go:242-253); raw == 0: already normalized.  Output: ids of all
  * documents back to back, encoding_length bytes each, little-endian (0 = automatic, go :990-996); byte_offsets[ndocs+1] is
  * always filled, so on TM_E_NOSPACE byte_offsets[ndocs] is the capacity required.  Buffers from tm_host_alloc (or registered

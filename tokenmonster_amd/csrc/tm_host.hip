@@ -14,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -26,8 +27,12 @@ namespace tmh {
 struct Lane {
   hipStream_t stream = nullptr;
   tm_batch* ws = nullptr;
-  uint8_t* h_stage = nullptr;     // pinned staging (input, then output), grow-only
+  uint8_t* h_stage = nullptr;     // pinned staging (pageable input of a one-shot call, pageable output), grow-only
   uint64_t h_cap = 0;
+  uint8_t* h_stage_in = nullptr;  // pinned staging of the pipeline's pageable input (filled for the next chunk while h_stage still holds output)
+  uint64_t h_in_cap = 0;
+  hipStream_t up_stream = nullptr;   // tm_tokenize_pipeline: the next chunk's raw text is uploaded here while the current chunk computes
+  hipEvent_t up_done = nullptr;
   uint8_t* d_bytes = nullptr;     // serialized ids on the device, grow-only
   uint64_t d_bytes_cap = 0;
   bool busy = false;
@@ -44,7 +49,10 @@ static void lane_destroy(Lane* l) {
   if (!l) return;
   tm_batch_free(l->ws);
   if (l->stream) (void)hipStreamDestroy(l->stream);
+  if (l->up_stream) (void)hipStreamDestroy(l->up_stream);
+  if (l->up_done) (void)hipEventDestroy(l->up_done);
   (void)hipHostFree(l->h_stage);
+  (void)hipHostFree(l->h_stage_in);
   (void)hipFree(l->d_bytes);
   delete l;
 }
@@ -102,15 +110,16 @@ static int lane_workspace(Lane* l, const tm_vocab* v, uint64_t bytes, uint32_t d
   return tm_batch_create(v, want_b, (uint32_t)std::min<uint64_t>(want_d, 0xFFFFFFF0ull), &l->ws);
 }
 
-static int lane_stage(Lane* l, uint64_t bytes) {
-  if (l->h_cap >= bytes) return TM_OK;
-  (void)hipHostFree(l->h_stage);
-  l->h_stage = nullptr;
-  l->h_cap = bytes + bytes / 4 + 4096;
-  hipError_t e = hipHostMalloc((void**)&l->h_stage, l->h_cap, hipHostMallocDefault);
-  if (e != hipSuccess) { l->h_cap = 0; return hip_fail(e, "hipHostMalloc (lane staging)"); }
+static int stage_grow(uint8_t** buf, uint64_t* cap, uint64_t bytes) {
+  if (*cap >= bytes) return TM_OK;
+  (void)hipHostFree(*buf);
+  *buf = nullptr;
+  *cap = bytes + bytes / 4 + 4096;
+  hipError_t e = hipHostMalloc((void**)buf, *cap, hipHostMallocDefault);
+  if (e != hipSuccess) { *cap = 0; return hip_fail(e, "hipHostMalloc (lane staging)"); }
   return TM_OK;
 }
+static int lane_stage(Lane* l, uint64_t bytes) { return stage_grow(&l->h_stage, &l->h_cap, bytes); }
 
 static int lane_dbytes(Lane* l, uint64_t bytes) {
   if (l->d_bytes_cap >= bytes) return TM_OK;
@@ -133,28 +142,35 @@ struct RunOut { uint64_t total_tokens = 0; };
 
 // upload + run one batch on a lane; the ids stay on the device (l->ws->d_out)
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-static int lane_run(Lane* l, const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, bool raw, bool emit, RunOut* ro) {
+// raw text grows under capcode (about 1.1x; worst case every byte a capital: "DC x" = 4x)
+static uint64_t lane_need(bool raw, uint64_t nbytes) { return raw ? nbytes + nbytes / 2 + 4096 : nbytes; }
+// H2D of one batch into the lane's workspace on stream `st` (the workspace must be idle, or — raw text only — past its normalizer pass)
+static int lane_upload(Lane* l, const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, bool raw, hipStream_t st) {
+  const uint64_t nbytes = ndocs ? offsets[ndocs] : 0;
+  int rc = lane_workspace(l, v, lane_need(raw, nbytes), ndocs);
+  if (rc != TM_OK) return rc;
+  return raw ? batch_upload_raw_on(l->ws, text, offsets, ndocs, st) : batch_upload_on(l->ws, text, offsets, ndocs, st);
+}
+// normalize (raw text) + the tokenizer pipeline on what lane_upload has put into the workspace; the ids stay on the device (l->ws->d_out)
+static int lane_compute(Lane* l, const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, bool raw, bool emit, RunOut* ro,
+                        const std::function<int()>& after_normalize = nullptr) {
   static const bool trace = getenv("TM_TRACE") != nullptr;
   const double t0 = trace ? now_ms() : 0;
   double t1 = 0, t2 = 0;
   const uint64_t nbytes = ndocs ? offsets[ndocs] : 0;
-  // raw text grows under capcode (about 1.1x; worst case every byte a capital: "DC x" = 4x)
-  int rc = lane_workspace(l, v, raw ? nbytes + nbytes / 2 + 4096 : nbytes, ndocs);
-  if (rc != TM_OK) return rc;
+  int rc = TM_OK;
   tm_batch* b = l->ws;
   if (raw) {
-    rc = batch_upload_raw_on(b, text, offsets, ndocs, l->stream);
-    if (rc == TM_OK) rc = tm_batch_normalize(b, l->stream);
+    rc = tm_batch_normalize(b, l->stream);
     if (rc == TM_E_LIMIT) {      // capital-heavy text: retry once with the worst-case workspace
       if ((rc = lane_workspace(l, v, 4 * nbytes + 4096, ndocs)) != TM_OK) return rc;
       b = l->ws;
       if ((rc = batch_upload_raw_on(b, text, offsets, ndocs, l->stream)) != TM_OK) return rc;
       rc = tm_batch_normalize(b, l->stream);
     }
-  } else {
-    rc = batch_upload_on(b, text, offsets, ndocs, l->stream);
   }
   if (rc != TM_OK) return rc;
+  if (after_normalize && (rc = after_normalize()) != TM_OK) return rc;     // (the raw text buffer is free from here on)
   if (trace) t1 = now_ms();
   if ((rc = run_pipeline(b, l->stream, false, nullptr, emit)) != TM_OK) return rc;
   if (trace) t2 = now_ms();
@@ -165,14 +181,17 @@ static int lane_run(Lane* l, const tm_vocab* v, const uint8_t* text, const uint6
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
   }
   if (ro) {
-    uint64_t totals[3] = {0, 0, 0};
-    hipError_t e = hipMemcpyAsync(totals, b->d_totals, sizeof totals, hipMemcpyDeviceToHost, l->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(l->stream);
-    if (e != hipSuccess) return hip_fail(e, "D2H totals");
-    ro->total_tokens = ndocs ? totals[1] : 0;
+    if (!emit) {                       // (ensure_output has read them already otherwise)
+      if ((rc = small_d2h(b, b->last_totals, b->d_totals, sizeof b->last_totals, l->stream)) != TM_OK || (rc = small_sync(b, l->stream)) != TM_OK) return rc;
+    }
+    ro->total_tokens = ndocs ? b->last_totals[1] : 0;
   }
-  if (trace) fprintf(stderr, "[lane %p] %llu bytes: upload%s %.2f ms, launch %.2f ms, wait %.2f ms\n", (void*)l, (unsigned long long)nbytes, raw ? "+normalize" : "", t1 - t0, t2 - t1, now_ms() - t2);
+  if (trace) fprintf(stderr, "[lane %p] %llu bytes: %s %.2f ms, launch %.2f ms, wait %.2f ms\n", (void*)l, (unsigned long long)nbytes, raw ? "normalize" : "-", t1 - t0, t2 - t1, now_ms() - t2);
   return TM_OK;
+}
+static int lane_run(Lane* l, const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, bool raw, bool emit, RunOut* ro) {
+  int rc = lane_upload(l, v, text, offsets, ndocs, raw, l->stream);
+  return rc == TM_OK ? lane_compute(l, v, text, offsets, ndocs, raw, emit, ro) : rc;
 }
 
 static int d2h(void* dst, const void* src, uint64_t bytes, hipStream_t st, const char* what) {
@@ -294,8 +313,8 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
   if (encoding_length < 2 || encoding_length > 4) return set_error(TM_E_INVALID, "Invalid encoding length");
   if (encoding_length_used) *encoding_length_used = encoding_length;
   if (ndocs && offsets[0] != 0) return set_error(TM_E_INVALID, "offsets[0] must be 0");
-  if (chunk_bytes == 0) chunk_bytes = 64ull << 20;
-  if (lanes == 0) lanes = 3;
+  if (chunk_bytes == 0) chunk_bytes = 32ull << 20;
+  if (lanes == 0) lanes = 4;
   lanes = std::min<uint32_t>(lanes, 8);
   // chunks = maximal runs of whole documents of at most chunk_bytes (a longer document is a chunk of its own)
   std::vector<uint32_t> first;     // first document of every chunk, + ndocs
@@ -303,7 +322,9 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
     first.push_back(d);
     uint32_t e = d + 1;
     if (offsets[e] < offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
-    while (e < ndocs && offsets[e + 1] >= offsets[e] && offsets[e + 1] - offsets[d] <= chunk_bytes) e++;
+    // (the first two chunks are a quarter and half the size: the first kernels start after a short upload)
+    const uint64_t limit = first.size() == 1 ? chunk_bytes / 4 : first.size() == 2 ? chunk_bytes / 2 : chunk_bytes;
+    while (e < ndocs && offsets[e + 1] >= offsets[e] && offsets[e + 1] - offsets[d] <= limit) e++;
     d = e;
   }
   first.push_back(ndocs);
@@ -323,26 +344,64 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
   std::string first_msg;
   std::atomic<size_t> next{0};
   lanes = (uint32_t)std::min<size_t>(lanes, nchunks);
+  // A lane works on one chunk at a time, but the raw text of its NEXT chunk is uploaded (on the lane's second stream) as soon as the
+  // normalizer pass of the current one is through with the raw buffer: the H2D of chunk k+1 hides behind the tokenizer kernels of chunk k.
   auto worker = [&]() {
     Lane* l = nullptr;
     int rc = lane_acquire(v, &l);
-    std::vector<uint64_t> loc, toff;
-    while (rc == TM_OK) {
-      const size_t k = next.fetch_add(1);
-      if (k >= nchunks) break;
+    std::vector<uint64_t> loc, loc_next, toff;
+    if (rc == TM_OK && !l->up_stream) {
+      hipError_t e = hipStreamCreateWithFlags(&l->up_stream, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&l->up_done, hipEventDisableTiming);
+      if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate (lane upload)");
+    }
+    // chunk k: offsets relative to its first byte into `lo`; uploads it on `st` (through the pinned input staging when the caller's
+    // buffer is pageable, so that the H2D runs at link speed); *srcp = where the text was read from (for a retry)
+    auto upload = [&](size_t k, std::vector<uint64_t>& lo, hipStream_t st, const uint8_t** srcp) -> int {
+      const uint32_t d0 = first[k], nd = first[k + 1] - d0;
+      const uint64_t b0 = offsets[d0], nb = offsets[d0 + nd] - b0;
+      lo.resize((size_t)nd + 1);
+      for (uint32_t d = 0; d <= nd; d++) lo[d] = offsets[d0 + d] - b0;
+      const uint8_t* src = text + b0;
+      if (!in_pinned) {
+        int r = stage_grow(&l->h_stage_in, &l->h_in_cap, nb);
+        if (r != TM_OK) return r;
+        std::memcpy(l->h_stage_in, src, nb);
+        src = l->h_stage_in;
+      }
+      *srcp = src;
+      return lane_upload(l, v, src, lo.data(), nd, raw != 0, st);
+    };
+    size_t k = rc == TM_OK ? next.fetch_add(1) : nchunks;
+    bool prefetched = false;
+    const uint8_t* src = nullptr;
+    while (rc == TM_OK && k < nchunks) {
       { std::lock_guard<std::mutex> g(mu); if (first_error != TM_OK) { break; } }
       const uint32_t d0 = first[k], d1 = first[k + 1], nd = d1 - d0;
-      const uint64_t b0 = offsets[d0], nb = offsets[d1] - b0;
-      loc.resize((size_t)nd + 1);
-      for (uint32_t d = 0; d <= nd; d++) loc[d] = offsets[d0 + d] - b0;
-      const uint8_t* src = text + b0;
-      if (!in_pinned) {                       // pageable input: through the lane's pinned staging, so that the H2D runs at link speed
-        if ((rc = lane_stage(l, nb)) != TM_OK) break;
-        std::memcpy(l->h_stage, src, nb);
-        src = l->h_stage;
-      }
+      if (prefetched) {
+        hipError_t e = hipStreamWaitEvent(l->stream, l->up_done, 0);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipStreamWaitEvent"); break; }
+      } else if ((rc = upload(k, loc, l->stream, &src)) != TM_OK) break;
+      size_t k_next = nchunks;
+      bool next_up = false;
+      const uint8_t* src_next = nullptr;
+      auto prefetch = [&]() -> int {
+        k_next = next.fetch_add(1);
+        if (k_next >= nchunks || !raw) return TM_OK;
+        const uint32_t n0 = first[k_next], nn = first[k_next + 1] - n0;
+        const uint64_t need = lane_need(true, offsets[n0 + nn] - offsets[n0]);
+        // (a chunk that would replace the workspace, or the per-document arrays the current chunk still reads, is uploaded later)
+        if (!l->ws || l->ws->max_bytes < need || l->ws->max_docs < nn || (uint64_t)nn + 2 > l->ws->raw_docs_cap) return TM_OK;
+        int r = upload(k_next, loc_next, l->up_stream, &src_next);
+        if (r != TM_OK) return r;
+        hipError_t e = hipEventRecord(l->up_done, l->up_stream);
+        if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
+        next_up = true;
+        return TM_OK;
+      };
       RunOut ro;
-      if ((rc = lane_run(l, v, src, loc.data(), nd, raw != 0, true, &ro)) != TM_OK) break;
+      if ((rc = lane_compute(l, v, src, loc.data(), nd, raw != 0, true, &ro, prefetch)) != TM_OK) break;
+      if (k_next == nchunks && !next_up) k_next = next.fetch_add(1);          // (already-normalized input: nothing was prefetched)
       {   // publish this chunk's count, learn where its ids go
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return known[k] || first_error != TM_OK; });
@@ -354,8 +413,8 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
       tm_batch* b = l->ws;
       const uint64_t base = tok_base[k], out_b = ro.total_tokens * encoding_length;
       toff.resize((size_t)nd + 1);
-      if ((rc = d2h(toff.data(), b->d_tok_offsets, toff.size() * 8, l->stream, "D2H tok_offsets")) != TM_OK) break;
-      if (missing && nd && (rc = d2h(missing + d0, b->d_doc_missing, (uint64_t)nd * 4, l->stream, "D2H missing")) != TM_OK) break;
+      if ((rc = small_d2h(b, toff.data(), b->d_tok_offsets, toff.size() * 8, l->stream)) != TM_OK) break;
+      if (missing && nd && (rc = small_d2h(b, missing + d0, b->d_doc_missing, (uint64_t)nd * 4, l->stream)) != TM_OK) break;
       const bool fits = (base + ro.total_tokens) * encoding_length <= bytes_cap && bytes_out;
       if (fits && out_b) {
         if ((rc = lane_dbytes(l, out_b)) != TM_OK) break;
@@ -368,11 +427,15 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
         }
         if (rc != TM_OK) break;
       }
-      { hipError_t e = hipStreamSynchronize(l->stream); if (e != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; } }
+      if ((rc = small_sync(b, l->stream)) != TM_OK) break;
       if (fits && out_b && !out_pinned) std::memcpy(bytes_out + base * encoding_length, l->h_stage, out_b);
       for (uint32_t d = 1; d <= nd; d++) byte_offsets[d0 + d] = (base + toff[d]) * encoding_length;
       if (stats) { std::lock_guard<std::mutex> g(mu); stats->host_fallback_docs += raw ? b->host_fallback_docs : 0; stats->normalized_bytes += b->nbytes; }
+      k = k_next;
+      prefetched = next_up;
+      if (next_up) { loc.swap(loc_next); src = src_next; }
     }
+    if (l && l->up_stream) (void)hipStreamSynchronize(l->up_stream);          // (an error may leave an upload in flight)
     if (rc != TM_OK) {
       { std::lock_guard<std::mutex> g(mu); if (first_error == TM_OK) { first_error = rc; first_msg = last_error(); } }
       cv.notify_all();

@@ -1290,14 +1290,79 @@ int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) 
 }
 
 // after a run: make sure the output buffer was large enough; if not, grow it and redo the emit stage
+// ---- small transfers through the pinned mailbox -----------------------------------------------------------------
+__global__ void k_copy_small(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t n, int words) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (words) { if (i < n / 8) reinterpret_cast<uint64_t*>(dst)[i] = reinterpret_cast<const uint64_t*>(src)[i]; }
+  else if (i < n) dst[i] = src[i];
+}
+static void launch_copy_small(const void* src, void* dst, uint64_t n, hipStream_t st) {
+  const int words = (((uintptr_t)src | (uintptr_t)dst | n) & 7u) == 0;
+  const uint64_t items = words ? n / 8 : n;
+  k_copy_small<<<(uint32_t)((items + 255) / 256), 256, 0, st>>>((const uint8_t*)src, (uint8_t*)dst, n, words);
+}
+static int mail_slot(tm_batch* b, uint64_t bytes, hipStream_t st, uint8_t** slot) {
+  hipError_t e;
+  if (!b->h_mail && (e = hipHostMalloc((void**)&b->h_mail, MAIL_BYTES, hipHostMallocDefault)) != hipSuccess) { b->h_mail = nullptr; return hip_fail(e, "hipHostMalloc (mailbox)"); }
+  const uint64_t need = (bytes + 63) & ~63ull;
+  if (b->mail_pos + need > MAIL_BYTES) {            // wrap: every copy kernel that reads or writes a slot handed out so far must be done
+    for (hipStream_t s2 : b->mail_streams) { int rc = small_sync(b, s2); if (rc != TM_OK) return rc; }
+    if (!b->mail_pending.empty()) return set_error(TM_E_INVALID, "mailbox wrapped with transfers pending");
+    b->mail_streams.clear();
+    b->mail_pos = 0;
+  }
+  if (std::find(b->mail_streams.begin(), b->mail_streams.end(), st) == b->mail_streams.end()) b->mail_streams.push_back(st);
+  *slot = b->h_mail + b->mail_pos;
+  b->mail_pos += need;
+  return TM_OK;
+}
+int small_d2h(tm_batch* b, void* host_dst, const void* dev_src, uint64_t bytes, hipStream_t st) {
+  if (bytes == 0) return TM_OK;
+  if (bytes > MAIL_MAX) {
+    hipError_t e = hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st);
+    return e == hipSuccess ? TM_OK : hip_fail(e, "D2H");
+  }
+  uint8_t* slot = nullptr;
+  int rc = mail_slot(b, bytes, st, &slot);
+  if (rc != TM_OK) return rc;
+  launch_copy_small(dev_src, slot, bytes, st);
+  b->mail_pending.push_back({host_dst, slot, bytes, st});
+  return TM_OK;
+}
+int small_h2d(tm_batch* b, void* dev_dst, const void* host_src, uint64_t bytes, hipStream_t st) {
+  if (bytes == 0) return TM_OK;
+  if (bytes > MAIL_MAX) {
+    hipError_t e = hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st);   // (pageable sources are staged before this returns)
+    return e == hipSuccess ? TM_OK : hip_fail(e, "H2D");
+  }
+  uint8_t* slot = nullptr;
+  int rc = mail_slot(b, bytes, st, &slot);
+  if (rc != TM_OK) return rc;
+  std::memcpy(slot, host_src, bytes);
+  launch_copy_small(slot, dev_dst, bytes, st);
+  return TM_OK;
+}
+int small_sync(tm_batch* b, hipStream_t st) {
+  hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  size_t keep = 0;
+  for (auto& m : b->mail_pending) {
+    if (m.st == st) std::memcpy(m.dst, m.slot, m.n);
+    else b->mail_pending[keep++] = m;
+  }
+  b->mail_pending.resize(keep);
+  return TM_OK;
+}
+
 int ensure_output(tm_batch* b) {
   { int rc = enter_device(b->vocab); if (rc != TM_OK) return rc; }
   hipError_t e;
-  uint64_t totals[3];
+  uint64_t* totals = b->last_totals;
   uint32_t err = 0;
-  if ((e = hipStreamSynchronize(b->last_stream)) != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
-  if ((e = hipMemcpy(totals, b->d_totals, sizeof totals, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "hipMemcpy totals");
-  if ((e = hipMemcpy(&err, b->d_error, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "hipMemcpy error flag");
+  { int rc = small_d2h(b, totals, b->d_totals, 3 * sizeof(uint64_t), b->last_stream);
+    if (rc == TM_OK) rc = small_d2h(b, &err, b->d_error, 4, b->last_stream);
+    if (rc == TM_OK) rc = small_sync(b, b->last_stream);
+    if (rc != TM_OK) return rc; }
   if (err != 0) return set_error(TM_E_HIP, "device pipeline inconsistency (unreachable segment entry state)");
   uint64_t total = b->ndocs ? totals[1] : 0;
   if (total > b->out_cap) {
@@ -1375,7 +1440,7 @@ void tm_batch_free(tm_batch* b) {
   for (void* p : ptrs) (void)hipFree(p);
   if (b->have_events) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
   if (b->aux_stream) (void)hipStreamDestroy(b->aux_stream);
-  (void)hipHostFree(b->h_fb_raw); (void)hipHostFree(b->h_fb_norm);
+  (void)hipHostFree(b->h_fb_raw); (void)hipHostFree(b->h_fb_norm); (void)hipHostFree(b->h_mail);
   delete b;
 }
 
@@ -1402,7 +1467,7 @@ int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
   }
   hipError_t e;
   if (nbytes && (e = hipMemcpyAsync(b->d_text, text, nbytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D text");
-  if (ndocs && (e = hipMemcpyAsync(b->d_offsets, offsets, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D offsets");
+  if (ndocs) { int rc = small_h2d(b, b->d_offsets, offsets, ((uint64_t)ndocs + 1) * 8, st); if (rc != TM_OK) return rc; }
   b->ndocs = ndocs;
   b->nbytes = nbytes;
   b->nseg = nseg;

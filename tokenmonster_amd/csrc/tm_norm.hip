@@ -574,7 +574,7 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
   if ((e = grow(&b->d_slab, &b->slab_cap, (npieces + 1) * (uint64_t)SLAB)) != hipSuccess) return hip_fail(e, "hipMalloc (normalizer slabs)");
   if (nbytes && (e = hipMemcpyAsync(b->d_raw, raw, nbytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D raw text");
   b->h_raw_off.assign(raw_offsets, raw_offsets + (ndocs ? ndocs + 1 : 0));      // (the batch's own copy: it outlives the caller's array)
-  if (ndocs && (e = hipMemcpyAsync(b->d_raw_off, b->h_raw_off.data(), ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D raw offsets");
+  if (ndocs) { int rc = small_h2d(b, b->d_raw_off, b->h_raw_off.data(), ((uint64_t)ndocs + 1) * 8, st); if (rc != TM_OK) return rc; }
   b->raw_bytes = nbytes;
   b->raw_docs = ndocs;
   b->raw_pieces = npieces;
@@ -616,8 +616,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   k_norm_carry<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids,
                                                   normalize_on_device(capcode, norm_flag) ? 0u : 1u);
   unsigned long long h_info[4] = {0, 0, 0, 0};
-  if ((e = hipMemcpyAsync(h_info, ninfo, 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
-    return hip_fail(e, "normalize (summaries)");
+  { int rc = small_d2h(b, h_info, ninfo, 8, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
   const double t1 = now();
   const uint32_t nf = (uint32_t)h_info[0];
   std::vector<uint32_t> ids;
@@ -638,23 +637,20 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     hipStream_t sx = b->aux_stream;
     // the (unordered) list k_norm_carry has left on the device, put into document order
     ids.resize(nf);
-    if ((e = hipMemcpyAsync(ids.data(), b->d_fb_ids, (size_t)nf * 4, hipMemcpyDeviceToHost, sx)) != hipSuccess || (e = hipStreamSynchronize(sx)) != hipSuccess)
-      return hip_fail(e, "D2H fallback list");
+    { int rc = small_d2h(b, ids.data(), b->d_fb_ids, (uint64_t)nf * 4, sx); if (rc == TM_OK) rc = small_sync(b, sx); if (rc != TM_OK) return rc; }
     std::sort(ids.begin(), ids.end());
     roff.assign(ids.size() + 1, 0);
     for (size_t k = 0; k < ids.size(); k++) roff[k + 1] = roff[k] + (b->h_raw_off[ids[k] + 1] - b->h_raw_off[ids[k]]);
-    if ((e = grow(&b->d_fb_raw, &b->fb_raw_cap, roff.back() + 16)) != hipSuccess) return hip_fail(e, "hipMalloc (fallback staging)");
     if (!b->h_fb_raw || b->h_fb_raw_cap < roff.back() + 16) {
       (void)hipHostFree(b->h_fb_raw);
       b->h_fb_raw = nullptr;
       b->h_fb_raw_cap = roff.back() + roff.back() / 4 + 4096;
       if ((e = hipHostMalloc((void**)&b->h_fb_raw, b->h_fb_raw_cap, hipHostMallocDefault)) != hipSuccess) return hip_fail(e, "hipHostMalloc (fallback staging)");
     }
-    if ((e = hipMemcpyAsync(b->d_fb_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, sx)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_fb_roff, roff.data(), roff.size() * 8, hipMemcpyHostToDevice, sx)) != hipSuccess) return hip_fail(e, "H2D fallback lists");
-    k_gather_docs<<<(uint32_t)ids.size(), 256, 0, sx>>>(b->d_raw, b->d_raw_off, b->d_fb_ids, b->d_fb_roff, (uint32_t)ids.size(), b->d_fb_raw);
-    if ((e = hipMemcpyAsync(b->h_fb_raw, b->d_fb_raw, roff.back(), hipMemcpyDeviceToHost, sx)) != hipSuccess || (e = hipStreamSynchronize(sx)) != hipSuccess)
-      return hip_fail(e, "D2H fallback documents");
+    { int rc = small_h2d(b, b->d_fb_ids, ids.data(), ids.size() * 4, sx); if (rc == TM_OK) rc = small_h2d(b, b->d_fb_roff, roff.data(), roff.size() * 8, sx); if (rc != TM_OK) return rc; }
+    // the gather writes straight into the pinned host buffer (no staging copy, nothing on the copy engines)
+    k_gather_docs<<<(uint32_t)ids.size(), 256, 0, sx>>>(b->d_raw, b->d_raw_off, b->d_fb_ids, b->d_fb_roff, (uint32_t)ids.size(), b->h_fb_raw);
+    if ((e = hipStreamSynchronize(sx)) != hipSuccess) return hip_fail(e, "fallback documents to the host");
     f2 = now();
   }
   uint64_t gpu_bytes = 0;
@@ -682,9 +678,8 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     hnorm = b->h_fb_norm;
     f3 = now();
   }
-  if ((e = hipMemcpyAsync(h_info, ninfo, 32, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(&gpu_bytes, b->d_totals + 2, 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "normalize (device pass)");
+  { int rc = small_d2h(b, h_info, ninfo, 32, st); if (rc == TM_OK) rc = small_d2h(b, &gpu_bytes, b->d_totals + 2, 8, st); if (rc == TM_OK) rc = small_sync(b, st);
+    if (rc != TM_OK) return rc; }
   if (gpu_bytes + noff.back() > b->max_bytes) {
     return set_error(TM_E_LIMIT, "normalized text needs %llu bytes, workspace sized for %llu", (unsigned long long)(gpu_bytes + noff.back()), (unsigned long long)b->max_bytes);
   }
@@ -700,10 +695,9 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   k_norm_ranges<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);
   uint64_t total = gpu_bytes;
   if (nf > 0) {
-    if ((e = grow(&b->d_fb_norm, &b->fb_norm_cap, noff.back() + 16)) != hipSuccess) return hip_fail(e, "hipMalloc (fallback output)");
-    if ((e = hipMemcpyAsync(b->d_fb_norm, hnorm, noff.back(), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_fb_noff, noff.data(), noff.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D fallback output");
-    k_place_fallback<<<(uint32_t)ids.size(), 256, 0, st>>>(b->d_fb_norm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), total, b->d_text, b->d_nbegin, b->d_nend);
+    // the placement kernel reads the host normalizer's output where it lies (pinned host memory)
+    { int rc = small_h2d(b, b->d_fb_noff, noff.data(), noff.size() * 8, st); if (rc != TM_OK) return rc; }
+    k_place_fallback<<<(uint32_t)ids.size(), 256, 0, st>>>(hnorm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), total, b->d_text, b->d_nbegin, b->d_nend);
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "fallback placement");
     total += noff.back();
     b->host_fallback_docs = (uint32_t)ids.size();
@@ -713,8 +707,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   const double t2 = now();
   // ---- what the tokenize pipeline needs to know on the host: #segments, and the long documents if any ------------
   k_norm_info<<<(nd + 255) / 256, 256, 0, st>>>(b->d_nbegin, b->d_nend, nd, ninfo, long_segs());
-  if ((e = hipMemcpyAsync(h_info, ninfo, 24, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess)
-    return hip_fail(e, "normalize (ranges)");
+  { int rc = small_d2h(b, h_info, ninfo, 24, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
   b->nbytes = total;
   b->nseg = h_info[2];
   int rc = TM_OK;

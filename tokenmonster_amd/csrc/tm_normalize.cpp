@@ -17,10 +17,12 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <algorithm>
 #include <cstring>
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 namespace tmh {
 
@@ -28,52 +30,53 @@ namespace tmh {
 // documents, and spawning their threads every time cost more than the work (64 fresh threads: 4 ms for 2 ms of work).
 // Workers are created on first use and never joined (the pool object is leaked on purpose: no destructor-order problems at
 // exit).  `work` must be a loop that pulls from a shared queue: helpers that do not wake up in time are simply not used.
+// Several jobs can be open at once (the lanes of the host-to-host pipeline each normalize a few fallback documents at the same
+// time): an idle worker joins whichever open job still wants helpers.
 namespace {
+struct Job { const std::function<void()>* work; uint32_t want, started = 0, running = 0; };
 struct WorkerPool {
   std::mutex mu;
   std::condition_variable cv_work, cv_done;
   size_t nthreads = 0;
-  const std::function<void()>* job = nullptr;
-  uint64_t generation = 0;
-  uint32_t want = 0, started = 0, running = 0;
+  std::vector<Job*> jobs;                        // open jobs
+  Job* pick() { for (Job* j : jobs) if (j->started < j->want) return j; return nullptr; }
   void worker() {
-    uint64_t seen = 0;
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
-      cv_work.wait(lk, [&] { return generation != seen; });
-      seen = generation;
-      if (started >= want) continue;            // not needed for this job (or it is over already)
-      started++; running++;
-      const std::function<void()>* j = job;
+      Job* j = nullptr;
+      cv_work.wait(lk, [&] { return (j = pick()) != nullptr; });
+      j->started++; j->running++;
       lk.unlock();
-      (*j)();
+      (*j->work)();
       lk.lock();
-      if (--running == 0) cv_done.notify_all();
+      if (--j->running == 0) cv_done.notify_all();
     }
   }
 };
 WorkerPool* g_pool = nullptr;
-std::mutex g_pool_call;    // one job at a time
+std::mutex g_pool_create;
 }  // namespace
 
 void run_on_workers(uint32_t threads, const std::function<void()>& work) {
   if (threads <= 1) { work(); return; }
-  std::lock_guard<std::mutex> call(g_pool_call);
-  if (!g_pool) g_pool = new WorkerPool();
+  { std::lock_guard<std::mutex> g(g_pool_create); if (!g_pool) g_pool = new WorkerPool(); }
   WorkerPool& p = *g_pool;
-  const uint32_t helpers = threads - 1;
+  Job job{&work, threads - 1};
   {
     std::unique_lock<std::mutex> lk(p.mu);
-    while (p.nthreads < helpers) { std::thread([&p] { p.worker(); }).detach(); p.nthreads++; }
-    p.job = &work; p.want = helpers; p.started = 0; p.running = 0; p.generation++;
+    size_t wanted = job.want;
+    for (Job* j : p.jobs) wanted += j->want;
+    const size_t cap = std::max<size_t>(job.want, std::max(1u, std::thread::hardware_concurrency()));
+    while (p.nthreads < std::min(wanted, cap)) { std::thread([&p] { p.worker(); }).detach(); p.nthreads++; }
+    p.jobs.push_back(&job);
   }
-  if (helpers >= p.nthreads) p.cv_work.notify_all();
-  else for (uint32_t k = 0; k < helpers; k++) p.cv_work.notify_one();   // (a pool that once served 256 threads is not woken for a job of 4)
+  if (job.want >= p.nthreads) p.cv_work.notify_all();
+  else for (uint32_t k = 0; k < job.want; k++) p.cv_work.notify_one();   // (a pool that once served 256 threads is not woken for a job of 4)
   work();                                       // the caller works too
   std::unique_lock<std::mutex> lk(p.mu);
-  p.want = 0;                                   // late wakers find nothing to do
-  p.cv_done.wait(lk, [&] { return p.running == 0; });
-  p.job = nullptr;
+  job.want = job.started;                       // late wakers find nothing to do
+  p.cv_done.wait(lk, [&] { return job.running == 0; });
+  p.jobs.erase(std::find(p.jobs.begin(), p.jobs.end(), &job));
 }
 
 }  // namespace tmh

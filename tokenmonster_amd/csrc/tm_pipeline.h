@@ -101,6 +101,13 @@ struct tm_batch {
   // grow-only staging for the host fallback
   uint8_t* d_fb_raw = nullptr; uint8_t* d_fb_norm = nullptr; uint64_t* d_fb_roff = nullptr; uint64_t* d_fb_noff = nullptr; uint32_t* d_fb_ids = nullptr;
   uint64_t fb_raw_cap = 0, fb_norm_cap = 0;
+  // small transfers (counters, lists of a few hundred KB) go through a pinned mailbox and a copy kernel on the caller's stream
+  // instead of the copy engines, where they would queue behind the bulk transfers of other lanes (small_d2h / small_h2d)
+  uint8_t* h_mail = nullptr; uint64_t mail_pos = 0;
+  struct MailPending { void* dst; const uint8_t* slot; uint64_t n; hipStream_t st; };
+  std::vector<MailPending> mail_pending;
+  std::vector<hipStream_t> mail_streams;   // streams that have used mailbox slots since it last wrapped
+  uint64_t last_totals[3] = {0, 0, 0};   // d_totals as read by ensure_output
   uint8_t* h_fb_raw = nullptr; uint8_t* h_fb_norm = nullptr;     // pinned host staging of the fallback documents (raw in, normalized out)
   uint64_t h_fb_raw_cap = 0, h_fb_norm_cap = 0;
   uint32_t* d_out = nullptr;
@@ -127,6 +134,12 @@ void launch_doc_exits(tm_batch* b, uint8_t* d_exits, hipStream_t st);
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
                        uint32_t n_ids, hipStream_t st);
 int ensure_output(tm_batch* b);
+// small device <-> host transfers that bypass the copy engines (tm_kernels.hip).  small_d2h's destination is filled by small_sync
+// (which synchronizes the stream); small_h2d's source may be reused as soon as the call returns (pageable memory, or at most MAIL_MAX bytes).
+constexpr uint64_t MAIL_BYTES = 4ull << 20, MAIL_MAX = 1ull << 20;
+int small_d2h(tm_batch* b, void* host_dst, const void* dev_src, uint64_t bytes, hipStream_t st);
+int small_h2d(tm_batch* b, void* dev_dst, const void* host_src, uint64_t bytes, hipStream_t st);
+int small_sync(tm_batch* b, hipStream_t st);
 int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, hipStream_t st);
 void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* out, hipStream_t st);
 // tm_norm.hip
