@@ -813,11 +813,39 @@ __global__ void k_doc_events(const uint32_t* __restrict__ doc_ntok, const uint32
 // ------------------------------------------------------------------------------------------------
 // hist layout (all uint32, so that one RCCL all-reduce(sum) merges ranks): scores[n_ids] | tokens_in_text as
 // four 16-bit limbs | missing[256] (per-byte counters, > 0 = that byte had no token)
-// The scoring variant keeps most of the histogram traffic in LDS: persistent workgroups (one per CU) own a
-// direct-mapped table of HSLOTS {id, count} counters; an id that finds its slot free or already its own adds in
-// LDS, anything else falls through to a global atomic; slots are flushed once when the workgroup retires.  Without
-// this, the hot ids (" the", ",") serialise tens of millions of L2 atomics on a handful of addresses.
+// The scoring variant keeps most of the histogram traffic in LDS: persistent workgroups (one per CU) own a two-way
+// set-associative table of HSLOTS counters {id << 32 | bytes}.  An id that finds itself in its set adds in LDS; one that does
+// not takes the way with the smaller count if that count is still below HSTICKY (the evicted counter is flushed with one global
+// atomic) and otherwise falls through to a global atomic itself: hot ids become sticky after a few occurrences, whichever id
+// came first, and only the cold ids of a set — spread over many addresses — go to the L2.  (A direct-mapped first-come table
+// left 4.2 of the kernel's 8.2 ms in global atomics on a 65 536-id vocabulary: eight ids per slot, the hottest not always the
+// owner, and atomics on one address serialise in the L2.)  Counters are flushed when the workgroup retires.
 constexpr int HSLOTS = 8192;
+constexpr uint32_t HSTICKY = 512;
+constexpr unsigned long long HEMPTY = 0xFFFFFFFF00000000ull;
+__device__ __forceinline__ void hist_add(unsigned long long* s_w, uint32_t* __restrict__ scores, uint32_t id, uint32_t adv) {
+  unsigned long long* set = s_w + 2u * ((id * 0x9E3779B1u) >> (32 - 12));
+  static_assert(HSLOTS == 2 << 12, "set index is 12 bits");
+  for (;;) {
+    const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(set);
+    const uint32_t t0 = (uint32_t)(w.x >> 32), t1 = (uint32_t)(w.y >> 32), c0 = (uint32_t)w.x, c1 = (uint32_t)w.y;
+    if (t0 == id || t1 == id) {
+      const int way = t0 == id ? 0 : 1;
+      const unsigned long long old = way ? w.y : w.x;
+      // a sticky counter can no longer change hands: plain add (same-address adds of a wavefront are serialised by the LDS, no retries)
+      if ((uint32_t)old >= HSTICKY) { atomicAdd(&set[way], (unsigned long long)adv); return; }
+      if (atomicCAS(&set[way], old, old + adv) == old) return;
+      continue;
+    }
+    const int way = c1 < c0 ? 1 : 0;
+    const unsigned long long old = way ? w.y : w.x;
+    if ((uint32_t)old >= HSTICKY) { atomicAdd(&scores[id], adv); return; }          // both ways are hot ids
+    if (atomicCAS(&set[way], old, ((unsigned long long)id << 32) | adv) == old) {
+      if ((uint32_t)old != 0) atomicAdd(&scores[(uint32_t)(old >> 32)], (uint32_t)old);
+      return;
+    }
+  }
+}
 
 // K4 as a chain walk through LDS tiles (a parallel list ranking of all 512 states of a segment, of which ~60 are on the chain,
 // was measured at 5.5 ms per GiB against 3.3 for this walk and has been removed).  A wavefront takes TS consecutive segments: their T(p,0) words are streamed into LDS
@@ -982,10 +1010,10 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
                                                         uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
                                                         uint32_t* __restrict__ missing_bits, uint32_t* __restrict__ error_flag) {
   __shared__ alignas(16) uint32_t s_tile[WV][TS][TROW];
-  __shared__ uint32_t s_tag[HSLOTS], s_cnt[HSLOTS];
+  __shared__ alignas(16) unsigned long long s_w[HSLOTS];
   __shared__ unsigned long long s_ntok;
   __shared__ uint32_t s_ndel;
-  for (int j = threadIdx.x; j < HSLOTS; j += WV * 64) { s_tag[j] = 0xFFFFFFFFu; s_cnt[j] = 0; }
+  for (int j = threadIdx.x; j < HSLOTS; j += WV * 64) s_w[j] = HEMPTY;
   if (threadIdx.x == 0) { s_ntok = 0; s_ndel = 0; }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -994,31 +1022,38 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
     const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
     const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
     tile_load(s_tile[wv], t, g0, nv, lane, R0);
+    // Walk (TS lanes, a chain each): the words of the chain are only collected — word number h of a segment's chain goes to word h
+    // of its own row, always in front of the position being read (a step advances at least one byte and TSLACK = 2) ...
+    uint32_t staged = 0;
     if (t.have) {
-      const uint32_t* row = s_tile[wv][lane];
+      uint32_t* row = s_tile[wv][lane];
       uint32_t p = t.entry >> 1, fd = t.entry & 1u;
       const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
       int hop = 0;
       for (; hop <= 2 * SEG && p < t.seglen; hop++) {
         const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, g0 + lane, p);
         if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }
-        const uint32_t id = w & ID_NONE, adv = (w >> 24) & 63u;
         fd = (w >> 30) & 1u;
         if (w >> 31) {                                       // trainvocab.go:1166-1173: no token for this byte
           const uint32_t byte = text[t.begin + p];
           atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
-        } else {                                             // scores[id] += bytes covered (:1109..1162)
-          const uint32_t slot = id & (HSLOTS - 1);
-          uint32_t owner = s_tag[slot];
-          if (owner == 0xFFFFFFFFu) { owner = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, id); if (owner == 0xFFFFFFFFu) owner = id; }
-          if (owner == id) atomicAdd(&s_cnt[slot], adv);
-          else atomicAdd(&scores[id], adv);
-        }
+        } else row[staged++] = w;
         ntok += 1 + fd;                                      // tokensInText++ (also for a missing byte, :1169) / += 2
         ndel += fd;                                          // scores[deleteToken]++ (:1134,1143,1152)
-        p += adv;
+        p += (w >> 24) & 63u;
       }
       if (hop > 2 * SEG) atomicOr(error_flag, 2u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    // ... and counted by all 64 lanes: scores[id] += bytes covered (:1109..1162), through the workgroup's LDS histogram
+    for (int sg = 0; sg < nv; sg++) {
+      const uint32_t n = (uint32_t)__shfl((int)staged, sg);
+      for (uint32_t j = (uint32_t)lane; j < n; j += 64u) {
+        const uint32_t w = s_tile[wv][sg][j];
+        const uint32_t id = w & ID_NONE, adv = (w >> 24) & 63u;
+        hist_add(s_w, scores, id, adv);
+      }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
@@ -1030,7 +1065,7 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
   }
   __syncthreads();
   for (int j = threadIdx.x; j < HSLOTS; j += WV * 64)
-    if (s_cnt[j] != 0) atomicAdd(&scores[s_tag[j]], s_cnt[j]);
+    if ((uint32_t)s_w[j] != 0) atomicAdd(&scores[(uint32_t)(s_w[j] >> 32)], (uint32_t)s_w[j]);
   if (threadIdx.x == 0) {
     if (s_ndel) atomicAdd(&scores[delete_id], s_ndel);
     if (s_ntok) atomicAdd(tokens, s_ntok);
@@ -1116,7 +1151,7 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
   const uint64_t nseg = b->nseg;
   if (nseg > 0) {
     launch_seg_params(b, st);
-    constexpr int WV = SEG <= 256 ? 10 : 5;      // wavefronts of a scoring workgroup: as many tiles as fit the LDS beside the histogram
+    constexpr int WV = SEG <= 256 ? 11 : 5;      // wavefronts of a scoring workgroup: as many tiles as fit the LDS beside the histogram
     k_score_tiles<WV><<<(uint32_t)std::min<uint64_t>((nseg + WV * TS - 1) / (WV * TS), (uint64_t)n_cu), WV * 64, 0, st>>>(
         b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_seg_par, nseg, delete_id, d_hist, d_tokens, d_missing_bits, b->d_error);
   }
