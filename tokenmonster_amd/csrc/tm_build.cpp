@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -78,9 +79,10 @@ uint32_t decode_last_rune(const uint8_t* b, size_t len, uint32_t charset) {
   return r.r;
 }
 
-bool uni_letter(uint32_t r) { return (U_GET_GC_MASK((UChar32)r) & U_GC_L_MASK) != 0; }
-bool uni_number(uint32_t r) { return (U_GET_GC_MASK((UChar32)r) & U_GC_N_MASK) != 0; }
-bool uni_mark(uint32_t r) { return (U_GET_GC_MASK((UChar32)r) & U_GC_M_MASK) != 0; }
+// (ASCII answered without the ICU property trie: most runes of a vocabulary are ASCII and the builder classifies each several times)
+inline bool uni_letter(uint32_t r) { return r < 0x80 ? ((r | 0x20u) - 'a') < 26u : (U_GET_GC_MASK((UChar32)r) & U_GC_L_MASK) != 0; }
+inline bool uni_number(uint32_t r) { return r < 0x80 ? (r - '0') < 10u : (U_GET_GC_MASK((UChar32)r) & U_GC_N_MASK) != 0; }
+inline bool uni_mark(uint32_t r) { return r < 0x80 ? false : (U_GET_GC_MASK((UChar32)r) & U_GC_M_MASK) != 0; }
 bool uni_space(uint32_t r) {
   if (r < 0x100) return r == '\t' || r == '\n' || r == '\v' || r == '\f' || r == '\r' || r == ' ' || r == 0x85 || r == 0xA0;
   return u_hasBinaryProperty((UChar32)r, UCHAR_WHITE_SPACE);
@@ -95,8 +97,65 @@ bool is_capcode(uint32_t r, uint32_t cc) {
   return (cc == 1 && r == 0x7F) || (cc == 2 && (r == 'C' || r == 'W' || r == 'D'));
 }
 
+// What the Go builder keeps in three maps keyed by the token string (idsMap, scoresMap, specialMap) plus the dictionary's Find:
+// one open-addressing table over string views.  Prefix look-ups (the alternatives of a token are its own prefixes, go :3597) take
+// the FNV-1a hash of every prefix from one pass over the token.
+struct Entry {
+  std::string_view key;
+  uint32_t id = TM_NONE;        // idsMap
+  uint32_t index = TM_NONE;     // position in the sorted dictionary (dictionary.Find), TM_NONE = not a dictionary key
+  bool neg = false;             // scoresMap[key] = -1
+  bool special = false;         // specialMap
+};
+inline uint64_t fnv_step(uint64_t h, uint8_t c) { return (h ^ c) * 0x100000001B3ull; }
+constexpr uint64_t kFnvInit = 0xCBF29CE484222325ull;
+inline uint64_t fnv(std::string_view s) { uint64_t h = kFnvInit; for (unsigned char c : s) h = fnv_step(h, c); return h; }
+class StrTable {
+ public:
+  explicit StrTable(size_t expect) {
+    size_t cap = 64;
+    while (cap < expect * 2 + 16) cap <<= 1;
+    slots_.assign(cap, Slot{0, 0});
+  }
+  Entry* find(std::string_view k, uint64_t h) {
+    const size_t mask = slots_.size() - 1;
+    for (size_t i = (size_t)(h ^ (h >> 29)) & mask;; i = (i + 1) & mask) {
+      const Slot& sl = slots_[i];
+      if (sl.entry == 0) return nullptr;
+      if (sl.hash == h) { Entry& en = entries_[sl.entry - 1]; if (en.key == k) return &en; }
+    }
+  }
+  Entry* find(std::string_view k) { return find(k, fnv(k)); }
+  // `k` must outlive the table (it views the caller's token list or the arena of "D "-prefixed copies)
+  Entry& get_or_add(std::string_view k) {
+    const uint64_t h = fnv(k);
+    if (Entry* e = find(k, h)) return *e;
+    if ((entries_.size() + 1) * 2 > slots_.size()) grow();
+    entries_.emplace_back();
+    entries_.back().key = k;
+    place(h, (uint32_t)entries_.size());
+    return entries_.back();
+  }
+ private:
+  struct Slot { uint64_t hash; uint32_t entry; };       // entry number + 1, 0 = free
+  void place(uint64_t h, uint32_t e) {
+    const size_t mask = slots_.size() - 1;
+    size_t i = (size_t)(h ^ (h >> 29)) & mask;
+    while (slots_[i].entry != 0) i = (i + 1) & mask;
+    slots_[i] = Slot{h, e};
+  }
+  void grow() {
+    std::vector<Slot> os;
+    os.swap(slots_);
+    slots_.assign(os.size() * 2, Slot{0, 0});
+    for (const Slot& sl : os) if (sl.entry) place(sl.hash, sl.entry);
+  }
+  std::vector<Slot> slots_;
+  std::deque<Entry> entries_;        // (references stay valid while the table grows)
+};
+
 struct Rec {
-  std::string key;
+  std::string_view key;
   uint32_t id = 0;
   float score = 1.0f;
   bool special = false;
@@ -104,14 +163,14 @@ struct Rec {
   uint32_t index1 = TM_NONE, index2 = TM_NONE;
 };
 
-bool key_less(const std::string& a, const std::string& b) {
+bool key_less(std::string_view a, std::string_view b) {
   if (a.size() != b.size()) return a.size() < b.size();
   return std::memcmp(a.data(), b.data(), a.size()) < 0;
 }
 
 // go/tokenmonster.go:287-299 with ungreedySuffixes {"'s", "’s"} (:3157)
-int has_suffix_pos(const std::string& key, uint32_t charset, uint32_t cc) {
-  static const std::string sfx[2] = {"'s", "\xE2\x80\x99s"};
+int has_suffix_pos(std::string_view key, uint32_t charset, uint32_t cc) {
+  static const std::string_view sfx[2] = {"'s", "\xE2\x80\x99s"};
   for (const auto& s : sfx) {
     if (key.size() >= s.size() && key.compare(key.size() - s.size(), s.size(), s) == 0) {
       if (s.size() < key.size()) {
@@ -136,46 +195,49 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
                       std::vector<uint8_t>& image, const std::vector<float>* token_scores) {
   if (capcode > 2 || charset > 2) return set_error(TM_E_INVALID, "capcode/charset out of range");
   // ---- dic1: unique tokens in (length, bytewise) order  (go :3364-3380) -------------------------
-  std::vector<std::pair<std::string, bool>> dic1;
+  std::vector<std::pair<std::string_view, bool>> dic1;
   dic1.reserve(tokens_in.size());
-  std::unordered_map<std::string, float> given_scores;   // the score column of the .vocab records (go :2636); 1.0 when not given
+  std::unordered_map<std::string_view, float> given_scores;   // the score column of the .vocab records (go :2636); 1.0 when not given
   for (size_t k = 0; k < tokens_in.size(); k++) {
     if (tokens_in[k].empty()) continue;
     if (tokens_in[k].size() > 40) return set_error(TM_E_INVALID, "token longer than 40 bytes");
-    dic1.emplace_back(tokens_in[k], k < special_in.size() && special_in[k] != 0);
-    if (token_scores && k < token_scores->size()) given_scores[tokens_in[k]] = std::max(0.0f, (*token_scores)[k]);
+    dic1.emplace_back(std::string_view(tokens_in[k]), k < special_in.size() && special_in[k] != 0);
+    if (token_scores && k < token_scores->size()) given_scores[std::string_view(tokens_in[k])] = std::max(0.0f, (*token_scores)[k]);
   }
-  std::sort(dic1.begin(), dic1.end(), [](const auto& a, const auto& b) { return key_less(a.first, b.first); });
+  std::stable_sort(dic1.begin(), dic1.end(), [](const auto& a, const auto& b) { return key_less(a.first, b.first); });
   dic1.erase(std::unique(dic1.begin(), dic1.end(), [](const auto& a, const auto& b) { return a.first == b.first; }),
              dic1.end());
   if (dic1.size() >= TM_NONE - 2) return set_error(TM_E_LIMIT, "too many tokens");
 
   // ---- IDs + "D "-duplicates  (go :3423-3470) ---------------------------------------------------
-  std::unordered_map<std::string, uint32_t> ids;       // idsMap
-  std::unordered_map<std::string, float> scores;       // scoresMap (only the -1 marker matters)
-  std::unordered_map<std::string, bool> specials;      // specialMap
-  ids.reserve(dic1.size() * 2);
-  std::vector<std::string> keys;
+  StrTable table(dic1.size() * 2);
+  std::vector<char> arena;                              // the "D "-prefixed copies (reserved up front: views into it stay valid)
+  { size_t need = 0; for (auto& d : dic1) need += d.first.size() + 2; arena.reserve(need); }
+  std::vector<std::string_view> keys;
   keys.reserve(dic1.size() * 2);
-  const std::string add = std::string(1, capcode == 1 ? (char)0x7F : 'D') + " ";
+  const char add0 = capcode == 1 ? (char)0x7F : 'D';
   uint32_t next_id = 0;
   size_t n_single = 0;
   for (auto& [tok, sp] : dic1) {
     if (tok.size() == 1) n_single++;
-    if (sp) specials[tok] = true;
-    uint32_t id;
-    auto it = ids.find(tok);
-    if (it != ids.end()) id = it->second;  // e.g. a real token equal to an earlier token's duplicate
-    else { id = next_id++; keys.push_back(tok); }
-    ids[tok] = id;
+    Entry& e = table.get_or_add(tok);
+    if (sp) e.special = true;
+    if (e.id == TM_NONE) { e.id = next_id++; keys.push_back(tok); }   // (else: a real token equal to an earlier token's duplicate keeps that id)
+    const uint32_t id = e.id;
     Rune r = decode_rune((const uint8_t*)tok.data(), tok.size(), charset);
     if (capcode != 0 && is_alnum(r.r, capcode)) {
-      std::string s = add + tok;
-      if (sp) specials[s] = true;
-      if (s.size() <= 40) {
-        if (ids.find(s) == ids.end()) keys.push_back(s);
-        ids[s] = id;
-        scores[s] = -1.0f;
+      const size_t at = arena.size();
+      arena.push_back(add0); arena.push_back(' ');
+      arena.insert(arena.end(), tok.begin(), tok.end());
+      const std::string_view sv(arena.data() + at, tok.size() + 2);
+      if (sp || sv.size() <= 40) {
+        Entry& d = table.get_or_add(sv);
+        if (sp) d.special = true;
+        if (sv.size() <= 40) {
+          if (d.id == TM_NONE) keys.push_back(sv);
+          d.id = id;
+          d.neg = true;
+        }
       }
     }
   }
@@ -186,17 +248,15 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
   uint32_t vocab_size = n_tokens + (unk != TM_NONE ? 1 : 0);
   uint32_t n_reverse = vocab_size;
 
-  std::sort(keys.begin(), keys.end(), key_less);      // dictionary.Build(): pansearch order
+  std::sort(keys.begin(), keys.end(), [](std::string_view a, std::string_view b) { return key_less(a, b); });      // dictionary.Build(): pansearch order
   keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
   const uint32_t n_info = (uint32_t)keys.size();
-  std::unordered_map<std::string_view, uint32_t> find;  // dictionary.Find
-  find.reserve(n_info * 2);
-  for (uint32_t i = 0; i < n_info; i++) find.emplace(std::string_view(keys[i]), i);
+  for (uint32_t i = 0; i < n_info; i++) table.find(keys[i])->index = i;                                             // dictionary.Find
 
   // deleteToken index (go :3474-3483)
   uint32_t delete_index = TM_NONE;
-  if (capcode == 2) { auto it = find.find(std::string_view("D", 1)); if (it != find.end()) delete_index = it->second; }
-  else if (capcode == 1) { auto it = find.find(std::string_view("\x7F", 1)); if (it != find.end()) delete_index = it->second; }
+  if (capcode == 2) { Entry* e = table.find(std::string_view("D", 1)); if (e) delete_index = e->index; }
+  else if (capcode == 1) { Entry* e = table.find(std::string_view("\x7F", 1)); if (e) delete_index = e->index; }
 
   uint32_t max_len = 0;
   for (auto& k : keys) max_len = std::max<uint32_t>(max_len, (uint32_t)k.size());
@@ -206,16 +266,19 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
   uint32_t begin_count[256][4];
   std::memset(begin_count, 0, sizeof begin_count);
   for (uint32_t on = 0; on < n_info; on++) {
-    const std::string& token = keys[on];
+    const std::string_view token = keys[on];
     const uint8_t* t = (const uint8_t*)token.data();
     const size_t tl = token.size();
     Rec& rec = recs[on];
     rec.key = token;
-    rec.id = ids[token];
-    auto sit = scores.find(token);
-    rec.score = sit != scores.end() ? sit->second : 1.0f;
-    if (sit == scores.end() && token_scores) { auto g = given_scores.find(token); if (g != given_scores.end()) rec.score = g->second; }
-    if (specials.count(token)) { rec.special = true; rec.flag = 64; continue; }   // go :3504-3511
+    uint64_t hp[41];                                          // FNV-1a of every prefix of the token
+    hp[0] = kFnvInit;
+    for (size_t i = 0; i < tl; i++) hp[i + 1] = fnv_step(hp[i], t[i]);
+    const Entry& self = *table.find(token, hp[tl]);
+    rec.id = self.id;
+    rec.score = self.neg ? -1.0f : 1.0f;
+    if (!self.neg && token_scores) { auto g = given_scores.find(token); if (g != given_scores.end()) rec.score = g->second; }
+    if (self.special) { rec.special = true; rec.flag = 64; continue; }   // go :3504-3511
     uint8_t flag = 0, n_words = 0, priority1 = 0, priority2 = 0;
     int min_alt = 1, alt_len1 = 0, alt_len2 = 0;
     bool only_letter_space = false, only_number_space = false, only_punc = false;
@@ -274,9 +337,9 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
       }
     };
     for (int length = (int)tl - 1; length >= min_alt; length--) {      // go :3597
-      auto fit = find.find(std::string_view(token.data(), (size_t)length));
-      if (fit == find.end()) continue;
-      const uint32_t index = fit->second;
+      const Entry* fit = table.find(token.substr(0, (size_t)length), hp[length]);
+      if (!fit || fit->index == TM_NONE) continue;
+      const uint32_t index = fit->index;
       // anything | space + letter-or-number (go :3602-3621)
       if (length <= (int)tl - 2 && t[length] == ' ') {
         Rune d = decode_rune(t + length + 1, tl - (size_t)length - 1, charset);

@@ -44,6 +44,43 @@ int enter_device(const tm_vocab* v) {
   return e == hipSuccess ? TM_OK : hip_fail(e, "hipSetDevice (device of the vocabulary)");
 }
 
+namespace {
+// (parent node << 8 | byte) -> child node of the trie under construction: open addressing over a flat array (the table build of a
+// candidate vocabulary is on the trainvocab worker's path, and std::unordered_map was most of its time), edges kept in creation order
+class EdgeMap {
+ public:
+  explicit EdgeMap(size_t expect) {
+    size_t cap = 64;
+    while (cap < expect * 2 + 16) cap <<= 1;
+    keys_.assign(cap, kFree);
+    vals_.assign(cap, 0);
+    list_.reserve(expect);
+  }
+  const uint32_t* find(uint64_t key) const {
+    const size_t mask = keys_.size() - 1;
+    for (size_t i = slot(key) & mask;; i = (i + 1) & mask) {
+      if (keys_[i] == key) return &vals_[i];
+      if (keys_[i] == kFree) return nullptr;
+    }
+  }
+  void emplace(uint64_t key, uint32_t val) {           // (the key is not present; capacity was sized for every edge up front)
+    const size_t mask = keys_.size() - 1;
+    size_t i = slot(key) & mask;
+    while (keys_[i] != kFree) i = (i + 1) & mask;
+    keys_[i] = key; vals_[i] = val;
+    list_.emplace_back(key, val);
+  }
+  std::vector<std::pair<uint64_t, uint32_t>>::const_iterator begin() const { return list_.begin(); }
+  std::vector<std::pair<uint64_t, uint32_t>>::const_iterator end() const { return list_.end(); }
+ private:
+  static constexpr uint64_t kFree = ~0ull;
+  static size_t slot(uint64_t key) { return (size_t)((key * 0x9E3779B97F4A7C15ull) >> 24); }
+  std::vector<uint64_t> keys_;
+  std::vector<uint32_t> vals_;
+  std::vector<std::pair<uint64_t, uint32_t>> list_;
+};
+}  // namespace
+
 int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   size_t pos = 0;
 #define NEED(k) do { if (pos + (size_t)(k) > n) return set_error(TM_E_INVALID, "truncated .vocab at byte %zu", pos); } while (0)
@@ -110,19 +147,26 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
 
   // ---- trie: accepting node id == record ordinal; internal nodes numbered from n_info ------------
   const uint32_t n_info = hv.n_info;
-  std::unordered_map<uint64_t, uint32_t> child;   // (parent id << 8 | byte) -> child id; parent kNodeMask = root
-  child.reserve((size_t)hv.keys.size() + 16);
+  EdgeMap child(hv.keys.size() + 16);             // (parent id << 8 | byte) -> child id; parent kNodeMask = root
   std::vector<uint8_t> depth_of;                   // depth per node id
   depth_of.assign(n_info, 0);
   std::vector<uint32_t> parent_of(n_info, 0);      // parent node id (kRoot for depth 1) and the edge byte, per node id
   std::vector<uint8_t> byte_of(n_info, 0);
   uint32_t next_internal = n_info;
   const uint32_t kRoot = kNodeMask;
+  // keys arrive in (length, bytewise) order, so a key shares most of its path with the one before it: the walk resumes behind
+  // their common prefix instead of at the root
+  uint32_t path[41];                               // path[d] = node of the first d+1 bytes of the previous key
+  const uint8_t* prev_k = nullptr;
+  uint32_t prev_kl = 0;
   for (uint32_t i = 0; i < n_info; i++) {
     const uint8_t* k = &hv.keys[hv.key_off[i]];
     uint32_t kl = lens[i];
-    uint32_t node = kRoot;
-    for (uint32_t d = 0; d < kl; d++) {
+    uint32_t common = 0;
+    while (common < prev_kl && common + 1 < kl && k[common] == prev_k[common]) common++;   // (the last byte always makes a new node)
+    uint32_t node = common ? path[common - 1] : kRoot;
+    prev_k = k; prev_kl = kl;
+    for (uint32_t d = common; d < kl; d++) {
       uint64_t key = ((uint64_t)node << 8) | k[d];
       if (d + 1 == kl) {
         // keys arrive shortest first, so this node cannot exist yet (a proper prefix of a key is shorter)
@@ -130,15 +174,17 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
         depth_of[i] = (uint8_t)kl;
         parent_of[i] = node; byte_of[i] = k[d];
         node = i;
+        path[d] = node;
       } else {
-        auto it = child.find(key);
-        if (it == child.end()) {
+        const uint32_t* it = child.find(key);
+        if (!it) {
           if (next_internal >= kMaxNodes) return set_error(TM_E_LIMIT, "vocabulary needs more than %u trie nodes", kMaxNodes);
-          it = child.emplace(key, next_internal++).first;
+          child.emplace(key, next_internal);
           depth_of.push_back((uint8_t)(d + 1));
           parent_of.push_back(node); byte_of.push_back(k[d]);
-        }
-        node = it->second;
+          node = next_internal++;
+        } else node = *it;
+        path[d] = node;
       }
     }
   }
@@ -151,8 +197,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   // ever carries both bits on one record the hint is switched off and the kernels probe every eligible position.
   const uint32_t spl_off = hv.charset == 2 ? 2u : 1u;
   uint32_t spl_start = kNone;
-  { auto it = child.find(((uint64_t)kRoot << 8) | ' '); if (it != child.end()) spl_start = it->second; }
-  if (spl_start != kNone && spl_off == 2) { auto it = child.find(((uint64_t)spl_start << 8) | 0u); spl_start = it != child.end() ? it->second : kNone; }
+  { const uint32_t* it = child.find(((uint64_t)kRoot << 8) | ' '); if (it) spl_start = *it; }
+  if (spl_start != kNone && spl_off == 2) { const uint32_t* it = child.find(((uint64_t)spl_start << 8) | 0u); spl_start = it ? *it : kNone; }
   struct Spl { uint32_t node, cont, bestlen, best; };
   std::vector<Spl> splw(n_info, Spl{kNone, 0, 0, kNone});
   std::vector<uint8_t> spl_hint(n_info, 0);
@@ -165,9 +211,9 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       uint32_t node = spl_start, depth = spl_off, bestlen = 0, best = kNone, used = 0;
       if (node < n_info) { bestlen = depth; best = node; }
       while (used < kl && depth < hv.max_len) {
-        auto it = child.find(((uint64_t)node << 8) | k[used]);
-        if (it == child.end()) break;
-        node = it->second; used++; depth++;
+        const uint32_t* it = child.find(((uint64_t)node << 8) | k[used]);
+        if (!it) break;
+        node = *it; used++; depth++;
         if (node < n_info) { bestlen = depth; best = node; }
       }
       const uint32_t cont = (used == kl && has_child[node] && depth < hv.max_len) ? 1u : 0u;
@@ -224,9 +270,13 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   // link(n) follows from link(parent(n)) as in Aho-Corasick, in order of depth; best[m] = deepest accepting node on the
   // path root..m.  Only links of nodes at depth >= 3 are ever read by the kernels.
   {
-    std::vector<uint32_t> by_depth(n_nodes);
-    for (uint32_t i = 0; i < n_nodes; i++) by_depth[i] = i;
-    std::stable_sort(by_depth.begin(), by_depth.end(), [&](uint32_t a, uint32_t b) { return depth_of[a] < depth_of[b]; });
+    std::vector<uint32_t> by_depth(n_nodes);      // counting sort by depth (<= 40)
+    {
+      uint32_t start[42] = {0};
+      for (uint32_t i = 0; i < n_nodes; i++) start[depth_of[i] + 1]++;
+      for (int d = 1; d < 42; d++) start[d] += start[d - 1];
+      for (uint32_t i = 0; i < n_nodes; i++) by_depth[start[depth_of[i]]++] = i;
+    }
     std::vector<uint32_t> best(n_nodes, kNone);          // best accepting ancestor-or-self
     std::vector<uint32_t> lnode(n_nodes, kRoot);          // link target (kRoot = depth 0)
     std::vector<uint8_t> lfull(n_nodes, 0);
@@ -237,8 +287,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       if (par == kRoot) { lnode[n] = kRoot; lfull[n] = 1; continue; }                 // s[1:] is empty
       const uint32_t pm = lnode[par];
       if (!lfull[par]) { lnode[n] = pm; lfull[n] = 0; continue; }                     // already fell off the trie
-      auto it = child.find(((uint64_t)pm << 8) | byte_of[n]);
-      if (it == child.end()) { lnode[n] = pm; lfull[n] = 0; } else { lnode[n] = it->second; lfull[n] = 1; }
+      const uint32_t* it = child.find(((uint64_t)pm << 8) | byte_of[n]);
+      if (!it) { lnode[n] = pm; lfull[n] = 0; } else { lnode[n] = *it; lfull[n] = 1; }
     }
     uint2* lt = hv.tab.data() + link_base;
     for (uint32_t n = 0; n < n_nodes; n++) {
