@@ -225,3 +225,18 @@ def test_tok_dictionary_format_round_trip_and_layout():
         hdr = (C.c_uint8 * 5)()
         b, o, cnt = C.c_void_p(), C.c_void_p(), C.c_uint32()
         N.check(N.lib.tm_tok_read(b"not zlib", 8, hdr, C.byref(b), C.byref(o), C.byref(cnt), None, None, None, None))
+
+
+def test_builder_images_match_the_pinned_digests():
+    """tests/golden/builder_images.json: md5 of the .vocab image for seeded token lists (capcode 0/1/2, UTF-16, specials, phrases,
+    with / without unk), written by the line-by-line restatement of go/tokenmonster.go:3423-3793; the faster single-table builder
+    must produce the same bytes."""
+    import importlib.util
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_builder_golden", os.path.join(here, "make_builder_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "builder_images.json")))
+    got = mod.digests()
+    assert got == want
