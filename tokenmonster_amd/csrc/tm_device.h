@@ -48,6 +48,8 @@ struct tm_vocab {
   tmh::Tables tables{};
   int device = 0;
   uint64_t device_bytes = 0;
+  void* d_block = nullptr;           // the one device allocation the table pointers below point into (tm_vocab.hip: block cache)
+  size_t block_bytes = 0;
   uint32_t* d_root = nullptr;
   uint2* d_tab = nullptr;
   uint4* d_spl = nullptr;

@@ -1187,7 +1187,7 @@ void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* to
 
 // host: the group tree of the long documents.  doc d has lens[d] bytes; segments are numbered in document order.  groups[] holds
 // level 1 first (children = segments), then level 2 (children = level-1 groups), ...; b->level_first[k] is where level k+1 begins.
-int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs) {
+int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs, hipStream_t st) {
   std::vector<std::vector<Group>> levels;        // levels[k]: groups of level k+1, all long documents, in document order
   std::vector<LongDoc> longs;
   struct Top { uint32_t level, first, count; };  // a long document's top groups: index range within its top level
@@ -1238,8 +1238,20 @@ int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32
     b->cap_long = b->nlong + 16;
     if ((e = hipMalloc((void**)&b->d_longs, (size_t)b->cap_long * sizeof(LongDoc))) != hipSuccess) return hip_fail(e, "hipMalloc (long documents)");
   }
-  if ((e = hipMemcpy(b->d_groups, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemcpy(b->d_longs, longs.data(), longs.size() * sizeof(LongDoc), hipMemcpyHostToDevice)) != hipSuccess)
+  // (not hipMemcpy from the vectors: a pageable copy pins its pages per call and runs on the NULL stream — with other threads
+  // loading vocabularies at the same time that cost 10 - 20 ms per scoring pass.  Through the batch's pinned staging instead.)
+  const size_t gb = groups.size() * sizeof(Group), lb = longs.size() * sizeof(LongDoc), lat = (gb + 255) & ~(size_t)255;
+  if (b->h_groups_cap < lat + lb) {
+    (void)hipHostFree(b->h_groups);
+    b->h_groups = nullptr;
+    b->h_groups_cap = (lat + lb) + (lat + lb) / 4 + 4096;
+    if ((e = hipHostMalloc((void**)&b->h_groups, b->h_groups_cap, hipHostMallocDefault)) != hipSuccess) { b->h_groups_cap = 0; return hip_fail(e, "hipHostMalloc (segment groups)"); }
+  }
+  std::memcpy(b->h_groups, groups.data(), gb);
+  std::memcpy(b->h_groups + lat, longs.data(), lb);
+  if ((e = hipMemcpyAsync(b->d_groups, b->h_groups, gb, hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(b->d_longs, b->h_groups + lat, lb, hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipStreamSynchronize(st)) != hipSuccess)             // (the staging buffer is reused by the next batch)
     return hip_fail(e, "H2D segment groups");
   return TM_OK;
 }
@@ -1475,7 +1487,7 @@ void tm_batch_free(tm_batch* b) {
   for (void* p : ptrs) (void)hipFree(p);
   if (b->have_events) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
   if (b->aux_stream) (void)hipStreamDestroy(b->aux_stream);
-  (void)hipHostFree(b->h_fb_raw); (void)hipHostFree(b->h_fb_norm); (void)hipHostFree(b->h_mail);
+  (void)hipHostFree(b->h_fb_raw); (void)hipHostFree(b->h_fb_norm); (void)hipHostFree(b->h_mail); (void)hipHostFree(b->h_groups);
   delete b;
 }
 
@@ -1508,7 +1520,7 @@ int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
   b->nseg = nseg;
   b->d_doc_begin = b->d_offsets;
   b->d_doc_end = b->d_offsets + 1;
-  return build_groups(b, offsets, offsets + 1, ndocs);
+  return build_groups(b, offsets, offsets + 1, ndocs, st);
 }
 void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* out, hipStream_t st) {
   if (n) k_serialize<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(ids, n, enc, out);

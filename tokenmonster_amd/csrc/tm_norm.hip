@@ -715,7 +715,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     std::vector<uint64_t> hb(nd), he(nd);
     if ((e = hipMemcpy(hb.data(), b->d_nbegin, (size_t)nd * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
         (e = hipMemcpy(he.data(), b->d_nend, (size_t)nd * 8, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H ranges");
-    rc = build_groups(b, hb.data(), he.data(), nd);
+    rc = build_groups(b, hb.data(), he.data(), nd, st);
   }
   if (trace) fprintf(stderr, "[tm_batch_normalize] summaries %.2f ms, device pass + host fallback (%u docs) %.2f ms, info %.2f ms\n", t1 - t0, nf, t2 - t1, now() - t2);
   return rc;

@@ -104,6 +104,7 @@ struct tm_batch {
   // small transfers (counters, lists of a few hundred KB) go through a pinned mailbox and a copy kernel on the caller's stream
   // instead of the copy engines, where they would queue behind the bulk transfers of other lanes (small_d2h / small_h2d)
   uint8_t* h_mail = nullptr; uint64_t mail_pos = 0;
+  uint8_t* h_groups = nullptr; uint64_t h_groups_cap = 0;   // pinned staging of the group tree of long documents (build_groups)
   struct MailPending { void* dst; const uint8_t* slot; uint64_t n; hipStream_t st; };
   std::vector<MailPending> mail_pending;
   std::vector<hipStream_t> mail_streams;   // streams that have used mailbox slots since it last wrapped
@@ -125,7 +126,7 @@ void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* to
 void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32_t ndocs, uint32_t unit, uint32_t* doc_nunits, hipStream_t st);
 void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st);
 uint32_t long_segs();    // documents with more segments than this hang under the group tree (LONG_SEGS; 8 under test hook bit 12)
-int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs);
+int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs, hipStream_t st);
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit);
 int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev);
 int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode);

@@ -6,6 +6,7 @@
 // token (trainvocab.go:1105-1174).  The histogram lives in HBM as plain uint32 sums so that data-parallel ranks merge it
 // with ONE RCCL all-reduce (tokenmonster_amd/dist.py).
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cstring>
@@ -22,7 +23,7 @@ struct tm_dataset {
   tm_batch* ws = nullptr;          // workspace, created on first use and reused by every scoring pass
   uint32_t ws_docs = 0;
   uint32_t* d_hist = nullptr;      // scores | 4 token limbs | 256 missing counters
-  uint64_t hist_words = 0;
+  uint64_t hist_words = 0, hist_cap = 0;
   unsigned long long* d_tokens = nullptr;
   uint32_t* d_missing_bits = nullptr;
   int n_cu = 256;
@@ -83,12 +84,14 @@ static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
   b->vocab = v;
   if (nseg > b->max_segs) return set_error(TM_E_LIMIT, "%llu segments, workspace holds %llu", (unsigned long long)nseg, (unsigned long long)b->max_segs);
   const uint64_t words = (uint64_t)v->host.n_ids + 4 + 256;
-  if (d->hist_words != words) {
+  if (d->hist_cap < words) {                 // grow-only: candidate vocabularies differ in size, and hipFree synchronizes the device
     (void)hipFree(d->d_hist);
     d->d_hist = nullptr;
-    if ((e = hipMalloc((void**)&d->d_hist, words * 4)) != hipSuccess) return hip_fail(e, "hipMalloc histogram");
-    d->hist_words = words;
+    d->hist_cap = 0;
+    if ((e = hipMalloc((void**)&d->d_hist, (words + words / 4) * 4)) != hipSuccess) return hip_fail(e, "hipMalloc histogram");
+    d->hist_cap = words + words / 4;
   }
+  d->hist_words = words;
   if (d->strip_cap < n_strips) {
     (void)hipFree(d->d_vis); (void)hipFree(d->d_entry); (void)hipFree(d->d_exits);
     d->d_vis = nullptr; d->d_entry = nullptr; d->d_exits = nullptr;
@@ -96,9 +99,9 @@ static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
     if ((e = hipMalloc((void**)&d->d_vis, (size_t)d->strip_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&d->d_entry, d->strip_cap)) != hipSuccess ||
         (e = hipMalloc((void**)&d->d_exits, (size_t)d->strip_cap * ENT)) != hipSuccess) { d->strip_cap = 0; return hip_fail(e, "hipMalloc (strips)"); }
   }
-  if ((e = hipMemcpyAsync(b->d_offsets, be.data(), 2ull * n_strips * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(d->d_vis, be.data() + 2ull * n_strips, (size_t)n_strips * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D strips");
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "sync");   // `be` is a host temporary
+  { int rc = small_h2d(b, b->d_offsets, be.data(), 2ull * n_strips * 8, st);          // (through the pinned mailbox: no pageable copies on this path)
+    if (rc == TM_OK) rc = small_h2d(b, d->d_vis, be.data() + 2ull * n_strips, (uint64_t)n_strips * 8, st);
+    if (rc != TM_OK) return rc; }
   b->d_doc_begin = b->d_offsets;
   b->d_doc_end = b->d_offsets + n_strips;
   b->d_doc_vis = d->d_vis;
@@ -106,7 +109,7 @@ static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
   b->ndocs = n_strips;
   b->nbytes = d->n;
   b->nseg = nseg;
-  { int grc = build_groups(b, be.data(), be.data() + n_strips, n_strips); if (grc != TM_OK) return grc; }
+  { int grc = build_groups(b, be.data(), be.data() + n_strips, n_strips, st); if (grc != TM_OK) return grc; }
   int rc = pipeline_match(b, st, nullptr);
   if (rc == TM_OK) d->prepared = true;
   return rc;
@@ -240,13 +243,21 @@ int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* 
 int tm_score(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off, const uint64_t* strip_len, uint32_t n_strips,
              uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]) {
   if (!d) return set_error(TM_E_INVALID, "null argument");
+  static const bool trace = getenv("TM_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = trace ? now() : 0;
   std::lock_guard<std::mutex> g(d->mu);
+  const double t1 = trace ? now() : 0;
   hipStream_t st = nullptr;
   if (!d->stream && hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) d->stream = nullptr;
   st = d->stream;          // (not the NULL stream: the table uploads of other threads' tm_vocab_load must not order behind this pass)
   int rc = score_run(v, d, strip_off, strip_len, n_strips, st);
+  const double t2 = trace ? now() : 0;
   if (rc == TM_OK) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize"); }
-  return rc == TM_OK ? tm_score_read(v, d, scores, tokens_in_text, missing_set) : rc;
+  const double t3 = trace ? now() : 0;
+  rc = rc == TM_OK ? tm_score_read(v, d, scores, tokens_in_text, missing_set) : rc;
+  if (trace) fprintf(stderr, "[tm_score] lock wait %.2f ms, launch %.2f ms, kernels %.2f ms, read %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
+  return rc;
 }
 
 }  // extern "C"

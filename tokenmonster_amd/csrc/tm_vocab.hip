@@ -5,6 +5,8 @@
 // resolves alt lengths / ids from earlier records exactly as :2703-2712 does, and instead of
 // pansearch.Fast builds the byte trie described in tm_tables.h.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <map>
 
 #include <algorithm>
 #include <cstdlib>
@@ -369,6 +371,57 @@ int tm_set_device(int device) {
   return TM_OK;
 }
 
+namespace {
+// The trainvocab worker loads and frees a vocabulary per candidate (trainvocab.go:530-907), several workers at once, while the GPU
+// scores: hipMalloc / hipFree per table would synchronize the device under the other workers' scoring passes, and a pageable
+// hipMemcpy would queue as a copy kernel behind them.  A vocabulary therefore lives in ONE device block, filled by ONE asynchronous
+// copy from a pinned staging block on a copy-only stream; freed blocks of both kinds are kept for the next load (bounded).
+struct BlockCache {
+  std::mutex mu;
+  std::multimap<size_t, void*> dev_free, host_free;
+  size_t dev_cached = 0, host_cached = 0;
+  hipStream_t stream = nullptr;
+};
+constexpr size_t kDevCacheMax = 4ull << 30, kHostCacheMax = 512ull << 20;
+BlockCache& cache_of(int device) {
+  static BlockCache caches[64];
+  return caches[device & 63];
+}
+size_t round_block(size_t bytes) { return (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1); }
+void* block_get(int device, bool host, size_t bytes, size_t* got, hipError_t* err) {
+  BlockCache& c = cache_of(device);
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto& fl = host ? c.host_free : c.dev_free;
+    auto it = fl.lower_bound(bytes);
+    if (it != fl.end() && it->first <= 2 * bytes + (4u << 20)) {
+      void* p = it->second; *got = it->first;
+      (host ? c.host_cached : c.dev_cached) -= it->first;
+      fl.erase(it);
+      return p;
+    }
+  }
+  void* p = nullptr;
+  *got = round_block(bytes);
+  *err = host ? hipHostMalloc(&p, *got, hipHostMallocDefault) : hipMalloc(&p, *got);
+  return *err == hipSuccess ? p : nullptr;
+}
+void block_put(int device, bool host, void* p, size_t bytes) {
+  if (!p) return;
+  BlockCache& c = cache_of(device);
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    size_t& cached = host ? c.host_cached : c.dev_cached;
+    if (cached + bytes <= (host ? kHostCacheMax : kDevCacheMax)) {
+      (host ? c.host_free : c.dev_free).emplace(bytes, p);
+      cached += bytes;
+      return;
+    }
+  }
+  if (host) (void)hipHostFree(p); else (void)hipFree(p);
+}
+}  // namespace
+
 int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   if (!vocab_file || !out) return set_error(TM_E_INVALID, "null argument");
   *out = nullptr;
@@ -381,20 +434,33 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   int dev = 0;
   if ((e = hipGetDevice(&dev)) != hipSuccess) { delete v; return hip_fail(e, "hipGetDevice"); }
   v->device = dev;
-  auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
-    hipError_t r = hipMalloc(dst, bytes ? bytes : 16);
-    if (r != hipSuccess) return r;
-    v->device_bytes += bytes;
-    return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
-  };
-  if ((e = up((void**)&v->d_root, hv.root.data(), 256 * 4)) != hipSuccess ||
-      (e = up((void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2))) != hipSuccess ||
-      (e = up((void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row))) != hipSuccess ||
-      (e = up((void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint4))) != hipSuccess ||
-      (e = up((void**)&v->d_vals, hv.vals.data(), hv.vals.size() * 4)) != hipSuccess ||
-      (e = up((void**)&v->d_rev_off, hv.rev_off.data(), hv.rev_off.size() * 4)) != hipSuccess ||
-      (e = up((void**)&v->d_rev_bytes, hv.rev_bytes.data(), hv.rev_bytes.size())) != hipSuccess ||
-      (e = up((void**)&v->d_begin_byte, hv.begin_byte, 256)) != hipSuccess) {
+  struct Part { void** dst; const void* src; size_t bytes, at; };
+  Part parts[] = {{(void**)&v->d_root, hv.root.data(), 256 * 4, 0}, {(void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2), 0},
+                  {(void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row), 0}, {(void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint4), 0},
+                  {(void**)&v->d_vals, hv.vals.data(), hv.vals.size() * 4, 0}, {(void**)&v->d_rev_off, hv.rev_off.data(), hv.rev_off.size() * 4, 0},
+                  {(void**)&v->d_rev_bytes, hv.rev_bytes.data(), hv.rev_bytes.size(), 0}, {(void**)&v->d_begin_byte, hv.begin_byte, 256, 0}};
+  size_t total = 0;
+  for (Part& q : parts) { q.at = total; total += (q.bytes + 255) & ~(size_t)255; v->device_bytes += q.bytes; }
+  total += 256;
+  e = hipSuccess;
+  size_t stage_bytes = 0;
+  void* stage = block_get(dev, true, total, &stage_bytes, &e);
+  v->d_block = stage ? block_get(dev, false, total, &v->block_bytes, &e) : nullptr;
+  if (v->d_block) {
+    for (Part& q : parts) {
+      if (q.bytes) std::memcpy((uint8_t*)stage + q.at, q.src, q.bytes);
+      *q.dst = (uint8_t*)v->d_block + q.at;
+    }
+    BlockCache& c = cache_of(dev);
+    {
+      std::lock_guard<std::mutex> g(c.mu);
+      if (!c.stream) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(v->d_block, stage, total, hipMemcpyHostToDevice, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+  }
+  block_put(dev, true, stage, stage_bytes);
+  if (!v->d_block || e != hipSuccess) {
     tm_vocab_free(v);
     return hip_fail(e, "vocabulary upload");
   }
@@ -410,7 +476,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
 void tm_vocab_free(tm_vocab* v) {
   if (!v) return;
   tmh::pool_destroy(v->pool);
-  (void)hipFree(v->d_root); (void)hipFree(v->d_tab); (void)hipFree(v->d_spl); (void)hipFree(v->d_vals); (void)hipFree(v->d_rev_off); (void)hipFree(v->d_rev_bytes); (void)hipFree(v->d_rows); (void)hipFree(v->d_begin_byte);
+  if (v->d_block) { int cur = -1; (void)hipGetDevice(&cur); if (cur != v->device) (void)hipSetDevice(v->device); block_put(v->device, false, v->d_block, v->block_bytes); }
   delete v;
 }
 
