@@ -231,14 +231,14 @@ int tm_tokenize_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* of
   rc = lane_run(l, v, text, offsets, ndocs, false, true, &ro);
   if (rc == TM_OK) {
     tm_batch* b = l->ws;
-    if (tok_offsets) rc = d2h(tok_offsets, b->d_tok_offsets, ((uint64_t)ndocs + 1) * 8, l->stream, "D2H tok_offsets");
-    if (rc == TM_OK && missing && ndocs) rc = d2h(missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream, "D2H missing");
+    if (tok_offsets) rc = small_d2h(b, tok_offsets, b->d_tok_offsets, ((uint64_t)ndocs + 1) * 8, l->stream);
+    if (rc == TM_OK && missing && ndocs) rc = small_d2h(b, missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream);
     if (rc == TM_OK && ro.total_tokens > tokens_cap) {
-      (void)hipStreamSynchronize(l->stream);
+      (void)small_sync(b, l->stream);
       rc = set_error(TM_E_NOSPACE, "tokens_cap %llu < %llu required", (unsigned long long)tokens_cap, (unsigned long long)ro.total_tokens);
     }
-    if (rc == TM_OK) rc = d2h(tokens_out, b->d_out, ro.total_tokens * 4, l->stream, "D2H tokens");
-    if (rc == TM_OK) { hipError_t e = hipStreamSynchronize(l->stream); if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize"); }
+    if (rc == TM_OK) rc = small_d2h(b, tokens_out, b->d_out, ro.total_tokens * 4, l->stream);
+    if (rc == TM_OK) rc = small_sync(b, l->stream); else (void)small_sync(b, l->stream);
     if (ndocs == 0 && tok_offsets) tok_offsets[0] = 0;
   }
   lane_release(v, l);
@@ -255,10 +255,10 @@ static int count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* o
     tm_batch* b = l->ws;
     std::vector<uint32_t> ev(ndocs);
     uint32_t err = 0;
-    rc = d2h(&err, b->d_error, 4, l->stream, "D2H error flag");
-    if (rc == TM_OK) rc = d2h(ev.data(), b->d_doc_events, (uint64_t)ndocs * 4, l->stream, "D2H counts");
-    if (rc == TM_OK && missing) rc = d2h(missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream, "D2H missing");
-    if (rc == TM_OK) { hipError_t e = hipStreamSynchronize(l->stream); if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize"); }
+    rc = small_d2h(b, &err, b->d_error, 4, l->stream);
+    if (rc == TM_OK) rc = small_d2h(b, ev.data(), b->d_doc_events, (uint64_t)ndocs * 4, l->stream);
+    if (rc == TM_OK && missing) rc = small_d2h(b, missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream);
+    if (rc == TM_OK) rc = small_sync(b, l->stream); else (void)small_sync(b, l->stream);
     if (rc == TM_OK && err) rc = set_error(TM_E_HIP, "device pipeline inconsistency");
     if (rc == TM_OK && counts) for (uint32_t d = 0; d < ndocs; d++) counts[d] = ev[d];
   }
@@ -288,15 +288,15 @@ int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const u
     tm_batch* b = l->ws;
     const uint64_t nb = ro.total_tokens * encoding_length;
     std::vector<uint64_t> offs((size_t)ndocs + 1, 0);
-    if (ndocs) rc = d2h(offs.data(), b->d_tok_offsets, offs.size() * 8, l->stream, "D2H tok_offsets");
-    if (rc == TM_OK && missing && ndocs) rc = d2h(missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream, "D2H missing");
+    if (ndocs) rc = small_d2h(b, offs.data(), b->d_tok_offsets, offs.size() * 8, l->stream);
+    if (rc == TM_OK && missing && ndocs) rc = small_d2h(b, missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream);
     if (rc == TM_OK && nb <= bytes_cap && nb) {
       if ((rc = lane_dbytes(l, nb)) == TM_OK) {
         launch_serialize(b->d_out, ro.total_tokens, encoding_length, l->d_bytes, l->stream);
-        rc = d2h(bytes_out, l->d_bytes, nb, l->stream, "D2H bytes");
+        rc = small_d2h(b, bytes_out, l->d_bytes, nb, l->stream);
       }
     }
-    { hipError_t e = hipStreamSynchronize(l->stream); if (rc == TM_OK && e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize"); }
+    { int rs = small_sync(b, l->stream); if (rc == TM_OK) rc = rs; }
     if (rc == TM_OK && byte_offsets) for (size_t d = 0; d <= ndocs; d++) byte_offsets[d] = offs[d] * encoding_length;
     if (rc == TM_OK && nb > bytes_cap) rc = set_error(TM_E_NOSPACE, "bytes_cap too small");
   }

@@ -1513,7 +1513,9 @@ int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
     nseg += (offsets[d + 1] - offsets[d] + SEG - 1) / SEG;
   }
   hipError_t e;
-  if (nbytes && (e = hipMemcpyAsync(b->d_text, text, nbytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D text");
+  // (a server-sized batch goes through the pinned mailbox: a pageable copy pins the caller's pages per call, and concurrent callers queue on that)
+  if (nbytes && nbytes <= MAIL_MAX) { int rc = small_h2d(b, b->d_text, text, nbytes, st); if (rc != TM_OK) return rc; }
+  else if (nbytes && (e = hipMemcpyAsync(b->d_text, text, nbytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D text");
   if (ndocs) { int rc = small_h2d(b, b->d_offsets, offsets, ((uint64_t)ndocs + 1) * 8, st); if (rc != TM_OK) return rc; }
   b->ndocs = ndocs;
   b->nbytes = nbytes;

@@ -223,8 +223,14 @@ int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* 
   hipError_t e;
   std::vector<uint32_t> h(d->hist_words);
   uint32_t err = 0;
-  if ((e = hipMemcpy(h.data(), d->d_hist, h.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H histogram");
-  if ((e = hipMemcpy(&err, d->ws->d_error, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "D2H error flag");
+  {
+    hipStream_t st = d->ws->last_stream;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    int rc = small_d2h(d->ws, h.data(), d->d_hist, h.size() * 4, st);
+    if (rc == TM_OK) rc = small_d2h(d->ws, &err, d->ws->d_error, 4, st);
+    if (rc == TM_OK) rc = small_sync(d->ws, st);
+    if (rc != TM_OK) return rc;
+  }
   if (err) return set_error(TM_E_HIP, "device pipeline inconsistency (unreachable segment entry state)");
   const uint32_t n_ids = v->host.n_ids;
   if (scores) std::memcpy(scores, h.data(), (size_t)n_ids * 4);
