@@ -109,3 +109,24 @@ def test_vocab_save_writes_back_the_loaded_image(setup, tmp_path):
     assert open(path, "rb").read() == bytes(img)
     v2 = tm.load(path)
     assert v2.n_ids() == v.n_ids() and v2.n_info() == v.n_info()
+
+
+def test_pipeline_capital_heavy_text_retries_with_a_larger_workspace(setup):
+    """capcode turns "A.B.C" into 2.5 times as many bytes: a lane's workspace (1.5 x the raw size plus headroom) is too small, the
+    normalizer answers TM_E_LIMIT and the lane uploads the chunk again into the worst-case workspace (tm_host.hip: lane_compute) —
+    here on a chunk that had been prefetched behind a lower-case one into a workspace that looked large enough."""
+    img = setup[0]
+    v = tm.Vocab(img)
+    rng = np.random.default_rng(5)
+    docs = [b"plain lower case words again and again " * 1300 for _ in range(80)]                       # 4 MB that do not grow
+    docs += [b".".join(bytes([65 + int(c)]) for c in rng.integers(0, 26, 25_000)) for _ in range(100)]   # 5 MB that grow 2.5 x
+    raw = np.frombuffer(b"".join(docs), dtype=np.uint8).copy()
+    roffs = np.zeros(len(docs) + 1, dtype=np.uint64)
+    roffs[1:] = np.cumsum([len(x) for x in docs])
+    text, offs = synth.normalize_batch(raw, roffs, 2, 1)
+    assert text.size > 1.7 * raw.size          # (the point of the test)
+    ids, toff, miss = v.tokenize_packed(text, offs)
+    for chunk, lanes in ((2 << 20, 1), (2 << 20, 2), (1 << 30, 1)):
+        blob, boff, bmiss, enc, st = v.tokenize_pipeline(raw, roffs, raw=True, chunk_bytes=chunk, lanes=lanes)
+        assert (boff == toff * np.uint64(enc)).all() and (bmiss == miss).all()
+        assert (_ids_from_bytes(np.asarray(blob), enc) == ids).all()
