@@ -1178,7 +1178,33 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store) {
   if (nd) k_doc_events<<<(nd + 255) / 256, 256, 0, st>>>(b->d_doc_ntok, b->d_doc_fd, nd, b->d_doc_events);
 }
 
+// the same scan for up to SCAN1_MAX elements in ONE launch of one workgroup (a run of elements per thread): a server batch or a chunk of the
+// host-to-host pipeline or a server batch scans a few thousand documents / pieces / segments several times, and there the two launches
+// saved per scan are worth more than the parallelism lost
+constexpr int SCAN1_T = 1024;
+constexpr uint64_t SCAN1_MAX = 1u << 14;     // (a single workgroup over 2^17 elements took longer than the two launches it saved)
+__global__ __launch_bounds__(SCAN1_T) void k_scan_single(const uint32_t* __restrict__ in, uint32_t n, uint64_t* __restrict__ total, uint64_t* __restrict__ out) {
+  __shared__ uint64_t s[SCAN1_T];
+  const uint32_t per = (n + SCAN1_T) / SCAN1_T;                       // (covers index n, the total slot)
+  const uint32_t b = threadIdx.x * per, e = b + per < n ? b + per : (b < n ? n : b);
+  uint64_t acc = 0;
+  for (uint32_t i = b; i < e; i++) acc += in[i];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 1; st < SCAN1_T; st <<= 1) {
+    const uint64_t t = (int)threadIdx.x >= st ? s[threadIdx.x - st] : 0;
+    __syncthreads();
+    s[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint64_t run = s[threadIdx.x] - acc;
+  for (uint32_t i = b; i < e; i++) { out[i] = run; run += in[i]; }
+  if (b <= n && n < b + per) out[n] = run;                              // one-past-the-end = grand total
+  if (threadIdx.x == SCAN1_T - 1) *total = s[SCAN1_T - 1];
+}
+
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {
+  if (n <= SCAN1_MAX) { k_scan_single<<<1, SCAN1_T, 0, st>>>(in, (uint32_t)n, total, out); return; }
   uint32_t nblocks = (uint32_t)((n + 1 + SCAN_CH - 1) / SCAN_CH);   // covers index n (the total slot)
   k_scan_partial<<<nblocks, SCAN_T, 0, st>>>(in, n, block_sums);
   k_scan_sums<<<1, SCAN_T, 0, st>>>(block_sums, nblocks, total);
