@@ -143,11 +143,11 @@ int tm_batch_run(tm_batch* b, void* stream);
 #define TM_NUM_KERNELS 5
 int tm_batch_run_timed(tm_batch* b, void* stream, float* ms);
 const char* tm_kernel_name(int k);
-/* Development aid: sets the debug switches and returns the previous value; flags < 0 only queries.  Bits 0-4 switch phases of the
- * match kernel off (profiling: results are wrong), bit 9 lowers its occupancy.  Bits that select an alternative implementation with
- * the same results, used by the tests: 6 = dense T(p,1) array, 7 = list-ranking K4 (k_chain) instead of the tile walk, 8 = per-lane
- * normalizer kernel instead of k_norm_emit2, 10 = K4 tile walk that stores every id directly (its overflow path),
- * 11 = experimental split of the match kernel (step A1 as its own kernel).  0 in production. */
+/* Test hooks: sets the switches and returns the previous value; flags < 0 only queries.  Every bit forces a rarely taken path of
+ * the product with the SAME results, so that the tests can cover it: 6 = dense T(p,1) array for every segment, 8 = per-lane
+ * normalizer kernel instead of k_norm_emit2, 10 = K4 tile walk that stores every id directly (its overflow path), 12 = group tree of
+ * long documents with fan-out 4 from 9 segments on, 13 = 64 KiB mailbox for the small host <-> device transfers.  Other bits are
+ * ignored (a -DTM_DEVEL build, tools/ only, adds profiling bits that switch phases of the match kernel off).  0 in production. */
 int tm_debug_flags(int flags);
 /* Totals of the last run (synchronizes the stream used by the last run). */
 int tm_batch_totals(tm_batch* b, uint64_t* total_tokens, uint64_t* total_missing);

@@ -130,3 +130,29 @@ def test_pipeline_capital_heavy_text_retries_with_a_larger_workspace(setup):
         blob, boff, bmiss, enc, st = v.tokenize_pipeline(raw, roffs, raw=True, chunk_bytes=chunk, lanes=lanes)
         assert (boff == toff * np.uint64(enc)).all() and (bmiss == miss).all()
         assert (_ids_from_bytes(np.asarray(blob), enc) == ids).all()
+
+
+def test_small_transfers_survive_a_wrapping_mailbox(setup):
+    """Counters, offsets and server-sized batches travel through a pinned mailbox and a copy kernel (tm_kernels.hip: small_d2h /
+    small_h2d).  Test hook bit 13 shrinks the mailbox to 64 KiB with 16 KiB transfers, so that this corpus wraps it many times and
+    also takes the copy-engine path for what no longer fits."""
+    from tokenmonster_amd import _native as N
+    img, raw, roffs, text, offs = setup
+    v = tm.Vocab(img)
+    ids, toff, miss = v.tokenize_packed(text, offs)
+    old = N.lib.tm_debug_flags(8192)
+    try:
+        assert N.lib.tm_debug_flags(-1) == 8192
+        v2 = tm.Vocab(img)
+        ids2, toff2, miss2 = v2.tokenize_packed(text, offs)
+        assert (ids2 == ids).all() and (toff2 == toff).all() and (miss2 == miss).all()
+        for k in range(0, offs.size - 1, 97):                     # server-sized batches: the text itself goes through the mailbox
+            a, b = int(offs[k]), int(offs[min(k + 3, offs.size - 1)])
+            sub_off = (offs[k:min(k + 3, offs.size - 1) + 1] - offs[k]).astype(np.uint64)
+            i3, t3, _ = v2.tokenize_packed(text[a:b], sub_off)
+            assert (i3 == ids[int(toff[k]):int(toff[k]) + i3.size]).all()
+        blob, boff, bmiss, enc, _ = v2.tokenize_pipeline(raw, roffs, raw=True, chunk_bytes=40_000, lanes=4)
+        assert (boff == toff * np.uint64(enc)).all() and (bmiss == miss).all()
+        assert (_ids_from_bytes(np.asarray(blob), enc) == ids).all()
+    finally:
+        N.lib.tm_debug_flags(old)

@@ -1103,7 +1103,8 @@ namespace tmh {
 
 // Test hooks (tm_debug_flags): bits that force a rarely taken fallback path of the product so that the tests can cover it, with the
 // same results: 6 = dense T(p,1) array for every segment, 8 = per-lane normalizer kernel, 10 = K4 tile walk that stores every id
-// directly, 12 = group tree of long documents with fan-out 4 from 9 segments on (a deep tree on a small document).  Nothing else is
+// directly, 12 = group tree of long documents with fan-out 4 from 9 segments on (a deep tree on a small document), 13 = a 64 KiB
+// mailbox for the small host <-> device transfers (wraps within a test).  Nothing else is
 // reachable in the default build.  With -DTM_DEVEL (tools/ only: results are WRONG) further bits switch
 // phases of K1 off for profiling — 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps — bit 9 adds 4 KB
 // of dummy LDS per K1 workgroup, and TM_DBG in the environment sets the initial value.
@@ -1111,7 +1112,7 @@ namespace tmh {
 constexpr int kDebugMask = ~0;
 #define TM_K1_EXTRA_LDS ((debug_flags() & 512) ? 4096 : 0)
 #else
-constexpr int kDebugMask = 64 | 256 | 1024 | 4096;
+constexpr int kDebugMask = 64 | 256 | 1024 | 4096 | 8192;
 #define TM_K1_EXTRA_LDS 0
 #endif
 int g_debug_flags = -1;
@@ -1374,12 +1375,16 @@ static void launch_copy_small(const void* src, void* dst, uint64_t n, hipStream_
   const uint64_t items = words ? n / 8 : n;
   k_copy_small<<<(uint32_t)((items + 255) / 256), 256, 0, st>>>((const uint8_t*)src, (uint8_t*)dst, n, words);
 }
+// (test hook bit 13: a 64 KiB mailbox with transfers of at most 16 KiB, so that a small test wraps it and takes the copy-engine path too)
+static uint64_t mail_bytes() { return (debug_flags() & 8192) ? (64u << 10) : MAIL_BYTES; }
+static uint64_t mail_max() { return (debug_flags() & 8192) ? (16u << 10) : MAIL_MAX; }
 static int mail_slot(tm_batch* b, uint64_t bytes, hipStream_t st, uint8_t** slot) {
   hipError_t e;
   if (!b->h_mail && (e = hipHostMalloc((void**)&b->h_mail, MAIL_BYTES, hipHostMallocDefault)) != hipSuccess) { b->h_mail = nullptr; return hip_fail(e, "hipHostMalloc (mailbox)"); }
   const uint64_t need = (bytes + 63) & ~63ull;
-  if (b->mail_pos + need > MAIL_BYTES) {            // wrap: every copy kernel that reads or writes a slot handed out so far must be done
-    for (hipStream_t s2 : b->mail_streams) { int rc = small_sync(b, s2); if (rc != TM_OK) return rc; }
+  if (b->mail_pos + need > mail_bytes()) {            // wrap: every copy kernel that reads or writes a slot handed out so far must be done
+    const std::vector<hipStream_t> live = b->mail_streams;           // (small_sync takes the stream off the list)
+    for (hipStream_t s2 : live) { int rc = small_sync(b, s2); if (rc != TM_OK) return rc; }
     if (!b->mail_pending.empty()) return set_error(TM_E_INVALID, "mailbox wrapped with transfers pending");
     b->mail_streams.clear();
     b->mail_pos = 0;
@@ -1391,7 +1396,7 @@ static int mail_slot(tm_batch* b, uint64_t bytes, hipStream_t st, uint8_t** slot
 }
 int small_d2h(tm_batch* b, void* host_dst, const void* dev_src, uint64_t bytes, hipStream_t st) {
   if (bytes == 0) return TM_OK;
-  if (bytes > MAIL_MAX) {
+  if (bytes > mail_max()) {
     hipError_t e = hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st);
     return e == hipSuccess ? TM_OK : hip_fail(e, "D2H");
   }
@@ -1404,7 +1409,7 @@ int small_d2h(tm_batch* b, void* host_dst, const void* dev_src, uint64_t bytes, 
 }
 int small_h2d(tm_batch* b, void* dev_dst, const void* host_src, uint64_t bytes, hipStream_t st) {
   if (bytes == 0) return TM_OK;
-  if (bytes > MAIL_MAX) {
+  if (bytes > mail_max()) {
     hipError_t e = hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st);   // (pageable sources are staged before this returns)
     return e == hipSuccess ? TM_OK : hip_fail(e, "H2D");
   }
@@ -1424,6 +1429,9 @@ int small_sync(tm_batch* b, hipStream_t st) {
     else b->mail_pending[keep++] = m;
   }
   b->mail_pending.resize(keep);
+  // every copy kernel of this stream is done: the stream no longer has to be waited for when the mailbox wraps (and a caller's
+  // stream that is destroyed later is not kept here)
+  b->mail_streams.erase(std::remove(b->mail_streams.begin(), b->mail_streams.end(), st), b->mail_streams.end());
   return TM_OK;
 }
 
@@ -1540,7 +1548,7 @@ int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
   }
   hipError_t e;
   // (a server-sized batch goes through the pinned mailbox: a pageable copy pins the caller's pages per call, and concurrent callers queue on that)
-  if (nbytes && nbytes <= MAIL_MAX) { int rc = small_h2d(b, b->d_text, text, nbytes, st); if (rc != TM_OK) return rc; }
+  if (nbytes && nbytes <= mail_max()) { int rc = small_h2d(b, b->d_text, text, nbytes, st); if (rc != TM_OK) return rc; }
   else if (nbytes && (e = hipMemcpyAsync(b->d_text, text, nbytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D text");
   if (ndocs) { int rc = small_h2d(b, b->d_offsets, offsets, ((uint64_t)ndocs + 1) * 8, st); if (rc != TM_OK) return rc; }
   b->ndocs = ndocs;
