@@ -478,7 +478,7 @@ __global__ void k_norm_ranges(const uint64_t* __restrict__ piece_off, const uint
                               uint32_t ndocs, uint64_t* __restrict__ nbegin, uint64_t* __restrict__ nend) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ndocs) return;
-  if (need_host[d]) { nbegin[d] = 0; nend[d] = 0; return; }
+  if (need_host[d]) return;                      // (k_place_fallback writes the range of a host-normalized document, possibly at the same time)
   nbegin[d] = piece_off[doc_piece_start[d]];
   nend[d] = piece_off[doc_piece_start[d + 1]];
 }
@@ -490,12 +490,28 @@ __global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t*
   for (int o = 32; o > 0; o >>= 1) nseg += __shfl_xor(nseg, o);
   if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&ninfo[2], (unsigned long long)nseg);
 }
+// One side of these two copies is pinned HOST memory, reached over PCIe: that side is accessed in aligned 16-byte units (a byte
+// per lane made a 64-byte request per wavefront), the device side at whatever alignment is left.
+template <bool DST_IS_HOST>
+__device__ __forceinline__ void copy_doc(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t len) {
+  const uintptr_t host_side = DST_IS_HOST ? (uintptr_t)dst : (uintptr_t)src;
+  uint64_t head = (16u - (uint32_t)(host_side & 15u)) & 15u;
+  if (head > len) head = len;
+  for (uint64_t j = threadIdx.x; j < head; j += blockDim.x) dst[j] = src[j];
+  const uint64_t nvec = (len - head) >> 4;
+  for (uint64_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+    uint4 t;
+    __builtin_memcpy(&t, src + head + 16 * v, 16);
+    __builtin_memcpy(dst + head + 16 * v, &t, 16);
+  }
+  for (uint64_t j = head + 16 * nvec + threadIdx.x; j < len; j += blockDim.x) dst[j] = src[j];
+}
 __global__ void k_gather_docs(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ doc_ids,
                               const uint64_t* __restrict__ dst_off, uint32_t n, uint8_t* __restrict__ staging) {
   const uint32_t k = blockIdx.x;
   if (k >= n) return;
   const uint64_t s = raw_off[doc_ids[k]], len = raw_off[doc_ids[k] + 1] - s, o = dst_off[k];
-  for (uint64_t j = threadIdx.x; j < len; j += blockDim.x) staging[o + j] = raw[s + j];
+  copy_doc<true>(staging + o, raw + s, len);
 }
 // place the host-normalized documents after the device-normalized text and record their ranges
 __global__ void k_place_fallback(const uint8_t* __restrict__ staging, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ doc_ids,
@@ -504,7 +520,7 @@ __global__ void k_place_fallback(const uint8_t* __restrict__ staging, const uint
   if (k >= n) return;
   const uint64_t s = src_off[k], len = src_off[k + 1] - s;
   if (threadIdx.x == 0) { nbegin[doc_ids[k]] = base + s; nend[doc_ids[k]] = base + s + len; }
-  for (uint64_t j = threadIdx.x; j < len; j += blockDim.x) out[base + s + j] = staging[s + j];
+  copy_doc<false>(out + base + s, staging + s, len);
 }
 
 }  // namespace tmh
@@ -683,6 +699,13 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   if (gpu_bytes + noff.back() > b->max_bytes) {
     return set_error(TM_E_LIMIT, "normalized text needs %llu bytes, workspace sized for %llu", (unsigned long long)(gpu_bytes + noff.back()), (unsigned long long)b->max_bytes);
   }
+  // the host-normalized documents go behind the device part; placing them (reads over PCIe) runs on the second stream beside the
+  // compaction of the device part — different bytes of d_text, different documents' ranges
+  if (nf > 0) {
+    hipStream_t sx = b->aux_stream;
+    { int rc = small_h2d(b, b->d_fb_noff, noff.data(), noff.size() * 8, sx); if (rc != TM_OK) return rc; }
+    k_place_fallback<<<(uint32_t)ids.size(), 256, 0, sx>>>(hnorm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), gpu_bytes, b->d_text, b->d_nbegin, b->d_nend);
+  }
   if (np > 0) {
     if (h_info[3] == 0) {
       k_norm_compact<<<pgrid, 256, 0, st>>>(b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text);
@@ -695,10 +718,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   k_norm_ranges<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);
   uint64_t total = gpu_bytes;
   if (nf > 0) {
-    // the placement kernel reads the host normalizer's output where it lies (pinned host memory)
-    { int rc = small_h2d(b, b->d_fb_noff, noff.data(), noff.size() * 8, st); if (rc != TM_OK) return rc; }
-    k_place_fallback<<<(uint32_t)ids.size(), 256, 0, st>>>(hnorm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), total, b->d_text, b->d_nbegin, b->d_nend);
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "fallback placement");
+    { int rc = small_sync(b, b->aux_stream); if (rc != TM_OK) return rc; }       // the placement: the text and ranges it wrote are read on `st` next
     total += noff.back();
     b->host_fallback_docs = (uint32_t)ids.size();
     f4 = now();
