@@ -681,7 +681,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     const uint32_t threads = (uint32_t)std::min<size_t>(std::min<size_t>(std::min<uint32_t>(128u, host_share), ids.size() / 8 + 1), (size_t)(roff.back() >> 18) + 1);
     hipError_t he = hipSuccess;
     int rc = normalize_batch_into(b->h_fb_raw, roff.data(), (uint32_t)ids.size(), capcode, norm_flag, threads, noff.data(), [&](uint64_t total) -> uint8_t* {
-      if (!b->h_fb_norm || b->h_fb_norm_cap < total + 16) {                         // pinned: the H2D below then runs at link speed
+      if (!b->h_fb_norm || b->h_fb_norm_cap < total + 16) {                         // pinned: the placement kernel reads it where it lies
         (void)hipHostFree(b->h_fb_norm);
         b->h_fb_norm = nullptr;
         b->h_fb_norm_cap = total + total / 4 + 4096;

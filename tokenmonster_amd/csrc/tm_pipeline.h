@@ -99,8 +99,7 @@ struct tm_batch {
   uint64_t* d_nend = nullptr;
   uint64_t* d_ninfo = nullptr;          // [0] #fallback docs [1] #long docs [2] #segments (device-computed)
   // grow-only staging for the host fallback
-  uint8_t* d_fb_raw = nullptr; uint8_t* d_fb_norm = nullptr; uint64_t* d_fb_roff = nullptr; uint64_t* d_fb_noff = nullptr; uint32_t* d_fb_ids = nullptr;
-  uint64_t fb_raw_cap = 0, fb_norm_cap = 0;
+  uint64_t* d_fb_roff = nullptr; uint64_t* d_fb_noff = nullptr; uint32_t* d_fb_ids = nullptr;   // lists of the host-fallback documents
   // small transfers (counters, lists of a few hundred KB) go through a pinned mailbox and a copy kernel on the caller's stream
   // instead of the copy engines, where they would queue behind the bulk transfers of other lanes (small_d2h / small_h2d)
   uint8_t* h_mail = nullptr; uint64_t mail_pos = 0;
