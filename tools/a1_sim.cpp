@@ -146,6 +146,90 @@ int main(int argc, char** argv) {
     printf("   first position of a run: %.2f gathers (others %.2f)\n", (double)st.first_g / st.first_n, (g - st.first_g) / (st.pos - st.first_n));
   }
 
+  // lockstep model with run splitting: every `every` rounds a lane whose run is finished takes the back half of what its right
+  // (mode 1) or right-else-left (mode 2) neighbour has not started yet; the stolen run starts from the direct map (no link).
+  // Result on the englishcode-32000 shape: 30.6 rounds per wavefront without, 30.3 with (and 8 % more gathers): the rounds of a
+  // wavefront are set by ONE deep walk (a multi-word token, one byte per round), which no hand-out can split.
+  for (int mode = 0; mode < 3; mode++) for (int every : {1, 4}) {
+    if (mode == 0 && every != 1) continue;
+    uint64_t rounds_total = 0, waves = 0, gathers = 0, steals = 0;
+    for (uint32_t d = 0; d < nd; d++) {
+      const uint64_t b0 = off[d], e0 = off[d + 1];
+      for (uint64_t begin = b0; begin < e0; begin += SEG) {
+        const int dl = (int)std::min<uint64_t>(e0 - begin, 1 << 20);
+        const uint8_t* t = text + begin;
+        auto at = [&](int i) -> uint32_t { return i < dl ? t[i] : 0u; };
+        const int ntask = std::min(NPOS, dl);
+        const int nwalkpos = dl <= NPOS ? ntask - 1 : ntask;
+        const int run = (std::max(nwalkpos, 0) + 63) >> 6;
+        struct L { int pos, end, left, depth; uint32_t node; bool first; } ln[64];
+        // gathers the walk at `pos` needs given the state the previous position of the run ended in
+        auto cost = [&](L& l) {
+          const int pos = l.pos, limit = std::min(dl - pos, Lmax);
+          const uint2* e = (!l.first && l.depth >= 3) ? link + 2 * (size_t)l.node : direct + 2 * (size_t)(at(pos) | (at(pos + 1) << 8));
+          int rounds = 1;
+          uint32_t src = e[0].x, filt = e[1].x;
+          int depth = (int)((src >> 23) & 63u); uint32_t node = src & kNodeMask;
+          bool from_set = true, go = (src & kHasChildren) != 0 && depth < limit;
+          while (go) {
+            const uint32_t c = at(pos + depth);
+            if (from_set ? !((filt >> (c & 31u)) & 1u) : !((filt >> (c & 3u)) & 1u)) break;
+            const uint32_t key = (node << 8) | c;
+            uint32_t h = edge_hash(node, c) >> hv.edge_shift;
+            bool hit = false;
+            for (;;) { rounds++; const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1];
+              if ((s0.x & kKeyMask) == key) { hit = true; src = s0.y; filt = s0.x >> 28; from_set = false; break; }
+              if ((s1.x & kKeyMask) == key) { hit = true; src = s1.y; filt = s1.x >> 28; from_set = false; break; }
+              if (s1.x == kNone) break; h = (h + 1) & hv.edge_mask; }
+            if (!hit) break;
+            depth++; node = src & kNodeMask; go = (src & kHasChildren) != 0 && depth < limit;
+          }
+          l.depth = depth; l.node = node; l.first = false; l.left = rounds;
+        };
+        for (int lane = 0; lane < 64; lane++) {
+          L& l = ln[lane];
+          l.pos = lane * run; l.end = std::max(std::min(lane * run + run, nwalkpos), 0); l.first = true; l.depth = 0; l.node = 0; l.left = 0;
+          if (l.pos < l.end) cost(l);
+        }
+        int tnow = 0;
+        for (;;) {
+          bool any = false;
+          for (int lane = 0; lane < 64; lane++) any |= ln[lane].left > 0;
+          if (!any) break;
+          tnow++;
+          for (int lane = 0; lane < 64; lane++) {
+            L& l = ln[lane];
+            if (l.left == 0) continue;
+            gathers++;
+            if (--l.left == 0) { l.pos++; if (l.pos < l.end) cost(l); }
+          }
+          if (mode != 0 && tnow % every == 0) {
+            bool idle[64]; int vp[64], ve[64];
+            for (int lane = 0; lane < 64; lane++) { idle[lane] = ln[lane].left == 0; vp[lane] = ln[lane].pos; ve[lane] = ln[lane].end; }
+            bool taken[64] = {false};
+            for (int lane = 0; lane < 64; lane++) {
+              if (!idle[lane]) continue;
+              int cand[2] = {lane + 1, mode == 2 ? lane - 1 : 64};
+              for (int k = 0; k < 2; k++) {
+                const int v = cand[k];
+                if (v < 0 || v > 63 || idle[v] || taken[v]) continue;
+                const int rem = ve[v] - vp[v] - 1;               // positions the victim has not started
+                if (rem < 1) continue;
+                const int m = ve[v] - (rem + 1) / 2;
+                ln[lane].pos = m; ln[lane].end = ve[v]; ln[lane].first = true; cost(ln[lane]);
+                ln[v].end = m; taken[v] = true; steals++;
+                break;
+              }
+            }
+          }
+        }
+        rounds_total += tnow; waves++;
+      }
+    }
+    printf("lockstep mode %d (0 static, 1 steal right, 2 steal right/left) every %d rounds: rounds/wave %.2f gathers/wave %.1f steals/wave %.2f\n", mode, every,
+           (double)rounds_total / waves, (double)gathers / waves, (double)steals / waves);
+  }
+
   // dynamic hand-out: runs of r consecutive positions, a lane that finishes takes the next unassigned run (from scratch)
   for (int variant = 0; variant < 2; variant++) for (int r = 1; r <= 6; r++) {
     uint64_t rounds_total = 0, waves = 0, gathers = 0, npos = 0;
