@@ -230,6 +230,70 @@ int main(int argc, char** argv) {
            (double)rounds_total / waves, (double)gathers / waves, (double)steals / waves);
   }
 
+  // skip edges (path compression): an edge carries up to K bytes of the non-accepting unary chain below its child and the node at
+  // the chain's end; a probe that hits and finds those bytes in the text advances 1 + L levels in one round.  Collisions are
+  // modelled with the existing two-slot buckets (a 16-byte single-slot table of twice the buckets behaves about the same).
+  {
+    std::vector<uint32_t> only_byte(hv.n_nodes, 0), only_child(hv.n_nodes, kNone);
+    for (uint32_t sl = 0; sl < 2 * (hv.edge_mask + 1); sl++) {
+      const uint2 e = hv.tab[sl];
+      if (e.x == kNone) continue;
+      const uint32_t parent = (e.x & kKeyMask) >> 8;
+      if (nchild[parent] == 1) { only_byte[parent] = e.x & 0xFFu; only_child[parent] = e.y; }
+    }
+    for (int K : {0, 4, 8, 12}) {
+      uint64_t rounds_total = 0, waves = 0, gathers = 0, jumps = 0, jumped = 0;
+      for (uint32_t d = 0; d < nd; d++) {
+        const uint64_t b0 = off[d], e0 = off[d + 1];
+        for (uint64_t begin = b0; begin < e0; begin += SEG) {
+          const int dl = (int)std::min<uint64_t>(e0 - begin, 1 << 20);
+          const uint8_t* t = text + begin;
+          auto at = [&](int i) -> uint32_t { return i < dl ? t[i] : 0u; };
+          const int ntask = std::min(NPOS, dl);
+          const int nwalkpos = dl <= NPOS ? ntask - 1 : ntask;
+          const int run = (std::max(nwalkpos, 0) + 63) >> 6;
+          int wave_rounds = 0;
+          for (int lane = 0; lane < 64; lane++) {
+            int pos = lane * run;
+            const int end = std::max(std::min(lane * run + run, nwalkpos), 0);
+            int rounds = 0, depth = 0; uint32_t node = 0; bool first = true;
+            while (pos < end) {
+              const int limit = std::min(dl - pos, Lmax);
+              const uint2* e = (!first && depth >= 3) ? link + 2 * (size_t)node : direct + 2 * (size_t)(at(pos) | (at(pos + 1) << 8));
+              rounds++;
+              uint32_t src = e[0].x, filt = e[1].x;
+              depth = (int)((src >> 23) & 63u); node = src & kNodeMask;
+              bool from_set = true, go = (src & kHasChildren) != 0 && depth < limit;
+              while (go) {
+                const uint32_t c = at(pos + depth);
+                if (from_set ? !((filt >> (c & 31u)) & 1u) : !((filt >> (c & 3u)) & 1u)) break;
+                const uint32_t key = (node << 8) | c;
+                uint32_t h = edge_hash(node, c) >> hv.edge_shift;
+                bool hit = false;
+                for (;;) { rounds++; const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1];
+                  if ((s0.x & kKeyMask) == key) { hit = true; src = s0.y; filt = s0.x >> 28; from_set = false; break; }
+                  if ((s1.x & kKeyMask) == key) { hit = true; src = s1.y; filt = s1.x >> 28; from_set = false; break; }
+                  if (s1.x == kNone) break; h = (h + 1) & hv.edge_mask; }
+                if (!hit) break;
+                depth++; node = src & kNodeMask;
+                // the chain below `node`: non-accepting nodes with one child each
+                int L = 0; uint32_t cn = node, csrc = src;
+                while (L < K && cn >= hv.n_info && nchild[cn] == 1 && depth + L < limit && at(pos + depth + L) == only_byte[cn]) { csrc = only_child[cn]; cn = csrc & kNodeMask; L++; }
+                if (L > 0) { jumps++; jumped += L; depth += L; node = cn; src = csrc; filt = 0xF; /* (the end node's filter rides in the slot too) */ }
+                go = (src & kHasChildren) != 0 && depth < limit;
+              }
+              first = false; pos++;
+            }
+            wave_rounds = std::max(wave_rounds, rounds); gathers += rounds;
+          }
+          rounds_total += wave_rounds; waves++;
+        }
+      }
+      printf("skip edges, up to %2d chain bytes per slot: rounds/wave %.2f gathers/wave %.1f jumps/wave %.1f (%.2f levels each)\n", K, (double)rounds_total / waves,
+             (double)gathers / waves, (double)jumps / waves, jumps ? (double)jumped / jumps : 0.0);
+    }
+  }
+
   // dynamic hand-out: runs of r consecutive positions, a lane that finishes takes the next unassigned run (from scratch)
   for (int variant = 0; variant < 2; variant++) for (int r = 1; r <= 6; r++) {
     uint64_t rounds_total = 0, waves = 0, gathers = 0, npos = 0;
