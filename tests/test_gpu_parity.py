@@ -6,7 +6,7 @@ import pytest
 
 import tokenmonster_amd as tm
 from tokenmonster_amd import synth
-from conftest import fuzz_text, fuzz_vocab_tokens, unit_vocab_image
+from conftest import EMULATED, fuzz_text, fuzz_vocab_tokens, unit_vocab_image
 from oracle_bind import Oracle, Reference, have_ref, oracle_stats
 
 pytestmark = pytest.mark.gpu
@@ -480,7 +480,7 @@ def test_full_size_properties():
     name = "englishcode-32000-consistent"
     kind, size, capcode, norm_flag, level, seed = synth.CONFIGS[name]
     v, orc = tm.Vocab(synth.config_vocab(name)), Oracle(synth.config_vocab(name))
-    raw, offs = synth.synth_corpus(kind, 256 << 20, seed=0x434F5250 + 77)
+    raw, offs = synth.synth_corpus(kind, (4 << 20) if EMULATED else (256 << 20), seed=0x434F5250 + 77)   # (the emulation leg runs ~1 MiB/s)
     text, noff = synth.normalize_batch(raw, offs, capcode, norm_flag)
     nd = noff.size - 1
     ids, toff, missing = v.tokenize_packed(text, noff)

@@ -60,15 +60,15 @@ extern "C" int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const 
                       (e = hipMemcpy(d_toff, tok_offsets, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess)) rc = hip_fail(e, "H2D tokens");
   uint64_t total = 0;
   if (rc == TM_OK) {
-    if (n) k_dec_len<<<(uint32_t)((n + 255) / 256), 256>>>(d_tok, n, v->d_rev_off, v->host.n_ids, d_len);
+    if (n) TM_LAUNCH(k_dec_len, (uint32_t)((n + 255) / 256), 256, 0, 0, d_tok, n, v->d_rev_off, v->host.n_ids, d_len);
     scan_u32(d_len, n, d_sums, d_total, d_off, nullptr);
-    k_dec_doc_off<<<(ndocs + 256) / 256, 256>>>(d_off, d_toff, ndocs, d_doff);
+    TM_LAUNCH(k_dec_doc_off, (ndocs + 256) / 256, 256, 0, 0, d_off, d_toff, ndocs, d_doff);
     if ((e = hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost)) != hipSuccess ||
         (e = hipMemcpy(doff.data(), d_doff, doff.size() * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "decode lengths");
   }
   if (rc == TM_OK && (e = hipMalloc((void**)&d_out, total + 16)) != hipSuccess) rc = hip_fail(e, "hipMalloc (decode output)");
   if (rc == TM_OK) {
-    if (n) k_dec_copy<<<(uint32_t)((n + 255) / 256), 256>>>(d_tok, n, v->d_rev_off, v->d_rev_bytes, v->host.n_ids, d_off, d_out);
+    if (n) TM_LAUNCH(k_dec_copy, (uint32_t)((n + 255) / 256), 256, 0, 0, d_tok, n, v->d_rev_off, v->d_rev_bytes, v->host.n_ids, d_off, d_out);
     rawbytes.resize(total);
     if (total && (e = hipMemcpy(rawbytes.data(), d_out, total, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_fail(e, "D2H decoded bytes");
   }

@@ -9,6 +9,29 @@
 #include "tm_internal.h"
 #include "tm_tables.h"
 
+// Kernel launches, raw LDS addresses and the two register-pinning asm statements go through these macros so that tools/emu (test
+// infrastructure: the kernel sources compiled for the host, work-items as fibers) can build the same files.  TM_EMU is never defined
+// in the product build, where every macro expands to exactly the tokens it replaced.
+#ifdef TM_EMU
+#define TM_LAUNCH(kern, grid, block, shmem, stream, ...) emu::launch(grid, block, [=]() { kern(__VA_ARGS__); })
+#define TM_LDS_SPACE
+#define TM_LDS_SPACE_UNALIGNED __attribute__((aligned(1)))
+#define TM_LDS_ADDR(p) emu::lds_addr(p)
+#define TM_LDS_PTR(T, a) ((T*)emu::lds_ptr(a))
+#define TM_LDS_OBJECTS(a, b) emu::lds_objects(&(a), sizeof(a), &(b), sizeof(b))
+#define TM_KEEP_IN_VGPRS2(a, b) ((void)0)
+#define TM_KEEP_IN_VGPRS4(a, b, c, d) ((void)0)
+#else
+#define TM_LAUNCH(kern, grid, block, shmem, stream, ...) kern<<<grid, block, shmem, stream>>>(__VA_ARGS__)
+#define TM_LDS_SPACE __attribute__((address_space(3)))
+#define TM_LDS_SPACE_UNALIGNED __attribute__((address_space(3), aligned(1)))
+#define TM_LDS_ADDR(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(p))     // 32-bit LDS byte address of an object
+#define TM_LDS_PTR(T, a) ((T*)(uintptr_t)(a))                                                        // and back (T: a TM_LDS_SPACE type)
+#define TM_LDS_OBJECTS(a, b) ((void)0)
+#define TM_KEEP_IN_VGPRS2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define TM_KEEP_IN_VGPRS4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#endif
+
 namespace tmh {
 
 int hip_fail(hipError_t e, const char* what);

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
   const int lane = threadIdx.x & 63, wvi = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the segment, its document and lengths live in SGPRs
+  TM_LDS_OBJECTS(s_bb, s_wave);
   s_bb[threadIdx.x] = T.begin_byte[threadIdx.x];
   __syncthreads();
   const uint64_t g = (uint64_t)blockIdx.x * WAVES + wvi;
@@ -349,11 +350,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       if (r != kNone && node_id(r) < T.n_info) { w.D[dl - 1] = 1u | ((r >> 22) << 6); w.X[dl - 1] = r; }
     }
     // Positions are carried as LDS byte addresses of their text byte (one add less per use, and the kernel is VALU bound).
-    typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    typedef __attribute__((address_space(3), aligned(1))) uint16_t lds_u16u;
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    const uint32_t tb = (uint32_t)(uintptr_t)(lds_u8*)w.text;                       // address of text[0]
-    const uint32_t dconst = (uint32_t)(uintptr_t)(lds_u8*)w.D - 4u * tb;              // &D[i] == dconst + 4 * (tb + i)
+    typedef TM_LDS_SPACE uint8_t lds_u8;
+    typedef TM_LDS_SPACE_UNALIGNED uint16_t lds_u16u;
+    typedef TM_LDS_SPACE uint32_t lds_u32;
+    const uint32_t tb = TM_LDS_ADDR(w.text);                                        // address of text[0]
+    const uint32_t dconst = TM_LDS_ADDR(w.D) - 4u * tb;                               // &D[i] == dconst + 4 * (tb + i)
     const int run = (max(nwalkpos, 0) + 63) >> 6;
     uint32_t posa = tb + (uint32_t)(lane * run);
     const uint32_t enda = tb + (uint32_t)max(min(lane * run + run, nwalkpos), 0), dla = tb + (uint32_t)dl;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     bool probing = false, setting = posa < enda;         // the state of the run; the compiler keeps these as lane masks
     if (setting) {
       limit = min((int)(dla - posa), Lmax);
-      off = T.direct_off + ((uint32_t)*(lds_u16u*)(uintptr_t)posa << 4);
+      off = T.direct_off + ((uint32_t)*TM_LDS_PTR(lds_u16u, posa) << 4);
       pfa = posa + 2u;
     }
 #ifdef TM_DEVEL
@@ -377,9 +378,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       // a lane is busy exactly as long as its gather address is not the idle slot
       while (__builtin_amdgcn_ballot_w64(off != idle_off) != 0ull) {
         const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // link format {x, y, child filter, best depth}, or a hash bucket {key0 | filter, value0, key1 | filter, value1}
-        uint32_t c = *(lds_u8*)(uintptr_t)pfa;
-        uint32_t nn = *(lds_u16u*)(uintptr_t)(posa + 1u);                // the two bytes at the next position, as the direct map indexes them
-        asm volatile("" : "+v"(c), "+v"(nn));                            // both LDS reads are issued here, under the gather's latency
+        uint32_t c = *TM_LDS_PTR(lds_u8, pfa);
+        uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);                // the two bytes at the next position, as the direct map indexes them
+        TM_KEEP_IN_VGPRS2(c, nn);                                        // both LDS reads are issued here, under the gather's latency
         const bool hit1 = probing && (e.z & kKeyMask) == key;
         const bool hit = hit1 || (probing && (e.x & kKeyMask) == key);
         const bool again = probing && !hit && e.z != kNone;              // both slots of the bucket hold other keys: next bucket
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         if (fin) {
           // position done: store (no match: bestlen == 0 and the link formats give bestv == 0, so the descriptor written is the
           // 0 that is there already), move on — through the suffix link if the walk got deep enough, else from the direct map
-          lds_u32* dp = (lds_u32*)(uintptr_t)(dconst + 4u * posa);
+          lds_u32* dp = TM_LDS_PTR(lds_u32, dconst + 4u * posa);
           dp[0] = (uint32_t)bestlen | ((bestv >> 22) << 6);              // D[pos]
           dp[2 * NPOS] = bestv;                                           // X[pos]
           posa++;
@@ -583,10 +584,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     // J entry: #tokens [0..15] | field [16..30] | left-the-segment [31]; the field is the LDS byte address of the entry it points
     // at, or — once the chain has left the segment — the entry state of the next segment (0x7FFF: the state is unreachable).
     // Composing two entries is (x & 0xFFFF) + x', and the address to read next is x >> 16.
-    typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    auto ld_j = [](uint32_t a) -> uint32_t { return *(lds_u32*)(uintptr_t)a; };
-    const uint32_t jaddr = (uint32_t)(uintptr_t)(lds_u8*)w.D;
+    typedef TM_LDS_SPACE uint32_t lds_u32;
+    auto ld_j = [](uint32_t a) -> uint32_t { return *TM_LDS_PTR(lds_u32, a); };
+    const uint32_t jaddr = TM_LDS_ADDR(w.D);
     static_assert(sizeof(s_wave) + 2048 < 32768, "LDS addresses must fit the 15-bit field");
     auto first_hop = [&](uint32_t r, int p, uint32_t fd) -> uint32_t {
       // at/after the end of the segment: nothing is emitted here.  At the end of the text that is the terminal state; in a byte
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
                                                    uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
                                                    uint32_t* __restrict__ error_flag, uint32_t stage_after, const uint32_t* __restrict__ seg_doc,
                                                    uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing) {
-  __shared__ alignas(16) uint32_t s_tile[TS][TROW];
+  alignas(16) __shared__ uint32_t s_tile[TS][TROW];
   const int lane = threadIdx.x;
   const uint64_t g0 = (uint64_t)blockIdx.x * TS;
   const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
@@ -1009,8 +1009,8 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
                                                         const uint4* __restrict__ par, uint64_t nseg, uint32_t delete_id,
                                                         uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
                                                         uint32_t* __restrict__ missing_bits, uint32_t* __restrict__ error_flag) {
-  __shared__ alignas(16) uint32_t s_tile[WV][TS][TROW];
-  __shared__ alignas(16) unsigned long long s_w[HSLOTS];
+  alignas(16) __shared__ uint32_t s_tile[WV][TS][TROW];
+  alignas(16) __shared__ unsigned long long s_w[HSLOTS];
   __shared__ unsigned long long s_ntok;
   __shared__ uint32_t s_ndel;
   for (int j = threadIdx.x; j < HSLOTS; j += WV * 64) s_w[j] = HEMPTY;
@@ -1141,10 +1141,10 @@ template <typename T>
 static hipError_t dalloc(tm_batch* b, T** p, uint64_t count) { return batch_alloc_bytes(b, (void**)p, count * sizeof(T)); }
 
 void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32_t ndocs, uint32_t unit, uint32_t* doc_nunits, hipStream_t st) {
-  if (ndocs) k_doc_nseg<<<(ndocs + 255) / 256, 256, 0, st>>>(doc_begin, doc_end, ndocs, doc_nunits, unit);
+  if (ndocs) TM_LAUNCH(k_doc_nseg, (ndocs + 255) / 256, 256, 0, st, doc_begin, doc_end, ndocs, doc_nunits, unit);
 }
 void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st) {
-  if (nunits) k_segments<<<(uint32_t)((nunits + 255) / 256), 256, 0, st>>>(doc_unit_start, ndocs, nunits, unit_doc);
+  if (nunits) TM_LAUNCH(k_segments, (uint32_t)((nunits + 255) / 256), 256, 0, st, doc_unit_start, ndocs, nunits, unit_doc);
 }
 static void launch_seg_params(tm_batch* b, hipStream_t st);
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
@@ -1153,15 +1153,15 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
   if (nseg > 0) {
     launch_seg_params(b, st);
     constexpr int WV = SEG <= 256 ? 11 : 5;      // wavefronts of a scoring workgroup: as many tiles as fit the LDS beside the histogram
-    k_score_tiles<WV><<<(uint32_t)std::min<uint64_t>((nseg + WV * TS - 1) / (WV * TS), (uint64_t)n_cu), WV * 64, 0, st>>>(
+    TM_LAUNCH(k_score_tiles<WV>, (uint32_t)std::min<uint64_t>((nseg + WV * TS - 1) / (WV * TS), (uint64_t)n_cu), WV * 64, 0, st, 
         b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_seg_par, nseg, delete_id, d_hist, d_tokens, d_missing_bits, b->d_error);
   }
-  k_hist_finish<<<1, 256, 0, st>>>(d_tokens, d_missing_bits, d_hist + n_ids);
+  TM_LAUNCH(k_hist_finish, 1, 256, 0, st, d_tokens, d_missing_bits, d_hist + n_ids);
 }
 
 // the per-segment records of k_seg_params (after the token-offset scan)
 static void launch_seg_params(tm_batch* b, hipStream_t st) {
-  k_seg_params<<<(uint32_t)((b->nseg + 1 + 255) / 256), 256, 0, st>>>(b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, b->nseg, b->ndocs, b->d_seg_entry,
+  TM_LAUNCH(k_seg_params, (uint32_t)((b->nseg + 1 + 255) / 256), 256, 0, st, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, b->nseg, b->ndocs, b->d_seg_entry,
                                                                       b->d_seg_tokbase, b->d_tok_offsets, b->d_seg_par);
 }
 // K4 for the id-emitting entry points: the tile walk (test hook bit 10: every id stored directly, the overflow path of the staging)
@@ -1173,10 +1173,10 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store) {
   (void)hipMemsetAsync(b->d_doc_missing, 0, (size_t)nd * 4, st);
   if (nseg > 0) {
     launch_seg_params(b, st);
-    k_emit_tiles<<<(uint32_t)((nseg + TS - 1) / TS), 64, 0, st>>>(b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
+    TM_LAUNCH(k_emit_tiles, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
                                                                  b->d_error, (debug_flags() & 1024) ? 512u : 0u, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing);
   }
-  if (nd) k_doc_events<<<(nd + 255) / 256, 256, 0, st>>>(b->d_doc_ntok, b->d_doc_fd, nd, b->d_doc_events);
+  if (nd) TM_LAUNCH(k_doc_events, (nd + 255) / 256, 256, 0, st, b->d_doc_ntok, b->d_doc_fd, nd, b->d_doc_events);
 }
 
 // the same scan for up to SCAN1_MAX elements in ONE launch of one workgroup (a run of elements per thread): a server batch or a chunk of the
@@ -1205,11 +1205,11 @@ __global__ __launch_bounds__(SCAN1_T) void k_scan_single(const uint32_t* __restr
 }
 
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {
-  if (n <= SCAN1_MAX) { k_scan_single<<<1, SCAN1_T, 0, st>>>(in, (uint32_t)n, total, out); return; }
+  if (n <= SCAN1_MAX) { TM_LAUNCH(k_scan_single, 1, SCAN1_T, 0, st, in, (uint32_t)n, total, out); return; }
   uint32_t nblocks = (uint32_t)((n + 1 + SCAN_CH - 1) / SCAN_CH);   // covers index n (the total slot)
-  k_scan_partial<<<nblocks, SCAN_T, 0, st>>>(in, n, block_sums);
-  k_scan_sums<<<1, SCAN_T, 0, st>>>(block_sums, nblocks, total);
-  k_scan_final<<<nblocks, SCAN_T, 0, st>>>(in, n, block_sums, out);
+  TM_LAUNCH(k_scan_partial, nblocks, SCAN_T, 0, st, in, n, block_sums);
+  TM_LAUNCH(k_scan_sums, 1, SCAN_T, 0, st, block_sums, nblocks, total);
+  TM_LAUNCH(k_scan_final, nblocks, SCAN_T, 0, st, in, n, block_sums, out);
 }
 
 // host: the group tree of the long documents.  doc d has lens[d] bytes; segments are numbered in document order.  groups[] holds
@@ -1295,21 +1295,21 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   const uint64_t nseg = b->nseg;
   mark(0);
   if (nd > 0) {
-    k_doc_nseg<<<(nd + 255) / 256, 256, 0, st>>>(b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nseg);
+    TM_LAUNCH(k_doc_nseg, (nd + 255) / 256, 256, 0, st, b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nseg);
     scan_u32(b->d_doc_nseg, nd, b->d_scan_tmp, b->d_totals + 0, b->d_doc_seg_start, st);
-    if (nseg > 0) k_segments<<<(uint32_t)((nseg + 255) / 256), 256, 0, st>>>(b->d_doc_seg_start, nd, nseg, b->d_seg_doc);
+    if (nseg > 0) TM_LAUNCH(k_segments, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_doc_seg_start, nd, nseg, b->d_seg_doc);
   }
   mark(1);
   if (nseg > 0)
-    k_match_branch<<<(uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st>>>(v->tables, b->d_text, b->d_doc_begin, b->d_doc_end,
+    TM_LAUNCH(k_match_branch, (uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st, v->tables, b->d_text, b->d_doc_begin, b->d_doc_end,
                                                                                           b->d_doc_vis ? b->d_doc_vis : b->d_doc_end, b->d_seg_doc,
                                                                                           b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
                                                                                           debug_flags());
   mark(2);
   for (size_t lvl = 0; lvl + 1 < b->level_first.size() && b->ngroups > 0; lvl++) {     // bottom up: a level reads the maps of the one below
     const uint32_t g0 = b->level_first[lvl], ng = b->level_first[lvl + 1] - g0;
-    if (lvl == 0) k_group_compose<true><<<ng, 128, 0, st>>>(b->d_exitmap, b->d_gmap, b->d_groups, g0, b->d_gmap);
-    else k_group_compose<false><<<ng, 128, 0, st>>>(b->d_exitmap, b->d_gmap, b->d_groups, g0, b->d_gmap);
+    if (lvl == 0) TM_LAUNCH(k_group_compose<true>, ng, 128, 0, st, b->d_exitmap, b->d_gmap, b->d_groups, g0, b->d_gmap);
+    else TM_LAUNCH(k_group_compose<false>, ng, 128, 0, st, b->d_exitmap, b->d_gmap, b->d_groups, g0, b->d_gmap);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
@@ -1320,15 +1320,15 @@ int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode) {
   const uint32_t nd = b->ndocs;
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   if (nd > 0)
-    k_resolve<<<(nd + 255) / 256, 256, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, nd, b->d_doc_entry, b->d_seg_entry, b->d_seg_tokbase,
+    TM_LAUNCH(k_resolve, (nd + 255) / 256, 256, 0, st, b->d_exitmap, b->d_doc_seg_start, nd, b->d_doc_entry, b->d_seg_entry, b->d_seg_tokbase,
                                                 b->d_doc_ntok, b->d_error, long_segs());
   if (b->ngroups > 0) {
-    k_long_top<<<(b->nlong + 63) / 64, 64, 0, st>>>(b->d_gmap, b->d_longs, b->nlong, b->d_doc_entry, b->d_group_entry, b->d_group_base, b->d_doc_ntok, b->d_error);
+    TM_LAUNCH(k_long_top, (b->nlong + 63) / 64, 64, 0, st, b->d_gmap, b->d_longs, b->nlong, b->d_doc_entry, b->d_group_entry, b->d_group_base, b->d_doc_ntok, b->d_error);
     for (size_t lvl = b->level_first.size() - 1; lvl-- > 0;) {                           // top down
       const uint32_t g0 = b->level_first[lvl], ng = b->level_first[lvl + 1] - g0;
-      if (lvl == 0) k_group_expand<true><<<(ng + 63) / 64, 64, 0, st>>>(b->d_exitmap, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
+      if (lvl == 0) TM_LAUNCH(k_group_expand<true>, (ng + 63) / 64, 64, 0, st, b->d_exitmap, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
                                                                          b->d_seg_entry, b->d_seg_tokbase, b->d_error);
-      else k_group_expand<false><<<(ng + 63) / 64, 64, 0, st>>>(b->d_exitmap, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
+      else TM_LAUNCH(k_group_expand<false>, (ng + 63) / 64, 64, 0, st, b->d_exitmap, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
                                                                  b->d_seg_entry, b->d_seg_tokbase, b->d_error);
     }
   }
@@ -1344,7 +1344,7 @@ int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode) {
 
 // exit state of every document for every entry state -> exits[ndocs * ENT] (device); needs pipeline_match
 void launch_doc_exits(tm_batch* b, uint8_t* d_exits, hipStream_t st) {
-  if (b->ndocs) k_doc_exits<<<b->ndocs, 128, 0, st>>>(b->d_exitmap, b->d_doc_seg_start, b->d_gmap, b->d_longs, b->nlong, d_exits, long_segs());
+  if (b->ndocs) TM_LAUNCH(k_doc_exits, b->ndocs, 128, 0, st, b->d_exitmap, b->d_doc_seg_start, b->d_gmap, b->d_longs, b->nlong, d_exits, long_segs());
 }
 
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) {
@@ -1373,7 +1373,7 @@ __global__ void k_copy_small(const uint8_t* __restrict__ src, uint8_t* __restric
 static void launch_copy_small(const void* src, void* dst, uint64_t n, hipStream_t st) {
   const int words = (((uintptr_t)src | (uintptr_t)dst | n) & 7u) == 0;
   const uint64_t items = words ? n / 8 : n;
-  k_copy_small<<<(uint32_t)((items + 255) / 256), 256, 0, st>>>((const uint8_t*)src, (uint8_t*)dst, n, words);
+  TM_LAUNCH(k_copy_small, (uint32_t)((items + 255) / 256), 256, 0, st, (const uint8_t*)src, (uint8_t*)dst, n, words);
 }
 // (test hook bit 13: a 64 KiB mailbox with transfers of at most 16 KiB, so that a small test wraps it and takes the copy-engine path too)
 static uint64_t mail_bytes() { return (debug_flags() & 8192) ? (64u << 10) : MAIL_BYTES; }
@@ -1559,7 +1559,7 @@ int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
   return build_groups(b, offsets, offsets + 1, ndocs, st);
 }
 void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* out, hipStream_t st) {
-  if (n) k_serialize<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(ids, n, enc, out);
+  if (n) TM_LAUNCH(k_serialize, (uint32_t)((n + 255) / 256), 256, 0, st, ids, n, enc, out);
 }
 }  // namespace tmh
 extern "C" {

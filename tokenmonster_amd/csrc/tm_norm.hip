@@ -337,9 +337,13 @@ __device__ const NmLut g_norm_lut = nm_make_lut();
 
 // per-lane select on a wave-uniform lane mask: bit set -> a, else b (one v_cndmask, the mask stays in scalar registers)
 __device__ __forceinline__ uint32_t sel_mask(unsigned long long mask, uint32_t a, uint32_t b) {
+#ifdef TM_EMU
+  return ((mask >> emu::cur->lane) & 1ull) ? a : b;
+#else
   uint32_t r;
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
   return r;
+#endif
 }
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask, uint32_t acc) {      // acc + #set bits of mask below the lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, acc));
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   constexpr int SLAB2 = 2 * PIECE, NCH = PIECE / 64;
   __shared__ PieceLds2 s_l[4];
   __shared__ uint8_t s_cls[128];
-  __shared__ alignas(16) uint16_t s_lut[NM_LUT_SIZE];
+  alignas(16) __shared__ uint16_t s_lut[NM_LUT_SIZE];
   static_assert(NM_LUT_SIZE * sizeof(uint16_t) == 256 * sizeof(uint4), "one 16-byte load per thread stages the rule table");
   if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
   reinterpret_cast<uint4*>(s_lut)[threadIdx.x] = reinterpret_cast<const uint4*>(g_norm_lut.e[lower_all ? 1 : 0])[threadIdx.x];
@@ -398,15 +402,15 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
     }
   }
   // ---- forward sweep ---------------------------------------------------------------------------------------------------
-  typedef __attribute__((address_space(3))) uint8_t lds_u8;
-  const uint32_t out0 = (uint32_t)(uintptr_t)(lds_u8*)L.out;
+  typedef TM_LDS_SPACE uint8_t lds_u8;
+  const uint32_t out0 = TM_LDS_ADDR(L.out);
   const uint32_t dump = out0 + (uint32_t)SLAB2 + (uint32_t)lane;     // where a lane's "not this byte" stores go
   unsigned long long w = (carry & 3u) ? 1ull : 0ull;
   uint32_t pos = 0;
   bool over = false;
   unsigned long long Ucur = __ballot((fl0[0] & NF_CLASS) == NC_U);
   uint32_t chC = 'C', chW = 'W', chSP = ' ', chD = 'D';
-  asm volatile("" : "+v"(chC), "+v"(chW), "+v"(chSP), "+v"(chD));      // four registers for the whole sweep, not four moves per chunk
+  TM_KEEP_IN_VGPRS4(chC, chW, chSP, chD);      // four registers for the whole sweep, not four moves per chunk
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     if (c < nch) {
@@ -436,10 +440,10 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
         // first output byte of the lane = out0 + pos + (bytes of the lanes below); its last byte is len1 further
         const uint32_t first = mbcnt64(ge4, mbcnt64(ge3, mbcnt64(ge2, mbcnt64(V, out0 + pos))));
         const uint32_t last = first + len1;
-        *(lds_u8*)(uintptr_t)sel_mask(V, last, dump) = (uint8_t)o3;
-        *(lds_u8*)(uintptr_t)sel_mask(ge2, last - 1u, dump) = (uint8_t)chSP;
-        *(lds_u8*)(uintptr_t)sel_mask(ge3, last - 2u, dump) = (uint8_t)(code >> 8);
-        *(lds_u8*)(uintptr_t)sel_mask(ge4, first, dump) = (uint8_t)chD;
+        *TM_LDS_PTR(lds_u8, sel_mask(V, last, dump)) = (uint8_t)o3;
+        *TM_LDS_PTR(lds_u8, sel_mask(ge2, last - 1u, dump)) = (uint8_t)chSP;
+        *TM_LDS_PTR(lds_u8, sel_mask(ge3, last - 2u, dump)) = (uint8_t)(code >> 8);
+        *TM_LDS_PTR(lds_u8, sel_mask(ge4, first, dump)) = (uint8_t)chD;
       } else over = true;                                   // wave-uniform: the piece does not fit its slab (exact two-pass path)
       pos += total;
       Ucur = Unext;
@@ -627,9 +631,9 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   const uint32_t pgrid = (uint32_t)((np + 3) / 4);
   if (np > 0) {
     launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
-    k_norm_summary<<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_sum);
+    TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_sum);
   }
-  k_norm_carry<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids,
+  TM_LAUNCH(k_norm_carry, (nd + 255) / 256, 256, 0, st, b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids,
                                                   normalize_on_device(capcode, norm_flag) ? 0u : 1u);
   unsigned long long h_info[4] = {0, 0, 0, 0};
   { int rc = small_d2h(b, h_info, ninfo, 8, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
@@ -640,10 +644,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   double f1 = now(), f2 = 0, f3 = 0, f4 = 0;
   // the device normalizes its documents (one pass into per-piece slabs, lengths on the side) ...
   if (np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
-    k_norm_emit2<<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
+    TM_LAUNCH(k_norm_emit2, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
                                         b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3);
   else if (np > 0)                    // capcode 0, or debug bit 8: the per-lane version of the rules
-    k_norm_emit<2><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+    TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                           b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3);
   scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
   if (nf > 0) {
@@ -665,7 +669,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     }
     { int rc = small_h2d(b, b->d_fb_ids, ids.data(), ids.size() * 4, sx); if (rc == TM_OK) rc = small_h2d(b, b->d_fb_roff, roff.data(), roff.size() * 8, sx); if (rc != TM_OK) return rc; }
     // the gather writes straight into the pinned host buffer (no staging copy, nothing on the copy engines)
-    k_gather_docs<<<(uint32_t)ids.size(), 256, 0, sx>>>(b->d_raw, b->d_raw_off, b->d_fb_ids, b->d_fb_roff, (uint32_t)ids.size(), b->h_fb_raw);
+    TM_LAUNCH(k_gather_docs, (uint32_t)ids.size(), 256, 0, sx, b->d_raw, b->d_raw_off, b->d_fb_ids, b->d_fb_roff, (uint32_t)ids.size(), b->h_fb_raw);
     if ((e = hipStreamSynchronize(sx)) != hipSuccess) return hip_fail(e, "fallback documents to the host");
     f2 = now();
   }
@@ -704,18 +708,18 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   if (nf > 0) {
     hipStream_t sx = b->aux_stream;
     { int rc = small_h2d(b, b->d_fb_noff, noff.data(), noff.size() * 8, sx); if (rc != TM_OK) return rc; }
-    k_place_fallback<<<(uint32_t)ids.size(), 256, 0, sx>>>(hnorm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), gpu_bytes, b->d_text, b->d_nbegin, b->d_nend);
+    TM_LAUNCH(k_place_fallback, (uint32_t)ids.size(), 256, 0, sx, hnorm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), gpu_bytes, b->d_text, b->d_nbegin, b->d_nend);
   }
   if (np > 0) {
     if (h_info[3] == 0) {
-      k_norm_compact<<<pgrid, 256, 0, st>>>(b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text);
+      TM_LAUNCH(k_norm_compact, pgrid, 256, 0, st, b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text);
     } else {
       // some piece expands beyond its slab (long runs of capitals): exact two-pass path
-      k_norm_emit<1><<<pgrid, 256, 0, st>>>(b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+      TM_LAUNCH(k_norm_emit<1>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                             b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text, nullptr);
     }
   }
-  k_norm_ranges<<<(nd + 255) / 256, 256, 0, st>>>(b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);
+  TM_LAUNCH(k_norm_ranges, (nd + 255) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);
   uint64_t total = gpu_bytes;
   if (nf > 0) {
     { int rc = small_sync(b, b->aux_stream); if (rc != TM_OK) return rc; }       // the placement: the text and ranges it wrote are read on `st` next
@@ -726,7 +730,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   }
   const double t2 = now();
   // ---- what the tokenize pipeline needs to know on the host: #segments, and the long documents if any ------------
-  k_norm_info<<<(nd + 255) / 256, 256, 0, st>>>(b->d_nbegin, b->d_nend, nd, ninfo, long_segs());
+  TM_LAUNCH(k_norm_info, (nd + 255) / 256, 256, 0, st, b->d_nbegin, b->d_nend, nd, ninfo, long_segs());
   { int rc = small_d2h(b, h_info, ninfo, 24, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
   b->nbytes = total;
   b->nseg = h_info[2];
