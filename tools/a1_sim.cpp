@@ -241,7 +241,7 @@ int main(int argc, char** argv) {
       const uint32_t parent = (e.x & kKeyMask) >> 8;
       if (nchild[parent] == 1) { only_byte[parent] = e.x & 0xFFu; only_child[parent] = e.y; }
     }
-    for (int K : {0, 4, 8, 12}) {
+    for (int K : {0, 2, 3, 4, 8}) {
       uint64_t rounds_total = 0, waves = 0, gathers = 0, jumps = 0, jumped = 0;
       for (uint32_t d = 0; d < nd; d++) {
         const uint64_t b0 = off[d], e0 = off[d + 1];
