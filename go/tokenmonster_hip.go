@@ -10,6 +10,7 @@
 //   (*Vocab).Tokenize / Count / TokenizeToSerialized over many documents   go/tokenmonster.go:959, :971, :986
 //   the goroutine fan-out of tokenmonsterserver jobs 1 and 20              training/tokenmonsterserver.go:363-378, :773-787
 //   the scoring loop of the trainvocab worker                              training/trainvocab.go:925-1176
+//   (*Vocab).Decode over many id streams, the streaming *Decoder, Save        go/tokenmonster.go:445, :552-700, :2602
 // Every call borrows Go memory for its duration only (cgo pointer rule).  Any error means: use the existing CPU path.
 // Goroutines may call concurrently: each call takes a lane (stream + workspace) of the vocabulary and makes the
 // vocabulary's device current on whatever OS thread the goroutine is on; no runtime.LockOSThread is needed.
@@ -220,6 +221,131 @@ func ScoreCandidate(d *HipDataset, tokens [][]byte, capcode, charset uint8, stri
 	var tit C.uint64_t
 	if C.tm_score(cand, d.h, so, sl, C.uint32_t(len(stripOff)), (*C.uint32_t)(unsafe.Pointer(&scores[0])), &tit,
 		(*C.uint8_t)(unsafe.Pointer(&missing[0]))) != C.TM_OK {
+		return nil, 0, missing, hipErr()
+	}
+	return scores[:len(scores)-1], uint64(tit), missing, nil
+}
+
+// ---- the Detokenize half: Decode (go/tokenmonster.go:445) and the streaming Decoder (:552-700) --------------------------------
+
+// DecodeBatch is (*Vocab).Decode over many id streams in one call: the gather of the token bytes runs on the device, capcode
+// decoding follows (raw == true skips it, like the C++ runtime's decode_raw).
+func (hv *HipVocab) DecodeBatch(tokens [][]uint32, raw bool) ([][]byte, error) {
+	n := len(tokens)
+	tokOff := make([]uint64, n+1)
+	total := 0
+	for i, t := range tokens {
+		total += len(t)
+		tokOff[i+1] = uint64(total)
+	}
+	flat := make([]uint32, total+1)
+	for i, t := range tokens {
+		copy(flat[tokOff[i]:], t)
+	}
+	outOff := make([]uint64, n+1)
+	capBytes := uint64(total)*6 + 64
+	r := C.int(0)
+	if raw {
+		r = 1
+	}
+	for {
+		out := make([]byte, capBytes+1)
+		rc := C.tm_decode_batch(hv.h, (*C.uint32_t)(unsafe.Pointer(&flat[0])), (*C.uint64_t)(unsafe.Pointer(&tokOff[0])), C.uint32_t(n), r,
+			(*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(capBytes), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
+		if rc == C.TM_E_NOSPACE { // the capacity required is reported in outOff[n]
+			capBytes = outOff[n]
+			continue
+		}
+		if rc != C.TM_OK {
+			return nil, hipErr()
+		}
+		res := make([][]byte, n)
+		for i := range res {
+			res[i] = out[outOff[i]:outOff[i+1]]
+		}
+		return res, nil
+	}
+}
+
+// HipDecoder is the twin of *Decoder (go/tokenmonster.go:552 NewDecoder): ids arrive a few at a time, Decode returns the text that
+// is complete so far and keeps the bytes of a cut UTF-8 character and the capcode state for the next call; Flush hands back the rest.
+type HipDecoder struct{ h *C.tm_decoder }
+
+func (hv *HipVocab) NewDecoder() (*HipDecoder, error) {
+	var d *C.tm_decoder
+	if C.tm_decoder_new(hv.h, &d) != C.TM_OK {
+		return nil, hipErr()
+	}
+	return &HipDecoder{d}, nil
+}
+func (d *HipDecoder) Close() { C.tm_decoder_free(d.h) }
+
+func (d *HipDecoder) Decode(tokens []uint32) ([]byte, error) {
+	var tp *C.uint32_t
+	if len(tokens) > 0 {
+		tp = (*C.uint32_t)(unsafe.Pointer(&tokens[0]))
+	}
+	out := make([]byte, len(tokens)*48+64)
+	var n C.uint64_t
+	rc := C.tm_decoder_decode(d.h, tp, C.uint64_t(len(tokens)), (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+	if rc == C.TM_E_NOSPACE { // the ids HAVE been consumed and the text is kept: fetch it with n = 0 and a buffer of the size reported
+		out = make([]byte, uint64(n)+1)
+		rc = C.tm_decoder_decode(d.h, nil, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+	}
+	if rc != C.TM_OK {
+		return nil, hipErr()
+	}
+	return out[:n], nil
+}
+
+func (d *HipDecoder) Flush() ([]byte, error) {
+	out := make([]byte, 64)
+	var n C.uint64_t
+	rc := C.tm_decoder_flush(d.h, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+	if rc == C.TM_E_NOSPACE { // text of an earlier call that did not fit is still held: fetch everything with a buffer of the size reported
+		out = make([]byte, uint64(n)+1)
+		rc = C.tm_decoder_decode(d.h, nil, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+	}
+	if rc != C.TM_OK {
+		return nil, hipErr()
+	}
+	return out[:n], nil
+}
+
+// Save writes the vocabulary file back (go/tokenmonster.go:2602 Save): this library never mutates a vocabulary, so the bytes are the
+// ones LoadHip read.
+func (hv *HipVocab) Save(filename string) error {
+	cs := C.CString(filename)
+	defer C.free(unsafe.Pointer(cs))
+	if C.tm_vocab_save(hv.h, cs) != C.TM_OK {
+		return hipErr()
+	}
+	return nil
+}
+
+// ---- trainvocab over several GPUs: one process (or one locked OS thread) per device, each owning a byte range of the dataset -------
+// ScoreRangeBegin / ScoreRangeFinish are the two halves of a pass over the range [0, ownLen) of a dataset that was uploaded followed by
+// >= 128 bytes of the text that comes next (continues == true): Begin returns what the range does to each of the 80 entry states; the
+// ranks exchange those 80 bytes, rank r chains the maps of the ranks before it from state 0 to its own entry state, and Finish
+// completes the pass from there.  Summed over the ranks the histograms equal ONE walk over the whole dataset (trainvocab.go:909-922).
+func ScoreRangeBegin(cand *HipVocab, d *HipDataset, ownLen uint64, continues bool) (exits [80]byte, err error) {
+	c := C.int(0)
+	if continues {
+		c = 1
+	}
+	if C.tm_score_begin(cand.h, d.h, 0, C.uint64_t(ownLen), c, nil, (*C.uint8_t)(unsafe.Pointer(&exits[0]))) != C.TM_OK {
+		return exits, hipErr()
+	}
+	return exits, nil
+}
+
+func ScoreRangeFinish(cand *HipVocab, d *HipDataset, entryState uint32) (scores []uint32, tokensInText uint64, missing [32]byte, err error) {
+	if C.tm_score_finish(cand.h, d.h, C.uint32_t(entryState), nil, nil, 0) != C.TM_OK {
+		return nil, 0, missing, hipErr()
+	}
+	scores = make([]uint32, int(C.tm_vocab_n_ids(cand.h))+1)
+	var tit C.uint64_t
+	if C.tm_score_read(cand.h, d.h, (*C.uint32_t)(unsafe.Pointer(&scores[0])), &tit, (*C.uint8_t)(unsafe.Pointer(&missing[0]))) != C.TM_OK {
 		return nil, 0, missing, hipErr()
 	}
 	return scores[:len(scores)-1], uint64(tit), missing, nil

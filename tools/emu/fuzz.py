@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/emu/fuzz.py [seconds] [first_seed] — differential fuzzing of the kernel logic on the emulated device (tools/emu) against the
+"""tools/emu/fuzz.py [seconds] [first_seed] [norm] — differential fuzzing of the kernel logic on the emulated device (tools/emu) against the
 oracle: random small vocabularies (capcode 0 / 2, UTF-8 / UTF-16, with and without an unk token), batches of documents whose lengths
 sit on and around the segment (256), tile (8 x 256) and group (512 segments) boundaries, through tokenize / count / serialized /
 score (strips) / decode.  Device allocations end at guard pages, so an out-of-bounds access of a kernel is a crash here, not silence.
@@ -91,13 +91,54 @@ def one(seed):
     return sum(len(x) for x in docs)
 
 
+NORM_ALPHABET = [chr(c) for c in b"aabcxyzABCDQWXYZ   ''1239..,-_()\n\t"] + ["\u2019", "\u2019", "\u201c", "\u2014", "\u2026", "\u00e9", "\u00c9", "\u4e2d", "\U0001f600", "\u0301"]
+
+
+def one_norm(seed):
+    """the device normalizer (NFD / lowercase + capcode 2; host fallback for what it does not do itself) against the host normalizer:
+    runs of capitals, digits and apostrophes of every length, also across the 64-byte chunks and 1 KiB pieces of the device pass"""
+    rng = np.random.default_rng(seed)
+    capcode, flag = (2, int(rng.choice([1, 1, 3, 0]))) if rng.random() < 0.85 else (0, int(rng.choice([1, 3])))
+    toks = [bytes([c]) for c in range(256)]
+    v = tm.Vocab(synth.build_vocab(toks, capcode=capcode, charset=1, norm_flag=flag))
+    docs = []
+    for _ in range(int(rng.integers(1, 60))):
+        parts = []
+        n = int(rng.choice([0, 1, 5, 60, 63, 64, 65, 127, 129, 1000, 1023, 1024, 1025, 2047, 2049, 3100]))
+        while sum(len(x) for x in parts) < n:
+            r = rng.random()
+            if r < 0.35:
+                parts.append("".join(rng.choice(NORM_ALPHABET[:36], size=int(rng.integers(1, 30)))))
+            elif r < 0.55:
+                parts.append(str(rng.choice(["A", "Q", "AB", "Ab", "I'M", "X\u2019S", "A1", "1A", "a'B"])) * int(rng.integers(1, 400)))
+            elif r < 0.75:
+                parts.append("x" * int(rng.integers(1, 1100)))
+            elif r < 0.95:
+                parts.append("".join(rng.choice(NORM_ALPHABET[:41], size=int(rng.integers(1, 12)))))
+            else:
+                parts.append("".join(rng.choice(NORM_ALPHABET, size=int(rng.integers(1, 8)))))
+        docs.append("".join(parts).encode()[: max(n, 0) + int(rng.integers(0, 40))])
+    if rng.random() < 0.2:
+        docs.append(bytes(rng.integers(0, 256, size=int(rng.integers(1, 300)), dtype=np.uint8)))      # not UTF-8 at all
+    raw, offs = tm.pack_documents(docs)
+    got, goff, _ = v.normalize_packed_device(raw, offs)
+    exp, eoff = synth.normalize_batch(raw, offs, capcode, flag)
+    if not ((goff == eoff).all() and got.size == exp.size and (got == exp).all()):
+        bad = [d for d in range(len(docs)) if int(goff[d + 1] - goff[d]) != int(eoff[d + 1] - eoff[d]) or
+               got[int(goff[d]):int(goff[d + 1])].tobytes() != exp[int(eoff[d]):int(eoff[d + 1])].tobytes()]
+        raise AssertionError("seed %d: device-normalized text differs from the host normalizer in documents %s (capcode %d flag %d): %r" % (
+            seed, bad[:5], capcode, flag, docs[bad[0]][:200] if bad else None))
+    return int(raw.size)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
     n = nbytes = 0
+    case = one_norm if (len(sys.argv) > 3 and sys.argv[3] == "norm") else one
     while time.time() - t0 < budget:
-        nbytes += one(seed)
+        nbytes += case(seed)
         seed += 1
         n += 1
     print("fuzz ok: %d cases, %.1f MB, seeds up to %d, %.0f s" % (n, nbytes / 1e6, seed - 1, time.time() - t0))
