@@ -34,6 +34,7 @@ def _rank(rank, world, port, img, data, out_dir):
     from tokenmonster_amd import dist as tmdist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # the box's hostname may not resolve: loopback, explicitly
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         N.check(N.lib.tm_set_device(0))
