@@ -6,7 +6,7 @@ import pytest
 
 import tokenmonster_amd as tm
 from tokenmonster_amd import synth
-from conftest import EMULATED, fuzz_text, fuzz_vocab_tokens, unit_vocab_image
+from conftest import EMULATED, example_env, fuzz_text, fuzz_vocab_tokens, unit_vocab_image
 from oracle_bind import Oracle, Reference, have_ref, oracle_stats
 
 pytestmark = pytest.mark.gpu
@@ -560,7 +560,7 @@ def test_c_example_matches_python_path(tmp_path):
     (tmp_path / "v.vocab").write_bytes(bytes(img))
     (tmp_path / "t.txt").write_bytes(b"".join(lines))
     r = subprocess.run([os.path.join(root, "examples", "tokenize_file"), str(tmp_path / "v.vocab"), str(tmp_path / "t.txt"), "--lines"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=example_env())
     assert r.returncode == 0, r.stderr.decode(errors="replace")
     got = [[int(x) for x in ln.split()] for ln in r.stdout.decode().split("\n")[:len(lines)]]
     v = tm.Vocab(img)

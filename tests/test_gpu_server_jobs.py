@@ -9,6 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from conftest import example_env
 import tokenmonster_amd as tm
 from oracle_bind import Oracle
 from tokenmonster_amd import synth
@@ -28,7 +29,7 @@ def batches(docs):
 
 class Client:
     def __init__(self):
-        self.p = subprocess.Popen([EXE], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+        self.p = subprocess.Popen([EXE], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=example_env())
 
     def call(self, job, vid, payload=b""):
         self.p.stdin.write(frame(job, vid, payload))

@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <map>
@@ -46,6 +47,20 @@ emu_switch:
 #error "tools/emu: the fiber switch is written for x86-64"
 #endif
 
+// ThreadSanitizer has to be told about the stack switches (tools/emu/tsan_host.cpp: races in the HOST layer — lanes, worker pool, mailbox —
+// with the kernels running on this runtime); a switch also orders the two fibers, which is what a barrier or cross-lane operation does
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define EMU_TSAN 1
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+}
+#endif
+#endif
+
 constexpr size_t kStack = 128 << 10;     // per work-item
 constexpr unsigned kMaxItems = 1024;
 
@@ -55,6 +70,7 @@ struct Fiber {
   bool done = false;
   const unsigned long long* wait_gen = nullptr;    // blocked until *wait_gen != wait_val
   unsigned long long wait_val = 0;
+  void* tsan = nullptr;
 };
 
 struct Sched {
@@ -66,6 +82,7 @@ struct Sched {
   Fiber* running = nullptr;
   Launch* launch = nullptr;
   unsigned nitems = 0;
+  void* main_tsan = nullptr;
 };
 thread_local Sched* g_sched = nullptr;
 std::recursive_mutex g_launch_mutex;      // one launch at a time: __shared__ variables are function-local statics
@@ -73,6 +90,9 @@ std::recursive_mutex g_launch_mutex;      // one launch at a time: __shared__ va
 void to_scheduler() {
   Sched* s = g_sched;
   Fiber* f = s->running;
+#ifdef EMU_TSAN
+  __tsan_switch_to_fiber(s->main_tsan, 0);
+#endif
   emu_switch(&f->sp, s->main_sp);
 }
 
@@ -120,6 +140,11 @@ void run_group(Sched* s) {
       f.wait_gen = nullptr;
       s->running = &f;
       cur = &f.ctx;
+#ifdef EMU_TSAN
+      if (!f.tsan) f.tsan = __tsan_create_fiber(0);
+      s->main_tsan = __tsan_get_current_fiber();
+      __tsan_switch_to_fiber(f.tsan, 0);
+#endif
       emu_switch(&s->main_sp, f.sp);
       progressed = true;
       if (f.done) live--;
@@ -327,7 +352,7 @@ hipError_t hipMemset(void* p, int v, size_t n) { if (n) std::memset(p, v, n); re
 hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { if (n) std::memset(p, v, n); return hipSuccess; }
 hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n) { std::memcpy(sym, src, n); return hipSuccess; }
 hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t n) { std::memcpy(dst, sym, n); return hipSuccess; }
-hipError_t hipStreamCreate(hipStream_t* s) { static int ids = 0; *s = new emuStream{++ids}; return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { static std::atomic<int> ids{0}; *s = new emuStream{++ids}; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
