@@ -1,0 +1,122 @@
+"""Differential fuzz cases shared by tests/test_gpu_fuzz.py (-m gpu: a few seeds on the real device, or on the emulated one under
+TM_EMU=1) and tools/emu/fuzz.py (as many seeds as time allows on the emulated device): random small vocabularies (capcode 0 / 2,
+UTF-8 / UTF-16, with and without an unk token), batches of documents whose lengths sit on and around the segment (256), tile (8 x 256)
+and group boundaries, through tokenize / count / serialized / score (strips) / decode against the oracle; and the device normalizer
+against the host normalizer on runs of capitals, digits and apostrophes of every length."""
+import numpy as np
+
+import conftest
+import tokenmonster_amd as tm
+from tokenmonster_amd import _native as N, synth
+from oracle_bind import Oracle
+
+LENS = [0, 1, 2, 3, 39, 40, 41, 80, 215, 216, 217, 255, 256, 257, 295, 296, 297, 511, 512, 513, 767, 1023, 1024, 1025, 2047, 2048, 2049, 4096]
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    capcode = int(rng.choice([0, 2, 2]))
+    charset = int(rng.choice([1, 1, 1, 2]))
+    unk = bool(rng.random() < 0.3)
+    toks = conftest.fuzz_vocab_tokens(rng, capcode, int(rng.integers(20, 400)), singles=bool(rng.random() < 0.85))
+    if charset == 2:
+        toks = sorted({bytes(b for ch in t for b in (ch, 0))[:40] for t in toks if len(t) <= 20})
+    img = synth.build_vocab(toks, capcode=capcode, charset=charset, with_unk=unk)
+    v, orc = tm.Vocab(img), Oracle(img)
+    nd = int(rng.integers(1, 40))
+    docs = []
+    for _ in range(nd):
+        r = rng.random()
+        n = int(rng.choice(LENS)) if r < 0.6 else int(rng.integers(0, 6000)) if r < 0.97 else int(rng.integers(60000, 140000))
+        t = conftest.fuzz_text(rng, capcode, max(n, 1))[:n]
+        if charset == 2:
+            t = bytes(b for ch in t[: n // 2] for b in (ch, 0)) + (b"a" if n % 2 else b"")
+        docs.append(t)
+    text, offs = tm.pack_documents(docs)
+    ids, toff, missing = v.tokenize_packed(text, offs)
+    counts, cmiss = v.count_packed(text, offs)
+    for d, doc in enumerate(docs):
+        exp, miss = orc.tokenize(doc)
+        got = ids[int(toff[d]):int(toff[d + 1])]
+        if got.size != exp.size or (got != exp).any() or int(missing[d]) != miss:
+            raise AssertionError("seed %d doc %d (len %d): ids differ" % (seed, d, len(doc)))
+        ec, em = orc.count(doc)
+        if int(counts[d]) != ec or int(cmiss[d]) != em:
+            raise AssertionError("seed %d doc %d: count %d/%d vs %d/%d" % (seed, d, int(counts[d]), int(cmiss[d]), ec, em))
+    # serialized, every width the vocabulary allows
+    for enc in (0, 2, 3, 4):
+        blob, boff, _, e = v.tokenize_serialized_packed(text, offs, encoding_length=enc)
+        w = np.zeros((ids.size, 4), dtype=np.uint8)
+        w[:, :e] = np.asarray(blob[: ids.size * e]).reshape(ids.size, e)
+        if not (w.view(np.uint32).ravel() == ids).all():
+            raise AssertionError("seed %d: serialized width %d" % (seed, enc))
+    # scoring: the documents concatenated as one dataset, one strip and a few strips
+    data = np.ascontiguousarray(text)
+    if data.size:
+        import ctypes as C
+        ds = C.c_void_p()
+        N.check(N.lib.tm_dataset_upload(N.ptr(data), int(data.size), C.byref(ds)))
+        cuts = sorted(set([0, int(data.size)] + [int(x) for x in rng.integers(0, data.size + 1, size=int(rng.integers(0, 4)))]))
+        so = np.array(cuts[:-1], dtype=np.uint64)
+        sl = np.array([b - a for a, b in zip(cuts, cuts[1:])], dtype=np.uint64)
+        got = np.zeros(v.n_ids(), dtype=np.uint32)
+        tit = C.c_uint64()
+        ms = np.zeros(32, dtype=np.uint8)
+        N.check(N.lib.tm_score(v.handle, ds, N.ptr(so), N.ptr(sl), so.size, N.ptr(got), C.byref(tit), N.ptr(ms)))
+        exp_s = np.zeros(v.n_ids(), dtype=np.uint64)
+        exp_t, exp_m = 0, np.zeros(32, dtype=np.uint8)
+        for a, b in zip(cuts, cuts[1:]):
+            s_, t_, m_ = orc.score(data[a:b])
+            exp_s += s_
+            exp_t += t_
+            exp_m |= m_
+        N.lib.tm_dataset_free(ds)
+        if not ((got == exp_s).all() and tit.value == exp_t and (ms == exp_m).all()):
+            raise AssertionError("seed %d: score histogram over strips %s" % (seed, cuts))
+    # raw decode = concatenated token bytes
+    out, ooff = v.decode_packed(ids, toff, raw=True)
+    for d in range(nd):
+        exp = orc.decode_raw(ids[int(toff[d]):int(toff[d + 1])])
+        if out[int(ooff[d]):int(ooff[d + 1])].tobytes() != exp:
+            raise AssertionError("seed %d doc %d: decode_raw" % (seed, d))
+    return sum(len(x) for x in docs)
+
+
+NORM_ALPHABET = [chr(c) for c in b"aabcxyzABCDQWXYZ   ''1239..,-_()\n\t"] + ["\u2019", "\u2019", "\u201c", "\u2014", "\u2026", "\u00e9", "\u00c9", "\u4e2d", "\U0001f600", "\u0301"]
+
+
+def one_norm(seed):
+    """the device normalizer (NFD / lowercase + capcode 2; host fallback for what it does not do itself) against the host normalizer:
+    runs of capitals, digits and apostrophes of every length, also across the 64-byte chunks and 1 KiB pieces of the device pass"""
+    rng = np.random.default_rng(seed)
+    capcode, flag = (2, int(rng.choice([1, 1, 3, 0]))) if rng.random() < 0.85 else (0, int(rng.choice([1, 3])))
+    toks = [bytes([c]) for c in range(256)]
+    v = tm.Vocab(synth.build_vocab(toks, capcode=capcode, charset=1, norm_flag=flag))
+    docs = []
+    for _ in range(int(rng.integers(1, 60))):
+        parts = []
+        n = int(rng.choice([0, 1, 5, 60, 63, 64, 65, 127, 129, 1000, 1023, 1024, 1025, 2047, 2049, 3100]))
+        while sum(len(x) for x in parts) < n:
+            r = rng.random()
+            if r < 0.35:
+                parts.append("".join(rng.choice(NORM_ALPHABET[:36], size=int(rng.integers(1, 30)))))
+            elif r < 0.55:
+                parts.append(str(rng.choice(["A", "Q", "AB", "Ab", "I'M", "X\u2019S", "A1", "1A", "a'B"])) * int(rng.integers(1, 400)))
+            elif r < 0.75:
+                parts.append("x" * int(rng.integers(1, 1100)))
+            elif r < 0.95:
+                parts.append("".join(rng.choice(NORM_ALPHABET[:41], size=int(rng.integers(1, 12)))))
+            else:
+                parts.append("".join(rng.choice(NORM_ALPHABET, size=int(rng.integers(1, 8)))))
+        docs.append("".join(parts).encode()[: max(n, 0) + int(rng.integers(0, 40))])
+    if rng.random() < 0.2:
+        docs.append(bytes(rng.integers(0, 256, size=int(rng.integers(1, 300)), dtype=np.uint8)))      # not UTF-8 at all
+    raw, offs = tm.pack_documents(docs)
+    got, goff, _ = v.normalize_packed_device(raw, offs)
+    exp, eoff = synth.normalize_batch(raw, offs, capcode, flag)
+    if not ((goff == eoff).all() and got.size == exp.size and (got == exp).all()):
+        bad = [d for d in range(len(docs)) if int(goff[d + 1] - goff[d]) != int(eoff[d + 1] - eoff[d]) or
+               got[int(goff[d]):int(goff[d + 1])].tobytes() != exp[int(eoff[d]):int(eoff[d + 1])].tobytes()]
+        raise AssertionError("seed %d: device-normalized text differs from the host normalizer in documents %s (capcode %d flag %d): %r" % (
+            seed, bad[:5], capcode, flag, docs[bad[0]][:200] if bad else None))
+    return int(raw.size)

@@ -1,0 +1,18 @@
+"""-m gpu: a few seeds of the differential fuzz cases (tests/fuzz_cases.py) on the device; tools/emu/fuzz.py runs the same cases by the
+thousand on the emulated one."""
+import pytest
+
+import fuzz_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [3, 1007, 1019, 1100, 1254, 1900])
+def test_tokenize_count_serialized_score_decode_against_the_oracle(seed):
+    fuzz_cases.one(seed)
+
+
+@pytest.mark.parametrize("first", [5000, 9000, 20000])
+def test_device_normalizer_against_the_host_normalizer(first):
+    for seed in range(first, first + 12):
+        fuzz_cases.one_norm(seed)
