@@ -120,3 +120,46 @@ def one_norm(seed):
         raise AssertionError("seed %d: device-normalized text differs from the host normalizer in documents %s (capcode %d flag %d): %r" % (
             seed, bad[:5], capcode, flag, docs[bad[0]][:200] if bad else None))
     return int(raw.size)
+
+
+DEC_ALPHABET = list(b"CCWWDD    aabcxyzQZ019''.,-\n\t_")
+
+
+def one_decode(seed):
+    """tm_decode_batch (capcode decoding of the pure-ASCII documents on the device, k_dec_capcode; the others on the host) against the
+    streaming host decoder (tm_decoder_*), on marker soups no encoder would write: every order of 'C', 'W', 'D', spaces and characters,
+    runs across the 64-byte chunks of the device pass, documents that end inside a pending flag."""
+    rng = np.random.default_rng(seed)
+    v = tm.Vocab(synth.build_vocab([bytes([c]) for c in range(256)], capcode=2, charset=1))
+    docs = []
+    for _ in range(int(rng.integers(1, 50))):
+        n = int(rng.choice([0, 1, 2, 63, 64, 65, 127, 128, 129, 200, 640, 1000]))
+        n += int(rng.integers(0, 5))
+        r = rng.random()
+        if r < 0.6:
+            doc = bytes(rng.choice(DEC_ALPHABET, size=n).tolist())
+        elif r < 0.8:
+            doc = (bytes(rng.choice(list(b"CWD"), size=int(rng.integers(1, 70))).tolist()) + bytes(rng.choice(DEC_ALPHABET, size=5).tolist())) * (n // 8 + 1)
+            doc = doc[:n]
+        elif r < 0.92:
+            doc = bytes(rng.choice(list(b"W helo wrd's 12"), size=n).tolist())
+        else:
+            doc = bytes(rng.choice(DEC_ALPHABET, size=n).tolist()) + "\u00e9\u2019 W\u00e9".encode() + bytes(rng.choice(DEC_ALPHABET, size=7).tolist())
+        docs.append(doc)
+    # the id of every single-byte token, so that the decoder's input IS the document, byte for byte
+    all_ids = np.arange(v.n_ids(), dtype=np.uint32)
+    rb, ro = v.decode_packed(all_ids, np.arange(v.n_ids() + 1, dtype=np.uint64), raw=True)
+    id_of = np.zeros(256, dtype=np.uint32)
+    for i in range(v.n_ids()):
+        if int(ro[i + 1] - ro[i]) == 1:
+            id_of[int(rb[int(ro[i])])] = i
+    text, toff = tm.pack_documents(docs)
+    tok = id_of[text]
+    out, ooff = v.decode_packed(tok, toff, raw=False)
+    for d, doc in enumerate(docs):
+        dec = v.decoder()
+        exp = dec.decode(tok[int(toff[d]):int(toff[d + 1])]) + dec.flush()
+        got = out[int(ooff[d]):int(ooff[d + 1])].tobytes()
+        if got != exp:
+            raise AssertionError("seed %d doc %d: device capcode decode differs from the host decoder\n in  %r\n exp %r\n got %r" % (seed, d, doc[:120], exp[:120], got[:120]))
+    return int(text.size)
