@@ -130,7 +130,10 @@ def one_decode(seed):
     streaming host decoder (tm_decoder_*), on marker soups no encoder would write: every order of 'C', 'W', 'D', spaces and characters,
     runs across the 64-byte chunks of the device pass, documents that end inside a pending flag."""
     rng = np.random.default_rng(seed)
-    v = tm.Vocab(synth.build_vocab([bytes([c]) for c in range(256)], capcode=2, charset=1))
+    # 256 single-byte tokens built WITHOUT capcode (no "D "+token twins, so that reverse[id] is the byte itself), header switched to capcode 2
+    img = synth.build_vocab([bytes([c]) for c in range(256)], capcode=0, charset=1)
+    v = tm.Vocab(b"\x02" + bytes(img[1:]))
+    assert v.capcode() == 2
     docs = []
     for _ in range(int(rng.integers(1, 50))):
         n = int(rng.choice([0, 1, 2, 63, 64, 65, 127, 128, 129, 200, 640, 1000]))
@@ -155,6 +158,7 @@ def one_decode(seed):
             id_of[int(rb[int(ro[i])])] = i
     text, toff = tm.pack_documents(docs)
     tok = id_of[text]
+    assert v.decode_packed(tok, toff, raw=True)[0].tobytes() == text.tobytes()
     out, ooff = v.decode_packed(tok, toff, raw=False)
     for d, doc in enumerate(docs):
         dec = v.decoder()

@@ -16,3 +16,9 @@ def test_tokenize_count_serialized_score_decode_against_the_oracle(seed):
 def test_device_normalizer_against_the_host_normalizer(first):
     for seed in range(first, first + 12):
         fuzz_cases.one_norm(seed)
+
+
+@pytest.mark.parametrize("first", [1, 700, 4000])
+def test_device_capcode_decode_against_the_host_decoder(first):
+    for seed in range(first, first + 15):
+        fuzz_cases.one_decode(seed)
