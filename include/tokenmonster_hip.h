@@ -167,7 +167,9 @@ uint64_t tm_batch_device_bytes(const tm_batch* b);
  * runs on the device; ids >= tm_vocab_n_ids are skipped.  raw != 0: the concatenated token bytes as they are
  * (decode_raw); raw == 0: capcode decoding (javascript/tokenmonster.js:1007-1065) follows — on the device for the pure-ASCII documents
  * of a capcode-2 UTF-8 vocabulary, on the host for documents with anything beyond ASCII (Unicode case needs ICU) and for capcode 1.
- * out_offsets[ndocs+1] is always filled; TM_E_NOSPACE if out_cap is too small (required size in out_offsets[ndocs]). */
+ * out_offsets[ndocs+1] is always filled; TM_E_NOSPACE if out_cap is too small (required size in out_offsets[ndocs]).
+ * Like the tokenize entry points the call borrows a lane of the vocabulary (its stream, grow-only device arenas and pinned
+ * staging): callable concurrently, no allocation in steady state, nothing on the NULL stream. */
 int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* tok_offsets, uint32_t ndocs, int raw,
                     uint8_t* out, uint64_t out_cap, uint64_t* out_offsets);
 

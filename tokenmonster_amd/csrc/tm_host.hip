@@ -35,6 +35,10 @@ struct Lane {
   hipEvent_t up_done = nullptr;
   uint8_t* d_bytes = nullptr;     // serialized ids on the device, grow-only
   uint64_t d_bytes_cap = 0;
+  uint8_t* d_dec_a = nullptr;     // tm_decode_batch: ids, lengths, offsets (grow-only) ...
+  uint64_t d_dec_a_cap = 0;
+  uint8_t* d_dec_b = nullptr;     // ... and the decoded bytes, before and after capcode decoding (grow-only)
+  uint64_t d_dec_b_cap = 0;
   bool busy = false;
 };
 
@@ -54,6 +58,8 @@ static void lane_destroy(Lane* l) {
   (void)hipHostFree(l->h_stage);
   (void)hipHostFree(l->h_stage_in);
   (void)hipFree(l->d_bytes);
+  (void)hipFree(l->d_dec_a);
+  (void)hipFree(l->d_dec_b);
   delete l;
 }
 
@@ -128,6 +134,16 @@ static int lane_dbytes(Lane* l, uint64_t bytes) {
   l->d_bytes_cap = bytes + bytes / 4 + 4096;
   hipError_t e = hipMalloc((void**)&l->d_bytes, l->d_bytes_cap);
   if (e != hipSuccess) { l->d_bytes_cap = 0; return hip_fail(e, "hipMalloc (serialized ids)"); }
+  return TM_OK;
+}
+
+static int dev_grow(uint8_t** buf, uint64_t* cap, uint64_t bytes, const char* what) {
+  if (*cap >= bytes) return TM_OK;
+  (void)hipFree(*buf);
+  *buf = nullptr;
+  *cap = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc((void**)buf, *cap);
+  if (e != hipSuccess) { *cap = 0; return hip_fail(e, what); }
   return TM_OK;
 }
 
@@ -450,6 +466,117 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
   if (stats) { stats->chunks = (uint32_t)nchunks; stats->lanes = lanes; stats->input_pinned = in_pinned; stats->output_pinned = out_pinned; }
   if (byte_offsets[ndocs] > bytes_cap || !bytes_out) return set_error(TM_E_NOSPACE, "bytes_cap %llu < %llu required", (unsigned long long)bytes_cap, (unsigned long long)byte_offsets[ndocs]);
   return TM_OK;
+}
+
+// Decode / decode_raw (go/tokenmonster.go:445-550; tokenmonster.cpp:1404-1425) on a lane like the tokenize entry points: the lane's
+// stream, grow-only device arenas and pinned staging — steady state allocates nothing and stays off the NULL stream, so decode jobs of a
+// server (tokenmonsterserver jobs 2-9) do not stall the tokenize jobs running beside them (a hipFree synchronizes the whole device).
+int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* tok_offsets, uint32_t ndocs, int raw,
+                    uint8_t* out, uint64_t out_cap, uint64_t* out_offsets) {
+  if (!v || !tok_offsets || !out_offsets) return set_error(TM_E_INVALID, "null argument");
+  const uint64_t n = tok_offsets[ndocs];
+  if (n && !tokens) return set_error(TM_E_INVALID, "null argument");
+  if (tok_offsets[0] != 0) return set_error(TM_E_INVALID, "tok_offsets[0] must be 0");
+  for (uint32_t d = 0; d < ndocs; d++) if (tok_offsets[d + 1] < tok_offsets[d]) return set_error(TM_E_INVALID, "tok_offsets not monotone");
+  Lane* l = nullptr;
+  int rc = lane_acquire(v, &l);
+  if (rc != TM_OK) return rc;
+  hipStream_t st = l->stream;
+  hipError_t e = hipSuccess;
+  const bool dev_capcode = !raw && v->host.capcode == 2 && v->host.charset == 1 && ndocs > 0;
+  // arena A: ids | document offsets | lengths | byte offset of every id | scan block sums | total | byte offset of every document | decoded lengths
+  auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
+  const uint64_t sblocks = (n + 1 + SCAN_CH - 1) / SCAN_CH + 2;
+  const uint64_t o_tok = 0, o_toff = o_tok + up((n + 1) * 4), o_len = o_toff + up(((uint64_t)ndocs + 1) * 8), o_off = o_len + up((n + 1) * 4),
+                 o_sums = o_off + up((n + 2) * 8), o_total = o_sums + up(sblocks * 8), o_doff = o_total + 256, o_declen = o_doff + up(((uint64_t)ndocs + 1) * 8),
+                 a_bytes = o_declen + up((uint64_t)ndocs * 8 + 8);
+  std::vector<uint64_t> doff((size_t)ndocs + 1, 0), declen;
+  uint64_t total = 0;
+  bool need_raw = !dev_capcode;
+  const uint8_t *h_dec = nullptr, *h_raw = nullptr;          // decoded / raw bytes in the lane's pinned staging
+  do {
+    if ((rc = dev_grow(&l->d_dec_a, &l->d_dec_a_cap, a_bytes, "hipMalloc (decode)")) != TM_OK) break;
+    uint8_t* A = l->d_dec_a;
+    uint32_t* d_tok = (uint32_t*)(A + o_tok); uint64_t* d_toff = (uint64_t*)(A + o_toff); uint32_t* d_len = (uint32_t*)(A + o_len);
+    uint64_t* d_off = (uint64_t*)(A + o_off); uint64_t* d_sums = (uint64_t*)(A + o_sums); uint64_t* d_total = (uint64_t*)(A + o_total);
+    uint64_t* d_doff = (uint64_t*)(A + o_doff); uint64_t* d_declen = (uint64_t*)(A + o_declen);
+    // ids and offsets through pinned staging (the caller's buffers are pageable Go / Python memory)
+    const uint64_t in_bytes = n * 4 + ((uint64_t)ndocs + 1) * 8;
+    if ((rc = stage_grow(&l->h_stage_in, &l->h_in_cap, in_bytes)) != TM_OK) break;
+    std::memcpy(l->h_stage_in, tok_offsets, ((uint64_t)ndocs + 1) * 8);
+    if (n) std::memcpy(l->h_stage_in + ((uint64_t)ndocs + 1) * 8, tokens, n * 4);
+    if ((e = hipMemcpyAsync(d_toff, l->h_stage_in, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (n && (e = hipMemcpyAsync(d_tok, l->h_stage_in + ((uint64_t)ndocs + 1) * 8, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess)) { rc = hip_fail(e, "H2D tokens"); break; }
+    launch_decode_lengths(v, d_tok, n, d_toff, ndocs, d_len, d_off, d_sums, d_total, d_doff, st);
+    if ((rc = lane_stage(l, 8 + ((uint64_t)ndocs + 1) * 8)) != TM_OK) break;
+    if ((rc = d2h(l->h_stage, d_total, 8, st, "decode lengths")) != TM_OK || (rc = d2h(l->h_stage + 8, d_doff, ((uint64_t)ndocs + 1) * 8, st, "decode lengths")) != TM_OK) break;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; }
+    std::memcpy(&total, l->h_stage, 8);
+    std::memcpy(doff.data(), l->h_stage + 8, doff.size() * 8);
+    // arena B: the gathered bytes | the same after capcode decoding (out of place: the host decoder needs the others as they were)
+    const uint64_t o_dec = up(total + 16);
+    if ((rc = dev_grow(&l->d_dec_b, &l->d_dec_b_cap, o_dec + up(total + 16), "hipMalloc (decode output)")) != TM_OK) break;
+    uint8_t* d_out = l->d_dec_b; uint8_t* d_dec = l->d_dec_b + o_dec;
+    launch_decode_copy(v, d_tok, n, d_off, d_out, st);
+    uint64_t h_need = total + 16;
+    if (dev_capcode) {
+      launch_decode_capcode(d_out, d_doff, ndocs, d_dec, d_declen, st);
+      declen.resize(ndocs);
+      h_need = up((uint64_t)ndocs * 8) + 2 * up(total + 16);
+    }
+    if ((rc = lane_stage(l, h_need)) != TM_OK) break;
+    if (dev_capcode) {
+      uint8_t* hp = l->h_stage + up((uint64_t)ndocs * 8);
+      if ((rc = d2h(l->h_stage, d_declen, (uint64_t)ndocs * 8, st, "D2H decoded text")) != TM_OK || (rc = d2h(hp, d_dec, total, st, "D2H decoded text")) != TM_OK) break;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; }
+      std::memcpy(declen.data(), l->h_stage, (uint64_t)ndocs * 8);
+      h_dec = hp;
+      for (uint32_t d = 0; d < ndocs && !need_raw; d++) need_raw = declen[d] == DEC_HOST;
+      if (need_raw) {
+        uint8_t* hr = hp + up(total + 16);
+        if ((rc = d2h(hr, d_out, total, st, "D2H decoded bytes")) != TM_OK) break;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; }
+        h_raw = hr;
+      }
+    } else {
+      if ((rc = d2h(l->h_stage, d_out, total, st, "D2H decoded bytes")) != TM_OK) break;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; }
+      h_raw = l->h_stage;
+    }
+  } while (false);
+  if (rc == TM_OK) {
+    if (raw || v->host.capcode == 0) {
+      std::memcpy(out_offsets, doff.data(), doff.size() * 8);
+      if (total > out_cap) rc = set_error(TM_E_NOSPACE, "out_cap %llu < %llu required", (unsigned long long)out_cap, (unsigned long long)total);
+      else if (total) std::memcpy(out, h_raw, total);
+    } else {
+      // the documents the device left alone (anything beyond ASCII; every document of a capcode-1 or UTF-16 vocabulary) go through the host decoder
+      std::vector<uint32_t> todo;
+      for (uint32_t d = 0; d < ndocs; d++) if (!dev_capcode || declen[d] == DEC_HOST) todo.push_back(d);
+      std::vector<std::vector<uint8_t>> touts;
+      if (!todo.empty()) {
+        std::vector<uint64_t> toff(todo.size() + 1, 0);
+        std::vector<uint8_t> tbytes;
+        for (size_t k = 0; k < todo.size(); k++) {
+          tbytes.insert(tbytes.end(), h_raw + doff[todo[k]], h_raw + doff[todo[k] + 1]);
+          toff[k + 1] = tbytes.size();
+        }
+        capcode_decode_batch(tbytes.data(), toff.data(), (uint32_t)todo.size(), v->host.capcode, 0, touts);
+      }
+      std::vector<uint64_t> hostlen((size_t)ndocs, DEC_HOST);
+      for (size_t k = 0; k < todo.size(); k++) hostlen[todo[k]] = k;
+      uint64_t o = 0;
+      for (uint32_t d = 0; d < ndocs; d++) { out_offsets[d] = o; o += hostlen[d] != DEC_HOST ? touts[hostlen[d]].size() : declen[d]; }
+      out_offsets[ndocs] = o;
+      if (o > out_cap) rc = set_error(TM_E_NOSPACE, "out_cap %llu < %llu required", (unsigned long long)out_cap, (unsigned long long)o);
+      else for (uint32_t d = 0; d < ndocs; d++) {
+        if (hostlen[d] != DEC_HOST) { const auto& t = touts[hostlen[d]]; if (!t.empty()) std::memcpy(out + out_offsets[d], t.data(), t.size()); }
+        else if (declen[d]) std::memcpy(out + out_offsets[d], h_dec + doff[d], declen[d]);
+      }
+    }
+  }
+  lane_release(v, l);
+  return rc;
 }
 
 }  // extern "C"

@@ -1,7 +1,7 @@
 // tools/emu/tsan_host.cpp — the HOST layer of the library (lanes, worker pool, pinned mailbox, block cache: tm_host.hip, tm_kernels.hip,
 // tm_vocab.hip, tm_normalize.cpp) under ThreadSanitizer, with the kernels running on the emulated device (tools/emu).  Development aid:
 //   bash tools/emu/tsan_host.sh
-// Several threads call the host-buffer entry points of ONE vocabulary at once (what goroutines of tokenmonsterserver do,
+// Several threads call the host-buffer entry points (tokenize, count, pipeline, decode) of ONE vocabulary at once (what goroutines of tokenmonsterserver do,
 // training/tokenmonsterserver.go:363-378), two of them the chunked pipeline, one loads and frees further vocabularies meanwhile (the
 // trainvocab worker's pattern); every result is compared with a single-threaded run.
 #include <atomic>
@@ -60,6 +60,16 @@ int main() {
     if (tm_tokenize_pipeline(v, raw.data(), roff.data(), nd, 1, 2, 96 << 10, 2, s2.data(), s2.size(), so.data(), ms.data(), &e2, nullptr) != TM_OK) { bad++; return; }
     if (so[nd] != soff[nd] || std::memcmp(s2.data(), ser.data(), so[nd]) != 0) bad++;
   });
+  // decode jobs beside the tokenize jobs (tokenmonsterserver jobs 2-9): same lanes, same answers as a single-threaded decode
+  std::vector<uint8_t> dec(off[nd] * 2 + 4096); std::vector<uint64_t> doff(nd + 1);
+  CHECK(tm_decode_batch(v, ids.data(), toff.data(), nd, 0, dec.data(), dec.size(), doff.data()));
+  for (int t = 0; t < 2; t++) th.emplace_back([&] {
+    for (int round = 0; round < 3; round++) {
+      std::vector<uint8_t> d2(dec.size()); std::vector<uint64_t> o2(nd + 1);
+      if (tm_decode_batch(v, ids.data(), toff.data(), nd, round == 1, d2.data(), d2.size(), o2.data()) != TM_OK) { bad++; return; }
+      if (round != 1 && (o2[nd] != doff[nd] || std::memcmp(d2.data(), dec.data(), o2[nd]) != 0)) bad++;
+    }
+  });
   th.emplace_back([&] {
     for (int k = 0; k < 4; k++) {
       tm_vocab* w = nullptr;
@@ -73,6 +83,6 @@ int main() {
   tm_vocab_free(v);
   tm_free(text); tm_free(img);
   if (bad.load()) { std::fprintf(stderr, "%d caller(s) got a wrong result\n", bad.load()); return 1; }
-  std::printf("tsan_host ok: %u documents, %llu ids, 9 concurrent callers\n", nd, (unsigned long long)toff[nd]);
+  std::printf("tsan_host ok: %u documents, %llu ids, 11 concurrent callers\n", nd, (unsigned long long)toff[nd]);
   return 0;
 }
