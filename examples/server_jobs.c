@@ -11,9 +11,13 @@
  *           the goroutine fan-out of :363-378 is ONE tm_tokenize_pipeline call
  *   job 20  count              same payload -> { 0, u64 4 + 8n, u32 n } + n x u64     (:753-800; one tm_count_batch_raw call)
  *   job 2/3/4 decode           payload { u32 n, n x { u64 len, ids of job bytes each } } -> like job 1 with decoded text (:399-446)
+ *   job 5   new decoder        id = vocabulary -> { 1, u32 decoder id }                 (:449-471; the streaming Decoder, go/tokenmonster.go:552)
+ *   job 6   unload decoder     id = decoder -> { 2, 0 }                                 (:473-482)
+ *   job 7/8/9 decoder: decode  id = decoder, payload = ids of job - 5 bytes each -> { 0, u64 len } + the text that is complete so far (:484-504)
+ *   job 12  save vocabulary    payload { u8 len, filename } -> { 2, 0 } or { 12, 0 }     (:537-554)
  *   job 10  load vocabulary    payload { u8 len, filename } -> { 1, u32 id } or { 12, 0 }
  *   job 11  unload             -> { 2, 0 } or { 10, 0 }
- *   anything else              -> { 15, 0 }                                            (:802-804)
+ *   anything else (14-19: vocabulary editing and YAML, not on the path)  -> { 15, 0 }   (:802-804)
  * Errors: unknown id 10, unloaded id 11 (header only, like sendError :104-114 without draining stdin, which a test harness must not).
  */
 #include <stdint.h>
@@ -21,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "tm_build.h"
 #include "tokenmonster_hip.h"
 
 enum { HEADER_IS_LENGTH = 0, HEADER_IS_ID = 1, HEADER_IS_EMPTY = 2, ERROR_ID_DOES_NOT_EXIST = 10, ERROR_ID_IS_UNLOADED = 11,
@@ -35,6 +40,10 @@ static void send9(uint8_t status, uint64_t v) { uint8_t h[9]; h[0] = status; wr(
 static tm_vocab* g_vocabs[MAX_VOCABS];
 static int g_used[MAX_VOCABS];   /* 0 never used, 1 loaded, 2 unloaded */
 static uint32_t g_nvocabs;
+#define MAX_DECODERS 256
+static tm_decoder* g_decoders[MAX_DECODERS];
+static int g_dec_used[MAX_DECODERS];   /* 0 never used, 1 live, 2 unloaded */
+static uint32_t g_ndecoders;
 
 /* payload { u32 n, n x { u64 len, bytes } } -> packed text + offsets; returns 0 on a malformed payload */
 static int unpack(const uint8_t* data, uint64_t len, uint32_t* n_out, uint8_t** text, uint64_t** offs) {
@@ -115,6 +124,48 @@ int main(void) {
     } else if (job == 11) {                                        /* unload (:525-535) */
       if (id < g_nvocabs && g_used[id] == 1) { tm_vocab_free(g_vocabs[id]); g_vocabs[id] = NULL; g_used[id] = 2; send9(HEADER_IS_EMPTY, 0); }
       else send9(ERROR_ID_DOES_NOT_EXIST, 0);
+    } else if (job == 12) {                                        /* save (:537-554) */
+      if (id >= g_nvocabs) send9(ERROR_ID_DOES_NOT_EXIST, 0);
+      else if (g_used[id] != 1) send9(ERROR_ID_IS_UNLOADED, 0);
+      else {
+        uint8_t status = ERROR_FILE_CANNOT_OPEN;
+        if (len >= 1 && (uint64_t)data[0] + 1 <= len) {
+          char name[257];
+          memcpy(name, data + 1, data[0]);
+          name[data[0]] = 0;
+          if (tm_vocab_save(g_vocabs[id], name) == TM_OK) status = HEADER_IS_EMPTY;
+        }
+        send9(status, 0);
+      }
+    } else if (job == 5) {                                         /* new decoder (:449-471) */
+      if (id >= g_nvocabs) send9(ERROR_ID_DOES_NOT_EXIST, 0);
+      else if (g_used[id] != 1) send9(ERROR_ID_IS_UNLOADED, 0);
+      else {
+        uint32_t slot;
+        tm_decoder* d = NULL;
+        for (slot = 0; slot < g_ndecoders && g_dec_used[slot] != 2; slot++) {}     /* reuse an unloaded slot like deletedDecoders */
+        if (slot >= MAX_DECODERS || tm_decoder_new(g_vocabs[id], &d) != TM_OK) send9(ERROR_INVALID_JOB, 0);
+        else { g_decoders[slot] = d; g_dec_used[slot] = 1; if (slot == g_ndecoders) g_ndecoders++; send9(HEADER_IS_ID, slot); }
+      }
+    } else if (job == 6) {                                         /* unload decoder (:473-482; the reference answers 4 for an unknown id) */
+      if (id >= g_ndecoders) send9(4, 0);
+      else { if (g_dec_used[id] == 1) { tm_decoder_free(g_decoders[id]); g_decoders[id] = NULL; g_dec_used[id] = 2; } send9(HEADER_IS_EMPTY, 0); }
+    } else if (job >= 7 && job <= 9) {                             /* decoder: decode (:484-504) */
+      if (id >= g_ndecoders) send9(ERROR_ID_DOES_NOT_EXIST, 0);
+      else if (g_dec_used[id] != 1) send9(ERROR_ID_IS_UNLOADED, 0);
+      else {
+        uint64_t cap = len * 24 + 256, got = 0;
+        uint8_t* out = (uint8_t*)malloc(cap);
+        int rc = tm_decoder_decode_serialized(g_decoders[id], data, len, (uint32_t)job - 5u, out, cap, &got);
+        if (rc == TM_E_NOSPACE) {                                  /* the ids have been consumed, the text is kept: fetch it */
+          cap = got + 1;
+          out = (uint8_t*)realloc(out, cap);
+          rc = tm_decoder_decode_serialized(g_decoders[id], NULL, 0, (uint32_t)job - 5u, out, cap, &got);
+        }
+        if (rc != TM_OK) { fprintf(stderr, "server_jobs: %s\n", tm_last_error()); send9(ERROR_INVALID_JOB, 0); }
+        else { send9(HEADER_IS_LENGTH, got); fwrite(out, 1, got, stdout); }
+        free(out);
+      }
     } else if (job == 1 || job == 20 || (job >= 2 && job <= 4)) {
       if (id >= g_nvocabs) send9(ERROR_ID_DOES_NOT_EXIST, 0);
       else if (g_used[id] != 1) send9(ERROR_ID_IS_UNLOADED, 0);
@@ -178,6 +229,7 @@ int main(void) {
     fflush(stdout);
     free(data);
   }
+  for (uint32_t i = 0; i < g_ndecoders; i++) if (g_dec_used[i] == 1) tm_decoder_free(g_decoders[i]);
   for (uint32_t i = 0; i < g_nvocabs; i++) if (g_used[i] == 1) tm_vocab_free(g_vocabs[i]);
   return 0;
 }

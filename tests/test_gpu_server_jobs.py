@@ -117,3 +117,47 @@ def test_job_1_packs_four_bytes_above_65536_ids(tmp_path):
     for g, d in zip(got, docs):
         assert g == orc.tokenize(synth.normalize(d, 2, 1))[0].astype("<u4").tobytes()
     c.close()
+
+
+def test_jobs_5_to_9_streaming_decoder_and_12_save(tmp_path):
+    """the streaming Decoder over the wire (training/tokenmonsterserver.go:449-504: jobs 5 new, 6 unload, 7/8/9 decode with 2/3/4-byte ids)
+    and Save (job 12, :537-554).  The ids arrive a few at a time, also cut inside a multi-byte character and inside a capcode marker
+    sequence; the pieces joined must be the text of one Decode of all ids, which the reference's own Decoder gives too
+    (tests/test_gpu_golden.py pins tm_decoder_* against it)."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, stdout=subprocess.PIPE)
+    img = synth.synth_vocab(synth.ENGLISHCODE, 3000, capcode=2, norm_flag=1, level=3, seed=0x53525653)
+    path = tmp_path / "v.vocab"
+    path.write_bytes(img)
+    v, orc = tm.Vocab(img), Oracle(img)
+    text = "Hello World, this is A TEST of HTTPServer2Go! It’s “quoted” — naïve café, ÉCOLE 12AB34cd x".encode()
+    ids = orc.tokenize(synth.normalize(text, 2, 1))[0]
+    whole = v.decode(ids)
+    c = Client()
+    name = str(path).encode()
+    assert c.call(10, 0, bytes([len(name)]) + name) == (1, 0)
+    assert c.call(5, 3) == (10, 0)                                                  # no such vocabulary
+    assert c.call(5, 0) == (1, 0) and c.call(5, 0) == (1, 1)                        # two decoders
+    rng = np.random.default_rng(3)
+    for dec, enc, dt in ((0, 2, "<u2"), (1, 4, "<u4")):
+        pieces, pos = [], 0
+        while pos < ids.size:
+            k = int(rng.integers(1, 4))
+            st, body = c.call(5 + enc, dec, ids[pos:pos + k].astype(dt).tobytes())
+            assert st == 0
+            pieces.append(body)
+            pos += k
+        got = b"".join(pieces)
+        assert whole.startswith(got) and len(whole) - len(got) < 8                  # (what a cut character still holds back stays in the decoder)
+    st, body = c.call(8, 0, b"".join(int(i).to_bytes(3, "little") for i in ids[:5]))  # 3-byte ids on a decoder that has seen others
+    assert st == 0
+    assert c.call(6, 1) == (2, 0) and c.call(9, 1, b"") == (11, 0)                  # unloaded decoder
+    assert c.call(5, 0) == (1, 1)                                                   # its slot is handed out again
+    assert c.call(7, 9, b"") == (10, 0) and c.call(6, 77) == (4, 0)
+    # job 12: Save writes the file back, byte for byte
+    out = str(tmp_path / "saved.vocab").encode()
+    assert c.call(12, 0, bytes([len(out)]) + out) == (2, 0)
+    assert (tmp_path / "saved.vocab").read_bytes() == bytes(img)
+    bad = b"/nonexistent-dir/x.vocab"
+    assert c.call(12, 0, bytes([len(bad)]) + bad) == (12, 0)
+    assert c.call(12, 4, bytes([len(out)]) + out) == (10, 0)
+    c.close()

@@ -544,6 +544,7 @@ int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* t
       h_raw = l->h_stage;
     }
   } while (false);
+  if (rc != TM_OK) (void)hipStreamSynchronize(st);      // nothing of this call may still be in flight when the lane goes back
   if (rc == TM_OK) {
     if (raw || v->host.capcode == 0) {
       std::memcpy(out_offsets, doff.data(), doff.size() * 8);
