@@ -273,6 +273,20 @@ __device__ unsigned long long g_phase[64 * 32];
 #endif
 
 
+// TM_K1_HALO_SHARE (build-time experiment, off in the product build until it has been timed on the device): the 40 halo positions of a
+// segment — 13.5 % of the positions steps A1 - A3 work on — are the first 40 positions of the NEXT segment; when the wavefront of that
+// segment sits in the same workgroup and the same document, this wavefront walks 256 positions instead of 296 (runs of 4 instead of 5
+// per lane) and copies the neighbour's descriptors after ONE workgroup barrier.  Step C's pointer-doubling table then overlays
+// D[40..] / Db[40..] instead of D[0..], so that a wavefront never overwrites what its left neighbour may still be copying.
+// Host model (tools/a1_sim.cpp): 70 % of the wavefronts share, 26.5 -> 24.3 rounds per wavefront in step A1.
+#ifndef TM_K1_HALO_SHARE
+#define TM_K1_HALO_SHARE 0
+#endif
+#if TM_K1_HALO_SHARE
+constexpr int J_SKIP = NPOS - SEG, J_PLANE = NPOS;     // step C: state (p, fd) lives at word J_SKIP + fd * J_PLANE + p of {D, Db}
+#else
+constexpr int J_SKIP = 0, J_PLANE = SEG;
+#endif
 __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
                                                                 const uint64_t* __restrict__ doc_end,
@@ -302,6 +316,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   const uint64_t rem = doc_end[doc] - begin, remv = doc_vis[doc] - begin;
   const int dl = remv > (uint64_t)(1 << 20) ? (1 << 20) : (int)remv;   // bytes of text from `begin` on that can be looked at (clamped)
   const int seglen = (int)(rem < (uint64_t)SEG ? rem : (uint64_t)SEG);  // positions of this segment
+#if TM_K1_HALO_SHARE
+  const bool share = wvi + 1 < WAVES && g + 1 < nseg && __builtin_amdgcn_readfirstlane((int)seg_doc[g + 1]) == (int)doc;   // (then rem > SEG: the text goes on)
+#else
+  constexpr bool share = false;
+#endif
   PH_INIT
 
   // stage the text with (unaligned) dword loads; bytes at and after the end of the document read as 0: the pad
@@ -329,9 +348,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   PH(0)
   PH_COUNT(12, 1)
 #ifdef TM_DEVEL
-  const int ntask = (dbg & 1) ? 0 : min(NPOS, dl);
+  const int ntask = (dbg & 1) ? 0 : (share ? SEG : min(NPOS, dl));
 #else
-  const int ntask = min(NPOS, dl);                     // positions >= dl keep descriptor 0 (nothing there)
+  const int ntask = share ? SEG : min(NPOS, dl);       // positions >= dl keep descriptor 0 (nothing there); a shared halo is the neighbour's work
 #endif
   {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
@@ -344,8 +363,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
     const uint32_t mask16 = T.edge_mask << 4;
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
-    const int nwalkpos = (dl <= NPOS) ? ntask - 1 : ntask;          // positions with at least two bytes of text left
-    if (lane == 0 && dl <= NPOS && ntask > 0) {
+    const bool tail_here = !share && dl <= NPOS;                    // the document's last byte is one of this wavefront's positions
+    const int nwalkpos = tail_here ? ntask - 1 : ntask;             // positions with at least two bytes of text left
+    if (lane == 0 && tail_here && ntask > 0) {
       const uint32_t r = T.root[w.text[dl - 1]];
       if (r != kNone && node_id(r) < T.n_info) { w.D[dl - 1] = 1u | ((r >> 22) << 6); w.X[dl - 1] = r; }
     }
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 #pragma unroll
     for (int it = 0; it < NPOS_PAD / 64; it++) {
       const int p = it * 64 + lane;
-      uint32_t d = p < NPOS ? w.D[p] : 0u;
+      uint32_t d = (p < NPOS && !(share && p >= SEG)) ? w.D[p] : 0u;
       bool el = false;
       if (d != 0) {
         const uint32_t nb = s_bb[w.text[p + (d & 63u)]];
@@ -503,6 +523,16 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   PH(5)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
+#if TM_K1_HALO_SHARE
+  __syncthreads();                                       // every wavefront of the workgroup has its descriptors
+  if (share && lane < NPOS - SEG) {
+    const WaveLds& nx = s_wave[wvi + 1];
+    w.D[SEG + lane] = nx.D[lane];
+    w.Db[SEG + lane] = nx.Db[lane];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
 
   // ---- step B: T(p,0) and T(p,1) for every position of the segment --------------------------------
   // The kernel is VALU-issue bound (profiles/r01_v3_pmc_k1.txt) and the six-branch scoring is its largest block of
@@ -578,15 +608,15 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   if (dbg & 16) { for (int e = lane; e < ENT; e += 64) exitmap[g * ENT + e] = 0u; return; }   // (timing experiments only)
 #endif
   {
-    uint32_t* J = reinterpret_cast<uint32_t*>(w.D);       // overlays D, Db (dead after step B): 512 x 4 B
-    static_assert(sizeof(uint32_t) * 2 * NPOS >= 2 * SEG * sizeof(uint32_t), "J overlay does not fit");
+    uint32_t* J = reinterpret_cast<uint32_t*>(w.D) + J_SKIP;       // overlays D, Db (dead after step B): 2 x SEG words, state (p, fd) at J[fd * J_PLANE + p]
+    static_assert(J_SKIP + J_PLANE + SEG <= 2 * NPOS, "J overlay does not fit");
     const bool more_text = remv > (uint64_t)seglen;       // text follows the segment: the chain leaves it into an entry state
     // J entry: #tokens [0..15] | field [16..30] | left-the-segment [31]; the field is the LDS byte address of the entry it points
     // at, or — once the chain has left the segment — the entry state of the next segment (0x7FFF: the state is unreachable).
     // Composing two entries is (x & 0xFFFF) + x', and the address to read next is x >> 16.
     typedef TM_LDS_SPACE uint32_t lds_u32;
     auto ld_j = [](uint32_t a) -> uint32_t { return *TM_LDS_PTR(lds_u32, a); };
-    const uint32_t jaddr = TM_LDS_ADDR(w.D);
+    const uint32_t jaddr = TM_LDS_ADDR(w.D) + 4u * (uint32_t)J_SKIP;
     static_assert(sizeof(s_wave) + 2048 < 32768, "LDS addresses must fit the 15-bit field");
     auto first_hop = [&](uint32_t r, int p, uint32_t fd) -> uint32_t {
       // at/after the end of the segment: nothing is emitted here.  At the end of the text that is the terminal state; in a byte
@@ -597,7 +627,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       const uint32_t fdn = (r >> 30) & 1u;
       const uint32_t nt = ((r & ID_NONE) != ID_NONE ? 1u : 0u) + fdn;          // ids this step emits: the token (unless it is "none") + the delete token
       const uint32_t x = pn >= seglen ? 0x80000000u | ((more_text ? (uint32_t)((pn - seglen) * 2) + fdn : 0u) << 16)
-                                      : (jaddr + 4u * (fdn * SEG + (uint32_t)pn)) << 16;
+                                      : (jaddr + 4u * (fdn * (uint32_t)J_PLANE + (uint32_t)pn)) << 16;
       return x | nt;
     };
     // every lane keeps its own 2*SEG/64 states in registers and only touches LDS for states that still point inside
@@ -611,7 +641,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       ja[it] = first_hop(r0[it], p, 0u);
       ja[N0 + it] = first_hop(r1[it], p, 1u);
       J[p] = ja[it];
-      J[SEG + p] = ja[N0 + it];
+      J[J_PLANE + p] = ja[N0 + it];
     }
     bool any0 = false, any1 = false;
 #pragma unroll
@@ -642,7 +672,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
           if (pend[k]) {
             const uint32_t b1 = ld_j(ja[k] >> 16);
             ja[k] = (ja[k] & 0xFFFFu) + b1;
-            J[k * 64 + lane] = ja[k];
+            J[J_PLANE + (k - N0) * 64 + lane] = ja[k];
             pend[k] = (int)ja[k] >= 0;
             any1 |= pend[k];
           }
@@ -654,7 +684,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     }
     // exit map entry: next entry state [0..7] | #ids << 8; 0xFFFFFFFF: the entry state cannot occur
     for (int e = lane; e < ENT; e += 64) {
-      const uint32_t a = J[(e & 1) * SEG + (e >> 1)];
+      const uint32_t a = J[(e & 1) * J_PLANE + (e >> 1)];
       const uint32_t t = (a >> 16) & 0x7FFFu;
       exitmap[g * ENT + e] = ((a >> 31) != 0 && t != 0x7FFFu) ? (t | ((a & 0xFFFFu) << 8)) : R_INVALID;
     }

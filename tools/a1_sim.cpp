@@ -294,6 +294,62 @@ int main(int argc, char** argv) {
     }
   }
 
+  // halo sharing: the 40 halo positions of a segment are the first 40 of the next one; if the wavefront of the next segment (same
+  // workgroup of WAVES = 4 consecutive segments, same document) hands them over through LDS, this wavefront walks 256 positions instead
+  // of 296 (runs of 4 instead of 5 per lane)
+  {
+    uint64_t rounds_now = 0, rounds_shared = 0, waves = 0, sharing = 0, g = 0;
+    for (uint32_t d = 0; d < nd; d++) {
+      const uint64_t b0 = off[d], e0 = off[d + 1];
+      for (uint64_t begin = b0; begin < e0; begin += SEG, g++) {
+        const int dl = (int)std::min<uint64_t>(e0 - begin, 1 << 20);
+        const uint8_t* t = text + begin;
+        auto at = [&](int i) -> uint32_t { return i < dl ? t[i] : 0u; };
+        const bool share = (g & 3) != 3 && begin + SEG < e0;
+        auto wave_rounds = [&](int npos) {
+          const int ntask = std::min(npos, dl);
+          const int nwalkpos = (dl <= npos && npos == NPOS) ? ntask - 1 : ntask;
+          const int run = (std::max(nwalkpos, 0) + 63) >> 6;
+          int wr = 0;
+          for (int lane = 0; lane < 64; lane++) {
+            const int end = std::max(std::min(lane * run + run, nwalkpos), 0);
+            int rounds = 0, depth = 0; uint32_t node = 0; bool first = true;
+            for (int pos = lane * run; pos < end; pos++) {
+              const int limit = std::min(dl - pos, Lmax);
+              const uint2* e = (!first && depth >= 3) ? link + 2 * (size_t)node : direct + 2 * (size_t)(at(pos) | (at(pos + 1) << 8));
+              rounds++;
+              uint32_t src = e[0].x, filt = e[1].x;
+              depth = (int)((src >> 23) & 63u); node = src & kNodeMask;
+              bool from_set = true, go = (src & kHasChildren) != 0 && depth < limit;
+              while (go) {
+                const uint32_t c = at(pos + depth);
+                if (from_set ? !((filt >> (c & 31u)) & 1u) : !((filt >> (c & 3u)) & 1u)) break;
+                const uint32_t key = (node << 8) | c;
+                uint32_t h = edge_hash(node, c) >> hv.edge_shift;
+                bool hit = false;
+                for (;;) { rounds++; const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1];
+                  if ((s0.x & kKeyMask) == key) { hit = true; src = s0.y; filt = s0.x >> 28; from_set = false; break; }
+                  if ((s1.x & kKeyMask) == key) { hit = true; src = s1.y; filt = s1.x >> 28; from_set = false; break; }
+                  if (s1.x == kNone) break; h = (h + 1) & hv.edge_mask; }
+                if (!hit) break;
+                depth++; node = src & kNodeMask; go = (src & kHasChildren) != 0 && depth < limit;
+              }
+              first = false;
+            }
+            wr = std::max(wr, rounds);
+          }
+          return wr;
+        };
+        const int full = wave_rounds(NPOS);
+        rounds_now += full;
+        rounds_shared += share ? wave_rounds(SEG) : full;
+        sharing += share; waves++;
+      }
+    }
+    printf("halo sharing: %.1f %% of the wavefronts take their halo from the next one: rounds/wave %.2f -> %.2f\n", 100.0 * sharing / waves, (double)rounds_now / waves,
+           (double)rounds_shared / waves);
+  }
+
   // dynamic hand-out: runs of r consecutive positions, a lane that finishes takes the next unassigned run (from scratch)
   for (int variant = 0; variant < 2; variant++) for (int r = 1; r <= 6; r++) {
     uint64_t rounds_total = 0, waves = 0, gathers = 0, npos = 0;
