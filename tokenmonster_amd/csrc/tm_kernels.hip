@@ -166,6 +166,32 @@ __device__ __forceinline__ bool child_possible4(uint32_t key_word, uint32_t c) {
 // Written without branches: every lane executes the same instructions, so the NWALK loads of a round are issued back
 // to back and the round has a single wait.  `c` is the text byte after the one being matched (text[tbase+depth+1]),
 // read from LDS while the probe was in flight.  Returns true when the slot is (or has become) idle.
+#if TM_SKIP_EDGES
+// number of chain bytes of slot word z (b1 | b2 << 8 | b3 << 16 | L << 24) that the text word t4 (the bytes behind the one being matched)
+// continues with, at most L and at most `room` levels
+__device__ __forceinline__ uint32_t chain_match(uint32_t z, uint32_t t4, uint32_t room) {
+  const uint32_t diff = ((t4 ^ z) & 0xFFFFFFu) | 0x1000000u;
+  return min(min((uint32_t)__builtin_ctz(diff) >> 3, z >> 24), room);
+}
+// (16-byte slots {key | filter of the landing node, child value, chain | L << 24, landing value}: tm_tables.h; t4 = text[tbase + depth + 1 ..+3])
+__device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uint4 e, const uint32_t t4) {
+  const bool hit = (e.x & kKeyMask) == k.key;
+  const bool again = !hit && e.x != kNone;                        // the slot is taken by another key: the next one
+  const uint32_t L = e.z >> 24, j = chain_match(e.z, t4, (uint32_t)(k.limit - k.depth - 1));
+  const bool full = j == L;
+  const uint32_t cur = full ? e.w : e.y, nid = full ? node_id(e.w) : node_id(e.y) + j;
+  k.depth += hit ? 1 + (int)j : 0;
+  const bool acc = hit && nid < T.n_info;                          // (a node inside a chain is internal: its id is >= n_info)
+  k.bestv = acc ? cur : k.bestv;
+  k.bestlen = acc ? k.depth : k.bestlen;
+  const uint32_t cn = (t4 >> (8u * L)) & 0xFFu;                    // the text byte behind the whole chain
+  const bool cont = hit && full && k.depth < k.limit && child_possible4(e.x, cn);
+  const uint32_t lin = (k.hoff + 16u) & (T.edge_mask << 4);
+  k.key = cont ? ((nid << 8) | cn) : (again ? k.key : KEY_IDLE);
+  k.hoff = cont ? edge_slot_offset(T, nid, cn) : (again ? lin : (T.edge_mask + 1u) << 4);
+  return !(cont || again);
+}
+#else
 __device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uint4 e, const uint32_t c) {
   const bool hit1 = (e.z & kKeyMask) == k.key;
   const bool hit = hit1 || (e.x & kKeyMask) == k.key;
@@ -181,6 +207,7 @@ __device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uin
   k.hoff = cont ? edge_slot_offset(T, nid, c) : (again ? lin : (T.edge_mask + 1u) << 4);
   return !(cont || again);
 }
+#endif
 
 // score of one branch, go/tokenmonster.go:1075-1084 (plain), :1096-1105 (forward-delete variant); alternatives add :1132-1133.
 //   fpart  what the candidate first token contributes on its own: flen + allLetters + max0(w-1) + w*100, w = nWords - fd (go :1071,1117,1169)
@@ -373,6 +400,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     typedef TM_LDS_SPACE uint8_t lds_u8;
     typedef TM_LDS_SPACE_UNALIGNED uint16_t lds_u16u;
     typedef TM_LDS_SPACE uint32_t lds_u32;
+#if TM_SKIP_EDGES
+    typedef TM_LDS_SPACE_UNALIGNED uint32_t lds_u32u;
+#endif
     const uint32_t tb = TM_LDS_ADDR(w.text);                                        // address of text[0]
     const uint32_t dconst = TM_LDS_ADDR(w.D) - 4u * tb;                               // &D[i] == dconst + 4 * (tb + i)
     const int run = (max(nwalkpos, 0) + 63) >> 6;
@@ -398,6 +428,28 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       // a lane is busy exactly as long as its gather address is not the idle slot
       while (__builtin_amdgcn_ballot_w64(off != idle_off) != 0ull) {
         const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // link format {x, y, child filter, best depth}, or a hash bucket {key0 | filter, value0, key1 | filter, value1}
+#if TM_SKIP_EDGES
+        // (a hash slot here: {key | filter of the landing node, child value, chain | L << 24, landing value}, tm_tables.h)
+        uint32_t t4 = *TM_LDS_PTR(lds_u32u, pfa);                       // the text from the byte behind the one being matched on
+        uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);
+        TM_KEEP_IN_VGPRS2(t4, nn);
+        const uint32_t c = t4 & 0xFFu;
+        const bool hit = probing && (e.x & kKeyMask) == key;
+        const bool again = probing && !hit && e.x != kNone;              // the slot holds another key: next slot
+        const bool adv = hit || setting;
+        const uint32_t L = e.z >> 24, j = chain_match(e.z, t4, (uint32_t)((TAIL ? limit : Lmax) - depth - 1));
+        const bool full = j == L;
+        const uint32_t hv = full ? e.w : e.y;
+        const uint32_t nid = hit ? (full ? (e.w & kNodeMask) : (e.y & kNodeMask) + j) : (e.x & kNodeMask);
+        if (hit) depth += 1 + (int)j;
+        if (setting) { depth = (int)((e.x >> 23) & 63u); bestv = e.y; bestlen = (int)e.w; }
+        if (adv) node = nid;
+        if (hit && nid < T.n_info) { bestv = hv; bestlen = depth; }      // (a node inside a chain is internal: never accepting)
+        const uint32_t cx = setting ? c : (t4 >> (8u * L)) & 0xFFu;      // the byte the walk would go on with
+        const bool go = adv && (setting ? child_possible32(e.z, c) : (full && child_possible4(e.x, cx))) && depth < (TAIL ? limit : Lmax) && !nowalk;
+        const bool fin = (adv && !go) || (probing && !hit && !again);
+        if (go) { key = (nid << 8) | cx; off = edge_slot_offset(T, nid, cx); pfa = posa + (uint32_t)depth + 1u; }
+#else
         uint32_t c = *TM_LDS_PTR(lds_u8, pfa);
         uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);                // the two bytes at the next position, as the direct map indexes them
         TM_KEEP_IN_VGPRS2(c, nn);                                        // both LDS reads are issued here, under the gather's latency
@@ -416,6 +468,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         const bool go = adv && (setting ? child_possible32(e.z, c) : child_possible4(hk, c)) && depth < (TAIL ? limit : Lmax) && !nowalk;
         const bool fin = (adv && !go) || (probing && !hit && !again);
         if (go) { key = (nid << 8) | c; off = edge_slot_offset(T, nid, c); pfa = posa + (uint32_t)depth + 1u; }
+#endif
         if (again) off = (off + 16u) & mask16;
         probing = go || again;
         setting = false;
@@ -507,7 +560,12 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       }
       while (__any(!walk_idle(k))) {
         const uint4 e = load_slot(hash_tab, k.hoff);
+#if TM_SKIP_EDGES
+        uint32_t c;                                                  // the four text bytes behind the one being matched
+        __builtin_memcpy(&c, &w.text[k.tbase + k.depth + 1], 4);
+#else
         const uint32_t c = w.text[k.tbase + k.depth + 1];
+#endif
         if (walk_consume(T, k, e, c) && k.bestlen > mainlen + 1) {
           const int lb = k.bestlen - off;                              // go :1093
           w.Db[k.pos] = make_sdesc((uint32_t)lb, k.bestv, s_bb[w.text[k.pos + lb]], true, T.spl_hint);

@@ -191,6 +191,43 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     }
   }
   const uint32_t n_nodes = next_internal;
+#if TM_SKIP_EDGES
+  // chains: non-accepting nodes with exactly one child.  Renumber the internal nodes so that every maximal chain has consecutive ids
+  // (tm_tables.h), then rebuild the edge map and the per-node arrays under the new ids; accepting ids (record ordinals) stay.
+  std::vector<uint32_t> only_child(n_nodes, kNone);
+  std::vector<uint8_t> only_byte(n_nodes, 0), in_chain(n_nodes, 0);
+  {
+    std::vector<uint32_t> nchild(n_nodes, 0);
+    for (auto& kv : child) { const uint32_t par = (uint32_t)(kv.first >> 8); if (par != kRoot) { nchild[par]++; only_child[par] = kv.second; only_byte[par] = (uint8_t)(kv.first & 0xFF); } }
+    for (uint32_t u = n_info; u < n_nodes; u++) in_chain[u] = nchild[u] == 1;
+    std::vector<uint32_t> R(n_nodes, kNone);
+    for (uint32_t u = 0; u < n_info; u++) R[u] = u;
+    uint32_t next_id = n_info;
+    for (uint32_t u = n_info; u < n_nodes; u++) {
+      if (!in_chain[u]) continue;
+      const uint32_t par = parent_of[u];
+      if (par != kRoot && par >= n_info && in_chain[par]) continue;          // not the head of its chain
+      for (uint32_t c = u; c != kNone && c >= n_info && in_chain[c]; c = only_child[c]) R[c] = next_id++;
+    }
+    for (uint32_t u = n_info; u < n_nodes; u++) if (R[u] == kNone) R[u] = next_id++;
+    EdgeMap child2(hv.keys.size() + 16);
+    std::vector<uint8_t> depth2(n_nodes), byte2(n_nodes), chain2(n_nodes);
+    std::vector<uint32_t> parent2(n_nodes), oc2(n_nodes, kNone);
+    for (auto& kv : child) {
+      const uint32_t par = (uint32_t)(kv.first >> 8);
+      child2.emplace(((uint64_t)(par == kRoot ? kRoot : R[par]) << 8) | (kv.first & 0xFF), R[kv.second]);
+    }
+    for (uint32_t u = 0; u < n_nodes; u++) {
+      depth2[R[u]] = depth_of[u]; byte2[R[u]] = byte_of[u]; chain2[R[u]] = in_chain[u];
+      parent2[R[u]] = parent_of[u] == kRoot ? kRoot : R[parent_of[u]];
+      oc2[R[u]] = only_child[u] == kNone ? kNone : R[only_child[u]];
+    }
+    std::vector<uint8_t> ob2(n_nodes);
+    for (uint32_t u = 0; u < n_nodes; u++) ob2[R[u]] = only_byte[u];
+    child = std::move(child2);
+    depth_of.swap(depth2); byte_of.swap(byte2); parent_of.swap(parent2); in_chain.swap(chain2); only_child.swap(oc2); only_byte.swap(ob2);
+  }
+#endif
   std::vector<uint8_t> has_child(n_nodes, 0);
   for (auto& kv : child) { uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) has_child[parent] = 1; }
   // Forward-delete hint (tm_tables.h): can the walk of ' '+key (the probe of go :1088-1095) end on something longer than
@@ -239,8 +276,13 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   while ((1ull << bits) < n_edges * 5 / 2 + 8) bits++;
   // two slots per 16-byte bucket: a probe is one 16-byte gather and sees both, so at this load nearly every key sits in the
   // bucket it hashes to (the walk's "occupied by another key, try the next slot" rounds all but disappear)
+#if TM_SKIP_EDGES
+  hv.edge_mask = (1u << bits) - 1;                 // one 16-byte slot per bucket (tm_tables.h)
+  hv.edge_shift = 32 - bits;
+#else
   hv.edge_mask = (1u << (bits - 1)) - 1;           // bucket mask
   hv.edge_shift = 32 - (bits - 1);
+#endif
   // child-byte filter of every node: bit (b & 31) is set if the node has a child over byte b.  A walk only probes the edge hash
   // for a byte whose bit is set, so a probe that cannot hit (half of all positions end on one, and with linear probing it is
   // ~1.5 gathers) is almost never issued: most nodes have one child.
@@ -280,11 +322,22 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     for (auto& kv : order) {
       const uint32_t parent = (uint32_t)(kv.first >> 8), byte = (uint32_t)(kv.first & 0xFF);
       uint32_t key = (parent << 8) | byte;
+#if TM_SKIP_EDGES
+      uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;                     // home bucket, one slot each
+      while (edges[2 * (size_t)h].x != kNone) h = (h + 1) & hv.edge_mask;
+      uint32_t land = kv.second, chain = 0, L = 0;                               // up to 3 bytes of the chain below the child
+      while (L < 3 && land >= n_info && in_chain[land]) { chain |= (uint32_t)only_byte[land] << (8 * L); land = only_child[land]; L++; }
+      uint32_t f4 = 0;                                                           // 4-bit filter of the landing node
+      for (uint32_t q = 0; q < 32; q++) if ((cmask[land] >> q) & 1u) f4 |= 1u << (q & 3u);
+      edges[2 * (size_t)h] = uint2{key | (f4 << 28), value_of(kv.second)};
+      edges[2 * (size_t)h + 1] = uint2{chain | (L << 24), value_of(land)};
+#else
       uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;                     // home bucket; slot 0 fills before slot 1
       while (edges[2 * (size_t)h + 1].x != kNone) h = (h + 1) & hv.edge_mask;
       uint32_t f4 = 0;                                                           // 4-bit filter of the node the edge leads to
       for (uint32_t q = 0; q < 32; q++) if ((cmask[kv.second] >> q) & 1u) f4 |= 1u << (q & 3u);
       edges[2 * (size_t)h + (edges[2 * (size_t)h].x != kNone ? 1 : 0)] = uint2{key | (f4 << 28), value_of(kv.second)};
+#endif
     }
   }
   // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.
