@@ -6,6 +6,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <utility>
 #include <cstdio>
 #include <map>
 #include <mutex>
@@ -129,11 +131,32 @@ void prepare(Sched* s, unsigned i) {
   f.wait_gen = nullptr;
 }
 
+// The order in which the work-items of a workgroup get their turn: 0 = ascending (default), 1 = descending, otherwise a new pseudo-random
+// order every pass seeded by the value (TM_EMU_ORDER in the environment).  The hardware runs the lanes of a wavefront in lockstep: between
+// two synchronisation points a lane may see what a lane that ran before it has written, but nothing may DEPEND on who ran first, so the
+// tests must give the same results under every order (a kernel that passes only under one of them has a race the device would decide
+// its own way).
+unsigned order_mode() {
+  static const unsigned m = [] { const char* e = getenv("TM_EMU_ORDER"); return e ? (unsigned)strtoul(e, nullptr, 10) : 0u; }();
+  return m;
+}
+
 void run_group(Sched* s) {
   unsigned live = s->nitems;
+  const unsigned mode = order_mode();
+  static thread_local std::vector<unsigned> perm;
+  static thread_local unsigned long long rng = 0;
+  if (mode > 1) {
+    if (!rng) rng = 0x9E3779B97F4A7C15ull * mode;
+    perm.resize(s->nitems);
+    for (unsigned i = 0; i < s->nitems; i++) perm[i] = i;
+  }
   while (live > 0) {
     bool progressed = false;
-    for (unsigned i = 0; i < s->nitems; i++) {
+    if (mode > 1)
+      for (unsigned i = s->nitems; i > 1; i--) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; std::swap(perm[i - 1], perm[rng % i]); }
+    for (unsigned k = 0; k < s->nitems; k++) {
+      const unsigned i = mode == 0 ? k : mode == 1 ? s->nitems - 1 - k : perm[k];
       Fiber& f = s->fibers[i];
       if (f.done) continue;
       if (f.wait_gen && *f.wait_gen == f.wait_val) continue;
