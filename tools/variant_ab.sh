@@ -34,13 +34,21 @@ run)
     fi
     ( cd "$work" && timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x -k "not full_size" > "$OUT/pytest_$name.log" 2>&1; echo "$name: pytest exit $? $(tail -1 "$OUT/pytest_$name.log")"
       timeout 600 python bench.py --mbytes "$MB" --steps 8 --warmup 2 --hot-path-only --no-cpu-baseline --no-host-to-host > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err"
-      python - "$OUT/bench_$name.json" "$name" <<'PY'
+      # dynamic instruction counts of K1 per wavefront (what the host model predicts): one rocprofv3 --pmc pass
+      ( cd /tmp && export TMPDIR=/tmp && timeout 600 python "$work/tools/pmc_profile.py" --mbytes "$MB" --groups 0 --kernel k_match_branch --out "$OUT/pmc_$name" > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" )
+      python - "$OUT/bench_$name.json" "$name" "$OUT/pmc_$name.json" <<'PY'
 import json, sys
 try:
     j = json.load(open(sys.argv[1]))
     print("%s: %.3f ms/step, kernels %s, verified %s" % (sys.argv[2], j["ms_per_step"], j["roofline"]["kernel_ms"], j["config"]["verified_docs_vs_oracle"]))
 except Exception as ex:
     print("%s: no bench line (%s)" % (sys.argv[2], ex))
+try:
+    k = list(json.load(open(sys.argv[3])).values())[0]
+    w = k["SQ_WAVES"]
+    print("%s: per wavefront %s" % (sys.argv[2], {c.replace("SQ_INSTS_", ""): round(v / w, 1) for c, v in k.items() if c.startswith("SQ_INSTS")}))
+except Exception as ex:
+    print("%s: no counters (%s)" % (sys.argv[2], ex))
 PY
     )
   done ;;
