@@ -273,7 +273,10 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   size_t n_edges = 0;
   for (auto& kv : child) if (depth_of[kv.second] >= 3) n_edges++;
   uint32_t bits = 4;
-  while ((1ull << bits) < n_edges * 5 / 2 + 8) bits++;
+#ifndef TM_HASH_QUARTERS
+#define TM_HASH_QUARTERS 10              // slots per edge, in quarters: 2.5 (build-time experiment knob, tools/variant_ab.sh)
+#endif
+  while ((1ull << bits) < n_edges * TM_HASH_QUARTERS / 4 + 8) bits++;
   // two slots per 16-byte bucket: a probe is one 16-byte gather and sees both, so at this load nearly every key sits in the
   // bucket it hashes to (the walk's "occupied by another key, try the next slot" rounds all but disappear)
 #if TM_SKIP_EDGES
