@@ -46,6 +46,11 @@ int enter_device(const tm_vocab* v) {
   return e == hipSuccess ? TM_OK : hip_fail(e, "hipSetDevice (device of the vocabulary)");
 }
 
+// build-time experiment knob (tools/variant_ab.sh): hash insertion order by traffic (the score column) instead of by depth
+#ifndef TM_HASH_HOT_FIRST
+#define TM_HASH_HOT_FIRST 0
+#endif
+
 namespace {
 // (parent node << 8 | byte) -> child node of the trie under construction: open addressing over a flat array (the table build of a
 // candidate vocabulary is on the trainvocab worker's path, and std::unordered_map was most of its time), edges kept in creation order
@@ -102,6 +107,9 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   hv.keys.clear(); hv.key_off.assign(1, 0); hv.rows.resize(hv.n_info);
   std::vector<uint8_t> lens(hv.n_info), flags(hv.n_info), nwords(hv.n_info);
   std::vector<uint32_t> ids(hv.n_info);
+#if TM_HASH_HOT_FIRST
+  std::vector<float> rec_score(hv.n_info, 0.0f);       // the score column: the share of the training data a token covered (go :2636)
+#endif
   uint32_t prev_len = 0;
   for (uint32_t i = 0; i < hv.n_info; i++) {
     NEED(1);
@@ -115,6 +123,9 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     hv.key_off.push_back((uint32_t)hv.keys.size());
     pos += kl;
     uint32_t flag = f[pos], nw = f[pos + 1], index1 = rd24(f + pos + 2), index2 = rd24(f + pos + 5), id = rd24(f + pos + 8);
+#if TM_HASH_HOT_FIRST
+    std::memcpy(&rec_score[i], f + pos + 11, 4);
+#endif
     pos += 15;
     if (id >= hv.n_ids) return set_error(TM_E_INVALID, "record %u: id %u out of range", i, id);
     if (nw > 31) return set_error(TM_E_LIMIT, "record %u: nWords %u > 31", i, nw);
@@ -322,6 +333,16 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     for (int d = 0; d < 42; d++) { const uint32_t c = start[d]; start[d] = total_edges; total_edges += c; }
     std::vector<std::pair<uint64_t, uint32_t>> order(total_edges);
     for (auto& kv : child) if (depth_of[kv.second] >= 3) order[start[41 - maxd[kv.second]]++] = kv;
+#if TM_HASH_HOT_FIRST
+    // (experiment) the edges a walk crosses most often keep their home buckets instead: weight of an edge = occurrences of the tokens
+    // below it, from the score column (score = share of the data covered, so occurrences ~ score / length); deepest-first among equals
+    {
+      std::vector<float> wgt(n_nodes, 0.0f);
+      for (uint32_t i = 0; i < n_info; i++) if (rec_score[i] > 0.0f && rec_score[i] < 1e9f) wgt[i] = rec_score[i] / (float)lens[i];
+      for (size_t q = n_nodes; q-- > 0;) { const uint32_t n = by_depth[q], par = parent_of[n]; if (par != kRoot) wgt[par] += wgt[n]; }
+      std::stable_sort(order.begin(), order.end(), [&](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return wgt[a.second] > wgt[b.second]; });
+    }
+#endif
     for (auto& kv : order) {
       const uint32_t parent = (uint32_t)(kv.first >> 8), byte = (uint32_t)(kv.first & 0xFF);
       uint32_t key = (parent << 8) | byte;
