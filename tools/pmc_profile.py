@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--extra", default="", help="extra bench.py flags")
     ap.add_argument("--e2e", action="store_true", help="profile the end-to-end step (device normalizer included) instead of the hot path")
     ap.add_argument("--groups", default="", help="comma separated group numbers (default all)")
+    ap.add_argument("--fast", action="store_true", help="drive the kernels with tools/k1_time.py (ctypes, no torch: seconds instead of a minute per pass)")
+    ap.add_argument("--lib", default="", help="with --fast: a variant library instead of the product's")
     args = ap.parse_args()
     args.out = os.path.abspath(args.out)
     os.makedirs(args.out, exist_ok=True)
@@ -40,9 +42,13 @@ def main():
         if gi not in want:
             continue
         d = os.path.join(args.out, "g%d" % gi)
-        cmd = ["rocprofv3", "--pmc"] + grp + ["--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--mbytes", str(args.mbytes), "--steps", "2", "--warmup", "1",
-               "--verify", "0", "--no-cpu-baseline", "--no-host-to-host"] + ([] if args.e2e else ["--hot-path-only"]) + args.extra.split()
+        if args.fast:
+            work = [sys.executable, os.path.join(ROOT, "tools", "k1_time.py"), "--one", os.path.abspath(args.lib) if args.lib else "", "--mbytes", str(args.mbytes),
+                    "--reps", "2"] + (["--e2e"] if args.e2e else []) + args.extra.split()
+        else:
+            work = [sys.executable, os.path.join(ROOT, "bench.py"), "--mbytes", str(args.mbytes), "--steps", "2", "--warmup", "1",
+                    "--verify", "0", "--no-cpu-baseline", "--no-host-to-host"] + ([] if args.e2e else ["--hot-path-only"]) + args.extra.split()
+        cmd = ["rocprofv3", "--pmc"] + grp + ["--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--"] + work
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             print("group %d failed:\n%s" % (gi, r.stdout.decode(errors="replace")[-2000:]), file=sys.stderr)

@@ -35,7 +35,7 @@ run)
     ( cd "$work" && timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x -k "not full_size" > "$OUT/pytest_$name.log" 2>&1; echo "$name: pytest exit $? $(tail -1 "$OUT/pytest_$name.log")"
       timeout 600 python bench.py --mbytes "$MB" --steps 8 --warmup 2 --hot-path-only --no-cpu-baseline --no-host-to-host > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err"
       # dynamic instruction counts of K1 per wavefront (what the host model predicts): one rocprofv3 --pmc pass
-      ( cd /tmp && export TMPDIR=/tmp && timeout 600 python "$work/tools/pmc_profile.py" --mbytes "$MB" --groups 0 --kernel k_match_branch --out "$OUT/pmc_$name" > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" )
+      ( cd /tmp && export TMPDIR=/tmp && timeout 600 python "$work/tools/pmc_profile.py" --fast --mbytes "$MB" --groups 0 --kernel k_match_branch --out "$OUT/pmc_$name" > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" )
       python - "$OUT/bench_$name.json" "$name" "$OUT/pmc_$name.json" <<'PY'
 import json, sys
 try:
