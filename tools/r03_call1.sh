@@ -4,4 +4,4 @@
 #   (2) A/B of the K1 variants built by `bash tools/variant_ab.sh build` (run that HERE first, then gpurun)    -> gpurun_out/variant_ab
 cd "$(dirname "$0")/.."
 bash tools/end_of_round_check.sh r03_start
-bash tools/variant_ab.sh run 256
+bash tools/variant_ab.sh run 256      # (seconds; `check <name>` runs the parity tests with one variant in place)

@@ -2,8 +2,8 @@
 # tools/variant_ab.sh — A/B of build-time kernel variants (experiments that are off in the product build until they have been timed).
 #   bash tools/variant_ab.sh build          HERE, before the GPU call: variants/<name>/libtokenmonster_hip.so for every variant
 #                                           (in-tree and git-ignored, so it travels to the GPU box like the product library)
-#   bash tools/variant_ab.sh run [MiB=256]  ON THE GPU BOX: for the default build and every variant, a copy of the tree with that
-#                                           library in place runs the parity tests of the tokenizer and times K1 on the bench corpus
+#   bash tools/variant_ab.sh run [MiB=256]  ON THE GPU BOX: K1 time and ids md5 of the product library and of every variant (torch-free: seconds)
+#   bash tools/variant_ab.sh check <name>   ON THE GPU BOX: the parity tests with ONE variant library in place, and its instruction counters
 # A variant is adopted (its macro flipped in the source) only if its ids are bit-exact and its K1 time is lower on the device.
 set -u
 cd "$(dirname "$0")/.."
@@ -23,34 +23,32 @@ build)
     echo "built variants/$name (${VARIANTS[$name]})"
   done ;;
 run)
+  # seconds, not minutes: K1 of the product library and of every variant library through tools/k1_time.py (ctypes, no torch); the ids of a
+  # variant must have the md5 of the product library's
   MB=${2:-256}
   OUT=$ROOT/gpurun_out/variant_ab; mkdir -p "$OUT"
-  for name in default "${!VARIANTS[@]}"; do
-    work=/tmp/ab_$name; rm -rf "$work"; mkdir -p "$work"
-    tar -C "$ROOT" --exclude=.git --exclude=gpurun_out --exclude=variants -cf - . | tar -C "$work" -xf -
-    if [ "$name" != default ]; then
-      [ -f "$ROOT/variants/$name/libtokenmonster_hip.so" ] || { echo "$name: not built (run: bash tools/variant_ab.sh build)"; continue; }
-      cp "$ROOT/variants/$name/libtokenmonster_hip.so" "$work/tokenmonster_amd/libtokenmonster_hip.so"
-    fi
-    ( cd "$work" && timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x -k "not full_size" > "$OUT/pytest_$name.log" 2>&1; echo "$name: pytest exit $? $(tail -1 "$OUT/pytest_$name.log")"
-      timeout 600 python bench.py --mbytes "$MB" --steps 8 --warmup 2 --hot-path-only --no-cpu-baseline --no-host-to-host > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err"
-      # dynamic instruction counts of K1 per wavefront (what the host model predicts): one rocprofv3 --pmc pass
-      ( cd /tmp && export TMPDIR=/tmp && timeout 600 python "$work/tools/pmc_profile.py" --fast --mbytes "$MB" --groups 0 --kernel k_match_branch --out "$OUT/pmc_$name" > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" )
-      python - "$OUT/bench_$name.json" "$name" "$OUT/pmc_$name.json" <<'PY'
+  libs=()
+  for name in "${!VARIANTS[@]}"; do [ -f "variants/$name/libtokenmonster_hip.so" ] && libs+=(--lib "variants/$name/libtokenmonster_hip.so"); done
+  python tools/k1_time.py --mbytes "$MB" "${libs[@]}" --lib tokenmonster_amd/libtokenmonster_hip.so 2>&1 | tee "$OUT/k1_time_${MB}m.txt" ;;
+check)
+  # the parity tests of the tokenizer with ONE variant library in place of the product's (a copy of the tree), and its K1 counters
+  name=${2:?variant name}; MB=${3:-256}
+  OUT=$ROOT/gpurun_out/variant_ab; mkdir -p "$OUT"
+  [ -f "$ROOT/variants/$name/libtokenmonster_hip.so" ] || { echo "$name: not built (run: bash tools/variant_ab.sh build)"; exit 1; }
+  work=/tmp/ab_$name; rm -rf "$work"; mkdir -p "$work"
+  tar -C "$ROOT" --exclude=.git --exclude=gpurun_out --exclude=variants -cf - . | tar -C "$work" -xf -
+  cp "$ROOT/variants/$name/libtokenmonster_hip.so" "$work/tokenmonster_amd/libtokenmonster_hip.so"
+  ( cd "$work" && timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x -p no:cacheprovider -k "not full_size" > "$OUT/pytest_$name.log" 2>&1; echo "$name: pytest exit $? $(tail -1 "$OUT/pytest_$name.log")" )
+  ( cd /tmp && export TMPDIR=/tmp && timeout 600 python "$ROOT/tools/pmc_profile.py" --fast --lib "$ROOT/variants/$name/libtokenmonster_hip.so" --mbytes "$MB" --groups 0 --kernel k_match_branch --out "$OUT/pmc_$name" > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" )
+  python - "$OUT/pmc_$name.json" "$name" <<'PY'
 import json, sys
 try:
-    j = json.load(open(sys.argv[1]))
-    print("%s: %.3f ms/step, kernels %s, verified %s" % (sys.argv[2], j["ms_per_step"], j["roofline"]["kernel_ms"], j["config"]["verified_docs_vs_oracle"]))
-except Exception as ex:
-    print("%s: no bench line (%s)" % (sys.argv[2], ex))
-try:
-    k = list(json.load(open(sys.argv[3])).values())[0]
+    k = list(json.load(open(sys.argv[1])).values())[0]
     w = k["SQ_WAVES"]
     print("%s: per wavefront %s" % (sys.argv[2], {c.replace("SQ_INSTS_", ""): round(v / w, 1) for c, v in k.items() if c.startswith("SQ_INSTS")}))
 except Exception as ex:
     print("%s: no counters (%s)" % (sys.argv[2], ex))
 PY
-    )
-  done ;;
-*) echo "usage: $0 build | run [MiB]"; exit 2 ;;
+  ;;
+*) echo "usage: $0 build | run [MiB] | check <variant> [MiB]"; exit 2 ;;
 esac
