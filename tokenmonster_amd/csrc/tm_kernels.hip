@@ -355,7 +355,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   for (int j = lane; j < TEXT_LEN / 4; j += 64) {
     uint32_t tw = 0;
     if (4 * j < dl) {
+#if TM_NT_STREAM
+      { typedef uint32_t __attribute__((aligned(1))) u32u; tw = TM_STREAM_LOAD(reinterpret_cast<const u32u*>(text + begin + 4 * j)); }
+#else
       __builtin_memcpy(&tw, text + begin + 4 * j, 4);       // the text buffer has >= 256 bytes of slack
+#endif
       if (4 * j + 4 > dl) tw &= (1u << (8 * (dl - 4 * j))) - 1u;
     }
     reinterpret_cast<uint32_t*>(w.text)[j] = tw;
@@ -634,7 +638,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         const Row row1 = T.rows[node_id(w.Xb[q])];
         const uint32_t t1 = transition<1>(T, w, s_bb, q, dl, dB, row1);
         w.Xb[q] = t1;                                              // Xb[q] is only ever read by this lane: reuse it for the result
+#if TM_NT_STREAM
+        if (side_ok) TM_STREAM_STORE(reinterpret_cast<unsigned long long*>(&side[g * SIDE_STRIDE + 1 + lane]), (unsigned long long)(uint32_t)q | ((unsigned long long)t1 << 32));
+#else
         if (side_ok) side[g * SIDE_STRIDE + 1 + lane] = make_uint2((uint32_t)q, t1);
+#endif
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0);
@@ -644,8 +652,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       const int p = it * 64 + lane;
       r1[it] = ((m1[it] >> lane) & 1ull) ? w.Xb[p] : R_INVALID;
       if (p < seglen) {
-        R0[g * SEG + p] = r0[it];                                  // rows of SEG words per SEGMENT (not per text position): every store is whole aligned lines
-        if (!side_ok) R1[g * SEG + p] = r1[it];                    // (rare) too many forward-delete states for the side list
+        TM_STREAM_STORE(&R0[g * SEG + p], r0[it]);                 // rows of SEG words per SEGMENT (not per text position): every store is whole aligned lines
+        if (!side_ok) TM_STREAM_STORE(&R1[g * SEG + p], r1[it]);   // (rare) too many forward-delete states for the side list
       }
     }
     if (lane == 0) side[g * SIDE_STRIDE] = make_uint2(side_ok ? (uint32_t)n1 : SIDE_DENSE, 0u);
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     for (int e = lane; e < ENT; e += 64) {
       const uint32_t a = J[(e & 1) * J_PLANE + (e >> 1)];
       const uint32_t t = (a >> 16) & 0x7FFFu;
-      exitmap[g * ENT + e] = ((a >> 31) != 0 && t != 0x7FFFu) ? (t | ((a & 0xFFFFu) << 8)) : R_INVALID;
+      TM_STREAM_STORE(&exitmap[g * ENT + e], ((a >> 31) != 0 && t != 0x7FFFu) ? (t | ((a & 0xFFFFu) << 8)) : R_INVALID);
     }
   }
   PH(7)
@@ -1003,7 +1011,15 @@ __device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg&
 #pragma unroll
     for (int h = 0; h < PARTS; h++) {
       v[s][h] = make_uint4(0u, 0u, 0u, 0u);
+#if TM_NT_STREAM
+      if (4u * (uint32_t)lane + 256u * h < len[s]) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q = TM_STREAM_LOAD(reinterpret_cast<const u32x4*>(src[s] + 256 * h));
+        v[s][h] = make_uint4(q.x, q.y, q.z, q.w);
+      }
+#else
       if (4u * (uint32_t)lane + 256u * h < len[s]) __builtin_memcpy(&v[s][h], src[s] + 256 * h, 16);
+#endif
     }
 #pragma unroll
   for (int s = 0; s < TS; s++)
@@ -1067,8 +1083,8 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
       fd = (w >> 30) & 1u;
       nfd += fd;
       nmiss += w >> 31;
-      if (id != ID_NONE) { if (t.base + E < out_cap) out[t.base + E] = id; E++; }
-      if (fd) { if (t.base + E < out_cap) out[t.base + E] = delete_id; E++; }
+      if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); E++; }
+      if (fd) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], delete_id); E++; }
       p += (w >> 24) & 63u;
     }
     if (hop > 2 * SEG) atomicOr(error_flag, 2u);
@@ -1085,7 +1101,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
   for (int s = 0; s < nv; s++) {
     const uint32_t n = (uint32_t)__shfl((int)staged, s);
     const uint64_t base = shfl_u64(t.base, s);
-    for (uint32_t j = (uint32_t)lane; j < n; j += 64u) if (base + j < out_cap) out[base + j] = s_tile[s][j];
+    for (uint32_t j = (uint32_t)lane; j < n; j += 64u) if (base + j < out_cap) TM_STREAM_STORE(&out[base + j], s_tile[s][j]);
   }
 }
 
