@@ -326,6 +326,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   __shared__ WaveLds s_wave[WAVES];
   const int lane = threadIdx.x & 63, wvi = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the segment, its document and lengths live in SGPRs
   TM_LDS_OBJECTS(s_bb, s_wave);
+  static_assert(WAVES * 64 == 256, "s_bb is filled one entry per work-item (a 2-wavefront build tokenized wrongly on the device)");
   s_bb[threadIdx.x] = T.begin_byte[threadIdx.x];
   __syncthreads();
   const uint64_t g = (uint64_t)blockIdx.x * WAVES + wvi;
