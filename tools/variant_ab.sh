@@ -8,7 +8,7 @@
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-declare -A VARIANTS=( [halo]="-DTM_K1_HALO_SHARE=1" [skip]="-DTM_SKIP_EDGES=1" [halo_skip]="-DTM_K1_HALO_SHARE=1 -DTM_SKIP_EDGES=1" [dense]="-DTM_HASH_QUARTERS=5" [sparse]="-DTM_HASH_QUARTERS=20" [halo_dense]="-DTM_K1_HALO_SHARE=1 -DTM_HASH_QUARTERS=5" [nt]="-DTM_NT_STREAM=1" [nt_halo]="-DTM_NT_STREAM=1 -DTM_K1_HALO_SHARE=1" [hot]="-DTM_HASH_HOT_FIRST=1" [dense_hot]="-DTM_HASH_QUARTERS=5 -DTM_HASH_HOT_FIRST=1" )
+declare -A VARIANTS=( [halo]="-DTM_K1_HALO_SHARE=1" [skip]="-DTM_SKIP_EDGES=1" [halo_skip]="-DTM_K1_HALO_SHARE=1 -DTM_SKIP_EDGES=1" [dense]="-DTM_HASH_QUARTERS=5" [sparse]="-DTM_HASH_QUARTERS=20" [halo_dense]="-DTM_K1_HALO_SHARE=1 -DTM_HASH_QUARTERS=5" [nt]="-DTM_NT_STREAM=1" [nt_halo]="-DTM_NT_STREAM=1 -DTM_K1_HALO_SHARE=1" [devel]="-DTM_DEVEL" [hot]="-DTM_HASH_HOT_FIRST=1" [dense_hot]="-DTM_HASH_QUARTERS=5 -DTM_HASH_HOT_FIRST=1" )
 case "${1:-}" in
 build)
   for name in "${!VARIANTS[@]}"; do
@@ -30,6 +30,15 @@ run)
   libs=()
   for name in "${!VARIANTS[@]}"; do [ -f "variants/$name/libtokenmonster_hip.so" ] && libs+=(--lib "variants/$name/libtokenmonster_hip.so"); done
   python tools/k1_time.py --mbytes "$MB" "${libs[@]}" --lib tokenmonster_amd/libtokenmonster_hip.so 2>&1 | tee "$OUT/k1_time_${MB}m.txt" ;;
+ablate)
+  # where K1's time goes: the TM_DEVEL build with phases switched off through TM_DBG (RESULTS ARE WRONG BY DESIGN, only the time counts):
+  # 0 everything, 1 no walks at all, 4 no hash probes, 8 no forward-delete probes, 16 no exit maps, 24 neither
+  MB=${2:-256}
+  OUT=$ROOT/gpurun_out/variant_ab; mkdir -p "$OUT"
+  [ -f variants/devel/libtokenmonster_hip.so ] || { echo "devel: not built (run: bash tools/variant_ab.sh build)"; exit 1; }
+  for dbg in 0 1 4 8 16 24; do
+    echo -n "TM_DBG=$dbg  "; TM_DBG=$dbg python tools/k1_time.py --one "$ROOT/variants/devel/libtokenmonster_hip.so" --mbytes "$MB" --reps 4 2>&1 | tail -1 | cut -c40-
+  done | tee "$OUT/k1_ablation_${MB}m.txt" ;;
 check)
   # the parity tests of the tokenizer with ONE variant library in place of the product's (a copy of the tree), and its K1 counters
   name=${2:?variant name}; MB=${3:-256}
@@ -50,5 +59,5 @@ except Exception as ex:
     print("%s: no counters (%s)" % (sys.argv[2], ex))
 PY
   ;;
-*) echo "usage: $0 build | run [MiB] | check <variant> [MiB]"; exit 2 ;;
+*) echo "usage: $0 build | run [MiB] | check <variant> [MiB] | ablate [MiB]"; exit 2 ;;
 esac
