@@ -1,4 +1,5 @@
-"""-m gpu: the scoring pass of N ranks as N PROCESSES, each with its own handle on the device, talking over torch.distributed —
+"""(named to run LAST under `pytest -x`: it is the one -m gpu test that starts further processes, each importing torch.)
+-m gpu: the scoring pass of N ranks as N PROCESSES, each with its own handle on the device, talking over torch.distributed —
 what bench.py --workload score --gpus N does, with gloo standing in for RCCL so that it runs on a one-GPU box (the ranks share
 device 0) and, on the emulated device (TM_EMU=1, tools/emu), on none.  Every rank is given its own byte range only; it fetches the
 halo from its neighbour (dist.exchange_halo), runs tm_score_begin, all-gathers the 80 exit states, finishes from its true entry
