@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--also-flags", default="", help="development aid: comma separated tm_debug_flags values; the same step is timed again under each "
                                                       "(kernel variants) and reported on stderr, its ids compared with the default's")
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-to-host pipeline and small-batch latency figures")
+    ap.add_argument("--measure-traffic", action="store_true", help="measure roofline.traffic in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over "
+                                                                    "tools/k1_time.py in a child process (adds about a minute); default: the figure of profiles/traffic_latest.json, labelled as static")
     return ap.parse_args()
 
 
@@ -422,6 +424,19 @@ def main():
                 traffic_source = "static: profiles/traffic_latest.json (%s), not measured in this run" % tj.get("measured", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE")
         except Exception:
             traffic = None
+    if args.measure_traffic and rank == 0 and world == 1:
+        # separate --pmc passes as /opt/skills/guides/MI355X_MICROARCH.md prescribes, the kernels driven without torch (tools/k1_time.py);
+        # FETCH_SIZE / WRITE_SIZE are in KB, gfx950 tallies 128-byte fetches at 64 bytes (x2)
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_profile.py"), "--fast", "--mbytes", str(args.mbytes), "--groups", "4,5",
+                                "--kernel", "k_match_branch", "--out", os.path.join("/tmp", "tm_bench_traffic")] + (["--extra=--config " + args.config] if args.config else []),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, start_new_session=True)
+            k = list(json.loads(r.stdout.decode()).values())[0]
+            traffic = int(k["FETCH_SIZE"] * 1024 * 2 + k["WRITE_SIZE"] * 1024)
+            traffic_source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over the same kernel, configuration and size"
+        except Exception as ex:     # noqa: BLE001
+            log("traffic measurement failed (%s): the static figure stays" % ex)
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms}
