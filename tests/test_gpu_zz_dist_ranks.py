@@ -36,7 +36,8 @@ def _rank(rank, world, port, img, data, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # the box's hostname may not resolve: loopback, explicitly
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         N.check(N.lib.tm_set_device(0))
         v = tm.Vocab(img)
@@ -62,6 +63,7 @@ def _rank(rank, world, port, img, data, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("world", [2, 3])
 def test_rank_processes_score_one_whole_buffer_walk(tmp_path, world):
     import torch.multiprocessing as mp
