@@ -406,6 +406,32 @@ def test_fuzz_utf16_vocab(seed):
             assert got.size == exp.size and (got == exp).all()
 
 
+def test_utf16_cut_character_ends_the_walk_with_an_error():
+    """A degenerate UTF-16 case on which the REFERENCE does not terminate: a vocabulary with one-byte keys (half a character) and a text
+    that ends in half a character.  In a forward-delete state the length of a candidate is its key length minus the two-byte prefix
+    ' ' 0x00 (tokenmonster.cpp:1790-1797: length1b -= lilbuf_offset), which for such keys is not positive: the walk stops advancing,
+    and the reference runtime — and the oracle, which restates it — loop forever (the same vocabulary hangs them on some texts of whole
+    characters too).  The device pipeline cannot loop: a state that never leaves its segment has no exit-map entry, and the call
+    returns TM_E_HIP.  Found by differential fuzzing on the emulated device; invalid input for the reference's callers."""
+    from tokenmonster_amd import _native as N
+    rng = np.random.default_rng(913)
+    toks8 = fuzz_vocab_tokens(rng, 2, 100)
+    toks = sorted(set(_utf16(t) for t in toks8 if len(t) <= 20) | {b"D", b" ", b"a"})
+    img = synth.build_vocab(toks, capcode=2, charset=2)
+    docs = []
+    for n in rng.integers(0, 1800, size=40):
+        doc = _utf16(fuzz_text(rng, 2, int(n)))
+        docs.append(doc[:-1] if n % 3 == 0 else doc)
+    bad = [d for d in docs if len(d) == 2975]
+    assert len(bad) == 1
+    v = tm.Vocab(img)
+    with pytest.raises(N.TokenMonsterHipError) as e:
+        v.tokenize_packed(*tm.pack_documents([bad[0]]))
+    assert e.value.code == N.TM_E_HIP
+    ids, _, _ = v.tokenize_packed(*tm.pack_documents([bad[0][:-1], bad[0] + b"\x00"]))      # whole characters either side of it: fine
+    assert ids.size > 0
+
+
 def test_host_api_edge_cases():
     from tokenmonster_amd import _native as N
     import ctypes as C
