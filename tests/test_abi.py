@@ -48,6 +48,29 @@ def test_no_oracle_in_product():
                 assert "oracle_bind" not in src and "libtm_oracle" not in src and "libtmref" not in src, f
 
 
+def test_no_emulation_in_product():
+    """tools/emu (the kernel sources built for the host) is test infrastructure: the product's Python layer must not know of it, the
+    product library must not have been built with it (no emulation runtime symbols), and without a GPU the product refuses to work."""
+    import subprocess
+    pkg = os.path.join(ROOT, "tokenmonster_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f), errors="replace").read()
+            assert "emu" not in src.lower().replace("enumerate", ""), f
+    r = subprocess.run(["nm", "-D", "--defined-only", os.path.join(pkg, "libtokenmonster_hip.so")], stdout=subprocess.PIPE)
+    syms = r.stdout.decode(errors="replace")
+    assert "emu_switch" not in syms and "launch_impl" not in syms
+    from tokenmonster_amd import _native as N
+    if N.lib.tm_device_count() == 0:          # (this container: no GPU)
+        import tokenmonster_amd as tm
+        from conftest import unit_vocab_image
+        try:
+            tm.Vocab(unit_vocab_image())
+            raise AssertionError("the product library worked without a GPU")
+        except N.TokenMonsterHipError as e:
+            assert e.code in (N.TM_E_NODEVICE, N.TM_E_HIP)
+
+
 def test_headers_are_plain_c_and_example_links(tmp_path):
     """include/*.h must be usable from C (the cgo stub of INTEGRATION.md compiles them as C), and the library must link
     into a program that knows nothing of Python or torch."""
