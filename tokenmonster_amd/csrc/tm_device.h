@@ -32,14 +32,10 @@
 #define TM_KEEP_IN_VGPRS4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #endif
 
-// TM_NT_STREAM (build-time experiment, off until timed): the data a kernel touches exactly once — the text K1 reads, the T(p,0) rows /
-// side lists / exit maps it writes (6 GB per GiB of text), the rows K4 reads and the ids it writes — with the non-temporal hint, so
-// that this stream does not push the vocabulary tables out of the 4 MB L2 of an XCD (K1's time follows the tables' cache footprint:
-// profiles/r02b_k1_variants_ab.txt).
-#ifndef TM_NT_STREAM
-#define TM_NT_STREAM 0
-#endif
-#if TM_NT_STREAM && !defined(TM_EMU)
+// Streams: the data a kernel touches exactly once — the text K1 reads, the T(p,0) rows / side lists / exit maps it writes (6 GB per GiB
+// of text), the rows K4 reads and the ids it writes — carry the non-temporal hint, so that they do not push the vocabulary tables out
+// of the 4 MB L2 of an XCD (K1's time follows the tables' cache footprint; measured -2.5 % on K1, profiles/r03_k1_variants_ab.txt).
+#ifndef TM_EMU
 #define TM_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #define TM_STREAM_LOAD(ptr) __builtin_nontemporal_load(ptr)
 #else

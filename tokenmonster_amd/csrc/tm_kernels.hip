@@ -166,32 +166,6 @@ __device__ __forceinline__ bool child_possible4(uint32_t key_word, uint32_t c) {
 // Written without branches: every lane executes the same instructions, so the NWALK loads of a round are issued back
 // to back and the round has a single wait.  `c` is the text byte after the one being matched (text[tbase+depth+1]),
 // read from LDS while the probe was in flight.  Returns true when the slot is (or has become) idle.
-#if TM_SKIP_EDGES
-// number of chain bytes of slot word z (b1 | b2 << 8 | b3 << 16 | L << 24) that the text word t4 (the bytes behind the one being matched)
-// continues with, at most L and at most `room` levels
-__device__ __forceinline__ uint32_t chain_match(uint32_t z, uint32_t t4, uint32_t room) {
-  const uint32_t diff = ((t4 ^ z) & 0xFFFFFFu) | 0x1000000u;
-  return min(min((uint32_t)__builtin_ctz(diff) >> 3, z >> 24), room);
-}
-// (16-byte slots {key | filter of the landing node, child value, chain | L << 24, landing value}: tm_tables.h; t4 = text[tbase + depth + 1 ..+3])
-__device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uint4 e, const uint32_t t4) {
-  const bool hit = (e.x & kKeyMask) == k.key;
-  const bool again = !hit && e.x != kNone;                        // the slot is taken by another key: the next one
-  const uint32_t L = e.z >> 24, j = chain_match(e.z, t4, (uint32_t)(k.limit - k.depth - 1));
-  const bool full = j == L;
-  const uint32_t cur = full ? e.w : e.y, nid = full ? node_id(e.w) : node_id(e.y) + j;
-  k.depth += hit ? 1 + (int)j : 0;
-  const bool acc = hit && nid < T.n_info;                          // (a node inside a chain is internal: its id is >= n_info)
-  k.bestv = acc ? cur : k.bestv;
-  k.bestlen = acc ? k.depth : k.bestlen;
-  const uint32_t cn = (t4 >> (8u * L)) & 0xFFu;                    // the text byte behind the whole chain
-  const bool cont = hit && full && k.depth < k.limit && child_possible4(e.x, cn);
-  const uint32_t lin = (k.hoff + 16u) & (T.edge_mask << 4);
-  k.key = cont ? ((nid << 8) | cn) : (again ? k.key : KEY_IDLE);
-  k.hoff = cont ? edge_slot_offset(T, nid, cn) : (again ? lin : (T.edge_mask + 1u) << 4);
-  return !(cont || again);
-}
-#else
 __device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uint4 e, const uint32_t c) {
   const bool hit1 = (e.z & kKeyMask) == k.key;
   const bool hit = hit1 || (e.x & kKeyMask) == k.key;
@@ -207,7 +181,6 @@ __device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uin
   k.hoff = cont ? edge_slot_offset(T, nid, c) : (again ? lin : (T.edge_mask + 1u) << 4);
   return !(cont || again);
 }
-#endif
 
 // score of one branch, go/tokenmonster.go:1075-1084 (plain), :1096-1105 (forward-delete variant); alternatives add :1132-1133.
 //   fpart  what the candidate first token contributes on its own: flen + allLetters + max0(w-1) + w*100, w = nWords - fd (go :1071,1117,1169)
@@ -300,20 +273,13 @@ __device__ unsigned long long g_phase[64 * 32];
 #endif
 
 
-// TM_K1_HALO_SHARE (build-time experiment, off in the product build until it has been timed on the device): the 40 halo positions of a
+// Halo sharing (measured -1.7 % alone, -4.9 % together with the non-temporal streams, profiles/r03_k1_variants_ab.txt): the 40 halo positions of a
 // segment — 13.5 % of the positions steps A1 - A3 work on — are the first 40 positions of the NEXT segment; when the wavefront of that
 // segment sits in the same workgroup and the same document, this wavefront walks 256 positions instead of 296 (runs of 4 instead of 5
 // per lane) and copies the neighbour's descriptors after ONE workgroup barrier.  Step C's pointer-doubling table then overlays
 // D[40..] / Db[40..] instead of D[0..], so that a wavefront never overwrites what its left neighbour may still be copying.
 // Host model (tools/a1_sim.cpp): 70 % of the wavefronts share, 26.5 -> 24.3 rounds per wavefront in step A1.
-#ifndef TM_K1_HALO_SHARE
-#define TM_K1_HALO_SHARE 0
-#endif
-#if TM_K1_HALO_SHARE
 constexpr int J_SKIP = NPOS - SEG, J_PLANE = NPOS;     // step C: state (p, fd) lives at word J_SKIP + fd * J_PLANE + p of {D, Db}
-#else
-constexpr int J_SKIP = 0, J_PLANE = SEG;
-#endif
 __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
                                                                 const uint64_t* __restrict__ doc_end,
@@ -344,11 +310,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   const uint64_t rem = doc_end[doc] - begin, remv = doc_vis[doc] - begin;
   const int dl = remv > (uint64_t)(1 << 20) ? (1 << 20) : (int)remv;   // bytes of text from `begin` on that can be looked at (clamped)
   const int seglen = (int)(rem < (uint64_t)SEG ? rem : (uint64_t)SEG);  // positions of this segment
-#if TM_K1_HALO_SHARE
   const bool share = wvi + 1 < WAVES && g + 1 < nseg && __builtin_amdgcn_readfirstlane((int)seg_doc[g + 1]) == (int)doc;   // (then rem > SEG: the text goes on)
-#else
-  constexpr bool share = false;
-#endif
   PH_INIT
 
   // stage the text with (unaligned) dword loads; bytes at and after the end of the document read as 0: the pad
@@ -356,11 +318,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   for (int j = lane; j < TEXT_LEN / 4; j += 64) {
     uint32_t tw = 0;
     if (4 * j < dl) {
-#if TM_NT_STREAM
       { typedef uint32_t __attribute__((aligned(1))) u32u; tw = TM_STREAM_LOAD(reinterpret_cast<const u32u*>(text + begin + 4 * j)); }
-#else
-      __builtin_memcpy(&tw, text + begin + 4 * j, 4);       // the text buffer has >= 256 bytes of slack
-#endif
       if (4 * j + 4 > dl) tw &= (1u << (8 * (dl - 4 * j))) - 1u;
     }
     reinterpret_cast<uint32_t*>(w.text)[j] = tw;
@@ -405,9 +363,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     typedef TM_LDS_SPACE uint8_t lds_u8;
     typedef TM_LDS_SPACE_UNALIGNED uint16_t lds_u16u;
     typedef TM_LDS_SPACE uint32_t lds_u32;
-#if TM_SKIP_EDGES
-    typedef TM_LDS_SPACE_UNALIGNED uint32_t lds_u32u;
-#endif
     const uint32_t tb = TM_LDS_ADDR(w.text);                                        // address of text[0]
     const uint32_t dconst = TM_LDS_ADDR(w.D) - 4u * tb;                               // &D[i] == dconst + 4 * (tb + i)
     const int run = (max(nwalkpos, 0) + 63) >> 6;
@@ -433,28 +388,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       // a lane is busy exactly as long as its gather address is not the idle slot
       while (__builtin_amdgcn_ballot_w64(off != idle_off) != 0ull) {
         const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // link format {x, y, child filter, best depth}, or a hash bucket {key0 | filter, value0, key1 | filter, value1}
-#if TM_SKIP_EDGES
-        // (a hash slot here: {key | filter of the landing node, child value, chain | L << 24, landing value}, tm_tables.h)
-        uint32_t t4 = *TM_LDS_PTR(lds_u32u, pfa);                       // the text from the byte behind the one being matched on
-        uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);
-        TM_KEEP_IN_VGPRS2(t4, nn);
-        const uint32_t c = t4 & 0xFFu;
-        const bool hit = probing && (e.x & kKeyMask) == key;
-        const bool again = probing && !hit && e.x != kNone;              // the slot holds another key: next slot
-        const bool adv = hit || setting;
-        const uint32_t L = e.z >> 24, j = chain_match(e.z, t4, (uint32_t)((TAIL ? limit : Lmax) - depth - 1));
-        const bool full = j == L;
-        const uint32_t hv = full ? e.w : e.y;
-        const uint32_t nid = hit ? (full ? (e.w & kNodeMask) : (e.y & kNodeMask) + j) : (e.x & kNodeMask);
-        if (hit) depth += 1 + (int)j;
-        if (setting) { depth = (int)((e.x >> 23) & 63u); bestv = e.y; bestlen = (int)e.w; }
-        if (adv) node = nid;
-        if (hit && nid < T.n_info) { bestv = hv; bestlen = depth; }      // (a node inside a chain is internal: never accepting)
-        const uint32_t cx = setting ? c : (t4 >> (8u * L)) & 0xFFu;      // the byte the walk would go on with
-        const bool go = adv && (setting ? child_possible32(e.z, c) : (full && child_possible4(e.x, cx))) && depth < (TAIL ? limit : Lmax) && !nowalk;
-        const bool fin = (adv && !go) || (probing && !hit && !again);
-        if (go) { key = (nid << 8) | cx; off = edge_slot_offset(T, nid, cx); pfa = posa + (uint32_t)depth + 1u; }
-#else
         uint32_t c = *TM_LDS_PTR(lds_u8, pfa);
         uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);                // the two bytes at the next position, as the direct map indexes them
         TM_KEEP_IN_VGPRS2(c, nn);                                        // both LDS reads are issued here, under the gather's latency
@@ -473,7 +406,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         const bool go = adv && (setting ? child_possible32(e.z, c) : child_possible4(hk, c)) && depth < (TAIL ? limit : Lmax) && !nowalk;
         const bool fin = (adv && !go) || (probing && !hit && !again);
         if (go) { key = (nid << 8) | c; off = edge_slot_offset(T, nid, c); pfa = posa + (uint32_t)depth + 1u; }
-#endif
         if (again) off = (off + 16u) & mask16;
         probing = go || again;
         setting = false;
@@ -565,12 +497,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       }
       while (__any(!walk_idle(k))) {
         const uint4 e = load_slot(hash_tab, k.hoff);
-#if TM_SKIP_EDGES
-        uint32_t c;                                                  // the four text bytes behind the one being matched
-        __builtin_memcpy(&c, &w.text[k.tbase + k.depth + 1], 4);
-#else
         const uint32_t c = w.text[k.tbase + k.depth + 1];
-#endif
         if (walk_consume(T, k, e, c) && k.bestlen > mainlen + 1) {
           const int lb = k.bestlen - off;                              // go :1093
           w.Db[k.pos] = make_sdesc((uint32_t)lb, k.bestv, s_bb[w.text[k.pos + lb]], true, T.spl_hint);
@@ -586,7 +513,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   PH(5)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-#if TM_K1_HALO_SHARE
   __syncthreads();                                       // every wavefront of the workgroup has its descriptors
   if (share && lane < NPOS - SEG) {
     const WaveLds& nx = s_wave[wvi + 1];
@@ -595,7 +521,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-#endif
 
   // ---- step B: T(p,0) and T(p,1) for every position of the segment --------------------------------
   // The kernel is VALU-issue bound (profiles/r01_v3_pmc_k1.txt) and the six-branch scoring is its largest block of
@@ -639,11 +564,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         const Row row1 = T.rows[node_id(w.Xb[q])];
         const uint32_t t1 = transition<1>(T, w, s_bb, q, dl, dB, row1);
         w.Xb[q] = t1;                                              // Xb[q] is only ever read by this lane: reuse it for the result
-#if TM_NT_STREAM
         if (side_ok) TM_STREAM_STORE(reinterpret_cast<unsigned long long*>(&side[g * SIDE_STRIDE + 1 + lane]), (unsigned long long)(uint32_t)q | ((unsigned long long)t1 << 32));
-#else
-        if (side_ok) side[g * SIDE_STRIDE + 1 + lane] = make_uint2((uint32_t)q, t1);
-#endif
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0);
@@ -952,10 +873,7 @@ __device__ __forceinline__ void hist_add(unsigned long long* s_w, uint32_t* __re
 // (p,1) states are rare: their words are looked up in the segment's side list (or the dense array) when one is entered.
 // (Letting every lane walk its segment straight from HBM — no tiles — was measured at 8.5 ms per GiB: ~0.6 G scattered 4-byte
 // accesses cost ~8 cycles each per CU.)
-#ifndef TM_TS
-#define TM_TS 8
-#endif
-constexpr int TS = TM_TS;                   // segments per wavefront (8: 18 wavefronts per CU; 16 was 8 % slower, the phases of a tile overlap less)
+constexpr int TS = 8;                       // segments per wavefront (8: 18 wavefronts per CU; 16 was 8 % slower, the phases of a tile overlap less)
 constexpr int TSLACK = 2;               // position p of a row is word TSLACK + p: the two ids of a first token fit in front of it
 constexpr int TROW = SEG + 8;           // words per tile row (16-byte multiple; the odd multiple of 8 spreads the rows over the LDS banks)
 
@@ -1012,15 +930,11 @@ __device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg&
 #pragma unroll
     for (int h = 0; h < PARTS; h++) {
       v[s][h] = make_uint4(0u, 0u, 0u, 0u);
-#if TM_NT_STREAM
       if (4u * (uint32_t)lane + 256u * h < len[s]) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 q = TM_STREAM_LOAD(reinterpret_cast<const u32x4*>(src[s] + 256 * h));
         v[s][h] = make_uint4(q.x, q.y, q.z, q.w);
       }
-#else
-      if (4u * (uint32_t)lane + 256u * h < len[s]) __builtin_memcpy(&v[s][h], src[s] + 256 * h, 16);
-#endif
     }
 #pragma unroll
   for (int s = 0; s < TS; s++)

@@ -30,19 +30,6 @@
 #pragma once
 #include <cstdint>
 
-// TM_SKIP_EDGES (build-time experiment, off in the product build until it has been timed on the device): path compression of the edge
-// hash.  55 008 of the 79 792 trie nodes of the 32 000-id shape have exactly one child, and the rounds a wavefront spends in step A1 are
-// set by its one deepest walk — a byte per round through such chains.  A hash slot becomes 16 bytes, one per bucket:
-//   x = parent << 8 | byte | 4-bit child filter of the LANDING node << 28      y = value of the child
-//   z = up to 3 bytes of the chain below the child (non-accepting nodes with one child each) | chain length L << 24
-//   w = value of the landing node (the node behind the chain; the child itself when L == 0)
-// A probe that hits compares the chain with the text in one go and advances 1 + j levels, j <= L the number of chain bytes that match.
-// Internal node ids are renumbered so that the nodes of a chain are consecutive: after a partial match the walk stands on node
-// id(child) + j, which is what the suffix link of the next position is taken from.  Model (tools/a1_sim.cpp): 26.5 -> 19.3 rounds.
-#ifndef TM_SKIP_EDGES
-#define TM_SKIP_EDGES 0
-#endif
-
 namespace tmh {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;

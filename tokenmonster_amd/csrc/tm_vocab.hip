@@ -46,11 +46,6 @@ int enter_device(const tm_vocab* v) {
   return e == hipSuccess ? TM_OK : hip_fail(e, "hipSetDevice (device of the vocabulary)");
 }
 
-// build-time experiment knob (tools/variant_ab.sh): hash insertion order by traffic (the score column) instead of by depth
-#ifndef TM_HASH_HOT_FIRST
-#define TM_HASH_HOT_FIRST 0
-#endif
-
 namespace {
 // (parent node << 8 | byte) -> child node of the trie under construction: open addressing over a flat array (the table build of a
 // candidate vocabulary is on the trainvocab worker's path, and std::unordered_map was most of its time), edges kept in creation order
@@ -107,9 +102,6 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   hv.keys.clear(); hv.key_off.assign(1, 0); hv.rows.resize(hv.n_info);
   std::vector<uint8_t> lens(hv.n_info), flags(hv.n_info), nwords(hv.n_info);
   std::vector<uint32_t> ids(hv.n_info);
-#if TM_HASH_HOT_FIRST
-  std::vector<float> rec_score(hv.n_info, 0.0f);       // the score column: the share of the training data a token covered (go :2636)
-#endif
   uint32_t prev_len = 0;
   for (uint32_t i = 0; i < hv.n_info; i++) {
     NEED(1);
@@ -123,9 +115,6 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     hv.key_off.push_back((uint32_t)hv.keys.size());
     pos += kl;
     uint32_t flag = f[pos], nw = f[pos + 1], index1 = rd24(f + pos + 2), index2 = rd24(f + pos + 5), id = rd24(f + pos + 8);
-#if TM_HASH_HOT_FIRST
-    std::memcpy(&rec_score[i], f + pos + 11, 4);
-#endif
     pos += 15;
     if (id >= hv.n_ids) return set_error(TM_E_INVALID, "record %u: id %u out of range", i, id);
     if (nw > 31) return set_error(TM_E_LIMIT, "record %u: nWords %u > 31", i, nw);
@@ -202,43 +191,6 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     }
   }
   const uint32_t n_nodes = next_internal;
-#if TM_SKIP_EDGES
-  // chains: non-accepting nodes with exactly one child.  Renumber the internal nodes so that every maximal chain has consecutive ids
-  // (tm_tables.h), then rebuild the edge map and the per-node arrays under the new ids; accepting ids (record ordinals) stay.
-  std::vector<uint32_t> only_child(n_nodes, kNone);
-  std::vector<uint8_t> only_byte(n_nodes, 0), in_chain(n_nodes, 0);
-  {
-    std::vector<uint32_t> nchild(n_nodes, 0);
-    for (auto& kv : child) { const uint32_t par = (uint32_t)(kv.first >> 8); if (par != kRoot) { nchild[par]++; only_child[par] = kv.second; only_byte[par] = (uint8_t)(kv.first & 0xFF); } }
-    for (uint32_t u = n_info; u < n_nodes; u++) in_chain[u] = nchild[u] == 1;
-    std::vector<uint32_t> R(n_nodes, kNone);
-    for (uint32_t u = 0; u < n_info; u++) R[u] = u;
-    uint32_t next_id = n_info;
-    for (uint32_t u = n_info; u < n_nodes; u++) {
-      if (!in_chain[u]) continue;
-      const uint32_t par = parent_of[u];
-      if (par != kRoot && par >= n_info && in_chain[par]) continue;          // not the head of its chain
-      for (uint32_t c = u; c != kNone && c >= n_info && in_chain[c]; c = only_child[c]) R[c] = next_id++;
-    }
-    for (uint32_t u = n_info; u < n_nodes; u++) if (R[u] == kNone) R[u] = next_id++;
-    EdgeMap child2(hv.keys.size() + 16);
-    std::vector<uint8_t> depth2(n_nodes), byte2(n_nodes), chain2(n_nodes);
-    std::vector<uint32_t> parent2(n_nodes), oc2(n_nodes, kNone);
-    for (auto& kv : child) {
-      const uint32_t par = (uint32_t)(kv.first >> 8);
-      child2.emplace(((uint64_t)(par == kRoot ? kRoot : R[par]) << 8) | (kv.first & 0xFF), R[kv.second]);
-    }
-    for (uint32_t u = 0; u < n_nodes; u++) {
-      depth2[R[u]] = depth_of[u]; byte2[R[u]] = byte_of[u]; chain2[R[u]] = in_chain[u];
-      parent2[R[u]] = parent_of[u] == kRoot ? kRoot : R[parent_of[u]];
-      oc2[R[u]] = only_child[u] == kNone ? kNone : R[only_child[u]];
-    }
-    std::vector<uint8_t> ob2(n_nodes);
-    for (uint32_t u = 0; u < n_nodes; u++) ob2[R[u]] = only_byte[u];
-    child = std::move(child2);
-    depth_of.swap(depth2); byte_of.swap(byte2); parent_of.swap(parent2); in_chain.swap(chain2); only_child.swap(oc2); only_byte.swap(ob2);
-  }
-#endif
   std::vector<uint8_t> has_child(n_nodes, 0);
   for (auto& kv : child) { uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) has_child[parent] = 1; }
   // Forward-delete hint (tm_tables.h): can the walk of ' '+key (the probe of go :1088-1095) end on something longer than
@@ -284,19 +236,13 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   size_t n_edges = 0;
   for (auto& kv : child) if (depth_of[kv.second] >= 3) n_edges++;
   uint32_t bits = 4;
-#ifndef TM_HASH_QUARTERS
-#define TM_HASH_QUARTERS 10              // slots per edge, in quarters: 2.5 (build-time experiment knob, tools/variant_ab.sh)
-#endif
-  while ((1ull << bits) < n_edges * TM_HASH_QUARTERS / 4 + 8) bits++;
+  // 2.5 slots per edge: on the device the same kernel is 5.7 % slower with half the table and 7.1 % slower with twice (the tables' L2
+  // footprint against the probe rounds, profiles/r03_k1_variants_ab.txt)
+  while ((1ull << bits) < n_edges * 10 / 4 + 8) bits++;
   // two slots per 16-byte bucket: a probe is one 16-byte gather and sees both, so at this load nearly every key sits in the
   // bucket it hashes to (the walk's "occupied by another key, try the next slot" rounds all but disappear)
-#if TM_SKIP_EDGES
-  hv.edge_mask = (1u << bits) - 1;                 // one 16-byte slot per bucket (tm_tables.h)
-  hv.edge_shift = 32 - bits;
-#else
   hv.edge_mask = (1u << (bits - 1)) - 1;           // bucket mask
   hv.edge_shift = 32 - (bits - 1);
-#endif
   // child-byte filter of every node: bit (b & 31) is set if the node has a child over byte b.  A walk only probes the edge hash
   // for a byte whose bit is set, so a probe that cannot hit (half of all positions end on one, and with linear probing it is
   // ~1.5 gathers) is almost never issued: most nodes have one child.
@@ -333,35 +279,14 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     for (int d = 0; d < 42; d++) { const uint32_t c = start[d]; start[d] = total_edges; total_edges += c; }
     std::vector<std::pair<uint64_t, uint32_t>> order(total_edges);
     for (auto& kv : child) if (depth_of[kv.second] >= 3) order[start[41 - maxd[kv.second]]++] = kv;
-#if TM_HASH_HOT_FIRST
-    // (experiment) the edges a walk crosses most often keep their home buckets instead: weight of an edge = occurrences of the tokens
-    // below it, from the score column (score = share of the data covered, so occurrences ~ score / length); deepest-first among equals
-    {
-      std::vector<float> wgt(n_nodes, 0.0f);
-      for (uint32_t i = 0; i < n_info; i++) if (rec_score[i] > 0.0f && rec_score[i] < 1e9f) wgt[i] = rec_score[i] / (float)lens[i];
-      for (size_t q = n_nodes; q-- > 0;) { const uint32_t n = by_depth[q], par = parent_of[n]; if (par != kRoot) wgt[par] += wgt[n]; }
-      std::stable_sort(order.begin(), order.end(), [&](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return wgt[a.second] > wgt[b.second]; });
-    }
-#endif
     for (auto& kv : order) {
       const uint32_t parent = (uint32_t)(kv.first >> 8), byte = (uint32_t)(kv.first & 0xFF);
       uint32_t key = (parent << 8) | byte;
-#if TM_SKIP_EDGES
-      uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;                     // home bucket, one slot each
-      while (edges[2 * (size_t)h].x != kNone) h = (h + 1) & hv.edge_mask;
-      uint32_t land = kv.second, chain = 0, L = 0;                               // up to 3 bytes of the chain below the child
-      while (L < 3 && land >= n_info && in_chain[land]) { chain |= (uint32_t)only_byte[land] << (8 * L); land = only_child[land]; L++; }
-      uint32_t f4 = 0;                                                           // 4-bit filter of the landing node
-      for (uint32_t q = 0; q < 32; q++) if ((cmask[land] >> q) & 1u) f4 |= 1u << (q & 3u);
-      edges[2 * (size_t)h] = uint2{key | (f4 << 28), value_of(kv.second)};
-      edges[2 * (size_t)h + 1] = uint2{chain | (L << 24), value_of(land)};
-#else
       uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;                     // home bucket; slot 0 fills before slot 1
       while (edges[2 * (size_t)h + 1].x != kNone) h = (h + 1) & hv.edge_mask;
       uint32_t f4 = 0;                                                           // 4-bit filter of the node the edge leads to
       for (uint32_t q = 0; q < 32; q++) if ((cmask[kv.second] >> q) & 1u) f4 |= 1u << (q & 3u);
       edges[2 * (size_t)h + (edges[2 * (size_t)h].x != kNone ? 1 : 0)] = uint2{key | (f4 << 28), value_of(kv.second)};
-#endif
     }
   }
   // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.

@@ -8,7 +8,7 @@
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-declare -A VARIANTS=( [halo]="-DTM_K1_HALO_SHARE=1" [skip]="-DTM_SKIP_EDGES=1" [halo_skip]="-DTM_K1_HALO_SHARE=1 -DTM_SKIP_EDGES=1" [dense]="-DTM_HASH_QUARTERS=5" [sparse]="-DTM_HASH_QUARTERS=20" [halo_dense]="-DTM_K1_HALO_SHARE=1 -DTM_HASH_QUARTERS=5" [nt]="-DTM_NT_STREAM=1" [nt_halo]="-DTM_NT_STREAM=1 -DTM_K1_HALO_SHARE=1" [ts4]="-DTM_TS=4" [devel]="-DTM_DEVEL" [hot]="-DTM_HASH_HOT_FIRST=1" [dense_hot]="-DTM_HASH_QUARTERS=5 -DTM_HASH_HOT_FIRST=1" )
+declare -A VARIANTS=( [devel]="-DTM_DEVEL" )   # every experiment of rounds 2-3 has been timed and either adopted or deleted (profiles/r03_k1_variants_ab.txt); add new ones here
 case "${1:-}" in
 build)
   for name in "${!VARIANTS[@]}"; do
