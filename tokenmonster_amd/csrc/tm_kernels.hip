@@ -145,20 +145,19 @@ __device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_
   return (uint32_t)sbegl | (len << D_LEN_SHIFT) | ((uint32_t)sbegc << 8) | ((uint32_t)(S + 4) << D_S_SHIFT);
 }
 
+__device__ __forceinline__ uint32_t edge_slot_offset(const Tables& T, uint32_t node, uint32_t byte) {
+  return (edge_hash(node, byte) >> T.edge_shift) << 4;     // byte offset of the home bucket (two 8-byte slots)
+}
+// child filter (tm_tables.h): can the node have a child over byte c?  32 bits in a link-format entry, 4 in the key word of a slot
+__device__ __forceinline__ bool child_possible32(uint32_t m, uint32_t c) { return ((m >> (c & 31u)) & 1u) != 0; }
+
 // one in-flight trie walk of a lane: text byte number d of the string being matched is text[tbase + d].
 // An idle slot has key == KEY_IDLE (never stored in the table) and probes the always-empty slot behind the table,
 // so it needs no flag of its own: it neither hits nor re-probes, and its bestlen of 0 keeps it from storing anything.
 struct Walk { int pos, tbase, depth, limit, bestlen; uint32_t hoff, key, bestv; };
 constexpr uint32_t KEY_IDLE = 0xFFFFFFFEu;
 __device__ __forceinline__ bool walk_idle(const Walk& k) { return k.key == KEY_IDLE; }
-__device__ __forceinline__ uint32_t edge_slot_offset(const Tables& T, uint32_t node, uint32_t byte) {
-  return (edge_hash(node, byte) >> T.edge_shift) << 4;     // byte offset of the home bucket (two 8-byte slots)
-}
-__device__ __forceinline__ uint4 load_slot(const uint2* hash_tab, uint32_t hoff) {          // a bucket: {key0, value0, key1, value1}
-  return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hash_tab) + hoff);   // scalar base + 32-bit lane offset
-}
 // child filter (tm_tables.h): can the node have a child over byte c?  32 bits in a link-format entry, 4 in the key word of a slot
-__device__ __forceinline__ bool child_possible32(uint32_t m, uint32_t c) { return ((m >> (c & 31u)) & 1u) != 0; }
 __device__ __forceinline__ bool child_possible4(uint32_t key_word, uint32_t c) { return ((key_word >> (28u + (c & 3u))) & 1u) != 0; }
 
 // consume one hash probe: follow the edge, remember the deepest accepting node, arm the next probe or stop
@@ -300,7 +299,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   WaveLds& w = s_wave[wvi];
   const int Lmax = (int)T.max_len;
   const unsigned long long lane_below = (1ull << lane) - 1ull;
-  const uint2* __restrict__ hash_tab = T.tab;
   const uint32_t idle_off = (T.edge_mask + 1u) << 4;      // the always-empty bucket behind the edge hash
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
@@ -342,6 +340,12 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 #else
   const int ntask = share ? SEG : min(NPOS, dl);       // positions >= dl keep descriptor 0 (nothing there); a shared halo is the neighbour's work
 #endif
+  // the walks of steps A1 and A3: a lane's state is its key — KEY_SET (A1: the gather is a link-format entry), KEY_IDLE_A1 (nothing to
+  // do; the gather is the always-empty bucket behind the table), anything else = the edge (parent << 8 | byte) being probed
+  constexpr uint32_t KEY_SET = ((kMaxNodes) << 8), KEY_IDLE_A1 = KEY_SET | 1u;     // parent ids no trie node has (tm_tables.h: kMaxNodes)
+  typedef unsigned long long M64;
+  const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
+  const uint32_t mask16 = T.edge_mask << 4;
   {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
     // A run is in one of two states.  SET: the gather is a link-format entry (a suffix link, or the direct map on the
@@ -350,8 +354,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     // as straight-line selects (one instruction costs about a third of a gather here, and branches cost more than the
     // work they skip); the LDS bytes a round may need — the next key byte, the first two bytes of the next position —
     // are read while the gather is in flight.
-    const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
-    const uint32_t mask16 = T.edge_mask << 4;
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
     const bool tail_here = !share && dl <= NPOS;                    // the document's last byte is one of this wavefront's positions
     const int nwalkpos = tail_here ? ntask - 1 : ntask;             // positions with at least two bytes of text left
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     const uint32_t enda = tb + (uint32_t)max(min(lane * run + run, nwalkpos), 0), dla = tb + (uint32_t)dl;
     int depth = 0, limit = 0, bestlen = 0;
     uint32_t pfa = tb, off = idle_off, key = 0u, bestv = 0u, node = 0u;
-    bool probing = false, setting = posa < enda;         // the state of the run; the compiler keeps these as lane masks
+    const bool setting = posa < enda;
     if (setting) {
       limit = min((int)(dla - posa), Lmax);
       off = T.direct_off + ((uint32_t)*TM_LDS_PTR(lds_u16u, posa) << 4);
@@ -378,50 +380,63 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     }
 #ifdef TM_DEVEL
     const bool nowalk = (dbg & 4) != 0;
-#else
-    constexpr bool nowalk = false;
 #endif
-    // The loop exists twice: when the document goes on for at least Lmax bytes behind the last position of the segment, no walk
-    // is cut short by the end of the text and `limit` is the constant Lmax (two instructions less per round).
+    // The round with its control state as explicit 64-bit lane masks (ballots) and v_cndmask selects on them.  Written this way because
+    // the scalar unit, not the vector unit, is the busier issue port of this loop (profiles/r03_k1_issue_ports.txt: one more scalar
+    // instruction per round costs 1.6 x one more vector instruction): the structured control flow the compiler builds from `if`s on
+    // per-lane booleans — save / restore of exec around every block, mask algebra for every && and || — was ~60 scalar instructions
+    // per round, the eight mask operations below are what the state machine needs.  A lane's state is its key: KEY_SET (the gather is
+    // a link-format entry), KEY_IDLE (nothing to do; it gathers the always-empty bucket), anything else = the edge being probed.
+    key = setting ? KEY_SET : KEY_IDLE_A1;
+    uint32_t v_link = T.link_off, v_direct = T.direct_off, v_idle = idle_off, v_kset = KEY_SET;
+    TM_KEEP_IN_VGPRS4(v_link, v_direct, v_idle, v_kset);          // operands of the selects: four registers for the whole loop, not four moves per round
+    const uint32_t dump0 = TM_LDS_ADDR(&w.Xb[lane]), dump1 = TM_LDS_ADDR(&w.Xb[64 + lane]);      // where the stores of a lane that has nothing to store go (Xb is not in use before step A3)
     auto rounds = [&](auto tail_tag) {
       constexpr bool TAIL = decltype(tail_tag)::value;
-      // a lane is busy exactly as long as its gather address is not the idle slot
-      while (__builtin_amdgcn_ballot_w64(off != idle_off) != 0ull) {
-        const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);     // link format {x, y, child filter, best depth}, or a hash bucket {key0 | filter, value0, key1 | filter, value1}
+      // (The loop exists twice: when the document goes on for at least Lmax bytes behind the last position of the segment, no walk is
+      // cut short by the end of the text and `limit` is the constant Lmax.)
+      for (;;) {
+        const M64 busy = __builtin_amdgcn_ballot_w64(off != idle_off);
+        if (busy == 0ull) break;
+        const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);
         uint32_t c = *TM_LDS_PTR(lds_u8, pfa);
-        uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);                // the two bytes at the next position, as the direct map indexes them
-        TM_KEEP_IN_VGPRS2(c, nn);                                        // both LDS reads are issued here, under the gather's latency
-        const bool hit1 = probing && (e.z & kKeyMask) == key;
-        const bool hit = hit1 || (probing && (e.x & kKeyMask) == key);
-        const bool again = probing && !hit && e.z != kNone;              // both slots of the bucket hold other keys: next bucket
-        const bool adv = hit || setting;                                 // the walk state is (re)set this round
-        const uint32_t hv = hit1 ? e.w : e.y, hk = hit1 ? e.z : e.x;     // the slot that hit
-        const uint32_t src = hit ? hv : e.x;                             // bits 0..20 node
-        const uint32_t nid = src & kNodeMask;
-        if (hit) depth++;
-        if (setting) { depth = (int)((e.x >> 23) & 63u); bestv = e.y; bestlen = (int)e.w; }
-        if (adv) node = nid;
-        if (hit && nid < T.n_info) { bestv = hv; bestlen = depth; }
-        // probe only for a byte the node can continue with (32-bit filter behind a link, 4 bits in the key word of a slot)
-        const bool go = adv && (setting ? child_possible32(e.z, c) : child_possible4(hk, c)) && depth < (TAIL ? limit : Lmax) && !nowalk;
-        const bool fin = (adv && !go) || (probing && !hit && !again);
-        if (go) { key = (nid << 8) | c; off = edge_slot_offset(T, nid, c); pfa = posa + (uint32_t)depth + 1u; }
-        if (again) off = (off + 16u) & mask16;
-        probing = go || again;
-        setting = false;
-        if (fin) {
-          // position done: store (no match: bestlen == 0 and the link formats give bestv == 0, so the descriptor written is the
-          // 0 that is there already), move on — through the suffix link if the walk got deep enough, else from the direct map
-          lds_u32* dp = TM_LDS_PTR(lds_u32, dconst + 4u * posa);
-          dp[0] = (uint32_t)bestlen | ((bestv >> 22) << 6);              // D[pos]
-          dp[2 * NPOS] = bestv;                                           // X[pos]
-          posa++;
-          setting = posa < enda;
-          if (TAIL) limit = min((int)(dla - posa), Lmax);
-          if (depth >= 3) { off = T.link_off + (node << 4); pfa = posa + (uint32_t)depth - 1u; }
-          else { off = T.direct_off + (nn << 4); pfa = posa + 2u; }
-          if (!setting) off = idle_off;
-        }
+        uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);
+        TM_KEEP_IN_VGPRS2(c, nn);
+        const uint32_t x0 = (e.x ^ key) & kKeyMask, x1 = (e.z ^ key) & kKeyMask;
+        const M64 hit1 = __builtin_amdgcn_ballot_w64(x1 == 0u), hitany = __builtin_amdgcn_ballot_w64(min(x0, x1) == 0u);
+        const M64 set = __builtin_amdgcn_ballot_w64(key == KEY_SET);
+        const M64 hit = hitany & ~set, adv = hitany | set;
+        const uint32_t hv = sel_mask(hit1, e.w, e.y), hk = sel_mask(hit1, e.z, e.x);
+        const uint32_t nid = sel_mask(set, e.x, hv) & kNodeMask;
+        node = sel_mask(adv, nid, node);
+        depth = (int)sel_mask(set, (e.x >> 23) & 63u, sel_mask(hit, (uint32_t)depth + 1u, (uint32_t)depth));
+        const M64 acc = hit & __builtin_amdgcn_ballot_w64(nid < T.n_info);
+        bestv = sel_mask(set, e.y, sel_mask(acc, hv, bestv));
+        bestlen = (int)sel_mask(set, e.w, sel_mask(acc, (uint32_t)depth, (uint32_t)bestlen));
+        // probe only for a byte the node can continue with: bit (c & 31) of the 32-bit filter behind a link, bit 28 + (c & 3) of the key word of a slot
+        const uint32_t fword = sel_mask(set, e.z, hk), fbit = sel_mask(set, c & 31u, 28u | (c & 3u));
+        M64 go = adv & __builtin_amdgcn_ballot_w64(((fword >> fbit) & 1u) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
+#ifdef TM_DEVEL
+        if (nowalk) go = 0ull;
+#endif
+        const M64 again = __builtin_amdgcn_ballot_w64(e.z != kNone) & ~adv;        // both slots hold other keys: next bucket (an idle lane sees the empty bucket)
+        const M64 fin = busy & ~(go | again);
+        // the position is done: store it (no match: bestlen == 0 and the link formats give bestv == 0: the 0 that is there already) ...
+        const uint32_t daddr = dconst + 4u * posa;
+        *TM_LDS_PTR(lds_u32, sel_mask(fin, daddr, dump0)) = (uint32_t)bestlen | ((bestv >> 22) << 6);      // D[pos]
+        *TM_LDS_PTR(lds_u32, sel_mask(fin, daddr + 8u * NPOS, dump1)) = bestv;                                // X[pos]
+        // ... and move on: through the suffix link if the walk got deep enough, else from the direct map
+        const uint32_t posn = posa + 1u;
+        const M64 more = __builtin_amdgcn_ballot_w64(posn < enda), deep = __builtin_amdgcn_ballot_w64(depth >= 3);
+        const uint32_t off_f = sel_mask(more, sel_mask(deep, v_link, v_direct) + (sel_mask(deep, node, nn) << 4), v_idle);
+        const uint32_t pfa_f = posn + (uint32_t)max(depth, 3) - 1u;            // depth >= 3: posn + depth - 1, else posn + 2
+        // the next gather of a walk that goes on
+        const uint32_t off_p = sel_mask(go, edge_slot_offset(T, nid, c), (off + 16u) & mask16);
+        key = sel_mask(fin, v_kset | sel_mask(more, 0u, 1u), sel_mask(go, (nid << 8) | c, key));
+        off = sel_mask(fin, off_f, sel_mask(go | again, off_p, off));
+        pfa = sel_mask(fin, pfa_f, sel_mask(go, posa + (uint32_t)depth + 1u, pfa));
+        if (TAIL) limit = (int)sel_mask(fin, (uint32_t)min((int)(dla - posn), Lmax), (uint32_t)limit);
+        posa = sel_mask(fin, posn, posa);
         PH_INC(8)
       }
     };
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         }
       }
       while (__any(!walk_idle(k))) {
-        const uint4 e = load_slot(hash_tab, k.hoff);
+        const uint4 e = *reinterpret_cast<const uint4*>(tabb + k.hoff);
         const uint32_t c = w.text[k.tbase + k.depth + 1];
         if (walk_consume(T, k, e, c) && k.bestlen > mainlen + 1) {
           const int lb = k.bestlen - off;                              // go :1093
@@ -537,6 +552,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     for (int it = 0; it < SEG / 64; it++) {
       const int p = it * 64 + lane;
       d0[it] = w.D[p];
+      row0[it] = Row{0u, 0u, 0u, 0u};
       if (p < seglen && d0[it] != 0) row0[it] = T.rows[node_id(w.X[p])];
       m1[it] = __ballot(p < seglen && w.Db[p] != 0);
       n1 += __popcll(m1[it]);
@@ -599,23 +615,24 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     uint32_t* J = reinterpret_cast<uint32_t*>(w.D) + J_SKIP;       // overlays D, Db (dead after step B): 2 x SEG words, state (p, fd) at J[fd * J_PLANE + p]
     static_assert(J_SKIP + J_PLANE + SEG <= 2 * NPOS, "J overlay does not fit");
     const bool more_text = remv > (uint64_t)seglen;       // text follows the segment: the chain leaves it into an entry state
-    // J entry: #tokens [0..15] | field [16..30] | left-the-segment [31]; the field is the LDS byte address of the entry it points
-    // at, or — once the chain has left the segment — the entry state of the next segment (0x7FFF: the state is unreachable).
-    // Composing two entries is (x & 0xFFFF) + x', and the address to read next is x >> 16.
+    // J entry: #tokens [0..JF-1] | field [JF..30] | left-the-segment [31]; the field is the LDS byte address of the entry it points
+    // at, or — once the chain has left the segment — the entry state of the next segment (JNONE: the state is unreachable).
+    // Composing two entries is (x & JCNT) + x', and the address to read next is x >> JF.
+    constexpr uint32_t JF = 12, JCNT = (1u << JF) - 1u, JNONE = (1u << (31 - JF)) - 1u;      // count: 12 bits (<= 2 ids per byte of a segment), field: 19 bits
     typedef TM_LDS_SPACE uint32_t lds_u32;
     auto ld_j = [](uint32_t a) -> uint32_t { return *TM_LDS_PTR(lds_u32, a); };
     const uint32_t jaddr = TM_LDS_ADDR(w.D) + 4u * (uint32_t)J_SKIP;
-    static_assert(sizeof(s_wave) + 2048 < 32768, "LDS addresses must fit the 15-bit field");
+    static_assert(sizeof(s_wave) + 2048 < (1u << 18), "LDS addresses must fit the field"); static_assert(2 * SEG + 2 < 4096, "id count of a segment must fit 12 bits");
     auto first_hop = [&](uint32_t r, int p, uint32_t fd) -> uint32_t {
       // at/after the end of the segment: nothing is emitted here.  At the end of the text that is the terminal state; in a byte
       // range that is followed by more text, a token of the range before may cover this whole (short, last) segment: pass through
-      if (p >= seglen) return 0x80000000u | ((more_text ? (uint32_t)((p - seglen) * 2) + fd : 0u) << 16);
-      if (r == R_INVALID) return 0x80000000u | (0x7FFFu << 16);
+      if (p >= seglen) return 0x80000000u | ((more_text ? (uint32_t)((p - seglen) * 2) + fd : 0u) << JF);
+      if (r == R_INVALID) return 0x80000000u | (JNONE << JF);
       const int pn = p + (int)((r >> 24) & 63u);
       const uint32_t fdn = (r >> 30) & 1u;
       const uint32_t nt = ((r & ID_NONE) != ID_NONE ? 1u : 0u) + fdn;          // ids this step emits: the token (unless it is "none") + the delete token
-      const uint32_t x = pn >= seglen ? 0x80000000u | ((more_text ? (uint32_t)((pn - seglen) * 2) + fdn : 0u) << 16)
-                                      : (jaddr + 4u * (fdn * (uint32_t)J_PLANE + (uint32_t)pn)) << 16;
+      const uint32_t x = pn >= seglen ? 0x80000000u | ((more_text ? (uint32_t)((pn - seglen) * 2) + fdn : 0u) << JF)
+                                      : (jaddr + 4u * (fdn * (uint32_t)J_PLANE + (uint32_t)pn)) << JF;
       return x | nt;
     };
     // every lane keeps its own 2*SEG/64 states in registers and only touches LDS for states that still point inside
@@ -642,12 +659,12 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     for (int round = 0; round < 12 && __any(any0 || any1); round++) {
       uint32_t bn[N0];
 #pragma unroll
-      for (int k = 0; k < N0; k++) if (pend[k]) bn[k] = ld_j(ja[k] >> 16);
+      for (int k = 0; k < N0; k++) if (pend[k]) bn[k] = ld_j(ja[k] >> JF);
       any0 = false;
 #pragma unroll
       for (int k = 0; k < N0; k++) {
         if (pend[k]) {
-          ja[k] = (ja[k] & 0xFFFFu) + bn[k];              // (a 16-bit count cannot overflow: <= 512 ids per segment)
+          ja[k] = (ja[k] & JCNT) + bn[k];              // (a 16-bit count cannot overflow: <= 512 ids per segment)
           J[k * 64 + lane] = ja[k];
           pend[k] = (int)ja[k] >= 0;
           any0 |= pend[k];
@@ -658,8 +675,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 #pragma unroll
         for (int k = N0; k < NS; k++) {
           if (pend[k]) {
-            const uint32_t b1 = ld_j(ja[k] >> 16);
-            ja[k] = (ja[k] & 0xFFFFu) + b1;
+            const uint32_t b1 = ld_j(ja[k] >> JF);
+            ja[k] = (ja[k] & JCNT) + b1;
             J[J_PLANE + (k - N0) * 64 + lane] = ja[k];
             pend[k] = (int)ja[k] >= 0;
             any1 |= pend[k];
@@ -673,8 +690,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     // exit map entry: next entry state [0..7] | #ids << 8; 0xFFFFFFFF: the entry state cannot occur
     for (int e = lane; e < ENT; e += 64) {
       const uint32_t a = J[(e & 1) * J_PLANE + (e >> 1)];
-      const uint32_t t = (a >> 16) & 0x7FFFu;
-      TM_STREAM_STORE(&exitmap[g * ENT + e], ((a >> 31) != 0 && t != 0x7FFFu) ? (t | ((a & 0xFFFFu) << 8)) : R_INVALID);
+      const uint32_t t = (a >> JF) & JNONE;
+      TM_STREAM_STORE(&exitmap[g * ENT + e], ((a >> 31) != 0 && t != JNONE) ? (t | ((a & JCNT) << 8)) : R_INVALID);
     }
   }
   PH(7)

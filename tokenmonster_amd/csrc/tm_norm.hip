@@ -335,20 +335,6 @@ struct PieceLds2 { uint8_t raw[PLDS]; uint8_t f[PLDS]; alignas(16) uint8_t out[2
 
 __device__ const NmLut g_norm_lut = nm_make_lut();
 
-// per-lane select on a wave-uniform lane mask: bit set -> a, else b (one v_cndmask, the mask stays in scalar registers)
-__device__ __forceinline__ uint32_t sel_mask(unsigned long long mask, uint32_t a, uint32_t b) {
-#ifdef TM_EMU
-  return ((mask >> emu::cur->lane) & 1ull) ? a : b;
-#else
-  uint32_t r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
-  return r;
-#endif
-}
-__device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask, uint32_t acc) {      // acc + #set bits of mask below the lane
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, acc));
-}
-
 __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rbegin,
                                                     const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
                                                     const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t lower_all,

@@ -15,7 +15,7 @@ constexpr int NPOS = SEG + 40;           // positions whose descriptors a segmen
 constexpr int NPOS_PAD = (NPOS + 63) / 64 * 64;
 constexpr int TEXT_LEN = SEG + 96;       // staged text: position i may read up to i + 40
 constexpr int ENT = 80;                  // entry states of a segment: 40 offsets x fd{0,1}
-constexpr int WAVES = 4;                 // wavefronts per workgroup in K1 (plain variant)
+constexpr int WAVES = 4;                 // wavefronts per workgroup in K1 (8: +14 %, the halo barrier couples more wavefronts)
 constexpr uint32_t R_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t J_EXIT = 1024;           // jump targets >= J_EXIT: left the segment; J_EXIT + next entry state
 constexpr uint32_t J_INVALID = 2047;        // state is not reachable (no forward-delete match there)
@@ -31,6 +31,20 @@ constexpr int SCAN_T = 256, SCAN_PER = 16, SCAN_CH = SCAN_T * SCAN_PER;   // exc
 constexpr uint32_t GROUP_FAN = 64;         // children per group of the tree over a long document's segments
 struct Group { uint32_t first_child, nchildren, doc, level; };   // children: segments (level 0 = leaf groups) or groups of the level below
 struct LongDoc { uint32_t doc, first_group, ngroups, pad; };
+
+// per-lane select on a wave-uniform lane mask: bit set -> a, else b (one v_cndmask, the mask stays in scalar registers)
+__device__ __forceinline__ uint32_t sel_mask(unsigned long long mask, uint32_t a, uint32_t b) {
+#ifdef TM_EMU
+  return ((mask >> emu::cur->lane) & 1ull) ? a : b;
+#else
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+  return r;
+#endif
+}
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask, uint32_t acc) {      // acc + #set bits of mask below the lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, acc));
+}
 
 }  // namespace tmh
 

@@ -8,7 +8,7 @@
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-declare -A VARIANTS=( [devel]="-DTM_DEVEL" )   # every experiment of rounds 2-3 has been timed and either adopted or deleted (profiles/r03_k1_variants_ab.txt); add new ones here
+declare -A VARIANTS=( [devel]="-DTM_DEVEL" )
 case "${1:-}" in
 build)
   for name in "${!VARIANTS[@]}"; do
