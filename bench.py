@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+# vector-instruction issue: 256 CUs x 4 SIMD-32 x 2.4 GHz, a wave64 instruction issues over 2 cycles (same guide, "Wave scheduling")
+VALU_PEAK_GINSTS = 256 * 4 * 2.4 / 2.0
 
 
 def parse():
@@ -41,12 +43,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hot-path-only", action="store_true", help="input = host-normalized bytes; time only the tokenize pipeline")
     ap.add_argument("--cpu-sample-mb", type=float, default=64.0)
-    ap.add_argument("--verify", type=int, default=64, help="documents re-checked against the oracle after timing (rank 0)")
+    ap.add_argument("--verify", type=int, default=1024, help="documents re-checked against the oracle after timing (rank 0)")
     ap.add_argument("--also-flags", default="", help="development aid: comma separated tm_debug_flags values; the same step is timed again under each "
                                                       "(kernel variants) and reported on stderr, its ids compared with the default's")
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-to-host pipeline and small-batch latency figures")
-    ap.add_argument("--measure-traffic", action="store_true", help="measure roofline.traffic in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over "
-                                                                    "tools/k1_time.py in a child process (adds about a minute); default: the figure of profiles/traffic_latest.json, labelled as static")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false",
+                    help="do not measure roofline.traffic / roofline_valu in this run (default: three rocprofv3 --pmc passes - instruction counts, FETCH_SIZE, "
+                         "WRITE_SIZE - over tools/k1_time.py in a child process, about a minute; without them the figures of profiles/traffic_latest.json are "
+                         "reported and labelled as static)")
     return ap.parse_args()
 
 
@@ -235,9 +239,13 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
         verified = n
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        offs = np.array([0, min(int(text.size), int(args.cpu_sample_mb * (1 << 20)))], dtype=np.uint64)
+        # the CPU leg walks strips of 1 MiB as the trainvocab workers do before "midway" (training/trainvocab.go:1668-1695): one unit of
+        # work per strip, so that the all-cores figure really uses the cores (one whole-buffer document is one unit of work)
+        strip = 1 << 20
+        cut = np.arange(0, int(text.size) + 1, strip, dtype=np.uint64)
+        offs = cut if int(cut[-1]) == int(text.size) else np.concatenate([cut, np.array([text.size], dtype=np.uint64)])
         cpu = cpu_baseline(img, text, offs, args.cpu_sample_mb, log)
-        cpu["sample"] += " (the reference runtime has no scoring mode: this times the identical walk, tokenize_normalized)"
+        cpu["sample"] += " (strips of 1 MiB; the reference runtime has no scoring mode: this times the identical walk, tokenize_normalized)"
     if rank == 0:
         value = all_raw * args.steps / elapsed / 1e9
         alg = float(text.size)                       # scoring pass B_alg = N per rank
@@ -279,6 +287,8 @@ def spawn_ranks(args):
 
 def main():
     args = parse()
+    if args.also_flags:
+        os.environ.setdefault("TM_TEST_HOOKS", "1")      # (the kernel-variant switches are inert unless the process is started this way)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -415,6 +425,7 @@ def main():
     # as /opt/skills/guides/MI355X_MICROARCH.md prescribes) and wrote to profiles/traffic_latest.json; null when that file is for
     # another configuration.  `traffic_source` says so in the line itself.
     traffic, traffic_source = None, None
+    valu_per_wave, salu_per_wave, waves_per_launch, insts_source = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
@@ -422,24 +433,40 @@ def main():
             if tj.get("config") == args.config and tj.get("mbytes") == args.mbytes:
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_source = "static: profiles/traffic_latest.json (%s), not measured in this run" % tj.get("measured", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE")
+                if tj.get("valu_per_wave"):
+                    valu_per_wave, salu_per_wave, waves_per_launch = tj["valu_per_wave"], tj.get("salu_per_wave"), tj.get("waves_per_launch")
+                    insts_source = "static: profiles/traffic_latest.json, not measured in this run"
         except Exception:
             traffic = None
-    if args.measure_traffic and rank == 0 and world == 1:
+    under_profiler = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")     # (no profiler inside a profiler)
+    if args.measure_traffic and rank == 0 and world == 1 and not args.hot_path_only and not under_profiler:
         # separate --pmc passes as /opt/skills/guides/MI355X_MICROARCH.md prescribes, the kernels driven without torch (tools/k1_time.py);
         # FETCH_SIZE / WRITE_SIZE are in KB, gfx950 tallies 128-byte fetches at 64 bytes (x2)
         import subprocess
         try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_profile.py"), "--fast", "--mbytes", str(args.mbytes), "--groups", "4,5",
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_profile.py"), "--fast", "--mbytes", str(args.mbytes), "--groups", "0,4,5",
                                 "--kernel", "k_match_branch", "--out", os.path.join("/tmp", "tm_bench_traffic")] + (["--extra=--config " + args.config] if args.config else []),
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, start_new_session=True)
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, start_new_session=True)
             k = list(json.loads(r.stdout.decode()).values())[0]
-            traffic = int(k["FETCH_SIZE"] * 1024 * 2 + k["WRITE_SIZE"] * 1024)
-            traffic_source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over the same kernel, configuration and size"
+            if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                traffic = int(k["FETCH_SIZE"] * 1024 * 2 + k["WRITE_SIZE"] * 1024)
+                traffic_source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; FETCH_SIZE x 2 on gfx950) over the same kernel, configuration and size"
+            if k.get("SQ_WAVES"):
+                valu_per_wave, salu_per_wave, waves_per_launch = k["SQ_INSTS_VALU"] / k["SQ_WAVES"], k["SQ_INSTS_SALU"] / k["SQ_WAVES"], k["SQ_WAVES"]
+                insts_source = "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES over the same kernel, configuration and size"
         except Exception as ex:     # noqa: BLE001
-            log("traffic measurement failed (%s): the static figure stays" % ex)
+            log("counter passes failed (%s): the static figures stay" % ex)
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms}
+    # the same kernel against the port it actually occupies: vector instructions issued per second (one wavefront = one 256-byte segment)
+    roofline_valu = None
+    if valu_per_wave:
+        gi = valu_per_wave * waves_per_launch / (acc[dom] * 1e-3) / 1e9
+        roofline_valu = {"bound": "valu_issue", "kernel": names[dom], "achieved": round(gi, 2), "peak": round(VALU_PEAK_GINSTS, 1), "unit": "G wave64 instructions/s",
+                         "frac": round(gi / VALU_PEAK_GINSTS, 4), "vector_instructions_per_segment": round(valu_per_wave, 1),
+                         "scalar_instructions_per_segment": None if salu_per_wave is None else round(salu_per_wave, 1),
+                         "vector_instructions_per_input_byte": round(valu_per_wave * waves_per_launch / float(text.size), 3), "source": insts_source}
 
     # ---- verification of a sample against the oracle (rank 0; outside the timed region) -------------------
     verified = None
@@ -521,7 +548,13 @@ def main():
                        "h2d_seconds": round(h2d_s, 3), "parallelism": "documents sharded by rank, no collective",
                        "verified_docs_vs_oracle": verified},
             "roofline": roofline,
+            "roofline_valu": roofline_valu,
             "cpu_baseline": cpu,
+            # `value` is the HBM-resident rate (the timed region starts with the raw text in HBM and ends with the ids in HBM); the rate of
+            # SURVEY 8(d)'s "first H2D to last D2H" harness (tm_tokenize_pipeline: raw UTF-8 in pinned host memory -> ids in pinned host memory,
+            # benchmark/tokenmonster_bench.go:41-55 times around the whole call) is the key below
+            "value_definition": "HBM-resident: raw UTF-8 in HBM -> uint32 ids in HBM (normalize + tokenize)",
+            "value_resident": round(value, 4),
             "value_host_to_host": None if h2h is None else h2h["pinned"]["value"],
             "host_to_host": h2h,
         }

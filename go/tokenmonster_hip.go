@@ -13,7 +13,9 @@
 //   (*Vocab).Decode over many id streams, the streaming *Decoder, Save        go/tokenmonster.go:445, :552-700, :2602
 // Every call borrows Go memory for its duration only (cgo pointer rule).  Any error means: use the existing CPU path.
 // Goroutines may call concurrently: each call takes a lane (stream + workspace) of the vocabulary and makes the
-// vocabulary's device current on whatever OS thread the goroutine is on; no runtime.LockOSThread is needed.
+// vocabulary's device current on whatever OS thread the goroutine is on.  The only per-thread state of the library is the text of
+// tm_last_error() and the 'current device' that tm_vocab_load / tm_dataset_upload use: the helper `locked` keeps a call and what
+// depends on it on one OS thread.
 package tokenmonster
 
 /*
@@ -28,6 +30,7 @@ import "C"
 import (
 	"errors"
 	"os"
+	"runtime"
 	"unsafe"
 )
 
@@ -37,12 +40,23 @@ type HipVocab struct {
 	len int // vocab.Len(): decides 2- or 4-byte ids on the server wire (tokenmonsterserver.go:350-353)
 }
 
-func hipErr() error { return errors.New("tokenmonster_hip: " + C.GoString(C.tm_last_error())) }
+// locked runs one library call and, if it failed, reads the library's THREAD-LOCAL error message on the same OS thread: between two
+// cgo calls the scheduler may move a goroutine to another thread, where tm_last_error() would be empty or somebody else's.
+// TM_E_NOSPACE is not an error for the callers below (they retry with the capacity reported).
+func locked(f func() C.int) (C.int, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	rc := f()
+	if rc != C.TM_OK && rc != C.TM_E_NOSPACE {
+		return rc, errors.New("tokenmonster_hip: " + C.GoString(C.tm_last_error()))
+	}
+	return rc, nil
+}
 
 // HipDeviceCount reports the usable gfx950 devices (0: keep using the CPU path).
 func HipDeviceCount() int { return int(C.tm_device_count()) }
 
-// LoadHip uploads the vocabulary file that Load (go/tokenmonster.go:2656) reads to the current device.
+// LoadHip uploads the vocabulary file that Load (go/tokenmonster.go:2656) reads to `device`.
 func LoadHip(filename string, device int) (*HipVocab, error) {
 	b, err := os.ReadFile(filename)
 	if err != nil {
@@ -51,12 +65,13 @@ func LoadHip(filename string, device int) (*HipVocab, error) {
 	if len(b) == 0 {
 		return nil, errors.New("tokenmonster_hip: empty vocabulary file")
 	}
-	if C.tm_set_device(C.int(device)) != C.TM_OK {
-		return nil, hipErr()
-	}
+	// (tm_set_device + tm_vocab_load would be two cgo calls, and "current device" belongs to the OS thread: the goroutine may be on
+	// another thread - another device - by the second one)
 	var h *C.tm_vocab
-	if C.tm_vocab_load((*C.uint8_t)(unsafe.Pointer(&b[0])), C.size_t(len(b)), &h) != C.TM_OK {
-		return nil, hipErr()
+	if _, err := locked(func() C.int {
+		return C.tm_vocab_load_on((*C.uint8_t)(unsafe.Pointer(&b[0])), C.size_t(len(b)), C.int(device), &h)
+	}); err != nil {
+		return nil, err
 	}
 	return &HipVocab{h: h, len: int(C.tm_vocab_size(h))}, nil
 }
@@ -96,15 +111,17 @@ func (hv *HipVocab) TokenizeSerializedBatch(docs [][]byte, encodingLength uint8)
 	var used C.uint32_t
 	for {
 		out := make([]byte, capBytes+1)
-		rc := C.tm_tokenize_pipeline(hv.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])),
-			C.uint32_t(n), 1, C.uint32_t(encodingLength), 0, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(capBytes),
-			(*C.uint64_t)(unsafe.Pointer(&byteOff[0])), (*C.uint32_t)(unsafe.Pointer(&missing[0])), &used, nil)
+		rc, err := locked(func() C.int {
+			return C.tm_tokenize_pipeline(hv.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])),
+				C.uint32_t(n), 1, C.uint32_t(encodingLength), 0, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(capBytes),
+				(*C.uint64_t)(unsafe.Pointer(&byteOff[0])), (*C.uint32_t)(unsafe.Pointer(&missing[0])), &used, nil)
+		})
+		if err != nil {
+			return nil, nil, 0, err
+		}
 		if rc == C.TM_E_NOSPACE { // the capacity required is reported in byteOff[n]
 			capBytes = byteOff[n]
 			continue
-		}
-		if rc != C.TM_OK {
-			return nil, nil, 0, hipErr()
 		}
 		res := make([][]byte, n)
 		miss := make([]int, n)
@@ -125,15 +142,17 @@ func (hv *HipVocab) TokenizeBatch(normalized [][]byte) ([][]uint32, []int, error
 	missing := make([]uint32, n+1)
 	for {
 		out := make([]uint32, capTok+1)
-		rc := C.tm_tokenize_batch(hv.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])),
-			C.uint32_t(n), (*C.uint32_t)(unsafe.Pointer(&out[0])), C.uint64_t(capTok),
-			(*C.uint64_t)(unsafe.Pointer(&tokOff[0])), (*C.uint32_t)(unsafe.Pointer(&missing[0])))
+		rc, err := locked(func() C.int {
+			return C.tm_tokenize_batch(hv.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])),
+				C.uint32_t(n), (*C.uint32_t)(unsafe.Pointer(&out[0])), C.uint64_t(capTok),
+				(*C.uint64_t)(unsafe.Pointer(&tokOff[0])), (*C.uint32_t)(unsafe.Pointer(&missing[0])))
+		})
+		if err != nil {
+			return nil, nil, err
+		}
 		if rc == C.TM_E_NOSPACE {
 			capTok = tokOff[n]
 			continue
-		}
-		if rc != C.TM_OK {
-			return nil, nil, hipErr()
 		}
 		res := make([][]uint32, n)
 		miss := make([]int, n)
@@ -150,9 +169,11 @@ func (hv *HipVocab) CountBatch(docs [][]byte) ([]int, error) {
 	n := len(docs)
 	text, offsets := pack(docs)
 	counts := make([]uint64, n+1)
-	if C.tm_count_batch_raw(hv.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])), C.uint32_t(n),
-		(*C.uint64_t)(unsafe.Pointer(&counts[0])), nil) != C.TM_OK {
-		return nil, hipErr()
+	if _, err := locked(func() C.int {
+		return C.tm_count_batch_raw(hv.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])), C.uint32_t(n),
+			(*C.uint64_t)(unsafe.Pointer(&counts[0])), nil)
+	}); err != nil {
+		return nil, err
 	}
 	res := make([]int, n)
 	for i := range res {
@@ -181,10 +202,16 @@ func (hv *HipVocab) ServerEncodingLength() uint8 {
 // HipDataset is the normalized training dataset of trainvocab, resident in HBM for the whole run (trainvocab.go:1660-1665).
 type HipDataset struct{ h *C.tm_dataset }
 
-func UploadDataset(normalized []byte) (*HipDataset, error) {
+// UploadDataset copies the dataset to `device` (named in the call: the current device of an OS thread is not a property of a goroutine).
+func UploadDataset(normalized []byte, device int) (*HipDataset, error) {
+	if len(normalized) == 0 {
+		return nil, errors.New("tokenmonster_hip: empty dataset")
+	}
 	var d *C.tm_dataset
-	if C.tm_dataset_upload((*C.uint8_t)(unsafe.Pointer(&normalized[0])), C.uint64_t(len(normalized)), &d) != C.TM_OK {
-		return nil, hipErr()
+	if _, err := locked(func() C.int {
+		return C.tm_dataset_upload_on((*C.uint8_t)(unsafe.Pointer(&normalized[0])), C.uint64_t(len(normalized)), C.int(device), &d)
+	}); err != nil {
+		return nil, err
 	}
 	return &HipDataset{d}, nil
 }
@@ -202,14 +229,16 @@ func ScoreCandidate(d *HipDataset, tokens [][]byte, capcode, charset uint8, stri
 	}
 	var img *C.uint8_t
 	var imgLen C.size_t
-	if C.tm_build_vocab((*C.uint8_t)(unsafe.Pointer(&blob[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(tokens)), nil,
-		C.uint32_t(capcode), C.uint32_t(charset), 0, 5, 0, &img, &imgLen) != C.TM_OK {
-		return nil, 0, missing, hipErr()
+	if _, err = locked(func() C.int {
+		return C.tm_build_vocab((*C.uint8_t)(unsafe.Pointer(&blob[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(tokens)), nil,
+			C.uint32_t(capcode), C.uint32_t(charset), 0, 5, 0, &img, &imgLen)
+	}); err != nil {
+		return nil, 0, missing, err
 	}
 	defer C.tm_free(unsafe.Pointer(img))
 	var cand *C.tm_vocab
-	if C.tm_vocab_load(img, imgLen, &cand) != C.TM_OK {
-		return nil, 0, missing, hipErr()
+	if _, err = locked(func() C.int { return C.tm_vocab_load_on(img, imgLen, C.tm_dataset_device(d.h), &cand) }); err != nil { // on the dataset's device
+		return nil, 0, missing, err
 	}
 	defer C.tm_vocab_free(cand)
 	scores = make([]uint32, int(C.tm_vocab_n_ids(cand))+1)
@@ -219,9 +248,11 @@ func ScoreCandidate(d *HipDataset, tokens [][]byte, capcode, charset uint8, stri
 		sl = (*C.uint64_t)(unsafe.Pointer(&stripLen[0]))
 	}
 	var tit C.uint64_t
-	if C.tm_score(cand, d.h, so, sl, C.uint32_t(len(stripOff)), (*C.uint32_t)(unsafe.Pointer(&scores[0])), &tit,
-		(*C.uint8_t)(unsafe.Pointer(&missing[0]))) != C.TM_OK {
-		return nil, 0, missing, hipErr()
+	if _, err = locked(func() C.int {
+		return C.tm_score(cand, d.h, so, sl, C.uint32_t(len(stripOff)), (*C.uint32_t)(unsafe.Pointer(&scores[0])), &tit,
+			(*C.uint8_t)(unsafe.Pointer(&missing[0])))
+	}); err != nil {
+		return nil, 0, missing, err
 	}
 	return scores[:len(scores)-1], uint64(tit), missing, nil
 }
@@ -250,14 +281,16 @@ func (hv *HipVocab) DecodeBatch(tokens [][]uint32, raw bool) ([][]byte, error) {
 	}
 	for {
 		out := make([]byte, capBytes+1)
-		rc := C.tm_decode_batch(hv.h, (*C.uint32_t)(unsafe.Pointer(&flat[0])), (*C.uint64_t)(unsafe.Pointer(&tokOff[0])), C.uint32_t(n), r,
-			(*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(capBytes), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
+		rc, err := locked(func() C.int {
+			return C.tm_decode_batch(hv.h, (*C.uint32_t)(unsafe.Pointer(&flat[0])), (*C.uint64_t)(unsafe.Pointer(&tokOff[0])), C.uint32_t(n), r,
+				(*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(capBytes), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
+		})
+		if err != nil {
+			return nil, err
+		}
 		if rc == C.TM_E_NOSPACE { // the capacity required is reported in outOff[n]
 			capBytes = outOff[n]
 			continue
-		}
-		if rc != C.TM_OK {
-			return nil, hipErr()
 		}
 		res := make([][]byte, n)
 		for i := range res {
@@ -273,8 +306,8 @@ type HipDecoder struct{ h *C.tm_decoder }
 
 func (hv *HipVocab) NewDecoder() (*HipDecoder, error) {
 	var d *C.tm_decoder
-	if C.tm_decoder_new(hv.h, &d) != C.TM_OK {
-		return nil, hipErr()
+	if _, err := locked(func() C.int { return C.tm_decoder_new(hv.h, &d) }); err != nil {
+		return nil, err
 	}
 	return &HipDecoder{d}, nil
 }
@@ -287,13 +320,17 @@ func (d *HipDecoder) Decode(tokens []uint32) ([]byte, error) {
 	}
 	out := make([]byte, len(tokens)*48+64)
 	var n C.uint64_t
-	rc := C.tm_decoder_decode(d.h, tp, C.uint64_t(len(tokens)), (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
-	if rc == C.TM_E_NOSPACE { // the ids HAVE been consumed and the text is kept: fetch it with n = 0 and a buffer of the size reported
+	rc, err := locked(func() C.int {
+		return C.tm_decoder_decode(d.h, tp, C.uint64_t(len(tokens)), (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+	})
+	if err == nil && rc == C.TM_E_NOSPACE { // the ids HAVE been consumed and the text is kept: fetch it with n = 0 and a buffer of the size reported
 		out = make([]byte, uint64(n)+1)
-		rc = C.tm_decoder_decode(d.h, nil, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+		_, err = locked(func() C.int {
+			return C.tm_decoder_decode(d.h, nil, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+		})
 	}
-	if rc != C.TM_OK {
-		return nil, hipErr()
+	if err != nil {
+		return nil, err
 	}
 	return out[:n], nil
 }
@@ -301,13 +338,17 @@ func (d *HipDecoder) Decode(tokens []uint32) ([]byte, error) {
 func (d *HipDecoder) Flush() ([]byte, error) {
 	out := make([]byte, 64)
 	var n C.uint64_t
-	rc := C.tm_decoder_flush(d.h, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
-	if rc == C.TM_E_NOSPACE { // text of an earlier call that did not fit is still held: fetch everything with a buffer of the size reported
+	rc, err := locked(func() C.int {
+		return C.tm_decoder_flush(d.h, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+	})
+	if err == nil && rc == C.TM_E_NOSPACE { // the remainder is held back (it has been moved to the pending text): fetch everything with a buffer of the size reported
 		out = make([]byte, uint64(n)+1)
-		rc = C.tm_decoder_decode(d.h, nil, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+		_, err = locked(func() C.int {
+			return C.tm_decoder_decode(d.h, nil, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(len(out)), &n)
+		})
 	}
-	if rc != C.TM_OK {
-		return nil, hipErr()
+	if err != nil {
+		return nil, err
 	}
 	return out[:n], nil
 }
@@ -317,10 +358,8 @@ func (d *HipDecoder) Flush() ([]byte, error) {
 func (hv *HipVocab) Save(filename string) error {
 	cs := C.CString(filename)
 	defer C.free(unsafe.Pointer(cs))
-	if C.tm_vocab_save(hv.h, cs) != C.TM_OK {
-		return hipErr()
-	}
-	return nil
+	_, err := locked(func() C.int { return C.tm_vocab_save(hv.h, cs) })
+	return err
 }
 
 // ---- trainvocab over several GPUs: one process (or one locked OS thread) per device, each owning a byte range of the dataset -------
@@ -333,20 +372,22 @@ func ScoreRangeBegin(cand *HipVocab, d *HipDataset, ownLen uint64, continues boo
 	if continues {
 		c = 1
 	}
-	if C.tm_score_begin(cand.h, d.h, 0, C.uint64_t(ownLen), c, nil, (*C.uint8_t)(unsafe.Pointer(&exits[0]))) != C.TM_OK {
-		return exits, hipErr()
-	}
-	return exits, nil
+	_, err = locked(func() C.int {
+		return C.tm_score_begin(cand.h, d.h, 0, C.uint64_t(ownLen), c, nil, (*C.uint8_t)(unsafe.Pointer(&exits[0])))
+	})
+	return exits, err
 }
 
 func ScoreRangeFinish(cand *HipVocab, d *HipDataset, entryState uint32) (scores []uint32, tokensInText uint64, missing [32]byte, err error) {
-	if C.tm_score_finish(cand.h, d.h, C.uint32_t(entryState), nil, nil, 0) != C.TM_OK {
-		return nil, 0, missing, hipErr()
+	if _, err = locked(func() C.int { return C.tm_score_finish(cand.h, d.h, C.uint32_t(entryState), nil, nil, 0) }); err != nil {
+		return nil, 0, missing, err
 	}
 	scores = make([]uint32, int(C.tm_vocab_n_ids(cand.h))+1)
 	var tit C.uint64_t
-	if C.tm_score_read(cand.h, d.h, (*C.uint32_t)(unsafe.Pointer(&scores[0])), &tit, (*C.uint8_t)(unsafe.Pointer(&missing[0]))) != C.TM_OK {
-		return nil, 0, missing, hipErr()
+	if _, err = locked(func() C.int {
+		return C.tm_score_read(cand.h, d.h, (*C.uint32_t)(unsafe.Pointer(&scores[0])), &tit, (*C.uint8_t)(unsafe.Pointer(&missing[0])))
+	}); err != nil {
+		return nil, 0, missing, err
 	}
 	return scores[:len(scores)-1], uint64(tit), missing, nil
 }

@@ -33,6 +33,8 @@ extern "C" {
 #define TM_E_HIP (-3)       /* a HIP runtime call failed */
 #define TM_E_NOSPACE (-4)   /* caller buffer too small; required size reported via out-params */
 #define TM_E_LIMIT (-5)     /* input exceeds a documented limit (batch bytes, trie nodes) */
+#define TM_E_INPUT (-6)     /* the walk cannot advance on this text with this vocabulary (the reference loops forever on it: a UTF-16
+                               vocabulary with one-byte keys beside the delete token); nothing is wrong with the device */
 
 #define TM_NONE 0xFFFFFFu   /* go/tokenmonster.go:32 DOES_NOT_EXIST */
 
@@ -50,6 +52,11 @@ int tm_set_device(int device);
 /* Parses the bytes of a .vocab file (layout: SURVEY.md Appendix A), builds the longest-match
  * index and per-record rows, uploads them to the current device's HBM. */
 int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out);
+/* The same on a named device: tm_set_device's "current device" belongs to the calling OS thread, which a goroutine under cgo does not own. */
+int tm_vocab_load_on(const uint8_t* vocab_file, size_t n, int device, tm_vocab** out);
+/* Batches, decoders and lanes of the vocabulary must not be used afterwards.  Kernels that an asynchronous entry point (tm_batch_run on a
+ * caller's stream, tm_score_device, tm_score_finish ...) has already launched may still be in flight: the device memory is parked for the
+ * next tm_vocab_load and is not refilled before they have finished (an event per stream the tables were used on). */
 void tm_vocab_free(tm_vocab* v);
 uint32_t tm_vocab_size(const tm_vocab* v);             /* go :2477 Len()              */
 uint32_t tm_vocab_n_info(const tm_vocab* v);           /* index records incl. "D " duplicates */
@@ -147,7 +154,9 @@ const char* tm_kernel_name(int k);
  * the product with the SAME results, so that the tests can cover it: 6 = dense T(p,1) array for every segment, 8 = per-lane
  * normalizer kernel instead of k_norm_emit2, 10 = K4 tile walk that stores every id directly (its overflow path), 12 = group tree of
  * long documents with fan-out 4 from 9 segments on, 13 = 64 KiB mailbox for the small host <-> device transfers.  Other bits are
- * ignored (a -DTM_DEVEL build, tools/ only, adds profiling bits that switch phases of the match kernel off).  0 in production. */
+ * ignored (a -DTM_DEVEL build, tools/ only, adds profiling bits that switch phases of the match kernel off).  The switches are process-wide,
+ * so they are armed only in a process started with TM_TEST_HOOKS in its environment (the test suite, bench.py --also-flags): anywhere
+ * else the call changes nothing and returns 0 - one caller of a server cannot change the code path under the others. */
 int tm_debug_flags(int flags);
 /* Totals of the last run (synchronizes the stream used by the last run). */
 int tm_batch_totals(tm_batch* b, uint64_t* total_tokens, uint64_t* total_missing);
@@ -192,6 +201,8 @@ int tm_decoder_flush(tm_decoder* d, uint8_t* out, uint64_t out_cap, uint64_t* ou
 /* ---- trainvocab scoring pass: replaces training/trainvocab.go:925-1176 ------------------------ */
 /* Upload the normalized dataset once (trainvocab.go:1660-1665 keeps it for the whole run). */
 int tm_dataset_upload(const uint8_t* normalized, uint64_t n, tm_dataset** out);
+int tm_dataset_upload_on(const uint8_t* normalized, uint64_t n, int device, tm_dataset** out);   /* on a named device */
+int tm_dataset_device(const tm_dataset* d);                                                       /* the device it lives on */
 void tm_dataset_free(tm_dataset* d);
 /* Walks each strip [strip_off[k], strip_off[k]+strip_len[k]) of the dataset exactly as the worker
  * does and accumulates scores[id] += bytes covered, scores[deleteToken] += 1 per forward-delete,

@@ -156,3 +156,53 @@ def test_small_transfers_survive_a_wrapping_mailbox(setup):
         assert (_ids_from_bytes(np.asarray(blob), enc) == ids).all()
     finally:
         N.lib.tm_debug_flags(old)
+
+
+def test_vocabulary_freed_under_an_asynchronous_pass():
+    """tm_vocab_free parks the device block of a vocabulary for the next tm_vocab_load (the trainvocab worker loads and frees one per
+    candidate).  A scoring pass launched through an asynchronous entry point may still be in flight then: the block must not be refilled
+    under its kernels.  Candidate A is scored asynchronously into a caller-owned device buffer and freed at once, candidate B (other
+    tokens, same size: it takes A's block) is loaded and scored before anybody has synchronized; A's histogram must be A's."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    from conftest import EMULATED
+    if EMULATED:
+        pytest.skip("the emulated device completes every launch at once: nothing can be in flight")
+    from tokenmonster_amd import _native as N, dist as tmdist
+    img_a = synth.synth_vocab(synth.ENGLISHCODE, 9000, capcode=2, norm_flag=1, level=5, seed=0x41414141)
+    img_b = synth.synth_vocab(synth.ENGLISHCODE, 9000, capcode=2, norm_flag=1, level=5, seed=0x42424242)
+    raw, roffs = synth.synth_corpus(synth.ENGLISHCODE, 48 << 20, seed=72)
+    text, _ = synth.normalize_batch(raw, roffs, 2, 1)
+    ds = C.c_void_p()
+    N.check(N.lib.tm_dataset_upload(N.ptr(np.ascontiguousarray(text)), int(text.size), C.byref(ds)))
+    try:
+        stream = torch.cuda.Stream()
+        for trial in range(3):
+            a, b = tm.Vocab(img_a), tm.Vocab(img_b)
+            wa, wb = a.n_ids() + 260, b.n_ids() + 260
+            b.close()                                       # a parked block of B's size is waiting
+            hist_a = torch.zeros(wa, dtype=torch.int32, device="cuda")
+            N.check(N.lib.tm_score_device_into(a.handle, ds, None, None, 0, C.c_void_p(stream.cuda_stream), C.c_void_p(hist_a.data_ptr()), wa))
+            a.close()                                       # kernels of the pass may still be running
+            b2 = tm.Vocab(img_b)                            # takes a parked block - A's, if nothing protects it
+            hist_b = torch.zeros(wb, dtype=torch.int32, device="cuda")
+            N.check(N.lib.tm_score_device_into(b2.handle, ds, None, None, 0, C.c_void_p(stream.cuda_stream), C.c_void_p(hist_b.data_ptr()), wb))
+            torch.cuda.synchronize()
+            if trial == 0:
+                orc_a, orc_b = Oracle(img_a), Oracle(img_b)
+                n = 2 << 20                                  # the oracle walks 15 MB/s: pin the head, compare the whole with a second, synchronous pass
+                exp_a = orc_a.score(text[:n])
+                so, sl = np.array([0], dtype=np.uint64), np.array([n], dtype=np.uint64)
+                ref_a = tm.Vocab(img_a)
+                got = np.zeros(ref_a.n_ids(), dtype=np.uint32)
+                tit = C.c_uint64()
+                ms = np.zeros(32, dtype=np.uint8)
+                N.check(N.lib.tm_score(ref_a.handle, ds, N.ptr(so), N.ptr(sl), 1, N.ptr(got), C.byref(tit), N.ptr(ms)))
+                assert (got == exp_a[0]).all() and tit.value == exp_a[1]
+                full_a = np.zeros(ref_a.n_ids(), dtype=np.uint32)
+                N.check(N.lib.tm_score(ref_a.handle, ds, None, None, 0, N.ptr(full_a), C.byref(tit), N.ptr(ms)))
+                full_a_tokens = tit.value
+            sa, ta, _ = tmdist.decode_histogram(hist_a.cpu().numpy(), wa - 260)
+            assert ta == full_a_tokens and (sa == full_a).all(), "trial %d: the histogram of the freed vocabulary is not its own" % trial
+    finally:
+        N.lib.tm_dataset_free(ds)

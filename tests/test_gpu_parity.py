@@ -412,7 +412,7 @@ def test_utf16_cut_character_ends_the_walk_with_an_error():
     ' ' 0x00 (tokenmonster.cpp:1790-1797: length1b -= lilbuf_offset), which for such keys is not positive: the walk stops advancing,
     and the reference runtime — and the oracle, which restates it — loop forever (the same vocabulary hangs them on some texts of whole
     characters too).  The device pipeline cannot loop: a state that never leaves its segment has no exit-map entry, and the call
-    returns TM_E_HIP.  Found by differential fuzzing on the emulated device; invalid input for the reference's callers."""
+    returns TM_E_INPUT.  Found by differential fuzzing on the emulated device; invalid input for the reference's callers."""
     from tokenmonster_amd import _native as N
     rng = np.random.default_rng(913)
     toks8 = fuzz_vocab_tokens(rng, 2, 100)
@@ -427,7 +427,7 @@ def test_utf16_cut_character_ends_the_walk_with_an_error():
     v = tm.Vocab(img)
     with pytest.raises(N.TokenMonsterHipError) as e:
         v.tokenize_packed(*tm.pack_documents([bad[0]]))
-    assert e.value.code == N.TM_E_HIP
+    assert e.value.code == N.TM_E_INPUT
     ids, _, _ = v.tokenize_packed(*tm.pack_documents([bad[0][:-1], bad[0] + b"\x00"]))      # whole characters either side of it: fine
     assert ids.size > 0
 
@@ -500,13 +500,15 @@ def test_decode_matches_reference_and_round_trips():
     assert v.decode_packed(weird, np.array([0, 0, 4], dtype=np.uint64), raw=True)[0].tobytes() == orc.decode_raw(np.array([5, 6], dtype=np.uint32))
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("name,mbytes", [("englishcode-32000-consistent", 256), ("englishcode-100256-clean", 64), ("code-4096-balanced-nocapcode", 64),
+                                         ("english-24000-consistent", 64)])
+def test_full_size_properties(name, mbytes):
     """BASELINE-size shapes cannot be re-walked by the oracle in seconds; check size-independent properties instead:
-    batch-split invariance, decode round trip, a random sample against the oracle, end-to-end == host-normalized path."""
-    name = "englishcode-32000-consistent"
+    batch-split invariance, decode round trip, a random sample against the oracle, end-to-end == host-normalized path.
+    Every named vocabulary shape of BASELINE.json: the bench shape at 256 MiB, the others at 64 MiB."""
     kind, size, capcode, norm_flag, level, seed = synth.CONFIGS[name]
     v, orc = tm.Vocab(synth.config_vocab(name)), Oracle(synth.config_vocab(name))
-    raw, offs = synth.synth_corpus(kind, (4 << 20) if EMULATED else (256 << 20), seed=0x434F5250 + 77)   # (the emulation leg runs ~1 MiB/s)
+    raw, offs = synth.synth_corpus(kind, ((4 if mbytes > 64 else 1) << 20) if EMULATED else (mbytes << 20), seed=0x434F5250 + 77)   # (the emulation leg runs ~1 MiB/s)
     text, noff = synth.normalize_batch(raw, offs, capcode, norm_flag)
     nd = noff.size - 1
     ids, toff, missing = v.tokenize_packed(text, noff)

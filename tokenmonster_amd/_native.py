@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtokenmonster_hip.so")
 
-TM_OK, TM_E_INVALID, TM_E_NODEVICE, TM_E_HIP, TM_E_NOSPACE, TM_E_LIMIT = 0, -1, -2, -3, -4, -5
+TM_OK, TM_E_INVALID, TM_E_NODEVICE, TM_E_HIP, TM_E_NOSPACE, TM_E_LIMIT, TM_E_INPUT = 0, -1, -2, -3, -4, -5, -6
 TM_NONE = 0xFFFFFF
 TM_NUM_KERNELS = 5
 KIND_ENGLISH, KIND_ENGLISHCODE, KIND_CODE = 0, 1, 2
@@ -27,6 +27,7 @@ SIGNATURES = {
     "tm_device_count": (C.c_int, []),
     "tm_set_device": (C.c_int, [C.c_int]),
     "tm_vocab_load": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "tm_vocab_load_on": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(vp)]),
     "tm_vocab_free": (None, [vp]),
     "tm_vocab_size": (C.c_uint32, [vp]),
     "tm_vocab_n_info": (C.c_uint32, [vp]),
@@ -71,6 +72,8 @@ SIGNATURES = {
     "tm_decoder_decode_serialized": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_uint64, u64p]),
     "tm_decoder_flush": (C.c_int, [vp, vp, C.c_uint64, u64p]),
     "tm_dataset_upload": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
+    "tm_dataset_upload_on": (C.c_int, [vp, C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "tm_dataset_device": (C.c_int, [vp]),
     "tm_dataset_free": (None, [vp]),
     "tm_score": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, u64p, vp]),
     "tm_score_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.POINTER(vp), u64p]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "tokenmonster_hip.h"
@@ -93,4 +94,9 @@ struct tm_vocab {
   tmh::Row* d_rows = nullptr;
   uint8_t* d_begin_byte = nullptr;
   mutable tmh::LanePool* pool = nullptr;   // created on first use; the tables themselves are immutable
+  // streams that kernels reading the tables have been launched on (note_table_use): tm_vocab_free parks the device block for the next
+  // load, and the block must not be refilled while such a kernel is still in flight
+  mutable std::mutex use_mu;
+  mutable std::vector<hipStream_t> used_streams;
 };
+namespace tmh { void note_table_use(const tm_vocab* v, hipStream_t st); }

@@ -275,7 +275,7 @@ static int count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* o
     if (rc == TM_OK) rc = small_d2h(b, ev.data(), b->d_doc_events, (uint64_t)ndocs * 4, l->stream);
     if (rc == TM_OK && missing) rc = small_d2h(b, missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream);
     if (rc == TM_OK) rc = small_sync(b, l->stream); else (void)small_sync(b, l->stream);
-    if (rc == TM_OK && err) rc = set_error(TM_E_HIP, "device pipeline inconsistency");
+    if (rc == TM_OK && err) rc = set_error(TM_E_INPUT, "the walk does not advance on this text (a vocabulary / text combination the reference does not terminate on: e.g. one-byte keys beside the delete token in a UTF-16 vocabulary)");
     if (rc == TM_OK && counts) for (uint32_t d = 0; d < ndocs; d++) counts[d] = ev[d];
   }
   lane_release(v, l);

@@ -1152,6 +1152,9 @@ constexpr int kDebugMask = 64 | 256 | 1024 | 4096 | 8192;
 #define TM_K1_EXTRA_LDS 0
 #endif
 int g_debug_flags = -1;
+// The hooks are armed only in a process that was started with TM_TEST_HOOKS in its environment (the test suite's conftest, bench.py
+// --also-flags): in any other process tm_debug_flags() is inert, so that no caller of a server can change the code path under the others.
+static bool hooks_armed() { static const bool armed = getenv("TM_TEST_HOOKS") != nullptr; return armed; }
 int debug_flags() {
   if (g_debug_flags < 0) {
 #ifdef TM_DEVEL
@@ -1337,6 +1340,7 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   }
   mark(1);
   if (nseg > 0)
+    note_table_use(v, st);
     TM_LAUNCH(k_match_branch, (uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st, v->tables, b->d_text, b->d_doc_begin, b->d_doc_end,
                                                                                           b->d_doc_vis ? b->d_doc_vis : b->d_doc_end, b->d_seg_doc,
                                                                                           b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
@@ -1480,7 +1484,7 @@ int ensure_output(tm_batch* b) {
     if (rc == TM_OK) rc = small_d2h(b, &err, b->d_error, 4, b->last_stream);
     if (rc == TM_OK) rc = small_sync(b, b->last_stream);
     if (rc != TM_OK) return rc; }
-  if (err != 0) return set_error(TM_E_HIP, "device pipeline inconsistency (unreachable segment entry state)");
+  if (err != 0) return set_error(TM_E_INPUT, "the walk does not advance on this text (a vocabulary / text combination the reference does not terminate on: e.g. one-byte keys beside the delete token in a UTF-16 vocabulary)");
   uint64_t total = b->ndocs ? totals[1] : 0;
   if (total > b->out_cap) {
     (void)hipFree(b->d_out);
@@ -1503,7 +1507,7 @@ const char* tm_kernel_name(int k) { return k >= 0 && k < TM_NUM_KERNELS ? kKerne
 
 int tm_debug_flags(int flags) {
   const int old = tmh::debug_flags();
-  if (flags >= 0) tmh::g_debug_flags = flags & tmh::kDebugMask;
+  if (flags >= 0 && tmh::hooks_armed()) tmh::g_debug_flags = flags & tmh::kDebugMask;
   return old;
 }
 

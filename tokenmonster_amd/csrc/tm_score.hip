@@ -143,6 +143,12 @@ static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off
 
 extern "C" {
 
+int tm_dataset_upload_on(const uint8_t* normalized, uint64_t n, int device, tm_dataset** out) {
+  const int rc = tm_set_device(device);
+  return rc == TM_OK ? tm_dataset_upload(normalized, n, out) : rc;
+}
+int tm_dataset_device(const tm_dataset* d) { return d ? d->device : -1; }
+
 int tm_dataset_upload(const uint8_t* normalized, uint64_t n, tm_dataset** out) {
   if (!out || (n && !normalized)) return set_error(TM_E_INVALID, "null argument");
   auto* d = new tm_dataset();
@@ -231,7 +237,7 @@ int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* 
     if (rc == TM_OK) rc = small_sync(d->ws, st);
     if (rc != TM_OK) return rc;
   }
-  if (err) return set_error(TM_E_HIP, "device pipeline inconsistency (unreachable segment entry state)");
+  if (err) return set_error(TM_E_INPUT, "the walk does not advance on this text (a vocabulary / text combination the reference does not terminate on: e.g. one-byte keys beside the delete token in a UTF-16 vocabulary)");
   const uint32_t n_ids = v->host.n_ids;
   if (scores) std::memcpy(scores, h.data(), (size_t)n_ids * 4);
   if (tokens_in_text) {

@@ -38,6 +38,12 @@ int hip_fail(hipError_t e, const char* what) {
   return set_error(TM_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
+void note_table_use(const tm_vocab* v, hipStream_t st) {
+  std::lock_guard<std::mutex> g(v->use_mu);
+  for (hipStream_t s : v->used_streams) if (s == st) return;
+  v->used_streams.push_back(st);
+}
+
 int enter_device(const tm_vocab* v) {
   if (!v) return set_error(TM_E_INVALID, "null argument");
   int cur = -1;
@@ -390,9 +396,13 @@ namespace {
 // scores: hipMalloc / hipFree per table would synchronize the device under the other workers' scoring passes, and a pageable
 // hipMemcpy would queue as a copy kernel behind them.  A vocabulary therefore lives in ONE device block, filled by ONE asynchronous
 // copy from a pinned staging block on a copy-only stream; freed blocks of both kinds are kept for the next load (bounded).
+// A parked device block may still be read by kernels that were in flight when its vocabulary was freed (the asynchronous entry points
+// return before their kernels have run): it carries one event per stream the tables were used on, and the loader that takes the block
+// waits for them before the copy that refills it.
+struct Parked { void* p; std::vector<hipEvent_t> pending; };
 struct BlockCache {
   std::mutex mu;
-  std::multimap<size_t, void*> dev_free, host_free;
+  std::multimap<size_t, Parked> dev_free, host_free;
   size_t dev_cached = 0, host_cached = 0;
   hipStream_t stream = nullptr;
 };
@@ -409,10 +419,11 @@ void* block_get(int device, bool host, size_t bytes, size_t* got, hipError_t* er
     auto& fl = host ? c.host_free : c.dev_free;
     auto it = fl.lower_bound(bytes);
     if (it != fl.end() && it->first <= 2 * bytes + (4u << 20)) {
-      void* p = it->second; *got = it->first;
+      Parked pk = std::move(it->second); *got = it->first;
       (host ? c.host_cached : c.dev_cached) -= it->first;
       fl.erase(it);
-      return p;
+      for (hipEvent_t ev : pk.pending) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }     // (outside of nothing: a handful of events, almost always complete)
+      return pk.p;
     }
   }
   void* p = nullptr;
@@ -420,21 +431,28 @@ void* block_get(int device, bool host, size_t bytes, size_t* got, hipError_t* er
   *err = host ? hipHostMalloc(&p, *got, hipHostMallocDefault) : hipMalloc(&p, *got);
   return *err == hipSuccess ? p : nullptr;
 }
-void block_put(int device, bool host, void* p, size_t bytes) {
+void block_put(int device, bool host, void* p, size_t bytes, std::vector<hipEvent_t> pending = {}) {
   if (!p) return;
   BlockCache& c = cache_of(device);
   {
     std::lock_guard<std::mutex> g(c.mu);
     size_t& cached = host ? c.host_cached : c.dev_cached;
     if (cached + bytes <= (host ? kHostCacheMax : kDevCacheMax)) {
-      (host ? c.host_free : c.dev_free).emplace(bytes, p);
+      (host ? c.host_free : c.dev_free).emplace(bytes, Parked{p, std::move(pending)});
       cached += bytes;
       return;
     }
   }
-  if (host) (void)hipHostFree(p); else (void)hipFree(p);
+  for (hipEvent_t ev : pending) (void)hipEventDestroy(ev);
+  if (host) (void)hipHostFree(p); else (void)hipFree(p);      // (hipFree waits for the device)
 }
 }  // namespace
+
+// "current device" is a property of the calling OS thread; a caller whose threads are not its own (a goroutine under cgo) names the device
+int tm_vocab_load_on(const uint8_t* vocab_file, size_t n, int device, tm_vocab** out) {
+  const int rc = tm_set_device(device);
+  return rc == TM_OK ? tm_vocab_load(vocab_file, n, out) : rc;
+}
 
 int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   if (!vocab_file || !out) return set_error(TM_E_INVALID, "null argument");
@@ -489,8 +507,19 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
 
 void tm_vocab_free(tm_vocab* v) {
   if (!v) return;
+  { int cur = -1; (void)hipGetDevice(&cur); if (cur != v->device) (void)hipSetDevice(v->device); }
+  // one event behind everything that has been launched on the streams the tables were used on (before the lanes' own streams go)
+  std::vector<hipEvent_t> pending;
+  if (v->d_block) {
+    std::lock_guard<std::mutex> g(v->use_mu);
+    for (hipStream_t st : v->used_streams) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) continue;
+      if (hipEventRecord(ev, st) == hipSuccess) pending.push_back(ev); else { (void)hipGetLastError(); (void)hipEventDestroy(ev); }    // (a stream its owner has destroyed: nothing left on it)
+    }
+  }
   tmh::pool_destroy(v->pool);
-  if (v->d_block) { int cur = -1; (void)hipGetDevice(&cur); if (cur != v->device) (void)hipSetDevice(v->device); block_put(v->device, false, v->d_block, v->block_bytes); }
+  if (v->d_block) block_put(v->device, false, v->d_block, v->block_bytes, std::move(pending));
   delete v;
 }
 
