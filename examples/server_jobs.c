@@ -43,6 +43,7 @@ static uint32_t g_nvocabs;
 #define MAX_DECODERS 256
 static tm_decoder* g_decoders[MAX_DECODERS];
 static int g_dec_used[MAX_DECODERS];   /* 0 never used, 1 live, 2 unloaded */
+static uint32_t g_dec_vocab[MAX_DECODERS];   /* the vocabulary slot a decoder was made from */
 static uint32_t g_ndecoders;
 
 /* payload { u32 n, n x { u64 len, bytes } } -> packed text + offsets; returns 0 on a malformed payload */
@@ -122,7 +123,13 @@ int main(void) {
       }
       send9(status, status == HEADER_IS_ID ? slot : 0);
     } else if (job == 11) {                                        /* unload (:525-535) */
-      if (id < g_nvocabs && g_used[id] == 1) { tm_vocab_free(g_vocabs[id]); g_vocabs[id] = NULL; g_used[id] = 2; send9(HEADER_IS_EMPTY, 0); }
+      if (id < g_nvocabs && g_used[id] == 1) {
+        /* a decoder keeps a pointer to its vocabulary (in the reference the Decoder keeps the Vocab alive through the GC): the decoders of
+         * an unloaded vocabulary are unloaded with it, later jobs 7-9 on them answer ERROR_ID_IS_UNLOADED */
+        for (uint32_t k = 0; k < g_ndecoders; k++)
+          if (g_dec_used[k] == 1 && g_dec_vocab[k] == id) { tm_decoder_free(g_decoders[k]); g_decoders[k] = NULL; g_dec_used[k] = 2; }
+        tm_vocab_free(g_vocabs[id]); g_vocabs[id] = NULL; g_used[id] = 2; send9(HEADER_IS_EMPTY, 0);
+      }
       else send9(ERROR_ID_DOES_NOT_EXIST, 0);
     } else if (job == 12) {                                        /* save (:537-554) */
       if (id >= g_nvocabs) send9(ERROR_ID_DOES_NOT_EXIST, 0);
@@ -145,7 +152,7 @@ int main(void) {
         tm_decoder* d = NULL;
         for (slot = 0; slot < g_ndecoders && g_dec_used[slot] != 2; slot++) {}     /* reuse an unloaded slot like deletedDecoders */
         if (slot >= MAX_DECODERS || tm_decoder_new(g_vocabs[id], &d) != TM_OK) send9(ERROR_INVALID_JOB, 0);
-        else { g_decoders[slot] = d; g_dec_used[slot] = 1; if (slot == g_ndecoders) g_ndecoders++; send9(HEADER_IS_ID, slot); }
+        else { g_decoders[slot] = d; g_dec_used[slot] = 1; g_dec_vocab[slot] = (uint32_t)id; if (slot == g_ndecoders) g_ndecoders++; send9(HEADER_IS_ID, slot); }
       }
     } else if (job == 6) {                                         /* unload decoder (:473-482; the reference answers 4 for an unknown id) */
       if (id >= g_ndecoders) send9(4, 0);

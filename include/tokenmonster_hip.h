@@ -233,7 +233,10 @@ int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
  *   tm_score_finish  completes the pass from that entry state: histogram exactly as tm_score_device[_into] leaves it (dst_device may be
  *                    NULL).  A token that begins inside the range is counted by this rank even if it ends in the halo.
  * Summed over the ranks (one all-reduce) the histograms equal tm_score of the whole dataset as one strip, bit for bit.
- * tm_score_read copies the histogram of the last pass to the host in tm_score's form. */
+ * tm_score_read copies the histogram of the last pass to the host in tm_score's form.
+ * continues: 0 = the text ends with the range; 1 = more text follows and the dataset holds >= 128 bytes of it behind the range (fewer:
+ * TM_E_INVALID - the exit states would silently differ from the whole-buffer walk's); 2 = text follows and ALL of it is in the dataset
+ * (it ends inside the halo).  One caller per dataset between the two halves of a pass. */
 int tm_score_begin(const tm_vocab* v, tm_dataset* d, uint64_t off, uint64_t len, int continues, void* stream, uint8_t* exits);
 int tm_score_finish(const tm_vocab* v, tm_dataset* d, uint32_t entry_state, void* stream, uint32_t* dst_device, uint64_t dst_words);
 int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]);

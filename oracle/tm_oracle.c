@@ -182,7 +182,7 @@ static long long walk_range(const tmo_vocab* v, const uint8_t* src, size_t n, si
   memset(lil, 0, sizeof lil);
   lil[0] = 32;                                    /* go :1030 */
 
-  int i = (int)start, fd = 0;
+  int i = (int)start, fd = (fd0 && start >= stop) ? 1 : 0;     /* (a range that is skipped whole hands its entry state on unchanged) */
   const int stopi = (int)stop;
   uint32_t index = 0, length = 0;
   if (fd0 && i < stopi) {

@@ -264,7 +264,7 @@ def test_score_ranges_of_one_walk(shape):
         ds = C.c_void_p()
         N.check(N.lib.tm_dataset_upload(N.ptr(np.ascontiguousarray(own)), own.size, C.byref(ds)))
         handles.append(ds)
-        eng = tmdist.HipRange(v, ds, b - a, continues=b < data.size)
+        eng = tmdist.HipRange(v, ds, b - a, continues=b < data.size, text_ends_in_halo=data.size - b < tmdist.HALO)
         ex = eng.begin()
         # the device's exit map agrees with the oracle's range walk on every entry state the walk can be in
         for e in (0, 2, 7, 21):

@@ -199,8 +199,13 @@ int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
 }
 
 int tm_score_begin(const tm_vocab* v, tm_dataset* d, uint64_t off, uint64_t len, int continues, void* stream, uint8_t* exits) {
-  if (!exits) return set_error(TM_E_INVALID, "null argument");
-  if (continues && len < 64 && off + len < (d ? d->n : 0)) return set_error(TM_E_INVALID, "a byte range that is followed by more text must be at least 64 bytes long");
+  if (!exits || !d) return set_error(TM_E_INVALID, "null argument");
+  if (off > d->n || len > d->n - off) return set_error(TM_E_INVALID, "byte range [%llu, +%llu) outside the dataset of %llu bytes", (unsigned long long)off, (unsigned long long)len, (unsigned long long)d->n);
+  if (continues && len < 64) return set_error(TM_E_INVALID, "a byte range that is followed by more text must be at least 64 bytes long");
+  // tokens that begin in the range may end behind it, and the look-ahead of the last ones reaches further still: without the halo the match
+  // kernel would take the text to end early and the exit states would silently differ from the whole-buffer walk's
+  if (continues == 1 && d->n - (off + len) < 128) return set_error(TM_E_INVALID, "a byte range that is followed by more text needs >= 128 bytes of it behind the range (the dataset holds %llu; continues = 2 if that is all the text there is)", (unsigned long long)(d->n - (off + len)));
+  std::lock_guard<std::mutex> g(d->mu);      // (the two halves of a pass are two calls: one caller per dataset between them; the lock keeps a concurrent tm_score out of each half)
   hipStream_t st = (hipStream_t)stream;
   int rc = score_prepare(v, d, &off, &len, 1, continues != 0, st);
   if (rc != TM_OK) return rc;
@@ -217,6 +222,7 @@ int tm_score_finish(const tm_vocab* v, tm_dataset* d, uint32_t entry_state, void
   if (!v || !d) return set_error(TM_E_INVALID, "null argument");
   if (entry_state >= (uint32_t)ENT) return set_error(TM_E_INVALID, "entry state %u out of range", entry_state);
   const uint8_t es = (uint8_t)entry_state;
+  std::lock_guard<std::mutex> g(d->mu);
   int rc = score_complete(v, d, &es, (hipStream_t)stream);
   if (rc != TM_OK || !dst_device) return rc;
   if (dst_words < d->hist_words) return set_error(TM_E_NOSPACE, "destination holds %llu words, histogram has %llu", (unsigned long long)dst_words, (unsigned long long)d->hist_words);

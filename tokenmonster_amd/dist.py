@@ -123,15 +123,16 @@ class HipRange:
     """engine for score_ranges_exact on this rank's GPU.  `dataset` holds the rank's bytes followed by the halo; the range is
     [0, own_len) of it."""
 
-    def __init__(self, vocab, dataset, own_len, continues, stream=None, dst=None, dst_words=0):
-        self.vocab, self.ds, self.own_len, self.continues = vocab, dataset, int(own_len), bool(continues)
+    def __init__(self, vocab, dataset, own_len, continues, stream=None, dst=None, dst_words=0, text_ends_in_halo=False):
+        """continues: text follows the range (the dataset then holds >= HALO bytes of it; text_ends_in_halo: or fewer, and they are all there is)"""
+        self.vocab, self.ds, self.own_len, self.continues = vocab, dataset, int(own_len), (2 if text_ends_in_halo else 1) if continues else 0
         self.stream, self.dst, self.dst_words = stream, dst, dst_words
 
     def begin(self):
         import ctypes as C
         from . import _native as N
         ex = np.zeros(ENTRY_STATES, dtype=np.uint8)
-        N.check(N.lib.tm_score_begin(self.vocab.handle, self.ds, 0, self.own_len, 1 if self.continues else 0, C.c_void_p(self.stream or 0), N.ptr(ex)))
+        N.check(N.lib.tm_score_begin(self.vocab.handle, self.ds, 0, self.own_len, self.continues, C.c_void_p(self.stream or 0), N.ptr(ex)))
         return ex
 
     def finish(self, entry):

@@ -273,7 +273,11 @@ class Decoder:
     def flush(self):
         n = C.c_uint64()
         out = np.empty(64, dtype=np.uint8)
-        N.check(N.lib.tm_decoder_flush(self._h, N.ptr(out), out.size, C.byref(n)))
+        rc = N.lib.tm_decoder_flush(self._h, N.ptr(out), out.size, C.byref(n))
+        if rc == N.TM_E_NOSPACE:         # the remainder (a run of continuation bytes can be long) has been kept: fetch it with a buffer of the reported size
+            out = np.empty(int(n.value), dtype=np.uint8)
+            rc = N.lib.tm_decoder_decode(self._h, None, 0, N.ptr(out), out.size, C.byref(n))
+        N.check(rc)
         return out[: int(n.value)].tobytes()
 
 
