@@ -58,6 +58,23 @@ int tm_vocab_load_on(const uint8_t* vocab_file, size_t n, int device, tm_vocab**
  * caller's stream, tm_score_device, tm_score_finish ...) has already launched may still be in flight: the device memory is parked for the
  * next tm_vocab_load and is not refilled before they have finished (an event per stream the tables were used on). */
 void tm_vocab_free(tm_vocab* v);
+/* The device block of a vocabulary from process to process (the data-parallel scoring mode: ONE rank builds a candidate's tables, the others
+ * take the finished block - e.g. as the destination of an RCCL broadcast - instead of repeating tm_build_vocab + tm_vocab_load).
+ * tm_vocab_block_export describes the block of `v` (plain data: send it as bytes) and returns its device pointer; tm_vocab_block_import makes
+ * an empty vocabulary of that shape on `device` and returns the device pointer the caller has to fill with the exporter's `bytes` bytes
+ * before the first use.  An imported vocabulary tokenizes, counts, scores and decodes on the device; it has no host tables (tm_vocab_image /
+ * tm_vocab_save fail, documents that need the host decoder fail). */
+typedef struct tm_vocab_block {
+  uint64_t bytes;            /* size of the device block */
+  uint64_t part_bytes[8];    /* root, walk tables, rows, space-prefix links, node values, reverse offsets, reverse bytes, begin_byte */
+  uint32_t edge_mask, edge_shift, n_info, max_len, off, bstart, spl_hint, link_off, direct_off, delete_id, unk_id;
+  uint32_t n_ids, vocab_size, capcode, charset, norm_flag, level, reserve, n_nodes, pad;
+} tm_vocab_block;
+int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* meta, void** device_ptr);
+int tm_vocab_block_import(const tm_vocab_block* meta, int device, tm_vocab** out, void** device_ptr);
+/* Synchronous device-to-device copy (also between two devices of the node with peer access), for callers that have no HIP binding of
+ * their own: e.g. to fill an imported block from the exporter's pointer inside one process. */
+int tm_device_copy(void* dst_device, const void* src_device, uint64_t bytes);
 uint32_t tm_vocab_size(const tm_vocab* v);             /* go :2477 Len()              */
 uint32_t tm_vocab_n_info(const tm_vocab* v);           /* index records incl. "D " duplicates */
 uint32_t tm_vocab_n_ids(const tm_vocab* v);            /* len(reverse) = highest ID + 1 */

@@ -3,7 +3,8 @@
 what bench.py --workload score --gpus N does, with gloo standing in for RCCL so that it runs on a one-GPU box (the ranks share
 device 0) and, on the emulated device (TM_EMU=1, tools/emu), on none.  Every rank is given its own byte range only; it fetches the
 halo from its neighbour (dist.exchange_halo), runs tm_score_begin, all-gathers the 80 exit states, finishes from its true entry
-state (dist.score_ranges_exact with the HipRange engine) and all-reduces the histogram words.  The result must equal the oracle's
+state (dist.score_ranges_exact with the HipRange engine) and all-reduces the histogram words.  Only rank 0 builds the vocabulary's
+tables: the others receive its device block (dist.broadcast_vocab).  The result must equal the oracle's
 ONE walk over the whole buffer (training/trainvocab.go:909-922)."""
 import os
 import socket
@@ -40,7 +41,8 @@ def _rank(rank, world, port, img, data, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         N.check(N.lib.tm_set_device(0))
-        v = tm.Vocab(img)
+        # ONE rank turns the candidate into tables; the others take the finished device block (tm_vocab_block_export / _import, one broadcast)
+        v = tmdist.broadcast_vocab(tm.Vocab(img) if rank == 0 else None, 0, rank, device=0, on_device=not conftest.EMULATED)
         lo, hi = tmdist.shard_strips(len(data), rank, world)
         own = np.frombuffer(data[lo:hi], dtype=np.uint8)
         halo = tmdist.exchange_halo(own, rank, world)

@@ -28,6 +28,9 @@ SIGNATURES = {
     "tm_set_device": (C.c_int, [C.c_int]),
     "tm_vocab_load": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "tm_vocab_load_on": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(vp)]),
+    "tm_vocab_block_export": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "tm_vocab_block_import": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]),
+    "tm_device_copy": (C.c_int, [vp, vp, C.c_uint64]),
     "tm_vocab_free": (None, [vp]),
     "tm_vocab_size": (C.c_uint32, [vp]),
     "tm_vocab_n_info": (C.c_uint32, [vp]),

@@ -90,14 +90,14 @@ namespace tmh {
 // the three stages of a decode on a stream, in buffers of the caller (tm_host.hip: a lane's grow-only arenas)
 void launch_decode_lengths(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_toff, uint32_t ndocs, uint32_t* d_len, uint64_t* d_off,
                            uint64_t* d_sums, uint64_t* d_total, uint64_t* d_doff, hipStream_t st) {
-  note_table_use(v, st);
   if (n) TM_LAUNCH(k_dec_len, (uint32_t)((n + 255) / 256), 256, 0, st, d_tok, n, v->d_rev_off, v->host.n_ids, d_len);
+  note_table_use(v, st);
   scan_u32(d_len, n, d_sums, d_total, d_off, st);
   TM_LAUNCH(k_dec_doc_off, (ndocs + 256) / 256, 256, 0, st, d_off, d_toff, ndocs, d_doff);
 }
 void launch_decode_copy(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_off, uint8_t* d_out, hipStream_t st) {
-  note_table_use(v, st);
   if (n) TM_LAUNCH(k_dec_copy, (uint32_t)((n + 255) / 256), 256, 0, st, d_tok, n, v->d_rev_off, v->d_rev_bytes, v->host.n_ids, d_off, d_out);
+  note_table_use(v, st);
 }
 void launch_decode_capcode(const uint8_t* d_out, const uint64_t* d_doff, uint32_t ndocs, uint8_t* d_dec, uint64_t* d_declen, hipStream_t st) {
   if (ndocs) TM_LAUNCH(k_dec_capcode, (ndocs + 3) / 4, 256, 0, st, d_out, d_doff, ndocs, d_dec, d_declen);

@@ -94,6 +94,7 @@ extern "C" {
 
 int tm_decoder_new(const tm_vocab* v, tm_decoder** out) {
   if (!v || !out) return set_error(TM_E_INVALID, "null argument");
+  if (v->host.rev_off.empty()) return set_error(TM_E_INVALID, "an imported vocabulary (tm_vocab_block_import) has no host tables: no streaming decoder");
   auto* d = new tm_decoder();
   d->v = v;
   *out = d;

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "tokenmonster_hip.h"
@@ -85,6 +86,7 @@ struct tm_vocab {
   uint64_t device_bytes = 0;
   void* d_block = nullptr;           // the one device allocation the table pointers below point into (tm_vocab.hip: block cache)
   size_t block_bytes = 0;
+  uint64_t part_bytes[8] = {};       // root, tab, rows, spl, vals, rev_off, rev_bytes, begin_byte: laid out in this order, each on a 256-byte boundary
   uint32_t* d_root = nullptr;
   uint2* d_tab = nullptr;
   uint4* d_spl = nullptr;
@@ -94,9 +96,10 @@ struct tm_vocab {
   tmh::Row* d_rows = nullptr;
   uint8_t* d_begin_byte = nullptr;
   mutable tmh::LanePool* pool = nullptr;   // created on first use; the tables themselves are immutable
-  // streams that kernels reading the tables have been launched on (note_table_use): tm_vocab_free parks the device block for the next
-  // load, and the block must not be refilled while such a kernel is still in flight
+  // one event per stream that kernels reading the tables have been launched on, re-recorded BEHIND every such launch (note_table_use):
+  // tm_vocab_free parks the device block for the next load, and the block must not be refilled while such a kernel is still in flight.
+  // (Recorded at launch time, not at free time: by then the stream may have been destroyed by its owner.)
   mutable std::mutex use_mu;
-  mutable std::vector<hipStream_t> used_streams;
+  mutable std::vector<std::pair<hipStream_t, hipEvent_t>> last_use;
 };
-namespace tmh { void note_table_use(const tm_vocab* v, hipStream_t st); }
+namespace tmh { void note_table_use(const tm_vocab* v, hipStream_t st); }    // call AFTER the launch

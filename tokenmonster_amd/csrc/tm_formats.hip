@@ -22,6 +22,7 @@ extern "C" {
 
 int tm_vocab_image(const tm_vocab* v, const uint8_t** image, size_t* n) {
   if (!v || !image || !n) return set_error(TM_E_INVALID, "null argument");
+  if (v->host.image.empty()) return set_error(TM_E_INVALID, "an imported vocabulary (tm_vocab_block_import) has no file image");
   *image = v->host.image.data();
   *n = v->host.image.size();
   return TM_OK;
@@ -29,6 +30,7 @@ int tm_vocab_image(const tm_vocab* v, const uint8_t** image, size_t* n) {
 
 int tm_vocab_save(const tm_vocab* v, const char* path) {
   if (!v || !path) return set_error(TM_E_INVALID, "null argument");
+  if (v->host.image.empty()) return set_error(TM_E_INVALID, "an imported vocabulary (tm_vocab_block_import) has no file image");
   FILE* f = std::fopen(path, "wb");
   if (!f) return set_error(TM_E_INVALID, "cannot open %s for writing", path);
   const size_t n = v->host.image.size();

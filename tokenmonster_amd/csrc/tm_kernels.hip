@@ -1340,11 +1340,11 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   }
   mark(1);
   if (nseg > 0)
-    note_table_use(v, st);
     TM_LAUNCH(k_match_branch, (uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st, v->tables, b->d_text, b->d_doc_begin, b->d_doc_end,
                                                                                           b->d_doc_vis ? b->d_doc_vis : b->d_doc_end, b->d_seg_doc,
                                                                                           b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
                                                                                           debug_flags());
+    note_table_use(v, st);
   mark(2);
   for (size_t lvl = 0; lvl + 1 < b->level_first.size() && b->ngroups > 0; lvl++) {     // bottom up: a level reads the maps of the one below
     const uint32_t g0 = b->level_first[lvl], ng = b->level_first[lvl + 1] - g0;

@@ -40,8 +40,13 @@ int hip_fail(hipError_t e, const char* what) {
 
 void note_table_use(const tm_vocab* v, hipStream_t st) {
   std::lock_guard<std::mutex> g(v->use_mu);
-  for (hipStream_t s : v->used_streams) if (s == st) return;
-  v->used_streams.push_back(st);
+  hipEvent_t ev = nullptr;
+  for (auto& u : v->last_use) if (u.first == st) ev = u.second;
+  if (!ev) {
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+    v->last_use.emplace_back(st, ev);
+  }
+  if (hipEventRecord(ev, st) != hipSuccess) (void)hipGetLastError();
 }
 
 int enter_device(const tm_vocab* v) {
@@ -448,6 +453,15 @@ void block_put(int device, bool host, void* p, size_t bytes, std::vector<hipEven
 }
 }  // namespace
 
+static void set_tables(tm_vocab* v) {
+  const HostVocab& hv = v->host;
+  Tables& t = v->tables;
+  t.root = v->d_root; t.tab = v->d_tab; t.spl = v->d_spl; t.vals = v->d_vals; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
+  t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
+  t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint; t.link_off = hv.link_off; t.direct_off = hv.direct_off;
+  t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
+}
+
 // "current device" is a property of the calling OS thread; a caller whose threads are not its own (a goroutine under cgo) names the device
 int tm_vocab_load_on(const uint8_t* vocab_file, size_t n, int device, tm_vocab** out) {
   const int rc = tm_set_device(device);
@@ -472,7 +486,7 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
                   {(void**)&v->d_vals, hv.vals.data(), hv.vals.size() * 4, 0}, {(void**)&v->d_rev_off, hv.rev_off.data(), hv.rev_off.size() * 4, 0},
                   {(void**)&v->d_rev_bytes, hv.rev_bytes.data(), hv.rev_bytes.size(), 0}, {(void**)&v->d_begin_byte, hv.begin_byte, 256, 0}};
   size_t total = 0;
-  for (Part& q : parts) { q.at = total; total += (q.bytes + 255) & ~(size_t)255; v->device_bytes += q.bytes; }
+  for (int k = 0; k < 8; k++) { Part& q = parts[k]; q.at = total; total += (q.bytes + 255) & ~(size_t)255; v->device_bytes += q.bytes; v->part_bytes[k] = q.bytes; }
   total += 256;
   e = hipSuccess;
   size_t stage_bytes = 0;
@@ -496,30 +510,76 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
     tm_vocab_free(v);
     return hip_fail(e, "vocabulary upload");
   }
-  Tables& t = v->tables;
-  t.root = v->d_root; t.tab = v->d_tab; t.spl = v->d_spl; t.vals = v->d_vals; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
-  t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
-  t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint; t.link_off = hv.link_off; t.direct_off = hv.direct_off;
-  t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
+  set_tables(v);
   *out = v;
+  return TM_OK;
+}
+
+// ---- the device block of a vocabulary handed from process to process -------------------------------------------------------------
+// In the data-parallel scoring mode (every rank scores its byte range of the dataset against the SAME candidate) only one
+// rank has to turn a candidate's token list into tables (tm_build_vocab + tm_vocab_load: ~50 ms of one host thread); the others take the
+// finished block - a few MB, one broadcast over xGMI - and the ~200 bytes that say what lies where in it.
+int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* m, void** device_ptr) {
+  if (!v || !m) return set_error(TM_E_INVALID, "null argument");
+  const HostVocab& hv = v->host;
+  std::memset(m, 0, sizeof(*m));
+  m->bytes = v->block_bytes;
+  for (int k = 0; k < 8; k++) m->part_bytes[k] = v->part_bytes[k];
+  m->edge_mask = hv.edge_mask; m->edge_shift = hv.edge_shift; m->n_info = hv.n_info; m->max_len = hv.max_len; m->off = hv.off; m->bstart = hv.bstart;
+  m->spl_hint = hv.spl_hint; m->link_off = hv.link_off; m->direct_off = hv.direct_off; m->delete_id = hv.delete_id; m->unk_id = hv.unk;
+  m->n_ids = hv.n_ids; m->vocab_size = hv.vocab_size; m->capcode = hv.capcode; m->charset = hv.charset; m->norm_flag = hv.norm_flag; m->level = hv.level;
+  m->reserve = hv.reserve; m->n_nodes = hv.n_nodes;
+  if (device_ptr) *device_ptr = v->d_block;
+  return TM_OK;
+}
+
+int tm_device_copy(void* dst_device, const void* src_device, uint64_t bytes) {
+  if (bytes && (!dst_device || !src_device)) return set_error(TM_E_INVALID, "null argument");
+  const hipError_t e = bytes ? hipMemcpy(dst_device, src_device, bytes, hipMemcpyDeviceToDevice) : hipSuccess;
+  return e == hipSuccess ? TM_OK : hip_fail(e, "device-to-device copy");
+}
+
+int tm_vocab_block_import(const tm_vocab_block* m, int device, tm_vocab** out, void** device_ptr) {
+  if (!m || !out || !device_ptr) return set_error(TM_E_INVALID, "null argument");
+  *out = nullptr;
+  size_t total = 256;
+  for (int k = 0; k < 8; k++) total += (m->part_bytes[k] + 255) & ~(uint64_t)255;
+  if (total > m->bytes || m->part_bytes[0] != 256 * 4 || m->part_bytes[7] != 256 || m->n_ids > kRowIdMask + 1)
+    return set_error(TM_E_INVALID, "vocabulary block description is inconsistent");
+  { int rc = tm_set_device(device); if (rc != TM_OK) return rc; }
+  auto* v = new tm_vocab();
+  v->device = device;
+  HostVocab& hv = v->host;                 // (scalars only: an imported vocabulary has no host tables - no Save, no host-side decode)
+  hv.edge_mask = m->edge_mask; hv.edge_shift = m->edge_shift; hv.n_info = m->n_info; hv.max_len = m->max_len; hv.off = m->off; hv.bstart = m->bstart;
+  hv.spl_hint = m->spl_hint; hv.link_off = m->link_off; hv.direct_off = m->direct_off; hv.delete_id = m->delete_id; hv.unk = m->unk_id;
+  hv.n_ids = m->n_ids; hv.vocab_size = m->vocab_size; hv.capcode = (uint8_t)m->capcode; hv.charset = (uint8_t)m->charset; hv.norm_flag = (uint8_t)m->norm_flag;
+  hv.level = (uint8_t)m->level; hv.reserve = (uint8_t)m->reserve; hv.n_nodes = m->n_nodes;
+  hipError_t e = hipSuccess;
+  v->d_block = block_get(device, false, (size_t)m->bytes, &v->block_bytes, &e);
+  if (!v->d_block) { delete v; return hip_fail(e, "vocabulary block"); }
+  void** dst[8] = {(void**)&v->d_root, (void**)&v->d_tab, (void**)&v->d_rows, (void**)&v->d_spl, (void**)&v->d_vals, (void**)&v->d_rev_off, (void**)&v->d_rev_bytes,
+                   (void**)&v->d_begin_byte};
+  size_t at = 0;
+  for (int k = 0; k < 8; k++) { *dst[k] = (uint8_t*)v->d_block + at; v->part_bytes[k] = m->part_bytes[k]; v->device_bytes += m->part_bytes[k]; at += (m->part_bytes[k] + 255) & ~(uint64_t)255; }
+  set_tables(v);
+  *out = v;
+  *device_ptr = v->d_block;      // the caller fills bytes [0, m->bytes) - e.g. the destination of an RCCL broadcast - before the first use
   return TM_OK;
 }
 
 void tm_vocab_free(tm_vocab* v) {
   if (!v) return;
   { int cur = -1; (void)hipGetDevice(&cur); if (cur != v->device) (void)hipSetDevice(v->device); }
-  // one event behind everything that has been launched on the streams the tables were used on (before the lanes' own streams go)
+  // the events behind the last table-reading kernel of every stream travel with the parked block
   std::vector<hipEvent_t> pending;
-  if (v->d_block) {
+  {
     std::lock_guard<std::mutex> g(v->use_mu);
-    for (hipStream_t st : v->used_streams) {
-      hipEvent_t ev = nullptr;
-      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) continue;
-      if (hipEventRecord(ev, st) == hipSuccess) pending.push_back(ev); else { (void)hipGetLastError(); (void)hipEventDestroy(ev); }    // (a stream its owner has destroyed: nothing left on it)
-    }
+    for (auto& u : v->last_use) pending.push_back(u.second);
+    v->last_use.clear();
   }
   tmh::pool_destroy(v->pool);
   if (v->d_block) block_put(v->device, false, v->d_block, v->block_bytes, std::move(pending));
+  else for (hipEvent_t ev : pending) (void)hipEventDestroy(ev);
   delete v;
 }
 

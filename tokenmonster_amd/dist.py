@@ -140,3 +140,50 @@ class HipRange:
         from . import _native as N
         N.check(N.lib.tm_score_finish(self.vocab.handle, self.ds, int(entry), C.c_void_p(self.stream or 0), C.c_void_p(self.dst or 0), self.dst_words))
         return entry
+
+
+# ---- one rank builds a candidate's tables, the others take the finished device block -----------------------------------------------
+# In the data-parallel scoring mode every rank scores its range against the SAME candidate; tm_build_vocab + tm_vocab_load cost ~50 ms
+# of one host thread, ten times the pass they feed at 8 GPUs.  So the candidates are built round-robin (rank r prepares candidates
+# r, r + N, ... ahead of time on its host threads) and the finished block - a few MB - goes to the others in one broadcast.
+
+class _DeviceBytes:
+    """`nbytes` bytes at a raw device pointer, as something torch.as_tensor can alias without a copy"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _alias(ptr, nbytes, on_device):
+    import torch
+    if on_device:
+        return torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
+    import ctypes as C       # (the emulated device of the test suite: "device" memory is host memory)
+    return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)))
+
+
+def broadcast_vocab(vocab, src, rank, group=None, device=0, on_device=True):
+    """`vocab`: the candidate on rank `src` (anything elsewhere).  Returns a vocabulary on every rank: the original on `src`, an imported
+    one (tm_vocab_block_import: device tables only) elsewhere, filled by ONE broadcast of the device block (RCCL over xGMI with the nccl
+    backend; gloo stages it through the host)."""
+    import torch
+    import torch.distributed as dist
+    from .vocab import Vocab, VocabBlock
+    import ctypes as C
+    where = "cuda" if on_device and dist.get_backend(group) == "nccl" else "cpu"
+    n_meta = C.sizeof(VocabBlock)
+    if rank == src:
+        desc, ptr, nbytes = vocab.export_block()
+        meta = torch.frombuffer(bytearray(desc), dtype=torch.uint8).to(where)
+    else:
+        meta = torch.zeros(n_meta, dtype=torch.uint8, device=where)
+    dist.broadcast(meta, src, group=group)
+    if rank != src:
+        vocab, ptr, nbytes = Vocab.import_block(bytes(meta.cpu().numpy().tobytes()), device)
+    block = _alias(ptr, nbytes, on_device)
+    if on_device:
+        torch.cuda.synchronize()          # (the exporter's upload ran on the library's copy stream)
+    dist.broadcast(block, src, group=group)
+    if on_device:
+        torch.cuda.synchronize()
+    return vocab

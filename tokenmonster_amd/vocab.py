@@ -22,6 +22,13 @@ def pack_documents(docs):
     return text, offsets
 
 
+class VocabBlock(C.Structure):
+    """tm_vocab_block (include/tokenmonster_hip.h): what a process needs besides the bytes of a vocabulary's device block"""
+    _fields_ = [("bytes", C.c_uint64), ("part_bytes", C.c_uint64 * 8)] + [(n, C.c_uint32) for n in (
+        "edge_mask", "edge_shift", "n_info", "max_len", "off", "bstart", "spl_hint", "link_off", "direct_off", "delete_id", "unk_id",
+        "n_ids", "vocab_size", "capcode", "charset", "norm_flag", "level", "reserve", "n_nodes", "pad")]
+
+
 class Vocab:
     def __init__(self, image):
         self._image = bytes(image)
@@ -29,6 +36,23 @@ class Vocab:
         buf = np.frombuffer(self._image, dtype=np.uint8)
         N.check(N.lib.tm_vocab_load(N.ptr(buf), buf.size, C.byref(h)))
         self._h = h
+
+    # ---- the device block from process to process (tm_vocab_block_export / _import: the data-parallel scoring mode) ----
+    def export_block(self):
+        """-> (description as bytes, device pointer of the block, its size): send the description, broadcast the block"""
+        m, p = VocabBlock(), C.c_void_p()
+        N.check(N.lib.tm_vocab_block_export(self._h, C.byref(m), C.byref(p)))
+        return bytes(m), int(p.value), int(m.bytes)
+
+    @classmethod
+    def import_block(cls, description, device=0):
+        """an empty vocabulary of the described shape on `device` -> (Vocab, device pointer to fill with the exporter's block before use)"""
+        m = VocabBlock.from_buffer_copy(description)
+        h, p = C.c_void_p(), C.c_void_p()
+        N.check(N.lib.tm_vocab_block_import(C.byref(m), int(device), C.byref(h), C.byref(p)))
+        v = cls.__new__(cls)
+        v._image, v._h = b"", h
+        return v, int(p.value), int(m.bytes)
 
     def close(self):
         if getattr(self, "_h", None):
