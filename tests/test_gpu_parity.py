@@ -530,7 +530,7 @@ def test_full_size_properties(name, mbytes):
         if doc.size and int(doc.max()) < 0x80:
             n_ascii += 1
             assert out[int(ooff[d]):int(ooff[d + 1])].tobytes() == doc.tobytes(), "document %d does not round-trip" % d
-    assert n_ascii > nd // 4
+    assert n_ascii > nd // 20            # (prose carries curly quotes and accents: a tenth of the english documents are pure ASCII, most of the code ones)
     # (4) a random sample against the oracle
     rng = np.random.default_rng(5)
     for d in rng.choice(nd, size=150, replace=False):

@@ -39,14 +39,14 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 void note_table_use(const tm_vocab* v, hipStream_t st) {
-  std::lock_guard<std::mutex> g(v->use_mu);
+  // a fresh event every time: a stream handle may be a NEW stream by now (a lane that rebuilt its workspace), and re-recording an event
+  // whose last stream is gone is an error on this runtime
   hipEvent_t ev = nullptr;
-  for (auto& u : v->last_use) if (u.first == st) ev = u.second;
-  if (!ev) {
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
-    v->last_use.emplace_back(st, ev);
-  }
-  if (hipEventRecord(ev, st) != hipSuccess) (void)hipGetLastError();
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (hipEventRecord(ev, st) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(ev); return; }
+  std::lock_guard<std::mutex> g(v->use_mu);
+  for (auto& u : v->last_use) if (u.first == st) { (void)hipEventDestroy(u.second); u.second = ev; return; }
+  v->last_use.emplace_back(st, ev);
 }
 
 int enter_device(const tm_vocab* v) {
