@@ -5,7 +5,13 @@
 // candidates while the GPU scores one (tm_score serialises passes per dataset).  Prints the stage times of one candidate and the
 // end-to-end candidates/s for 1..T threads.
 //   hipcc -O2 -std=c++17 -I include tools/candidate_throughput.cpp -o /tmp/cand -Ltokenmonster_amd -ltokenmonster_hip -ltm_testsupport -lpthread -Wl,-rpath,$PWD/tokenmonster_amd
-//   /tmp/cand [MiB of raw text = 256] [candidates = 48] [max threads = 16]
+//   /tmp/cand [MiB of raw text = 256] [candidates = 48] [max threads = 16] [ranks = 0]
+// ranks = N > 0: the data-parallel mode of DESIGN section 5 with N lanes of ONE GPU standing in for N GPUs — the dataset is cut into N byte
+// ranges (each uploaded with its halo), every candidate is built and loaded ONCE (round-robin over the worker threads), its device block
+// goes to the other N - 1 "ranks" (tm_vocab_block_export / _import + a device copy where N GPUs would do one RCCL broadcast), and each rank
+// scores its range as a piece of the one whole-buffer walk (tm_score_begin / 80 exit states / tm_score_finish).  Prints what a candidate
+// costs a rank on the host besides the pass, the rate at which the worker threads turn out candidates, and what N GPUs could sustain.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -25,6 +31,7 @@ int main(int argc, char** argv) {
   const uint64_t mib = argc > 1 ? atoll(argv[1]) : 256;
   const int ncand = argc > 2 ? atoi(argv[2]) : 48;
   const int maxt = argc > 3 ? atoi(argv[3]) : 16;
+  const int nranks = argc > 4 ? atoi(argv[4]) : 0;
   if (tm_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
   uint8_t* img = nullptr; size_t img_n = 0;
   if (tm_synth_vocab(TM_KIND_ENGLISHCODE, 65536, 2, 1, 5, 0x544D0005, 0, &img, &img_n) != 0) { fprintf(stderr, "synth_vocab: %s\n", tm_last_error()); return 1; }
@@ -92,6 +99,77 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nt; i++) for (int q = 0; q < 3; q++) a[q] += st[3 * i + q];
     printf("%2d worker threads: %d candidates in %.2f s = %5.1f candidates/s  (the scoring pass alone allows %.1f/s); per candidate: build %.0f ms, load %.0f ms, score incl. waiting %.0f ms\n",
            nt, ncand, dt, ncand / dt, 4.0 / t[2], a[0] / ncand * 1e3, a[1] / ncand * 1e3, a[2] / ncand * 1e3);
+  }
+  if (nranks > 0) {
+    // ---- N lanes of this GPU standing in for N GPUs ---------------------------------------------------------------------------
+    const uint64_t N = off[nd], HALO = 128;
+    std::vector<tm_dataset*> rds(nranks);
+    std::vector<uint64_t> lo(nranks + 1);
+    for (int r = 0; r <= nranks; r++) lo[r] = N * r / nranks;
+    for (int r = 0; r < nranks; r++) {
+      const uint64_t end = std::min<uint64_t>(N, lo[r + 1] + (r + 1 < nranks ? HALO : 0));
+      if (tm_dataset_upload(text + lo[r], end - lo[r], &rds[r]) != 0) { fprintf(stderr, "upload: %s\n", tm_last_error()); return 1; }
+    }
+    auto build_load = [&](int k, tm_vocab** out) {
+      std::vector<uint8_t> blob; std::vector<uint32_t> o(1, 0);
+      uint64_t s = 0x9E3779B97F4A7C15ull * (uint64_t)(k + 1);
+      auto add = [&](const std::string& tk) { blob.insert(blob.end(), tk.begin(), tk.end()); o.push_back((uint32_t)blob.size()); };
+      for (auto& tk : singles) add(tk);
+      for (auto& tk : multi) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; if ((s >> 11) % 100 < 97) add(tk); }
+      uint8_t* im = nullptr; size_t im_n = 0;
+      if (tm_build_vocab(blob.data(), o.data(), (uint32_t)o.size() - 1, nullptr, 2, 1, 1, 5, 0, &im, &im_n) != 0 || tm_vocab_load(im, im_n, out) != 0) { fprintf(stderr, "build/load: %s\n", tm_last_error()); exit(1); }
+      tm_free(im);
+    };
+    // (1) how fast the host turns out candidates, GPU otherwise idle
+    for (int nt = 1; nt <= maxt; nt *= 2) {
+      std::atomic<int> next{0};
+      const double t0 = now();
+      std::vector<std::thread> th;
+      for (int i = 0; i < nt; i++) th.emplace_back([&] { for (;;) { int k = next.fetch_add(1); if (k >= ncand) break; tm_vocab* v = nullptr; build_load(k, &v); tm_vocab_free(v); } });
+      for (auto& x : th) x.join();
+      printf("build + load only, %2d host threads: %5.1f candidates/s\n", nt, ncand / (now() - t0));
+    }
+    // (2) one candidate through all ranks: what the ranks that did NOT build it pay, and the pass over a range
+    double t_imp = 0, t_pass = 0, t_first = 0, block_mb = 0;
+    uint64_t tokens_total = 0;
+    const int reps = 6;
+    for (int k = 0; k < reps; k++) {
+      tm_vocab* v0 = nullptr;
+      build_load(k, &v0);
+      tm_vocab_block meta; void* src = nullptr;
+      if (tm_vocab_block_export(v0, &meta, &src) != 0) return 1;
+      block_mb = meta.bytes / 1e6;
+      std::vector<tm_vocab*> vs(nranks, nullptr);
+      vs[0] = v0;
+      const double a = now();
+      for (int r = 1; r < nranks; r++) {
+        void* dst = nullptr;
+        if (tm_vocab_block_import(&meta, 0, &vs[r], &dst) != 0 || tm_device_copy(dst, src, meta.bytes) != 0) { fprintf(stderr, "import: %s\n", tm_last_error()); return 1; }
+      }
+      const double b = now();
+      uint32_t entry = 0;
+      uint64_t tok = 0;
+      for (int r = 0; r < nranks; r++) {
+        uint8_t exits[80];
+        const double c = now();
+        if (tm_score_begin(vs[r], rds[r], 0, lo[r + 1] - lo[r], r + 1 < nranks ? 1 : 0, nullptr, exits) != 0 ||
+            tm_score_finish(vs[r], rds[r], entry, nullptr, nullptr, 0) != 0) { fprintf(stderr, "range pass: %s\n", tm_last_error()); return 1; }
+        std::vector<uint32_t> sc(tm_vocab_n_ids(vs[r])); uint64_t tit = 0; uint8_t ms[32];
+        if (tm_score_read(vs[r], rds[r], sc.data(), &tit, ms) != 0) return 1;
+        if (k > 0) { t_pass += now() - c; if (r == 0) t_first += now() - c; }
+        tok += tit;
+        entry = exits[entry];
+      }
+      if (k > 0) t_imp += (b - a) / std::max(1, nranks - 1);
+      tokens_total = tok;
+      for (auto* v : vs) tm_vocab_free(v);
+    }
+    const double pass_ms = t_pass / (reps - 1) / nranks * 1e3;
+    printf("%d ranks: a rank that did not build the candidate pays %.2f ms (import + block copy, %.1f MB) instead of build + load (%.1f ms); pass over 1/%d of the dataset %.2f ms "
+           "(incl. the histogram read); tokens of the whole walk %llu\n", nranks, t_imp / (reps - 1) * 1e3, block_mb, (t[0] + t[1]) / 4 * 1e3, nranks, pass_ms, (unsigned long long)tokens_total);
+    printf("  => %d GPUs in the data-parallel mode need a new candidate every %.2f ms = %.0f candidates/s; the builders above must turn out that many (round-robin over the ranks' host threads)\n",
+           nranks, pass_ms, 1e3 / pass_ms);
+    for (auto* d : rds) tm_dataset_free(d);
   }
   tm_dataset_free(ds);
   tm_free(text);
