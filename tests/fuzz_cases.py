@@ -85,6 +85,12 @@ def one(seed):
 NORM_ALPHABET = [chr(c) for c in b"aabcxyzABCDQWXYZ   ''1239..,-_()\n\t"] + ["\u2019", "\u2019", "\u201c", "\u2014", "\u2026", "\u00e9", "\u00c9", "\u4e2d", "\U0001f600", "\u0301"]
 
 
+# accented Latin: two-byte characters that decompose under NFD (é -> e + U+0301), that stay whole (Æ ø ß Ł), letters without case (ª º),
+# symbols, and the two whose lower case is special (İ ı)
+LATIN = [chr(c) for c in (0xE9, 0xC9, 0xE8, 0xC0, 0xEF, 0xF1, 0xD1, 0xFC, 0xDC, 0xE7, 0xC7, 0xC6, 0xE6, 0xD8, 0xF8, 0xDF, 0xDE, 0xFE, 0xD0, 0xF0, 0xAA, 0xBA, 0xB5, 0xAB, 0xBB,
+                          0xA0, 0xB2, 0xBD, 0xD7, 0xF7, 0x100, 0x101, 0x10C, 0x10D, 0x141, 0x142, 0x152, 0x153, 0x130, 0x131, 0x149, 0x17F, 0x178, 0xFF, 0x138, 0x13F, 0x140)]
+
+
 def one_norm(seed):
     """the device normalizer (NFD / lowercase + capcode 2; host fallback for what it does not do itself) against the host normalizer:
     runs of capitals, digits and apostrophes of every length, also across the 64-byte chunks and 1 KiB pieces of the device pass"""
@@ -98,7 +104,9 @@ def one_norm(seed):
         n = int(rng.choice([0, 1, 5, 60, 63, 64, 65, 127, 129, 1000, 1023, 1024, 1025, 2047, 2049, 3100]))
         while sum(len(x) for x in parts) < n:
             r = rng.random()
-            if r < 0.35:
+            if r < 0.15:
+                parts.append("".join(rng.choice(NORM_ALPHABET[:30] + LATIN, size=int(rng.integers(1, 40)))))
+            elif r < 0.35:
                 parts.append("".join(rng.choice(NORM_ALPHABET[:36], size=int(rng.integers(1, 30)))))
             elif r < 0.55:
                 parts.append(str(rng.choice(["A", "Q", "AB", "Ab", "I'M", "X\u2019S", "A1", "1A", "a'B"])) * int(rng.integers(1, 400)))

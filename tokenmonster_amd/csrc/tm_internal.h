@@ -19,6 +19,8 @@ int build_vocab_image(const std::vector<std::string>& tokens, const std::vector<
                       std::vector<uint8_t>& image, const std::vector<float>* token_scores = nullptr);
 
 // tm_normalize.cpp
+struct NmTwo;
+void build_two_table(uint32_t norm_flag, NmTwo* out);     // 256 entries: the device normalizer's table of the two-byte characters (tm_norm_masks.h)
 void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out);
 
 int normalize_batch_into(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t norm_flag,

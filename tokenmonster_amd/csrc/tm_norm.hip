@@ -48,18 +48,20 @@ __device__ __forceinline__ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
   if (c == ' ') return NC_SP;
   return NC_O;
 }
-__device__ __forceinline__ bool npunct3(uint32_t b1, uint32_t b2) {   // E2 b1 b2 in the supported punctuation ranges
-  return (b1 == 0x80u && ((b2 >= 0x90u && b2 <= 0xA7u) || (b2 >= 0xB0u && b2 <= 0xBFu))) || (b1 == 0x81u && b2 >= 0x80u && b2 <= 0x9Eu);
-}
-__device__ __forceinline__ bool nblock(uint32_t cls) { return cls == NC_U || cls == NC_N || cls == NC_AP; }
+__device__ __forceinline__ bool nblock(uint32_t cls) { return (cls & NF_BLOCK) != 0; }       // capital, digit, apostrophe, combining mark
 
 struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
+// the table of the two-byte characters (tm_norm_masks.h: NmTwo), 2 KB, staged by the 256 work-items of a workgroup
+__device__ __forceinline__ void stage_two(NmTwo* s_two, const NmTwo* __restrict__ two) {
+  static_assert(NM_TWO_SIZE == 256, "one entry per work-item");
+  s_two[threadIdx.x] = two[threadIdx.x];
+}
 
 // stage the piece (+ margins) and classify every byte; continuation bytes inherit the class of their lead byte.
 // returns the piece length; LDS index of document byte (pb + i) is PMARGIN + i.
 template <typename LDS>
 __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict__ raw, uint64_t rb, uint64_t re, uint64_t pb, int lane,
-                                               const uint8_t* s_cls) {
+                                               const uint8_t* s_cls, const NmTwo* s_two) {
   for (int i = lane; i < PLDS / 4; i += 64) {
     const int64_t g = (int64_t)pb - PMARGIN + 4 * i;
     uint32_t wv = 0;
@@ -87,14 +89,7 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
         uint32_t fl = 0;                                    // (the two bytes at either end of the staged range are never looked at)
         if (b < 0x80u) fl = s_cls[b];                       // class of an ASCII byte: one LDS read instead of five range checks
         else if (x >= 2 && x < PLDS - 2) {
-          const uint32_t m1 = L.raw[x - 1], m2 = L.raw[x - 2], p1 = L.raw[x + 1], p2 = L.raw[x + 2];
-          uint32_t b1 = 0, b2 = 0, cont = 0;
-          bool ok = false;
-          if (b == 0xE2u) { b1 = p1; b2 = p2; ok = true; }
-          else if (m1 == 0xE2u) { b1 = b; b2 = p1; cont = NF_CONT; ok = true; }
-          else if (m2 == 0xE2u) { b1 = m1; b2 = b; cont = NF_CONT; ok = true; }
-          ok = ok && npunct3(b1, b2);
-          fl = ok ? (((b1 == 0x80u && b2 == 0x99u) ? NC_AP : NC_O) | cont) : NF_BAD;
+          fl = nm_classify_high(b, L.raw[x - 1], L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], s_two);     // two-byte Latin, three-byte punctuation, or NF_BAD
         }
         f4 |= fl << (8 * q);
       }
@@ -110,10 +105,12 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
 __global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rbegin,
                                                       const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
                                                       const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t lower_all,
-                                                      uint32_t* __restrict__ piece_sum) {
+                                                      const NmTwo* __restrict__ two, uint32_t* __restrict__ piece_sum) {
   __shared__ PieceLds s_l[4];
   __shared__ uint8_t s_cls[128];
+  __shared__ NmTwo s_two[NM_TWO_SIZE];
   if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
+  stage_two(s_two, two);
   __syncthreads();
   // (wave-uniform wavefront index: the run bookkeeping below is arithmetic on ballots and then runs on the scalar unit)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -122,7 +119,7 @@ __global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict_
   PieceLds& L = s_l[wv];
   const uint32_t d = piece_doc[k];
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls));
+  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, s_two));
   bool lead_open = true, lead_tl = false, bad = false;
   uint32_t lead_u = 0, trail_u = 0;
   for (int c = 0; c * 64 < m; c++) {
@@ -196,11 +193,13 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
                                                    uint32_t lower_all, const uint8_t* __restrict__ piece_carry,
                                                    const uint8_t* __restrict__ need_host, uint32_t* __restrict__ piece_len,
                                                    const uint64_t* __restrict__ piece_off, uint8_t* __restrict__ out,
-                                                   unsigned long long* __restrict__ overflow) {
+                                                   unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two) {
   constexpr bool WRITE = MODE != 0;
   __shared__ PieceLds s_l[4];
   __shared__ uint8_t s_cls[128];
+  __shared__ NmTwo s_two[NM_TWO_SIZE];
   if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
+  stage_two(s_two, two);
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
@@ -209,11 +208,20 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
   const uint32_t d = piece_doc[k];
   if (need_host[d]) { if (MODE != 1 && lane == 0) piece_len[k] = 0; return; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls);
+  const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls, s_two);
   uint8_t* dst = MODE == 1 ? out + piece_off[k] : (MODE == 2 ? out + k * (uint64_t)SLAB : nullptr);
   if (capcode != 2) {                                       // no capcode: same length, only the lower-case flag applies
     if (MODE != 1 && lane == 0) piece_len[k] = (uint32_t)m;
-    if (WRITE) for (int i = lane; i < m; i += 64) { uint32_t b = L.raw[PMARGIN + i]; if (lower_all && b - 'A' < 26u) b |= 0x20u; dst[i] = (uint8_t)b; }
+    if (WRITE) for (int i = lane; i < m; i += 64) {
+      const int x = PMARGIN + i;
+      uint32_t b = L.raw[x], y = 0;
+      if (lower_all && b - 'A' < 26u) b |= 0x20u;
+      const uint32_t bm1 = L.raw[x - 1];
+      // (a two-byte character that stays one: its bytes under the vocabulary's flags; those that decompose are not in this table)
+      if (nm_two_lead(b)) nm_two_out(s_two[nm_two_index(b, L.raw[x + 1])], false, false, false, &b, &y);
+      else if (nm_cont_byte(b) && nm_two_lead(bm1)) nm_two_out(s_two[nm_two_index(bm1, b)], true, false, false, &b, &y);
+      dst[i] = (uint8_t)b;
+    }
     return;
   }
   const uint32_t carry = piece_carry[k];
@@ -273,34 +281,29 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
     uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, len = 0;
     if (in) {
       const uint32_t b = L.raw[x];
-      o3 = b; len = 1;
-      if (!(fl & NF_CONT)) {
-        const uint32_t fm1 = L.f[x - 1], P = fm1 & NF_CLASS;
-        uint32_t P2 = NC_O;
-        if (P == NC_AP) P2 = L.f[(fm1 & NF_CONT) ? x - 4 : x - 2] & NF_CLASS;
-        const bool inword = ub >= 1;                           // javascript/tokenmonster.js `inWord` before this character
-        const bool tl = (fl & NF_TERML) != 0;
-        const uint32_t lowc = b | 0x20u;
-        if (cls == NC_U) {
-          o3 = lowc;
-          if (!inword) {                                       // first capital of a run  (:975-990)
-            if (P == NC_SP) { o2 = ' '; len = 2; }             // the space before it turns into the marker (below)
-            else { o0 = 'D'; o1 = tl ? 'C' : 'W'; o2 = ' '; len = 4; }
-          } else if (tl) { o0 = 'D'; o1 = 'C'; o2 = ' '; len = 4; }        // :924-951 every later capital of a 'C' run
-          else if (P == NC_N) { o1 = 'D'; o2 = ' '; len = 3; }              // :913-916
-        } else if (cls == NC_L) {
-          if (lower_all) o3 = lowc;
-          const bool joined = inword ? (P == NC_U || P == NC_AP)           // :952-955 (the letter that ends a run)
-                                     : (P == NC_SP || P == NC_L || P == NC_U || (P == NC_AP && (P2 == NC_L || P2 == NC_U)));   // :970
-          if (!joined) { o1 = 'D'; o2 = ' '; len = 3; }
-        } else if (cls == NC_N) {
-          const bool joined = inword ? (P == NC_N) : (P == NC_SP || P == NC_N);   // :958 / :992
-          if (!joined) { o1 = 'D'; o2 = ' '; len = 3; }
-        } else if (cls == NC_SP) {
-          const bool last = i + 1 == m;                        // the next byte lives in the next piece (or nowhere)
-          const uint32_t fp1 = L.f[x + 1];
-          if ((fp1 & NF_CLASS) == NC_U && fp1 != NF_BAD) o3 = (last ? next_tl : (fp1 & NF_TERML) != 0) ? 'C' : 'W';   // :976-979
-        }
+      const uint32_t fm1 = L.f[x - 1], P = fm1 & NF_CLASS;
+      uint32_t P2 = NC_O;
+      if (P == NC_AP) P2 = L.f[(fm1 & NF_CONT) ? x - 4 : x - 2] & NF_CLASS;
+      const bool inword = ub >= 1;                             // javascript/tokenmonster.js `inWord` before this character
+      const bool tl = (fl & NF_TERML) != 0;
+      // the rules themselves are the ones k_norm_emit2 reads from its table (tm_norm_masks.h: nm_lut_entry); what this kernel does
+      // differently is how it finds inWord and the 'C' look-ahead (per-lane counting instead of flood fills on the ballots)
+      const uint32_t code = nm_lut_entry(nm_lut_index((fl & NF_CONT) ? (uint32_t)NC_O : cls, P, P2, inword ? 1u : 0u, tl ? 1u : 0u), lower_all != 0);
+      len = (code & 3u) + 1u;
+      o0 = 'D'; o1 = code >> 8; o2 = ' ';
+      o3 = b | ((code & 4u) << 3);
+      if (cls == NC_SP) {
+        const bool last = i + 1 == m;                          // the next byte lives in the next piece (or nowhere)
+        const uint32_t fp1 = L.f[x + 1];
+        if ((fp1 & NF_CLASS) == NC_U && fp1 != NF_BAD && !(fp1 & NF_CONT)) o3 = (last ? next_tl : (fp1 & NF_TERML) != 0) ? 'C' : 'W';   // :976-979
+      }
+      // one byte of a two-byte character: its bytes come from the table (a decomposed character's second half emits the two bytes of the mark)
+      const uint32_t bm1 = L.raw[x - 1];
+      const bool lead2 = nm_two_lead(b), cont2 = nm_cont_byte(b) && nm_two_lead(bm1);
+      if (lead2 || cont2) {
+        const NmTwo e = s_two[lead2 ? nm_two_index(b, L.raw[x + 1]) : nm_two_index(bm1, b)];
+        uint32_t y = 0;
+        if (nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y)) { len = 2; o2 = y; }
       }
     }
     // inclusive prefix sum of len (0..4) over the wavefront: bytes-with-len>=k ballots, counted below the lane
@@ -340,10 +343,12 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
                                                     const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t lower_all,
                                                     const uint8_t* __restrict__ piece_carry, const uint8_t* __restrict__ need_host,
                                                     uint32_t* __restrict__ piece_len, uint8_t* __restrict__ slab,
-                                                    unsigned long long* __restrict__ overflow) {
+                                                    unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two) {
   constexpr int SLAB2 = 2 * PIECE, NCH = PIECE / 64;
   __shared__ PieceLds2 s_l[4];
   __shared__ uint8_t s_cls[128];
+  __shared__ NmTwo s_two[NM_TWO_SIZE];
+  stage_two(s_two, two);
   alignas(16) __shared__ uint16_t s_lut[NM_LUT_SIZE];
   static_assert(NM_LUT_SIZE * sizeof(uint16_t) == 256 * sizeof(uint4), "one 16-byte load per thread stages the rule table");
   if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   const uint32_t d = piece_doc[k];
   if (need_host[d]) { if (lane == 0) piece_len[k] = 0; return; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls));
+  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, s_two));
   const uint32_t carry = __builtin_amdgcn_readfirstlane((uint32_t)piece_carry[k]);
   const unsigned long long carry_tl = (carry >> 4) & 1u;
   const int nch = (m + 63) >> 6;
@@ -411,15 +416,28 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
       nm_space_markers(__ballot((fl & NF_CLASS) == NC_SP), Ucur, Unext, V, TX[c], TX[c + 1], &spC, &spW);
       w = w_out;
       // the rule table: index = class | previous class << 3 | class before the apostrophe << 6 | W << 9 | T << 10
+      // (a continuation byte takes no part in the rules as a character of its own: class O here; as the PREVIOUS byte it stands for its character)
       const uint32_t p2 = (fp & NF_CONT) ? f4 : f2;
-      uint32_t idx = (fl & 7u) | ((fp & 7u) << 3) | ((p2 & 7u) << 6);
+      uint32_t idx = ((fl & NF_CONT) ? (uint32_t)NC_O : (fl & 7u)) | ((fp & 7u) << 3) | ((p2 & 7u) << 6);
       idx = sel_mask(W, idx | 512u, idx);
       idx = sel_mask(TX[c], idx | 1024u, idx);
       const uint32_t code = s_lut[idx];
-      const uint32_t len1 = code & 3u;                                   // bytes emitted - 1
+      uint32_t len1 = code & 3u;                                         // bytes emitted - 1
       uint32_t o3 = b | ((code & 4u) << 3);
       o3 = sel_mask(spC, chC, o3);
       o3 = sel_mask(spW, chW, o3);
+      // the bytes of a two-byte character (U+0080..U+017F) come from the table: the lead lane its first byte - or the ASCII letter the
+      // character decomposes into -, the second lane its second byte - or the two bytes of the combining mark.  Chunks without any are the rule.
+      uint32_t ysp = chSP;
+      if (__ballot(nm_two_lead(b) || (lane == 0 && nm_cont_byte(b))) != 0ull) {       // (lane 0 may hold the second byte of a character that began in the chunk before)
+        const uint32_t bm1 = L.raw[PMARGIN + 64 * c + lane - 1], bp1 = L.raw[PMARGIN + 64 * c + lane + 1];
+        const bool lead2 = nm_two_lead(b), cont2 = nm_cont_byte(b) && nm_two_lead(bm1);
+        if (lead2 || cont2) {
+          const NmTwo e = s_two[lead2 ? nm_two_index(b, bp1) : nm_two_index(bm1, b)];
+          uint32_t y = 0;
+          if (nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y)) { len1 = 1u; ysp = y; }
+        }
+      }
       const unsigned long long ge2 = __ballot(len1 >= 1u) & V, ge3 = __ballot(len1 >= 2u) & V, ge4 = __ballot(len1 >= 3u) & V;
       const uint32_t total = (uint32_t)(__builtin_popcountll(V) + __builtin_popcountll(ge2) + __builtin_popcountll(ge3) + __builtin_popcountll(ge4));
       if (pos + total <= (uint32_t)SLAB2) {
@@ -427,7 +445,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
         const uint32_t first = mbcnt64(ge4, mbcnt64(ge3, mbcnt64(ge2, mbcnt64(V, out0 + pos))));
         const uint32_t last = first + len1;
         *TM_LDS_PTR(lds_u8, sel_mask(V, last, dump)) = (uint8_t)o3;
-        *TM_LDS_PTR(lds_u8, sel_mask(ge2, last - 1u, dump)) = (uint8_t)chSP;
+        *TM_LDS_PTR(lds_u8, sel_mask(ge2, last - 1u, dump)) = (uint8_t)ysp;
         *TM_LDS_PTR(lds_u8, sel_mask(ge3, last - 2u, dump)) = (uint8_t)(code >> 8);
         *TM_LDS_PTR(lds_u8, sel_mask(ge4, first, dump)) = (uint8_t)chD;
       } else over = true;                                   // wave-uniform: the piece does not fit its slab (exact two-pass path)
@@ -568,6 +586,15 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
     b->raw_docs_cap = (uint32_t)std::min<uint64_t>(docs_cap - 2, 0xFFFFFFFFull);
   }
   if (!b->d_ninfo && (e = hipMalloc((void**)&b->d_ninfo, 64)) != hipSuccess) return hip_fail(e, "hipMalloc");
+  if (!b->d_two) {
+    // what the vocabulary's flags {NFD, lowercase} do to the two-byte characters U+0080..U+017F, from the host normalizer's own building blocks
+    if ((e = hipMalloc((void**)&b->d_two, NM_TWO_SIZE * sizeof(NmTwo))) != hipSuccess) return hip_fail(e, "hipMalloc");
+    std::vector<NmTwo> two(NM_TWO_SIZE);
+    build_two_table(b->vocab->host.norm_flag & 3u, two.data());
+    if (b->vocab->host.capcode != 2) for (auto& t : two) if (t.a & NT_DECOMP) t.a = 0;      // (without capcode the pass keeps lengths: decomposing characters take the host path)
+    int rc = small_h2d(b, b->d_two, two.data(), NM_TWO_SIZE * sizeof(NmTwo), st);
+    if (rc != TM_OK) return rc;
+  }
   if (!b->d_piece_doc || npieces + 2 > b->piece_cap) {
     void** ps[] = {(void**)&b->d_piece_doc, (void**)&b->d_piece_sum, (void**)&b->d_piece_carry, (void**)&b->d_piece_len, (void**)&b->d_piece_off};
     for (void** q : ps) { (void)hipFree(*q); *q = nullptr; }
@@ -617,7 +644,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   const uint32_t pgrid = (uint32_t)((np + 3) / 4);
   if (np > 0) {
     launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
-    TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_sum);
+    TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_two, b->d_piece_sum);
   }
   TM_LAUNCH(k_norm_carry, (nd + 255) / 256, 256, 0, st, b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids,
                                                   normalize_on_device(capcode, norm_flag) ? 0u : 1u);
@@ -631,10 +658,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   // the device normalizes its documents (one pass into per-piece slabs, lengths on the side) ...
   if (np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
     TM_LAUNCH(k_norm_emit2, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
-                                        b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3);
+                                        b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
   else if (np > 0)                    // capcode 0, or debug bit 8: the per-lane version of the rules
     TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                          b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3);
+                                          b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
   scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
   if (nf > 0) {
     // ... while the documents it cannot normalize (other non-ASCII content: NFD / Unicode case need ICU) are fetched on a
@@ -702,7 +729,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     } else {
       // some piece expands beyond its slab (long runs of capitals): exact two-pass path
       TM_LAUNCH(k_norm_emit<1>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                            b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text, nullptr);
+                                            b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text, nullptr, b->d_two);
     }
   }
   TM_LAUNCH(k_norm_ranges, (nd + 255) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);

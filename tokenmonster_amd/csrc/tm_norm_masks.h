@@ -24,8 +24,58 @@
 namespace tmh {
 
 // character classes (3 bits; bit 2 = member of a block) and flag bits of a classified byte
-enum : uint32_t { NC_O = 0, NC_L = 1, NC_SP = 2, NC_U = 4, NC_N = 5, NC_AP = 6 };
+//   O other   L lower-case letter   SP space   LO letter that is neither upper nor lower case (ª º: isLetter only)
+//   U capital   N digit   AP apostrophe (' and U+2019)   M combining mark (isModifier: here always the second half of a decomposed letter)
+enum : uint32_t { NC_O = 0, NC_L = 1, NC_SP = 2, NC_LO = 3, NC_U = 4, NC_N = 5, NC_AP = 6, NC_M = 7 };
 constexpr uint32_t NF_CLASS = 7u, NF_BLOCK = 4u, NF_CONT = 8u, NF_TERML = 16u, NF_UA_SHIFT = 5, NF_BAD = 0x80u;
+
+// ---- two-byte UTF-8 characters U+0080..U+017F (lead bytes C2..C5: Latin-1 Supplement, Latin Extended-A) -----------------------------
+// What NFD / lowercase / capcode do to them is a table of 256 entries (one per lead byte x second byte), built on the HOST from the
+// host normalizer's own building blocks (ICU; tm_normalize.cpp: build_two_table) for the vocabulary's normalization flags, so that
+// the device cannot disagree with it:  a character either stays one two-byte character (Æ ø ß « ...: lead lane emits its first
+// byte, continuation lane its second) or decomposes into an ASCII letter and one combining mark (é -> e + U+0301: lead lane takes
+// the letter's role - class, markers, the letter - and the continuation lane, class M, emits the two bytes of the mark).
+//   a: class of the first code point [0..2] | NT_OK [3] | NT_DECOMP [4] | lead byte out [8..15] | continuation out A [16..23] | B [24..31]
+//      (decomposed: A B = the mark; otherwise A = the second byte)
+//   b: lead byte out when capcode lower-cases the character [0..7] | continuation byte out then [8..15]
+struct NmTwo { uint32_t a, b; };
+constexpr int NM_TWO_SIZE = 256;
+constexpr uint32_t NT_OK = 8u, NT_DECOMP = 16u;
+TM_HD bool nm_two_lead(uint32_t b) { return b - 0xC2u < 4u; }
+TM_HD bool nm_cont_byte(uint32_t b) { return (b & 0xC0u) == 0x80u; }
+TM_HD uint32_t nm_two_index(uint32_t lead, uint32_t second) { return ((lead - 0xC2u) << 6) | (second & 63u); }
+TM_HD bool nm_punct3(uint32_t b1, uint32_t b2) {   // E2 b1 b2 in the supported (NFD-stable) General Punctuation ranges U+2010..U+2027, U+2030..U+205E
+  return (b1 == 0x80u && ((b2 >= 0x90u && b2 <= 0xA7u) || (b2 >= 0xB0u && b2 <= 0xBFu))) || (b1 == 0x81u && b2 >= 0x80u && b2 <= 0x9Eu);
+}
+// class byte of the non-ASCII byte b between m2 m1 and p1 p2 (NF_BAD: the document needs the host normalizer)
+template <class Two>
+TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32_t p2, const Two& two) {
+  if (nm_two_lead(b)) {
+    if (!nm_cont_byte(p1)) return NF_BAD;
+    const uint32_t a = two[nm_two_index(b, p1)].a;
+    return (a & NT_OK) ? (a & NF_CLASS) : NF_BAD;
+  }
+  if (nm_cont_byte(b) && nm_two_lead(m1)) {
+    const uint32_t a = two[nm_two_index(m1, b)].a;
+    return (a & NT_OK) ? ((a & NT_DECOMP) ? (uint32_t)NC_M : ((a & NF_CLASS) | NF_CONT)) : NF_BAD;
+  }
+  uint32_t b1 = 0, b2 = 0, cont = 0;
+  bool ok = false;
+  if (b == 0xE2u) { b1 = p1; b2 = p2; ok = true; }
+  else if (m1 == 0xE2u) { b1 = b; b2 = p1; cont = NF_CONT; ok = true; }
+  else if (m2 == 0xE2u) { b1 = m1; b2 = b; cont = NF_CONT; ok = true; }
+  ok = ok && nm_punct3(b1, b2);
+  return ok ? (((b1 == 0x80u && b2 == 0x99u) ? (uint32_t)NC_AP : (uint32_t)NC_O) | cont) : NF_BAD;      // U+2019 is an apostrophe (tokenmonster.js:878)
+}
+// the bytes of a lane that holds one byte of a two-byte character: *o3 = its last output byte; returns true when the lane is the
+// second half of a decomposed character and emits TWO bytes, *y then *o3 (the combining mark)
+// (`lowered`: the rule table says capcode lower-cases this character - lead lane; `capcode`: level 2 is on, which lower-cases every capital)
+TM_HD bool nm_two_out(NmTwo e, bool cont, bool lowered, bool capcode, uint32_t* o3, uint32_t* y) {
+  if (!cont) { *o3 = lowered ? (e.b & 0xFFu) : ((e.a >> 8) & 0xFFu); return false; }
+  if (e.a & NT_DECOMP) { *y = (e.a >> 16) & 0xFFu; *o3 = e.a >> 24; return true; }
+  *o3 = (capcode && (e.a & NF_CLASS) == NC_U) ? ((e.b >> 8) & 0xFFu) : ((e.a >> 16) & 0xFFu);
+  return false;
+}
 
 TM_HD uint64_t nm_brev(uint64_t x) { return __builtin_bitreverse64(x); }   // s_brev_b64 on the device
 // every bit of M reachable upwards from a seed through consecutive set bits of M (seeds outside M are ignored):
@@ -82,6 +132,8 @@ TM_HD constexpr uint32_t nm_lut_index(uint32_t cls, uint32_t prev, uint32_t prev
 TM_HD constexpr uint16_t nm_lut_entry(uint32_t idx, bool lower_all) {
   const uint32_t cls = idx & 7u, P = (idx >> 3) & 7u, P2 = (idx >> 6) & 7u;
   const bool W = (idx >> 9) & 1u, T = (idx >> 10) & 1u;
+  // isLetter(rlast) / isLetter(rlast2) of tokenmonster.js:883-885; a combining mark behind a letter joins like the letter (:915, :954, :970)
+  const bool Pletter = P == NC_L || P == NC_U || P == NC_LO, P2letter = P2 == NC_L || P2 == NC_U || P2 == NC_LO;
   uint32_t len = 1, lower = 0, mark = 0;
   if (cls == NC_U) {                                         // :913-916, :924-951, :975-990
     lower = 1;
@@ -92,8 +144,8 @@ TM_HD constexpr uint16_t nm_lut_entry(uint32_t idx, bool lower_all) {
     else if (P == NC_N) { len = 3; mark = 'D'; }
   } else if (cls == NC_L) {                                  // :952-955 (the letter that ends a run), :970
     lower = lower_all ? 1 : 0;
-    const bool joined = W ? (P == NC_U || P == NC_AP)
-                          : (P == NC_SP || P == NC_L || P == NC_U || (P == NC_AP && (P2 == NC_L || P2 == NC_U)));
+    const bool joined = W ? (P == NC_U || P == NC_AP || P == NC_M)
+                          : (P == NC_SP || Pletter || P == NC_M || (P == NC_AP && P2letter));
     if (!joined) { len = 3; mark = 'D'; }
   } else if (cls == NC_N) {                                  // :958 / :992
     const bool joined = W ? (P == NC_N) : (P == NC_SP || P == NC_N);

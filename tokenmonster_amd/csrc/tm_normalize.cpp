@@ -9,6 +9,7 @@
 #include "tm_build.h"
 #include "tokenmonster_hip.h"
 #include "tm_internal.h"
+#include "tm_norm_masks.h"
 
 #include <unicode/normalizer2.h>
 #include <unicode/uchar.h>
@@ -363,6 +364,40 @@ void nocapcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
   out.clear();
   CapcodeState st;
   nocapcode_decode_stream(st, in, n, out);
+}
+
+// The table of the device normalizer for the two-byte characters U+0080..U+017F (tm_norm_masks.h: NmTwo), made from this file's own
+// building blocks for the flags {NFD, lowercase} of a vocabulary: the device cannot disagree with the host about them.  A character
+// the table cannot express (anything but "stays one two-byte character" or "ASCII letter + one two-byte combining mark", or a lower-case
+// form of another length) is left without NT_OK: documents that contain it take the host path.
+void build_two_table(uint32_t norm_flag, NmTwo* out) {
+  for (uint32_t cp = 0x80; cp < 0x180; cp++) {
+    const uint32_t lead = 0xC0u | (cp >> 6), second = 0x80u | (cp & 0x3Fu);
+    NmTwo& e = out[nm_two_index(lead, second)];
+    e.a = 0; e.b = 0;
+    std::vector<uint8_t> t = {(uint8_t)lead, (uint8_t)second};
+    if (norm_flag & 1) nfd_bytes(t);
+    if (norm_flag & 2) lower_bytes(t);
+    if (t.empty()) continue;
+    const Cp c1 = next_cp(t.data(), t.size());
+    if (c1.raw) continue;
+    const uint8_t k1 = classify(c1);
+    uint32_t cls;
+    if (k1 & kUpper) cls = NC_U; else if (k1 & kLower) cls = NC_L; else if (k1 & kLetter) cls = NC_LO; else if (k1 & (kDigit | kMark)) continue; else cls = NC_O;
+    if (c1.r == ' ' || c1.r == '\'') continue;                             // (no character of the range turns into one of these)
+    std::vector<uint8_t> low;
+    put_lower(low, c1);                                                    // what capcode writes for a capital (:918, :986)
+    if ((size_t)c1.n == t.size() && c1.n == 2) {                           // stays one two-byte character
+      if (low.size() != 2) continue;
+      e.a = cls | NT_OK | ((uint32_t)t[0] << 8) | ((uint32_t)t[1] << 16);
+      e.b = (uint32_t)low[0] | ((uint32_t)low[1] << 8);
+    } else if (c1.n == 1 && t.size() == 3) {                               // ASCII letter + one combining mark
+      const Cp c2 = next_cp(t.data() + 1, 2);
+      if (c2.raw || c2.n != 2 || !(classify(c2) & kMark) || !(k1 & kLetter) || low.size() != 1) continue;
+      e.a = cls | NT_OK | NT_DECOMP | ((uint32_t)t[0] << 8) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 24);
+      e.b = (uint32_t)low[0] | ((uint32_t)t[1] << 8);
+    }
+  }
 }
 
 // capcode level 1 has no statement in the reference tree: refused rather than guessed

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "tm_device.h"
+#include "tm_norm_masks.h"
 
 namespace tmh {
 
@@ -108,6 +109,7 @@ struct tm_batch {
   uint8_t* d_piece_carry = nullptr;     // per-piece carries (pass 2)
   uint32_t* d_piece_len = nullptr;      // normalized bytes per piece (pass 3)
   uint64_t* d_piece_off = nullptr;      // their exclusive scan
+  tmh::NmTwo* d_two = nullptr;          // the device normalizer's table of the two-byte characters (tm_norm_masks.h)
   uint8_t* d_need_host = nullptr;       // per document: needs the host normalizer
   uint64_t* d_nbegin = nullptr;         // normalized document ranges (GPU documents packed first, fallback documents after)
   uint64_t* d_nend = nullptr;

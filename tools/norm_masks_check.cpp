@@ -28,9 +28,7 @@ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
   if (c == ' ') return NC_SP;
   return NC_O;
 }
-bool npunct3(uint32_t b1, uint32_t b2) {
-  return (b1 == 0x80u && ((b2 >= 0x90u && b2 <= 0xA7u) || (b2 >= 0xB0u && b2 <= 0xBFu))) || (b1 == 0x81u && b2 >= 0x80u && b2 <= 0x9Eu);
-}
+static NmTwo g_two[2][NM_TWO_SIZE];     // [lower_all]: flags 1 (NFD) and 3 (NFD + lowercase)
 // class byte of every byte of a document as norm_load_piece computes it (bytes outside the document read as 0)
 bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t>& f) {
   const int n = (int)d.size();
@@ -39,18 +37,7 @@ bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t
   bool ok_all = true;
   for (int i = 0; i < n; i++) {
     const uint32_t b = d[i];
-    uint32_t fl;
-    if (b < 0x80u) fl = ncls_ascii(b, lower_all);
-    else {
-      const uint32_t m1 = at(i - 1), m2 = at(i - 2), p1 = at(i + 1), p2 = at(i + 2);
-      uint32_t b1 = 0, b2 = 0, cont = 0;
-      bool ok = false;
-      if (b == 0xE2u) { b1 = p1; b2 = p2; ok = true; }
-      else if (m1 == 0xE2u) { b1 = b; b2 = p1; cont = NF_CONT; ok = true; }
-      else if (m2 == 0xE2u) { b1 = m1; b2 = b; cont = NF_CONT; ok = true; }
-      ok = ok && npunct3(b1, b2);
-      fl = ok ? (((b1 == 0x80u && b2 == 0x99u) ? NC_AP : NC_O) | cont) : NF_BAD;
-    }
+    const uint32_t fl = b < 0x80u ? ncls_ascii(b, lower_all) : nm_classify_high(b, at(i - 1), at(i - 2), at(i + 1), at(i + 2), g_two[lower_all ? 1 : 0]);
     if (fl == NF_BAD) ok_all = false;
     f[i] = (uint8_t)fl;
   }
@@ -109,15 +96,24 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
       if (!(V & bit)) continue;
       const int rel = 64 * c + i;
       const uint32_t fl = fat(rel), fp = fat(rel - 1), f2 = fat(rel - 2), f4 = fat(rel - 4);
-      const uint32_t idx = nm_lut_index(fl, fp, (fp & NF_CONT) ? f4 : f2, (uint32_t)((W >> i) & 1ull), (uint32_t)((TX[c] >> i) & 1ull));
+      const uint32_t idx = nm_lut_index((fl & NF_CONT) ? (uint32_t)NC_O : fl, fp, (fp & NF_CONT) ? f4 : f2, (uint32_t)((W >> i) & 1ull), (uint32_t)((TX[c] >> i) & 1ull));
       const uint32_t code = kLut.e[lower_all ? 1 : 0][idx];
-      const uint32_t len = (code & 3u) + 1u;
-      uint32_t o3 = d[pb + rel] | ((code & 4u) << 3);
+      uint32_t len = (code & 3u) + 1u;
+      const uint32_t b = d[pb + rel];
+      uint32_t o3 = b | ((code & 4u) << 3), ysp = ' ';
       if (spC & bit) o3 = 'C';
       if (spW & bit) o3 = 'W';
+      auto rawat = [&](int r) -> uint32_t { const int p = pb + r; return (p < 0 || p >= n) ? 0u : d[p]; };
+      const uint32_t bm1 = rawat(rel - 1), bp1 = rawat(rel + 1);
+      const bool lead2 = nm_two_lead(b), cont2 = nm_cont_byte(b) && nm_two_lead(bm1);
+      if (lead2 || cont2) {
+        const NmTwo e = g_two[lower_all ? 1 : 0][lead2 ? nm_two_index(b, bp1) : nm_two_index(bm1, b)];
+        uint32_t y = 0;
+        if (nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y)) { len = 2; ysp = y; }
+      }
       if (len == 4) out.push_back('D');
       if (len >= 3) out.push_back((uint8_t)(code >> 8));
-      if (len >= 2) out.push_back(' ');
+      if (len >= 2) out.push_back((uint8_t)ysp);
       out.push_back((uint8_t)o3);
     }
     Ucur = Unext;
@@ -166,11 +162,18 @@ int main(int argc, char** argv) {
   uint64_t bad = 0, skipped = 0, total = 0;
   const char* ascii = "aBcDeFGhijKLMnop XYZ  '''1234567890.,-_()\n\tQ";
   const char* multi[] = {"\xE2\x80\x99", "\xE2\x80\x9C", "\xE2\x80\x9D", "\xE2\x80\x94", "\xE2\x80\xA6", "\xE2\x81\x80"};
+  build_two_table(1, g_two[0]);
+  build_two_table(3, g_two[1]);
+  { int ok = 0, dec = 0; for (int k = 0; k < NM_TWO_SIZE; k++) { ok += (g_two[0][k].a & NT_OK) != 0; dec += (g_two[0][k].a & NT_DECOMP) != 0; }
+    printf("two-byte table (NFD): %d of 256 characters on the device, %d of them decompose\n", ok, dec); }
   std::vector<std::string> fixed = {"", "A", "a", "AB", "Ab", "aB", "ABc", "ABC", " ABC d", "HTTPServer2Go x", "X's Y'S it's 'a' I'M", "12AB34cd", "A1B2c",
                                     "X\xE2\x80\x99s Y\xE2\x80\x99S it\xE2\x80\x99s", std::string(200, 'A') + "b", std::string(200, 'A'),
                                     "a" + std::string(130, 'B') + " " + std::string(70, 'C') + "d", std::string(3000, 'A') + "b", std::string(5000, 'Q'),
                                     std::string(1023, 'x') + " Abc", std::string(1023, 'x') + "A" + "bc", std::string(1022, 'x') + " A" + std::string(1100, 'B') + "c",
-                                    std::string(1024, 'A') + std::string(1024, '1') + "z", std::string(1020, ' ') + "AB'\xE2\x80\x99" + "cD"};
+                                    std::string(1024, 'A') + std::string(1024, '1') + "z", std::string(1020, ' ') + "AB'\xE2\x80\x99" + "cD",
+                                    "\xC3\x89t\xC3\xA9 \xC3\x80 la carte", "\xC3\x89\xC3\x89\xC3\x89 x \xC3\x89\xC3\x89" "b", "na\xC3\xAFve caf\xC3\xA9's \xC3\x86on \xC3\x98L", "stra\xC3\x9F" "e \xC2\xAB" "a\xC2\xBB 1\xC2\xBA 2\xC2\xAA",
+                                    "\xC5\x81\xC3\xB3" "d\xC5\xBA \xC4\x8C\xC4\x8D" "SR \xC4\xB0stanbul \xC4\xB1\xC5\xBF", std::string(1023, 'x') + "\xC3\x89" "b", std::string(1022, 'x') + " \xC3\x89" + std::string(40, 'A') + "c",
+                                    std::string(63, 'a') + "\xC3\xA9\xC3\xA9", "l'\xC3\xA9t\xC3\xA9 d'\xC3\x89" "mile 3\xC3\xA8me \xC3\xA9's"};
   for (int lower = 0; lower < 2; lower++) {
     const uint32_t flag = lower ? 3u : 1u;
     for (const auto& s : fixed) { std::vector<uint8_t> d(s.begin(), s.end()); total++; if (!check_doc(d, flag, &skipped)) bad++; }
@@ -180,10 +183,17 @@ int main(int argc, char** argv) {
       size_t len = mode == 0 ? rng.below(200) : mode == 1 ? 1024u * (1 + rng.below(3)) - 40 + rng.below(80) : mode == 2 ? 64u * (1 + rng.below(40)) - 4 + rng.below(8) : rng.below(5000);
       std::vector<uint8_t> d;
       const uint32_t style = rng.below(5);      // 0 mixed, 1 capitals-heavy, 2 digits/apostrophes-heavy, 3 spaces + capitals, 4 long runs
+      const bool latin = rng.below(2) != 0;     // half of the documents carry accented Latin letters, a few of them a lot
+      const uint32_t latin_share = rng.below(4) == 0 ? 40 : 6;
       while (d.size() < len) {
         const uint32_t r = rng.below(100);
         if (style == 4 && r < 30) { const char ch = "AB1'a "[rng.below(6)]; const uint32_t rep = 1 + rng.below(150); for (uint32_t q = 0; q < rep; q++) d.push_back((uint8_t)ch); continue; }
         if (r < 4) { const char* mchar = multi[rng.below(6)]; d.insert(d.end(), mchar, mchar + 3); continue; }
+        if (latin && r < 4 + latin_share) {      // a character of U+00A0..U+017F (now and then an unsupported or broken one: the document then takes the host path)
+          const uint32_t cp = rng.below(40) == 0 ? 0x80 + rng.below(0x100) : (rng.below(3) ? 0xC0 + rng.below(0x40) : 0xA0 + rng.below(0xE0));
+          d.push_back((uint8_t)(0xC0 | (cp >> 6))); if (rng.below(300)) d.push_back((uint8_t)(0x80 | (cp & 0x3F)));
+          continue;
+        }
         if (style == 1 && r < 60) { d.push_back((uint8_t)('A' + rng.below(26))); continue; }
         if (style == 2 && r < 60) { d.push_back((uint8_t)("0123456789''"[rng.below(12)])); continue; }
         if (style == 3 && r < 50) { d.push_back(rng.below(2) ? ' ' : (uint8_t)('A' + rng.below(26))); continue; }
