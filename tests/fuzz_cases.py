@@ -109,7 +109,8 @@ def one_norm(seed):
             elif r < 0.35:
                 parts.append("".join(rng.choice(NORM_ALPHABET[:36], size=int(rng.integers(1, 30)))))
             elif r < 0.55:
-                parts.append(str(rng.choice(["A", "Q", "AB", "Ab", "I'M", "X\u2019S", "A1", "1A", "a'B"])) * int(rng.integers(1, 400)))
+                # (runs of digits / apostrophes without a capital, longer than the 64-byte margins of the one-pass normalizer: the exact path)
+                parts.append(str(rng.choice(["A", "Q", "AB", "Ab", "I'M", "X\u2019S", "A1", "1A", "a'B", "7", "'", "12'", "É", "é1"])) * int(rng.integers(1, 400)))
             elif r < 0.75:
                 parts.append("x" * int(rng.integers(1, 1100)))
             elif r < 0.95:

@@ -35,7 +35,7 @@ using namespace tmh;
 // layout of the device part never waits for the host.
 namespace tmh {
 
-constexpr int PIECE = 1024, PMARGIN = 8, PLDS = PIECE + 2 * PMARGIN;
+constexpr int PIECE = 1024, PMARGIN = 68, PLDS = PIECE + 2 * PMARGIN;      // 64 bytes of margin either side (k_norm_emit2<false> takes its carries from them) + 4 that the classifier looks at
 // character classes NC_* and flag bits NF_*: tm_norm_masks.h
 // piece summary bits
 constexpr uint32_t PS_WHOLE = 1u, PS_LEADU_SHIFT = 1, PS_LEADTL = 8u, PS_TRAILU_SHIFT = 5, PS_FIRSTBLOCK = 128u, PS_FIRSTL = 256u, PS_BAD = 512u;
@@ -338,10 +338,15 @@ struct PieceLds2 { uint8_t raw[PLDS]; uint8_t f[PLDS]; alignas(16) uint8_t out[2
 
 __device__ const NmLut g_norm_lut = nm_make_lut();
 
+// CARRY = true: the carries of the piece (inWord at its first byte, how the block at its end ends) and the documents that need the host
+// normalizer are known (k_norm_summary + k_norm_carry have run: the exact path).  CARRY = false (the usual path): no pass before this
+// one — the carries come from the 64 bytes either side of the piece (nm_margin_carries), a piece whose margins cannot tell raises
+// overflow[1] and the exact path runs after all; a piece that finds a byte it cannot normalize marks its document in need_host.
+template <bool CARRY>
 __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rbegin,
                                                     const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
                                                     const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t lower_all,
-                                                    const uint8_t* __restrict__ piece_carry, const uint8_t* __restrict__ need_host,
+                                                    const uint8_t* __restrict__ piece_carry, uint8_t* __restrict__ need_host,
                                                     uint32_t* __restrict__ piece_len, uint8_t* __restrict__ slab,
                                                     unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two) {
   constexpr int SLAB2 = 2 * PIECE, NCH = PIECE / 64;
@@ -361,23 +366,30 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   if (k >= npieces) return;
   PieceLds2& L = s_l[wv];
   const uint32_t d = piece_doc[k];
-  if (need_host[d]) { if (lane == 0) piece_len[k] = 0; return; }
+  if (CARRY && need_host[d]) { if (lane == 0) piece_len[k] = 0; return; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
   const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, s_two));
-  const uint32_t carry = __builtin_amdgcn_readfirstlane((uint32_t)piece_carry[k]);
-  const unsigned long long carry_tl = (carry >> 4) & 1u;
+  const uint32_t carry = CARRY ? __builtin_amdgcn_readfirstlane((uint32_t)piece_carry[k]) : 0u;
   const int nch = (m + 63) >> 6;
   // all chunks but the last are whole; the piece boundary m lies in chunk m >> 6 (which is chunk nch when m is a multiple of 64)
   const unsigned long long v_last = nm_valid(nch - 1, m);
   const int c_bnd = m >> 6;
-  const unsigned long long bnd_bit = carry_tl << (m & 63);
-  const uint8_t* fl0 = L.f + PMARGIN + lane;       // class byte of byte (64 c + lane) of the piece = fl0[64 c]
-  // norm_load_piece has classified the LDS bytes from six before the piece to five after its 1024 (all the rules ever reach);
-  // a ballot over chunk c must not look at lanes outside that range
+  const uint8_t* fl0 = L.f + PMARGIN + lane;       // class byte of byte (64 c + lane) of the piece = fl0[64 c]; chunk -1 and chunk NCH are the margins
+  // (norm_load_piece has classified the LDS bytes from 66 before the piece to 66 after its 1024)
+  unsigned long long w_seed = (carry & 3u) ? 1ull : 0ull, carry_tl = (carry >> 4) & 1u, lx_after = carry_tl;
+  if (!CARRY) {
+    const uint32_t fb = fl0[-64], fa = m == PIECE ? (uint32_t)fl0[64 * NCH] : 0u;       // (a shorter piece is the last of its document: nothing follows)
+    uint64_t w_in, tx_after, lx0_after;
+    const bool known = nm_margin_carries(__ballot((fb & NF_BLOCK) != 0), __ballot((fb & NF_CLASS) == NC_U), __ballot((fa & NF_BLOCK) != 0), __ballot((fa & NF_CLASS) == NC_L),
+                                         &w_in, &tx_after, &lx0_after);
+    if (!known && lane == 0) atomicAdd(overflow + 1, 1ull);
+    w_seed = w_in; carry_tl = tx_after; lx_after = lx0_after;
+  }
   // ---- backward sweep: TX[c] = 'C'-lookahead of the block bytes of chunk c (+ the piece boundary bit) ------------------------
+  const unsigned long long bnd_bit = (CARRY ? carry_tl : 0ull) << (m & 63);       // (with margins the chunk behind the piece is a chunk like any other: no boundary bit)
   unsigned long long TX[NCH + 1];
   {
-    unsigned long long tx_next = ((m & 63) == 0) ? carry_tl : 0ull, lx_next0 = tx_next;
+    unsigned long long tx_next = ((m & 63) == 0) ? carry_tl : 0ull, lx_next0 = ((m & 63) == 0) ? lx_after : 0ull;
 #pragma unroll
     for (int c = NCH; c >= 0; c--) {
       TX[c] = 0ull;
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   typedef TM_LDS_SPACE uint8_t lds_u8;
   const uint32_t out0 = TM_LDS_ADDR(L.out);
   const uint32_t dump = out0 + (uint32_t)SLAB2 + (uint32_t)lane;     // where a lane's "not this byte" stores go
-  unsigned long long w = (carry & 3u) ? 1ull : 0ull;
+  unsigned long long w = w_seed, badm = 0ull;
   uint32_t pos = 0;
   bool over = false;
   unsigned long long Ucur = __ballot((fl0[0] & NF_CLASS) == NC_U);
@@ -406,12 +418,13 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   for (int c = 0; c < NCH; c++) {
     if (c < nch) {
       // capitals of the next chunk (its first byte may be the capital a trailing space announces); chunk 16 is the six margin bytes
-      const uint32_t fnext = (c + 1 < NCH || lane <= 5) ? (uint32_t)fl0[64 * (c + 1)] : 0u;
+      const uint32_t fnext = fl0[64 * (c + 1)];
       const unsigned long long Unext = __ballot((fnext & NF_CLASS) == NC_U);
       const uint32_t fl = fl0[64 * c], fp = fl0[64 * c - 1], f2 = fl0[64 * c - 2], f4 = fl0[64 * c - 4];
       const uint32_t b = L.raw[PMARGIN + 64 * c + lane];
       uint64_t w_out, spC, spW;
       const unsigned long long V = c == nch - 1 ? v_last : ~0ull;
+      if (!CARRY) badm |= __ballot(fl == NF_BAD) & V;
       const unsigned long long W = nm_inword(__ballot((fl & NF_BLOCK) != 0), Ucur, V, w, &w_out);
       nm_space_markers(__ballot((fl & NF_CLASS) == NC_SP), Ucur, Unext, V, TX[c], TX[c + 1], &spC, &spW);
       w = w_out;
@@ -463,7 +476,20 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   if (lane == 0) {
     piece_len[k] = pos;
     if (pos > (uint32_t)SLAB2) atomicAdd(overflow, 1ull);
+    if (!CARRY && badm != 0ull) need_host[d] = 1;      // (every writer writes 1; the piece lengths of such a document are zeroed by k_norm_bad_pieces)
   }
+}
+
+
+// behind k_norm_emit2<false>: the pieces of the documents that turned out to need the host normalizer count for nothing, and those documents
+// are listed for the host (in no particular order)
+__global__ void k_norm_bad_pieces(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, uint64_t npieces, uint32_t* __restrict__ piece_len) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < npieces && need_host[piece_doc[k]]) piece_len[k] = 0;
+}
+__global__ void k_norm_bad_docs(const uint8_t* __restrict__ need_host, uint32_t ndocs, unsigned long long* __restrict__ ninfo, uint32_t* __restrict__ fb_ids) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < ndocs && need_host[d]) fb_ids[atomicAdd(&ninfo[0], 1ull)] = d;
 }
 
 // pack the slabs: piece k's bytes go to out[piece_off[k] ..)
@@ -642,24 +668,41 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   launch_doc_units(b->d_raw_off, b->d_raw_off + 1, nd, (uint32_t)PIECE, b->d_doc_npiece, st);
   scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
   const uint32_t pgrid = (uint32_t)((np + 3) / 4);
-  if (np > 0) {
-    launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
-    TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_two, b->d_piece_sum);
+  if (np > 0) launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
+  unsigned long long h_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // The usual path is ONE pass over the raw text: k_norm_emit2<false> takes the carries of a piece from the 64 bytes either side of it and
+  // finds the documents that need the host normalizer as it goes.  A piece whose margins cannot tell (a run of 64 digits / apostrophes /
+  // capitals across a piece boundary) or whose output outgrows its slab sends the batch through the exact path after all: summaries of the
+  // pieces, carries per document, then the same emit kernel with the carries given.
+  bool fast = np > 0 && capcode == 2 && normalize_on_device(capcode, norm_flag) && !(tm_debug_flags(-1) & 256);
+  if (fast) {
+    (void)hipMemsetAsync(b->d_need_host, 0, nd, st);
+    TM_LAUNCH(k_norm_emit2<false>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
+                                               b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
+    TM_LAUNCH(k_norm_bad_pieces, (uint32_t)((np + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, np, b->d_piece_len);
+    TM_LAUNCH(k_norm_bad_docs, (nd + 255) / 256, 256, 0, st, b->d_need_host, nd, ninfo, b->d_fb_ids);
+    { int rc = small_d2h(b, h_info, ninfo, 40, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
+    if (h_info[3] != 0 || h_info[4] != 0) {
+      fast = false;
+      (void)hipMemsetAsync(ninfo, 0, 64, st);
+    }
   }
-  TM_LAUNCH(k_norm_carry, (nd + 255) / 256, 256, 0, st, b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids,
-                                                  normalize_on_device(capcode, norm_flag) ? 0u : 1u);
-  unsigned long long h_info[4] = {0, 0, 0, 0};
-  { int rc = small_d2h(b, h_info, ninfo, 8, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
+  if (!fast) {
+    if (np > 0) TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_two, b->d_piece_sum);
+    TM_LAUNCH(k_norm_carry, (nd + 255) / 256, 256, 0, st, b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids,
+                                                    normalize_on_device(capcode, norm_flag) ? 0u : 1u);
+    int rc = small_d2h(b, h_info, ninfo, 8, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc;
+  }
   const double t1 = now();
   const uint32_t nf = (uint32_t)h_info[0];
   std::vector<uint32_t> ids;
   std::vector<uint64_t> roff;
   double f1 = now(), f2 = 0, f3 = 0, f4 = 0;
-  // the device normalizes its documents (one pass into per-piece slabs, lengths on the side) ...
-  if (np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
-    TM_LAUNCH(k_norm_emit2, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
-                                        b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
-  else if (np > 0)                    // capcode 0, or debug bit 8: the per-lane version of the rules
+  // the exact path: the device normalizes its documents with the carries given (one pass into per-piece slabs, lengths on the side) ...
+  if (!fast && np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
+    TM_LAUNCH(k_norm_emit2<true>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
+                                              b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
+  else if (!fast && np > 0)           // capcode 0, or debug bit 8: the per-lane version of the rules
     TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                           b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
   scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
@@ -668,7 +711,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     // second stream, so that the fetch does not hold up the pass above
     if (!b->aux_stream && (e = hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
     hipStream_t sx = b->aux_stream;
-    // the (unordered) list k_norm_carry has left on the device, put into document order
+    // the (unordered) list k_norm_carry / k_norm_bad_docs has left on the device, put into document order
     ids.resize(nf);
     { int rc = small_d2h(b, ids.data(), b->d_fb_ids, (uint64_t)nf * 4, sx); if (rc == TM_OK) rc = small_sync(b, sx); if (rc != TM_OK) return rc; }
     std::sort(ids.begin(), ids.end());

@@ -120,6 +120,20 @@ TM_HD void nm_space_markers(uint64_t SP, uint64_t U, uint64_t next_u0, uint64_t 
   *spW = spM & ~nextT;
 }
 
+// The carries of a piece from its MARGINS instead of from a pass over the whole document (k_norm_emit2<false>): the 64 bytes before
+// the piece say whether its first byte is inside a word — unless all 64 are one block without a capital, which may still have one
+// further back —, the 64 bytes after a full piece say how the block that reaches its end ends — unless all 64 still belong to it.
+// Bb / Ub: ballots "in a block" / "capital" of the bytes before; Ba / La: "in a block" / "lower-case letter" of the bytes after (all
+// zero when the text ends with the piece).  *w_in: W of byte 0; *tx_after / *lx0_after: what nm_backward wants to know about the
+// chunk behind the piece.  Returns false when the margins cannot tell: the exact path (summaries + carries) has to run.
+TM_HD bool nm_margin_carries(uint64_t Bb, uint64_t Ub, uint64_t Ba, uint64_t La, uint64_t* w_in, uint64_t* tx_after, uint64_t* lx0_after) {
+  uint64_t w_out;
+  (void)nm_inword(Bb, Ub, ~0ull, 0ull, &w_out);
+  *w_in = w_out;
+  *tx_after = nm_backward(Ba, La, ~0ull, 0ull, 0ull, 0ull, lx0_after);
+  return !((Bb == ~0ull && Ub == 0ull) || Ba == ~0ull);
+}
+
 // ---- the rule table ------------------------------------------------------------------------------------------------------
 // index: class [0..2] | class of the previous byte [3..5] | class two characters back, looked at only behind an apostrophe
 //        [6..8] | W [9] | T [10]

@@ -28,6 +28,7 @@ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
   if (c == ' ') return NC_SP;
   return NC_O;
 }
+static uint64_t g_margin_ok = 0, g_margin_unknown = 0;
 static NmTwo g_two[2][NM_TWO_SIZE];     // [lower_all]: flags 1 (NFD) and 3 (NFD + lowercase)
 // class byte of every byte of a document as norm_load_piece computes it (bytes outside the document read as 0)
 bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t>& f) {
@@ -47,21 +48,23 @@ bool is_block(uint32_t cls) { return (cls & NF_BLOCK) != 0; }
 
 // what k_norm_emit2 does for one piece: returns the bytes
 static const NmLut kLut = nm_make_lut();
-void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, int pb, int m, bool w_in, bool carry_tl, bool lower_all,
+// (margins == true: w_in / tx_after / lx_after come from nm_margin_carries, the piece boundary carries no bit of its own: k_norm_emit2<false>)
+void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, int pb, int m, bool w_in, uint64_t tx_after, uint64_t lx_after, bool margins, bool lower_all,
                 std::vector<uint8_t>& out) {
+  const bool carry_tl = !margins && (tx_after & 1ull);
   const int n = (int)d.size();
   // class byte at piece-relative position rel, as the kernel's LDS holds it: classified from six bytes before the piece to five
   // after its 1024; bytes outside the document read as class O
   auto fat = [&](int rel) -> uint32_t {
     const int p = pb + rel;
-    if (rel < -6 || rel > PIECE + 5) { fprintf(stderr, "harness: class byte %d outside the classified LDS range\n", rel); abort(); }
+    if (rel < -66 || rel > PIECE + 65) { fprintf(stderr, "harness: class byte %d outside the classified LDS range\n", rel); abort(); }
     return (p < 0 || p >= n) ? (uint32_t)NC_O : (uint32_t)f[p];
   };
   auto ballot = [&](int c, auto pred) -> uint64_t {
     uint64_t r = 0;
     for (int i = 0; i < 64; i++) {
       const int rel = 64 * c + i;
-      if (rel < -6 || rel > PIECE + 5) continue;             // lanes the kernel masks off
+      if (rel < -66 || rel > PIECE + 65) continue;
       if (pred(fat(rel))) r |= 1ull << i;
     }
     return r;
@@ -73,11 +76,11 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
   const int nch = (m + 63) / 64;
   uint64_t TX[18] = {0};
   {
-    uint64_t tx_next = (m % 64 == 0 && carry_tl) ? 1ull : 0ull, lx_next0 = tx_next;   // boundary exactly at the start of chunk nch
+    uint64_t tx_next = m % 64 == 0 ? (margins ? tx_after : (carry_tl ? 1ull : 0ull)) : 0ull, lx_next0 = m % 64 == 0 ? (margins ? lx_after : tx_next) : 0ull;   // boundary exactly at the start of chunk nch
     if (nch <= 16) TX[nch] = tx_next;
     for (int c = nch - 1; c >= 0; c--) {
       uint64_t lx0;
-      TX[c] = nm_backward(ballot(c, is_b), ballot(c, is_l), nm_valid(c, m), carry_tl ? nm_boundary(c, m) : 0ull, tx_next, lx_next0, &lx0);
+      TX[c] = nm_backward(ballot(c, is_b), ballot(c, is_l), nm_valid(c, m), (carry_tl && !margins) ? nm_boundary(c, m) : 0ull, tx_next, lx_next0, &lx0);
       tx_next = TX[c];
       lx_next0 = lx0;
     }
@@ -136,7 +139,26 @@ bool check_doc(const std::vector<uint8_t>& d, uint32_t norm_flag, uint64_t* skip
       while (j < n && is_block(f[j] & 7u)) j++;
       carry_tl = j < n && (f[j] & 7u) == NC_L;
     }
-    emit_piece(d, f, pb, m, w_in, carry_tl, lower_all, got);
+    // the carries as k_norm_emit2<false> finds them: from the 64 bytes either side of the piece; when they cannot tell, the exact path
+    // (the document-wide carries above) runs on the device too
+    auto cls_at = [&](int p) -> uint32_t { return (p < 0 || p >= n) ? (uint32_t)NC_O : (uint32_t)f[p]; };
+    uint64_t Bb = 0, Ub = 0, Ba = 0, La = 0;
+    for (int i = 0; i < 64; i++) {
+      const uint32_t fb = cls_at(pb - 64 + i), fa = m == PIECE ? cls_at(pb + PIECE + i) : 0u;
+      if (fb & NF_BLOCK) Bb |= 1ull << i;
+      if ((fb & NF_CLASS) == NC_U) Ub |= 1ull << i;
+      if (fa & NF_BLOCK) Ba |= 1ull << i;
+      if ((fa & NF_CLASS) == NC_L) La |= 1ull << i;
+    }
+    uint64_t w_m, tx_a, lx_a;
+    if (nm_margin_carries(Bb, Ub, Ba, La, &w_m, &tx_a, &lx_a)) {
+      g_margin_ok++;
+      if ((w_m != 0) != w_in) { fprintf(stderr, "MARGIN: inWord seed %d, the document says %d (piece at %d)\n", (int)w_m, (int)w_in, pb); return false; }
+      emit_piece(d, f, pb, m, w_m != 0, tx_a, lx_a, true, lower_all, got);
+    } else {
+      g_margin_unknown++;
+      emit_piece(d, f, pb, m, w_in, carry_tl ? 1ull : 0ull, 0ull, false, lower_all, got);
+    }
   }
   uint8_t* exp = nullptr; size_t exp_n = 0;
   if (tm_normalize(d.data(), d.size(), 2, norm_flag, &exp, &exp_n) != 0) { fprintf(stderr, "tm_normalize failed\n"); return false; }
@@ -215,6 +237,7 @@ int main(int argc, char** argv) {
       if (!check_doc(d, 1, &skipped)) bad++;
     }
   }
+  printf("pieces whose carries came from their margins: %llu; margins could not tell (exact path): %llu\n", (unsigned long long)g_margin_ok, (unsigned long long)g_margin_unknown);
   printf("%llu documents, %llu skipped (host-fallback class), %llu mismatches\n", (unsigned long long)total, (unsigned long long)skipped, (unsigned long long)bad);
   return bad ? 1 : 0;
 }
