@@ -446,7 +446,7 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
       if ((rc = small_sync(b, l->stream)) != TM_OK) break;
       if (fits && out_b && !out_pinned) std::memcpy(bytes_out + base * encoding_length, l->h_stage, out_b);
       for (uint32_t d = 1; d <= nd; d++) byte_offsets[d0 + d] = (base + toff[d]) * encoding_length;
-      if (stats) { std::lock_guard<std::mutex> g(mu); stats->host_fallback_docs += raw ? b->host_fallback_docs : 0; stats->normalized_bytes += b->doc_bytes; }
+      if (stats) { std::lock_guard<std::mutex> g(mu); stats->host_fallback_docs += raw ? b->host_fallback_docs : 0; stats->normalized_bytes += b->nbytes; }
       k = k_next;
       prefetched = next_up;
       if (next_up) { loc.swap(loc_next); src = src_next; }

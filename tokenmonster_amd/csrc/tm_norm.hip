@@ -334,9 +334,6 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
 // and the 'C'/'W' lookahead — are flood fills on the chunk's class ballots, done by the scalar unit; the rule chain is a
 // 2048-entry table in LDS (tm_norm_masks.h; both checked on the CPU by tools/norm_masks_check.cpp); the output is assembled in
 // LDS and leaves for the slab in 16-byte stores.
-__device__ __forceinline__ unsigned long long shfl_u64v(unsigned long long v, int src) {
-  return (unsigned long long)(uint32_t)__shfl((int)(uint32_t)v, src) | ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32);
-}
 struct PieceLds2 { uint8_t raw[PLDS]; uint8_t f[PLDS]; alignas(16) uint8_t out[2 * PIECE + 64]; };   // out: slab image + one dump byte per lane
 
 __device__ const NmLut g_norm_lut = nm_make_lut();
@@ -351,9 +348,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
                                                     const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t lower_all,
                                                     const uint8_t* __restrict__ piece_carry, uint8_t* __restrict__ need_host,
                                                     uint32_t* __restrict__ piece_len, uint8_t* __restrict__ slab,
-                                                    unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two,
-                                                    unsigned long long* __restrict__ status, uint64_t* __restrict__ piece_off, uint8_t* __restrict__ text_out,
-                                                    uint64_t text_cap, uint64_t* __restrict__ total_out) {
+                                                    unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two) {
   constexpr int SLAB2 = 2 * PIECE, NCH = PIECE / 64;
   __shared__ PieceLds2 s_l[4];
   __shared__ uint8_t s_cls[128];
@@ -473,58 +468,25 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-  if (CARRY) {
-    if (!over) {
-      uint8_t* dst = slab + k * (uint64_t)SLAB2;
-      for (uint32_t j = (uint32_t)lane * 16u; j < pos; j += 64u * 16u)
-        *reinterpret_cast<uint4*>(dst + j) = *reinterpret_cast<const uint4*>(L.out + j);    // the slab is 16-byte aligned and 2 KiB long
-    }
-    if (lane == 0) {
-      piece_len[k] = pos;
-      if (pos > (uint32_t)SLAB2) atomicAdd(overflow, 1ull);
-    }
-    return;
+  if (!over) {
+    uint8_t* dst = slab + k * (uint64_t)SLAB2;
+    for (uint32_t j = (uint32_t)lane * 16u; j < pos; j += 64u * 16u)
+      *reinterpret_cast<uint4*>(dst + j) = *reinterpret_cast<const uint4*>(L.out + j);    // the slab is 16-byte aligned and 2 KiB long
   }
-  // ---- one pass: where the piece goes is the sum of the lengths of all pieces before it, found by looking back over the pieces that are
-  // under way (a chained scan with decoupled look-back: a piece publishes its own length at once - flag A - and the sum up to and including
-  // itself - flag P - as soon as it knows it; a successor adds up the A's behind it until it meets a P).  Workgroups start in index order, so
-  // whatever a piece waits for is running or done.  status[k] = flag << 62 | value, one relaxed 64-bit store / load each.
-  constexpr unsigned long long FLAG_A = 1ull << 62, FLAG_P = 2ull << 62, VAL = FLAG_A - 1ull;
   if (lane == 0) {
+    piece_len[k] = pos;
     if (pos > (uint32_t)SLAB2) atomicAdd(overflow, 1ull);
-    if (badm != 0ull) need_host[d] = 1;      // (every writer writes 1; such a document's bytes stay where they fall - dead space - and its range is set by k_place_fallback)
-    __atomic_store_n(&status[k], (k == 0 ? FLAG_P : FLAG_A) | (unsigned long long)pos, __ATOMIC_RELAXED);
-  }
-  unsigned long long excl = 0ull;
-  if (k > 0) {
-    for (long long idx = (long long)k - 1;; idx -= 64) {
-      const long long j = idx - lane;
-      unsigned long long st;
-      do { st = j >= 0 ? __atomic_load_n(&status[j], __ATOMIC_RELAXED) : FLAG_P; } while (__any((st >> 62) == 0ull));
-      const unsigned long long pm = __ballot((st >> 62) == 2ull);
-      const int first = pm ? __ffsll((long long)pm) - 1 : 64;                // the nearest piece that knows its inclusive sum
-      uint32_t a = lane < first ? (uint32_t)(st & VAL) : 0u;                  // the lengths of the pieces between it and this one
-      for (int o = 32; o > 0; o >>= 1) a += (uint32_t)__shfl_xor((int)a, o);
-      excl += a;
-      if (pm) { excl += shfl_u64v(st & VAL, first); break; }
-    }
-    if (lane == 0) __atomic_store_n(&status[k], FLAG_P | (excl + pos), __ATOMIC_RELAXED);
-  }
-  if (lane == 0) {
-    piece_off[k] = excl;
-    if (k + 1 == npieces) { piece_off[npieces] = excl + pos; *total_out = excl + pos; }
-    if (excl + pos > text_cap) atomicAdd(overflow + 2, 1ull);                  // the normalized text outgrows the workspace: TM_E_LIMIT
-  }
-  if (!over && excl + pos <= text_cap) {
-    uint8_t* dst = text_out + excl;
-    for (uint32_t j = (uint32_t)lane * 16u; j < pos; j += 64u * 16u) {
-      if (j + 16u <= pos) { uint4 q = *reinterpret_cast<const uint4*>(L.out + j); __builtin_memcpy(dst + j, &q, 16); }
-      else for (uint32_t t = j; t < pos; t++) dst[t] = L.out[t];
-    }
+    if (!CARRY && badm != 0ull) need_host[d] = 1;      // (every writer writes 1; the piece lengths of such a document are zeroed by k_norm_bad_pieces)
   }
 }
 
-// behind k_norm_emit2<false>: the documents that turned out to need the host normalizer are listed for the host (in no particular order)
+
+// behind k_norm_emit2<false>: the pieces of the documents that turned out to need the host normalizer count for nothing, and those documents
+// are listed for the host (in no particular order)
+__global__ void k_norm_bad_pieces(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, uint64_t npieces, uint32_t* __restrict__ piece_len) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < npieces && need_host[piece_doc[k]]) piece_len[k] = 0;
+}
 __global__ void k_norm_bad_docs(const uint8_t* __restrict__ need_host, uint32_t ndocs, unsigned long long* __restrict__ ninfo, uint32_t* __restrict__ fb_ids) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d < ndocs && need_host[d]) fb_ids[atomicAdd(&ninfo[0], 1ull)] = d;
@@ -557,11 +519,10 @@ __global__ void k_norm_ranges(const uint64_t* __restrict__ piece_off, const uint
 __global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t* __restrict__ nend, uint32_t ndocs, unsigned long long* __restrict__ ninfo,
                             uint32_t long_segs) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t nseg = 0, nb = 0;
-  if (d < ndocs) { nb = nend[d] - nbegin[d]; nseg = (nb + SEG - 1) / SEG; if (nseg > long_segs) atomicAdd(&ninfo[1], 1ull); }
-  for (int o = 32; o > 0; o >>= 1) { nseg += __shfl_xor(nseg, o); nb += __shfl_xor(nb, o); }
+  uint64_t nseg = 0;
+  if (d < ndocs) { nseg = (nend[d] - nbegin[d] + SEG - 1) / SEG; if (nseg > long_segs) atomicAdd(&ninfo[1], 1ull); }
+  for (int o = 32; o > 0; o >>= 1) nseg += __shfl_xor(nseg, o);
   if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&ninfo[2], (unsigned long long)nseg);
-  if ((threadIdx.x & 63) == 0 && nb) atomicAdd(&ninfo[6], (unsigned long long)nb);      // bytes of the documents (the text may hold dead space: the pieces of documents that went to the host after all)
 }
 // One side of these two copies is pinned HOST memory, reached over PCIe: that side is accessed in aligned 16-byte units (a byte
 // per lane made a 64-byte request per wavefront), the device side at whatever alignment is left.
@@ -661,12 +622,12 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
     if (rc != TM_OK) return rc;
   }
   if (!b->d_piece_doc || npieces + 2 > b->piece_cap) {
-    void** ps[] = {(void**)&b->d_piece_doc, (void**)&b->d_piece_sum, (void**)&b->d_piece_carry, (void**)&b->d_piece_len, (void**)&b->d_piece_off, (void**)&b->d_piece_status};
+    void** ps[] = {(void**)&b->d_piece_doc, (void**)&b->d_piece_sum, (void**)&b->d_piece_carry, (void**)&b->d_piece_len, (void**)&b->d_piece_off};
     for (void** q : ps) { (void)hipFree(*q); *q = nullptr; }
     b->piece_cap = npieces + npieces / 4 + 16;
     if ((e = hipMalloc((void**)&b->d_piece_doc, b->piece_cap * 4)) != hipSuccess || (e = hipMalloc((void**)&b->d_piece_sum, b->piece_cap * 4)) != hipSuccess ||
         (e = hipMalloc((void**)&b->d_piece_carry, b->piece_cap)) != hipSuccess || (e = hipMalloc((void**)&b->d_piece_len, b->piece_cap * 4)) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_piece_off, (b->piece_cap + 1) * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_piece_status, (b->piece_cap + 1) * 8)) != hipSuccess)
+        (e = hipMalloc((void**)&b->d_piece_off, (b->piece_cap + 1) * 8)) != hipSuccess)
       return hip_fail(e, "hipMalloc (pieces)");
   }
   if ((e = grow(&b->d_slab, &b->slab_cap, (npieces + 1) * (uint64_t)SLAB)) != hipSuccess) return hip_fail(e, "hipMalloc (normalizer slabs)");
@@ -695,7 +656,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   b->host_fallback_docs = 0;
   b->d_doc_begin = b->d_nbegin;
   b->d_doc_end = b->d_nend;
-  b->ndocs = nd; b->nbytes = 0; b->doc_bytes = 0; b->nseg = 0; b->ngroups = 0; b->nlong = 0;
+  b->ndocs = nd; b->nbytes = 0; b->nseg = 0; b->ngroups = 0; b->nlong = 0;
   if (nd == 0) return TM_OK;
   static const bool trace = getenv("TM_TRACE") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -716,10 +677,9 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   bool fast = np > 0 && capcode == 2 && normalize_on_device(capcode, norm_flag) && !(tm_debug_flags(-1) & 256);
   if (fast) {
     (void)hipMemsetAsync(b->d_need_host, 0, nd, st);
-    (void)hipMemsetAsync(b->d_piece_status, 0, (size_t)np * 8, st);
     TM_LAUNCH(k_norm_emit2<false>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
-                                               b->d_need_host, b->d_piece_len, nullptr, ninfo + 3, b->d_two, (unsigned long long*)b->d_piece_status, b->d_piece_off, b->d_text,
-                                               b->max_bytes, b->d_totals + 2);
+                                               b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
+    TM_LAUNCH(k_norm_bad_pieces, (uint32_t)((np + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, np, b->d_piece_len);
     TM_LAUNCH(k_norm_bad_docs, (nd + 255) / 256, 256, 0, st, b->d_need_host, nd, ninfo, b->d_fb_ids);
     { int rc = small_d2h(b, h_info, ninfo, 40, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
     if (h_info[3] != 0 || h_info[4] != 0) {
@@ -741,11 +701,11 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   // the exact path: the device normalizes its documents with the carries given (one pass into per-piece slabs, lengths on the side) ...
   if (!fast && np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
     TM_LAUNCH(k_norm_emit2<true>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
-                                              b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two, nullptr, nullptr, nullptr, 0, nullptr);
+                                              b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
   else if (!fast && np > 0)           // capcode 0, or debug bit 8: the per-lane version of the rules
     TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                           b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
-  if (!fast) scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);      // (the one-pass kernel has placed its pieces itself)
+  scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
   if (nf > 0) {
     // ... while the documents it cannot normalize (other non-ASCII content: NFD / Unicode case need ICU) are fetched on a
     // second stream, so that the fetch does not hold up the pass above
@@ -806,7 +766,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     { int rc = small_h2d(b, b->d_fb_noff, noff.data(), noff.size() * 8, sx); if (rc != TM_OK) return rc; }
     TM_LAUNCH(k_place_fallback, (uint32_t)ids.size(), 256, 0, sx, hnorm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), gpu_bytes, b->d_text, b->d_nbegin, b->d_nend);
   }
-  if (np > 0 && !fast) {
+  if (np > 0) {
     if (h_info[3] == 0) {
       TM_LAUNCH(k_norm_compact, pgrid, 256, 0, st, b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text);
     } else {
@@ -827,9 +787,8 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   const double t2 = now();
   // ---- what the tokenize pipeline needs to know on the host: #segments, and the long documents if any ------------
   TM_LAUNCH(k_norm_info, (nd + 255) / 256, 256, 0, st, b->d_nbegin, b->d_nend, nd, ninfo, long_segs());
-  { int rc = small_d2h(b, h_info, ninfo, 56, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
-  b->nbytes = total;               // extent of the text in the workspace
-  b->doc_bytes = h_info[6];        // what the documents add up to
+  { int rc = small_d2h(b, h_info, ninfo, 24, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
+  b->nbytes = total;
   b->nseg = h_info[2];
   int rc = TM_OK;
   if (h_info[1] > 0) {
@@ -842,7 +801,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   return rc;
 }
 
-uint64_t tm_batch_normalized_bytes(const tm_batch* b) { return b->doc_bytes; }
+uint64_t tm_batch_normalized_bytes(const tm_batch* b) { return b->nbytes; }
 uint32_t tm_batch_host_fallback_docs(const tm_batch* b) { return b->host_fallback_docs; }
 
 // D2H of the normalized text of the current batch in DOCUMENT ORDER (for tests): text_out[nbytes], offsets_out[ndocs+1]
@@ -850,7 +809,7 @@ int tm_batch_download_text(tm_batch* b, uint8_t* text_out, uint64_t text_cap, ui
   if (!b) return set_error(TM_E_INVALID, "null argument");
   hipError_t e;
   if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "sync");
-  if (b->doc_bytes > text_cap) return set_error(TM_E_NOSPACE, "text_cap too small");
+  if (b->nbytes > text_cap) return set_error(TM_E_NOSPACE, "text_cap too small");
   const uint32_t nd = b->ndocs;
   std::vector<uint64_t> hb(nd), he(nd);
   std::vector<uint8_t> all(b->nbytes);

@@ -55,7 +55,6 @@ struct tm_batch {
   uint32_t max_docs = 0;
   uint64_t max_segs = 0;
   uint64_t nbytes = 0, nseg = 0;
-  uint64_t doc_bytes = 0;              // after tm_batch_normalize: the bytes of the documents (nbytes may include dead space)
   uint32_t ndocs = 0;
   uint64_t device_bytes = 0;
   hipStream_t last_stream = nullptr;
@@ -110,7 +109,6 @@ struct tm_batch {
   uint8_t* d_piece_carry = nullptr;     // per-piece carries (pass 2)
   uint32_t* d_piece_len = nullptr;      // normalized bytes per piece (pass 3)
   uint64_t* d_piece_off = nullptr;      // their exclusive scan
-  uint64_t* d_piece_status = nullptr;   // one-pass normalizer: flag | length or inclusive sum of every piece (the chained scan of k_norm_emit2<false>)
   tmh::NmTwo* d_two = nullptr;          // the device normalizer's table of the two-byte characters (tm_norm_masks.h)
   uint8_t* d_need_host = nullptr;       // per document: needs the host normalizer
   uint64_t* d_nbegin = nullptr;         // normalized document ranges (GPU documents packed first, fallback documents after)
