@@ -123,6 +123,16 @@ __global__ void k_segments(const uint64_t* __restrict__ doc_seg_start, uint32_t 
   seg_doc[g] = lo;
 }
 
+// narrow T(p,0) rows (vocabularies of at most 65 536 ids): per segment SEG ids (u16), then SEG bytes advance [0..5] | fd' [6] | missing [7]
+constexpr uint64_t R0_NARROW = 3 * SEG;
+// exit map of a segment as K3 reads it: next entry state [0..7] | #ids << 8, R_INVALID = the entry state cannot occur (k_match_branch, step C)
+__device__ __forceinline__ uint32_t exit_entry(const uint16_t* __restrict__ exit16, const uint32_t* __restrict__ exit_wide, uint64_t idx) {
+  const uint32_t x = exit16[idx];
+  if (x == 0xFFFFu) return R_INVALID;
+  const uint32_t c = x >> 7;
+  return c == 511u ? exit_wide[idx] : ((x & 0x7Fu) | (c << 8));
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: match + branch
 // ------------------------------------------------------------------------------------------------
@@ -286,7 +296,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
                                                                 const uint32_t* __restrict__ seg_doc,
                                                                 const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
                                                                 uint32_t* __restrict__ R0, uint2* __restrict__ side,
-                                                                uint32_t* __restrict__ R1, uint32_t* __restrict__ exitmap, int dbg) {
+                                                                uint32_t* __restrict__ R1, uint32_t* __restrict__ exitmap, uint16_t* __restrict__ exit16,
+                                                                int narrow, int dbg) {
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
   const int lane = threadIdx.x & 63, wvi = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the segment, its document and lengths live in SGPRs
@@ -591,7 +602,12 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       const int p = it * 64 + lane;
       r1[it] = ((m1[it] >> lane) & 1ull) ? w.Xb[p] : R_INVALID;
       if (p < seglen) {
-        TM_STREAM_STORE(&R0[g * SEG + p], r0[it]);                 // rows of SEG words per SEGMENT (not per text position): every store is whole aligned lines
+        // rows per SEGMENT (not per text position): every store is whole aligned lines.  With at most 65 536 ids a row is two planes, ids
+        // (u16) and advance | fd' | missing (u8): 768 instead of 1 024 bytes of the largest stream this kernel writes (r0_narrow_* below)
+        if (narrow) {
+          TM_STREAM_STORE(reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(R0) + g * R0_NARROW) + p, (uint16_t)r0[it]);
+          TM_STREAM_STORE(reinterpret_cast<uint8_t*>(R0) + g * R0_NARROW + 2 * SEG + p, (uint8_t)(((r0[it] >> 24) & 63u) | ((r0[it] >> 30) << 6)));
+        } else TM_STREAM_STORE(&R0[g * SEG + p], r0[it]);
         if (!side_ok) TM_STREAM_STORE(&R1[g * SEG + p], r1[it]);   // (rare) too many forward-delete states for the side list
       }
     }
@@ -610,7 +626,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   // state's chain.  (What a chain emits besides its count — forward-deletes, missing characters — is counted by K4, which walks
   // the one chain that is real.)
 #ifdef TM_DEVEL
-  if (dbg & 16) { for (int e = lane; e < ENT; e += 64) exitmap[g * ENT + e] = 0u; return; }   // (timing experiments only)
+  if (dbg & 16) { for (int e = lane; e < ENT; e += 64) exit16[g * ENT + e] = 0u; return; }   // (timing experiments only)
 #endif
   {
     uint32_t* J = reinterpret_cast<uint32_t*>(w.D) + J_SKIP;       // overlays D, Db (dead after step B): 2 x SEG words, state (p, fd) at J[fd * J_PLANE + p]
@@ -688,11 +704,23 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       __builtin_amdgcn_s_waitcnt(0);
       PH_INC(13)
     }
-    // exit map entry: next entry state [0..7] | #ids << 8; 0xFFFFFFFF: the entry state cannot occur
+    // exit map entry (exit_entry below): next entry state [0..6] | #ids << 7 in 16 bits, 0xFFFF: the entry state cannot occur; a count that
+    // does not fit 9 bits (more than 510 ids from one 256-byte segment: one-byte tokens with delete tokens) is written as 511 and the
+    // segment's map goes to the wide array as well (next entry state [0..7] | #ids << 8, 0xFFFFFFFF)
+    bool wide = false;
     for (int e = lane; e < ENT; e += 64) {
       const uint32_t a = J[(e & 1) * J_PLANE + (e >> 1)];
-      const uint32_t t = (a >> JF) & JNONE;
-      TM_STREAM_STORE(&exitmap[g * ENT + e], ((a >> 31) != 0 && t != JNONE) ? (t | ((a & JCNT) << 8)) : R_INVALID);
+      const uint32_t t = (a >> JF) & JNONE, cnt = a & JCNT;
+      const bool ok = (a >> 31) != 0 && t != JNONE;
+      TM_STREAM_STORE(&exit16[g * ENT + e], (uint16_t)(ok ? (t | (min(cnt, 511u) << 7)) : 0xFFFFu));
+      wide |= ok && cnt >= 511u;
+    }
+    if (__any(wide)) {
+      for (int e = lane; e < ENT; e += 64) {
+        const uint32_t a = J[(e & 1) * J_PLANE + (e >> 1)];
+        const uint32_t t = (a >> JF) & JNONE;
+        exitmap[g * ENT + e] = ((a >> 31) != 0 && t != JNONE) ? (t | ((a & JCNT) << 8)) : R_INVALID;
+      }
     }
   }
   PH(7)
@@ -707,7 +735,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 // ------------------------------------------------------------------------------------------------
 // doc_entry (may be null = all 0): the entry state of a document's first segment.  It is 0 for a document; a byte range of a
 // dataset that continues the whole-buffer walk of the range before it enters in the state that walk left (tm_score_begin/finish).
-__global__ void k_resolve(const uint32_t* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs,
+__global__ void k_resolve(const uint32_t* __restrict__ exitmap, const uint16_t* __restrict__ exit16, const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs,
                           const uint8_t* __restrict__ doc_entry, uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
                           uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ error_flag, uint32_t long_segs) {
   uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -718,7 +746,7 @@ __global__ void k_resolve(const uint32_t* __restrict__ exitmap, const uint64_t* 
   for (uint64_t g = g0; g < g1; g++) {
     seg_entry[g] = (uint8_t)e;
     seg_tokbase[g] = ntok;
-    const uint32_t x = exitmap[g * ENT + e];
+    const uint32_t x = exit_entry(exit16, exitmap, g * ENT + e);
     if (x == R_INVALID) { atomicOr(error_flag, 1u); break; }
     e = x & 0xFFu;
     ntok += x >> 8;
@@ -736,7 +764,7 @@ __global__ void k_resolve(const uint32_t* __restrict__ exitmap, const uint64_t* 
 // group map entry (uint2): x = next entry state, y = #ids; x == R_INVALID: unreachable
 
 template <bool LEAF>     // LEAF: the children are segments (exit maps, uint32); otherwise groups of the level below (group maps, uint2)
-__global__ __launch_bounds__(128) void k_group_compose(const uint32_t* __restrict__ exitmap, const uint2* __restrict__ gmap_in, const Group* __restrict__ groups,
+__global__ __launch_bounds__(128) void k_group_compose(const uint32_t* __restrict__ exitmap, const uint16_t* __restrict__ exit16, const uint2* __restrict__ gmap_in, const Group* __restrict__ groups,
                                                        uint32_t first_group, uint2* __restrict__ gmap) {
   const uint32_t gi = first_group + blockIdx.x;
   const Group gr = groups[gi];
@@ -746,7 +774,7 @@ __global__ __launch_bounds__(128) void k_group_compose(const uint32_t* __restric
   bool ok = true;
   for (uint32_t k = 0; k < gr.nchildren; k++) {
     if (LEAF) {
-      const uint32_t x = exitmap[(uint64_t)(gr.first_child + k) * ENT + e];
+      const uint32_t x = exit_entry(exit16, exitmap, (uint64_t)(gr.first_child + k) * ENT + e);
       if (x == R_INVALID) { ok = false; break; }
       e = x & 0xFFu;
       ntok += x >> 8;
@@ -780,7 +808,7 @@ __global__ void k_long_top(const uint2* __restrict__ gmap, const LongDoc* __rest
 }
 
 template <bool LEAF>     // one thread per group of the level: hands its entry state and token base down to its children
-__global__ void k_group_expand(const uint32_t* __restrict__ exitmap, const uint2* __restrict__ gmap, const Group* __restrict__ groups, uint32_t first_group,
+__global__ void k_group_expand(const uint32_t* __restrict__ exitmap, const uint16_t* __restrict__ exit16, const uint2* __restrict__ gmap, const Group* __restrict__ groups, uint32_t first_group,
                                uint32_t ngroups, uint8_t* __restrict__ group_entry, uint32_t* __restrict__ group_base,
                                uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase, uint32_t* __restrict__ error_flag) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -793,7 +821,7 @@ __global__ void k_group_expand(const uint32_t* __restrict__ exitmap, const uint2
     if (LEAF) {
       seg_entry[c] = (uint8_t)e;
       seg_tokbase[c] = ntok;
-      const uint32_t x = exitmap[c * ENT + e];
+      const uint32_t x = exit_entry(exit16, exitmap, c * ENT + e);
       if (x == R_INVALID) { atomicOr(error_flag, 1u); break; }
       e = x & 0xFFu;
       ntok += x >> 8;
@@ -811,7 +839,7 @@ __global__ void k_group_expand(const uint32_t* __restrict__ exitmap, const uint2
 // Exit state of a document for EVERY entry state (one thread per entry state): what a rank hands to its neighbours when a dataset is
 // scored as byte ranges of ONE whole-buffer walk.  Short documents chain their segments' exit maps, long ones their top groups' maps
 // (k_group_compose has composed those for all 80 entry states already).  0xFF: the entry state cannot occur.
-__global__ __launch_bounds__(128) void k_doc_exits(const uint32_t* __restrict__ exitmap, const uint64_t* __restrict__ doc_seg_start, const uint2* __restrict__ gmap,
+__global__ __launch_bounds__(128) void k_doc_exits(const uint32_t* __restrict__ exitmap, const uint16_t* __restrict__ exit16, const uint64_t* __restrict__ doc_seg_start, const uint2* __restrict__ gmap,
                                                    const LongDoc* __restrict__ longs, uint32_t nlong, uint8_t* __restrict__ exits, uint32_t long_segs) {
   const uint32_t d = blockIdx.x, e0 = threadIdx.x;
   if (e0 >= ENT) return;
@@ -831,7 +859,7 @@ __global__ __launch_bounds__(128) void k_doc_exits(const uint32_t* __restrict__ 
     }
   } else {
     for (uint64_t g = g0; g < g1 && ok; g++) {
-      const uint32_t x = exitmap[g * ENT + e];
+      const uint32_t x = exit_entry(exit16, exitmap, g * ENT + e);
       if (x == R_INVALID) ok = false; else e = x & 0xFFu;
     }
   }
@@ -931,7 +959,42 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
 // stream the T(p,0) words of the tile's segments into LDS, position p of segment s at tile[s][TSLACK + p]: lane l fetches words
 // 4l..4l+3 of a row with one aligned 16-byte load (segment g owns words [g * SEG, (g + 1) * SEG) of R0, so a tile is one contiguous
 // block).  All loads are issued before the first LDS write, so a tile costs one HBM latency, not sixteen.
-__device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg& t, uint64_t g0, int nv, int lane, const uint32_t* __restrict__ R0) {
+// narrow != 0: the rows are in the two-plane form (R0_NARROW bytes per segment); `no_id` is the id a missing character gets (the unk token, or none)
+__device__ __forceinline__ void tile_load(uint32_t (*tile)[TROW], const TileSeg& t, uint64_t g0, int nv, int lane, const uint32_t* __restrict__ R0, int narrow, uint32_t no_id) {
+  if (narrow) {
+    static_assert(SEG == 256, "one 8-byte + one 4-byte load per lane fetch a narrow row");
+    uint2 va[TS];
+    uint32_t vb[TS];
+#pragma unroll
+    for (int s = 0; s < TS; s++) {
+      const int ss = s < nv ? s : nv - 1;
+      const uint8_t* row = reinterpret_cast<const uint8_t*>(R0) + (g0 + (uint64_t)ss) * R0_NARROW;
+      const uint32_t len = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;
+      va[s] = make_uint2(0u, 0u); vb[s] = 0u;
+      if (4u * (uint32_t)lane < len) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 q = TM_STREAM_LOAD(reinterpret_cast<const u32x2*>(row) + lane);
+        va[s] = make_uint2(q.x, q.y);
+        vb[s] = TM_STREAM_LOAD(reinterpret_cast<const uint32_t*>(row + 2 * SEG) + lane);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < TS; s++) {
+      uint32_t w4[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t id16 = ((q < 2 ? va[s].x : va[s].y) >> (16 * (q & 1))) & 0xFFFFu, m8 = (vb[s] >> (8 * q)) & 0xFFu;
+        const uint32_t id = (m8 >> 7) ? no_id : id16;              // (a character without a token carries the unk id, or none)
+        w4[q] = id | ((m8 & 63u) << 24) | ((m8 >> 6) << 30);
+      }
+      uint2* dst = reinterpret_cast<uint2*>(&tile[s][TSLACK + 4 * lane]);
+      dst[0] = make_uint2(w4[0], w4[1]);
+      dst[1] = make_uint2(w4[2], w4[3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    return;
+  }
   constexpr int PARTS = SEG / 256;                                       // a row is fetched 256 words (one 16-byte load per lane) at a time
   static_assert(SEG % 256 == 0, "tile_load fetches rows in units of 256 words");
   uint4 v[TS][PARTS];
@@ -978,13 +1041,13 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
                                                    uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
                                                    uint32_t* __restrict__ error_flag, uint32_t stage_after, const uint32_t* __restrict__ seg_doc,
-                                                   uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing) {
+                                                   uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing, int narrow, uint32_t no_id) {
   alignas(16) __shared__ uint32_t s_tile[TS][TROW];
   const int lane = threadIdx.x;
   const uint64_t g0 = (uint64_t)blockIdx.x * TS;
   const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
   const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
-  tile_load(s_tile, t, g0, nv, lane, R0);
+  tile_load(s_tile, t, g0, nv, lane, R0, narrow, no_id);
   // Walk.  Id number E of the segment is staged in word E of its own row while that word lies before the position being read
   // (E < TSLACK + p: true unless the text averages more than one id per byte); from the first id that does not fit, the rest of
   // the segment's ids go straight to HBM.  (stage_after = 0; the tests pass 512 so that nothing is staged: debug bit 10.)
@@ -1045,7 +1108,7 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
                                                         const uint32_t* __restrict__ R1, const uint8_t* __restrict__ text,
                                                         const uint4* __restrict__ par, uint64_t nseg, uint32_t delete_id,
                                                         uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
-                                                        uint32_t* __restrict__ missing_bits, uint32_t* __restrict__ error_flag) {
+                                                        uint32_t* __restrict__ missing_bits, uint32_t* __restrict__ error_flag, int narrow, uint32_t no_id) {
   alignas(16) __shared__ uint32_t s_tile[WV][TS][TROW];
   alignas(16) __shared__ unsigned long long s_w[HSLOTS];
   __shared__ unsigned long long s_ntok;
@@ -1058,7 +1121,7 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
   for (uint64_t g0 = ((uint64_t)blockIdx.x * WV + wv) * TS; g0 < nseg; g0 += (uint64_t)gridDim.x * WV * TS) {
     const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
     const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
-    tile_load(s_tile[wv], t, g0, nv, lane, R0);
+    tile_load(s_tile[wv], t, g0, nv, lane, R0, narrow, no_id);
     // Walk (TS lanes, a chain each): the words of the chain are only collected — word number h of a segment's chain goes to word h
     // of its own row, always in front of the position being read (a step advances at least one byte and TSLACK = 2) ...
     uint32_t staged = 0;
@@ -1168,6 +1231,10 @@ int debug_flags() {
   return g_debug_flags;
 }
 
+// T(p,0) rows in the narrow form (u16 id + u8 advance / flags per position) whenever the ids fit
+static bool r0_narrow(const tm_batch* b) { return b->vocab->host.n_ids <= 65536u; }
+static uint32_t r0_no_id(const tm_batch* b) { return b->vocab->tables.unk_id != TM_NONE ? b->vocab->tables.unk_id : ID_NONE; }      // what a character without a token emits (go :1269-1276)
+
 uint32_t long_segs() { return (debug_flags() & 4096) ? 8u : LONG_SEGS; }
 
 static const char* kKernelNames[TM_NUM_KERNELS] = {"segments", "match_branch", "resolve", "scan", "emit"};
@@ -1194,7 +1261,7 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
     launch_seg_params(b, st);
     constexpr int WV = SEG <= 256 ? 11 : 5;      // wavefronts of a scoring workgroup: as many tiles as fit the LDS beside the histogram
     TM_LAUNCH(k_score_tiles<WV>, (uint32_t)std::min<uint64_t>((nseg + WV * TS - 1) / (WV * TS), (uint64_t)n_cu), WV * 64, 0, st, 
-        b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_seg_par, nseg, delete_id, d_hist, d_tokens, d_missing_bits, b->d_error);
+        b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_seg_par, nseg, delete_id, d_hist, d_tokens, d_missing_bits, b->d_error, r0_narrow(b) ? 1 : 0, r0_no_id(b));
   }
   TM_LAUNCH(k_hist_finish, 1, 256, 0, st, d_tokens, d_missing_bits, d_hist + n_ids);
 }
@@ -1214,7 +1281,7 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store) {
   if (nseg > 0) {
     launch_seg_params(b, st);
     TM_LAUNCH(k_emit_tiles, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
-                                                                 b->d_error, (debug_flags() & 1024) ? 512u : 0u, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing);
+                                                                 b->d_error, (debug_flags() & 1024) ? 512u : 0u, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_narrow(b) ? 1 : 0, r0_no_id(b));
   }
   if (nd) TM_LAUNCH(k_doc_events, (nd + 255) / 256, 256, 0, st, b->d_doc_ntok, b->d_doc_fd, nd, b->d_doc_events);
 }
@@ -1343,14 +1410,14 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   if (nseg > 0)
     TM_LAUNCH(k_match_branch, (uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st, v->tables, b->d_text, b->d_doc_begin, b->d_doc_end,
                                                                                           b->d_doc_vis ? b->d_doc_vis : b->d_doc_end, b->d_seg_doc,
-                                                                                          b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap,
+                                                                                          b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap, b->d_exit16, r0_narrow(b) ? 1 : 0,
                                                                                           debug_flags());
     note_table_use(v, st);
   mark(2);
   for (size_t lvl = 0; lvl + 1 < b->level_first.size() && b->ngroups > 0; lvl++) {     // bottom up: a level reads the maps of the one below
     const uint32_t g0 = b->level_first[lvl], ng = b->level_first[lvl + 1] - g0;
-    if (lvl == 0) TM_LAUNCH(k_group_compose<true>, ng, 128, 0, st, b->d_exitmap, b->d_gmap, b->d_groups, g0, b->d_gmap);
-    else TM_LAUNCH(k_group_compose<false>, ng, 128, 0, st, b->d_exitmap, b->d_gmap, b->d_groups, g0, b->d_gmap);
+    if (lvl == 0) TM_LAUNCH(k_group_compose<true>, ng, 128, 0, st, b->d_exitmap, b->d_exit16, b->d_gmap, b->d_groups, g0, b->d_gmap);
+    else TM_LAUNCH(k_group_compose<false>, ng, 128, 0, st, b->d_exitmap, b->d_exit16, b->d_gmap, b->d_groups, g0, b->d_gmap);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
@@ -1361,15 +1428,15 @@ int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode) {
   const uint32_t nd = b->ndocs;
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   if (nd > 0)
-    TM_LAUNCH(k_resolve, (nd + 255) / 256, 256, 0, st, b->d_exitmap, b->d_doc_seg_start, nd, b->d_doc_entry, b->d_seg_entry, b->d_seg_tokbase,
+    TM_LAUNCH(k_resolve, (nd + 255) / 256, 256, 0, st, b->d_exitmap, b->d_exit16, b->d_doc_seg_start, nd, b->d_doc_entry, b->d_seg_entry, b->d_seg_tokbase,
                                                 b->d_doc_ntok, b->d_error, long_segs());
   if (b->ngroups > 0) {
     TM_LAUNCH(k_long_top, (b->nlong + 63) / 64, 64, 0, st, b->d_gmap, b->d_longs, b->nlong, b->d_doc_entry, b->d_group_entry, b->d_group_base, b->d_doc_ntok, b->d_error);
     for (size_t lvl = b->level_first.size() - 1; lvl-- > 0;) {                           // top down
       const uint32_t g0 = b->level_first[lvl], ng = b->level_first[lvl + 1] - g0;
-      if (lvl == 0) TM_LAUNCH(k_group_expand<true>, (ng + 63) / 64, 64, 0, st, b->d_exitmap, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
+      if (lvl == 0) TM_LAUNCH(k_group_expand<true>, (ng + 63) / 64, 64, 0, st, b->d_exitmap, b->d_exit16, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
                                                                          b->d_seg_entry, b->d_seg_tokbase, b->d_error);
-      else TM_LAUNCH(k_group_expand<false>, (ng + 63) / 64, 64, 0, st, b->d_exitmap, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
+      else TM_LAUNCH(k_group_expand<false>, (ng + 63) / 64, 64, 0, st, b->d_exitmap, b->d_exit16, b->d_gmap, b->d_groups, g0, ng, b->d_group_entry, b->d_group_base,
                                                                  b->d_seg_entry, b->d_seg_tokbase, b->d_error);
     }
   }
@@ -1385,7 +1452,7 @@ int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode) {
 
 // exit state of every document for every entry state -> exits[ndocs * ENT] (device); needs pipeline_match
 void launch_doc_exits(tm_batch* b, uint8_t* d_exits, hipStream_t st) {
-  if (b->ndocs) TM_LAUNCH(k_doc_exits, b->ndocs, 128, 0, st, b->d_exitmap, b->d_doc_seg_start, b->d_gmap, b->d_longs, b->nlong, d_exits, long_segs());
+  if (b->ndocs) TM_LAUNCH(k_doc_exits, b->ndocs, 128, 0, st, b->d_exitmap, b->d_exit16, b->d_doc_seg_start, b->d_gmap, b->d_longs, b->nlong, d_exits, long_segs());
 }
 
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit) {
@@ -1531,7 +1598,7 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
       (e = dalloc(b, &b->d_doc_nseg, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_seg_start, nd1 + 1)) != hipSuccess ||
       (e = dalloc(b, &b->d_seg_doc, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_R0, b->max_segs * SEG)) != hipSuccess || (e = dalloc(b, &b->d_R1, b->max_segs * SEG)) != hipSuccess ||
       (e = dalloc(b, &b->d_side, b->max_segs * SIDE_STRIDE)) != hipSuccess ||
-      (e = dalloc(b, &b->d_exitmap, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_seg_entry, b->max_segs)) != hipSuccess ||
+      (e = dalloc(b, &b->d_exitmap, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_exit16, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_seg_entry, b->max_segs)) != hipSuccess ||
       (e = dalloc(b, &b->d_seg_tokbase, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_seg_par, b->max_segs + 1)) != hipSuccess || (e = dalloc(b, &b->d_doc_ntok, nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_doc_events, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_missing, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_fd, nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_tok_offsets, nd1 + 1)) != hipSuccess || (e = dalloc(b, &b->d_scan_tmp, scan_blocks)) != hipSuccess ||
@@ -1554,7 +1621,7 @@ int tm_batch_create(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, tm
 
 void tm_batch_free(tm_batch* b) {
   if (!b) return;
-  void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R0, b->d_R1, b->d_side, b->d_exitmap, b->d_seg_entry,
+  void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R0, b->d_R1, b->d_side, b->d_exitmap, b->d_exit16, b->d_seg_entry,
                   b->d_seg_tokbase, b->d_seg_par, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_doc_fd, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
                   b->d_error, b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
                   b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,

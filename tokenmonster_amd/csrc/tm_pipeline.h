@@ -73,7 +73,8 @@ struct tm_batch {
   uint32_t* d_R0 = nullptr;          // T(p,0): SEG words per segment (position p of segment g at g * SEG + p)
   uint2* d_side = nullptr;           // per segment: its few T(p,1) words (SIDE_STRIDE entries: header + {position, word})
   uint32_t* d_R1 = nullptr;          // T(p,1) per position, written only for segments whose side list overflows
-  uint32_t* d_exitmap = nullptr;       // per segment: 80 entries {next entry state | #ids << 8}
+  uint32_t* d_exitmap = nullptr;       // per segment: 80 entries {next entry state | #ids << 8}: written only for a segment with a count that does not fit the 16-bit form
+  uint16_t* d_exit16 = nullptr;        // per segment: 80 entries {next entry state | #ids << 7}, 0xFFFF = unreachable (exit_entry, tm_kernels.hip)
   uint8_t* d_seg_entry = nullptr;
   uint32_t* d_seg_tokbase = nullptr;
   uint4* d_seg_par = nullptr;          // per segment: begin | length | entry state | first output index (k_seg_params)
