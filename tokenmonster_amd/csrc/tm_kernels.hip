@@ -1039,43 +1039,85 @@ __device__ __forceinline__ uint32_t side_word(const uint2* __restrict__ sl, cons
   return w;
 }
 
+// NARROW: the rows are in the two-plane form (k_match_branch: u16 ids, u8 advance | fd' | missing) and stay that way in LDS - 6 instead of
+// 8 KB per tile, a third more walking lanes per CU, and no words to rebuild; an id is staged as 16 bits and widened on the way out.
+constexpr int TSLACK_N = 4, TROW_N = SEG + 16;        // narrow tile row: position p at index TSLACK_N + p of both planes
+template <bool NARROW>
 __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
                                                    const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
                                                    uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
                                                    uint32_t* __restrict__ error_flag, uint32_t stage_after, const uint32_t* __restrict__ seg_doc,
-                                                   uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing, int narrow, uint32_t no_id) {
-  alignas(16) __shared__ uint32_t s_tile[TS][TROW];
+                                                   uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing, uint32_t no_id) {
+  alignas(16) __shared__ uint32_t s_tile[NARROW ? 1 : TS][NARROW ? 4 : TROW];
+  alignas(16) __shared__ uint16_t s_a[NARROW ? TS : 1][NARROW ? TROW_N : 8];
+  alignas(16) __shared__ uint8_t s_m[NARROW ? TS : 1][NARROW ? TROW_N : 16];
   const int lane = threadIdx.x;
   const uint64_t g0 = (uint64_t)blockIdx.x * TS;
   const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
   const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
-  tile_load(s_tile, t, g0, nv, lane, R0, narrow, no_id);
-  // Walk.  Id number E of the segment is staged in word E of its own row while that word lies before the position being read
-  // (E < TSLACK + p: true unless the text averages more than one id per byte); from the first id that does not fit, the rest of
+  constexpr uint32_t SLACK = NARROW ? TSLACK_N : TSLACK;
+  if constexpr (NARROW) {
+    // lane l fetches positions 4l .. 4l+3 of every row: 8 bytes of ids, 4 bytes of advance / flags; all loads before the first LDS write
+    uint2 va[TS];
+    uint32_t vb[TS];
+#pragma unroll
+    for (int s = 0; s < TS; s++) {
+      const int ss = s < nv ? s : nv - 1;
+      const uint8_t* rowg = reinterpret_cast<const uint8_t*>(R0) + (g0 + (uint64_t)ss) * R0_NARROW;
+      const uint32_t len = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;
+      va[s] = make_uint2(0u, 0u); vb[s] = 0u;
+      if (4u * (uint32_t)lane < len) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 q = TM_STREAM_LOAD(reinterpret_cast<const u32x2*>(rowg) + lane);
+        va[s] = make_uint2(q.x, q.y);
+        vb[s] = TM_STREAM_LOAD(reinterpret_cast<const uint32_t*>(rowg + 2 * SEG) + lane);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < TS; s++) {
+      *reinterpret_cast<uint2*>(&s_a[s][TSLACK_N + 4 * lane]) = va[s];
+      *reinterpret_cast<uint32_t*>(&s_m[s][TSLACK_N + 4 * lane]) = vb[s];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+  } else {
+    tile_load(s_tile, t, g0, nv, lane, R0, 0, no_id);
+  }
+  // Walk.  Id number E of the segment is staged in slot E of its own row while that slot lies before the position being read
+  // (E < SLACK + p: true unless the text averages more than one id per byte); from the first id that does not fit, the rest of
   // the segment's ids go straight to HBM.  (stage_after = 0; the tests pass 512 so that nothing is staged: debug bit 10.)
   uint32_t staged = 0;
   if (t.have) {
-    uint32_t* row = s_tile[lane];
+    uint32_t* row = s_tile[NARROW ? 0 : lane];
+    uint16_t* rowa = s_a[NARROW ? lane : 0];
+    const uint8_t* rowm = s_m[NARROW ? lane : 0];
     uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0;
     const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
     uint32_t nfd = 0, nmiss = 0;                                       // delete tokens emitted / characters without a token (go :1274)
     int hop = 0;
+    // the word of state (p, fd): T(p,0) from the tile, T(p,1) from the segment's side list
+    auto word = [&](uint32_t pp, uint32_t f) -> uint32_t {
+      if (f != 0) return side_word(sl, R1, g0 + lane, pp);
+      if (!NARROW) return row[SLACK + pp];
+      const uint32_t m8 = rowm[SLACK + pp], i16 = rowa[SLACK + pp];
+      return ((m8 >> 7) ? no_id : i16) | ((m8 & 63u) << 24) | ((m8 >> 6) << 30);
+    };
     // fast loop: both ids a step can emit still fit in front of the word being read (stage_after = 0; the test hook passes 512: never)
-    for (; hop <= 2 * SEG && p < t.seglen && E + 2u + stage_after <= (uint32_t)TSLACK + p; hop++) {      // a chain visits a state (p, fd) at most once
-      const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, g0 + lane, p);
+    for (; hop <= 2 * SEG && p < t.seglen && E + 2u + stage_after <= SLACK + p; hop++) {      // a chain visits a state (p, fd) at most once
+      const uint32_t w = word(p, fd);
       if (w == R_INVALID) { atomicOr(error_flag, 2u); p = t.seglen; break; }     // cannot happen on a chain K1/K3 produced
       const uint32_t id = w & ID_NONE;
       fd = (w >> 30) & 1u;
       nfd += fd;
       nmiss += w >> 31;
-      if (id != ID_NONE) row[E++] = id;
-      if (fd) row[E++] = delete_id;
+      if (NARROW) { if (id != ID_NONE) rowa[E++] = (uint16_t)id; if (fd) rowa[E++] = (uint16_t)delete_id; }
+      else { if (id != ID_NONE) row[E++] = id; if (fd) row[E++] = delete_id; }
       p += (w >> 24) & 63u;                                            // (0 is possible: a one-byte alternative of a forward-delete state)
     }
     staged = E;
     // the rest of a segment whose ids have caught up with its words (more than one id per byte of text) goes straight to HBM
     for (; hop <= 2 * SEG && p < t.seglen; hop++) {
-      const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, g0 + lane, p);
+      const uint32_t w = word(p, fd);
       if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }
       const uint32_t id = w & ID_NONE;
       fd = (w >> 30) & 1u;
@@ -1099,7 +1141,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
   for (int s = 0; s < nv; s++) {
     const uint32_t n = (uint32_t)__shfl((int)staged, s);
     const uint64_t base = shfl_u64(t.base, s);
-    for (uint32_t j = (uint32_t)lane; j < n; j += 64u) if (base + j < out_cap) TM_STREAM_STORE(&out[base + j], s_tile[s][j]);
+    for (uint32_t j = (uint32_t)lane; j < n; j += 64u) if (base + j < out_cap) TM_STREAM_STORE(&out[base + j], NARROW ? (uint32_t)s_a[NARROW ? s : 0][j] : s_tile[NARROW ? 0 : s][j]);
   }
 }
 
@@ -1282,8 +1324,13 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store) {
   (void)hipMemsetAsync(b->d_doc_missing, 0, (size_t)nd * 4, st);
   if (nseg > 0) {
     launch_seg_params(b, st);
-    TM_LAUNCH(k_emit_tiles, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
-                                                                 b->d_error, (debug_flags() & 1024) ? 512u : 0u, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_narrow(b) ? 1 : 0, r0_no_id(b));
+    const uint32_t stage_after = (debug_flags() & 1024) ? 512u : 0u;
+    if (r0_narrow(b))
+      TM_LAUNCH(k_emit_tiles<true>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
+                                                                         b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
+    else
+      TM_LAUNCH(k_emit_tiles<false>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
+                                                                          b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
   }
   if (nd) TM_LAUNCH(k_doc_events, (nd + 255) / 256, 256, 0, st, b->d_doc_ntok, b->d_doc_fd, nd, b->d_doc_events);
 }
