@@ -246,6 +246,20 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
         offs = cut if int(cut[-1]) == int(text.size) else np.concatenate([cut, np.array([text.size], dtype=np.uint64)])
         cpu = cpu_baseline(img, text, offs, args.cpu_sample_mb, log)
         cpu["sample"] += " (strips of 1 MiB; the reference runtime has no scoring mode: this times the identical walk, tokenize_normalized)"
+    traffic, traffic_source = None, None
+    under_profiler = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if args.measure_traffic and rank == 0 and world == 1 and not under_profiler:
+        # HBM traffic of the match kernel of the same pass (it is 85 % of it): separate --pmc passes over tools/k1_time.py --score in a child process
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_profile.py"), "--fast", "--mbytes", str(args.mbytes), "--groups", "4,5",
+                                "--kernel", "k_match_branch", "--out", os.path.join("/tmp", "tm_bench_traffic"), "--extra=--config %s --score" % args.config],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, start_new_session=True)
+            k = list(json.loads(r.stdout.decode()).values())[0]
+            traffic = int(k["FETCH_SIZE"] * 1024 * 2 + k["WRITE_SIZE"] * 1024)
+            traffic_source = "k_match_branch of the same pass, measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; FETCH_SIZE x 2 on gfx950)"
+        except Exception as ex:     # noqa: BLE001
+            log("counter passes failed (%s)" % ex)
     if rank == 0:
         value = all_raw * args.steps / elapsed / 1e9
         alg = float(text.size)                       # scoring pass B_alg = N per rank
@@ -262,7 +276,7 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
                        "verified_bytes_vs_oracle": verified},
             "roofline": {"bound": "hbm", "kernel": "whole scoring pass of one rank", "achieved": round(alg / (elapsed / args.steps) / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
-                         "traffic": None, "algorithmic_bytes_per_launch": alg},
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -11,6 +11,7 @@ run() {   # name, bench args...
   echo "== $name: exit $?"; cut -c1-420 $OUT/bench_$name.json; echo; grep -E "host_to_host|cpu_baseline|INVALID|rror" $OUT/bench_$name.err | cut -c1-600
   (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats_$name -o s --output-format csv -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-to-host --verify 0 "$@" > $OUT/bench_${name}_under_rocprof.json 2> $OUT/stats_$name.err)
   f=$(find $OUT/stats_$name -name "*kernel_stats.csv" | head -1)
+  find $OUT/stats_$name -name "*kernel_trace.csv" -delete
   [ -n "$f" ] && cp "$f" $OUT/kernel_stats_$name.csv && python3 - "$f" <<'PY'
 import csv, sys
 for i, r in enumerate(csv.DictReader(open(sys.argv[1]))):
