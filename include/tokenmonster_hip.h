@@ -67,7 +67,7 @@ void tm_vocab_free(tm_vocab* v);
 typedef struct tm_vocab_block {
   uint64_t bytes;            /* size of the device block */
   uint64_t part_bytes[8];    /* root, walk tables, rows, space-prefix links, node values, reverse offsets, reverse bytes, begin_byte */
-  uint32_t edge_mask, edge_shift, n_info, max_len, off, bstart, spl_hint, link_off, direct_off, delete_id, unk_id;
+  uint32_t idle_off, n_da, n_info, max_len, off, bstart, spl_hint, link_off, direct_off, delete_id, unk_id;
   uint32_t n_ids, vocab_size, capcode, charset, norm_flag, level, reserve, n_nodes, pad;
 } tm_vocab_block;
 int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* meta, void** device_ptr);

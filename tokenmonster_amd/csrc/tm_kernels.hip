@@ -155,40 +155,31 @@ __device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_
   return (uint32_t)sbegl | (len << D_LEN_SHIFT) | ((uint32_t)sbegc << 8) | ((uint32_t)(S + 4) << D_S_SHIFT);
 }
 
-__device__ __forceinline__ uint32_t edge_slot_offset(const Tables& T, uint32_t node, uint32_t byte) {
-  return (edge_hash(node, byte) >> T.edge_shift) << 4;     // byte offset of the home bucket (two 8-byte slots)
-}
-// child filter (tm_tables.h): can the node have a child over byte c?  32 bits in a link-format entry, 4 in the key word of a slot
+// child filter (tm_tables.h): can the node have a child over byte c?
 __device__ __forceinline__ bool child_possible32(uint32_t m, uint32_t c) { return ((m >> (c & 31u)) & 1u) != 0; }
 
 // one in-flight trie walk of a lane: text byte number d of the string being matched is text[tbase + d].
-// An idle slot has key == KEY_IDLE (never stored in the table) and probes the always-empty slot behind the table,
-// so it needs no flag of its own: it neither hits nor re-probes, and its bestlen of 0 keeps it from storing anything.
+// An idle slot has key == KEY_IDLE (no entry's check word) and gathers the always-empty entry behind the double array,
+// so it needs no flag of its own: it never hits, and its bestlen of 0 keeps it from storing anything.
 struct Walk { int pos, tbase, depth, limit, bestlen; uint32_t hoff, key, bestv; };
-constexpr uint32_t KEY_IDLE = 0xFFFFFFFEu;
+constexpr uint32_t KEY_IDLE = 0xFFFFFFFDu;
 __device__ __forceinline__ bool walk_idle(const Walk& k) { return k.key == KEY_IDLE; }
-// child filter (tm_tables.h): can the node have a child over byte c?  32 bits in a link-format entry, 4 in the key word of a slot
-__device__ __forceinline__ bool child_possible4(uint32_t key_word, uint32_t c) { return ((key_word >> (28u + (c & 3u))) & 1u) != 0; }
 
-// consume one hash probe: follow the edge, remember the deepest accepting node, arm the next probe or stop
+// consume one probe of the double array: follow the edge, remember the deepest accepting node, arm the next probe or stop
 // (pansearch LongestSubstring semantics, tokenmonster.cpp:786-877: longest prefix that is a key).
-// Written without branches: every lane executes the same instructions, so the NWALK loads of a round are issued back
-// to back and the round has a single wait.  `c` is the text byte after the one being matched (text[tbase+depth+1]),
-// read from LDS while the probe was in flight.  Returns true when the slot is (or has become) idle.
+// Written without branches: every lane executes the same instructions.  `c` is the text byte after the one being matched
+// (text[tbase+depth+1]), read from LDS while the probe was in flight.  Returns true when the slot is (or has become) idle.
 __device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uint4 e, const uint32_t c) {
-  const bool hit1 = (e.z & kKeyMask) == k.key;
-  const bool hit = hit1 || (e.x & kKeyMask) == k.key;
-  const bool again = !hit && e.z != kNone;                        // both slots taken by other keys: the next bucket
-  const uint32_t cur = hit1 ? e.w : e.y, kw = hit1 ? e.z : e.x, nid = node_id(cur);
+  const bool hit = e.x == k.key;
+  const uint32_t nid = node_id(e.y);
   k.depth += hit ? 1 : 0;
   const bool acc = hit && nid < T.n_info;
-  k.bestv = acc ? cur : k.bestv;
+  k.bestv = acc ? e.y : k.bestv;
   k.bestlen = acc ? k.depth : k.bestlen;
-  const bool cont = hit && k.depth < k.limit && child_possible4(kw, c);
-  const uint32_t lin = (k.hoff + 16u) & (T.edge_mask << 4);
-  k.key = cont ? ((nid << 8) | c) : (again ? k.key : KEY_IDLE);
-  k.hoff = cont ? edge_slot_offset(T, nid, c) : (again ? lin : (T.edge_mask + 1u) << 4);
-  return !(cont || again);
+  const bool cont = hit && k.depth < k.limit && child_possible32(e.z, c);
+  k.key = cont ? nid : KEY_IDLE;
+  k.hoff = cont ? (e.w + c) << 4 : T.idle_off;
+  return !cont;
 }
 
 // score of one branch, go/tokenmonster.go:1075-1084 (plain), :1096-1105 (forward-delete variant); alternatives add :1132-1133.
@@ -310,7 +301,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   WaveLds& w = s_wave[wvi];
   const int Lmax = (int)T.max_len;
   const unsigned long long lane_below = (1ull << lane) - 1ull;
-  const uint32_t idle_off = (T.edge_mask + 1u) << 4;      // the always-empty bucket behind the edge hash
+  const uint32_t idle_off = T.idle_off;                   // the always-empty entry behind the double array
   const uint32_t doc = seg_doc[g];
   const uint64_t begin = doc_begin[doc] + (g - doc_seg_start[doc]) * SEG;
   // A document owns the positions [doc_begin, doc_end) but may LOOK at text up to doc_vis >= doc_end: a byte range of a dataset
@@ -352,12 +343,13 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 #else
   const int ntask = share ? SEG : min(NPOS, dl);       // positions >= dl keep descriptor 0 (nothing there); a shared halo is the neighbour's work
 #endif
-  // the walks of steps A1 and A3: a lane's state is its key — KEY_SET (A1: the gather is a link-format entry), KEY_IDLE_A1 (nothing to
-  // do; the gather is the always-empty bucket behind the table), anything else = the edge (parent << 8 | byte) being probed
-  constexpr uint32_t KEY_SET = ((kMaxNodes) << 8), KEY_IDLE_A1 = KEY_SET | 1u;     // parent ids no trie node has (tm_tables.h: kMaxNodes)
+  // the walks of steps A1 and A3: a lane's state is its key — KEY_SET (A1: the gather is a link-format entry), KEY_IDLE (nothing to
+  // do; the gather is the always-empty entry behind the double array), anything else = the node whose child is being probed (the
+  // check word the entry must carry)
+  constexpr uint32_t KEY_SET = 0xFFFFFFFEu;        // neither is a node id, the x of a link-format entry (depths <= 63 in its top bits: tm_tables.h) or kNone
+  static_assert(KEY_IDLE != KEY_SET && KEY_IDLE != kNone && KEY_SET != kNone && (KEY_IDLE >> 26) == 63u && (KEY_SET >> 26) == 63u, "walk states");
   typedef unsigned long long M64;
   const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
-  const uint32_t mask16 = T.edge_mask << 4;
   {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
     // A run is in one of two states.  SET: the gather is a link-format entry (a suffix link, or the direct map on the
@@ -399,9 +391,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     // per-lane booleans — save / restore of exec around every block, mask algebra for every && and || — was ~60 scalar instructions
     // per round, the eight mask operations below are what the state machine needs.  A lane's state is its key: KEY_SET (the gather is
     // a link-format entry), KEY_IDLE (nothing to do; it gathers the always-empty bucket), anything else = the edge being probed.
-    key = setting ? KEY_SET : KEY_IDLE_A1;
-    uint32_t v_link = T.link_off, v_direct = T.direct_off, v_idle = idle_off, v_kset = KEY_SET;
-    TM_KEEP_IN_VGPRS4(v_link, v_direct, v_idle, v_kset);          // operands of the selects: four registers for the whole loop, not four moves per round
+    key = setting ? KEY_SET : KEY_IDLE;
+    uint32_t v_link = T.link_off, v_direct = T.direct_off, v_idle = idle_off, v_kset = KEY_SET, v_kidle = KEY_IDLE;
+    TM_KEEP_IN_VGPRS4(v_link, v_direct, v_idle, v_kset);          // operands of the selects: registers for the whole loop, not moves per round
+    TM_KEEP_IN_VGPRS2(v_kidle, v_kset);
     const uint32_t dump0 = TM_LDS_ADDR(&w.Xb[lane]), dump1 = TM_LDS_ADDR(&w.Xb[64 + lane]);      // where the stores of a lane that has nothing to store go (Xb is not in use before step A3)
     auto rounds = [&](auto tail_tag) {
       constexpr bool TAIL = decltype(tail_tag)::value;
@@ -414,25 +407,21 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         uint32_t c = *TM_LDS_PTR(lds_u8, pfa);
         uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);
         TM_KEEP_IN_VGPRS2(c, nn);
-        const uint32_t x0 = (e.x ^ key) & kKeyMask, x1 = (e.z ^ key) & kKeyMask;
-        const M64 hit1 = __builtin_amdgcn_ballot_w64(x1 == 0u), hitany = __builtin_amdgcn_ballot_w64(min(x0, x1) == 0u);
-        const M64 set = __builtin_amdgcn_ballot_w64(key == KEY_SET);
-        const M64 hit = hitany & ~set, adv = hitany | set;
-        const uint32_t hv = sel_mask(hit1, e.w, e.y), hk = sel_mask(hit1, e.z, e.x);
-        const uint32_t nid = sel_mask(set, e.x, hv) & kNodeMask;
+        // a double-array entry is the child being probed for iff its check word is the parent (tm_tables.h); a link-format entry always "hits"
+        const M64 hit = __builtin_amdgcn_ballot_w64(e.x == key), set = __builtin_amdgcn_ballot_w64(key == KEY_SET);
+        const M64 adv = hit | set;
+        const uint32_t nid = sel_mask(set, e.x, e.y) & kLinkNodeMask;
         node = sel_mask(adv, nid, node);
-        depth = (int)sel_mask(set, (e.x >> 23) & 63u, sel_mask(hit, (uint32_t)depth + 1u, (uint32_t)depth));
+        depth = (int)sel_mask(set, link_depth(e.x), sel_mask(hit, (uint32_t)depth + 1u, (uint32_t)depth));
         const M64 acc = hit & __builtin_amdgcn_ballot_w64(nid < T.n_info);
-        bestv = sel_mask(set, e.y, sel_mask(acc, hv, bestv));
-        bestlen = (int)sel_mask(set, e.w, sel_mask(acc, (uint32_t)depth, (uint32_t)bestlen));
-        // probe only for a byte the node can continue with: bit (c & 31) of the 32-bit filter behind a link, bit 28 + (c & 3) of the key word of a slot
-        const uint32_t fword = sel_mask(set, e.z, hk), fbit = sel_mask(set, c & 31u, 28u | (c & 3u));
-        M64 go = adv & __builtin_amdgcn_ballot_w64(((fword >> fbit) & 1u) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
+        bestv = sel_mask(set | acc, e.y, bestv);
+        bestlen = (int)sel_mask(set, link_bestlen(e.x), sel_mask(acc, (uint32_t)depth, (uint32_t)bestlen));
+        // probe only for a byte the node can continue with: bit (c & 31) of its child filter (0 behind a link that cannot go on)
+        M64 go = adv & __builtin_amdgcn_ballot_w64(((e.z >> (c & 31u)) & 1u) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
 #ifdef TM_DEVEL
         if (nowalk) go = 0ull;
 #endif
-        const M64 again = __builtin_amdgcn_ballot_w64(e.z != kNone) & ~adv;        // both slots hold other keys: next bucket (an idle lane sees the empty bucket)
-        const M64 fin = busy & ~(go | again);
+        const M64 fin = busy & ~go;
         // the position is done: store it (no match: bestlen == 0 and the link formats give bestv == 0: the 0 that is there already) ...
         const uint32_t daddr = dconst + 4u * posa;
         *TM_LDS_PTR(lds_u32, sel_mask(fin, daddr, dump0)) = (uint32_t)bestlen | ((bestv >> 22) << 6);      // D[pos]
@@ -442,10 +431,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         const M64 more = __builtin_amdgcn_ballot_w64(posn < enda), deep = __builtin_amdgcn_ballot_w64(depth >= 3);
         const uint32_t off_f = sel_mask(more, sel_mask(deep, v_link, v_direct) + (sel_mask(deep, node, nn) << 4), v_idle);
         const uint32_t pfa_f = posn + (uint32_t)max(depth, 3) - 1u;            // depth >= 3: posn + depth - 1, else posn + 2
-        // the next gather of a walk that goes on
-        const uint32_t off_p = sel_mask(go, edge_slot_offset(T, nid, c), (off + 16u) & mask16);
-        key = sel_mask(fin, v_kset | sel_mask(more, 0u, 1u), sel_mask(go, (nid << 8) | c, key));
-        off = sel_mask(fin, off_f, sel_mask(go | again, off_p, off));
+        // the next gather of a walk that goes on: entry base + byte
+        key = sel_mask(fin, sel_mask(more, v_kset, v_kidle), sel_mask(go, nid, key));
+        off = sel_mask(fin, off_f, sel_mask(go, (e.w + c) << 4, off));
         pfa = sel_mask(fin, pfa_f, sel_mask(go, posa + (uint32_t)depth + 1u, pfa));
         if (TAIL) limit = (int)sel_mask(fin, (uint32_t)min((int)(dla - posn), Lmax), (uint32_t)limit);
         posa = sel_mask(fin, posn, posa);
@@ -514,8 +502,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         if (e.x != kNone && ((e.x >> 21) & 1u) && depth < limit && child_possible32(e.z, c0)) {
           k.pos = p; k.tbase = p - off; k.bestlen = bl; k.bestv = e.y; k.depth = depth; k.limit = limit;
           mainlen = (int)ml;
-          k.key = ((e.x & kNodeMask) << 8) | c0;
-          k.hoff = edge_slot_offset(T, e.x & kNodeMask, c0);
+          k.key = e.x & kNodeMask;
+          k.hoff = (e.w + c0) << 4;
         } else if (e.x != kNone && bl > (int)ml + 1) {               // (only possible with the two-byte UTF-16 prefix)
           const int lb = bl - off;
           w.Db[p] = make_sdesc((uint32_t)lb, e.y, s_bb[w.text[p + lb]], true, T.spl_hint);

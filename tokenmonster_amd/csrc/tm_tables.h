@@ -6,17 +6,16 @@
 // (index, length, found) with index = record ordinal in the .vocab file.
 // Here it is a byte trie whose accepting nodes ARE the record ordinals:
 //   depth 1   root[256]            (staged in LDS by every workgroup)
-//   depth 2   tab[0..65535]        direct map on the first two bytes (512 KiB, L2-resident)
-//   depth >=3 tab[..]              open-addressing hash of (parent node, byte) -> child: 16-byte buckets of two 8-byte slots
-//             (one table, one 16-byte load per probe whatever the depth: every walk step is the same instruction; the load
-//             sees both slots of the bucket, so at load 0.3 a key is almost always found — or known absent — in one gather)
-// Every entry a walk can stand on carries a CHILD FILTER of its node: the next probe is only issued if the bit of the next text
-// byte is set.  Half of all positions end on a probe that cannot hit, and with linear probing such a probe is ~1.5 gathers.
-// Link-format entries (16 B) have room for 32 bits (bit b & 31: the node has a child over some byte congruent to b); a hash
-// slot keeps 4 bits (bit b & 3) in the top of its key word, so that the table stays 8 B per slot: with 16-byte slots and 32 bits
-// everywhere the walk needs 2.76 instead of 3.44 gathers per position (tools/a1_sim.cpp) but the tables of the 32 000-id
-// vocabulary grow from 4.3 to 6.4 MB, past the 4 MB L2 of an XCD — measured: HBM fetches of the match kernel x5 and the time
-// unchanged.  With 4 bits in the slots it is 2.89 gathers per position at the old size.
+//   depth 2   tab[..]              direct map on the first two bytes (1 MiB, L2-resident)
+//   depth >=3 tab[0..n_da)         a DOUBLE-ARRAY trie: the child of node n over byte b is the 16-byte entry base(n) + b, valid if
+//             its check word is n.  One 16-byte gather per byte of the walk, a hit or a miss and never "occupied by another key,
+//             try the next bucket"; the address of the next probe is ONE add (base + byte) on what the gather returned, the test
+//             ONE compare — against two multiplies, a shift and two masked compares for the open-addressing hash of (parent, byte)
+//             this replaces (rounds 1-3: 16-byte buckets of two 8-byte slots at load 0.3) — and the array is full (no empty
+//             slots to keep the probe sequences short): 16 bytes per edge instead of 27.
+// Every entry a walk can stand on carries the 32-bit CHILD FILTER of its node (bit b & 31: the node has a child over some byte
+// congruent to b): the next probe is only issued if the bit of the next text byte is set.  Half of all positions end on a probe
+// that cannot hit.
 // A 32-bit node value carries everything a look-ahead needs about the token it accepts, so scoring a
 // branch never touches the row table:
 //   bits  0..20  node id; id < n_info  <=>  the prefix is a vocabulary key and id is its record ordinal
@@ -36,21 +35,16 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kNodeBits = 21;
 constexpr uint32_t kNodeMask = (1u << kNodeBits) - 1;
 constexpr uint32_t kHasChildren = 1u << 21;
-constexpr uint32_t kMaxNodes = (1u << 20) - 2;       // 20 bits: the top four bits of a hash slot's key word hold its child filter
-constexpr uint32_t kKeyMask = 0x0FFFFFFFu;          // parent node << 8 | byte
+constexpr uint32_t kMaxNodes = (1u << 20) - 2;       // 20 bits: a link-format entry keeps two depths beside the node id
+constexpr uint32_t kLinkNodeMask = (1u << 20) - 1;
 constexpr uint32_t kL2Size = 65536;
 constexpr uint32_t kDirectSlots = 2 * kL2Size;   // the direct map in uint2 units (16-byte entries)
 
 __host__ __device__ inline uint32_t node_id(uint32_t v) { return v & kNodeMask; }
-// hash of the edge (parent node, byte): both factors fit 24 bits so the device computes it with two full-rate
-// v_mad_u32_u24 instead of a quarter-rate 32-bit multiply; the slot is the top bits
-__host__ __device__ inline uint32_t edge_hash(uint32_t node, uint32_t byte) {
-#ifdef __HIP_DEVICE_COMPILE__
-  return __umul24(node, 0x9E3779u) + __umul24(byte, 0x85EBCBu);
-#else
-  return node * 0x9E3779u + byte * 0x85EBCBu;
-#endif
-}
+// link-format word x: node | depth of the node << 20 | depth of the deepest accepting node on the way << 26
+__host__ __device__ inline uint32_t link_node(uint32_t x) { return x & kLinkNodeMask; }
+__host__ __device__ inline uint32_t link_depth(uint32_t x) { return (x >> 20) & 63u; }
+__host__ __device__ inline uint32_t link_bestlen(uint32_t x) { return x >> 26; }
 __host__ __device__ inline uint32_t node_nwords(uint32_t v) { return (v >> 22) & 31u; }
 __host__ __device__ inline uint32_t node_flag5(uint32_t v) { return v >> 27; }
 __host__ __device__ inline uint32_t flag8_to_flag5(uint32_t f) {
@@ -74,29 +68,31 @@ struct alignas(16) Row { uint32_t x, y, z, w; };
 
 struct Tables {
   const uint32_t* root;    // [256]
-  const uint2* tab;        // one table for everything a walk gathers (8-byte units; link-format entries take two):
-                           //   [0, 2*(mask+2))         depth>=3 edge hash, bucket b = slots 2b, 2b+1 (slot 0 fills first); slot x = parent<<8|byte
-                           //                           | 4-bit child filter of the child << 28 (kNone = empty), y = node value; home
-                           //                           bucket edge_hash >> edge_shift, a full bucket overflows into the next one; the
-                           //                           bucket behind the table stays empty (idle walks probe it)
-                           //   [direct_off/8, +2*65536) direct map on the first two bytes, index b0 | b1<<8 (the little-endian u16 at
+  const uint2* tab;        // one table for everything a walk gathers, in 16-byte entries (uint4 on the device):
+                           //   [0, n_da]                double-array trie of the edges at depth >= 3.  Entry base(n) + b of the child c of n
+                           //                           over byte b: x = n (kNone: empty), y = node value of c, z = child filter of c,
+                           //                           w = base(c) (entry index; 0 if c has no children).  base(n) + 255 <= n_da for
+                           //                           every n; entry n_da stays empty (idle walks gather it: idle_off)
+                           //   [direct_off/16, +65536) direct map on the first two bytes, index b0 | b1<<8 (the little-endian u16 at
                            //                           the position), link format: the whole answer for depth <= 2 and, if the
                            //                           node b0b1 has children, where to go on
-                           //   [link_off/8, +2*nodes)  suffix links, 16 B per trie node n (string s): where the walk of s[1:] ends up,
+                           //   [link_off/16, +nodes)   suffix links, one per trie node n (string s): where the walk of s[1:] ends up,
                            //                           so the walk at text position p+1 CONTINUES from the walk at p instead of
                            //                           starting over (Aho-Corasick failure links turned into longest-prefix state)
-                           //   link format:            x = node m reached | go << 21 (all of s[1:] is in the trie AND m has
-                           //                               children: probe on) | depth(m) << 23
-                           //                           y = value of the deepest accepting node on the path to m (0: none)
-                           //                           z = child filter of m (0 unless go), w = depth of that accepting node
+                           //   link format:            x = node m reached | depth(m) << 20 | depth of the deepest accepting node on
+                           //                               the path to m << 26
+                           //                           y = value of that accepting node (0: none)
+                           //                           z = child filter of m if all of s[1:] is in the trie (the walk may probe on), else 0
+                           //                           w = base(m)
   const uint4* spl;        // [n_info] "space-prefix link" of record s: where the walk of ' '+s (the forward-delete probe of
                            //   go/tokenmonster.go:1088-1095; ' ' 0x00 + s for UTF-16) ends up, so that probe only has to CONTINUE:
                            //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node;
-                           //   z = 32-bit child filter of the node reached (0 unless the continue flag is set): most probes end here
+                           //   z = 32-bit child filter of the node reached (0 unless the continue flag is set): most probes end here;
+                           //   w = base of the node reached
   const uint32_t* vals;    // [n_info] node value of every record (the split pipeline hands positions over as record ordinals)
   const Row* rows;         // [n_info]
   const uint8_t* begin_byte;  // [256]  go/tokenmonster.go:43
-  uint32_t edge_mask, edge_shift;     // bucket mask / hash shift
+  uint32_t idle_off, n_da;            // byte offset of the always-empty entry behind the double array / its number of entries
   uint32_t n_info, max_len;
   uint32_t off;            // 1, or 2 for UTF-16 (lilbufOffset, go :1031-1034)
   uint32_t bstart;         // node value after consuming ' ' (and 0x00 for UTF-16), kNone if absent

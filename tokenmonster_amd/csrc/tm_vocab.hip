@@ -244,62 +244,75 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     return v;
   };
   hv.root.assign(256, kNone);
-  size_t n_edges = 0;
-  for (auto& kv : child) if (depth_of[kv.second] >= 3) n_edges++;
-  uint32_t bits = 4;
-  // 2.5 slots per edge: on the device the same kernel is 5.7 % slower with half the table and 7.1 % slower with twice (the tables' L2
-  // footprint against the probe rounds, profiles/r03_k1_variants_ab.txt)
-  while ((1ull << bits) < n_edges * 10 / 4 + 8) bits++;
-  // two slots per 16-byte bucket: a probe is one 16-byte gather and sees both, so at this load nearly every key sits in the
-  // bucket it hashes to (the walk's "occupied by another key, try the next slot" rounds all but disappear)
-  hv.edge_mask = (1u << (bits - 1)) - 1;           // bucket mask
-  hv.edge_shift = 32 - (bits - 1);
-  // child-byte filter of every node: bit (b & 31) is set if the node has a child over byte b.  A walk only probes the edge hash
-  // for a byte whose bit is set, so a probe that cannot hit (half of all positions end on one, and with linear probing it is
-  // ~1.5 gathers) is almost never issued: most nodes have one child.
+  // child-byte filter of every node: bit (b & 31) is set if the node has a child over byte b.  A walk only probes for a byte
+  // whose bit is set, so a probe that cannot hit (half of all positions end on one) is almost never issued: most nodes have one child.
   std::vector<uint32_t> cmask(n_nodes, 0);
   for (auto& kv : child) { const uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) cmask[parent] |= 1u << (kv.first & 31u); }
-  // one allocation (tm_tables.h): edge hash | always-empty slot | direct map | suffix links
-  const size_t direct_base = 2 * (((size_t)hv.edge_mask + 1) + 1);            // buckets + the always-empty one, in 8-byte units
+  std::vector<uint32_t> by_depth(n_nodes);      // counting sort by depth (<= 40), also used for the suffix links below
+  {
+    uint32_t start[66] = {0};
+    for (uint32_t i = 0; i < n_nodes; i++) start[depth_of[i] + 1]++;
+    for (int d = 1; d < 66; d++) start[d] += start[d - 1];
+    for (uint32_t i = 0; i < n_nodes; i++) by_depth[start[depth_of[i]]++] = i;
+  }
+  // ---- the double array (tm_tables.h): a base for every node at depth >= 2 that has children, such that the entries base + b of
+  // its children are free.  Parents are placed shallow first (the shallow end of the trie is where most walks are, and it ends up
+  // together at the front of the array) by first fit from the lowest free entry; a parent that does not fit after a bounded number
+  // of tries goes behind everything placed so far, and the holes it skipped are filled by the one-child parents that make up most
+  // of the deeper levels: the array ends up > 95 % full.
+  std::vector<uint32_t> base_of(n_nodes, 0);
+  std::vector<uint4> da;
+  {
+    std::vector<uint32_t> kid_start(n_nodes + 1, 0);             // children of every node at depth >= 2, as (byte, child) sorted by byte
+    for (auto& kv : child) if (depth_of[kv.second] >= 3) kid_start[(uint32_t)(kv.first >> 8) + 1]++;
+    for (uint32_t i = 0; i < n_nodes; i++) kid_start[i + 1] += kid_start[i];
+    const uint32_t n_edges = kid_start[n_nodes];
+    std::vector<uint32_t> kid(n_edges), fill(kid_start.begin(), kid_start.end() - 1);
+    for (auto& kv : child) if (depth_of[kv.second] >= 3) kid[fill[(uint32_t)(kv.first >> 8)]++] = ((uint32_t)(kv.first & 0xFF) << 24) | kv.second;
+    for (uint32_t n = 0; n < n_nodes; n++) if (kid_start[n + 1] - kid_start[n] > 1) std::sort(kid.begin() + kid_start[n], kid.begin() + kid_start[n + 1]);
+    const uint32_t first = 256;                                  // entries below stay empty: base = entry - byte is never negative
+    std::vector<uint8_t> used((size_t)n_edges + n_edges / 4 + 1024, 0);
+    uint32_t cursor = first, frontier = first;                    // lowest free entry / one past the highest used one
+    auto grow = [&](size_t need) { if (need > used.size()) used.resize(need + need / 4, 0); };
+    for (uint32_t n : by_depth) {
+      const uint32_t k0 = kid_start[n], k1 = kid_start[n + 1];
+      if (k0 == k1) continue;
+      const uint32_t b_lo = kid[k0] >> 24, span = (kid[k1 - 1] >> 24) - b_lo;
+      while (used[cursor]) cursor++;
+      uint32_t f = cursor, tries = 0;
+      for (;;) {                                                  // f = entry of the child over the smallest byte
+        if (f >= frontier || ++tries > 48) { f = std::max(f, frontier); grow((size_t)f + span + 2); break; }
+        grow((size_t)f + span + 2);
+        bool ok = true;
+        for (uint32_t q = k0 + 1; q < k1 && ok; q++) ok = !used[f + (kid[q] >> 24) - b_lo];
+        if (ok) break;
+        do f++; while (used[f]);
+      }
+      const uint32_t base = f - b_lo;
+      base_of[n] = base;
+      for (uint32_t q = k0; q < k1; q++) used[base + (kid[q] >> 24)] = 1;
+      frontier = std::max(frontier, f + span + 1);
+    }
+    hv.n_da = frontier + 256;                                    // base + 255 stays inside for every base
+    da.assign((size_t)hv.n_da + 1, uint4{kNone, kNone, 0u, 0u});
+    for (uint32_t n = 0; n < n_nodes; n++)
+      for (uint32_t q = kid_start[n]; q < kid_start[n + 1]; q++) {
+        const uint32_t c = kid[q] & 0xFFFFFFu;
+        da[base_of[n] + (kid[q] >> 24)] = uint4{n, value_of(c), cmask[c], base_of[c]};
+      }
+  }
+  hv.idle_off = hv.n_da * 16u;
+  // one allocation (tm_tables.h): double array | always-empty entry | direct map | suffix links
+  const size_t direct_base = 2 * ((size_t)hv.n_da + 1);                       // in 8-byte units
   const size_t link_base = direct_base + kDirectSlots;
   hv.direct_off = (uint32_t)(direct_base * sizeof(uint2));
   hv.link_off = (uint32_t)(link_base * sizeof(uint2));
   hv.tab.assign(link_base + 2 * (size_t)n_nodes, uint2{kNone, kNone});
+  memcpy(hv.tab.data(), da.data(), da.size() * sizeof(uint4));
   std::vector<uint32_t> l2v(kL2Size, kNone);       // value of the depth-2 node b0b1
-  uint2* edges = hv.tab.data();
   std::vector<uint32_t> first_byte(n_nodes, 0);   // for depth-1 nodes: their byte, to index l2
   for (auto& kv : child) if (depth_of[kv.second] == 1) { hv.root[kv.first & 0xFF] = value_of(kv.second); first_byte[kv.second] = (uint32_t)(kv.first & 0xFF); }
   for (auto& kv : child) if (depth_of[kv.second] == 2) l2v[(first_byte[(uint32_t)(kv.first >> 8)] << 8) | (uint32_t)(kv.first & 0xFF)] = value_of(kv.second);
-  // Insertion order decides who keeps the home bucket and who moves on to the next one ("occupied by two other keys": one more
-  // round of the walk).  The rounds a wavefront spends in step A1 are set by its one deepest walk, so the edges on paths to deep
-  // nodes go in first: ordered by the depth of the deepest node below the edge.  Against creation order (shallow first) the model
-  // (tools/a1_sim.cpp) gives 32.0 -> 30.1 rounds per wavefront on the englishcode-32000 shape, for 2 % more gathers overall.
-  std::vector<uint32_t> by_depth(n_nodes);      // counting sort by depth (<= 40), also used for the suffix links below
-  {
-    uint32_t start[42] = {0};
-    for (uint32_t i = 0; i < n_nodes; i++) start[depth_of[i] + 1]++;
-    for (int d = 1; d < 42; d++) start[d] += start[d - 1];
-    for (uint32_t i = 0; i < n_nodes; i++) by_depth[start[depth_of[i]]++] = i;
-  }
-  {
-    std::vector<uint8_t> maxd(depth_of.begin(), depth_of.end());                 // depth of the deepest node in the subtree
-    for (size_t q = n_nodes; q-- > 0;) { const uint32_t n = by_depth[q], par = parent_of[n]; if (par != kRoot && maxd[par] < maxd[n]) maxd[par] = maxd[n]; }
-    uint32_t start[42] = {0};
-    for (auto& kv : child) if (depth_of[kv.second] >= 3) start[41 - maxd[kv.second]]++;      // bucket 0 = deepest
-    uint32_t total_edges = 0;
-    for (int d = 0; d < 42; d++) { const uint32_t c = start[d]; start[d] = total_edges; total_edges += c; }
-    std::vector<std::pair<uint64_t, uint32_t>> order(total_edges);
-    for (auto& kv : child) if (depth_of[kv.second] >= 3) order[start[41 - maxd[kv.second]]++] = kv;
-    for (auto& kv : order) {
-      const uint32_t parent = (uint32_t)(kv.first >> 8), byte = (uint32_t)(kv.first & 0xFF);
-      uint32_t key = (parent << 8) | byte;
-      uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;                     // home bucket; slot 0 fills before slot 1
-      while (edges[2 * (size_t)h + 1].x != kNone) h = (h + 1) & hv.edge_mask;
-      uint32_t f4 = 0;                                                           // 4-bit filter of the node the edge leads to
-      for (uint32_t q = 0; q < 32; q++) if ((cmask[kv.second] >> q) & 1u) f4 |= 1u << (q & 3u);
-      edges[2 * (size_t)h + (edges[2 * (size_t)h].x != kNone ? 1 : 0)] = uint2{key | (f4 << 28), value_of(kv.second)};
-    }
-  }
   // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.
   // link(n) follows from link(parent(n)) as in Aho-Corasick, in order of depth; best[m] = deepest accepting node on the
   // path root..m.  Only links of nodes at depth >= 3 are ever read by the kernels.
@@ -322,8 +335,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       const uint32_t m = lnode[n], dm = depth_at(m);
       const uint32_t hc = (m != kRoot && has_child[m]) ? 1u : 0u;
       const uint32_t b = m == kRoot ? kNone : best[m];
-      lt[2 * (size_t)n] = uint2{(m & kNodeMask) | (((uint32_t)lfull[n] & hc) << 21) | (dm << 23), b != kNone ? value_of(b) : 0u};
-      lt[2 * (size_t)n + 1] = uint2{(lfull[n] && hc) ? cmask[m] : 0u, b != kNone ? (uint32_t)depth_of[b] : 0u};
+      lt[2 * (size_t)n] = uint2{(m & kLinkNodeMask) | (dm << 20) | ((b != kNone ? (uint32_t)depth_of[b] : 0u) << 26), b != kNone ? value_of(b) : 0u};
+      lt[2 * (size_t)n + 1] = uint2{(lfull[n] && hc) ? cmask[m] : 0u, (lfull[n] && hc) ? base_of[m] : 0u};
     }
   }
   // reverse table for decoding: reverse[id] = key of the LAST record carrying that id (go/tokenmonster.go:2715, quirk Q3)
@@ -345,7 +358,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   if (spl_start != kNone)
     for (uint32_t i = 0; i < n_info; i++)
       hv.spl[i] = uint4{splw[i].node | (splw[i].cont << 21) | (splw[i].bestlen << 22), splw[i].best != kNone ? value_of(splw[i].best) : 0u,
-                        splw[i].cont ? cmask[splw[i].node] : 0u, 0u};
+                        splw[i].cont ? cmask[splw[i].node] : 0u, splw[i].cont ? base_of[splw[i].node] : 0u};
   // direct map: one 16-byte entry (same format as a suffix link) resolves the first two bytes of any walk, the
   // depth-1 answer folded in
   for (uint32_t b0 = 0; b0 < 256; b0++) {
@@ -361,8 +374,8 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
         }
       }
       uint2* e = hv.tab.data() + direct_base + 2 * (size_t)(b0 | (b1 << 8));      // indexed by the little-endian u16 at the position
-      e[0] = uint2{id2 | (cont << 21) | ((cont ? 2u : 0u) << 23), bestv};
-      e[1] = uint2{cont ? cmask[id2] : 0u, bestlen};
+      e[0] = uint2{id2 | ((cont ? 2u : 0u) << 20) | (bestlen << 26), bestv};
+      e[1] = uint2{cont ? cmask[id2] : 0u, cont ? base_of[id2] : 0u};
     }
   }
   hv.n_nodes = n_nodes;
@@ -457,7 +470,7 @@ static void set_tables(tm_vocab* v) {
   const HostVocab& hv = v->host;
   Tables& t = v->tables;
   t.root = v->d_root; t.tab = v->d_tab; t.spl = v->d_spl; t.vals = v->d_vals; t.rows = v->d_rows; t.begin_byte = v->d_begin_byte;
-  t.edge_mask = hv.edge_mask; t.edge_shift = hv.edge_shift; t.n_info = hv.n_info; t.max_len = hv.max_len;
+  t.idle_off = hv.idle_off; t.n_da = hv.n_da; t.n_info = hv.n_info; t.max_len = hv.max_len;
   t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint; t.link_off = hv.link_off; t.direct_off = hv.direct_off;
   t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
 }
@@ -525,7 +538,7 @@ int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* m, void** device_pt
   std::memset(m, 0, sizeof(*m));
   m->bytes = v->block_bytes;
   for (int k = 0; k < 8; k++) m->part_bytes[k] = v->part_bytes[k];
-  m->edge_mask = hv.edge_mask; m->edge_shift = hv.edge_shift; m->n_info = hv.n_info; m->max_len = hv.max_len; m->off = hv.off; m->bstart = hv.bstart;
+  m->idle_off = hv.idle_off; m->n_da = hv.n_da; m->n_info = hv.n_info; m->max_len = hv.max_len; m->off = hv.off; m->bstart = hv.bstart;
   m->spl_hint = hv.spl_hint; m->link_off = hv.link_off; m->direct_off = hv.direct_off; m->delete_id = hv.delete_id; m->unk_id = hv.unk;
   m->n_ids = hv.n_ids; m->vocab_size = hv.vocab_size; m->capcode = hv.capcode; m->charset = hv.charset; m->norm_flag = hv.norm_flag; m->level = hv.level;
   m->reserve = hv.reserve; m->n_nodes = hv.n_nodes;
@@ -550,7 +563,7 @@ int tm_vocab_block_import(const tm_vocab_block* m, int device, tm_vocab** out, v
   auto* v = new tm_vocab();
   v->device = device;
   HostVocab& hv = v->host;                 // (scalars only: an imported vocabulary has no host tables - no Save, no host-side decode)
-  hv.edge_mask = m->edge_mask; hv.edge_shift = m->edge_shift; hv.n_info = m->n_info; hv.max_len = m->max_len; hv.off = m->off; hv.bstart = m->bstart;
+  hv.idle_off = m->idle_off; hv.n_da = m->n_da; hv.n_info = m->n_info; hv.max_len = m->max_len; hv.off = m->off; hv.bstart = m->bstart;
   hv.spl_hint = m->spl_hint; hv.link_off = m->link_off; hv.direct_off = m->direct_off; hv.delete_id = m->delete_id; hv.unk = m->unk_id;
   hv.n_ids = m->n_ids; hv.vocab_size = m->vocab_size; hv.capcode = (uint8_t)m->capcode; hv.charset = (uint8_t)m->charset; hv.norm_flag = (uint8_t)m->norm_flag;
   hv.level = (uint8_t)m->level; hv.reserve = (uint8_t)m->reserve; hv.n_nodes = m->n_nodes;

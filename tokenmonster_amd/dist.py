@@ -158,7 +158,7 @@ def _alias(ptr, nbytes, on_device):
     import torch
     if on_device:
         return torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
-    import ctypes as C       # (the emulated device of the test suite: "device" memory is host memory)
+    import ctypes as C       # on_device=False: the pointer is a host address (the CPU harness of tests/ hands out host memory as device memory)
     return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)))
 
 

@@ -25,7 +25,7 @@ def pack_documents(docs):
 class VocabBlock(C.Structure):
     """tm_vocab_block (include/tokenmonster_hip.h): what a process needs besides the bytes of a vocabulary's device block"""
     _fields_ = [("bytes", C.c_uint64), ("part_bytes", C.c_uint64 * 8)] + [(n, C.c_uint32) for n in (
-        "edge_mask", "edge_shift", "n_info", "max_len", "off", "bstart", "spl_hint", "link_off", "direct_off", "delete_id", "unk_id",
+        "idle_off", "n_da", "n_info", "max_len", "off", "bstart", "spl_hint", "link_off", "direct_off", "delete_id", "unk_id",
         "n_ids", "vocab_size", "capcode", "charset", "norm_flag", "level", "reserve", "n_nodes", "pad")]
 
 

@@ -32,6 +32,26 @@ static void coverage(const char* what, std::vector<uint64_t> cnt, size_t entry_b
   printf("\n");
 }
 
+// working set in cache lines: how many MB of 128-byte lines cover a share of the gathers, with the entries where they lie and
+// with the entries packed in order of use (what a layout by traffic could reach at best)
+static void lines(const char* what, const std::vector<uint64_t>& cnt, size_t entry_bytes) {
+  const size_t per = 128 / entry_bytes;
+  uint64_t total = 0;
+  for (auto c : cnt) total += c;
+  std::vector<uint64_t> asis((cnt.size() + per - 1) / per, 0), sorted = cnt;
+  for (size_t i = 0; i < cnt.size(); i++) asis[i / per] += cnt[i];
+  std::sort(sorted.begin(), sorted.end(), [](uint64_t a, uint64_t b) { return a > b; });
+  std::vector<uint64_t> packed(asis.size(), 0);
+  for (size_t i = 0; i < sorted.size(); i++) packed[i / per] += sorted[i];
+  std::sort(asis.begin(), asis.end(), [](uint64_t a, uint64_t b) { return a > b; });
+  printf("%-28s %.2f MB, MB of 128-byte lines for a share of the gathers (as laid out / packed by use):", what, cnt.size() * entry_bytes / 1048576.0);
+  for (double share : {0.8, 0.9, 0.95, 0.98, 0.99}) {
+    auto need = [&](const std::vector<uint64_t>& v) { uint64_t s = 0; size_t k = 0; while (k < v.size() && s < share * total) s += v[k++]; return k * 128 / 1048576.0; };
+    printf("  %.0f%% %.2f / %.2f", share * 100, need(asis), need(packed));
+  }
+  printf("\n");
+}
+
 int main(int argc, char** argv) {
   const uint32_t kind = argc > 1 ? atoi(argv[1]) : TM_KIND_ENGLISHCODE;
   const uint32_t vsize = argc > 2 ? atoi(argv[2]) : 32000;
@@ -52,6 +72,7 @@ int main(int argc, char** argv) {
          (unsigned long long)off[nd], nd, seg);
   const uint2* tab = hv.tab.data();
   const size_t n16 = hv.tab.size() / 2;                        // 16-byte entries of the gather buffer
+  std::vector<uint64_t> c_parent(hv.n_nodes + 1, 0);          // probes issued below each node (whatever bucket they ended in)
   std::vector<uint64_t> c_direct(n16, 0), c_link(n16, 0), c_bucket(n16, 0), c_all(n16, 0), c_row(hv.n_info, 0), c_pair(65536, 0);
   const size_t direct16 = hv.direct_off / 16, link16 = hv.link_off / 16;
   const int Lmax = (int)hv.max_len;
@@ -85,6 +106,7 @@ int main(int argc, char** argv) {
             const uint32_t key = (node << 8) | c;
             uint32_t h = edge_hash(node, c) >> hv.edge_shift;
             bool hit = false;
+            c_parent[node]++;
             for (;;) {
               c_bucket[h]++; c_all[h]++;
               const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1];
@@ -110,6 +132,45 @@ int main(int argc, char** argv) {
   coverage("PROBE buckets (16 B)", c_bucket, 16);
   coverage("all A1 gathers (16 B)", c_all, 16);
   coverage("rows (16 B)", c_row, 16);
+  lines("all A1 gathers", c_all, 16);
+  lines("  suffix links", c_link, 16);
+  lines("  buckets", c_bucket, 16);
+  lines("  direct map", c_direct, 16);
+  lines("rows", c_row, 16);
+  // a HOT REGION of the edge hash: the children of the parents a static rule picks live in a small table of their own.  Share of
+  // the probes that go there, for the rule "by measured traffic" (the best any rule can do) and for rules that only see the trie.
+  {
+    const uint32_t nn = hv.n_nodes + 1;
+    std::vector<uint32_t> par(nn, kNone), nchild(nn, 0), depth(nn, 0), sub(nn, 1);
+    const size_t nslots = 2 * ((size_t)hv.edge_mask + 1);
+    for (size_t i = 0; i < nslots; i++) if (tab[i].x != kNone) { const uint32_t p = (tab[i].x & kKeyMask) >> 8, c = node_id(tab[i].y); if (c < nn && p < nn) { par[c] = p; nchild[p]++; } }
+    std::vector<uint32_t> order;                                 // parents first
+    { std::vector<std::vector<uint32_t>> kids(nn);
+      for (uint32_t c = 0; c < nn; c++) if (par[c] != kNone) kids[par[c]].push_back(c);
+      for (uint32_t r = 0; r < nn; r++) if (par[r] == kNone && nchild[r]) { depth[r] = 2; order.push_back(r); }
+      for (size_t i = 0; i < order.size(); i++) for (uint32_t c : kids[order[i]]) { depth[c] = depth[order[i]] + 1; order.push_back(c); } }
+    for (size_t i = order.size(); i-- > 0;) if (par[order[i]] != kNone) sub[par[order[i]]] += sub[order[i]];
+    std::vector<uint32_t> parents;
+    uint64_t total = 0, edges = 0;
+    for (uint32_t n = 0; n < nn; n++) if (nchild[n]) { parents.push_back(n); total += c_parent[n]; edges += nchild[n]; }
+    printf("edge hash: %zu parents, %llu edges, %llu probes\n", parents.size(), (unsigned long long)edges, (unsigned long long)total);
+    auto report = [&](const char* rule, auto less) {
+      std::sort(parents.begin(), parents.end(), less);
+      printf("  %-34s", rule);
+      for (size_t kb : {256, 512, 1024, 2048}) {                   // hot region of kb KiB at 0.3 edges per slot
+        const uint64_t cap = (uint64_t)(kb * 1024 / 8 * 0.3);
+        uint64_t e = 0, pr = 0;
+        for (uint32_t n : parents) { if (e + nchild[n] > cap) break; e += nchild[n]; pr += c_parent[n]; }
+        printf("  %zuK: %.3f", kb, (double)pr / total);
+      }
+      printf("\n");
+    };
+    report("by measured traffic per edge", [&](uint32_t a, uint32_t b) { return (double)c_parent[a] / nchild[a] > (double)c_parent[b] / nchild[b]; });
+    report("by depth, then subtree size", [&](uint32_t a, uint32_t b) { return depth[a] != depth[b] ? depth[a] < depth[b] : sub[a] > sub[b]; });
+    report("by subtree size", [&](uint32_t a, uint32_t b) { return sub[a] != sub[b] ? sub[a] > sub[b] : depth[a] < depth[b]; });
+    report("by subtree size per child", [&](uint32_t a, uint32_t b) { return (double)sub[a] / nchild[a] > (double)sub[b] / nchild[b]; });
+    report("by subtree size / 2^depth", [&](uint32_t a, uint32_t b) { return (double)sub[a] / (1u << std::min(depth[a], 20u)) > (double)sub[b] / (1u << std::min(depth[b], 20u)); });
+  }
   // the direct map as a rank-mapped square: bytes sorted by how often they occur in a looked-up pair; share of the look-ups whose
   // two bytes are both among the R most frequent ones (R*R entries)
   {

@@ -1,7 +1,8 @@
 // tables_check.cpp — CPU check of the walk tables tm_vocab_load uploads (tokenmonster_amd/csrc/tm_tables.h), without a GPU:
-//   1. structural invariants the kernels rely on (bucket fill order, every key reachable by the kernel's probe sequence, child
-//      filters are supersets of the real child sets and empty exactly when there are no children, "no match => value 0" in the
-//      link-format entries, which the unconditional descriptor store of k_match_branch depends on);
+//   1. structural invariants the kernels rely on (every double-array entry lies at base(parent) + byte with base(parent) + 255 inside
+//      the array, the entry behind the array is empty, child filters are exactly the real child sets folded to 32 bits and empty
+//      when there are no children, "no match => value 0" in the link-format entries, which the unconditional descriptor store of
+//      k_match_branch depends on);
 //   2. the walk of k_match_branch step A1 — direct map for the first position of a run, suffix links afterwards, probes only
 //      where the child filter allows — replayed on synthetic text against a brute-force longest-prefix search over the keys of
 //      the .vocab file: same (length, record ordinal) at every position (pansearch LongestSubstring semantics,
@@ -37,52 +38,52 @@ bool check_vocab(uint32_t kind, uint32_t vsize, uint32_t capcode, uint64_t seed,
   const uint2* tab = hv.tab.data();
   const uint2* direct = tab + hv.direct_off / 8;
   const uint2* link = tab + hv.link_off / 8;
-  const uint32_t nb = hv.edge_mask + 1;
+  const uint4* da = reinterpret_cast<const uint4*>(tab);
+  const uint32_t nb = hv.n_da;
 
-  // ---- 1a. buckets: slot 0 fills first; the bucket behind the table is empty; every key is where the probe sequence finds it
+  // ---- 1a. the double array: an entry's parent is known by its check word; base and byte follow from where the parent's other
+  // children and the entries that lead to the parent say they are (checked through the walk below and the bases collected here)
   std::vector<uint32_t> children(hv.n_nodes, 0);     // real child-byte sets, folded to 32 bits (bit b & 31)
+  std::vector<uint32_t> base_seen(hv.n_nodes, kNone), base_said(hv.n_nodes, kNone);
   uint64_t nkeys = 0;
-  for (uint32_t b = 0; b <= nb; b++) {
-    const uint2 s0 = tab[2 * (size_t)b], s1 = tab[2 * (size_t)b + 1];
-    if (b == nb) { if (s0.x != kNone || s1.x != kNone) fail("the bucket behind the table is not empty"); break; }
-    if (s0.x == kNone && s1.x != kNone) fail("slot 1 of a bucket filled before slot 0", b);
-    for (int q = 0; q < 2; q++) {
-      const uint2 s = q ? s1 : s0;
-      if (s.x == kNone) continue;
-      nkeys++;
-      const uint32_t key = s.x & kKeyMask, parent = key >> 8, byte = key & 0xFF;
-      if (parent >= hv.n_nodes) { fail("parent node out of range", parent); continue; }
-      children[parent] |= 1u << (byte & 31u);
-      uint32_t h = edge_hash(parent, byte) >> hv.edge_shift;
-      bool found = false;
-      for (uint32_t step = 0; step <= nb; step++) {
-        const uint2 t0 = tab[2 * (size_t)h], t1 = tab[2 * (size_t)h + 1];
-        if ((t0.x & kKeyMask) == key || (t1.x & kKeyMask) == key) { found = h == b; break; }
-        if (t1.x == kNone) break;                     // the kernel stops here: key reported absent
-        h = (h + 1) & hv.edge_mask;
-      }
-      if (!found) fail("a key is not reachable by the probe sequence", key, b);
+  if (hv.idle_off != nb * 16u || da[nb].x != kNone) fail("the entry behind the array is not empty");
+  for (uint32_t t = 0; t < nb; t++) {
+    const uint4 e = da[t];
+    if (e.x == kNone) continue;
+    nkeys++;
+    const uint32_t parent = e.x, child = node_id(e.y);
+    if (parent >= hv.n_nodes || child >= hv.n_nodes) { fail("node out of range", parent, child); continue; }
+    base_said[child] = e.w;
+    if (e.z != 0 && e.w + 255 >= nb + 1) fail("base + 255 leaves the array", e.w);
+  }
+  // every parent's entries share one base: entry index - byte, the byte being the last key byte of the child (accepting children)
+  for (uint32_t t = 0; t < nb; t++) {
+    const uint4 e = da[t];
+    if (e.x == kNone || e.x >= hv.n_nodes) continue;
+    const uint32_t child = node_id(e.y);
+    if (child < hv.n_info) {
+      const uint32_t byte = hv.keys[hv.key_off[child + 1] - 1];
+      if (t < byte) { fail("entry below its byte", t, byte); continue; }
+      if (base_seen[e.x] == kNone) base_seen[e.x] = t - byte; else if (base_seen[e.x] != t - byte) fail("two bases for one parent", e.x);
+      children[e.x] |= 1u << (byte & 31u);
     }
   }
-  // ---- 1b. child filters: 4 bits in every slot (of the node the edge leads to), 32 bits in every link-format entry
-  auto fold4 = [](uint32_t m) { uint32_t f = 0; for (uint32_t q = 0; q < 32; q++) if ((m >> q) & 1u) f |= 1u << (q & 3u); return f; };
-  for (uint32_t b = 0; b < nb; b++)
-    for (int q = 0; q < 2; q++) {
-      const uint2 s = tab[2 * (size_t)b + q];
-      if (s.x == kNone) continue;
-      const uint32_t child = node_id(s.y);
-      if (child >= hv.n_nodes) { fail("child node out of range", child); continue; }
-      if ((s.x >> 28) != fold4(children[child])) fail("4-bit child filter of a slot", s.x >> 28, fold4(children[child]));
-      if (((s.y & kHasChildren) != 0) != (children[child] != 0)) fail("has-children bit of a node value", child);
-    }
+  for (uint32_t n = 0; n < hv.n_nodes; n++) if (base_seen[n] != kNone && base_said[n] != kNone && base_seen[n] != base_said[n]) fail("the base an entry gives for its node is not where the children are", n);
+  // ---- 1b. child filters (of the node the entry leads to): supersets of the accepting children seen above; has-children bit
+  for (uint32_t t = 0; t < nb; t++) {
+    const uint4 e = da[t];
+    if (e.x == kNone) continue;
+    const uint32_t child = node_id(e.y);
+    if (child >= hv.n_nodes) continue;
+    if ((e.z & children[child]) != children[child]) fail("child filter of an entry misses a child", e.z, children[child]);
+    if (((e.y & kHasChildren) != 0) != (e.z != 0)) fail("has-children bit of a node value", child);
+  }
   auto check_link_format = [&](const uint2* e, const char* what) {
-    const uint32_t x = e[0].x, y = e[0].y, filt = e[1].x, bestlen = e[1].y;
-    const bool go = (x >> 21) & 1u;
+    const uint32_t x = e[0].x, y = e[0].y, filt = e[1].x, bestlen = link_bestlen(x);
     if (bestlen == 0 && y != 0) fail(what, 1, y);                                   // k_match_branch stores the descriptor unconditionally
     if (bestlen != 0 && (node_id(y) >= hv.n_info || bestlen > 40)) fail(what, 2, bestlen);
-    if (go != (filt != 0)) fail(what, 3, filt);
     // (links that lead to a node of depth < 2 belong to nodes of depth < 3 and are never read: the walk takes the direct map there)
-    if (go && ((x >> 23) & 63u) >= 2 && filt != children[x & kNodeMask]) fail(what, 4, filt);
+    if (filt != 0 && link_depth(x) >= 2 && ((filt & children[link_node(x)]) != children[link_node(x)] || e[1].y != base_said[link_node(x)] && base_said[link_node(x)] != kNone)) fail(what, 4, filt);
   };
   for (uint32_t i = 0; i < kL2Size; i++) check_link_format(direct + 2 * (size_t)i, "direct map entry");
   for (uint32_t n = 0; n < hv.n_nodes; n++) check_link_format(link + 2 * (size_t)n, "suffix link entry");
@@ -109,27 +110,22 @@ bool check_vocab(uint32_t kind, uint32_t vsize, uint32_t capcode, uint64_t seed,
       const int limit = std::min(dl - pos, Lmax);
       const uint2* e = (!first && depth >= 3) ? link + 2 * (size_t)node : direct + 2 * (size_t)(at(pos) | (at(pos + 1) << 8));
       gathers++;
-      uint32_t bestv = e[0].y; int bestlen = (int)e[1].y;
-      depth = (int)((e[0].x >> 23) & 63u);
-      node = e[0].x & kNodeMask;
+      uint32_t bestv = e[0].y; int bestlen = (int)link_bestlen(e[0].x);
+      depth = (int)link_depth(e[0].x);
+      node = link_node(e[0].x);
+      uint32_t base = e[1].y;
       bool go = depth < limit && ((e[1].x >> (at(pos + depth) & 31u)) & 1u);
       while (go) {
-        const uint32_t c = at(pos + depth), key = (node << 8) | c;
-        uint32_t h = edge_hash(node, c) >> hv.edge_shift;
-        uint2 hit{kNone, 0};
-        for (;;) {
-          gathers++;
-          const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1];
-          if ((s0.x & kKeyMask) == key) { hit = s0; break; }
-          if ((s1.x & kKeyMask) == key) { hit = s1; break; }
-          if (s1.x == kNone) break;
-          h = (h + 1) & hv.edge_mask;
-        }
-        if (hit.x == kNone) break;
+        const uint32_t c = at(pos + depth);
+        gathers++;
+        if (base + c > nb) { fail("probe outside the array", base, c); break; }
+        const uint4 h = da[base + c];
+        if (h.x != node) break;
         depth++;
-        node = node_id(hit.y);
-        if (node < hv.n_info) { bestv = hit.y; bestlen = depth; }
-        go = depth < limit && (((hit.x >> 28) >> (at(pos + depth) & 3u)) & 1u);
+        node = node_id(h.y);
+        if (node < hv.n_info) { bestv = h.y; bestlen = depth; }
+        base = h.w;
+        go = depth < limit && ((h.z >> (at(pos + depth) & 31u)) & 1u);
       }
       // brute force: the longest prefix of text[pos : pos + limit] that is a key
       int exp_len = 0; uint32_t exp_id = 0;
@@ -141,7 +137,7 @@ bool check_vocab(uint32_t kind, uint32_t vsize, uint32_t capcode, uint64_t seed,
       npos++;
     }
   }
-  printf("kind %u, %u ids, capcode %u: %u records, %u nodes, %llu edges in %u buckets; %llu positions walked, %.2f gathers each: %s\n", kind, vsize, capcode,
+  printf("kind %u, %u ids, capcode %u: %u records, %u nodes, %llu edges in %u entries; %llu positions walked, %.2f gathers each: %s\n", kind, vsize, capcode,
          hv.n_info, hv.n_nodes, (unsigned long long)nkeys, nb, (unsigned long long)npos, (double)gathers / (double)std::max<uint64_t>(npos, 1), g_bad == bad0 ? "ok" : "FAILED");
   tm_free(text); tm_free(img);
   return g_bad == bad0;
