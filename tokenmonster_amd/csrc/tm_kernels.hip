@@ -529,6 +529,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();                                       // every wavefront of the workgroup has its descriptors
+  PH(3)
   if (share && lane < NPOS - SEG) {
     const WaveLds& nx = s_wave[wvi + 1];
     w.D[SEG + lane] = nx.D[lane];
@@ -563,6 +564,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       r0[it] = R_INVALID;
       if (p < seglen) r0[it] = transition<0>(T, w, s_bb, p, dl, d0[it], row0[it]);
     }
+    PH(1)
     const bool side_ok = n1 < SIDE_STRIDE && !(dbg & 64);          // (dbg & 64: tests force the dense path)
     for (int base = 0; base < n1; base += 64) {
       int run = 0;

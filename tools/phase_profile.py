@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("TM_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # TM_PKG_ROOT: a copy of the package with the phase-timer library
 from tokenmonster_amd import _native as N, synth, vocab as V   # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "englishcode-32000-consistent"
@@ -33,11 +33,11 @@ for _ in range(reps):
 lib.tm_debug_phases(out, 0)
 v = np.array(list(out), dtype=np.float64)
 nseg = v[12]
-names = ["stage+zero", "A1 refill", "A1 main loop", "A1 drain", "A2", "A3", "B", "C"]
+names = ["stage+zero", "B: rows + T(p,0)", "A1 main loop", "barrier wait", "A2", "A3", "B: T(p,1) + stores", "C"]
 tot = v[:8].sum()
 print("segments %d (x%d passes), k_match_branch %.3f ms" % (nseg / reps, reps, ms[1]))
 for i, n in enumerate(names):
-    print("%-14s %9.0f cycles/segment  %5.1f %%" % (n, v[i] / nseg, 100 * v[i] / tot))
+    print("%-20s %9.0f cycles/segment  %5.1f %%" % (n, v[i] / nseg, 100 * v[i] / tot))
 print("total %.0f cycles/segment" % (tot / nseg))
 print("per segment: main rounds %.1f, drain rounds %.1f, refills %.1f, A3 rounds %.1f, C rounds %.1f, A3 tasks %.1f, (p,1) states %.1f"
       % (v[8] / nseg, v[9] / nseg, v[10] / nseg, v[11] / nseg, v[13] / nseg, v[14] / nseg, v[15] / nseg))
