@@ -136,7 +136,7 @@ __device__ __forceinline__ uint32_t exit_entry(const uint16_t* __restrict__ exit
 // ------------------------------------------------------------------------------------------------
 // K1: match + branch
 // ------------------------------------------------------------------------------------------------
-// While the walks run, D[p] holds len[0..5] | nWords[6..10] | flag5[11..15] (bits 22..31 of the node value, shifted).
+// While the walks run, D[p] holds the length of the longest match and X[p] its node value.
 // Step A2 then folds everything a *second* token contributes to a branch score (go/tokenmonster.go:1075-1084) into the
 // final descriptor, so that scoring a branch is a handful of adds instead of re-deriving it six times per state:
 //   beginsWithLetter[0] | len[1..6] | beginsOnCapcode[8] | S[9..20]
@@ -199,15 +199,16 @@ __device__ __forceinline__ int alt_penalty(int flen, uint32_t dS, int len) {
 }
 
 struct WaveLds {
-  alignas(16) uint8_t text[TEXT_LEN];
   // (arrays of NPOS, not NPOS_PAD, entries: with the 256 bytes of begin_byte[] a workgroup takes exactly 20 KB, 8 workgroups = 32
   // wavefronts per CU fill the 160 KB; the loops over NPOS_PAD positions guard p < NPOS)
-  uint32_t D[NPOS];        // longest match at p                      (second-token descriptor)
+  alignas(16) uint32_t X[NPOS];        // node value of D's token (node id = record ordinal)
+  alignas(16) uint8_t text[TEXT_LEN];  // (between X and D: D[p] lies 6 * 256 bytes behind X[p], and step A1 stores both with one ds_write2st64_b32)
+  uint32_t D[NPOS];        // longest match at p                      (second-token descriptor); Db must follow (step C overlays both)
   uint32_t Db[NPOS];       // longest match of ' '+text[p:], if usable (forward-delete descriptor), 0 = none
-  uint32_t X[NPOS];        // node value of D's token (node id = record ordinal)
   uint32_t Xb[SEG];        // node value of Db's token
   uint16_t xch[64];        // dense task list of the forward-delete walks (step A3), one batch at a time
 };
+static_assert(offsetof(WaveLds, D) - offsetof(WaveLds, X) == 6 * 256 && offsetof(WaveLds, Db) == offsetof(WaveLds, D) + 4 * NPOS, "WaveLds layout");
 
 // T(p, fd): go/tokenmonster.go:1051-1276
 template <int FD>
@@ -361,16 +362,12 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
     const bool tail_here = !share && dl <= NPOS;                    // the document's last byte is one of this wavefront's positions
     const int nwalkpos = tail_here ? ntask - 1 : ntask;             // positions with at least two bytes of text left
-    if (lane == 0 && tail_here && ntask > 0) {
-      const uint32_t r = T.root[w.text[dl - 1]];
-      if (r != kNone && node_id(r) < T.n_info) { w.D[dl - 1] = 1u | ((r >> 22) << 6); w.X[dl - 1] = r; }
-    }
     // Positions are carried as LDS byte addresses of their text byte (one add less per use, and the kernel is VALU bound).
     typedef TM_LDS_SPACE uint8_t lds_u8;
     typedef TM_LDS_SPACE_UNALIGNED uint16_t lds_u16u;
     typedef TM_LDS_SPACE uint32_t lds_u32;
     const uint32_t tb = TM_LDS_ADDR(w.text);                                        // address of text[0]
-    const uint32_t dconst = TM_LDS_ADDR(w.D) - 4u * tb;                               // &D[i] == dconst + 4 * (tb + i)
+    const uint32_t xconst = TM_LDS_ADDR(w.X) - 4u * tb;                               // &X[i] == xconst + 4 * (tb + i), &D[i] 6 * 256 bytes behind
     const int run = (max(nwalkpos, 0) + 63) >> 6;
     uint32_t posa = tb + (uint32_t)(lane * run);
     const uint32_t enda = tb + (uint32_t)max(min(lane * run + run, nwalkpos), 0), dla = tb + (uint32_t)dl;
@@ -381,6 +378,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       limit = min((int)(dla - posa), Lmax);
       off = T.direct_off + ((uint32_t)*TM_LDS_PTR(lds_u16u, posa) << 4);
       pfa = posa + 2u;
+    } else {
+      // a lane without positions stores its (0, 0) every round like the others: into Db[lane] and, 6 * 256 bytes behind, Xb[..], which are
+      // all zero / not in use before step A3
+      static_assert(offsetof(WaveLds, Db) + 4 * 63 + 6 * 256 + 4 <= offsetof(WaveLds, xch) && offsetof(WaveLds, Db) + 6 * 256 >= offsetof(WaveLds, Xb), "dump words");
+      posa = tb + (uint32_t)((offsetof(WaveLds, Db) - offsetof(WaveLds, X)) / 4) + (uint32_t)lane;
     }
 #ifdef TM_DEVEL
     const bool nowalk = (dbg & 4) != 0;
@@ -389,17 +391,17 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     // the scalar unit, not the vector unit, is the busier issue port of this loop (profiles/r03_k1_issue_ports.txt: one more scalar
     // instruction per round costs 1.6 x one more vector instruction): the structured control flow the compiler builds from `if`s on
     // per-lane booleans — save / restore of exec around every block, mask algebra for every && and || — was ~60 scalar instructions
-    // per round, the eight mask operations below are what the state machine needs.  A lane's state is its key: KEY_SET (the gather is
-    // a link-format entry), KEY_IDLE (nothing to do; it gathers the always-empty bucket), anything else = the edge being probed.
-    key = setting ? KEY_SET : KEY_IDLE;
-    uint32_t v_link = T.link_off, v_direct = T.direct_off, v_idle = idle_off, v_kset = KEY_SET, v_kidle = KEY_IDLE;
-    TM_KEEP_IN_VGPRS4(v_link, v_direct, v_idle, v_kset);          // operands of the selects: registers for the whole loop, not moves per round
-    TM_KEEP_IN_VGPRS2(v_kidle, v_kset);
-    const uint32_t dump0 = TM_LDS_ADDR(&w.Xb[lane]), dump1 = TM_LDS_ADDR(&w.Xb[64 + lane]);      // where the stores of a lane that has nothing to store go (Xb is not in use before step A3)
+    // per round, the mask operations below are what the state machine needs.  A lane is SETTING (its gather is a link-format entry: the
+    // mask `setm`, carried from round to round), PROBING (a double-array entry, valid if its check word is `key`) or idle (it gathers
+    // the always-empty entry, which is nobody's child).
+    uint32_t v_link = T.link_off, v_direct = T.direct_off, v_idle = idle_off;
+    TM_KEEP_IN_VGPRS2(v_link, v_direct);
+    TM_KEEP_IN_VGPRS2(v_idle, v_link);            // operands of the selects: registers for the whole loop, not moves per round
     auto rounds = [&](auto tail_tag) {
       constexpr bool TAIL = decltype(tail_tag)::value;
       // (The loop exists twice: when the document goes on for at least Lmax bytes behind the last position of the segment, no walk is
       // cut short by the end of the text and `limit` is the constant Lmax.)
+      M64 setm = __builtin_amdgcn_ballot_w64(setting);
       for (;;) {
         const M64 busy = __builtin_amdgcn_ballot_w64(off != idle_off);
         if (busy == 0ull) break;
@@ -408,39 +410,49 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);
         TM_KEEP_IN_VGPRS2(c, nn);
         // a double-array entry is the child being probed for iff its check word is the parent (tm_tables.h); a link-format entry always "hits"
-        const M64 hit = __builtin_amdgcn_ballot_w64(e.x == key), set = __builtin_amdgcn_ballot_w64(key == KEY_SET);
-        const M64 adv = hit | set;
-        const uint32_t nid = sel_mask(set, e.x, e.y) & kLinkNodeMask;
+        const M64 hit = __builtin_amdgcn_ballot_w64(e.x == key) & ~setm;
+        const M64 adv = hit | setm;
+        const uint32_t nid = sel_mask(setm, e.x, e.y) & kLinkNodeMask;
         node = sel_mask(adv, nid, node);
-        depth = (int)sel_mask(set, link_depth(e.x), sel_mask(hit, (uint32_t)depth + 1u, (uint32_t)depth));
+        depth = (int)sel_mask(setm, link_depth(e.x), add_mask_bit((uint32_t)depth, hit));
         const M64 acc = hit & __builtin_amdgcn_ballot_w64(nid < T.n_info);
-        bestv = sel_mask(set | acc, e.y, bestv);
-        bestlen = (int)sel_mask(set, link_bestlen(e.x), sel_mask(acc, (uint32_t)depth, (uint32_t)bestlen));
+        bestv = sel_mask(setm | acc, e.y, bestv);
+        bestlen = (int)sel_mask(setm, link_bestlen(e.x), sel_mask(acc, (uint32_t)depth, (uint32_t)bestlen));
         // probe only for a byte the node can continue with: bit (c & 31) of its child filter (0 behind a link that cannot go on)
         M64 go = adv & __builtin_amdgcn_ballot_w64(((e.z >> (c & 31u)) & 1u) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
 #ifdef TM_DEVEL
         if (nowalk) go = 0ull;
 #endif
         const M64 fin = busy & ~go;
-        // the position is done: store it (no match: bestlen == 0 and the link formats give bestv == 0: the 0 that is there already) ...
-        const uint32_t daddr = dconst + 4u * posa;
-        *TM_LDS_PTR(lds_u32, sel_mask(fin, daddr, dump0)) = (uint32_t)bestlen | ((bestv >> 22) << 6);      // D[pos]
-        *TM_LDS_PTR(lds_u32, sel_mask(fin, daddr + 8u * NPOS, dump1)) = bestv;                                // X[pos]
+        // the best match so far at the lane's position, every round (the last store of a position is its result; a lane that has run out
+        // of positions stays on its last one and stores the same values again): no select of a store address, and ONE store for both
+        // words (WaveLds: D[p] lies 6 * 256 bytes behind X[p]).  No match: bestlen == 0 and the link formats give bestv == 0.
+        {
+          TM_LDS_SPACE uint32_t* xp = TM_LDS_PTR(lds_u32, xconst + 4u * posa);
+          xp[0] = bestv;                                                                                      // X[pos]
+          xp[6 * 64] = (uint32_t)bestlen;                                                                      // D[pos]
+        }
         // ... and move on: through the suffix link if the walk got deep enough, else from the direct map
         const uint32_t posn = posa + 1u;
         const M64 more = __builtin_amdgcn_ballot_w64(posn < enda), deep = __builtin_amdgcn_ballot_w64(depth >= 3);
         const uint32_t off_f = sel_mask(more, sel_mask(deep, v_link, v_direct) + (sel_mask(deep, node, nn) << 4), v_idle);
-        const uint32_t pfa_f = posn + (uint32_t)max(depth, 3) - 1u;            // depth >= 3: posn + depth - 1, else posn + 2
-        // the next gather of a walk that goes on: entry base + byte
-        key = sel_mask(fin, sel_mask(more, v_kset, v_kidle), sel_mask(go, nid, key));
-        off = sel_mask(fin, off_f, sel_mask(go, (e.w + c) << 4, off));
-        pfa = sel_mask(fin, pfa_f, sel_mask(go, posa + (uint32_t)depth + 1u, pfa));
+        // a walk that goes on probes entry base + byte for the byte behind the one just read (also behind a link: it stands for the bytes
+        // up to there); the first byte a new position reads: posn + depth - 1 behind a suffix link, posn + 2 behind the direct map
+        key = sel_mask(go, nid, key);
+        off = sel_mask(go, (e.w + c) << 4, off_f);                              // (an idle lane has no more positions: off_f is the idle entry)
+        pfa = sel_mask(go, pfa + 1u, posn + (uint32_t)max(depth, 3) - 1u);
         if (TAIL) limit = (int)sel_mask(fin, (uint32_t)min((int)(dla - posn), Lmax), (uint32_t)limit);
-        posa = sel_mask(fin, posn, posa);
+        setm = fin & more;
+        posa = sel_mask(setm, posn, posa);
         PH_INC(8)
       }
     };
     if (dl >= NPOS + Lmax) rounds(std::false_type{}); else rounds(std::true_type{});
+    // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
+    if (lane == 0 && tail_here && ntask > 0) {
+      const uint32_t r = T.root[w.text[dl - 1]];
+      if (r != kNone && node_id(r) < T.n_info) { w.D[dl - 1] = 1u; w.X[dl - 1] = r; }
+    }
     PH(2)
   }
   __builtin_amdgcn_wave_barrier();
@@ -458,12 +470,13 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 #pragma unroll
     for (int it = 0; it < NPOS_PAD / 64; it++) {
       const int p = it * 64 + lane;
-      uint32_t d = (p < NPOS && !(share && p >= SEG)) ? w.D[p] : 0u;
+      const uint32_t d = (p < NPOS && !(share && p >= SEG)) ? w.D[p] : 0u;      // length of the longest match (step A1)
       bool el = false;
       if (d != 0) {
-        const uint32_t nb = s_bb[w.text[p + (d & 63u)]];
-        el = can_b && ((d >> 12) & 1u) && (((d >> 13) & 1u) | (T.spl_hint ^ 1u)) && nb == 1 && ((d >> 6) & 31u) == 0 && min(dl - p, Lmax - off) > 0;
-        w.D[p] = make_sdesc(d & 63u, (d >> 6) << 22, nb, false, T.spl_hint);
+        const uint32_t v = w.X[p];
+        const uint32_t nb = s_bb[w.text[p + d]];
+        el = can_b && ((v >> 28) & 1u) && (((v >> 29) & 1u) | (T.spl_hint ^ 1u)) && nb == 1 && node_nwords(v) == 0 && min(dl - p, Lmax - off) > 0;
+        w.D[p] = make_sdesc(d, v, nb, false, T.spl_hint);
       }
       elig[it] = __ballot(el);
     }

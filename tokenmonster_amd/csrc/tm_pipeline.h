@@ -43,6 +43,17 @@ __device__ __forceinline__ uint32_t sel_mask(unsigned long long mask, uint32_t a
   return r;
 #endif
 }
+// a + (bit of the lane in a wave-uniform mask): the mask goes in as the carry of ONE add (v_addc_co), instead of an add and a select
+__device__ __forceinline__ uint32_t add_mask_bit(uint32_t a, unsigned long long mask) {
+#ifdef TM_EMU
+  return a + (uint32_t)((mask >> emu::cur->lane) & 1ull);
+#else
+  uint32_t r;
+  unsigned long long carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carry_out) : "v"(a), "s"(mask));
+  return r;
+#endif
+}
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask, uint32_t acc) {      // acc + #set bits of mask below the lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, acc));
 }
