@@ -335,7 +335,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   // start over at p+1 but follows the suffix link of n (tm_tables.h) — the state of the walk of text[p+1:] after the
   // bytes already known to match — and only probes for what may come after them.  ~3.1 gathers per position instead of
   // ~4.9 (two-byte map + one probe per further byte).  (pansearch LongestSubstring, call sites go/tokenmonster.go:1049..)
-  for (int j = lane; j < NPOS; j += 64) { w.D[j] = 0; w.Db[j] = 0; }
+  static_assert((2 * NPOS * 4) % 16 == 0 && offsetof(WaveLds, D) % 16 == 0, "D and Db are zeroed as 16-byte words");
+  for (int j = lane; j < 2 * NPOS / 4; j += 64) reinterpret_cast<uint4*>(w.D)[j] = make_uint4(0u, 0u, 0u, 0u);      // D and Db
   __builtin_amdgcn_wave_barrier();
   PH(0)
   PH_COUNT(12, 1)
@@ -526,13 +527,14 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       while (__any(!walk_idle(k))) {
         const uint4 e = *reinterpret_cast<const uint4*>(tabb + k.hoff);
         const uint32_t c = w.text[k.tbase + k.depth + 1];
-        if (walk_consume(T, k, e, c) && k.bestlen > mainlen + 1) {
-          const int lb = k.bestlen - off;                              // go :1093
-          w.Db[k.pos] = make_sdesc((uint32_t)lb, k.bestv, s_bb[w.text[k.pos + lb]], true, T.spl_hint);
-          if (k.pos < SEG) w.Xb[k.pos] = k.bestv;
-        }
-        k.bestlen = walk_idle(k) ? 0 : k.bestlen;
+        walk_consume(T, k, e, c);
         PH_INC(11)
+      }
+      // a lane walks ONE task per batch: what it found is stored once, after the loop (not in the round in which its walk happens to end)
+      if (k.bestlen > mainlen + 1) {
+        const int lb = k.bestlen - off;                              // go :1093
+        w.Db[k.pos] = make_sdesc((uint32_t)lb, k.bestv, s_bb[w.text[k.pos + lb]], true, T.spl_hint);
+        if (k.pos < SEG) w.Xb[k.pos] = k.bestv;
       }
       __builtin_amdgcn_wave_barrier();
     }

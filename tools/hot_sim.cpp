@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
   std::vector<uint64_t> c_direct(n16, 0), c_link(n16, 0), c_bucket(n16, 0), c_all(n16, 0), c_row(hv.n_info, 0), c_pair(65536, 0);
   const size_t direct16 = hv.direct_off / 16, link16 = hv.link_off / 16;
   const int Lmax = (int)hv.max_len;
-  uint64_t npos = 0, nrow = 0;
+  uint64_t npos = 0, nrow = 0, nwaves = 0, tot_rounds = 0, sum_lane_rounds = 0, tot_rounds_c[4] = {0, 0, 0, 0};
   for (uint32_t d = 0; d < nd; d++) {
     const uint64_t b0 = off[d], e0 = off[d + 1];
     for (uint64_t begin = b0; begin < e0; begin += seg) {
@@ -87,9 +87,11 @@ int main(int argc, char** argv) {
       const int ntask = std::min(np, dl);
       const int nwalkpos = dl <= np ? ntask - 1 : ntask;
       const int run = (std::max(nwalkpos, 0) + 63) >> 6;
+      int wave_rounds = 0, wave_rounds_c[4] = {0, 0, 0, 0};
       for (int lane = 0; lane < 64; lane++) {
         const int end = std::max(std::min(lane * run + run, nwalkpos), 0);
         int depth = 0; uint32_t node = 0; bool first = true;
+        int lane_rounds = 0, lane_rounds_c[4] = {0, 0, 0, 0};
         for (int pos = lane * run; pos < end; pos++) {
           const int limit = std::min(dl - pos, Lmax);
           size_t e16;
@@ -97,39 +99,47 @@ int main(int argc, char** argv) {
           else { const uint32_t pr = at(pos) | (at(pos + 1) << 8); e16 = direct16 + pr; c_direct[e16]++; c_pair[pr]++; }
           c_all[e16]++;
           const uint2* e = tab + 2 * e16;
-          uint32_t src = e[0].x, filt = e[1].x, bestv = e[0].y;
-          depth = (int)((src >> 23) & 63u); node = src & kNodeMask;
-          bool from_set = true, go = (src & kHasChildren) != 0 && depth < limit;
+          uint32_t src = e[0].x, filt = e[1].x, bestv = e[0].y, base = e[1].y;
+          depth = (int)link_depth(src); node = link_node(src);
+          int rounds = 1, rounds_c[4] = {1, 1, 1, 1};       // this position's rounds: as built / with unary non-accepting chains walked 2, 3, 4 bytes per probe
+          int chain = 0;                                      // probes since the last node that is accepting or branches
+          bool go = depth < limit;
           while (go) {
             const uint32_t c = at(pos + depth);
-            if (from_set ? !((filt >> (c & 31u)) & 1u) : !((filt >> (c & 3u)) & 1u)) break;
-            const uint32_t key = (node << 8) | c;
-            uint32_t h = edge_hash(node, c) >> hv.edge_shift;
-            bool hit = false;
-            c_parent[node]++;
-            for (;;) {
-              c_bucket[h]++; c_all[h]++;
-              const uint2 s0 = tab[2 * (size_t)h], s1 = tab[2 * (size_t)h + 1];
-              if ((s0.x & kKeyMask) == key) { hit = true; src = s0.y; filt = s0.x >> 28; break; }
-              if ((s1.x & kKeyMask) == key) { hit = true; src = s1.y; filt = s1.x >> 28; break; }
-              if (s1.x == kNone) break;
-              h = (h + 1) & hv.edge_mask;
-            }
-            if (!hit) break;
-            from_set = false; depth++; node = src & kNodeMask;
-            if (node < hv.n_info) bestv = src;
-            go = (src & kHasChildren) != 0 && depth < limit;
+            if (!((filt >> (c & 31u)) & 1u)) break;
+            const size_t h = (size_t)base + c;
+            c_parent[node]++; c_bucket[h]++; c_all[h]++;
+            rounds++;
+            const uint4 d = reinterpret_cast<const uint4*>(tab)[h];
+            if (d.x != node) { for (int q = 0; q < 4; q++) rounds_c[q]++; break; }
+            // a probe is free in the compressed models if it continues a chain: the previous node had one child and was not accepting
+            const bool unary_prev = depth >= 3 && chain > 0;
+            for (int q = 0; q < 4; q++) if (!(unary_prev && (chain % (q + 1)) != 0)) rounds_c[q]++;
+            depth++; node = node_id(d.y);
+            if (node < hv.n_info) bestv = d.y;
+            const bool plain = node >= hv.n_info && d.z != 0 && (d.z & (d.z - 1)) == 0;    // not accepting, children over one residue (mostly: one child)
+            chain = plain ? chain + 1 : 0;
+            filt = d.z; base = d.w;
+            go = (d.y & kHasChildren) != 0 && depth < limit;
           }
+          lane_rounds += rounds;
+          for (int q = 0; q < 4; q++) lane_rounds_c[q] += rounds_c[q];
           if (pos < seg && bestv != 0 && node_id(bestv) < hv.n_info) { c_row[node_id(bestv)]++; nrow++; }
           first = false; npos++;
         }
+        wave_rounds = std::max(wave_rounds, lane_rounds); sum_lane_rounds += lane_rounds;
+        for (int q = 0; q < 4; q++) wave_rounds_c[q] = std::max(wave_rounds_c[q], lane_rounds_c[q]);
       }
+      nwaves++; tot_rounds += wave_rounds;
+      for (int q = 0; q < 4; q++) tot_rounds_c[q] += wave_rounds_c[q];
     }
   }
   printf("positions walked %llu (%.3f per byte), row gathers %.3f per byte\n", (unsigned long long)npos, (double)npos / off[nd], (double)nrow / off[nd]);
+  printf("step A1: %.2f rounds per wavefront (the slowest lane), %.2f per lane on average; with unary chains walked k bytes per probe: k=2 %.2f, k=3 %.2f, k=4 %.2f\n",
+         (double)tot_rounds / nwaves, (double)sum_lane_rounds / nwaves / 64, (double)tot_rounds_c[1] / nwaves, (double)tot_rounds_c[2] / nwaves, (double)tot_rounds_c[3] / nwaves);
   coverage("SET via direct map (16 B)", c_direct, 16);
   coverage("SET via suffix link (16 B)", c_link, 16);
-  coverage("PROBE buckets (16 B)", c_bucket, 16);
+  coverage("PROBE entries (16 B)", c_bucket, 16);
   coverage("all A1 gathers (16 B)", c_all, 16);
   coverage("rows (16 B)", c_row, 16);
   lines("all A1 gathers", c_all, 16);
@@ -142,8 +152,7 @@ int main(int argc, char** argv) {
   {
     const uint32_t nn = hv.n_nodes + 1;
     std::vector<uint32_t> par(nn, kNone), nchild(nn, 0), depth(nn, 0), sub(nn, 1);
-    const size_t nslots = 2 * ((size_t)hv.edge_mask + 1);
-    for (size_t i = 0; i < nslots; i++) if (tab[i].x != kNone) { const uint32_t p = (tab[i].x & kKeyMask) >> 8, c = node_id(tab[i].y); if (c < nn && p < nn) { par[c] = p; nchild[p]++; } }
+    for (size_t i = 0; i < hv.n_da; i++) { const uint4 d = reinterpret_cast<const uint4*>(tab)[i]; if (d.x != kNone) { const uint32_t pnode = d.x, c = node_id(d.y); if (c < nn && pnode < nn) { par[c] = pnode; nchild[pnode]++; } } }
     std::vector<uint32_t> order;                                 // parents first
     { std::vector<std::vector<uint32_t>> kids(nn);
       for (uint32_t c = 0; c < nn; c++) if (par[c] != kNone) kids[par[c]].push_back(c);
