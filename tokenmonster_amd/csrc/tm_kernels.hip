@@ -279,7 +279,7 @@ __device__ unsigned long long g_phase[64 * 32];
 // segment sits in the same workgroup and the same document, this wavefront walks 256 positions instead of 296 (runs of 4 instead of 5
 // per lane) and copies the neighbour's descriptors after ONE workgroup barrier.  Step C's pointer-doubling table then overlays
 // D[40..] / Db[40..] instead of D[0..], so that a wavefront never overwrites what its left neighbour may still be copying.
-// Host model (tools/a1_sim.cpp): 70 % of the wavefronts share, 26.5 -> 24.3 rounds per wavefront in step A1.
+// Host model (round 2): 70 % of the wavefronts share, 26.5 -> 24.3 rounds per wavefront in step A1.
 constexpr int J_SKIP = NPOS - SEG, J_PLANE = NPOS;     // step C: state (p, fd) lives at word J_SKIP + fd * J_PLANE + p of {D, Db}
 __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,

@@ -75,6 +75,30 @@ int main(int argc, char** argv) {
   std::vector<uint64_t> c_parent(hv.n_nodes + 1, 0);          // probes issued below each node (whatever bucket they ended in)
   std::vector<uint64_t> c_direct(n16, 0), c_link(n16, 0), c_bucket(n16, 0), c_all(n16, 0), c_row(hv.n_info, 0), c_pair(65536, 0);
   const size_t direct16 = hv.direct_off / 16, link16 = hv.link_off / 16;
+  // TAIL model: a chain of one-child, non-accepting nodes that ends in an accepting leaf, entered at its head c: tail_len[c] = edges from c to the leaf
+  std::vector<uint32_t> tail_len(hv.n_nodes + 1, 0);
+  {
+    const uint32_t nn = hv.n_nodes + 1;
+    std::vector<uint32_t> nch(nn, 0), only(nn, kNone);
+    std::vector<uint8_t> haskids(nn, 0);
+    for (size_t i = 0; i < hv.n_da; i++) { const uint4 d = reinterpret_cast<const uint4*>(tab)[i]; if (d.x != kNone && d.x < nn) { nch[d.x]++; only[d.x] = node_id(d.y); } }
+    // memo from the leaves up: process nodes repeatedly along chains (chains are short: <= 40)
+    for (uint32_t c = 0; c < nn; c++) {
+      if (c < hv.n_info || nch[c] != 1) continue;                 // heads must be plain
+      uint32_t n = c, L = 0; bool ok = false;
+      for (int step = 0; step < 64; step++) {
+        if (n >= nn) break;
+        if (n < hv.n_info) { ok = nch[n] == 0; break; }            // accepting: a leaf ends the chain, anything else breaks it
+        if (nch[n] != 1) break;
+        n = only[n]; L++;
+      }
+      if (ok) tail_len[c] = L;
+    }
+    uint64_t heads = 0, sumL = 0;
+    for (uint32_t c = 0; c < nn; c++) if (tail_len[c] >= 3) { heads++; sumL += tail_len[c]; }
+    printf("TAIL model: %llu nodes head a chain of >= 3 one-child nodes to an accepting leaf (mean length %.1f)\n", (unsigned long long)heads, heads ? (double)sumL / heads : 0.0);
+  }
+  uint64_t tot_rounds_t[3] = {0, 0, 0}, tot_maxpos = 0;                            // chains of >= 3 / >= 5 / >= 8 as tails
   const int Lmax = (int)hv.max_len;
   uint64_t npos = 0, nrow = 0, nwaves = 0, tot_rounds = 0, sum_lane_rounds = 0, tot_rounds_c[4] = {0, 0, 0, 0};
   for (uint32_t d = 0; d < nd; d++) {
@@ -87,11 +111,11 @@ int main(int argc, char** argv) {
       const int ntask = std::min(np, dl);
       const int nwalkpos = dl <= np ? ntask - 1 : ntask;
       const int run = (std::max(nwalkpos, 0) + 63) >> 6;
-      int wave_rounds = 0, wave_rounds_c[4] = {0, 0, 0, 0};
+      int wave_rounds = 0, wave_rounds_c[4] = {0, 0, 0, 0}, wave_rounds_t[3] = {0, 0, 0}, wave_maxpos = 0;
       for (int lane = 0; lane < 64; lane++) {
         const int end = std::max(std::min(lane * run + run, nwalkpos), 0);
         int depth = 0; uint32_t node = 0; bool first = true;
-        int lane_rounds = 0, lane_rounds_c[4] = {0, 0, 0, 0};
+        int lane_rounds = 0, lane_rounds_c[4] = {0, 0, 0, 0}, lane_rounds_t[3] = {0, 0, 0};
         for (int pos = lane * run; pos < end; pos++) {
           const int limit = std::min(dl - pos, Lmax);
           size_t e16;
@@ -103,6 +127,7 @@ int main(int argc, char** argv) {
           depth = (int)link_depth(src); node = link_node(src);
           int rounds = 1, rounds_c[4] = {1, 1, 1, 1};       // this position's rounds: as built / with unary non-accepting chains walked 2, 3, 4 bytes per probe
           int chain = 0;                                      // probes since the last node that is accepting or branches
+          int rounds_t[3] = {1, 1, 1}; bool in_tail[3] = {false, false, false};
           bool go = depth < limit;
           while (go) {
             const uint32_t c = at(pos + depth);
@@ -111,10 +136,16 @@ int main(int argc, char** argv) {
             c_parent[node]++; c_bucket[h]++; c_all[h]++;
             rounds++;
             const uint4 d = reinterpret_cast<const uint4*>(tab)[h];
-            if (d.x != node) { for (int q = 0; q < 4; q++) rounds_c[q]++; break; }
+            if (d.x != node) { for (int q = 0; q < 4; q++) rounds_c[q]++; for (int q = 0; q < 3; q++) if (!in_tail[q]) rounds_t[q]++; break; }
+            for (int q = 0; q < 3; q++) {
+              if (in_tail[q]) continue;
+              rounds_t[q]++;
+              const uint32_t tl = tail_len[node_id(d.y)], need = q == 0 ? 3u : q == 1 ? 5u : 8u;
+              if (depth >= 2 && tl >= need) { in_tail[q] = true; rounds_t[q] += (int)((tl + 15) / 16); }
+            }
             // a probe is free in the compressed models if it continues a chain: the previous node had one child and was not accepting
             const bool unary_prev = depth >= 3 && chain > 0;
-            for (int q = 0; q < 4; q++) if (!(unary_prev && (chain % (q + 1)) != 0)) rounds_c[q]++;
+            for (int q = 0; q < 4; q++) if (!(unary_prev && (chain % (q == 0 ? 16 : q + 1)) != 0)) rounds_c[q]++;
             depth++; node = node_id(d.y);
             if (node < hv.n_info) bestv = d.y;
             const bool plain = node >= hv.n_info && d.z != 0 && (d.z & (d.z - 1)) == 0;    // not accepting, children over one residue (mostly: one child)
@@ -122,21 +153,27 @@ int main(int argc, char** argv) {
             filt = d.z; base = d.w;
             go = (d.y & kHasChildren) != 0 && depth < limit;
           }
-          lane_rounds += rounds;
+          lane_rounds += rounds; wave_maxpos = std::max(wave_maxpos, rounds);
           for (int q = 0; q < 4; q++) lane_rounds_c[q] += rounds_c[q];
+          for (int q = 0; q < 3; q++) lane_rounds_t[q] += rounds_t[q];
           if (pos < seg && bestv != 0 && node_id(bestv) < hv.n_info) { c_row[node_id(bestv)]++; nrow++; }
           first = false; npos++;
         }
         wave_rounds = std::max(wave_rounds, lane_rounds); sum_lane_rounds += lane_rounds;
         for (int q = 0; q < 4; q++) wave_rounds_c[q] = std::max(wave_rounds_c[q], lane_rounds_c[q]);
+        for (int q = 0; q < 3; q++) wave_rounds_t[q] = std::max(wave_rounds_t[q], lane_rounds_t[q]);
       }
-      nwaves++; tot_rounds += wave_rounds;
+      nwaves++; tot_rounds += wave_rounds; tot_maxpos += wave_maxpos;
       for (int q = 0; q < 4; q++) tot_rounds_c[q] += wave_rounds_c[q];
+      for (int q = 0; q < 3; q++) tot_rounds_t[q] += wave_rounds_t[q];
     }
   }
   printf("positions walked %llu (%.3f per byte), row gathers %.3f per byte\n", (unsigned long long)npos, (double)npos / off[nd], (double)nrow / off[nd]);
-  printf("step A1: %.2f rounds per wavefront (the slowest lane), %.2f per lane on average; with unary chains walked k bytes per probe: k=2 %.2f, k=3 %.2f, k=4 %.2f\n",
-         (double)tot_rounds / nwaves, (double)sum_lane_rounds / nwaves / 64, (double)tot_rounds_c[1] / nwaves, (double)tot_rounds_c[2] / nwaves, (double)tot_rounds_c[3] / nwaves);
+  printf("step A1: %.2f rounds per wavefront (the slowest lane), %.2f per lane on average; with unary chains walked k bytes per probe: k=2 %.2f, k=3 %.2f, k=4 %.2f, k=16 %.2f\n",
+         (double)tot_rounds / nwaves, (double)sum_lane_rounds / nwaves / 64, (double)tot_rounds_c[1] / nwaves, (double)tot_rounds_c[2] / nwaves, (double)tot_rounds_c[3] / nwaves, (double)tot_rounds_c[0] / nwaves);
+  printf("step A1: the deepest single position of a wavefront takes %.2f rounds (no re-balancing of the lanes' runs can go below that)\n", (double)tot_maxpos / nwaves);
+  printf("step A1 with chains to an accepting leaf compared 16 bytes per gather (head probe + ceil(L / 16) rounds): chains >= 3: %.2f, >= 5: %.2f, >= 8: %.2f rounds per wavefront\n",
+         (double)tot_rounds_t[0] / nwaves, (double)tot_rounds_t[1] / nwaves, (double)tot_rounds_t[2] / nwaves);
   coverage("SET via direct map (16 B)", c_direct, 16);
   coverage("SET via suffix link (16 B)", c_link, 16);
   coverage("PROBE entries (16 B)", c_bucket, 16);
