@@ -1091,48 +1091,87 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
   // Walk.  Id number E of the segment is staged in slot E of its own row while that slot lies before the position being read
   // (E < SLACK + p: true unless the text averages more than one id per byte); from the first id that does not fit, the rest of
   // the segment's ids go straight to HBM.  (stage_after = 0; the tests pass 512 so that nothing is staged: debug bit 10.)
+  // The walk is ONE loop of the wavefront with two kinds of step.  The common one — a (p, 0) state whose ids still fit in front of the word
+  // being read — is straight-line code under a single lane mask: both staging stores are unconditional (slot E, then slot E + has-an-id;
+  // both lie before the position being read, and a slot that was not meant is overwritten by the next id or lies behind the count).
+  // Everything else — a forward-delete state (T(p,1) comes from the side list in HBM), a segment whose ids have caught up with its
+  // words, the test hook — takes the general step, which the wavefront only enters when one of its lanes needs it.  (As nested per-lane
+  // loops with a branch per store this was ~100 instructions per step, 60 of them scalar: the walk is bound by instruction issue, 8 lanes at a time.)
   uint32_t staged = 0;
-  if (t.have) {
-    uint32_t* row = s_tile[NARROW ? 0 : lane];
-    uint16_t* rowa = s_a[NARROW ? lane : 0];
-    const uint8_t* rowm = s_m[NARROW ? lane : 0];
-    uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0;
-    const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
+  {
+    const int rl = lane & (TS - 1);                                      // (lanes >= TS have no segment; they only need valid pointers)
+    uint32_t* row = s_tile[NARROW ? 0 : rl];
+    uint16_t* rowa = s_a[NARROW ? rl : 0];
+    const uint8_t* rowm = s_m[NARROW ? rl : 0];
+    const uint2* __restrict__ sl = side + (g0 + rl) * SIDE_STRIDE;
     uint32_t nfd = 0, nmiss = 0;                                       // delete tokens emitted / characters without a token (go :1274)
-    int hop = 0;
     // the word of state (p, fd): T(p,0) from the tile, T(p,1) from the segment's side list
     auto word = [&](uint32_t pp, uint32_t f) -> uint32_t {
-      if (f != 0) return side_word(sl, R1, g0 + lane, pp);
+      if (f != 0) return side_word(sl, R1, g0 + rl, pp);
       if (!NARROW) return row[SLACK + pp];
       const uint32_t m8 = rowm[SLACK + pp], i16 = rowa[SLACK + pp];
       return ((m8 >> 7) ? no_id : i16) | ((m8 & 63u) << 24) | ((m8 >> 6) << 30);
     };
-    // fast loop: both ids a step can emit still fit in front of the word being read (stage_after = 0; the test hook passes 512: never)
-    for (; hop <= 2 * SEG && p < t.seglen && E + 2u + stage_after <= SLACK + p; hop++) {      // a chain visits a state (p, fd) at most once
-      const uint32_t w = word(p, fd);
-      if (w == R_INVALID) { atomicOr(error_flag, 2u); p = t.seglen; break; }     // cannot happen on a chain K1/K3 produced
-      const uint32_t id = w & ID_NONE;
-      fd = (w >> 30) & 1u;
-      nfd += fd;
-      nmiss += w >> 31;
-      if (NARROW) { if (id != ID_NONE) rowa[E++] = (uint16_t)id; if (fd) rowa[E++] = (uint16_t)delete_id; }
-      else { if (id != ID_NONE) row[E++] = id; if (fd) row[E++] = delete_id; }
-      p += (w >> 24) & 63u;                                            // (0 is possible: a one-byte alternative of a forward-delete state)
+    // lane state, all in 32-bit registers (no per-lane booleans carried around the loop: the compiler keeps those as lane masks and spends
+    // a dozen scalar instructions per round re-deriving them): p >= seglen = the chain has left the segment (or the lane has none);
+    // room = slots free in front of the word being read, minus the two a step may need (< 0: general step); direct = 1 once the ids go to HBM
+    const uint32_t seglen = t.have ? t.seglen : 0u;
+    uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0, direct = 0, hop = 0;
+    int room = (int)SLACK + (int)p - 2 - (int)stage_after;
+    const uint32_t nounk = no_id == ID_NONE ? 1u : 0u;
+    for (;;) {
+      const bool alive = p < seglen;
+      if (!__any(alive)) break;
+      const bool slow = alive && ((fd | direct) != 0u || room < 0);
+      if (__any(slow)) {
+        if (slow) {
+          const uint32_t w = word(p, fd);
+          if (w == R_INVALID || hop > 2u * SEG) { atomicOr(error_flag, 2u); p = seglen; }      // cannot happen on a chain K1/K3 produced (a chain visits a state at most once)
+          else {
+            const uint32_t id = w & ID_NONE;
+            const bool fits = direct == 0u && room >= 0;
+            if (!fits && direct == 0u) { direct = 1u; staged = E; }      // from here on the segment's ids go straight to HBM
+            fd = (w >> 30) & 1u;
+            nfd += fd;
+            nmiss += w >> 31;
+            const uint32_t E0 = E;
+            if (fits) {
+              if (NARROW) { if (id != ID_NONE) rowa[E++] = (uint16_t)id; if (fd) rowa[E++] = (uint16_t)delete_id; }
+              else { if (id != ID_NONE) row[E++] = id; if (fd) row[E++] = delete_id; }
+            } else {
+              if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); E++; }
+              if (fd) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], delete_id); E++; }
+            }
+            const uint32_t adv = (w >> 24) & 63u;                          // (0 is possible: a one-byte alternative of a forward-delete state)
+            p += adv;
+            room += (int)adv - (int)(E - E0);
+            hop++;
+          }
+        }
+      }
+      if (alive && !slow) {
+        uint32_t id, fdn, miss, adv;
+        if (NARROW) {
+          const uint32_t m8 = rowm[SLACK + p];
+          id = rowa[SLACK + p];                                          // (a character without a token carries the unk id in the id plane, if there is one)
+          miss = m8 >> 7; fdn = (m8 >> 6) & 1u; adv = m8 & 63u;
+        } else {
+          const uint32_t w = row[SLACK + p];
+          miss = w >> 31; fdn = (w >> 30) & 1u; adv = (w >> 24) & 63u;
+          id = w & ID_NONE;
+        }
+        const uint32_t has = 1u - (miss & nounk);
+        if (NARROW) { rowa[E] = (uint16_t)id; E += has; rowa[E] = (uint16_t)delete_id; }
+        else { row[E] = id; E += has; row[E] = delete_id; }
+        E += fdn;
+        room += (int)adv - (int)(has + fdn);
+        nfd += fdn;
+        nmiss += miss;
+        fd = fdn;
+        p += adv;                                                        // (a (p, 0) state always advances: the walk ends)
+      }
     }
-    staged = E;
-    // the rest of a segment whose ids have caught up with its words (more than one id per byte of text) goes straight to HBM
-    for (; hop <= 2 * SEG && p < t.seglen; hop++) {
-      const uint32_t w = word(p, fd);
-      if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }
-      const uint32_t id = w & ID_NONE;
-      fd = (w >> 30) & 1u;
-      nfd += fd;
-      nmiss += w >> 31;
-      if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); E++; }
-      if (fd) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], delete_id); E++; }
-      p += (w >> 24) & 63u;
-    }
-    if (hop > 2 * SEG) atomicOr(error_flag, 2u);
+    if (direct == 0u) staged = E;
     // what the document's Count() and `missing` need beyond the id count of K3 (rare: the document is only looked up when there is something to add)
     if (nfd | nmiss) {
       const uint32_t doc = seg_doc[g0 + lane];
