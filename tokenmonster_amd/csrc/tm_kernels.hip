@@ -1212,25 +1212,51 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
     tile_load(s_tile[wv], t, g0, nv, lane, R0, narrow, no_id);
     // Walk (TS lanes, a chain each): the words of the chain are only collected — word number h of a segment's chain goes to word h
     // of its own row, always in front of the position being read (a step advances at least one byte and TSLACK = 2) ...
+    // (one loop of the wavefront, as in k_emit_tiles: a straight-line step for the (p, 0) states, the general one only when a lane is in a
+    // forward-delete state)
     uint32_t staged = 0;
-    if (t.have) {
-      uint32_t* row = s_tile[wv][lane];
-      uint32_t p = t.entry >> 1, fd = t.entry & 1u;
-      const uint2* __restrict__ sl = side + (g0 + lane) * SIDE_STRIDE;
-      int hop = 0;
-      for (; hop <= 2 * SEG && p < t.seglen; hop++) {
-        const uint32_t w = fd == 0 ? row[TSLACK + p] : side_word(sl, R1, g0 + lane, p);
-        if (w == R_INVALID) { atomicOr(error_flag, 2u); break; }
-        fd = (w >> 30) & 1u;
-        if (w >> 31) {                                       // trainvocab.go:1166-1173: no token for this byte
-          const uint32_t byte = text[t.begin + p];
-          atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
-        } else row[staged++] = w;
-        ntok += 1 + fd;                                      // tokensInText++ (also for a missing byte, :1169) / += 2
-        ndel += fd;                                          // scores[deleteToken]++ (:1134,1143,1152)
-        p += (w >> 24) & 63u;
+    {
+      const int rl = lane & (TS - 1);                                   // (lanes >= TS have no segment; they only need a valid pointer)
+      uint32_t* row = s_tile[wv][rl];
+      const uint32_t seglen = t.have ? t.seglen : 0u;
+      uint32_t p = t.entry >> 1, fd = t.entry & 1u, hop = 0;
+      const uint2* __restrict__ sl = side + (g0 + rl) * SIDE_STRIDE;
+      for (;;) {
+        const bool alive = p < seglen;
+        if (!__any(alive)) break;
+        const bool slow = alive && fd != 0u;
+        if (__any(slow)) {
+          if (slow) {
+            const uint32_t w = side_word(sl, R1, g0 + rl, p);
+            if (w == R_INVALID || hop > 2u * SEG) { atomicOr(error_flag, 2u); p = seglen; }      // cannot happen on a chain K1/K3 produced
+            else {
+              fd = (w >> 30) & 1u;
+              if (w >> 31) {                                       // trainvocab.go:1166-1173: no token for this byte
+                const uint32_t byte = text[t.begin + p];
+                atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
+              } else row[staged++] = w;
+              ntok += 1 + fd;                                      // tokensInText++ (also for a missing byte, :1169) / += 2
+              ndel += fd;                                          // scores[deleteToken]++ (:1134,1143,1152)
+              p += (w >> 24) & 63u;
+              hop++;
+            }
+          }
+        }
+        if (alive && !slow) {
+          const uint32_t w = row[TSLACK + p];
+          const uint32_t miss = w >> 31;
+          fd = (w >> 30) & 1u;
+          row[staged] = w;                                         // (unconditional: a word that does not count is overwritten by the next one or lies behind the count)
+          staged += 1u - miss;
+          if (miss) {                                              // trainvocab.go:1166-1173: no token for this byte
+            const uint32_t byte = text[t.begin + p];
+            atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
+          }
+          ntok += 1 + fd;
+          ndel += fd;
+          p += (w >> 24) & 63u;                                    // (a (p, 0) state always advances)
+        }
       }
-      if (hop > 2 * SEG) atomicOr(error_flag, 2u);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
