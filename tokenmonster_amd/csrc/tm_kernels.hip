@@ -1117,24 +1117,26 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
     // room = slots free in front of the word being read, minus the two a step may need (< 0: general step); direct = 1 once the ids go to HBM
     const uint32_t seglen = t.have ? t.seglen : 0u;
     uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0, direct = 0, hop = 0;
-    int room = (int)SLACK + (int)p - 2 - (int)stage_after;
+    // gate >= 0 <=> the lane may take the straight-line step: (p, 0) state, staging, and the two slots a step may need are free in front
+    // of the word being read (gate = free slots - 2 - (fd | direct) << 16)
+    const int slack0 = (int)SLACK - 2 - (int)stage_after;
+    int gate = slack0 + (int)p - (int)(fd << 16);
     const uint32_t nounk = no_id == ID_NONE ? 1u : 0u;
     for (;;) {
-      const bool alive = p < seglen;
-      if (!__any(alive)) break;
-      const bool slow = alive && ((fd | direct) != 0u || room < 0);
-      if (__any(slow)) {
-        if (slow) {
+      const unsigned long long alive = __builtin_amdgcn_ballot_w64(p < seglen);
+      if (alive == 0ull) break;
+      const unsigned long long slow = alive & __builtin_amdgcn_ballot_w64(gate < 0);
+      if (slow != 0ull) {
+        if (p < seglen && gate < 0) {
           const uint32_t w = word(p, fd);
           if (w == R_INVALID || hop > 2u * SEG) { atomicOr(error_flag, 2u); p = seglen; }      // cannot happen on a chain K1/K3 produced (a chain visits a state at most once)
           else {
             const uint32_t id = w & ID_NONE;
-            const bool fits = direct == 0u && room >= 0;
+            const bool fits = direct == 0u && slack0 + (int)p - (int)E >= 0;
             if (!fits && direct == 0u) { direct = 1u; staged = E; }      // from here on the segment's ids go straight to HBM
             fd = (w >> 30) & 1u;
             nfd += fd;
             nmiss += w >> 31;
-            const uint32_t E0 = E;
             if (fits) {
               if (NARROW) { if (id != ID_NONE) rowa[E++] = (uint16_t)id; if (fd) rowa[E++] = (uint16_t)delete_id; }
               else { if (id != ID_NONE) row[E++] = id; if (fd) row[E++] = delete_id; }
@@ -1142,14 +1144,14 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
               if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); E++; }
               if (fd) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], delete_id); E++; }
             }
-            const uint32_t adv = (w >> 24) & 63u;                          // (0 is possible: a one-byte alternative of a forward-delete state)
-            p += adv;
-            room += (int)adv - (int)(E - E0);
+            p += (w >> 24) & 63u;                                          // (0 is possible: a one-byte alternative of a forward-delete state)
             hop++;
+            gate = slack0 + (int)p - (int)E - (int)((fd | direct) << 16);
           }
         }
       }
-      if (alive && !slow) {
+      const unsigned long long fast = alive & ~slow;
+      if ((fast >> lane) & 1ull) {
         uint32_t id, fdn, miss, adv;
         if (NARROW) {
           const uint32_t m8 = rowm[SLACK + p];
@@ -1164,7 +1166,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
         if (NARROW) { rowa[E] = (uint16_t)id; E += has; rowa[E] = (uint16_t)delete_id; }
         else { row[E] = id; E += has; row[E] = delete_id; }
         E += fdn;
-        room += (int)adv - (int)(has + fdn);
+        gate += (int)adv - (int)(fdn * 0x10001u + has);                    // one slot per id, and out of the straight-line steps while fd' is set
         nfd += fdn;
         nmiss += miss;
         fd = fdn;
