@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 # vector-instruction issue: 256 CUs x 4 SIMD-32 x 2.4 GHz, a wave64 instruction issues over 2 cycles (same guide, "Wave scheduling")
 VALU_PEAK_GINSTS = 256 * 4 * 2.4 / 2.0
+L2_PEAK_GREQS = 128 * 2.1          # 128 L2 channels, one request each per clock (MI355X_MICROARCH.md: 34.5 TB/s = 128 channels x 128 B x 2.1 GHz)
 
 
 def parse():
@@ -444,6 +445,7 @@ def main():
     # another configuration.  `traffic_source` says so in the line itself.
     traffic, traffic_source = None, None
     valu_per_wave, salu_per_wave, waves_per_launch, insts_source = None, None, None, None
+    l2_reqs = None            # requests of the vector L1s to the L2 per launch of the match kernel (reads + writes)
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
@@ -454,6 +456,7 @@ def main():
                 if tj.get("valu_per_wave"):
                     valu_per_wave, salu_per_wave, waves_per_launch = tj["valu_per_wave"], tj.get("salu_per_wave"), tj.get("waves_per_launch")
                     insts_source = "static: profiles/traffic_latest.json, not measured in this run"
+                l2_reqs = tj.get("l2_requests_per_launch")
         except Exception:
             traffic = None
     under_profiler = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")     # (no profiler inside a profiler)
@@ -462,7 +465,7 @@ def main():
         # FETCH_SIZE / WRITE_SIZE are in KB, gfx950 tallies 128-byte fetches at 64 bytes (x2)
         import subprocess
         try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_profile.py"), "--fast", "--mbytes", str(args.mbytes), "--groups", "0,4,5",
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_profile.py"), "--fast", "--mbytes", str(args.mbytes), "--groups", "0,3,4,5",
                                 "--kernel", "k_match_branch", "--out", os.path.join("/tmp", "tm_bench_traffic")] + (["--extra=--config " + args.config] if args.config else []),
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, start_new_session=True)
             k = list(json.loads(r.stdout.decode()).values())[0]
@@ -472,6 +475,8 @@ def main():
             if k.get("SQ_WAVES"):
                 valu_per_wave, salu_per_wave, waves_per_launch = k["SQ_INSTS_VALU"] / k["SQ_WAVES"], k["SQ_INSTS_SALU"] / k["SQ_WAVES"], k["SQ_WAVES"]
                 insts_source = "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES over the same kernel, configuration and size"
+            if k.get("TCP_TCC_READ_REQ_sum"):
+                l2_reqs = k["TCP_TCC_READ_REQ_sum"] + k.get("TCP_TCC_WRITE_REQ_sum", 0.0)
         except Exception as ex:     # noqa: BLE001
             log("counter passes failed (%s): the static figures stay" % ex)
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -485,6 +490,15 @@ def main():
                          "frac": round(gi / VALU_PEAK_GINSTS, 4), "vector_instructions_per_segment": round(valu_per_wave, 1),
                          "scalar_instructions_per_segment": None if salu_per_wave is None else round(salu_per_wave, 1),
                          "vector_instructions_per_input_byte": round(valu_per_wave * waves_per_launch / float(text.size), 3), "source": insts_source}
+
+    # ... and against what its divergent gathers load most: the request rate of the L2 (16 channels per XCD x 8 XCDs, one request per channel
+    # and clock of the 2.1 GHz the guide's 34.5 TB/s of L2 bandwidth are 128-byte lines at)
+    roofline_l2 = None
+    if l2_reqs:
+        gr = l2_reqs / (acc[dom] * 1e-3) / 1e9
+        roofline_l2 = {"bound": "l2_requests", "kernel": names[dom], "achieved": round(gr, 1), "peak": L2_PEAK_GREQS, "unit": "G requests/s",
+                       "frac": round(gr / L2_PEAK_GREQS, 4), "requests_per_segment": round(l2_reqs / waves_per_launch, 1) if waves_per_launch else None,
+                       "source": "rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum over the same kernel, configuration and size"}
 
     # ---- verification of a sample against the oracle (rank 0; outside the timed region) -------------------
     verified = None
@@ -567,6 +581,7 @@ def main():
                        "verified_docs_vs_oracle": verified},
             "roofline": roofline,
             "roofline_valu": roofline_valu,
+            "roofline_l2": roofline_l2,
             "cpu_baseline": cpu,
             # `value` is the HBM-resident rate (the timed region starts with the raw text in HBM and ends with the ids in HBM); the rate of
             # SURVEY 8(d)'s "first H2D to last D2H" harness (tm_tokenize_pipeline: raw UTF-8 in pinned host memory -> ids in pinned host memory,

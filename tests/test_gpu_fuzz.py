@@ -7,7 +7,8 @@ import fuzz_cases
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [3, 1007, 1019, 1100, 1254, 1900])
+# (1100002: a chain that alternates forward-delete and plain states byte after byte: two words per byte in the scoring walk)
+@pytest.mark.parametrize("seed", [3, 1007, 1019, 1100, 1254, 1900, 1100002])
 def test_tokenize_count_serialized_score_decode_against_the_oracle(seed):
     fuzz_cases.one(seed)
 

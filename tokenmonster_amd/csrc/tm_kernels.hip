@@ -1213,9 +1213,12 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
     const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
     tile_load(s_tile[wv], t, g0, nv, lane, R0, narrow, no_id);
     // Walk (TS lanes, a chain each): the words of the chain are only collected — word number h of a segment's chain goes to word h
-    // of its own row, always in front of the position being read (a step advances at least one byte and TSLACK = 2) ...
+    // of its own row while that lies in front of the position being read ...
     // (one loop of the wavefront, as in k_emit_tiles: a straight-line step for the (p, 0) states, the general one only when a lane is in a
-    // forward-delete state)
+    // forward-delete state or has no room: a forward-delete state may advance by 0 bytes, so a chain that alternates between the two kinds
+    // of state byte after byte collects words faster than it reads them — two per byte — and TSLACK does not cover that.  A word that would
+    // reach the words still to be read is counted at once instead of being staged.  (Until round 3 it was staged regardless: the chain then
+    // read its own staged words as transitions — found by tools/emu/fuzz.py, seed 1100002.)
     uint32_t staged = 0;
     {
       const int rl = lane & (TS - 1);                                   // (lanes >= TS have no segment; they only need a valid pointer)
@@ -1226,17 +1229,18 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
       for (;;) {
         const bool alive = p < seglen;
         if (!__any(alive)) break;
-        const bool slow = alive && fd != 0u;
+        const bool slow = alive && (fd != 0u || staged >= TSLACK + p);
         if (__any(slow)) {
           if (slow) {
-            const uint32_t w = side_word(sl, R1, g0 + rl, p);
+            const uint32_t w = fd != 0u ? side_word(sl, R1, g0 + rl, p) : row[TSLACK + p];
             if (w == R_INVALID || hop > 2u * SEG) { atomicOr(error_flag, 2u); p = seglen; }      // cannot happen on a chain K1/K3 produced
             else {
               fd = (w >> 30) & 1u;
               if (w >> 31) {                                       // trainvocab.go:1166-1173: no token for this byte
                 const uint32_t byte = text[t.begin + p];
                 atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
-              } else row[staged++] = w;
+              } else if (staged < TSLACK + p) row[staged++] = w;
+              else atomicAdd(&scores[w & ID_NONE], (w >> 24) & 63u);     // no room in front of the words still to be read: counted here
               ntok += 1 + fd;                                      // tokensInText++ (also for a missing byte, :1169) / += 2
               ndel += fd;                                          // scores[deleteToken]++ (:1134,1143,1152)
               p += (w >> 24) & 63u;
@@ -1248,7 +1252,7 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
           const uint32_t w = row[TSLACK + p];
           const uint32_t miss = w >> 31;
           fd = (w >> 30) & 1u;
-          row[staged] = w;                                         // (unconditional: a word that does not count is overwritten by the next one or lies behind the count)
+          row[staged] = w;                                         // (staged < TSLACK + p; unconditional: a word that does not count is overwritten by the next one or lies behind the count)
           staged += 1u - miss;
           if (miss) {                                              // trainvocab.go:1166-1173: no token for this byte
             const uint32_t byte = text[t.begin + p];
