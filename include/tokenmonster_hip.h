@@ -63,7 +63,7 @@ void tm_vocab_free(tm_vocab* v);
  * tm_vocab_block_export describes the block of `v` (plain data: send it as bytes) and returns its device pointer; tm_vocab_block_import makes
  * an empty vocabulary of that shape on `device` and returns the device pointer the caller has to fill with the exporter's `bytes` bytes
  * before the first use.  An imported vocabulary tokenizes, counts, scores and decodes on the device; it has no host tables (tm_vocab_image /
- * tm_vocab_save fail, documents that need the host decoder fail). */
+ * tm_vocab_save and the streaming decoder fail). */
 typedef struct tm_vocab_block {
   uint64_t bytes;            /* size of the device block */
   uint64_t part_bytes[8];    /* root, walk tables, rows, space-prefix links, node values, reverse offsets, reverse bytes, begin_byte */
@@ -191,13 +191,16 @@ uint64_t tm_batch_device_bytes(const tm_batch* b);
 /* ---- decode: Decode / decode_raw (go/tokenmonster.go:445-550; tokenmonster.cpp:1404-1425) ------------------------ */
 /* ids of document d = tokens[tok_offsets[d] .. tok_offsets[d+1]).  The gather of reverse[id] (lengths -> scan -> copy)
  * runs on the device; ids >= tm_vocab_n_ids are skipped.  raw != 0: the concatenated token bytes as they are
- * (decode_raw); raw == 0: capcode decoding (javascript/tokenmonster.js:1007-1065) follows — on the device for the pure-ASCII documents
- * of a capcode-2 UTF-8 vocabulary, on the host for documents with anything beyond ASCII (Unicode case needs ICU) and for capcode 1.
+ * (decode_raw); raw == 0: capcode decoding (javascript/tokenmonster.js:1007-1065) follows — on the device for the documents of a capcode-2
+ * UTF-8 vocabulary that are ASCII, accented Latin (U+0080..U+017F, combining marks U+0300..U+036F) and the punctuation U+2000..U+203F; on the
+ * host for documents with other scripts, malformed UTF-8 or a character whose upper-case form has another length (Unicode case needs ICU),
+ * and for capcode 1.  tm_decode_host_docs(): how many documents of the calling thread's last tm_decode_batch went to the host decoder.
  * out_offsets[ndocs+1] is always filled; TM_E_NOSPACE if out_cap is too small (required size in out_offsets[ndocs]).
  * Like the tokenize entry points the call borrows a lane of the vocabulary (its stream, grow-only device arenas and pinned
  * staging): callable concurrently, no allocation in steady state, nothing on the NULL stream. */
 int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* tok_offsets, uint32_t ndocs, int raw,
                     uint8_t* out, uint64_t out_cap, uint64_t* out_offsets);
+uint32_t tm_decode_host_docs(void);
 
 /* Streaming Decoder (go/tokenmonster.go:552-700 NewDecoder / Decode / DecodeSerialized / Flush; server jobs 5-9): ids arrive a few
  * at a time, a call returns the text that is COMPLETE so far; the bytes of a character that is not (a token may end in the middle of a

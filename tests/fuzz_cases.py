@@ -134,6 +134,11 @@ def one_norm(seed):
 DEC_ALPHABET = list(b"CCWWDD    aabcxyzQZ019''.,-\n\t_")
 
 
+# what the device decoder takes on itself beyond ASCII, and what it must hand to the host (upper-case forms of another length or lead byte: \u00ff \u00b5 \u0131 \u017f \u0149)
+DEC_LATIN = [chr(c) for c in (0xE9, 0xC9, 0xE8, 0xEF, 0xF1, 0xFC, 0xDC, 0xE7, 0xC6, 0xE6, 0xD8, 0xF8, 0xDF, 0xFE, 0xF0, 0xAA, 0xBA, 0xB5, 0xAB, 0xA0, 0xB2, 0xBD, 0xD7, 0xF7, 0x101, 0x10D, 0x141, 0x142,
+                              0x153, 0x130, 0x131, 0x149, 0x17F, 0x17E, 0xFF, 0x138, 0x140, 0x161, 0x151)]
+
+
 def one_decode(seed):
     """tm_decode_batch (capcode decoding of the pure-ASCII documents on the device, k_dec_capcode; the others on the host) against the
     streaming host decoder (tm_decoder_*), on marker soups no encoder would write: every order of 'C', 'W', 'D', spaces and characters,
@@ -155,8 +160,22 @@ def one_decode(seed):
             doc = doc[:n]
         elif r < 0.92:
             doc = bytes(rng.choice(list(b"W helo wrd's 12"), size=n).tolist())
-        else:
+        elif r < 0.96:
             doc = bytes(rng.choice(DEC_ALPHABET, size=n).tolist()) + "\u00e9\u2019 W\u00e9".encode() + bytes(rng.choice(DEC_ALPHABET, size=7).tolist())
+        else:
+            doc = bytes(rng.choice(DEC_ALPHABET, size=n).tolist()) + "\u4e2d W\u0416".encode() + bytes(rng.choice(DEC_ALPHABET, size=7).tolist())      # other scripts: the host decoder
+        # a third of the documents: accented Latin, decomposed (marks) and not, curly quotes, and now and then a byte that breaks the UTF-8
+        if rng.random() < 0.35:
+            pieces = []
+            for _ in range(max(1, n // 3)):
+                q = rng.random()
+                if q < 0.45: pieces.append(bytes([int(rng.choice(DEC_ALPHABET))]))
+                elif q < 0.75: pieces.append(str(rng.choice(DEC_LATIN)).encode())
+                elif q < 0.85: pieces.append(bytes([int(rng.choice(list(b"aeoun")))]) + str(rng.choice(["\u0301", "\u0300", "\u0308", "\u0303", "\u0327", "\u036f"])).encode())
+                elif q < 0.93: pieces.append(str(rng.choice(["\u2019", "\u2018", "\u201c", "\u2014", "\u2026", "\u2009"])).encode())
+                elif q < 0.97: pieces.append(bytes(rng.choice(list(b"CWD "), size=int(rng.integers(1, 4))).tolist()))
+                else: pieces.append(bytes([int(rng.choice([0xC3, 0xA9, 0xE2, 0x80, 0xCD, 0xB5, 0xFF, 0xC5]))]))
+            doc = b"".join(pieces) + b"."       # (ends in ASCII: the streaming decoder this is compared with holds back what looks like an incomplete character at the end, tokenmonster.cpp:105-107)
         docs.append(doc)
     # the id of every single-byte token, so that the decoder's input IS the document, byte for byte
     all_ids = np.arange(v.n_ids(), dtype=np.uint32)

@@ -229,3 +229,34 @@ def test_vocabulary_block_export_import(setup):
     assert out.tobytes() == out_a.tobytes()
     with pytest.raises(N.TokenMonsterHipError):               # ... the streaming decoder and Save need host tables
         tm.Decoder(b)
+
+
+def test_latin_text_is_decoded_on_the_device():
+    """Capcode decoding of accented Latin text (two-byte characters, combining marks, curly quotes) happens in k_dec_capcode:
+    tm_decode_host_docs() counts the documents of the last call that were left to the host decoder."""
+    import ctypes as C
+    from tokenmonster_amd import _native as N
+    import numpy as np
+    from tokenmonster_amd import synth
+    img = synth.build_vocab([bytes([c]) for c in range(256)], capcode=0, charset=1)
+    a = tm.Vocab(b"\x02" + bytes(img[1:]))                    # 256 one-byte tokens, header switched to capcode 2: the decoder's input is the document
+    all_ids = np.arange(a.n_ids(), dtype=np.uint32)
+    rb, ro = a.decode_packed(all_ids, np.arange(a.n_ids() + 1, dtype=np.uint64), raw=True)
+    id_of = np.zeros(256, dtype=np.uint32)
+    for i in range(a.n_ids()):
+        if int(ro[i + 1] - ro[i]) == 1:
+            id_of[int(rb[int(ro[i])])] = i
+    docs = ["Wdécouvert Dà Cparis, Wcœur Dde l\u2019été: Cgarçon".encode(), "Wstraße Cøre Cn\u0303andu\u0301 Wñu".encode(), ("Cé" * 40 + " Wàb c").encode(), b"Wplain ascii"]
+    text, toff = tm.pack_documents(docs)
+    tok = id_of[text]
+    out, ooff = a.decode_packed(tok, toff, raw=False)
+    assert N.lib.tm_decode_host_docs() == 0
+    for d, doc in enumerate(docs):
+        dec = a.decoder()
+        exp = dec.decode(tok[int(toff[d]):int(toff[d + 1])]) + dec.flush()
+        assert out[int(ooff[d]):int(ooff[d + 1])].tobytes() == exp, doc
+    assert out[int(ooff[1]):int(ooff[2])].tobytes() == "STRAßE Øre N\u0303andu\u0301 ÑU".encode()      # (ß has no simple upper case)
+    for other in ["W\u4e2d\u6587".encode(), "Cÿ".encode(), b"W\xc3("]:     # another script; an upper-case form with another lead byte; malformed UTF-8
+        t2, o2 = tm.pack_documents([other, b"Wascii"])
+        a.decode_packed(id_of[t2], o2, raw=False)
+        assert N.lib.tm_decode_host_docs() == 1

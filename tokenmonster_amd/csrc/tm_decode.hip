@@ -2,8 +2,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
 #include <vector>
 
+#include "tm_internal.h"
 #include "tm_pipeline.h"
 
 using namespace tmh;
@@ -38,20 +40,28 @@ __global__ void k_dec_doc_off(const uint64_t* __restrict__ out_off, const uint64
 }
 
 // Capcode level 2 decoding (javascript/tokenmonster.js:1007-1065; the host form is capcode_decode_stream, tm_normalize.cpp) of documents
-// that are pure ASCII — there NFD and Unicode case play no part and the decoder is a four-bit state machine over bytes: 'D' deletes the
+// made of ASCII, the two-byte characters U+0080..U+017F, the combining marks U+0300..U+036F (what NFD leaves of an accented Latin letter)
+// and the punctuation U+2000..U+203F — there the decoder is a four-bit state machine over CHARACTERS: 'D' deletes the
 // next character, 'C' capitalises the next one that is not a (kept) space, 'W' capitalises letters until the word ends, and a space
 // straight after 'W' does not end it.  One wavefront per document walks it 64 bytes at a time; inside a chunk each flag is a flood fill on
 // the ballots of the byte classes, done with the carry chain of ONE 64-bit addition: with P the positions a flag survives, S where it is
 // set (S inside P) and the flag's value on entry as carry-in, (P + S + carry) ^ P has a one from every start up to and INCLUDING the
 // first position outside P above it — the position that sees the flag and consumes or clears it — and the carry out of bit 63 is the flag's
-// value for the next chunk.  Documents with any byte >= 0x80 are left to the host decoder (dec_len = DEC_HOST).
+// value for the next chunk.  A character is decided at its first byte; its other bytes are transparent to every flag and take the decision
+// (kept / capitalised) of the first, also across the end of a chunk.  Capitalising a two-byte letter changes its second byte only
+// (`tab`, built by the host from the host decoder's own functions: tm_normalize.cpp build_dec_table); a character whose upper-case form
+// needs more than that, any other script, and any byte sequence that is not well-formed UTF-8 leave the document to the host decoder
+// (dec_len = DEC_HOST).
 __device__ __forceinline__ unsigned long long dec_fill(unsigned long long P, unsigned long long S, unsigned& carry) {
   const unsigned long long t = P + S, u = t + carry;
   carry = (t < P) | (u < t);
   return u ^ P;
 }
+__device__ __forceinline__ uint32_t dec_tab_index(uint32_t lead, uint32_t second) {      // lead in {C2..C5, CC, CD}
+  return ((lead >= 0xCCu ? lead - 0xCCu + 4u : lead - 0xC2u) << 6) | (second & 63u);
+}
 __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__ in, const uint64_t* __restrict__ doc_off, uint32_t ndocs,
-                                                      uint8_t* __restrict__ out, uint64_t* __restrict__ dec_len) {
+                                                      uint8_t* __restrict__ out, uint64_t* __restrict__ dec_len, const uint16_t* __restrict__ tab) {
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t d = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (d >= ndocs) return;
@@ -59,18 +69,39 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
   const unsigned long long below = (1ull << lane) - 1ull;
   uint64_t o = b;                                        // decoded bytes of the document go to out[b ..): never more than it had
   unsigned c_del = 0, c_char = 0, c_word = 0, c_ign = 0;   // the decoder's state (tm_internal.h CapcodeState) between chunks
+  unsigned long long kept_in = 0, cap_in = 0;              // bytes at the start of this chunk that continue a character of the chunk before: kept / capitalised
   bool host = false;
   for (uint64_t pos = b; pos < e; pos += 64) {
-    const bool valid = pos + lane < e;
-    const uint32_t c = valid ? in[pos + lane] : 0u;
-    if (__any(c >= 0x80u)) { host = true; break; }
+    const uint64_t at = pos + lane;
+    const bool valid = at < e;
+    const uint32_t c = valid ? in[at] : 0u;
+    const bool hi = __any(c >= 0x80u);
+    uint32_t cn = 0, cnn = 0, cp = 0, cpp = 0;              // the bytes around it (inside the document), only looked at when the chunk is not pure ASCII
+    if (hi) {
+      cn = at + 1 < e ? in[at + 1] : 0u; cnn = at + 2 < e ? in[at + 2] : 0u;
+      cp = valid && at >= b + 1 ? in[at - 1] : 0u; cpp = valid && at >= b + 2 ? in[at - 2] : 0u;
+    }
+    auto is_lead2 = [](uint32_t x) { return (x - 0xC2u < 4u) || x == 0xCCu || x == 0xCDu; };
+    auto is_cont = [](uint32_t x) { return (x & 0xC0u) == 0x80u; };
+    const bool ascii = c < 0x80u;
+    const bool lead2 = valid && is_lead2(c), lead3 = valid && c == 0xE2u;
+    uint32_t te = 0;                                        // table entry of the two-byte character this lane starts or ends
+    if (lead2 && is_cont(cn)) te = tab[dec_tab_index(c, cn)];
+    const bool tail2 = valid && is_cont(c) && is_lead2(cp);
+    if (tail2) te = tab[dec_tab_index(cp, c)];
+    const bool tail3a = valid && c == 0x80u && cp == 0xE2u, tail3b = valid && is_cont(c) && cpp == 0xE2u && cp == 0x80u;
+    const bool ok = !valid || ascii || (lead2 && (te & 1u)) || (lead3 && cn == 0x80u && is_cont(cnn)) || (tail2 && (te & 1u)) || tail3a || tail3b;
+    if (__any(!ok)) { host = true; break; }
     const unsigned long long V = __ballot(valid);
+    const unsigned long long L2 = __ballot(lead2), L3 = __ballot(lead3);
+    const unsigned long long START = __ballot(valid && (ascii || lead2 || lead3));
     const unsigned long long mC = __ballot(c == 'C'), mW = __ballot(c == 'W'), mD = __ballot(c == 'D');
-    const unsigned long long M = mC | mW | mD, N = V & ~M;
+    const unsigned long long M = mC | mW | mD, N = START & ~M;
     const unsigned long long SP = __ballot(c == ' ');
     const bool lower = c - 'a' < 26u;
-    const unsigned long long LET = __ballot(lower || c - 'A' < 26u) & N;
-    const unsigned long long WC = __ballot(c - '0' < 10u || c == '\'');          // what keeps a capitalised word going besides letters
+    const unsigned long long LET = __ballot(lower || c - 'A' < 26u || (lead2 && (te & 2u))) & N;      // upper- or lower-case letters
+    // what keeps a capitalised word going besides letters: digits, the apostrophe and U+2019, marks
+    const unsigned long long WC = __ballot(c - '0' < 10u || c == '\'' || (lead2 && (te & 4u)) || (lead3 && cnn == 0x99u));
     const unsigned long long deleted = N & dec_fill(M, mD, c_del);               // a 'D' since the last character: this one goes
     const unsigned long long ign = N & dec_fill(M, mW, c_ign);                   // a 'W' since the last character
     const unsigned long long kept = N & ~deleted;
@@ -78,9 +109,18 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
     const unsigned long long in_char = K & dec_fill(~(mW | K), mC, c_char);
     const unsigned long long ends_word = mC | (SP & kept & ~ign) | (K & ~LET & ~WC);
     const unsigned long long in_word = dec_fill(~ends_word, mW, c_word);
-    const bool cap = lower && (((in_char | (in_word & LET & K)) >> lane) & 1ull);
-    if ((kept >> lane) & 1ull) out[o + (uint64_t)__popcll(kept & below)] = (uint8_t)(cap ? c - 32u : c);
-    o += (uint64_t)__popcll(kept);
+    const unsigned long long capS = in_char | (in_word & LET & K);                // characters that come out in upper case
+    // the other bytes of a character: kept / capitalised like its first byte
+    const unsigned long long k23 = kept & (L2 | L3), k3 = kept & L3, cap2 = capS & L2;
+    const unsigned long long kept_all = kept | (k23 << 1) | (k3 << 2) | kept_in;
+    const unsigned long long cap_tail = (cap2 << 1) | cap_in;
+    kept_in = (k23 >> 63) | (((k3 >> 62) & 1ull)) | ((k3 >> 63) << 1);
+    cap_in = cap2 >> 63;
+    uint32_t oc = c;
+    if (lower && ((capS >> lane) & 1ull)) oc = c - 32u;
+    if (tail2 && ((cap_tail >> lane) & 1ull)) oc = te >> 8;
+    if ((kept_all >> lane) & 1ull) out[o + (uint64_t)__popcll(kept_all & below)] = (uint8_t)oc;
+    o += (uint64_t)__popcll(kept_all);
   }
   if (lane == 0) dec_len[d] = host ? DEC_HOST : o - b;
 }
@@ -99,7 +139,26 @@ void launch_decode_copy(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, co
   if (n) TM_LAUNCH(k_dec_copy, (uint32_t)((n + 255) / 256), 256, 0, st, d_tok, n, v->d_rev_off, v->d_rev_bytes, v->host.n_ids, d_off, d_out);
   note_table_use(v, st);
 }
-void launch_decode_capcode(const uint8_t* d_out, const uint64_t* d_doff, uint32_t ndocs, uint8_t* d_dec, uint64_t* d_declen, hipStream_t st) {
-  if (ndocs) TM_LAUNCH(k_dec_capcode, (ndocs + 3) / 4, 256, 0, st, d_out, d_doff, ndocs, d_dec, d_declen);
+// the decoder's table of two-byte characters (vocabulary-independent): one copy per device, made on first use and kept
+static const uint16_t* dec_table(int device) {
+  static std::mutex mu;
+  static const uint16_t* tabs[64] = {};
+  std::lock_guard<std::mutex> g(mu);
+  if (device < 0 || device >= 64) return nullptr;
+  if (!tabs[device]) {
+    uint16_t h[DEC_LEADS * 64];
+    build_dec_table(h);
+    uint16_t* dp = nullptr;
+    if (hipMalloc((void**)&dp, sizeof h) != hipSuccess) return nullptr;
+    if (hipMemcpy(dp, h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dp); return nullptr; }
+    tabs[device] = dp;
+  }
+  return tabs[device];
+}
+int launch_decode_capcode(const tm_vocab* v, const uint8_t* d_out, const uint64_t* d_doff, uint32_t ndocs, uint8_t* d_dec, uint64_t* d_declen, hipStream_t st) {
+  const uint16_t* tab = dec_table(v->device);
+  if (!tab) return set_error(TM_E_HIP, "the decoder's character table could not be placed on device %d", v->device);
+  if (ndocs) TM_LAUNCH(k_dec_capcode, (ndocs + 3) / 4, 256, 0, st, d_out, d_doff, ndocs, d_dec, d_declen, tab);
+  return TM_OK;
 }
 }  // namespace tmh

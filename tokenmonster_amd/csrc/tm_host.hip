@@ -471,8 +471,12 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
 // Decode / decode_raw (go/tokenmonster.go:445-550; tokenmonster.cpp:1404-1425) on a lane like the tokenize entry points: the lane's
 // stream, grow-only device arenas and pinned staging — steady state allocates nothing and stays off the NULL stream, so decode jobs of a
 // server (tokenmonsterserver jobs 2-9) do not stall the tokenize jobs running beside them (a hipFree synchronizes the whole device).
+static thread_local uint32_t g_decode_host_docs = 0;
+uint32_t tm_decode_host_docs(void) { return g_decode_host_docs; }
+
 int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* tok_offsets, uint32_t ndocs, int raw,
                     uint8_t* out, uint64_t out_cap, uint64_t* out_offsets) {
+  g_decode_host_docs = 0;
   if (!v || !tok_offsets || !out_offsets) return set_error(TM_E_INVALID, "null argument");
   const uint64_t n = tok_offsets[ndocs];
   if (n && !tokens) return set_error(TM_E_INVALID, "null argument");
@@ -520,7 +524,7 @@ int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* t
     launch_decode_copy(v, d_tok, n, d_off, d_out, st);
     uint64_t h_need = total + 16;
     if (dev_capcode) {
-      launch_decode_capcode(d_out, d_doff, ndocs, d_dec, d_declen, st);
+      if ((rc = launch_decode_capcode(v, d_out, d_doff, ndocs, d_dec, d_declen, st)) != TM_OK) break;
       declen.resize(ndocs);
       h_need = up((uint64_t)ndocs * 8) + 2 * up(total + 16);
     }
@@ -554,6 +558,7 @@ int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* t
       // the documents the device left alone (anything beyond ASCII; every document of a capcode-1 or UTF-16 vocabulary) go through the host decoder
       std::vector<uint32_t> todo;
       for (uint32_t d = 0; d < ndocs; d++) if (!dev_capcode || declen[d] == DEC_HOST) todo.push_back(d);
+      g_decode_host_docs = (uint32_t)todo.size();
       std::vector<std::vector<uint8_t>> touts;
       if (!todo.empty()) {
         std::vector<uint64_t> toff(todo.size() + 1, 0);

@@ -400,6 +400,29 @@ void build_two_table(uint32_t norm_flag, NmTwo* out) {
   }
 }
 
+// The table of the device capcode DECODER (tm_decode.hip: k_dec_capcode) for the two-byte characters it handles itself: U+0080..U+017F (leads
+// C2..C5) and the combining marks U+0300..U+037F (leads CC, CD), made from the functions the host decoder above uses, so that the device cannot
+// disagree with it.  Entry (lead index << 6 | second & 63): bit 0 the device may decode the character, bit 1 upper- or lower-case letter (a
+// capitalised word capitalises it), bit 2 digit or mark (keeps a capitalised word going), bits 8..15 the second byte of its upper-case form.
+// A character whose upper-case form has another lead byte or length (ÿ µ ı ſ ŉ) stays without bit 0: its document is left to the host.
+void build_dec_table(uint16_t* out) {
+  static const uint8_t leads[DEC_LEADS] = {0xC2, 0xC3, 0xC4, 0xC5, 0xCC, 0xCD};
+  for (uint32_t li = 0; li < DEC_LEADS; li++)
+    for (uint32_t s6 = 0; s6 < 64; s6++) {
+      const uint8_t b[2] = {leads[li], (uint8_t)(0x80u | s6)};
+      uint16_t e = 0;
+      const Cp c = next_cp(b, 2);
+      if (!c.raw && c.n == 2) {
+        const uint8_t cls = classify(c);
+        std::vector<uint8_t> up;
+        put_cp(up, (uint32_t)u_toupper((UChar32)c.r));
+        if (up.size() == 2 && up[0] == b[0])
+          e = (uint16_t)(1u | ((cls & (kLower | kUpper)) ? 2u : 0u) | ((cls & (kDigit | kMark)) ? 4u : 0u) | ((uint32_t)up[1] << 8));
+      }
+      out[(li << 6) | s6] = e;
+    }
+}
+
 // capcode level 1 has no statement in the reference tree: refused rather than guessed
 bool normalize_supported(uint32_t capcode, uint32_t norm_flag) { return (capcode == 0 || capcode == 2) && norm_flag < 256; }
 // what the DEVICE normalizer (tm_norm.hip) does itself; documents of vocabularies with further flags take the host path below

@@ -171,11 +171,11 @@ int small_sync(tm_batch* b, hipStream_t st);
 int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, hipStream_t st);
 void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* out, hipStream_t st);
 // tm_decode.hip: the stages of a decode on a stream, in buffers of the caller
-constexpr uint64_t DEC_HOST = ~0ull;      // k_dec_capcode's length of a document it leaves to the host decoder (anything beyond ASCII)
+constexpr uint64_t DEC_HOST = ~0ull;      // k_dec_capcode's length of a document it leaves to the host decoder (scripts beyond Latin, malformed UTF-8)
 void launch_decode_lengths(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_toff, uint32_t ndocs, uint32_t* d_len, uint64_t* d_off,
                            uint64_t* d_sums, uint64_t* d_total, uint64_t* d_doff, hipStream_t st);
 void launch_decode_copy(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_off, uint8_t* d_out, hipStream_t st);
-void launch_decode_capcode(const uint8_t* d_out, const uint64_t* d_doff, uint32_t ndocs, uint8_t* d_dec, uint64_t* d_declen, hipStream_t st);
+int launch_decode_capcode(const tm_vocab* v, const uint8_t* d_out, const uint64_t* d_doff, uint32_t ndocs, uint8_t* d_dec, uint64_t* d_declen, hipStream_t st);
 // tm_norm.hip
 int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs, hipStream_t st);
 // tm_normalize.cpp
