@@ -127,7 +127,7 @@ def host_to_host(vocab, raw, roffs, text, offs, ids_expected, log, tm, steps=3):
     res = {}
     for label, src, dst in (("pinned", pin_in.array, pin_out.array), ("pageable", raw, np.empty(4 * ids_expected + 4096, dtype=np.uint8))):
         best = None
-        for lanes, chunk in ((4, 32 << 20), (6, 32 << 20), (6, 16 << 20), (8, 16 << 20)):
+        for lanes, chunk in ((4, 32 << 20), (6, 32 << 20), (6, 16 << 20), (8, 16 << 20), (4, 64 << 20), (3, 64 << 20)):
             vocab.tokenize_pipeline(src, roffs, raw=True, chunk_bytes=chunk, lanes=lanes, out=dst)      # warm the lanes
             t0 = time.perf_counter()
             for _ in range(steps):
