@@ -156,7 +156,7 @@ __device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_
 }
 
 // child filter (tm_tables.h): can the node have a child over byte c?
-__device__ __forceinline__ bool child_possible32(uint32_t m, uint32_t c) { return ((m >> (c & 31u)) & 1u) != 0; }
+__device__ __forceinline__ bool child_possible32(uint32_t m, uint32_t c) { return bit_of(m, c) != 0u; }
 
 // one in-flight trie walk of a lane: text byte number d of the string being matched is text[tbase + d].
 // An idle slot has key == KEY_IDLE (no entry's check word) and gathers the always-empty entry behind the double array,
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     const uint32_t xconst = TM_LDS_ADDR(w.X) - 4u * tb;                               // &X[i] == xconst + 4 * (tb + i), &D[i] 6 * 256 bytes behind
     const int run = (max(nwalkpos, 0) + 63) >> 6;
     uint32_t posa = tb + (uint32_t)(lane * run);
-    const uint32_t enda = tb + (uint32_t)max(min(lane * run + run, nwalkpos), 0), dla = tb + (uint32_t)dl;
+    const uint32_t enda = tb + (uint32_t)max(min(lane * run + run, nwalkpos), 0), dla = tb + (uint32_t)dl, lasta = enda - 1u;
     int depth = 0, limit = 0, bestlen = 0;
     uint32_t pfa = tb, off = idle_off, key = 0u, bestv = 0u, node = 0u;
     const bool setting = posa < enda;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         bestv = sel_mask(setm | acc, e.y, bestv);
         bestlen = (int)sel_mask(setm, link_bestlen(e.x), sel_mask(acc, (uint32_t)depth, (uint32_t)bestlen));
         // probe only for a byte the node can continue with: bit (c & 31) of its child filter (0 behind a link that cannot go on)
-        M64 go = adv & __builtin_amdgcn_ballot_w64(((e.z >> (c & 31u)) & 1u) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
+        M64 go = adv & __builtin_amdgcn_ballot_w64(bit_of(e.z, c) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
 #ifdef TM_DEVEL
         if (nowalk) go = 0ull;
 #endif
@@ -434,17 +434,16 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
           xp[6 * 64] = (uint32_t)bestlen;                                                                      // D[pos]
         }
         // ... and move on: through the suffix link if the walk got deep enough, else from the direct map
-        const uint32_t posn = posa + 1u;
-        const M64 more = __builtin_amdgcn_ballot_w64(posn < enda), deep = __builtin_amdgcn_ballot_w64(depth >= 3);
+        const M64 more = __builtin_amdgcn_ballot_w64(posa < lasta), deep = __builtin_amdgcn_ballot_w64(depth >= 3);      // (the next position is posa + 1)
         const uint32_t off_f = sel_mask(more, sel_mask(deep, v_link, v_direct) + (sel_mask(deep, node, nn) << 4), v_idle);
         // a walk that goes on probes entry base + byte for the byte behind the one just read (also behind a link: it stands for the bytes
         // up to there); the first byte a new position reads: posn + depth - 1 behind a suffix link, posn + 2 behind the direct map
         key = sel_mask(go, nid, key);
         off = sel_mask(go, (e.w + c) << 4, off_f);                              // (an idle lane has no more positions: off_f is the idle entry)
-        pfa = sel_mask(go, pfa + 1u, posn + (uint32_t)max(depth, 3) - 1u);
-        if (TAIL) limit = (int)sel_mask(fin, (uint32_t)min((int)(dla - posn), Lmax), (uint32_t)limit);
+        pfa = sel_mask(go, pfa + 1u, posa + (uint32_t)max(depth, 3));
+        if (TAIL) limit = (int)sel_mask(fin, (uint32_t)min((int)(dla - posa) - 1, Lmax), (uint32_t)limit);
         setm = fin & more;
-        posa = sel_mask(setm, posn, posa);
+        posa = add_mask_bit(posa, setm);
         PH_INC(8)
       }
     };

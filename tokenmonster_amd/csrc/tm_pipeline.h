@@ -43,6 +43,14 @@ __device__ __forceinline__ uint32_t sel_mask(unsigned long long mask, uint32_t a
   return r;
 #endif
 }
+// bit (n & 31) of x: v_bfe_u32 takes the low five bits of its offset operand by itself, the compiler does not drop the `& 31` of the C form
+__device__ __forceinline__ uint32_t bit_of(uint32_t x, uint32_t n) {
+#ifdef TM_EMU
+  return (x >> (n & 31u)) & 1u;
+#else
+  return __builtin_amdgcn_ubfe(x, n, 1u);
+#endif
+}
 // a + (bit of the lane in a wave-uniform mask): the mask goes in as the carry of ONE add (v_addc_co), instead of an add and a select
 __device__ __forceinline__ uint32_t add_mask_bit(uint32_t a, unsigned long long mask) {
 #ifdef TM_EMU
