@@ -495,7 +495,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       int run = 0;
 #pragma unroll
       for (int it = 0; it < NPOS_PAD / 64; it++) {
-        const int dst = run + __popcll(elig[it] & lane_below) - base;
+        const int dst = (int)mbcnt64(elig[it], (uint32_t)run) - base;                 // (run + the eligible positions below this lane: two v_mbcnt)
         if (((elig[it] >> lane) & 1ull) && dst >= 0 && dst < 64) w.xch[dst] = (uint16_t)(it * 64 + lane);
         run += __popcll(elig[it]);
       }
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       int run = 0;
 #pragma unroll
       for (int it = 0; it < SEG / 64; it++) {
-        const int dst = run + __popcll(m1[it] & lane_below) - base;
+        const int dst = (int)mbcnt64(m1[it], (uint32_t)run) - base;
         if (((m1[it] >> lane) & 1ull) && dst >= 0 && dst < 64) w.xch[dst] = (uint16_t)(it * 64 + lane);
         run += __popcll(m1[it]);
       }
