@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
         nfd += fdn;
         nmiss += miss;
         fd = fdn;
-        p += adv;                                                        // (a (p, 0) state always advances: the walk ends)
+        p += max(adv, 1u);                                               // (a (p, 0) state always advances — also on a row that is not one: the walk ends)
       }
     }
     if (direct == 0u) staged = E;
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
           }
           ntok += 1 + fd;
           ndel += fd;
-          p += (w >> 24) & 63u;                                    // (a (p, 0) state always advances)
+          p += max((w >> 24) & 63u, 1u);                           // (a (p, 0) state always advances — also on a row that is not one: the walk ends)
         }
       }
     }

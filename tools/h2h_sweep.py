@@ -1,6 +1,6 @@
 """tools/h2h_sweep.py — the host-to-host pipeline (tm_tokenize_pipeline) over lanes x chunk size on one GPU (development aid)."""
 import sys, time, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import tokenmonster_amd as tm
 from tokenmonster_amd import synth

@@ -1,5 +1,7 @@
+"""tools/pipeline_stress_fresh.py [iterations] — the four variants of tests/test_gpu_host_api.py::test_pipeline_equals_single_batch with a FRESH vocabulary
+(new lanes, new workspaces) every time, over and over (development aid: races in the first calls of a pipeline)."""
 import os, sys, time, gc
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import tokenmonster_amd as tm
 from tokenmonster_amd import synth
