@@ -34,6 +34,9 @@ const apos = ["'", '’'];
 const gpunct = ['‘', '“', '”', '—', '–', '…', '•', ' ', ' '];
 const marks = ['́', '̀', '̈', '̧', '̃'];                 // combining marks (\p{M})
 const accented = ['é', 'É', 'ü', 'Ü', 'ñ', 'Ñ', 'ç', 'Ç', 'å', 'Å', 'ö', 'Ö', 'ß', 'ø', 'Ø', 'š', 'Š', 'ž', 'Ž', 'ő', 'Ő'];
+// Latin-1 Supplement / Latin Extended-A beyond the accented letters: letters that do not decompose, letters without case, symbols, the
+// characters whose case mapping changes the length or the lead byte (what the device normalizer / decoder take or hand to the host)
+const latin1 = ['ø', 'Ø', 'æ', 'Æ', 'ð', 'Ð', 'þ', 'Þ', 'ß', 'œ', 'Œ', 'ł', 'Ł', 'đ', 'Đ', 'ħ', 'Ħ', 'ª', 'º', 'µ', '×', '÷', '«', '»', '¿', '¡', '½', '²', '\u00a0', 'ÿ', 'Ÿ', 'ı', 'İ', 'ŉ', 'ſ', 'ĸ', 'ŀ', 'Ŀ', 'à', 'À', 'ê', 'Ê', 'î', 'Î', 'õ', 'Õ', 'ů', 'Ů', 'ż', 'Ż', 'ę', 'Ę'];
 const other = ['中', '文', '日', '本', 'あ', 'カ', '한', 'д', 'Д', 'ж', 'Ж', 'λ', 'Λ', 'ω', 'Ω', 'ا', 'ב', '😀', '🚀', 'ǅ', 'ʰ', '٣', '५', '½', 'Ⅷ', 'ª'];
 const words = ['the', 'HTTP', 'Server', 'iPhone', 'McDonald', 'NASA', 'it', 'don', 't', 's', 'I', 'M', 'x86', 'USA', 'e', 'Go', 'API', 'v2', 'a', 'B'];
 
@@ -45,6 +48,7 @@ const flavours = [
   () => pick([lower, upper, marks, apos, [' '], accented, digits]),                                  // marks and accents (NFD changes these)
   () => pick([lower, upper, other, digits, apos, [' '], punct, marks]),                              // CJK, Cyrillic, Greek, emoji, titlecase, other digits
   () => pick([words, words, [' '], [' '], apos, punct, digits, upper]),                              // word pieces
+  () => pick([lower, upper, latin1, latin1, accented, apos, [' '], digits, marks, gpunct]),            // Latin-1 / Latin Extended-A heavy
 ];
 
 const inputs = [];
@@ -55,7 +59,7 @@ const inputs = [];
  'MiXeD cAsE', 'x1Y2z3', '3D', '2ND', 'ÉCOLE', 'École', 'ÜBER', 'İ', 'İstanbul', 'ǅ', 'STRASSE', 'Ⅷ', 'ΑΒΓ αβγ', 'ДА нет', '1st 2ND 3Rd',
  ' W', 'C D W', 'DW', ' D', 'a  B', 'a\tB', 'a\nB', "'A", "'a", "1'a", "a'1", 'áB', 'Áb', 'ÁB', 'Á', 'ÁB', 'Áb',
 ].forEach(s => inputs.push(s));
-for (let i = 0; i < 5200; i++) {
+for (let i = 0; i < 6300; i++) {
   const f = flavours[i % flavours.length];
   const n = rnd(rnd(4) === 0 ? 90 : 28);
   let s = '';
