@@ -36,6 +36,10 @@ extern "C" {
 #define TM_E_INPUT (-6)     /* the walk cannot advance on this text with this vocabulary (the reference loops forever on it: a UTF-16
                                vocabulary with one-byte keys beside the delete token); nothing is wrong with the device */
 
+#define TM_E_INTERNAL (-7)  /* the pipeline's stages disagree with each other (the emit stage met a transition the match stage never wrote): a fault
+                               of this library, never of the input.  Callers that fall back to the CPU path on errors may do so here; on TM_E_INPUT they
+                               must NOT (the reference's own walk does not terminate on that input) */
+
 #define TM_NONE 0xFFFFFFu   /* go/tokenmonster.go:32 DOES_NOT_EXIST */
 
 typedef struct tm_vocab tm_vocab;     /* immutable device-resident vocabulary tables */
@@ -68,8 +72,9 @@ typedef struct tm_vocab_block {
   uint64_t bytes;            /* size of the device block */
   uint64_t part_bytes[8];    /* root, walk tables, rows, space-prefix links, node values, reverse offsets, reverse bytes, begin_byte */
   uint32_t idle_off, n_da, n_info, max_len, off, bstart, spl_hint, link_off, direct_off, delete_id, unk_id;
-  uint32_t n_ids, vocab_size, capcode, charset, norm_flag, level, reserve, n_nodes, pad;
+  uint32_t n_ids, vocab_size, capcode, charset, norm_flag, level, reserve, n_nodes, pad;   /* pad: TM_VOCAB_BLOCK_FORMAT of the exporting build */
 } tm_vocab_block;
+#define TM_VOCAB_BLOCK_FORMAT 4u   /* layout of the device tables inside a block (tm_tables.h); an importer refuses any other */
 int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* meta, void** device_ptr);
 int tm_vocab_block_import(const tm_vocab_block* meta, int device, tm_vocab** out, void** device_ptr);
 /* Synchronous device-to-device copy (also between two devices of the node with peer access), for callers that have no HIP binding of
@@ -260,6 +265,52 @@ int tm_score_device_into(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
 int tm_score_begin(const tm_vocab* v, tm_dataset* d, uint64_t off, uint64_t len, int continues, void* stream, uint8_t* exits);
 int tm_score_finish(const tm_vocab* v, tm_dataset* d, uint32_t entry_state, void* stream, uint32_t* dst_device, uint64_t dst_words);
 int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]);
+
+/* ---- several devices of one node behind one handle: the multi-GPU half of the path for a host that stays ONE process ------------------------
+ * The reference's parallelism is in-process: trainvocab starts `workers` goroutines over one dataset (training/trainvocab.go:1827-1829; after
+ * "midway" each walks it as ONE strip, :909-922), the server fans a job's documents out over goroutines (training/tokenmonsterserver.go:363-378,
+ * :773-787).  tm_devices names the GPUs; every call below drives all of them from inside the library, one host thread per device, and the ONE
+ * collective of the path - the sum of the scoring pass's histograms - is an ncclAllReduce(sum, uint32) over xGMI inside tm_score_multi.
+ * RCCL is loaded at the first collective (librccl.so.1 is 570 MB: the single-GPU entry points never map it).
+ *
+ * tm_devices_open: the first max_devices visible devices (<= 0: all).  With TM_VIRTUAL_DEVICES=N in the environment the handle has N members that
+ * all sit on device 0 instead - the multi-device code paths on a one-GPU box; tm_devices_open_list names the devices itself (a device may appear
+ * more than once).  Members that share a device cannot form an RCCL communicator (RCCL refuses two ranks on one device): there, with TM_RCCL=0, and
+ * where librccl cannot be loaded, member 0 sums the histograms by peer copies and an add kernel - same result.  tm_devices_rccl_ranks: the
+ * number of ranks of the communicator the handle uses (it is made on the first call of this or of tm_score_multi), 0 and *why_not = the
+ * reason if there is none.  One-member handles skip the collective unless TM_RCCL=1. */
+typedef struct tm_devices tm_devices;
+typedef struct tm_vocab_set tm_vocab_set;       /* one replica of a vocabulary per member */
+typedef struct tm_dataset_set tm_dataset_set;   /* one byte range of a normalized dataset per member */
+int tm_devices_open(int max_devices, tm_devices** out);
+int tm_devices_open_list(const int* devices, int n, tm_devices** out);
+int tm_devices_count(const tm_devices* g);
+int tm_devices_device(const tm_devices* g, int member);
+int tm_devices_rccl_ranks(tm_devices* g, const char** why_not);
+void tm_devices_close(tm_devices* g);            /* after every vocabulary set and dataset set made from it has been freed */
+/* Load for all members: the tables are built once (tm_vocab_load on member 0) and the finished device block is copied device to device into
+ * every other member (tm_vocab_block_export / _import).  tm_vocab_set_member(s, 0) is a full vocabulary (decoder, image); the other members
+ * have device tables only.  The handles stay owned by the set. */
+int tm_vocab_load_all(tm_devices* g, const uint8_t* vocab_file, size_t n, tm_vocab_set** out);
+int tm_vocab_set_count(const tm_vocab_set* s);
+const tm_vocab* tm_vocab_set_member(const tm_vocab_set* s, int member);
+void tm_vocab_set_free(tm_vocab_set* s);
+/* tm_tokenize_pipeline over every device (the server's fan-out, tokenmonsterserver.go:363-378): the chunks of whole documents are handed to
+ * lanes_per_device lanes (0 = 4) of EVERY member from one queue, so a faster or less loaded device takes more of them; ids land in document
+ * order whichever device computed them.  No collective.  Arguments and results exactly as tm_tokenize_pipeline. */
+int tm_tokenize_pipeline_multi(const tm_vocab_set* s, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, int raw,
+                               uint32_t encoding_length, uint64_t chunk_bytes, uint32_t lanes_per_device, uint8_t* bytes_out, uint64_t bytes_cap,
+                               uint64_t* byte_offsets, uint32_t* missing, uint32_t* encoding_length_used, tm_pipeline_stats* stats);
+/* The dataset of a training run cut into one contiguous byte range per member (multiples of 4 bytes, trainvocab.go:1674), each uploaded with
+ * the 128 bytes that follow it (tokens straddle the cuts); a dataset of less than 4 KiB per member uses fewer members.
+ * tm_dataset_set_range: bytes of a member's range, *halo_bytes (may be NULL) the bytes of following text it holds as well. */
+int tm_dataset_upload_sharded(tm_devices* g, const uint8_t* normalized, uint64_t n, tm_dataset_set** out);
+uint64_t tm_dataset_set_range(const tm_dataset_set* s, int member, uint64_t* halo_bytes);
+void tm_dataset_set_free(tm_dataset_set* s);
+/* One scoring pass over the WHOLE dataset as one strip (trainvocab.go:909-922), bit-identical to tm_score(v, whole dataset, n_strips = 0) on one
+ * device: every member runs tm_score_begin on its range, the 80-entry exit maps are chained on the host into every member's entry state,
+ * tm_score_finish completes the ranges, and one all-reduce(sum) of the n_ids + 4 + 256 uint32 histogram words merges them.  Results as tm_score. */
+int tm_score_multi(const tm_vocab_set* vs, tm_dataset_set* ds, uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtokenmonster_hip.so")
 
-TM_OK, TM_E_INVALID, TM_E_NODEVICE, TM_E_HIP, TM_E_NOSPACE, TM_E_LIMIT, TM_E_INPUT = 0, -1, -2, -3, -4, -5, -6
+TM_OK, TM_E_INVALID, TM_E_NODEVICE, TM_E_HIP, TM_E_NOSPACE, TM_E_LIMIT, TM_E_INPUT, TM_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7
 TM_NONE = 0xFFFFFF
 TM_NUM_KERNELS = 5
 KIND_ENGLISH, KIND_ENGLISHCODE, KIND_CODE = 0, 1, 2
@@ -85,6 +85,21 @@ SIGNATURES = {
     "tm_score_begin": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp]),
     "tm_score_finish": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint64]),
     "tm_score_read": (C.c_int, [vp, vp, vp, u64p, vp]),
+    "tm_devices_open": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "tm_devices_open_list": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "tm_devices_count": (C.c_int, [vp]),
+    "tm_devices_device": (C.c_int, [vp, C.c_int]),
+    "tm_devices_rccl_ranks": (C.c_int, [vp, C.POINTER(C.c_char_p)]),
+    "tm_devices_close": (None, [vp]),
+    "tm_vocab_load_all": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(vp)]),
+    "tm_vocab_set_count": (C.c_int, [vp]),
+    "tm_vocab_set_member": (vp, [vp, C.c_int]),
+    "tm_vocab_set_free": (None, [vp]),
+    "tm_tokenize_pipeline_multi": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_uint64, vp, vp, u32p, vp]),
+    "tm_dataset_upload_sharded": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(vp)]),
+    "tm_dataset_set_range": (C.c_uint64, [vp, C.c_int, u64p]),
+    "tm_dataset_set_free": (None, [vp]),
+    "tm_score_multi": (C.c_int, [vp, vp, vp, u64p, vp]),
     # tm_build.h
     "tm_free": (None, [vp]),
     "tm_build_vocab": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,

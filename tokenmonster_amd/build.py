@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libtokenmonster_hip.so")
 # test / benchmark support (synthetic vocabularies and corpora): its own library, not part of the product
 SUPPORT_LIB = os.path.join(HERE, "libtm_testsupport.so")
 SUPPORT_SOURCES = [os.path.join(HERE, "testsupport", "tm_synth.cpp")]
-SOURCES = ["tm_vocab.hip", "tm_kernels.hip", "tm_score.hip", "tm_norm.hip", "tm_decode.hip", "tm_host.hip", "tm_decoder.hip", "tm_formats.hip", "tm_build.cpp", "tm_normalize.cpp"]
+SOURCES = ["tm_vocab.hip", "tm_kernels.hip", "tm_score.hip", "tm_norm.hip", "tm_decode.hip", "tm_host.hip", "tm_decoder.hip", "tm_formats.hip", "tm_multi.hip", "tm_build.cpp", "tm_normalize.cpp"]
 HEADERS = ["tm_device.h", "tm_internal.h", "tm_tables.h", "tm_pipeline.h", "tm_norm_masks.h", "../../include/tokenmonster_hip.h", "../../include/tm_build.h"]
 
 
@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
         if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-licuuc", "-licui18n", "-lz"]
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-licuuc", "-licui18n", "-lz", "-ldl"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))

@@ -275,7 +275,7 @@ static int count_batch(const tm_vocab* v, const uint8_t* text, const uint64_t* o
     if (rc == TM_OK) rc = small_d2h(b, ev.data(), b->d_doc_events, (uint64_t)ndocs * 4, l->stream);
     if (rc == TM_OK && missing) rc = small_d2h(b, missing, b->d_doc_missing, (uint64_t)ndocs * 4, l->stream);
     if (rc == TM_OK) rc = small_sync(b, l->stream); else (void)small_sync(b, l->stream);
-    if (rc == TM_OK && err) rc = set_error(TM_E_INPUT, "the walk does not advance on this text (a vocabulary / text combination the reference does not terminate on: e.g. one-byte keys beside the delete token in a UTF-16 vocabulary)");
+    if (rc == TM_OK && err) rc = error_from_flag(err);
     if (rc == TM_OK && counts) for (uint32_t d = 0; d < ndocs; d++) counts[d] = ev[d];
   }
   lane_release(v, l);
@@ -324,7 +324,20 @@ int tm_tokenize_batch_serialized(const tm_vocab* v, const uint8_t* text, const u
 int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, int raw, uint32_t encoding_length,
                          uint64_t chunk_bytes, uint32_t lanes, uint8_t* bytes_out, uint64_t bytes_cap, uint64_t* byte_offsets, uint32_t* missing,
                          uint32_t* encoding_length_used, tm_pipeline_stats* stats) {
-  if (!v || (ndocs && (!offsets || !text)) || !byte_offsets) return set_error(TM_E_INVALID, "null argument");
+  return tmh::tokenize_pipeline_on(&v, 1, text, offsets, ndocs, raw, encoding_length, chunk_bytes, lanes, bytes_out, bytes_cap, byte_offsets, missing,
+                                   encoding_length_used, stats);
+}
+
+}  // extern "C"
+namespace tmh {
+// The pipeline over the lanes of ONE vocabulary or of its replicas on several devices (tm_tokenize_pipeline_multi, tm_multi.hip): worker w
+// borrows a lane of replica w % nv, so the chunks — handed out from one counter — go to whichever lane of whichever device is free, and the
+// ids of chunk k land behind those of chunks 0..k-1 wherever they were computed.  `lanes` = lanes per replica.
+int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, int raw, uint32_t encoding_length,
+                         uint64_t chunk_bytes, uint32_t lanes, uint8_t* bytes_out, uint64_t bytes_cap, uint64_t* byte_offsets, uint32_t* missing,
+                         uint32_t* encoding_length_used, tm_pipeline_stats* stats) {
+  if (!vs || nv == 0 || !vs[0] || (ndocs && (!offsets || !text)) || !byte_offsets) return set_error(TM_E_INVALID, "null argument");
+  const tm_vocab* const v = vs[0];          // (what the replicas have in common: id width)
   if (encoding_length <= 1) encoding_length = v->host.n_ids <= 65536 ? 2 : 3;
   if (encoding_length < 2 || encoding_length > 4) return set_error(TM_E_INVALID, "Invalid encoding length");
   if (encoding_length_used) *encoding_length_used = encoding_length;
@@ -338,8 +351,8 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
     first.push_back(d);
     uint32_t e = d + 1;
     if (offsets[e] < offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
-    // (the first two chunks are a quarter and half the size: the first kernels start after a short upload)
-    const uint64_t limit = first.size() == 1 ? chunk_bytes / 4 : first.size() == 2 ? chunk_bytes / 2 : chunk_bytes;
+    // (the first chunk of every device is a quarter, the second half the size: the first kernels start after a short upload)
+    const uint64_t limit = first.size() <= nv ? chunk_bytes / 4 : first.size() <= 2 * (size_t)nv ? chunk_bytes / 2 : chunk_bytes;
     while (e < ndocs && offsets[e + 1] >= offsets[e] && offsets[e + 1] - offsets[d] <= limit) e++;
     d = e;
   }
@@ -359,10 +372,11 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
   int first_error = TM_OK;
   std::string first_msg;
   std::atomic<size_t> next{0};
-  lanes = (uint32_t)std::min<size_t>(lanes, nchunks);
+  const uint32_t nworkers = (uint32_t)std::min<size_t>((size_t)lanes * nv, nchunks);
   // A lane works on one chunk at a time, but the raw text of its NEXT chunk is uploaded (on the lane's second stream) as soon as the
   // normalizer pass of the current one is through with the raw buffer: the H2D of chunk k+1 hides behind the tokenizer kernels of chunk k.
-  auto worker = [&]() {
+  auto worker = [&](uint32_t wi) {
+    const tm_vocab* const v = vs[wi % nv];
     Lane* l = nullptr;
     int rc = lane_acquire(v, &l);
     std::vector<uint64_t> loc, loc_next, toff;
@@ -459,14 +473,16 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
     if (l) lane_release(v, l);
   };
   std::vector<std::thread> th;
-  for (uint32_t t = 1; t < lanes; t++) th.emplace_back(worker);
-  worker();
+  for (uint32_t t = 1; t < nworkers; t++) th.emplace_back(worker, t);
+  worker(0);
   for (auto& t : th) t.join();
   if (first_error != TM_OK) return set_error(first_error, "%s", first_msg.c_str());
-  if (stats) { stats->chunks = (uint32_t)nchunks; stats->lanes = lanes; stats->input_pinned = in_pinned; stats->output_pinned = out_pinned; }
+  if (stats) { stats->chunks = (uint32_t)nchunks; stats->lanes = nworkers; stats->input_pinned = in_pinned; stats->output_pinned = out_pinned; }
   if (byte_offsets[ndocs] > bytes_cap || !bytes_out) return set_error(TM_E_NOSPACE, "bytes_cap %llu < %llu required", (unsigned long long)bytes_cap, (unsigned long long)byte_offsets[ndocs]);
   return TM_OK;
 }
+}  // namespace tmh
+extern "C" {
 
 // Decode / decode_raw (go/tokenmonster.go:445-550; tokenmonster.cpp:1404-1425) on a lane like the tokenize entry points: the lane's
 // stream, grow-only device arenas and pinned staging — steady state allocates nothing and stays off the NULL stream, so decode jobs of a

@@ -1158,6 +1158,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
           miss = m8 >> 7; fdn = (m8 >> 6) & 1u; adv = m8 & 63u;
         } else {
           const uint32_t w = row[SLACK + p];
+          if (w == R_INVALID) atomicOr(error_flag, 2u);                  // (never on a chain K1 / K3 produced: T(p,0) exists for every p < seglen; the walk ends, adv = 63)
           miss = w >> 31; fdn = (w >> 30) & 1u; adv = (w >> 24) & 63u;
           id = w & ID_NONE;
         }
@@ -1249,6 +1250,7 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
         }
         if (alive && !slow) {
           const uint32_t w = row[TSLACK + p];
+          if (w == R_INVALID) atomicOr(error_flag, 2u);            // (never on a chain K1 / K3 produced: T(p,0) exists for every p < seglen; the walk ends, adv = 63)
           const uint32_t miss = w >> 31;
           fd = (w >> 30) & 1u;
           row[staged] = w;                                         // (staged < TSLACK + p; unconditional: a word that does not count is overwritten by the next one or lies behind the count)
@@ -1667,6 +1669,12 @@ int small_sync(tm_batch* b, hipStream_t st) {
   return TM_OK;
 }
 
+int error_from_flag(uint32_t err) {
+  if (err == 0) return TM_OK;
+  if ((err & 1u) == 0u) return set_error(TM_E_INTERNAL, "the emit stage met a transition the match stage never wrote (device error word %u): a fault of this library, not of the input", err);
+  return set_error(TM_E_INPUT, "the walk does not advance on this text (a vocabulary / text combination the reference does not terminate on: e.g. one-byte keys beside the delete token in a UTF-16 vocabulary)");
+}
+
 int ensure_output(tm_batch* b) {
   { int rc = enter_device(b->vocab); if (rc != TM_OK) return rc; }
   hipError_t e;
@@ -1676,7 +1684,7 @@ int ensure_output(tm_batch* b) {
     if (rc == TM_OK) rc = small_d2h(b, &err, b->d_error, 4, b->last_stream);
     if (rc == TM_OK) rc = small_sync(b, b->last_stream);
     if (rc != TM_OK) return rc; }
-  if (err != 0) return set_error(TM_E_INPUT, "the walk does not advance on this text (a vocabulary / text combination the reference does not terminate on: e.g. one-byte keys beside the delete token in a UTF-16 vocabulary)");
+  if (err != 0) return error_from_flag(err);
   uint64_t total = b->ndocs ? totals[1] : 0;
   if (total > b->out_cap) {
     (void)hipFree(b->d_out);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "tm_device.h"
@@ -152,6 +153,30 @@ struct tm_batch {
   bool have_events = false;
 };
 
+// device-resident normalized dataset of the scoring pass (tm_score.hip)
+struct tm_dataset {
+  uint8_t* d_text = nullptr;
+  uint64_t n = 0;
+  tm_batch* ws = nullptr;          // workspace, created on first use and reused by every scoring pass
+  uint32_t ws_docs = 0;
+  uint32_t* d_hist = nullptr;      // scores | 4 token limbs | 256 missing counters
+  uint64_t hist_words = 0, hist_cap = 0;
+  unsigned long long* d_tokens = nullptr;
+  uint32_t* d_missing_bits = nullptr;
+  int n_cu = 256;
+  int device = 0;
+  // byte ranges of a whole-buffer walk (tm_score_begin / tm_score_finish)
+  uint64_t* d_vis = nullptr;       // per strip: how far it may look at the text
+  uint8_t* d_entry = nullptr;      // per strip: entry state
+  uint8_t* d_exits = nullptr;      // per strip: exit state for each of the ENT entry states
+  uint32_t strip_cap = 0;
+  bool prepared = false;
+  // one scoring pass at a time per dataset (it owns ONE workspace); host threads that build and load the next candidates
+  // (tm_build_vocab, tm_vocab_load) run beside the pass of the current one
+  std::mutex mu;
+  hipStream_t stream = nullptr;    // tm_score's own stream
+};
+
 namespace tmh {
 
 // tm_kernels.hip
@@ -184,6 +209,16 @@ void launch_decode_lengths(const tm_vocab* v, const uint32_t* d_tok, uint64_t n,
                            uint64_t* d_sums, uint64_t* d_total, uint64_t* d_doff, hipStream_t st);
 void launch_decode_copy(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_off, uint8_t* d_out, hipStream_t st);
 int launch_decode_capcode(const tm_vocab* v, const uint8_t* d_out, const uint64_t* d_doff, uint32_t ndocs, uint8_t* d_dec, uint64_t* d_declen, hipStream_t st);
+// tm_host.hip: tm_tokenize_pipeline over the lanes of one vocabulary or of its replicas on several devices
+int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, int raw, uint32_t encoding_length,
+                         uint64_t chunk_bytes, uint32_t lanes, uint8_t* bytes_out, uint64_t bytes_cap, uint64_t* byte_offsets, uint32_t* missing,
+                         uint32_t* encoding_length_used, tm_pipeline_stats* stats);
+// what the device's error word (tm_batch::d_error) means for the caller: bit 0 = an entry state from which the walk never leaves its segment
+// (k_resolve and the group kernels: the text / vocabulary pair does not advance, TM_E_INPUT), bit 1 = K4 met a row that K1 never wrote or a
+// chain longer than its segment (an inconsistency of this library, TM_E_INTERNAL).  0 -> TM_OK.
+int error_from_flag(uint32_t err);
+// tm_score.hip: the error word of the dataset's last pass, once its stream has been synchronized
+int score_check(tm_dataset* d);
 // tm_norm.hip
 int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs, hipStream_t st);
 // tm_normalize.cpp

@@ -17,28 +17,7 @@
 
 using namespace tmh;
 
-struct tm_dataset {
-  uint8_t* d_text = nullptr;
-  uint64_t n = 0;
-  tm_batch* ws = nullptr;          // workspace, created on first use and reused by every scoring pass
-  uint32_t ws_docs = 0;
-  uint32_t* d_hist = nullptr;      // scores | 4 token limbs | 256 missing counters
-  uint64_t hist_words = 0, hist_cap = 0;
-  unsigned long long* d_tokens = nullptr;
-  uint32_t* d_missing_bits = nullptr;
-  int n_cu = 256;
-  int device = 0;
-  // byte ranges of a whole-buffer walk (tm_score_begin / tm_score_finish)
-  uint64_t* d_vis = nullptr;       // per strip: how far it may look at the text
-  uint8_t* d_entry = nullptr;      // per strip: entry state
-  uint8_t* d_exits = nullptr;      // per strip: exit state for each of the ENT entry states
-  uint32_t strip_cap = 0;
-  bool prepared = false;
-  // one scoring pass at a time per dataset (it owns ONE workspace); host threads that build and load the next candidates
-  // (tm_build_vocab, tm_vocab_load) run beside the pass of the current one
-  std::mutex mu;
-  hipStream_t stream = nullptr;    // tm_score's own stream
-};
+// (struct tm_dataset: tm_pipeline.h - tm_multi.hip drives one dataset per device)
 
 // One scoring pass in two halves.  score_prepare: the strips become the documents of the workspace, K0 + K1 run (and the group maps
 // of long strips).  score_complete: K3 from the strips' entry states + the histogram walk.  Between the two a caller that scores
@@ -140,6 +119,16 @@ static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off
   int rc = score_prepare(v, d, strip_off, strip_len, n_strips, false, st);
   return rc == TM_OK ? score_complete(v, d, nullptr, st) : rc;
 }
+
+namespace tmh {
+int score_check(tm_dataset* d) {
+  if (!d || !d->ws) return TM_OK;
+  uint32_t err = 0;
+  int rc = small_d2h(d->ws, &err, d->ws->d_error, 4, d->ws->last_stream);
+  if (rc == TM_OK) rc = small_sync(d->ws, d->ws->last_stream);
+  return rc == TM_OK ? error_from_flag(err) : rc;
+}
+}  // namespace tmh
 
 extern "C" {
 
@@ -243,7 +232,7 @@ int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* 
     if (rc == TM_OK) rc = small_sync(d->ws, st);
     if (rc != TM_OK) return rc;
   }
-  if (err) return set_error(TM_E_INPUT, "the walk does not advance on this text (a vocabulary / text combination the reference does not terminate on: e.g. one-byte keys beside the delete token in a UTF-16 vocabulary)");
+  if (err) return error_from_flag(err);
   const uint32_t n_ids = v->host.n_ids;
   if (scores) std::memcpy(scores, h.data(), (size_t)n_ids * 4);
   if (tokens_in_text) {

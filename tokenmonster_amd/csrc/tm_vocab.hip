@@ -432,17 +432,23 @@ BlockCache& cache_of(int device) {
 size_t round_block(size_t bytes) { return (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1); }
 void* block_get(int device, bool host, size_t bytes, size_t* got, hipError_t* err) {
   BlockCache& c = cache_of(device);
+  Parked pk{nullptr, {}};
+  bool found = false;
   {
     std::lock_guard<std::mutex> g(c.mu);
     auto& fl = host ? c.host_free : c.dev_free;
     auto it = fl.lower_bound(bytes);
     if (it != fl.end() && it->first <= 2 * bytes + (4u << 20)) {
-      Parked pk = std::move(it->second); *got = it->first;
+      pk = std::move(it->second); *got = it->first;
       (host ? c.host_cached : c.dev_cached) -= it->first;
       fl.erase(it);
-      for (hipEvent_t ev : pk.pending) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }     // (outside of nothing: a handful of events, almost always complete)
-      return pk.p;
+      found = true;
     }
+  }
+  if (found) {
+    // outside the lock: a kernel of the freed vocabulary may still be running, and the other loaders / frees of the device must not wait for it
+    for (hipEvent_t ev : pk.pending) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+    return pk.p;
   }
   void* p = nullptr;
   *got = round_block(bytes);
@@ -541,7 +547,7 @@ int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* m, void** device_pt
   m->idle_off = hv.idle_off; m->n_da = hv.n_da; m->n_info = hv.n_info; m->max_len = hv.max_len; m->off = hv.off; m->bstart = hv.bstart;
   m->spl_hint = hv.spl_hint; m->link_off = hv.link_off; m->direct_off = hv.direct_off; m->delete_id = hv.delete_id; m->unk_id = hv.unk;
   m->n_ids = hv.n_ids; m->vocab_size = hv.vocab_size; m->capcode = hv.capcode; m->charset = hv.charset; m->norm_flag = hv.norm_flag; m->level = hv.level;
-  m->reserve = hv.reserve; m->n_nodes = hv.n_nodes;
+  m->reserve = hv.reserve; m->n_nodes = hv.n_nodes; m->pad = TM_VOCAB_BLOCK_FORMAT;
   if (device_ptr) *device_ptr = v->d_block;
   return TM_OK;
 }
@@ -557,7 +563,14 @@ int tm_vocab_block_import(const tm_vocab_block* m, int device, tm_vocab** out, v
   *out = nullptr;
   size_t total = 256;
   for (int k = 0; k < 8; k++) total += (m->part_bytes[k] + 255) & ~(uint64_t)255;
-  if (total > m->bytes || m->part_bytes[0] != 256 * 4 || m->part_bytes[7] != 256 || m->n_ids > kRowIdMask + 1)
+  if (m->pad != TM_VOCAB_BLOCK_FORMAT) return set_error(TM_E_INVALID, "vocabulary block of table format %u, this library reads format %u (exporter and importer are different builds)", m->pad, (unsigned)TM_VOCAB_BLOCK_FORMAT);
+  // every offset the kernels add to a table pointer is checked against the part it indexes: a stale or foreign description must not make K1 gather outside the block
+  const uint64_t tab = m->part_bytes[1];
+  if (total > m->bytes || m->part_bytes[0] != 256 * 4 || m->part_bytes[7] != 256 || m->n_ids > kRowIdMask + 1 || m->n_info >= kMaxNodes || m->n_nodes < m->n_info ||
+      m->n_nodes >= kMaxNodes || m->max_len > 40 || (m->off != 1 && m->off != 2) || m->idle_off != (uint64_t)m->n_da * 16 || ((uint64_t)m->n_da + 1) * 16 != m->direct_off ||
+      (uint64_t)m->direct_off + (uint64_t)kDirectSlots * sizeof(uint2) != m->link_off || (uint64_t)m->link_off + 16ull * m->n_nodes != tab ||
+      m->part_bytes[2] != 16ull * m->n_info || m->part_bytes[3] != 16ull * m->n_info || m->part_bytes[4] != 4ull * m->n_info ||
+      m->part_bytes[5] != 4ull * ((uint64_t)m->n_ids + 1) || (m->delete_id != TM_NONE && m->delete_id >= m->n_ids) || (m->unk_id != TM_NONE && m->unk_id >= m->n_ids))
     return set_error(TM_E_INVALID, "vocabulary block description is inconsistent");
   { int rc = tm_set_device(device); if (rc != TM_OK) return rc; }
   auto* v = new tm_vocab();

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "tokenmonster_amd", "csrc")
 LIB = os.path.join(HERE, "libtokenmonster_emu.so")
 BUILD = os.path.join(HERE, "build")
-SOURCES = ["tm_vocab.hip", "tm_kernels.hip", "tm_score.hip", "tm_norm.hip", "tm_decode.hip", "tm_host.hip", "tm_decoder.hip", "tm_formats.hip",
+SOURCES = ["tm_vocab.hip", "tm_kernels.hip", "tm_score.hip", "tm_norm.hip", "tm_decode.hip", "tm_host.hip", "tm_decoder.hip", "tm_formats.hip", "tm_multi.hip",
            "tm_build.cpp", "tm_normalize.cpp"]
 
 
@@ -55,7 +55,7 @@ def build(force=False, verbose=False, extra=()):
         if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
     if force or procs or _stale(LIB, objs):
-        cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-licuuc", "-licui18n", "-lz", "-lpthread"]
+        cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-licuuc", "-licui18n", "-lz", "-lpthread", "-ldl"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError("emulation link failed:\n" + r.stdout.decode(errors="replace"))

@@ -371,6 +371,10 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
 }
 hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) { if (n) std::memmove(dst, src, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memmove(dst, src, n); return hipSuccess; }
+hipError_t hipMemcpyPeer(void* dst, int, const void* src, int, size_t n) { if (n) std::memmove(dst, src, n); return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void* dst, int, const void* src, int, size_t n, hipStream_t) { if (n) std::memmove(dst, src, n); return hipSuccess; }
+hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 0; return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipErrorInvalidDevice; }
 hipError_t hipMemset(void* p, int v, size_t n) { if (n) std::memset(p, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { if (n) std::memset(p, v, n); return hipSuccess; }
 hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n) { std::memcpy(sym, src, n); return hipSuccess; }

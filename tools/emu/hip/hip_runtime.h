@@ -169,7 +169,7 @@ typedef enum { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDevi
 typedef enum { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 } hipMemoryType;
 typedef struct { hipMemoryType type; int device; void* devicePointer; void* hostPointer; } hipPointerAttribute_t;
 typedef enum { hipDeviceAttributeMultiprocessorCount = 0 } hipDeviceAttribute_t;
-enum { hipHostMallocDefault = 0, hipHostRegisterDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostRegisterDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipGetDevice(int* d);
@@ -189,6 +189,10 @@ hipError_t hipHostUnregister(void* p);
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p);
 hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t st = nullptr);
+hipError_t hipMemcpyPeer(void* dst, int dst_dev, const void* src, int src_dev, size_t n);
+hipError_t hipMemcpyPeerAsync(void* dst, int dst_dev, const void* src, int src_dev, size_t n, hipStream_t st = nullptr);
+hipError_t hipDeviceCanAccessPeer(int* can, int dev, int peer);
+hipError_t hipDeviceEnablePeerAccess(int peer, unsigned flags);
 hipError_t hipMemset(void* p, int v, size_t n);
 hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t st = nullptr);
 hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n);
