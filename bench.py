@@ -44,10 +44,17 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hot-path-only", action="store_true", help="input = host-normalized bytes; time only the tokenize pipeline")
     ap.add_argument("--cpu-sample-mb", type=float, default=64.0)
-    ap.add_argument("--verify", type=int, default=1024, help="documents re-checked against the oracle after timing (rank 0)")
+    ap.add_argument("--verify", type=int, default=-1, help="documents re-checked after timing (rank 0): -1 = ALL of them against the reference runtime on every host core "
+                                                           "(a bounded sample where the host has few cores), n > 0 = a random sample of n against the oracle, 0 = none")
     ap.add_argument("--also-flags", default="", help="development aid: comma separated tm_debug_flags values; the same step is timed again under each "
                                                       "(kernel variants) and reported on stderr, its ids compared with the default's")
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-to-host pipeline and small-batch latency figures")
+    ap.add_argument("--h2h-lanes", type=int, default=4, help="lanes of the host-to-host pipeline (ONE stated setting, timed over --steps)")
+    ap.add_argument("--h2h-chunk-mib", type=int, default=32, help="chunk size of the host-to-host pipeline in MiB")
+    ap.add_argument("--h2h-sweep", action="store_true", help="development aid: also time other (lanes, chunk) settings, reported on stderr only")
+    ap.add_argument("--in-process", action="store_true",
+                    help="N GPUs from ONE process through the library's own multi-device driver (tm_devices / tm_vocab_load_all / tm_score_multi, RCCL inside "
+                         "the library; include/tokenmonster_hip.h) - the path a Go host uses - instead of one torch.distributed rank per GPU")
     ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false",
                     help="do not measure roofline.traffic / roofline_valu in this run (default: three rocprofv3 --pmc passes - instruction counts, FETCH_SIZE, "
                          "WRITE_SIZE - over tools/k1_time.py in a child process, about a minute; without them the figures of profiles/traffic_latest.json are "
@@ -55,7 +62,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(img, text, offs, sample_mb, log, raw_mode=False):
+def cpu_baseline(img, text, offs, sample_mb, log, raw_mode=False, check=None):
     """the reference's own C++ runtime (oracle/_ref, kind 'reference') — or our C port when it is absent — timed
     single-threaded on a bounded sample of the SAME normalized documents, the way benchmark/tokenmonster_bench.go
     :41-55 times Go: wall clock around tokenize calls."""
@@ -90,10 +97,20 @@ def cpu_baseline(img, text, offs, sample_mb, log, raw_mode=False):
         d2 = int(np.searchsorted(offs, want, side="right")) - 1
         d2 = max(1, min(nd, d2))
         t0 = time.perf_counter()
-        eng.tokenize_docs_mt(text[: int(offs[d2])], offs[: d2 + 1], raw_mode, ncores)
+        if check is None:
+            eng.tokenize_docs_mt(text[: int(offs[d2])], offs[: d2 + 1], raw_mode, ncores)
+        else:
+            # the same fan-out as the CHECKER of the device's ids: every document's id stream and `missing` compared (memcmp) with what the
+            # reference produced for it; the comparison is negligible beside the tokenization it rides on
+            ids, toff, miss = check
+            bad, first_bad, _ = eng.verify_docs_mt(text[: int(offs[d2])], offs[: d2 + 1], raw_mode, ncores, ids, toff[: d2 + 1], miss)
+            if bad:
+                raise SystemExit("bench.py: HIP ids differ from the reference runtime's in %d of %d documents (first: document %d) - number is INVALID" % (bad, d2, first_bad))
+            res["verified_docs_vs_reference"] = d2
         dt2 = time.perf_counter() - t0
         res["all_cores"] = {"value": round(int(offs[d2]) / dt2 / 1e9, 6), "unit": "GB/s", "cores": ncores,
-                            "sample": "first %d documents (%.1f MB) of the same corpus, %d threads, %.1f s" % (d2, int(offs[d2]) / 1e6, ncores, dt2)}
+                            "sample": "first %d documents (%.1f MB) of the same corpus, %d threads, %.1f s%s" % (
+                                d2, int(offs[d2]) / 1e6, ncores, dt2, "" if check is None else "; every document's ids compared with the device's")}
         # the reference's own micro-benchmark on its own 1 MiB micro-corpus (tokenmonster-cpp/tests/bench.cpp:39-55), 1 thread
         if os.path.exists(ob.REF_BENCH):
             import subprocess
@@ -114,7 +131,7 @@ def cpu_baseline(img, text, offs, sample_mb, log, raw_mode=False):
     return res
 
 
-def host_to_host(vocab, raw, roffs, text, offs, ids_expected, log, tm, steps=3):
+def host_to_host(vocab, raw, roffs, text, offs, ids_expected, log, tm, steps=3, lanes=4, chunk=32 << 20, sweep=False):
     """RAW UTF-8 in (pinned) host memory -> 2-byte serialized ids in (pinned) host memory, through tm_tokenize_pipeline:
     chunks run H2D | normalize + tokenize + serialize | D2H on several lanes.  This is SURVEY 8(d)'s 'first H2D to last D2H'
     figure; `value` stays the HBM-resident rate.  Also the latency of a small batch (64 documents of 2 KiB, already normalized)
@@ -126,20 +143,24 @@ def host_to_host(vocab, raw, roffs, text, offs, ids_expected, log, tm, steps=3):
     pin_out = tm.PinnedBuffer(4 * ids_expected + 4096)
     res = {}
     for label, src, dst in (("pinned", pin_in.array, pin_out.array), ("pageable", raw, np.empty(4 * ids_expected + 4096, dtype=np.uint8))):
-        best = None
-        for lanes, chunk in ((4, 32 << 20), (6, 32 << 20), (6, 16 << 20), (8, 16 << 20), (4, 64 << 20), (3, 64 << 20)):
-            vocab.tokenize_pipeline(src, roffs, raw=True, chunk_bytes=chunk, lanes=lanes, out=dst)      # warm the lanes
+        # ONE stated setting, `steps` passes after one warm-up pass (benchmark/tokenmonster_bench.go:41-55 times around the whole call)
+        settings = [(lanes, chunk)] + ([(6, 32 << 20), (6, 16 << 20), (8, 16 << 20), (4, 64 << 20), (3, 64 << 20), (4, 32 << 20)] if sweep else [])
+        for k, (ln, ch) in enumerate(settings):
+            vocab.tokenize_pipeline(src, roffs, raw=True, chunk_bytes=ch, lanes=ln, out=dst)      # warm the lanes
             t0 = time.perf_counter()
             for _ in range(steps):
-                blob, boff, _, enc, st = vocab.tokenize_pipeline(src, roffs, raw=True, chunk_bytes=chunk, lanes=lanes, out=dst)
+                blob, boff, _, enc, st = vocab.tokenize_pipeline(src, roffs, raw=True, chunk_bytes=ch, lanes=ln, out=dst)
             dt = (time.perf_counter() - t0) / steps
-            if best is None or dt < best[0]:
-                best = (dt, lanes, chunk, enc, int(boff[-1]) // enc, st)
-        dt, lanes, chunk, enc, ntok, st = best
-        res[label] = {"value": round(raw.size / dt / 1e9, 4), "unit": "GB/s raw UTF-8, host to host", "ms": round(dt * 1e3, 3), "lanes": lanes,
-                      "chunk_MiB": chunk >> 20, "id_bytes": enc, "tokens": ntok}
-        if ntok != ids_expected:
-            raise SystemExit("bench.py: host-to-host pipeline produced %d tokens, the resident pass %d - number is INVALID" % (ntok, ids_expected))
+            ntok = int(boff[-1]) // enc
+            if k == 0:
+                res[label] = {"value": round(raw.size / dt / 1e9, 4), "unit": "GB/s raw UTF-8, host to host", "ms": round(dt * 1e3, 3), "lanes": ln,
+                              "chunk_MiB": ch >> 20, "id_bytes": enc, "tokens": ntok, "steps": steps}
+                if label == "pinned":
+                    res["_ids"] = (blob.copy(), boff.copy(), enc)
+            else:
+                log("host_to_host sweep (%s): %d lanes x %d MiB: %.3f ms = %.2f GB/s" % (label, ln, ch >> 20, dt * 1e3, raw.size / dt / 1e9))
+            if ntok != ids_expected:
+                raise SystemExit("bench.py: host-to-host pipeline produced %d tokens, the resident pass %d - number is INVALID" % (ntok, ids_expected))
     # small batch latency
     nd = 64
     small_off = np.zeros(nd + 1, dtype=np.uint64)
@@ -160,7 +181,7 @@ def host_to_host(vocab, raw, roffs, text, offs, ids_expected, log, tm, steps=3):
     lat = np.sort(np.array(lat[20:]))
     res["small_batch_latency"] = {"docs": nd, "bytes": int(small.size), "p50_ms": round(float(lat[lat.size // 2]) * 1e3, 3),
                                   "p99_ms": round(float(lat[int(lat.size * 0.99)]) * 1e3, 3), "api": "tm_tokenize_batch (host buffers, warm lane)"}
-    log("host_to_host: %s" % res)
+    log("host_to_host: %s" % {k: v for k, v in res.items() if k != "_ids"})
     return res
 
 
@@ -223,21 +244,12 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
     all_raw, all_norm = float(tot[0].item()), float(tot[1].item())
     scores, tokens, missing = tmdist.decode_histogram(hist.cpu().numpy(), n_ids)
     verified = None
-    if rank == 0 and world == 1 and args.verify > 0:
-        # bit-exact check of a bounded prefix against the oracle's scoring mode (outside the timed region)
+    if rank == 0 and world == 1 and args.verify != 0:
+        # bit-exact check against the oracle's scoring mode (outside the timed region): the whole buffer where the host has the cores for it
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_bind import Oracle
         orc = Oracle(img)
-        n = min(int(text.size), 2 << 20)
-        exp_s, exp_t, exp_m = orc.score(text[:n])
-        so, sl = np.array([0], dtype=np.uint64), np.array([n], dtype=np.uint64)
-        got = np.zeros(n_ids, dtype=np.uint32)
-        tit = C.c_uint64()
-        ms8 = np.zeros(32, dtype=np.uint8)
-        N.check(N.lib.tm_score(vocab.handle, ds, N.ptr(so), N.ptr(sl), 1, N.ptr(got), C.byref(tit), N.ptr(ms8)))
-        if not ((got == exp_s).all() and tit.value == exp_t and (ms8 == exp_m).all()):
-            raise SystemExit("bench.py: HIP score histogram differs from the oracle - number is INVALID")
-        verified = n
+        verified = verify_score(orc, text, lambda n: score_prefix(N, vocab, ds, n_ids, n), (scores, tokens, missing), args, log)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the CPU leg walks strips of 1 MiB as the trainvocab workers do before "midway" (training/trainvocab.go:1668-1695): one unit of
@@ -274,7 +286,7 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
                        "raw_bytes_total": int(all_raw), "normalized_bytes_total": int(all_norm), "tokens_in_text": int(tokens),
                        "normalized_GBps": round(all_norm * args.steps / elapsed / 1e9, 4),
                        "parallelism": "one whole-buffer walk cut into a byte range per rank (halo + all-gather of 80 exit states per rank), RCCL all-reduce of the score histogram",
-                       "verified_bytes_vs_oracle": verified},
+                       "verified_bytes_vs_oracle": ("all (%d)" % verified) if verified == int(text.size) else verified},
             "roofline": {"bound": "hbm", "kernel": "whole scoring pass of one rank", "achieved": round(alg / (elapsed / args.steps) / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_source, "traffic_note": TRAFFIC_NOTE, "algorithmic_bytes_per_launch": alg},
@@ -284,6 +296,168 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
     N.lib.tm_dataset_free(ds)
     if world > 1:
         dist.destroy_process_group()
+
+
+def score_prefix(N, vocab, ds, n_ids, n):
+    """tm_score over the first n bytes of the resident dataset as one strip -> (scores, tokens_in_text, missing_set)"""
+    so, sl = np.array([0], dtype=np.uint64), np.array([n], dtype=np.uint64)
+    got = np.zeros(n_ids, dtype=np.uint32)
+    tit = C.c_uint64()
+    ms8 = np.zeros(32, dtype=np.uint8)
+    N.check(N.lib.tm_score(vocab.handle, ds, N.ptr(so), N.ptr(sl), 1, N.ptr(got), C.byref(tit), N.ptr(ms8)))
+    return got, tit.value, ms8
+
+
+def verify_score(orc, text, device_prefix, whole, args, log):
+    """the scoring pass against the oracle's scoring mode (training/trainvocab.go:1105-1174 restated; the reference runtime has none), outside
+    the timed region.  With the cores for it (-1 = default): the WHOLE buffer as ONE strip, the oracle's serial walk run on every host core
+    by tmo_score_strips_mt (exact: strips chained through their entry states) against the histogram of the timed pass itself (`whole`).
+    Otherwise a prefix, against tm_score of the same prefix (`device_prefix`).  Returns the number of bytes verified."""
+    ncores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    if args.verify == -1 and ncores >= 32 and whole is not None:
+        exp_s, exp_t, exp_m, redone = orc.score_mt(text, ncores)
+        got_s, got_t, got_m = whole
+        n = int(text.size)
+        what = "whole buffer, %d threads (%d strips redone)" % (ncores, redone)
+    else:
+        n = min(int(text.size), (2 << 20) * max(1, min(ncores, 16)))
+        exp_s, exp_t, exp_m, _ = orc.score_mt(text[:n], ncores)
+        got_s, got_t, got_m = device_prefix(n)
+        what = "prefix, %d threads" % ncores
+    if not ((np.asarray(got_s) == exp_s).all() and int(got_t) == int(exp_t) and (np.asarray(got_m) == exp_m).all()):
+        raise SystemExit("bench.py: HIP score histogram differs from the oracle (%s) - number is INVALID" % what)
+    log("scoring pass verified against the oracle: %d bytes (%s), %.1f s" % (n, what, time.perf_counter() - t0))
+    return n
+
+
+def bench_in_process(args, img, kind, capcode, norm_flag, log):
+    """--in-process: N GPUs driven by ONE process through the library's own multi-device entry points (include/tokenmonster_hip.h "several
+    devices", tm_multi.hip) - what a Go host (go/tokenmonster_hip.go: OpenHipDevices / LoadHipAll / ScoreCandidateAll) runs; no torch, no
+    ranks.  tokenize: every device owns a resident batch of --mbytes MiB (weak scaling), one host thread per device steps it, all threads
+    start together and the clock stops when the last one is through.  score: ONE dataset of --mbytes MiB in total over all devices (strong
+    scaling), a step = tm_score_multi = ranges + exit-map chain + the RCCL all-reduce inside the library + the copy of the histogram to the host."""
+    import threading
+    import tokenmonster_amd as tm
+    from tokenmonster_amd import _native as N, synth, multi
+    ndev = args.gpus
+    have = N.lib.tm_device_count()
+    virt = os.environ.get("TM_VIRTUAL_DEVICES")
+    if ndev > have and not virt:
+        raise SystemExit("--gpus %d but only %d device(s) visible (TM_VIRTUAL_DEVICES=N puts N members on device 0: a code-path check, not a measurement)" % (ndev, have))
+    g = multi.Devices([0] * ndev) if virt else multi.Devices(list(range(ndev)))
+    vs = multi.VocabSet(g, img)
+    n_ids = vs.n_ids()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_bind import Oracle
+    base = {"n_gpus": ndev, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "unit": "GB/s"}
+    if args.workload == "score":
+        raw, roffs = synth.synth_corpus(kind, args.mbytes << 20, seed=0x434F5250 + 5)
+        raw_bytes = int(raw.size)
+        text, _ = synth.normalize_batch(raw, roffs, capcode, norm_flag)
+        del raw
+        ds = multi.DatasetSet(g, text)
+        for _ in range(args.warmup):
+            res = ds.score(vs)
+        ranks, why = g.rccl_ranks()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = ds.score(vs)
+        elapsed = time.perf_counter() - t0
+        verified = None
+        if args.verify != 0:
+            one = tm.Vocab(img)
+            dsh = C.c_void_p()
+            N.check(N.lib.tm_dataset_upload(N.ptr(np.ascontiguousarray(text)), int(text.size), C.byref(dsh)))
+            verified = verify_score(Oracle(img), text, lambda n: score_prefix(N, one, dsh, n_ids, n), res, args, log)
+            # ... and the multi-device histogram must be the single-device one, word for word
+            s1, t1, m1 = score_prefix(N, one, dsh, n_ids, int(text.size))
+            if not ((s1 == res[0]).all() and t1 == res[1] and (m1 == res[2]).all()):
+                raise SystemExit("bench.py: tm_score_multi differs from tm_score on one device - number is INVALID")
+            N.lib.tm_dataset_free(dsh)
+        out = dict(base, metric="GB/s raw UTF-8 scored, trainvocab candidate-scoring pass, 65536-id candidate vocabulary", value=round(raw_bytes * args.steps / elapsed / 1e9, 4),
+                   ms_per_step=round(elapsed / args.steps * 1e3, 3), scaling="strong",
+                   config={"workload": "%s vocabulary shape (synthetic, %d ids); ONE %d MiB synthetic mixed dataset in total, normalized on the host, resident in HBM "
+                                       "(1/N per device); step = tm_score_multi: ranges + halos, 80-state exit maps chained on the host, all-reduce(sum) of %d uint32, histogram to the host" % (
+                                           args.config, n_ids, args.mbytes, n_ids + 260),
+                           "raw_bytes_total": raw_bytes, "normalized_bytes_total": int(text.size), "tokens_in_text": int(res[1]),
+                           "parallelism": "in-process: one host thread per device inside libtokenmonster_hip.so, RCCL all-reduce inside tm_score_multi",
+                           "rccl_ranks": ranks, "rccl_note": why, "ranges": ds.ranges(), "virtual_devices": bool(virt), "verified_bytes_vs_oracle": verified},
+                   roofline={"bound": "hbm", "kernel": "whole scoring pass", "achieved": round(float(text.size) / (elapsed / args.steps) / 1e9, 3), "peak": HBM_PEAK_GBS * ndev,
+                             "unit": "GB/s", "frac": round(float(text.size) / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * ndev), 6), "traffic": None,
+                             "algorithmic_bytes_per_launch": float(text.size)}, cpu_baseline=None)
+        print(json.dumps(out), flush=True)
+        ds.close(); vs.close(); g.close()
+        return
+    # tokenize: a resident batch per device
+    shards = []
+    for i in range(ndev):
+        raw, roffs = synth.synth_corpus(kind, args.mbytes << 20, seed=0x434F5250 + 2 + 1000 * i)
+        b = C.c_void_p()
+        N.check(N.lib.tm_batch_create(vs.member(i), int(raw.size) + int(raw.size) // 8 + (2 << 20), roffs.size - 1, C.byref(b)))
+        N.check(N.lib.tm_batch_upload_raw(b, N.ptr(raw), N.ptr(roffs), roffs.size - 1))
+        shards.append((raw, roffs, b))
+    start = threading.Barrier(ndev + 1)
+    done = [0.0] * ndev
+    errs = []
+
+    def worker(i):
+        try:
+            b = shards[i][2]
+            for k in range(args.warmup + args.steps):
+                if k == args.warmup:
+                    N.check(N.lib.tm_batch_totals(b, None, None))      # (synchronizes the batch's stream)
+                    start.wait()
+                N.check(N.lib.tm_batch_normalize(b, None))
+                N.check(N.lib.tm_batch_run(b, None))
+            N.check(N.lib.tm_batch_totals(b, None, None))
+            done[i] = time.perf_counter()
+        except Exception as ex:     # noqa: BLE001
+            errs.append(ex)
+            start.abort()
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(ndev)]
+    for t in th:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    elapsed = max(done) - t0
+    all_raw = float(sum(int(r.size) for r, _, _ in shards))
+    # every document of every device against the reference runtime (RAW text through its Tokenize)
+    verified = 0
+    ntok_all = 0
+    from oracle_bind import Reference, have_ref
+    ref = Reference(img) if have_ref() and args.verify != 0 else None
+    for i, (raw, roffs, b) in enumerate(shards):
+        nt = C.c_uint64()
+        N.check(N.lib.tm_batch_totals(b, C.byref(nt), None))
+        ntok_all += int(nt.value)
+        if ref is not None:
+            nd = roffs.size - 1
+            ids = np.empty(max(int(nt.value), 1), dtype=np.uint32)
+            toff = np.empty(nd + 1, dtype=np.uint64)
+            miss = np.empty(max(nd, 1), dtype=np.uint32)
+            N.check(N.lib.tm_batch_download(b, N.ptr(ids), int(nt.value), N.ptr(toff), N.ptr(miss)))
+            ncores = os.cpu_count() or 1
+            d2 = nd if ncores >= 32 else max(1, min(nd, int(np.searchsorted(roffs, int(4e6 * ncores), side="right")) - 1))
+            bad, first_bad, _ = ref.verify_docs_mt(raw[: int(roffs[d2])], roffs[: d2 + 1], True, ncores, ids, toff[: d2 + 1], miss)
+            if bad:
+                raise SystemExit("bench.py: device %d: HIP ids differ from the reference runtime's in %d documents (first: %d) - number is INVALID" % (i, bad, first_bad))
+            verified += d2
+        N.lib.tm_batch_free(b)
+    out = dict(base, metric="GB/s raw UTF-8 tokenized, %s vocab" % args.config.split("-consistent")[0].split("-clean")[0].split("-balanced")[0],
+               value=round(all_raw * args.steps / elapsed / 1e9, 4), ms_per_step=round(elapsed / args.steps * 1e3, 3), scaling="weak",
+               config={"workload": "%s vocabulary shape (synthetic, %d ids), %d MiB raw synthetic mixed text per GPU; end to end: RAW UTF-8 resident in HBM -> normalize + "
+                                   "tokenize on the GPU -> uint32 ids in HBM" % (args.config, n_ids, args.mbytes),
+                       "parallelism": "in-process: one vocabulary replica (tm_vocab_load_all) and one resident batch per device, one host thread per device, no collective",
+                       "raw_bytes_total": int(all_raw), "tokens_total": ntok_all, "virtual_devices": bool(virt), "verified_docs_vs_reference": verified},
+               roofline=None, cpu_baseline=None)
+    print(json.dumps(out), flush=True)
+    vs.close(); g.close()
 
 
 def spawn_ranks(args):
@@ -310,6 +484,19 @@ def main():
         os.environ.setdefault("TM_TEST_HOOKS", "1")      # (the kernel-variant switches are inert unless the process is started this way)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.in_process:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--in-process is ONE process driving all GPUs: run it without a launcher")
+
+        def log0(msg):
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+        import __graft_entry__ as g0
+        g0.build()
+        from tokenmonster_amd import synth as synth0
+        if args.config is None:
+            args.config = "englishcode-32000-consistent" if args.workload == "tokenize" else "candidates-65536"
+        kind0, _, capcode0, norm0, _, _ = synth0.CONFIGS[args.config]
+        return bench_in_process(args, synth0.config_vocab(args.config), kind0, capcode0, norm0, log0)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -502,7 +689,8 @@ def main():
 
     # ---- verification of a sample against the oracle (rank 0; outside the timed region) -------------------
     verified = None
-    if rank == 0 and args.verify > 0:
+    dev_ids = None            # (ids, tok_offsets, missing) of the timed pass, on the host: what every check below compares with
+    if rank == 0 and args.verify != 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_bind import Oracle
         orc = Oracle(img)
@@ -511,9 +699,11 @@ def main():
         toff = np.empty(ndocs + 1, dtype=np.uint64)
         miss = np.empty(max(ndocs, 1), dtype=np.uint32)
         N.check(N.lib.tm_batch_download(batch, N.ptr(ids), cap, N.ptr(toff), N.ptr(miss)))
+        dev_ids = (ids, toff, miss)
         rng = np.random.default_rng(1)
         verified = 0
-        for d in rng.choice(ndocs, size=min(args.verify, ndocs), replace=False):
+        # a random sample against the oracle (our C restatement) in any case; ALL documents against the reference runtime below (cpu_baseline)
+        for d in rng.choice(ndocs, size=min(args.verify if args.verify > 0 else 256, ndocs), replace=False):
             exp, m = orc.tokenize(text[int(offs[d]):int(offs[d + 1])])
             got = ids[int(toff[d]):int(toff[d + 1])]
             if got.size != exp.size or (got != exp).any() or m != int(miss[d]):
@@ -553,15 +743,27 @@ def main():
     # wherever the scheduler put them last, and pinned memory on the far socket halves the PCIe rate
     h2h = None
     if rank == 0 and world == 1 and not args.hot_path_only and not args.no_host_to_host:
-        h2h = host_to_host(vocab, raw, roffs, text, offs, int(ntok.value), log, tm)
+        h2h = host_to_host(vocab, raw, roffs, text, offs, int(ntok.value), log, tm, steps=max(args.steps, 1), lanes=args.h2h_lanes, chunk=args.h2h_chunk_mib << 20,
+                           sweep=args.h2h_sweep)
+        blob, boff, enc = h2h.pop("_ids")
+        if dev_ids is not None and enc == 2:
+            # the host-to-host call must have produced the very ids of the resident pass, all of them
+            same = np.array_equal(np.frombuffer(blob, dtype=np.uint16), dev_ids[0][: int(ntok.value)].astype(np.uint16)) and np.array_equal(boff, dev_ids[1] * 2)
+            if not same:
+                raise SystemExit("bench.py: the host-to-host pipeline's ids differ from the resident pass's - number is INVALID")
+            h2h["ids_equal_resident_pass"] = True
+        del blob, boff
 
     cpu = None
+    verified_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
+        chk = dev_ids if args.verify == -1 else None
         if args.hot_path_only or not __import__("oracle_bind").have_ref():
-            cpu = cpu_baseline(img, text, offs, args.cpu_sample_mb, log)
+            cpu = cpu_baseline(img, text, offs, args.cpu_sample_mb, log, check=chk)
         else:
-            cpu = cpu_baseline(img, raw, roffs, args.cpu_sample_mb, log, raw_mode=True)
+            cpu = cpu_baseline(img, raw, roffs, args.cpu_sample_mb, log, raw_mode=True, check=chk)
+        verified_ref = cpu.pop("verified_docs_vs_reference", None)
 
     if rank == 0:
         value = all_raw * args.steps / elapsed / 1e9
@@ -578,7 +780,10 @@ def main():
                        "raw_bytes_per_gpu": raw_bytes, "normalized_bytes_per_gpu": int(text.size), "tokens_per_gpu": int(ntok.value),
                        "missing": int(nmiss.value), "normalized_GBps": round(all_norm * args.steps / elapsed / 1e9, 4),
                        "h2d_seconds": round(h2d_s, 3), "parallelism": "documents sharded by rank, no collective",
-                       "verified_docs_vs_oracle": verified},
+                       "verified_docs_vs_oracle": verified,
+                       # every document of the timed pass against the REFERENCE runtime (oracle/_ref: RAW text through its Tokenize, ids and `missing`
+                       # compared one by one): "all" when the host had the cores to do the whole corpus in the all-cores leg, else the count
+                       "verified_docs_vs_reference": ("all (%d)" % ndocs) if verified_ref == ndocs else verified_ref},
             "roofline": roofline,
             "roofline_valu": roofline_valu,
             "roofline_l2": roofline_l2,

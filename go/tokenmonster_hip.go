@@ -11,7 +11,9 @@
 //   the goroutine fan-out of tokenmonsterserver jobs 1 and 20              training/tokenmonsterserver.go:363-378, :773-787
 //   the scoring loop of the trainvocab worker                              training/trainvocab.go:925-1176
 //   (*Vocab).Decode over many id streams, the streaming *Decoder, Save        go/tokenmonster.go:445, :552-700, :2602
-// Every call borrows Go memory for its duration only (cgo pointer rule).  Any error means: use the existing CPU path.
+// Every call borrows Go memory for its duration only (cgo pointer rule).  An error means: use the existing CPU path - EXCEPT
+// ErrHipInput (TM_E_INPUT): the text / vocabulary pair is one the reference's own walk does not terminate on (a UTF-16 vocabulary
+// with one-byte keys beside the delete token), so falling back to vocab.tokenize would hang; report it to the caller instead.
 // Goroutines may call concurrently: each call takes a lane (stream + workspace) of the vocabulary and makes the
 // vocabulary's device current on whatever OS thread the goroutine is on.  The only per-thread state of the library is the text of
 // tm_last_error() and the 'current device' that tm_vocab_load / tm_dataset_upload use: the helper `locked` keeps a call and what
@@ -47,11 +49,17 @@ func locked(f func() C.int) (C.int, error) {
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
 	rc := f()
+	if rc == C.TM_E_INPUT {
+		return rc, ErrHipInput
+	}
 	if rc != C.TM_OK && rc != C.TM_E_NOSPACE {
 		return rc, errors.New("tokenmonster_hip: " + C.GoString(C.tm_last_error()))
 	}
 	return rc, nil
 }
+
+// ErrHipInput: do NOT retry on the CPU path (see the file comment).
+var ErrHipInput = errors.New("tokenmonster_hip: the walk does not advance on this text with this vocabulary (the reference loops forever on it)")
 
 // HipDeviceCount reports the usable gfx950 devices (0: keep using the CPU path).
 func HipDeviceCount() int { return int(C.tm_device_count()) }
@@ -367,10 +375,14 @@ func (hv *HipVocab) Save(filename string) error {
 // >= 128 bytes of the text that comes next (continues == true): Begin returns what the range does to each of the 80 entry states; the
 // ranks exchange those 80 bytes, rank r chains the maps of the ranks before it from state 0 to its own entry state, and Finish
 // completes the pass from there.  Summed over the ranks the histograms equal ONE walk over the whole dataset (trainvocab.go:909-922).
-func ScoreRangeBegin(cand *HipVocab, d *HipDataset, ownLen uint64, continues bool) (exits [80]byte, err error) {
+// textEndsInHalo: text follows the range, but fewer than 128 bytes of it - and the dataset holds all of them (continues = 2 in the C ABI).
+func ScoreRangeBegin(cand *HipVocab, d *HipDataset, ownLen uint64, continues bool, textEndsInHalo bool) (exits [80]byte, err error) {
 	c := C.int(0)
 	if continues {
 		c = 1
+		if textEndsInHalo {
+			c = 2
+		}
 	}
 	_, err = locked(func() C.int {
 		return C.tm_score_begin(cand.h, d.h, 0, C.uint64_t(ownLen), c, nil, (*C.uint8_t)(unsafe.Pointer(&exits[0])))
@@ -390,4 +402,134 @@ func ScoreRangeFinish(cand *HipVocab, d *HipDataset, entryState uint32) (scores 
 		return nil, 0, missing, err
 	}
 	return scores[:len(scores)-1], uint64(tit), missing, nil
+}
+
+// ---- every GPU of the node from ONE process (include/tokenmonster_hip.h, "several devices") ---------------------------------------
+// The reference's own parallelism is in-process: tokenmonsterserver fans a job's documents out over goroutines
+// (training/tokenmonsterserver.go:363-378), trainvocab starts `workers` goroutines over one dataset (training/trainvocab.go:1827-1829).
+// HipDevices is the handle of the node's GPUs; the library drives them itself (one host thread per device) and does the one collective of
+// the path - the all-reduce of the scoring pass's histogram - with RCCL inside tm_score_multi.  Nothing here needs LockOSThread beyond
+// locked(): the library makes the right device current on whatever thread it runs.
+type HipDevices struct{ h *C.tm_devices }
+type HipVocabSet struct{ h *C.tm_vocab_set }
+type HipDatasetSet struct{ h *C.tm_dataset_set }
+
+// OpenHipDevices(0) = every visible GPU.
+func OpenHipDevices(maxDevices int) (*HipDevices, error) {
+	var h *C.tm_devices
+	if _, err := locked(func() C.int { return C.tm_devices_open(C.int(maxDevices), &h) }); err != nil {
+		return nil, err
+	}
+	return &HipDevices{h}, nil
+}
+func (g *HipDevices) Count() int { return int(C.tm_devices_count(g.h)) }
+func (g *HipDevices) Close()     { C.tm_devices_close(g.h) }
+
+// LoadHipAll is LoadHip for every device of the handle: the tables are built once, the finished device block is replicated over xGMI.
+func LoadHipAll(g *HipDevices, filename string) (*HipVocabSet, error) {
+	b, err := os.ReadFile(filename)
+	if err != nil {
+		return nil, err
+	}
+	return NewHipVocabSet(g, b)
+}
+
+// BuildHipVocabImage turns a candidate's token list into the bytes of a .vocab file with the rules of trainvocab.go:548-907
+// (tm_build_vocab, include/tm_build.h): what ScoreCandidate does before it loads the tables.
+func BuildHipVocabImage(tokens [][]byte, capcode, charset uint8) ([]byte, error) {
+	blob, off64 := pack(tokens)
+	off := make([]uint32, len(off64))
+	for i, o := range off64 {
+		off[i] = uint32(o)
+	}
+	var img *C.uint8_t
+	var imgLen C.size_t
+	if _, err := locked(func() C.int {
+		return C.tm_build_vocab((*C.uint8_t)(unsafe.Pointer(&blob[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(tokens)), nil,
+			C.uint32_t(capcode), C.uint32_t(charset), 0, 5, 0, &img, &imgLen)
+	}); err != nil {
+		return nil, err
+	}
+	defer C.tm_free(unsafe.Pointer(img))
+	return C.GoBytes(unsafe.Pointer(img), C.int(imgLen)), nil
+}
+
+// NewHipVocabSet: the same from the bytes of a .vocab image (a candidate from BuildHipVocabImage in the trainvocab worker).
+func NewHipVocabSet(g *HipDevices, image []byte) (*HipVocabSet, error) {
+	var h *C.tm_vocab_set
+	if _, err := locked(func() C.int {
+		return C.tm_vocab_load_all(g.h, (*C.uint8_t)(unsafe.Pointer(&image[0])), C.size_t(len(image)), &h)
+	}); err != nil {
+		return nil, err
+	}
+	return &HipVocabSet{h}, nil
+}
+func (s *HipVocabSet) Close() { C.tm_vocab_set_free(s.h) }
+
+// Member(0) is a full vocabulary (Decode, NewDecoder, Save); the handle stays owned by the set.
+func (s *HipVocabSet) Member(i int) *HipVocab {
+	h := (*C.tm_vocab)(unsafe.Pointer(C.tm_vocab_set_member(s.h, C.int(i))))
+	return &HipVocab{h: h, len: int(C.tm_vocab_size(h))}
+}
+
+// TokenizeSerializedBatch over every GPU: same arguments and results as (*HipVocab).TokenizeSerializedBatch - server job 1 does not change.
+func (s *HipVocabSet) TokenizeSerializedBatch(docs [][]byte, encodingLength uint8) ([][]byte, []int, uint8, error) {
+	text, offsets := pack(docs)
+	n := len(docs)
+	capBytes := uint64(len(text))*2 + uint64(8*n) + 64
+	byteOff := make([]uint64, n+1)
+	missing := make([]uint32, n+1)
+	var used C.uint32_t
+	for {
+		out := make([]byte, capBytes+1)
+		rc, err := locked(func() C.int {
+			return C.tm_tokenize_pipeline_multi(s.h, (*C.uint8_t)(unsafe.Pointer(&text[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])), C.uint32_t(n), 1,
+				C.uint32_t(encodingLength), 0, 0, (*C.uint8_t)(unsafe.Pointer(&out[0])), C.uint64_t(capBytes), (*C.uint64_t)(unsafe.Pointer(&byteOff[0])),
+				(*C.uint32_t)(unsafe.Pointer(&missing[0])), &used, nil)
+		})
+		if err != nil {
+			return nil, nil, 0, err
+		}
+		if rc == C.TM_E_NOSPACE {
+			capBytes = byteOff[n]
+			continue
+		}
+		res := make([][]byte, n)
+		miss := make([]int, n)
+		for i := 0; i < n; i++ {
+			res[i] = out[byteOff[i]:byteOff[i+1]]
+			miss[i] = int(missing[i])
+		}
+		return res, miss, uint8(used), nil
+	}
+}
+
+// UploadHipDatasetSharded: once per training run, after `filedata = normalize(ReadFile(dataset))` (trainvocab.go:1660-1665): one byte
+// range (+ 128 bytes of halo) per GPU.
+func UploadHipDatasetSharded(g *HipDevices, normalized []byte) (*HipDatasetSet, error) {
+	var h *C.tm_dataset_set
+	var p *C.uint8_t
+	if len(normalized) > 0 {
+		p = (*C.uint8_t)(unsafe.Pointer(&normalized[0]))
+	}
+	if _, err := locked(func() C.int { return C.tm_dataset_upload_sharded(g.h, p, C.uint64_t(len(normalized)), &h) }); err != nil {
+		return nil, err
+	}
+	return &HipDatasetSet{h}, nil
+}
+func (d *HipDatasetSet) Close() { C.tm_dataset_set_free(d.h) }
+
+// ScoreCandidateAll replaces the worker's inner loop (trainvocab.go:925-1176) for the post-"midway" mode (:909-922: the dataset as ONE
+// strip) on every GPU of the node: scores[id] == scores[index].V of :1109-1162 summed over the whole dataset, bit-identical to ScoreCandidate
+// on one GPU.  The histogram all-reduce is RCCL inside the call.
+func ScoreCandidateAll(cand *HipVocabSet, d *HipDatasetSet) (scores []uint32, tokensInText uint64, missing [32]byte, err error) {
+	nIds := int(C.tm_vocab_n_ids(C.tm_vocab_set_member(cand.h, 0)))
+	scores = make([]uint32, nIds+1)
+	var tit C.uint64_t
+	if _, err = locked(func() C.int {
+		return C.tm_score_multi(cand.h, d.h, (*C.uint32_t)(unsafe.Pointer(&scores[0])), &tit, (*C.uint8_t)(unsafe.Pointer(&missing[0])))
+	}); err != nil {
+		return nil, 0, missing, err
+	}
+	return scores[:nIds], uint64(tit), missing, nil
 }

@@ -202,4 +202,53 @@ long long tmref_tokenize_docs_mt(void* v, const std::uint8_t* text, const std::u
   }
 }
 
+// The same fan-out as a CHECKER (bench.py's verification of the whole corpus, outside the timed region): every document is tokenized by the
+// reference and its ids and `missing` are compared with what the device produced (ids[toff[d] .. toff[d+1]), missing[d]).  Returns the
+// number of documents that differ (0 = all equal), -1 on failure; *first_bad = the lowest differing document; *ntok = the reference's
+// token total.  Nothing is restated here either: the comparison is memcmp.
+long long tmref_verify_docs_mt(void* v, const std::uint8_t* text, const std::uint64_t* offsets, std::uint32_t ndocs, int raw, std::uint32_t threads,
+                               const std::uint32_t* ids, const std::uint64_t* toff, const std::uint32_t* missing, std::uint32_t* first_bad,
+                               long long* ntok) {
+  try {
+    auto* vocab = static_cast<Vocab*>(v);
+    if (threads == 0) threads = 1;
+    std::atomic<std::uint32_t> next{0}, worst{0xFFFFFFFFu};
+    std::atomic<long long> total{0}, bad{0};
+    std::atomic<bool> failed{false};
+    auto work = [&]() {
+      long long mine = 0, mybad = 0;
+      std::uint32_t myworst = 0xFFFFFFFFu;
+      try {
+        for (;;) {
+          const std::uint32_t base = next.fetch_add(16);
+          if (base >= ndocs) break;
+          for (std::uint32_t d = base; d < ndocs && d < base + 16; d++) {
+            auto doc = sp(text + offsets[d], (std::size_t)(offsets[d + 1] - offsets[d]));
+            const auto r = raw ? vocab->tokenize(doc) : vocab->tokenize_normalized(doc);
+            mine += (long long)r.tokens.size();
+            const std::uint64_t n = toff[d + 1] - toff[d];
+            const bool same = n == r.tokens.size() && (n == 0 || std::memcmp(ids + toff[d], r.tokens.data(), n * 4) == 0) &&
+                              (!missing || (long long)missing[d] == (long long)r.missing);
+            if (!same) { mybad++; if (d < myworst) myworst = d; }
+          }
+        }
+      } catch (...) { failed = true; }
+      total += mine; bad += mybad;
+      std::uint32_t w = worst.load();
+      while (myworst < w && !worst.compare_exchange_weak(w, myworst)) {}
+    };
+    std::vector<std::thread> th;
+    for (std::uint32_t t = 1; t < threads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (failed) { g_err = "a worker thread failed"; return -1; }
+    if (first_bad) *first_bad = worst.load();
+    if (ntok) *ntok = total.load();
+    return bad.load();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 }  // extern "C"

@@ -145,6 +145,8 @@ typedef struct {
   int mode;
   uint32_t* out; size_t cap; long long ntok;      /* mode 0/1 */
   uint32_t* scores; uint64_t tokens_in_text; uint8_t* missing_set; /* mode 2 */
+  int negate;                /* mode 2: take the contributions back instead of adding them (tmo_score_strips_mt re-walks a strip it had entered in the wrong state) */
+  int64_t* missing_cnt;      /* mode 2: per-byte counters instead of the bit set (bits cannot be taken back) */
 } sink_t;
 
 static void emit(const tmo_vocab* v, sink_t* s, uint32_t id, int adv, int with_delete) {
@@ -155,6 +157,12 @@ static void emit(const tmo_vocab* v, sink_t* s, uint32_t id, int adv, int with_d
   } else if (s->mode == 1) {
     s->ntok++;                        /* go/tokenmonster.go:1505-1521: +1 even for b-branches */
   } else {
+    if (s->negate) {
+      s->scores[id] -= (uint32_t)adv;
+      if (with_delete) s->scores[v->delete_id]--;
+      s->tokens_in_text -= with_delete ? 2 : 1;
+      return;
+    }
     s->scores[id] += (uint32_t)adv;   /* trainvocab.go:1109..1162 */
     if (with_delete) s->scores[v->delete_id]++;   /* :1134,1143,1152 (Q4: we use the ID) */
     s->tokens_in_text += with_delete ? 2 : 1;
@@ -166,13 +174,11 @@ static void emit(const tmo_vocab* v, sink_t* s, uint32_t id, int adv, int with_d
  * pass rests on: the walk's whole state at a token boundary is (i, forwardDelete) — index/length are recomputed from the text — so a
  * range of the whole-buffer walk (training/trainvocab.go:909-922) can be entered at start with fd0 and left where the first token
  * begins at or behind `stop`.  *exit_state = 2 * (i - stop) + forwardDelete at that point. */
-static long long walk_range(const tmo_vocab* v, const uint8_t* src, size_t n, size_t start, int fd0, size_t stop, sink_t* s, uint32_t* exit_state) {
+/* `data` holds n bytes of text followed by the pad byte 0 (go :1038-1046; tokenmonster.cpp:1726) */
+static long long walk_range_padded(const tmo_vocab* v, const uint8_t* data, size_t n, size_t start, int fd0, size_t stop, sink_t* s, uint32_t* exit_state) {
   long long missing = 0;
   if (exit_state) *exit_state = 0;
   if (v->max_len == 0) return 0;                  /* go :960 */
-  uint8_t* data = (uint8_t*)malloc(n + 1);
-  memcpy(data, src, n);
-  data[n] = 0;                                    /* go :1038-1046, pad 0 (tokenmonster.cpp:1726) */
   const int lenData = (int)n, maxlen = (int)v->max_len;
   const int off = v->charset == 2 ? 2 : 1;        /* go :1031-1034 */
   const int maxlen_sp = maxlen - off;             /* go :1036 */
@@ -201,7 +207,11 @@ static long long walk_range(const tmo_vocab* v, const uint8_t* src, size_t n, si
     int rem = lenData - i;
     if (!tmo_longest(v, data + i, (size_t)(rem < maxlen ? rem : maxlen), &index, &length)) {
       /* go :1269-1276 */
-      if (s->mode == 2) { s->tokens_in_text++; if (s->missing_set) s->missing_set[data[i] >> 3] |= (uint8_t)(1u << (data[i] & 7)); }
+      if (s->mode == 2) {
+        if (s->negate) s->tokens_in_text--; else s->tokens_in_text++;
+        if (s->missing_cnt) s->missing_cnt[data[i]] += s->negate ? -1 : 1;
+        else if (s->missing_set) s->missing_set[data[i] >> 3] |= (uint8_t)(1u << (data[i] & 7));
+      }
       else if (v->unk != TMO_NONE) { if (s->mode == 0) { if ((size_t)s->ntok < s->cap) s->out[s->ntok] = v->unk; } s->ntok++; }
       i++; missing++; fd = 0; g_stats[8]++;
       continue;
@@ -274,6 +284,14 @@ static long long walk_range(const tmo_vocab* v, const uint8_t* src, size_t n, si
     i += len; fd = 0;
   }
   if (exit_state) *exit_state = (uint32_t)(2 * (i - stopi) + fd);
+  return missing;
+}
+
+static long long walk_range(const tmo_vocab* v, const uint8_t* src, size_t n, size_t start, int fd0, size_t stop, sink_t* s, uint32_t* exit_state) {
+  uint8_t* data = (uint8_t*)malloc(n + 1);
+  memcpy(data, src, n);
+  data[n] = 0;                                    /* go :1038-1046, pad 0 (tokenmonster.cpp:1726) */
+  const long long missing = walk_range_padded(v, data, n, start, fd0, stop, s, exit_state);
   free(data);
   return missing;
 }
@@ -319,4 +337,91 @@ long long tmo_decode_raw(const tmo_vocab* v, const uint32_t* toks, size_t n, uin
     pos += l;
   }
   return (long long)pos;
+}
+
+/* ---- the whole-buffer scoring walk on many threads, EXACT (bench.py's verification of the scoring pass at full size) -------------------
+ * training/trainvocab.go:909-922 walks the dataset as ONE strip: serial.  The walk's whole state at a token boundary is (i, forwardDelete)
+ * (walk_range above), so the text is cut into strips; the entry state of a strip is first GUESSED from a short walk that starts `warm`
+ * bytes before it (walks from different states run into each other within a few tokens), every strip is walked from its guess on the
+ * pool, and then the chain exit(k) == entry(k + 1) is checked strip by strip from the front: a strip whose guess was wrong is taken back
+ * (the same walk with negated contributions) and walked again from the true state.  What is left satisfies entry(0) = (0, 0),
+ * entry(k + 1) = exit(k) for every k - the serial walk, whatever the guesses were.  Returns the number of strips that had to be redone. */
+#include <pthread.h>
+typedef struct {
+  const tmo_vocab* v; const uint8_t* data; size_t n, strip, nstrips, warm;
+  uint32_t* entry; uint32_t* exit_; size_t next; pthread_mutex_t mu;
+  uint32_t n_rev;
+} strips_job;
+typedef struct { strips_job* job; uint32_t* scores; uint64_t tokens; int64_t missing[256]; } strips_worker;
+
+static void strip_walk(const strips_job* J, size_t k, uint32_t entry, sink_t* s, uint32_t* exit_state) {
+  const size_t a = k * J->strip, b = a + J->strip < J->n ? a + J->strip : J->n;
+  walk_range_padded(J->v, J->data, J->n, a + (entry >> 1), (int)(entry & 1u), b, s, exit_state);
+}
+static void* strips_thread(void* arg) {
+  strips_worker* W = (strips_worker*)arg;
+  strips_job* J = W->job;
+  for (;;) {
+    pthread_mutex_lock(&J->mu);
+    const size_t k = J->next++;
+    pthread_mutex_unlock(&J->mu);
+    if (k >= J->nstrips) break;
+    uint32_t e = 0;
+    if (k > 0 && J->warm > 0) {
+      const size_t a = k * J->strip, from = a > J->warm ? a - J->warm : 0;
+      sink_t nul; memset(&nul, 0, sizeof nul); nul.mode = 1;
+      walk_range_padded(J->v, J->data, J->n, from, 0, a, &nul, &e);
+    }
+    J->entry[k] = e;
+    sink_t s; memset(&s, 0, sizeof s); s.mode = 2; s.scores = W->scores; s.missing_cnt = W->missing;
+    strip_walk(J, k, e, &s, &J->exit_[k]);
+    W->tokens += s.tokens_in_text;
+  }
+  return NULL;
+}
+long long tmo_score_strips_mt(const tmo_vocab* v, const uint8_t* src, size_t n, size_t strip, size_t warm, uint32_t threads, uint32_t* scores,
+                              uint64_t* tokens_in_text, uint8_t missing_set[32]) {
+  if (strip < 4096) strip = 4096;
+  if (threads == 0) threads = 1;
+  strips_job J; memset(&J, 0, sizeof J);
+  uint8_t* data = (uint8_t*)malloc(n + 1);
+  memcpy(data, src, n); data[n] = 0;
+  J.v = v; J.data = data; J.n = n; J.strip = strip; J.nstrips = (n + strip - 1) / strip; J.warm = warm; J.n_rev = v->n_reverse;
+  if (J.nstrips == 0) J.nstrips = 1;
+  J.entry = (uint32_t*)calloc(J.nstrips, 4); J.exit_ = (uint32_t*)calloc(J.nstrips, 4);
+  pthread_mutex_init(&J.mu, NULL);
+  if (threads > J.nstrips) threads = (uint32_t)J.nstrips;
+  strips_worker* W = (strips_worker*)calloc(threads, sizeof *W);
+  pthread_t* th = (pthread_t*)calloc(threads, sizeof *th);
+  for (uint32_t t = 0; t < threads; t++) { W[t].job = &J; W[t].scores = (uint32_t*)calloc(v->n_reverse ? v->n_reverse : 1, 4); }
+  for (uint32_t t = 1; t < threads; t++) pthread_create(&th[t], NULL, strips_thread, &W[t]);
+  strips_thread(&W[0]);
+  for (uint32_t t = 1; t < threads; t++) pthread_join(th[t], NULL);
+  /* the chain, from the front: a wrong guess is taken back and walked again */
+  long long redone = 0;
+  uint32_t e = 0;
+  for (size_t k = 0; k < J.nstrips; k++) {
+    if (J.entry[k] != e) {
+      sink_t s; memset(&s, 0, sizeof s); s.mode = 2; s.scores = W[0].scores; s.missing_cnt = W[0].missing;
+      s.negate = 1; strip_walk(&J, k, J.entry[k], &s, NULL);
+      s.negate = 0; strip_walk(&J, k, e, &s, &J.exit_[k]);
+      W[0].tokens += s.tokens_in_text;           /* (wraps through zero and back: unsigned arithmetic) */
+      J.entry[k] = e;
+      redone++;
+    }
+    e = J.exit_[k];
+  }
+  uint64_t tok = 0;
+  int64_t miss[256]; memset(miss, 0, sizeof miss);
+  for (uint32_t t = 0; t < threads; t++) {
+    for (uint32_t i = 0; i < v->n_reverse; i++) scores[i] += W[t].scores[i];
+    tok += W[t].tokens;
+    for (int b = 0; b < 256; b++) miss[b] += W[t].missing[b];
+    free(W[t].scores);
+  }
+  if (tokens_in_text) *tokens_in_text += tok;
+  if (missing_set) for (int b = 0; b < 256; b++) if (miss[b] > 0) missing_set[b >> 3] |= (uint8_t)(1u << (b & 7));
+  pthread_mutex_destroy(&J.mu);
+  free(W); free(th); free(J.entry); free(J.exit_); free(data);
+  return redone;
 }

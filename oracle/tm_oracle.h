@@ -50,6 +50,12 @@ void tmo_score(const tmo_vocab* v, const uint8_t* data, size_t n, uint32_t* scor
 void tmo_score_range(const tmo_vocab* v, const uint8_t* data, size_t n, size_t start, int fd0, size_t stop, uint32_t* scores,
                      uint64_t* tokens_in_text, uint8_t missing_set[32], uint32_t* exit_state);
 
+/* tmo_score of the whole text (ONE strip, trainvocab.go:909-922) computed on `threads` threads, exactly: strips of `strip` bytes entered in
+ * states guessed from a walk that starts `warm` bytes before them (0: guess state 0), then chained from the front and redone where a guess
+ * was wrong (tm_oracle.c).  Accumulates like tmo_score; returns the number of strips that had to be redone. */
+long long tmo_score_strips_mt(const tmo_vocab* v, const uint8_t* data, size_t n, size_t strip, size_t warm, uint32_t threads, uint32_t* scores,
+                              uint64_t* tokens_in_text, uint8_t missing_set[32]);
+
 /* go/tokenmonster.go:445-...(decode of raw token bytes, no capcode decoding): concatenates reverse[id] */
 long long tmo_decode_raw(const tmo_vocab* v, const uint32_t* toks, size_t n, uint8_t* out, size_t cap);
 

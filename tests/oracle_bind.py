@@ -109,6 +109,18 @@ class Oracle:
                                ms.ctypes.data, C.byref(ex))
         return scores, tit.value, ms, ex.value
 
+    def score_mt(self, data, threads, strip=1 << 20, warm=1024):
+        """tmo_score of the whole text on `threads` threads, exact (strips entered in guessed states, chained and redone where a guess was
+        wrong) -> (scores, tokens_in_text, missing_set, strips redone)"""
+        d = _u8(data)
+        self.L.tmo_score_strips_mt.restype = C.c_longlong
+        self.L.tmo_score_strips_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+        scores = np.zeros(self.n_ids(), dtype=np.uint32)
+        tit = C.c_uint64(0)
+        ms = np.zeros(32, dtype=np.uint8)
+        redone = self.L.tmo_score_strips_mt(self.h, d.ctypes.data, d.size, strip, warm, threads, scores.ctypes.data, C.byref(tit), ms.ctypes.data)
+        return scores, tit.value, ms, int(redone)
+
     def decode_raw(self, toks):
         t = np.ascontiguousarray(toks, dtype=np.uint32)
         cap = 40 * t.size + 8
@@ -210,6 +222,24 @@ class Reference:
         if n < 0:
             raise RuntimeError("reference tokenize (multi-threaded) failed")
         return int(n)
+
+    def verify_docs_mt(self, text, offsets, raw, threads, ids, toff, missing=None):
+        """every document through the reference on `threads` threads, its ids (and `missing`) compared with ids[toff[d]:toff[d+1]]
+        -> (documents that differ, lowest differing document or None, the reference's token total)"""
+        t = _u8(text)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        i = np.ascontiguousarray(ids, dtype=np.uint32)
+        f = np.ascontiguousarray(toff, dtype=np.uint64)
+        m = None if missing is None else np.ascontiguousarray(missing, dtype=np.uint32)
+        self.L.tmref_verify_docs_mt.restype = C.c_longlong
+        self.L.tmref_verify_docs_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.POINTER(C.c_uint32), C.POINTER(C.c_longlong)]
+        fb, nt = C.c_uint32(), C.c_longlong()
+        bad = self.L.tmref_verify_docs_mt(self.h, t.ctypes.data, o.ctypes.data, o.size - 1, 1 if raw else 0, threads, i.ctypes.data, f.ctypes.data,
+                                          None if m is None else m.ctypes.data, C.byref(fb), C.byref(nt))
+        if bad < 0:
+            raise RuntimeError("reference verification (multi-threaded) failed")
+        return int(bad), (None if bad == 0 else int(fb.value)), int(nt.value)
 
     def decode(self, toks):
         """Vocab::decode (tokenmonster.cpp:1404-1425): decode_raw + capcode / charset post-processing"""

@@ -156,6 +156,9 @@ static bool rccl_ready(tm_devices* g) {
   Rccl& r = rccl();
   if (!r.ok) { g->rccl_note = "librccl.so.1 could not be loaded"; return false; }
   g->comm.assign(n, nullptr);
+  // (RCCL looks at the runtime's sticky "last error" between its own calls: one left behind by an unrelated earlier call - a probe of a
+  // pageable pointer, say - would be reported as RCCL's failure)
+  for (int i = 0; i < n; i++) { (void)hipSetDevice(g->dev[i]); (void)hipGetLastError(); }
   const ncclResult_t rc = r.CommInitAll(g->comm.data(), n, g->dev.data());
   if (rc != ncclSuccess) { g->rccl_note = std::string("ncclCommInitAll: ") + r.GetErrorString(rc); g->comm.clear(); return false; }
   g->rccl_ranks = n;
@@ -357,6 +360,7 @@ int tm_score_multi(const tm_vocab_set* vs, tm_dataset_set* ds, uint32_t* scores,
 #ifndef TM_EMU
     if (use_rccl) {
       // in place, on the member's own stream behind its histogram kernel; the members call from their own threads (RCCL's one-thread-per-device mode)
+      (void)hipGetLastError();
       const ncclResult_t nr = rccl().AllReduce(d->d_hist, d->d_hist, (size_t)words, ncclUint32, ncclSum, g->comm[i], st);
       if (nr != ncclSuccess) r = set_error(TM_E_HIP, "ncclAllReduce: %s", rccl().GetErrorString(nr));
     } else
