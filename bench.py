@@ -286,6 +286,7 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
                        "raw_bytes_total": int(all_raw), "normalized_bytes_total": int(all_norm), "tokens_in_text": int(tokens),
                        "normalized_GBps": round(all_norm * args.steps / elapsed / 1e9, 4),
                        "parallelism": "one whole-buffer walk cut into a byte range per rank (halo + all-gather of 80 exit states per rank), RCCL all-reduce of the score histogram",
+                       "rccl_ranks": dist.get_world_size() if world > 1 else 0,
                        "verified_bytes_vs_oracle": ("all (%d)" % verified) if verified == int(text.size) else verified},
             "roofline": {"bound": "hbm", "kernel": "whole scoring pass of one rank", "achieved": round(alg / (elapsed / args.steps) / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
@@ -780,6 +781,7 @@ def main():
                        "raw_bytes_per_gpu": raw_bytes, "normalized_bytes_per_gpu": int(text.size), "tokens_per_gpu": int(ntok.value),
                        "missing": int(nmiss.value), "normalized_GBps": round(all_norm * args.steps / elapsed / 1e9, 4),
                        "h2d_seconds": round(h2d_s, 3), "parallelism": "documents sharded by rank, no collective",
+                       "rccl_ranks": dist.get_world_size() if world > 1 else 0,
                        "verified_docs_vs_oracle": verified,
                        # every document of the timed pass against the REFERENCE runtime (oracle/_ref: RAW text through its Tokenize, ids and `missing`
                        # compared one by one): "all" when the host had the cores to do the whole corpus in the all-cores leg, else the count

@@ -235,6 +235,30 @@ def test_score_histogram_full_candidate_shape():
     assert (got_s == es).all() and got_t == et and (got_m == em).all()
 
 
+@pytest.mark.parametrize("shape", ["micro-capcode2", "micro-capcode0-unk", "englishcode-8000"])
+def test_score_histogram_equals_the_replay_of_the_reference_ids(shape):
+    """the reference-anchored check of the scoring accumulation (training/trainvocab.go:1105-1174): the reference runtime has no scoring
+    mode, but the histogram follows from the ids IT emits for the same text once every id is given back the bytes it covered
+    (tests/replay.py: which token - from the reference; how many bytes - from the text and the key set).  tm_score must equal that."""
+    from oracle_bind import Reference, have_ref
+    from replay import histogram_from_ids
+    if not have_ref():
+        pytest.skip("oracle/_ref not built")
+    if shape == "englishcode-8000":
+        img = synth.synth_vocab(synth.ENGLISHCODE, 8000, capcode=2, norm_flag=1, level=5, seed=0x544D0005)
+        raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 300_000, seed=45)
+        data, _ = synth.normalize_batch(raw, offs, 2, 1)
+    else:
+        capcode = 2 if shape == "micro-capcode2" else 0
+        rng = np.random.default_rng(4100 + capcode)
+        img = synth.build_vocab(fuzz_vocab_tokens(rng, capcode, 150), capcode=capcode, charset=1, with_unk=(capcode == 0))
+        data = np.frombuffer(fuzz_text(rng, capcode, 120_000), dtype=np.uint8)
+    ids, missing = Reference(img).tokenize_normalized(data)
+    exp_s, exp_t, exp_m = histogram_from_ids(img, data, ids, missing)
+    got_s, got_t, got_m = _score(tm.Vocab(img), data)
+    assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
+
+
 @pytest.mark.parametrize("shape", ["micro", "candidates"])
 def test_score_ranges_of_one_walk(shape):
     """tm_score_begin / tm_score_finish: a dataset cut into byte ranges, each uploaded with a halo of the following text and scored as a

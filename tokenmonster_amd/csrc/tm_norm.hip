@@ -492,13 +492,23 @@ __global__ void k_norm_bad_docs(const uint8_t* __restrict__ need_host, uint32_t 
   if (d < ndocs && need_host[d]) fb_ids[atomicAdd(&ninfo[0], 1ull)] = d;
 }
 
-// pack the slabs: piece k's bytes go to out[piece_off[k] ..)
+// the two kernels above in one launch (thread k looks at piece k and at document k): the one-sync path of tm_batch_normalize
+__global__ void k_norm_bad(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, uint64_t npieces, uint32_t ndocs,
+                           uint32_t* __restrict__ piece_len, unsigned long long* __restrict__ ninfo, uint32_t* __restrict__ fb_ids) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < npieces && need_host[piece_doc[k]]) piece_len[k] = 0;
+  if (k < ndocs && need_host[k]) fb_ids[atomicAdd(&ninfo[0], 1ull)] = (uint32_t)k;
+}
+
+// pack the slabs: piece k's bytes go to out[piece_off[k] ..); a piece that would end behind `cap` bytes is left out (the caller - which
+// has not seen the total yet when it launches this - then reports TM_E_LIMIT)
 __global__ __launch_bounds__(256) void k_norm_compact(const uint8_t* __restrict__ slab, const uint32_t* __restrict__ piece_len,
-                                                      const uint64_t* __restrict__ piece_off, uint64_t npieces, uint8_t* __restrict__ out) {
+                                                      const uint64_t* __restrict__ piece_off, uint64_t npieces, uint8_t* __restrict__ out, uint64_t cap) {
   const int lane = threadIdx.x & 63;
   const uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (k >= npieces) return;
   const uint32_t len = piece_len[k];
+  if (piece_off[k] + len > cap) return;
   const uint8_t* src = slab + k * (uint64_t)SLAB;
   uint8_t* dst = out + piece_off[k];
   for (uint32_t i = (uint32_t)lane * 16u; i < len; i += 64u * 16u) {
@@ -515,6 +525,21 @@ __global__ void k_norm_ranges(const uint64_t* __restrict__ piece_off, const uint
   if (need_host[d]) return;                      // (k_place_fallback writes the range of a host-normalized document, possibly at the same time)
   nbegin[d] = piece_off[doc_piece_start[d]];
   nend[d] = piece_off[doc_piece_start[d + 1]];
+}
+// k_norm_ranges and k_norm_info in one launch, for a batch without host-normalized documents (a document that needs the host counts for
+// nothing here: the caller runs k_norm_info again once those are placed)
+__global__ void k_norm_ranges_info(const uint64_t* __restrict__ piece_off, const uint64_t* __restrict__ doc_piece_start, const uint8_t* __restrict__ need_host,
+                                   uint32_t ndocs, uint64_t* __restrict__ nbegin, uint64_t* __restrict__ nend, unsigned long long* __restrict__ ninfo, uint32_t long_segs) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t nseg = 0;
+  if (d < ndocs && !need_host[d]) {
+    const uint64_t a = piece_off[doc_piece_start[d]], b = piece_off[doc_piece_start[d + 1]];
+    nbegin[d] = a; nend[d] = b;
+    nseg = (b - a + SEG - 1) / SEG;
+    if (nseg > long_segs) atomicAdd(&ninfo[1], 1ull);
+  }
+  for (int o = 32; o > 0; o >>= 1) nseg += __shfl_xor(nseg, o);
+  if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&ninfo[2], (unsigned long long)nseg);
 }
 __global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t* __restrict__ nend, uint32_t ndocs, unsigned long long* __restrict__ ninfo,
                             uint32_t long_segs) {
@@ -675,17 +700,41 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   // capitals across a piece boundary) or whose output outgrows its slab sends the batch through the exact path after all: summaries of the
   // pieces, carries per document, then the same emit kernel with the carries given.
   bool fast = np > 0 && capcode == 2 && normalize_on_device(capcode, norm_flag) && !(tm_debug_flags(-1) & 256);
+  // ... and ONE trip to the host: the whole device part — the pass, the scan of the piece lengths, the compaction, the documents' ranges
+  // and segment counts — is enqueued before anything comes back, and what comes back is everything at once: how many documents need the
+  // host normalizer, whether a piece was undecided or outgrew its slab, the normalized size, the segment and long-document counts.  (A
+  // chunk of the host-to-host pipeline used to wait for the device three times here; with four lanes' launches queueing on the runtime's
+  // lock every wait was also a gap in its stream.)  `pre`: the device part is done and valid.
+  bool pre = false;
+  uint64_t pre_bytes = 0;
   if (fast) {
     (void)hipMemsetAsync(b->d_need_host, 0, nd, st);
     TM_LAUNCH(k_norm_emit2<false>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
                                                b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
-    TM_LAUNCH(k_norm_bad_pieces, (uint32_t)((np + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, np, b->d_piece_len);
-    TM_LAUNCH(k_norm_bad_docs, (nd + 255) / 256, 256, 0, st, b->d_need_host, nd, ninfo, b->d_fb_ids);
-    { int rc = small_d2h(b, h_info, ninfo, 40, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
-    if (h_info[3] != 0 || h_info[4] != 0) {
+    TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
+    scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
+    TM_LAUNCH(k_norm_compact, pgrid, 256, 0, st, b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text, b->max_bytes);
+    TM_LAUNCH(k_norm_ranges_info, (nd + 255) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend, ninfo, long_segs());
+    { int rc = small_d2h(b, h_info, ninfo, 40, st); if (rc == TM_OK) rc = small_d2h(b, &pre_bytes, b->d_totals + 2, 8, st); if (rc == TM_OK) rc = small_sync(b, st);
+      if (rc != TM_OK) return rc; }
+    if (h_info[3] != 0 || h_info[4] != 0) {        // a piece whose margins could not tell, or one that outgrew its slab: the exact path, from the start
       fast = false;
       (void)hipMemsetAsync(ninfo, 0, 64, st);
-    }
+    } else if (h_info[0] == 0) {                    // the usual case: every document was normalized on the device
+      if (pre_bytes > b->max_bytes)
+        return set_error(TM_E_LIMIT, "normalized text needs %llu bytes, workspace sized for %llu", (unsigned long long)pre_bytes, (unsigned long long)b->max_bytes);
+      b->nbytes = pre_bytes;
+      b->nseg = h_info[2];
+      int rc = TM_OK;
+      if (h_info[1] > 0) {
+        std::vector<uint64_t> hb(nd), he(nd);
+        if ((e = hipMemcpyAsync(hb.data(), b->d_nbegin, (size_t)nd * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+            (e = hipMemcpyAsync(he.data(), b->d_nend, (size_t)nd * 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "D2H ranges");
+        rc = build_groups(b, hb.data(), he.data(), nd, st);
+      }
+      if (trace) fprintf(stderr, "[tm_batch_normalize] one trip: %.2f ms\n", now() - t0);
+      return rc;
+    } else pre = true;                              // some documents need the host normalizer: fetch, normalize, place them behind the device part below
   }
   if (!fast) {
     if (np > 0) TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_two, b->d_piece_sum);
@@ -705,7 +754,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   else if (!fast && np > 0)           // capcode 0, or debug bit 8: the per-lane version of the rules
     TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                           b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
-  scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
+  if (!pre) scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
   if (nf > 0) {
     // ... while the documents it cannot normalize (other non-ASCII content: NFD / Unicode case need ICU) are fetched on a
     // second stream, so that the fetch does not hold up the pass above
@@ -766,9 +815,9 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     { int rc = small_h2d(b, b->d_fb_noff, noff.data(), noff.size() * 8, sx); if (rc != TM_OK) return rc; }
     TM_LAUNCH(k_place_fallback, (uint32_t)ids.size(), 256, 0, sx, hnorm, b->d_fb_noff, b->d_fb_ids, (uint32_t)ids.size(), gpu_bytes, b->d_text, b->d_nbegin, b->d_nend);
   }
-  if (np > 0) {
+  if (np > 0 && !pre) {
     if (h_info[3] == 0) {
-      TM_LAUNCH(k_norm_compact, pgrid, 256, 0, st, b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text);
+      TM_LAUNCH(k_norm_compact, pgrid, 256, 0, st, b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text, b->max_bytes);
     } else {
       // some piece expands beyond its slab (long runs of capitals): exact two-pass path
       TM_LAUNCH(k_norm_emit<1>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
@@ -786,6 +835,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   }
   const double t2 = now();
   // ---- what the tokenize pipeline needs to know on the host: #segments, and the long documents if any ------------
+  if (pre) (void)hipMemsetAsync(ninfo + 1, 0, 16, st);          // (k_norm_ranges_info has counted the device documents already: count them all again)
   TM_LAUNCH(k_norm_info, (nd + 255) / 256, 256, 0, st, b->d_nbegin, b->d_nend, nd, ninfo, long_segs());
   { int rc = small_d2h(b, h_info, ninfo, 24, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
   b->nbytes = total;
