@@ -10,6 +10,9 @@
 #include <unicode/uchar.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -194,6 +197,14 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
                       uint32_t capcode, uint32_t charset, uint32_t norm_flag, uint32_t level, bool with_unk,
                       std::vector<uint8_t>& image, const std::vector<float>* token_scores) {
   if (capcode > 2 || charset > 2) return set_error(TM_E_INVALID, "capcode/charset out of range");
+  const bool trace = getenv("TM_TRACE_BUILD") != nullptr;
+  auto tprev = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!trace) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "  [build]  %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - tprev).count());
+    tprev = n;
+  };
   // ---- dic1: unique tokens in (length, bytewise) order  (go :3364-3380) -------------------------
   std::vector<std::pair<std::string_view, bool>> dic1;
   dic1.reserve(tokens_in.size());
@@ -209,6 +220,7 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
              dic1.end());
   if (dic1.size() >= TM_NONE - 2) return set_error(TM_E_LIMIT, "too many tokens");
 
+  mark("sort tokens");
   // ---- IDs + "D "-duplicates  (go :3423-3470) ---------------------------------------------------
   StrTable table(dic1.size() * 2);
   std::vector<char> arena;                              // the "D "-prefixed copies (reserved up front: views into it stay valid)
@@ -241,6 +253,7 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
       }
     }
   }
+  mark("ids + duplicates");
   uint32_t n_tokens = next_id;
   // unk: id = number of tokens (go :3382-3398); canHaveUnkToken (go :437-442)
   uint32_t unk = TM_NONE;
@@ -253,6 +266,7 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
   const uint32_t n_info = (uint32_t)keys.size();
   for (uint32_t i = 0; i < n_info; i++) table.find(keys[i])->index = i;                                             // dictionary.Find
 
+  mark("sort keys + index");
   // deleteToken index (go :3474-3483)
   uint32_t delete_index = TM_NONE;
   if (capcode == 2) { Entry* e = table.find(std::string_view("D", 1)); if (e) delete_index = e->index; }
@@ -368,6 +382,7 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
     rec.index2 = alt_len2 > 0 ? index2 : TM_NONE;
   }
 
+  mark("metadata + alternatives");
   // ---- beginByte (go :3779-3788) ----------------------------------------------------------------
   uint8_t begin_byte[256];
   for (int i = 0; i < 256; i++) {
@@ -393,6 +408,7 @@ int build_vocab_image(const std::vector<std::string>& tokens_in, const std::vect
     w24(image, rec.index1); w24(image, rec.index2); w24(image, rec.id);
     wf32(image, rec.score);
   }
+  mark("write");
   image.insert(image.end(), begin_byte, begin_byte + 256);
   w24(image, 0);  // deleted tokens
   return TM_OK;

@@ -347,12 +347,22 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
   lanes = std::min<uint32_t>(lanes, 8);
   // chunks = maximal runs of whole documents of at most chunk_bytes (a longer document is a chunk of its own)
   std::vector<uint32_t> first;     // first document of every chunk, + ndocs
+  const size_t nramp = (size_t)lanes * nv;                          // workers, if there are chunks enough
   for (uint32_t d = 0; d < ndocs;) {
     first.push_back(d);
     uint32_t e = d + 1;
     if (offsets[e] < offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
-    // (the first chunk of every device is a quarter, the second half the size: the first kernels start after a short upload)
-    const uint64_t limit = first.size() <= nv ? chunk_bytes / 4 : first.size() <= 2 * (size_t)nv ? chunk_bytes / 2 : chunk_bytes;
+    // The steady state of the pipeline runs at the device-resident rate (profiles/r04_h2h_lanes.txt: one 32 MiB chunk per 0.87 ms against
+    // 0.83); what it loses it loses at the two ends.  Start: W workers that all begin with full chunks upload W chunks at once (the GPU idles
+    // behind a shared PCIe link) and then run their kernels in lock step, thin phases together.  So the first W chunks grow geometrically -
+    // chunk_bytes / 2^W ... chunk_bytes / 2: the first kernels start after a 2 MiB upload, and the workers come out of the ramp staggered.
+    // End: the last chunks shrink the same way (each takes 1/W of what is left), so that the drain - one worker's kernels and its download
+    // with nothing beside them - is short.
+    const size_t ci = first.size() - 1;                              // this chunk's number
+    const uint64_t left = offsets[ndocs] - offsets[d];
+    uint64_t limit = chunk_bytes;
+    if (ci < nramp) limit = std::max<uint64_t>(chunk_bytes >> (nramp - ci), std::min<uint64_t>(chunk_bytes, 1u << 20));
+    if (left < (uint64_t)nramp * chunk_bytes) limit = std::min(limit, std::max<uint64_t>(left / nramp, std::min<uint64_t>(chunk_bytes, 2u << 20)));
     while (e < ndocs && offsets[e + 1] >= offsets[e] && offsets[e + 1] - offsets[d] <= limit) e++;
     d = e;
   }
@@ -375,6 +385,8 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
   const uint32_t nworkers = (uint32_t)std::min<size_t>((size_t)lanes * nv, nchunks);
   // A lane works on one chunk at a time, but the raw text of its NEXT chunk is uploaded (on the lane's second stream) as soon as the
   // normalizer pass of the current one is through with the raw buffer: the H2D of chunk k+1 hides behind the tokenizer kernels of chunk k.
+  static const bool trace = getenv("TM_TRACE") != nullptr;
+  const double t_pipe0 = now_ms();
   auto worker = [&](uint32_t wi) {
     const tm_vocab* const v = vs[wi % nv];
     Lane* l = nullptr;
@@ -408,6 +420,8 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
     while (rc == TM_OK && k < nchunks) {
       { std::lock_guard<std::mutex> g(mu); if (first_error != TM_OK) { break; } }
       const uint32_t d0 = first[k], d1 = first[k + 1], nd = d1 - d0;
+      const double tr0 = trace ? now_ms() : 0;
+      double tr1 = 0, tr2 = 0, tr3 = 0;
       if (prefetched) {
         hipError_t e = hipStreamWaitEvent(l->stream, l->up_done, 0);
         if (e != hipSuccess) { rc = hip_fail(e, "hipStreamWaitEvent"); break; }
@@ -430,7 +444,9 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
         return TM_OK;
       };
       RunOut ro;
+      if (trace) tr1 = now_ms();
       if ((rc = lane_compute(l, v, src, loc.data(), nd, raw != 0, true, &ro, prefetch)) != TM_OK) break;
+      if (trace) tr2 = now_ms();
       if (k_next == nchunks && !next_up) k_next = next.fetch_add(1);          // (already-normalized input: nothing was prefetched)
       {   // publish this chunk's count, learn where its ids go
         std::unique_lock<std::mutex> lk(mu);
@@ -440,6 +456,7 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
         known[k + 1] = 1;
       }
       cv.notify_all();
+      if (trace) tr3 = now_ms();
       tm_batch* b = l->ws;
       const uint64_t base = tok_base[k], out_b = ro.total_tokens * encoding_length;
       toff.resize((size_t)nd + 1);
@@ -459,6 +476,8 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
       }
       if ((rc = small_sync(b, l->stream)) != TM_OK) break;
       if (fits && out_b && !out_pinned) std::memcpy(bytes_out + base * encoding_length, l->h_stage, out_b);
+      if (trace) fprintf(stderr, "[pipe] worker %u chunk %3zu (%5.1f MiB): start %7.2f  upload/wait %5.2f  compute %5.2f  order-wait %5.2f  download %5.2f  -> end %7.2f ms\n", wi, k,
+                         (offsets[d1] - offsets[d0]) / 1048576.0, tr0 - t_pipe0, tr1 - tr0, tr2 - tr1, tr3 - tr2, now_ms() - tr3, now_ms() - t_pipe0);
       for (uint32_t d = 1; d <= nd; d++) byte_offsets[d0 + d] = (base + toff[d]) * encoding_length;
       if (stats) { std::lock_guard<std::mutex> g(mu); stats->host_fallback_docs += raw ? b->host_fallback_docs : 0; stats->normalized_bytes += b->nbytes; }
       k = k_next;

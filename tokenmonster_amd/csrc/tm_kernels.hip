@@ -37,9 +37,12 @@ namespace tmh {
 // ------------------------------------------------------------------------------------------------
 // Documents are given as doc_begin[d] .. doc_end[d] (for packed batches doc_end == doc_begin + 1 of the same
 // offsets array; for the scoring pass they are arbitrary disjoint strips of the dataset).
+// (zero_word: a word this launch clears on the side - the batch's error word - instead of a memset command of its own: a chunk of the
+// host-to-host pipeline is some thirty commands, and four lanes' commands queue on one lock of the runtime)
 __global__ void k_doc_nseg(const uint64_t* __restrict__ doc_begin, const uint64_t* __restrict__ doc_end, uint32_t ndocs,
-                           uint32_t* __restrict__ doc_nseg, uint32_t unit = SEG) {
+                           uint32_t* __restrict__ doc_nseg, uint32_t unit = SEG, uint32_t* __restrict__ zero_word = nullptr) {
   uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (zero_word && d == 0) *zero_word = 0u;
   if (d < ndocs) {
     uint64_t len = doc_end[d] - doc_begin[d];
     doc_nseg[d] = (uint32_t)((len + unit - 1) / unit);
@@ -743,9 +746,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 // dataset that continues the whole-buffer walk of the range before it enters in the state that walk left (tm_score_begin/finish).
 __global__ void k_resolve(const uint32_t* __restrict__ exitmap, const uint16_t* __restrict__ exit16, const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs,
                           const uint8_t* __restrict__ doc_entry, uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
-                          uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ error_flag, uint32_t long_segs) {
+                          uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ error_flag, uint32_t long_segs, uint32_t* __restrict__ doc_fd,
+                          uint32_t* __restrict__ doc_missing) {
   uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ndocs) return;
+  doc_fd[d] = 0u; doc_missing[d] = 0u;          // (what K4 counts per document starts at zero: no memset commands of their own)
   uint64_t g0 = doc_seg_start[d], g1 = doc_seg_start[d + 1];
   if (g1 - g0 > long_segs) return;               // long documents: k_group_compose / k_long_top / k_group_expand
   uint32_t e = doc_entry ? doc_entry[d] : 0u, ntok = 0;
@@ -1394,11 +1399,14 @@ static void launch_seg_params(tm_batch* b, hipStream_t st) {
 }
 // K4 for the id-emitting entry points: the tile walk (test hook bit 10: every id stored directly, the overflow path of the staging)
 // store == false (Count): the same walk with an output capacity of 0 — it is there for the delete tokens and missing characters it counts
-static void launch_emit(tm_batch* b, hipStream_t st, bool store) {
+// rezero: the per-document counters have been added to since k_resolve cleared them (the emit stage is being repeated)
+static void launch_emit(tm_batch* b, hipStream_t st, bool store, bool rezero = false) {
   const uint64_t nseg = b->nseg;
   const uint32_t nd = b->ndocs;
-  (void)hipMemsetAsync(b->d_doc_fd, 0, (size_t)nd * 4, st);
-  (void)hipMemsetAsync(b->d_doc_missing, 0, (size_t)nd * 4, st);
+  if (rezero) {
+    (void)hipMemsetAsync(b->d_doc_fd, 0, (size_t)nd * 4, st);
+    (void)hipMemsetAsync(b->d_doc_missing, 0, (size_t)nd * 4, st);
+  }
   if (nseg > 0) {
     launch_seg_params(b, st);
     const uint32_t stage_after = (debug_flags() & 1024) ? 512u : 0u;
@@ -1409,7 +1417,7 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store) {
       TM_LAUNCH(k_emit_tiles<false>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
                                                                           b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
   }
-  if (nd) TM_LAUNCH(k_doc_events, (nd + 255) / 256, 256, 0, st, b->d_doc_ntok, b->d_doc_fd, nd, b->d_doc_events);
+  if (nd && !store) TM_LAUNCH(k_doc_events, (nd + 255) / 256, 256, 0, st, b->d_doc_ntok, b->d_doc_fd, nd, b->d_doc_events);      // (Count() is the only reader)
 }
 
 // the same scan for up to SCAN1_MAX elements in ONE launch of one workgroup (a run of elements per thread): a server batch or a chunk of the
@@ -1523,12 +1531,12 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   { int rc = enter_device(v); if (rc != TM_OK) return rc; }
   b->last_stream = st;
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
-  (void)hipMemsetAsync(b->d_error, 0, 4, st);
   const uint32_t nd = b->ndocs;
   const uint64_t nseg = b->nseg;
+  if (nd == 0) (void)hipMemsetAsync(b->d_error, 0, 4, st);
   mark(0);
   if (nd > 0) {
-    TM_LAUNCH(k_doc_nseg, (nd + 255) / 256, 256, 0, st, b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nseg);
+    TM_LAUNCH(k_doc_nseg, (nd + 255) / 256, 256, 0, st, b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nseg, (uint32_t)SEG, b->d_error);
     scan_u32(b->d_doc_nseg, nd, b->d_scan_tmp, b->d_totals + 0, b->d_doc_seg_start, st);
     if (nseg > 0) TM_LAUNCH(k_segments, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_doc_seg_start, nd, nseg, b->d_seg_doc);
   }
@@ -1555,7 +1563,7 @@ int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode) {
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   if (nd > 0)
     TM_LAUNCH(k_resolve, (nd + 255) / 256, 256, 0, st, b->d_exitmap, b->d_exit16, b->d_doc_seg_start, nd, b->d_doc_entry, b->d_seg_entry, b->d_seg_tokbase,
-                                                b->d_doc_ntok, b->d_error, long_segs());
+                                                b->d_doc_ntok, b->d_error, long_segs(), b->d_doc_fd, b->d_doc_missing);
   if (b->ngroups > 0) {
     TM_LAUNCH(k_long_top, (b->nlong + 63) / 64, 64, 0, st, b->d_gmap, b->d_longs, b->nlong, b->d_doc_entry, b->d_group_entry, b->d_group_base, b->d_doc_ntok, b->d_error);
     for (size_t lvl = b->level_first.size() - 1; lvl-- > 0;) {                           // top down
@@ -1680,10 +1688,12 @@ int ensure_output(tm_batch* b) {
   hipError_t e;
   uint64_t* totals = b->last_totals;
   uint32_t err = 0;
-  { int rc = small_d2h(b, totals, b->d_totals, 3 * sizeof(uint64_t), b->last_stream);
-    if (rc == TM_OK) rc = small_d2h(b, &err, b->d_error, 4, b->last_stream);
+  { uint64_t both[5] = {0, 0, 0, 0, 0};
+    int rc = small_d2h(b, both, b->d_totals, sizeof both, b->last_stream);
     if (rc == TM_OK) rc = small_sync(b, b->last_stream);
-    if (rc != TM_OK) return rc; }
+    if (rc != TM_OK) return rc;
+    totals[0] = both[0]; totals[1] = both[1]; totals[2] = both[2];
+    err = (uint32_t)both[4]; }
   if (err != 0) return error_from_flag(err);
   uint64_t total = b->ndocs ? totals[1] : 0;
   if (total > b->out_cap) {
@@ -1693,7 +1703,7 @@ int ensure_output(tm_batch* b) {
     b->out_cap = total + 1024;
     if ((e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc output");
     hipStream_t st = b->last_stream;
-    launch_emit(b, st, true);
+    launch_emit(b, st, true, true);
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "emit rerun");
   }
   return TM_OK;
@@ -1734,12 +1744,13 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
       (e = dalloc(b, &b->d_seg_tokbase, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_seg_par, b->max_segs + 1)) != hipSuccess || (e = dalloc(b, &b->d_doc_ntok, nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_doc_events, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_missing, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_fd, nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_tok_offsets, nd1 + 1)) != hipSuccess || (e = dalloc(b, &b->d_scan_tmp, scan_blocks)) != hipSuccess ||
-      (e = dalloc(b, &b->d_totals, 4)) != hipSuccess || (e = dalloc(b, &b->d_error, 4)) != hipSuccess ||
+      (e = dalloc(b, &b->d_totals, 8)) != hipSuccess ||
       (e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) {
     tm_batch_free(b);
     return hip_fail(e, "hipMalloc (batch workspace)");
   }
-  (void)hipMemset(b->d_totals, 0, 32);
+  (void)hipMemset(b->d_totals, 0, 64);
+  b->d_error = reinterpret_cast<uint32_t*>(b->d_totals + 4);        // (the error word lies behind the totals: ensure_output fetches both with one copy)
   *out = b;
   return TM_OK;
 }
@@ -1755,7 +1766,7 @@ void tm_batch_free(tm_batch* b) {
   if (!b) return;
   void* ptrs[] = {b->text_borrowed ? nullptr : (void*)b->d_text, b->d_offsets, b->d_doc_nseg, b->d_doc_seg_start, b->d_seg_doc, b->d_R0, b->d_R1, b->d_side, b->d_exitmap, b->d_exit16, b->d_seg_entry,
                   b->d_seg_tokbase, b->d_seg_par, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_doc_fd, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
-                  b->d_error, b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
+                  b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
                   b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,
                   b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids, b->d_two};
   for (void* p : ptrs) (void)hipFree(p);

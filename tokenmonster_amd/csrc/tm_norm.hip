@@ -481,6 +481,17 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
 }
 
 
+// pieces per document; clears what the pass writes to on the side (need_host, the info words): no memset commands of their own
+__global__ void k_norm_begin(const uint64_t* __restrict__ raw_off, uint32_t ndocs, uint32_t* __restrict__ doc_npiece, uint8_t* __restrict__ need_host,
+                             unsigned long long* __restrict__ ninfo) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < 8) ninfo[d] = 0ull;
+  if (d < ndocs) {
+    doc_npiece[d] = (uint32_t)((raw_off[d + 1] - raw_off[d] + PIECE - 1) / PIECE);
+    need_host[d] = 0;
+  }
+}
+
 // behind k_norm_emit2<false>: the pieces of the documents that turned out to need the host normalizer count for nothing, and those documents
 // are listed for the host (in no particular order)
 __global__ void k_norm_bad_pieces(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, uint64_t npieces, uint32_t* __restrict__ piece_len) {
@@ -688,9 +699,8 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   const double t0 = now();
   const uint32_t lower_all = (norm_flag & 2u) ? 1u : 0u;
   unsigned long long* ninfo = (unsigned long long*)b->d_ninfo;
-  (void)hipMemsetAsync(ninfo, 0, 64, st);
   // piece table
-  launch_doc_units(b->d_raw_off, b->d_raw_off + 1, nd, (uint32_t)PIECE, b->d_doc_npiece, st);
+  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, b->d_raw_off, nd, b->d_doc_npiece, b->d_need_host, ninfo);
   scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
   const uint32_t pgrid = (uint32_t)((np + 3) / 4);
   if (np > 0) launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
@@ -708,15 +718,15 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   bool pre = false;
   uint64_t pre_bytes = 0;
   if (fast) {
-    (void)hipMemsetAsync(b->d_need_host, 0, nd, st);
     TM_LAUNCH(k_norm_emit2<false>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
                                                b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
     TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
-    scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
+    scan_u32(b->d_piece_len, np, b->d_scan_tmp, reinterpret_cast<uint64_t*>(ninfo + 5), b->d_piece_off, st);      // (the total lands beside the info words: one copy brings everything)
     TM_LAUNCH(k_norm_compact, pgrid, 256, 0, st, b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text, b->max_bytes);
     TM_LAUNCH(k_norm_ranges_info, (nd + 255) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend, ninfo, long_segs());
-    { int rc = small_d2h(b, h_info, ninfo, 40, st); if (rc == TM_OK) rc = small_d2h(b, &pre_bytes, b->d_totals + 2, 8, st); if (rc == TM_OK) rc = small_sync(b, st);
+    { int rc = small_d2h(b, h_info, ninfo, 48, st); if (rc == TM_OK) rc = small_sync(b, st);
       if (rc != TM_OK) return rc; }
+    pre_bytes = h_info[5];
     if (h_info[3] != 0 || h_info[4] != 0) {        // a piece whose margins could not tell, or one that outgrew its slab: the exact path, from the start
       fast = false;
       (void)hipMemsetAsync(ninfo, 0, 64, st);
@@ -803,8 +813,9 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     hnorm = b->h_fb_norm;
     f3 = now();
   }
-  { int rc = small_d2h(b, h_info, ninfo, 32, st); if (rc == TM_OK) rc = small_d2h(b, &gpu_bytes, b->d_totals + 2, 8, st); if (rc == TM_OK) rc = small_sync(b, st);
+  { int rc = small_d2h(b, h_info, ninfo, 32, st); if (rc == TM_OK && !pre) rc = small_d2h(b, &gpu_bytes, b->d_totals + 2, 8, st); if (rc == TM_OK) rc = small_sync(b, st);
     if (rc != TM_OK) return rc; }
+  if (pre) gpu_bytes = pre_bytes;
   if (gpu_bytes + noff.back() > b->max_bytes) {
     return set_error(TM_E_LIMIT, "normalized text needs %llu bytes, workspace sized for %llu", (unsigned long long)(gpu_bytes + noff.back()), (unsigned long long)b->max_bytes);
   }

@@ -5,6 +5,7 @@
 // resolves alt lengths / ids from earlier records exactly as :2703-2712 does, and instead of
 // pansearch.Fast builds the byte trie described in tm_tables.h.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <mutex>
 #include <map>
 
@@ -94,7 +95,21 @@ class EdgeMap {
 };
 }  // namespace
 
+namespace {
+struct StageTimer {           // TM_TRACE_BUILD=1: wall time of the stages of a table build on stderr (tools/build_profile.cpp)
+  const bool on = getenv("TM_TRACE_BUILD") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "  [tables] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
+
 int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
+  StageTimer st;
   size_t pos = 0;
 #define NEED(k) do { if (pos + (size_t)(k) > n) return set_error(TM_E_INVALID, "truncated .vocab at byte %zu", pos); } while (0)
   NEED(24);
@@ -158,6 +173,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   if (pos != n) return set_error(TM_E_INVALID, "trailing bytes after .vocab payload");   // go :2731
 #undef NEED
 
+  st.mark("records");
   // ---- trie: accepting node id == record ordinal; internal nodes numbered from n_info ------------
   const uint32_t n_info = hv.n_info;
   EdgeMap child(hv.keys.size() + 16);             // (parent id << 8 | byte) -> child id; parent kNodeMask = root
@@ -201,6 +217,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       }
     }
   }
+  st.mark("trie");
   const uint32_t n_nodes = next_internal;
   std::vector<uint8_t> has_child(n_nodes, 0);
   for (auto& kv : child) { uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) has_child[parent] = 1; }
@@ -234,6 +251,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       spl_hint[i] = (cont || bestlen > kl + 1) ? 1 : 0;
     }
   }
+  st.mark("space-prefix walks");
   auto value_of = [&](uint32_t id) {
     uint32_t v = id | (has_child[id] ? kHasChildren : 0);
     if (id < n_info) {
@@ -255,6 +273,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     for (int d = 1; d < 66; d++) start[d] += start[d - 1];
     for (uint32_t i = 0; i < n_nodes; i++) by_depth[start[depth_of[i]]++] = i;
   }
+  st.mark("filters, depth order");
   // ---- the double array (tm_tables.h): a base for every node at depth >= 2 that has children, such that the entries base + b of
   // its children are free.  Parents are placed shallow first (the shallow end of the trie is where most walks are, and it ends up
   // together at the front of the array) by first fit from the lowest free entry; a parent that does not fit after a bounded number
@@ -301,6 +320,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
         da[base_of[n] + (kid[q] >> 24)] = uint4{n, value_of(c), cmask[c], base_of[c]};
       }
   }
+  st.mark("double array");
   hv.idle_off = hv.n_da * 16u;
   // one allocation (tm_tables.h): double array | always-empty entry | direct map | suffix links
   const size_t direct_base = 2 * ((size_t)hv.n_da + 1);                       // in 8-byte units
@@ -313,6 +333,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   std::vector<uint32_t> first_byte(n_nodes, 0);   // for depth-1 nodes: their byte, to index l2
   for (auto& kv : child) if (depth_of[kv.second] == 1) { hv.root[kv.first & 0xFF] = value_of(kv.second); first_byte[kv.second] = (uint32_t)(kv.first & 0xFF); }
   for (auto& kv : child) if (depth_of[kv.second] == 2) l2v[(first_byte[(uint32_t)(kv.first >> 8)] << 8) | (uint32_t)(kv.first & 0xFF)] = value_of(kv.second);
+  st.mark("direct map prep");
   // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.
   // link(n) follows from link(parent(n)) as in Aho-Corasick, in order of depth; best[m] = deepest accepting node on the
   // path root..m.  Only links of nodes at depth >= 3 are ever read by the kernels.
@@ -339,6 +360,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       lt[2 * (size_t)n + 1] = uint2{(lfull[n] && hc) ? cmask[m] : 0u, (lfull[n] && hc) ? base_of[m] : 0u};
     }
   }
+  st.mark("suffix links");
   // reverse table for decoding: reverse[id] = key of the LAST record carrying that id (go/tokenmonster.go:2715, quirk Q3)
   {
     std::vector<uint32_t> last(hv.n_ids, kNone);
@@ -351,6 +373,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     }
     hv.rev_off[hv.n_ids] = (uint32_t)hv.rev_bytes.size();
   }
+  st.mark("reverse table");
   // space-prefix links (walked above): x = node reached | continue << 21 | best accepting depth << 22, y = that node's value
   hv.vals.resize(n_info);
   for (uint32_t i = 0; i < n_info; i++) hv.vals[i] = value_of(i);
@@ -359,6 +382,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     for (uint32_t i = 0; i < n_info; i++)
       hv.spl[i] = uint4{splw[i].node | (splw[i].cont << 21) | (splw[i].bestlen << 22), splw[i].best != kNone ? value_of(splw[i].best) : 0u,
                         splw[i].cont ? cmask[splw[i].node] : 0u, splw[i].cont ? base_of[splw[i].node] : 0u};
+  st.mark("vals, spl");
   // direct map: one 16-byte entry (same format as a suffix link) resolves the first two bytes of any walk, the
   // depth-1 answer folded in
   for (uint32_t b0 = 0; b0 < 256; b0++) {
@@ -378,6 +402,7 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
       e[1] = uint2{cont ? cmask[id2] : 0u, cont ? base_of[id2] : 0u};
     }
   }
+  st.mark("direct map");
   hv.n_nodes = n_nodes;
   hv.off = hv.charset == 2 ? 2 : 1;
   hv.bstart = hv.root[' '];

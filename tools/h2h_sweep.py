@@ -10,7 +10,7 @@ v = tm.Vocab(synth.config_vocab(cfg))
 raw, roffs = synth.synth_corpus(kind, 1024 << 20, seed=0x434F5250 + 2)
 pin_in = tm.PinnedBuffer(raw.size); pin_in.array[:] = raw
 pin_out = tm.PinnedBuffer(raw.size + 4096)
-for lanes, chunk in ((4, 32), (6, 32), (8, 32), (6, 16), (8, 16), (12, 16), (4, 64), (6, 64), (3, 128), (4, 128)):
+for lanes, chunk in ((4, 32), (2, 64), (2, 48), (2, 32), (3, 32), (2, 96), (1, 64), (4, 32), (2, 64)):
     v.tokenize_pipeline(pin_in.array, roffs, raw=True, chunk_bytes=chunk << 20, lanes=lanes, out=pin_out.array)
     best = 1e9
     for _ in range(3):
