@@ -235,17 +235,13 @@ func ScoreCandidate(d *HipDataset, tokens [][]byte, capcode, charset uint8, stri
 	for i, o := range off64 {
 		off[i] = uint32(o)
 	}
-	var img *C.uint8_t
-	var imgLen C.size_t
-	if _, err = locked(func() C.int {
-		return C.tm_build_vocab((*C.uint8_t)(unsafe.Pointer(&blob[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(tokens)), nil,
-			C.uint32_t(capcode), C.uint32_t(charset), 0, 5, 0, &img, &imgLen)
-	}); err != nil {
-		return nil, 0, missing, err
-	}
-	defer C.tm_free(unsafe.Pointer(img))
+	// token list -> records -> walk tables -> the dataset's device in one call (tm_vocab_build; rounds 2-3 wrote a .vocab image with
+	// tm_build_vocab and parsed it again in tm_vocab_load: twice the host time)
 	var cand *C.tm_vocab
-	if _, err = locked(func() C.int { return C.tm_vocab_load_on(img, imgLen, C.tm_dataset_device(d.h), &cand) }); err != nil { // on the dataset's device
+	if _, err = locked(func() C.int {
+		return C.tm_vocab_build((*C.uint8_t)(unsafe.Pointer(&blob[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(tokens)), nil,
+			C.uint32_t(capcode), C.uint32_t(charset), 0, 5, 0, C.tm_dataset_device(d.h), &cand)
+	}); err != nil {
 		return nil, 0, missing, err
 	}
 	defer C.tm_vocab_free(cand)
@@ -532,4 +528,22 @@ func ScoreCandidateAll(cand *HipVocabSet, d *HipDatasetSet) (scores []uint32, to
 		return nil, 0, missing, err
 	}
 	return scores[:nIds], uint64(tit), missing, nil
+}
+
+// NewHipVocabSetFromTokens: a candidate's tables for every GPU straight from its token list (tm_vocab_build_all): built once on the host,
+// uploaded to the first device, replicated device to device.
+func NewHipVocabSetFromTokens(g *HipDevices, tokens [][]byte, capcode, charset uint8) (*HipVocabSet, error) {
+	blob, off64 := pack(tokens)
+	off := make([]uint32, len(off64))
+	for i, o := range off64 {
+		off[i] = uint32(o)
+	}
+	var h *C.tm_vocab_set
+	if _, err := locked(func() C.int {
+		return C.tm_vocab_build_all(g.h, (*C.uint8_t)(unsafe.Pointer(&blob[0])), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(tokens)), nil,
+			C.uint32_t(capcode), C.uint32_t(charset), 0, 5, 0, &h)
+	}); err != nil {
+		return nil, err
+	}
+	return &HipVocabSet{h}, nil
 }

@@ -29,6 +29,19 @@ int tm_build_vocab(const uint8_t* blob, const uint32_t* off, uint32_t n_tokens, 
                    uint32_t capcode, uint32_t charset, uint32_t norm_flag, uint32_t level, int with_unk,
                    uint8_t** out, size_t* out_n);
 
+/* The trainvocab worker's per-candidate step in ONE call (training/trainvocab.go:530-907 builds a candidate's tables in place): the same
+ * token list -> the same rules -> records -> walk tables -> `device`, without the .vocab image in between that tm_build_vocab writes and
+ * tm_vocab_load parses again (the search for a token's alternatives rides on the trie the tables need anyway).  The vocabulary is the one
+ * tm_vocab_load(tm_build_vocab(...)) gives - tm_vocab_image() of it returns those very bytes (written on first request). */
+struct tm_vocab;
+int tm_vocab_build(const uint8_t* blob, const uint32_t* off, uint32_t n_tokens, const uint8_t* special, uint32_t capcode, uint32_t charset,
+                   uint32_t norm_flag, uint32_t level, int with_unk, int device, struct tm_vocab** out);
+/* ... and for every member of a tm_devices handle (tokenmonster_hip.h): built once, the device block replicated GPU to GPU. */
+struct tm_devices;
+struct tm_vocab_set;
+int tm_vocab_build_all(struct tm_devices* g, const uint8_t* blob, const uint32_t* off, uint32_t n_tokens, const uint8_t* special, uint32_t capcode,
+                       uint32_t charset, uint32_t norm_flag, uint32_t level, int with_unk, struct tm_vocab_set** out);
+
 /* Host-side normalize + capcode (go/tokenmonster.go:242-253).  Returns a malloc'd buffer. */
 int tm_normalize(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, uint8_t** out,
                  size_t* out_n);
@@ -43,7 +56,6 @@ int tm_normalize_batch(const uint8_t* text, const uint64_t* offsets, uint32_t nd
 /* ---- on-disk formats either side of the path (host only) --------------------------------------------------------------------------
  * .vocab (go/tokenmonster.go:2602-2653 Save): this library never mutates a vocabulary, so saving one is writing back the image it was
  * loaded from.  *image stays valid until tm_vocab_free. */
-struct tm_vocab;
 int tm_vocab_image(const struct tm_vocab* v, const uint8_t** image, size_t* n);
 int tm_vocab_save(const struct tm_vocab* v, const char* path);
 /* .tok token dictionaries (training/trainvocab.go:412-480: what getalltokens writes and trainvocab reads and writes): a zlib stream of

@@ -260,3 +260,47 @@ def test_latin_text_is_decoded_on_the_device():
         t2, o2 = tm.pack_documents([other, b"Wascii"])
         a.decode_packed(id_of[t2], o2, raw=False)
         assert N.lib.tm_decode_host_docs() == 1
+
+
+@pytest.mark.parametrize("capcode,with_unk", [(2, False), (0, True)])
+def test_vocab_build_equals_build_image_then_load(capcode, with_unk):
+    """tm_vocab_build (token list -> tables -> device in one call: the trainvocab worker's per-candidate step, training/trainvocab.go:530-907)
+    gives the vocabulary tm_vocab_load(tm_build_vocab(same list)) gives: the same .vocab bytes (written from its records on request), the same
+    ids, the same scoring histogram, and the same device block byte for byte; tm_vocab_build_all replicates it over the members of a handle."""
+    import ctypes as C
+    from conftest import fuzz_text, fuzz_vocab_tokens
+    from tokenmonster_amd import _native as N, multi
+    from tokenmonster_amd.vocab import VocabBlock
+    from test_gpu_parity import _score
+    rng = np.random.default_rng(900 + capcode)
+    toks = fuzz_vocab_tokens(rng, capcode, 400)
+    img = synth.build_vocab(toks, capcode=capcode, charset=1, with_unk=with_unk)
+    a = tm.Vocab(img)
+    b = tm.Vocab.from_tokens(toks, capcode=capcode, charset=1, with_unk=with_unk)
+    assert b.image() == bytes(img)
+    ma, pa, na = a.export_block()
+    mb, pb, nb = b.export_block()
+    assert ma == mb and na == nb
+    ha, hb = np.empty(na, dtype=np.uint8), np.empty(nb, dtype=np.uint8)
+    for ptr, host in ((pa, ha), (pb, hb)):
+        pin = tm.PinnedBuffer(host.size)
+        N.check(N.lib.tm_device_copy(C.c_void_p(pin.array.ctypes.data), C.c_void_p(ptr), host.size))
+        host[:] = pin.array
+    total = 256 + sum(((x + 255) & ~255) for x in VocabBlock.from_buffer_copy(ma).part_bytes)
+    assert (ha[:total] == hb[:total]).all()                       # the tables themselves (the tail of a block is allocation slack)
+    data = np.frombuffer(fuzz_text(rng, capcode, 50_000), dtype=np.uint8)
+    offs = np.array([0, 10_000, 10_000, 31_111, 50_000], dtype=np.uint64)
+    ia, oa, xa = a.tokenize_packed(data, offs)
+    ib, ob, xb = b.tokenize_packed(data, offs)
+    assert (ia == ib).all() and (oa == ob).all() and (xa == xb).all()
+    sa, sb = _score(a, data), _score(b, data)
+    assert (sa[0] == sb[0]).all() and sa[1] == sb[1] and (sa[2] == sb[2]).all()
+    g = multi.Devices([0, 0, 0])
+    try:
+        vs = multi.VocabSet.from_tokens(g, toks, capcode=capcode, charset=1, with_unk=with_unk)
+        ds = multi.DatasetSet(g, data)
+        sm = ds.score(vs)
+        assert (sm[0] == sa[0]).all() and sm[1] == sa[1] and (sm[2] == sa[2]).all()
+        ds.close(); vs.close()
+    finally:
+        g.close()

@@ -104,6 +104,8 @@ SIGNATURES = {
     "tm_free": (None, [vp]),
     "tm_build_vocab": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                  C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "tm_vocab_build": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(vp)]),
+    "tm_vocab_build_all": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]),
     "tm_vocab_image": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "tm_vocab_save": (C.c_int, [vp, C.c_char_p]),
     "tm_tok_read": (C.c_int, [vp, C.c_size_t, vp, C.POINTER(vp), C.POINTER(vp), u32p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u32p]),

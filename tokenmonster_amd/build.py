@@ -44,7 +44,9 @@ def build(force=False, verbose=False):
         o = os.path.join(CSRC, "build", os.path.basename(s) + ".o")
         objs.append(o)
         if force or _stale(o, [s] + deps[len(srcs):]):
-            cmd = [hipcc] + common + (["-x", "hip"] if s.endswith(".hip") else ["-x", "c++"]) + ["-c", s, "-o", o]
+            # (the plain C++ units see the HIP headers too - tm_device.h's host structures use its vector types - but no device code)
+            rocm_inc = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "include")
+            cmd = [hipcc] + common + (["-x", "hip"] if s.endswith(".hip") else ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", rocm_inc]) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

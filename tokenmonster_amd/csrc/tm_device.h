@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -52,9 +53,14 @@ int hip_fail(hipError_t e, const char* what);
 struct HostVocab {
   uint8_t capcode = 0, charset = 0, norm_flag = 0, level = 0, reserve = 0;
   uint32_t unk = TM_NONE, vocab_size = 0, n_ids = 0, n_info = 0, delete_id = TM_NONE, max_len = 0;
-  std::vector<uint8_t> image;       // the .vocab bytes the vocabulary was loaded from (tm_vocab_image / tm_vocab_save)
+  mutable std::vector<uint8_t> image;   // the .vocab bytes (tm_vocab_image / tm_vocab_save): what the vocabulary was loaded from, or - for one built straight from a
+                                        // token list (tm_vocab_build) - written from the records below the first time somebody asks (vocab_image())
   std::vector<uint8_t> keys;        // concatenated key bytes
   std::vector<uint32_t> key_off;    // n_info + 1
+  // the records as the .vocab file holds them, in file order = pansearch order
+  std::vector<uint8_t> rec_flag, rec_nwords;
+  std::vector<uint32_t> rec_id, rec_index1, rec_index2;
+  std::vector<float> rec_score;
   std::vector<Row> rows;
   uint8_t begin_byte[256];
   std::vector<uint32_t> root;
@@ -66,7 +72,41 @@ struct HostVocab {
   uint32_t idle_off = 0, n_da = 0, n_nodes = 0, off = 1, bstart = kNone, spl_hint = 0, link_off = 0, direct_off = 0;
 };
 
+// .vocab bytes -> records -> tables (what tm_vocab_load does on the host)
 int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv);
+int parse_records(const uint8_t* f, size_t n, HostVocab& hv);        // the first half: header, keys, records, begin_byte (checked)
+
+// The byte trie of the keys, built WITHOUT a hash of its edges: the keys are visited in plain lexicographic order (the file keeps them by
+// length, bytewise within a length: a merge of the length groups), where every key continues the path of the one before it behind their
+// common prefix, and a key's prefixes have all been visited before it.  Accepting node id == record ordinal, internal nodes are numbered
+// from n_info in order of creation (depth-first: chains of one-child nodes get consecutive ids).
+struct Trie {
+  static constexpr uint32_t kRoot = kNodeMask;
+  uint32_t n_info = 0, n_nodes = 0;
+  std::vector<uint8_t> depth_of, byte_of;          // per node
+  std::vector<uint32_t> parent_of;                  // per node (kRoot for depth 1)
+  std::vector<uint32_t> kid_start, kid;             // children of node n: kid[kid_start[n] .. kid_start[n + 1]) = byte << 24 | child, bytes ascending
+  uint32_t root_child[256];                         // children of the root (kNone: none)
+  uint32_t find(uint32_t node, uint32_t byte) const {
+    if (node == kRoot) return root_child[byte];
+    uint32_t lo = kid_start[node], hi = kid_start[node + 1];
+    while (hi - lo > 8) { const uint32_t mid = (lo + hi) / 2; if ((kid[mid] >> 24) <= byte) lo = mid; else hi = mid; }
+    for (; lo < hi; lo++) if ((kid[lo] >> 24) == byte) return kid[lo] & 0xFFFFFFu;
+    return kNone;
+  }
+};
+// on_key(ordinal, path_ord, lex_rank): called once per key in lexicographic order, path_ord[d] = ordinal of the key that is this key's prefix of
+// length d + 1 (kNone: that prefix is not a key), for d + 1 < length of the key: what the builder's search for alternatives (go/tokenmonster.go:3597)
+// needs, for free.  May be null.
+struct TrieVisitor { virtual void key(uint32_t ordinal, const uint32_t* path_ord) = 0; virtual ~TrieVisitor() = default; };
+int build_trie(const HostVocab& hv, Trie& t, TrieVisitor* on_key);
+// rows, double array, links, direct map, space-prefix links, reverse table: everything the device block is made of (tm_tables.h)
+int build_tables(HostVocab& hv, const Trie& t);
+// tm_build.cpp: token list -> records + trie (the rules of go/tokenmonster.go:3423-3793 == training/trainvocab.go:548-907)
+int build_vocab_records(const std::vector<std::string>& tokens, const std::vector<uint8_t>& special, uint32_t capcode, uint32_t charset, uint32_t norm_flag,
+                        uint32_t level, bool with_unk, HostVocab& hv, Trie& trie, const std::vector<float>* token_scores = nullptr);
+// the .vocab bytes of the vocabulary (written from the records when it was built from a token list)
+const std::vector<uint8_t>& vocab_image(const HostVocab& hv);
 
 }  // namespace tmh
 

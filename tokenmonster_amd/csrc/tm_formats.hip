@@ -22,19 +22,21 @@ extern "C" {
 
 int tm_vocab_image(const tm_vocab* v, const uint8_t** image, size_t* n) {
   if (!v || !image || !n) return set_error(TM_E_INVALID, "null argument");
-  if (v->host.image.empty()) return set_error(TM_E_INVALID, "an imported vocabulary (tm_vocab_block_import) has no file image");
-  *image = v->host.image.data();
-  *n = v->host.image.size();
+  const std::vector<uint8_t>& img = tmh::vocab_image(v->host);      // (a vocabulary built from a token list writes its image on first request)
+  if (img.empty()) return set_error(TM_E_INVALID, "an imported vocabulary (tm_vocab_block_import) has no file image");
+  *image = img.data();
+  *n = img.size();
   return TM_OK;
 }
 
 int tm_vocab_save(const tm_vocab* v, const char* path) {
   if (!v || !path) return set_error(TM_E_INVALID, "null argument");
-  if (v->host.image.empty()) return set_error(TM_E_INVALID, "an imported vocabulary (tm_vocab_block_import) has no file image");
+  const std::vector<uint8_t>& img = tmh::vocab_image(v->host);
+  if (img.empty()) return set_error(TM_E_INVALID, "an imported vocabulary (tm_vocab_block_import) has no file image");
   FILE* f = std::fopen(path, "wb");
   if (!f) return set_error(TM_E_INVALID, "cannot open %s for writing", path);
-  const size_t n = v->host.image.size();
-  const bool ok = std::fwrite(v->host.image.data(), 1, n, f) == n;
+  const size_t n = img.size();
+  const bool ok = std::fwrite(img.data(), 1, n, f) == n;
   return (std::fclose(f) == 0 && ok) ? TM_OK : set_error(TM_E_INVALID, "short write to %s", path);
 }
 

@@ -13,7 +13,7 @@ namespace tmh {
 int set_error(int code, const char* fmt, ...);
 const char* last_error();
 
-// tm_build.cpp
+// tm_build.cpp (build_vocab_records, which fills a HostVocab and its trie directly, is declared in tm_device.h)
 int build_vocab_image(const std::vector<std::string>& tokens, const std::vector<uint8_t>& special, uint32_t capcode,
                       uint32_t charset, uint32_t norm_flag, uint32_t level, bool with_unk,
                       std::vector<uint8_t>& image, const std::vector<float>* token_scores = nullptr);

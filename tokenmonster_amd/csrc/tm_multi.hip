@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "tm_pipeline.h"
+#include "tm_build.h"
 
 using namespace tmh;
 
@@ -248,18 +249,26 @@ void tm_devices_close(tm_devices* g) {
 }
 
 // ---- one vocabulary on every device ---------------------------------------------------------------------------------------------------
+static int replicate(tm_devices* g, tm_vocab* first, tm_vocab_set** out);
 int tm_vocab_load_all(tm_devices* g, const uint8_t* vocab_file, size_t n, tm_vocab_set** out) {
   if (!g || !out) return set_error(TM_E_INVALID, "null argument");
   *out = nullptr;
+  // the tables are built ONCE (parse, trie, double array, links: tm_vocab_load) and uploaded to member 0; the finished block then goes
+  // device to device (xGMI where the devices are peers) into an imported vocabulary of the same shape on every other member
+  tm_vocab* first = nullptr;
+  const int rc = tm_vocab_load_on(vocab_file, n, g->dev[0], &first);
+  return rc == TM_OK ? replicate(g, first, out) : rc;
+}
+
+// the set around a vocabulary that already lives on member 0: replicas of its device block on every other member
+static int replicate(tm_devices* g, tm_vocab* first, tm_vocab_set** out) {
   auto* s = new tm_vocab_set();
   s->devs = g;
   s->v.assign(g->dev.size(), nullptr);
-  // the tables are built ONCE (parse, trie, double array, links: tm_vocab_load) and uploaded to member 0; the finished block then goes
-  // device to device (xGMI where the devices are peers) into an imported vocabulary of the same shape on every other member
-  int rc = tm_vocab_load_on(vocab_file, n, g->dev[0], &s->v[0]);
+  s->v[0] = first;
   tm_vocab_block meta;
   void* src = nullptr;
-  if (rc == TM_OK) rc = tm_vocab_block_export(s->v[0], &meta, &src);
+  int rc = tm_vocab_block_export(first, &meta, &src);
   for (size_t i = 1; i < g->dev.size() && rc == TM_OK; i++) {
     void* dst = nullptr;
     if ((rc = tm_vocab_block_import(&meta, g->dev[i], &s->v[i], &dst)) != TM_OK) break;
@@ -269,6 +278,15 @@ int tm_vocab_load_all(tm_devices* g, const uint8_t* vocab_file, size_t n, tm_voc
   if (rc != TM_OK) { const std::string keep = last_error(); tm_vocab_set_free(s); return set_error(rc, "%s", keep.c_str()); }
   *out = s;
   return TM_OK;
+}
+
+int tm_vocab_build_all(tm_devices* g, const uint8_t* blob, const uint32_t* off, uint32_t n_tokens, const uint8_t* special, uint32_t capcode, uint32_t charset,
+                       uint32_t norm_flag, uint32_t level, int with_unk, tm_vocab_set** out) {
+  if (!g || !out) return set_error(TM_E_INVALID, "null argument");
+  *out = nullptr;
+  tm_vocab* first = nullptr;
+  const int rc = tm_vocab_build(blob, off, n_tokens, special, capcode, charset, norm_flag, level, with_unk, g->dev[0], &first);
+  return rc == TM_OK ? replicate(g, first, out) : rc;
 }
 
 const tm_vocab* tm_vocab_set_member(const tm_vocab_set* s, int member) { return s && member >= 0 && member < (int)s->v.size() ? s->v[member] : nullptr; }

@@ -58,42 +58,6 @@ int enter_device(const tm_vocab* v) {
   return e == hipSuccess ? TM_OK : hip_fail(e, "hipSetDevice (device of the vocabulary)");
 }
 
-namespace {
-// (parent node << 8 | byte) -> child node of the trie under construction: open addressing over a flat array (the table build of a
-// candidate vocabulary is on the trainvocab worker's path, and std::unordered_map was most of its time), edges kept in creation order
-class EdgeMap {
- public:
-  explicit EdgeMap(size_t expect) {
-    size_t cap = 64;
-    while (cap < expect * 2 + 16) cap <<= 1;
-    keys_.assign(cap, kFree);
-    vals_.assign(cap, 0);
-    list_.reserve(expect);
-  }
-  const uint32_t* find(uint64_t key) const {
-    const size_t mask = keys_.size() - 1;
-    for (size_t i = slot(key) & mask;; i = (i + 1) & mask) {
-      if (keys_[i] == key) return &vals_[i];
-      if (keys_[i] == kFree) return nullptr;
-    }
-  }
-  void emplace(uint64_t key, uint32_t val) {           // (the key is not present; capacity was sized for every edge up front)
-    const size_t mask = keys_.size() - 1;
-    size_t i = slot(key) & mask;
-    while (keys_[i] != kFree) i = (i + 1) & mask;
-    keys_[i] = key; vals_[i] = val;
-    list_.emplace_back(key, val);
-  }
-  std::vector<std::pair<uint64_t, uint32_t>>::const_iterator begin() const { return list_.begin(); }
-  std::vector<std::pair<uint64_t, uint32_t>>::const_iterator end() const { return list_.end(); }
- private:
-  static constexpr uint64_t kFree = ~0ull;
-  static size_t slot(uint64_t key) { return (size_t)((key * 0x9E3779B97F4A7C15ull) >> 24); }
-  std::vector<uint64_t> keys_;
-  std::vector<uint32_t> vals_;
-  std::vector<std::pair<uint64_t, uint32_t>> list_;
-};
-}  // namespace
 
 namespace {
 struct StageTimer {           // TM_TRACE_BUILD=1: wall time of the stages of a table build on stderr (tools/build_profile.cpp)
@@ -108,8 +72,8 @@ struct StageTimer {           // TM_TRACE_BUILD=1: wall time of the stages of a 
 };
 }  // namespace
 
-int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
-  StageTimer st;
+// ---- .vocab bytes -> records (go/tokenmonster.go:2656-2736; layout: SURVEY.md Appendix A) ---------------------------------------------
+int parse_records(const uint8_t* f, size_t n, HostVocab& hv) {
   size_t pos = 0;
 #define NEED(k) do { if (pos + (size_t)(k) > n) return set_error(TM_E_INVALID, "truncated .vocab at byte %zu", pos); } while (0)
   NEED(24);
@@ -125,11 +89,13 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   if (hv.n_ids > kRowIdMask) return set_error(TM_E_LIMIT, "%u ids: the device tables hold at most %u", hv.n_ids, kRowIdMask);
   if (hv.n_info >= kMaxNodes) return set_error(TM_E_LIMIT, "%u index records: the walk tables hold fewer than %u trie nodes", hv.n_info, kMaxNodes);
   if ((uint64_t)hv.n_info * 16 > n) return set_error(TM_E_INVALID, "truncated .vocab: %u records do not fit %zu bytes", hv.n_info, n);
-  hv.keys.clear(); hv.key_off.assign(1, 0); hv.rows.resize(hv.n_info);
-  std::vector<uint8_t> lens(hv.n_info), flags(hv.n_info), nwords(hv.n_info);
-  std::vector<uint32_t> ids(hv.n_info);
+  const uint32_t n_info = hv.n_info;
+  hv.keys.clear(); hv.key_off.assign(1, 0);
+  hv.keys.reserve(n);
+  hv.key_off.reserve((size_t)n_info + 1);
+  hv.rec_flag.resize(n_info); hv.rec_nwords.resize(n_info); hv.rec_id.resize(n_info); hv.rec_index1.resize(n_info); hv.rec_index2.resize(n_info); hv.rec_score.resize(n_info);
   uint32_t prev_len = 0;
-  for (uint32_t i = 0; i < hv.n_info; i++) {
+  for (uint32_t i = 0; i < n_info; i++) {
     NEED(1);
     uint32_t kl = f[pos++];
     if (kl == 0 || kl > 40) return set_error(TM_E_INVALID, "record %u: key length %u", i, kl);     // go :2695
@@ -140,28 +106,14 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     hv.keys.insert(hv.keys.end(), f + pos, f + pos + kl);
     hv.key_off.push_back((uint32_t)hv.keys.size());
     pos += kl;
-    uint32_t flag = f[pos], nw = f[pos + 1], index1 = rd24(f + pos + 2), index2 = rd24(f + pos + 5), id = rd24(f + pos + 8);
+    const uint32_t flag = f[pos], nw = f[pos + 1], index1 = rd24(f + pos + 2), index2 = rd24(f + pos + 5), id = rd24(f + pos + 8);
+    std::memcpy(&hv.rec_score[i], f + pos + 11, 4);
     pos += 15;
     if (id >= hv.n_ids) return set_error(TM_E_INVALID, "record %u: id %u out of range", i, id);
     if (nw > 31) return set_error(TM_E_LIMIT, "record %u: nWords %u > 31", i, nw);
-    lens[i] = (uint8_t)kl; flags[i] = (uint8_t)flag; nwords[i] = (uint8_t)nw; ids[i] = id;
-    uint32_t id1 = 0, id2 = 0, len1 = 0, len2 = 0, nw1 = 0, nw2 = 0, fl1 = 0, fl2 = 0;
-    if (index1 != TM_NONE) {                                   // go :2703-2706
-      if (index1 >= i) return set_error(TM_E_INVALID, "record %u: alternative does not precede it", i);
-      len1 = lens[index1]; id1 = ids[index1]; nw1 = nwords[index1]; fl1 = flags[index1];
-    }
-    if (index2 != TM_NONE) {                                   // go :2708-2711
-      if (index2 >= i) return set_error(TM_E_INVALID, "record %u: alternative does not precede it", i);
-      len2 = lens[index2]; id2 = ids[index2]; nw2 = nwords[index2]; fl2 = flags[index2];
-    }
-    // first-token constants (tm_tables.h): allLetters + max0(nWords-1) + nWords*100 (+ the length, for the alternatives)
-    auto fconst = [](uint32_t fl, uint32_t nwk) { return ((fl >> 7) & 1u) + (nwk > 0 ? nwk - 1 : 0u) + nwk * 100u; };
-    Row& r = hv.rows[i];
-    r.x = id | (fconst(flag, nw) << kRowIdBits);
-    r.y = id1 | ((len1 ? len1 + fconst(fl1, nw1) : 0u) << kRowIdBits);
-    r.z = id2 | ((len2 ? len2 + fconst(fl2, nw2) : 0u) << kRowIdBits);
-    r.w = len1 | (len2 << 6) | ((flag & 1u) << 12) | ((fl1 & 1u) << 13) | ((fl2 & 1u) << 14) | (((flag >> 3) & 1u) << 15) | (((fl1 >> 3) & 1u) << 16) |
-          (((fl2 >> 3) & 1u) << 17) | ((nw >= 2 ? 1u : 0u) << 18) | ((nw1 >= 2 ? 1u : 0u) << 19) | ((nw2 >= 2 ? 1u : 0u) << 20) | (((flag >> 5) & 1u) << 21);
+    if (index1 != TM_NONE && index1 >= i) return set_error(TM_E_INVALID, "record %u: alternative does not precede it", i);   // go :2703-2706
+    if (index2 != TM_NONE && index2 >= i) return set_error(TM_E_INVALID, "record %u: alternative does not precede it", i);   // go :2708-2711
+    hv.rec_flag[i] = (uint8_t)flag; hv.rec_nwords[i] = (uint8_t)nw; hv.rec_id[i] = id; hv.rec_index1[i] = index1; hv.rec_index2[i] = index2;
   }
   NEED(256);
   std::memcpy(hv.begin_byte, f + pos, 256);
@@ -172,101 +124,120 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   for (uint32_t i = 0; i < nd; i++) { NEED(1); uint32_t l = f[pos++]; NEED(l + 7); pos += l + 7; }
   if (pos != n) return set_error(TM_E_INVALID, "trailing bytes after .vocab payload");   // go :2731
 #undef NEED
+  return TM_OK;
+}
 
-  st.mark("records");
-  // ---- trie: accepting node id == record ordinal; internal nodes numbered from n_info ------------
+// ---- the trie: accepting node id == record ordinal; internal nodes numbered from n_info ------------------------------------------------
+int build_trie(const HostVocab& hv, Trie& t, TrieVisitor* on_key) {
   const uint32_t n_info = hv.n_info;
-  EdgeMap child(hv.keys.size() + 16);             // (parent id << 8 | byte) -> child id; parent kNodeMask = root
-  std::vector<uint8_t> depth_of;                   // depth per node id
-  depth_of.assign(n_info, 0);
-  std::vector<uint32_t> parent_of(n_info, 0);      // parent node id (kRoot for depth 1) and the edge byte, per node id
-  std::vector<uint8_t> byte_of(n_info, 0);
-  uint32_t next_internal = n_info;
-  const uint32_t kRoot = kNodeMask;
-  // keys arrive in (length, bytewise) order, so a key shares most of its path with the one before it: the walk resumes behind
-  // their common prefix instead of at the root
-  uint32_t path[41];                               // path[d] = node of the first d+1 bytes of the previous key
-  const uint8_t* prev_k = nullptr;
-  uint32_t prev_kl = 0;
-  for (uint32_t i = 0; i < n_info; i++) {
-    const uint8_t* k = &hv.keys[hv.key_off[i]];
-    uint32_t kl = lens[i];
-    uint32_t common = 0;
-    while (common < prev_kl && common + 1 < kl && k[common] == prev_k[common]) common++;   // (the last byte always makes a new node)
-    uint32_t node = common ? path[common - 1] : kRoot;
-    prev_k = k; prev_kl = kl;
-    for (uint32_t d = common; d < kl; d++) {
-      uint64_t key = ((uint64_t)node << 8) | k[d];
-      if (d + 1 == kl) {
-        // keys arrive shortest first, so this node cannot exist yet (a proper prefix of a key is shorter)
-        child.emplace(key, i);
-        depth_of[i] = (uint8_t)kl;
-        parent_of[i] = node; byte_of[i] = k[d];
-        node = i;
-        path[d] = node;
-      } else {
-        const uint32_t* it = child.find(key);
-        if (!it) {
-          if (next_internal >= kMaxNodes) return set_error(TM_E_LIMIT, "vocabulary needs more than %u trie nodes", kMaxNodes);
-          child.emplace(key, next_internal);
-          depth_of.push_back((uint8_t)(d + 1));
-          parent_of.push_back(node); byte_of.push_back(k[d]);
-          node = next_internal++;
-        } else node = *it;
-        path[d] = node;
-      }
-    }
+  const uint8_t* K = hv.keys.data();
+  const uint32_t* ko = hv.key_off.data();
+  // the records lie by length, bytewise within a length: one run per length, merged into plain lexicographic order through a small heap
+  struct Run { uint32_t cur, end; };
+  std::vector<Run> runs;
+  for (uint32_t i = 0; i < n_info;) {
+    const uint32_t L = ko[i + 1] - ko[i];
+    uint32_t j = i + 1;
+    while (j < n_info && ko[j + 1] - ko[j] == L) j++;
+    runs.push_back(Run{i, j});
+    i = j;
   }
-  st.mark("trie");
-  const uint32_t n_nodes = next_internal;
-  std::vector<uint8_t> has_child(n_nodes, 0);
-  for (auto& kv : child) { uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) has_child[parent] = 1; }
-  // Forward-delete hint (tm_tables.h): can the walk of ' '+key (the probe of go :1088-1095) end on something longer than
-  // ' '+key itself?  Only then is the probe worth starting.  The hint rides in the begins-with-space bit of tokens that
-  // begin with a letter (the two are mutually exclusive in any vocabulary the reference's builder writes); if a file
-  // ever carries both bits on one record the hint is switched off and the kernels probe every eligible position.
-  const uint32_t spl_off = hv.charset == 2 ? 2u : 1u;
-  uint32_t spl_start = kNone;
-  { const uint32_t* it = child.find(((uint64_t)kRoot << 8) | ' '); if (it) spl_start = *it; }
-  if (spl_start != kNone && spl_off == 2) { const uint32_t* it = child.find(((uint64_t)spl_start << 8) | 0u); spl_start = it ? *it : kNone; }
-  struct Spl { uint32_t node, cont, bestlen, best; };
-  std::vector<Spl> splw(n_info, Spl{kNone, 0, 0, kNone});
-  std::vector<uint8_t> spl_hint(n_info, 0);
-  hv.spl_hint = 1;
-  for (uint32_t i = 0; i < n_info; i++) if ((flags[i] & 2u) && (flags[i] & 4u)) hv.spl_hint = 0;
-  if (spl_start != kNone) {
-    for (uint32_t i = 0; i < n_info; i++) {
-      const uint8_t* k = &hv.keys[hv.key_off[i]];
-      const uint32_t kl = lens[i];
-      uint32_t node = spl_start, depth = spl_off, bestlen = 0, best = kNone, used = 0;
-      if (node < n_info) { bestlen = depth; best = node; }
-      while (used < kl && depth < hv.max_len) {
-        const uint32_t* it = child.find(((uint64_t)node << 8) | k[used]);
-        if (!it) break;
-        node = *it; used++; depth++;
-        if (node < n_info) { bestlen = depth; best = node; }
-      }
-      const uint32_t cont = (used == kl && has_child[node] && depth < hv.max_len) ? 1u : 0u;
-      splw[i] = Spl{node, cont, bestlen, best};
-      spl_hint[i] = (cont || bestlen > kl + 1) ? 1 : 0;
-    }
-  }
-  st.mark("space-prefix walks");
-  auto value_of = [&](uint32_t id) {
-    uint32_t v = id | (has_child[id] ? kHasChildren : 0);
-    if (id < n_info) {
-      uint32_t f5 = flag8_to_flag5(flags[id]);
-      if (hv.spl_hint && (f5 & 2u)) f5 = (f5 & ~4u) | (spl_hint[id] ? 4u : 0u);
-      v |= ((uint32_t)nwords[id] << 22) | (f5 << 27);
-    }
-    return v;
+  auto less = [&](uint32_t a, uint32_t b) {             // key a < key b, lexicographically (a prefix before what extends it)
+    const uint32_t la = ko[a + 1] - ko[a], lb = ko[b + 1] - ko[b];
+    const int c = std::memcmp(K + ko[a], K + ko[b], la < lb ? la : lb);
+    return c != 0 ? c < 0 : la < lb;
   };
-  hv.root.assign(256, kNone);
+  std::vector<uint32_t> heap;                            // run numbers, the run whose current key is smallest on top
+  auto run_less = [&](uint32_t x, uint32_t y) { return less(runs[y].cur, runs[x].cur); };     // (std:: heaps are max-heaps)
+  for (uint32_t r = 0; r < runs.size(); r++) heap.push_back(r);
+  std::make_heap(heap.begin(), heap.end(), run_less);
+
+  t.n_info = n_info;
+  t.depth_of.assign(n_info, 0); t.byte_of.assign(n_info, 0); t.parent_of.assign(n_info, 0);
+  t.depth_of.reserve(hv.keys.size() / 2 + n_info); t.byte_of.reserve(hv.keys.size() / 2 + n_info); t.parent_of.reserve(hv.keys.size() / 2 + n_info);
+  for (auto& c : t.root_child) c = kNone;
+  std::vector<uint32_t> e_parent, e_kid;                 // edges in order of creation: per parent their bytes ascend
+  e_parent.reserve(hv.keys.size() / 2 + n_info); e_kid.reserve(hv.keys.size() / 2 + n_info);
+  uint32_t next_internal = n_info;
+  uint32_t path[41], path_ord[41];                       // node / key ordinal of the first d + 1 bytes of the key before
+  const uint8_t* prev = nullptr;
+  uint32_t prev_len = 0;
+  while (!heap.empty()) {
+    std::pop_heap(heap.begin(), heap.end(), run_less);
+    Run& r = runs[heap.back()];
+    const uint32_t i = r.cur++;
+    if (r.cur < r.end) std::push_heap(heap.begin(), heap.end(), run_less); else heap.pop_back();
+    const uint8_t* k = K + ko[i];
+    const uint32_t kl = ko[i + 1] - ko[i];
+    uint32_t common = 0;
+    while (common < prev_len && common < kl && k[common] == prev[common]) common++;
+    if (common == kl) return set_error(TM_E_INVALID, "record %u repeats a key", i);           // (equal keys: the order check of the records rules it out)
+    uint32_t node = common ? path[common - 1] : Trie::kRoot;
+    for (uint32_t d = common; d < kl; d++) {
+      uint32_t c;
+      if (d + 1 == kl) c = i;                            // the key's own node: its prefixes were visited before it, so it is new
+      else {
+        if (next_internal >= kMaxNodes) return set_error(TM_E_LIMIT, "vocabulary needs more than %u trie nodes", kMaxNodes);
+        c = next_internal++;
+        t.depth_of.push_back(0); t.byte_of.push_back(0); t.parent_of.push_back(0);
+      }
+      t.depth_of[c] = (uint8_t)(d + 1); t.byte_of[c] = k[d]; t.parent_of[c] = node;
+      if (node == Trie::kRoot) t.root_child[k[d]] = c;
+      else { e_parent.push_back(node); e_kid.push_back(((uint32_t)k[d] << 24) | c); }
+      path[d] = c; path_ord[d] = d + 1 == kl ? i : kNone;
+      node = c;
+    }
+    if (on_key) on_key->key(i, path_ord);
+    prev = k; prev_len = kl;
+  }
+  t.n_nodes = next_internal;
+  // children per node, bytes ascending (a stable counting sort of the edges by parent keeps the order of creation)
+  t.kid_start.assign((size_t)t.n_nodes + 1, 0);
+  for (uint32_t p : e_parent) t.kid_start[p + 1]++;
+  for (uint32_t n = 0; n < t.n_nodes; n++) t.kid_start[n + 1] += t.kid_start[n];
+  t.kid.resize(e_kid.size());
+  { std::vector<uint32_t> fill(t.kid_start.begin(), t.kid_start.end() - 1);
+    for (size_t q = 0; q < e_kid.size(); q++) t.kid[fill[e_parent[q]]++] = e_kid[q]; }
+  return TM_OK;
+}
+
+// ---- records + trie -> the tables of tm_tables.h -----------------------------------------------------------------------------------------
+int build_tables(HostVocab& hv, const Trie& t) {
+  StageTimer st;
+  const uint32_t n_info = hv.n_info, n_nodes = t.n_nodes;
+  const uint32_t kRoot = Trie::kRoot;
+  const std::vector<uint8_t>& depth_of = t.depth_of;
+  const std::vector<uint8_t>& flags = hv.rec_flag;
+  const std::vector<uint8_t>& nwords = hv.rec_nwords;
+  const std::vector<uint32_t>& ids = hv.rec_id;
+  auto klen = [&](uint32_t i) { return hv.key_off[i + 1] - hv.key_off[i]; };
+  // rows: first-token constants (tm_tables.h): allLetters + max0(nWords-1) + nWords*100 (+ the length, for the alternatives), alternatives resolved as Load does (go :2703-2712)
+  hv.rows.resize(n_info);
+  for (uint32_t i = 0; i < n_info; i++) {
+    const uint32_t flag = flags[i], nw = nwords[i], id = ids[i], index1 = hv.rec_index1[i], index2 = hv.rec_index2[i];
+    uint32_t id1 = 0, id2 = 0, len1 = 0, len2 = 0, nw1 = 0, nw2 = 0, fl1 = 0, fl2 = 0;
+    if (index1 != TM_NONE) { len1 = klen(index1); id1 = ids[index1]; nw1 = nwords[index1]; fl1 = flags[index1]; }
+    if (index2 != TM_NONE) { len2 = klen(index2); id2 = ids[index2]; nw2 = nwords[index2]; fl2 = flags[index2]; }
+    auto fconst = [](uint32_t fl, uint32_t nwk) { return ((fl >> 7) & 1u) + (nwk > 0 ? nwk - 1 : 0u) + nwk * 100u; };
+    Row& r = hv.rows[i];
+    r.x = id | (fconst(flag, nw) << kRowIdBits);
+    r.y = id1 | ((len1 ? len1 + fconst(fl1, nw1) : 0u) << kRowIdBits);
+    r.z = id2 | ((len2 ? len2 + fconst(fl2, nw2) : 0u) << kRowIdBits);
+    r.w = len1 | (len2 << 6) | ((flag & 1u) << 12) | ((fl1 & 1u) << 13) | ((fl2 & 1u) << 14) | (((flag >> 3) & 1u) << 15) | (((fl1 >> 3) & 1u) << 16) |
+          (((fl2 >> 3) & 1u) << 17) | ((nw >= 2 ? 1u : 0u) << 18) | ((nw1 >= 2 ? 1u : 0u) << 19) | ((nw2 >= 2 ? 1u : 0u) << 20) | (((flag >> 5) & 1u) << 21);
+  }
+  st.mark("rows");
+  std::vector<uint8_t> has_child(n_nodes, 0);
+  std::vector<uint32_t> cmask(n_nodes, 0);
   // child-byte filter of every node: bit (b & 31) is set if the node has a child over byte b.  A walk only probes for a byte
   // whose bit is set, so a probe that cannot hit (half of all positions end on one) is almost never issued: most nodes have one child.
-  std::vector<uint32_t> cmask(n_nodes, 0);
-  for (auto& kv : child) { const uint32_t parent = (uint32_t)(kv.first >> 8); if (parent != kRoot) cmask[parent] |= 1u << (kv.first & 31u); }
-  std::vector<uint32_t> by_depth(n_nodes);      // counting sort by depth (<= 40), also used for the suffix links below
+  for (uint32_t n = 0; n < n_nodes; n++) {
+    uint32_t m = 0;
+    for (uint32_t q = t.kid_start[n]; q < t.kid_start[n + 1]; q++) m |= 1u << ((t.kid[q] >> 24) & 31u);
+    cmask[n] = m;
+    has_child[n] = t.kid_start[n + 1] > t.kid_start[n];
+  }
+  std::vector<uint32_t> by_depth(n_nodes);      // counting sort by depth (<= 40): parents before children
   {
     uint32_t start[66] = {0};
     for (uint32_t i = 0; i < n_nodes; i++) start[depth_of[i] + 1]++;
@@ -274,6 +245,47 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     for (uint32_t i = 0; i < n_nodes; i++) by_depth[start[depth_of[i]]++] = i;
   }
   st.mark("filters, depth order");
+  // Forward-delete hint (tm_tables.h): can the walk of ' '+key (the probe of go :1088-1095) end on something longer than
+  // ' '+key itself?  Only then is the probe worth starting.  The hint rides in the begins-with-space bit of tokens that
+  // begin with a letter (the two are mutually exclusive in any vocabulary the reference's builder writes); if a file
+  // ever carries both bits on one record the hint is switched off and the kernels probe every eligible position.
+  // Where ' ' + s stands in the trie follows, for EVERY node s, from where ' ' + parent(s) stands (one child look-up per node instead of a
+  // walk per key): sp_node[s] = the node reached, sp_full[s] = all of s was consumed, sp_best[s] = the deepest accepting node on the way.
+  const uint32_t spl_off = hv.charset == 2 ? 2u : 1u;
+  uint32_t spl_start = t.root_child[' '];
+  if (spl_start != kNone && spl_off == 2) spl_start = t.find(spl_start, 0u);
+  std::vector<uint32_t> sp_node, sp_best;
+  std::vector<uint8_t> sp_full;
+  hv.spl_hint = 1;
+  for (uint32_t i = 0; i < n_info; i++) if ((flags[i] & 2u) && (flags[i] & 4u)) hv.spl_hint = 0;
+  if (spl_start != kNone) {
+    sp_node.assign(n_nodes, kNone); sp_best.assign(n_nodes, kNone); sp_full.assign(n_nodes, 0);
+    const uint32_t best0 = spl_start < n_info ? spl_start : kNone;
+    for (uint32_t n : by_depth) {
+      const uint32_t par = t.parent_of[n];
+      const uint32_t pn = par == kRoot ? spl_start : sp_node[par], pb = par == kRoot ? best0 : sp_best[par];
+      const bool pfull = par == kRoot ? true : sp_full[par] != 0;
+      uint32_t c = kNone;
+      if (pfull && depth_of[pn] < hv.max_len) c = t.find(pn, t.byte_of[n]);
+      if (c != kNone) { sp_node[n] = c; sp_full[n] = 1; sp_best[n] = c < n_info ? c : pb; }
+      else { sp_node[n] = pn; sp_full[n] = 0; sp_best[n] = pb; }
+    }
+  }
+  auto spl_cont = [&](uint32_t i) -> uint32_t { return (sp_full[i] && has_child[sp_node[i]] && depth_of[sp_node[i]] < hv.max_len) ? 1u : 0u; };
+  auto value_of = [&](uint32_t id) {
+    uint32_t v = id | (has_child[id] ? kHasChildren : 0);
+    if (id < n_info) {
+      uint32_t f5 = flag8_to_flag5(flags[id]);
+      if (hv.spl_hint && (f5 & 2u)) {
+        const bool hint = spl_start != kNone && (spl_cont(id) || (sp_best[id] != kNone && depth_of[sp_best[id]] > klen(id) + 1));
+        f5 = (f5 & ~4u) | (hint ? 4u : 0u);
+      }
+      v |= ((uint32_t)nwords[id] << 22) | (f5 << 27);
+    }
+    return v;
+  };
+  st.mark("space-prefix links");
+  hv.root.assign(256, kNone);
   // ---- the double array (tm_tables.h): a base for every node at depth >= 2 that has children, such that the entries base + b of
   // its children are free.  Parents are placed shallow first (the shallow end of the trie is where most walks are, and it ends up
   // together at the front of the array) by first fit from the lowest free entry; a parent that does not fit after a bounded number
@@ -282,18 +294,16 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   std::vector<uint32_t> base_of(n_nodes, 0);
   std::vector<uint4> da;
   {
-    std::vector<uint32_t> kid_start(n_nodes + 1, 0);             // children of every node at depth >= 2, as (byte, child) sorted by byte
-    for (auto& kv : child) if (depth_of[kv.second] >= 3) kid_start[(uint32_t)(kv.first >> 8) + 1]++;
-    for (uint32_t i = 0; i < n_nodes; i++) kid_start[i + 1] += kid_start[i];
-    const uint32_t n_edges = kid_start[n_nodes];
-    std::vector<uint32_t> kid(n_edges), fill(kid_start.begin(), kid_start.end() - 1);
-    for (auto& kv : child) if (depth_of[kv.second] >= 3) kid[fill[(uint32_t)(kv.first >> 8)]++] = ((uint32_t)(kv.first & 0xFF) << 24) | kv.second;
-    for (uint32_t n = 0; n < n_nodes; n++) if (kid_start[n + 1] - kid_start[n] > 1) std::sort(kid.begin() + kid_start[n], kid.begin() + kid_start[n + 1]);
+    const std::vector<uint32_t>& kid_start = t.kid_start;
+    const std::vector<uint32_t>& kid = t.kid;
+    size_t n_edges = 0;
+    for (uint32_t n = 0; n < n_nodes; n++) if (depth_of[n] >= 2) n_edges += kid_start[n + 1] - kid_start[n];
     const uint32_t first = 256;                                  // entries below stay empty: base = entry - byte is never negative
-    std::vector<uint8_t> used((size_t)n_edges + n_edges / 4 + 1024, 0);
+    std::vector<uint8_t> used(n_edges + n_edges / 4 + 1024, 0);
     uint32_t cursor = first, frontier = first;                    // lowest free entry / one past the highest used one
     auto grow = [&](size_t need) { if (need > used.size()) used.resize(need + need / 4, 0); };
     for (uint32_t n : by_depth) {
+      if (depth_of[n] < 2) continue;
       const uint32_t k0 = kid_start[n], k1 = kid_start[n + 1];
       if (k0 == k1) continue;
       const uint32_t b_lo = kid[k0] >> 24, span = (kid[k1 - 1] >> 24) - b_lo;
@@ -314,11 +324,13 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     }
     hv.n_da = frontier + 256;                                    // base + 255 stays inside for every base
     da.assign((size_t)hv.n_da + 1, uint4{kNone, kNone, 0u, 0u});
-    for (uint32_t n = 0; n < n_nodes; n++)
+    for (uint32_t n = 0; n < n_nodes; n++) {
+      if (depth_of[n] < 2) continue;
       for (uint32_t q = kid_start[n]; q < kid_start[n + 1]; q++) {
         const uint32_t c = kid[q] & 0xFFFFFFu;
         da[base_of[n] + (kid[q] >> 24)] = uint4{n, value_of(c), cmask[c], base_of[c]};
       }
+    }
   }
   st.mark("double array");
   hv.idle_off = hv.n_da * 16u;
@@ -330,10 +342,13 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
   hv.tab.assign(link_base + 2 * (size_t)n_nodes, uint2{kNone, kNone});
   memcpy(hv.tab.data(), da.data(), da.size() * sizeof(uint4));
   std::vector<uint32_t> l2v(kL2Size, kNone);       // value of the depth-2 node b0b1
-  std::vector<uint32_t> first_byte(n_nodes, 0);   // for depth-1 nodes: their byte, to index l2
-  for (auto& kv : child) if (depth_of[kv.second] == 1) { hv.root[kv.first & 0xFF] = value_of(kv.second); first_byte[kv.second] = (uint32_t)(kv.first & 0xFF); }
-  for (auto& kv : child) if (depth_of[kv.second] == 2) l2v[(first_byte[(uint32_t)(kv.first >> 8)] << 8) | (uint32_t)(kv.first & 0xFF)] = value_of(kv.second);
-  st.mark("direct map prep");
+  for (uint32_t b0 = 0; b0 < 256; b0++) {
+    const uint32_t c1 = t.root_child[b0];
+    if (c1 == kNone) continue;
+    hv.root[b0] = value_of(c1);
+    for (uint32_t q = t.kid_start[c1]; q < t.kid_start[c1 + 1]; q++) l2v[(b0 << 8) | (t.kid[q] >> 24)] = value_of(t.kid[q] & 0xFFFFFFu);
+  }
+  st.mark("table layout, depth 1 and 2");
   // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.
   // link(n) follows from link(parent(n)) as in Aho-Corasick, in order of depth; best[m] = deepest accepting node on the
   // path root..m.  Only links of nodes at depth >= 3 are ever read by the kernels.
@@ -343,13 +358,13 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     std::vector<uint8_t> lfull(n_nodes, 0);
     auto depth_at = [&](uint32_t n) -> uint32_t { return n == kRoot ? 0u : depth_of[n]; };
     for (uint32_t n : by_depth) {
-      const uint32_t par = parent_of[n];
+      const uint32_t par = t.parent_of[n];
       best[n] = n < n_info ? n : (par == kRoot ? kNone : best[par]);
       if (par == kRoot) { lnode[n] = kRoot; lfull[n] = 1; continue; }                 // s[1:] is empty
       const uint32_t pm = lnode[par];
       if (!lfull[par]) { lnode[n] = pm; lfull[n] = 0; continue; }                     // already fell off the trie
-      const uint32_t* it = child.find(((uint64_t)pm << 8) | byte_of[n]);
-      if (!it) { lnode[n] = pm; lfull[n] = 0; } else { lnode[n] = *it; lfull[n] = 1; }
+      const uint32_t c = t.find(pm, t.byte_of[n]);
+      if (c == kNone) { lnode[n] = pm; lfull[n] = 0; } else { lnode[n] = c; lfull[n] = 1; }
     }
     uint2* lt = hv.tab.data() + link_base;
     for (uint32_t n = 0; n < n_nodes; n++) {
@@ -367,22 +382,24 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     for (uint32_t i = 0; i < n_info; i++) last[ids[i]] = i;
     hv.rev_off.assign((size_t)hv.n_ids + 1, 0);
     hv.rev_bytes.clear();
+    hv.rev_bytes.reserve(hv.keys.size());
     for (uint32_t id = 0; id < hv.n_ids; id++) {
       hv.rev_off[id] = (uint32_t)hv.rev_bytes.size();
       if (last[id] != kNone) hv.rev_bytes.insert(hv.rev_bytes.end(), hv.keys.begin() + hv.key_off[last[id]], hv.keys.begin() + hv.key_off[last[id] + 1]);
     }
     hv.rev_off[hv.n_ids] = (uint32_t)hv.rev_bytes.size();
   }
-  st.mark("reverse table");
-  // space-prefix links (walked above): x = node reached | continue << 21 | best accepting depth << 22, y = that node's value
+  // space-prefix links: x = node reached | continue << 21 | best accepting depth << 22, y = that node's value
   hv.vals.resize(n_info);
   for (uint32_t i = 0; i < n_info; i++) hv.vals[i] = value_of(i);
   hv.spl.assign(n_info, uint4{kNone, 0u, 0u, 0u});
   if (spl_start != kNone)
-    for (uint32_t i = 0; i < n_info; i++)
-      hv.spl[i] = uint4{splw[i].node | (splw[i].cont << 21) | (splw[i].bestlen << 22), splw[i].best != kNone ? value_of(splw[i].best) : 0u,
-                        splw[i].cont ? cmask[splw[i].node] : 0u, splw[i].cont ? base_of[splw[i].node] : 0u};
-  st.mark("vals, spl");
+    for (uint32_t i = 0; i < n_info; i++) {
+      const uint32_t cont = spl_cont(i), bestn = sp_best[i];
+      hv.spl[i] = uint4{sp_node[i] | (cont << 21) | ((bestn != kNone ? (uint32_t)depth_of[bestn] : 0u) << 22), bestn != kNone ? value_of(bestn) : 0u,
+                        cont ? cmask[sp_node[i]] : 0u, cont ? base_of[sp_node[i]] : 0u};
+    }
+  st.mark("reverse, values, space-prefix entries");
   // direct map: one 16-byte entry (same format as a suffix link) resolves the first two bytes of any walk, the
   // depth-1 answer folded in
   for (uint32_t b0 = 0; b0 < 256; b0++) {
@@ -412,6 +429,42 @@ int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
     hv.bstart = (v2 != kNone && (v2 & kHasChildren)) ? (node_id(v2) | kHasChildren) : kNone;
   }
   return TM_OK;
+}
+
+int parse_vocab(const uint8_t* f, size_t n, HostVocab& hv) {
+  StageTimer st;
+  int rc = parse_records(f, n, hv);
+  if (rc != TM_OK) return rc;
+  st.mark("records");
+  Trie t;
+  if ((rc = build_trie(hv, t, nullptr)) != TM_OK) return rc;
+  st.mark("trie");
+  return build_tables(hv, t);
+}
+
+// go/tokenmonster.go:2602-2653 (Save): the records back in the layout of SURVEY.md Appendix A
+const std::vector<uint8_t>& vocab_image(const HostVocab& hv) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> g(mu);
+  if (!hv.image.empty() || hv.key_off.empty()) return hv.image;
+  std::vector<uint8_t>& o = hv.image;
+  auto w24 = [&](uint32_t v) { o.push_back((uint8_t)v); o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)(v >> 16)); };
+  o.reserve(24 + hv.keys.size() + (size_t)hv.n_info * 16 + 300);
+  o.push_back(hv.capcode); o.push_back(hv.charset); o.push_back(hv.norm_flag); o.push_back(hv.level); o.push_back(hv.reserve); o.push_back(0); o.push_back(0); o.push_back(0);
+  w24(hv.unk); w24(hv.vocab_size); w24(hv.n_ids); w24(hv.n_info); w24(hv.delete_id);
+  o.push_back((uint8_t)hv.max_len);
+  for (uint32_t i = 0; i < hv.n_info; i++) {
+    const uint32_t kl = hv.key_off[i + 1] - hv.key_off[i];
+    o.push_back((uint8_t)kl);
+    o.insert(o.end(), hv.keys.begin() + hv.key_off[i], hv.keys.begin() + hv.key_off[i + 1]);
+    o.push_back(hv.rec_flag[i]); o.push_back(hv.rec_nwords[i]);
+    w24(hv.rec_index1[i]); w24(hv.rec_index2[i]); w24(hv.rec_id[i]);
+    uint32_t b; std::memcpy(&b, &hv.rec_score[i], 4);
+    o.push_back((uint8_t)b); o.push_back((uint8_t)(b >> 8)); o.push_back((uint8_t)(b >> 16)); o.push_back((uint8_t)(b >> 24));
+  }
+  o.insert(o.end(), hv.begin_byte, hv.begin_byte + 256);
+  w24(0);                                                      // deleted tokens: this library keeps none
+  return o;
 }
 
 }  // namespace tmh
@@ -512,6 +565,8 @@ int tm_vocab_load_on(const uint8_t* vocab_file, size_t n, int device, tm_vocab**
   return rc == TM_OK ? tm_vocab_load(vocab_file, n, out) : rc;
 }
 
+static int upload_tables(tm_vocab* v);
+
 int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   if (!vocab_file || !out) return set_error(TM_E_INVALID, "null argument");
   *out = nullptr;
@@ -519,6 +574,37 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   int rc = parse_vocab(vocab_file, n, v->host);
   if (rc != TM_OK) { delete v; return rc; }
   v->host.image.assign(vocab_file, vocab_file + n);
+  if ((rc = upload_tables(v)) != TM_OK) return rc;       // (frees v on failure)
+  *out = v;
+  return TM_OK;
+}
+
+// A candidate of the trainvocab loop (training/trainvocab.go:530-907 builds the tables of every candidate in place): token list ->
+// records + trie (tm_build.cpp) -> tables -> device, without the .vocab image in between that tm_build_vocab + tm_vocab_load write and
+// parse again.  Same tables, bit for bit, as loading the image tm_build_vocab makes of the same list (tests/test_builder_normalizer.py).
+int tm_vocab_build(const uint8_t* blob, const uint32_t* off, uint32_t n_tokens, const uint8_t* special, uint32_t capcode, uint32_t charset, uint32_t norm_flag,
+                   uint32_t level, int with_unk, int device, tm_vocab** out) {
+  if (!out || (n_tokens && (!blob || !off))) return set_error(TM_E_INVALID, "null argument");
+  *out = nullptr;
+  { const int rc = tm_set_device(device); if (rc != TM_OK) return rc; }
+  std::vector<std::string> toks(n_tokens);
+  std::vector<uint8_t> sp(special ? n_tokens : 0, 0);
+  for (uint32_t k = 0; k < n_tokens; k++) {
+    toks[k].assign((const char*)blob + off[k], off[k + 1] - off[k]);
+    if (special) sp[k] = special[k];
+  }
+  auto* v = new tm_vocab();
+  Trie trie;
+  int rc = build_vocab_records(toks, sp, capcode, charset, norm_flag, level, with_unk != 0, v->host, trie);
+  if (rc == TM_OK) rc = build_tables(v->host, trie);
+  if (rc != TM_OK) { delete v; return rc; }
+  if ((rc = upload_tables(v)) != TM_OK) return rc;
+  *out = v;
+  return TM_OK;
+}
+
+// the tables of v->host into ONE device block on the current device; deletes v on failure
+static int upload_tables(tm_vocab* v) {
   HostVocab& hv = v->host;
   hipError_t e;
   int dev = 0;
@@ -555,7 +641,6 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
     return hip_fail(e, "vocabulary upload");
   }
   set_tables(v);
-  *out = v;
   return TM_OK;
 }
 
@@ -579,7 +664,7 @@ int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* m, void** device_pt
 
 int tm_device_copy(void* dst_device, const void* src_device, uint64_t bytes) {
   if (bytes && (!dst_device || !src_device)) return set_error(TM_E_INVALID, "null argument");
-  const hipError_t e = bytes ? hipMemcpy(dst_device, src_device, bytes, hipMemcpyDeviceToDevice) : hipSuccess;
+  const hipError_t e = bytes ? hipMemcpy(dst_device, src_device, bytes, hipMemcpyDefault) : hipSuccess;      // (unified addressing: either side may also be page-locked host memory)
   return e == hipSuccess ? TM_OK : hip_fail(e, "device-to-device copy");
 }
 

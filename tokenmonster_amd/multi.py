@@ -53,6 +53,18 @@ class VocabSet:
         buf = np.frombuffer(bytes(image), dtype=np.uint8)
         N.check(N.lib.tm_vocab_load_all(devices.handle, N.ptr(buf), buf.size, C.byref(self._h)))
 
+    @classmethod
+    def from_tokens(cls, devices, tokens, capcode=0, charset=1, norm_flag=0, level=5, with_unk=False):
+        """tm_vocab_build_all: a candidate's tables built once from its token list, the device block replicated to every member"""
+        tokens = [bytes(t) for t in tokens]
+        blob = np.frombuffer(b"".join(tokens), dtype=np.uint8) if tokens else np.zeros(0, np.uint8)
+        off = np.zeros(len(tokens) + 1, dtype=np.uint32)
+        np.cumsum([len(t) for t in tokens], out=off[1:])
+        s = cls.__new__(cls)
+        s.devices, s._h = devices, C.c_void_p()
+        N.check(N.lib.tm_vocab_build_all(devices.handle, N.ptr(blob), N.ptr(off), len(tokens), None, capcode, charset, norm_flag, level, 1 if with_unk else 0, C.byref(s._h)))
+        return s
+
     handle = property(lambda self: self._h)
 
     def member(self, i):

@@ -54,6 +54,27 @@ class Vocab:
         v._image, v._h = b"", h
         return v, int(p.value), int(m.bytes)
 
+    @classmethod
+    def from_tokens(cls, tokens, capcode=0, charset=1, norm_flag=0, level=5, with_unk=False, special=None, device=0):
+        """a vocabulary straight from a token list (tm_vocab_build: the trainvocab worker's per-candidate step, training/trainvocab.go:530-907),
+        without the .vocab image in between; `image()` writes it on request"""
+        tokens = [bytes(t) for t in tokens]
+        blob = np.frombuffer(b"".join(tokens), dtype=np.uint8) if tokens else np.zeros(0, np.uint8)
+        off = np.zeros(len(tokens) + 1, dtype=np.uint32)
+        np.cumsum([len(t) for t in tokens], out=off[1:])
+        sp = None if special is None else np.ascontiguousarray(np.asarray(special, dtype=np.uint8))
+        h = C.c_void_p()
+        N.check(N.lib.tm_vocab_build(N.ptr(blob), N.ptr(off), len(tokens), N.ptr(sp), capcode, charset, norm_flag, level, 1 if with_unk else 0, int(device), C.byref(h)))
+        v = cls.__new__(cls)
+        v._image, v._h = b"", h
+        return v
+
+    def image(self):
+        """the bytes of the .vocab file of this vocabulary (tm_vocab_image)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        N.check(N.lib.tm_vocab_image(self._h, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value)
+
     def close(self):
         if getattr(self, "_h", None):
             N.lib.tm_vocab_free(self._h)

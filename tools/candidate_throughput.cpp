@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
   if (tm_dataset_upload(text, off[nd], &ds) != 0) { fprintf(stderr, "upload: %s\n", tm_last_error()); return 1; }
   printf("dataset %.1f MB normalized; %zu single-byte + %zu longer tokens\n", off[nd] / 1e6, singles.size(), multi.size());
 
+  bool via_image = false;
   auto one = [&](int k, double* t) -> uint64_t {
     // a candidate set like trainvocab's (:2250-2263): the single bytes + a random 97 % of the other tokens
     double t0 = now();
@@ -67,13 +68,19 @@ int main(int argc, char** argv) {
     auto add = [&](const std::string& tk) { blob.insert(blob.end(), tk.begin(), tk.end()); o.push_back((uint32_t)blob.size()); };
     for (auto& tk : singles) add(tk);
     for (auto& tk : multi) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; if ((s >> 11) % 100 < 97) add(tk); }
-    uint8_t* im = nullptr; size_t im_n = 0;
-    if (tm_build_vocab(blob.data(), o.data(), (uint32_t)o.size() - 1, nullptr, 2, 1, 1, 5, 0, &im, &im_n) != 0) { fprintf(stderr, "build: %s\n", tm_last_error()); exit(1); }
-    double t1 = now();
     tm_vocab* v = nullptr;
-    if (tm_vocab_load(im, im_n, &v) != 0) { fprintf(stderr, "load: %s\n", tm_last_error()); exit(1); }
-    tm_free(im);
-    double t2 = now();
+    double t1, t2;
+    if (via_image) {             // rounds 2-3: the .vocab image in between
+      uint8_t* im = nullptr; size_t im_n = 0;
+      if (tm_build_vocab(blob.data(), o.data(), (uint32_t)o.size() - 1, nullptr, 2, 1, 1, 5, 0, &im, &im_n) != 0) { fprintf(stderr, "build: %s\n", tm_last_error()); exit(1); }
+      t1 = now();
+      if (tm_vocab_load(im, im_n, &v) != 0) { fprintf(stderr, "load: %s\n", tm_last_error()); exit(1); }
+      tm_free(im);
+      t2 = now();
+    } else {                     // token list -> tables -> device in one call
+      if (tm_vocab_build(blob.data(), o.data(), (uint32_t)o.size() - 1, nullptr, 2, 1, 1, 5, 0, 0, &v) != 0) { fprintf(stderr, "build: %s\n", tm_last_error()); exit(1); }
+      t1 = t2 = now();
+    }
     std::vector<uint32_t> scores(tm_vocab_n_ids(v));
     uint64_t tit = 0; uint8_t ms[32];
     if (tm_score(v, ds, nullptr, nullptr, 0, scores.data(), &tit, ms) != 0) { fprintf(stderr, "score: %s\n", tm_last_error()); exit(1); }
@@ -84,9 +91,16 @@ int main(int argc, char** argv) {
   };
   one(0, nullptr);
   double t[3] = {0, 0, 0};
+  via_image = true;
+  one(0, nullptr);
   for (int k = 0; k < 4; k++) one(k, t);
-  printf("one candidate (about 63 600 ids): tm_build_vocab %.1f ms, tm_vocab_load %.1f ms, tm_score %.1f ms  -> build + load = %.2f x the scoring pass\n",
+  printf("one candidate (about 63 600 ids), through the .vocab image: tm_build_vocab %.1f ms, tm_vocab_load %.1f ms, tm_score %.1f ms  -> build + load = %.2f x the scoring pass\n",
          t[0] / 4 * 1e3, t[1] / 4 * 1e3, t[2] / 4 * 1e3, (t[0] + t[1]) / t[2]);
+  via_image = false;
+  t[0] = t[1] = t[2] = 0;
+  for (int k = 0; k < 4; k++) one(k, t);
+  printf("one candidate (about 63 600 ids), tm_vocab_build (token list -> tables -> device): %.1f ms, tm_score %.1f ms  -> build = %.2f x the scoring pass\n",
+         t[0] / 4 * 1e3, t[2] / 4 * 1e3, t[0] / t[2]);
   for (int nt = 1; nt <= maxt; nt *= 2) {
     std::atomic<int> next{0};
     const double t0 = now();
@@ -116,9 +130,7 @@ int main(int argc, char** argv) {
       auto add = [&](const std::string& tk) { blob.insert(blob.end(), tk.begin(), tk.end()); o.push_back((uint32_t)blob.size()); };
       for (auto& tk : singles) add(tk);
       for (auto& tk : multi) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; if ((s >> 11) % 100 < 97) add(tk); }
-      uint8_t* im = nullptr; size_t im_n = 0;
-      if (tm_build_vocab(blob.data(), o.data(), (uint32_t)o.size() - 1, nullptr, 2, 1, 1, 5, 0, &im, &im_n) != 0 || tm_vocab_load(im, im_n, out) != 0) { fprintf(stderr, "build/load: %s\n", tm_last_error()); exit(1); }
-      tm_free(im);
+      if (tm_vocab_build(blob.data(), o.data(), (uint32_t)o.size() - 1, nullptr, 2, 1, 1, 5, 0, 0, out) != 0) { fprintf(stderr, "build: %s\n", tm_last_error()); exit(1); }
     };
     // (1) how fast the host turns out candidates, GPU otherwise idle
     for (int nt = 1; nt <= maxt; nt *= 2) {
@@ -127,7 +139,7 @@ int main(int argc, char** argv) {
       std::vector<std::thread> th;
       for (int i = 0; i < nt; i++) th.emplace_back([&] { for (;;) { int k = next.fetch_add(1); if (k >= ncand) break; tm_vocab* v = nullptr; build_load(k, &v); tm_vocab_free(v); } });
       for (auto& x : th) x.join();
-      printf("build + load only, %2d host threads: %5.1f candidates/s\n", nt, ncand / (now() - t0));
+      printf("tm_vocab_build only, %2d host threads: %5.1f candidates/s\n", nt, ncand / (now() - t0));
     }
     // (2) one candidate through all ranks: what the ranks that did NOT build it pay, and the pass over a range
     double t_imp = 0, t_pass = 0, t_first = 0, block_mb = 0;
