@@ -67,6 +67,33 @@ for (let i = 0; i < 6300; i++) {
   inputs.push(s);
 }
 
+// round 4: the scripts the device normalizer / decoder took over from the host - Cyrillic and Greek (case, letters that decompose into a
+// two-byte letter + mark: й ё Й ά ώ ΐ), Hebrew and Arabic with their points, Arabic-Indic digits, Chinese, kana (voiced kana decompose),
+// Hangul - appended BEHIND the cases above so that those stay what they were
+const cyr = 'абвгдежзийклмнопрстуфхцчшщъыьэюяёАБВГДЕЖЗИЙКЛМНОПРСТУФХЦЧШЩЪЫЬЭЮЯЁѐѝЍї'.split('');
+const grk = 'αβγδεζηθικλμνξοπρστυφχψωςάέήίόύώϊϋΐΰΑΒΓΔΕΖΗΘΙΚΛΜΝΞΟΠΡΣΤΥΦΧΨΩΆΈΉΊΌΎΏ'.split('');
+const heb = 'אבגדהוזחטיכלמנסעפצקרשתךםןףץ'.split('').concat(['ְ', 'ִ', 'ֵ', 'ָ', 'ּ']);
+const arb = 'ابتثجحخدذرزسشصضطظعغفقكلمنهوي'.split('').concat(['َ', 'ُ', 'ِ', 'ّ', '٠', '١', '٢', '٣', '٩', 'آ', 'أ', 'ؤ']);
+const cjk = '中文字符测试世界你好日本語漢字東京大学人工智能，。、「」！？（）'.split('');
+const kana = 'あいうえおかきくけこさしすせそたちつてとなにぬねのはひふへほまみむめもやゆよらりるれろわをんアイウエオカキクケコガギグゲゴパピプペポばびぶべぼーっッ'.split('');
+const hangul = '한국어텍스트가나다'.split('');
+const flavours4 = [
+  () => pick([cyr, cyr, lower, upper, [' '], [' '], digits, apos, punct]),
+  () => pick([grk, grk, lower, upper, [' '], [' '], digits, apos, marks]),
+  () => pick([heb, arb, lower, upper, [' '], digits, punct]),
+  () => pick([cjk, cjk, kana, lower, upper, [' '], digits, gpunct]),
+  () => pick([cyr, grk, cjk, kana, hangul, heb, arb, lower, upper, [' '], apos, digits, marks]),
+];
+['Привет, Мир! Ёжик и йод. МОСКВА', 'Καλημέρα κόσμε. ΑΘΗΝΑ ά ώ ΐ Σίσυφος ΟΔΟΣ', 'שלום עולם בְּרֵאשִׁית', 'مرحبا بالعالم ١٢٣ كِتَاب', '中文文本，测试。Hello世界 ABC中文',
+ 'こんにちは世界 カタカナ がぎぐ パピプ', '한국어 텍스트', 'Йод йод ЙОД', "ДОН'Т д'Артаньян", 'x1Й2й3'].forEach(s => inputs.push(s));
+for (let i = 0; i < 3000; i++) {
+  const f = flavours4[i % flavours4.length];
+  const n = rnd(rnd(4) === 0 ? 90 : 28);
+  let s = '';
+  for (let k = 0; k < n; k++) s += pick(f());
+  inputs.push(s);
+}
+
 const b64 = s => Buffer.from(s, 'utf8').toString('base64');
 const cases = inputs.map(s => {
   const nfd = s.normalize('NFD');

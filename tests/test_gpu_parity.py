@@ -664,3 +664,54 @@ def test_european_text_stays_on_the_device():
             gotids = v.tokenize(docs[:200])
             for k in range(200):
                 assert (gotids[k] == ids[int(toff[k]):int(toff[k + 1])]).all()
+
+
+def multilingual_corpus(rng, nbytes):
+    """synthetic Russian / Greek / Chinese / Japanese / Hebrew / Arabic running text with English mixed in: two-byte scripts with case
+    and decomposing letters (й ё Й, ά ώ), combining marks, CJK ideographs and kana; a few percent of the documents carry what the device
+    leaves to the host (Hangul, voiced kana, emoji, Latin Extended Additional)"""
+    ru = "Привет мир Москва Россия Ёжик йод объём СЪЕЗД Киев Санкт-Петербург это русский текст и ещё й ЙОД".split()
+    el = "Καλημέρα κόσμε Αθήνα Ελλάδα ΑΘΗΝΑ ά έ ή ί ό ύ ώ Ώρα το και είναι ελληνικό κείμενο".split()
+    zh = ["中文", "文本", "测试", "世界", "你好", "数据", "模型", "，", "。", "ABC", "GPU"]
+    ja = ["こんにちは", "世界", "カタカナ", "ひらかな", "テスト", "日本", "の", "は", "、", "。", "Tokyo"]
+    he = "שלום עולם זה טקסט בעברית".split()
+    ar = "مرحبا بالعالم هذا نص عربي ١٢٣".split()
+    en = "the quick Brown FOX jumps over 13 lazy dogs it's NASA's iPhone".split()
+    host_only = ["한국어", "がぎぐ", "😀", "Ḁḁ", "ΐ"]
+    langs = [ru, el, zh, ja, he, ar]
+    docs, total = [], 0
+    while total < nbytes:
+        n = int(rng.integers(3, 300))
+        lang = langs[int(rng.integers(0, len(langs)))]
+        ws = [str(rng.choice(lang if rng.random() < 0.8 else en)) for _ in range(n)]
+        if rng.random() < 0.03:
+            ws.insert(int(rng.integers(0, n)), str(rng.choice(host_only)))
+        sep = "" if lang in (zh, ja) else " "
+        d = (sep.join(ws) + str(rng.choice([".", "!", "", "…"]))).encode()
+        docs.append(d)
+        total += len(d)
+    return docs
+
+
+def test_multilingual_text_stays_on_the_device():
+    """the device normalizer beyond Latin (go/tokenmonster.go:233-253; classes javascript/tokenmonster.js:880-898): every two-byte script
+    (Greek, Cyrillic, Hebrew, Arabic ...: NFD, case and capcode from a 1 920-entry table the HOST normalizer fills) and the three-byte
+    characters the normalizer leaves alone (CJK ideographs, most kana: two bits per code point, from the host's functions too).  The bytes
+    must equal the host normalizer's and >= 95 % of the documents must have stayed on the device; the ids of the whole raw path equal
+    the ids of the host-normalized text."""
+    rng = np.random.default_rng(2025)
+    docs = multilingual_corpus(rng, 200_000 if EMULATED else 6_000_000)
+    raw, offs = tm.pack_documents(docs)
+    for capcode, flag in ((2, 1), (2, 3), (0, 0)):
+        v = tm.Vocab(synth.build_vocab([bytes([c]) for c in range(256)], capcode=capcode, charset=1, norm_flag=flag))
+        got, goff, nfb = v.normalize_packed_device(raw, offs)
+        exp, eoff = synth.normalize_batch(raw, offs, capcode, flag)
+        assert (goff == eoff).all() and got.size == exp.size
+        assert (got == exp).all(), "capcode %d flag %d" % (capcode, flag)
+        assert nfb <= len(docs) // 20, "%d of %d documents took the host path (capcode %d flag %d)" % (nfb, len(docs), capcode, flag)
+        if capcode == 2 and flag == 1:
+            ids, toff, _ = v.tokenize_packed(exp, eoff)
+            nchk = min(200, len(docs))
+            gotids = v.tokenize(docs[:nchk])
+            for k in range(nchk):
+                assert (gotids[k] == ids[int(toff[k]):int(toff[k + 1])]).all()

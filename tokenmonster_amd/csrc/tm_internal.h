@@ -20,7 +20,8 @@ int build_vocab_image(const std::vector<std::string>& tokens, const std::vector<
 
 // tm_normalize.cpp
 struct NmTwo;
-void build_two_table(uint32_t norm_flag, NmTwo* out);     // 256 entries: the device normalizer's table of the two-byte characters (tm_norm_masks.h)
+void build_two_table(uint32_t norm_flag, NmTwo* out);     // NM_TWO_SIZE entries: the device normalizer's table of the two-byte characters (tm_norm_masks.h)
+void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cp);    // NM_BLK_WORDS + NM_CP_WORDS words: the three-byte characters it passes through
 void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out);
 
 int normalize_batch_into(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t norm_flag,

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -51,17 +52,23 @@ __device__ __forceinline__ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
 __device__ __forceinline__ bool nblock(uint32_t cls) { return (cls & NF_BLOCK) != 0; }       // capital, digit, apostrophe, combining mark
 
 struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
-// the table of the two-byte characters (tm_norm_masks.h: NmTwo), 2 KB, staged by the 256 work-items of a workgroup
-__device__ __forceinline__ void stage_two(NmTwo* s_two, const NmTwo* __restrict__ two) {
-  static_assert(NM_TWO_SIZE == 256, "one entry per work-item");
-  s_two[threadIdx.x] = two[threadIdx.x];
+// The normalizer's tables in ONE device buffer (tm_norm_masks.h): NmTwo[NM_TWO_SIZE] | block codes [NM_BLK_WORDS] | code-point codes
+// [NM_CP_WORDS].  The 256 work-items of a workgroup stage the entries of U+0080..U+017F (2 KB) and the block codes (256 bytes) in LDS.
+constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS) * sizeof(uint32_t);
+struct TabLds { NmTwo two[NM_TWO_FAST]; uint32_t blk[NM_BLK_WORDS]; };
+__device__ __forceinline__ NmTabs stage_tabs(TabLds& s, const NmTwo* __restrict__ two) {
+  static_assert(NM_TWO_FAST == 256 && NM_BLK_WORDS <= 256, "one entry per work-item");
+  const uint32_t* blk = reinterpret_cast<const uint32_t*>(two + NM_TWO_SIZE);
+  s.two[threadIdx.x] = two[threadIdx.x];
+  if (threadIdx.x < NM_BLK_WORDS) s.blk[threadIdx.x] = blk[threadIdx.x];
+  return NmTabs{s.two, two, s.blk, blk + NM_BLK_WORDS};
 }
 
 // stage the piece (+ margins) and classify every byte; continuation bytes inherit the class of their lead byte.
 // returns the piece length; LDS index of document byte (pb + i) is PMARGIN + i.
 template <typename LDS>
 __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict__ raw, uint64_t rb, uint64_t re, uint64_t pb, int lane,
-                                               const uint8_t* s_cls, const NmTwo* s_two) {
+                                               const uint8_t* s_cls, const NmTabs& tabs) {
   for (int i = lane; i < PLDS / 4; i += 64) {
     const int64_t g = (int64_t)pb - PMARGIN + 4 * i;
     uint32_t wv = 0;
@@ -89,7 +96,7 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
         uint32_t fl = 0;                                    // (the two bytes at either end of the staged range are never looked at)
         if (b < 0x80u) fl = s_cls[b];                       // class of an ASCII byte: one LDS read instead of five range checks
         else if (x >= 2 && x < PLDS - 2) {
-          fl = nm_classify_high(b, L.raw[x - 1], L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], s_two);     // two-byte Latin, three-byte punctuation, or NF_BAD
+          fl = nm_classify_high(b, L.raw[x - 1], L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], tabs);     // a two-byte character, a three-byte one the pass leaves alone, or NF_BAD
         }
         f4 |= fl << (8 * q);
       }
@@ -108,9 +115,9 @@ __global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict_
                                                       const NmTwo* __restrict__ two, uint32_t* __restrict__ piece_sum) {
   __shared__ PieceLds s_l[4];
   __shared__ uint8_t s_cls[128];
-  __shared__ NmTwo s_two[NM_TWO_SIZE];
+  __shared__ TabLds s_tab;
   if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
-  stage_two(s_two, two);
+  const NmTabs tabs = stage_tabs(s_tab, two);
   __syncthreads();
   // (wave-uniform wavefront index: the run bookkeeping below is arithmetic on ballots and then runs on the scalar unit)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict_
   PieceLds& L = s_l[wv];
   const uint32_t d = piece_doc[k];
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, s_two));
+  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, tabs));
   bool lead_open = true, lead_tl = false, bad = false;
   uint32_t lead_u = 0, trail_u = 0;
   for (int c = 0; c * 64 < m; c++) {
@@ -197,9 +204,9 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
   constexpr bool WRITE = MODE != 0;
   __shared__ PieceLds s_l[4];
   __shared__ uint8_t s_cls[128];
-  __shared__ NmTwo s_two[NM_TWO_SIZE];
+  __shared__ TabLds s_tab;
   if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
-  stage_two(s_two, two);
+  const NmTabs tabs = stage_tabs(s_tab, two);
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
@@ -208,18 +215,18 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
   const uint32_t d = piece_doc[k];
   if (need_host[d]) { if (MODE != 1 && lane == 0) piece_len[k] = 0; return; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls, s_two);
+  const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls, tabs);
   uint8_t* dst = MODE == 1 ? out + piece_off[k] : (MODE == 2 ? out + k * (uint64_t)SLAB : nullptr);
   if (capcode != 2) {                                       // no capcode: same length, only the lower-case flag applies
     if (MODE != 1 && lane == 0) piece_len[k] = (uint32_t)m;
     if (WRITE) for (int i = lane; i < m; i += 64) {
       const int x = PMARGIN + i;
-      uint32_t b = L.raw[x], y = 0;
+      uint32_t b = L.raw[x], y = 0, m3 = 0;
       if (lower_all && b - 'A' < 26u) b |= 0x20u;
       const uint32_t bm1 = L.raw[x - 1];
       // (a two-byte character that stays one: its bytes under the vocabulary's flags; those that decompose are not in this table)
-      if (nm_two_lead(b)) nm_two_out(s_two[nm_two_index(b, L.raw[x + 1])], false, false, false, &b, &y);
-      else if (nm_cont_byte(b) && nm_two_lead(bm1)) nm_two_out(s_two[nm_two_index(bm1, b)], true, false, false, &b, &y);
+      if (nm_two_lead(b)) (void)nm_two_out(nm_two_get(tabs, nm_two_index(b, L.raw[x + 1])), false, false, false, &b, &y, &m3);
+      else if (nm_cont_byte(b) && nm_two_lead(bm1)) (void)nm_two_out(nm_two_get(tabs, nm_two_index(bm1, b)), true, false, false, &b, &y, &m3);
       dst[i] = (uint8_t)b;
     }
     return;
@@ -301,9 +308,10 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
       const uint32_t bm1 = L.raw[x - 1];
       const bool lead2 = nm_two_lead(b), cont2 = nm_cont_byte(b) && nm_two_lead(bm1);
       if (lead2 || cont2) {
-        const NmTwo e = s_two[lead2 ? nm_two_index(b, L.raw[x + 1]) : nm_two_index(bm1, b)];
-        uint32_t y = 0;
-        if (nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y)) { len = 2; o2 = y; }
+        const NmTwo e = nm_two_get(tabs, lead2 ? nm_two_index(b, L.raw[x + 1]) : nm_two_index(bm1, b));
+        uint32_t y = 0, m3 = 0;
+        const uint32_t extra = nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y, &m3);
+        if (extra >= 1u) { len = 1u + extra; o2 = y; o1 = m3; }
       }
     }
     // inclusive prefix sum of len (0..4) over the wavefront: bytes-with-len>=k ballots, counted below the lane
@@ -352,8 +360,8 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   constexpr int SLAB2 = 2 * PIECE, NCH = PIECE / 64;
   __shared__ PieceLds2 s_l[4];
   __shared__ uint8_t s_cls[128];
-  __shared__ NmTwo s_two[NM_TWO_SIZE];
-  stage_two(s_two, two);
+  __shared__ TabLds s_tab;
+  const NmTabs tabs = stage_tabs(s_tab, two);
   alignas(16) __shared__ uint16_t s_lut[NM_LUT_SIZE];
   static_assert(NM_LUT_SIZE * sizeof(uint16_t) == 256 * sizeof(uint4), "one 16-byte load per thread stages the rule table");
   if (threadIdx.x < 128) s_cls[threadIdx.x] = (uint8_t)ncls_ascii(threadIdx.x, lower_all != 0);
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   const uint32_t d = piece_doc[k];
   if (CARRY && need_host[d]) { if (lane == 0) piece_len[k] = 0; return; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, s_two));
+  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, tabs));
   const uint32_t carry = CARRY ? __builtin_amdgcn_readfirstlane((uint32_t)piece_carry[k]) : 0u;
   const int nch = (m + 63) >> 6;
   // all chunks but the last are whole; the piece boundary m lies in chunk m >> 6 (which is chunk nch when m is a multiple of 64)
@@ -441,14 +449,15 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
       o3 = sel_mask(spW, chW, o3);
       // the bytes of a two-byte character (U+0080..U+017F) come from the table: the lead lane its first byte - or the ASCII letter the
       // character decomposes into -, the second lane its second byte - or the two bytes of the combining mark.  Chunks without any are the rule.
-      uint32_t ysp = chSP;
+      uint32_t ysp = chSP, m3 = code >> 8;
       if (__ballot(nm_two_lead(b) || (lane == 0 && nm_cont_byte(b))) != 0ull) {       // (lane 0 may hold the second byte of a character that began in the chunk before)
         const uint32_t bm1 = L.raw[PMARGIN + 64 * c + lane - 1], bp1 = L.raw[PMARGIN + 64 * c + lane + 1];
         const bool lead2 = nm_two_lead(b), cont2 = nm_cont_byte(b) && nm_two_lead(bm1);
         if (lead2 || cont2) {
-          const NmTwo e = s_two[lead2 ? nm_two_index(b, bp1) : nm_two_index(bm1, b)];
-          uint32_t y = 0;
-          if (nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y)) { len1 = 1u; ysp = y; }
+          const NmTwo e = nm_two_get(tabs, lead2 ? nm_two_index(b, bp1) : nm_two_index(bm1, b));
+          uint32_t y = 0, mm = 0;
+          const uint32_t extra = nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y, &mm);
+          if (extra >= 1u) { len1 = extra; ysp = y; m3 = mm; }
         }
       }
       const unsigned long long ge2 = __ballot(len1 >= 1u) & V, ge3 = __ballot(len1 >= 2u) & V, ge4 = __ballot(len1 >= 3u) & V;
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
         const uint32_t last = first + len1;
         *TM_LDS_PTR(lds_u8, sel_mask(V, last, dump)) = (uint8_t)o3;
         *TM_LDS_PTR(lds_u8, sel_mask(ge2, last - 1u, dump)) = (uint8_t)ysp;
-        *TM_LDS_PTR(lds_u8, sel_mask(ge3, last - 2u, dump)) = (uint8_t)(code >> 8);
+        *TM_LDS_PTR(lds_u8, sel_mask(ge3, last - 2u, dump)) = (uint8_t)m3;
         *TM_LDS_PTR(lds_u8, sel_mask(ge4, first, dump)) = (uint8_t)chD;
       } else over = true;                                   // wave-uniform: the piece does not fit its slab (exact two-pass path)
       pos += total;
@@ -596,6 +605,23 @@ __global__ void k_place_fallback(const uint8_t* __restrict__ staging, const uint
 }  // namespace tmh
 
 namespace {
+// the normalizer's tables for {NFD, lowercase} x {capcode 2 or not}, built once per process from the host normalizer's functions (a few
+// milliseconds of ICU calls: every lane's workspace uploads its own copy)
+const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
+  static std::mutex mu;
+  static std::vector<uint8_t> cache[8];
+  std::lock_guard<std::mutex> g(mu);
+  std::vector<uint8_t>& t = cache[(flags & 3u) | (capcode2 ? 4u : 0u)];
+  if (t.empty()) {
+    t.resize(NM_TABLE_BYTES);
+    NmTwo* two = reinterpret_cast<NmTwo*>(t.data());
+    uint32_t* blk = reinterpret_cast<uint32_t*>(two + NM_TWO_SIZE);
+    build_two_table(flags & 3u, two);
+    if (!capcode2) for (int k = 0; k < NM_TWO_SIZE; k++) if (two[k].a & (NT_DECOMP | NT_DECOMP2)) two[k].a = 0;      // (without capcode the pass keeps lengths: decomposing characters take the host path)
+    build_three_tables(flags & 3u, blk, blk + NM_BLK_WORDS);
+  }
+  return t;
+}
 template <typename T>
 hipError_t grow(T** p, uint64_t* cap, uint64_t need, uint64_t slack = 0) {
   if (*p && *cap >= need) return hipSuccess;
@@ -650,11 +676,9 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
   if (!b->d_ninfo && (e = hipMalloc((void**)&b->d_ninfo, 64)) != hipSuccess) return hip_fail(e, "hipMalloc");
   if (!b->d_two) {
     // what the vocabulary's flags {NFD, lowercase} do to the two-byte characters U+0080..U+017F, from the host normalizer's own building blocks
-    if ((e = hipMalloc((void**)&b->d_two, NM_TWO_SIZE * sizeof(NmTwo))) != hipSuccess) return hip_fail(e, "hipMalloc");
-    std::vector<NmTwo> two(NM_TWO_SIZE);
-    build_two_table(b->vocab->host.norm_flag & 3u, two.data());
-    if (b->vocab->host.capcode != 2) for (auto& t : two) if (t.a & NT_DECOMP) t.a = 0;      // (without capcode the pass keeps lengths: decomposing characters take the host path)
-    int rc = small_h2d(b, b->d_two, two.data(), NM_TWO_SIZE * sizeof(NmTwo), st);
+    if ((e = hipMalloc((void**)&b->d_two, NM_TABLE_BYTES)) != hipSuccess) return hip_fail(e, "hipMalloc");
+    const std::vector<uint8_t>& tab = norm_tables(b->vocab->host.norm_flag & 3u, b->vocab->host.capcode == 2);
+    int rc = small_h2d(b, b->d_two, tab.data(), NM_TABLE_BYTES, st);
     if (rc != TM_OK) return rc;
   }
   if (!b->d_piece_doc || npieces + 2 > b->piece_cap) {

@@ -29,52 +29,84 @@ namespace tmh {
 enum : uint32_t { NC_O = 0, NC_L = 1, NC_SP = 2, NC_LO = 3, NC_U = 4, NC_N = 5, NC_AP = 6, NC_M = 7 };
 constexpr uint32_t NF_CLASS = 7u, NF_BLOCK = 4u, NF_CONT = 8u, NF_TERML = 16u, NF_UA_SHIFT = 5, NF_BAD = 0x80u;
 
-// ---- two-byte UTF-8 characters U+0080..U+017F (lead bytes C2..C5: Latin-1 Supplement, Latin Extended-A) -----------------------------
-// What NFD / lowercase / capcode do to them is a table of 256 entries (one per lead byte x second byte), built on the HOST from the
+// ---- two-byte UTF-8 characters U+0080..U+07FF (lead bytes C2..DF: Latin-1 Supplement to NKo - accented Latin, IPA, the combining
+// marks, Greek, Cyrillic, Armenian, Hebrew, Arabic ...) ---------------------------------------------------------------------------------
+// What NFD / lowercase / capcode do to them is a table of 30 x 64 entries (one per lead byte x second byte), built on the HOST from the
 // host normalizer's own building blocks (ICU; tm_normalize.cpp: build_two_table) for the vocabulary's normalization flags, so that
-// the device cannot disagree with it:  a character either stays one two-byte character (Æ ø ß « ...: lead lane emits its first
-// byte, continuation lane its second) or decomposes into an ASCII letter and one combining mark (é -> e + U+0301: lead lane takes
-// the letter's role - class, markers, the letter - and the continuation lane, class M, emits the two bytes of the mark).
-//   a: class of the first code point [0..2] | NT_OK [3] | NT_DECOMP [4] | lead byte out [8..15] | continuation out A [16..23] | B [24..31]
-//      (decomposed: A B = the mark; otherwise A = the second byte)
-//   b: lead byte out when capcode lower-cases the character [0..7] | continuation byte out then [8..15]
+// the device cannot disagree with it.  A character either stays one two-byte character (Æ ß « я ω ...: lead lane emits its first byte,
+// continuation lane its second), or decomposes into an ASCII letter and one two-byte combining mark (é -> e + U+0301: lead lane takes
+// the letter's role - class, markers, the letter - and the continuation lane, class M, emits the two bytes of the mark), or into a
+// two-byte letter and one two-byte mark (й -> и + U+0306, ά -> α + U+0301: lead lane the first byte of the letter, continuation lane,
+// class M, its second byte and the two bytes of the mark).  Anything else (three code points, a lower-case form of another length)
+// stays without NT_OK: its document takes the host path.
+//   a: class of the first code point [0..2] | NT_OK [3] | NT_DECOMP [4] | NT_DECOMP2 [5] | out0 [8..15] | out1 [16..23] | out2 [24..31]
+//   b: low0 [0..7] | low1 [8..15] | out3 [16..23]
+//      stays one character: out0 out1 (capcode lower-cases a capital to low0 low1);  NT_DECOMP: letter out0 (low0), mark out1 out2;
+//      NT_DECOMP2: letter out0 out1 (low0 low1), mark out2 out3
+// The entries of the leads C2..C5 (U+0080..U+017F: what European text is made of) are staged in LDS, the others are read where they lie.
 struct NmTwo { uint32_t a, b; };
-constexpr int NM_TWO_SIZE = 256;
-constexpr uint32_t NT_OK = 8u, NT_DECOMP = 16u;
-TM_HD bool nm_two_lead(uint32_t b) { return b - 0xC2u < 4u; }
+constexpr int NM_TWO_LEADS = 30, NM_TWO_SIZE = NM_TWO_LEADS * 64, NM_TWO_FAST = 256;
+constexpr uint32_t NT_OK = 8u, NT_DECOMP = 16u, NT_DECOMP2 = 32u;
+TM_HD bool nm_two_lead(uint32_t b) { return b - 0xC2u < (uint32_t)NM_TWO_LEADS; }
+TM_HD bool nm_three_lead(uint32_t b) { return (b & 0xF0u) == 0xE0u; }
 TM_HD bool nm_cont_byte(uint32_t b) { return (b & 0xC0u) == 0x80u; }
 TM_HD uint32_t nm_two_index(uint32_t lead, uint32_t second) { return ((lead - 0xC2u) << 6) | (second & 63u); }
 TM_HD bool nm_punct3(uint32_t b1, uint32_t b2) {   // E2 b1 b2 in the supported (NFD-stable) General Punctuation ranges U+2010..U+2027, U+2030..U+205E
   return (b1 == 0x80u && ((b2 >= 0x90u && b2 <= 0xA7u) || (b2 >= 0xB0u && b2 <= 0xBFu))) || (b1 == 0x81u && b2 >= 0x80u && b2 <= 0x9Eu);
 }
+// ---- three-byte characters U+0800..U+FFFF that the normalizer leaves alone ------------------------------------------------------------
+// CJK ideographs, most kana, symbols, box drawing ...: NFD-stable, caseless, and to capcode either a letter that is neither upper nor
+// lower case (class LO: \p{L}) or "other" (class O).  Two bits per code point, from the host normalizer's own functions
+// (tm_normalize.cpp: build_three_tables): 0 = the document takes the host path (the character decomposes, has case, is a mark, a digit
+// or a surrogate: Hangul syllables, voiced kana, Latin Extended Additional ...), 1 = class O, 2 = class LO.  First a table of the 1 024
+// blocks of 64 code points (256 bytes, staged in LDS): 0 / 1 / 2 when the whole block agrees, 3 = look the code point up (16 KB, in HBM).
+constexpr int NM_BLK_WORDS = 64, NM_CP_WORDS = 4096;
+// what a kernel knows the tables by: the fast part of the two-byte table and the block table (LDS), the full tables (global memory)
+struct NmTabs { const NmTwo* two_fast; const NmTwo* two_all; const uint32_t* blk; const uint32_t* cp; };
+TM_HD NmTwo nm_two_get(const NmTabs& t, uint32_t idx) { return idx < (uint32_t)NM_TWO_FAST ? t.two_fast[idx] : t.two_all[idx]; }
+TM_HD uint32_t nm_three_code(const NmTabs& t, uint32_t cp) {
+  const uint32_t bc = (t.blk[cp >> 10] >> (2u * ((cp >> 6) & 15u))) & 3u;
+  return bc != 3u ? bc : ((t.cp[cp >> 4] >> (2u * (cp & 15u))) & 3u);
+}
 // class byte of the non-ASCII byte b between m2 m1 and p1 p2 (NF_BAD: the document needs the host normalizer)
-template <class Two>
-TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32_t p2, const Two& two) {
+TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32_t p2, const NmTabs& tabs) {
   if (nm_two_lead(b)) {
     if (!nm_cont_byte(p1)) return NF_BAD;
-    const uint32_t a = two[nm_two_index(b, p1)].a;
-    return (a & NT_OK) ? (a & NF_CLASS) : NF_BAD;
+    const uint32_t a = nm_two_get(tabs, nm_two_index(b, p1)).a;
+    if (!(a & NT_OK)) return NF_BAD;
+    if ((a & NF_CLASS) == NC_M && nm_cont_byte(m1) && nm_two_lead(m2)) {
+      // two combining marks in a row (the second of them possibly out of a decomposition) may have to change places under NFD
+      // (canonical ordering): not on the device
+      const uint32_t pa = nm_two_get(tabs, nm_two_index(m2, m1)).a;
+      if ((pa & NF_CLASS) == NC_M || (pa & (NT_DECOMP | NT_DECOMP2))) return NF_BAD;
+    }
+    return a & NF_CLASS;
   }
   if (nm_cont_byte(b) && nm_two_lead(m1)) {
-    const uint32_t a = two[nm_two_index(m1, b)].a;
-    return (a & NT_OK) ? ((a & NT_DECOMP) ? (uint32_t)NC_M : ((a & NF_CLASS) | NF_CONT)) : NF_BAD;
+    const uint32_t a = nm_two_get(tabs, nm_two_index(m1, b)).a;
+    return (a & NT_OK) ? ((a & (NT_DECOMP | NT_DECOMP2)) ? (uint32_t)NC_M : ((a & NF_CLASS) | NF_CONT)) : NF_BAD;
   }
-  uint32_t b1 = 0, b2 = 0, cont = 0;
-  bool ok = false;
-  if (b == 0xE2u) { b1 = p1; b2 = p2; ok = true; }
-  else if (m1 == 0xE2u) { b1 = b; b2 = p1; cont = NF_CONT; ok = true; }
-  else if (m2 == 0xE2u) { b1 = m1; b2 = b; cont = NF_CONT; ok = true; }
-  ok = ok && nm_punct3(b1, b2);
-  return ok ? (((b1 == 0x80u && b2 == 0x99u) ? (uint32_t)NC_AP : (uint32_t)NC_O) | cont) : NF_BAD;      // U+2019 is an apostrophe (tokenmonster.js:878)
+  uint32_t lead = 0, b1 = 0, b2 = 0, cont = 0;
+  if (nm_three_lead(b)) { lead = b; b1 = p1; b2 = p2; }
+  else if (nm_cont_byte(b) && nm_three_lead(m1)) { lead = m1; b1 = b; b2 = p1; cont = NF_CONT; }
+  else if (nm_cont_byte(b) && nm_cont_byte(m1) && nm_three_lead(m2)) { lead = m2; b1 = m1; b2 = b; cont = NF_CONT; }
+  else return NF_BAD;
+  if (!nm_cont_byte(b1) || !nm_cont_byte(b2)) return NF_BAD;
+  if (lead == 0xE2u && nm_punct3(b1, b2)) return ((b1 == 0x80u && b2 == 0x99u) ? (uint32_t)NC_AP : (uint32_t)NC_O) | cont;      // U+2019 is an apostrophe (tokenmonster.js:878)
+  const uint32_t code = nm_three_code(tabs, ((lead & 15u) << 12) | ((b1 & 63u) << 6) | (b2 & 63u));
+  return code == 0u ? (uint32_t)NF_BAD : ((code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O) | cont);
 }
-// the bytes of a lane that holds one byte of a two-byte character: *o3 = its last output byte; returns true when the lane is the
-// second half of a decomposed character and emits TWO bytes, *y then *o3 (the combining mark)
+// the bytes of a lane that holds one byte of a two-byte character: *o3 = its last output byte; returns how many bytes the lane emits
+// IN FRONT of it: 0, 1 (*y: the second half of a character that decomposes into an ASCII letter and a mark emits the mark) or 2 (*m3 *y:
+// the second half of one that decomposes into a two-byte letter and a mark emits the letter's second byte and the mark)
 // (`lowered`: the rule table says capcode lower-cases this character - lead lane; `capcode`: level 2 is on, which lower-cases every capital)
-TM_HD bool nm_two_out(NmTwo e, bool cont, bool lowered, bool capcode, uint32_t* o3, uint32_t* y) {
-  if (!cont) { *o3 = lowered ? (e.b & 0xFFu) : ((e.a >> 8) & 0xFFu); return false; }
-  if (e.a & NT_DECOMP) { *y = (e.a >> 16) & 0xFFu; *o3 = e.a >> 24; return true; }
-  *o3 = (capcode && (e.a & NF_CLASS) == NC_U) ? ((e.b >> 8) & 0xFFu) : ((e.a >> 16) & 0xFFu);
-  return false;
+TM_HD uint32_t nm_two_out(NmTwo e, bool cont, bool lowered, bool capcode, uint32_t* o3, uint32_t* y, uint32_t* m3) {
+  if (!cont) { *o3 = lowered ? (e.b & 0xFFu) : ((e.a >> 8) & 0xFFu); return 0u; }
+  const bool upper = capcode && (e.a & NF_CLASS) == NC_U;
+  if (e.a & NT_DECOMP) { *y = (e.a >> 16) & 0xFFu; *o3 = e.a >> 24; return 1u; }
+  if (e.a & NT_DECOMP2) { *m3 = upper ? ((e.b >> 8) & 0xFFu) : ((e.a >> 16) & 0xFFu); *y = e.a >> 24; *o3 = (e.b >> 16) & 0xFFu; return 2u; }
+  *o3 = upper ? ((e.b >> 8) & 0xFFu) : ((e.a >> 16) & 0xFFu);
+  return 0u;
 }
 
 TM_HD uint64_t nm_brev(uint64_t x) { return __builtin_bitreverse64(x); }   // s_brev_b64 on the device

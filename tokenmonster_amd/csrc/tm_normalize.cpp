@@ -366,25 +366,36 @@ void nocapcode_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
   nocapcode_decode_stream(st, in, n, out);
 }
 
-// The table of the device normalizer for the two-byte characters U+0080..U+017F (tm_norm_masks.h: NmTwo), made from this file's own
-// building blocks for the flags {NFD, lowercase} of a vocabulary: the device cannot disagree with the host about them.  A character
-// the table cannot express (anything but "stays one two-byte character" or "ASCII letter + one two-byte combining mark", or a lower-case
-// form of another length) is left without NT_OK: documents that contain it take the host path.
+// The tables of the device normalizer for the two-byte characters U+0080..U+07FF (tm_norm_masks.h: NmTwo) and for the three-byte characters
+// it passes through, made from this file's own building blocks for the flags {NFD, lowercase} of a vocabulary: the device cannot disagree
+// with the host about them.  A character the tables cannot express (anything but "stays one character", "ASCII letter + one two-byte combining
+// mark" or "two-byte letter + one two-byte combining mark"; a lower-case form of another length) is left without NT_OK: documents that contain
+// it take the host path.
 void build_two_table(uint32_t norm_flag, NmTwo* out) {
-  for (uint32_t cp = 0x80; cp < 0x180; cp++) {
+  for (int k = 0; k < NM_TWO_SIZE; k++) out[k] = NmTwo{0, 0};
+  for (uint32_t cp = 0x80; cp < 0x800; cp++) {
     const uint32_t lead = 0xC0u | (cp >> 6), second = 0x80u | (cp & 0x3Fu);
     NmTwo& e = out[nm_two_index(lead, second)];
-    e.a = 0; e.b = 0;
     std::vector<uint8_t> t = {(uint8_t)lead, (uint8_t)second};
     if (norm_flag & 1) nfd_bytes(t);
-    if (norm_flag & 2) lower_bytes(t);
+    if (norm_flag & 2) {
+      // lower-casing a whole text looks at a letter's neighbours (the final sigma: Σ -> ς at the end of a word, σ elsewhere); a character
+      // whose lower-case form depends on them is not for a table
+      std::vector<uint8_t> mid = {'a'};
+      mid.insert(mid.end(), t.begin(), t.end());
+      std::vector<uint8_t> both = mid, after = t;
+      both.push_back('a'); after.push_back('a');
+      lower_bytes(t); lower_bytes(mid); lower_bytes(both); lower_bytes(after);
+      if (mid.size() != t.size() + 1 || both.size() != t.size() + 2 || after.size() != t.size() + 1 || !std::equal(t.begin(), t.end(), mid.begin() + 1) ||
+          !std::equal(t.begin(), t.end(), both.begin() + 1) || !std::equal(t.begin(), t.end(), after.begin())) continue;
+    }
     if (t.empty()) continue;
     const Cp c1 = next_cp(t.data(), t.size());
     if (c1.raw) continue;
     const uint8_t k1 = classify(c1);
     uint32_t cls;
-    if (k1 & kUpper) cls = NC_U; else if (k1 & kLower) cls = NC_L; else if (k1 & kLetter) cls = NC_LO; else if (k1 & (kDigit | kMark)) continue; else cls = NC_O;
-    if (c1.r == ' ' || c1.r == '\'') continue;                             // (no character of the range turns into one of these)
+    if (k1 & kUpper) cls = NC_U; else if (k1 & kLower) cls = NC_L; else if (k1 & kLetter) cls = NC_LO; else if (k1 & kDigit) cls = NC_N; else if (k1 & kMark) cls = NC_M; else cls = NC_O;
+    if (c1.r == ' ' || c1.r == '\'') continue;                            // (no character of the range turns into one of these)
     std::vector<uint8_t> low;
     put_lower(low, c1);                                                    // what capcode writes for a capital (:918, :986)
     if ((size_t)c1.n == t.size() && c1.n == 2) {                           // stays one two-byte character
@@ -396,7 +407,41 @@ void build_two_table(uint32_t norm_flag, NmTwo* out) {
       if (c2.raw || c2.n != 2 || !(classify(c2) & kMark) || !(k1 & kLetter) || low.size() != 1) continue;
       e.a = cls | NT_OK | NT_DECOMP | ((uint32_t)t[0] << 8) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 24);
       e.b = (uint32_t)low[0] | ((uint32_t)t[1] << 8);
+    } else if (c1.n == 2 && t.size() == 4) {                               // two-byte letter + one combining mark (й ё ά ...)
+      const Cp c2 = next_cp(t.data() + 2, 2);
+      if (c2.raw || c2.n != 2 || !(classify(c2) & kMark) || !(k1 & kLetter) || low.size() != 2) continue;
+      e.a = cls | NT_OK | NT_DECOMP2 | ((uint32_t)t[0] << 8) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 24);
+      e.b = (uint32_t)low[0] | ((uint32_t)low[1] << 8) | ((uint32_t)t[3] << 16);
     }
+  }
+}
+
+// blk[NM_BLK_WORDS], cp[NM_CP_WORDS]: two bits per block of 64 code points / per code point of U+0000..U+FFFF (tm_norm_masks.h)
+void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cpt) {
+  for (int k = 0; k < NM_BLK_WORDS; k++) blk[k] = 0;
+  for (int k = 0; k < NM_CP_WORDS; k++) cpt[k] = 0;
+  for (uint32_t block = 0x800 >> 6; block < 1024; block++) {
+    uint32_t first = 4;
+    bool same = true;
+    for (uint32_t cp = block << 6; cp < (block + 1) << 6; cp++) {
+      uint32_t code = 0;
+      if (cp < 0xD800 || cp > 0xDFFF) {
+        std::vector<uint8_t> in, t;
+        put_cp(in, cp);
+        t = in;
+        if (norm_flag & 1) nfd_bytes(t);
+        if (norm_flag & 2) lower_bytes(t);
+        const Cp c1 = next_cp(in.data(), in.size());
+        std::vector<uint8_t> low;
+        if (!c1.raw) put_lower(low, c1);
+        const uint8_t k1 = classify(c1);
+        // untouched by the flags, nothing capcode would mark or lower-case, and to capcode a letter without case or "other"
+        if (t == in && !c1.raw && c1.n == 3 && low == in && !(k1 & (kUpper | kLower | kDigit | kMark))) code = (k1 & kLetter) ? 2u : 1u;
+      }
+      cpt[cp >> 4] |= code << (2u * (cp & 15u));
+      if (first == 4) first = code; else if (code != first) same = false;
+    }
+    blk[block >> 4] |= (same ? first : 3u) << (2u * (block & 15u));
   }
 }
 

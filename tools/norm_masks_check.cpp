@@ -30,6 +30,8 @@ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
 }
 static uint64_t g_margin_ok = 0, g_margin_unknown = 0;
 static NmTwo g_two[2][NM_TWO_SIZE];     // [lower_all]: flags 1 (NFD) and 3 (NFD + lowercase)
+static uint32_t g_blk[2][NM_BLK_WORDS], g_cp[2][NM_CP_WORDS];      // the three-byte characters the pass leaves alone (tm_norm_masks.h)
+static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k]}; }
 // class byte of every byte of a document as norm_load_piece computes it (bytes outside the document read as 0)
 bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t>& f) {
   const int n = (int)d.size();
@@ -38,7 +40,7 @@ bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t
   bool ok_all = true;
   for (int i = 0; i < n; i++) {
     const uint32_t b = d[i];
-    const uint32_t fl = b < 0x80u ? ncls_ascii(b, lower_all) : nm_classify_high(b, at(i - 1), at(i - 2), at(i + 1), at(i + 2), g_two[lower_all ? 1 : 0]);
+    const uint32_t fl = b < 0x80u ? ncls_ascii(b, lower_all) : nm_classify_high(b, at(i - 1), at(i - 2), at(i + 1), at(i + 2), tabs_of(lower_all));
     if (fl == NF_BAD) ok_all = false;
     f[i] = (uint8_t)fl;
   }
@@ -103,7 +105,7 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
       const uint32_t code = kLut.e[lower_all ? 1 : 0][idx];
       uint32_t len = (code & 3u) + 1u;
       const uint32_t b = d[pb + rel];
-      uint32_t o3 = b | ((code & 4u) << 3), ysp = ' ';
+      uint32_t o3 = b | ((code & 4u) << 3), ysp = ' ', m3 = code >> 8;
       if (spC & bit) o3 = 'C';
       if (spW & bit) o3 = 'W';
       auto rawat = [&](int r) -> uint32_t { const int p = pb + r; return (p < 0 || p >= n) ? 0u : d[p]; };
@@ -111,11 +113,12 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
       const bool lead2 = nm_two_lead(b), cont2 = nm_cont_byte(b) && nm_two_lead(bm1);
       if (lead2 || cont2) {
         const NmTwo e = g_two[lower_all ? 1 : 0][lead2 ? nm_two_index(b, bp1) : nm_two_index(bm1, b)];
-        uint32_t y = 0;
-        if (nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y)) { len = 2; ysp = y; }
+        uint32_t y = 0, mm = 0;
+        const uint32_t extra = nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y, &mm);
+        if (extra >= 1u) { len = 1u + extra; ysp = y; m3 = mm; }
       }
       if (len == 4) out.push_back('D');
-      if (len >= 3) out.push_back((uint8_t)(code >> 8));
+      if (len >= 3) out.push_back((uint8_t)m3);
       if (len >= 2) out.push_back((uint8_t)ysp);
       out.push_back((uint8_t)o3);
     }
@@ -186,8 +189,14 @@ int main(int argc, char** argv) {
   const char* multi[] = {"\xE2\x80\x99", "\xE2\x80\x9C", "\xE2\x80\x9D", "\xE2\x80\x94", "\xE2\x80\xA6", "\xE2\x81\x80"};
   build_two_table(1, g_two[0]);
   build_two_table(3, g_two[1]);
-  { int ok = 0, dec = 0; for (int k = 0; k < NM_TWO_SIZE; k++) { ok += (g_two[0][k].a & NT_OK) != 0; dec += (g_two[0][k].a & NT_DECOMP) != 0; }
-    printf("two-byte table (NFD): %d of 256 characters on the device, %d of them decompose\n", ok, dec); }
+  build_three_tables(1, g_blk[0], g_cp[0]);
+  build_three_tables(3, g_blk[1], g_cp[1]);
+  { int ok = 0, dec = 0, dec2 = 0; for (int k = 0; k < NM_TWO_SIZE; k++) { ok += (g_two[0][k].a & NT_OK) != 0; dec += (g_two[0][k].a & NT_DECOMP) != 0; dec2 += (g_two[0][k].a & NT_DECOMP2) != 0; }
+    int c1 = 0, c2 = 0, mixed = 0;
+    for (uint32_t cp = 0x800; cp < 0x10000; cp++) { const uint32_t c = (g_cp[0][cp >> 4] >> (2 * (cp & 15))) & 3u; c1 += c == 1; c2 += c == 2; }
+    for (uint32_t b = 0; b < 1024; b++) mixed += ((g_blk[0][b >> 4] >> (2 * (b & 15))) & 3u) == 3u;
+    printf("two-byte table (NFD): %d of %d characters on the device, %d decompose into an ASCII letter + mark, %d into a two-byte letter + mark\n", ok, NM_TWO_SIZE, dec, dec2);
+    printf("three-byte characters left alone on the device: %d class O, %d letters without case; %d of 1024 blocks are mixed (per code point)\n", c1, c2, mixed); }
   std::vector<std::string> fixed = {"", "A", "a", "AB", "Ab", "aB", "ABc", "ABC", " ABC d", "HTTPServer2Go x", "X's Y'S it's 'a' I'M", "12AB34cd", "A1B2c",
                                     "X\xE2\x80\x99s Y\xE2\x80\x99S it\xE2\x80\x99s", std::string(200, 'A') + "b", std::string(200, 'A'),
                                     "a" + std::string(130, 'B') + " " + std::string(70, 'C') + "d", std::string(3000, 'A') + "b", std::string(5000, 'Q'),
@@ -195,7 +204,10 @@ int main(int argc, char** argv) {
                                     std::string(1024, 'A') + std::string(1024, '1') + "z", std::string(1020, ' ') + "AB'\xE2\x80\x99" + "cD",
                                     "\xC3\x89t\xC3\xA9 \xC3\x80 la carte", "\xC3\x89\xC3\x89\xC3\x89 x \xC3\x89\xC3\x89" "b", "na\xC3\xAFve caf\xC3\xA9's \xC3\x86on \xC3\x98L", "stra\xC3\x9F" "e \xC2\xAB" "a\xC2\xBB 1\xC2\xBA 2\xC2\xAA",
                                     "\xC5\x81\xC3\xB3" "d\xC5\xBA \xC4\x8C\xC4\x8D" "SR \xC4\xB0stanbul \xC4\xB1\xC5\xBF", std::string(1023, 'x') + "\xC3\x89" "b", std::string(1022, 'x') + " \xC3\x89" + std::string(40, 'A') + "c",
-                                    std::string(63, 'a') + "\xC3\xA9\xC3\xA9", "l'\xC3\xA9t\xC3\xA9 d'\xC3\x89" "mile 3\xC3\xA8me \xC3\xA9's"};
+                                    std::string(63, 'a') + "\xC3\xA9\xC3\xA9", "l'\xC3\xA9t\xC3\xA9 d'\xC3\x89" "mile 3\xC3\xA8me \xC3\xA9's",
+                                    u8"Привет, Мир! Ёжик и йод. МОСКВА Санкт-Петербург", u8"Καλημέρα κόσμε. ΑΘΗΝΑ Ελλάδα ά έ ή ί ό ύ ώ ΐ", u8"שלום עולם בְּרֵאשִׁית", u8"مرحبا بالعالم ١٢٣ كِتَاب",
+                                    u8"中文文本，测试。Hello世界 ABC中文", u8"こんにちは世界 カタカナ がぎぐ パピプ", u8"한국어 텍스트", u8"a\u0301 e\u0301\u0323 o\u0323\u0301 Ắ ǖ", u8"→ ★ ∑ √ ①②③ Ḁḁ ẞ",
+                                    std::string(1023, 'x') + u8"й", std::string(1022, 'x') + u8"Йод", std::string(62, 'a') + u8"йй" + std::string(61, 'b') + u8"中文"};
   for (int lower = 0; lower < 2; lower++) {
     const uint32_t flag = lower ? 3u : 1u;
     for (const auto& s : fixed) { std::vector<uint8_t> d(s.begin(), s.end()); total++; if (!check_doc(d, flag, &skipped)) bad++; }
@@ -206,11 +218,31 @@ int main(int argc, char** argv) {
       std::vector<uint8_t> d;
       const uint32_t style = rng.below(5);      // 0 mixed, 1 capitals-heavy, 2 digits/apostrophes-heavy, 3 spaces + capitals, 4 long runs
       const bool latin = rng.below(2) != 0;     // half of the documents carry accented Latin letters, a few of them a lot
+      // a third of the documents are written in another script: Greek, Cyrillic (with the letters that decompose: й ё ά ...), Hebrew, Arabic,
+      // standalone combining marks, Chinese, Japanese (with voiced kana, which send the document to the host), Korean (host), symbols
+      const uint32_t script = rng.below(3) == 0 ? 1 + rng.below(8) : 0;
       const uint32_t latin_share = rng.below(4) == 0 ? 40 : 6;
       while (d.size() < len) {
         const uint32_t r = rng.below(100);
         if (style == 4 && r < 30) { const char ch = "AB1'a "[rng.below(6)]; const uint32_t rep = 1 + rng.below(150); for (uint32_t q = 0; q < rep; q++) d.push_back((uint8_t)ch); continue; }
         if (r < 4) { const char* mchar = multi[rng.below(6)]; d.insert(d.end(), mchar, mchar + 3); continue; }
+        if (script && r < 60) {
+          uint32_t cp = 0;
+          switch (script) {
+            case 1: cp = 0x0386 + rng.below(0x48); break;                                   // Greek
+            case 2: cp = 0x0400 + rng.below(0x60); break;                                   // Cyrillic
+            case 3: cp = 0x05D0 + rng.below(0x1B); if (rng.below(8) == 0) cp = 0x05B0 + rng.below(0x10); break;   // Hebrew letters, now and then a point
+            case 4: cp = 0x0621 + rng.below(0x2A); if (rng.below(8) == 0) cp = 0x064B + rng.below(8); if (rng.below(10) == 0) cp = 0x0660 + rng.below(10); break;   // Arabic, marks, digits
+            case 5: cp = rng.below(4) ? 0x4E00 + rng.below(0x5000) : 0x3000 + rng.below(0x40); break;   // Chinese + CJK punctuation
+            case 6: cp = rng.below(3) ? 0x3041 + rng.below(0x56) : (rng.below(2) ? 0x30A1 + rng.below(0x5A) : 0x4E00 + rng.below(0x5000)); break;   // Japanese
+            case 7: cp = rng.below(6) ? 0x0180 + rng.below(0x680) : 0x0300 + rng.below(0x70); break;   // anything two-byte, and stray combining marks
+            default: cp = rng.below(3) ? 0x2190 + rng.below(0x400) : (rng.below(2) ? 0xAC00 + rng.below(0x2BA4) : 0x1E00 + rng.below(0x100)); break;   // arrows / symbols; Hangul, Latin Extended Additional (host)
+          }
+          if (cp < 0x800) { d.push_back((uint8_t)(0xC0 | (cp >> 6))); d.push_back((uint8_t)(0x80 | (cp & 0x3F))); }
+          else { d.push_back((uint8_t)(0xE0 | (cp >> 12))); d.push_back((uint8_t)(0x80 | ((cp >> 6) & 0x3F))); if (rng.below(400)) d.push_back((uint8_t)(0x80 | (cp & 0x3F))); }
+          if (rng.below(5) == 0) d.push_back(' ');
+          continue;
+        }
         if (latin && r < 4 + latin_share) {      // a character of U+00A0..U+017F (now and then an unsupported or broken one: the document then takes the host path)
           const uint32_t cp = rng.below(40) == 0 ? 0x80 + rng.below(0x100) : (rng.below(3) ? 0xC0 + rng.below(0x40) : 0xA0 + rng.below(0xE0));
           d.push_back((uint8_t)(0xC0 | (cp >> 6))); if (rng.below(300)) d.push_back((uint8_t)(0x80 | (cp & 0x3F)));
