@@ -151,9 +151,12 @@ void tm_batch_free(tm_batch* b);
 int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs);
 /* Raw (un-normalized) input: H2D of packed raw UTF-8 documents, then tm_batch_normalize runs the pre-step of
  * Tokenize (go/tokenmonster.go:242-253: norm.Normalize + capcode.Encode) ON THE DEVICE into the batch's text buffer
- * (max_bytes of tm_batch_create must cover the normalized size, about 1.1x raw with capcode 2).  Documents that
- * contain non-ASCII characters other than NFD-stable general punctuation (U+2010..U+205E) are normalized by the
- * host normalizer instead (they need ICU); tm_batch_host_fallback_docs reports how many.  Supported: capcode 0 and 2 (level 1
+ * (max_bytes of tm_batch_create must cover the normalized size, about 1.1x raw with capcode 2).  The device pass handles ASCII, every
+ * two-byte script (U+0080..U+07FF: accented Latin, Greek, Cyrillic, Armenian, Hebrew, Arabic ...: NFD, case and capcode from a table the
+ * host normalizer fills) and the three-byte characters the normalizer leaves alone (General Punctuation, CJK ideographs, most kana,
+ * symbols); documents with anything else (Hangul, voiced kana, Latin Extended Additional, four-byte characters, two combining marks in a
+ * row, malformed UTF-8) are normalized by the host normalizer inside the same call; tm_batch_host_fallback_docs reports how many.
+ * Supported: capcode 0 and 2 (level 1
  * has no statement in the reference tree and is refused), every normalization flag (training/README.md:110-123); the device
  * pass itself implements NFD and lowercase (what the reference's pretrained vocabularies use), a vocabulary with any of the
  * lossy flags accents / quotemarks / collapse / trim / leadingspace / unixlines sends ALL its documents through the (multi-threaded)
@@ -197,9 +200,9 @@ uint64_t tm_batch_device_bytes(const tm_batch* b);
 /* ids of document d = tokens[tok_offsets[d] .. tok_offsets[d+1]).  The gather of reverse[id] (lengths -> scan -> copy)
  * runs on the device; ids >= tm_vocab_n_ids are skipped.  raw != 0: the concatenated token bytes as they are
  * (decode_raw); raw == 0: capcode decoding (javascript/tokenmonster.js:1007-1065) follows — on the device for the documents of a capcode-2
- * UTF-8 vocabulary that are ASCII, accented Latin (U+0080..U+017F, combining marks U+0300..U+036F) and the punctuation U+2000..U+203F; on the
- * host for documents with other scripts, malformed UTF-8 or a character whose upper-case form has another length (Unicode case needs ICU),
- * and for capcode 1.  tm_decode_host_docs(): how many documents of the calling thread's last tm_decode_batch went to the host decoder.
+ * UTF-8 vocabulary made of ASCII, the two-byte scripts (U+0080..U+07FF) and the three-byte characters without case (punctuation, CJK, kana,
+ * Hangul, symbols); on the host for documents with a letter whose upper-case form has another length, a three-byte letter with case, a
+ * four-byte character or malformed UTF-8, and for capcode 1.  tm_decode_host_docs(): how many documents of the calling thread's last tm_decode_batch went to the host decoder.
  * out_offsets[ndocs+1] is always filled; TM_E_NOSPACE if out_cap is too small (required size in out_offsets[ndocs]).
  * Like the tokenize entry points the call borrows a lane of the vocabulary (its stream, grow-only device arenas and pinned
  * staging): callable concurrently, no allocation in steady state, nothing on the NULL stream. */

@@ -132,6 +132,10 @@ def one_norm(seed):
 
 
 DEC_ALPHABET = list(b"CCWWDD    aabcxyzQZ019''.,-\n\t_")
+# round 4: the two-byte scripts (case pairs that keep or change the lead byte: а/А р/Р, Greek with the final sigma and the letters whose
+# upper-case form has another length: ΐ ŉ), Hebrew / Arabic with points and digits, CJK, kana, and what stays with the host (Hangul is
+# caseless and decoded on the device too; cased three-byte letters and four-byte characters are not)
+DEC_SCRIPTS = list("абвгджзийклмнопрстуфхцчшщъыьэюяёАБРСЯЁѐїλμνξοπρστυφχψωςάώΐΰΑΩΣשלוםְִّمرحبا١٢٣中文字测试。、こんにちはカタガギ한국ḁẞ①→★\U0001F600")
 
 
 # what the device decoder takes on itself beyond ASCII, and what it must hand to the host (upper-case forms of another length or lead byte: \u00ff \u00b5 \u0131 \u017f \u0149)
@@ -170,7 +174,8 @@ def one_decode(seed):
             for _ in range(max(1, n // 3)):
                 q = rng.random()
                 if q < 0.45: pieces.append(bytes([int(rng.choice(DEC_ALPHABET))]))
-                elif q < 0.75: pieces.append(str(rng.choice(DEC_LATIN)).encode())
+                elif q < 0.60: pieces.append(str(rng.choice(DEC_LATIN)).encode())
+                elif q < 0.75: pieces.append(str(rng.choice(DEC_SCRIPTS)).encode())
                 elif q < 0.85: pieces.append(bytes([int(rng.choice(list(b"aeoun")))]) + str(rng.choice(["\u0301", "\u0300", "\u0308", "\u0303", "\u0327", "\u036f"])).encode())
                 elif q < 0.93: pieces.append(str(rng.choice(["\u2019", "\u2018", "\u201c", "\u2014", "\u2026", "\u2009"])).encode())
                 elif q < 0.97: pieces.append(bytes(rng.choice(list(b"CWD "), size=int(rng.integers(1, 4))).tolist()))

@@ -715,3 +715,10 @@ def test_multilingual_text_stays_on_the_device():
             gotids = v.tokenize(docs[:nchk])
             for k in range(nchk):
                 assert (gotids[k] == ids[int(toff[k]):int(toff[k + 1])]).all()
+            # ... and back: the capcode decoder takes the same scripts on the device (k_dec_capcode), equal to the host's streaming decoder
+            from tokenmonster_amd import _native as N
+            out, ooff = v.decode_packed(ids[: int(toff[nchk])], np.ascontiguousarray(toff[: nchk + 1]))
+            assert N.lib.tm_decode_host_docs() <= max(1, nchk // 10), "%d of %d documents were decoded on the host" % (N.lib.tm_decode_host_docs(), nchk)
+            for k in range(nchk):
+                dec = v.decoder()
+                assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == dec.decode(ids[int(toff[k]):int(toff[k + 1])]) + dec.flush()

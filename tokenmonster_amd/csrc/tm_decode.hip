@@ -40,28 +40,34 @@ __global__ void k_dec_doc_off(const uint64_t* __restrict__ out_off, const uint64
 }
 
 // Capcode level 2 decoding (javascript/tokenmonster.js:1007-1065; the host form is capcode_decode_stream, tm_normalize.cpp) of documents
-// made of ASCII, the two-byte characters U+0080..U+017F, the combining marks U+0300..U+036F (what NFD leaves of an accented Latin letter)
-// and the punctuation U+2000..U+203F — there the decoder is a four-bit state machine over CHARACTERS: 'D' deletes the
+// made of ASCII, the two-byte characters U+0080..U+07FF (Latin, the combining marks, Greek, Cyrillic, Armenian, Hebrew, Arabic ...) and the
+// three-byte characters without case (punctuation, CJK, kana, symbols ...) — there the decoder is a four-bit state machine over CHARACTERS: 'D' deletes the
 // next character, 'C' capitalises the next one that is not a (kept) space, 'W' capitalises letters until the word ends, and a space
 // straight after 'W' does not end it.  One wavefront per document walks it 64 bytes at a time; inside a chunk each flag is a flood fill on
 // the ballots of the byte classes, done with the carry chain of ONE 64-bit addition: with P the positions a flag survives, S where it is
 // set (S inside P) and the flag's value on entry as carry-in, (P + S + carry) ^ P has a one from every start up to and INCLUDING the
 // first position outside P above it — the position that sees the flag and consumes or clears it — and the carry out of bit 63 is the flag's
 // value for the next chunk.  A character is decided at its first byte; its other bytes are transparent to every flag and take the decision
-// (kept / capitalised) of the first, also across the end of a chunk.  Capitalising a two-byte letter changes its second byte only
-// (`tab`, built by the host from the host decoder's own functions: tm_normalize.cpp build_dec_table); a character whose upper-case form
-// needs more than that, any other script, and any byte sequence that is not well-formed UTF-8 leave the document to the host decoder
-// (dec_len = DEC_HOST).
+// (kept / capitalised) of the first, also across the end of a chunk.  Capitalising a two-byte letter replaces its two bytes by those of
+// its upper-case form (`tab`, built by the host from the host decoder's own functions: tm_normalize.cpp build_dec_tables; р D1 80 -> Р D0 A0
+// changes the lead byte too); a character whose upper-case form has another length, a three-byte letter with case, anything of four
+// bytes, and any byte sequence that is not well-formed UTF-8 leave the document to the host decoder (dec_len = DEC_HOST).
 __device__ __forceinline__ unsigned long long dec_fill(unsigned long long P, unsigned long long S, unsigned& carry) {
   const unsigned long long t = P + S, u = t + carry;
   carry = (t < P) | (u < t);
   return u ^ P;
 }
-__device__ __forceinline__ uint32_t dec_tab_index(uint32_t lead, uint32_t second) {      // lead in {C2..C5, CC, CD}
-  return ((lead >= 0xCCu ? lead - 0xCCu + 4u : lead - 0xC2u) << 6) | (second & 63u);
+__device__ __forceinline__ uint32_t dec_tab_index(uint32_t lead, uint32_t second) {      // lead in C2..DF
+  return ((lead - 0xC2u) << 6) | (second & 63u);
+}
+// code of the three-byte character lead b1 b2 (tm_internal.h: 0 host, 1 passed on, 2 digit or mark)
+__device__ __forceinline__ uint32_t dec_three_code(const uint32_t* __restrict__ tab, uint32_t lead, uint32_t b1, uint32_t b2) {
+  const uint32_t cp = ((lead & 15u) << 12) | ((b1 & 63u) << 6) | (b2 & 63u);
+  const uint32_t bc = (tab[DEC_TWO + (cp >> 10)] >> (2u * ((cp >> 6) & 15u))) & 3u;
+  return bc != 3u ? bc : ((tab[DEC_TWO + DEC_BLK_WORDS + (cp >> 4)] >> (2u * (cp & 15u))) & 3u);
 }
 __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__ in, const uint64_t* __restrict__ doc_off, uint32_t ndocs,
-                                                      uint8_t* __restrict__ out, uint64_t* __restrict__ dec_len, const uint16_t* __restrict__ tab) {
+                                                      uint8_t* __restrict__ out, uint64_t* __restrict__ dec_len, const uint32_t* __restrict__ tab) {
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t d = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (d >= ndocs) return;
@@ -81,16 +87,19 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
       cn = at + 1 < e ? in[at + 1] : 0u; cnn = at + 2 < e ? in[at + 2] : 0u;
       cp = valid && at >= b + 1 ? in[at - 1] : 0u; cpp = valid && at >= b + 2 ? in[at - 2] : 0u;
     }
-    auto is_lead2 = [](uint32_t x) { return (x - 0xC2u < 4u) || x == 0xCCu || x == 0xCDu; };
+    auto is_lead2 = [](uint32_t x) { return x - 0xC2u < 30u; };
+    auto is_lead3 = [](uint32_t x) { return (x & 0xF0u) == 0xE0u; };
     auto is_cont = [](uint32_t x) { return (x & 0xC0u) == 0x80u; };
     const bool ascii = c < 0x80u;
-    const bool lead2 = valid && is_lead2(c), lead3 = valid && c == 0xE2u;
-    uint32_t te = 0;                                        // table entry of the two-byte character this lane starts or ends
+    const bool lead2 = valid && is_lead2(c), lead3 = valid && is_lead3(c);
+    uint32_t te = 0, t3 = 0;                                // table entry of the two-byte character this lane starts or ends / code of the three-byte character it starts
     if (lead2 && is_cont(cn)) te = tab[dec_tab_index(c, cn)];
     const bool tail2 = valid && is_cont(c) && is_lead2(cp);
     if (tail2) te = tab[dec_tab_index(cp, c)];
-    const bool tail3a = valid && c == 0x80u && cp == 0xE2u, tail3b = valid && is_cont(c) && cpp == 0xE2u && cp == 0x80u;
-    const bool ok = !valid || ascii || (lead2 && (te & 1u)) || (lead3 && cn == 0x80u && is_cont(cnn)) || (tail2 && (te & 1u)) || tail3a || tail3b;
+    if (lead3 && is_cont(cn) && is_cont(cnn)) t3 = dec_three_code(tab, c, cn, cnn);
+    // (the other bytes of a three-byte character: the lane of its first byte vouches for it)
+    const bool tail3a = valid && is_cont(c) && is_lead3(cp), tail3b = valid && is_cont(c) && is_cont(cp) && is_lead3(cpp);
+    const bool ok = !valid || ascii || (lead2 && (te & 1u)) || (lead3 && t3 != 0u) || (tail2 && (te & 1u)) || tail3a || tail3b;
     if (__any(!ok)) { host = true; break; }
     const unsigned long long V = __ballot(valid);
     const unsigned long long L2 = __ballot(lead2), L3 = __ballot(lead3);
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
     const bool lower = c - 'a' < 26u;
     const unsigned long long LET = __ballot(lower || c - 'A' < 26u || (lead2 && (te & 2u))) & N;      // upper- or lower-case letters
     // what keeps a capitalised word going besides letters: digits, the apostrophe and U+2019, marks
-    const unsigned long long WC = __ballot(c - '0' < 10u || c == '\'' || (lead2 && (te & 4u)) || (lead3 && cnn == 0x99u));
+    const unsigned long long WC = __ballot(c - '0' < 10u || c == '\'' || (lead2 && (te & 4u)) || (lead3 && (t3 == 2u || (c == 0xE2u && cn == 0x80u && cnn == 0x99u))));
     const unsigned long long deleted = N & dec_fill(M, mD, c_del);               // a 'D' since the last character: this one goes
     const unsigned long long ign = N & dec_fill(M, mW, c_ign);                   // a 'W' since the last character
     const unsigned long long kept = N & ~deleted;
@@ -118,7 +127,8 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
     cap_in = cap2 >> 63;
     uint32_t oc = c;
     if (lower && ((capS >> lane) & 1ull)) oc = c - 32u;
-    if (tail2 && ((cap_tail >> lane) & 1ull)) oc = te >> 8;
+    if (lead2 && ((capS >> lane) & 1ull)) oc = (te >> 8) & 0xFFu;
+    if (tail2 && ((cap_tail >> lane) & 1ull)) oc = (te >> 16) & 0xFFu;
     if ((kept_all >> lane) & 1ull) out[o + (uint64_t)__popcll(kept_all & below)] = (uint8_t)oc;
     o += (uint64_t)__popcll(kept_all);
   }
@@ -140,23 +150,23 @@ void launch_decode_copy(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, co
   note_table_use(v, st);
 }
 // the decoder's table of two-byte characters (vocabulary-independent): one copy per device, made on first use and kept
-static const uint16_t* dec_table(int device) {
+static const uint32_t* dec_table(int device) {
   static std::mutex mu;
-  static const uint16_t* tabs[64] = {};
+  static const uint32_t* tabs[64] = {};
+  static std::vector<uint32_t> h;
   std::lock_guard<std::mutex> g(mu);
   if (device < 0 || device >= 64) return nullptr;
   if (!tabs[device]) {
-    uint16_t h[DEC_LEADS * 64];
-    build_dec_table(h);
-    uint16_t* dp = nullptr;
-    if (hipMalloc((void**)&dp, sizeof h) != hipSuccess) return nullptr;
-    if (hipMemcpy(dp, h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dp); return nullptr; }
+    if (h.empty()) { h.resize(DEC_TABLE_WORDS); build_dec_tables(h.data(), h.data() + DEC_TWO, h.data() + DEC_TWO + DEC_BLK_WORDS); }
+    uint32_t* dp = nullptr;
+    if (hipMalloc((void**)&dp, h.size() * 4) != hipSuccess) return nullptr;
+    if (hipMemcpy(dp, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dp); return nullptr; }
     tabs[device] = dp;
   }
   return tabs[device];
 }
 int launch_decode_capcode(const tm_vocab* v, const uint8_t* d_out, const uint64_t* d_doff, uint32_t ndocs, uint8_t* d_dec, uint64_t* d_declen, hipStream_t st) {
-  const uint16_t* tab = dec_table(v->device);
+  const uint32_t* tab = dec_table(v->device);
   if (!tab) return set_error(TM_E_HIP, "the decoder's character table could not be placed on device %d", v->device);
   if (ndocs) TM_LAUNCH(k_dec_capcode, (ndocs + 3) / 4, 256, 0, st, d_out, d_doff, ndocs, d_dec, d_declen, tab);
   return TM_OK;

@@ -32,8 +32,9 @@ struct CapcodeState { bool in_word = false, in_char = false, del = false, ignore
 void capcode_decode_stream(CapcodeState& st, const uint8_t* in, size_t n, std::vector<uint8_t>& out);     // appends
 void nocapcode_decode_stream(CapcodeState& st, const uint8_t* in, size_t n, std::vector<uint8_t>& out);   // appends
 
-constexpr uint32_t DEC_LEADS = 6;                     // lead bytes C2 C3 C4 C5 CC CD of the device decoder's table (build_dec_table: 64 entries each)
-void build_dec_table(uint16_t* out);
+// the device decoder's tables (tm_decode.hip): the two-byte characters U+0080..U+07FF, then block and code-point codes of the three-byte ones
+constexpr uint32_t DEC_TWO = 0x780, DEC_BLK_WORDS = 64, DEC_CP_WORDS = 4096, DEC_TABLE_WORDS = DEC_TWO + DEC_BLK_WORDS + DEC_CP_WORDS;
+void build_dec_tables(uint32_t* two, uint32_t* blk, uint32_t* cp);
 
 void capcode_decode_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t threads,
                           std::vector<std::vector<uint8_t>>& outs);

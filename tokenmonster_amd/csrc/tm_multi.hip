@@ -52,7 +52,19 @@ static Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    // RCCL has to come from the SAME ROCm installation as the HIP runtime this process runs on: a process may hold a second one (a Python
+    // host that has imported torch carries torch's own librccl / libhsa-runtime64 under the same sonames), and a librccl that talks to
+    // the other installation's HSA runtime finds it uninitialised ("no ROCm-capable device is detected").  So: first the librccl that lies
+    // beside the libamdhip64 in use (by path: a soname look-up would hand back whichever copy was loaded first), then the usual names.
+    std::vector<std::string> names;
+    Dl_info di;
+    if (dladdr((const void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+      std::string dir(di.dli_fname);
+      const size_t cut = dir.rfind('/');
+      if (cut != std::string::npos) { dir.resize(cut + 1); names.push_back(dir + "librccl.so.1"); names.push_back(dir + "librccl.so"); }
+    }
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) names.push_back(n);
+    for (const std::string& name : names) if ((r.so = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
     if (!r.so) return;
     auto sym = [&](const char* n) { return dlsym(r.so, n); };
     r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");

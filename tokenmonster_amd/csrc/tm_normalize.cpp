@@ -4,8 +4,11 @@
 // statement of capcode level 2, javascript/tokenmonster.js:900-1005.  This implementation works on
 // the UTF-8 byte stream directly (ASCII classified by table, everything else through ICU).
 //
-// Scope this round: normalizer flags 0, 1 (NFD) and 2 (lowercase, with or without NFD); capcode 0 and 2.
-// Other flag combinations are rejected (TM_E_INVALID) instead of being approximated.
+// Scope: all 256 values of the normalizer flag byte (NFD, lowercase, accents, quotemarks, collapse, trim, leadingspace, unixlines:
+// training/README.md:110-123; checked against the reference runtime's normalize for every value, tests/test_builder_normalizer.py) and
+// capcode 0 and 2.  Capcode level 1 has no statement in the reference tree and is refused (TM_E_INVALID) instead of being guessed.  This
+// file is also where the device normalizer's and decoder's character tables come from (build_two_table, build_three_tables,
+// build_dec_tables): made by the functions below, so the device cannot disagree with the host about a character.
 #include "tm_build.h"
 #include "tokenmonster_hip.h"
 #include "tm_internal.h"
@@ -445,27 +448,47 @@ void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cpt) {
   }
 }
 
-// The table of the device capcode DECODER (tm_decode.hip: k_dec_capcode) for the two-byte characters it handles itself: U+0080..U+017F (leads
-// C2..C5) and the combining marks U+0300..U+037F (leads CC, CD), made from the functions the host decoder above uses, so that the device cannot
-// disagree with it.  Entry (lead index << 6 | second & 63): bit 0 the device may decode the character, bit 1 upper- or lower-case letter (a
-// capitalised word capitalises it), bit 2 digit or mark (keeps a capitalised word going), bits 8..15 the second byte of its upper-case form.
-// A character whose upper-case form has another lead byte or length (ÿ µ ı ſ ŉ) stays without bit 0: its document is left to the host.
-void build_dec_table(uint16_t* out) {
-  static const uint8_t leads[DEC_LEADS] = {0xC2, 0xC3, 0xC4, 0xC5, 0xCC, 0xCD};
-  for (uint32_t li = 0; li < DEC_LEADS; li++)
-    for (uint32_t s6 = 0; s6 < 64; s6++) {
-      const uint8_t b[2] = {leads[li], (uint8_t)(0x80u | s6)};
-      uint16_t e = 0;
-      const Cp c = next_cp(b, 2);
-      if (!c.raw && c.n == 2) {
-        const uint8_t cls = classify(c);
-        std::vector<uint8_t> up;
-        put_cp(up, (uint32_t)u_toupper((UChar32)c.r));
-        if (up.size() == 2 && up[0] == b[0])
-          e = (uint16_t)(1u | ((cls & (kLower | kUpper)) ? 2u : 0u) | ((cls & (kDigit | kMark)) ? 4u : 0u) | ((uint32_t)up[1] << 8));
-      }
-      out[(li << 6) | s6] = e;
+// The tables of the device capcode DECODER (tm_decode.hip: k_dec_capcode), made from the functions the host decoder above uses, so that the
+// device cannot disagree with it.
+//   two[(lead - 0xC2) << 6 | second & 63], the two-byte characters U+0080..U+07FF: bit 0 the device may decode the character, bit 1 upper- or
+//     lower-case letter (a capitalised word capitalises it), bit 2 digit or mark (keeps a capitalised word going), bits 8..15 / 16..23 the two
+//     bytes of its upper-case form.  A character whose upper-case form has another length (ÿ µ ı ſ ŉ ...) stays without bit 0: its document
+//     is left to the host.
+//   blk / cp, the three-byte characters, two bits per block of 64 code points / per code point as in the normalizer's tables: 0 = host (a
+//     letter with case, a surrogate), 1 = a character the decoder only passes on (it ends a capitalised word), 2 = a digit or mark (keeps the
+//     word going); blocks: 3 = look the code point up.
+void build_dec_tables(uint32_t* two, uint32_t* blk, uint32_t* cpt) {
+  for (uint32_t cp = 0x80; cp < 0x800; cp++) {
+    const uint8_t b[2] = {(uint8_t)(0xC0u | (cp >> 6)), (uint8_t)(0x80u | (cp & 0x3Fu))};
+    uint32_t e = 0;
+    const Cp c = next_cp(b, 2);
+    if (!c.raw && c.n == 2) {
+      const uint8_t cls = classify(c);
+      std::vector<uint8_t> up;
+      put_cp(up, (uint32_t)u_toupper((UChar32)c.r));
+      if (up.size() == 2) e = 1u | ((cls & (kLower | kUpper)) ? 2u : 0u) | ((cls & (kDigit | kMark)) ? 4u : 0u) | ((uint32_t)up[0] << 8) | ((uint32_t)up[1] << 16);
     }
+    two[cp - 0x80] = e;
+  }
+  for (int k = 0; k < NM_BLK_WORDS; k++) blk[k] = 0;
+  for (int k = 0; k < NM_CP_WORDS; k++) cpt[k] = 0;
+  for (uint32_t block = 0x800 >> 6; block < 1024; block++) {
+    uint32_t first = 4;
+    bool same = true;
+    for (uint32_t cp = block << 6; cp < (block + 1) << 6; cp++) {
+      uint32_t code = 0;
+      if (cp < 0xD800 || cp > 0xDFFF) {
+        std::vector<uint8_t> in;
+        put_cp(in, cp);
+        const Cp c = next_cp(in.data(), in.size());
+        const uint8_t cls = classify(c);
+        if (!c.raw && c.n == 3 && !(cls & (kLower | kUpper)) && (uint32_t)u_toupper((UChar32)cp) == cp) code = (cls & (kDigit | kMark)) ? 2u : 1u;
+      }
+      cpt[cp >> 4] |= code << (2u * (cp & 15u));
+      if (first == 4) first = code; else if (code != first) same = false;
+    }
+    blk[block >> 4] |= (same ? first : 3u) << (2u * (block & 15u));
+  }
 }
 
 // capcode level 1 has no statement in the reference tree: refused rather than guessed
