@@ -260,15 +260,12 @@ __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w
   return res;
 }
 
-#ifdef TM_PHASE_TIMERS
-// development aid (never defined in the product build): per-phase wall cycles of one wavefront, summed over all of them
-__device__ unsigned long long g_phase[64 * 32];
-#define PH_INIT unsigned long long ph_t = __builtin_readcyclecounter(); unsigned long long ph_a[8] = {0}; int ph_c[16] = {0};
-#define PH(i) { const unsigned long long ph_n = __builtin_readcyclecounter(); ph_a[i] += ph_n - ph_t; ph_t = ph_n; }
-#define PH_COUNT(i, n) ph_c[i] += (int)(n);
-#define PH_INC(i) ph_c[i]++;
-#define PH_FLUSH { if (lane == 0) { unsigned long long* gp = g_phase + (blockIdx.x & 63) * 32; for (int q = 0; q < 8; q++) atomicAdd(&gp[q], ph_a[q]); for (int q = 8; q < 16; q++) atomicAdd(&gp[q], (unsigned long long)ph_c[q]); } }
+// Development switches (per-phase cycle timers, phases of this kernel switched off for profiling) live in tools/devel/tm_devel.h and exist
+// only in builds that ask for them (-DTM_DEVEL / -DTM_PHASE_TIMERS: tools/, never the product); here they are these no-ops.
+#if defined(TM_DEVEL) || defined(TM_PHASE_TIMERS)
+#include "../../tools/devel/tm_devel.h"
 #else
+#define TM_DBG_ON(x) false
 #define PH_INIT
 #define PH_INC(i)
 #define PH_FLUSH
@@ -343,11 +340,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   __builtin_amdgcn_wave_barrier();
   PH(0)
   PH_COUNT(12, 1)
-#ifdef TM_DEVEL
-  const int ntask = (dbg & 1) ? 0 : (share ? SEG : min(NPOS, dl));
-#else
-  const int ntask = share ? SEG : min(NPOS, dl);       // positions >= dl keep descriptor 0 (nothing there); a shared halo is the neighbour's work
-#endif
+  const int ntask = TM_DBG_ON(dbg & 1) ? 0 : (share ? SEG : min(NPOS, dl));       // positions >= dl keep descriptor 0 (nothing there); a shared halo is the neighbour's work
   // the walks of steps A1 and A3: a lane's state is its key — KEY_SET (A1: the gather is a link-format entry), KEY_IDLE (nothing to
   // do; the gather is the always-empty entry behind the double array), anything else = the node whose child is being probed (the
   // check word the entry must carry)
@@ -388,9 +381,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       static_assert(offsetof(WaveLds, Db) + 4 * 63 + 6 * 256 + 4 <= offsetof(WaveLds, xch) && offsetof(WaveLds, Db) + 6 * 256 >= offsetof(WaveLds, Xb), "dump words");
       posa = tb + (uint32_t)((offsetof(WaveLds, Db) - offsetof(WaveLds, X)) / 4) + (uint32_t)lane;
     }
-#ifdef TM_DEVEL
-    const bool nowalk = (dbg & 4) != 0;
-#endif
+    const bool nowalk = TM_DBG_ON((dbg & 4) != 0);
     // The round with its control state as explicit 64-bit lane masks (ballots) and v_cndmask selects on them.  Written this way because
     // the scalar unit, not the vector unit, is the busier issue port of this loop (profiles/r03_k1_issue_ports.txt: one more scalar
     // instruction per round costs 1.6 x one more vector instruction): the structured control flow the compiler builds from `if`s on
@@ -424,9 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         bestlen = (int)sel_mask(setm, link_bestlen(e.x), sel_mask(acc, (uint32_t)depth, (uint32_t)bestlen));
         // probe only for a byte the node can continue with: bit (c & 31) of its child filter (0 behind a link that cannot go on)
         M64 go = adv & __builtin_amdgcn_ballot_w64(bit_of(e.z, c) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
-#ifdef TM_DEVEL
         if (nowalk) go = 0ull;
-#endif
         const M64 fin = busy & ~go;
         // the best match so far at the lane's position, every round (the last store of a position is its result; a lane that has run out
         // of positions stays on its last one and stores the same values again): no select of a store address, and ONE store for both
@@ -465,11 +454,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   unsigned long long elig[NPOS_PAD / 64];
   {
     const int off = (int)T.off;
-#ifdef TM_DEVEL
-    const bool can_b = T.has_delete && T.bstart != kNone && !(dbg & 8);
-#else
-    const bool can_b = T.has_delete && T.bstart != kNone;
-#endif
+    const bool can_b = T.has_delete && T.bstart != kNone && !TM_DBG_ON(dbg & 8);
 #pragma unroll
     for (int it = 0; it < NPOS_PAD / 64; it++) {
       const int p = it * 64 + lane;
@@ -632,9 +617,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   // In-place updates are safe: an entry is read and written as one 4-byte LDS access and always describes a valid prefix of its
   // state's chain.  (What a chain emits besides its count — forward-deletes, missing characters — is counted by K4, which walks
   // the one chain that is real.)
-#ifdef TM_DEVEL
-  if (dbg & 16) { for (int e = lane; e < ENT; e += 64) exit16[g * ENT + e] = 0u; return; }   // (timing experiments only)
-#endif
+  if (TM_DBG_ON(dbg & 16)) { for (int e = lane; e < ENT; e += 64) exit16[g * ENT + e] = 0u; return; }   // (timing experiments only)
   {
     uint32_t* J = reinterpret_cast<uint32_t*>(w.D) + J_SKIP;       // overlays D, Db (dead after step B): 2 x SEG words, state (p, fd) at J[fd * J_PLANE + p]
     static_assert(J_SKIP + J_PLANE + SEG <= 2 * NPOS, "J overlay does not fit");
@@ -1334,26 +1317,17 @@ namespace tmh {
 // reachable in the default build.  With -DTM_DEVEL (tools/ only: results are WRONG) further bits switch
 // phases of K1 off for profiling — 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps — bit 9 adds 4 KB
 // of dummy LDS per K1 workgroup, and TM_DBG in the environment sets the initial value.
-#ifdef TM_DEVEL
-constexpr int kDebugMask = ~0;
-#define TM_K1_EXTRA_LDS ((debug_flags() & 512) ? 4096 : 0)
-#else
+#ifndef TM_DEVEL
 constexpr int kDebugMask = 64 | 256 | 1024 | 4096 | 8192;
 #define TM_K1_EXTRA_LDS 0
+#define TM_DBG_INITIAL 0
 #endif
 int g_debug_flags = -1;
 // The hooks are armed only in a process that was started with TM_TEST_HOOKS in its environment (the test suite's conftest, bench.py
 // --also-flags): in any other process tm_debug_flags() is inert, so that no caller of a server can change the code path under the others.
 static bool hooks_armed() { static const bool armed = getenv("TM_TEST_HOOKS") != nullptr; return armed; }
 int debug_flags() {
-  if (g_debug_flags < 0) {
-#ifdef TM_DEVEL
-    const char* e = getenv("TM_DBG");
-    g_debug_flags = e ? atoi(e) : 0;
-#else
-    g_debug_flags = 0;
-#endif
-  }
+  if (g_debug_flags < 0) g_debug_flags = TM_DBG_INITIAL;
   return g_debug_flags;
 }
 
@@ -1863,15 +1837,7 @@ const uint64_t* tm_batch_device_tok_offsets(const tm_batch* b) { return b->d_tok
 uint64_t tm_batch_device_bytes(const tm_batch* b) { return b->device_bytes; }
 
 #ifdef TM_PHASE_TIMERS
-int tm_debug_phases(unsigned long long* out, int reset) {
-  static unsigned long long z[64 * 32];
-  if (out) {
-    if (hipMemcpyFromSymbol(z, HIP_SYMBOL(tmh::g_phase), sizeof z) != hipSuccess) return -1;
-    for (int i = 0; i < 32; i++) { out[i] = 0; for (int b = 0; b < 64; b++) out[i] += z[b * 32 + i]; }
-  }
-  if (reset) { for (auto& x : z) x = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(tmh::g_phase), z, sizeof z) != hipSuccess) return -1; }
-  return 0;
-}
+TM_DEVEL_PHASES_ENTRY
 #endif
 
 }  // extern "C"
