@@ -177,7 +177,8 @@ int tm_batch_run_timed(tm_batch* b, void* stream, float* ms);
 const char* tm_kernel_name(int k);
 /* Test hooks: sets the switches and returns the previous value; flags < 0 only queries.  Every bit forces a rarely taken path of
  * the product with the SAME results, so that the tests can cover it: 6 = dense T(p,1) array for every segment, 8 = per-lane
- * normalizer kernel instead of k_norm_emit2, 10 = K4 tile walk that stores every id directly (its overflow path), 12 = group tree of
+ * normalizer kernel instead of k_norm_emit2, 10 = K4 tile walk that stores every id directly (its overflow path), 11 = the device normalizer packs its text
+ * (the path of a batch with host-normalized documents) instead of leaving it in its slabs for the match kernel, 12 = group tree of
  * long documents with fan-out 4 from 9 segments on, 13 = 64 KiB mailbox for the small host <-> device transfers.  Other bits are
  * ignored (a -DTM_DEVEL build, tools/ only, adds profiling bits that switch phases of the match kernel off).  The switches are process-wide,
  * so they are armed only in a process started with TM_TEST_HOOKS in its environment (the test suite, bench.py --also-flags): anywhere

@@ -256,10 +256,14 @@ def test_latin_text_is_decoded_on_the_device():
         exp = dec.decode(tok[int(toff[d]):int(toff[d + 1])]) + dec.flush()
         assert out[int(ooff[d]):int(ooff[d + 1])].tobytes() == exp, doc
     assert out[int(ooff[1]):int(ooff[2])].tobytes() == "STRAßE Øre N\u0303andu\u0301 ÑU".encode()      # (ß has no simple upper case)
-    for other in ["W\u4e2d\u6587".encode(), "Cÿ".encode(), b"W\xc3("]:     # another script; an upper-case form with another lead byte; malformed UTF-8
+    # what is left to the host decoder: an upper-case form of another length (ı -> I), case in three bytes (fullwidth Latin), malformed UTF-8;
+    # another two-byte lead for the upper-case form (ÿ -> Ÿ) and caseless three-byte scripts stay on the device since round 4
+    for other, on_host in [("W\u4e2d\u6587 Cの".encode(), 0), ("Cÿ Wÿz".encode(), 0), ("Wж Cσ Wֆ".encode(), 0), ("Cı".encode(), 1), ("C\uff41".encode(), 1), (b"W\xc3(", 1)]:
         t2, o2 = tm.pack_documents([other, b"Wascii"])
-        a.decode_packed(id_of[t2], o2, raw=False)
-        assert N.lib.tm_decode_host_docs() == 1
+        out2, oo2 = a.decode_packed(id_of[t2], o2, raw=False)
+        assert N.lib.tm_decode_host_docs() == on_host, other
+        dec = a.decoder()
+        assert out2[:int(oo2[1])].tobytes() == dec.decode(id_of[t2][:int(o2[1])]) + dec.flush(), other
 
 
 @pytest.mark.parametrize("capcode,with_unk", [(2, False), (0, True)])

@@ -122,7 +122,7 @@ def test_fallback_paths_behind_test_hooks(flags):
     finally:
         N.lib.tm_debug_flags(old)
     assert (got_s == exp_s).all() and got_t == exp_t and (got_m == exp_m).all()
-    assert N.lib.tm_debug_flags(1 | 4 | 16 | 128 | 2048) == 0 and N.lib.tm_debug_flags(0) == 0    # profiling switches: not in this build
+    assert N.lib.tm_debug_flags(1 | 4 | 16 | 128 | 512) == 0 and N.lib.tm_debug_flags(0) == 0    # profiling switches: not in this build
 
 
 @pytest.mark.parametrize("name", ["english-24000-consistent", "englishcode-32000-consistent", "englishcode-100256-clean",
@@ -380,6 +380,47 @@ def test_device_normalizer_matches_host_and_reference():
     got, goff, _ = v0.normalize_packed_device(etext, eoffs)
     exp, eoff = synth.normalize_batch(etext, eoffs, 0, 3)
     assert (goff == eoff).all() and (got == exp).all()
+
+
+def test_match_kernel_stages_the_text_from_the_normalizer_slabs():
+    """tm_batch_normalize leaves the normalized text in its per-piece slabs (no compaction pass) and k_match_branch stages every segment from
+    there (k_seg_src: a segment begins anywhere in a piece and may run into the next one, words straddle the seam at every alignment):
+    ids == the ids of the host-normalized text == the ids with the text packed first (test hook 11, the path a batch with host-normalized
+    documents takes); a batch with such documents; the packed text can still be had afterwards"""
+    from tokenmonster_amd import _native as N
+    img = synth.synth_vocab(synth.ENGLISHCODE, 1500, capcode=2, norm_flag=1, level=3, seed=11)
+    v = tm.Vocab(img)
+    raw, offs = synth.synth_corpus(synth.ENGLISHCODE, 600_000, seed=33)
+    docs = [raw[int(offs[d]):int(offs[d + 1])].tobytes() for d in range(offs.size - 1)]
+    rng = np.random.default_rng(5)
+    for n in (1, 255, 256, 257, 352, 1023, 1024, 1025, 1279, 1280, 2047, 2048, 2049, 4095, 4096, 4097, 70_000):
+        for caps in (0, 1, 2, 3, 5):            # capitals move the seams between the pieces byte by byte (a marker in front of each)
+            body = bytearray(b"the quick brown fox jumps over the lazy dog " * (n // 44 + 1))[:n]
+            for i in rng.integers(0, max(n, 1), size=caps):
+                body[int(i)] = ord("Q")
+            docs.append(bytes(body))
+    docs += [b"", b"A", "déjà vu Élan".encode() * 300, b"x" * 1024 + b"Y" * 3 + b"z" * 1021]
+    clean = list(docs)
+    host_ids, _ = v.tokenize_normalized([v.normalize(d) for d in clean])
+    for flags in (0, 2048):
+        old = N.lib.tm_debug_flags(flags)
+        try:
+            got = v.tokenize(clean)
+        finally:
+            N.lib.tm_debug_flags(old)
+        bad = [(d, len(clean[d]), g.size, h.size) for d, (g, h) in enumerate(zip(got, host_ids)) if g.size != h.size or (g != h).any()]
+        assert not bad, (flags, len(bad), bad[:12])
+    # a batch in which some documents go to the host normalizer (the device part is packed, the host part placed behind it)
+    mixed = clean[:200] + ["\u1e9e gro\u00dfe \U0001d400 x".encode(), "\uff21\uff22 fullwidth".encode()] + clean[200:400]
+    got = v.tokenize(mixed)
+    exp, _ = v.tokenize_normalized([v.normalize(d) for d in mixed])
+    for d, (g, h) in enumerate(zip(got, exp)):
+        assert g.size == h.size and (g == h).all(), d
+    # ... and the normalized text itself, packed on request after the usual path has left it in the slabs
+    text_in, offs_in = tm.pack_documents(clean)
+    gtext, goff, nfb = v.normalize_packed_device(text_in, offs_in)
+    etext, eoff = synth.normalize_batch(text_in, offs_in, 2, 1)
+    assert nfb == 0 and (goff == eoff).all() and (gtext == etext).all()
 
 
 def test_lossy_normalizer_flags_take_the_host_path_inside_the_device_call():

@@ -436,6 +436,9 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
         const uint64_t need = lane_need(true, offsets[n0 + nn] - offsets[n0]);
         // (a chunk that would replace the workspace, or the per-document arrays the current chunk still reads, is uploaded later)
         if (!l->ws || l->ws->max_bytes < need || l->ws->max_docs < nn || (uint64_t)nn + 2 > l->ws->raw_docs_cap) return TM_OK;
+        loc_next.resize((size_t)nn + 1);
+        for (uint32_t d = 0; d <= nn; d++) loc_next[d] = offsets[n0 + d] - offsets[n0];
+        if (raw_upload_replaces_buffers(l->ws, loc_next.data(), nn)) return TM_OK;       // (the slabs and piece offsets of the current chunk are read by its match kernel)
         int r = upload(k_next, loc_next, l->up_stream, &src_next);
         if (r != TM_OK) return r;
         hipError_t e = hipEventRecord(l->up_done, l->up_stream);

@@ -280,6 +280,22 @@ __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w
 // per lane) and copies the neighbour's descriptors after ONE workgroup barrier.  Step C's pointer-doubling table then overlays
 // D[40..] / Db[40..] instead of D[0..], so that a wavefront never overwrites what its left neighbour may still be copying.
 // Host model (round 2): 70 % of the wavefronts share, 26.5 -> 24.3 rounds per wavefront in step A1.
+// For a batch whose text still lies in the device normalizer's slabs (tm_norm.hip): the piece a segment begins in, the offset of its first
+// byte in that piece's slab, and how many bytes the piece holds from there.  piece_off = the pieces' places in the packed text.
+__global__ void k_seg_src(const uint32_t* __restrict__ seg_doc, const uint64_t* __restrict__ doc_seg_start, const uint64_t* __restrict__ doc_begin,
+                          const uint64_t* __restrict__ doc_piece_start, const uint64_t* __restrict__ piece_off, uint64_t nseg, uint4* __restrict__ seg_src) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nseg) return;
+  const uint32_t d = seg_doc[g];
+  const uint64_t begin = doc_begin[d] + (g - doc_seg_start[d]) * SEG;
+  uint64_t lo = doc_piece_start[d], hi = doc_piece_start[d + 1];          // the last piece of the document that begins at or before `begin`
+  while (hi - lo > 1) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (piece_off[mid] <= begin) lo = mid; else hi = mid;
+  }
+  seg_src[g] = make_uint4((uint32_t)lo, (uint32_t)(begin - piece_off[lo]), (uint32_t)(piece_off[lo + 1] - begin), 0u);
+}
+
 constexpr int J_SKIP = NPOS - SEG, J_PLANE = NPOS;     // step C: state (p, fd) lives at word J_SKIP + fd * J_PLANE + p of {D, Db}
 __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
@@ -289,13 +305,12 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
                                                                 const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
                                                                 uint32_t* __restrict__ R0, uint2* __restrict__ side,
                                                                 uint32_t* __restrict__ R1, uint32_t* __restrict__ exitmap, uint16_t* __restrict__ exit16,
-                                                                int narrow, int dbg) {
+                                                                int narrow, int dbg, const uint8_t* __restrict__ slab, const uint4* __restrict__ seg_src) {
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
   const int lane = threadIdx.x & 63, wvi = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the segment, its document and lengths live in SGPRs
   TM_LDS_OBJECTS(s_bb, s_wave);
-  static_assert(WAVES * 64 == 256, "s_bb is filled one entry per work-item (a 2-wavefront build tokenized wrongly on the device)");
-  s_bb[threadIdx.x] = T.begin_byte[threadIdx.x];
+  for (int j = threadIdx.x; j < 256; j += WAVES * 64) s_bb[j] = T.begin_byte[j];
   __syncthreads();
   const uint64_t g = (uint64_t)blockIdx.x * WAVES + wvi;
   if (g >= nseg) return;
@@ -316,14 +331,41 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 
   // stage the text with (unaligned) dword loads; bytes at and after the end of the document read as 0: the pad
   // byte of go/tokenmonster.go:1038-1046 (quirk Q1: we define it as 0 like tokenmonster.cpp:1724-1726)
-  for (int j = lane; j < TEXT_LEN / 4; j += 64) {
-    uint32_t tw = 0;
-    if (4 * j < dl) {
-      // (non-temporal: with ordinary loads the kernel FETCHES 20 % more - the text lines push table lines out of the L2 - at the same time)
-      { typedef uint32_t __attribute__((aligned(1))) u32u; tw = TM_STREAM_LOAD(reinterpret_cast<const u32u*>(text + begin + 4 * j)); }
-      if (4 * j + 4 > dl) tw &= (1u << (8 * (dl - 4 * j))) - 1u;
+  typedef uint32_t __attribute__((aligned(1))) u32u;
+  if (slab == nullptr) {
+    for (int j = lane; j < TEXT_LEN / 4; j += 64) {
+      uint32_t tw = 0;
+      if (4 * j < dl) {
+        // (non-temporal: with ordinary loads the kernel FETCHES 20 % more - the text lines push table lines out of the L2 - at the same time)
+        tw = TM_STREAM_LOAD(reinterpret_cast<const u32u*>(text + begin + 4 * j));
+        if (4 * j + 4 > dl) tw &= (1u << (8 * (dl - 4 * j))) - 1u;
+      }
+      reinterpret_cast<uint32_t*>(w.text)[j] = tw;
     }
-    reinterpret_cast<uint32_t*>(w.text)[j] = tw;
+  } else {
+    // The text as the device normalizer left it: one 2 KiB slab per piece of a document, the pieces' bytes not yet packed (tm_batch_normalize
+    // skips its compaction pass: that was 2.2 GB of traffic per GiB for something this loop does on the way).  `begin` and the documents'
+    // ranges stay positions in the packed text that never was; k_seg_src has found the piece the segment begins in: byte i of the segment is
+    // byte i of s0 while i < len0 and of the next piece's slab after that (a piece that is not the last of its document holds at least
+    // TEXT_LEN bytes - tm_batch_normalize packs the text after all when one does not -, so two pieces cover what a segment looks at).
+    const uint4 ss = seg_src[g];
+    const uint8_t* s0 = slab + (uint64_t)ss.x * SLAB_BYTES + ss.y;
+    const int len0 = (int)ss.z;
+    const uint8_t* s1 = slab + ((uint64_t)ss.x + 1) * SLAB_BYTES - len0;                // byte i >= len0 of the segment
+    for (int j = lane; j < TEXT_LEN / 4; j += 64) {
+      uint32_t tw = 0;
+      const int i = 4 * j;
+      if (i < dl) {
+        tw = TM_STREAM_LOAD(reinterpret_cast<const u32u*>((i + 4 <= len0 ? s0 : s1) + i));
+        const int n0 = len0 - i;                                                        // bytes of this word that lie in the first piece
+        if (n0 > 0 && n0 < 4) {
+          const uint32_t lo = TM_STREAM_LOAD(reinterpret_cast<const u32u*>(s0 + i)), m = (1u << (8 * n0)) - 1u;
+          tw = (lo & m) | (tw & ~m);
+        }
+        if (i + 4 > dl) tw &= (1u << (8 * (dl - i))) - 1u;
+      }
+      reinterpret_cast<uint32_t*>(w.text)[j] = tw;
+    }
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
@@ -1312,13 +1354,14 @@ namespace tmh {
 
 // Test hooks (tm_debug_flags): bits that force a rarely taken fallback path of the product so that the tests can cover it, with the
 // same results: 6 = dense T(p,1) array for every segment, 8 = per-lane normalizer kernel, 10 = K4 tile walk that stores every id
-// directly, 12 = group tree of long documents with fan-out 4 from 9 segments on (a deep tree on a small document), 13 = a 64 KiB
+// directly, 11 = the device normalizer packs its text instead of leaving it in the slabs for K1, 12 = group tree of long documents with fan-out 4
+// from 9 segments on (a deep tree on a small document), 13 = a 64 KiB
 // mailbox for the small host <-> device transfers (wraps within a test).  Nothing else is
 // reachable in the default build.  With -DTM_DEVEL (tools/ only: results are WRONG) further bits switch
 // phases of K1 off for profiling — 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps — bit 9 adds 4 KB
 // of dummy LDS per K1 workgroup, and TM_DBG in the environment sets the initial value.
 #ifndef TM_DEVEL
-constexpr int kDebugMask = 64 | 256 | 1024 | 4096 | 8192;
+constexpr int kDebugMask = 64 | 256 | 1024 | 2048 | 4096 | 8192;
 #define TM_K1_EXTRA_LDS 0
 #define TM_DBG_INITIAL 0
 #endif
@@ -1357,6 +1400,7 @@ static void launch_seg_params(tm_batch* b, hipStream_t st);
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
                        uint32_t n_ids, hipStream_t st) {
   const uint64_t nseg = b->nseg;
+  pack_text(b, st);                    // (k_score_tiles looks at the text)
   if (nseg > 0) {
     launch_seg_params(b, st);
     constexpr int WV = SEG <= 256 ? 11 : 5;      // wavefronts of a scoring workgroup: as many tiles as fit the LDS beside the histogram
@@ -1513,13 +1557,16 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
     TM_LAUNCH(k_doc_nseg, (nd + 255) / 256, 256, 0, st, b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nseg, (uint32_t)SEG, b->d_error);
     scan_u32(b->d_doc_nseg, nd, b->d_scan_tmp, b->d_totals + 0, b->d_doc_seg_start, st);
     if (nseg > 0) TM_LAUNCH(k_segments, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_doc_seg_start, nd, nseg, b->d_seg_doc);
+    // the text still lies in the normalizer's slabs: where each segment begins in them (in d_seg_par, which K4's parameters take over after K3)
+    if (nseg > 0 && b->text_in_slabs)
+      TM_LAUNCH(k_seg_src, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_seg_doc, b->d_doc_seg_start, b->d_doc_begin, b->d_doc_piece_start, b->d_piece_off, nseg, b->d_seg_par);
   }
   mark(1);
   if (nseg > 0)
     TM_LAUNCH(k_match_branch, (uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st, v->tables, b->d_text, b->d_doc_begin, b->d_doc_end,
                                                                                           b->d_doc_vis ? b->d_doc_vis : b->d_doc_end, b->d_seg_doc,
                                                                                           b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap, b->d_exit16, r0_narrow(b) ? 1 : 0,
-                                                                                          debug_flags());
+                                                                                          debug_flags(), b->text_in_slabs ? b->d_slab : nullptr, b->d_seg_par);
     note_table_use(v, st);
   mark(2);
   for (size_t lvl = 0; lvl + 1 < b->level_first.size() && b->ngroups > 0; lvl++) {     // bottom up: a level reads the maps of the one below
@@ -1780,6 +1827,7 @@ int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
   b->nbytes = nbytes;
   b->nseg = nseg;
   b->d_doc_begin = b->d_offsets;
+  b->text_in_slabs = false;
   b->d_doc_end = b->d_offsets + 1;
   return build_groups(b, offsets, offsets + 1, ndocs, st);
 }

@@ -193,6 +193,7 @@ __global__ void k_norm_carry(const uint32_t* __restrict__ piece_sum, const uint6
 // private slab (SLAB bytes apart; a piece that would not fit raises the overflow flag) and the length — the common
 // one-pass path; k_norm_compact then packs the slabs.
 constexpr int SLAB = 2 * PIECE;
+static_assert(SLAB == SLAB_BYTES, "k_match_branch stages the text from these slabs");
 template <int MODE>
 __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rbegin,
                                                    const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
@@ -513,10 +514,16 @@ __global__ void k_norm_bad_docs(const uint8_t* __restrict__ need_host, uint32_t 
 }
 
 // the two kernels above in one launch (thread k looks at piece k and at document k): the one-sync path of tm_batch_normalize
-__global__ void k_norm_bad(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, uint64_t npieces, uint32_t ndocs,
-                           uint32_t* __restrict__ piece_len, unsigned long long* __restrict__ ninfo, uint32_t* __restrict__ fb_ids) {
+// ... and ninfo[6] counts the pieces that are not the last of their document yet shorter than what a segment looks at (TEXT_LEN): with one
+// of those the text cannot be staged from the slabs by k_match_branch (which looks at two pieces at most) and is packed after all
+__global__ void k_norm_bad(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, const uint64_t* __restrict__ doc_piece_start, uint64_t npieces,
+                           uint32_t ndocs, uint32_t* __restrict__ piece_len, unsigned long long* __restrict__ ninfo, uint32_t* __restrict__ fb_ids) {
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < npieces && need_host[piece_doc[k]]) piece_len[k] = 0;
+  if (k < npieces) {
+    const uint32_t d = piece_doc[k];
+    if (need_host[d]) piece_len[k] = 0;
+    else if (piece_len[k] < (uint32_t)TEXT_LEN && k + 1 != doc_piece_start[d + 1]) atomicAdd(&ninfo[6], 1ull);
+  }
   if (k < ndocs && need_host[k]) fb_ids[atomicAdd(&ninfo[0], 1ull)] = (uint32_t)k;
 }
 
@@ -699,8 +706,28 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
   b->raw_pieces = npieces;
   return TM_OK;
 }
+
+// Would batch_upload_raw_on(these documents) replace a buffer that the batch in flight still reads?  After its normalizer pass that is the
+// per-document ranges (always) and - when the text stays in the slabs for k_match_branch - the slabs and the pieces' offsets.  The
+// host-to-host pipeline asks before it uploads a lane's next chunk beside the tokenizer kernels of the current one.
+bool raw_upload_replaces_buffers(const tm_batch* b, const uint64_t* raw_offsets, uint32_t ndocs) {
+  if (!b || !b->d_raw_off || !b->d_piece_doc) return true;
+  uint64_t npieces = 0;
+  for (uint32_t d = 0; d < ndocs; d++) npieces += (raw_offsets[d + 1] - raw_offsets[d] + PIECE - 1) / PIECE;
+  return (uint64_t)ndocs + 2 > b->raw_docs_cap || npieces + 2 > b->piece_cap || (npieces + 1) * (uint64_t)SLAB > b->slab_cap;
+}
+
+// the slabs of the current batch packed into d_text (what tm_batch_normalize leaves out in the usual case); piece lengths and offsets are
+// those of the last normalize call
+void pack_text(tm_batch* b, hipStream_t st) {
+  if (!b->text_in_slabs) return;
+  b->text_in_slabs = false;
+  const uint64_t np = b->slab_pieces;
+  if (np > 0) TM_LAUNCH(k_norm_compact, (uint32_t)((np + 3) / 4), 256, 0, st, b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text, b->max_bytes);
+}
 }  // namespace tmh
 extern "C" {
+
 
 int tm_batch_normalize(tm_batch* b, void* stream) {
   if (!b) return set_error(TM_E_INVALID, "null argument");
@@ -717,6 +744,8 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   b->d_doc_begin = b->d_nbegin;
   b->d_doc_end = b->d_nend;
   b->ndocs = nd; b->nbytes = 0; b->nseg = 0; b->ngroups = 0; b->nlong = 0;
+  b->text_in_slabs = false;
+  b->slab_pieces = np;
   if (nd == 0) return TM_OK;
   static const bool trace = getenv("TM_TRACE") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -744,11 +773,12 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   if (fast) {
     TM_LAUNCH(k_norm_emit2<false>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
                                                b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
-    TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
+    TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
     scan_u32(b->d_piece_len, np, b->d_scan_tmp, reinterpret_cast<uint64_t*>(ninfo + 5), b->d_piece_off, st);      // (the total lands beside the info words: one copy brings everything)
-    TM_LAUNCH(k_norm_compact, pgrid, 256, 0, st, b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text, b->max_bytes);
+    // NO compaction pass here: in the usual case the text stays in the slabs and k_match_branch stages its segments from there (k_seg_src) —
+    // packing it was 2.2 GB of traffic and 0.8 ms per GiB; pack_text() below is for the cases that need the packed text after all
     TM_LAUNCH(k_norm_ranges_info, (nd + 255) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend, ninfo, long_segs());
-    { int rc = small_d2h(b, h_info, ninfo, 48, st); if (rc == TM_OK) rc = small_sync(b, st);
+    { int rc = small_d2h(b, h_info, ninfo, 56, st); if (rc == TM_OK) rc = small_sync(b, st);
       if (rc != TM_OK) return rc; }
     pre_bytes = h_info[5];
     if (h_info[3] != 0 || h_info[4] != 0) {        // a piece whose margins could not tell, or one that outgrew its slab: the exact path, from the start
@@ -759,6 +789,8 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
         return set_error(TM_E_LIMIT, "normalized text needs %llu bytes, workspace sized for %llu", (unsigned long long)pre_bytes, (unsigned long long)b->max_bytes);
       b->nbytes = pre_bytes;
       b->nseg = h_info[2];
+      b->text_in_slabs = true;
+      if (h_info[6] != 0 || (tm_debug_flags(-1) & 2048)) pack_text(b, st);        // a short piece inside a document (or the test hook): the packed text after all
       int rc = TM_OK;
       if (h_info[1] > 0) {
         std::vector<uint64_t> hb(nd), he(nd);
@@ -768,7 +800,11 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
       }
       if (trace) fprintf(stderr, "[tm_batch_normalize] one trip: %.2f ms\n", now() - t0);
       return rc;
-    } else pre = true;                              // some documents need the host normalizer: fetch, normalize, place them behind the device part below
+    } else {                                        // some documents need the host normalizer: fetch, normalize, place them behind the device part below
+      pre = true;
+      b->text_in_slabs = true;
+      pack_text(b, st);
+    }
   }
   if (!fast) {
     if (np > 0) TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_two, b->d_piece_sum);
@@ -893,6 +929,8 @@ uint32_t tm_batch_host_fallback_docs(const tm_batch* b) { return b->host_fallbac
 int tm_batch_download_text(tm_batch* b, uint8_t* text_out, uint64_t text_cap, uint64_t* offsets_out) {
   if (!b) return set_error(TM_E_INVALID, "null argument");
   hipError_t e;
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "sync");
+  pack_text(b, nullptr);
   if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "sync");
   if (b->nbytes > text_cap) return set_error(TM_E_NOSPACE, "text_cap too small");
   const uint32_t nd = b->ndocs;

@@ -16,8 +16,12 @@ constexpr int SEG = 256;                 // bytes of one document segment (one w
 constexpr int NPOS = SEG + 40;           // positions whose descriptors a segment needs (look-ahead <= 40)
 constexpr int NPOS_PAD = (NPOS + 63) / 64 * 64;
 constexpr int TEXT_LEN = SEG + 96;       // staged text: position i may read up to i + 40
+constexpr int SLAB_BYTES = 2048;         // the device normalizer's slab for one 1 KiB piece of raw text (tm_norm.hip); K1 can stage the text from there
 constexpr int ENT = 80;                  // entry states of a segment: 40 offsets x fd{0,1}
-constexpr int WAVES = 4;                 // wavefronts per workgroup in K1 (8: +14 %, the halo barrier couples more wavefronts)
+#ifndef TM_K1_WAVES
+#define TM_K1_WAVES 4
+#endif
+constexpr int WAVES = TM_K1_WAVES;                 // wavefronts per workgroup in K1 (8: +14 %, the halo barrier couples more wavefronts)
 constexpr uint32_t R_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t J_EXIT = 1024;           // jump targets >= J_EXIT: left the segment; J_EXIT + next entry state
 constexpr uint32_t J_INVALID = 2047;        // state is not reachable (no forward-delete match there)
@@ -117,6 +121,8 @@ struct tm_batch {
   // raw (un-normalized) input of tm_batch_upload_raw / tm_batch_normalize
   uint8_t* d_raw = nullptr;
   uint8_t* d_slab = nullptr;            // normalizer: one 2 KiB slab per 1 KiB piece
+  uint64_t slab_pieces = 0;             // pieces of the batch that was normalized last (raw_pieces may already count the next upload)
+  bool text_in_slabs = false;           // the normalized text of this batch has not been packed into d_text: K1 stages it from the slabs (k_seg_src)
   uint64_t slab_cap = 0;
   uint64_t* d_raw_off = nullptr;
   uint64_t raw_cap = 0, raw_bytes = 0, raw_pieces = 0, piece_cap = 0;
@@ -192,6 +198,8 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev);
 int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode);
 void launch_doc_exits(tm_batch* b, uint8_t* d_exits, hipStream_t st);
 // scoring variant of the chain kernel: histogram in HBM (scores | 4 limbs | 256 counters), see tm_score.hip
+bool raw_upload_replaces_buffers(const tm_batch* b, const uint64_t* raw_offsets, uint32_t ndocs);
+void pack_text(tm_batch* b, hipStream_t st);     // tm_norm.hip: the normalizer's slabs packed into d_text (no-op unless text_in_slabs)
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,
                        uint32_t n_ids, hipStream_t st);
 int ensure_output(tm_batch* b);

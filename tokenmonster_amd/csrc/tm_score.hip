@@ -82,6 +82,7 @@ static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
     if (rc == TM_OK) rc = small_h2d(b, d->d_vis, be.data() + 2ull * n_strips, (uint64_t)n_strips * 8, st);
     if (rc != TM_OK) return rc; }
   b->d_doc_begin = b->d_offsets;
+  b->text_in_slabs = false;
   b->d_doc_end = b->d_offsets + n_strips;
   b->d_doc_vis = d->d_vis;
   b->d_doc_entry = nullptr;

@@ -315,6 +315,10 @@ void* guarded_alloc(size_t n) {
   if (m == MAP_FAILED) return nullptr;
   mprotect(static_cast<char*>(m) + body, pg, PROT_NONE);
   char* start = static_cast<char*>(m) + body - need;
+  // device memory is not zero when it is handed out: a kernel that reads what nobody has written must not get away with it here
+  // (TM_EMU_POISON=0: the zero pages of the mapping, as before round 4)
+  static const bool poison = [] { const char* e = getenv("TM_EMU_POISON"); return !e || atoi(e) != 0; }();
+  if (poison) memset(start, 0xA5, need);
   std::lock_guard<std::mutex> lk(g_mem_mutex);
   g_blocks[(uintptr_t)start] = Block{body + pg, m};
   return start;

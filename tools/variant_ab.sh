@@ -8,12 +8,12 @@
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-declare -A VARIANTS=( [devel]="-DTM_DEVEL" )
+declare -A VARIANTS=( [devel]="-DTM_DEVEL" [waves1]="-DTM_K1_WAVES=1" [waves2]="-DTM_K1_WAVES=2" [waves3]="-DTM_K1_WAVES=3" )
 case "${1:-}" in
 build)
   for name in "${!VARIANTS[@]}"; do
     tmp=$(mktemp -d)
-    cp -r tokenmonster_amd include "$tmp/"
+    cp -r tokenmonster_amd include "$tmp/"; mkdir -p "$tmp/tools"; cp -r tools/devel "$tmp/tools/"
     rm -rf "$tmp/tokenmonster_amd/csrc/build" "$tmp"/tokenmonster_amd/*.so
     ( cd "$tmp" && TM_EXTRA_FLAGS="${VARIANTS[$name]}" python tokenmonster_amd/build.py > "$tmp/build.log" 2>&1 ) || { tail -20 "$tmp/build.log"; exit 1; }
     mkdir -p "variants/$name"
