@@ -491,6 +491,15 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
+  // the row gathers of step B need only what step A1 has left (X[p]): issued here, they are under way while step A3 walks (-2 % on the
+  // 100 256-id shape, whose rows miss the L2 more often; nothing on the others: 32 wavefronts per CU hide a latency like this one anyway)
+  Row row0[SEG / 64];
+#pragma unroll
+  for (int it = 0; it < SEG / 64; it++) {
+    const int p = it * 64 + lane;
+    row0[it] = Row{0u, 0u, 0u, 0u};
+    if (p < seglen && w.D[p] != 0) row0[it] = T.rows[node_id(w.X[p])];
+  }
   // ---- A2: class of the byte after each match; which positions need the forward-delete probe (go :1088) ----------
   // second token begins with a letter, has no word boundary and the byte after it is letter-class
   unsigned long long elig[NPOS_PAD / 64];
@@ -589,7 +598,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   // the task list of step A3, free by now — and evaluated in as few full-width passes as possible.
   uint32_t r0[SEG / 64], r1[SEG / 64];
   {
-    Row row0[SEG / 64];
     uint32_t d0[SEG / 64];
     unsigned long long m1[SEG / 64];
     int n1 = 0;
@@ -597,8 +605,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     for (int it = 0; it < SEG / 64; it++) {
       const int p = it * 64 + lane;
       d0[it] = w.D[p];
-      row0[it] = Row{0u, 0u, 0u, 0u};
-      if (p < seglen && d0[it] != 0) row0[it] = T.rows[node_id(w.X[p])];
       m1[it] = __ballot(p < seglen && w.Db[p] != 0);
       n1 += __popcll(m1[it]);
     }
