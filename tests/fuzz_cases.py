@@ -131,6 +131,52 @@ def one_norm(seed):
     return int(raw.size)
 
 
+def one_raw(seed):
+    """raw text -> ids in ONE device pass (tm_batch_upload_raw + tm_batch_normalize + tm_batch_run: the normalized text stays in the
+    normalizer's slabs and the match kernel stages its segments from there; with test hook 11 it is packed first; through the chunked
+    host-to-host pipeline) against the host normalizer + the oracle's walk: random vocabularies over what the normalizer writes (capcode
+    markers included), documents whose pieces (1 KiB of raw text) and segments (256 normalized bytes) fall everywhere relative to each other"""
+    rng = np.random.default_rng(seed)
+    flag = int(rng.choice([1, 1, 3]))
+    toks = conftest.fuzz_vocab_tokens(rng, 2, int(rng.integers(40, 500)), singles=True)
+    toks = sorted(set(toks) | {"\u0301".encode(), "\u00e9".encode(), "\u2019".encode(), b"C", b"W", b"D", b"Ca", b"W x", b" the", b"ing ", b"D a"})
+    img = synth.build_vocab(toks, capcode=2, charset=1, norm_flag=flag, with_unk=bool(rng.random() < 0.5))
+    v, orc = tm.Vocab(img), Oracle(img)
+    words = ["the", "The", "THE", "a", "I", "I'm", "X\u2019s", "caf\u00e9", "\u00c9cole", "HTTPServer", "x1", "42", "3.14", "snake_case", "Q", "\u4e2d\u6587", "\u0434\u0430", "\u0394"]
+    docs = []
+    for _ in range(int(rng.integers(1, 40))):
+        n = int(rng.choice([0, 1, 3, 255, 256, 257, 351, 352, 353, 1000, 1023, 1024, 1025, 1279, 1281, 2047, 2048, 2049, 3000, 4097, 9000])) + int(rng.integers(0, 3))
+        parts, size = [], 0
+        while size < n:
+            r = rng.random()
+            w = str(rng.choice(words)) if r < 0.7 else "".join(rng.choice(NORM_ALPHABET[:36], size=int(rng.integers(1, 12)))) if r < 0.9 else "x" * int(rng.integers(1, 700))
+            sep = str(rng.choice([" ", " ", " ", "\n", ", ", "", "-"]))
+            parts.append(w + sep)
+            size += len((w + sep).encode())
+        docs.append("".join(parts).encode()[:n])
+    if rng.random() < 0.3:
+        docs.append(("\U0001f600 \u1e9e " * int(rng.integers(1, 30))).encode())                  # a document for the host normalizer: the batch is packed
+    hook = 2048 if rng.random() < 0.25 else 0
+    old = N.lib.tm_debug_flags(hook)
+    try:
+        got = v.tokenize(docs)
+    finally:
+        N.lib.tm_debug_flags(old)
+    norm = [v.normalize(d) for d in docs]
+    for d, doc in enumerate(norm):
+        exp, _ = orc.tokenize(doc)
+        if got[d].size != exp.size or (got[d] != exp).any():
+            raise AssertionError("seed %d (hook %d) doc %d (raw %d bytes, normalized %d): ids of the one-pass device path differ" % (seed, hook, d, len(docs[d]), len(doc)))
+    raw, offs = tm.pack_documents(docs)
+    blob, boff, bmiss, enc, st = v.tokenize_pipeline(raw, offs, raw=True, chunk_bytes=int(rng.choice([4096, 20000, 1 << 20])), lanes=int(rng.integers(1, 4)))
+    ids = np.concatenate([g for g in got]) if got else np.zeros(0, np.uint32)
+    w = np.zeros((ids.size, 4), dtype=np.uint8)
+    w[:, :enc] = np.asarray(blob[: ids.size * enc]).reshape(ids.size, enc)
+    if int(boff[-1]) != ids.size * enc or not (w.view(np.uint32).ravel() == ids).all():
+        raise AssertionError("seed %d: ids of the host-to-host pipeline differ" % seed)
+    return int(raw.size)
+
+
 DEC_ALPHABET = list(b"CCWWDD    aabcxyzQZ019''.,-\n\t_")
 # round 4: the two-byte scripts (case pairs that keep or change the lead byte: а/А р/Р, Greek with the final sigma and the letters whose
 # upper-case form has another length: ΐ ŉ), Hebrew / Arabic with points and digits, CJK, kana, and what stays with the host (Hangul is

@@ -23,3 +23,9 @@ def test_device_normalizer_against_the_host_normalizer(first):
 def test_device_capcode_decode_against_the_host_decoder(first):
     for seed in range(first, first + 15):
         fuzz_cases.one_decode(seed)
+
+
+@pytest.mark.parametrize("first", [1, 501])
+def test_raw_text_to_ids_in_one_device_pass(first):
+    for seed in range(first, first + 6):
+        fuzz_cases.one_raw(seed)

@@ -111,6 +111,7 @@ static int lane_workspace(Lane* l, const tm_vocab* v, uint64_t bytes, uint32_t d
   if (l->ws && l->ws->vocab == v && l->ws->max_bytes >= bytes && l->ws->max_docs >= docs) return TM_OK;
   uint64_t want_b = std::max<uint64_t>(bytes + bytes / 4 + (1u << 20), l->ws ? l->ws->max_bytes : 0);
   uint64_t want_d = std::max<uint64_t>((uint64_t)docs + docs / 4 + 64, l->ws ? l->ws->max_docs : 0);
+  if (l->ws) trace_grow("lane workspace", want_b);
   tm_batch_free(l->ws);
   l->ws = nullptr;
   return tm_batch_create(v, want_b, (uint32_t)std::min<uint64_t>(want_d, 0xFFFFFFF0ull), &l->ws);
@@ -118,6 +119,7 @@ static int lane_workspace(Lane* l, const tm_vocab* v, uint64_t bytes, uint32_t d
 
 static int stage_grow(uint8_t** buf, uint64_t* cap, uint64_t bytes) {
   if (*cap >= bytes) return TM_OK;
+  if (*cap) trace_grow("lane staging (pinned)", bytes);
   (void)hipHostFree(*buf);
   *buf = nullptr;
   *cap = bytes + bytes / 4 + 4096;
@@ -129,6 +131,7 @@ static int lane_stage(Lane* l, uint64_t bytes) { return stage_grow(&l->h_stage, 
 
 static int lane_dbytes(Lane* l, uint64_t bytes) {
   if (l->d_bytes_cap >= bytes) return TM_OK;
+  if (l->d_bytes_cap) trace_grow("lane serialized ids", bytes);
   (void)hipFree(l->d_bytes);
   l->d_bytes = nullptr;
   l->d_bytes_cap = bytes + bytes / 4 + 4096;
@@ -139,6 +142,7 @@ static int lane_dbytes(Lane* l, uint64_t bytes) {
 
 static int dev_grow(uint8_t** buf, uint64_t* cap, uint64_t bytes, const char* what) {
   if (*cap >= bytes) return TM_OK;
+  if (*cap) trace_grow(what, bytes);
   (void)hipFree(*buf);
   *buf = nullptr;
   *cap = bytes + bytes / 4 + 4096;

@@ -1477,6 +1477,40 @@ void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* to
   TM_LAUNCH(k_scan_final, nblocks, SCAN_T, 0, st, in, n, block_sums, out);
 }
 
+// room for the group tree of the long documents: ngroups groups, nlong documents, and their pinned staging.  make_workspace reserves what a
+// batch of the workspace's size can need at most (a few MB): long documents are rare, and when each lane of the host-to-host pipeline met
+// its first one in a different call, each of those calls stopped the whole device for ~8 ms (hipFree / hipMalloc / hipHostMalloc).
+int reserve_groups(tm_batch* b, uint32_t ngroups, uint32_t nlong) {
+  hipError_t e;
+  if (ngroups > b->cap_groups) {
+    if (b->cap_groups) trace_grow("segment groups", (uint64_t)ngroups * (sizeof(Group) + ENT * sizeof(uint2) + 5));
+    (void)hipFree(b->d_groups); (void)hipFree(b->d_gmap); (void)hipFree(b->d_group_entry); (void)hipFree(b->d_group_base);
+    b->d_groups = nullptr; b->d_gmap = nullptr; b->d_group_entry = nullptr; b->d_group_base = nullptr;
+    b->cap_groups = ngroups + ngroups / 4 + 16;
+    if ((e = hipMalloc((void**)&b->d_groups, (size_t)b->cap_groups * sizeof(Group))) != hipSuccess ||
+        (e = hipMalloc((void**)&b->d_gmap, (size_t)b->cap_groups * ENT * sizeof(uint2))) != hipSuccess ||
+        (e = hipMalloc((void**)&b->d_group_entry, b->cap_groups)) != hipSuccess ||
+        (e = hipMalloc((void**)&b->d_group_base, (size_t)b->cap_groups * sizeof(uint32_t))) != hipSuccess)
+      return hip_fail(e, "hipMalloc (segment groups)");
+  }
+  if (nlong > b->cap_long) {
+    if (b->cap_long) trace_grow("long documents", (uint64_t)nlong * sizeof(LongDoc));
+    (void)hipFree(b->d_longs);
+    b->d_longs = nullptr;
+    b->cap_long = nlong + nlong / 4 + 16;
+    if ((e = hipMalloc((void**)&b->d_longs, (size_t)b->cap_long * sizeof(LongDoc))) != hipSuccess) return hip_fail(e, "hipMalloc (long documents)");
+  }
+  const size_t need = (((size_t)ngroups * sizeof(Group) + 255) & ~(size_t)255) + (size_t)nlong * sizeof(LongDoc);
+  if (b->h_groups_cap < need) {
+    if (b->h_groups_cap) trace_grow("segment groups (pinned staging)", need);
+    (void)hipHostFree(b->h_groups);
+    b->h_groups = nullptr;
+    b->h_groups_cap = need + need / 4 + 4096;
+    if ((e = hipHostMalloc((void**)&b->h_groups, b->h_groups_cap, hipHostMallocDefault)) != hipSuccess) { b->h_groups_cap = 0; return hip_fail(e, "hipHostMalloc (segment groups)"); }
+  }
+  return TM_OK;
+}
+
 // host: the group tree of the long documents.  doc d has lens[d] bytes; segments are numbered in document order.  groups[] holds
 // level 1 first (children = segments), then level 2 (children = level-1 groups), ...; b->level_first[k] is where level k+1 begins.
 int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs, hipStream_t st) {
@@ -1514,31 +1548,10 @@ int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32
   b->nlong = (uint32_t)longs.size();
   if (b->ngroups == 0) return TM_OK;
   hipError_t e;
-  if (b->ngroups > b->cap_groups) {
-    (void)hipFree(b->d_groups); (void)hipFree(b->d_gmap); (void)hipFree(b->d_group_entry); (void)hipFree(b->d_group_base);
-    b->d_groups = nullptr; b->d_gmap = nullptr; b->d_group_entry = nullptr; b->d_group_base = nullptr;
-    b->cap_groups = b->ngroups + b->ngroups / 4 + 16;
-    if ((e = hipMalloc((void**)&b->d_groups, (size_t)b->cap_groups * sizeof(Group))) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_gmap, (size_t)b->cap_groups * ENT * sizeof(uint2))) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_group_entry, b->cap_groups)) != hipSuccess ||
-        (e = hipMalloc((void**)&b->d_group_base, (size_t)b->cap_groups * sizeof(uint32_t))) != hipSuccess)
-      return hip_fail(e, "hipMalloc (segment groups)");
-  }
-  if (b->nlong > b->cap_long) {
-    (void)hipFree(b->d_longs);
-    b->d_longs = nullptr;
-    b->cap_long = b->nlong + 16;
-    if ((e = hipMalloc((void**)&b->d_longs, (size_t)b->cap_long * sizeof(LongDoc))) != hipSuccess) return hip_fail(e, "hipMalloc (long documents)");
-  }
+  { int rc = reserve_groups(b, b->ngroups, b->nlong); if (rc != TM_OK) return rc; }
   // (not hipMemcpy from the vectors: a pageable copy pins its pages per call and runs on the NULL stream — with other threads
   // loading vocabularies at the same time that cost 10 - 20 ms per scoring pass.  Through the batch's pinned staging instead.)
   const size_t gb = groups.size() * sizeof(Group), lb = longs.size() * sizeof(LongDoc), lat = (gb + 255) & ~(size_t)255;
-  if (b->h_groups_cap < lat + lb) {
-    (void)hipHostFree(b->h_groups);
-    b->h_groups = nullptr;
-    b->h_groups_cap = (lat + lb) + (lat + lb) / 4 + 4096;
-    if ((e = hipHostMalloc((void**)&b->h_groups, b->h_groups_cap, hipHostMallocDefault)) != hipSuccess) { b->h_groups_cap = 0; return hip_fail(e, "hipHostMalloc (segment groups)"); }
-  }
   std::memcpy(b->h_groups, groups.data(), gb);
   std::memcpy(b->h_groups + lat, longs.data(), lb);
   if ((e = hipMemcpyAsync(b->d_groups, b->h_groups, gb, hipMemcpyHostToDevice, st)) != hipSuccess ||
@@ -1724,10 +1737,11 @@ int ensure_output(tm_batch* b) {
   if (err != 0) return error_from_flag(err);
   uint64_t total = b->ndocs ? totals[1] : 0;
   if (total > b->out_cap) {
+    trace_grow("ids", total * 4);
     (void)hipFree(b->d_out);
     b->device_bytes -= b->out_cap * 4;
     b->d_out = nullptr;
-    b->out_cap = total + 1024;
+    b->out_cap = total + total / 4 + 1024;
     if ((e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc output");
     hipStream_t st = b->last_stream;
     launch_emit(b, st, true, true);
@@ -1775,6 +1789,13 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
       (e = dalloc(b, &b->d_out, b->out_cap)) != hipSuccess) {
     tm_batch_free(b);
     return hip_fail(e, "hipMalloc (batch workspace)");
+  }
+  {
+    // the group tree of long documents at its largest for this workspace: a level of segments / GROUP_FAN groups, the levels above it, and
+    // a partial group per level and long document
+    const uint64_t nlong_max = b->max_segs / LONG_SEGS + 1, ngroups_max = b->max_segs / GROUP_FAN + b->max_segs / (GROUP_FAN * GROUP_FAN) + 3 * nlong_max + 64;
+    int rc = reserve_groups(b, (uint32_t)std::min<uint64_t>(ngroups_max, 1u << 30), (uint32_t)std::min<uint64_t>(nlong_max, 1u << 30));
+    if (rc != TM_OK) { tm_batch_free(b); return rc; }
   }
   (void)hipMemset(b->d_totals, 0, 64);
   b->d_error = reinterpret_cast<uint32_t*>(b->d_totals + 4);        // (the error word lies behind the totals: ensure_output fetches both with one copy)

@@ -632,6 +632,7 @@ const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
 template <typename T>
 hipError_t grow(T** p, uint64_t* cap, uint64_t need, uint64_t slack = 0) {
   if (*p && *cap >= need) return hipSuccess;
+  if (*p) trace_grow("normalizer buffer", need * sizeof(T));
   (void)hipFree(*p);
   *p = nullptr;
   *cap = need + need / 4 + slack;
@@ -670,6 +671,7 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
   if (!b->d_raw_off || ndocs + 2 > docs_cap) {
     void** ps[] = {(void**)&b->d_raw_off, (void**)&b->d_doc_npiece, (void**)&b->d_doc_piece_start, (void**)&b->d_need_host, (void**)&b->d_nbegin, (void**)&b->d_nend,
                    (void**)&b->d_fb_ids, (void**)&b->d_fb_roff, (void**)&b->d_fb_noff};
+    if (b->d_raw_off) trace_grow("normalizer per-document arrays", (uint64_t)ndocs * 60);
     for (void** q : ps) { (void)hipFree(*q); *q = nullptr; }
     docs_cap = (uint64_t)ndocs + ndocs / 4 + 16;
     if ((e = hipMalloc((void**)&b->d_raw_off, docs_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_doc_npiece, docs_cap * 4)) != hipSuccess ||
@@ -690,6 +692,7 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
   }
   if (!b->d_piece_doc || npieces + 2 > b->piece_cap) {
     void** ps[] = {(void**)&b->d_piece_doc, (void**)&b->d_piece_sum, (void**)&b->d_piece_carry, (void**)&b->d_piece_len, (void**)&b->d_piece_off};
+    if (b->d_piece_doc) trace_grow("normalizer per-piece arrays", npieces * 21);
     for (void** q : ps) { (void)hipFree(*q); *q = nullptr; }
     b->piece_cap = npieces + npieces / 4 + 16;
     if ((e = hipMalloc((void**)&b->d_piece_doc, b->piece_cap * 4)) != hipSuccess || (e = hipMalloc((void**)&b->d_piece_sum, b->piece_cap * 4)) != hipSuccess ||

@@ -191,6 +191,9 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st);
 void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32_t ndocs, uint32_t unit, uint32_t* doc_nunits, hipStream_t st);
 void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st);
+// (TM_TRACE: every buffer that is replaced by a larger one after a workspace exists - each is a hipFree, which waits for the whole device)
+inline void trace_grow(const char* what, uint64_t bytes) { static const bool on = getenv("TM_TRACE") != nullptr; if (on) fprintf(stderr, "[grow] %s -> %.2f MB\n", what, bytes / 1048576.0); }
+int reserve_groups(tm_batch* b, uint32_t ngroups, uint32_t nlong);
 uint32_t long_segs();    // documents with more segments than this hang under the group tree (LONG_SEGS; 8 under test hook bit 12)
 int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs, hipStream_t st);
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit);

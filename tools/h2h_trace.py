@@ -28,10 +28,11 @@ def union(iv):
     return tot
 
 
-def analyze(d):
+def analyze(d, head_ms=0.0):
     kf = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     mf = glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True)
     ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]) for f in kf for r in csv.DictReader(open(f))]
+    kq = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): r.get("Queue_Id", r.get("Stream_Id", "?")) for f in kf for r in csv.DictReader(open(f))}
     ms = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Direction"], int(r.get("Bytes", 0) or 0)) for f in mf for r in csv.DictReader(open(f))]
     if not ks:
         print("no kernel trace under", d)
@@ -73,18 +74,27 @@ def analyze(d):
         cur = max(cur, b)
     gaps.sort(reverse=True)
     print("  idle gaps between kernels: total %.2f ms, largest %s ms" % (sum(gaps) / 1e6, [round(g / 1e6, 2) for g in gaps[:8]]))
+    if head_ms > 0:
+        # what the device did in the first head_ms of the pass: every kernel (queue, name) and copy, in order of their start
+        ev = [(a, b, "q%s %s" % (kq.get((a, b), "?"), n[-34:])) for a, b, n in kl] + [(m[0], m[1], "%s %.2f MB" % (m[2], m[3] / 1e6)) for m in ml]
+        for a, b, what in sorted(ev):
+            if a - lo > head_ms * 1e6:
+                break
+            if b - a >= 15_000 or "MB" in what:           # (kernels of 15 us and more; all copies)
+                print("    %8.3f ms  +%7.3f  %s" % ((a - lo) / 1e6, (b - a) / 1e6, what))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--analyze")
+    ap.add_argument("--head", type=float, default=0.0, help="with --analyze: list what ran in the first HEAD ms of the last pass")
     ap.add_argument("--lanes", type=int, default=3)
     ap.add_argument("--chunk-mib", type=int, default=64)
     ap.add_argument("--mbytes", type=int, default=1024)
     ap.add_argument("--passes", type=int, default=3)
     a = ap.parse_args()
     if a.analyze:
-        return analyze(a.analyze)
+        return analyze(a.analyze, a.head)
     import numpy as np
     import tokenmonster_amd as tm
     from tokenmonster_amd import synth

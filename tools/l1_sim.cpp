@@ -186,7 +186,8 @@ int main(int argc, char** argv) {
   for (size_t lines : {256, 128}) {
     for (const Layout& L : layouts) {
       Lru l1(lines);
-      uint64_t per_tab_miss[4] = {0, 0, 0, 0}, per_tab[4] = {0, 0, 0, 0};
+      uint64_t per_tab_miss[4] = {0, 0, 0, 0}, per_tab[4] = {0, 0, 0, 0}, lookups = 0;
+      std::vector<uint64_t> uniq;
       // a CU: 32 slots; slot s works through segments s, s + 32 * (number of CUs) ... here simply consecutive blocks of 32 segments at a time, each slot
       // starting its next segment when it finishes the current one
       size_t next = 0;
@@ -199,6 +200,7 @@ int main(int argc, char** argv) {
           if (!s.live) continue;
           const WaveTrace& w = segs[s.seg];
           if (s.round >= w.rounds.size()) { if (next < segs.size()) s = Slot{next++, 0, true}; else { s.live = false; live--; } continue; }
+          uniq.clear();
           for (const G& g : w.rounds[s.round]) {
             uint64_t idx = g.idx;
             if (g.tab == 0 && L.da) idx = da_new[g.idx];
@@ -207,14 +209,18 @@ int main(int argc, char** argv) {
             if (g.tab == 3 && L.row) idx = rank_row[g.idx];
             const uint64_t before = l1.misses;
             l1.touch((base_tab[g.tab] + idx) >> 3);
+            uniq.push_back((base_tab[g.tab] + idx) >> 3);
             per_tab[g.tab]++; per_tab_miss[g.tab] += l1.misses - before;
           }
+          // the L1 looks a line up once per gather INSTRUCTION however many lanes want it
+          std::sort(uniq.begin(), uniq.end());
+          lookups += std::unique(uniq.begin(), uniq.end()) - uniq.begin();
           s.round++;
         }
       }
       const double nseg = (double)segs.size();
-      printf("L1 %3zu lines  %-56s misses per segment %7.1f  (double array %6.1f of %6.1f, direct %5.1f of %5.1f, links %6.1f of %6.1f, rows %6.1f of %6.1f)\n", lines, L.name,
-             l1.misses / nseg, per_tab_miss[0] / nseg, per_tab[0] / nseg, per_tab_miss[1] / nseg, per_tab[1] / nseg, per_tab_miss[2] / nseg, per_tab[2] / nseg,
+      printf("L1 %3zu lines  %-56s line look-ups per segment %7.1f  misses %7.1f  (double array %6.1f of %6.1f, direct %5.1f of %5.1f, links %6.1f of %6.1f, rows %6.1f of %6.1f)\n", lines, L.name,
+             lookups / nseg, l1.misses / nseg, per_tab_miss[0] / nseg, per_tab[0] / nseg, per_tab_miss[1] / nseg, per_tab[1] / nseg, per_tab_miss[2] / nseg, per_tab[2] / nseg,
              per_tab_miss[3] / nseg, per_tab[3] / nseg);
     }
   }
