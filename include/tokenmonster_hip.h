@@ -161,7 +161,9 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
  * pass itself implements NFD and lowercase (what the reference's pretrained vocabularies use), a vocabulary with any of the
  * lossy flags accents / quotemarks / collapse / trim / leadingspace / unixlines sends ALL its documents through the (multi-threaded)
  * host normalizer inside this call.  tm_batch_normalize synchronizes `stream`; afterwards tm_batch_run tokenizes the normalized
- * documents. */
+ * documents.  (Where the normalized text lies between the two calls is the library's business: when every document was normalized on the
+ * device it stays in the normalizer's per-piece slabs and the match kernel reads it from there - no packing pass; tm_batch_download_text
+ * packs it on request and returns it in document order either way.) */
 int tm_batch_upload_raw(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs);
 int tm_batch_normalize(tm_batch* b, void* stream);
 uint64_t tm_batch_normalized_bytes(const tm_batch* b);
