@@ -1567,6 +1567,7 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   const tm_vocab* v = b->vocab;
   { int rc = enter_device(v); if (rc != TM_OK) return rc; }
   b->last_stream = st;
+  (void)hipGetLastError();               // (the check at the end is for the launches in between, not for what some earlier call of this thread has left behind)
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   const uint32_t nd = b->ndocs;
   const uint64_t nseg = b->nseg;
@@ -1599,6 +1600,7 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
 
 // mode: 0 = resolve only (the scoring pass walks the chains itself), 1 = + K4 counting only (Count), 2 = + K4 writing the ids
 int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode) {
+  (void)hipGetLastError();               // (as in pipeline_match)
   const uint32_t nd = b->ndocs;
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   if (nd > 0)

@@ -526,6 +526,7 @@ void* block_get(int device, bool host, size_t bytes, size_t* got, hipError_t* er
   if (found) {
     // outside the lock: a kernel of the freed vocabulary may still be running, and the other loaders / frees of the device must not wait for it
     for (hipEvent_t ev : pk.pending) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+    if (!pk.pending.empty()) (void)hipGetLastError();
     return pk.p;
   }
   void* p = nullptr;
@@ -706,13 +707,20 @@ int tm_vocab_block_import(const tm_vocab_block* m, int device, tm_vocab** out, v
 void tm_vocab_free(tm_vocab* v) {
   if (!v) return;
   { int cur = -1; (void)hipGetDevice(&cur); if (cur != v->device) (void)hipSetDevice(v->device); }
-  // the events behind the last table-reading kernel of every stream travel with the parked block
+  // The last table-reading kernel of every stream is waited for HERE, while the streams it may have run on - the lanes of this vocabulary's
+  // pool, destroyed two lines below - still exist: a free waits for the vocabulary's own work (not for the device, as hipFree would) and the
+  // block is parked with nothing pending.  (Until round 4 the events travelled with the parked block and the next load waited for them: by
+  // then their streams were gone, and this runtime answers hipEventSynchronize on such an event with whatever the freed stream object holds
+  // - "operation not permitted when stream is capturing" among others -, which the next launch check then took for its own error.)
   std::vector<hipEvent_t> pending;
   {
     std::lock_guard<std::mutex> g(v->use_mu);
     for (auto& u : v->last_use) pending.push_back(u.second);
     v->last_use.clear();
   }
+  for (hipEvent_t ev : pending) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+  pending.clear();
+  (void)hipGetLastError();             // (an event of a caller's stream that the caller has destroyed already: nothing to wait for)
   tmh::pool_destroy(v->pool);
   if (v->d_block) block_put(v->device, false, v->d_block, v->block_bytes, std::move(pending));
   else for (hipEvent_t ev : pending) (void)hipEventDestroy(ev);
