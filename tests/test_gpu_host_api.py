@@ -308,3 +308,24 @@ def test_vocab_build_equals_build_image_then_load(capcode, with_unk):
         ds.close(); vs.close()
     finally:
         g.close()
+
+
+def test_vocabularies_come_and_go_between_calls():
+    """a vocabulary per call, loaded into the parked block of the one before (the trainvocab worker's life, training/trainvocab.go:1827-1829): the
+    next load must not trip over the last kernels of the vocabulary that was freed - its events used to outlive the streams they were recorded on,
+    and the runtime's answer to a wait on such an event surfaced as a 'kernel launch' error several calls later"""
+    from conftest import fuzz_text, fuzz_vocab_tokens
+    from oracle_bind import Oracle
+    rng = np.random.default_rng(4242)
+    for i in range(60):
+        toks = fuzz_vocab_tokens(rng, 2, 80 + i)
+        img = synth.build_vocab(toks, capcode=2, charset=1)
+        v = tm.Vocab(img)
+        docs = [fuzz_text(rng, 2, int(n)) for n in rng.integers(1, 3000, size=12)]
+        ids, _ = v.tokenize_normalized(docs)
+        if i % 10 == 0:
+            orc = Oracle(img)
+            for d, doc in enumerate(docs):
+                exp, _ = orc.tokenize(doc)
+                assert ids[d].size == exp.size and (ids[d] == exp).all()
+        del v
