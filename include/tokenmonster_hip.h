@@ -59,8 +59,9 @@ int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out);
 /* The same on a named device: tm_set_device's "current device" belongs to the calling OS thread, which a goroutine under cgo does not own. */
 int tm_vocab_load_on(const uint8_t* vocab_file, size_t n, int device, tm_vocab** out);
 /* Batches, decoders and lanes of the vocabulary must not be used afterwards.  Kernels that an asynchronous entry point (tm_batch_run on a
- * caller's stream, tm_score_device, tm_score_finish ...) has already launched may still be in flight: the device memory is parked for the
- * next tm_vocab_load and is not refilled before they have finished (an event per stream the tables were used on). */
+ * caller's stream, tm_score_device, tm_score_finish ...) has already launched may still be in flight: tm_vocab_free waits for them (an
+ * event per stream the tables were used on - this vocabulary's work only, not the device as hipFree would) and then parks the device
+ * memory for the next tm_vocab_load.  A caller's stream on which this vocabulary's kernels were launched must still exist at this point. */
 void tm_vocab_free(tm_vocab* v);
 /* The device block of a vocabulary from process to process (the data-parallel scoring mode: ONE rank builds a candidate's tables, the others
  * take the finished block - e.g. as the destination of an RCCL broadcast - instead of repeating tm_build_vocab + tm_vocab_load).
