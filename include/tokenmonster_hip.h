@@ -70,7 +70,7 @@ void tm_vocab_free(tm_vocab* v);
  * before the first use.  An imported vocabulary tokenizes, counts, scores and decodes on the device; it has no host tables (tm_vocab_image /
  * tm_vocab_save and the streaming decoder fail). */
 typedef struct tm_vocab_block {
-  uint64_t bytes;            /* size of the device block */
+  uint64_t bytes;            /* bytes the tables occupy from the block's start (what has to be sent) */
   uint64_t part_bytes[8];    /* root, walk tables, rows, space-prefix links, node values, reverse offsets, reverse bytes, begin_byte */
   uint32_t idle_off, n_da, n_info, max_len, off, bstart, spl_hint, link_off, direct_off, delete_id, unk_id;
   uint32_t n_ids, vocab_size, capcode, charset, norm_flag, level, reserve, n_nodes, pad;   /* pad: TM_VOCAB_BLOCK_FORMAT of the exporting build */

@@ -527,6 +527,15 @@ __global__ void k_norm_bad(const uint32_t* __restrict__ piece_doc, const uint8_t
   if (k < ndocs && need_host[k]) fb_ids[atomicAdd(&ninfo[0], 1ull)] = (uint32_t)k;
 }
 
+// the exact path's share of k_norm_bad: ninfo[6] counts the pieces that are too short for the text to stay in the slabs
+__global__ void k_norm_short(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, const uint64_t* __restrict__ doc_piece_start, uint64_t npieces,
+                             const uint32_t* __restrict__ piece_len, unsigned long long* __restrict__ ninfo) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= npieces) return;
+  const uint32_t d = piece_doc[k];
+  if (!need_host[d] && piece_len[k] < (uint32_t)TEXT_LEN && k + 1 != doc_piece_start[d + 1]) atomicAdd(&ninfo[6], 1ull);
+}
+
 // pack the slabs: piece k's bytes go to out[piece_off[k] ..); a piece that would end behind `cap` bytes is left out (the caller - which
 // has not seen the total yet when it launches this - then reports TM_E_LIMIT)
 __global__ __launch_bounds__(256) void k_norm_compact(const uint8_t* __restrict__ slab, const uint32_t* __restrict__ piece_len,
@@ -828,6 +837,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                           b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
   if (!pre) scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
+  if (!pre && np > 0 && nf == 0) TM_LAUNCH(k_norm_short, (uint32_t)((np + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, b->d_piece_len, ninfo);
   if (nf > 0) {
     // ... while the documents it cannot normalize (other non-ASCII content: NFD / Unicode case need ICU) are fetched on a
     // second stream, so that the fetch does not hold up the pass above
@@ -876,7 +886,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     hnorm = b->h_fb_norm;
     f3 = now();
   }
-  { int rc = small_d2h(b, h_info, ninfo, 32, st); if (rc == TM_OK && !pre) rc = small_d2h(b, &gpu_bytes, b->d_totals + 2, 8, st); if (rc == TM_OK) rc = small_sync(b, st);
+  { int rc = small_d2h(b, h_info, ninfo, 56, st); if (rc == TM_OK && !pre) rc = small_d2h(b, &gpu_bytes, b->d_totals + 2, 8, st); if (rc == TM_OK) rc = small_sync(b, st);
     if (rc != TM_OK) return rc; }
   if (pre) gpu_bytes = pre_bytes;
   if (gpu_bytes + noff.back() > b->max_bytes) {
@@ -891,7 +901,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   }
   if (np > 0 && !pre) {
     if (h_info[3] == 0) {
-      TM_LAUNCH(k_norm_compact, pgrid, 256, 0, st, b->d_slab, b->d_piece_len, b->d_piece_off, np, b->d_text, b->max_bytes);
+      // every document normalized on the device and no short piece inside a document: the text stays in the slabs here too (k_match_branch
+      // stages it from there); otherwise it is packed - the host-normalized documents are placed behind the packed device part
+      b->text_in_slabs = true;
+      if (nf > 0 || h_info[6] != 0 || (tm_debug_flags(-1) & 2048)) pack_text(b, st);
     } else {
       // some piece expands beyond its slab (long runs of capitals): exact two-pass path
       TM_LAUNCH(k_norm_emit<1>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,

@@ -653,8 +653,8 @@ int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* m, void** device_pt
   if (!v || !m) return set_error(TM_E_INVALID, "null argument");
   const HostVocab& hv = v->host;
   std::memset(m, 0, sizeof(*m));
-  m->bytes = v->block_bytes;
-  for (int k = 0; k < 8; k++) m->part_bytes[k] = v->part_bytes[k];
+  m->bytes = 256;                  // what the tables occupy (the parked block they lie in may be larger: that is nobody else's business, and not worth sending)
+  for (int k = 0; k < 8; k++) { m->part_bytes[k] = v->part_bytes[k]; m->bytes += (v->part_bytes[k] + 255) & ~(uint64_t)255; }
   m->idle_off = hv.idle_off; m->n_da = hv.n_da; m->n_info = hv.n_info; m->max_len = hv.max_len; m->off = hv.off; m->bstart = hv.bstart;
   m->spl_hint = hv.spl_hint; m->link_off = hv.link_off; m->direct_off = hv.direct_off; m->delete_id = hv.delete_id; m->unk_id = hv.unk;
   m->n_ids = hv.n_ids; m->vocab_size = hv.vocab_size; m->capcode = hv.capcode; m->charset = hv.charset; m->norm_flag = hv.norm_flag; m->level = hv.level;
