@@ -503,7 +503,7 @@ struct BlockCache {
   hipStream_t stream = nullptr;
 };
 constexpr size_t kDevCacheMax = 4ull << 30, kHostCacheMax = 512ull << 20;
-BlockCache& cache_of(int device) {
+extern "C++" BlockCache& cache_of(int device) {
   static BlockCache caches[64];
   return caches[device & 63];
 }

@@ -79,10 +79,34 @@ int main() {
       tm_vocab_free(w);
     }
   });
+  // the multi-device driver beside all of that (tm_multi.hip: a host thread per member, its meeting points, the sum of the members' histograms):
+  // three members on the one emulated device, the chunked pipeline over all their lanes and two whole-buffer scoring passes, from two callers
+  std::vector<uint32_t> sc_ref(tm_vocab_n_ids(v)); uint64_t tit_ref = 0; uint8_t ms_ref[32];
+  {
+    tm_dataset* d1 = nullptr;
+    CHECK(tm_dataset_upload(text, off[nd], &d1));
+    const uint64_t so0 = 0, sl0 = off[nd];
+    CHECK(tm_score(v, d1, &so0, &sl0, 1, sc_ref.data(), &tit_ref, ms_ref));
+    tm_dataset_free(d1);
+  }
+  for (int t = 0; t < 2; t++) th.emplace_back([&] {
+    const int devs[3] = {0, 0, 0};
+    tm_devices* g = nullptr; tm_vocab_set* vs = nullptr; tm_dataset_set* ds = nullptr;
+    if (tm_devices_open_list(devs, 3, &g) != TM_OK || tm_vocab_load_all(g, img, img_n, &vs) != TM_OK) { bad++; return; }
+    std::vector<uint8_t> s3(ser.size()); std::vector<uint64_t> so(nd + 1); std::vector<uint32_t> ms(nd + 1); uint32_t e3 = 0;
+    if (tm_tokenize_pipeline_multi(vs, raw.data(), roff.data(), nd, 1, 2, 48 << 10, 2, s3.data(), s3.size(), so.data(), ms.data(), &e3, nullptr) != TM_OK ||
+        so[nd] != soff[nd] || std::memcmp(s3.data(), ser.data(), so[nd]) != 0) bad++;
+    if (tm_dataset_upload_sharded(g, text, off[nd], &ds) != TM_OK) { bad++; return; }
+    for (int round = 0; round < 2; round++) {
+      std::vector<uint32_t> sc(sc_ref.size()); uint64_t tit = 0; uint8_t m3[32];
+      if (tm_score_multi(vs, ds, sc.data(), &tit, m3) != TM_OK || tit != tit_ref || sc != sc_ref || std::memcmp(m3, ms_ref, 32) != 0) bad++;
+    }
+    tm_dataset_set_free(ds); tm_vocab_set_free(vs); tm_devices_close(g);
+  });
   for (auto& t : th) t.join();
   tm_vocab_free(v);
   tm_free(text); tm_free(img);
   if (bad.load()) { std::fprintf(stderr, "%d caller(s) got a wrong result\n", bad.load()); return 1; }
-  std::printf("tsan_host ok: %u documents, %llu ids, 11 concurrent callers\n", nd, (unsigned long long)toff[nd]);
+  std::printf("tsan_host ok: %u documents, %llu ids, 13 concurrent callers (two of them through the multi-device driver)\n", nd, (unsigned long long)toff[nd]);
   return 0;
 }
