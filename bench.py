@@ -699,7 +699,7 @@ def main():
     # ---- verification of a sample against the oracle (rank 0; outside the timed region) -------------------
     verified = None
     dev_ids = None            # (ids, tok_offsets, missing) of the timed pass, on the host: what every check below compares with
-    if rank == 0 and args.verify != 0:
+    if args.verify != 0 and (rank == 0 or world > 1):         # (with several ranks every rank checks a sample of its own shard)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_bind import Oracle
         orc = Oracle(img)
@@ -718,6 +718,10 @@ def main():
             if got.size != exp.size or (got != exp).any() or m != int(miss[d]):
                 raise SystemExit("bench.py: HIP ids differ from the oracle in document %d - number is INVALID" % d)
             verified += 1
+    if world > 1 and args.verify != 0:
+        tv = torch.tensor([float(verified or 0)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+        verified = int(tv.item())                        # documents checked against the oracle over all ranks
 
     if args.also_flags and rank == 0:
         cap = int(ntok.value)
