@@ -139,7 +139,13 @@ int main(int argc, char** argv) {
     for (uint32_t i = 0; i < c.size(); i++) rank[order[i]] = i;
     return rank;
   };
-  const std::vector<uint32_t> rank_link = rank_of(cnt[2]), rank_row = rank_of(cnt[3]), rank_direct = rank_of(cnt[1]), rank_da_free = rank_of(cnt[0]);
+  const std::vector<uint32_t> rank_link = rank_of(cnt[2]), rank_direct = rank_of(cnt[1]), rank_da_free = rank_of(cnt[0]);
+  std::vector<uint32_t> rank_row = rank_of(cnt[3]);
+  if (getenv("ROWS_BY_SCORE")) {          // a STATIC predictor of use: the score column of the .vocab file (what the trainer measured), nothing from a sample
+    std::vector<uint64_t> sc(hv.n_info);
+    for (uint32_t i = 0; i < hv.n_info; i++) sc[i] = (uint64_t)(std::max(0.0f, hv.rec_score[i]) * 1e15);
+    rank_row = rank_of(sc);
+  }
   // double array: families (children of one parent) re-placed by first fit in order of the family's use
   std::vector<uint32_t> da_new(hv.n_da + 1, 0);
   {
@@ -183,7 +189,10 @@ int main(int argc, char** argv) {
   const Layout layouts[] = {{"as laid out", false, false, false, false}, {"rows by use", false, false, false, true}, {"links by use", false, false, true, false},
                             {"rows + links by use", false, false, true, true}, {"+ double-array families by use", true, false, true, true},
                             {"+ direct map by use (needs an index step: bound only)", true, true, true, true}};
-  for (size_t lines : {256, 128}) {
+  // (argv[6] / argv[7]: another cache - e.g. 32768 lines and 1024 wavefronts: the 4 MB L2 of an XCD under its 32 CUs)
+  const size_t arg_lines = argc > 6 ? (size_t)atoll(argv[6]) : 0, arg_slots = argc > 7 ? (size_t)atoll(argv[7]) : 32;
+  for (size_t lines : {arg_lines ? arg_lines : (size_t)256, arg_lines ? (size_t)0 : (size_t)128}) {
+    if (!lines) continue;
     for (const Layout& L : layouts) {
       Lru l1(lines);
       uint64_t per_tab_miss[4] = {0, 0, 0, 0}, per_tab[4] = {0, 0, 0, 0}, lookups = 0;
@@ -192,7 +201,7 @@ int main(int argc, char** argv) {
       // starting its next segment when it finishes the current one
       size_t next = 0;
       struct Slot { size_t seg; size_t round; bool live; };
-      std::vector<Slot> slots(32, Slot{0, 0, false});
+      std::vector<Slot> slots(arg_slots, Slot{0, 0, false});
       size_t live = 0;
       for (auto& s : slots) if (next < segs.size()) { s = Slot{next++, 0, true}; live++; }
       while (live) {
