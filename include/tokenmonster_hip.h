@@ -63,6 +63,13 @@ int tm_vocab_load_on(const uint8_t* vocab_file, size_t n, int device, tm_vocab**
  * event per stream the tables were used on - this vocabulary's work only, not the device as hipFree would) and then parks the device
  * memory for the next tm_vocab_load.  A caller's stream on which this vocabulary's kernels were launched must still exist at this point. */
 void tm_vocab_free(tm_vocab* v);
+/* OPTIONAL, for large vocabularies (tables of 10 MB and more against the 4 MB of L2 an XCD has): lays the tables out by USE.  The match
+ * kernel's table walk is replayed on the host over `normalized_sample` (text as tm_normalize writes it; a few MiB of what the vocabulary
+ * will be used on), the trie's nodes are renumbered - most used first, so that the rows, space-prefix links and suffix links that are
+ * gathered most share cache lines - and the tables are written again into the device block they lie in.  Token ids and every result are
+ * unchanged (only internal node numbers move); nothing else of this vocabulary may run meanwhile, and the call waits for what already does.
+ * Not for vocabularies made by tm_vocab_block_import (no records).  Cost: about as long as loading the vocabulary + 0.2 s per MiB of sample. */
+int tm_vocab_tune(tm_vocab* v, const uint8_t* normalized_sample, uint64_t n);
 /* The device block of a vocabulary from process to process (the data-parallel scoring mode: ONE rank builds a candidate's tables, the others
  * take the finished block - e.g. as the destination of an RCCL broadcast - instead of repeating tm_build_vocab + tm_vocab_load).
  * tm_vocab_block_export describes the block of `v` (plain data: send it as bytes) and returns its device pointer; tm_vocab_block_import makes

@@ -329,3 +329,40 @@ def test_vocabularies_come_and_go_between_calls():
                 exp, _ = orc.tokenize(doc)
                 assert ids[d].size == exp.size and (ids[d] == exp).all()
         del v
+
+
+@pytest.mark.parametrize("capcode,charset", [(2, 1), (0, 1), (2, 2)])
+def test_tables_laid_out_by_use_give_the_same_results(capcode, charset):
+    """tm_vocab_tune renumbers the trie's nodes by how often a sample uses them and writes every table again: ids, counts, scoring histogram,
+    decode and the saved image are those of the untuned vocabulary - on the sample, on other text, after a second tuning on another sample"""
+    from conftest import fuzz_text, fuzz_vocab_tokens
+    from test_gpu_parity import _score
+    rng = np.random.default_rng(7100 + 10 * capcode + charset)
+    toks = fuzz_vocab_tokens(rng, capcode, 600)
+    if charset == 2:
+        toks = sorted({bytes(b for ch in t for b in (ch, 0))[:40] for t in toks if len(t) <= 20})
+    img = synth.build_vocab(toks, capcode=capcode, charset=charset, with_unk=(capcode == 0))
+    plain, tuned = tm.Vocab(img), tm.Vocab(img)
+
+    def text(n):
+        t = fuzz_text(rng, capcode, n)
+        return bytes(b for ch in t[: n // 2] for b in (ch, 0)) if charset == 2 else t
+    docs = [text(int(n)) for n in rng.integers(0, 4000, size=80)] + [b"", text(70_000)]
+    data = np.frombuffer(text(60_000), dtype=np.uint8)
+    exp_ids, exp_miss = plain.tokenize_normalized(docs)
+    exp_cnt = plain.tokenize_count(docs)
+    exp_score = _score(plain, data)
+    for sample in (b"".join(docs[:40]), text(200_000), b"", text(3)):
+        tuned.tune(sample)
+        got_ids, got_miss = tuned.tokenize_normalized(docs)
+        assert all(g.size == e.size and (g == e).all() for g, e in zip(got_ids, exp_ids)) and (got_miss == exp_miss).all()
+        got_cnt = tuned.tokenize_count(docs)
+        assert all((np.asarray(g) == np.asarray(e)).all() for g, e in zip(got_cnt, exp_cnt))
+        s = _score(tuned, data)
+        assert (s[0] == exp_score[0]).all() and s[1] == exp_score[1] and (s[2] == exp_score[2]).all()
+        assert tuned.image() == plain.image()
+    text0, offs0 = tm.pack_documents(docs)
+    ids0, toff0, _ = plain.tokenize_packed(text0, offs0)
+    a, ao = plain.decode_packed(ids0, toff0, raw=True)
+    b, bo = tuned.decode_packed(ids0, toff0, raw=True)
+    assert (a == b).all() and (ao == bo).all()

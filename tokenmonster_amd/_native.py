@@ -32,6 +32,7 @@ SIGNATURES = {
     "tm_vocab_block_import": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]),
     "tm_device_copy": (C.c_int, [vp, vp, C.c_uint64]),
     "tm_vocab_free": (None, [vp]),
+    "tm_vocab_tune": (C.c_int, [vp, vp, C.c_uint64]),
     "tm_vocab_size": (C.c_uint32, [vp]),
     "tm_vocab_n_info": (C.c_uint32, [vp]),
     "tm_vocab_n_ids": (C.c_uint32, [vp]),

@@ -101,7 +101,7 @@ struct Trie {
 struct TrieVisitor { virtual void key(uint32_t ordinal, const uint32_t* path_ord) = 0; virtual ~TrieVisitor() = default; };
 int build_trie(const HostVocab& hv, Trie& t, TrieVisitor* on_key);
 // rows, double array, links, direct map, space-prefix links, reverse table: everything the device block is made of (tm_tables.h)
-int build_tables(HostVocab& hv, const Trie& t);
+int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm = nullptr);     // perm: node ids by use (tm_vocab_tune), or none
 // tm_build.cpp: token list -> records + trie (the rules of go/tokenmonster.go:3423-3793 == training/trainvocab.go:548-907)
 int build_vocab_records(const std::vector<std::string>& tokens, const std::vector<uint8_t>& special, uint32_t capcode, uint32_t charset, uint32_t norm_flag,
                         uint32_t level, bool with_unk, HostVocab& hv, Trie& trie, const std::vector<float>* token_scores = nullptr);
@@ -126,6 +126,7 @@ struct tm_vocab {
   uint64_t device_bytes = 0;
   void* d_block = nullptr;           // the one device allocation the table pointers below point into (tm_vocab.hip: block cache)
   size_t block_bytes = 0;
+  bool tuned = false;                // the tables are laid out by use (tm_vocab_tune)
   uint64_t part_bytes[8] = {};       // root, tab, rows, spl, vals, rev_off, rev_bytes, begin_byte: laid out in this order, each on a 256-byte boundary
   uint32_t* d_root = nullptr;
   uint2* d_tab = nullptr;

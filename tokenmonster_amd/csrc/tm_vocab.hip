@@ -202,8 +202,13 @@ int build_trie(const HostVocab& hv, Trie& t, TrieVisitor* on_key) {
 }
 
 // ---- records + trie -> the tables of tm_tables.h -----------------------------------------------------------------------------------------
-int build_tables(HostVocab& hv, const Trie& t) {
+int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm) {
   StageTimer st;
+  // node ids as the tables carry them: the trie's own (accepting node == record ordinal, tm_device.h) unless a layout by use renumbers them
+  // (tm_vocab_tune: `perm` maps accepting nodes onto [0, n_info) and the others onto [n_info, n_nodes)).  Everything that is INDEXED by a
+  // node id (rows, space-prefix links, values, suffix links) or CARRIES one (node values, check words, link targets) goes through P();
+  // cmask / base_of / depth_of / has_child below stay indexed by the trie's ids.
+  auto P = [&](uint32_t n) -> uint32_t { return perm ? (*perm)[n] : n; };
   const uint32_t n_info = hv.n_info, n_nodes = t.n_nodes;
   const uint32_t kRoot = Trie::kRoot;
   const std::vector<uint8_t>& depth_of = t.depth_of;
@@ -219,7 +224,7 @@ int build_tables(HostVocab& hv, const Trie& t) {
     if (index1 != TM_NONE) { len1 = klen(index1); id1 = ids[index1]; nw1 = nwords[index1]; fl1 = flags[index1]; }
     if (index2 != TM_NONE) { len2 = klen(index2); id2 = ids[index2]; nw2 = nwords[index2]; fl2 = flags[index2]; }
     auto fconst = [](uint32_t fl, uint32_t nwk) { return ((fl >> 7) & 1u) + (nwk > 0 ? nwk - 1 : 0u) + nwk * 100u; };
-    Row& r = hv.rows[i];
+    Row& r = hv.rows[P(i)];
     r.x = id | (fconst(flag, nw) << kRowIdBits);
     r.y = id1 | ((len1 ? len1 + fconst(fl1, nw1) : 0u) << kRowIdBits);
     r.z = id2 | ((len2 ? len2 + fconst(fl2, nw2) : 0u) << kRowIdBits);
@@ -273,7 +278,7 @@ int build_tables(HostVocab& hv, const Trie& t) {
   }
   auto spl_cont = [&](uint32_t i) -> uint32_t { return (sp_full[i] && has_child[sp_node[i]] && depth_of[sp_node[i]] < hv.max_len) ? 1u : 0u; };
   auto value_of = [&](uint32_t id) {
-    uint32_t v = id | (has_child[id] ? kHasChildren : 0);
+    uint32_t v = P(id) | (has_child[id] ? kHasChildren : 0);
     if (id < n_info) {
       uint32_t f5 = flag8_to_flag5(flags[id]);
       if (hv.spl_hint && (f5 & 2u)) {
@@ -328,7 +333,7 @@ int build_tables(HostVocab& hv, const Trie& t) {
       if (depth_of[n] < 2) continue;
       for (uint32_t q = kid_start[n]; q < kid_start[n + 1]; q++) {
         const uint32_t c = kid[q] & 0xFFFFFFu;
-        da[base_of[n] + (kid[q] >> 24)] = uint4{n, value_of(c), cmask[c], base_of[c]};
+        da[base_of[n] + (kid[q] >> 24)] = uint4{P(n), value_of(c), cmask[c], base_of[c]};
       }
     }
   }
@@ -341,12 +346,12 @@ int build_tables(HostVocab& hv, const Trie& t) {
   hv.link_off = (uint32_t)(link_base * sizeof(uint2));
   hv.tab.assign(link_base + 2 * (size_t)n_nodes, uint2{kNone, kNone});
   memcpy(hv.tab.data(), da.data(), da.size() * sizeof(uint4));
-  std::vector<uint32_t> l2v(kL2Size, kNone);       // value of the depth-2 node b0b1
+  std::vector<uint32_t> l2v(kL2Size, kNone), l2n(kL2Size, kNone);       // value / trie id of the depth-2 node b0b1
   for (uint32_t b0 = 0; b0 < 256; b0++) {
     const uint32_t c1 = t.root_child[b0];
     if (c1 == kNone) continue;
     hv.root[b0] = value_of(c1);
-    for (uint32_t q = t.kid_start[c1]; q < t.kid_start[c1 + 1]; q++) l2v[(b0 << 8) | (t.kid[q] >> 24)] = value_of(t.kid[q] & 0xFFFFFFu);
+    for (uint32_t q = t.kid_start[c1]; q < t.kid_start[c1 + 1]; q++) { l2v[(b0 << 8) | (t.kid[q] >> 24)] = value_of(t.kid[q] & 0xFFFFFFu); l2n[(b0 << 8) | (t.kid[q] >> 24)] = t.kid[q] & 0xFFFFFFu; }
   }
   st.mark("table layout, depth 1 and 2");
   // suffix links (tm_tables.h): where the walk of text[p+1:] stands once the walk of text[p:] has ended on node n.
@@ -371,8 +376,9 @@ int build_tables(HostVocab& hv, const Trie& t) {
       const uint32_t m = lnode[n], dm = depth_at(m);
       const uint32_t hc = (m != kRoot && has_child[m]) ? 1u : 0u;
       const uint32_t b = m == kRoot ? kNone : best[m];
-      lt[2 * (size_t)n] = uint2{(m & kLinkNodeMask) | (dm << 20) | ((b != kNone ? (uint32_t)depth_of[b] : 0u) << 26), b != kNone ? value_of(b) : 0u};
-      lt[2 * (size_t)n + 1] = uint2{(lfull[n] && hc) ? cmask[m] : 0u, (lfull[n] && hc) ? base_of[m] : 0u};
+      const size_t at = P(n);
+      lt[2 * at] = uint2{((m == kRoot ? m : P(m)) & kLinkNodeMask) | (dm << 20) | ((b != kNone ? (uint32_t)depth_of[b] : 0u) << 26), b != kNone ? value_of(b) : 0u};
+      lt[2 * at + 1] = uint2{(lfull[n] && hc) ? cmask[m] : 0u, (lfull[n] && hc) ? base_of[m] : 0u};
     }
   }
   st.mark("suffix links");
@@ -391,12 +397,12 @@ int build_tables(HostVocab& hv, const Trie& t) {
   }
   // space-prefix links: x = node reached | continue << 21 | best accepting depth << 22, y = that node's value
   hv.vals.resize(n_info);
-  for (uint32_t i = 0; i < n_info; i++) hv.vals[i] = value_of(i);
+  for (uint32_t i = 0; i < n_info; i++) hv.vals[P(i)] = value_of(i);
   hv.spl.assign(n_info, uint4{kNone, 0u, 0u, 0u});
   if (spl_start != kNone)
     for (uint32_t i = 0; i < n_info; i++) {
       const uint32_t cont = spl_cont(i), bestn = sp_best[i];
-      hv.spl[i] = uint4{sp_node[i] | (cont << 21) | ((bestn != kNone ? (uint32_t)depth_of[bestn] : 0u) << 22), bestn != kNone ? value_of(bestn) : 0u,
+      hv.spl[P(i)] = uint4{P(sp_node[i]) | (cont << 21) | ((bestn != kNone ? (uint32_t)depth_of[bestn] : 0u) << 22), bestn != kNone ? value_of(bestn) : 0u,
                         cont ? cmask[sp_node[i]] : 0u, cont ? base_of[sp_node[i]] : 0u};
     }
   st.mark("reverse, values, space-prefix entries");
@@ -405,18 +411,18 @@ int build_tables(HostVocab& hv, const Trie& t) {
   for (uint32_t b0 = 0; b0 < 256; b0++) {
     const uint32_t r = hv.root[b0];
     for (uint32_t b1 = 0; b1 < 256; b1++) {
-      uint32_t bestlen = 0, bestv = 0, cont = 0, id2 = 0;
+      uint32_t bestlen = 0, bestv = 0, cont = 0, id2 = 0, n2 = 0;
       const uint32_t v2 = l2v[(b0 << 8) | b1];
       if (r != kNone) {
         if (node_id(r) < n_info) { bestlen = 1; bestv = r; }
         if (v2 != kNone) {                        // node b0b1 exists
           if (node_id(v2) < n_info) { bestlen = 2; bestv = v2; }
-          if (v2 & kHasChildren) { cont = 1; id2 = node_id(v2); }
+          if (v2 & kHasChildren) { cont = 1; id2 = node_id(v2); n2 = l2n[(b0 << 8) | b1]; }
         }
       }
       uint2* e = hv.tab.data() + direct_base + 2 * (size_t)(b0 | (b1 << 8));      // indexed by the little-endian u16 at the position
       e[0] = uint2{id2 | ((cont ? 2u : 0u) << 20) | (bestlen << 26), bestv};
-      e[1] = uint2{cont ? cmask[id2] : 0u, cont ? base_of[id2] : 0u};
+      e[1] = uint2{cont ? cmask[n2] : 0u, cont ? base_of[n2] : 0u};
     }
   }
   st.mark("direct map");
@@ -567,6 +573,7 @@ int tm_vocab_load_on(const uint8_t* vocab_file, size_t n, int device, tm_vocab**
 }
 
 static int upload_tables(tm_vocab* v);
+static int reupload_tables(tm_vocab* v);
 
 int tm_vocab_load(const uint8_t* vocab_file, size_t n, tm_vocab** out) {
   if (!vocab_file || !out) return set_error(TM_E_INVALID, "null argument");
@@ -604,18 +611,52 @@ int tm_vocab_build(const uint8_t* blob, const uint32_t* off, uint32_t n_tokens, 
   return TM_OK;
 }
 
+struct Part { void** dst; const void* src; size_t bytes, at; };
+static void table_parts(tm_vocab* v, Part (&parts)[8]) {
+  HostVocab& hv = v->host;
+  const Part p[8] = {{(void**)&v->d_root, hv.root.data(), 256 * 4, 0}, {(void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2), 0},
+                     {(void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row), 0}, {(void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint4), 0},
+                     {(void**)&v->d_vals, hv.vals.data(), hv.vals.size() * 4, 0}, {(void**)&v->d_rev_off, hv.rev_off.data(), hv.rev_off.size() * 4, 0},
+                     {(void**)&v->d_rev_bytes, hv.rev_bytes.data(), hv.rev_bytes.size(), 0}, {(void**)&v->d_begin_byte, hv.begin_byte, 256, 0}};
+  for (int k = 0; k < 8; k++) parts[k] = p[k];
+}
+
+// the tables of v->host once more into the block they already lie in (tm_vocab_tune: same sizes, other contents)
+static int reupload_tables(tm_vocab* v) {
+  Part parts[8];
+  table_parts(v, parts);
+  size_t total = 0;
+  for (int k = 0; k < 8; k++) {
+    if (parts[k].bytes != v->part_bytes[k]) return set_error(TM_E_INTERNAL, "table %d changed size", k);
+    parts[k].at = total; total += (parts[k].bytes + 255) & ~(size_t)255;
+  }
+  total += 256;
+  hipError_t e = hipSuccess;
+  size_t stage_bytes = 0;
+  void* stage = block_get(v->device, true, total, &stage_bytes, &e);
+  if (!stage) return hip_fail(e, "vocabulary staging");
+  for (Part& q : parts) if (q.bytes) std::memcpy((uint8_t*)stage + q.at, q.src, q.bytes);
+  BlockCache& c = cache_of(v->device);
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.stream) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(v->d_block, stage, total, hipMemcpyHostToDevice, c.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+  block_put(v->device, true, stage, stage_bytes);
+  if (e != hipSuccess) return hip_fail(e, "vocabulary upload");
+  set_tables(v);
+  return TM_OK;
+}
+
 // the tables of v->host into ONE device block on the current device; deletes v on failure
 static int upload_tables(tm_vocab* v) {
-  HostVocab& hv = v->host;
   hipError_t e;
   int dev = 0;
   if ((e = hipGetDevice(&dev)) != hipSuccess) { delete v; return hip_fail(e, "hipGetDevice"); }
   v->device = dev;
-  struct Part { void** dst; const void* src; size_t bytes, at; };
-  Part parts[] = {{(void**)&v->d_root, hv.root.data(), 256 * 4, 0}, {(void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2), 0},
-                  {(void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row), 0}, {(void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint4), 0},
-                  {(void**)&v->d_vals, hv.vals.data(), hv.vals.size() * 4, 0}, {(void**)&v->d_rev_off, hv.rev_off.data(), hv.rev_off.size() * 4, 0},
-                  {(void**)&v->d_rev_bytes, hv.rev_bytes.data(), hv.rev_bytes.size(), 0}, {(void**)&v->d_begin_byte, hv.begin_byte, 256, 0}};
+  Part parts[8];
+  table_parts(v, parts);
   size_t total = 0;
   for (int k = 0; k < 8; k++) { Part& q = parts[k]; q.at = total; total += (q.bytes + 255) & ~(size_t)255; v->device_bytes += q.bytes; v->part_bytes[k] = q.bytes; }
   total += 256;
@@ -649,6 +690,72 @@ static int upload_tables(tm_vocab* v) {
 // In the data-parallel scoring mode (every rank scores its byte range of the dataset against the SAME candidate) only one
 // rank has to turn a candidate's token list into tables (tm_build_vocab + tm_vocab_load: ~50 ms of one host thread); the others take the
 // finished block - a few MB, one broadcast over xGMI - and the ~200 bytes that say what lies where in it.
+// ---- tables laid out by use (tm_vocab_tune) ---------------------------------------------------------------------------------------
+// How often the match kernel would gather the entry of every node - its suffix link when a walk has ended on it, its row / space-prefix
+// link when it is the longest match at a position - on `text`: the kernel's step A1 replayed on the host over the tables as they are
+// (direct map on two bytes, suffix links, double-array probes behind the child filters).  use[] is indexed by the CURRENT node ids.
+static void count_node_use(const HostVocab& hv, const uint8_t* text, uint64_t n, std::vector<uint64_t>& use) {
+  use.assign(hv.n_nodes, 0);
+  const uint2* tab = hv.tab.data();
+  const uint4* da = reinterpret_cast<const uint4*>(tab);
+  const size_t direct16 = hv.direct_off / 16, link16 = hv.link_off / 16;
+  const int Lmax = (int)hv.max_len;
+  auto at = [&](uint64_t i) -> uint32_t { return i < n ? text[i] : 0u; };
+  int depth = 0;
+  uint32_t node = 0;
+  for (uint64_t pos = 0; pos + 1 < n; pos++) {
+    const int limit = (int)std::min<uint64_t>(n - pos, (uint64_t)Lmax);
+    const uint2* e;
+    if (pos > 0 && depth >= 3) { use[node]++; e = tab + 2 * (link16 + node); }
+    else e = tab + 2 * (direct16 + (at(pos) | (at(pos + 1) << 8)));
+    const uint32_t src = e[0].x;
+    uint32_t filt = e[1].x, bestv = e[0].y, base = e[1].y;
+    depth = (int)link_depth(src); node = link_node(src);
+    while (depth < limit) {
+      const uint32_t c = at(pos + depth);
+      if (!((filt >> (c & 31u)) & 1u)) break;
+      const uint4 d = da[base + c];
+      if (d.x != node) break;
+      depth++; node = node_id(d.y);
+      if (node < hv.n_info) bestv = d.y;
+      filt = d.z; base = d.w;
+      if (!(d.y & kHasChildren)) break;
+    }
+    if (bestv != 0 && node_id(bestv) < hv.n_info) use[node_id(bestv)]++;
+  }
+}
+
+extern "C" int tm_vocab_tune(tm_vocab* v, const uint8_t* normalized_sample, uint64_t n) {
+  if (!v || (n && !normalized_sample)) return set_error(TM_E_INVALID, "null argument");
+  HostVocab& hv = v->host;
+  if (hv.key_off.empty() || hv.rec_id.empty()) return set_error(TM_E_INVALID, "a vocabulary made from an imported block has no records to lay out again");
+  { int rc = enter_device(v); if (rc != TM_OK) return rc; }
+  // this vocabulary's kernels first (as tm_vocab_free does): the tables change under them otherwise
+  {
+    std::vector<hipEvent_t> pending;
+    { std::lock_guard<std::mutex> g(v->use_mu); for (auto& u : v->last_use) pending.push_back(u.second); v->last_use.clear(); }
+    for (hipEvent_t ev : pending) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+    (void)hipGetLastError();
+  }
+  Trie trie;
+  int rc = build_trie(hv, trie, nullptr);
+  if (rc == TM_OK && v->tuned) rc = build_tables(hv, trie);            // count over the trie's own numbering
+  if (rc != TM_OK) return rc;
+  std::vector<uint64_t> use;
+  count_node_use(hv, normalized_sample, n, use);
+  // accepting nodes among themselves (they index the rows and space-prefix links too), the others among themselves; ties keep their order
+  std::vector<uint32_t> order(hv.n_nodes), perm(hv.n_nodes);
+  for (uint32_t i = 0; i < hv.n_nodes; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.begin() + hv.n_info, [&](uint32_t a, uint32_t b) { return use[a] > use[b]; });
+  std::stable_sort(order.begin() + hv.n_info, order.end(), [&](uint32_t a, uint32_t b) { return use[a] > use[b]; });
+  for (uint32_t i = 0; i < hv.n_nodes; i++) perm[order[i]] = i;
+  const uint32_t n_da = hv.n_da;
+  if ((rc = build_tables(hv, trie, &perm)) != TM_OK) return rc;
+  if (hv.n_da != n_da) return set_error(TM_E_INTERNAL, "the double array changed size under a renumbering of the nodes");
+  v->tuned = true;
+  return reupload_tables(v);
+}
+
 int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* m, void** device_ptr) {
   if (!v || !m) return set_error(TM_E_INVALID, "null argument");
   const HostVocab& hv = v->host;

@@ -112,6 +112,11 @@ class Vocab:
     def n_ids(self):
         return N.lib.tm_vocab_n_ids(self._h)
 
+    def tune(self, normalized_sample):
+        """tm_vocab_tune: the tables laid out by use on a sample of NORMALIZED text (results unchanged; worth it for large vocabularies)"""
+        data = N.as_u8(normalized_sample)
+        N.check(N.lib.tm_vocab_tune(self._h, N.ptr(data), data.size))
+
     def unk_token_id(self):
         u = N.lib.tm_vocab_unk(self._h)
         return None if u == N.TM_NONE else u

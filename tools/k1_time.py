@@ -38,6 +38,14 @@ def one(lib, mbytes, config="englishcode-32000-consistent", e2e=False, score=Fal
     text, offs = synth.normalize_batch(raw, roffs, capcode, norm_flag)
     nd = offs.size - 1
     label = os.path.relpath(lib, ROOT) if lib else "product library"
+    tune_mib = float(os.environ.get("TM_K1_TUNE_MIB", "0") or 0)
+    if tune_mib > 0:
+        # tm_vocab_tune on OTHER text of the same kind (another seed), not on what is timed
+        sraw, sroffs = synth.synth_corpus(kind, int(tune_mib * (1 << 20)), seed=0x434F5250 + 77)
+        stext, _ = synth.normalize_batch(sraw, sroffs, capcode, norm_flag)
+        tt = time.time()
+        v.tune(stext)
+        label += " tuned on %.3g MiB (%.2f s)" % (tune_mib, time.time() - tt)
     if score:
         # the trainvocab scoring pass over ONE strip (tm_score: match kernel, resolve, histogram walk), wall clock around the call
         ds = C.c_void_p()
