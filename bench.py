@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mbytes", type=int, default=1024, help="MiB of raw text per GPU (default 1024 = BASELINE configs[1])")
     ap.add_argument("--config", default=None, help="vocabulary shape (default: englishcode-32000-consistent; score: candidates-65536)")
+    ap.add_argument("--tune-mib", type=float, default=0.0, help="tm_vocab_tune the vocabulary on this many MiB of OTHER synthetic text of the same kind before anything is "
+                                                                "timed (off by default: the lines of record are untuned); recorded in config.tables_tuned_on")
     ap.add_argument("--workload", default="tokenize", choices=["tokenize", "score"],
                     help="tokenize = BASELINE configs[1] (default); score = trainvocab candidate-scoring pass, configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -547,6 +549,12 @@ def main():
         dist.barrier()
     img = synth.config_vocab(args.config)
     vocab = tm.Vocab(img)
+    if args.tune_mib > 0:
+        sraw, sroffs = synth.synth_corpus(kind, int(args.tune_mib * (1 << 20)), seed=0x434F5250 + 77)        # (not the corpus that is timed: another seed)
+        stext, _ = synth.normalize_batch(sraw, sroffs, capcode, norm_flag)
+        tt = time.time()
+        vocab.tune(stext)
+        log("tm_vocab_tune on %.3g MiB of other text: %.2f s" % (args.tune_mib, time.time() - tt))
     log("vocab %s: %d ids, %d index records, max token %d, tables %.1f MB (%.1fs)" % (
         args.config, vocab.n_ids(), vocab.n_info(), vocab.max_token_length(), N.lib.tm_vocab_device_bytes(vocab.handle) / 1e6, time.time() - t0))
 
@@ -794,6 +802,7 @@ def main():
                        "missing": int(nmiss.value), "normalized_GBps": round(all_norm * args.steps / elapsed / 1e9, 4),
                        "h2d_seconds": round(h2d_s, 3), "parallelism": "documents sharded by rank, no collective",
                        "rccl_ranks": dist.get_world_size() if world > 1 else 0,
+                       "tables_tuned_on": ("%.3g MiB of other synthetic text (tm_vocab_tune)" % args.tune_mib) if args.tune_mib > 0 else None,
                        "verified_docs_vs_oracle": verified,
                        # every document of the timed pass against the REFERENCE runtime (oracle/_ref: RAW text through its Tokenize, ids and `missing`
                        # compared one by one): "all" when the host had the cores to do the whole corpus in the all-cores leg, else the count

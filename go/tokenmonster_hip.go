@@ -366,6 +366,17 @@ func (hv *HipVocab) Save(filename string) error {
 	return err
 }
 
+// Tune lays the vocabulary's device tables out by use on a sample of NORMALIZED text (tm_vocab_tune): worth it for large vocabularies
+// (100 000 ids: -5 % on the match kernel), changes no result, and must not run beside other calls on this vocabulary.
+func (hv *HipVocab) Tune(normalizedSample []byte) error {
+	var p *C.uint8_t
+	if len(normalizedSample) > 0 {
+		p = (*C.uint8_t)(unsafe.Pointer(&normalizedSample[0]))
+	}
+	_, err := locked(func() C.int { return C.tm_vocab_tune(hv.h, p, C.uint64_t(len(normalizedSample))) })
+	return err
+}
+
 // ---- trainvocab over several GPUs: one process (or one locked OS thread) per device, each owning a byte range of the dataset -------
 // ScoreRangeBegin / ScoreRangeFinish are the two halves of a pass over the range [0, ownLen) of a dataset that was uploaded followed by
 // >= 128 bytes of the text that comes next (continues == true): Begin returns what the range does to each of the 80 entry states; the
