@@ -309,6 +309,8 @@ int tm_vocab_load_all(tm_devices* g, const uint8_t* vocab_file, size_t n, tm_voc
 int tm_vocab_set_count(const tm_vocab_set* s);
 const tm_vocab* tm_vocab_set_member(const tm_vocab_set* s, int member);
 void tm_vocab_set_free(tm_vocab_set* s);
+/* tm_vocab_tune for every member: the tables are laid out again once (member 0) and the block goes to the others as at tm_vocab_load_all. */
+int tm_vocab_set_tune(tm_vocab_set* s, const uint8_t* normalized_sample, uint64_t n);
 /* tm_tokenize_pipeline over every device (the server's fan-out, tokenmonsterserver.go:363-378): the chunks of whole documents are handed to
  * lanes_per_device lanes (0 = 4) of EVERY member from one queue, so a faster or less loaded device takes more of them; ids land in document
  * order whichever device computed them.  No collective.  Arguments and results exactly as tm_tokenize_pipeline. */

@@ -85,3 +85,14 @@ def test_headers_are_plain_c_and_example_links(tmp_path):
     assert r.returncode == 0, r.stdout.decode(errors="replace")
     r = subprocess.run(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode(errors="replace")
+
+
+def test_library_leaves_none_of_its_own_symbols_undefined():
+    """a declaration with the wrong linkage (extern "C" against C++) links into a shared library without a word and fails at the first
+    program that links against it"""
+    import subprocess
+    from tokenmonster_amd import build as _b
+    lib = os.path.join(os.path.dirname(os.path.abspath(_b.__file__)), "libtokenmonster_hip.so")
+    out = subprocess.run(["nm", "-D", "--undefined-only", lib], stdout=subprocess.PIPE, check=True).stdout.decode()
+    own = [l.split()[-1] for l in out.splitlines() if l.split() and (l.split()[-1].startswith(("tm_", "tmh", "_ZN3tmh")) or "tmh" in l.split()[-1])]
+    assert own == [], own

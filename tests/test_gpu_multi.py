@@ -153,3 +153,27 @@ def test_rccl_allreduce_on_the_visible_devices():
         ds.close(); vs.close(); g.close()
     finally:
         del os.environ["TM_RCCL"]
+
+
+def test_vocab_set_tune_keeps_every_result():
+    """tm_vocab_set_tune: member 0 lays its tables out by use, the other members take over the block and the scalars that move with it
+    (node values): the sharded scoring pass and the multi-device pipeline give what they gave before"""
+    img, data = _micro(901, 150_000)
+    g = multi.Devices([0, 0, 0])
+    try:
+        vs = multi.VocabSet(g, img)
+        ds = multi.DatasetSet(g, data)
+        before = ds.score(vs)
+        raw = bytes(data[:60_000])
+        docs = [raw[i:i + 3000] for i in range(0, len(raw), 3000)]
+        text, offs = tm.pack_documents(docs)
+        b0 = vs.tokenize_pipeline(text, offs, raw=False, chunk_bytes=20_000)
+        for sample in (data[:50_000], data[50_000:], data[:0]):
+            vs.tune(sample)
+            after = ds.score(vs)
+            assert (after[0] == before[0]).all() and after[1] == before[1] and (after[2] == before[2]).all()
+            b1 = vs.tokenize_pipeline(text, offs, raw=False, chunk_bytes=20_000)
+            assert (b1[0] == b0[0]).all() and (b1[1] == b0[1]).all()
+        ds.close(); vs.close()
+    finally:
+        g.close()

@@ -301,6 +301,30 @@ int tm_vocab_build_all(tm_devices* g, const uint8_t* blob, const uint32_t* off, 
   return rc == TM_OK ? replicate(g, first, out) : rc;
 }
 
+// tm_vocab_tune for a set: member 0 (the one with the records) lays its tables out again, the others take over its block as they did at first
+extern "C++" void tmh_vocab_quiesce(tm_vocab* v);                                   // (tm_vocab.hip)
+extern "C++" int tmh_vocab_adopt(tm_vocab* v, const tm_vocab_block* m);
+int tm_vocab_set_tune(tm_vocab_set* s, const uint8_t* normalized_sample, uint64_t n) {
+  if (!s || s->v.empty() || !s->v[0]) return set_error(TM_E_INVALID, "null argument");
+  int rc = tm_vocab_tune(s->v[0], normalized_sample, n);
+  tm_vocab_block meta;
+  void* src = nullptr;
+  if (rc == TM_OK) rc = tm_vocab_block_export(s->v[0], &meta, &src);
+  const tm_devices* g = s->devs;
+  for (size_t i = 1; i < s->v.size() && rc == TM_OK; i++) {
+    tm_vocab* w = s->v[i];
+    if ((rc = tm_set_device(g->dev[i])) != TM_OK) break;
+    tmh_vocab_quiesce(w);
+    void* dst = nullptr;
+    tm_vocab_block mine;
+    if ((rc = tm_vocab_block_export(w, &mine, &dst)) != TM_OK) break;
+    const hipError_t e = g->dev[i] == g->dev[0] ? hipMemcpy(dst, src, meta.bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, g->dev[i], src, g->dev[0], meta.bytes);
+    if (e != hipSuccess) { rc = hip_fail(e, "replicating the vocabulary block"); break; }
+    rc = tmh_vocab_adopt(w, &meta);
+  }
+  return rc;
+}
+
 const tm_vocab* tm_vocab_set_member(const tm_vocab_set* s, int member) { return s && member >= 0 && member < (int)s->v.size() ? s->v[member] : nullptr; }
 int tm_vocab_set_count(const tm_vocab_set* s) { return s ? (int)s->v.size() : 0; }
 

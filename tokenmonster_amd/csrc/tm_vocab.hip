@@ -690,6 +690,7 @@ static int upload_tables(tm_vocab* v) {
 // In the data-parallel scoring mode (every rank scores its byte range of the dataset against the SAME candidate) only one
 // rank has to turn a candidate's token list into tables (tm_build_vocab + tm_vocab_load: ~50 ms of one host thread); the others take the
 // finished block - a few MB, one broadcast over xGMI - and the ~200 bytes that say what lies where in it.
+extern "C++" void tmh_vocab_quiesce(tm_vocab* v);
 // ---- tables laid out by use (tm_vocab_tune) ---------------------------------------------------------------------------------------
 // How often the match kernel would gather the entry of every node - its suffix link when a walk has ended on it, its row / space-prefix
 // link when it is the longest match at a position - on `text`: the kernel's step A1 replayed on the host over the tables as they are
@@ -731,12 +732,7 @@ extern "C" int tm_vocab_tune(tm_vocab* v, const uint8_t* normalized_sample, uint
   if (hv.key_off.empty() || hv.rec_id.empty()) return set_error(TM_E_INVALID, "a vocabulary made from an imported block has no records to lay out again");
   { int rc = enter_device(v); if (rc != TM_OK) return rc; }
   // this vocabulary's kernels first (as tm_vocab_free does): the tables change under them otherwise
-  {
-    std::vector<hipEvent_t> pending;
-    { std::lock_guard<std::mutex> g(v->use_mu); for (auto& u : v->last_use) pending.push_back(u.second); v->last_use.clear(); }
-    for (hipEvent_t ev : pending) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
-    (void)hipGetLastError();
-  }
+  tmh_vocab_quiesce(v);
   Trie trie;
   int rc = build_trie(hv, trie, nullptr);
   if (rc == TM_OK && v->tuned) rc = build_tables(hv, trie);            // count over the trie's own numbering
@@ -776,6 +772,28 @@ int tm_device_copy(void* dst_device, const void* src_device, uint64_t bytes) {
   return e == hipSuccess ? TM_OK : hip_fail(e, "device-to-device copy");
 }
 
+static void adopt_scalars(HostVocab& hv, const tm_vocab_block* m) {
+  hv.idle_off = m->idle_off; hv.n_da = m->n_da; hv.n_info = m->n_info; hv.max_len = m->max_len; hv.off = m->off; hv.bstart = m->bstart;
+  hv.spl_hint = m->spl_hint; hv.link_off = m->link_off; hv.direct_off = m->direct_off; hv.delete_id = m->delete_id; hv.unk = m->unk_id;
+  hv.n_ids = m->n_ids; hv.vocab_size = m->vocab_size; hv.capcode = (uint8_t)m->capcode; hv.charset = (uint8_t)m->charset; hv.norm_flag = (uint8_t)m->norm_flag;
+  hv.level = (uint8_t)m->level; hv.reserve = (uint8_t)m->reserve; hv.n_nodes = m->n_nodes;
+}
+
+// for a replica whose block is being overwritten with the exporter's retuned one (tm_vocab_set_tune): wait for the replica's own kernels,
+// and afterwards take over the scalars that ride in the description (node values such as bstart move with a renumbering)
+extern "C++" void tmh_vocab_quiesce(tm_vocab* v) {
+  std::vector<hipEvent_t> pending;
+  { std::lock_guard<std::mutex> g(v->use_mu); for (auto& u : v->last_use) pending.push_back(u.second); v->last_use.clear(); }
+  for (hipEvent_t ev : pending) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+  (void)hipGetLastError();
+}
+extern "C++" int tmh_vocab_adopt(tm_vocab* v, const tm_vocab_block* m) {
+  for (int k = 0; k < 8; k++) if (m->part_bytes[k] != v->part_bytes[k]) return set_error(TM_E_INVALID, "vocabulary block of another shape");
+  adopt_scalars(v->host, m);
+  set_tables(v);
+  return TM_OK;
+}
+
 int tm_vocab_block_import(const tm_vocab_block* m, int device, tm_vocab** out, void** device_ptr) {
   if (!m || !out || !device_ptr) return set_error(TM_E_INVALID, "null argument");
   *out = nullptr;
@@ -793,11 +811,7 @@ int tm_vocab_block_import(const tm_vocab_block* m, int device, tm_vocab** out, v
   { int rc = tm_set_device(device); if (rc != TM_OK) return rc; }
   auto* v = new tm_vocab();
   v->device = device;
-  HostVocab& hv = v->host;                 // (scalars only: an imported vocabulary has no host tables - no Save, no host-side decode)
-  hv.idle_off = m->idle_off; hv.n_da = m->n_da; hv.n_info = m->n_info; hv.max_len = m->max_len; hv.off = m->off; hv.bstart = m->bstart;
-  hv.spl_hint = m->spl_hint; hv.link_off = m->link_off; hv.direct_off = m->direct_off; hv.delete_id = m->delete_id; hv.unk = m->unk_id;
-  hv.n_ids = m->n_ids; hv.vocab_size = m->vocab_size; hv.capcode = (uint8_t)m->capcode; hv.charset = (uint8_t)m->charset; hv.norm_flag = (uint8_t)m->norm_flag;
-  hv.level = (uint8_t)m->level; hv.reserve = (uint8_t)m->reserve; hv.n_nodes = m->n_nodes;
+  adopt_scalars(v->host, m);               // (scalars only: an imported vocabulary has no host tables - no Save, no host-side decode)
   hipError_t e = hipSuccess;
   v->d_block = block_get(device, false, (size_t)m->bytes, &v->block_bytes, &e);
   if (!v->d_block) { delete v; return hip_fail(e, "vocabulary block"); }

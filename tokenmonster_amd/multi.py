@@ -73,6 +73,11 @@ class VocabSet:
     def n_ids(self):
         return N.lib.tm_vocab_n_ids(self.member(0))
 
+    def tune(self, normalized_sample):
+        """tm_vocab_set_tune: tables by use on every member"""
+        data = N.as_u8(normalized_sample)
+        N.check(N.lib.tm_vocab_set_tune(self._h, N.ptr(data), data.size))
+
     def tokenize_pipeline(self, text, offsets, raw=True, encoding_length=0, chunk_bytes=0, lanes_per_device=0, out=None):
         """tm_tokenize_pipeline_multi -> (serialized ids u8, byte_offsets u64[D+1], missing u32[D], encoding length, stats)"""
         text = N.as_u8(text)
