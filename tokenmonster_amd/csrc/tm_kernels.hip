@@ -688,7 +688,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       // a state that is its own successor (no byte consumed, same forward-delete flag: a UTF-16 vocabulary with one-byte keys beside the
       // delete token can make one) would double its token count in every round below until the count runs over into the address field:
       // a dead end here; K4, which walks the one chain that is real, reports the text (TM_E_INPUT)
-      if (pn == p && fdn == fd) return 0x80000000u | (JNONE << JF);
+      // (only a forward-delete state can stand still: a plain one consumes at least the byte it stands on)
+      if (fd == 1u && pn == p && fdn == 1u) return 0x80000000u | (JNONE << JF);
       const uint32_t nt = ((r & ID_NONE) != ID_NONE ? 1u : 0u) + fdn;          // ids this step emits: the token (unless it is "none") + the delete token
       const uint32_t x = pn >= seglen ? 0x80000000u | ((more_text ? (uint32_t)((pn - seglen) * 2) + fdn : 0u) << JF)
                                       : (jaddr + 4u * (fdn * (uint32_t)J_PLANE + (uint32_t)pn)) << JF;
