@@ -707,6 +707,14 @@ def main():
     # ---- verification of a sample against the oracle (rank 0; outside the timed region) -------------------
     verified = None
     dev_ids = None            # (ids, tok_offsets, missing) of the timed pass, on the host: what every check below compares with
+    if args.verify != 0 and world > 1:
+        # the checker's library is built once (it normally travels prebuilt), not by every rank at the same moment
+        if rank == 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_bind
+            if not os.path.exists(oracle_bind.ORACLE_SO):
+                oracle_bind.build_oracles()
+        dist.barrier()
     if args.verify != 0 and (rank == 0 or world > 1):         # (with several ranks every rank checks a sample of its own shard)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_bind import Oracle
