@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   if (lane == 0) {
     piece_len[k] = pos;
     if (pos > (uint32_t)SLAB2) atomicAdd(overflow, 1ull);
-    if (!CARRY && badm != 0ull) need_host[d] = 1;      // (every writer writes 1; the piece lengths of such a document are zeroed by k_norm_bad_pieces)
+    if (!CARRY && badm != 0ull) need_host[d] = 1;      // (every writer writes 1; the piece lengths of such a document are zeroed by k_norm_bad)
   }
 }
 
@@ -503,17 +503,7 @@ __global__ void k_norm_begin(const uint64_t* __restrict__ raw_off, uint32_t ndoc
 }
 
 // behind k_norm_emit2<false>: the pieces of the documents that turned out to need the host normalizer count for nothing, and those documents
-// are listed for the host (in no particular order)
-__global__ void k_norm_bad_pieces(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, uint64_t npieces, uint32_t* __restrict__ piece_len) {
-  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < npieces && need_host[piece_doc[k]]) piece_len[k] = 0;
-}
-__global__ void k_norm_bad_docs(const uint8_t* __restrict__ need_host, uint32_t ndocs, unsigned long long* __restrict__ ninfo, uint32_t* __restrict__ fb_ids) {
-  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d < ndocs && need_host[d]) fb_ids[atomicAdd(&ninfo[0], 1ull)] = d;
-}
-
-// the two kernels above in one launch (thread k looks at piece k and at document k): the one-sync path of tm_batch_normalize
+// are listed for the host (in no particular order) - thread k looks at piece k and at document k
 // ... and ninfo[6] counts the pieces that are not the last of their document yet shorter than what a segment looks at (TEXT_LEN): with one
 // of those the text cannot be staged from the slabs by k_match_branch (which looks at two pieces at most) and is packed after all
 __global__ void k_norm_bad(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, const uint64_t* __restrict__ doc_piece_start, uint64_t npieces,
@@ -843,7 +833,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     // second stream, so that the fetch does not hold up the pass above
     if (!b->aux_stream && (e = hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
     hipStream_t sx = b->aux_stream;
-    // the (unordered) list k_norm_carry / k_norm_bad_docs has left on the device, put into document order
+    // the (unordered) list k_norm_carry / k_norm_bad has left on the device, put into document order
     ids.resize(nf);
     { int rc = small_d2h(b, ids.data(), b->d_fb_ids, (uint64_t)nf * 4, sx); if (rc == TM_OK) rc = small_sync(b, sx); if (rc != TM_OK) return rc; }
     std::sort(ids.begin(), ids.end());
