@@ -40,6 +40,7 @@ import (
 type HipVocab struct {
 	h   *C.tm_vocab
 	len int // vocab.Len(): decides 2- or 4-byte ids on the server wire (tokenmonsterserver.go:350-353)
+	borrowed bool // the handle belongs to a HipVocabSet (Member): Close must not free it
 }
 
 // locked runs one library call and, if it failed, reads the library's THREAD-LOCAL error message on the same OS thread: between two
@@ -85,10 +86,10 @@ func LoadHip(filename string, device int) (*HipVocab, error) {
 }
 
 func (hv *HipVocab) Close() {
-	if hv.h != nil {
+	if hv.h != nil && !hv.borrowed {
 		C.tm_vocab_free(hv.h)
-		hv.h = nil
 	}
+	hv.h = nil
 }
 
 // pack lays documents out the way the kernels read them: one contiguous buffer + offsets.
@@ -463,6 +464,9 @@ func BuildHipVocabImage(tokens [][]byte, capcode, charset uint8) ([]byte, error)
 
 // NewHipVocabSet: the same from the bytes of a .vocab image (a candidate from BuildHipVocabImage in the trainvocab worker).
 func NewHipVocabSet(g *HipDevices, image []byte) (*HipVocabSet, error) {
+	if len(image) == 0 {
+		return nil, errors.New("tokenmonster_hip: empty vocabulary image")
+	}
 	var h *C.tm_vocab_set
 	if _, err := locked(func() C.int {
 		return C.tm_vocab_load_all(g.h, (*C.uint8_t)(unsafe.Pointer(&image[0])), C.size_t(len(image)), &h)
@@ -473,10 +477,14 @@ func NewHipVocabSet(g *HipDevices, image []byte) (*HipVocabSet, error) {
 }
 func (s *HipVocabSet) Close() { C.tm_vocab_set_free(s.h) }
 
-// Member(0) is a full vocabulary (Decode, NewDecoder, Save); the handle stays owned by the set.
+// Member(0) is a full vocabulary (Decode, NewDecoder, Save); the handle stays owned by the set: Close on the returned value does
+// nothing (tm_vocab_set_free frees the members), and it must not be used after the set has been closed.  nil: no such member.
 func (s *HipVocabSet) Member(i int) *HipVocab {
 	h := (*C.tm_vocab)(unsafe.Pointer(C.tm_vocab_set_member(s.h, C.int(i))))
-	return &HipVocab{h: h, len: int(C.tm_vocab_size(h))}
+	if h == nil {
+		return nil
+	}
+	return &HipVocab{h: h, len: int(C.tm_vocab_size(h)), borrowed: true}
 }
 
 // TokenizeSerializedBatch over every GPU: same arguments and results as (*HipVocab).TokenizeSerializedBatch - server job 1 does not change.

@@ -189,7 +189,8 @@ const char* tm_kernel_name(int k);
  * the product with the SAME results, so that the tests can cover it: 6 = dense T(p,1) array for every segment, 8 = per-lane
  * normalizer kernel instead of k_norm_emit2, 10 = K4 tile walk that stores every id directly (its overflow path), 11 = the device normalizer packs its text
  * (the path of a batch with host-normalized documents) instead of leaving it in its slabs for the match kernel, 12 = group tree of
- * long documents with fan-out 4 from 9 segments on, 13 = 64 KiB mailbox for the small host <-> device transfers.  Other bits are
+ * long documents with fan-out 4 from 9 segments on, 13 = 64 KiB mailbox for the small host <-> device transfers, 14 = the last member of tm_score_multi gives up
+ * after the members' first meeting (an error path: the call must return that member's error).  Other bits are
  * ignored (a -DTM_DEVEL build, tools/ only, adds profiling bits that switch phases of the match kernel off).  The switches are process-wide,
  * so they are armed only in a process started with TM_TEST_HOOKS in its environment (the test suite, bench.py --also-flags): anywhere
  * else the call changes nothing and returns 0 - one caller of a server cannot change the code path under the others. */
@@ -287,12 +288,13 @@ int tm_score_read(const tm_vocab* v, tm_dataset* d, uint32_t* scores, uint64_t* 
  * collective of the path - the sum of the scoring pass's histograms - is an ncclAllReduce(sum, uint32) over xGMI inside tm_score_multi.
  * RCCL is loaded at the first collective (librccl.so.1 is 570 MB: the single-GPU entry points never map it).
  *
- * tm_devices_open: the first max_devices visible devices (<= 0: all).  With TM_VIRTUAL_DEVICES=N in the environment the handle has N members that
- * all sit on device 0 instead - the multi-device code paths on a one-GPU box; tm_devices_open_list names the devices itself (a device may appear
+ * tm_devices_open: the first max_devices visible devices (<= 0: all).  In a test process (TM_TEST_HOOKS set, like tm_debug_flags) TM_VIRTUAL_DEVICES=N
+ * gives the handle N members that all sit on device 0 instead - the multi-device code paths on a one-GPU box; tm_devices_open_list names the devices itself (a device may appear
  * more than once).  Members that share a device cannot form an RCCL communicator (RCCL refuses two ranks on one device): there, with TM_RCCL=0, and
  * where librccl cannot be loaded, member 0 sums the histograms by peer copies and an add kernel - same result.  tm_devices_rccl_ranks: the
  * number of ranks of the communicator the handle uses (it is made on the first call of this or of tm_score_multi), 0 and *why_not = the
- * reason if there is none.  One-member handles skip the collective unless TM_RCCL=1. */
+ * reason if there is none.  One-member handles skip the collective unless TM_RCCL=1.  Every call of this section leaves the calling thread's
+ * current device as it found it. */
 typedef struct tm_devices tm_devices;
 typedef struct tm_vocab_set tm_vocab_set;       /* one replica of a vocabulary per member */
 typedef struct tm_dataset_set tm_dataset_set;   /* one byte range of a normalized dataset per member */

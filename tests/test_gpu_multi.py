@@ -118,6 +118,42 @@ def test_pipeline_multi_equals_one_device(members, raw):
         g.close()
 
 
+@pytest.mark.parametrize("members", [2, 3, 5])
+def test_a_member_that_fails_between_the_meetings_brings_everybody_home(members):
+    """round-4 advice: a failure raised right after the first meeting of the members' threads must not change what a slower member is
+    told AT that meeting (it would leave early, and the failing member would wait for it at the second meeting forever).  Test hook 14
+    makes the last member give up there; the call has to return its error - under a watchdog, because the bug is a hang."""
+    import threading
+    from tokenmonster_amd import _native as N
+    img, data = _micro(321 + members, 120_000)
+    g = multi.Devices([0] * members)
+    try:
+        vs, ds = multi.VocabSet(g, img), multi.DatasetSet(g, data)
+        good = ds.score(vs)
+        old = N.lib.tm_debug_flags(16384)
+        box = {}
+        try:
+            for _ in range(20):                                      # the interleaving is a race: many tries
+                def call():
+                    try:
+                        ds.score(vs)
+                        box["r"] = "returned ok"
+                    except N.TokenMonsterHipError as ex:
+                        box["r"] = str(ex)
+                t = threading.Thread(target=call, daemon=True)
+                t.start()
+                t.join(60)
+                assert not t.is_alive(), "tm_score_multi hangs when a member fails after the first meeting"
+                assert "test hook 14" in box["r"], box["r"]
+        finally:
+            N.lib.tm_debug_flags(old)
+        again = ds.score(vs)                                         # ... and the handle is as good as before
+        assert (again[0] == good[0]).all() and again[1] == good[1]
+        ds.close(); vs.close()
+    finally:
+        g.close()
+
+
 def test_devices_handle_rules():
     from tokenmonster_amd import _native as N
     with pytest.raises(N.TokenMonsterHipError):

@@ -365,7 +365,8 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
     const size_t ci = first.size() - 1;                              // this chunk's number
     const uint64_t left = offsets[ndocs] - offsets[d];
     uint64_t limit = chunk_bytes;
-    if (ci < nramp) limit = std::max<uint64_t>(chunk_bytes >> (nramp - ci), std::min<uint64_t>(chunk_bytes, 1u << 20));
+    // (the shift count is clamped: 8 lanes on 8 devices - or on the virtual devices of a test - make nramp 64 and more)
+    if (ci < nramp) limit = std::max<uint64_t>(chunk_bytes >> std::min<size_t>(nramp - ci, 63), std::min<uint64_t>(chunk_bytes, 1u << 20));
     if (left < (uint64_t)nramp * chunk_bytes) limit = std::min(limit, std::max<uint64_t>(left / nramp, std::min<uint64_t>(chunk_bytes, 2u << 20)));
     while (e < ndocs && offsets[e + 1] >= offsets[e] && offsets[e + 1] - offsets[d] <= limit) e++;
     d = e;

@@ -1367,19 +1367,20 @@ namespace tmh {
 // same results: 6 = dense T(p,1) array for every segment, 8 = per-lane normalizer kernel, 10 = K4 tile walk that stores every id
 // directly, 11 = the device normalizer packs its text instead of leaving it in the slabs for K1, 12 = group tree of long documents with fan-out 4
 // from 9 segments on (a deep tree on a small document), 13 = a 64 KiB
-// mailbox for the small host <-> device transfers (wraps within a test).  Nothing else is
+// mailbox for the small host <-> device transfers (wraps within a test), 14 = the last member of tm_score_multi gives up after the first
+// meeting of the members (an ERROR path: every member must return).  Nothing else is
 // reachable in the default build.  With -DTM_DEVEL (tools/ only: results are WRONG) further bits switch
 // phases of K1 off for profiling — 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps — bit 9 adds 4 KB
 // of dummy LDS per K1 workgroup, and TM_DBG in the environment sets the initial value.
 #ifndef TM_DEVEL
-constexpr int kDebugMask = 64 | 256 | 1024 | 2048 | 4096 | 8192;
+constexpr int kDebugMask = 64 | 256 | 1024 | 2048 | 4096 | 8192 | 16384;
 #define TM_K1_EXTRA_LDS 0
 #define TM_DBG_INITIAL 0
 #endif
 int g_debug_flags = -1;
 // The hooks are armed only in a process that was started with TM_TEST_HOOKS in its environment (the test suite's conftest, bench.py
 // --also-flags): in any other process tm_debug_flags() is inert, so that no caller of a server can change the code path under the others.
-static bool hooks_armed() { static const bool armed = getenv("TM_TEST_HOOKS") != nullptr; return armed; }
+bool hooks_armed() { static const bool armed = getenv("TM_TEST_HOOKS") != nullptr; return armed; }
 int debug_flags() {
   if (g_debug_flags < 0) g_debug_flags = TM_DBG_INITIAL;
   return g_debug_flags;

@@ -80,6 +80,16 @@ static Rccl& rccl() {
 }
 #endif
 
+// the calling thread's current device, put back when an entry point that had to visit the members' devices returns: the one-device entry
+// points (tm_vocab_load, tm_dataset_upload, ...) use the current device implicitly, and a caller must find it where it left it
+struct DeviceKeeper {
+  int dev = -1;
+  DeviceKeeper() { if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); } }
+  ~DeviceKeeper() { if (dev >= 0) (void)hipSetDevice(dev); }
+  DeviceKeeper(const DeviceKeeper&) = delete;
+  DeviceKeeper& operator=(const DeviceKeeper&) = delete;
+};
+
 __global__ void k_hist_add(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] += src[i];
@@ -124,6 +134,7 @@ static int open_list(const int* devices, int n, tm_devices** out) {
   int have = 0;
   hipError_t e = hipGetDeviceCount(&have);
   if (e != hipSuccess || have < 1) return set_error(TM_E_NODEVICE, "no HIP device visible");
+  DeviceKeeper keep;
   auto* g = new tm_devices();
   for (int i = 0; i < n; i++) {
     if (devices[i] < 0 || devices[i] >= have) { delete g; return set_error(TM_E_INVALID, "device %d of %d visible", devices[i], have); }
@@ -148,7 +159,6 @@ static int open_list(const int* devices, int n, tm_devices** out) {
       const hipError_t pe = hipDeviceEnablePeerAccess(g->dev[j], 0);
       if (pe != hipSuccess) (void)hipGetLastError();        // (already enabled: fine)
     }
-  (void)hipSetDevice(g->dev[0]);
   *out = g;
   return TM_OK;
 }
@@ -168,6 +178,7 @@ static bool rccl_ready(tm_devices* g) {
   if (n < 2 && !(env && atoi(env) > 0)) { g->rccl_note = "one member: nothing to reduce (TM_RCCL=1 runs the collective anyway)"; return false; }
   Rccl& r = rccl();
   if (!r.ok) { g->rccl_note = "librccl.so.1 could not be loaded"; return false; }
+  DeviceKeeper keep;                      // (ncclCommInitAll leaves the thread on a device of its choosing)
   g->comm.assign(n, nullptr);
   // (RCCL looks at the runtime's sticky "last error" between its own calls: one left behind by an unrelated earlier call - a probe of a
   // pageable pointer, say - would be reported as RCCL's failure)
@@ -184,6 +195,7 @@ static bool rccl_ready(tm_devices* g) {
 // `work(member)` on one host thread per member (member 0 on the calling thread), each with its device current; the first failure wins
 static int on_members(const tm_devices* g, const std::function<int(int)>& work) {
   const int n = (int)g->dev.size();
+  DeviceKeeper keep;                      // (member 0 runs on the calling thread)
   std::vector<int> rc(n, TM_OK);
   std::vector<std::string> msg(n);
   auto run = [&](int i) {
@@ -204,15 +216,20 @@ struct Meet {
   std::mutex mu;
   std::condition_variable cv;
   int n, arrived = 0, round = 0;
-  bool failed = false;
+  bool failed = false, verdict = true;
   explicit Meet(int members) : n(members) {}
-  bool wait(bool ok) {           // returns false if any member has failed so far
+  // Returns false if any member had failed when the LAST member of this round arrived - the same answer for every member of the round.
+  // (A member that fails right after this barrier and reaches the next one before a slower member has woken up from this one must not
+  // change what the slower member is told here: it would leave, never reach the next barrier, and the failing member would wait there
+  // forever.  `verdict` is written when a round completes and can only be written again when the next one does, which needs every
+  // member - the slow one included - to have arrived there, i.e. to have read it.)
+  bool wait(bool ok) {
     std::unique_lock<std::mutex> lk(mu);
     if (!ok) failed = true;
     const int my = round;
-    if (++arrived == n) { arrived = 0; round++; cv.notify_all(); }
+    if (++arrived == n) { arrived = 0; verdict = !failed; round++; cv.notify_all(); }
     else cv.wait(lk, [&] { return round != my; });
-    return !failed;
+    return verdict;
   }
 };
 
@@ -224,7 +241,7 @@ int tm_devices_open(int max_devices, tm_devices** out) {
   int have = 0;
   if (hipGetDeviceCount(&have) != hipSuccess || have < 1) { (void)hipGetLastError(); return set_error(TM_E_NODEVICE, "no HIP device visible"); }
   std::vector<int> list;
-  if (const char* e = getenv("TM_VIRTUAL_DEVICES")) {       // N members on device 0: the multi-device code paths on a one-GPU box
+  if (const char* e = hooks_armed() ? getenv("TM_VIRTUAL_DEVICES") : nullptr) {       // N members on device 0: the multi-device code paths on a one-GPU box (test processes only: TM_TEST_HOOKS)
     const int n = atoi(e);
     if (n >= 1 && n <= 64) list.assign((size_t)n, 0);
   }
@@ -248,6 +265,7 @@ int tm_devices_rccl_ranks(tm_devices* g, const char** why_not) {
 
 void tm_devices_close(tm_devices* g) {
   if (!g) return;
+  DeviceKeeper keep;
 #ifndef TM_EMU
   for (size_t i = 0; i < g->comm.size(); i++) if (g->comm[i]) { (void)hipSetDevice(g->dev[i]); (void)rccl().CommDestroy(g->comm[i]); }
 #endif
@@ -274,6 +292,7 @@ int tm_vocab_load_all(tm_devices* g, const uint8_t* vocab_file, size_t n, tm_voc
 
 // the set around a vocabulary that already lives on member 0: replicas of its device block on every other member
 static int replicate(tm_devices* g, tm_vocab* first, tm_vocab_set** out) {
+  DeviceKeeper keep;
   auto* s = new tm_vocab_set();
   s->devs = g;
   s->v.assign(g->dev.size(), nullptr);
@@ -306,6 +325,7 @@ extern "C++" void tmh_vocab_quiesce(tm_vocab* v);                               
 extern "C++" int tmh_vocab_adopt(tm_vocab* v, const tm_vocab_block* m);
 int tm_vocab_set_tune(tm_vocab_set* s, const uint8_t* normalized_sample, uint64_t n) {
   if (!s || s->v.empty() || !s->v[0]) return set_error(TM_E_INVALID, "null argument");
+  DeviceKeeper keep;
   int rc = tm_vocab_tune(s->v[0], normalized_sample, n);
   tm_vocab_block meta;
   void* src = nullptr;
@@ -330,6 +350,7 @@ int tm_vocab_set_count(const tm_vocab_set* s) { return s ? (int)s->v.size() : 0;
 
 void tm_vocab_set_free(tm_vocab_set* s) {
   if (!s) return;
+  DeviceKeeper keep;
   for (tm_vocab* v : s->v) tm_vocab_free(v);
   delete s;
 }
@@ -372,6 +393,7 @@ int tm_dataset_upload_sharded(tm_devices* g, const uint8_t* normalized, uint64_t
 
 void tm_dataset_set_free(tm_dataset_set* s) {
   if (!s) return;
+  DeviceKeeper keep;
   for (size_t i = 0; i < s->part.size(); i++) if (s->part[i]) { (void)hipSetDevice(s->devs->dev[i]); tm_dataset_free(s->part[i]); }
   delete s;
 }
@@ -387,6 +409,7 @@ int tm_score_multi(const tm_vocab_set* vs, tm_dataset_set* ds, uint32_t* scores,
   tm_devices* g = vs->devs;
   if (ds->devs != g) return set_error(TM_E_INVALID, "vocabulary set and dataset set belong to different tm_devices handles");
   const int nd = (int)g->dev.size();
+  DeviceKeeper keep;
   std::lock_guard<std::mutex> pass(g->mu);
   const bool use_rccl = rccl_ready(g);
   const uint64_t words = (uint64_t)vs->v[0]->host.n_ids + 4 + 256;
@@ -402,6 +425,9 @@ int tm_score_multi(const tm_vocab_set* vs, tm_dataset_set* ds, uint32_t* scores,
     hipStream_t st = g->stream[i];
     int r = tm_score_begin(v, d, 0, ds->own[i], ds->continues[i], st, &exits[(size_t)i * ENT]);
     if (!meet.wait(r == TM_OK)) return r;
+    // (test hook 14: the last member gives up between the first and the second meeting - every member must come back with its error,
+    // nobody may be left waiting at a meeting the others never reach)
+    if ((debug_flags() & 16384) && i == nd - 1) r = set_error(TM_E_INPUT, "test hook 14: member %d gives up after the first meeting", i);
     uint32_t entry = 0;
     for (int k = 0; k < i && r == TM_OK; k++) {
       entry = exits[(size_t)k * ENT + entry];

@@ -194,6 +194,8 @@ void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t 
 // (TM_TRACE: every buffer that is replaced by a larger one after a workspace exists - each is a hipFree, which waits for the whole device)
 inline void trace_grow(const char* what, uint64_t bytes) { static const bool on = getenv("TM_TRACE") != nullptr; if (on) fprintf(stderr, "[grow] %s -> %.2f MB\n", what, bytes / 1048576.0); }
 int reserve_groups(tm_batch* b, uint32_t ngroups, uint32_t nlong);
+int debug_flags();        // the test hooks in force (tm_debug_flags)
+bool hooks_armed();       // the process was started with TM_TEST_HOOKS in its environment: only then do tm_debug_flags / TM_VIRTUAL_DEVICES change anything
 uint32_t long_segs();    // documents with more segments than this hang under the group tree (LONG_SEGS; 8 under test hook bit 12)
 int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs, hipStream_t st);
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit);

@@ -746,10 +746,16 @@ extern "C" int tm_vocab_tune(tm_vocab* v, const uint8_t* normalized_sample, uint
   std::stable_sort(order.begin() + hv.n_info, order.end(), [&](uint32_t a, uint32_t b) { return use[a] > use[b]; });
   for (uint32_t i = 0; i < hv.n_nodes; i++) perm[order[i]] = i;
   const uint32_t n_da = hv.n_da;
-  if ((rc = build_tables(hv, trie, &perm)) != TM_OK) return rc;
-  if (hv.n_da != n_da) return set_error(TM_E_INTERNAL, "the double array changed size under a renumbering of the nodes");
-  v->tuned = true;
-  return reupload_tables(v);
+  // The host tables are rewritten in place; whatever goes wrong from here on, host and device must describe the SAME layout when the call
+  // returns (a later tm_vocab_block_export, a replica adopting the block or a second tune replays the host's view): on a failure the
+  // natural layout is rebuilt and uploaded, and the error of the failed step is what the caller sees.
+  rc = build_tables(hv, trie, &perm);
+  if (rc == TM_OK && hv.n_da != n_da) rc = set_error(TM_E_INTERNAL, "the double array changed size under a renumbering of the nodes");
+  if (rc == TM_OK) rc = reupload_tables(v);
+  if (rc == TM_OK) { v->tuned = true; return TM_OK; }
+  const std::string keep = last_error();
+  if (build_tables(hv, trie) == TM_OK && reupload_tables(v) == TM_OK) v->tuned = false;
+  return set_error(rc, "%s", keep.c_str());
 }
 
 int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* m, void** device_ptr) {
