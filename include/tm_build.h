@@ -45,6 +45,11 @@ int tm_vocab_build_all(struct tm_devices* g, const uint8_t* blob, const uint32_t
 /* Host-side normalize + capcode (go/tokenmonster.go:242-253).  Returns a malloc'd buffer. */
 int tm_normalize(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, uint8_t** out,
                  size_t* out_n);
+/* The way back for ONE byte string (a token, a decoded fragment): capcode decoding as Vocab.Denormalize does it (go/tokenmonster.go:445-462;
+ * tokenmonster-cpp/src/tokenmonster.cpp:3248-3253) - level 2 by the decoder of javascript/tokenmonster.js:1007-1065, level 1 drops the 0x7F
+ * marker and the character behind it, level 0 copies.  Host code (token lists are small); documents go through tm_decode_batch.  Returns a
+ * malloc'd buffer (tm_free). */
+int tm_denormalize(const uint8_t* data, size_t n, uint32_t capcode, uint8_t** out, size_t* out_n);
 /* Batch form: normalizes each document independently on `threads` host threads and re-packs into a
  * malloc'd buffer (*out_text, free with tm_free); out_offsets has ndocs+1 entries (caller-allocated).
  * Every normalizer flag bit is implemented (tokenmonster-cpp/src/tokenmonster.cpp:428-475: 1 NFD, 2 lowercase, 4 accents,

@@ -113,6 +113,7 @@ SIGNATURES = {
     "tm_tok_read": (C.c_int, [vp, C.c_size_t, vp, C.POINTER(vp), C.POINTER(vp), u32p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u32p]),
     "tm_tok_write": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "tm_normalize": (C.c_int, [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "tm_denormalize": (C.c_int, [vp, C.c_size_t, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "tm_normalize_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp), vp]),
 }
 

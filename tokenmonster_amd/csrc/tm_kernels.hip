@@ -443,6 +443,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         const M64 busy = __builtin_amdgcn_ballot_w64(off != idle_off);
         if (busy == 0ull) break;
         const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);
+#ifdef TM_DEVEL
+        // (pricing experiments, tools/ builds only: what a second 16-byte load per round costs when it lies in the same 32 bytes / on another line)
+        if (dbg & 0x60000) { const uint4 e2 = *reinterpret_cast<const uint4*>(tabb + (off ^ ((dbg & 0x20000) ? 16u : 0x1000u))); asm volatile("" :: "v"(e2.x), "v"(e2.y), "v"(e2.z), "v"(e2.w)); }
+#endif
         uint32_t c = *TM_LDS_PTR(lds_u8, pfa);
         uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);
         TM_KEEP_IN_VGPRS2(c, nn);
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   for (int it = 0; it < SEG / 64; it++) {
     const int p = it * 64 + lane;
     row0[it] = Row{0u, 0u, 0u, 0u};
-    if (p < seglen && w.D[p] != 0) row0[it] = T.rows[node_id(w.X[p])];
+    if (p < seglen && w.D[p] != 0) row0[it] = T.rows[TM_DBG_ON(dbg & 0x10000) ? (node_id(w.X[p]) & 63u) : node_id(w.X[p])];      // (devel bit 16: every row gather hits the same 1 KiB)
   }
   // ---- A2: class of the byte after each match; which positions need the forward-delete probe (go :1088) ----------
   // second token begins with a letter, has no word boundary and the byte after it is letter-class

@@ -663,6 +663,20 @@ int tm_normalize(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_
   return TM_OK;
 }
 
+int tm_denormalize(const uint8_t* data, size_t n, uint32_t capcode, uint8_t** out, size_t* out_n) {
+  if (!out || !out_n || (n && !data)) return tmh::set_error(TM_E_INVALID, "null argument");
+  if (capcode > 2) return tmh::set_error(TM_E_INVALID, "capcode %u", capcode);
+  std::vector<uint8_t> o;
+  tmh::CapcodeState st;
+  if (capcode == 2) tmh::capcode_decode_stream(st, data, n, o);
+  else if (capcode == 1) tmh::nocapcode_decode_stream(st, data, n, o);
+  else o.assign(data, data + n);
+  *out = (uint8_t*)std::malloc(o.size() ? o.size() : 1);
+  if (!o.empty()) std::memcpy(*out, o.data(), o.size());
+  *out_n = o.size();
+  return TM_OK;
+}
+
 int tm_normalize_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode,
                        uint32_t norm_flag, uint32_t threads, uint8_t** out_text, uint64_t* out_offsets) {
   if (!out_text || !out_offsets || (ndocs && (!text || !offsets))) return tmh::set_error(TM_E_INVALID, "null argument");

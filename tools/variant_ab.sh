@@ -8,7 +8,7 @@
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-declare -A VARIANTS=( [devel]="-DTM_DEVEL" [waves1]="-DTM_K1_WAVES=1" [waves2]="-DTM_K1_WAVES=2" [waves3]="-DTM_K1_WAVES=3" )
+declare -A VARIANTS=( [devel]="-DTM_DEVEL" )
 case "${1:-}" in
 build)
   for name in "${!VARIANTS[@]}"; do
