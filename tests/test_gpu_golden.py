@@ -127,3 +127,49 @@ def test_streaming_decoder_equals_reference_decoder():
         if max(c[2], default=0) < 0xE0:      # (a longer character cut in two is handed on in pieces, as the reference does: see above)
             d2 = v2.decoder()
             assert b"".join(d2.decode(toks[i:i + 1]) for i in range(toks.size)) + d2.flush() == c[3]
+
+
+@pytest.mark.parametrize("key", ["gpt2", "gpt2-capcode2-nfd"])
+def test_real_text_fixture_through_hip(key):
+    """tests/golden/realtext.json.gz (make_realtext_golden.py): REAL prose and code — the reference tree's own READMEs and Go / JS / C++ /
+    Python sources, one document per file and per 4 KiB slice — with the gpt2.json vocabulary as it stands (capcode 0) and as a capcode-2 /
+    NFD vocabulary; ids / missing / count by the reference runtime.  Through tm_tokenize_batch and tm_count_batch on host-normalized text,
+    through the RAW device pass (device normalizer + walk in one batch), through the chunked host-to-host pipeline, and back through
+    tm_decode_batch."""
+    from conftest import GOLDEN_DIR, realtext_fixture, realtext_ids
+    from oracle_bind import Reference, have_ref
+    g, docs = realtext_fixture()
+    if docs is None:
+        pytest.skip("the documents' text (tests/golden/_realtext_docs.bin.gz, git-ignored) is not here and /root/reference is absent")
+    img = base64.b64decode(load_golden(os.path.join(GOLDEN_DIR, "gpt2_vocab.json.gz"))["vocab_b64"] if key == "gpt2" else g["vocab_b_b64"])
+    fx = g["vocabs"][key]
+    exp = [realtext_ids(g, key, k) for k in range(len(docs))]
+    v = tm.Vocab(img)
+    # (1) host-normalized text -> tm_tokenize_batch / tm_count_batch
+    norm = [v.normalize(d) for d in docs]
+    assert [len(x) for x in norm] == fx["normalized_bytes"]
+    text, offs = tm.pack_documents(norm)
+    ids, toff, missing = v.tokenize_packed(text, offs)
+    counts, _ = v.count_packed(text, offs)
+    for k in range(len(docs)):
+        got = ids[int(toff[k]):int(toff[k + 1])]
+        assert got.size == exp[k].size and (got == exp[k]).all(), g["names"][k]
+        assert int(missing[k]) == fx["missing"][k] and int(counts[k]) == fx["count"][k], g["names"][k]
+    # (2) RAW text -> device normalizer + walk in one batch (tm_batch_upload_raw / tm_batch_normalize / tm_batch_run)
+    for k, got in enumerate(v.tokenize(docs)):
+        assert got.size == exp[k].size and (got == exp[k]).all(), g["names"][k]
+    # (3) RAW text -> the chunked pipeline, four bytes per id, chunks far smaller than the corpus
+    rtext, roffs = tm.pack_documents(docs)
+    blob, boff, pmiss, enc, st = v.tokenize_pipeline(rtext, roffs, raw=True, encoding_length=4, chunk_bytes=96 * 1024, lanes=3)
+    assert enc == 4 and st["chunks"] > 4 and (pmiss == np.array(fx["missing"], dtype=np.uint32)).all()
+    assert blob.tobytes() == np.concatenate(exp).astype("<u4").tobytes()
+    # (4) and back: tm_decode_batch == the reference runtime's decode of the same ids (capital letters, accents and all)
+    out, ooff = v.decode_packed(ids, toff, raw=False)
+    if have_ref():
+        ref = Reference(img)
+        for k in range(0, len(docs), 3):
+            assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == ref.decode(exp[k]), g["names"][k]
+    if key == "gpt2":
+        for k in range(len(docs)):
+            if fx["missing"][k] == 0:
+                assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == docs[k], g["names"][k]        # capcode 0, no normalization: the text itself
