@@ -145,6 +145,27 @@ def host_to_host(vocab, raw, roffs, text, offs, ids_expected, log, tm, steps=3, 
     pin_in.array[:] = raw
     pin_out = tm.PinnedBuffer(4 * ids_expected + 4096)
     res = {}
+
+    def pages_on_nodes(arr):
+        """where the pages of a buffer lie: {node: pages of the mapping it is part of} from /proc/self/maps + numa_maps (None if the kernel does not say)"""
+        try:
+            addr, start = arr.ctypes.data, None
+            for line in open("/proc/self/maps"):
+                a, b = line.split()[0].split("-")
+                if int(a, 16) <= addr < int(b, 16):
+                    start = a
+                    break
+            for line in open("/proc/self/numa_maps"):
+                f = line.split()
+                if f and f[0] == start:
+                    return {x.split("=")[0]: int(x.split("=")[1]) for x in f[1:] if x[0] == "N" and x[1:].split("=")[0].isdigit()} or None
+        except Exception:      # noqa: BLE001
+            pass
+        return None
+    # NUMA: the node of the GPU's PCIe root, where the page-locked buffers ended up (hipHostMalloc: the node nearest to the device), and the
+    # library's workers run on that node's CPUs for the length of a call (tm_host.hip: NearDevice; TM_NUMA=0 switches it off)
+    res["numa"] = {"gpu_node": int(N.lib.tm_device_numa_node(0)), "pinned_input_pages": pages_on_nodes(pin_in.array), "pinned_output_pages": pages_on_nodes(pin_out.array),
+                   "worker_threads": "bound to the GPU's node by the library" if os.environ.get("TM_NUMA", "1") != "0" else "left where the scheduler puts them (TM_NUMA=0)"}
     for label, src, dst in (("pinned", pin_in.array, pin_out.array), ("pageable", raw, np.empty(4 * ids_expected + 4096, dtype=np.uint8))):
         # ONE stated setting, `steps` passes after H2H_WARM warm-up passes (benchmark/tokenmonster_bench.go:41-55 times around the whole call).
         # Several, not one: in a fresh process the first five or so calls with four lanes' commands in flight take ~40 ms instead of ~32, each

@@ -145,7 +145,11 @@ typedef struct tm_pipeline_stats {
 int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, int raw,
                          uint32_t encoding_length, uint64_t chunk_bytes, uint32_t lanes, uint8_t* bytes_out, uint64_t bytes_cap,
                          uint64_t* byte_offsets, uint32_t* missing, uint32_t* encoding_length_used, tm_pipeline_stats* stats);
-/* Page-locked host memory for the buffers of tm_tokenize_pipeline (hipHostMalloc / hipHostRegister). */
+/* Page-locked host memory for the buffers of tm_tokenize_pipeline (hipHostMalloc / hipHostRegister).  hipHostMalloc places it on the NUMA
+ * node nearest to the current device; the pipeline's worker threads (the calling thread included, for the length of the call) run on that
+ * node's CPUs (TM_NUMA=0 in the environment: leave the threads where they are).  tm_device_numa_node: the node of a device's PCIe root as
+ * /sys/bus/pci/devices/<bdf>/numa_node gives it, -1 if the host does not say - what a caller pins its own feeding threads to. */
+int tm_device_numa_node(int device);
 void* tm_host_alloc(size_t bytes);
 void tm_host_free(void* p);
 int tm_host_register(void* p, size_t bytes);

@@ -96,6 +96,13 @@ LATIN = [chr(c) for c in (0xE9, 0xC9, 0xE8, 0xC0, 0xEF, 0xF1, 0xD1, 0xFC, 0xDC, 
                           0xA0, 0xB2, 0xBD, 0xD7, 0xF7, 0x100, 0x101, 0x10C, 0x10D, 0x141, 0x142, 0x152, 0x153, 0x130, 0x131, 0x149, 0x17F, 0x178, 0xFF, 0x138, 0x13F, 0x140)]
 
 
+# round 5: what the device pass took over last - four-byte characters (emoji, a skin-tone modifier, plane-2 ideographs, hieroglyphs; Deseret
+# with its case, a mathematical letter and a musical symbol that decomposes keep their documents on the host) and Hangul syllables with and
+# without a final consonant (NFD: jamo by arithmetic)
+ASTRAL_HANGUL = ["\U0001f600", "\U0001f680", "\U0001f44d\U0001f3fd", "\U0001f1e9\U0001f1ea", "\U00020000", "\U00020bb7", "\U00013000", "\U0001d49c", "\U00010400", "\U00010428",
+                 "\U0001d15e", "\uac00", "\uac01", "\ud7a3", "\ud55c", "\uad6d", "\uc5b4", "\ubdc1", "\uac12", "\ub2ed", "\u1100", "\u1161", "\u11a8", "\ufe0f"]
+
+
 def one_norm(seed):
     """the device normalizer (NFD / lowercase + capcode 2; host fallback for what it does not do itself) against the host normalizer:
     runs of capitals, digits and apostrophes of every length, also across the 64-byte chunks and 1 KiB pieces of the device pass"""
@@ -111,6 +118,8 @@ def one_norm(seed):
             r = rng.random()
             if r < 0.15:
                 parts.append("".join(rng.choice(NORM_ALPHABET[:30] + LATIN, size=int(rng.integers(1, 40)))))
+            elif r < 0.22:
+                parts.append("".join(rng.choice(NORM_ALPHABET[:30] + ASTRAL_HANGUL[int(rng.integers(0, 12)):], size=int(rng.integers(1, 40)))))
             elif r < 0.35:
                 parts.append("".join(rng.choice(NORM_ALPHABET[:36], size=int(rng.integers(1, 30)))))
             elif r < 0.55:
@@ -186,7 +195,7 @@ DEC_ALPHABET = list(b"CCWWDD    aabcxyzQZ019''.,-\n\t_")
 # round 4: the two-byte scripts (case pairs that keep or change the lead byte: а/А р/Р, Greek with the final sigma and the letters whose
 # upper-case form has another length: ΐ ŉ), Hebrew / Arabic with points and digits, CJK, kana, and what stays with the host (Hangul is
 # caseless and decoded on the device too; cased three-byte letters and four-byte characters are not)
-DEC_SCRIPTS = list("абвгджзийклмнопрстуфхцчшщъыьэюяёАБРСЯЁѐїλμνξοπρστυφχψωςάώΐΰΑΩΣשלוםְִّمرحبا١٢٣中文字测试。、こんにちはカタガギ한국ḁẞ①→★\U0001F600")
+DEC_SCRIPTS = list("абвгджзийклмнопрстуфхцчшщъыьэюяёАБРСЯЁѐїλμνξοπρστυφχψωςάώΐΰΑΩΣשלוםְִّمرحبا١٢٣中文字测试。、こんにちはカタガギ한국ḁẞ①→★\U0001F600") + ["\U0001f680", "\U0001f44d\U0001f3fd", "\U00020000", "\U00013000", "\U0001d49c", "\U00010428", "\U0001d7d8", "\uac01", "\u1100\u1161\u11a8"]
 
 
 # what the device decoder takes on itself beyond ASCII, and what it must hand to the host (upper-case forms of another length or lead byte: \u00ff \u00b5 \u0131 \u017f \u0149)

@@ -763,3 +763,63 @@ def test_multilingual_text_stays_on_the_device():
             for k in range(nchk):
                 dec = v.decoder()
                 assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == dec.decode(ids[int(toff[k]):int(toff[k + 1])]) + dec.flush()
+
+
+def emoji_korean_corpus(rng, nbytes):
+    """web-like text: English / French sentences with AT LEAST one emoji per document (four bytes of UTF-8: emoticons, pictographs, a
+    skin-tone modifier, flags), Korean running text (Hangul syllables with and without a final consonant) with English mixed in, and
+    plane-2 ideographs / hieroglyphs / cuneiform here and there; one document in a hundred carries what still needs the host (a Deseret
+    capital, a musical symbol that decomposes, the variation selector U+FE0F - a combining mark of three bytes -, a mathematical letter)"""
+    en = "the quick Brown FOX jumps over 13 lazy dogs it's NASA's iPhone LOL omg so café naïve Über".split()
+    ko = "한국어 텍스트 대한민국 서울 값 삶 닭 없다 읽다 가 나 다 라 마 바 사 아 자 차 카 타 파 하 안녕하세요 감사합니다 GPU 토큰".split()
+    emoji = ["😀", "😂", "🚀", "🌍", "👍", "👍🏽", "🎉", "🔥", "💯", "🤖", "🦄", "🇰🇷", "🀄"]
+    astral = ["𠀀", "𠮷", "𓀀", "𒀀"]
+    host_only = ["𐐀", "𝅗𝅥", "❤️", "𝒜"]         # (mathematical letters: their blocks of 64 code points have unassigned holes, the block table says "mixed")
+    docs, total = [], 0
+    while total < nbytes:
+        n = int(rng.integers(2, 200))
+        korean = rng.random() < 0.4
+        ws = [str(rng.choice(ko if korean and rng.random() < 0.8 else en)) for _ in range(n)]
+        for _ in range(1 + int(rng.integers(0, 3))):
+            ws.insert(int(rng.integers(0, len(ws) + 1)), str(rng.choice(emoji)))
+        if rng.random() < 0.1:
+            ws.insert(int(rng.integers(0, len(ws))), str(rng.choice(astral)))
+        if rng.random() < 0.01:
+            ws.insert(int(rng.integers(0, len(ws))), str(rng.choice(host_only)))
+        glue = "" if rng.random() < 0.2 else " "          # (now and then no spaces at all: emoji and syllables next to capitals and digits)
+        d = glue.join(ws).encode()
+        docs.append(d)
+        total += len(d)
+    return docs
+
+
+def test_emoji_and_korean_text_stay_on_the_device():
+    """round 5: characters beyond the Basic Multilingual Plane (emoji ...: two bits per block of 64 code points, from the host normalizer's
+    own functions) pass through the device normalizer and decoder, and Hangul syllables are decomposed by arithmetic (NFD: two or three
+    conjoining jamo per syllable) - one emoji no longer sends its document to ICU.  Bytes == the host normalizer's; >= 98 % of the documents
+    stay on the device (the corpus plants host-only characters in 1 %); ids of the raw path == ids of the host-normalized text; the device
+    decoder gives back NFD of the text."""
+    rng = np.random.default_rng(2026)
+    docs = emoji_korean_corpus(rng, 150_000 if EMULATED else 5_000_000)
+    raw, offs = tm.pack_documents(docs)
+    for capcode, flag in ((2, 1), (2, 3), (2, 0), (0, 0), (0, 1)):
+        v = tm.Vocab(synth.build_vocab([bytes([c]) for c in range(256)], capcode=capcode, charset=1, norm_flag=flag))
+        got, goff, nfb = v.normalize_packed_device(raw, offs)
+        exp, eoff = synth.normalize_batch(raw, offs, capcode, flag)
+        assert (goff == eoff).all() and got.size == exp.size
+        assert (got == exp).all(), "capcode %d flag %d" % (capcode, flag)
+        if not (capcode == 0 and (flag & 1)):      # (without capcode the pass keeps lengths: there the syllables that NFD decomposes take the host path)
+            assert nfb <= len(docs) // 50, "%d of %d documents took the host path (capcode %d flag %d)" % (nfb, len(docs), capcode, flag)
+        if capcode == 2 and flag == 1:
+            ids, toff, miss = v.tokenize_packed(exp, eoff)
+            assert int(miss.sum()) == 0
+            nchk = min(300, len(docs))
+            gotids = v.tokenize(docs[:nchk])
+            for k in range(nchk):
+                assert (gotids[k] == ids[int(toff[k]):int(toff[k + 1])]).all()
+            from tokenmonster_amd import _native as N
+            import unicodedata
+            out, ooff = v.decode_packed(ids[: int(toff[nchk])], np.ascontiguousarray(toff[: nchk + 1]))
+            assert N.lib.tm_decode_host_docs() <= max(1, nchk // 20), "%d of %d documents were decoded on the host" % (N.lib.tm_decode_host_docs(), nchk)
+            for k in range(nchk):
+                assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == unicodedata.normalize("NFD", docs[k].decode()).encode(), docs[k]

@@ -50,6 +50,7 @@ SIGNATURES = {
     "tm_tokenize_batch_serialized": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, u32p]),
     "tm_tokenize_pipeline": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_uint64, vp, vp, u32p, vp]),
     "tm_host_alloc": (vp, [C.c_size_t]),
+    "tm_device_numa_node": (C.c_int, [C.c_int]),
     "tm_host_free": (None, [vp]),
     "tm_host_register": (C.c_int, [vp, C.c_size_t]),
     "tm_host_unregister": (C.c_int, [vp]),

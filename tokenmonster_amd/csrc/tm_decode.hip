@@ -50,8 +50,9 @@ __global__ void k_dec_doc_off(const uint64_t* __restrict__ out_off, const uint64
 // value for the next chunk.  A character is decided at its first byte; its other bytes are transparent to every flag and take the decision
 // (kept / capitalised) of the first, also across the end of a chunk.  Capitalising a two-byte letter replaces its two bytes by those of
 // its upper-case form (`tab`, built by the host from the host decoder's own functions: tm_normalize.cpp build_dec_tables; р D1 80 -> Р D0 A0
-// changes the lead byte too); a character whose upper-case form has another length, a three-byte letter with case, anything of four
-// bytes, and any byte sequence that is not well-formed UTF-8 leave the document to the host decoder (dec_len = DEC_HOST).
+// changes the lead byte too); four-byte characters whose block of 64 code points is caseless throughout (emoji, symbols, the ideographs of
+// plane 2 ...) are passed on like the three-byte ones; a character whose upper-case form has another length, a three- or four-byte letter
+// with case, and any byte sequence that is not well-formed UTF-8 leave the document to the host decoder (dec_len = DEC_HOST).
 __device__ __forceinline__ unsigned long long dec_fill(unsigned long long P, unsigned long long S, unsigned& carry) {
   const unsigned long long t = P + S, u = t + carry;
   carry = (t < P) | (u < t);
@@ -65,6 +66,14 @@ __device__ __forceinline__ uint32_t dec_three_code(const uint32_t* __restrict__ 
   const uint32_t cp = ((lead & 15u) << 12) | ((b1 & 63u) << 6) | (b2 & 63u);
   const uint32_t bc = (tab[DEC_TWO + (cp >> 10)] >> (2u * ((cp >> 6) & 15u))) & 3u;
   return bc != 3u ? bc : ((tab[DEC_TWO + DEC_BLK_WORDS + (cp >> 4)] >> (2u * (cp & 15u))) & 3u);
+}
+// the same for the four-byte character lead b1 b2 b3: a code per block of 64 code points of the planes 1..16 (0 also for what is not one)
+__device__ __forceinline__ uint32_t dec_four_code(const uint32_t* __restrict__ tab, uint32_t lead, uint32_t b1, uint32_t b2, uint32_t b3) {
+  const uint32_t cp = ((lead & 7u) << 18) | ((b1 & 63u) << 12) | ((b2 & 63u) << 6) | (b3 & 63u);
+  if (cp - 0x10000u >= 0x100000u) return 0u;
+  const uint32_t blk = (cp - 0x10000u) >> 6;
+  const uint32_t code = (tab[DEC_TWO + DEC_BLK_WORDS + DEC_CP_WORDS + (blk >> 4)] >> (2u * (blk & 15u))) & 3u;
+  return code == 3u ? 0u : code;
 }
 __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__ in, const uint64_t* __restrict__ doc_off, uint32_t ndocs,
                                                       uint8_t* __restrict__ out, uint64_t* __restrict__ dec_len, const uint32_t* __restrict__ tab) {
@@ -82,35 +91,38 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
     const bool valid = at < e;
     const uint32_t c = valid ? in[at] : 0u;
     const bool hi = __any(c >= 0x80u);
-    uint32_t cn = 0, cnn = 0, cp = 0, cpp = 0;              // the bytes around it (inside the document), only looked at when the chunk is not pure ASCII
+    uint32_t cn = 0, cnn = 0, cn3 = 0, cp = 0, cpp = 0, cp3 = 0;   // the bytes around it (inside the document), only looked at when the chunk is not pure ASCII
     if (hi) {
-      cn = at + 1 < e ? in[at + 1] : 0u; cnn = at + 2 < e ? in[at + 2] : 0u;
-      cp = valid && at >= b + 1 ? in[at - 1] : 0u; cpp = valid && at >= b + 2 ? in[at - 2] : 0u;
+      cn = at + 1 < e ? in[at + 1] : 0u; cnn = at + 2 < e ? in[at + 2] : 0u; cn3 = at + 3 < e ? in[at + 3] : 0u;
+      cp = valid && at >= b + 1 ? in[at - 1] : 0u; cpp = valid && at >= b + 2 ? in[at - 2] : 0u; cp3 = valid && at >= b + 3 ? in[at - 3] : 0u;
     }
     auto is_lead2 = [](uint32_t x) { return x - 0xC2u < 30u; };
     auto is_lead3 = [](uint32_t x) { return (x & 0xF0u) == 0xE0u; };
     auto is_cont = [](uint32_t x) { return (x & 0xC0u) == 0x80u; };
+    auto is_lead4 = [](uint32_t x) { return x - 0xF0u < 5u; };
     const bool ascii = c < 0x80u;
-    const bool lead2 = valid && is_lead2(c), lead3 = valid && is_lead3(c);
-    uint32_t te = 0, t3 = 0;                                // table entry of the two-byte character this lane starts or ends / code of the three-byte character it starts
+    const bool lead2 = valid && is_lead2(c), lead3 = valid && is_lead3(c), lead4 = valid && is_lead4(c);
+    uint32_t te = 0, t3 = 0;                                // table entry of the two-byte character this lane starts or ends / code of the three- or four-byte character it starts
     if (lead2 && is_cont(cn)) te = tab[dec_tab_index(c, cn)];
     const bool tail2 = valid && is_cont(c) && is_lead2(cp);
     if (tail2) te = tab[dec_tab_index(cp, c)];
     if (lead3 && is_cont(cn) && is_cont(cnn)) t3 = dec_three_code(tab, c, cn, cnn);
-    // (the other bytes of a three-byte character: the lane of its first byte vouches for it)
+    if (lead4 && is_cont(cn) && is_cont(cnn) && is_cont(cn3)) t3 = dec_four_code(tab, c, cn, cnn, cn3);
+    // (the other bytes of a three- or four-byte character: the lane of its first byte vouches for it)
     const bool tail3a = valid && is_cont(c) && is_lead3(cp), tail3b = valid && is_cont(c) && is_cont(cp) && is_lead3(cpp);
-    const bool ok = !valid || ascii || (lead2 && (te & 1u)) || (lead3 && t3 != 0u) || (tail2 && (te & 1u)) || tail3a || tail3b;
+    const bool tail4 = valid && is_cont(c) && (is_lead4(cp) || (is_cont(cp) && (is_lead4(cpp) || (is_cont(cpp) && is_lead4(cp3)))));
+    const bool ok = !valid || ascii || (lead2 && (te & 1u)) || ((lead3 || lead4) && t3 != 0u) || (tail2 && (te & 1u)) || tail3a || tail3b || tail4;
     if (__any(!ok)) { host = true; break; }
     const unsigned long long V = __ballot(valid);
-    const unsigned long long L2 = __ballot(lead2), L3 = __ballot(lead3);
-    const unsigned long long START = __ballot(valid && (ascii || lead2 || lead3));
+    const unsigned long long L2 = __ballot(lead2), L4 = __ballot(lead4), L3 = __ballot(lead3) | L4;      // (L3: characters of three bytes or more)
+    const unsigned long long START = __ballot(valid && (ascii || lead2 || lead3 || lead4));
     const unsigned long long mC = __ballot(c == 'C'), mW = __ballot(c == 'W'), mD = __ballot(c == 'D');
     const unsigned long long M = mC | mW | mD, N = START & ~M;
     const unsigned long long SP = __ballot(c == ' ');
     const bool lower = c - 'a' < 26u;
     const unsigned long long LET = __ballot(lower || c - 'A' < 26u || (lead2 && (te & 2u))) & N;      // upper- or lower-case letters
     // what keeps a capitalised word going besides letters: digits, the apostrophe and U+2019, marks
-    const unsigned long long WC = __ballot(c - '0' < 10u || c == '\'' || (lead2 && (te & 4u)) || (lead3 && (t3 == 2u || (c == 0xE2u && cn == 0x80u && cnn == 0x99u))));
+    const unsigned long long WC = __ballot(c - '0' < 10u || c == '\'' || (lead2 && (te & 4u)) || ((lead3 || lead4) && (t3 == 2u || (c == 0xE2u && cn == 0x80u && cnn == 0x99u))));
     const unsigned long long deleted = N & dec_fill(M, mD, c_del);               // a 'D' since the last character: this one goes
     const unsigned long long ign = N & dec_fill(M, mW, c_ign);                   // a 'W' since the last character
     const unsigned long long kept = N & ~deleted;
@@ -120,10 +132,10 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
     const unsigned long long in_word = dec_fill(~ends_word, mW, c_word);
     const unsigned long long capS = in_char | (in_word & LET & K);                // characters that come out in upper case
     // the other bytes of a character: kept / capitalised like its first byte
-    const unsigned long long k23 = kept & (L2 | L3), k3 = kept & L3, cap2 = capS & L2;
-    const unsigned long long kept_all = kept | (k23 << 1) | (k3 << 2) | kept_in;
+    const unsigned long long k23 = kept & (L2 | L3), k3 = kept & L3, k4 = kept & L4, cap2 = capS & L2;
+    const unsigned long long kept_all = kept | (k23 << 1) | (k3 << 2) | (k4 << 3) | kept_in;
     const unsigned long long cap_tail = (cap2 << 1) | cap_in;
-    kept_in = (k23 >> 63) | (((k3 >> 62) & 1ull)) | ((k3 >> 63) << 1);
+    kept_in = (k23 >> 63) | (k3 >> 62) | (k4 >> 61);          // what the shifts above push beyond bit 63: the first bytes of the next chunk
     cap_in = cap2 >> 63;
     uint32_t oc = c;
     if (lower && ((capS >> lane) & 1ull)) oc = c - 32u;
@@ -157,7 +169,7 @@ static const uint32_t* dec_table(int device) {
   std::lock_guard<std::mutex> g(mu);
   if (device < 0 || device >= 64) return nullptr;
   if (!tabs[device]) {
-    if (h.empty()) { h.resize(DEC_TABLE_WORDS); build_dec_tables(h.data(), h.data() + DEC_TWO, h.data() + DEC_TWO + DEC_BLK_WORDS); }
+    if (h.empty()) { h.resize(DEC_TABLE_WORDS); build_dec_tables(h.data(), h.data() + DEC_TWO, h.data() + DEC_TWO + DEC_BLK_WORDS, h.data() + DEC_TWO + DEC_BLK_WORDS + DEC_CP_WORDS); }
     uint32_t* dp = nullptr;
     if (hipMalloc((void**)&dp, h.size() * 4) != hipSuccess) return nullptr;
     if (hipMemcpy(dp, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dp); return nullptr; }

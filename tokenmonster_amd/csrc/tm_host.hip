@@ -8,6 +8,7 @@
 // run H2D | normalize + tokenize (+ serialize) | D2H on several lanes at once, so that PCIe moves chunk k+1 in and chunk k-1 out
 // while chunk k computes — the host-to-host number of bench.py.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -99,6 +100,72 @@ static int lane_acquire(const tm_vocab* v, Lane** out) {
     p->cv.wait(lk);
   }
 }
+
+// ---- the GPU's NUMA node ------------------------------------------------------------------------------------------------------------------
+// A two-socket host has the GPU's PCIe root under ONE of its sockets.  Page-locked memory from hipHostMalloc already comes from the NUMA node
+// nearest to the current device (the runtime's default; hipHostMallocNumaUser would switch that off), but the THREADS that feed a lane -
+// command submission, the memcpy through pinned staging for pageable buffers, the waits - run wherever the scheduler put them, and from the
+// far socket every doorbell and every completion crosses the inter-socket link: the box-to-box spread of the host-to-host rate in rounds
+// 3 and 4 (27 - 34 GB/s for one library).  The workers of tm_tokenize_pipeline therefore run on the CPUs of the device's node for the length
+// of the call (the calling thread gets its own mask back); TM_NUMA=0 in the environment switches that off.
+struct NumaNear { int node = -1; cpu_set_t cpus; bool usable = false; };
+static const NumaNear& numa_near(int device) {
+  static std::mutex mu;
+  static NumaNear table[64];
+  static bool done[64] = {};
+  std::lock_guard<std::mutex> g(mu);
+  NumaNear& n = table[device < 0 || device >= 64 ? 0 : device];
+  if (device < 0 || device >= 64 || done[device]) return n;
+  done[device] = true;
+  CPU_ZERO(&n.cpus);
+  const char* off = getenv("TM_NUMA");
+  char bdf[64] = {0};
+  if ((off && atoi(off) == 0) || hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return n; }
+  for (char* c = bdf; *c; c++) *c = (char)tolower((unsigned char)*c);
+  char path[160];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return n;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  if (node < 0) return n;                        // (a one-node host, or a kernel that does not say)
+  snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  if (!(f = fopen(path, "r"))) return n;
+  char list[4096] = {0};
+  const bool got = fgets(list, sizeof list, f) != nullptr;
+  fclose(f);
+  if (!got) return n;
+  int count = 0;
+  for (char* p = list; *p && *p != '\n';) {       // "0-63,128-191"
+    char* end = nullptr;
+    const long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &n.cpus); count++; }
+    p = *end == ',' ? end + 1 : end;
+  }
+  // only the CPUs this process may use at all (a container's cpuset): an empty intersection leaves everything as it is
+  cpu_set_t mine;
+  if (sched_getaffinity(0, sizeof mine, &mine) == 0) { CPU_AND(&n.cpus, &n.cpus, &mine); count = CPU_COUNT(&n.cpus); }
+  n.node = node;
+  n.usable = count > 0;
+  return n;
+}
+// the calling thread on the CPUs near `device` while the object lives
+struct NearDevice {
+  cpu_set_t before;
+  bool changed = false;
+  explicit NearDevice(int device) {
+    const NumaNear& n = numa_near(device);
+    if (!n.usable || sched_getaffinity(0, sizeof before, &before) != 0) return;
+    changed = sched_setaffinity(0, sizeof n.cpus, &n.cpus) == 0;
+  }
+  ~NearDevice() { if (changed) (void)sched_setaffinity(0, sizeof before, &before); }
+  NearDevice(const NearDevice&) = delete;
+  NearDevice& operator=(const NearDevice&) = delete;
+};
 
 static void lane_release(const tm_vocab* v, Lane* l) {
   LanePool* p = v->pool;
@@ -225,6 +292,12 @@ static int d2h(void* dst, const void* src, uint64_t bytes, hipStream_t st, const
 using namespace tmh;
 
 extern "C" {
+
+int tm_device_numa_node(int device) {
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || device < 0 || device >= have) { (void)hipGetLastError(); return -1; }
+  return numa_near(device).node;
+}
 
 void* tm_host_alloc(size_t bytes) {
   void* p = nullptr;
@@ -394,6 +467,7 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
   const double t_pipe0 = now_ms();
   auto worker = [&](uint32_t wi) {
     const tm_vocab* const v = vs[wi % nv];
+    NearDevice near_gpu(v->device);             // (worker 0 is the calling thread: it gets its affinity back when the call returns)
     Lane* l = nullptr;
     int rc = lane_acquire(v, &l);
     std::vector<uint64_t> loc, loc_next, toff;

@@ -22,6 +22,7 @@ int build_vocab_image(const std::vector<std::string>& tokens, const std::vector<
 struct NmTwo;
 void build_two_table(uint32_t norm_flag, NmTwo* out);     // NM_TWO_SIZE entries: the device normalizer's table of the two-byte characters (tm_norm_masks.h)
 void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cp);    // NM_BLK_WORDS + NM_CP_WORDS words: the three-byte characters it passes through
+void build_four_table(uint32_t norm_flag, uint32_t* blk4);                   // NM_BLK4_WORDS words: the blocks of four-byte characters it passes through
 void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out);
 
 int normalize_batch_into(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t norm_flag,
@@ -33,8 +34,8 @@ void capcode_decode_stream(CapcodeState& st, const uint8_t* in, size_t n, std::v
 void nocapcode_decode_stream(CapcodeState& st, const uint8_t* in, size_t n, std::vector<uint8_t>& out);   // appends
 
 // the device decoder's tables (tm_decode.hip): the two-byte characters U+0080..U+07FF, then block and code-point codes of the three-byte ones
-constexpr uint32_t DEC_TWO = 0x780, DEC_BLK_WORDS = 64, DEC_CP_WORDS = 4096, DEC_TABLE_WORDS = DEC_TWO + DEC_BLK_WORDS + DEC_CP_WORDS;
-void build_dec_tables(uint32_t* two, uint32_t* blk, uint32_t* cp);
+constexpr uint32_t DEC_TWO = 0x780, DEC_BLK_WORDS = 64, DEC_CP_WORDS = 4096, DEC_BLK4_WORDS = 1024, DEC_TABLE_WORDS = DEC_TWO + DEC_BLK_WORDS + DEC_CP_WORDS + DEC_BLK4_WORDS;
+void build_dec_tables(uint32_t* two, uint32_t* blk, uint32_t* cp, uint32_t* blk4);
 
 void capcode_decode_batch(const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, uint32_t capcode, uint32_t threads,
                           std::vector<std::vector<uint8_t>>& outs);

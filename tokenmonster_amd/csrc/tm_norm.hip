@@ -36,7 +36,7 @@ using namespace tmh;
 // layout of the device part never waits for the host.
 namespace tmh {
 
-constexpr int PIECE = 1024, PMARGIN = 68, PLDS = PIECE + 2 * PMARGIN;      // 64 bytes of margin either side (k_norm_emit2<false> takes its carries from them) + 4 that the classifier looks at
+constexpr int PIECE = 1024, PMARGIN = 68, PLDS = PIECE + 2 * PMARGIN;      // 64 bytes of margin either side (k_norm_emit2<false> takes its carries from them) + 4: the classifier looks three bytes either way
 // character classes NC_* and flag bits NF_*: tm_norm_masks.h
 // piece summary bits
 constexpr uint32_t PS_WHOLE = 1u, PS_LEADU_SHIFT = 1, PS_LEADTL = 8u, PS_TRAILU_SHIFT = 5, PS_FIRSTBLOCK = 128u, PS_FIRSTL = 256u, PS_BAD = 512u;
@@ -53,15 +53,15 @@ __device__ __forceinline__ bool nblock(uint32_t cls) { return (cls & NF_BLOCK) !
 
 struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
 // The normalizer's tables in ONE device buffer (tm_norm_masks.h): NmTwo[NM_TWO_SIZE] | block codes [NM_BLK_WORDS] | code-point codes
-// [NM_CP_WORDS].  The 256 work-items of a workgroup stage the entries of U+0080..U+017F (2 KB) and the block codes (256 bytes) in LDS.
-constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS) * sizeof(uint32_t);
+// [NM_CP_WORDS] | block codes of the four-byte characters [NM_BLK4_WORDS] | one word of switches (NM_MISC_*; 16 bytes with its padding).  The 256 work-items of a workgroup stage the entries of U+0080..U+017F (2 KB) and the block codes (256 bytes) in LDS.
+constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t);
 struct TabLds { NmTwo two[NM_TWO_FAST]; uint32_t blk[NM_BLK_WORDS]; };
 __device__ __forceinline__ NmTabs stage_tabs(TabLds& s, const NmTwo* __restrict__ two) {
   static_assert(NM_TWO_FAST == 256 && NM_BLK_WORDS <= 256, "one entry per work-item");
   const uint32_t* blk = reinterpret_cast<const uint32_t*>(two + NM_TWO_SIZE);
   s.two[threadIdx.x] = two[threadIdx.x];
   if (threadIdx.x < NM_BLK_WORDS) s.blk[threadIdx.x] = blk[threadIdx.x];
-  return NmTabs{s.two, two, s.blk, blk + NM_BLK_WORDS};
+  return NmTabs{s.two, two, s.blk, blk + NM_BLK_WORDS, blk + NM_BLK_WORDS + NM_CP_WORDS, (uint32_t)__builtin_amdgcn_readfirstlane((int)blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS])};
 }
 
 // stage the piece (+ margins) and classify every byte; continuation bytes inherit the class of their lead byte.
@@ -93,10 +93,11 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
       for (int q = 0; q < 4; q++) {
         const int x = 4 * i + q;
         const uint32_t b = (w4 >> (8 * q)) & 0xFFu;
-        uint32_t fl = 0;                                    // (the two bytes at either end of the staged range are never looked at)
+        uint32_t fl = 0;                                    // (the three bytes at either end of the staged range are never looked at)
         if (b < 0x80u) fl = s_cls[b];                       // class of an ASCII byte: one LDS read instead of five range checks
-        else if (x >= 2 && x < PLDS - 2) {
-          fl = nm_classify_high(b, L.raw[x - 1], L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], tabs);     // a two-byte character, a three-byte one the pass leaves alone, or NF_BAD
+        else if (x >= 3 && x < PLDS - 3) {
+          // a two-byte character, a three- or four-byte one the pass leaves alone, or NF_BAD
+          fl = nm_classify_high(b, L.raw[x - 1], L.raw[x - 2], L.raw[x - 3], L.raw[x + 1], L.raw[x + 2], L.raw[x + 3], tabs);
         }
         f4 |= fl << (8 * q);
       }
@@ -314,6 +315,9 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
         const uint32_t extra = nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y, &m3);
         if (extra >= 1u) { len = 1u + extra; o2 = y; o1 = m3; }
       }
+      // one byte of a Hangul syllable (NFD): its lane emits one of the syllable's jamo - or nothing (tm_norm_masks.h)
+      uint32_t hrole, hcp;
+      if ((tabs.misc & NM_MISC_HANGUL) && fl != NF_BAD && nm_hangul_role(b, bm1, L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], &hrole, &hcp)) len = nm_hangul_out(hcp, hrole, &o1, &o2, &o3);
     }
     // inclusive prefix sum of len (0..4) over the wavefront: bytes-with-len>=k ballots, counted below the lane
     uint32_t incl = len;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
       if (len == 4) { w[0] = (uint8_t)o0; w[1] = (uint8_t)o1; w[2] = (uint8_t)o2; w[3] = (uint8_t)o3; }
       else if (len == 3) { w[0] = (uint8_t)o1; w[1] = (uint8_t)o2; w[2] = (uint8_t)o3; }
       else if (len == 2) { w[0] = (uint8_t)o2; w[1] = (uint8_t)o3; }
-      else w[0] = (uint8_t)o3;
+      else if (len == 1) w[0] = (uint8_t)o3;
     }
     pos += __shfl(incl, 63);
   }
@@ -461,13 +465,22 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
           if (extra >= 1u) { len1 = extra; ysp = y; m3 = mm; }
         }
       }
+      // Hangul syllables under NFD: every lane of a syllable emits the three bytes of one of its jamo, or - the third lane of a syllable
+      // without a final consonant - nothing at all: E, the lanes that emit at least one byte, is V everywhere else
+      unsigned long long E = V;
+      if ((tabs.misc & NM_MISC_HANGUL) && __ballot(nm_hangul_lead(b) || (lane < 2 && nm_cont_byte(b))) != 0ull) {
+        const uint8_t* r = L.raw + PMARGIN + 64 * c + lane;
+        uint32_t hrole, hcp, n = 1u;
+        if (fl != NF_BAD && nm_hangul_role(b, r[-1], r[-2], r[1], r[2], &hrole, &hcp)) { n = nm_hangul_out(hcp, hrole, &m3, &ysp, &o3); len1 = n ? 2u : 0u; }
+        E = V & ~__ballot(n == 0u);
+      }
       const unsigned long long ge2 = __ballot(len1 >= 1u) & V, ge3 = __ballot(len1 >= 2u) & V, ge4 = __ballot(len1 >= 3u) & V;
-      const uint32_t total = (uint32_t)(__builtin_popcountll(V) + __builtin_popcountll(ge2) + __builtin_popcountll(ge3) + __builtin_popcountll(ge4));
+      const uint32_t total = (uint32_t)(__builtin_popcountll(E) + __builtin_popcountll(ge2) + __builtin_popcountll(ge3) + __builtin_popcountll(ge4));
       if (pos + total <= (uint32_t)SLAB2) {
         // first output byte of the lane = out0 + pos + (bytes of the lanes below); its last byte is len1 further
-        const uint32_t first = mbcnt64(ge4, mbcnt64(ge3, mbcnt64(ge2, mbcnt64(V, out0 + pos))));
+        const uint32_t first = mbcnt64(ge4, mbcnt64(ge3, mbcnt64(ge2, mbcnt64(E, out0 + pos))));
         const uint32_t last = first + len1;
-        *TM_LDS_PTR(lds_u8, sel_mask(V, last, dump)) = (uint8_t)o3;
+        *TM_LDS_PTR(lds_u8, sel_mask(E, last, dump)) = (uint8_t)o3;
         *TM_LDS_PTR(lds_u8, sel_mask(ge2, last - 1u, dump)) = (uint8_t)ysp;
         *TM_LDS_PTR(lds_u8, sel_mask(ge3, last - 2u, dump)) = (uint8_t)m3;
         *TM_LDS_PTR(lds_u8, sel_mask(ge4, first, dump)) = (uint8_t)chD;
@@ -625,6 +638,8 @@ const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
     build_two_table(flags & 3u, two);
     if (!capcode2) for (int k = 0; k < NM_TWO_SIZE; k++) if (two[k].a & (NT_DECOMP | NT_DECOMP2)) two[k].a = 0;      // (without capcode the pass keeps lengths: decomposing characters take the host path)
     build_three_tables(flags & 3u, blk, blk + NM_BLK_WORDS);
+    build_four_table(flags & 3u, blk + NM_BLK_WORDS + NM_CP_WORDS);
+    blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] = (capcode2 && (flags & 1u)) ? NM_MISC_HANGUL : 0u;      // NFD of the Hangul syllables: by arithmetic, where the pass may change lengths
   }
   return t;
 }

@@ -61,15 +61,61 @@ TM_HD bool nm_punct3(uint32_t b1, uint32_t b2) {   // E2 b1 b2 in the supported 
 // or a surrogate: Hangul syllables, voiced kana, Latin Extended Additional ...), 1 = class O, 2 = class LO.  First a table of the 1 024
 // blocks of 64 code points (256 bytes, staged in LDS): 0 / 1 / 2 when the whole block agrees, 3 = look the code point up (16 KB, in HBM).
 constexpr int NM_BLK_WORDS = 64, NM_CP_WORDS = 4096;
+// ---- four-byte characters U+10000..U+10FFFF (lead bytes F0..F4): emoji, pictographs, historic scripts, mathematical alphanumerics ... --
+// The same two-bit codes per BLOCK of 64 code points (16 384 blocks of the planes 1..16, 4 KB, read where they lie: the characters are rare
+// and the blocks of one text few), again from the host normalizer's own functions (tm_normalize.cpp: build_four_table): 1 = class O, 2 =
+// class LO when every code point of the block is NFD-stable, caseless, neither digit nor mark - the emoji and symbol blocks, the
+// ideographs of plane 2, Linear B, cuneiform, hieroglyphs ...; 0 = the document takes the host path (Deseret, Adlam and the other cased
+// scripts of plane 1, the musical symbols that decompose, blocks with digits or combining marks, blocks that mix classes).
+constexpr int NM_BLK4_WORDS = 1024;
+TM_HD bool nm_four_lead(uint32_t b) { return b - 0xF0u < 5u; }
+// ---- Hangul syllables U+AC00..U+D7A3 under NFD: the conjoining jamo L V (T) by arithmetic (Unicode 3.12) ----------------------------------
+// 11 172 characters that DO decompose, but by rule instead of by table: s = cp - 0xAC00, L = U+1100 + s / 588, V = U+1161 + s % 588 / 28,
+// T = U+11A7 + s % 28 (none when s % 28 == 0).  Three bytes in, six or nine out, which fits the one-lane-per-input-byte scheme: the lane
+// of the syllable's first byte emits L, the second V, the third T or NOTHING (the only lanes of the pass that emit no byte at all).  To
+// capcode syllable and jamo alike are letters without case (class LO).  Only with the NFD flag and capcode 2 (NM_MISC_HANGUL in the
+// tables' last word: without capcode the pass keeps lengths, and without NFD the syllables are three-byte characters like any other).
+constexpr uint32_t NM_MISC_HANGUL = 1u;
+TM_HD bool nm_hangul_lead(uint32_t b) { return b - 0xEAu < 4u; }                      // EA B0 80 (U+AC00) .. ED 9E A3 (U+D7A3)
+TM_HD bool nm_hangul(uint32_t cp) { return cp - 0xAC00u < 11172u; }
+TM_HD uint32_t nm_cp3(uint32_t lead, uint32_t b1, uint32_t b2) { return ((lead & 15u) << 12) | ((b1 & 63u) << 6) | (b2 & 63u); }
+// the bytes the lane of byte number `role` (0, 1, 2) of the syllable emits: returns 3 (*o1 *o2 *o3) or 0
+TM_HD uint32_t nm_hangul_out(uint32_t cp, uint32_t role, uint32_t* o1, uint32_t* o2, uint32_t* o3) {
+  const uint32_t s = cp - 0xAC00u, t = s % 28u;
+  if (role == 2u && t == 0u) return 0u;
+  const uint32_t j = role == 0u ? 0x1100u + s / 588u : (role == 1u ? 0x1161u + (s % 588u) / 28u : 0x11A7u + t);
+  *o1 = 0xE1u; *o2 = 0x80u | ((j >> 6) & 63u); *o3 = 0x80u | (j & 63u);
+  return 3u;
+}
+// which byte of a Hangul syllable the byte b between m2 m1 and p1 p2 is (0, 1, 2), and the syllable: false if it is none
+TM_HD bool nm_hangul_role(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32_t p2, uint32_t* role, uint32_t* cp) {
+  uint32_t lead, b1, b2;
+  if (nm_hangul_lead(b)) { lead = b; b1 = p1; b2 = p2; *role = 0u; }
+  else if (!nm_cont_byte(b)) return false;
+  else if (nm_hangul_lead(m1)) { lead = m1; b1 = b; b2 = p1; *role = 1u; }
+  else if (nm_cont_byte(m1) && nm_hangul_lead(m2)) { lead = m2; b1 = m1; b2 = b; *role = 2u; }
+  else return false;
+  if (!nm_cont_byte(b1) || !nm_cont_byte(b2)) return false;
+  *cp = nm_cp3(lead, b1, b2);
+  return nm_hangul(*cp);
+}
 // what a kernel knows the tables by: the fast part of the two-byte table and the block table (LDS), the full tables (global memory)
-struct NmTabs { const NmTwo* two_fast; const NmTwo* two_all; const uint32_t* blk; const uint32_t* cp; };
+struct NmTabs { const NmTwo* two_fast; const NmTwo* two_all; const uint32_t* blk; const uint32_t* cp; const uint32_t* blk4; uint32_t misc; };
 TM_HD NmTwo nm_two_get(const NmTabs& t, uint32_t idx) { return idx < (uint32_t)NM_TWO_FAST ? t.two_fast[idx] : t.two_all[idx]; }
 TM_HD uint32_t nm_three_code(const NmTabs& t, uint32_t cp) {
   const uint32_t bc = (t.blk[cp >> 10] >> (2u * ((cp >> 6) & 15u))) & 3u;
   return bc != 3u ? bc : ((t.cp[cp >> 4] >> (2u * (cp & 15u))) & 3u);
 }
+TM_HD uint32_t nm_four_code(const NmTabs& t, uint32_t lead, uint32_t b1, uint32_t b2, uint32_t b3) {       // 0 also for anything that is not a well-formed character of the planes 1..16
+  if (!nm_cont_byte(b1) || !nm_cont_byte(b2) || !nm_cont_byte(b3)) return 0u;
+  const uint32_t cp = ((lead & 7u) << 18) | ((b1 & 63u) << 12) | ((b2 & 63u) << 6) | (b3 & 63u);
+  if (cp - 0x10000u >= 0x100000u) return 0u;                                                             // overlong, or beyond U+10FFFF
+  const uint32_t blk = (cp - 0x10000u) >> 6;
+  const uint32_t code = (t.blk4[blk >> 4] >> (2u * (blk & 15u))) & 3u;
+  return code == 3u ? 0u : code;
+}
 // class byte of the non-ASCII byte b between m2 m1 and p1 p2 (NF_BAD: the document needs the host normalizer)
-TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32_t p2, const NmTabs& tabs) {
+TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m3, uint32_t p1, uint32_t p2, uint32_t p3, const NmTabs& tabs) {
   if (nm_two_lead(b)) {
     if (!nm_cont_byte(p1)) return NF_BAD;
     const uint32_t a = nm_two_get(tabs, nm_two_index(b, p1)).a;
@@ -90,10 +136,23 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p
   if (nm_three_lead(b)) { lead = b; b1 = p1; b2 = p2; }
   else if (nm_cont_byte(b) && nm_three_lead(m1)) { lead = m1; b1 = b; b2 = p1; cont = NF_CONT; }
   else if (nm_cont_byte(b) && nm_cont_byte(m1) && nm_three_lead(m2)) { lead = m2; b1 = m1; b2 = b; cont = NF_CONT; }
-  else return NF_BAD;
+  else {
+    // one of the four bytes of a character beyond the Basic Multilingual Plane: every byte takes the class of the character's block
+    uint32_t code = 0u;
+    if (nm_four_lead(b)) code = nm_four_code(tabs, b, p1, p2, p3);
+    else if (nm_cont_byte(b)) {
+      cont = NF_CONT;
+      if (nm_four_lead(m1)) code = nm_four_code(tabs, m1, b, p1, p2);
+      else if (nm_four_lead(m2)) code = nm_four_code(tabs, m2, m1, b, p1);
+      else if (nm_four_lead(m3)) code = nm_four_code(tabs, m3, m2, m1, b);
+    }
+    return code == 0u ? (uint32_t)NF_BAD : ((code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O) | cont);
+  }
   if (!nm_cont_byte(b1) || !nm_cont_byte(b2)) return NF_BAD;
   if (lead == 0xE2u && nm_punct3(b1, b2)) return ((b1 == 0x80u && b2 == 0x99u) ? (uint32_t)NC_AP : (uint32_t)NC_O) | cont;      // U+2019 is an apostrophe (tokenmonster.js:878)
-  const uint32_t code = nm_three_code(tabs, ((lead & 15u) << 12) | ((b1 & 63u) << 6) | (b2 & 63u));
+  const uint32_t cp3 = nm_cp3(lead, b1, b2);
+  const uint32_t code = nm_three_code(tabs, cp3);
+  if (code == 0u && (tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp3)) return (uint32_t)NC_LO | cont;       // decomposes, but by arithmetic: nm_hangul_out
   return code == 0u ? (uint32_t)NF_BAD : ((code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O) | cont);
 }
 // the bytes of a lane that holds one byte of a two-byte character: *o3 = its last output byte; returns how many bytes the lane emits

@@ -448,6 +448,30 @@ void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cpt) {
   }
 }
 
+// blk4[NM_BLK4_WORDS]: two bits per block of 64 code points of U+10000..U+10FFFF (tm_norm_masks.h): 1 / 2 when EVERY code point of the block
+// is untouched by the flags, caseless, neither digit nor mark, and all of them are "other" (1) resp. all letters (2); 0 otherwise
+void build_four_table(uint32_t norm_flag, uint32_t* blk4) {
+  for (int k = 0; k < NM_BLK4_WORDS; k++) blk4[k] = 0;
+  for (uint32_t block = 0; block < 16384; block++) {
+    uint32_t first = 4;
+    for (uint32_t cp = 0x10000u + (block << 6); cp < 0x10000u + ((block + 1) << 6) && first != 0; cp++) {
+      uint32_t code = 0;
+      std::vector<uint8_t> in, t;
+      put_cp(in, cp);
+      t = in;
+      if (norm_flag & 1) nfd_bytes(t);
+      if (norm_flag & 2) lower_bytes(t);
+      const Cp c1 = next_cp(in.data(), in.size());
+      std::vector<uint8_t> low;
+      if (!c1.raw) put_lower(low, c1);
+      const uint8_t k1 = classify(c1);
+      if (t == in && !c1.raw && c1.n == 4 && low == in && !(k1 & (kUpper | kLower | kDigit | kMark))) code = (k1 & kLetter) ? 2u : 1u;
+      if (first == 4) first = code; else if (code != first) first = 0;
+    }
+    blk4[block >> 4] |= (first & 3u) << (2u * (block & 15u));
+  }
+}
+
 // The tables of the device capcode DECODER (tm_decode.hip: k_dec_capcode), made from the functions the host decoder above uses, so that the
 // device cannot disagree with it.
 //   two[(lead - 0xC2) << 6 | second & 63], the two-byte characters U+0080..U+07FF: bit 0 the device may decode the character, bit 1 upper- or
@@ -457,7 +481,24 @@ void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cpt) {
 //   blk / cp, the three-byte characters, two bits per block of 64 code points / per code point as in the normalizer's tables: 0 = host (a
 //     letter with case, a surrogate), 1 = a character the decoder only passes on (it ends a capitalised word), 2 = a digit or mark (keeps the
 //     word going); blocks: 3 = look the code point up.
-void build_dec_tables(uint32_t* two, uint32_t* blk, uint32_t* cpt) {
+//   blk4, the four-byte characters, two bits per block of 64 code points of U+10000..U+10FFFF: 1 / 2 as above when the whole block agrees
+//     (emoji, symbols, the ideographs of plane 2 ...), else 0 = host (Deseret, Adlam and the other cased scripts; blocks that mix digits or
+//     marks with other characters).
+void build_dec_tables(uint32_t* two, uint32_t* blk, uint32_t* cpt, uint32_t* blk4) {
+  for (uint32_t k = 0; k < DEC_BLK4_WORDS; k++) blk4[k] = 0;
+  for (uint32_t block = 0; block < 16384; block++) {
+    uint32_t first = 4;
+    for (uint32_t cp = 0x10000u + (block << 6); cp < 0x10000u + ((block + 1) << 6) && first != 0; cp++) {
+      std::vector<uint8_t> in;
+      put_cp(in, cp);
+      const Cp c = next_cp(in.data(), in.size());
+      const uint8_t cls = classify(c);
+      uint32_t code = 0;
+      if (!c.raw && c.n == 4 && !(cls & (kLower | kUpper)) && (uint32_t)u_toupper((UChar32)cp) == cp) code = (cls & (kDigit | kMark)) ? 2u : 1u;
+      if (first == 4) first = code; else if (code != first) first = 0;
+    }
+    blk4[block >> 4] |= (first & 3u) << (2u * (block & 15u));
+  }
   for (uint32_t cp = 0x80; cp < 0x800; cp++) {
     const uint8_t b[2] = {(uint8_t)(0xC0u | (cp >> 6)), (uint8_t)(0x80u | (cp & 0x3Fu))};
     uint32_t e = 0;

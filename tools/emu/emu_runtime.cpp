@@ -340,6 +340,7 @@ hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipDeviceGetPCIBusId(char*, int, int) { return hipErrorInvalidDevice; }      // (no PCI device behind the emulated one: the library then leaves thread placement alone)
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }    // "compute units": few persistent workgroups
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated HIP runtime error"; }

@@ -175,6 +175,7 @@ hipError_t hipGetDeviceCount(int* n);
 hipError_t hipGetDevice(int* d);
 hipError_t hipSetDevice(int d);
 hipError_t hipDeviceSynchronize();
+hipError_t hipDeviceGetPCIBusId(char* bdf, int len, int dev);
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int dev);
 hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);

@@ -30,8 +30,8 @@ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
 }
 static uint64_t g_margin_ok = 0, g_margin_unknown = 0;
 static NmTwo g_two[2][NM_TWO_SIZE];     // [lower_all]: flags 1 (NFD) and 3 (NFD + lowercase)
-static uint32_t g_blk[2][NM_BLK_WORDS], g_cp[2][NM_CP_WORDS];      // the three-byte characters the pass leaves alone (tm_norm_masks.h)
-static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k]}; }
+static uint32_t g_blk[2][NM_BLK_WORDS], g_cp[2][NM_CP_WORDS], g_blk4[2][NM_BLK4_WORDS];      // the three- and four-byte characters the pass leaves alone (tm_norm_masks.h)
+static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k], g_blk4[k], NM_MISC_HANGUL}; }
 // class byte of every byte of a document as norm_load_piece computes it (bytes outside the document read as 0)
 bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t>& f) {
   const int n = (int)d.size();
@@ -40,7 +40,7 @@ bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t
   bool ok_all = true;
   for (int i = 0; i < n; i++) {
     const uint32_t b = d[i];
-    const uint32_t fl = b < 0x80u ? ncls_ascii(b, lower_all) : nm_classify_high(b, at(i - 1), at(i - 2), at(i + 1), at(i + 2), tabs_of(lower_all));
+    const uint32_t fl = b < 0x80u ? ncls_ascii(b, lower_all) : nm_classify_high(b, at(i - 1), at(i - 2), at(i - 3), at(i + 1), at(i + 2), at(i + 3), tabs_of(lower_all));
     if (fl == NF_BAD) ok_all = false;
     f[i] = (uint8_t)fl;
   }
@@ -117,6 +117,8 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
         const uint32_t extra = nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y, &mm);
         if (extra >= 1u) { len = 1u + extra; ysp = y; m3 = mm; }
       }
+      uint32_t hrole, hcp;
+      if (fl != NF_BAD && nm_hangul_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &hrole, &hcp)) { len = nm_hangul_out(hcp, hrole, &m3, &ysp, &o3); if (len == 0) continue; }
       if (len == 4) out.push_back('D');
       if (len >= 3) out.push_back((uint8_t)m3);
       if (len >= 2) out.push_back((uint8_t)ysp);
@@ -191,11 +193,15 @@ int main(int argc, char** argv) {
   build_two_table(3, g_two[1]);
   build_three_tables(1, g_blk[0], g_cp[0]);
   build_three_tables(3, g_blk[1], g_cp[1]);
+  build_four_table(1, g_blk4[0]);
+  build_four_table(3, g_blk4[1]);
   { int ok = 0, dec = 0, dec2 = 0; for (int k = 0; k < NM_TWO_SIZE; k++) { ok += (g_two[0][k].a & NT_OK) != 0; dec += (g_two[0][k].a & NT_DECOMP) != 0; dec2 += (g_two[0][k].a & NT_DECOMP2) != 0; }
     int c1 = 0, c2 = 0, mixed = 0;
     for (uint32_t cp = 0x800; cp < 0x10000; cp++) { const uint32_t c = (g_cp[0][cp >> 4] >> (2 * (cp & 15))) & 3u; c1 += c == 1; c2 += c == 2; }
     for (uint32_t b = 0; b < 1024; b++) mixed += ((g_blk[0][b >> 4] >> (2 * (b & 15))) & 3u) == 3u;
     printf("two-byte table (NFD): %d of %d characters on the device, %d decompose into an ASCII letter + mark, %d into a two-byte letter + mark\n", ok, NM_TWO_SIZE, dec, dec2);
+    { int b1 = 0, b2 = 0; for (uint32_t b = 0; b < 16384; b++) { const uint32_t c = (g_blk4[0][b >> 4] >> (2 * (b & 15))) & 3u; b1 += c == 1; b2 += c == 2; }
+      printf("four-byte characters: %d of 16384 blocks of 64 code points pass as class O, %d as letters without case\n", b1, b2); }
     printf("three-byte characters left alone on the device: %d class O, %d letters without case; %d of 1024 blocks are mixed (per code point)\n", c1, c2, mixed); }
   std::vector<std::string> fixed = {"", "A", "a", "AB", "Ab", "aB", "ABc", "ABC", " ABC d", "HTTPServer2Go x", "X's Y'S it's 'a' I'M", "12AB34cd", "A1B2c",
                                     "X\xE2\x80\x99s Y\xE2\x80\x99S it\xE2\x80\x99s", std::string(200, 'A') + "b", std::string(200, 'A'),
@@ -206,8 +212,10 @@ int main(int argc, char** argv) {
                                     "\xC5\x81\xC3\xB3" "d\xC5\xBA \xC4\x8C\xC4\x8D" "SR \xC4\xB0stanbul \xC4\xB1\xC5\xBF", std::string(1023, 'x') + "\xC3\x89" "b", std::string(1022, 'x') + " \xC3\x89" + std::string(40, 'A') + "c",
                                     std::string(63, 'a') + "\xC3\xA9\xC3\xA9", "l'\xC3\xA9t\xC3\xA9 d'\xC3\x89" "mile 3\xC3\xA8me \xC3\xA9's",
                                     u8"Привет, Мир! Ёжик и йод. МОСКВА Санкт-Петербург", u8"Καλημέρα κόσμε. ΑΘΗΝΑ Ελλάδα ά έ ή ί ό ύ ώ ΐ", u8"שלום עולם בְּרֵאשִׁית", u8"مرحبا بالعالم ١٢٣ كِتَاب",
-                                    u8"中文文本，测试。Hello世界 ABC中文", u8"こんにちは世界 カタカナ がぎぐ パピプ", u8"한국어 텍스트", u8"a\u0301 e\u0301\u0323 o\u0323\u0301 Ắ ǖ", u8"→ ★ ∑ √ ①②③ Ḁḁ ẞ",
-                                    std::string(1023, 'x') + u8"й", std::string(1022, 'x') + u8"Йод", std::string(62, 'a') + u8"йй" + std::string(61, 'b') + u8"中文"};
+                                    u8"中文文本，测试。Hello世界 ABC中文", u8"こんにちは世界 カタカナ がぎぐ パピプ", u8"한국어 텍스트", u8"가 각 힣 뷁 A가B 가a 1가 '가' 한글Hangul 가\u0301", std::string(1022, 'x') + u8"한국", std::string(1023, 'x') + u8"각", std::string(400, 'x') + std::string(u8"한국어텍스트가나다라마바사") + std::string(u8"아자차카타파하") + std::string(600, 'y'), u8"a\u0301 e\u0301\u0323 o\u0323\u0301 Ắ ǖ", u8"→ ★ ∑ √ ①②③ Ḁḁ ẞ",
+                                    std::string(1023, 'x') + u8"й", std::string(1022, 'x') + u8"Йод", std::string(62, 'a') + u8"йй" + std::string(61, 'b') + u8"中文",
+                                    u8"Hello 😀 World 🌍🚀 it's 👍🏽 A😀B c😀d 1😀2 '😀' 𝒜𝒷 𠀀𠀁 done", std::string(1021, 'x') + u8"😀Ab", std::string(1022, 'x') + u8"😀" + " Ab", std::string(1023, 'x') + u8"A😀b", std::string(61, 'A') + u8"😀😀" + std::string(70, 'b'),
+                                    u8"𐐀𐐨 Deseret", u8"𝅗𝅥 half note", "\xF0\x9F\x98", "\xF4\x90\x80\x80 beyond", "\xF0\x80\x80\x80 overlong", u8"x😀"};
   for (int lower = 0; lower < 2; lower++) {
     const uint32_t flag = lower ? 3u : 1u;
     for (const auto& s : fixed) { std::vector<uint8_t> d(s.begin(), s.end()); total++; if (!check_doc(d, flag, &skipped)) bad++; }
@@ -219,13 +227,14 @@ int main(int argc, char** argv) {
       const uint32_t style = rng.below(5);      // 0 mixed, 1 capitals-heavy, 2 digits/apostrophes-heavy, 3 spaces + capitals, 4 long runs
       const bool latin = rng.below(2) != 0;     // half of the documents carry accented Latin letters, a few of them a lot
       // a third of the documents are written in another script: Greek, Cyrillic (with the letters that decompose: й ё ά ...), Hebrew, Arabic,
-      // standalone combining marks, Chinese, Japanese (with voiced kana, which send the document to the host), Korean (host), symbols
-      const uint32_t script = rng.below(3) == 0 ? 1 + rng.below(8) : 0;
+      // standalone combining marks, Chinese, Japanese (with voiced kana, which send the document to the host), Korean (Hangul syllables decompose by arithmetic), symbols, four-byte characters
+      const uint32_t script = rng.below(3) == 0 ? 1 + rng.below(9) : 0;
       const uint32_t latin_share = rng.below(4) == 0 ? 40 : 6;
       while (d.size() < len) {
         const uint32_t r = rng.below(100);
         if (style == 4 && r < 30) { const char ch = "AB1'a "[rng.below(6)]; const uint32_t rep = 1 + rng.below(150); for (uint32_t q = 0; q < rep; q++) d.push_back((uint8_t)ch); continue; }
         if (r < 4) { const char* mchar = multi[rng.below(6)]; d.insert(d.end(), mchar, mchar + 3); continue; }
+        if (r == 4 && rng.below(3) == 0) { const uint32_t e = 0x1F600 + rng.below(0x50); const uint8_t b4[4] = {0xF0, (uint8_t)(0x80 | ((e >> 12) & 0x3F)), (uint8_t)(0x80 | ((e >> 6) & 0x3F)), (uint8_t)(0x80 | (e & 0x3F))}; d.insert(d.end(), b4, b4 + 4); continue; }   // an emoticon anywhere
         if (script && r < 60) {
           uint32_t cp = 0;
           switch (script) {
@@ -236,9 +245,18 @@ int main(int argc, char** argv) {
             case 5: cp = rng.below(4) ? 0x4E00 + rng.below(0x5000) : 0x3000 + rng.below(0x40); break;   // Chinese + CJK punctuation
             case 6: cp = rng.below(3) ? 0x3041 + rng.below(0x56) : (rng.below(2) ? 0x30A1 + rng.below(0x5A) : 0x4E00 + rng.below(0x5000)); break;   // Japanese
             case 7: cp = rng.below(6) ? 0x0180 + rng.below(0x680) : 0x0300 + rng.below(0x70); break;   // anything two-byte, and stray combining marks
+            case 9: {                                                                        // four bytes: emoji and pictographs, plane-2 ideographs, mathematical letters; now and then what the host has to do
+              const uint32_t q = rng.below(40);
+              cp = q < 20 ? 0x1F300 + rng.below(0x700) : q < 28 ? 0x20000 + rng.below(0xA000) : q < 34 ? 0x1D400 + rng.below(0x400) : q < 36 ? 0x10000 + rng.below(0x100) :
+                   q == 36 ? 0x10400 + rng.below(0x50) /* Deseret: case */ : q == 37 ? 0x1D15E + rng.below(7) /* musical symbols that decompose */ : q == 38 ? 0x1F100 + rng.below(0x10) : 0x10000 + rng.below(0x100000);
+              break; }
             default: cp = rng.below(3) ? 0x2190 + rng.below(0x400) : (rng.below(2) ? 0xAC00 + rng.below(0x2BA4) : 0x1E00 + rng.below(0x100)); break;   // arrows / symbols; Hangul, Latin Extended Additional (host)
           }
           if (cp < 0x800) { d.push_back((uint8_t)(0xC0 | (cp >> 6))); d.push_back((uint8_t)(0x80 | (cp & 0x3F))); }
+          else if (cp >= 0x10000) {
+            d.push_back((uint8_t)(0xF0 | (cp >> 18))); d.push_back((uint8_t)(0x80 | ((cp >> 12) & 0x3F)));
+            if (rng.below(300)) { d.push_back((uint8_t)(0x80 | ((cp >> 6) & 0x3F))); if (rng.below(300)) d.push_back((uint8_t)(0x80 | (cp & 0x3F))); }      // (now and then cut short)
+          }
           else { d.push_back((uint8_t)(0xE0 | (cp >> 12))); d.push_back((uint8_t)(0x80 | ((cp >> 6) & 0x3F))); if (rng.below(400)) d.push_back((uint8_t)(0x80 | (cp & 0x3F))); }
           if (rng.below(5) == 0) d.push_back(' ');
           continue;
