@@ -546,9 +546,12 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
       if (missing && nd && (rc = small_d2h(b, missing + d0, b->d_doc_missing, (uint64_t)nd * 4, l->stream)) != TM_OK) break;
       const bool fits = (base + ro.total_tokens) * encoding_length <= bytes_cap && bytes_out;
       if (fits && out_b) {
+        uint8_t* dst = bytes_out + base * encoding_length;
+        // (Writing the ids straight into the caller's page-locked buffer from the serialize kernel - no device staging, no copy command - was
+        // built and timed in round 5: 42 - 45 ms per GiB call against 32 - 36 with the copy engine, profiles/r05_h2h.txt: stores of a kernel to
+        // fine-grained host memory cross PCIe far below the engine's rate.  Removed.)
         if ((rc = lane_dbytes(l, out_b)) != TM_OK) break;
         launch_serialize(b->d_out, ro.total_tokens, encoding_length, l->d_bytes, l->stream);
-        uint8_t* dst = bytes_out + base * encoding_length;
         if (out_pinned) rc = d2h(dst, l->d_bytes, out_b, l->stream, "D2H ids");
         else {
           if ((rc = lane_stage(l, out_b)) != TM_OK) break;

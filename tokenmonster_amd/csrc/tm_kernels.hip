@@ -1357,6 +1357,25 @@ __global__ void k_serialize(const uint32_t* __restrict__ ids, uint64_t n, uint32
   if (enc == 4) o[3] = 0;                     // go :2089 writes a zero high byte
 }
 
+// The same, eight ids per work-item and 16-byte stores, for the two widths a stream is normally written in (2 bytes: up to 65 536 ids; 4:
+// the server's wide form): `out` may be page-locked HOST memory (tm_tokenize_pipeline writes the ids of a chunk straight into the caller's
+// pinned buffer: no device staging, no copy command behind the kernel), where only full-width stores of neighbouring lanes make sensible
+// PCIe writes.  ids [0, head) and the last few are left to k_serialize (the vector part starts at the first 16-byte boundary of `out`).
+template <int ENC>
+__global__ __launch_bounds__(256) void k_serialize_wide(const uint32_t* __restrict__ ids, uint64_t head, uint64_t nvec, uint8_t* __restrict__ out) {
+  constexpr int PER = 16 / ENC;                       // ids per 16 bytes of output
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nvec) return;
+  const uint32_t* src = ids + head + t * PER;
+  uint32_t v[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) v[k] = src[k];
+  uint4 o;
+  if (ENC == 2) o = make_uint4((v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16), (v[4] & 0xFFFFu) | (v[5] << 16), (v[6] & 0xFFFFu) | (v[7] << 16));
+  else o = make_uint4(v[0] & 0xFFFFFFu, v[1] & 0xFFFFFFu, v[2] & 0xFFFFFFu, v[3 % PER] & 0xFFFFFFu);
+  *reinterpret_cast<uint4*>(out + (head + t * PER) * ENC) = o;
+}
+
 }  // namespace tmh
 
 using namespace tmh;
@@ -1871,7 +1890,21 @@ int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
   return build_groups(b, offsets, offsets + 1, ndocs, st);
 }
 void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* out, hipStream_t st) {
-  if (n) TM_LAUNCH(k_serialize, (uint32_t)((n + 255) / 256), 256, 0, st, ids, n, enc, out);
+  if (!n) return;
+  if ((enc == 2 || enc == 4) && n >= 4096) {
+    // ids before the first 16-byte boundary of `out` and behind the last whole 16 bytes: the byte-wise kernel; everything between: 16-byte stores
+    const uint64_t per = 16 / enc, mis = (uint64_t)(reinterpret_cast<uintptr_t>(out) & 15u);
+    const uint64_t head = mis ? (16 - mis) / enc : 0;          // (`out` is a multiple of enc bytes into a 16-byte aligned buffer in every caller; an odd address falls through below)
+    if (mis % enc == 0) {
+      const uint64_t nvec = (n - head) / per, tail0 = head + nvec * per;
+      if (head) TM_LAUNCH(k_serialize, 1, 256, 0, st, ids, head, enc, out);
+      if (enc == 2) TM_LAUNCH(k_serialize_wide<2>, (uint32_t)((nvec + 255) / 256), 256, 0, st, ids, head, nvec, out);
+      else TM_LAUNCH(k_serialize_wide<4>, (uint32_t)((nvec + 255) / 256), 256, 0, st, ids, head, nvec, out);
+      if (tail0 < n) TM_LAUNCH(k_serialize, 1, 256, 0, st, ids + tail0, n - tail0, enc, out + tail0 * enc);
+      return;
+    }
+  }
+  TM_LAUNCH(k_serialize, (uint32_t)((n + 255) / 256), 256, 0, st, ids, n, enc, out);
 }
 }  // namespace tmh
 extern "C" {

@@ -64,6 +64,33 @@ __device__ __forceinline__ NmTabs stage_tabs(TabLds& s, const NmTwo* __restrict_
   return NmTabs{s.two, two, s.blk, blk + NM_BLK_WORDS, blk + NM_BLK_WORDS + NM_CP_WORDS, (uint32_t)__builtin_amdgcn_readfirstlane((int)blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS])};
 }
 
+// Bytes beyond ASCII are the exception (a dword of plain ASCII never gets here), and what they need is long: kept OUT of line, so that the
+// unrolled loops of the kernels stay short enough for the instruction cache (inlined into every copy of a loop body, the classifier and the
+// two-byte / Hangul output code made k_norm_emit2 57 % larger and 7 % slower on text that has none of these characters).
+__device__ __noinline__ uint32_t classify_high_byte(const uint8_t* raw_x, NmTabs tabs) {
+  return nm_classify_high(raw_x[0], raw_x[-1], raw_x[-2], raw_x[-3], raw_x[1], raw_x[2], raw_x[3], tabs);
+}
+// what the lane of a byte >= 0x80 emits in k_norm_emit2 (tm_norm_masks.h): the bytes of a two-byte character come from the table - the lead
+// lane its first byte, or the ASCII letter the character decomposes into; the second lane its second byte, or the two bytes of the combining
+// mark -; every lane of a Hangul syllable (NFD) emits the three bytes of one of its jamo, or - the third lane of a syllable without a final
+// consonant - nothing at all.  In: r = the byte in LDS, fl its class byte, code its rule-table entry; o = {o3, ysp, m3, len1} as the rule
+// table left them.  Returns the same four, len1 = 0xFF for "no byte at all".
+struct HighOut { uint32_t o3, ysp, m3, len1; };
+__device__ __noinline__ HighOut emit_high_byte(const uint8_t* r, uint32_t fl, uint32_t code, HighOut o, NmTabs tabs) {
+  const uint32_t b = r[0], bm1 = r[-1], bp1 = r[1];
+  const bool lead2 = nm_two_lead(b), cont2 = nm_cont_byte(b) && nm_two_lead(bm1);
+  if (lead2 || cont2) {
+    const NmTwo e = nm_two_get(tabs, lead2 ? nm_two_index(b, bp1) : nm_two_index(bm1, b));
+    uint32_t y = 0, mm = 0;
+    const uint32_t extra = nm_two_out(e, cont2, (code & 4u) != 0, true, &o.o3, &y, &mm);
+    if (extra >= 1u) { o.len1 = extra; o.ysp = y; o.m3 = mm; }
+  } else if (tabs.misc & NM_MISC_HANGUL) {
+    uint32_t hrole, hcp;
+    if (fl != NF_BAD && nm_hangul_role(b, bm1, r[-2], bp1, r[2], &hrole, &hcp)) o.len1 = nm_hangul_out(hcp, hrole, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
+  }
+  return o;
+}
+
 // stage the piece (+ margins) and classify every byte; continuation bytes inherit the class of their lead byte.
 // returns the piece length; LDS index of document byte (pb + i) is PMARGIN + i.
 template <typename LDS>
@@ -97,7 +124,7 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
         if (b < 0x80u) fl = s_cls[b];                       // class of an ASCII byte: one LDS read instead of five range checks
         else if (x >= 3 && x < PLDS - 3) {
           // a two-byte character, a three- or four-byte one the pass leaves alone, or NF_BAD
-          fl = nm_classify_high(b, L.raw[x - 1], L.raw[x - 2], L.raw[x - 3], L.raw[x + 1], L.raw[x + 2], L.raw[x + 3], tabs);
+          fl = classify_high_byte(L.raw + x, tabs);
         }
         f4 |= fl << (8 * q);
       }
@@ -452,27 +479,17 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
       uint32_t o3 = b | ((code & 4u) << 3);
       o3 = sel_mask(spC, chC, o3);
       o3 = sel_mask(spW, chW, o3);
-      // the bytes of a two-byte character (U+0080..U+017F) come from the table: the lead lane its first byte - or the ASCII letter the
-      // character decomposes into -, the second lane its second byte - or the two bytes of the combining mark.  Chunks without any are the rule.
       uint32_t ysp = chSP, m3 = code >> 8;
-      if (__ballot(nm_two_lead(b) || (lane == 0 && nm_cont_byte(b))) != 0ull) {       // (lane 0 may hold the second byte of a character that began in the chunk before)
-        const uint32_t bm1 = L.raw[PMARGIN + 64 * c + lane - 1], bp1 = L.raw[PMARGIN + 64 * c + lane + 1];
-        const bool lead2 = nm_two_lead(b), cont2 = nm_cont_byte(b) && nm_two_lead(bm1);
-        if (lead2 || cont2) {
-          const NmTwo e = nm_two_get(tabs, lead2 ? nm_two_index(b, bp1) : nm_two_index(bm1, b));
-          uint32_t y = 0, mm = 0;
-          const uint32_t extra = nm_two_out(e, cont2, (code & 4u) != 0, true, &o3, &y, &mm);
-          if (extra >= 1u) { len1 = extra; ysp = y; m3 = mm; }
-        }
-      }
-      // Hangul syllables under NFD: every lane of a syllable emits the three bytes of one of its jamo, or - the third lane of a syllable
-      // without a final consonant - nothing at all: E, the lanes that emit at least one byte, is V everywhere else
+      // Everything a character beyond ASCII needs sits behind ONE test of the chunk and out of line (emit_high_byte): chunks of plain ASCII are
+      // the rule.  E = the lanes that emit at least one byte: V, but for the third lane of a Hangul syllable without a final consonant.
       unsigned long long E = V;
-      if ((tabs.misc & NM_MISC_HANGUL) && __ballot(nm_hangul_lead(b) || (lane < 2 && nm_cont_byte(b))) != 0ull) {
-        const uint8_t* r = L.raw + PMARGIN + 64 * c + lane;
-        uint32_t hrole, hcp, n = 1u;
-        if (fl != NF_BAD && nm_hangul_role(b, r[-1], r[-2], r[1], r[2], &hrole, &hcp)) { n = nm_hangul_out(hcp, hrole, &m3, &ysp, &o3); len1 = n ? 2u : 0u; }
-        E = V & ~__ballot(n == 0u);
+      if (__ballot(b >= 0x80u) != 0ull) {
+        if (b >= 0x80u) {
+          const HighOut h = emit_high_byte(L.raw + PMARGIN + 64 * c + lane, fl, code, HighOut{o3, ysp, m3, len1}, tabs);
+          o3 = h.o3; ysp = h.ysp; m3 = h.m3; len1 = h.len1;
+        }
+        E = V & ~__ballot(len1 == 0xFFu);
+        len1 = len1 == 0xFFu ? 0u : len1;
       }
       const unsigned long long ge2 = __ballot(len1 >= 1u) & V, ge3 = __ballot(len1 >= 2u) & V, ge4 = __ballot(len1 >= 3u) & V;
       const uint32_t total = (uint32_t)(__builtin_popcountll(E) + __builtin_popcountll(ge2) + __builtin_popcountll(ge3) + __builtin_popcountll(ge4));

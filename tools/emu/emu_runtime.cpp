@@ -360,6 +360,7 @@ hipError_t hipHostFree(void* p) {
 }
 hipError_t hipHostRegister(void* p, size_t n, unsigned) { std::lock_guard<std::mutex> lk(g_mem_mutex); g_pinned[(uintptr_t)p] = n; return hipSuccess; }
 hipError_t hipHostUnregister(void* p) { std::lock_guard<std::mutex> lk(g_mem_mutex); return g_pinned.erase((uintptr_t)p) ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
   std::lock_guard<std::mutex> lk(g_mem_mutex);
   auto it = g_pinned.upper_bound((uintptr_t)p);

@@ -28,6 +28,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 #define __shared__ static
 #define __launch_bounds__(...)
 #define HIP_SYMBOL(x) (&(x))
@@ -187,6 +188,7 @@ template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsig
 hipError_t hipHostFree(void* p);
 hipError_t hipHostRegister(void* p, size_t n, unsigned flags);
 hipError_t hipHostUnregister(void* p);
+hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned flags);
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p);
 hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t st = nullptr);
