@@ -823,3 +823,54 @@ def test_emoji_and_korean_text_stay_on_the_device():
             assert N.lib.tm_decode_host_docs() <= max(1, nchk // 20), "%d of %d documents were decoded on the host" % (N.lib.tm_decode_host_docs(), nchk)
             for k in range(nchk):
                 assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == unicodedata.normalize("NFD", docs[k].decode()).encode(), docs[k]
+
+
+def test_one_child_chains_in_the_trie():
+    """round 5: a node below which the trie is a chain of one-child nodes down to the next key is walked in ONE round - the chain's string
+    (a record of three table entries, tm_tables.h "tails") against the text - instead of a byte per round, in the plain walk (step A1) and
+    in the forward-delete walk (step A3).  Vocabularies made of long tokens: chains of every length around the minimum (5) and the record size
+    (32), keys in the middle of a chain, chains that branch late, chains entered through a suffix link; texts that match them fully, break
+    off at every byte, and end inside them.  ids == the oracle's for every document."""
+    rng = np.random.default_rng(55)
+    words = [b"alpha", b"beta", b"gamma", b"delta", b"epsilon", b"zeta", b"eta", b"theta", b"iota", b"kappa", b"lambda", b"mu"]
+    longs = []
+    for _ in range(60):
+        n = int(rng.integers(2, 8))
+        t = b"".join(b" " + words[int(rng.integers(0, len(words)))] for _ in range(n))[:40]
+        longs.append(t)
+        if rng.random() < 0.5:
+            longs.append(t[: int(rng.integers(3, len(t) + 1))])            # a key in the middle of the chain
+        if rng.random() < 0.3 and len(t) > 12:
+            longs.append(t[: len(t) - 3] + b"xyz"[: 40 - (len(t) - 3)])      # a chain that branches three bytes before its end
+        if rng.random() < 0.4:
+            longs.append(t[1:])                                              # the same without its first byte: suffix links lead into the chain
+    for cut in range(4, 41):                                                 # one chain of every length
+        longs.append((b" q" + b"abcdefghijklmnopqrstuvwxyz0123456789-+*/")[:cut])
+    singles = [bytes([c]) for c in b" abcdefghijklmnopqrstuvwxyz0123456789-+*/."]
+    for capcode in (0, 2):
+        toks = sorted(set(longs + singles + [b" " + x for x in words] + words + ([b"D"] if capcode == 2 else [])))
+        img = synth.build_vocab(toks, capcode=capcode, charset=1)
+        v, orc = tm.Vocab(img), Oracle(img)
+        docs = []
+        for _ in range(400):
+            parts = []
+            for _ in range(int(rng.integers(1, 30))):
+                t = longs[int(rng.integers(0, len(longs)))]
+                r = rng.random()
+                if r < 0.5:
+                    parts.append(t)
+                elif r < 0.8:
+                    parts.append(t[: int(rng.integers(1, len(t) + 1))])    # breaks off somewhere inside
+                else:
+                    k = int(rng.integers(0, len(t)))
+                    parts.append(t[:k] + b"." + t[k + 1:])                   # one byte wrong
+                if rng.random() < 0.2:
+                    parts.append(words[int(rng.integers(0, len(words)))])    # a word without its space: forward-delete probes
+            docs.append(b"".join(parts))
+        docs += [longs[0][:k] for k in range(1, len(longs[0]) + 1)]          # the text ends inside a chain, at every byte
+        text, offs = tm.pack_documents(docs)
+        ids, toff, missing = v.tokenize_packed(text, offs)
+        for d in range(len(docs)):
+            exp, miss = orc.tokenize(docs[d])
+            got = ids[int(toff[d]):int(toff[d + 1])]
+            assert got.size == exp.size and (got == exp).all() and miss == int(missing[d]), (capcode, d, docs[d][:80])

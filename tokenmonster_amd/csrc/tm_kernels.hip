@@ -164,7 +164,7 @@ __device__ __forceinline__ bool child_possible32(uint32_t m, uint32_t c) { retur
 // one in-flight trie walk of a lane: text byte number d of the string being matched is text[tbase + d].
 // An idle slot has key == KEY_IDLE (no entry's check word) and gathers the always-empty entry behind the double array,
 // so it needs no flag of its own: it never hits, and its bestlen of 0 keeps it from storing anything.
-struct Walk { int pos, tbase, depth, limit, bestlen; uint32_t hoff, key, bestv; };
+struct Walk { int pos, tbase, depth, limit, bestlen; uint32_t hoff, key, bestv, tw; };      // tw: the chain word of the node the walk stands on, if it has to take a chain next (tm_tables.h), else 0
 constexpr uint32_t KEY_IDLE = 0xFFFFFFFDu;
 __device__ __forceinline__ bool walk_idle(const Walk& k) { return k.key == KEY_IDLE; }
 
@@ -180,8 +180,10 @@ __device__ __forceinline__ bool walk_consume(const Tables& T, Walk& k, const uin
   k.bestv = acc ? e.y : k.bestv;
   k.bestlen = acc ? k.depth : k.bestlen;
   const bool cont = hit && k.depth < k.limit && child_possible32(e.z, c);
-  k.key = cont ? nid : KEY_IDLE;
-  k.hoff = cont ? (e.w + c) << 4 : T.idle_off;
+  const bool chain = cont && is_tail_word(e.w);            // the node begins a one-child chain: the next round compares the whole chain (walk_chain)
+  k.tw = chain ? e.w : 0u;
+  k.key = (cont && !chain) ? nid : KEY_IDLE;
+  k.hoff = (cont && !chain) ? (e.w + c) << 4 : T.idle_off;
   return !cont;
 }
 
@@ -199,6 +201,31 @@ __device__ __forceinline__ int branch_score(int fpart, uint32_t fb, uint32_t dS,
 __device__ __forceinline__ int alt_penalty(int flen, uint32_t dS, int len) {
   const int BL = flen + (int)desc_len(dS);
   return (BL < len ? 100 : 0) + (BL == len ? 10000 : 0);
+}
+
+// A walk that stands on a node with a chain word and may go on (tm_tables.h, "tails"): compares the next tail_len bytes of text (LDS byte
+// address ta) with the chain's string in one go.  Rare - a wavefront meets a handful of them - so all of it sits behind a wave-uniform test at
+// the call sites, and the lanes that are not `on` gather the always-empty entry.  Returns whether the lane's walk now stands on the chain's end
+// node, with *h = the record's header (link format: node | len << 20, value of the end node or 0, its child filter, its base word).
+__device__ __forceinline__ bool tail_compare(const char* __restrict__ tabb, uint32_t idle_off, bool on, uint32_t word, uint32_t ta, int room, uint4* h) {
+  typedef TM_LDS_SPACE_UNALIGNED uint32_t lds_u32u;
+  const char* rp = tabb + (on ? (size_t)tail_record(word) << 4 : (size_t)idle_off);
+  *h = *reinterpret_cast<const uint4*>(rp);
+  const uint4 s0 = *reinterpret_cast<const uint4*>(rp + 16);
+  const int len = (int)tail_len(h->x);
+  // bytes [0, len) of the string against the text; a dword's bytes at and behind len do not count
+  auto differ = [&](uint32_t sw, int k) -> uint32_t {
+    const uint32_t tw = *TM_LDS_PTR(lds_u32u, ta + 4u * (uint32_t)k);
+    const int nb = len - 4 * k;
+    const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+    return (tw ^ sw) & mask;
+  };
+  uint32_t bad = differ(s0.x, 0) | differ(s0.y, 1) | differ(s0.z, 2) | differ(s0.w, 3);
+  if (__any(on && len > 16)) {
+    const uint4 s1 = *reinterpret_cast<const uint4*>(rp + 32);
+    bad |= differ(s1.x, 4) | differ(s1.y, 5) | differ(s1.z, 6) | differ(s1.w, 7);
+  }
+  return on && bad == 0u && len <= room;
 }
 
 struct WaveLds {
@@ -315,7 +342,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   const uint64_t g = (uint64_t)blockIdx.x * WAVES + wvi;
   if (g >= nseg) return;
   WaveLds& w = s_wave[wvi];
-  const int Lmax = (int)T.max_len;
+  const int Lmax = TM_DBG_ON(dbg & 0x180000) ? min((dbg & 0x80000) ? 12 : 20, (int)T.max_len) : (int)T.max_len;      // (devel bits 19 / 20: no walk deeper than 12 / 20 bytes - what the deep tail of step A1 costs)
   const unsigned long long lane_below = (1ull << lane) - 1ull;
   const uint32_t idle_off = T.idle_off;                   // the always-empty entry behind the double array
   const uint32_t doc = seg_doc[g];
@@ -390,6 +417,35 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   static_assert(KEY_IDLE != KEY_SET && KEY_IDLE != kNone && KEY_SET != kNone && (KEY_IDLE >> 26) == 63u && (KEY_SET >> 26) == 63u, "walk states");
   typedef unsigned long long M64;
   const char* __restrict__ tabb = reinterpret_cast<const char*>(T.tab);
+  // the walks of a wavefront that go one lane each - the forward-delete probes of step A3, the chain walks behind step A1 - until the last of
+  // them has ended: probe rounds (a double-array entry per lane and round) and, rarely, a round for the walks that stand at the head of a
+  // one-child chain (tm_tables.h)
+  auto run_walks = [&](Walk& k) {
+    while (__any(!walk_idle(k) || k.tw != 0u)) {
+      if (__any(k.tw != 0u)) {
+        // a round for the walks that stand at the head of a one-child chain (the others wait it out: rare)
+        const bool on = k.tw != 0u;
+        uint4 h;
+        const bool ok = tail_compare(tabb, idle_off, on, k.tw, TM_LDS_ADDR(w.text) + (uint32_t)(k.tbase + k.depth), k.limit - k.depth, &h);
+        if (on) {
+          k.tw = 0u;
+          if (ok) {
+            k.depth += (int)tail_len(h.x);
+            if (h.y != 0u) { k.bestv = h.y; k.bestlen = k.depth; }
+            const uint32_t c2 = w.text[k.tbase + k.depth];
+            if (k.depth < k.limit && child_possible32(h.z, c2)) {
+              if (is_tail_word(h.w)) k.tw = h.w; else { k.key = h.x & kLinkNodeMask; k.hoff = (h.w + c2) << 4; }
+            }
+          }
+        }
+        continue;
+      }
+      const uint4 e = *reinterpret_cast<const uint4*>(tabb + k.hoff);
+      const uint32_t c = w.text[k.tbase + k.depth + 1];
+      walk_consume(T, k, e, c);
+      PH_INC(11)
+    }
+  };
   {
     // ---- A1: longest match at every position -> D[p] = len | nWords | flag5 (next-byte class added in A2), X[p] = node value
     // A run is in one of two states.  SET: the gather is a link-format entry (a suffix link, or the direct map on the
@@ -434,6 +490,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     uint32_t v_link = T.link_off, v_direct = T.direct_off, v_idle = idle_off;
     TM_KEEP_IN_VGPRS2(v_link, v_direct);
     TM_KEEP_IN_VGPRS2(v_idle, v_link);            // operands of the selects: registers for the whole loop, not moves per round
+    // tasks of the chain walks (below): pairs of words in the part of Xb nothing else touches before step A3 (the dump words of lanes
+    // without positions lie in Xb[88..151])
+    constexpr int TAIL_TASK0 = 152, TAIL_TASKS = (SEG - TAIL_TASK0) / 2;
+    static_assert(offsetof(WaveLds, Db) + 4 * 63 + 6 * 256 + 4 <= offsetof(WaveLds, Xb) + 4 * TAIL_TASK0, "the task list lies behind the dump words");
+    int ntask_tail = 0;
     auto rounds = [&](auto tail_tag) {
       constexpr bool TAIL = decltype(tail_tag)::value;
       // (The loop exists twice: when the document goes on for at least Lmax bytes behind the last position of the segment, no walk is
@@ -462,6 +523,47 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         // probe only for a byte the node can continue with: bit (c & 31) of its child filter (0 behind a link that cannot go on)
         M64 go = adv & __builtin_amdgcn_ballot_w64(bit_of(e.z, c) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
         if (nowalk) go = 0ull;
+        // one-child chains (tm_tables.h): a walk about to go on from a node with a chain word ENDS here as far as this loop is concerned - the
+        // position keeps the best match up to that node, the next position starts from the node's suffix link (valid, if shallower than the
+        // link of the node the chain would have led to) - and leaves a task: {chain word, position | depth << 16}.  The tasks of a wavefront
+        // are walked together behind the loop, one lane each (chain compare, then on as far as the trie goes).  Taking the chains inside the
+        // round instead was timed: +11 % (a wavefront then runs the compare in every round in which ANY lane meets a chain).
+        uint32_t ew = e.w, cnode = nid;
+        M64 tl = go & __builtin_amdgcn_ballot_w64(is_tail_word(e.w));
+        if (tl != 0ull) {
+          const int nt = __builtin_popcountll(tl);
+          if (ntask_tail + nt <= TAIL_TASKS) {
+            if ((tl >> lane) & 1ull) {
+              const uint32_t slot = mbcnt64(tl, (uint32_t)ntask_tail);
+              w.Xb[TAIL_TASK0 + 2 * slot] = e.w;
+              w.Xb[TAIL_TASK0 + 2 * slot + 1] = (posa - tb) | ((uint32_t)depth << 16);
+            }
+            ntask_tail += nt;
+            go &= ~tl;
+          } else {
+            // (no room in the list - more than TAIL_TASKS chains under one wavefront: these are taken on the spot)
+            while (tl != 0ull) {
+              const bool on = (tl >> lane) & 1ull;
+              uint4 h;
+              const bool ok = tail_compare(tabb, idle_off, on, ew, pfa, (TAIL ? limit : Lmax) - depth, &h);
+              const M64 okm = __builtin_amdgcn_ballot_w64(ok);
+              const uint32_t len = tail_len(h.x);
+              depth = (int)sel_mask(okm, (uint32_t)depth + len, (uint32_t)depth);
+              pfa = sel_mask(okm, pfa + len, pfa);
+              cnode = sel_mask(okm, h.x & kLinkNodeMask, cnode);
+              node = sel_mask(okm, h.x & kLinkNodeMask, node);
+              const M64 accm = okm & __builtin_amdgcn_ballot_w64(h.y != 0u);
+              bestv = sel_mask(accm, h.y, bestv);
+              bestlen = (int)sel_mask(accm, (uint32_t)depth, (uint32_t)bestlen);
+              ew = sel_mask(okm, h.w, ew);
+              const uint32_t c2 = *TM_LDS_PTR(lds_u8, pfa);                  // the byte behind the chain (pfa has moved for the lanes that took it)
+              c = sel_mask(okm, c2, c);
+              const M64 go2 = okm & __builtin_amdgcn_ballot_w64(bit_of(h.z, c2) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
+              go = (go & ~tl) | go2;
+              tl = go2 & __builtin_amdgcn_ballot_w64(is_tail_word(ew));       // (a chain longer than a record goes on in the next one)
+            }
+          }
+        }
         const M64 fin = busy & ~go;
         // the best match so far at the lane's position, every round (the last store of a position is its result; a lane that has run out
         // of positions stays on its last one and stores the same values again): no select of a store address, and ONE store for both
@@ -476,8 +578,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         const uint32_t off_f = sel_mask(more, sel_mask(deep, v_link, v_direct) + (sel_mask(deep, node, nn) << 4), v_idle);
         // a walk that goes on probes entry base + byte for the byte behind the one just read (also behind a link: it stands for the bytes
         // up to there); the first byte a new position reads: posn + depth - 1 behind a suffix link, posn + 2 behind the direct map
-        key = sel_mask(go, nid, key);
-        off = sel_mask(go, (e.w + c) << 4, off_f);                              // (an idle lane has no more positions: off_f is the idle entry)
+        key = sel_mask(go, cnode, key);
+        off = sel_mask(go, (ew + c) << 4, off_f);                               // (an idle lane has no more positions: off_f is the idle entry)
         pfa = sel_mask(go, pfa + 1u, posa + (uint32_t)max(depth, 3));
         if (TAIL) limit = (int)sel_mask(fin, (uint32_t)min((int)(dla - posa) - 1, Lmax), (uint32_t)limit);
         setm = fin & more;
@@ -486,6 +588,22 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       }
     };
     if (dl >= NPOS + Lmax) rounds(std::false_type{}); else rounds(std::true_type{});
+    // ---- the chains the walks above stopped at: one lane per task - the chain's string against the text in one round, then on as far as the
+    // trie goes (most chains end in a leaf) -, and the position's match replaced if this one is longer
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int tbase0 = 0; tbase0 < ntask_tail; tbase0 += 64) {
+      Walk k = Walk{0, 0, 0, 0, 0, idle_off, KEY_IDLE, 0u, 0u};
+      const bool mine = tbase0 + lane < ntask_tail;
+      if (mine) {
+        const uint32_t tw0 = w.Xb[TAIL_TASK0 + 2 * (tbase0 + lane)], pd = w.Xb[TAIL_TASK0 + 2 * (tbase0 + lane) + 1];
+        k.pos = (int)(pd & 0xFFFFu); k.tbase = k.pos; k.depth = (int)(pd >> 16); k.limit = min(dl - k.pos, Lmax);
+        k.bestlen = (int)w.D[k.pos]; k.bestv = w.X[k.pos]; k.tw = tw0;
+      }
+      run_walks(k);
+      if (mine && k.bestlen > (int)w.D[k.pos]) { w.X[k.pos] = k.bestv; w.D[k.pos] = (uint32_t)k.bestlen; }
+    }
+    __builtin_amdgcn_wave_barrier();
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
     if (lane == 0 && tail_here && ntask > 0) {
       const uint32_t r = T.root[w.text[dl - 1]];
@@ -495,15 +613,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-  // the row gathers of step B need only what step A1 has left (X[p]): issued here, they are under way while step A3 walks (-2 % on the
-  // 100 256-id shape, whose rows miss the L2 more often; nothing on the others: 32 wavefronts per CU hide a latency like this one anyway)
-  Row row0[SEG / 64];
-#pragma unroll
-  for (int it = 0; it < SEG / 64; it++) {
-    const int p = it * 64 + lane;
-    row0[it] = Row{0u, 0u, 0u, 0u};
-    if (p < seglen && w.D[p] != 0) row0[it] = T.rows[TM_DBG_ON(dbg & 0x10000) ? (node_id(w.X[p]) & 63u) : node_id(w.X[p])];      // (devel bit 16: every row gather hits the same 1 KiB)
-  }
   // ---- A2: class of the byte after each match; which positions need the forward-delete probe (go :1088) ----------
   // second token begins with a letter, has no word boundary and the byte after it is letter-class
   unsigned long long elig[NPOS_PAD / 64];
@@ -544,7 +653,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0);
-      Walk k = Walk{0, 0, 0, 0, 0, idle_off, KEY_IDLE, 0u};
+      Walk k = Walk{0, 0, 0, 0, 0, idle_off, KEY_IDLE, 0u, 0u};
       int mainlen = 0;
       if (base + lane < n_el) {
         const int p = (int)w.xch[lane];
@@ -558,20 +667,15 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         if (e.x != kNone && ((e.x >> 21) & 1u) && depth < limit && child_possible32(e.z, c0)) {
           k.pos = p; k.tbase = p - off; k.bestlen = bl; k.bestv = e.y; k.depth = depth; k.limit = limit;
           mainlen = (int)ml;
-          k.key = e.x & kNodeMask;
-          k.hoff = (e.w + c0) << 4;
+          if (is_tail_word(e.w)) k.tw = e.w;                         // (the node of ' '+match begins a one-child chain)
+          else { k.key = e.x & kNodeMask; k.hoff = (e.w + c0) << 4; }
         } else if (e.x != kNone && bl > (int)ml + 1) {               // (only possible with the two-byte UTF-16 prefix)
           const int lb = bl - off;
           w.Db[p] = make_sdesc((uint32_t)lb, e.y, s_bb[w.text[p + lb]], true, T.spl_hint);
           if (p < SEG) w.Xb[p] = e.y;
         }
       }
-      while (__any(!walk_idle(k))) {
-        const uint4 e = *reinterpret_cast<const uint4*>(tabb + k.hoff);
-        const uint32_t c = w.text[k.tbase + k.depth + 1];
-        walk_consume(T, k, e, c);
-        PH_INC(11)
-      }
+      run_walks(k);
       // a lane walks ONE task per batch: what it found is stored once, after the loop (not in the round in which its walk happens to end)
       if (k.bestlen > mainlen + 1) {
         const int lb = k.bestlen - off;                              // go :1093
@@ -584,7 +688,17 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   }
   PH(5)
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
+  // the row gathers of step B need only what step A1 has left (X[p]; step A2 has folded the flags into D[p], which stays non-zero where it
+  // was): issued here, they are under way while the wavefront waits for its neighbours at the barrier.  (Round 4 issued them before step A3 - 16
+  // registers held across it, -2 % on the 100 256-id shape only; with the chain rounds of round 5 in A3 that spilled a row to scratch.)
+  Row row0[SEG / 64];
+#pragma unroll
+  for (int it = 0; it < SEG / 64; it++) {
+    const int p = it * 64 + lane;
+    row0[it] = Row{0u, 0u, 0u, 0u};
+    if (p < seglen && w.D[p] != 0) row0[it] = T.rows[TM_DBG_ON(dbg & 0x10000) ? (node_id(w.X[p]) & 63u) : node_id(w.X[p])];      // (devel bit 16: every row gather hits the same 1 KiB)
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0) only: the LDS stores of this wavefront are done; its row gathers stay in flight
   __syncthreads();                                       // every wavefront of the workgroup has its descriptors
   PH(3)
   if (share && lane < NPOS - SEG) {

@@ -40,6 +40,25 @@ constexpr uint32_t kLinkNodeMask = (1u << 20) - 1;
 constexpr uint32_t kL2Size = 65536;
 constexpr uint32_t kDirectSlots = 2 * kL2Size;   // the direct map in uint2 units (16-byte entries)
 
+// ---- one-child chains ("tails") ----------------------------------------------------------------------------------------------------------
+// The deep end of the trie is made of chains: below a node of a multi-word token there is, for twenty or thirty bytes, exactly one child per
+// node and no key until the chain's end.  Walked a byte per gather such a chain sets the number of dependent rounds of a whole wavefront
+// (the deepest walk of a 256-byte segment: 21 rounds on the englishcode shapes; capping the walks at 12 bytes - wrong results - makes
+// k_match_branch 16 % faster, profiles/r05_k1_tails.txt).  So a node c below which the trie is a chain of kTailMin..kTailMax non-accepting
+// one-child nodes down to a node e (a key, or the 32nd node of a longer chain) says so in its BASE WORD - the w of every entry a walk can
+// stand on c through: its double-array entry, link-format entries that lead to it, space-prefix links, other chain records:
+//     kTailFlag | index of c's chain record in 16-byte entries of tab
+// (a walk never probes for c's only child, so the base is not needed; the shift of "(base + byte) << 4" drops the flag for code that does not
+// look).  The record is three entries: a header in link format - x = e | len << 20 (bytes from c down to e), y = value of e if it is a key,
+// else 0, z = child filter of e (0: the walk cannot go on), w = base word of e, possibly a chain word again - and 32 bytes of string.  A
+// walk that stands on c with `go` set compares the next len bytes of text with the string in ONE round: equal, and it stands on e; not
+// equal (or the text ends first), and it ends on c - whose suffix link is a valid, if shallower, start for the next position, and nothing
+// between c and e is a key.
+constexpr uint32_t kTailFlag = 0x80000000u, kTailMin = 5u, kTailMax = 32u;
+__host__ __device__ inline bool is_tail_word(uint32_t w) { return (int32_t)w < 0; }
+__host__ __device__ inline uint32_t tail_record(uint32_t w) { return w & 0x7FFFFFFFu; }
+__host__ __device__ inline uint32_t tail_len(uint32_t hx) { return (hx >> 20) & 63u; }
+
 __host__ __device__ inline uint32_t node_id(uint32_t v) { return v & kNodeMask; }
 // link-format word x: node | depth of the node << 20 | depth of the deepest accepting node on the way << 26
 __host__ __device__ inline uint32_t link_node(uint32_t x) { return x & kLinkNodeMask; }
@@ -83,7 +102,8 @@ struct Tables {
                            //                               the path to m << 26
                            //                           y = value of that accepting node (0: none)
                            //                           z = child filter of m if all of s[1:] is in the trie (the walk may probe on), else 0
-                           //                           w = base(m)
+                           //                           w = base(m), or m's chain word (kTailFlag, above)
+                           //   [behind the links]      chain records, three entries each
   const uint4* spl;        // [n_info] "space-prefix link" of record s: where the walk of ' '+s (the forward-delete probe of
                            //   go/tokenmonster.go:1088-1095; ' ' 0x00 + s for UTF-16) ends up, so that probe only has to CONTINUE:
                            //   x = node id reached | continue-flag << 21 | best accepting depth << 22 ; y = value of that node;
@@ -99,6 +119,7 @@ struct Tables {
   uint32_t has_delete, delete_id, unk_id;
   uint32_t spl_hint;       // b2 of letter-initial tokens is the forward-delete hint
   uint32_t link_off, direct_off;   // byte offsets of the suffix links / the direct map inside tab
+                                   // (the chain records lie behind the suffix links; their entries name them by index: nothing here has to know where)
 };
 
 }  // namespace tmh

@@ -297,6 +297,10 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
   // of tries goes behind everything placed so far, and the holes it skipped are filled by the one-child parents that make up most
   // of the deeper levels: the array ends up > 95 % full.
   std::vector<uint32_t> base_of(n_nodes, 0);
+  std::vector<uint8_t> chain;                   // one-child chains (tm_tables.h)
+  std::vector<uint32_t> tailw(n_nodes, 0);      // chain word of a node that has a record, else 0
+  uint32_t n_tail_records = 0;
+  auto base_word = [&](uint32_t n) -> uint32_t { return tailw[n] ? tailw[n] : base_of[n]; };      // what an entry says about where to go on from node n
   std::vector<uint4> da;
   {
     const std::vector<uint32_t>& kid_start = t.kid_start;
@@ -328,12 +332,31 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
       frontier = std::max(frontier, f + span + 1);
     }
     hv.n_da = frontier + 256;                                    // base + 255 stays inside for every base
+    // ---- one-child chains (tm_tables.h): chain[n] = bytes from n down to the first key below it if the trie is a chain of one-child
+    // nodes until there, else 0.  Every node whose chain is at least kTailMin long gets a record (its first kTailMax bytes at most: a longer
+    // chain goes on from the record's end node, which has a record of its own); the record's place in tab is known once the links' size is.
+    chain.assign(n_nodes, 0);
+    for (size_t q = by_depth.size(); q-- > 0;) {
+      const uint32_t n = by_depth[q];
+      if (kid_start[n + 1] - kid_start[n] != 1) continue;
+      const uint32_t k = kid[kid_start[n]] & 0xFFFFFFu;
+      if (k < n_info) chain[n] = 1; else if (chain[k] > 0) chain[n] = (uint8_t)(chain[k] + 1);
+    }
+    {
+      const size_t first_rec = ((size_t)hv.n_da + 1) + kL2Size + n_nodes;      // in 16-byte entries: double array | empty entry | direct map | links | records
+      uint32_t nrec = 0;
+      const bool off = getenv("TM_NO_TAILS") != nullptr;          // (development: the tables without chain records, for an A/B of the kernels)
+      const uint32_t tmin = getenv("TM_TAIL_MIN") ? (uint32_t)std::max(2, atoi(getenv("TM_TAIL_MIN"))) : kTailMin;      // (development: A/B of the shortest chain that gets a record)
+      for (uint32_t n = 0; n < n_nodes && !off; n++)
+        if (depth_of[n] >= 2 && chain[n] >= tmin) tailw[n] = kTailFlag | (uint32_t)(first_rec + 3 * (size_t)nrec++);
+      n_tail_records = nrec;
+    }
     da.assign((size_t)hv.n_da + 1, uint4{kNone, kNone, 0u, 0u});
     for (uint32_t n = 0; n < n_nodes; n++) {
       if (depth_of[n] < 2) continue;
       for (uint32_t q = kid_start[n]; q < kid_start[n + 1]; q++) {
         const uint32_t c = kid[q] & 0xFFFFFFu;
-        da[base_of[n] + (kid[q] >> 24)] = uint4{P(n), value_of(c), cmask[c], base_of[c]};
+        da[base_of[n] + (kid[q] >> 24)] = uint4{P(n), value_of(c), cmask[c], base_word(c)};
       }
     }
   }
@@ -344,7 +367,8 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
   const size_t link_base = direct_base + kDirectSlots;
   hv.direct_off = (uint32_t)(direct_base * sizeof(uint2));
   hv.link_off = (uint32_t)(link_base * sizeof(uint2));
-  hv.tab.assign(link_base + 2 * (size_t)n_nodes, uint2{kNone, kNone});
+  const size_t rec_base = link_base + 2 * (size_t)n_nodes;                  // (8-byte units) chain records; two spare entries behind them (nothing reads them: room for a reader that looks ahead)
+  hv.tab.assign(rec_base + 2 * (3 * (size_t)n_tail_records + 2), uint2{kNone, kNone});
   memcpy(hv.tab.data(), da.data(), da.size() * sizeof(uint4));
   std::vector<uint32_t> l2v(kL2Size, kNone), l2n(kL2Size, kNone);       // value / trie id of the depth-2 node b0b1
   for (uint32_t b0 = 0; b0 < 256; b0++) {
@@ -378,7 +402,22 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
       const uint32_t b = m == kRoot ? kNone : best[m];
       const size_t at = P(n);
       lt[2 * at] = uint2{((m == kRoot ? m : P(m)) & kLinkNodeMask) | (dm << 20) | ((b != kNone ? (uint32_t)depth_of[b] : 0u) << 26), b != kNone ? value_of(b) : 0u};
-      lt[2 * at + 1] = uint2{(lfull[n] && hc) ? cmask[m] : 0u, (lfull[n] && hc) ? base_of[m] : 0u};
+      lt[2 * at + 1] = uint2{(lfull[n] && hc) ? cmask[m] : 0u, (lfull[n] && hc) ? base_word(m) : 0u};
+    }
+  }
+  // chain records: header in link format + 32 bytes of string, for every node with a chain word
+  if (n_tail_records) {
+    uint4* tab16 = reinterpret_cast<uint4*>(hv.tab.data());
+    for (uint32_t n = 0; n < n_nodes; n++) {
+      if (!tailw[n]) continue;
+      uint4* r = tab16 + tail_record(tailw[n]);
+      uint8_t str[32] = {0};
+      const uint32_t len = std::min<uint32_t>(chain[n], kTailMax);
+      uint32_t e = n;
+      for (uint32_t k = 0; k < len; k++) { const uint32_t kq = t.kid[t.kid_start[e]]; str[k] = (uint8_t)(kq >> 24); e = kq & 0xFFFFFFu; }
+      const bool go_on = has_child[e] && depth_of[e] < hv.max_len;
+      r[0] = uint4{(P(e) & kLinkNodeMask) | (len << 20), e < n_info ? value_of(e) : 0u, go_on ? cmask[e] : 0u, go_on ? base_word(e) : 0u};
+      std::memcpy(&r[1], str, 32);
     }
   }
   st.mark("suffix links");
@@ -403,7 +442,7 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
     for (uint32_t i = 0; i < n_info; i++) {
       const uint32_t cont = spl_cont(i), bestn = sp_best[i];
       hv.spl[P(i)] = uint4{P(sp_node[i]) | (cont << 21) | ((bestn != kNone ? (uint32_t)depth_of[bestn] : 0u) << 22), bestn != kNone ? value_of(bestn) : 0u,
-                        cont ? cmask[sp_node[i]] : 0u, cont ? base_of[sp_node[i]] : 0u};
+                        cont ? cmask[sp_node[i]] : 0u, cont ? base_word(sp_node[i]) : 0u};
     }
   st.mark("reverse, values, space-prefix entries");
   // direct map: one 16-byte entry (same format as a suffix link) resolves the first two bytes of any walk, the
@@ -422,7 +461,7 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
       }
       uint2* e = hv.tab.data() + direct_base + 2 * (size_t)(b0 | (b1 << 8));      // indexed by the little-endian u16 at the position
       e[0] = uint2{id2 | ((cont ? 2u : 0u) << 20) | (bestlen << 26), bestv};
-      e[1] = uint2{cont ? cmask[n2] : 0u, cont ? base_of[n2] : 0u};
+      e[1] = uint2{cont ? cmask[n2] : 0u, cont ? base_word(n2) : 0u};
     }
   }
   st.mark("direct map");
@@ -715,6 +754,19 @@ static void count_node_use(const HostVocab& hv, const uint8_t* text, uint64_t n,
     while (depth < limit) {
       const uint32_t c = at(pos + depth);
       if (!((filt >> (c & 31u)) & 1u)) break;
+      if (is_tail_word(base)) {                                   // a one-child chain (tm_tables.h): the whole chain or nothing
+        const uint4* r = da + tail_record(base);
+        const int len = (int)tail_len(r[0].x);
+        const uint8_t* str = reinterpret_cast<const uint8_t*>(r + 1);
+        bool same = depth + len <= limit;
+        for (int k = 0; k < len && same; k++) same = at(pos + depth + k) == str[k];
+        if (!same) break;
+        depth += len; node = link_node(r[0].x);
+        if (r[0].y != 0) bestv = r[0].y;
+        filt = r[0].z; base = r[0].w;
+        if (filt == 0) break;
+        continue;
+      }
       const uint4 d = da[base + c];
       if (d.x != node) break;
       depth++; node = node_id(d.y);

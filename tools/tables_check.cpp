@@ -53,6 +53,7 @@ bool check_vocab(uint32_t kind, uint32_t vsize, uint32_t capcode, uint64_t seed,
     nkeys++;
     const uint32_t parent = e.x, child = node_id(e.y);
     if (parent >= hv.n_nodes || child >= hv.n_nodes) { fail("node out of range", parent, child); continue; }
+    if (is_tail_word(e.w)) continue;                            // (a chain word instead of a base: checked through the walk below)
     base_said[child] = e.w;
     if (e.z != 0 && e.w + 255 >= nb + 1) fail("base + 255 leaves the array", e.w);
   }
@@ -83,7 +84,7 @@ bool check_vocab(uint32_t kind, uint32_t vsize, uint32_t capcode, uint64_t seed,
     if (bestlen == 0 && y != 0) fail(what, 1, y);                                   // k_match_branch stores the descriptor unconditionally
     if (bestlen != 0 && (node_id(y) >= hv.n_info || bestlen > 40)) fail(what, 2, bestlen);
     // (links that lead to a node of depth < 2 belong to nodes of depth < 3 and are never read: the walk takes the direct map there)
-    if (filt != 0 && link_depth(x) >= 2 && ((filt & children[link_node(x)]) != children[link_node(x)] || e[1].y != base_said[link_node(x)] && base_said[link_node(x)] != kNone)) fail(what, 4, filt);
+    if (filt != 0 && link_depth(x) >= 2 && ((filt & children[link_node(x)]) != children[link_node(x)] || !is_tail_word(e[1].y) && e[1].y != base_said[link_node(x)] && base_said[link_node(x)] != kNone)) fail(what, 4, filt);
   };
   for (uint32_t i = 0; i < kL2Size; i++) check_link_format(direct + 2 * (size_t)i, "direct map entry");
   for (uint32_t n = 0; n < hv.n_nodes; n++) check_link_format(link + 2 * (size_t)n, "suffix link entry");
@@ -99,7 +100,7 @@ bool check_vocab(uint32_t kind, uint32_t vsize, uint32_t capcode, uint64_t seed,
   uint8_t* text = nullptr; std::vector<uint64_t> off(nd + 1);
   if (tm_normalize_batch(raw.data(), roff.data(), nd, capcode, 1, 0, &text, off.data()) != 0) { fail("tm_normalize_batch"); tm_free(img); return false; }
   const int Lmax = (int)hv.max_len;
-  uint64_t npos = 0, gathers = 0;
+  uint64_t npos = 0, gathers = 0, ntail = 0;
   for (uint32_t d = 0; d < nd; d++) {
     const uint8_t* t = text + off[d];
     const int dl = (int)(off[d + 1] - off[d]);
@@ -118,6 +119,22 @@ bool check_vocab(uint32_t kind, uint32_t vsize, uint32_t capcode, uint64_t seed,
       while (go) {
         const uint32_t c = at(pos + depth);
         gathers++;
+        if (is_tail_word(base)) {                                  // a one-child chain: the record's string against the text, all of it or nothing (tm_tables.h)
+          const uint4* r = da + tail_record(base);
+          const int len = (int)tail_len(r[0].x);
+          if (tail_record(base) + 3 > hv.tab.size() / 2 || len < (int)kTailMin || len > (int)kTailMax) { fail("chain record", base, (uint64_t)len); break; }
+          const uint8_t* str = reinterpret_cast<const uint8_t*>(r + 1);
+          bool same = depth + len <= limit;
+          for (int k = 0; k < len && same; k++) same = at(pos + depth + k) == str[k];
+          ntail++;
+          if (!same) break;                                        // the walk ends on the chain's head: nothing between it and the end node is a key
+          depth += len;
+          node = link_node(r[0].x);
+          if (r[0].y != 0) { bestv = r[0].y; bestlen = depth; if (node_id(r[0].y) != node) fail("chain record: value of another node", node); }
+          base = r[0].w;
+          go = depth < limit && ((r[0].z >> (at(pos + depth) & 31u)) & 1u);
+          continue;
+        }
         if (base + c > nb) { fail("probe outside the array", base, c); break; }
         const uint4 h = da[base + c];
         if (h.x != node) break;
@@ -137,8 +154,8 @@ bool check_vocab(uint32_t kind, uint32_t vsize, uint32_t capcode, uint64_t seed,
       npos++;
     }
   }
-  printf("kind %u, %u ids, capcode %u: %u records, %u nodes, %llu edges in %u entries; %llu positions walked, %.2f gathers each: %s\n", kind, vsize, capcode,
-         hv.n_info, hv.n_nodes, (unsigned long long)nkeys, nb, (unsigned long long)npos, (double)gathers / (double)std::max<uint64_t>(npos, 1), g_bad == bad0 ? "ok" : "FAILED");
+  printf("kind %u, %u ids, capcode %u: %u records, %u nodes, %llu edges in %u entries; %llu positions walked, %.2f gathers each, %llu chain compares: %s\n", kind, vsize, capcode,
+         hv.n_info, hv.n_nodes, (unsigned long long)nkeys, nb, (unsigned long long)npos, (double)gathers / (double)std::max<uint64_t>(npos, 1), (unsigned long long)ntail, g_bad == bad0 ? "ok" : "FAILED");
   tm_free(text); tm_free(img);
   return g_bad == bad0;
 }
