@@ -492,8 +492,16 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     TM_KEEP_IN_VGPRS2(v_idle, v_link);            // operands of the selects: registers for the whole loop, not moves per round
     // tasks of the chain walks (below): pairs of words in the part of Xb nothing else touches before step A3 (the dump words of lanes
     // without positions lie in Xb[88..151])
-    constexpr int TAIL_TASK0 = 152, TAIL_TASKS = (SEG - TAIL_TASK0) / 2;
-    static_assert(offsetof(WaveLds, Db) + 4 * 63 + 6 * 256 + 4 <= offsetof(WaveLds, Xb) + 4 * TAIL_TASK0, "the task list lies behind the dump words");
+    // (three words a task - base or chain word, node, position | depth << 16 - in the part of Db that nothing touches before step A3: the dump
+    // words of lanes without positions lie in Db[0..63]; the words used are zeroed again behind the walks, as step A3 expects all of Db)
+    constexpr int TAIL_TASK0 = 64, TAIL_TASKS = (NPOS - TAIL_TASK0) / 3;
+    // A walk that is DEFER bytes deep and wants to go on is handed to the task list as well: the deep end of a walk is what a lane's whole run
+    // of positions waits for, and behind the loop the deep walks of a wavefront run side by side.  Measured (profiles/r05_k1_tails.txt, K1 per
+    // 256 MiB, 32 000 / 100 256 ids): chains only 4.92 / 6.21 ms, DEFER 16: 4.90, 12: 4.85 / 6.14, 10: 4.87 / 6.18, 8: 5.14 / 6.71, 6: 5.31.
+#ifndef TM_K1_DEFER_DEPTH
+#define TM_K1_DEFER_DEPTH 12
+#endif
+    constexpr int DEFER = TM_K1_DEFER_DEPTH;
     int ntask_tail = 0;
     auto rounds = [&](auto tail_tag) {
       constexpr bool TAIL = decltype(tail_tag)::value;
@@ -525,22 +533,24 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         if (nowalk) go = 0ull;
         // one-child chains (tm_tables.h): a walk about to go on from a node with a chain word ENDS here as far as this loop is concerned - the
         // position keeps the best match up to that node, the next position starts from the node's suffix link (valid, if shallower than the
-        // link of the node the chain would have led to) - and leaves a task: {chain word, position | depth << 16}.  The tasks of a wavefront
+        // link of the node the chain would have led to) - and leaves a task: {chain word, node, position | depth << 16}.  The tasks of a wavefront
         // are walked together behind the loop, one lane each (chain compare, then on as far as the trie goes).  Taking the chains inside the
         // round instead was timed: +11 % (a wavefront then runs the compare in every round in which ANY lane meets a chain).
         uint32_t ew = e.w, cnode = nid;
         M64 tl = go & __builtin_amdgcn_ballot_w64(is_tail_word(e.w));
-        if (tl != 0ull) {
-          const int nt = __builtin_popcountll(tl);
+        const M64 dm = DEFER > 0 ? (tl | (go & __builtin_amdgcn_ballot_w64(depth >= DEFER))) : tl;      // walks that leave this loop for the task list
+        if (dm != 0ull) {
+          const int nt = __builtin_popcountll(dm);
           if (ntask_tail + nt <= TAIL_TASKS) {
-            if ((tl >> lane) & 1ull) {
-              const uint32_t slot = mbcnt64(tl, (uint32_t)ntask_tail);
-              w.Xb[TAIL_TASK0 + 2 * slot] = e.w;
-              w.Xb[TAIL_TASK0 + 2 * slot + 1] = (posa - tb) | ((uint32_t)depth << 16);
+            if ((dm >> lane) & 1ull) {
+              const uint32_t slot = mbcnt64(dm, (uint32_t)ntask_tail);
+              w.Db[TAIL_TASK0 + 3 * slot] = e.w;
+              w.Db[TAIL_TASK0 + 3 * slot + 1] = nid;
+              w.Db[TAIL_TASK0 + 3 * slot + 2] = (posa - tb) | ((uint32_t)depth << 16);
             }
             ntask_tail += nt;
-            go &= ~tl;
-          } else {
+            go &= ~dm;
+          } else if (tl != 0ull) {
             // (no room in the list - more than TAIL_TASKS chains under one wavefront: these are taken on the spot)
             while (tl != 0ull) {
               const bool on = (tl >> lane) & 1ull;
@@ -596,13 +606,18 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       Walk k = Walk{0, 0, 0, 0, 0, idle_off, KEY_IDLE, 0u, 0u};
       const bool mine = tbase0 + lane < ntask_tail;
       if (mine) {
-        const uint32_t tw0 = w.Xb[TAIL_TASK0 + 2 * (tbase0 + lane)], pd = w.Xb[TAIL_TASK0 + 2 * (tbase0 + lane) + 1];
+        const uint32_t bw0 = w.Db[TAIL_TASK0 + 3 * (tbase0 + lane)], nd0 = w.Db[TAIL_TASK0 + 3 * (tbase0 + lane) + 1], pd = w.Db[TAIL_TASK0 + 3 * (tbase0 + lane) + 2];
         k.pos = (int)(pd & 0xFFFFu); k.tbase = k.pos; k.depth = (int)(pd >> 16); k.limit = min(dl - k.pos, Lmax);
-        k.bestlen = (int)w.D[k.pos]; k.bestv = w.X[k.pos]; k.tw = tw0;
+        k.bestlen = (int)w.D[k.pos]; k.bestv = w.X[k.pos];
+        if (is_tail_word(bw0)) k.tw = bw0;
+        else { k.key = nd0; k.hoff = (bw0 + (uint32_t)w.text[k.pos + k.depth]) << 4; }      // (a walk handed over for its depth: it goes on probing)
       }
       run_walks(k);
       if (mine && k.bestlen > (int)w.D[k.pos]) { w.X[k.pos] = k.bestv; w.D[k.pos] = (uint32_t)k.bestlen; }
     }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int j = lane; j < 3 * ntask_tail; j += 64) w.Db[TAIL_TASK0 + j] = 0u;
     __builtin_amdgcn_wave_barrier();
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
     if (lane == 0 && tail_here && ntask > 0) {
