@@ -65,6 +65,27 @@ var ErrHipInput = errors.New("tokenmonster_hip: the walk does not advance on thi
 // HipDeviceCount reports the usable gfx950 devices (0: keep using the CPU path).
 func HipDeviceCount() int { return int(C.tm_device_count()) }
 
+// HipDeviceNumaNode: the NUMA node the device's PCIe root hangs under (-1: the host does not say).  The library's own pipeline workers
+// run there for the length of a call; a host that fills pinned input buffers from its own goroutines pins those threads to the same node.
+func HipDeviceNumaNode(device int) int { return int(C.tm_device_numa_node(C.int(device))) }
+
+// Denormalize is Vocab.Denormalize (go/tokenmonster.go:445-462) for one byte string (a token, a decoded fragment): capcode decoding only,
+// on the host (tm_denormalize); documents go through Decode.
+func (hv *HipVocab) Denormalize(b []byte) ([]byte, error) {
+	if len(b) == 0 {
+		return []byte{}, nil
+	}
+	var out *C.uint8_t
+	var n C.size_t
+	if _, err := locked(func() C.int {
+		return C.tm_denormalize((*C.uint8_t)(unsafe.Pointer(&b[0])), C.size_t(len(b)), C.tm_vocab_capcode(hv.h), &out, &n)
+	}); err != nil {
+		return nil, err
+	}
+	defer C.tm_free(unsafe.Pointer(out))
+	return C.GoBytes(unsafe.Pointer(out), C.int(n)), nil
+}
+
 // LoadHip uploads the vocabulary file that Load (go/tokenmonster.go:2656) reads to `device`.
 func LoadHip(filename string, device int) (*HipVocab, error) {
 	b, err := os.ReadFile(filename)

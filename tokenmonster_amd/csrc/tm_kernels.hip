@@ -420,8 +420,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   // the walks of a wavefront that go one lane each - the forward-delete probes of step A3, the chain walks behind step A1 - until the last of
   // them has ended: probe rounds (a double-array entry per lane and round) and, rarely, a round for the walks that stand at the head of a
   // one-child chain (tm_tables.h)
+  int rw_rounds = 0;                     // (rounds of the walker, for the phase profile of tools/: dead in the product build)
   auto run_walks = [&](Walk& k) {
     while (__any(!walk_idle(k) || k.tw != 0u)) {
+      rw_rounds++;
       if (__any(k.tw != 0u)) {
         // a round for the walks that stand at the head of a one-child chain (the others wait it out: rare)
         const bool on = k.tw != 0u;
@@ -619,6 +621,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     __builtin_amdgcn_s_waitcnt(0);
     for (int j = lane; j < 3 * ntask_tail; j += 64) w.Db[TAIL_TASK0 + j] = 0u;
     __builtin_amdgcn_wave_barrier();
+    PH_COUNT(9, ntask_tail)
+    PH_COUNT(10, rw_rounds)
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
     if (lane == 0 && tail_here && ntask > 0) {
       const uint32_t r = T.root[w.text[dl - 1]];

@@ -420,6 +420,7 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
       std::memcpy(&r[1], str, 32);
     }
   }
+  if (st.on) fprintf(stderr, "  [tables] %u nodes, %u double-array entries, %u chain records, tab %.2f MB\n", n_nodes, hv.n_da, n_tail_records, hv.tab.size() * 8 / 1e6);
   st.mark("suffix links");
   // reverse table for decoding: reverse[id] = key of the LAST record carrying that id (go/tokenmonster.go:2715, quirk Q3)
   {

@@ -39,5 +39,5 @@ print("segments %d (x%d passes), k_match_branch %.3f ms" % (nseg / reps, reps, m
 for i, n in enumerate(names):
     print("%-20s %9.0f cycles/segment  %5.1f %%" % (n, v[i] / nseg, 100 * v[i] / tot))
 print("total %.0f cycles/segment" % (tot / nseg))
-print("per segment: main rounds %.1f, drain rounds %.1f, refills %.1f, A3 rounds %.1f, C rounds %.1f, A3 tasks %.1f, (p,1) states %.1f"
+print("per segment: A1 loop rounds %.1f, walks handed to the task list %.1f, their rounds behind the loop %.1f, A3 + task probe rounds %.1f, C rounds %.1f, A3 tasks %.1f, (p,1) states %.1f"
       % (v[8] / nseg, v[9] / nseg, v[10] / nseg, v[11] / nseg, v[13] / nseg, v[14] / nseg, v[15] / nseg))
