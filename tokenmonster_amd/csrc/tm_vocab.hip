@@ -863,7 +863,7 @@ int tm_vocab_block_import(const tm_vocab_block* m, int device, tm_vocab** out, v
   const uint64_t tab = m->part_bytes[1];
   if (total > m->bytes || m->part_bytes[0] != 256 * 4 || m->part_bytes[7] != 256 || m->n_ids > kRowIdMask + 1 || m->n_info >= kMaxNodes || m->n_nodes < m->n_info ||
       m->n_nodes >= kMaxNodes || m->max_len > 40 || (m->off != 1 && m->off != 2) || m->idle_off != (uint64_t)m->n_da * 16 || ((uint64_t)m->n_da + 1) * 16 != m->direct_off ||
-      (uint64_t)m->direct_off + (uint64_t)kDirectSlots * sizeof(uint2) != m->link_off || (uint64_t)m->link_off + 16ull * m->n_nodes != tab ||
+      (uint64_t)m->direct_off + (uint64_t)kDirectSlots * sizeof(uint2) != m->link_off || (uint64_t)m->link_off + 16ull * m->n_nodes > tab || (tab - ((uint64_t)m->link_off + 16ull * m->n_nodes)) % 48 != 32 ||        /* the chain records behind the links: three entries each + two spare */
       m->part_bytes[2] != 16ull * m->n_info || m->part_bytes[3] != 16ull * m->n_info || m->part_bytes[4] != 4ull * m->n_info ||
       m->part_bytes[5] != 4ull * ((uint64_t)m->n_ids + 1) || (m->delete_id != TM_NONE && m->delete_id >= m->n_ids) || (m->unk_id != TM_NONE && m->unk_id >= m->n_ids))
     return set_error(TM_E_INVALID, "vocabulary block description is inconsistent");
