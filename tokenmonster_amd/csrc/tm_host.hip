@@ -440,6 +440,8 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
     uint64_t limit = chunk_bytes;
     // (the shift count is clamped: 8 lanes on 8 devices - or on the virtual devices of a test - make nramp 64 and more)
     if (ci < nramp) limit = std::max<uint64_t>(chunk_bytes >> std::min<size_t>(nramp - ci, 63), std::min<uint64_t>(chunk_bytes, 1u << 20));
+    // (the drain's shape - a floor of 2 / 4 / 8 / 16 MiB, a third or half of what is left instead of a quarter - was swept in round 5: every
+    // setting 30 - 37 ms per call, the same as this one; the spread of a call is the copy engines' queueing, not the chunk sizes: profiles/r05_h2h.txt)
     if (left < (uint64_t)nramp * chunk_bytes) limit = std::min(limit, std::max<uint64_t>(left / nramp, std::min<uint64_t>(chunk_bytes, 2u << 20)));
     while (e < ndocs && offsets[e + 1] >= offsets[e] && offsets[e + 1] - offsets[d] <= limit) e++;
     d = e;
