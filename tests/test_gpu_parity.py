@@ -847,6 +847,9 @@ def test_one_child_chains_in_the_trie():
     for cut in range(4, 41):                                                 # one chain of every length
         longs.append((b" q" + b"abcdefghijklmnopqrstuvwxyz0123456789-+*/")[:cut])
     singles = [bytes([c]) for c in b" abcdefghijklmnopqrstuvwxyz0123456789-+*/."]
+    # a chain that every position of a run of one letter stands at the head of: more chain heads under one wavefront than its task list holds
+    # (the positions are marked and walked again from their first byte)
+    longs += [b"z" * 40, b"zz", b"zzz", b"y" * 33, b"yy"]
     for capcode in (0, 2):
         toks = sorted(set(longs + singles + [b" " + x for x in words] + words + ([b"D"] if capcode == 2 else [])))
         img = synth.build_vocab(toks, capcode=capcode, charset=1)
@@ -868,6 +871,7 @@ def test_one_child_chains_in_the_trie():
                     parts.append(words[int(rng.integers(0, len(words)))])    # a word without its space: forward-delete probes
             docs.append(b"".join(parts))
         docs += [longs[0][:k] for k in range(1, len(longs[0]) + 1)]          # the text ends inside a chain, at every byte
+        docs += [b"z" * 1000, b"z" * 39 + b"a" + b"z" * 300 + b"y" * 500, (b"z" * 37 + b"q") * 40, b"y" * 32 + b"z" * 41 + b"y" * 34 + b" alpha" + b"z" * 700]
         text, offs = tm.pack_documents(docs)
         ids, toff, missing = v.tokenize_packed(text, offs)
         for d in range(len(docs)):

@@ -465,38 +465,61 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     typedef TM_LDS_SPACE uint32_t lds_u32;
     const uint32_t tb = TM_LDS_ADDR(w.text);                                        // address of text[0]
     const uint32_t xconst = TM_LDS_ADDR(w.X) - 4u * tb;                               // &X[i] == xconst + 4 * (tb + i), &D[i] 6 * 256 bytes behind
+    // A lane owns `run` consecutive positions.  The loop is written for NRUN independent streams of consecutive positions per lane whose
+    // rounds are interleaved (while the gather of one stream is in flight the lane works on the entry of the other) because round 5 wanted to
+    // know whether a wavefront's life - a gather's latency plus ~45 dependent instructions per round, 32 wavefronts per CU - is waiting that a
+    // second gather in flight per lane could fill.  It is not: NRUN 2 +14 % / +8 % / +21 % (32 000 / 100 256 / 4 096 ids), NRUN 3 +46 %
+    // (profiles/r05_k1_tails.txt (6)): twice the instructions per round and fewer positions that start from a suffix link cost more than the
+    // rounds saved - the kernel is bound by what it issues, not by what it waits for.  NRUN stays 1.
+#ifndef TM_K1_RUNS
+#define TM_K1_RUNS 1
+#endif
+    constexpr int NRUN = TM_K1_RUNS;
+    struct Run { uint32_t posa, pfa, off, key, bestv, node, lasta, c, nn; int depth, limit, bestlen; uint4 e; };
+    Run R[NRUN];
+    M64 setm[NRUN];
     const int run = (max(nwalkpos, 0) + 63) >> 6;
-    uint32_t posa = tb + (uint32_t)(lane * run);
-    const uint32_t enda = tb + (uint32_t)max(min(lane * run + run, nwalkpos), 0), dla = tb + (uint32_t)dl, lasta = enda - 1u;
-    int depth = 0, limit = 0, bestlen = 0;
-    uint32_t pfa = tb, off = idle_off, key = 0u, bestv = 0u, node = 0u;
-    const bool setting = posa < enda;
-    if (setting) {
-      limit = min((int)(dla - posa), Lmax);
-      off = T.direct_off + ((uint32_t)*TM_LDS_PTR(lds_u16u, posa) << 4);
-      pfa = posa + 2u;
-    } else {
-      // a lane without positions stores its (0, 0) every round like the others: into Db[lane] and, 6 * 256 bytes behind, Xb[..], which are
-      // all zero / not in use before step A3
-      static_assert(offsetof(WaveLds, Db) + 4 * 63 + 6 * 256 + 4 <= offsetof(WaveLds, xch) && offsetof(WaveLds, Db) + 6 * 256 >= offsetof(WaveLds, Xb), "dump words");
-      posa = tb + (uint32_t)((offsetof(WaveLds, Db) - offsetof(WaveLds, X)) / 4) + (uint32_t)lane;
+    const uint32_t dla = tb + (uint32_t)dl;
+    {
+      const int lo = min(lane * run, max(nwalkpos, 0)), hi = min(lane * run + run, max(nwalkpos, 0));
+#pragma unroll
+      for (int q = 0; q < NRUN; q++) {
+        // stream q: positions [a, b) of the lane's [lo, hi)
+        const int a = lo + ((hi - lo) * q + NRUN - 1) / NRUN, b = lo + ((hi - lo) * (q + 1) + NRUN - 1) / NRUN;
+        Run& r = R[q];
+        r.posa = tb + (uint32_t)a; r.lasta = tb + (uint32_t)b - 1u;
+        r.depth = 0; r.limit = 0; r.bestlen = 0; r.pfa = tb; r.off = idle_off; r.key = 0u; r.bestv = 0u; r.node = 0u;
+        const bool setting = a < b;
+        if (setting) {
+          r.limit = min((int)(dla - r.posa), Lmax);
+          r.off = T.direct_off + ((uint32_t)*TM_LDS_PTR(lds_u16u, r.posa) << 4);
+          r.pfa = r.posa + 2u;
+        } else {
+          // a stream without positions stores its (0, 0) every round like the others: into Db[lane] and, 6 * 256 bytes behind, Xb[..], which are
+          // all zero / not in use before step A3
+          static_assert(offsetof(WaveLds, Db) + 4 * 63 + 6 * 256 + 4 <= offsetof(WaveLds, xch) && offsetof(WaveLds, Db) + 6 * 256 >= offsetof(WaveLds, Xb), "dump words");
+          r.posa = tb + (uint32_t)((offsetof(WaveLds, Db) - offsetof(WaveLds, X)) / 4) + (uint32_t)lane;
+        }
+        setm[q] = __builtin_amdgcn_ballot_w64(setting);
+      }
     }
     const bool nowalk = TM_DBG_ON((dbg & 4) != 0);
     // The round with its control state as explicit 64-bit lane masks (ballots) and v_cndmask selects on them.  Written this way because
     // the scalar unit, not the vector unit, is the busier issue port of this loop (profiles/r03_k1_issue_ports.txt: one more scalar
     // instruction per round costs 1.6 x one more vector instruction): the structured control flow the compiler builds from `if`s on
     // per-lane booleans — save / restore of exec around every block, mask algebra for every && and || — was ~60 scalar instructions
-    // per round, the mask operations below are what the state machine needs.  A lane is SETTING (its gather is a link-format entry: the
+    // per round, the mask operations below are what the state machine needs.  A stream is SETTING (its gather is a link-format entry: the
     // mask `setm`, carried from round to round), PROBING (a double-array entry, valid if its check word is `key`) or idle (it gathers
     // the always-empty entry, which is nobody's child).
     uint32_t v_link = T.link_off, v_direct = T.direct_off, v_idle = idle_off;
     TM_KEEP_IN_VGPRS2(v_link, v_direct);
     TM_KEEP_IN_VGPRS2(v_idle, v_link);            // operands of the selects: registers for the whole loop, not moves per round
-    // tasks of the chain walks (below): pairs of words in the part of Xb nothing else touches before step A3 (the dump words of lanes
-    // without positions lie in Xb[88..151])
-    // (three words a task - base or chain word, node, position | depth << 16 - in the part of Db that nothing touches before step A3: the dump
-    // words of lanes without positions lie in Db[0..63]; the words used are zeroed again behind the walks, as step A3 expects all of Db)
-    constexpr int TAIL_TASK0 = 64, TAIL_TASKS = (NPOS - TAIL_TASK0) / 3;
+    // Walks that leave the loop (below): three words a task - base or chain word, node, position | depth << 16 - in the part of Db that nothing
+    // touches before step A3 (the dump words of streams without positions lie in Db[0..63]; the words used are zeroed again behind the walks, as
+    // step A3 expects all of Db).  A chain head that finds the list full marks its position in a bitmap (Xb[160..169]; the dump words reach
+    // Xb[151]) and is walked again from its first byte behind the tasks.
+    constexpr int TAIL_TASK0 = 64, TAIL_TASKS = (NPOS - TAIL_TASK0) / 3, REDO0 = 160, REDO_WORDS = (NPOS + 31) / 32;
+    static_assert(REDO0 + REDO_WORDS <= SEG && offsetof(WaveLds, Db) + 4 * 63 + 6 * 256 + 4 <= offsetof(WaveLds, Xb) + 4 * REDO0, "the bitmap lies behind the dump words");
     // A walk that is DEFER bytes deep and wants to go on is handed to the task list as well: the deep end of a walk is what a lane's whole run
     // of positions waits for, and behind the loop the deep walks of a wavefront run side by side.  Measured (profiles/r05_k1_tails.txt, K1 per
     // 256 MiB, 32 000 / 100 256 ids): chains only 4.92 / 6.21 ms, DEFER 16: 4.90, 12: 4.85 / 6.14, 10: 4.87 / 6.18, 8: 5.14 / 6.71, 6: 5.31.
@@ -505,42 +528,46 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 #endif
     constexpr int DEFER = TM_K1_DEFER_DEPTH;
     int ntask_tail = 0;
+    bool redo_any = false;                       // (wave-uniform)
+    if (lane < REDO_WORDS) w.Xb[REDO0 + lane] = 0u;
+    // the gather of a stream's next round and the LDS bytes that round may need - the next key byte, the first two bytes of the next position
+    auto issue = [&](Run& r) {
+      r.e = *reinterpret_cast<const uint4*>(tabb + r.off);
+#ifdef TM_DEVEL
+      // (pricing experiments, tools/ builds only: what a second 16-byte load per round costs when it lies in the same 32 bytes / on another line)
+      if (dbg & 0x60000) { const uint4 e2 = *reinterpret_cast<const uint4*>(tabb + (r.off ^ ((dbg & 0x20000) ? 16u : 0x1000u))); asm volatile("" :: "v"(e2.x), "v"(e2.y), "v"(e2.z), "v"(e2.w)); }
+#endif
+      r.c = *TM_LDS_PTR(lds_u8, r.pfa);
+      r.nn = *TM_LDS_PTR(lds_u16u, r.posa + 1u);
+    };
     auto rounds = [&](auto tail_tag) {
       constexpr bool TAIL = decltype(tail_tag)::value;
       // (The loop exists twice: when the document goes on for at least Lmax bytes behind the last position of the segment, no walk is
       // cut short by the end of the text and `limit` is the constant Lmax.)
-      M64 setm = __builtin_amdgcn_ballot_w64(setting);
-      for (;;) {
-        const M64 busy = __builtin_amdgcn_ballot_w64(off != idle_off);
-        if (busy == 0ull) break;
-        const uint4 e = *reinterpret_cast<const uint4*>(tabb + off);
-#ifdef TM_DEVEL
-        // (pricing experiments, tools/ builds only: what a second 16-byte load per round costs when it lies in the same 32 bytes / on another line)
-        if (dbg & 0x60000) { const uint4 e2 = *reinterpret_cast<const uint4*>(tabb + (off ^ ((dbg & 0x20000) ? 16u : 0x1000u))); asm volatile("" :: "v"(e2.x), "v"(e2.y), "v"(e2.z), "v"(e2.w)); }
-#endif
-        uint32_t c = *TM_LDS_PTR(lds_u8, pfa);
-        uint32_t nn = *TM_LDS_PTR(lds_u16u, posa + 1u);
-        TM_KEEP_IN_VGPRS2(c, nn);
+      // one round of one stream: its entry has arrived
+      auto step = [&](Run& r, M64& setm_r) {
+        const M64 busy = __builtin_amdgcn_ballot_w64(r.off != idle_off);
+        const uint4 e = r.e;
+        const uint32_t c = r.c, nn = r.nn;
         // a double-array entry is the child being probed for iff its check word is the parent (tm_tables.h); a link-format entry always "hits"
-        const M64 hit = __builtin_amdgcn_ballot_w64(e.x == key) & ~setm;
-        const M64 adv = hit | setm;
-        const uint32_t nid = sel_mask(setm, e.x, e.y) & kLinkNodeMask;
-        node = sel_mask(adv, nid, node);
-        depth = (int)sel_mask(setm, link_depth(e.x), add_mask_bit((uint32_t)depth, hit));
+        const M64 hit = __builtin_amdgcn_ballot_w64(e.x == r.key) & ~setm_r;
+        const M64 adv = hit | setm_r;
+        const uint32_t nid = sel_mask(setm_r, e.x, e.y) & kLinkNodeMask;
+        r.node = sel_mask(adv, nid, r.node);
+        r.depth = (int)sel_mask(setm_r, link_depth(e.x), add_mask_bit((uint32_t)r.depth, hit));
         const M64 acc = hit & __builtin_amdgcn_ballot_w64(nid < T.n_info);
-        bestv = sel_mask(setm | acc, e.y, bestv);
-        bestlen = (int)sel_mask(setm, link_bestlen(e.x), sel_mask(acc, (uint32_t)depth, (uint32_t)bestlen));
+        r.bestv = sel_mask(setm_r | acc, e.y, r.bestv);
+        r.bestlen = (int)sel_mask(setm_r, link_bestlen(e.x), sel_mask(acc, (uint32_t)r.depth, (uint32_t)r.bestlen));
         // probe only for a byte the node can continue with: bit (c & 31) of its child filter (0 behind a link that cannot go on)
-        M64 go = adv & __builtin_amdgcn_ballot_w64(bit_of(e.z, c) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
+        M64 go = adv & __builtin_amdgcn_ballot_w64(bit_of(e.z, c) != 0u) & __builtin_amdgcn_ballot_w64(r.depth < (TAIL ? r.limit : Lmax));
         if (nowalk) go = 0ull;
         // one-child chains (tm_tables.h): a walk about to go on from a node with a chain word ENDS here as far as this loop is concerned - the
         // position keeps the best match up to that node, the next position starts from the node's suffix link (valid, if shallower than the
         // link of the node the chain would have led to) - and leaves a task: {chain word, node, position | depth << 16}.  The tasks of a wavefront
         // are walked together behind the loop, one lane each (chain compare, then on as far as the trie goes).  Taking the chains inside the
         // round instead was timed: +11 % (a wavefront then runs the compare in every round in which ANY lane meets a chain).
-        uint32_t ew = e.w, cnode = nid;
-        M64 tl = go & __builtin_amdgcn_ballot_w64(is_tail_word(e.w));
-        const M64 dm = DEFER > 0 ? (tl | (go & __builtin_amdgcn_ballot_w64(depth >= DEFER))) : tl;      // walks that leave this loop for the task list
+        const M64 tl = go & __builtin_amdgcn_ballot_w64(is_tail_word(e.w));
+        const M64 dm = DEFER > 0 ? (tl | (go & __builtin_amdgcn_ballot_w64(r.depth >= DEFER))) : tl;      // walks that leave this loop for the task list
         if (dm != 0ull) {
           const int nt = __builtin_popcountll(dm);
           if (ntask_tail + nt <= TAIL_TASKS) {
@@ -548,54 +575,49 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
               const uint32_t slot = mbcnt64(dm, (uint32_t)ntask_tail);
               w.Db[TAIL_TASK0 + 3 * slot] = e.w;
               w.Db[TAIL_TASK0 + 3 * slot + 1] = nid;
-              w.Db[TAIL_TASK0 + 3 * slot + 2] = (posa - tb) | ((uint32_t)depth << 16);
+              w.Db[TAIL_TASK0 + 3 * slot + 2] = (r.posa - tb) | ((uint32_t)r.depth << 16);
             }
             ntask_tail += nt;
             go &= ~dm;
           } else if (tl != 0ull) {
-            // (no room in the list - more than TAIL_TASKS chains under one wavefront: these are taken on the spot)
-            while (tl != 0ull) {
-              const bool on = (tl >> lane) & 1ull;
-              uint4 h;
-              const bool ok = tail_compare(tabb, idle_off, on, ew, pfa, (TAIL ? limit : Lmax) - depth, &h);
-              const M64 okm = __builtin_amdgcn_ballot_w64(ok);
-              const uint32_t len = tail_len(h.x);
-              depth = (int)sel_mask(okm, (uint32_t)depth + len, (uint32_t)depth);
-              pfa = sel_mask(okm, pfa + len, pfa);
-              cnode = sel_mask(okm, h.x & kLinkNodeMask, cnode);
-              node = sel_mask(okm, h.x & kLinkNodeMask, node);
-              const M64 accm = okm & __builtin_amdgcn_ballot_w64(h.y != 0u);
-              bestv = sel_mask(accm, h.y, bestv);
-              bestlen = (int)sel_mask(accm, (uint32_t)depth, (uint32_t)bestlen);
-              ew = sel_mask(okm, h.w, ew);
-              const uint32_t c2 = *TM_LDS_PTR(lds_u8, pfa);                  // the byte behind the chain (pfa has moved for the lanes that took it)
-              c = sel_mask(okm, c2, c);
-              const M64 go2 = okm & __builtin_amdgcn_ballot_w64(bit_of(h.z, c2) != 0u) & __builtin_amdgcn_ballot_w64(depth < (TAIL ? limit : Lmax));
-              go = (go & ~tl) | go2;
-              tl = go2 & __builtin_amdgcn_ballot_w64(is_tail_word(ew));       // (a chain longer than a record goes on in the next one)
-            }
+            // (no room in the list: a walk that is merely deep goes on in the loop; one at the head of a chain cannot - its base word is the
+            // chain's record - and marks its position for the walks behind the tasks)
+            if ((tl >> lane) & 1ull) atomicOr(&w.Xb[REDO0 + ((r.posa - tb) >> 5)], 1u << ((r.posa - tb) & 31u));
+            redo_any = true;
+            go &= ~tl;
           }
         }
         const M64 fin = busy & ~go;
-        // the best match so far at the lane's position, every round (the last store of a position is its result; a lane that has run out
+        // the best match so far at the stream's position, every round (the last store of a position is its result; a stream that has run out
         // of positions stays on its last one and stores the same values again): no select of a store address, and ONE store for both
         // words (WaveLds: D[p] lies 6 * 256 bytes behind X[p]).  No match: bestlen == 0 and the link formats give bestv == 0.
         {
-          TM_LDS_SPACE uint32_t* xp = TM_LDS_PTR(lds_u32, xconst + 4u * posa);
-          xp[0] = bestv;                                                                                      // X[pos]
-          xp[6 * 64] = (uint32_t)bestlen;                                                                      // D[pos]
+          TM_LDS_SPACE uint32_t* xp = TM_LDS_PTR(lds_u32, xconst + 4u * r.posa);
+          xp[0] = r.bestv;                                                                                      // X[pos]
+          xp[6 * 64] = (uint32_t)r.bestlen;                                                                      // D[pos]
         }
         // ... and move on: through the suffix link if the walk got deep enough, else from the direct map
-        const M64 more = __builtin_amdgcn_ballot_w64(posa < lasta), deep = __builtin_amdgcn_ballot_w64(depth >= 3);      // (the next position is posa + 1)
-        const uint32_t off_f = sel_mask(more, sel_mask(deep, v_link, v_direct) + (sel_mask(deep, node, nn) << 4), v_idle);
+        const M64 more = __builtin_amdgcn_ballot_w64(r.posa < r.lasta), deep = __builtin_amdgcn_ballot_w64(r.depth >= 3);      // (the next position is posa + 1)
+        const uint32_t off_f = sel_mask(more, sel_mask(deep, v_link, v_direct) + (sel_mask(deep, r.node, nn) << 4), v_idle);
         // a walk that goes on probes entry base + byte for the byte behind the one just read (also behind a link: it stands for the bytes
         // up to there); the first byte a new position reads: posn + depth - 1 behind a suffix link, posn + 2 behind the direct map
-        key = sel_mask(go, cnode, key);
-        off = sel_mask(go, (ew + c) << 4, off_f);                               // (an idle lane has no more positions: off_f is the idle entry)
-        pfa = sel_mask(go, pfa + 1u, posa + (uint32_t)max(depth, 3));
-        if (TAIL) limit = (int)sel_mask(fin, (uint32_t)min((int)(dla - posa) - 1, Lmax), (uint32_t)limit);
-        setm = fin & more;
-        posa = add_mask_bit(posa, setm);
+        r.key = sel_mask(go, nid, r.key);
+        r.off = sel_mask(go, (e.w + c) << 4, off_f);                             // (an idle stream has no more positions: off_f is the idle entry)
+        r.pfa = sel_mask(go, r.pfa + 1u, r.posa + (uint32_t)max(r.depth, 3));
+        if (TAIL) r.limit = (int)sel_mask(fin, (uint32_t)min((int)(dla - r.posa) - 1, Lmax), (uint32_t)r.limit);
+        setm_r = fin & more;
+        r.posa = add_mask_bit(r.posa, setm_r);
+        issue(r);
+      };
+#pragma unroll
+      for (int q = 0; q < NRUN; q++) issue(R[q]);
+      for (;;) {
+        bool any_busy = false;
+#pragma unroll
+        for (int q = 0; q < NRUN; q++) any_busy |= R[q].off != idle_off;
+        if (__builtin_amdgcn_ballot_w64(any_busy) == 0ull) break;
+#pragma unroll
+        for (int q = 0; q < NRUN; q++) step(R[q], setm[q]);
         PH_INC(8)
       }
     };
@@ -623,6 +645,30 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     __builtin_amdgcn_wave_barrier();
     PH_COUNT(9, ntask_tail)
     PH_COUNT(10, rw_rounds)
+    if (redo_any) {
+      // (rare: more chain heads under one wavefront than the task list holds) the marked positions once more, from their first byte: the
+      // direct map says where the walk stands after two bytes, the walker does the rest
+      __builtin_amdgcn_s_waitcnt(0);
+      for (int it = 0; it < NPOS_PAD / 64; it++) {
+        const int p0 = it * 64 + lane;
+        const bool marked = p0 < NPOS && ((w.Xb[REDO0 + (p0 >> 5)] >> (p0 & 31)) & 1u) != 0u;
+        Walk k = Walk{0, 0, 0, 0, 0, idle_off, KEY_IDLE, 0u, 0u};
+        if (marked) {
+          const uint4 e = *reinterpret_cast<const uint4*>(tabb + T.direct_off + ((uint32_t)*TM_LDS_PTR(lds_u16u, tb + (uint32_t)p0) << 4));
+          k.pos = p0; k.tbase = p0; k.depth = (int)link_depth(e.x); k.limit = min(dl - p0, Lmax);
+          k.bestlen = (int)link_bestlen(e.x); k.bestv = e.y;
+          const uint32_t c0 = w.text[p0 + k.depth];
+          if (k.depth < k.limit && child_possible32(e.z, c0)) {
+            if (is_tail_word(e.w)) k.tw = e.w; else { k.key = link_node(e.x); k.hoff = (e.w + c0) << 4; }
+          }
+        }
+        if (__any(marked)) {
+          run_walks(k);
+          if (marked) { w.X[p0] = k.bestv; w.D[p0] = (uint32_t)k.bestlen; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     // the last byte of a document can only match a one-byte token: no table walk, and it is left out of the runs
     if (lane == 0 && tail_here && ntask > 0) {
       const uint32_t r = T.root[w.text[dl - 1]];
