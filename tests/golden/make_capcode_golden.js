@@ -97,7 +97,7 @@ for (let i = 0; i < 3000; i++) {
 // round 5: what the device normalizer / decoder took over last - the characters beyond the Basic Multilingual Plane (four bytes of UTF-8:
 // emoji and pictographs, their skin-tone modifiers, mathematical letters, plane-2 ideographs, Deseret with its case, a musical symbol that
 // decomposes) and Hangul syllables, which NFD decomposes by arithmetic into two or three conjoining jamo - again appended BEHIND everything else
-const emoji = ['😀', '😂', '🚀', '🌍', '👍', '🏽', '🎉', '🔥', '💯', '🤖', '🦄', '🧠', '🫠', '🇩', '🇪', '🀄', '🂡'];
+const emoji = ['😀', '😂', '🚀', '🌍', '👍', '🏽', '🎉', '🔥', '💯', '🤖', '🦄', '🧠', '🫠', '🇩', '🇪', '🀄', '🂡', '❤️', '☺️', '1️⃣', '\ufe0f', '✨'];
 const astral = ['𝒜', '𝒷', '𝔘', '𝟘', '𠀀', '𠮷', '𪚥', '𐐀', '𐐨', '𝅗𝅥', '𐀀', '𒀀', '𓀀'];
 const syll = '가각갂힣뷁한국어텍스트나다라마바사아자차카타파하값삶닭없읽'.split('');
 const flavours5 = [
@@ -108,7 +108,7 @@ const flavours5 = [
   () => pick([words, words, emoji, [' '], [' '], punct, syll]),
 ];
 ['Hello 😀 World 🌍🚀', "it's 👍🏽 A😀B c😀d 1😀2 '😀'", '😀', ' 😀', '😀A', 'A😀', '😀a', 'AB😀CD', 'Ab😀cD', '𝒜𝒷 𠀀𠮷 done', '𐐀𐐨 Deseret', '𝅗𝅥 half',
- '한국어 텍스트', '가', '각', '힣', 'A가B 가a 1가', "'가' 한글Hangul", '대한민국 KOREA 서울 Seoul', '값 삶 닭 없다 읽다', '가́', '🇩🇪 🇰🇷'].forEach(s => inputs.push(s));
+ '한국어 텍스트', '가', '각', '힣', 'A가B 가a 1가', "'가' 한글Hangul", '대한민국 KOREA 서울 Seoul', '값 삶 닭 없다 읽다', '가́', '🇩🇪 🇰🇷', 'I ❤️ U', 'A️b a️B ️', '1️⃣2️⃣ #️⃣', 'हिन्दी की कि HINDI'].forEach(s => inputs.push(s));
 for (let i = 0; i < 2500; i++) {
   const f = flavours5[i % flavours5.length];
   const n = rnd(rnd(4) === 0 ? 90 : 28);

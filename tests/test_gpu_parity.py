@@ -769,12 +769,13 @@ def emoji_korean_corpus(rng, nbytes):
     """web-like text: English / French sentences with AT LEAST one emoji per document (four bytes of UTF-8: emoticons, pictographs, a
     skin-tone modifier, flags), Korean running text (Hangul syllables with and without a final consonant) with English mixed in, and
     plane-2 ideographs / hieroglyphs / cuneiform here and there; one document in a hundred carries what still needs the host (a Deseret
-    capital, a musical symbol that decomposes, the variation selector U+FE0F - a combining mark of three bytes -, a mathematical letter)"""
+    capital, a musical symbol that decomposes, voiced kana, a mathematical letter); the variation selector U+FE0F behind an emoji and the enclosing
+    keycap - combining marks of three bytes and canonical class 0 - stay on the device"""
     en = "the quick Brown FOX jumps over 13 lazy dogs it's NASA's iPhone LOL omg so café naïve Über".split()
     ko = "한국어 텍스트 대한민국 서울 값 삶 닭 없다 읽다 가 나 다 라 마 바 사 아 자 차 카 타 파 하 안녕하세요 감사합니다 GPU 토큰".split()
-    emoji = ["😀", "😂", "🚀", "🌍", "👍", "👍🏽", "🎉", "🔥", "💯", "🤖", "🦄", "🇰🇷", "🀄"]
+    emoji = ["😀", "😂", "🚀", "🌍", "👍", "👍🏽", "🎉", "🔥", "💯", "🤖", "🦄", "🇰🇷", "🀄", "❤️", "☺️", "1️⃣"]
     astral = ["𠀀", "𠮷", "𓀀", "𒀀"]
-    host_only = ["𐐀", "𝅗𝅥", "❤️", "𝒜"]         # (mathematical letters: their blocks of 64 code points have unassigned holes, the block table says "mixed")
+    host_only = ["𐐀", "𝅗𝅥", "がぎ", "𝒜"]         # (mathematical letters: their blocks of 64 code points have unassigned holes, the block table says "mixed")
     docs, total = [], 0
     while total < nbytes:
         n = int(rng.integers(2, 200))

@@ -58,8 +58,9 @@ TM_HD bool nm_punct3(uint32_t b1, uint32_t b2) {   // E2 b1 b2 in the supported 
 // CJK ideographs, most kana, symbols, box drawing ...: NFD-stable, caseless, and to capcode either a letter that is neither upper nor
 // lower case (class LO: \p{L}) or "other" (class O).  Two bits per code point, from the host normalizer's own functions
 // (tm_normalize.cpp: build_three_tables): 0 = the document takes the host path (the character decomposes, has case, is a mark, a digit
-// or a surrogate: Hangul syllables, voiced kana, Latin Extended Additional ...), 1 = class O, 2 = class LO.  First a table of the 1 024
-// blocks of 64 code points (256 bytes, staged in LDS): 0 / 1 / 2 when the whole block agrees, 3 = look the code point up (16 KB, in HBM).
+// or a surrogate: voiced kana, Latin Extended Additional ...; Hangul syllables: below), 1 = class O, 2 = class LO, 3 (per code point only) = a
+// combining mark of canonical class 0 (variation selectors, the enclosing keycap, spacing vowel signs: class M, never reordered).  First a table
+// of the 1 024 blocks of 64 code points (256 bytes, staged in LDS): 0 / 1 / 2 when the whole block agrees, 3 = look the code point up (16 KB, in HBM).
 constexpr int NM_BLK_WORDS = 64, NM_CP_WORDS = 4096;
 // ---- four-byte characters U+10000..U+10FFFF (lead bytes F0..F4): emoji, pictographs, historic scripts, mathematical alphanumerics ... --
 // The same two-bit codes per BLOCK of 64 code points (16 384 blocks of the planes 1..16, 4 KB, read where they lie: the characters are rare
@@ -153,7 +154,7 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
   const uint32_t cp3 = nm_cp3(lead, b1, b2);
   const uint32_t code = nm_three_code(tabs, cp3);
   if (code == 0u && (tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp3)) return (uint32_t)NC_LO | cont;       // decomposes, but by arithmetic: nm_hangul_out
-  return code == 0u ? (uint32_t)NF_BAD : ((code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O) | cont);
+  return code == 0u ? (uint32_t)NF_BAD : ((code == 3u ? (uint32_t)NC_M : (code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O)) | cont);      // (3: a combining mark of class 0)
 }
 // the bytes of a lane that holds one byte of a two-byte character: *o3 = its last output byte; returns how many bytes the lane emits
 // IN FRONT of it: 0, 1 (*y: the second half of a character that decomposes into an ASCII letter and a mark emits the mark) or 2 (*m3 *y:

@@ -440,6 +440,9 @@ void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cpt) {
         const uint8_t k1 = classify(c1);
         // untouched by the flags, nothing capcode would mark or lower-case, and to capcode a letter without case or "other"
         if (t == in && !c1.raw && c1.n == 3 && low == in && !(k1 & (kUpper | kLower | kDigit | kMark))) code = (k1 & kLetter) ? 2u : 1u;
+        // a combining mark of class 0 - the variation selectors (U+FE0F behind an emoji), the enclosing keycap, the spacing vowel signs of the
+        // Indic scripts ...: canonical ordering never moves it, NFD leaves it alone: class M on the device too (round 5)
+        else if (t == in && !c1.raw && c1.n == 3 && low == in && k1 == kMark && u_getCombiningClass((UChar32)cp) == 0) code = 3u;
       }
       cpt[cp >> 4] |= code << (2u * (cp & 15u));
       if (first == 4) first = code; else if (code != first) same = false;

@@ -345,10 +345,8 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
     {
       const size_t first_rec = ((size_t)hv.n_da + 1) + kL2Size + n_nodes;      // in 16-byte entries: double array | empty entry | direct map | links | records
       uint32_t nrec = 0;
-      const bool off = getenv("TM_NO_TAILS") != nullptr;          // (development: the tables without chain records, for an A/B of the kernels)
-      const uint32_t tmin = getenv("TM_TAIL_MIN") ? (uint32_t)std::max(2, atoi(getenv("TM_TAIL_MIN"))) : kTailMin;      // (development: A/B of the shortest chain that gets a record)
-      for (uint32_t n = 0; n < n_nodes && !off; n++)
-        if (depth_of[n] >= 2 && chain[n] >= tmin) tailw[n] = kTailFlag | (uint32_t)(first_rec + 3 * (size_t)nrec++);
+      for (uint32_t n = 0; n < n_nodes; n++)
+        if (depth_of[n] >= 2 && chain[n] >= kTailMin) tailw[n] = kTailFlag | (uint32_t)(first_rec + 3 * (size_t)nrec++);
       n_tail_records = nrec;
     }
     da.assign((size_t)hv.n_da + 1, uint4{kNone, kNone, 0u, 0u});

@@ -215,7 +215,7 @@ int main(int argc, char** argv) {
                                     u8"中文文本，测试。Hello世界 ABC中文", u8"こんにちは世界 カタカナ がぎぐ パピプ", u8"한국어 텍스트", u8"가 각 힣 뷁 A가B 가a 1가 '가' 한글Hangul 가\u0301", std::string(1022, 'x') + u8"한국", std::string(1023, 'x') + u8"각", std::string(400, 'x') + std::string(u8"한국어텍스트가나다라마바사") + std::string(u8"아자차카타파하") + std::string(600, 'y'), u8"a\u0301 e\u0301\u0323 o\u0323\u0301 Ắ ǖ", u8"→ ★ ∑ √ ①②③ Ḁḁ ẞ",
                                     std::string(1023, 'x') + u8"й", std::string(1022, 'x') + u8"Йод", std::string(62, 'a') + u8"йй" + std::string(61, 'b') + u8"中文",
                                     u8"Hello 😀 World 🌍🚀 it's 👍🏽 A😀B c😀d 1😀2 '😀' 𝒜𝒷 𠀀𠀁 done", std::string(1021, 'x') + u8"😀Ab", std::string(1022, 'x') + u8"😀" + " Ab", std::string(1023, 'x') + u8"A😀b", std::string(61, 'A') + u8"😀😀" + std::string(70, 'b'),
-                                    u8"𐐀𐐨 Deseret", u8"𝅗𝅥 half note", "\xF0\x9F\x98", "\xF4\x90\x80\x80 beyond", "\xF0\x80\x80\x80 overlong", u8"x😀"};
+                                    u8"𐐀𐐨 Deseret", u8"𝅗𝅥 half note", "\xF0\x9F\x98", "\xF4\x90\x80\x80 beyond", "\xF0\x80\x80\x80 overlong", u8"x😀", u8"I ❤️ U ☺️ 1️⃣ A️b a️B ❤️️", u8"की कि कु हिन्दी HINDI ह"};
   for (int lower = 0; lower < 2; lower++) {
     const uint32_t flag = lower ? 3u : 1u;
     for (const auto& s : fixed) { std::vector<uint8_t> d(s.begin(), s.end()); total++; if (!check_doc(d, flag, &skipped)) bad++; }
@@ -250,7 +250,8 @@ int main(int argc, char** argv) {
               cp = q < 20 ? 0x1F300 + rng.below(0x700) : q < 28 ? 0x20000 + rng.below(0xA000) : q < 34 ? 0x1D400 + rng.below(0x400) : q < 36 ? 0x10000 + rng.below(0x100) :
                    q == 36 ? 0x10400 + rng.below(0x50) /* Deseret: case */ : q == 37 ? 0x1D15E + rng.below(7) /* musical symbols that decompose */ : q == 38 ? 0x1F100 + rng.below(0x10) : 0x10000 + rng.below(0x100000);
               break; }
-            default: cp = rng.below(3) ? 0x2190 + rng.below(0x400) : (rng.below(2) ? 0xAC00 + rng.below(0x2BA4) : 0x1E00 + rng.below(0x100)); break;   // arrows / symbols; Hangul, Latin Extended Additional (host)
+            default: if (rng.below(6) == 0) { cp = rng.below(2) ? 0xFE0F : (rng.below(2) ? 0x20E3 : 0x093E + rng.below(0x10)); break; }      // three-byte marks: variation selector, keycap, Devanagari vowel signs (some of class 0, some not)
+                     cp = rng.below(3) ? 0x2190 + rng.below(0x400) : (rng.below(2) ? 0xAC00 + rng.below(0x2BA4) : 0x1E00 + rng.below(0x100)); break;   // arrows / symbols; Hangul, Latin Extended Additional (host)
           }
           if (cp < 0x800) { d.push_back((uint8_t)(0xC0 | (cp >> 6))); d.push_back((uint8_t)(0x80 | (cp & 0x3F))); }
           else if (cp >= 0x10000) {
