@@ -147,7 +147,7 @@ __device__ __forceinline__ uint32_t exit_entry(const uint16_t* __restrict__ exit
 //           + (nWords + nextIsNotLetter) * 100 - 3 * (endsWithLetter & nextIsLetter)
 // The two cross terms of the penalty need the first token: begins-with-letter and begins-on-capcode sit in bit 0 of bytes 0 and 1,
 // so that the penalty is ONE dot product of (descriptor & first-token bits) with the bytes {103, 100} (v_dot4_u32_u8).
-constexpr uint32_t D_LEN_SHIFT = 1, D_S_SHIFT = 9;
+constexpr uint32_t D_LEN_SHIFT = 1, D_S_SHIFT = 9, D_NEXT_SPACE = 30, D_HAS_B = 0x80000000u;
 __device__ __forceinline__ uint32_t desc_len(uint32_t d) { return (d >> D_LEN_SHIFT) & 63u; }
 __device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_t nb, bool bvariant, uint32_t hint) {
   const uint32_t f5 = v >> 27, snw = (v >> 22) & 31u;
@@ -155,7 +155,10 @@ __device__ __forceinline__ uint32_t make_sdesc(uint32_t len, uint32_t v, uint32_
             sall = (int)((f5 >> 4) & 1u);
   const int S = (int)len + sall + max((int)snw - 1, 0) + (bvariant ? 0 : sbegs) + (int)((nb >> 2) & 1u) + ((int)snw + (int)(nb >> 3)) * 100 -
                 (send & (int)(nb & 1u)) * 3;
-  return (uint32_t)sbegl | (len << D_LEN_SHIFT) | ((uint32_t)sbegc << 8) | ((uint32_t)(S + 4) << D_S_SHIFT);
+  // bit 30: the byte behind the token is of the space class (begin_byte 12: the fast exit of go :1057 asks for it when this token is the FIRST
+  // of a step); bit 31 (D[] only, set by step A3): the position also has a forward-delete descriptor in Db[] - most do not, and step B then
+  // does not look
+  return (uint32_t)sbegl | (len << D_LEN_SHIFT) | ((uint32_t)sbegc << 8) | ((uint32_t)(S + 4) << D_S_SHIFT) | (((nb >> 2) & 1u) << D_NEXT_SPACE);
 }
 
 // child filter (tm_tables.h): can the node have a child over byte c?
@@ -249,7 +252,7 @@ __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w
   const uint32_t id = O.x & kRowIdMask;
   const int i1 = p + len;
   uint32_t res = id | ((uint32_t)len << 24);                                                   // go :1265-1267
-  if (i1 < dl && ((O.w & (1u << 21)) == 0 || s_bb[w.text[i1]] != 12)) {                       // go :1057 (flag 32: a whole word, followed by a space)
+  if (i1 < dl && ((O.w & (1u << 21)) == 0 || ((d >> D_NEXT_SPACE) & 1u) == 0u)) {               // go :1057 (flag 32: a whole word, followed by a space)
     const int len1 = (int)(O.w & 63u), len2 = (int)((O.w >> 6) & 63u);
     // candidate first tokens: the match itself, alternative 1, alternative 2 (lengths and constants of a forward-delete state: tm_tables.h)
     const int flen[3] = {len, len1 - FD, len2 - FD};
@@ -273,8 +276,8 @@ __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w
           if (k > 0) sc -= alt_penalty(flen[k], dS, len);
           const uint32_t rk = (k == 0 ? id : ((k == 1 ? O.y : O.z) & kRowIdMask)) | ((uint32_t)flen[k] << 24);
           if (sc > best) { best = sc; res = rk; }
-          const uint32_t dB = w.Db[ik];
-          if (dB != 0) {
+          if (dS & D_HAS_B) {
+            const uint32_t dB = w.Db[ik];
             int sb = branch_score(fpart[k], fb[k], dB, true);
             if (k > 0) sb -= alt_penalty(flen[k], dB, len);
             if (sb > bestb) { bestb = sb; resb = rk | (1u << 30); }
@@ -737,6 +740,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         } else if (e.x != kNone && bl > (int)ml + 1) {               // (only possible with the two-byte UTF-16 prefix)
           const int lb = bl - off;
           w.Db[p] = make_sdesc((uint32_t)lb, e.y, s_bb[w.text[p + lb]], true, T.spl_hint);
+          w.D[p] |= D_HAS_B;
           if (p < SEG) w.Xb[p] = e.y;
         }
       }
@@ -745,6 +749,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       if (k.bestlen > mainlen + 1) {
         const int lb = k.bestlen - off;                              // go :1093
         w.Db[k.pos] = make_sdesc((uint32_t)lb, k.bestv, s_bb[w.text[k.pos + lb]], true, T.spl_hint);
+        w.D[k.pos] |= D_HAS_B;
         if (k.pos < SEG) w.Xb[k.pos] = k.bestv;
       }
       __builtin_amdgcn_wave_barrier();
