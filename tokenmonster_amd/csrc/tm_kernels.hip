@@ -800,7 +800,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     for (int it = 0; it < SEG / 64; it++) {
       const int p = it * 64 + lane;
       r0[it] = R_INVALID;
-      if (p < seglen) r0[it] = transition<0>(T, w, s_bb, p, dl, d0[it], row0[it]);
+      if (p < seglen) r0[it] = TM_DBG_ON(dbg & 0x800000) ? ((row0[it].x & kRowIdMask) | (max(desc_len(d0[it]), 1u) << 24)) : transition<0>(T, w, s_bb, p, dl, d0[it], row0[it]);      // (devel bit 23: greedy, what step B's scoring costs)
     }
     PH(1)
     const bool side_ok = n1 < SIDE_STRIDE && !(dbg & 64);          // (dbg & 64: tests force the dense path)
@@ -892,9 +892,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     for (int it = 0; it < N0; it++) {
       const int p = it * 64 + lane;
       ja[it] = first_hop(r0[it], p, 0u);
-      ja[N0 + it] = first_hop(r1[it], p, 1u);
       J[p] = ja[it];
-      J[J_PLANE + p] = ja[N0 + it];
+      if (TM_DBG_ON(dbg & 0x400000)) ja[N0 + it] = 0x80000000u | (JNONE << JF);      // (devel bit 22: no forward-delete states in step C - what their four slots per lane cost)
+      else { ja[N0 + it] = first_hop(r1[it], p, 1u); J[J_PLANE + p] = ja[N0 + it]; }
     }
     bool any0 = false, any1 = false;
 #pragma unroll
