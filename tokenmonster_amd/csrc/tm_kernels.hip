@@ -1346,40 +1346,21 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
     const uint32_t seglen = t.have ? t.seglen : 0u;
     uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0, direct = 0, hop = 0;
     // gate >= 0 <=> the lane may take the straight-line step: (p, 0) state, staging, and the two slots a step may need are free in front
-    // of the word being read (gate = free slots - 2 - (fd | direct) << 16)
+    // of the word being read (gate = free slots - 2 - (fd | direct) << 16); GATE_DEAD: the chain has left the segment (or the lane has none).
+    // ONE register says which of the three a lane is, and a round costs two compares and two branches beside its step: fast lanes step
+    // under their mask, the general step is entered only when some lane is in (GATE_DEAD, 0), and the loop ends with the first round in
+    // which no lane did anything.  (As ballots of p < seglen and gate < 0 combined into alive / slow / fast masks the bookkeeping of a round
+    // was 20 instructions beside the 26 of the step, on a kernel that is bound by instruction issue with 8 lanes at work.)
+    constexpr int GATE_DEAD = -(1 << 24);
     const int slack0 = (int)SLACK - 2 - (int)stage_after;
-    int gate = slack0 + (int)p - (int)(fd << 16);
+    int gate = p < seglen ? slack0 + (int)p - (int)(fd << 16) : GATE_DEAD;
     const uint32_t nounk = no_id == ID_NONE ? 1u : 0u;
     for (;;) {
-      const unsigned long long alive = __builtin_amdgcn_ballot_w64(p < seglen);
-      if (alive == 0ull) break;
-      const unsigned long long slow = alive & __builtin_amdgcn_ballot_w64(gate < 0);
-      if (slow != 0ull) {
-        if (p < seglen && gate < 0) {
-          const uint32_t w = word(p, fd);
-          if (w == R_INVALID || hop > 2u * SEG) { atomicOr(error_flag, 2u); p = seglen; }      // cannot happen on a chain K1/K3 produced (a chain visits a state at most once)
-          else {
-            const uint32_t id = w & ID_NONE;
-            const bool fits = direct == 0u && slack0 + (int)p - (int)E >= 0;
-            if (!fits && direct == 0u) { direct = 1u; staged = E; }      // from here on the segment's ids go straight to HBM
-            fd = (w >> 30) & 1u;
-            nfd += fd;
-            nmiss += w >> 31;
-            if (fits) {
-              if (NARROW) { if (id != ID_NONE) rowa[E++] = (uint16_t)id; if (fd) rowa[E++] = (uint16_t)delete_id; }
-              else { if (id != ID_NONE) row[E++] = id; if (fd) row[E++] = delete_id; }
-            } else {
-              if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); E++; }
-              if (fd) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], delete_id); E++; }
-            }
-            p += (w >> 24) & 63u;                                          // (0 is possible: a one-byte alternative of a forward-delete state)
-            hop++;
-            gate = slack0 + (int)p - (int)E - (int)((fd | direct) << 16);
-          }
-        }
-      }
-      const unsigned long long fast = alive & ~slow;
-      if ((fast >> lane) & 1ull) {
+      // (the straight-line rounds are a loop of their own: with the general step inside it the compiler copies nine registers out of and
+      // back into their places on every round)
+      for (;;) {
+      if (__builtin_amdgcn_ballot_w64(gate >= 0) == 0ull) break;
+      if (gate >= 0) {
         uint32_t id, fdn, miss, adv;
         if (NARROW) {
           const uint32_t m8 = rowm[SLACK + p];
@@ -1400,7 +1381,35 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
         nmiss += miss;
         fd = fdn;
         p += max(adv, 1u);                                               // (a (p, 0) state always advances — also on a row that is not one: the walk ends)
+        gate = p < seglen ? gate : GATE_DEAD;
       }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64((uint32_t)gate > (uint32_t)GATE_DEAD) != 0ull, 0)) break;      // a lane in (GATE_DEAD, 0)
+      }
+      const bool general = (uint32_t)gate > (uint32_t)GATE_DEAD;      // GATE_DEAD < gate < 0 (as unsigned numbers these lie above everything else)
+      if (__builtin_amdgcn_ballot_w64(general) != 0ull) {
+        if (general) {
+          const uint32_t w = word(p, fd);
+          if (w == R_INVALID || hop > 2u * SEG) { atomicOr(error_flag, 2u); p = seglen; gate = GATE_DEAD; }      // cannot happen on a chain K1/K3 produced (a chain visits a state at most once)
+          else {
+            const uint32_t id = w & ID_NONE;
+            const bool fits = direct == 0u && slack0 + (int)p - (int)E >= 0;
+            if (!fits && direct == 0u) { direct = 1u; staged = E; }      // from here on the segment's ids go straight to HBM
+            fd = (w >> 30) & 1u;
+            nfd += fd;
+            nmiss += w >> 31;
+            if (fits) {
+              if (NARROW) { if (id != ID_NONE) rowa[E++] = (uint16_t)id; if (fd) rowa[E++] = (uint16_t)delete_id; }
+              else { if (id != ID_NONE) row[E++] = id; if (fd) row[E++] = delete_id; }
+            } else {
+              if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); E++; }
+              if (fd) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], delete_id); E++; }
+            }
+            p += (w >> 24) & 63u;                                          // (0 is possible: a one-byte alternative of a forward-delete state)
+            hop++;
+            gate = p < seglen ? slack0 + (int)p - (int)E - (int)((fd | direct) << 16) : GATE_DEAD;
+          }
+        }
+      } else break;                 // no lane can step: every chain has left its segment
     }
     if (direct == 0u) staged = E;
     // what the document's Count() and `missing` need beyond the id count of K3 (rare: the document is only looked up when there is something to add)

@@ -93,47 +93,65 @@ __device__ __noinline__ HighOut emit_high_byte(const uint8_t* r, uint32_t fl, ui
 
 // stage the piece (+ margins) and classify every byte; continuation bytes inherit the class of their lead byte.
 // returns the piece length; LDS index of document byte (pb + i) is PMARGIN + i.
+// The staged range is a WINDOW of the wavefront on the raw text (tm_device.h: a buffer resource cut to the document): what lies outside the
+// document reads as 0 - class O - without a compare or a branch per dword (the loop this replaces spent 18 scalar instructions per step on
+// 64-bit range tests and exec masks, on a kernel that is bound by its scalar instructions).
 template <typename LDS>
 __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict__ raw, uint64_t rb, uint64_t re, uint64_t pb, int lane,
                                                const uint8_t* s_cls, const NmTabs& tabs) {
-  for (int i = lane; i < PLDS / 4; i += 64) {
-    const int64_t g = (int64_t)pb - PMARGIN + 4 * i;
-    uint32_t wv = 0;
-    if (g >= (int64_t)rb && g + 4 <= (int64_t)re) __builtin_memcpy(&wv, raw + g, 4);       // whole dword inside the document
-    else {
+  const uint64_t left = re - pb;
+  const uint32_t before = pb != rb ? (uint32_t)PMARGIN : 0u;            // (pb - rb is a multiple of PIECE: the whole margin in front, or none of it)
+  const uint32_t after = left > (uint64_t)(PIECE + PMARGIN) ? (uint32_t)(PIECE + PMARGIN) : (uint32_t)left;
+  const uint32_t a = (uint32_t)PMARGIN - before, e = (uint32_t)PMARGIN + after;      // LDS indices of the first byte of the document in the range, and one past its last
+  const TmWindow win = tm_window(raw + (pb - before), (before + after) & ~3u);        // whole dwords only: a dword that straddles the document's end is outside
+  constexpr int STEPS = (PLDS / 4 + 63) / 64;
+  uint32_t w4[STEPS], high = 0u;
 #pragma unroll
-      for (int q = 0; q < 4; q++) if (g + q >= (int64_t)rb && g + q < (int64_t)re) wv |= (uint32_t)raw[g + q] << (8 * q);
+  for (int s = 0; s < STEPS; s++) w4[s] = tm_window_u32(win, (uint32_t)(4 * (lane + 64 * s)) - a);       // (a is a multiple of 4: the dwords of the range are the dwords of the window)
+#pragma unroll
+  for (int s = 0; s < STEPS; s++) {
+    const int i = lane + 64 * s;
+    if (s < STEPS - 1 || i < PLDS / 4) {
+      const uint32_t v = w4[s];
+      reinterpret_cast<uint32_t*>(L.raw)[i] = v;
+      // four table reads classify a dword of ASCII; a dword with anything else in it is done again below, byte by byte
+      reinterpret_cast<uint32_t*>(L.f)[i] = (uint32_t)s_cls[v & 0x7Fu] | ((uint32_t)s_cls[(v >> 8) & 0x7Fu] << 8) | ((uint32_t)s_cls[(v >> 16) & 0x7Fu] << 16) | ((uint32_t)s_cls[(v >> 24) & 0x7Fu] << 24);
+      high |= v;
     }
-    reinterpret_cast<uint32_t*>(L.raw)[i] = wv;
+  }
+  // the last dword of the document may be a partial one: its bytes one by one (behind the zero the loop above has put there)
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t tail = e & 3u;
+  if ((uint32_t)lane < tail) {
+    const uint32_t x = (e & ~3u) + (uint32_t)lane, bt = raw[pb + x - (uint32_t)PMARGIN];
+    L.raw[x] = (uint8_t)bt;
+    L.f[x] = bt < 0x80u ? s_cls[bt] : (uint8_t)0;
+    high |= bt;
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-  // four bytes per lane and step; a dword of plain ASCII (nearly all of them) is four table reads, anything else goes byte by byte
-  for (int i = lane; i < PLDS / 4; i += 64) {
-    const uint32_t w4 = reinterpret_cast<const uint32_t*>(L.raw)[i];
-    uint32_t f4;
-    if ((w4 & 0x80808080u) == 0u) {
-      f4 = (uint32_t)s_cls[w4 & 0xFFu] | ((uint32_t)s_cls[(w4 >> 8) & 0xFFu] << 8) | ((uint32_t)s_cls[(w4 >> 16) & 0xFFu] << 16) | ((uint32_t)s_cls[w4 >> 24] << 24);
-    } else {
-      f4 = 0;
+  if (__ballot((high & 0x80808080u) != 0u) != 0ull) {
+    // bytes beyond ASCII somewhere in the range (the exception): their dwords again, with the classifier that looks three bytes either way
+#pragma unroll 1
+    for (int i = lane; i < PLDS / 4; i += 64) {
+      const uint32_t v = reinterpret_cast<const uint32_t*>(L.raw)[i];
+      if ((v & 0x80808080u) != 0u) {
+        uint32_t f4 = 0;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int x = 4 * i + q;
-        const uint32_t b = (w4 >> (8 * q)) & 0xFFu;
-        uint32_t fl = 0;                                    // (the three bytes at either end of the staged range are never looked at)
-        if (b < 0x80u) fl = s_cls[b];                       // class of an ASCII byte: one LDS read instead of five range checks
-        else if (x >= 3 && x < PLDS - 3) {
-          // a two-byte character, a three- or four-byte one the pass leaves alone, or NF_BAD
-          fl = classify_high_byte(L.raw + x, tabs);
+        for (int q = 0; q < 4; q++) {
+          const int x = 4 * i + q;
+          const uint32_t b = (v >> (8 * q)) & 0xFFu;
+          uint32_t fl = 0;                                    // (the three bytes at either end of the staged range are never looked at)
+          if (b < 0x80u) fl = s_cls[b];
+          else if (x >= 3 && x < PLDS - 3) fl = classify_high_byte(L.raw + x, tabs);     // a two-byte character, a three- or four-byte one the pass leaves alone, or NF_BAD
+          f4 |= fl << (8 * q);
         }
-        f4 |= fl << (8 * q);
+        reinterpret_cast<uint32_t*>(L.f)[i] = f4;
       }
     }
-    reinterpret_cast<uint32_t*>(L.f)[i] = f4;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  const uint64_t left = re - pb;
   return left > (uint64_t)PIECE ? PIECE : (int)left;
 }
 
@@ -382,6 +400,9 @@ __device__ const NmLut g_norm_lut = nm_make_lut();
 // normalizer are known (k_norm_summary + k_norm_carry have run: the exact path).  CARRY = false (the usual path): no pass before this
 // one — the carries come from the 64 bytes either side of the piece (nm_margin_carries), a piece whose margins cannot tell raises
 // overflow[1] and the exact path runs after all; a piece that finds a byte it cannot normalize marks its document in need_host.
+#ifndef TM_NORM_UNROLL
+#define TM_NORM_UNROLL 2
+#endif
 template <bool CARRY>
 __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rbegin,
                                                     const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
@@ -411,101 +432,109 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, tabs));
   const uint32_t carry = CARRY ? __builtin_amdgcn_readfirstlane((uint32_t)piece_carry[k]) : 0u;
   const int nch = (m + 63) >> 6;
-  // all chunks but the last are whole; the piece boundary m lies in chunk m >> 6 (which is chunk nch when m is a multiple of 64)
-  const unsigned long long v_last = nm_valid(nch - 1, m);
-  const int c_bnd = m >> 6;
   const uint8_t* fl0 = L.f + PMARGIN + lane;       // class byte of byte (64 c + lane) of the piece = fl0[64 c]; chunk -1 and chunk NCH are the margins
-  // (norm_load_piece has classified the LDS bytes from 66 before the piece to 66 after its 1024)
-  unsigned long long w_seed = (carry & 3u) ? 1ull : 0ull, carry_tl = (carry >> 4) & 1u, lx_after = carry_tl;
+  // (norm_load_piece has classified the LDS bytes from 66 before the piece to 66 after its 1024; behind the end of the document they are class O)
+  unsigned long long w_seed = (carry & 3u) ? 1ull : 0ull;
+  const unsigned long long t0_beyond = CARRY ? (unsigned long long)((carry >> 4) & 1u) : 0ull;       // T0 (tm_norm_masks.h) of what lies behind the margin: looked at only when all of the margin is one block
   if (!CARRY) {
     const uint32_t fb = fl0[-64], fa = m == PIECE ? (uint32_t)fl0[64 * NCH] : 0u;       // (a shorter piece is the last of its document: nothing follows)
     uint64_t w_in, tx_after, lx0_after;
     const bool known = nm_margin_carries(__ballot((fb & NF_BLOCK) != 0), __ballot((fb & NF_CLASS) == NC_U), __ballot((fa & NF_BLOCK) != 0), __ballot((fa & NF_CLASS) == NC_L),
                                          &w_in, &tx_after, &lx0_after);
     if (!known && lane == 0) atomicAdd(overflow + 1, 1ull);
-    w_seed = w_in; carry_tl = tx_after; lx_after = lx0_after;
+    w_seed = w_in;
   }
-  // ---- backward sweep: TX[c] = 'C'-lookahead of the block bytes of chunk c (+ the piece boundary bit) ------------------------
-  const unsigned long long bnd_bit = (CARRY ? carry_tl : 0ull) << (m & 63);       // (with margins the chunk behind the piece is a chunk like any other: no boundary bit)
-  unsigned long long TX[NCH + 1];
-  {
-    unsigned long long tx_next = ((m & 63) == 0) ? carry_tl : 0ull, lx_next0 = ((m & 63) == 0) ? lx_after : 0ull;
-#pragma unroll
-    for (int c = NCH; c >= 0; c--) {
-      TX[c] = 0ull;
-      if (c == nch) TX[c] = tx_next;
-      if (c < nch && c < NCH) {
-        const uint32_t fl = fl0[64 * c];
-        uint64_t lx0;
-        TX[c] = nm_backward(__ballot((fl & NF_BLOCK) != 0), __ballot((fl & NF_CLASS) == NC_L), c == nch - 1 ? v_last : ~0ull, c == c_bnd ? bnd_bit : 0ull,
-                            tx_next, lx_next0, &lx0);
-        tx_next = TX[c];
-        lx_next0 = lx0;
-      }
-    }
-  }
-  // ---- forward sweep ---------------------------------------------------------------------------------------------------
+  // ---- ONE sweep, forwards: W carried from chunk to chunk, T from the ballots of the chunk and of the one behind it (nm_t0 / nm_tx) -----------
+  // No masks for the end of the document: the bytes behind it are class O, which take no part in anything and emit themselves - one zero
+  // byte per lane, behind everything else in the output image, and subtracted from the length below.
   typedef TM_LDS_SPACE uint8_t lds_u8;
   const uint32_t out0 = TM_LDS_ADDR(L.out);
   const uint32_t dump = out0 + (uint32_t)SLAB2 + (uint32_t)lane;     // where a lane's "not this byte" stores go
+  const uint32_t lim = out0 + (uint32_t)SLAB2;
   unsigned long long w = w_seed, badm = 0ull;
-  uint32_t pos = 0;
+  uint32_t posabs = out0;                                             // LDS address of the next output byte (wave-uniform)
   bool over = false;
-  unsigned long long Ucur = __ballot((fl0[0] & NF_CLASS) == NC_U);
   uint32_t chC = 'C', chW = 'W', chSP = ' ', chD = 'D';
   TM_KEEP_IN_VGPRS4(chC, chW, chSP, chD);      // four registers for the whole sweep, not four moves per chunk
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    if (c < nch) {
-      // capitals of the next chunk (its first byte may be the capital a trailing space announces); chunk 16 is the six margin bytes
-      const uint32_t fnext = fl0[64 * (c + 1)];
-      const unsigned long long Unext = __ballot((fnext & NF_CLASS) == NC_U);
-      const uint32_t fl = fl0[64 * c], fp = fl0[64 * c - 1], f2 = fl0[64 * c - 2], f4 = fl0[64 * c - 4];
-      const uint32_t b = L.raw[PMARGIN + 64 * c + lane];
-      uint64_t w_out, spC, spW;
-      const unsigned long long V = c == nch - 1 ? v_last : ~0ull;
-      if (!CARRY) badm |= __ballot(fl == NF_BAD) & V;
-      const unsigned long long W = nm_inword(__ballot((fl & NF_BLOCK) != 0), Ucur, V, w, &w_out);
-      nm_space_markers(__ballot((fl & NF_CLASS) == NC_SP), Ucur, Unext, V, TX[c], TX[c + 1], &spC, &spW);
-      w = w_out;
-      // the rule table: index = class | previous class << 3 | class before the apostrophe << 6 | W << 9 | T << 10
-      // (a continuation byte takes no part in the rules as a character of its own: class O here; as the PREVIOUS byte it stands for its character)
-      const uint32_t p2 = (fp & NF_CONT) ? f4 : f2;
-      uint32_t idx = ((fl & NF_CONT) ? (uint32_t)NC_O : (fl & 7u)) | ((fp & 7u) << 3) | ((p2 & 7u) << 6);
-      idx = sel_mask(W, idx | 512u, idx);
-      idx = sel_mask(TX[c], idx | 1024u, idx);
-      const uint32_t code = s_lut[idx];
-      uint32_t len1 = code & 3u;                                         // bytes emitted - 1
-      uint32_t o3 = b | ((code & 4u) << 3);
-      o3 = sel_mask(spC, chC, o3);
-      o3 = sel_mask(spW, chW, o3);
-      uint32_t ysp = chSP, m3 = code >> 8;
-      // Everything a character beyond ASCII needs sits behind ONE test of the chunk and out of line (emit_high_byte): chunks of plain ASCII are
-      // the rule.  E = the lanes that emit at least one byte: V, but for the third lane of a Hangul syllable without a final consonant.
-      unsigned long long E = V;
-      if (__ballot(b >= 0x80u) != 0ull) {
-        if (b >= 0x80u) {
-          const HighOut h = emit_high_byte(L.raw + PMARGIN + 64 * c + lane, fl, code, HighOut{o3, ysp, m3, len1}, tabs);
-          o3 = h.o3; ysp = h.ysp; m3 = h.m3; len1 = h.len1;
-        }
-        E = V & ~__ballot(len1 == 0xFFu);
-        len1 = len1 == 0xFFu ? 0u : len1;
+  const uint8_t* fc = fl0;                      // this lane's class byte in chunk c
+  const uint8_t* rc = L.raw + PMARGIN + lane;   // and its byte
+  uint32_t fl = fc[0];
+  unsigned long long Bcur = __ballot((fl & NF_BLOCK) != 0), Lcur = __ballot((fl & NF_CLASS) == NC_L), Ucur = __ballot((fl & NF_CLASS) == NC_U);
+  int c = 0;
+  auto chunk = [&]() __attribute__((always_inline)) {
+    // the chunk behind this one (chunk NCH is the margin): its capitals (its first byte may be the capital a trailing space announces), and what
+    // a block that reaches the end of this chunk ends in
+    const uint32_t fnext = fc[64];
+    const unsigned long long Bn = __ballot((fnext & NF_BLOCK) != 0), Ln = __ballot((fnext & NF_CLASS) == NC_L), Un = __ballot((fnext & NF_CLASS) == NC_U);
+    // (bit 63 set in what ctz looks at: defined when every byte is in the block, and no compare-and-select when - as good as always - not)
+    unsigned long long t0n = Ln >> __builtin_ctzll(~Bn | (1ull << 63));
+    if (__builtin_expect(Bn == ~0ull, 0)) {       // 64 bytes of one block behind this chunk: the first chunk behind that with anything else in it decides
+      t0n = t0_beyond;
+#pragma unroll 1
+      for (int j = c + 2; j <= NCH; j++) {
+        const uint32_t fj = fl0[64 * j];
+        const unsigned long long Bj = __ballot((fj & NF_BLOCK) != 0), Lj = __ballot((fj & NF_CLASS) == NC_L);
+        if (Bj != ~0ull) { t0n = nm_t0(Bj, Lj, 0ull); break; }
       }
-      const unsigned long long ge2 = __ballot(len1 >= 1u) & V, ge3 = __ballot(len1 >= 2u) & V, ge4 = __ballot(len1 >= 3u) & V;
-      const uint32_t total = (uint32_t)(__builtin_popcountll(E) + __builtin_popcountll(ge2) + __builtin_popcountll(ge3) + __builtin_popcountll(ge4));
-      if (pos + total <= (uint32_t)SLAB2) {
-        // first output byte of the lane = out0 + pos + (bytes of the lanes below); its last byte is len1 further
-        const uint32_t first = mbcnt64(ge4, mbcnt64(ge3, mbcnt64(ge2, mbcnt64(E, out0 + pos))));
-        const uint32_t last = first + len1;
-        *TM_LDS_PTR(lds_u8, sel_mask(E, last, dump)) = (uint8_t)o3;
-        *TM_LDS_PTR(lds_u8, sel_mask(ge2, last - 1u, dump)) = (uint8_t)ysp;
-        *TM_LDS_PTR(lds_u8, sel_mask(ge3, last - 2u, dump)) = (uint8_t)m3;
-        *TM_LDS_PTR(lds_u8, sel_mask(ge4, first, dump)) = (uint8_t)chD;
-      } else over = true;                                   // wave-uniform: the piece does not fit its slab (exact two-pass path)
-      pos += total;
-      Ucur = Unext;
     }
+    const unsigned long long TXc = nm_tx(Bcur, Lcur, t0n);
+    const uint32_t fp = fc[-1], f2 = fc[-2], f4 = fc[-4];
+    const uint32_t b = rc[0];
+    uint64_t w_out, spC, spW;
+    if (!CARRY) badm |= __ballot(fl == NF_BAD);
+    const unsigned long long W = nm_inword(Bcur, Ucur, ~0ull, w, &w_out);
+    nm_space_markers(__ballot((fl & NF_CLASS) == NC_SP), Ucur, Un, ~0ull, TXc, t0n, &spC, &spW);
+    w = w_out;
+    // the rule table: index = class | previous class << 3 | class before the apostrophe << 6 | W << 9 | T << 10
+    // (a continuation byte takes no part in the rules as a character of its own: class O here; as the PREVIOUS byte it stands for its character)
+    const uint32_t p2 = (fp & NF_CONT) ? f4 : f2;
+    uint32_t idx = ((fl & NF_CONT) ? (uint32_t)NC_O : (fl & 7u)) | ((fp & 7u) << 3) | ((p2 & 7u) << 6);
+    idx = sel_mask(W, idx | 512u, idx);
+    idx = sel_mask(TXc, idx | 1024u, idx);
+    const uint32_t code = s_lut[idx];
+    uint32_t len1 = code & 3u;                                         // bytes emitted - 1
+    uint32_t o3 = b | ((code & 4u) << 3);
+    o3 = sel_mask(spC, chC, o3);
+    o3 = sel_mask(spW, chW, o3);
+    uint32_t ysp = chSP, m3 = code >> 8;
+    // Everything a character beyond ASCII needs sits behind ONE test of the chunk and out of line (emit_high_byte): chunks of plain ASCII are
+    // the rule.  E = the lanes that emit at least one byte: all, but for the third lane of a Hangul syllable without a final consonant.
+    unsigned long long E = ~0ull;
+    uint32_t below = posabs + (uint32_t)lane, n = len1 + 1u;           // first output byte of the lane before the extra bytes of the lanes below it; bytes it emits
+    if (__ballot(b >= 0x80u) != 0ull) {
+      if (b >= 0x80u) {
+        const HighOut h = emit_high_byte(rc, fl, code, HighOut{o3, ysp, m3, len1}, tabs);
+        o3 = h.o3; ysp = h.ysp; m3 = h.m3; len1 = h.len1;
+      }
+      E = ~__ballot(len1 == 0xFFu);
+      len1 = len1 == 0xFFu ? 0u : len1;
+      n = sel_mask(E, len1 + 1u, 0u);
+      below = mbcnt64(E, posabs);
+    }
+    const unsigned long long ge2 = __ballot(len1 >= 1u), ge3 = __ballot(len1 >= 2u), ge4 = __ballot(len1 >= 3u);
+    // first output byte of the lane = the bytes of the lanes below behind posabs; its last byte is len1 further; the chunk ends where lane 63 does
+    const uint32_t first = mbcnt64(ge4, mbcnt64(ge3, mbcnt64(ge2, below)));
+    const uint32_t last = first + len1;
+    const uint32_t end = read_lane(first + n, 63);
+    if (end <= lim) {
+      *TM_LDS_PTR(lds_u8, sel_mask(E, last, dump)) = (uint8_t)o3;
+      *TM_LDS_PTR(lds_u8, sel_mask(ge2, last - 1u, dump)) = (uint8_t)ysp;
+      *TM_LDS_PTR(lds_u8, sel_mask(ge3, last - 2u, dump)) = (uint8_t)m3;
+      *TM_LDS_PTR(lds_u8, sel_mask(ge4, first, dump)) = (uint8_t)chD;
+    } else over = true;                                   // wave-uniform: the piece does not fit its slab (exact two-pass path)
+    posabs = end;
+    fl = fnext; Bcur = Bn; Lcur = Ln; Ucur = Un;
+    c++; fc += 64; rc += 64;
+  };
+  // (two chunks per trip: what the chunk behind hands on stays where it is instead of being copied back - five scalar moves and a branch per chunk)
+#pragma unroll 1
+  while (c + TM_NORM_UNROLL <= nch) {
+#pragma unroll
+    for (int u = 0; u < TM_NORM_UNROLL; u++) chunk();
   }
+#pragma unroll 1
+  while (c < nch) chunk();
+  const uint32_t pos = posabs - out0 - (uint32_t)(64 * nch - m);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
   if (!over) {
@@ -515,7 +544,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   }
   if (lane == 0) {
     piece_len[k] = pos;
-    if (pos > (uint32_t)SLAB2) atomicAdd(overflow, 1ull);
+    if (over) atomicAdd(overflow, 1ull);             // (with the zero bytes of a last chunk counted in: a piece within 63 bytes of its slab's end may take the exact path for nothing)
     if (!CARRY && badm != 0ull) need_host[d] = 1;      // (every writer writes 1; the piece lengths of such a document are zeroed by k_norm_bad)
   }
 }

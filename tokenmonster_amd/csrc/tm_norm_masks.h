@@ -174,6 +174,8 @@ TM_HD uint64_t nm_brev(uint64_t x) { return __builtin_bitreverse64(x); }   // s_
 // the carry of M + S ripples from a seed to the end of its run
 TM_HD uint64_t nm_flood_up(uint64_t M, uint64_t S) { S &= M; return ((M ^ (M + S)) | S) & M; }
 TM_HD uint64_t nm_flood_down(uint64_t M, uint64_t S) { return nm_brev(nm_flood_up(nm_brev(M), nm_brev(S))); }
+// the same for seeds that are known to lie inside M (one instruction less)
+TM_HD uint64_t nm_flood_down_inside(uint64_t M, uint64_t S) { const uint64_t m = nm_brev(M), s = nm_brev(S); return nm_brev(((m ^ (m + s)) | s) & m); }
 // bit i = bit (i + 1) of the byte stream (next0 = bit 0 of the following chunk)
 TM_HD uint64_t nm_shr1(uint64_t cur, uint64_t next0) { return (cur >> 1) | (next0 << 63); }
 // valid-byte mask of chunk c of a piece of m bytes, and the bit of absolute position m inside chunk c (0 if elsewhere)
@@ -193,6 +195,17 @@ TM_HD uint64_t nm_backward(uint64_t B, uint64_t L, uint64_t V, uint64_t bnd, uin
   *lx0 = Lx & 1ull;
   return T | bnd;
 }
+
+// The same T WITHOUT a sweep from the end of the piece: what a chunk needs to know about everything behind it is one bit,
+//   T0(next chunk) = "the first byte at or after the next chunk's first byte that is not in a block is a lower-case letter"
+// (that byte decides T of a block that reaches this chunk's end), and T0 of a chunk is a function of its own two ballots unless all 64 of
+// its bytes are in one block - only then of the chunk behind it (`beyond`).  k_norm_emit2 computes TX of a chunk from the ballots of the
+// chunk and of the one behind it as it goes forward; bytes behind the end of the text are class O (no block, no letter): T0 = 0 there.
+TM_HD uint64_t nm_t0(uint64_t B, uint64_t L, uint64_t beyond) {
+  const uint64_t nb = ~B;
+  return nb == 0ull ? (beyond & 1ull) : ((L >> __builtin_ctzll(nb)) & 1ull);
+}
+TM_HD uint64_t nm_tx(uint64_t B, uint64_t L, uint64_t t0_next) { return nm_flood_down_inside(B, B & nm_shr1(L, t0_next & 1ull)); }
 
 // Forward sweep over a chunk: W of every byte.  B / U: ballots "in a block" / "capital" (masked to the piece here); w_in: W of byte 0
 // of the chunk; *w_out: W of byte 0 of the next chunk.

@@ -67,6 +67,26 @@ __device__ __forceinline__ uint32_t add_mask_bit(uint32_t a, unsigned long long 
   return r;
 #endif
 }
+// the value a wave-uniform lane holds, as a scalar (v_readlane)
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) {
+#ifdef TM_EMU
+  return __shfl(v, l);
+#else
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+#endif
+}
+// A wavefront's window on global memory: a buffer resource (base and size wave-uniform), so that the range check is the hardware's - a dword
+// load outside [base, base + bytes) returns 0 and costs no branch and no 64-bit compare (offsets are unsigned: "before the window" is
+// outside too).  `bytes` a multiple of 4 and offsets multiples of 4, so that no dword is partly inside.
+#ifdef TM_EMU
+struct TmWindow { const uint8_t* base; uint32_t bytes; };
+static inline TmWindow tm_window(const void* base, uint32_t bytes) { return TmWindow{(const uint8_t*)base, bytes}; }
+static inline uint32_t tm_window_u32(const TmWindow& w, uint32_t off) { uint32_t v = 0; if (off < w.bytes && w.bytes - off >= 4u) __builtin_memcpy(&v, w.base + off, 4); return v; }
+#else
+typedef __amdgpu_buffer_rsrc_t TmWindow;
+__device__ __forceinline__ TmWindow tm_window(const void* base, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ uint32_t tm_window_u32(TmWindow w, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(w, (int)off, 0, 0); }
+#endif
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask, uint32_t acc) {      // acc + #set bits of mask below the lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, acc));
 }

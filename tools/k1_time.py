@@ -81,6 +81,11 @@ def one(lib, mbytes, config="englishcode-32000-consistent", e2e=False, score=Fal
             N.check(N.lib.tm_batch_run(batch, None))
         N.check(N.lib.tm_batch_totals(batch, C.byref(ntok), C.byref(nmiss)))
         step_ms = (time.perf_counter() - t1) / reps * 1e3
+        # the normalizer alone (tm_batch_normalize synchronizes): median of 2 x reps calls
+        tn = []
+        for _ in range(2 * reps):
+            t1 = time.perf_counter(); N.check(N.lib.tm_batch_normalize(batch, None)); tn.append((time.perf_counter() - t1) * 1e3)
+        norm_ms = sorted(tn)[len(tn) // 2]
     else:
         N.check(N.lib.tm_batch_upload(batch, N.ptr(text), N.ptr(offs), nd))
     ms = (C.c_float * N.TM_NUM_KERNELS)()
@@ -97,7 +102,7 @@ def one(lib, mbytes, config="englishcode-32000-consistent", e2e=False, score=Fal
     h = hashlib.md5(ids[: int(ntok.value)].tobytes() + toff.tobytes()).hexdigest()
     names = [N.lib.tm_kernel_name(k).decode() for k in range(N.TM_NUM_KERNELS)]
     print("%-40s %s %d MiB: %s%s  tokens %d  ids md5 %s  (%.1f s)" % (label, name, mbytes, " ".join("%s %.3f" % (n, x) for n, x in zip(names, acc)),
-          "" if step_ms is None else "  | end-to-end step %.3f ms = %.2f GB/s raw" % (step_ms, raw.size / step_ms / 1e6), int(ntok.value), h[:12], time.time() - t0), flush=True)
+          "" if step_ms is None else "  | end-to-end step %.3f ms = %.2f GB/s raw, normalize alone %.3f ms" % (step_ms, raw.size / step_ms / 1e6, norm_ms), int(ntok.value), h[:12], time.time() - t0), flush=True)
     N.lib.tm_batch_free(batch)
 
 

@@ -50,10 +50,9 @@ bool is_block(uint32_t cls) { return (cls & NF_BLOCK) != 0; }
 
 // what k_norm_emit2 does for one piece: returns the bytes
 static const NmLut kLut = nm_make_lut();
-// (margins == true: w_in / tx_after / lx_after come from nm_margin_carries, the piece boundary carries no bit of its own: k_norm_emit2<false>)
-void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, int pb, int m, bool w_in, uint64_t tx_after, uint64_t lx_after, bool margins, bool lower_all,
+// (t0_beyond: nm_t0 of what lies behind the 64 bytes of margin after the piece - the exact path's carry; 0 when the margins are all there is: k_norm_emit2<false>)
+void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, int pb, int m, bool w_in, uint64_t t0_beyond, bool lower_all,
                 std::vector<uint8_t>& out) {
-  const bool carry_tl = !margins && (tx_after & 1ull);
   const int n = (int)d.size();
   // class byte at piece-relative position rel, as the kernel's LDS holds it: classified from six bytes before the piece to five
   // after its 1024; bytes outside the document read as class O
@@ -76,25 +75,26 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
   auto is_u = [](uint32_t fl) { return (fl & NF_CLASS) == NC_U; };
   auto is_sp = [](uint32_t fl) { return (fl & NF_CLASS) == NC_SP; };
   const int nch = (m + 63) / 64;
-  uint64_t TX[18] = {0};
-  {
-    uint64_t tx_next = m % 64 == 0 ? (margins ? tx_after : (carry_tl ? 1ull : 0ull)) : 0ull, lx_next0 = m % 64 == 0 ? (margins ? lx_after : tx_next) : 0ull;   // boundary exactly at the start of chunk nch
-    if (nch <= 16) TX[nch] = tx_next;
-    for (int c = nch - 1; c >= 0; c--) {
-      uint64_t lx0;
-      TX[c] = nm_backward(ballot(c, is_b), ballot(c, is_l), nm_valid(c, m), (carry_tl && !margins) ? nm_boundary(c, m) : 0ull, tx_next, lx_next0, &lx0);
-      tx_next = TX[c];
-      lx_next0 = lx0;
-    }
+  // T of chunk c as the kernel finds it going forwards: from the ballots of the chunk and T0 of the one behind it
+  uint64_t TX[18] = {0}, T0N[18] = {0};
+  for (int c = 0; c < nch; c++) {
+    const uint64_t Bn = ballot(c + 1, is_b);
+    uint64_t t0n;
+    if (Bn == ~0ull) {
+      t0n = t0_beyond & 1ull;
+      for (int j = c + 2; j <= 16; j++) { const uint64_t Bj = ballot(j, is_b); if (Bj != ~0ull) { t0n = nm_t0(Bj, ballot(j, is_l), 0ull); break; } }
+    } else t0n = nm_t0(Bn, ballot(c + 1, is_l), 0ull);
+    T0N[c] = t0n;
+    TX[c] = nm_tx(ballot(c, is_b), ballot(c, is_l), t0n);
   }
   uint64_t w = w_in ? 1ull : 0ull;
   uint64_t Ucur = ballot(0, is_u);
   for (int c = 0; c < nch; c++) {
     const uint64_t Unext = ballot(c + 1, is_u);
     uint64_t w_out, spC, spW;
-    const uint64_t V = nm_valid(c, m);
-    const uint64_t W = nm_inword(ballot(c, is_b), Ucur, V, w, &w_out);
-    nm_space_markers(ballot(c, is_sp), Ucur, Unext, V, TX[c], TX[c + 1], &spC, &spW);
+    const uint64_t V = nm_valid(c, m);      // (the kernel lets the lanes behind the end of the document emit their zero byte behind everything else and subtracts them)
+    const uint64_t W = nm_inword(ballot(c, is_b), Ucur, ~0ull, w, &w_out);
+    nm_space_markers(ballot(c, is_sp), Ucur, Unext, ~0ull, TX[c], T0N[c], &spC, &spW);
     w = w_out;
     for (int i = 0; i < 64; i++) {
       const uint64_t bit = 1ull << i;
@@ -159,10 +159,10 @@ bool check_doc(const std::vector<uint8_t>& d, uint32_t norm_flag, uint64_t* skip
     if (nm_margin_carries(Bb, Ub, Ba, La, &w_m, &tx_a, &lx_a)) {
       g_margin_ok++;
       if ((w_m != 0) != w_in) { fprintf(stderr, "MARGIN: inWord seed %d, the document says %d (piece at %d)\n", (int)w_m, (int)w_in, pb); return false; }
-      emit_piece(d, f, pb, m, w_m != 0, tx_a, lx_a, true, lower_all, got);
+      emit_piece(d, f, pb, m, w_m != 0, 0ull, lower_all, got);
     } else {
       g_margin_unknown++;
-      emit_piece(d, f, pb, m, w_in, carry_tl ? 1ull : 0ull, 0ull, false, lower_all, got);
+      emit_piece(d, f, pb, m, w_in, carry_tl ? 1ull : 0ull, lower_all, got);
     }
   }
   uint8_t* exp = nullptr; size_t exp_n = 0;
