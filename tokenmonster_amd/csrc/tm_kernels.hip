@@ -887,7 +887,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
     // the segment (most (p,1) states are unreachable and finished from the start)
     constexpr int NS = 2 * SEG / 64, N0 = SEG / 64;
     uint32_t ja[NS];
-    bool pend[NS];
 #pragma unroll
     for (int it = 0; it < N0; it++) {
       const int p = it * 64 + lane;
@@ -896,39 +895,38 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       if (TM_DBG_ON(dbg & 0x400000)) ja[N0 + it] = 0x80000000u | (JNONE << JF);      // (devel bit 22: no forward-delete states in step C - what their four slots per lane cost)
       else { ja[N0 + it] = first_hop(r1[it], p, 1u); J[J_PLANE + p] = ja[N0 + it]; }
     }
-    bool any0 = false, any1 = false;
-#pragma unroll
-    for (int k = 0; k < NS; k++) { pend[k] = (int)ja[k] >= 0; if (k < N0) any0 |= pend[k]; else any1 |= pend[k]; }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
-    // One round: every pending state composes itself with the state it points at.  The LDS reads of a round are issued
-    // back to back (one LDS latency per round); the (p,1) states are rarely pending and skipped as a group.  The entry
-    // states sit at the start of the segment and have the longest chains, so "nothing pending" is also when they are done.
-    for (int round = 0; round < 12 && __any(any0 || any1); round++) {
+    // One round: every pending state (bit 31 clear: it still points inside the segment) composes itself with the state it points at.  The
+    // LDS reads of a round are issued back to back (one LDS latency per round); the (p,1) states are rarely pending and skipped as a group.
+    // The entry states sit at the start of the segment and have the longest chains, so "nothing pending" is also when they are done.
+    // No branch per state: a finished state reads its own entry and writes back what it holds.  (As `if (pend[k])` blocks - three scalar
+    // instructions around every state, twelve rounds unrolled - this was a third of the kernel's code and 268 of its 1 229 scalar
+    // instructions per segment; in select form it is 111 vector instructions more and the kernel's time is the same, measured:
+    // K1 does not wait for its scalar unit.  Kept for the smaller code.)
+    const uint32_t own = jaddr + 4u * (uint32_t)lane;         // LDS address of the lane's state 0; state k is 256 bytes further, the (p,1) states J_PLANE words
+    auto st_j = [](uint32_t a, uint32_t v) { *TM_LDS_PTR(lds_u32, a) = v; };
+    for (int round = 0; round < 12; round++) {
+      uint32_t all0 = ja[0], all1 = ja[N0];
+#pragma unroll
+      for (int k = 1; k < N0; k++) { all0 &= ja[k]; all1 &= ja[N0 + k]; }
+      const unsigned long long m0 = __builtin_amdgcn_ballot_w64((int)all0 >= 0), m1 = __builtin_amdgcn_ballot_w64((int)all1 >= 0);
+      if ((m0 | m1) == 0ull) break;
       uint32_t bn[N0];
 #pragma unroll
-      for (int k = 0; k < N0; k++) if (pend[k]) bn[k] = ld_j(ja[k] >> JF);
-      any0 = false;
+      for (int k = 0; k < N0; k++) bn[k] = ld_j((int)ja[k] >= 0 ? ja[k] >> JF : own + 256u * (uint32_t)k);
 #pragma unroll
       for (int k = 0; k < N0; k++) {
-        if (pend[k]) {
-          ja[k] = (ja[k] & JCNT) + bn[k];              // (a 16-bit count cannot overflow: <= 512 ids per segment)
-          J[k * 64 + lane] = ja[k];
-          pend[k] = (int)ja[k] >= 0;
-          any0 |= pend[k];
-        }
+        ja[k] = (int)ja[k] >= 0 ? (ja[k] & JCNT) + bn[k] : ja[k];              // (a 12-bit count cannot overflow: <= 512 ids per segment)
+        st_j(own + 256u * (uint32_t)k, ja[k]);
       }
-      if (__any(any1)) {
-        any1 = false;
+      if (m1 != 0ull) {
 #pragma unroll
-        for (int k = N0; k < NS; k++) {
-          if (pend[k]) {
-            const uint32_t b1 = ld_j(ja[k] >> JF);
-            ja[k] = (ja[k] & JCNT) + b1;
-            J[J_PLANE + (k - N0) * 64 + lane] = ja[k];
-            pend[k] = (int)ja[k] >= 0;
-            any1 |= pend[k];
-          }
+        for (int k = 0; k < N0; k++) bn[k] = ld_j((int)ja[N0 + k] >= 0 ? ja[N0 + k] >> JF : own + 4u * (uint32_t)J_PLANE + 256u * (uint32_t)k);
+#pragma unroll
+        for (int k = 0; k < N0; k++) {
+          ja[N0 + k] = (int)ja[N0 + k] >= 0 ? (ja[N0 + k] & JCNT) + bn[k] : ja[N0 + k];
+          st_j(own + 4u * (uint32_t)J_PLANE + 256u * (uint32_t)k, ja[N0 + k]);
         }
       }
       __builtin_amdgcn_wave_barrier();
