@@ -362,6 +362,14 @@ def test_device_normalizer_matches_host_and_reference():
                 assert (goff == eoff).all(), "flags %d" % flags
                 assert got.size == exp.size and (got == exp).all(), "flags %d" % flags
                 assert nfb < (offs_in.size - 1) // 5 + 8          # most documents are handled on the device
+                if flags == 0:
+                    # the same with a small grid: every wavefront of k_norm_emit2 takes several pieces, one after the other
+                    os.environ["TM_NORM_WG_PER_CU"] = "1"
+                    try:
+                        got1, goff1, _ = v.normalize_packed_device(text_in, offs_in)
+                    finally:
+                        del os.environ["TM_NORM_WG_PER_CU"]
+                    assert (goff1 == eoff).all() and got1.size == exp.size and (got1 == exp).all()
         finally:
             N.lib.tm_debug_flags(old)
     # lower-case-everything flag with capcode 2 (capitals are classified as letters)

@@ -423,11 +423,12 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   // the wavefront index is made visibly wave-uniform: everything derived from it (piece, length, carries) then lives in scalar
   // registers, and so does the mask algebra below
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
-  if (k >= npieces) return;
   PieceLds2& L = s_l[wv];
+  // A wavefront takes piece after piece (the grid: norm_grid()): the tables above are staged once per workgroup, not once per four pieces.
+#pragma unroll 1
+  for (uint64_t k = (uint64_t)blockIdx.x * 4 + wv; k < npieces; k += (uint64_t)gridDim.x * 4) {
   const uint32_t d = piece_doc[k];
-  if (CARRY && need_host[d]) { if (lane == 0) piece_len[k] = 0; return; }
+  if (CARRY && need_host[d]) { if (lane == 0) piece_len[k] = 0; continue; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
   const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, tabs));
   const uint32_t carry = CARRY ? __builtin_amdgcn_readfirstlane((uint32_t)piece_carry[k]) : 0u;
@@ -546,6 +547,8 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
     piece_len[k] = pos;
     if (over) atomicAdd(overflow, 1ull);             // (with the zero bytes of a last chunk counted in: a piece within 63 bytes of its slab's end may take the exact path for nothing)
     if (!CARRY && badm != 0ull) need_host[d] = 1;      // (every writer writes 1; the piece lengths of such a document are zeroed by k_norm_bad)
+  }
+  __builtin_amdgcn_wave_barrier();                     // (the output image is read above and written again by the next piece)
   }
 }
 
@@ -792,6 +795,19 @@ void pack_text(tm_batch* b, hipStream_t st) {
 extern "C" {
 
 
+// The grid of k_norm_emit2: its wavefronts take piece after piece, so that the tables are staged once per workgroup instead of once per four
+// pieces - but NOT one workgroup per slot of the device (6 per compute unit: 25 KB of LDS each): the dispatcher does not spread those evenly, and
+// a compute unit that got a seventh finishes late.  Measured per 512 MiB (MI355X, 256 compute units): one piece per wavefront 1.54 ms; 6 workgroups
+// per compute unit 1.58; 12: 1.49; 24: 1.43; 48 - 96: 1.365; 256: 1.43.  (TM_NORM_WG_PER_CU: the sweep.)
+static uint32_t norm_grid() {
+  const char* e = getenv("TM_NORM_WG_PER_CU");
+  const int v = e ? atoi(e) : 0;
+  const uint32_t wg_per_cu = v > 0 ? (uint32_t)v : 64u;
+  int dev = 0, cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+  return (uint32_t)cu * wg_per_cu;
+}
+
 int tm_batch_normalize(tm_batch* b, void* stream) {
   if (!b) return set_error(TM_E_INVALID, "null argument");
   const tm_vocab* v = b->vocab;
@@ -819,6 +835,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, b->d_raw_off, nd, b->d_doc_npiece, b->d_need_host, ninfo);
   scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
   const uint32_t pgrid = (uint32_t)((np + 3) / 4);
+  const uint32_t egrid = std::min(pgrid, norm_grid());       // k_norm_emit2: its wavefronts take piece after piece
   if (np > 0) launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
   unsigned long long h_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // The usual path is ONE pass over the raw text: k_norm_emit2<false> takes the carries of a piece from the 64 bytes either side of it and
@@ -834,7 +851,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   bool pre = false;
   uint64_t pre_bytes = 0;
   if (fast) {
-    TM_LAUNCH(k_norm_emit2<false>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
+    TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
                                                b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
     TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
     scan_u32(b->d_piece_len, np, b->d_scan_tmp, reinterpret_cast<uint64_t*>(ninfo + 5), b->d_piece_off, st);      // (the total lands beside the info words: one copy brings everything)
@@ -882,7 +899,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   double f1 = now(), f2 = 0, f3 = 0, f4 = 0;
   // the exact path: the device normalizes its documents with the carries given (one pass into per-piece slabs, lengths on the side) ...
   if (!fast && np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
-    TM_LAUNCH(k_norm_emit2<true>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
+    TM_LAUNCH(k_norm_emit2<true>, egrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
                                               b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
   else if (!fast && np > 0)           // capcode 0, or debug bit 8: the per-lane version of the rules
     TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
