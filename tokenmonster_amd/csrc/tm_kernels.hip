@@ -1345,44 +1345,52 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
     uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0, direct = 0, hop = 0;
     // gate >= 0 <=> the lane may take the straight-line step: (p, 0) state, staging, and the two slots a step may need are free in front
     // of the word being read (gate = free slots - 2 - (fd | direct) << 16); GATE_DEAD: the chain has left the segment (or the lane has none).
-    // ONE register says which of the three a lane is, and a round costs two compares and two branches beside its step: fast lanes step
-    // under their mask, the general step is entered only when some lane is in (GATE_DEAD, 0), and the loop ends with the first round in
-    // which no lane did anything.  (As ballots of p < seglen and gate < 0 combined into alive / slow / fast masks the bookkeeping of a round
-    // was 20 instructions beside the 26 of the step, on a kernel that is bound by instruction issue with 8 lanes at work.)
+    // ONE register says which of the three a lane is.
     constexpr int GATE_DEAD = -(1 << 24);
     const int slack0 = (int)SLACK - 2 - (int)stage_after;
     int gate = p < seglen ? slack0 + (int)p - (int)(fd << 16) : GATE_DEAD;
     const uint32_t nounk = no_id == ID_NONE ? 1u : 0u;
+    // the straight-line step of one lane
+    auto fast_step = [&]() __attribute__((always_inline)) {
+      uint32_t id, fdn, miss, adv;
+      if (NARROW) {
+        const uint32_t m8 = rowm[SLACK + p];
+        id = rowa[SLACK + p];                                          // (a character without a token carries the unk id in the id plane, if there is one)
+        miss = m8 >> 7; fdn = (m8 >> 6) & 1u; adv = m8 & 63u;
+      } else {
+        const uint32_t w = row[SLACK + p];
+        if (w == R_INVALID) atomicOr(error_flag, 2u);                  // (never on a chain K1 / K3 produced: T(p,0) exists for every p < seglen; the walk ends, adv = 63)
+        miss = w >> 31; fdn = (w >> 30) & 1u; adv = (w >> 24) & 63u;
+        id = w & ID_NONE;
+      }
+      const uint32_t has = 1u - (miss & nounk);
+      if (NARROW) { rowa[E] = (uint16_t)id; E += has; rowa[E] = (uint16_t)delete_id; }
+      else { row[E] = id; E += has; row[E] = delete_id; }
+      E += fdn;
+      gate += (int)adv - (int)(fdn * 0x10001u + has);                    // one slot per id, and out of the straight-line steps while fd' is set
+      nfd += fdn;
+      nmiss += miss;
+      fd = fdn;
+      p += max(adv, 1u);                                               // (a (p, 0) state always advances — also on a row that is not one: the walk ends)
+      gate = p < seglen ? gate : GATE_DEAD;
+    };
     for (;;) {
-      // (the straight-line rounds are a loop of their own: with the general step inside it the compiler copies nine registers out of and
-      // back into their places on every round)
-      for (;;) {
-      if (__builtin_amdgcn_ballot_w64(gate >= 0) == 0ull) break;
+      // The straight-line rounds are a loop of their own, entered by the lanes that can take them and left when the first of THEM cannot any
+      // more (its chain has left the segment, or it needs the general step: gate < 0 either way): inside, a round is the step, one compare and
+      // one branch - no lane mask to set and restore, no second question.  A wavefront leaves this loop a dozen times in its life.  (The
+      // kernel's time is its scalar instructions plus half its vector instructions - profiles/r05_issue_model.txt -, and with the masks inside
+      // the loop a round was 11 scalar instructions beside its 27 vector ones.)
+#ifndef TM_EMU
       if (gate >= 0) {
-        uint32_t id, fdn, miss, adv;
-        if (NARROW) {
-          const uint32_t m8 = rowm[SLACK + p];
-          id = rowa[SLACK + p];                                          // (a character without a token carries the unk id in the id plane, if there is one)
-          miss = m8 >> 7; fdn = (m8 >> 6) & 1u; adv = m8 & 63u;
-        } else {
-          const uint32_t w = row[SLACK + p];
-          if (w == R_INVALID) atomicOr(error_flag, 2u);                  // (never on a chain K1 / K3 produced: T(p,0) exists for every p < seglen; the walk ends, adv = 63)
-          miss = w >> 31; fdn = (w >> 30) & 1u; adv = (w >> 24) & 63u;
-          id = w & ID_NONE;
-        }
-        const uint32_t has = 1u - (miss & nounk);
-        if (NARROW) { rowa[E] = (uint16_t)id; E += has; rowa[E] = (uint16_t)delete_id; }
-        else { row[E] = id; E += has; row[E] = delete_id; }
-        E += fdn;
-        gate += (int)adv - (int)(fdn * 0x10001u + has);                    // one slot per id, and out of the straight-line steps while fd' is set
-        nfd += fdn;
-        nmiss += miss;
-        fd = fdn;
-        p += max(adv, 1u);                                               // (a (p, 0) state always advances — also on a row that is not one: the walk ends)
-        gate = p < seglen ? gate : GATE_DEAD;
+        do fast_step(); while (__builtin_amdgcn_ballot_w64(gate < 0) == 0ull);       // (a ballot of the lanes in the loop)
       }
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64((uint32_t)gate > (uint32_t)GATE_DEAD) != 0ull, 0)) break;      // a lane in (GATE_DEAD, 0)
+#else
+      // (tools/emu: wave-level operations are meeting points of ALL lanes of a wavefront, so the lanes that stay outside go round too)
+      if (__builtin_amdgcn_ballot_w64(gate >= 0) != 0ull) {
+        const bool in = gate >= 0;
+        do { if (in) fast_step(); } while (__builtin_amdgcn_ballot_w64(in && gate < 0) == 0ull);
       }
+#endif
       const bool general = (uint32_t)gate > (uint32_t)GATE_DEAD;      // GATE_DEAD < gate < 0 (as unsigned numbers these lie above everything else)
       if (__builtin_amdgcn_ballot_w64(general) != 0ull) {
         if (general) {
@@ -1407,7 +1415,7 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
             gate = p < seglen ? slack0 + (int)p - (int)E - (int)((fd | direct) << 16) : GATE_DEAD;
           }
         }
-      } else break;                 // no lane can step: every chain has left its segment
+      } else if (__builtin_amdgcn_ballot_w64(gate >= 0) == 0ull) break;                 // no lane can step: every chain has left its segment
     }
     if (direct == 0u) staged = E;
     // what the document's Count() and `missing` need beyond the id count of K3 (rare: the document is only looked up when there is something to add)
