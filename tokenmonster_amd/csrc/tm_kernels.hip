@@ -1377,9 +1377,9 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
     for (;;) {
       // The straight-line rounds are a loop of their own, entered by the lanes that can take them and left when the first of THEM cannot any
       // more (its chain has left the segment, or it needs the general step: gate < 0 either way): inside, a round is the step, one compare and
-      // one branch - no lane mask to set and restore, no second question.  A wavefront leaves this loop a dozen times in its life.  (The
-      // kernel's time is its scalar instructions plus half its vector instructions - profiles/r05_issue_model.txt -, and with the masks inside
-      // the loop a round was 11 scalar instructions beside its 27 vector ones.)
+      // one branch - no lane mask to set and restore, no second question.  A wavefront leaves this loop a dozen times in its life.  (With the
+      // masks inside the loop a round was 11 scalar instructions beside its 27 vector ones; what that bought, and what it did not, is in
+      // profiles/r05_issue_model.txt.)
 #ifndef TM_EMU
       if (gate >= 0) {
         do fast_step(); while (__builtin_amdgcn_ballot_w64(gate < 0) == 0ull);       // (a ballot of the lanes in the loop)
@@ -1663,7 +1663,7 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store, bool rezero = f
     launch_seg_params(b, st);
     const uint32_t stage_after = (debug_flags() & 1024) ? 512u : 0u;
     if (r0_narrow(b))
-      TM_LAUNCH(k_emit_tiles<true>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
+      TM_LAUNCH(k_emit_tiles<true>, (uint32_t)((nseg + TS - 1) / TS), 64, (getenv("TM_K4_EXTRA_LDS") ? atoi(getenv("TM_K4_EXTRA_LDS")) : 0), st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
                                                                          b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
     else
       TM_LAUNCH(k_emit_tiles<false>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
