@@ -236,8 +236,10 @@ __global__ void k_norm_carry(const uint32_t* __restrict__ piece_sum, const uint6
 }
 
 // MODE 0: normalized length of every piece.  MODE 1: the bytes, packed at piece_off.  MODE 2: the bytes into the piece's
-// private slab (SLAB bytes apart; a piece that would not fit raises the overflow flag) and the length — the common
-// one-pass path; k_norm_compact then packs the slabs.
+// private slab (SLAB bytes apart; a piece that would not fit raises the overflow flag) and the length.  MODE 3: a vocabulary WITHOUT
+// capcode in one pass, as k_norm_emit2<false> is for capcode 2: nothing is known about the documents beforehand (no k_norm_summary /
+// k_norm_carry: without capcode a byte's output depends on nothing but its character), the bytes go into the slabs, and a piece that finds
+// a byte it cannot normalize marks its document in need_host.
 constexpr int SLAB = 2 * PIECE;
 static_assert(SLAB == SLAB_BYTES, "k_match_branch stages the text from these slabs");
 template <int MODE>
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
                                                    const uint64_t* __restrict__ rend, const uint32_t* __restrict__ piece_doc,
                                                    const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t capcode,
                                                    uint32_t lower_all, const uint8_t* __restrict__ piece_carry,
-                                                   const uint8_t* __restrict__ need_host, uint32_t* __restrict__ piece_len,
+                                                   uint8_t* __restrict__ need_host, uint32_t* __restrict__ piece_len,
                                                    const uint64_t* __restrict__ piece_off, uint8_t* __restrict__ out,
                                                    unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two) {
   constexpr bool WRITE = MODE != 0;
@@ -260,14 +262,16 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
   if (k >= npieces) return;
   PieceLds& L = s_l[wv];
   const uint32_t d = piece_doc[k];
-  if (need_host[d]) { if (MODE != 1 && lane == 0) piece_len[k] = 0; return; }
+  if (MODE != 3 && need_host[d]) { if (MODE != 1 && lane == 0) piece_len[k] = 0; return; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
   const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls, tabs);
-  uint8_t* dst = MODE == 1 ? out + piece_off[k] : (MODE == 2 ? out + k * (uint64_t)SLAB : nullptr);
-  if (capcode != 2) {                                       // no capcode: same length, only the lower-case flag applies
+  uint8_t* dst = MODE == 1 ? out + piece_off[k] : (MODE >= 2 ? out + k * (uint64_t)SLAB : nullptr);
+  if (capcode != 2 || MODE == 3) {                          // no capcode: same length, only the lower-case flag applies
     if (MODE != 1 && lane == 0) piece_len[k] = (uint32_t)m;
+    bool bad = false;
     if (WRITE) for (int i = lane; i < m; i += 64) {
       const int x = PMARGIN + i;
+      if (MODE == 3) bad |= L.f[x] == NF_BAD;
       uint32_t b = L.raw[x], y = 0, m3 = 0;
       if (lower_all && b - 'A' < 26u) b |= 0x20u;
       const uint32_t bm1 = L.raw[x - 1];
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
       else if (nm_cont_byte(b) && nm_two_lead(bm1)) (void)nm_two_out(nm_two_get(tabs, nm_two_index(bm1, b)), true, false, false, &b, &y, &m3);
       dst[i] = (uint8_t)b;
     }
+    if (MODE == 3 && __any(bad) && lane == 0) need_host[d] = 1;      // (every writer writes 1; the piece lengths of such a document are zeroed by k_norm_bad)
     return;
   }
   const uint32_t carry = piece_carry[k];
@@ -842,7 +847,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   // finds the documents that need the host normalizer as it goes.  A piece whose margins cannot tell (a run of 64 digits / apostrophes /
   // capitals across a piece boundary) or whose output outgrows its slab sends the batch through the exact path after all: summaries of the
   // pieces, carries per document, then the same emit kernel with the carries given.
-  bool fast = np > 0 && capcode == 2 && normalize_on_device(capcode, norm_flag) && !(tm_debug_flags(-1) & 256);
+  bool fast = np > 0 && (capcode == 2 || capcode == 0) && normalize_on_device(capcode, norm_flag) && !(tm_debug_flags(-1) & 256);
   // ... and ONE trip to the host: the whole device part — the pass, the scan of the piece lengths, the compaction, the documents' ranges
   // and segment counts — is enqueued before anything comes back, and what comes back is everything at once: how many documents need the
   // host normalizer, whether a piece was undecided or outgrew its slab, the normalized size, the segment and long-document counts.  (A
@@ -851,8 +856,12 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   bool pre = false;
   uint64_t pre_bytes = 0;
   if (fast) {
-    TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
-                                               b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
+    if (capcode == 2)
+      TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
+                                                 b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
+    else
+      TM_LAUNCH(k_norm_emit<3>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+                                            nullptr, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
     TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
     scan_u32(b->d_piece_len, np, b->d_scan_tmp, reinterpret_cast<uint64_t*>(ninfo + 5), b->d_piece_off, st);      // (the total lands beside the info words: one copy brings everything)
     // NO compaction pass here: in the usual case the text stays in the slabs and k_match_branch stages its segments from there (k_seg_src) —
