@@ -57,6 +57,7 @@ const inputs = [];
  'A'.repeat(200) + 'b', 'A'.repeat(200), 'a' + 'B'.repeat(130) + ' ' + 'C'.repeat(70) + 'd', 'café Über', ' en quad',
  'Hello World', 'HELLO WORLD', 'hello WORLD again', 'THE QUICK brown FOX', "DON'T STOP", "I'M OK", 'O’NEIL', "ROCK'N'ROLL", 'A-B', 'A.B.C.',
  'MiXeD cAsE', 'x1Y2z3', '3D', '2ND', 'ÉCOLE', 'École', 'ÜBER', 'İ', 'İstanbul', 'ǅ', 'STRASSE', 'Ⅷ', 'ΑΒΓ αβγ', 'ДА нет', '1st 2ND 3Rd',
+ 'Bϒa', "B'ϔ0Ba", 'BϔBa', 'ϒa', 'Bϒ', 'ϓΑβ',       // capitals without a lower-case form (round 5: found by tools/norm_masks_check.cpp, seed 21)
  ' W', 'C D W', 'DW', ' D', 'a  B', 'a\tB', 'a\nB', "'A", "'a", "1'a", "a'1", 'áB', 'Áb', 'ÁB', 'Á', 'ÁB', 'Áb',
 ].forEach(s => inputs.push(s));
 for (let i = 0; i < 6300; i++) {

@@ -162,9 +162,12 @@ def test_device_normalizer_rule_table_and_flood_fills_on_cpu(tmp_path):
                         os.path.join(root, "tools", "norm_masks_check.cpp"), "-o", exe, "-L" + libdir, "-ltokenmonster_hip", "-ltm_testsupport", "-Wl,-rpath," + libdir],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
-    r = subprocess.run([exe, "6000", "17"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-    out = r.stdout.decode(errors="replace")
-    assert r.returncode == 0 and " 0 mismatches" in out, out[-3000:]
+    # (seed 21 is the run that found the capitals without a lower-case form, U+03D2..U+03D4, in round 5: as a later capital of a run that
+    # ends in a lower-case letter the reference gives them no marker; since then their documents take the host path)
+    for ndocs, seed in (("6000", "17"), ("20000", "21")):
+        r = subprocess.run([exe, ndocs, seed], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        out = r.stdout.decode(errors="replace")
+        assert r.returncode == 0 and " 0 mismatches" in out, out[-3000:]
 
 
 def test_tok_dictionary_format_round_trip_and_layout():

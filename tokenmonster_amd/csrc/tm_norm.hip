@@ -444,9 +444,8 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   const unsigned long long t0_beyond = CARRY ? (unsigned long long)((carry >> 4) & 1u) : 0ull;       // T0 (tm_norm_masks.h) of what lies behind the margin: looked at only when all of the margin is one block
   if (!CARRY) {
     const uint32_t fb = fl0[-64], fa = m == PIECE ? (uint32_t)fl0[64 * NCH] : 0u;       // (a shorter piece is the last of its document: nothing follows)
-    uint64_t w_in, tx_after, lx0_after;
-    const bool known = nm_margin_carries(__ballot((fb & NF_BLOCK) != 0), __ballot((fb & NF_CLASS) == NC_U), __ballot((fa & NF_BLOCK) != 0), __ballot((fa & NF_CLASS) == NC_L),
-                                         &w_in, &tx_after, &lx0_after);
+    uint64_t w_in;
+    const bool known = nm_margin_carries(__ballot((fb & NF_BLOCK) != 0), __ballot((fb & NF_CLASS) == NC_U), __ballot((fa & NF_BLOCK) != 0), &w_in);
     if (!known && lane == 0) atomicAdd(overflow + 1, 1ull);
     w_seed = w_in;
   }

@@ -178,25 +178,10 @@ TM_HD uint64_t nm_flood_down(uint64_t M, uint64_t S) { return nm_brev(nm_flood_u
 TM_HD uint64_t nm_flood_down_inside(uint64_t M, uint64_t S) { const uint64_t m = nm_brev(M), s = nm_brev(S); return nm_brev(((m ^ (m + s)) | s) & m); }
 // bit i = bit (i + 1) of the byte stream (next0 = bit 0 of the following chunk)
 TM_HD uint64_t nm_shr1(uint64_t cur, uint64_t next0) { return (cur >> 1) | (next0 << 63); }
-// valid-byte mask of chunk c of a piece of m bytes, and the bit of absolute position m inside chunk c (0 if elsewhere)
+// valid-byte mask of chunk c of a piece of m bytes
 TM_HD uint64_t nm_valid(int c, int m) { const int r = m - 64 * c; return r >= 64 ? ~0ull : (r <= 0 ? 0ull : ((1ull << r) - 1ull)); }
-TM_HD uint64_t nm_boundary(int c, int m) { const int r = m - 64 * c; return (r >= 0 && r < 64) ? (1ull << r) : 0ull; }
 
-// Backward sweep over a chunk.  B / L: ballots "byte is in a block" / "byte is a lower-case letter" of the chunk (any bytes; bytes
-// beyond the piece are masked here); V = nm_valid of the chunk; bnd = nm_boundary of the chunk if a block that reaches the end of
-// the piece ends in a lower-case letter (carry_tl from k_norm_carry), else 0.
-// Returns TX = T of the chunk's block bytes | bnd.
-// tx_next / lx_next0: TX of chunk c+1 and bit 0 of its boundary-augmented lower-case mask; *lx0: the same bit of this chunk.
-TM_HD uint64_t nm_backward(uint64_t B, uint64_t L, uint64_t V, uint64_t bnd, uint64_t tx_next, uint64_t lx_next0, uint64_t* lx0) {
-  const uint64_t Bv = B & V;
-  const uint64_t Lx = (L & V) | bnd;
-  const uint64_t succ = (lx_next0 | tx_next) & 1ull;              // what a block byte at bit 63 inherits from the next chunk
-  const uint64_t T = nm_flood_down(Bv, Bv & nm_shr1(Lx, succ));
-  *lx0 = Lx & 1ull;
-  return T | bnd;
-}
-
-// The same T WITHOUT a sweep from the end of the piece: what a chunk needs to know about everything behind it is one bit,
+// T of a chunk's block bytes WITHOUT a sweep from the end of the piece: what a chunk needs to know about everything behind it is one bit,
 //   T0(next chunk) = "the first byte at or after the next chunk's first byte that is not in a block is a lower-case letter"
 // (that byte decides T of a block that reaches this chunk's end), and T0 of a chunk is a function of its own two ballots unless all 64 of
 // its bytes are in one block - only then of the chunk behind it (`beyond`).  k_norm_emit2 computes TX of a chunk from the ballots of the
@@ -227,15 +212,13 @@ TM_HD void nm_space_markers(uint64_t SP, uint64_t U, uint64_t next_u0, uint64_t 
 
 // The carries of a piece from its MARGINS instead of from a pass over the whole document (k_norm_emit2<false>): the 64 bytes before
 // the piece say whether its first byte is inside a word — unless all 64 are one block without a capital, which may still have one
-// further back —, the 64 bytes after a full piece say how the block that reaches its end ends — unless all 64 still belong to it.
-// Bb / Ub: ballots "in a block" / "capital" of the bytes before; Ba / La: "in a block" / "lower-case letter" of the bytes after (all
-// zero when the text ends with the piece).  *w_in: W of byte 0; *tx_after / *lx0_after: what nm_backward wants to know about the
-// chunk behind the piece.  Returns false when the margins cannot tell: the exact path (summaries + carries) has to run.
-TM_HD bool nm_margin_carries(uint64_t Bb, uint64_t Ub, uint64_t Ba, uint64_t La, uint64_t* w_in, uint64_t* tx_after, uint64_t* lx0_after) {
+// further back —; the 64 bytes after a full piece are the "next chunk" of its last chunk (nm_t0) — unless all 64 still belong to one block.
+// Bb / Ub: ballots "in a block" / "capital" of the bytes before; Ba: "in a block" of the bytes after (zero when the text ends with the
+// piece).  *w_in: W of byte 0.  Returns false when the margins cannot tell: the exact path (summaries + carries) has to run.
+TM_HD bool nm_margin_carries(uint64_t Bb, uint64_t Ub, uint64_t Ba, uint64_t* w_in) {
   uint64_t w_out;
   (void)nm_inword(Bb, Ub, ~0ull, 0ull, &w_out);
   *w_in = w_out;
-  *tx_after = nm_backward(Ba, La, ~0ull, 0ull, 0ull, 0ull, lx0_after);
   return !((Bb == ~0ull && Ub == 0ull) || Ba == ~0ull);
 }
 

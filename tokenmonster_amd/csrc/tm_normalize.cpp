@@ -401,6 +401,10 @@ void build_two_table(uint32_t norm_flag, NmTwo* out) {
     if (c1.r == ' ' || c1.r == '\'') continue;                            // (no character of the range turns into one of these)
     std::vector<uint8_t> low;
     put_lower(low, c1);                                                    // what capcode writes for a capital (:918, :986)
+    // A capital whose lower-case form is not a lower-case letter (ϒ ϓ ϔ: upper-case symbols without one) is not for the device's rule table:
+    // as a later capital of a run that ends in a lower-case letter the reference gives it no "DC " - its pass over the run (:924-951,
+    // mark_run_letters above) looks at the letters AFTER lower-casing, and this one is still a capital.  Its documents take the host path.
+    if ((k1 & kUpper) && !(classify(next_cp(low.data(), low.size())) & kLower)) continue;
     if ((size_t)c1.n == t.size() && c1.n == 2) {                           // stays one two-byte character
       if (low.size() != 2) continue;
       e.a = cls | NT_OK | ((uint32_t)t[0] << 8) | ((uint32_t)t[1] << 16);

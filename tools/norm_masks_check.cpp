@@ -147,16 +147,15 @@ bool check_doc(const std::vector<uint8_t>& d, uint32_t norm_flag, uint64_t* skip
     // the carries as k_norm_emit2<false> finds them: from the 64 bytes either side of the piece; when they cannot tell, the exact path
     // (the document-wide carries above) runs on the device too
     auto cls_at = [&](int p) -> uint32_t { return (p < 0 || p >= n) ? (uint32_t)NC_O : (uint32_t)f[p]; };
-    uint64_t Bb = 0, Ub = 0, Ba = 0, La = 0;
+    uint64_t Bb = 0, Ub = 0, Ba = 0;
     for (int i = 0; i < 64; i++) {
       const uint32_t fb = cls_at(pb - 64 + i), fa = m == PIECE ? cls_at(pb + PIECE + i) : 0u;
       if (fb & NF_BLOCK) Bb |= 1ull << i;
       if ((fb & NF_CLASS) == NC_U) Ub |= 1ull << i;
       if (fa & NF_BLOCK) Ba |= 1ull << i;
-      if ((fa & NF_CLASS) == NC_L) La |= 1ull << i;
     }
-    uint64_t w_m, tx_a, lx_a;
-    if (nm_margin_carries(Bb, Ub, Ba, La, &w_m, &tx_a, &lx_a)) {
+    uint64_t w_m;
+    if (nm_margin_carries(Bb, Ub, Ba, &w_m)) {
       g_margin_ok++;
       if ((w_m != 0) != w_in) { fprintf(stderr, "MARGIN: inWord seed %d, the document says %d (piece at %d)\n", (int)w_m, (int)w_in, pb); return false; }
       emit_piece(d, f, pb, m, w_m != 0, 0ull, lower_all, got);
@@ -173,6 +172,7 @@ bool check_doc(const std::vector<uint8_t>& d, uint32_t norm_flag, uint64_t* skip
     while (k < exp_n && k < got.size() && exp[k] == got[k]) k++;
     fprintf(stderr, "MISMATCH (flag %u, %zu bytes): expected %zu bytes, got %zu; first difference at output byte %zu\n  input : %.*s\n", norm_flag, d.size(),
             exp_n, got.size(), k, (int)std::min<size_t>(d.size(), 200), (const char*)d.data());
+    if (const char* dump = getenv("NM_DUMP")) { FILE* f = fopen(dump, "wb"); if (f) { fwrite(d.data(), 1, d.size(), f); fclose(f); } }      // the document, for a closer look
     const size_t a = k > 20 ? k - 20 : 0;
     fprintf(stderr, "  expect: ...%.*s\n  got   : ...%.*s\n", (int)std::min<size_t>(exp_n - a, 60), (const char*)exp + a, (int)std::min<size_t>(got.size() - a, 60),
             (const char*)got.data() + a);
