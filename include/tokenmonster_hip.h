@@ -165,9 +165,12 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
  * Tokenize (go/tokenmonster.go:242-253: norm.Normalize + capcode.Encode) ON THE DEVICE into the batch's text buffer
  * (max_bytes of tm_batch_create must cover the normalized size, about 1.1x raw with capcode 2).  The device pass handles ASCII, every
  * two-byte script (U+0080..U+07FF: accented Latin, Greek, Cyrillic, Armenian, Hebrew, Arabic ...: NFD, case and capcode from a table the
- * host normalizer fills) and the three-byte characters the normalizer leaves alone (General Punctuation, CJK ideographs, most kana,
- * symbols); documents with anything else (Hangul, voiced kana, Latin Extended Additional, four-byte characters, two combining marks in a
- * row, malformed UTF-8) are normalized by the host normalizer inside the same call; tm_batch_host_fallback_docs reports how many.
+ * host normalizer fills), the three-byte characters the normalizer leaves alone (General Punctuation, CJK ideographs, most kana,
+ * symbols), Hangul syllables (decomposed by arithmetic) and the four-byte characters of caseless, NFD-stable blocks (emoji, symbols, plane-2
+ * ideographs); documents with anything else (voiced kana, Latin Extended Additional, cased scripts beyond the BMP, a capital without a
+ * lower-case form - U+03D2..U+03D4 -, two combining marks in a row, malformed UTF-8) are normalized by the host normalizer inside the same
+ * call; tm_batch_host_fallback_docs reports how many.  (TM_NORM_WG_PER_CU in the environment: the grid of the pass, workgroups per compute
+ * unit, default 64 - a tuning knob, profiles/r05_issue_model.txt.)
  * Supported: capcode 0 and 2 (level 1
  * has no statement in the reference tree and is refused), every normalization flag (training/README.md:110-123); the device
  * pass itself implements NFD and lowercase (what the reference's pretrained vocabularies use), a vocabulary with any of the

@@ -1663,7 +1663,7 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store, bool rezero = f
     launch_seg_params(b, st);
     const uint32_t stage_after = (debug_flags() & 1024) ? 512u : 0u;
     if (r0_narrow(b))
-      TM_LAUNCH(k_emit_tiles<true>, (uint32_t)((nseg + TS - 1) / TS), 64, (getenv("TM_K4_EXTRA_LDS") ? atoi(getenv("TM_K4_EXTRA_LDS")) : 0), st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
+      TM_LAUNCH(k_emit_tiles<true>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
                                                                          b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
     else
       TM_LAUNCH(k_emit_tiles<false>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
