@@ -197,7 +197,8 @@ const char* tm_kernel_name(int k);
  * normalizer kernel instead of k_norm_emit2, 10 = K4 tile walk that stores every id directly (its overflow path), 11 = the device normalizer packs its text
  * (the path of a batch with host-normalized documents) instead of leaving it in its slabs for the match kernel, 12 = group tree of
  * long documents with fan-out 4 from 9 segments on, 13 = 64 KiB mailbox for the small host <-> device transfers, 14 = the last member of tm_score_multi gives up
- * after the members' first meeting (an error path: the call must return that member's error).  Other bits are
+ * after the members' first meeting (an error path: the call must return that member's error), 15 = the id-staging form of the K4 walk (what vocabularies
+ * of more than 65 536 ids use) for the two-plane rows too, instead of the position-staging form.  Other bits are
  * ignored (a -DTM_DEVEL build, tools/ only, adds profiling bits that switch phases of the match kernel off).  The switches are process-wide,
  * so they are armed only in a process started with TM_TEST_HOOKS in its environment (the test suite, bench.py --also-flags): anywhere
  * else the call changes nothing and returns 0 - one caller of a server cannot change the code path under the others. */

@@ -38,7 +38,13 @@ def one(seed):
     rng_t = np.random.default_rng(seed ^ 0x5EED)
     if rng_t.random() < 0.33:
         v.tune(text[: int(rng_t.integers(0, text.size + 1))])
-    ids, toff, missing = v.tokenize_packed(text, offs)
+    # (a quarter of the cases through the id-staging form of the K4 walk - test hook 15 -, which the two-plane rows otherwise do not take)
+    from tokenmonster_amd import _native as N
+    old_flags = N.lib.tm_debug_flags(32768 if rng.random() < 0.25 else 0)
+    try:
+        ids, toff, missing = v.tokenize_packed(text, offs)
+    finally:
+        N.lib.tm_debug_flags(old_flags)
     counts, cmiss = v.count_packed(text, offs)
     for d, doc in enumerate(docs):
         exp, miss = orc.tokenize(doc)

@@ -98,13 +98,14 @@ def test_dense_forward_delete_path():
     check_docs(v, orc, docs[:10], "side-list path")
 
 
-@pytest.mark.parametrize("flags", [64, 1024, 1024 | 64, 4096, 4096 | 64])
+@pytest.mark.parametrize("flags", [64, 1024, 1024 | 64, 4096, 4096 | 64, 32768, 32768 | 1024, 32768 | 64])
 def test_fallback_paths_behind_test_hooks(flags):
     """Rarely taken fallback paths of the product, forced through the test hooks of tm_debug_flags: bit 10 makes the K4 tile walk
     store every id directly (the path it takes when a text averages more than one id per byte), bit 6 uses the dense T(p,1) array
     for every segment (the path of a segment with more forward-delete states than its side list holds), bit 12 hangs every
     document of more than 8 segments under a group tree of fan-out 4 (the resolve of multi-megabyte documents and of dataset strips,
-    five levels deep on the 200 000-byte document here).  All must give the oracle's ids / histogram.  Bits outside the hooks are ignored by the default build (they need -DTM_DEVEL)."""
+    five levels deep on the 200 000-byte document here), bit 15 walks the two-plane rows in the id-staging form that vocabularies of more than
+    65 536 ids use (k_emit_tiles) instead of the position-staging one (k_emit_list).  All must give the oracle's ids / histogram.  Bits outside the hooks are ignored by the default build (they need -DTM_DEVEL)."""
     from tokenmonster_amd import _native as N
     rng = np.random.default_rng(78)
     toks = fuzz_vocab_tokens(rng, 2, 140)

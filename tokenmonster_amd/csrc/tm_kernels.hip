@@ -1435,6 +1435,151 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
   }
 }
 
+// K4 for the two-plane rows, second form: POSITIONS are staged, not ids.  The walk only needs the advance / flag byte of a position, so only
+// that plane of a segment's row is in LDS (272 bytes instead of 816), and what the walk leaves behind - in the bytes it has passed, as the id
+// form does - is the position of every id; a second phase of the whole wavefront then fetches the ids of the listed positions from the id plane
+// where it lies in HBM and writes them out.  K4's time follows the number of chains a CU walks side by side (profiles/r05_issue_model.txt (3)):
+// 16 segments per wavefront and 32 wavefronts per CU = 512 instead of 192.
+//   list entry (one byte): the position the id of this output slot comes from; the SAME position twice in a row: the second slot is the delete
+//   token behind the token of the first.  A slot whose id comes from a forward-delete state (the side list, not the row) has its bit set in a
+//   256-bit map of the segment.  Positions of consecutive ids differ (a step that consumes no byte - a forward-delete state may - and everything
+//   behind it is written straight to HBM, like ids that do not fit in front of the byte being read), and a word without an id carries no
+//   forward-delete flag (tm_kernels.hip: the only producer of "missing" is T's first line), so the rule has no second reading.
+#ifndef TM_K4_TSL
+#define TM_K4_TSL 16
+#endif
+constexpr int TSL = TM_K4_TSL, TSLACK_L = 4, TROW_L = SEG + 16;
+__global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
+                                                  const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
+                                                  uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
+                                                  uint32_t* __restrict__ error_flag, uint32_t stage_after, const uint32_t* __restrict__ seg_doc,
+                                                  uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing, uint32_t no_id) {
+  alignas(16) __shared__ uint8_t s_m[TSL][TROW_L];
+  __shared__ uint32_t s_side[TSL][8];
+  const int lane = threadIdx.x;
+  const uint64_t g0 = (uint64_t)blockIdx.x * TSL;
+  const int nv = (int)(nseg - g0 < (uint64_t)TSL ? nseg - g0 : (uint64_t)TSL);
+  const TileSeg t = tile_segment(par, g0 + lane, lane < TSL, nseg);
+  constexpr uint32_t SLACK = TSLACK_L;
+  const uint8_t* rows_g = reinterpret_cast<const uint8_t*>(R0);
+  {
+    // lane l fetches the flag bytes of positions 4l .. 4l+3 of every row; all loads before the first LDS write
+    uint32_t vb[TSL];
+#pragma unroll
+    for (int s = 0; s < TSL; s++) {
+      const int ss = s < nv ? s : nv - 1;
+      const uint32_t len = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;
+      vb[s] = 0u;
+      if (4u * (uint32_t)lane < len) vb[s] = TM_STREAM_LOAD(reinterpret_cast<const uint32_t*>(rows_g + (g0 + (uint64_t)ss) * R0_NARROW + 2 * SEG) + lane);
+    }
+#pragma unroll
+    for (int s = 0; s < TSL; s++) *reinterpret_cast<uint32_t*>(&s_m[s][TSLACK_L + 4 * lane]) = vb[s];
+#pragma unroll
+    for (int i = lane; i < TSL * 8; i += 64) reinterpret_cast<uint32_t*>(s_side)[i] = 0u;
+    static_assert((TSL & (TSL - 1)) == 0 && TSL >= 8 && TSL <= 64, "a lane per segment, lane & (TSL - 1)");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  uint32_t staged = 0;
+  {
+    const int rl = lane & (TSL - 1);                                     // (lanes >= TSL have no segment; they only need valid pointers)
+    uint8_t* rowm = s_m[rl];
+    uint32_t* smap = s_side[rl];
+    const uint2* __restrict__ sl = side + (g0 + rl) * SIDE_STRIDE;
+    const uint16_t* __restrict__ ids_g = reinterpret_cast<const uint16_t*>(rows_g + (g0 + (uint64_t)(rl < nv ? rl : 0)) * R0_NARROW);
+    uint32_t nfd = 0, nmiss = 0;                                       // delete tokens emitted / characters without a token (go :1274)
+    // the word of state (p, fd): T(p,1) from the segment's side list, T(p,0) from the flag byte in LDS and the id where it lies (general step only)
+    auto word = [&](uint32_t pp, uint32_t f) -> uint32_t {
+      if (f != 0) return side_word(sl, R1, g0 + rl, pp);
+      const uint32_t m8 = rowm[SLACK + pp];
+      return ((m8 >> 7) ? no_id : (uint32_t)ids_g[pp]) | ((m8 & 63u) << 24) | ((m8 >> 6) << 30);
+    };
+    const uint32_t seglen = t.have ? t.seglen : 0u;
+    uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0, direct = 0, hop = 0;
+    // gate: as in k_emit_tiles (>= 0: straight-line step; GATE_DEAD < gate < 0: general step; GATE_DEAD: the chain has left the segment)
+    constexpr int GATE_DEAD = -(1 << 24);
+    const int slack0 = (int)SLACK - 2 - (int)stage_after;
+    int gate = p < seglen ? slack0 + (int)p - (int)(fd << 16) : GATE_DEAD;
+    const uint32_t nounk = no_id == ID_NONE ? 1u : 0u;
+    auto fast_step = [&]() __attribute__((always_inline)) {
+      const uint32_t m8 = rowm[SLACK + p];
+      const uint32_t miss = m8 >> 7, fdn = (m8 >> 6) & 1u, adv = m8 & 63u;
+      const uint32_t has = 1u - (miss & nounk);
+      rowm[E] = (uint8_t)p; E += has; rowm[E] = (uint8_t)p;              // the id's slot, then (same position again) the delete token's
+      E += fdn;
+      gate += (int)adv - (int)(fdn * 0x10001u + has);
+      nfd += fdn;
+      nmiss += miss;
+      fd = fdn;
+      p += max(adv, 1u);
+      gate = p < seglen ? gate : GATE_DEAD;
+    };
+    for (;;) {
+#ifndef TM_EMU
+      if (gate >= 0) {
+        do fast_step(); while (__builtin_amdgcn_ballot_w64(gate < 0) == 0ull);       // (a ballot of the lanes in the loop)
+      }
+#else
+      if (__builtin_amdgcn_ballot_w64(gate >= 0) != 0ull) {
+        const bool in = gate >= 0;
+        do { if (in) fast_step(); } while (__builtin_amdgcn_ballot_w64(in && gate < 0) == 0ull);
+      }
+#endif
+      const bool general = (uint32_t)gate > (uint32_t)GATE_DEAD;      // GATE_DEAD < gate < 0
+      if (__builtin_amdgcn_ballot_w64(general) != 0ull) {
+        if (general) {
+          const uint32_t w = word(p, fd);
+          if (w == R_INVALID || hop > 2u * SEG) { atomicOr(error_flag, 2u); p = seglen; gate = GATE_DEAD; }      // cannot happen on a chain K1/K3 produced
+          else {
+            const uint32_t id = w & ID_NONE, adv = (w >> 24) & 63u, fdn = (w >> 30) & 1u;
+            // staged only while the list can say it: room in front of the byte being read, a byte consumed (positions of consecutive ids differ),
+            // and no delete token without a token in front of it
+            const bool fits = direct == 0u && slack0 + (int)p - (int)E >= 0 && adv != 0u && !(id == ID_NONE && fdn != 0u);
+            if (!fits && direct == 0u) { direct = 1u; staged = E; }      // from here on the segment's ids go straight to HBM
+            nfd += fdn;
+            nmiss += w >> 31;
+            if (fits) {
+              if (id != ID_NONE) { if (fd) smap[E >> 5] |= 1u << (E & 31u); rowm[E++] = (uint8_t)p; }
+              if (fdn) rowm[E++] = (uint8_t)p;
+            } else {
+              if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); E++; }
+              if (fdn) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], delete_id); E++; }
+            }
+            fd = fdn;
+            p += adv;                                                      // (0 is possible: a one-byte alternative of a forward-delete state)
+            hop++;
+            gate = p < seglen ? slack0 + (int)p - (int)E - (int)((fd | direct) << 16) : GATE_DEAD;
+          }
+        }
+      } else if (__builtin_amdgcn_ballot_w64(gate >= 0) == 0ull) break;                 // no lane can step: every chain has left its segment
+    }
+    if (direct == 0u) staged = E;
+    if (nfd | nmiss) {
+      const uint32_t doc = seg_doc[g0 + lane];
+      if (nfd) atomicAdd(&doc_fd[doc], nfd);
+      if (nmiss) atomicAdd(&doc_missing[doc], nmiss);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  // second phase: the ids of the listed positions, 64 slots of a segment at a time
+  if (out_cap == 0) return;
+  for (int s = 0; s < nv; s++) {
+    const uint32_t n = (uint32_t)__shfl((int)staged, s);
+    const uint64_t base = shfl_u64(t.base, s);
+    const uint8_t* rowm = s_m[s];
+    const uint16_t* __restrict__ ids_g = reinterpret_cast<const uint16_t*>(rows_g + (g0 + (uint64_t)s) * R0_NARROW);
+    for (uint32_t j = (uint32_t)lane; j < n; j += 64u) {
+      const uint32_t pp = rowm[j], prev = j ? (uint32_t)rowm[j - 1] : 0x100u;
+      uint32_t id;
+      if (pp == prev) id = delete_id;
+      else if ((s_side[s][j >> 5] >> (j & 31u)) & 1u) id = side_word(side + (g0 + (uint64_t)s) * SIDE_STRIDE, R1, g0 + (uint64_t)s, pp) & ID_NONE;
+      else id = ids_g[pp];
+      if (base + j < out_cap) TM_STREAM_STORE(&out[base + j], id);
+    }
+  }
+}
+
 // K4, scoring variant of the tile walk (training/trainvocab.go:1105-1174): persistent workgroups (the LDS-privatised histogram is
 // what keeps the hot ids off the L2 atomics), every wavefront walks tiles of TS segments.
 template <int WV>
@@ -1595,7 +1740,7 @@ namespace tmh {
 // phases of K1 off for profiling — 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps — bit 9 adds 4 KB
 // of dummy LDS per K1 workgroup, and TM_DBG in the environment sets the initial value.
 #ifndef TM_DEVEL
-constexpr int kDebugMask = 64 | 256 | 1024 | 2048 | 4096 | 8192 | 16384;
+constexpr int kDebugMask = 64 | 256 | 1024 | 2048 | 4096 | 8192 | 16384 | 32768;
 #define TM_K1_EXTRA_LDS 0
 #define TM_DBG_INITIAL 0
 #endif
@@ -1662,7 +1807,10 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store, bool rezero = f
   if (nseg > 0) {
     launch_seg_params(b, st);
     const uint32_t stage_after = (debug_flags() & 1024) ? 512u : 0u;
-    if (r0_narrow(b))
+    if (r0_narrow(b) && !(debug_flags() & 32768))             // (test hook 15: the id-staging form of the walk for the two-plane rows too)
+      TM_LAUNCH(k_emit_list, (uint32_t)((nseg + TSL - 1) / TSL), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
+                                                                   b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
+    else if (r0_narrow(b))
       TM_LAUNCH(k_emit_tiles<true>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
                                                                          b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
     else
