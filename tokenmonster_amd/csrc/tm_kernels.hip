@@ -1441,8 +1441,8 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
 // where it lies in HBM and writes them out.  K4's time follows the number of chains a CU walks side by side (profiles/r05_issue_model.txt (3)):
 // 16 segments per wavefront and 32 wavefronts per CU = 512 instead of 192.
 //   list entry (one byte): the position the id of this output slot comes from; the SAME position twice in a row: the second slot is the delete
-//   token behind the token of the first.  A slot whose id comes from a forward-delete state (the side list, not the row) has its bit set in a
-//   256-bit map of the segment.  Positions of consecutive ids differ (a step that consumes no byte - a forward-delete state may - and everything
+//   token behind the token of the first.  A slot whose id comes from a forward-delete state (the side list, not the row) is written by the walk
+//   itself and has its bit set in a 256-bit map of the segment: the second phase leaves it alone.  Positions of consecutive ids differ (a step that consumes no byte - a forward-delete state may - and everything
 //   behind it is written straight to HBM, like ids that do not fit in front of the byte being read), and a word without an id carries no
 //   forward-delete flag (tm_kernels.hip: the only producer of "missing" is T's first line), so the rule has no second reading.
 #ifndef TM_K4_TSL
@@ -1455,7 +1455,9 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
                                                   uint32_t* __restrict__ error_flag, uint32_t stage_after, const uint32_t* __restrict__ seg_doc,
                                                   uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing, uint32_t no_id) {
   alignas(16) __shared__ uint8_t s_m[TSL][TROW_L];
-  __shared__ uint32_t s_side[TSL][8];
+  __shared__ uint32_t s_side[TSL][9];                 // (a word of slack: slot numbers up to TROW_L - 1 are looked up)
+  __shared__ uint32_t s_n[TSL];
+  __shared__ uint64_t s_base[TSL];
   const int lane = threadIdx.x;
   const uint64_t g0 = (uint64_t)blockIdx.x * TSL;
   const int nv = (int)(nseg - g0 < (uint64_t)TSL ? nseg - g0 : (uint64_t)TSL);
@@ -1475,8 +1477,8 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
 #pragma unroll
     for (int s = 0; s < TSL; s++) *reinterpret_cast<uint32_t*>(&s_m[s][TSLACK_L + 4 * lane]) = vb[s];
 #pragma unroll
-    for (int i = lane; i < TSL * 8; i += 64) reinterpret_cast<uint32_t*>(s_side)[i] = 0u;
-    static_assert((TSL & (TSL - 1)) == 0 && TSL >= 8 && TSL <= 64, "a lane per segment, lane & (TSL - 1)");
+    for (int i = lane; i < TSL * 9; i += 64) reinterpret_cast<uint32_t*>(s_side)[i] = 0u;
+    static_assert((TSL & (TSL - 1)) == 0 && TSL >= 8 && TSL <= 64, "a lane per segment, lane & (TSL - 1); the second phase takes eight at a time");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);
   }
@@ -1539,7 +1541,11 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
             nfd += fdn;
             nmiss += w >> 31;
             if (fits) {
-              if (id != ID_NONE) { if (fd) smap[E >> 5] |= 1u << (E & 31u); rowm[E++] = (uint8_t)p; }
+              if (id != ID_NONE) {
+                // (the id of a forward-delete state is not in the row: it goes out here, and the slot is marked as written)
+                if (fd) { smap[E >> 5] |= 1u << (E & 31u); if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); }
+                rowm[E++] = (uint8_t)p;
+              }
               if (fdn) rowm[E++] = (uint8_t)p;
             } else {
               if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); E++; }
@@ -1562,20 +1568,37 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
-  // second phase: the ids of the listed positions, 64 slots of a segment at a time
+  // second phase: the ids of the listed positions.  A round takes 64 slots of EVERY segment of the tile: the fetches of a round are issued back to
+  // back (one trip to HBM per round, not per segment), then its stores; a segment has more than 64 slots about every other time, 512 at most.
+  // Nothing branches before the stores: a lane without a slot reads the last byte of the row and fetches some id of the row.
   if (out_cap == 0) return;
-  for (int s = 0; s < nv; s++) {
-    const uint32_t n = (uint32_t)__shfl((int)staged, s);
-    const uint64_t base = shfl_u64(t.base, s);
-    const uint8_t* rowm = s_m[s];
-    const uint16_t* __restrict__ ids_g = reinterpret_cast<const uint16_t*>(rows_g + (g0 + (uint64_t)s) * R0_NARROW);
-    for (uint32_t j = (uint32_t)lane; j < n; j += 64u) {
-      const uint32_t pp = rowm[j], prev = j ? (uint32_t)rowm[j - 1] : 0x100u;
-      uint32_t id;
-      if (pp == prev) id = delete_id;
-      else if ((s_side[s][j >> 5] >> (j & 31u)) & 1u) id = side_word(side + (g0 + (uint64_t)s) * SIDE_STRIDE, R1, g0 + (uint64_t)s, pp) & ID_NONE;
-      else id = ids_g[pp];
-      if (base + j < out_cap) TM_STREAM_STORE(&out[base + j], id);
+  if (lane < TSL) { s_n[lane] = lane < nv ? staged : 0u; s_base[lane] = t.base; }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  uint32_t nmax = 0;
+#pragma unroll
+  for (int s = 0; s < TSL; s++) nmax = max(nmax, s_n[s]);
+  nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+  for (uint32_t j0 = 0; j0 < nmax; j0 += 64u) {
+    const uint32_t j = j0 + (uint32_t)lane, jj = min(j, (uint32_t)TROW_L - 1u), jp = max(jj, 1u) - 1u;
+    // (eight segments at a time: sixteen fetches in flight cost the registers of half the wavefronts a CU holds)
+#pragma unroll 1
+    for (int s0 = 0; s0 < TSL; s0 += 8) {
+      uint32_t idv[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int s = s0 + k, ss = s < nv ? s : nv - 1;
+        const uint32_t pp = s_m[s][jj], prev = s_m[s][jp];
+        const uint32_t fetched = reinterpret_cast<const uint16_t*>(rows_g + (g0 + (uint64_t)ss) * R0_NARROW)[pp];
+        idv[k] = (pp == prev && j != 0u) ? delete_id : fetched;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int s = s0 + k;
+        const uint64_t base = s_base[s];
+        const bool written = ((s_side[s][jj >> 5] >> (jj & 31u)) & 1u) != 0u;
+        if (j < s_n[s] && !written && base + j < out_cap) TM_STREAM_STORE(&out[base + j], idv[k]);
+      }
     }
   }
 }
