@@ -1,3 +1,6 @@
+#!/bin/bash
+# tools/final_gpu_short.sh — ON THE GPU BOX, when GPU minutes are short: the default bench line, kernel stats of the same step, the test files that are not picked by
+# tools/end_of_round_check.sh's full run, 20 s of device fuzz.  Output in gpurun_out/final_r05d.
 cd "$(dirname "$0")/.." 2>/dev/null || true
 ROOT=$PWD; OUT=gpurun_out/final_r05d; mkdir -p $OUT
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cut -c1-300 $OUT/bench_default.json; grep -E "host_to_host" $OUT/bench_default.err | cut -c1-400
