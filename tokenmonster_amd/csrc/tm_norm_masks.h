@@ -173,8 +173,7 @@ TM_HD uint64_t nm_brev(uint64_t x) { return __builtin_bitreverse64(x); }   // s_
 // every bit of M reachable upwards from a seed through consecutive set bits of M (seeds outside M are ignored):
 // the carry of M + S ripples from a seed to the end of its run
 TM_HD uint64_t nm_flood_up(uint64_t M, uint64_t S) { S &= M; return ((M ^ (M + S)) | S) & M; }
-TM_HD uint64_t nm_flood_down(uint64_t M, uint64_t S) { return nm_brev(nm_flood_up(nm_brev(M), nm_brev(S))); }
-// the same for seeds that are known to lie inside M (one instruction less)
+// the same downwards, for seeds that are known to lie inside M (the carry ripples in the bit-reversed masks)
 TM_HD uint64_t nm_flood_down_inside(uint64_t M, uint64_t S) { const uint64_t m = nm_brev(M), s = nm_brev(S); return nm_brev(((m ^ (m + s)) | s) & m); }
 // bit i = bit (i + 1) of the byte stream (next0 = bit 0 of the following chunk)
 TM_HD uint64_t nm_shr1(uint64_t cur, uint64_t next0) { return (cur >> 1) | (next0 << 63); }
