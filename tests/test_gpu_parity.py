@@ -891,3 +891,34 @@ def test_one_child_chains_in_the_trie():
             exp, miss = orc.tokenize(docs[d])
             got = ids[int(toff[d]):int(toff[d + 1])]
             assert got.size == exp.size and (got == exp).all() and miss == int(missing[d]), (capcode, d, docs[d][:80])
+
+
+@pytest.mark.parametrize("flags", [0, 32768, 1024])
+def test_walk_with_an_id_per_byte_and_more(flags):
+    """K4 on texts that emit an id for every byte and, where delete tokens follow, more ids than bytes: the position-staging walk (k_emit_list)
+    fills its second phase's rounds (64 slots of a segment per round: up to four and more), runs out of room in front of the byte being read and
+    switches a segment to direct stores half way, and meets forward-delete states whose ids it writes itself; flags 32768 / 1024: the id-staging
+    form, and every id stored directly.  All against the oracle."""
+    from tokenmonster_amd import _native as N
+    rng = np.random.default_rng(4242)
+    alphabet = b"qrstuvwx"          # (letters the fuzz vocabulary below has no words of: every one of them is a token of its own)
+    toks = [bytes([c]) for c in alphabet + b" D.\n"] + [b" " + bytes([c]) for c in alphabet] + [b"D " + bytes([c]) for c in alphabet[:4]] + [b"qr", b"st", b" qr", b"D qr"]
+    toks = list(dict.fromkeys(toks + fuzz_vocab_tokens(rng, 2, 60)))       # + the fuzz vocabulary: its space-prefixed words bring the forward-delete branches
+    img = synth.build_vocab(toks, capcode=2, charset=1, with_unk=True)
+    v = tm.Vocab(img)
+    orc = Oracle(img)
+    docs = []
+    for n in (1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 5000):
+        docs.append(bytes(rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=n)))                                   # one id per byte
+        docs.append(bytes(rng.choice(np.frombuffer(alphabet + b"   ", dtype=np.uint8), size=n)))                             # ' x' tokens: fewer ids than bytes
+        docs.append(b"".join(bytes(rng.choice([b"D a", b"D b", b"a", b"D", b" ", b"D ab", b"b."])) for _ in range(n))[:max(n, 1)])   # markers and words of the fuzz vocabulary
+        docs.append(fuzz_text(rng, 2, n))
+    oracle_stats(reset=True)
+    old = N.lib.tm_debug_flags(flags)
+    try:
+        check_docs(v, orc, docs, "an id per byte, flags %d" % flags)
+    finally:
+        N.lib.tm_debug_flags(old)
+    st = oracle_stats()
+    assert st["s1b"] + st["s2b"] + st["s3b"] > 0, st                                           # forward-delete states were walked
+    assert any(orc.tokenize(d)[0].size >= 0.95 * len(d) >= 240 for d in docs)                  # and segments with (nearly) an id per byte
