@@ -141,6 +141,8 @@ typedef struct tm_pipeline_stats {
   int input_pinned, output_pinned;
   uint64_t normalized_bytes;
   uint32_t host_fallback_docs;
+  uint32_t ring;              /* 1: the call ran on the ring (raw text, page-locked buffers on both sides: no host round trip inside a chunk) */
+  uint32_t ring_exact_chunks; /* chunks the ring handed to the exact path (documents for the host normalizer, a long document ...) */
 } tm_pipeline_stats;
 int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, int raw,
                          uint32_t encoding_length, uint64_t chunk_bytes, uint32_t lanes, uint8_t* bytes_out, uint64_t bytes_cap,

@@ -366,3 +366,62 @@ def test_tables_laid_out_by_use_give_the_same_results(capcode, charset):
     a, ao = plain.decode_packed(ids0, toff0, raw=True)
     b, bo = tuned.decode_packed(ids0, toff0, raw=True)
     assert (a == b).all() and (ao == bo).all()
+
+
+def _pinned_copy(a):
+    p = tm.PinnedBuffer(max(int(a.size), 16))
+    p.array[: a.size] = a
+    return p
+
+
+def test_ring_equals_single_batch():
+    """tm_tokenize_pipeline on page-locked buffers runs on the RING (tm_host.hip: no host round trip inside a chunk - the kernels behind the
+    normalizer pass are launched over a bound and look the segment / id counts up on the device).  Chunks of every size of the ramp, several
+    id widths, the TM_E_NOSPACE answer, two calls in a row on the same slots."""
+    from conftest import EMULATED
+    img = synth.synth_vocab(synth.ENGLISHCODE, 3000, capcode=2, norm_flag=1, level=3, seed=0x52494E47)
+    raw, roffs = synth.synth_corpus(synth.ENGLISHCODE, 400_000 if EMULATED else 6_000_000, seed=73)
+    text, offs = synth.normalize_batch(raw, roffs, 2, 1)
+    v = tm.Vocab(img)
+    ids, toff, miss = v.tokenize_packed(text, offs)
+    pin, pout = _pinned_copy(raw), tm.PinnedBuffer(4 * ids.size + 64)
+    for chunk, lanes, width in ((30_000, 2, 0), (30_000, 4, 3), (90_000, 3, 4), (9_000, 4, 2)):
+        blob, boff, bmiss, enc, st = v.tokenize_pipeline(pin.array[: raw.size], roffs, raw=True, encoding_length=width, chunk_bytes=chunk, lanes=lanes, out=pout.array)
+        assert st["ring"] == 1 and st["ring_exact_chunks"] == 0 and st["chunks"] > 3, st
+        assert enc == (width or 2) and (bmiss == miss).all()
+        assert (boff == toff * np.uint64(enc)).all()
+        assert (_ids_from_bytes(np.asarray(blob), enc) == ids).all()
+        assert st["normalized_bytes"] == text.size and st["host_fallback_docs"] == 0
+    small = tm.PinnedBuffer(64)
+    blob, boff, _, enc, st = v.tokenize_pipeline(pin.array[: raw.size], roffs, raw=True, chunk_bytes=30_000, out=small.array)      # (the wrapper retries with a pageable buffer of the size asked for)
+    assert int(boff[-1]) == 2 * ids.size and (_ids_from_bytes(np.asarray(blob), 2) == ids).all()
+
+
+def test_ring_hands_chunks_to_the_exact_path():
+    """A chunk the one-pass form of the ring cannot finish by itself - a document for the host normalizer, a document of more than 512 segments,
+    text that capcode more than doubles (beyond the bound the segment kernels were launched over) - costs nothing behind its normalizer pass
+    and is run through the exact path by the ring's finisher; the ids land in document order all the same."""
+    from conftest import EMULATED
+    img = synth.synth_vocab(synth.ENGLISHCODE, 3000, capcode=2, norm_flag=1, level=3, seed=0x52494E47)
+    v = tm.Vocab(img)
+    rng = np.random.default_rng(11)
+    base_raw, base_off = synth.synth_corpus(synth.ENGLISHCODE, 150_000, seed=74)
+    docs = [bytes(base_raw[int(base_off[d]):int(base_off[d + 1])]) for d in range(base_off.size - 1)]
+    n0 = len(docs)
+    docs.insert(n0 // 5, "Việt Nam: tiếng Việt cần bộ chuẩn hoá của máy chủ ".encode() * 20)                      # Latin Extended Additional: host normalizer
+    docs.insert(n0 // 2, b"one long document of plain words that goes on and on " * 3200)                               # 170 KB: more than 512 segments
+    docs.insert(4 * n0 // 5, b".".join(bytes([65 + int(c)]) for c in rng.integers(0, 26, 9_000)))                        # grows 2.5 x under capcode
+    docs.append(b"")
+    raw = np.frombuffer(b"".join(docs), dtype=np.uint8).copy()
+    roffs = np.zeros(len(docs) + 1, dtype=np.uint64)
+    roffs[1:] = np.cumsum([len(x) for x in docs])
+    text, offs = synth.normalize_batch(raw, roffs, 2, 1)
+    ids, toff, miss = v.tokenize_packed(text, offs)
+    pin, pout = _pinned_copy(raw), tm.PinnedBuffer(2 * ids.size + 64)
+    for chunk in (20_000, 60_000):
+        blob, boff, bmiss, enc, st = v.tokenize_pipeline(pin.array[: raw.size], roffs, raw=True, chunk_bytes=chunk, lanes=3, out=pout.array)
+        assert st["ring"] == 1 and 3 <= st["ring_exact_chunks"] < st["chunks"], st
+        assert st["host_fallback_docs"] == 1
+        assert (boff == toff * np.uint64(enc)).all() and (bmiss == miss).all()
+        assert (_ids_from_bytes(np.asarray(blob), enc) == ids).all()
+        assert st["normalized_bytes"] == text.size

@@ -16,12 +16,22 @@
 #include <condition_variable>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "tm_pipeline.h"
+
+#ifndef TM_EMU
+// The HIP runtime spreads the streams of a process over GPU_MAX_HW_QUEUES hardware queues - four unless the environment says otherwise - and
+// two streams that share one run their commands in the order they were submitted in: a copy stream's 32 MiB transfer in front of a compute
+// stream's kernels holds those back for its 0.6 ms.  The ring (below) has four streams of its own beside the lanes' and the caller's; with
+// four queues it ran 1 GiB in 36.2 ms, with eight in 28.1 (profiles/r06_h2h.txt; the lanes' form 34.3 -> 31.9 with sixteen).  So the library
+// asks for eight when it is loaded - before the runtime reads the variable at its first call - unless the environment has set it already.
+__attribute__((constructor)) static void tm_runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+#endif
 
 namespace tmh {
 
@@ -43,11 +53,34 @@ struct Lane {
   bool busy = false;
 };
 
+// ---- the host-to-host ring (tm_tokenize_pipeline on page-locked buffers) ---------------------------------------------------------------------
+// A slot = one chunk in flight: a workspace, the packed ids on the device, and a page-locked block for what goes to and comes from the host
+// beside the bulk data (the chunk's verdict, raw offsets in, id offsets and missing counts out).
+struct RingSlot {
+  tm_batch* ws = nullptr;
+  uint8_t* d_bytes = nullptr;
+  uint64_t d_bytes_cap = 0;
+  uint8_t* h_pin = nullptr;
+  uint64_t h_pin_cap = 0, docs_cap = 0;
+  hipEvent_t up_done = nullptr, comp_done = nullptr, dl_done = nullptr;
+  uint64_t* h_status() const { return reinterpret_cast<uint64_t*>(h_pin); }
+  uint64_t* h_roff() const { return reinterpret_cast<uint64_t*>(h_pin + 64); }
+  uint64_t* h_toff() const { return reinterpret_cast<uint64_t*>(h_pin + 64 + (docs_cap + 2) * 8); }
+  uint32_t* h_missing() const { return reinterpret_cast<uint32_t*>(h_pin + 64 + 2 * (docs_cap + 2) * 8); }
+};
+struct Ring {
+  hipStream_t up = nullptr, down = nullptr;
+  std::vector<hipStream_t> comp;
+  std::vector<RingSlot> slots;
+  bool busy = false;                 // one call at a time drives the ring (LanePool::mu); a second caller takes the lanes
+};
+
 struct LanePool {
   std::mutex mu;
   std::condition_variable cv;
   std::vector<Lane*> lanes;
   size_t max_lanes = 8;
+  Ring ring;
 };
 
 static void lane_destroy(Lane* l) {
@@ -67,6 +100,16 @@ static void lane_destroy(Lane* l) {
 void pool_destroy(LanePool* p) {
   if (!p) return;
   for (Lane* l : p->lanes) lane_destroy(l);
+  Ring& r = p->ring;
+  for (RingSlot& s : r.slots) {
+    tm_batch_free(s.ws);
+    (void)hipFree(s.d_bytes);
+    (void)hipHostFree(s.h_pin);
+    for (hipEvent_t ev : {s.up_done, s.comp_done, s.dl_done}) if (ev) (void)hipEventDestroy(ev);
+  }
+  for (hipStream_t st : r.comp) if (st) (void)hipStreamDestroy(st);
+  if (r.up) (void)hipStreamDestroy(r.up);
+  if (r.down) (void)hipStreamDestroy(r.down);
   delete p;
 }
 
@@ -407,6 +450,313 @@ int tm_tokenize_pipeline(const tm_vocab* v, const uint8_t* text, const uint64_t*
 
 }  // extern "C"
 namespace tmh {
+// ---- tm_tokenize_pipeline ------------------------------------------------------------------------------------------------------------------
+// What both forms of the pipeline share: the call's arguments, the chunk list, and the chain of id counts - chunk k's ids go behind those of
+// chunks 0..k-1 wherever and whenever they were computed.
+struct PipeCall {
+  const tm_vocab* const* vs; uint32_t nv;
+  const uint8_t* text; const uint64_t* offsets; uint32_t ndocs; int raw; uint32_t enc;
+  uint64_t chunk_bytes; uint32_t lanes;
+  uint8_t* bytes_out; uint64_t bytes_cap; uint64_t* byte_offsets; uint32_t* missing; tm_pipeline_stats* stats;
+  bool in_pinned = false, out_pinned = false;
+  std::vector<uint32_t> first;     // first document of every chunk, + ndocs
+  size_t nchunks = 0;
+  std::vector<uint64_t> tok_base;  // ids before chunk k
+  std::vector<char> known;
+  std::mutex mu;
+  std::condition_variable cv;
+  int first_error = TM_OK;
+  std::string first_msg;
+  std::atomic<size_t> next{0};
+  double t0 = 0;
+  void fail(int rc) {
+    { std::lock_guard<std::mutex> g(mu); if (first_error == TM_OK) { first_error = rc; first_msg = last_error(); } }
+    cv.notify_all();
+  }
+  bool failed() { std::lock_guard<std::mutex> g(mu); return first_error != TM_OK; }
+  // publish chunk k's count, learn where its ids go; false: another chunk has failed
+  bool order(size_t k, uint64_t ntok, uint64_t* base) {
+    { std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return known[k] || first_error != TM_OK; });
+      if (first_error != TM_OK) return false;
+      tok_base[k + 1] = tok_base[k] + ntok;
+      known[k + 1] = 1;
+      *base = tok_base[k]; }
+    cv.notify_all();
+    return true;
+  }
+};
+
+// One chunk through the exact path on a borrowed lane, start to finish (the ring's way out for a chunk its one-pass form does not take; no
+// prefetching, every wait in line)
+static int chunk_exact(PipeCall& c, const tm_vocab* v, size_t k) {
+  const uint32_t d0 = c.first[k], nd = c.first[k + 1] - d0;
+  const uint64_t b0 = c.offsets[d0];
+  Lane* l = nullptr;
+  int rc = lane_acquire(v, &l);
+  if (rc != TM_OK) return rc;
+  std::vector<uint64_t> lo((size_t)nd + 1), toff((size_t)nd + 1);
+  for (uint32_t d = 0; d <= nd; d++) lo[d] = c.offsets[d0 + d] - b0;
+  const uint8_t* src = c.text + b0;
+  do {
+    if (!c.in_pinned) {
+      if ((rc = stage_grow(&l->h_stage_in, &l->h_in_cap, lo[nd])) != TM_OK) break;
+      std::memcpy(l->h_stage_in, src, lo[nd]);
+      src = l->h_stage_in;
+    }
+    RunOut ro;
+    if ((rc = lane_run(l, v, src, lo.data(), nd, c.raw != 0, true, &ro)) != TM_OK) break;
+    uint64_t base = 0;
+    if (!c.order(k, ro.total_tokens, &base)) break;
+    tm_batch* b = l->ws;
+    const uint64_t out_b = ro.total_tokens * c.enc;
+    if ((rc = small_d2h(b, toff.data(), b->d_tok_offsets, toff.size() * 8, l->stream)) != TM_OK) break;
+    if (c.missing && nd && (rc = small_d2h(b, c.missing + d0, b->d_doc_missing, (uint64_t)nd * 4, l->stream)) != TM_OK) break;
+    const bool fits = (base + ro.total_tokens) * c.enc <= c.bytes_cap && c.bytes_out;
+    if (fits && out_b) {
+      if ((rc = lane_dbytes(l, out_b)) != TM_OK) break;
+      launch_serialize(b->d_out, ro.total_tokens, c.enc, l->d_bytes, l->stream);
+      if (c.out_pinned) rc = d2h(c.bytes_out + base * c.enc, l->d_bytes, out_b, l->stream, "D2H ids");
+      else if ((rc = lane_stage(l, out_b)) == TM_OK) rc = d2h(l->h_stage, l->d_bytes, out_b, l->stream, "D2H ids");
+      if (rc != TM_OK) break;
+    }
+    if ((rc = small_sync(b, l->stream)) != TM_OK) break;
+    if (fits && out_b && !c.out_pinned) std::memcpy(c.bytes_out + base * c.enc, l->h_stage, out_b);
+    for (uint32_t d = 1; d <= nd; d++) c.byte_offsets[d0 + d] = (base + toff[d]) * c.enc;
+    if (c.stats) { std::lock_guard<std::mutex> g(c.mu); c.stats->host_fallback_docs += c.raw ? b->host_fallback_docs : 0; c.stats->normalized_bytes += b->nbytes; }
+  } while (false);
+  if (rc != TM_OK) (void)hipStreamSynchronize(l->stream);
+  lane_release(v, l);
+  return rc;
+}
+
+// ---- the ring --------------------------------------------------------------------------------------------------------------------------------
+// Raw text in page-locked memory -> packed ids in page-locked memory, with NO host round trip inside a chunk.  The lanes' form below waits
+// for the device three times per chunk (the normalizer's counts, the id count, the end of the download), and every wait drains the lane's
+// stream: four lanes' streams on the runtime's four hardware queues kept the device 85 % busy at best (profiles/r06_h2h.txt).  Here ONE
+// thread per device (the issuer) enqueues chunk after chunk - upload on the copy stream `up`, the normalizer pass and K0 .. K4 + the packing
+// of the ids on one of two compute streams, alternating, so that the thin kernels of one chunk run beside the wide ones of the next - and never
+// waits for the device: grids behind the normalizer pass are launched over a bound and the kernels look the counts up (tm_batch::d_ctl).
+// A second thread (the finisher) waits for a chunk's end, reads its verdict and id count from the slot's page-locked block, takes the chunk's
+// place in the output from the chain of counts, and enqueues the download on the copy stream `down`.  A chunk the one-pass form does not
+// take (documents for the host normalizer, a long document, a piece whose margins could not tell ...) costs its kernels nothing behind the
+// normalizer pass (ctl[0] == 0) and is run through the exact path by the finisher (chunk_exact).
+static int ring_slot_size(RingSlot& s, const tm_vocab* v, uint64_t need_bytes, uint32_t need_docs, uint32_t enc) {
+  hipError_t e;
+  if (!s.ws || s.ws->vocab != v || s.ws->max_bytes < need_bytes || s.ws->max_docs < need_docs) {
+    const uint64_t wb = std::max<uint64_t>(need_bytes + need_bytes / 8 + (1u << 20), s.ws ? s.ws->max_bytes : 0);
+    const uint64_t wd = std::max<uint64_t>((uint64_t)need_docs + need_docs / 4 + 64, s.ws ? s.ws->max_docs : 0);
+    if (s.ws) trace_grow("ring workspace", wb);
+    tm_batch_free(s.ws);
+    s.ws = nullptr;
+    int rc = tm_batch_create(v, wb, (uint32_t)std::min<uint64_t>(wd, 0xFFFFFFF0ull), &s.ws);
+    if (rc != TM_OK) return rc;
+  }
+  const uint64_t nb = s.ws->out_cap * 4;          // (room for the widest form: the slot outlives the call)
+  (void)enc;
+  if (s.d_bytes_cap < nb) {
+    (void)hipFree(s.d_bytes);
+    s.d_bytes = nullptr;
+    if ((e = hipMalloc((void**)&s.d_bytes, nb)) != hipSuccess) { s.d_bytes_cap = 0; return hip_fail(e, "hipMalloc (ring ids)"); }
+    s.d_bytes_cap = nb;
+  }
+  const uint64_t dc = s.ws->max_docs;
+  const uint64_t hp = 64 + 2 * (dc + 2) * 8 + (dc + 2) * 4;
+  if (s.h_pin_cap < hp || s.docs_cap != dc) {
+    (void)hipHostFree(s.h_pin);
+    s.h_pin = nullptr;
+    if ((e = hipHostMalloc((void**)&s.h_pin, hp, hipHostMallocDefault)) != hipSuccess) { s.h_pin_cap = 0; return hip_fail(e, "hipHostMalloc (ring slot)"); }
+    s.h_pin_cap = hp;
+    s.docs_cap = dc;
+  }
+  for (hipEvent_t* ev : {&s.up_done, &s.comp_done, &s.dl_done})
+    if (!*ev && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate (ring)");
+  return TM_OK;
+}
+
+static int pipeline_ring(PipeCall& c, const std::vector<Ring*>& rings) {
+  static const bool trace = getenv("TM_TRACE") != nullptr;
+  static const uint32_t slack_pct = [] { const char* e = getenv("TM_RING_SLACK"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 100 && v <= 400 ? v : 125); }();
+  // per device: a queue of issued chunks for the finisher, and the slots' states
+  struct Dev {
+    const tm_vocab* v; Ring* r;
+    std::mutex mu; std::condition_variable cv;
+    std::vector<std::pair<size_t, int>> queue;       // (chunk, slot) in issue order; slot -1: a chunk for the exact path as it is
+    size_t qhead = 0;
+    bool issuer_done = false;
+    std::vector<char> slot_free;
+  };
+  std::vector<std::unique_ptr<Dev>> devs;
+  for (uint32_t i = 0; i < c.nv; i++) { auto d = std::make_unique<Dev>(); d->v = c.vs[i]; d->r = rings[i]; d->slot_free.assign(rings[i]->slots.size(), 1); devs.push_back(std::move(d)); }
+
+  auto issuer = [&](Dev& dv) {
+    const tm_vocab* const v = dv.v;
+    Ring& r = *dv.r;
+    NearDevice near_gpu(v->device);
+    int rc = enter_device(v);
+    size_t issued = 0;
+    while (rc == TM_OK && !c.failed()) {
+      const size_t k = c.next.fetch_add(1);
+      if (k >= c.nchunks) break;
+      const uint32_t d0 = c.first[k], nd = c.first[k + 1] - d0;
+      const uint64_t b0 = c.offsets[d0], nb = c.offsets[d0 + nd] - b0;
+      int si = -1;
+      if (nb > 0) {
+        // a free slot (the finisher hands them back in order)
+        std::unique_lock<std::mutex> lk(dv.mu);
+        dv.cv.wait(lk, [&] { for (char f : dv.slot_free) if (f) return true; return false; });
+        for (size_t j = 0; j < dv.slot_free.size(); j++) { const size_t q = (issued + j) % dv.slot_free.size(); if (dv.slot_free[q]) { si = (int)q; break; } }
+        dv.slot_free[si] = 0;
+      }
+      if (si >= 0) {
+        RingSlot& s = r.slots[si];
+        tm_batch* b = s.ws;
+        uint64_t* lo = s.h_roff();
+        uint64_t npieces = 0;
+        for (uint32_t d = 0; d <= nd; d++) lo[d] = c.offsets[d0 + d] - b0;
+        for (uint32_t d = 0; d < nd; d++) npieces += (lo[d + 1] - lo[d] + 1023) / 1024;
+        hipStream_t cs = r.comp[issued % r.comp.size()];
+        hipError_t e = hipSuccess;
+        const double ti0 = trace ? now_ms() : 0;
+        if ((rc = raw_prepare(b, nb, nd, npieces, cs)) != TM_OK) break;
+        if ((e = hipMemcpyAsync(b->d_raw, c.text + b0, nb, hipMemcpyHostToDevice, r.up)) != hipSuccess ||
+            (e = hipMemcpyAsync(b->d_raw_off, lo, ((uint64_t)nd + 1) * 8, hipMemcpyHostToDevice, r.up)) != hipSuccess ||
+            (e = hipEventRecord(s.up_done, r.up)) != hipSuccess || (e = hipStreamWaitEvent(cs, s.up_done, 0)) != hipSuccess) { rc = hip_fail(e, "ring upload"); break; }
+        const uint64_t seg_bound = (nb / 100 * slack_pct + 99) / SEG + nd + 1;
+        s.h_status()[0] = ~0ull;
+        if ((rc = ring_enqueue_normalize(b, cs, seg_bound)) != TM_OK) break;
+        if ((rc = ring_enqueue_tokenize(b, cs, c.enc, s.d_bytes, s.d_bytes_cap, s.h_status())) != TM_OK) break;
+        if ((e = hipEventRecord(s.comp_done, cs)) != hipSuccess) { rc = hip_fail(e, "hipEventRecord"); break; }
+        if (trace) fprintf(stderr, "[ring] issue chunk %3zu (%5.1f MiB, %u docs) slot %d at %7.2f ms, %.3f ms of launches\n", k, nb / 1048576.0, nd, si, ti0 - c.t0, now_ms() - ti0);
+        issued++;
+      }
+      { std::lock_guard<std::mutex> g(dv.mu); dv.queue.emplace_back(k, si); }
+      dv.cv.notify_all();
+    }
+    if (rc != TM_OK) c.fail(rc);
+    { std::lock_guard<std::mutex> g(dv.mu); dv.issuer_done = true; }
+    dv.cv.notify_all();
+  };
+
+  auto finisher = [&](Dev& dv) {
+    const tm_vocab* const v = dv.v;
+    Ring& r = *dv.r;
+    NearDevice near_gpu(v->device);
+    int rc = enter_device(v);
+    struct Pending { size_t k; int si; uint64_t base, ntok; };
+    Pending prev{0, -1, 0, 0};
+    // the downloads of a chunk are through: its offsets and counts to the caller, the slot back to the issuer
+    auto complete = [&](const Pending& p) -> int {
+      RingSlot& s = r.slots[p.si];
+      hipError_t e = hipEventSynchronize(s.dl_done);
+      if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize (ring download)");
+      const uint32_t d0 = c.first[p.k], nd = c.first[p.k + 1] - d0;
+      const uint64_t* toff = s.h_toff();
+      for (uint32_t d = 1; d <= nd; d++) c.byte_offsets[d0 + d] = (p.base + toff[d]) * c.enc;
+      if (c.missing && nd) std::memcpy(c.missing + d0, s.h_missing(), (size_t)nd * 4);
+      if (c.stats) { std::lock_guard<std::mutex> g(c.mu); c.stats->normalized_bytes += s.h_status()[2]; }
+      { std::lock_guard<std::mutex> g(dv.mu); dv.slot_free[p.si] = 1; }
+      dv.cv.notify_all();
+      if (trace) fprintf(stderr, "[ring] chunk %3zu complete at %7.2f ms\n", p.k, now_ms() - c.t0);
+      return TM_OK;
+    };
+    for (;;) {
+      std::pair<size_t, int> item;
+      { std::unique_lock<std::mutex> lk(dv.mu);
+        dv.cv.wait(lk, [&] { return dv.qhead < dv.queue.size() || dv.issuer_done; });
+        if (dv.qhead >= dv.queue.size()) break;
+        item = dv.queue[dv.qhead++]; }
+      const size_t k = item.first;
+      const int si = item.second;
+      if (rc != TM_OK || c.failed()) {              // (drain: whatever is in flight ends before the call returns)
+        if (si >= 0) (void)hipEventSynchronize(r.slots[si].comp_done);
+        continue;
+      }
+      bool exact = si < 0;
+      uint64_t ntok = 0;
+      if (si >= 0) {
+        RingSlot& s = r.slots[si];
+        hipError_t e = hipEventSynchronize(s.comp_done);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize (ring chunk)"); c.fail(rc); continue; }
+        const uint64_t st = s.h_status()[0];
+        if (trace) fprintf(stderr, "[ring] chunk %3zu computed at %7.2f ms: status %llu, %llu ids, %llu segments\n", k, now_ms() - c.t0, (unsigned long long)st,
+                           (unsigned long long)s.h_status()[1], (unsigned long long)s.h_status()[3]);
+        if (st != 0) exact = true; else ntok = s.h_status()[1];
+      }
+      if (exact) {
+        if (si >= 0) { std::lock_guard<std::mutex> g(dv.mu); dv.slot_free[si] = 1; }
+        if (si >= 0) dv.cv.notify_all();
+        if (c.stats && si >= 0) { std::lock_guard<std::mutex> g(c.mu); c.stats->ring_exact_chunks++; }
+        if ((rc = chunk_exact(c, v, k)) != TM_OK) c.fail(rc);
+        continue;
+      }
+      RingSlot& s = r.slots[si];
+      uint64_t base = 0;
+      if (!c.order(k, ntok, &base)) { rc = TM_E_INTERNAL; continue; }
+      const uint32_t nd = c.first[k + 1] - c.first[k];
+      const uint64_t out_b = ntok * c.enc;
+      const bool fits = (base + ntok) * c.enc <= c.bytes_cap && c.bytes_out;
+      hipError_t e = hipSuccess;
+      if (fits && out_b) e = hipMemcpyAsync(c.bytes_out + base * c.enc, s.d_bytes, out_b, hipMemcpyDeviceToHost, r.down);
+      if (e == hipSuccess) e = hipMemcpyAsync(s.h_toff(), s.ws->d_tok_offsets, ((uint64_t)nd + 1) * 8, hipMemcpyDeviceToHost, r.down);
+      if (e == hipSuccess && c.missing) e = hipMemcpyAsync(s.h_missing(), s.ws->d_doc_missing, (uint64_t)nd * 4, hipMemcpyDeviceToHost, r.down);
+      if (e == hipSuccess) e = hipEventRecord(s.dl_done, r.down);
+      if (e != hipSuccess) { rc = hip_fail(e, "ring download"); c.fail(rc); continue; }
+      if (prev.si >= 0 && (rc = complete(prev)) != TM_OK) { c.fail(rc); prev.si = -1; continue; }
+      prev = Pending{k, si, base, ntok};
+    }
+    if (prev.si >= 0) { if (rc == TM_OK && !c.failed()) { if ((rc = complete(prev)) != TM_OK) c.fail(rc); } else (void)hipEventSynchronize(r.slots[prev.si].dl_done); }
+    (void)hipStreamSynchronize(r.down);
+  };
+
+  std::vector<std::thread> th;
+  for (uint32_t i = 0; i < c.nv; i++) {
+    th.emplace_back(finisher, std::ref(*devs[i]));
+    if (i > 0) th.emplace_back(issuer, std::ref(*devs[i]));
+  }
+  issuer(*devs[0]);
+  for (auto& t : th) t.join();
+  return c.first_error;
+}
+
+// borrow the rings of the replicas (all or none) and size their slots for this call; false: somebody else drives one of them
+static int rings_acquire(PipeCall& c, uint32_t nslots, uint32_t nstreams, std::vector<Ring*>& rings, bool* got) {
+  *got = false;
+  uint64_t max_nb = 0; uint32_t max_nd = 0;
+  for (size_t k = 0; k < c.nchunks; k++) {
+    max_nb = std::max<uint64_t>(max_nb, c.offsets[c.first[k + 1]] - c.offsets[c.first[k]]);
+    max_nd = std::max<uint32_t>(max_nd, c.first[k + 1] - c.first[k]);
+  }
+  for (uint32_t i = 0; i < c.nv; i++) {
+    LanePool* p = pool_of(c.vs[i]);
+    std::lock_guard<std::mutex> g(p->mu);
+    if (p->ring.busy) { for (Ring* r : rings) r->busy = false; rings.clear(); return TM_OK; }      // (a ring's busy flag is only read under its pool's lock; clearing ours without it is safe: nobody else sets it while true)
+    p->ring.busy = true;
+    rings.push_back(&p->ring);
+  }
+  int rc = TM_OK;
+  for (uint32_t i = 0; i < c.nv && rc == TM_OK; i++) {
+    Ring& r = *rings[i];
+    if ((rc = enter_device(c.vs[i])) != TM_OK) break;
+    hipError_t e = hipSuccess;
+    if (!r.up && (e = hipStreamCreateWithFlags(&r.up, hipStreamNonBlocking)) != hipSuccess) { rc = hip_fail(e, "hipStreamCreate (ring)"); break; }
+    if (!r.down && (e = hipStreamCreateWithFlags(&r.down, hipStreamNonBlocking)) != hipSuccess) { rc = hip_fail(e, "hipStreamCreate (ring)"); break; }
+    while (r.comp.size() < nstreams) {
+      hipStream_t st = nullptr;
+      if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) { rc = hip_fail(e, "hipStreamCreate (ring)"); break; }
+      r.comp.push_back(st);
+    }
+    if (rc != TM_OK) break;
+    if (r.slots.size() < nslots) r.slots.resize(nslots);
+    for (RingSlot& s : r.slots) if ((rc = ring_slot_size(s, c.vs[i], lane_need(true, max_nb), max_nd, c.enc)) != TM_OK) break;
+  }
+  if (rc != TM_OK) { for (Ring* r : rings) r->busy = false; rings.clear(); return rc; }
+  *got = true;
+  return TM_OK;
+}
+
+static int pipeline_lanes(PipeCall& c);
+
 // The pipeline over the lanes of ONE vocabulary or of its replicas on several devices (tm_tokenize_pipeline_multi, tm_multi.hip): worker w
 // borrows a lane of replica w % nv, so the chunks — handed out from one counter — go to whichever lane of whichever device is free, and the
 // ids of chunk k land behind those of chunks 0..k-1 wherever they were computed.  `lanes` = lanes per replica.
@@ -422,51 +772,96 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
   if (chunk_bytes == 0) chunk_bytes = 32ull << 20;
   if (lanes == 0) lanes = 4;
   lanes = std::min<uint32_t>(lanes, 8);
-  // chunks = maximal runs of whole documents of at most chunk_bytes (a longer document is a chunk of its own)
-  std::vector<uint32_t> first;     // first document of every chunk, + ndocs
-  const size_t nramp = (size_t)lanes * nv;                          // workers, if there are chunks enough
+  PipeCall c{vs, nv, text, offsets, ndocs, raw, encoding_length, chunk_bytes, lanes, bytes_out, bytes_cap, byte_offsets, missing, stats};
+  c.in_pinned = is_pinned(text); c.out_pinned = is_pinned(bytes_out);
+  // the ring: raw text, page-locked buffers on both sides, and a normalizer pass in the one-pass form
+  static const int ring_env = [] { const char* e = getenv("TM_RING"); return e ? atoi(e) : 1; }();
+  static const uint32_t ring_slots = [] { const char* e = getenv("TM_RING_SLOTS"); const int n = e ? atoi(e) : 0; return (uint32_t)(n >= 2 && n <= 16 ? n : 4); }();
+  static const uint32_t ring_streams = [] { const char* e = getenv("TM_RING_STREAMS"); const int n = e ? atoi(e) : 0; return (uint32_t)(n >= 1 && n <= 4 ? n : 2); }();
+  bool use_ring = ring_env != 0 && raw && c.in_pinned && c.out_pinned && ndocs > 0;
+  for (uint32_t i = 0; i < nv && use_ring; i++) use_ring = ring_supported(vs[i]);
+  // chunks = maximal runs of whole documents of at most `limit` bytes (a longer document is a chunk of its own)
+  std::vector<uint32_t>& first = c.first;
+  for (uint32_t d = 0; d < ndocs; d++) if (offsets[d + 1] < offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
+  const double t_entry = now_ms();
+  const size_t nramp = (size_t)lanes * nv;                          // the lanes' form: workers, if there are chunks enough
+  // The steady state of the pipeline runs near the device-resident rate; what it loses it loses at the two ends.
+  // Lanes' form: W workers that all begin with full chunks upload W chunks at once and then run their kernels in lock step, so the first W
+  // chunks grow geometrically - chunk_bytes / 2^W ... chunk_bytes / 2 - and the last ones shrink by 1 / W of what is left each.
+  // Ring: a chunk's kernels cannot begin before its upload has ended, and the link is only a fifth faster than the kernels (56 against 46 GB/s):
+  // behind a chunk of c bytes the next may have c x RAMP / 100 (default 1.5: 2, 3, 4.5 ... MiB) or the device waits for it; the tail halves
+  // (... 32, 16, 8, 4 MiB: what the end costs is the last chunk's kernels and download with nothing beside them).
+  static const uint64_t ramp_pct = [] { const char* e = getenv("TM_RING_RAMP"); const int v = e ? atoi(e) : 0; return (uint64_t)(v >= 110 && v <= 400 ? v : 150); }();
+  static const uint64_t ramp_first = [] { const char* e = getenv("TM_RING_FIRST_KIB"); const int v = e ? atoi(e) : 0; return (uint64_t)(v >= 64 && v <= (1 << 20) ? v : 2048) << 10; }();
+  uint64_t ring_limit = ramp_first;
   for (uint32_t d = 0; d < ndocs;) {
     first.push_back(d);
-    uint32_t e = d + 1;
-    if (offsets[e] < offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
-    // The steady state of the pipeline runs at the device-resident rate (profiles/r04_h2h_lanes.txt: one 32 MiB chunk per 0.87 ms against
-    // 0.83); what it loses it loses at the two ends.  Start: W workers that all begin with full chunks upload W chunks at once (the GPU idles
-    // behind a shared PCIe link) and then run their kernels in lock step, thin phases together.  So the first W chunks grow geometrically -
-    // chunk_bytes / 2^W ... chunk_bytes / 2: the first kernels start after a 2 MiB upload, and the workers come out of the ramp staggered.
-    // End: the last chunks shrink the same way (each takes 1/W of what is left), so that the drain - one worker's kernels and its download
-    // with nothing beside them - is short.
     const size_t ci = first.size() - 1;                              // this chunk's number
     const uint64_t left = offsets[ndocs] - offsets[d];
     uint64_t limit = chunk_bytes;
-    // (the shift count is clamped: 8 lanes on 8 devices - or on the virtual devices of a test - make nramp 64 and more)
-    if (ci < nramp) limit = std::max<uint64_t>(chunk_bytes >> std::min<size_t>(nramp - ci, 63), std::min<uint64_t>(chunk_bytes, 1u << 20));
-    // (the drain's shape - a floor of 2 / 4 / 8 / 16 MiB, a third or half of what is left instead of a quarter - was swept in round 5: every
-    // setting 30 - 37 ms per call, the same as this one; the spread of a call is the copy engines' queueing, not the chunk sizes: profiles/r05_h2h.txt)
-    if (left < (uint64_t)nramp * chunk_bytes) limit = std::min(limit, std::max<uint64_t>(left / nramp, std::min<uint64_t>(chunk_bytes, 2u << 20)));
-    while (e < ndocs && offsets[e + 1] >= offsets[e] && offsets[e + 1] - offsets[d] <= limit) e++;
-    d = e;
+    if (use_ring) {
+      limit = std::min(chunk_bytes, ring_limit);
+      ring_limit = std::min<uint64_t>(chunk_bytes, ring_limit / 100 * ramp_pct);
+      if (left < 2 * (uint64_t)nv * chunk_bytes) limit = std::min(limit, std::max<uint64_t>(left / (2 * (uint64_t)nv), std::min<uint64_t>(chunk_bytes, 4u << 20)));
+    } else {
+      // (the shift count is clamped: 8 lanes on 8 devices - or on the virtual devices of a test - make nramp 64 and more)
+      if (ci < nramp) limit = std::max<uint64_t>(chunk_bytes >> std::min<size_t>(nramp - ci, 63), std::min<uint64_t>(chunk_bytes, 1u << 20));
+      // (the drain's shape - a floor of 2 / 4 / 8 / 16 MiB, a third or half of what is left instead of a quarter - was swept in round 5: every
+      // setting 30 - 37 ms per call, the same as this one: profiles/r05_h2h.txt)
+      if (left < (uint64_t)nramp * chunk_bytes) limit = std::min(limit, std::max<uint64_t>(left / nramp, std::min<uint64_t>(chunk_bytes, 2u << 20)));
+    }
+    // the last document that still ends within `limit` bytes of the chunk's first byte (at least one document)
+    const uint64_t* const lo = offsets + d + 1;
+    const uint64_t* const hi = std::upper_bound(lo, offsets + ndocs + 1, offsets[d] + limit);
+    d = std::max<uint32_t>(d + 1, (uint32_t)(hi - offsets) - 1);
   }
   first.push_back(ndocs);
-  const size_t nchunks = first.size() - 1;
+  c.nchunks = first.size() - 1;
   byte_offsets[0] = 0;
   if (stats) *stats = tm_pipeline_stats{};
-  if (nchunks == 0) return TM_OK;
-  const bool in_pinned = is_pinned(text), out_pinned = is_pinned(bytes_out);
-  // chunk k's ids go behind those of chunks 0..k-1: a chunk publishes its token count as soon as its kernels have run, and the
-  // next one waits for it only before its own D2H
-  std::vector<uint64_t> tok_base(nchunks + 1, 0);
-  std::vector<char> known(nchunks + 1, 0);
-  known[0] = 1;
-  std::mutex mu;
-  std::condition_variable cv;
-  int first_error = TM_OK;
-  std::string first_msg;
-  std::atomic<size_t> next{0};
-  const uint32_t nworkers = (uint32_t)std::min<size_t>((size_t)lanes * nv, nchunks);
+  if (c.nchunks == 0) return TM_OK;
+  c.tok_base.assign(c.nchunks + 1, 0);
+  c.known.assign(c.nchunks + 1, 0);
+  c.known[0] = 1;
+  c.t0 = now_ms();
+  { static const bool trace = getenv("TM_TRACE") != nullptr; if (trace) fprintf(stderr, "[pipe] %zu chunks laid out in %.3f ms (%s)\n", c.nchunks, c.t0 - t_entry, use_ring ? "ring" : "lanes"); }
+  if (c.nchunks < 2) use_ring = false;          // (one chunk: the lanes' form is the shorter way)
+  int rc = TM_OK;
+  uint32_t workers = 0;
+  if (use_ring) {
+    std::vector<Ring*> rings;
+    bool got = false;
+    if ((rc = rings_acquire(c, ring_slots, ring_streams, rings, &got)) != TM_OK) return rc;
+    if (got) {
+      rc = pipeline_ring(c, rings);
+      for (uint32_t i = 0; i < nv; i++) { LanePool* p = pool_of(vs[i]); std::lock_guard<std::mutex> g(p->mu); p->ring.busy = false; }
+      workers = nv;
+      if (stats) stats->ring = 1;
+    } else use_ring = false;
+  }
+  if (!use_ring) { rc = pipeline_lanes(c); workers = (uint32_t)std::min<size_t>((size_t)lanes * nv, c.nchunks); }
+  if (rc != TM_OK || c.first_error != TM_OK) return set_error(c.first_error != TM_OK ? c.first_error : rc, "%s", c.first_msg.c_str());
+  if (stats) { stats->chunks = (uint32_t)c.nchunks; stats->lanes = workers; stats->input_pinned = c.in_pinned; stats->output_pinned = c.out_pinned; }
+  if (byte_offsets[ndocs] > bytes_cap || !bytes_out) return set_error(TM_E_NOSPACE, "bytes_cap %llu < %llu required", (unsigned long long)bytes_cap, (unsigned long long)byte_offsets[ndocs]);
+  return TM_OK;
+}
+
+// The lanes' form: every worker thread borrows a lane and takes chunk after chunk through it - upload, tm_batch_normalize (one wait), the
+// tokenizer (one wait for the id count), the download (one wait).  For pageable buffers, already-normalized text, vocabularies whose
+// normalizer is not the one-pass form, and callers that find the ring taken.
+static int pipeline_lanes(PipeCall& c) {
+  const tm_vocab* const* vs = c.vs; const uint32_t nv = c.nv; const uint8_t* text = c.text; const uint64_t* offsets = c.offsets; const int raw = c.raw;
+  const uint32_t encoding_length = c.enc; uint8_t* bytes_out = c.bytes_out; const uint64_t bytes_cap = c.bytes_cap; uint64_t* byte_offsets = c.byte_offsets;
+  uint32_t* missing = c.missing; tm_pipeline_stats* stats = c.stats;
+  const std::vector<uint32_t>& first = c.first;
+  const size_t nchunks = c.nchunks;
+  const bool in_pinned = c.in_pinned, out_pinned = c.out_pinned;
+  std::atomic<size_t>& next = c.next;
+  const uint32_t nworkers = (uint32_t)std::min<size_t>((size_t)c.lanes * nv, nchunks);
   // A lane works on one chunk at a time, but the raw text of its NEXT chunk is uploaded (on the lane's second stream) as soon as the
   // normalizer pass of the current one is through with the raw buffer: the H2D of chunk k+1 hides behind the tokenizer kernels of chunk k.
   static const bool trace = getenv("TM_TRACE") != nullptr;
-  const double t_pipe0 = now_ms();
+  const double t_pipe0 = c.t0;
   auto worker = [&](uint32_t wi) {
     const tm_vocab* const v = vs[wi % nv];
     NearDevice near_gpu(v->device);             // (worker 0 is the calling thread: it gets its affinity back when the call returns)
@@ -499,7 +894,7 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
     bool prefetched = false;
     const uint8_t* src = nullptr;
     while (rc == TM_OK && k < nchunks) {
-      { std::lock_guard<std::mutex> g(mu); if (first_error != TM_OK) { break; } }
+      if (c.failed()) break;
       const uint32_t d0 = first[k], d1 = first[k + 1], nd = d1 - d0;
       const double tr0 = trace ? now_ms() : 0;
       double tr1 = 0, tr2 = 0, tr3 = 0;
@@ -532,17 +927,11 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
       if ((rc = lane_compute(l, v, src, loc.data(), nd, raw != 0, true, &ro, prefetch)) != TM_OK) break;
       if (trace) tr2 = now_ms();
       if (k_next == nchunks && !next_up) k_next = next.fetch_add(1);          // (already-normalized input: nothing was prefetched)
-      {   // publish this chunk's count, learn where its ids go
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return known[k] || first_error != TM_OK; });
-        if (first_error != TM_OK) break;
-        tok_base[k + 1] = tok_base[k] + ro.total_tokens;
-        known[k + 1] = 1;
-      }
-      cv.notify_all();
+      uint64_t base = 0;
+      if (!c.order(k, ro.total_tokens, &base)) break;          // publish this chunk's count, learn where its ids go
       if (trace) tr3 = now_ms();
       tm_batch* b = l->ws;
-      const uint64_t base = tok_base[k], out_b = ro.total_tokens * encoding_length;
+      const uint64_t out_b = ro.total_tokens * encoding_length;
       toff.resize((size_t)nd + 1);
       if ((rc = small_d2h(b, toff.data(), b->d_tok_offsets, toff.size() * 8, l->stream)) != TM_OK) break;
       if (missing && nd && (rc = small_d2h(b, missing + d0, b->d_doc_missing, (uint64_t)nd * 4, l->stream)) != TM_OK) break;
@@ -566,26 +955,20 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
       if (trace) fprintf(stderr, "[pipe] worker %u chunk %3zu (%5.1f MiB): start %7.2f  upload/wait %5.2f  compute %5.2f  order-wait %5.2f  download %5.2f  -> end %7.2f ms\n", wi, k,
                          (offsets[d1] - offsets[d0]) / 1048576.0, tr0 - t_pipe0, tr1 - tr0, tr2 - tr1, tr3 - tr2, now_ms() - tr3, now_ms() - t_pipe0);
       for (uint32_t d = 1; d <= nd; d++) byte_offsets[d0 + d] = (base + toff[d]) * encoding_length;
-      if (stats) { std::lock_guard<std::mutex> g(mu); stats->host_fallback_docs += raw ? b->host_fallback_docs : 0; stats->normalized_bytes += b->nbytes; }
+      if (stats) { std::lock_guard<std::mutex> g(c.mu); stats->host_fallback_docs += raw ? b->host_fallback_docs : 0; stats->normalized_bytes += b->nbytes; }
       k = k_next;
       prefetched = next_up;
       if (next_up) { loc.swap(loc_next); src = src_next; }
     }
     if (l && l->up_stream) (void)hipStreamSynchronize(l->up_stream);          // (an error may leave an upload in flight)
-    if (rc != TM_OK) {
-      { std::lock_guard<std::mutex> g(mu); if (first_error == TM_OK) { first_error = rc; first_msg = last_error(); } }
-      cv.notify_all();
-    }
+    if (rc != TM_OK) c.fail(rc);
     if (l) lane_release(v, l);
   };
   std::vector<std::thread> th;
   for (uint32_t t = 1; t < nworkers; t++) th.emplace_back(worker, t);
   worker(0);
   for (auto& t : th) t.join();
-  if (first_error != TM_OK) return set_error(first_error, "%s", first_msg.c_str());
-  if (stats) { stats->chunks = (uint32_t)nchunks; stats->lanes = nworkers; stats->input_pinned = in_pinned; stats->output_pinned = out_pinned; }
-  if (byte_offsets[ndocs] > bytes_cap || !bytes_out) return set_error(TM_E_NOSPACE, "bytes_cap %llu < %llu required", (unsigned long long)bytes_cap, (unsigned long long)byte_offsets[ndocs]);
-  return TM_OK;
+  return c.first_error;
 }
 }  // namespace tmh
 extern "C" {

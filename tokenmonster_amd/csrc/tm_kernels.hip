@@ -114,9 +114,12 @@ __global__ void k_scan_final(const uint32_t* __restrict__ in, uint64_t n, const 
 }
 
 // K0: segment g belongs to the document d with doc_seg_start[d] <= g < doc_seg_start[d+1]
+// (ctl, here and in the kernels below: the control words of a chunk of the host-to-host ring, k_chunk_ctl - when given, the number of segments /
+// documents is what the DEVICE has found, ctl[0] / ctl[1], and the kernel argument is only the bound the grid was sized for)
 __global__ void k_segments(const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs, uint64_t nseg,
-                           uint32_t* __restrict__ seg_doc) {
+                           uint32_t* __restrict__ seg_doc, const uint64_t* __restrict__ ctl = nullptr) {
   uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ctl) nseg = ctl[0];
   if (g >= nseg) return;
   uint32_t lo = 0, hi = ndocs;   // invariant: start[lo] <= g < start[hi]
   while (hi - lo > 1) {
@@ -313,8 +316,10 @@ __device__ __forceinline__ uint32_t transition(const Tables& T, const WaveLds& w
 // For a batch whose text still lies in the device normalizer's slabs (tm_norm.hip): the piece a segment begins in, the offset of its first
 // byte in that piece's slab, and how many bytes the piece holds from there.  piece_off = the pieces' places in the packed text.
 __global__ void k_seg_src(const uint32_t* __restrict__ seg_doc, const uint64_t* __restrict__ doc_seg_start, const uint64_t* __restrict__ doc_begin,
-                          const uint64_t* __restrict__ doc_piece_start, const uint64_t* __restrict__ piece_off, uint64_t nseg, uint4* __restrict__ seg_src) {
+                          const uint64_t* __restrict__ doc_piece_start, const uint64_t* __restrict__ piece_off, uint64_t nseg, uint4* __restrict__ seg_src,
+                          const uint64_t* __restrict__ ctl = nullptr) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ctl) nseg = ctl[0];
   if (g >= nseg) return;
   const uint32_t d = seg_doc[g];
   const uint64_t begin = doc_begin[d] + (g - doc_seg_start[d]) * SEG;
@@ -335,7 +340,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
                                                                 const uint64_t* __restrict__ doc_seg_start, uint64_t nseg,
                                                                 uint32_t* __restrict__ R0, uint2* __restrict__ side,
                                                                 uint32_t* __restrict__ R1, uint32_t* __restrict__ exitmap, uint16_t* __restrict__ exit16,
-                                                                int narrow, int dbg, const uint8_t* __restrict__ slab, const uint4* __restrict__ seg_src) {
+                                                                int narrow, int dbg, const uint8_t* __restrict__ slab, const uint4* __restrict__ seg_src,
+                                                                const uint64_t* __restrict__ ctl = nullptr) {
   __shared__ uint8_t s_bb[256];
   __shared__ WaveLds s_wave[WAVES];
   const int lane = threadIdx.x & 63, wvi = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the segment, its document and lengths live in SGPRs
@@ -343,6 +349,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
   for (int j = threadIdx.x; j < 256; j += WAVES * 64) s_bb[j] = T.begin_byte[j];
   __syncthreads();
   const uint64_t g = (uint64_t)blockIdx.x * WAVES + wvi;
+  if (ctl) nseg = ctl[0];
   if (g >= nseg) return;
   WaveLds& w = s_wave[wvi];
   const int Lmax = TM_DBG_ON(dbg & 0x180000) ? min((dbg & 0x80000) ? 12 : 20, (int)T.max_len) : (int)T.max_len;      // (devel bits 19 / 20: no walk deeper than 12 / 20 bytes - what the deep tail of step A1 costs)
@@ -969,8 +976,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
 __global__ void k_resolve(const uint32_t* __restrict__ exitmap, const uint16_t* __restrict__ exit16, const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs,
                           const uint8_t* __restrict__ doc_entry, uint8_t* __restrict__ seg_entry, uint32_t* __restrict__ seg_tokbase,
                           uint32_t* __restrict__ doc_ntok, uint32_t* __restrict__ error_flag, uint32_t long_segs, uint32_t* __restrict__ doc_fd,
-                          uint32_t* __restrict__ doc_missing) {
+                          uint32_t* __restrict__ doc_missing, const uint64_t* __restrict__ ctl = nullptr) {
   uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ctl && d < ndocs && ctl[1] == 0) { doc_ntok[d] = 0u; return; }          // (a chunk the ring does not take: no ids)
   if (d >= ndocs) return;
   doc_fd[d] = 0u; doc_missing[d] = 0u;          // (what K4 counts per document starts at zero: no memset commands of their own)
   uint64_t g0 = doc_seg_start[d], g1 = doc_seg_start[d + 1];
@@ -1162,8 +1170,10 @@ constexpr int TROW = SEG + 8;           // words per tile row (16-byte multiple;
 // Record nseg holds the end of the output stream.
 __global__ void k_seg_params(const uint64_t* __restrict__ doc_begin, const uint64_t* __restrict__ doc_end, const uint32_t* __restrict__ seg_doc,
                              const uint64_t* __restrict__ doc_seg_start, uint64_t nseg, uint32_t ndocs, const uint8_t* __restrict__ seg_entry,
-                             const uint32_t* __restrict__ seg_tokbase, const uint64_t* __restrict__ tok_offsets, uint4* __restrict__ par) {
+                             const uint32_t* __restrict__ seg_tokbase, const uint64_t* __restrict__ tok_offsets, uint4* __restrict__ par,
+                             const uint64_t* __restrict__ ctl = nullptr) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ctl) nseg = ctl[0];
   if (g > nseg) return;
   if (g == nseg) { const uint64_t total = tok_offsets[ndocs]; par[g] = make_uint4(0u, 0u, (uint32_t)total, (uint32_t)(total >> 32)); return; }
   const uint32_t doc = seg_doc[g];
@@ -1278,12 +1288,14 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
                                                    uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
                                                    uint32_t* __restrict__ error_flag, uint32_t stage_after, const uint32_t* __restrict__ seg_doc,
-                                                   uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing, uint32_t no_id) {
+                                                   uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing, uint32_t no_id,
+                                                   const uint64_t* __restrict__ ctl = nullptr) {
   alignas(16) __shared__ uint32_t s_tile[NARROW ? 1 : TS][NARROW ? 4 : TROW];
   alignas(16) __shared__ uint16_t s_a[NARROW ? TS : 1][NARROW ? TROW_N : 8];
   alignas(16) __shared__ uint8_t s_m[NARROW ? TS : 1][NARROW ? TROW_N : 16];
   const int lane = threadIdx.x;
   const uint64_t g0 = (uint64_t)blockIdx.x * TS;
+  if (ctl) { nseg = ctl[0]; if (g0 >= nseg) return; }
   const int nv = (int)(nseg - g0 < (uint64_t)TS ? nseg - g0 : (uint64_t)TS);
   const TileSeg t = tile_segment(par, g0 + lane, lane < TS, nseg);
   constexpr uint32_t SLACK = NARROW ? TSLACK_N : TSLACK;
@@ -1453,13 +1465,15 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
                                                   const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
                                                   uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
                                                   uint32_t* __restrict__ error_flag, uint32_t stage_after, const uint32_t* __restrict__ seg_doc,
-                                                  uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing, uint32_t no_id) {
+                                                  uint32_t* __restrict__ doc_fd, uint32_t* __restrict__ doc_missing, uint32_t no_id,
+                                                  const uint64_t* __restrict__ ctl = nullptr) {
   alignas(16) __shared__ uint8_t s_m[TSL][TROW_L];
   __shared__ uint32_t s_side[TSL][9];                 // (a word of slack: slot numbers up to TROW_L - 1 are looked up)
   __shared__ uint32_t s_n[TSL];
   __shared__ uint64_t s_base[TSL];
   const int lane = threadIdx.x;
   const uint64_t g0 = (uint64_t)blockIdx.x * TSL;
+  if (ctl) { nseg = ctl[0]; if (g0 >= nseg) return; }
   const int nv = (int)(nseg - g0 < (uint64_t)TSL ? nseg - g0 : (uint64_t)TSL);
   const TileSeg t = tile_segment(par, g0 + lane, lane < TSL, nseg);
   constexpr uint32_t SLACK = TSLACK_L;
@@ -1743,6 +1757,81 @@ __global__ __launch_bounds__(256) void k_serialize_wide(const uint32_t* __restri
   *reinterpret_cast<uint4*>(out + (head + t * PER) * ENC) = o;
 }
 
+// ---- a chunk of the host-to-host ring: the counts stay on the device --------------------------------------------------------------------
+// k_chunk_ctl, behind the normalizer pass: ninfo = what tm_batch_normalize reads back ([0] documents for the host normalizer, [1] long
+// documents, [2] segments, [3] undecided pieces, [4] pieces that outgrew their slab, [5] normalized bytes, [6] short pieces inside a document).
+// A chunk with any of those (or beyond the bounds its kernels were launched over) is NOT taken: ctl[0] = ctl[1] = 0 turn the kernels behind
+// this one into no-ops, the status word tells the host, which runs the chunk through the exact path (tm_host.hip).
+__global__ void k_chunk_ctl(const unsigned long long* __restrict__ ninfo, uint32_t ndocs, uint64_t max_bytes, uint64_t seg_bound, uint64_t* __restrict__ ctl) {
+  if (threadIdx.x != 0) return;
+  uint64_t st = 0;
+  if (ninfo[0]) st |= RING_HOST_DOCS;
+  if (ninfo[1]) st |= RING_LONG_DOCS;
+  if (ninfo[3]) st |= RING_UNDECIDED;
+  if (ninfo[4]) st |= RING_SLAB;
+  if (ninfo[6]) st |= RING_SHORT_PIECE;
+  if (ninfo[5] > max_bytes) st |= RING_BYTES;
+  if (ninfo[2] > seg_bound) st |= RING_SEGS;
+  ctl[0] = st ? 0ull : ninfo[2];
+  ctl[1] = st ? 0ull : (uint64_t)ndocs;
+  ctl[2] = 0ull;
+  ctl[3] = st;
+  ctl[4] = ninfo[5];
+  ctl[5] = ninfo[0];
+}
+// k_chunk_done, behind K4: the number of ids for the serializer (ctl[2]) and the verdict for the host
+__global__ void k_chunk_done(uint64_t* __restrict__ ctl, const uint64_t* __restrict__ totals, const uint32_t* __restrict__ error_flag, uint64_t out_cap,
+                             uint64_t* __restrict__ h_status) {
+  if (threadIdx.x != 0) return;
+  uint64_t st = ctl[3];
+  const uint64_t ntok = st ? 0ull : totals[1];
+  const uint32_t err = *error_flag;
+  if (!st && err) st |= RING_ERROR;
+  if (!st && ntok > out_cap) st |= RING_OUT_CAP;
+  ctl[2] = st ? 0ull : ntok;
+  h_status[1] = ntok; h_status[2] = ctl[4]; h_status[3] = ctl[0]; h_status[4] = err; h_status[5] = ctl[5];
+  h_status[0] = st;
+}
+// ids -> enc bytes each, the count read on the device (ctl[2]); sixteen ids per work-item, 16-byte stores (`out` 16-byte aligned)
+template <int ENC>
+__global__ __launch_bounds__(256) void k_serialize_ctl(const uint32_t* __restrict__ ids, const uint64_t* __restrict__ ctl, uint8_t* __restrict__ out) {
+  const uint64_t n = ctl[2];
+  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+  if (i0 >= n) return;
+  if (i0 + 16u <= n) {
+    uint32_t v[16];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint4 q = reinterpret_cast<const uint4*>(ids + i0)[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+    uint4* o = reinterpret_cast<uint4*>(out + i0 * ENC);
+    if (ENC == 2) {
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        o[k] = make_uint4((v[8 * k] & 0xFFFFu) | (v[8 * k + 1] << 16), (v[8 * k + 2] & 0xFFFFu) | (v[8 * k + 3] << 16), (v[8 * k + 4] & 0xFFFFu) | (v[8 * k + 5] << 16),
+                          (v[8 * k + 6] & 0xFFFFu) | (v[8 * k + 7] << 16));
+    } else if (ENC == 4) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) o[k] = make_uint4(v[4 * k] & 0xFFFFFFu, v[4 * k + 1] & 0xFFFFFFu, v[4 * k + 2] & 0xFFFFFFu, v[4 * k + 3] & 0xFFFFFFu);
+    } else {
+      // 3 bytes each: four ids make three words
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t a = v[4 * k] & 0xFFFFFFu, b = v[4 * k + 1] & 0xFFFFFFu, c = v[4 * k + 2] & 0xFFFFFFu, d = v[4 * k + 3] & 0xFFFFFFu;
+        reinterpret_cast<uint32_t*>(o)[3 * k] = a | (b << 24);
+        reinterpret_cast<uint32_t*>(o)[3 * k + 1] = (b >> 8) | (c << 16);
+        reinterpret_cast<uint32_t*>(o)[3 * k + 2] = (c >> 16) | (d << 8);
+      }
+    }
+  } else {
+    for (uint64_t i = i0; i < n; i++) {
+      const uint32_t v = ids[i];
+      uint8_t* o = out + i * ENC;
+      o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8);
+      if (ENC >= 3) o[2] = (uint8_t)(v >> 16);
+      if (ENC == 4) o[3] = 0;
+    }
+  }
+}
+
 }  // namespace tmh
 
 using namespace tmh;
@@ -1815,7 +1904,7 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
 // the per-segment records of k_seg_params (after the token-offset scan)
 static void launch_seg_params(tm_batch* b, hipStream_t st) {
   TM_LAUNCH(k_seg_params, (uint32_t)((b->nseg + 1 + 255) / 256), 256, 0, st, b->d_doc_begin, b->d_doc_end, b->d_seg_doc, b->d_doc_seg_start, b->nseg, b->ndocs, b->d_seg_entry,
-                                                                      b->d_seg_tokbase, b->d_tok_offsets, b->d_seg_par);
+                                                                      b->d_seg_tokbase, b->d_tok_offsets, b->d_seg_par, b->d_ctl);
 }
 // K4 for the id-emitting entry points: the tile walk (test hook bit 10: every id stored directly, the overflow path of the staging)
 // store == false (Count): the same walk with an output capacity of 0 — it is there for the delete tokens and missing characters it counts
@@ -1832,13 +1921,13 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store, bool rezero = f
     const uint32_t stage_after = (debug_flags() & 1024) ? 512u : 0u;
     if (r0_narrow(b) && !(debug_flags() & 32768))             // (test hook 15: the id-staging form of the walk for the two-plane rows too)
       TM_LAUNCH(k_emit_list, (uint32_t)((nseg + TSL - 1) / TSL), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
-                                                                   b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
+                                                                   b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b), b->d_ctl);
     else if (r0_narrow(b))
       TM_LAUNCH(k_emit_tiles<true>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
-                                                                         b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
+                                                                         b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b), b->d_ctl);
     else
       TM_LAUNCH(k_emit_tiles<false>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
-                                                                          b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b));
+                                                                          b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b), b->d_ctl);
   }
   if (nd && !store) TM_LAUNCH(k_doc_events, (nd + 255) / 256, 256, 0, st, b->d_doc_ntok, b->d_doc_fd, nd, b->d_doc_events);      // (Count() is the only reader)
 }
@@ -1975,17 +2064,17 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   if (nd > 0) {
     TM_LAUNCH(k_doc_nseg, (nd + 255) / 256, 256, 0, st, b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nseg, (uint32_t)SEG, b->d_error);
     scan_u32(b->d_doc_nseg, nd, b->d_scan_tmp, b->d_totals + 0, b->d_doc_seg_start, st);
-    if (nseg > 0) TM_LAUNCH(k_segments, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_doc_seg_start, nd, nseg, b->d_seg_doc);
+    if (nseg > 0) TM_LAUNCH(k_segments, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_doc_seg_start, nd, nseg, b->d_seg_doc, b->d_ctl);
     // the text still lies in the normalizer's slabs: where each segment begins in them (in d_seg_par, which K4's parameters take over after K3)
     if (nseg > 0 && b->text_in_slabs)
-      TM_LAUNCH(k_seg_src, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_seg_doc, b->d_doc_seg_start, b->d_doc_begin, b->d_doc_piece_start, b->d_piece_off, nseg, b->d_seg_par);
+      TM_LAUNCH(k_seg_src, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_seg_doc, b->d_doc_seg_start, b->d_doc_begin, b->d_doc_piece_start, b->d_piece_off, nseg, b->d_seg_par, b->d_ctl);
   }
   mark(1);
   if (nseg > 0)
     TM_LAUNCH(k_match_branch, (uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st, v->tables, b->d_text, b->d_doc_begin, b->d_doc_end,
                                                                                           b->d_doc_vis ? b->d_doc_vis : b->d_doc_end, b->d_seg_doc,
                                                                                           b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap, b->d_exit16, r0_narrow(b) ? 1 : 0,
-                                                                                          debug_flags(), b->text_in_slabs ? b->d_slab : nullptr, b->d_seg_par);
+                                                                                          debug_flags(), b->text_in_slabs ? b->d_slab : nullptr, b->d_seg_par, b->d_ctl);
     note_table_use(v, st);
   mark(2);
   for (size_t lvl = 0; lvl + 1 < b->level_first.size() && b->ngroups > 0; lvl++) {     // bottom up: a level reads the maps of the one below
@@ -2004,7 +2093,7 @@ int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode) {
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], st); };
   if (nd > 0)
     TM_LAUNCH(k_resolve, (nd + 255) / 256, 256, 0, st, b->d_exitmap, b->d_exit16, b->d_doc_seg_start, nd, b->d_doc_entry, b->d_seg_entry, b->d_seg_tokbase,
-                                                b->d_doc_ntok, b->d_error, long_segs(), b->d_doc_fd, b->d_doc_missing);
+                                                b->d_doc_ntok, b->d_error, long_segs(), b->d_doc_fd, b->d_doc_missing, b->d_ctl);
   if (b->ngroups > 0) {
     TM_LAUNCH(k_long_top, (b->nlong + 63) / 64, 64, 0, st, b->d_gmap, b->d_longs, b->nlong, b->d_doc_entry, b->d_group_entry, b->d_group_base, b->d_doc_ntok, b->d_error);
     for (size_t lvl = b->level_first.size() - 1; lvl-- > 0;) {                           // top down
@@ -2217,7 +2306,7 @@ void tm_batch_free(tm_batch* b) {
                   b->d_seg_tokbase, b->d_seg_par, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_doc_fd, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
                   b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
                   b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,
-                  b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids, b->d_two};
+                  b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids, b->d_two, b->d_ctl_store};
   for (void* p : ptrs) (void)hipFree(p);
   if (b->have_events) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
   if (b->aux_stream) (void)hipStreamDestroy(b->aux_stream);
@@ -2275,6 +2364,26 @@ void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* ou
     }
   }
   TM_LAUNCH(k_serialize, (uint32_t)((n + 255) / 256), 256, 0, st, ids, n, enc, out);
+}
+
+// ---- the host-to-host ring (tm_host.hip): a chunk's kernels without a host round trip ----------------------------------------------------
+void launch_chunk_ctl(tm_batch* b, uint64_t seg_bound, hipStream_t st) {
+  TM_LAUNCH(k_chunk_ctl, 1, 64, 0, st, (const unsigned long long*)b->d_ninfo, b->ndocs, b->max_bytes, seg_bound, b->d_ctl_store);
+}
+int ring_enqueue_tokenize(tm_batch* b, hipStream_t st, uint32_t enc, uint8_t* d_bytes, uint64_t d_bytes_cap, uint64_t* h_status) {
+  if (!b->d_ctl) return set_error(TM_E_INTERNAL, "ring_enqueue_tokenize: the workspace has no control words");
+  int rc = pipeline_match(b, st, nullptr);
+  if (rc == TM_OK) rc = pipeline_resolve(b, st, nullptr, 2);
+  if (rc != TM_OK) return rc;
+  // (the ids that fit d_bytes: what K4 may store is bounded by out_cap, and the chunk is not taken when it needed more)
+  const uint64_t cap_ids = std::min<uint64_t>(b->out_cap, d_bytes_cap / enc);
+  TM_LAUNCH(k_chunk_done, 1, 64, 0, st, b->d_ctl_store, b->d_totals, b->d_error, cap_ids, h_status);
+  const uint32_t grid = (uint32_t)((cap_ids / 16 + 1 + 255) / 256);
+  if (enc == 2) TM_LAUNCH(k_serialize_ctl<2>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes);
+  else if (enc == 3) TM_LAUNCH(k_serialize_ctl<3>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes);
+  else TM_LAUNCH(k_serialize_ctl<4>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
 }
 }  // namespace tmh
 extern "C" {

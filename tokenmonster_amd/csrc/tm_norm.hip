@@ -728,8 +728,19 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
     if (raw_offsets[d + 1] < raw_offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
     npieces += (raw_offsets[d + 1] - raw_offsets[d] + PIECE - 1) / PIECE;
   }
+  { int rc = raw_prepare(b, nbytes, ndocs, npieces, st); if (rc != TM_OK) return rc; }
+  hipError_t e;
+  if (nbytes && (e = hipMemcpyAsync(b->d_raw, raw, nbytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D raw text");
+  b->h_raw_off.assign(raw_offsets, raw_offsets + (ndocs ? ndocs + 1 : 0));      // (the batch's own copy: it outlives the caller's array)
+  if (ndocs) { int rc = small_h2d(b, b->d_raw_off, b->h_raw_off.data(), ((uint64_t)ndocs + 1) * 8, st); if (rc != TM_OK) return rc; }
+  return TM_OK;
+}
+
+// the device buffers of a raw batch of this size (grow-only), the normalizer's tables on first use, and the batch's counts
+int raw_prepare(tm_batch* b, uint64_t nbytes, uint32_t ndocs, uint64_t npieces, hipStream_t st) {
   // the normalized text cannot be shorter than what capcode leaves of the raw text, and the scans of tm_batch_normalize run over
   // one entry per piece with block sums sized (make_workspace) for max_bytes / 256 + max_docs entries
+  if (ndocs > b->max_docs) return set_error(TM_E_LIMIT, "batch has %u documents, workspace sized for %u", ndocs, b->max_docs);
   if (nbytes > b->max_bytes) return set_error(TM_E_LIMIT, "raw batch has %llu bytes, workspace sized for %llu", (unsigned long long)nbytes, (unsigned long long)b->max_bytes);
   if (npieces > b->max_bytes / 256 + (uint64_t)b->max_docs) return set_error(TM_E_LIMIT, "raw batch has %llu pieces, workspace scans hold %llu", (unsigned long long)npieces, (unsigned long long)(b->max_bytes / 256 + b->max_docs));
   hipError_t e;
@@ -768,9 +779,6 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
       return hip_fail(e, "hipMalloc (pieces)");
   }
   if ((e = grow(&b->d_slab, &b->slab_cap, (npieces + 1) * (uint64_t)SLAB)) != hipSuccess) return hip_fail(e, "hipMalloc (normalizer slabs)");
-  if (nbytes && (e = hipMemcpyAsync(b->d_raw, raw, nbytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(e, "H2D raw text");
-  b->h_raw_off.assign(raw_offsets, raw_offsets + (ndocs ? ndocs + 1 : 0));      // (the batch's own copy: it outlives the caller's array)
-  if (ndocs) { int rc = small_h2d(b, b->d_raw_off, b->h_raw_off.data(), ((uint64_t)ndocs + 1) * 8, st); if (rc != TM_OK) return rc; }
   b->raw_bytes = nbytes;
   b->raw_docs = ndocs;
   b->raw_pieces = npieces;
@@ -804,12 +812,22 @@ extern "C" {
 // a compute unit that got a seventh finishes late.  Measured per 512 MiB (MI355X, 256 compute units): one piece per wavefront 1.54 ms; 6 workgroups
 // per compute unit 1.58; 12: 1.49; 24: 1.43; 48 - 96: 1.365; 256: 1.43.  (TM_NORM_WG_PER_CU: the sweep.)
 static uint32_t norm_grid() {
-  const char* e = getenv("TM_NORM_WG_PER_CU");
-  const int v = e ? atoi(e) : 0;
-  const uint32_t wg_per_cu = v > 0 ? (uint32_t)v : 64u;
-  int dev = 0, cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
-  return (uint32_t)cu * wg_per_cu;
+  // (once per device and process: this runs per chunk and lane of the host-to-host pipeline)
+  static std::mutex mu;
+  static uint32_t cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  std::lock_guard<std::mutex> g(mu);
+  uint32_t& slot = cached[dev >= 0 && dev < 64 ? dev : 0];
+  if (slot == 0) {
+    const char* e = getenv("TM_NORM_WG_PER_CU");
+    const int v = e ? atoi(e) : 0;
+    const uint32_t wg_per_cu = v > 0 ? (uint32_t)v : 64u;
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) { (void)hipGetLastError(); cu = 256; }
+    slot = (uint32_t)cu * wg_per_cu;
+  }
+  return slot;
 }
 
 int tm_batch_normalize(tm_batch* b, void* stream) {
@@ -1013,6 +1031,57 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   if (trace) fprintf(stderr, "[tm_batch_normalize] summaries %.2f ms, device pass + host fallback (%u docs) %.2f ms, info %.2f ms\n", t1 - t0, nf, t2 - t1, now() - t2);
   return rc;
 }
+
+}  // extern "C"
+namespace tmh {
+// The host-to-host ring takes a vocabulary whose normalizer pass is the one-pass form (capcode 0 or 2 with flags the device implements)
+bool ring_supported(const tm_vocab* v) {
+  const uint32_t capcode = v->host.capcode, norm_flag = v->host.norm_flag;
+  return normalize_supported(capcode, norm_flag) && (capcode == 2 || capcode == 0) && normalize_on_device(capcode, norm_flag) && !(tm_debug_flags(-1) & (256 | 2048));
+}
+// tm_batch_normalize's usual path - ONE pass over the raw text that raw_prepare + the upload have put into the workspace - enqueued on `st`
+// and NOT waited for: what the host would read back stays in d_ninfo, k_chunk_ctl turns it into the control words the kernels behind it
+// look at (the segments are launched over `seg_bound`), and a chunk the pass cannot finish by itself (documents for the host normalizer, a
+// piece whose margins could not tell, a long document ...) is marked there and run through tm_batch_normalize by the caller afterwards.
+int ring_enqueue_normalize(tm_batch* b, hipStream_t st, uint64_t seg_bound) {
+  const tm_vocab* v = b->vocab;
+  const uint32_t capcode = v->host.capcode, norm_flag = v->host.norm_flag;
+  const uint32_t nd = b->raw_docs;
+  const uint64_t np = b->raw_pieces;
+  if (nd == 0 || np == 0) return set_error(TM_E_INTERNAL, "ring_enqueue_normalize: empty chunk");
+  hipError_t e;
+  if (!b->d_ctl_store && (e = hipMalloc((void**)&b->d_ctl_store, 64)) != hipSuccess) return hip_fail(e, "hipMalloc");
+  b->d_ctl = b->d_ctl_store;
+  b->host_fallback_docs = 0;
+  b->d_doc_begin = b->d_nbegin;
+  b->d_doc_end = b->d_nend;
+  b->ndocs = nd; b->nbytes = 0; b->ngroups = 0; b->nlong = 0;
+  b->nseg = std::min<uint64_t>(seg_bound, b->max_segs);
+  b->text_in_slabs = true;
+  b->slab_pieces = np;
+  (void)hipGetLastError();
+  const uint32_t lower_all = (norm_flag & 2u) ? 1u : 0u;
+  unsigned long long* ninfo = (unsigned long long*)b->d_ninfo;
+  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, b->d_raw_off, nd, b->d_doc_npiece, b->d_need_host, ninfo);
+  scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
+  const uint32_t pgrid = (uint32_t)((np + 3) / 4);
+  const uint32_t egrid = std::min(pgrid, norm_grid());
+  launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
+  if (capcode == 2)
+    TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
+                                               b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
+  else
+    TM_LAUNCH(k_norm_emit<3>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+                                          nullptr, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
+  TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
+  scan_u32(b->d_piece_len, np, b->d_scan_tmp, reinterpret_cast<uint64_t*>(ninfo + 5), b->d_piece_off, st);
+  TM_LAUNCH(k_norm_ranges_info, (nd + 255) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend, ninfo, long_segs());
+  launch_chunk_ctl(b, b->nseg, st);
+  e = hipGetLastError();
+  return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
+}
+}  // namespace tmh
+extern "C" {
 
 uint64_t tm_batch_normalized_bytes(const tm_batch* b) { return b->nbytes; }
 uint32_t tm_batch_host_fallback_docs(const tm_batch* b) { return b->host_fallback_docs; }

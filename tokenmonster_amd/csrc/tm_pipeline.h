@@ -175,6 +175,11 @@ struct tm_batch {
   uint64_t h_fb_raw_cap = 0, h_fb_norm_cap = 0;
   uint32_t* d_out = nullptr;
   uint64_t out_cap = 0;
+  // a chunk of the host-to-host ring (tm_host.hip): what the host would have read back between the stages - the number of segments the normalizer
+  // pass left, whether the chunk can be taken on this path at all, the number of ids - stays on the device in these control words, and the
+  // kernels behind the pass are launched over a bound and look the counts up (d_ctl != null; k_chunk_ctl / k_chunk_done, tm_kernels.hip)
+  uint64_t* d_ctl_store = nullptr;      // 8 words, allocated on first use
+  const uint64_t* d_ctl = nullptr;      // = d_ctl_store while the workspace belongs to a slot of the ring
   hipEvent_t ev[TM_NUM_KERNELS + 1] = {};
   bool have_events = false;
 };
@@ -236,6 +241,16 @@ int small_h2d(tm_batch* b, void* dev_dst, const void* host_src, uint64_t bytes, 
 int small_sync(tm_batch* b, hipStream_t st);
 int batch_upload_on(tm_batch* b, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, hipStream_t st);
 void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* out, hipStream_t st);
+// the host-to-host ring: a chunk's stages behind the upload enqueued on `st` without a host round trip (tm_norm.hip / tm_kernels.hip)
+constexpr uint32_t RING_HOST_DOCS = 1, RING_LONG_DOCS = 2, RING_UNDECIDED = 4, RING_SLAB = 8, RING_SHORT_PIECE = 16, RING_BYTES = 32, RING_SEGS = 64,
+                   RING_ERROR = 128, RING_OUT_CAP = 256;      // status bits of a chunk the ring hands to the exact path instead
+bool ring_supported(const tm_vocab* v);
+int raw_prepare(tm_batch* b, uint64_t nbytes, uint32_t ndocs, uint64_t npieces, hipStream_t st);      // the buffers tm_batch_upload_raw fills, grown to size
+int ring_enqueue_normalize(tm_batch* b, hipStream_t st, uint64_t seg_bound);
+void launch_chunk_ctl(tm_batch* b, uint64_t seg_bound, hipStream_t st);
+// K0 .. K4, the ids packed to `enc` bytes into d_bytes (16-byte aligned), and the chunk's verdict written to `h_status` (page-locked host memory, 8 words:
+// status bits, ids, normalized bytes, segments, device error word)
+int ring_enqueue_tokenize(tm_batch* b, hipStream_t st, uint32_t enc, uint8_t* d_bytes, uint64_t d_bytes_cap, uint64_t* h_status);
 // tm_decode.hip: the stages of a decode on a stream, in buffers of the caller
 constexpr uint64_t DEC_HOST = ~0ull;      // k_dec_capcode's length of a document it leaves to the host decoder (scripts beyond Latin, malformed UTF-8)
 void launch_decode_lengths(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_toff, uint32_t ndocs, uint32_t* d_len, uint64_t* d_off,

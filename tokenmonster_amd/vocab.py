@@ -333,7 +333,7 @@ class Decoder:
 
 class PipelineStats(C.Structure):
     _fields_ = [("chunks", C.c_uint32), ("lanes", C.c_uint32), ("input_pinned", C.c_int), ("output_pinned", C.c_int),
-                ("normalized_bytes", C.c_uint64), ("host_fallback_docs", C.c_uint32)]
+                ("normalized_bytes", C.c_uint64), ("host_fallback_docs", C.c_uint32), ("ring", C.c_uint32), ("ring_exact_chunks", C.c_uint32)]
 
 
 class PinnedBuffer:

@@ -28,7 +28,7 @@ def union(iv):
     return tot
 
 
-def analyze(d, head_ms=0.0):
+def analyze(d, head_ms=0.0, win=None):
     kf = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     mf = glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True)
     ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]) for f in kf for r in csv.DictReader(open(f))]
@@ -74,6 +74,12 @@ def analyze(d, head_ms=0.0):
         cur = max(cur, b)
     gaps.sort(reverse=True)
     print("  idle gaps between kernels: total %.2f ms, largest %s ms" % (sum(gaps) / 1e6, [round(g / 1e6, 2) for g in gaps[:8]]))
+    if win:
+        # everything the device did between win[0] and win[1] ms of the pass, one line per kernel / copy, with its queue
+        ev = [(a, b, "q%s %s" % (kq.get((a, b), "?"), n[-34:])) for a, b, n in kl] + [(m[0], m[1], "      %s %.2f MB" % (m[2][-14:], m[3] / 1e6)) for m in ml]
+        for a, b, what in sorted(ev):
+            if (b - lo) / 1e6 >= win[0] and (a - lo) / 1e6 <= win[1]:
+                print("    %8.3f ms  +%7.3f  %s" % ((a - lo) / 1e6, (b - a) / 1e6, what))
     if head_ms > 0:
         # what the device did in the first head_ms of the pass: every kernel (queue, name) and copy, in order of their start
         ev = [(a, b, "q%s %s" % (kq.get((a, b), "?"), n[-34:])) for a, b, n in kl] + [(m[0], m[1], "%s %.2f MB" % (m[2], m[3] / 1e6)) for m in ml]
@@ -88,13 +94,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--analyze")
     ap.add_argument("--head", type=float, default=0.0, help="with --analyze: list what ran in the first HEAD ms of the last pass")
+    ap.add_argument("--window", type=float, nargs=2, help="with --analyze: list what ran between A and B ms of the last pass")
     ap.add_argument("--lanes", type=int, default=3)
     ap.add_argument("--chunk-mib", type=int, default=64)
     ap.add_argument("--mbytes", type=int, default=1024)
     ap.add_argument("--passes", type=int, default=3)
     a = ap.parse_args()
     if a.analyze:
-        return analyze(a.analyze, a.head)
+        return analyze(a.analyze, a.head, a.window)
     import numpy as np
     import tokenmonster_amd as tm
     from tokenmonster_amd import synth
