@@ -53,7 +53,7 @@ def parse():
                                                       "(kernel variants) and reported on stderr, its ids compared with the default's")
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-to-host pipeline and small-batch latency figures")
     ap.add_argument("--h2h-lanes", type=int, default=4, help="lanes of the host-to-host pipeline (ONE stated setting, timed over --steps)")
-    ap.add_argument("--h2h-chunk-mib", type=int, default=32, help="chunk size of the host-to-host pipeline in MiB")
+    ap.add_argument("--h2h-chunk-mib", type=int, default=0, help="chunk size of the host-to-host pipeline in MiB (0: the library's default - 48 on the ring, 32 with lanes)")
     ap.add_argument("--h2h-sweep", action="store_true", help="development aid: also time other (lanes, chunk) settings, reported on stderr only")
     ap.add_argument("--in-process", action="store_true",
                     help="N GPUs from ONE process through the library's own multi-device driver (tm_devices / tm_vocab_load_all / tm_score_multi, RCCL inside "
@@ -197,7 +197,8 @@ def host_to_host(vocab, raw, roffs, text, offs, ids_expected, log, tm, steps=3, 
             ntok = int(boff[-1]) // enc
             if k == 0:
                 res[label] = {"value": round(raw.size / dt / 1e9, 4), "unit": "GB/s raw UTF-8, host to host", "ms": round(dt * 1e3, 3), "lanes": ln,
-                              "chunk_MiB": ch >> 20, "id_bytes": enc, "tokens": ntok, "steps": steps, "warmup_passes": H2H_WARM if label == "pinned" else 1,
+                              "chunk_MiB": (ch >> 20) or ("library default (48 ring / 32 lanes)"), "id_bytes": enc, "tokens": ntok, "steps": steps, "warmup_passes": H2H_WARM if label == "pinned" else 1,
+                              "form": "ring (no host round trip inside a chunk)" if st.get("ring") else "lanes", "chunks": st["chunks"], "ring_exact_chunks": st.get("ring_exact_chunks", 0),
                               "ms_each": [round(x * 1e3, 2) for x in each]}
                 if label == "pinned":
                     res["_ids"] = (blob.copy(), boff.copy(), enc)
@@ -857,6 +858,10 @@ def main():
             # SURVEY 8(d)'s "first H2D to last D2H" harness (tm_tokenize_pipeline: raw UTF-8 in pinned host memory -> ids in pinned host memory,
             # benchmark/tokenmonster_bench.go:41-55 times around the whole call) is the key below
             "value_definition": "HBM-resident: raw UTF-8 in HBM -> uint32 ids in HBM (normalize + tokenize)",
+            # (why `value` is not the host-to-host rate: the measurement contract of this build - task statement, section 4 "Measurement" - reads
+            # "`value` is whole-job throughput with inputs already resident in HBM when the timed region starts (if the boundary hands over host
+            # buffers, note the PCIe-inclusive rate in DESIGN.md - it is never `value`)"; SURVEY 8(d)'s H2D -> D2H figure is `value_host_to_host`)
+            "value_contract": "task statement section 4: value = inputs resident in HBM when the timed region starts; the PCIe-inclusive rate is never `value` -> value_host_to_host",
             "value_resident": round(value, 4),
             "value_host_to_host": None if h2h is None else h2h["pinned"]["value"],
             "host_to_host": h2h,

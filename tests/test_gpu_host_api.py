@@ -395,6 +395,15 @@ def test_ring_equals_single_batch():
     small = tm.PinnedBuffer(64)
     blob, boff, _, enc, st = v.tokenize_pipeline(pin.array[: raw.size], roffs, raw=True, chunk_bytes=30_000, out=small.array)      # (the wrapper retries with a pageable buffer of the size asked for)
     assert int(boff[-1]) == 2 * ids.size and (_ids_from_bytes(np.asarray(blob), 2) == ids).all()
+    # test hook 16: the thin kernels of a chunk one by one (what a chunk of more than 2^18 pieces takes) instead of fused
+    from tokenmonster_amd import _native as N
+    old = N.lib.tm_debug_flags(65536)
+    try:
+        blob, boff, bmiss, enc, st = v.tokenize_pipeline(pin.array[: raw.size], roffs, raw=True, chunk_bytes=30_000, lanes=2, out=pout.array)
+        assert st["ring"] == 1 and st["ring_exact_chunks"] == 0
+        assert (boff == toff * np.uint64(enc)).all() and (bmiss == miss).all() and (_ids_from_bytes(np.asarray(blob), enc) == ids).all()
+    finally:
+        N.lib.tm_debug_flags(old)
 
 
 def test_ring_hands_chunks_to_the_exact_path():

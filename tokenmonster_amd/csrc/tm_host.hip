@@ -769,7 +769,8 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
   if (encoding_length < 2 || encoding_length > 4) return set_error(TM_E_INVALID, "Invalid encoding length");
   if (encoding_length_used) *encoding_length_used = encoding_length;
   if (ndocs && offsets[0] != 0) return set_error(TM_E_INVALID, "offsets[0] must be 0");
-  if (chunk_bytes == 0) chunk_bytes = 32ull << 20;
+  const bool chunk_default = chunk_bytes == 0;
+  if (chunk_default) chunk_bytes = 32ull << 20;
   if (lanes == 0) lanes = 4;
   lanes = std::min<uint32_t>(lanes, 8);
   PipeCall c{vs, nv, text, offsets, ndocs, raw, encoding_length, chunk_bytes, lanes, bytes_out, bytes_cap, byte_offsets, missing, stats};
@@ -780,6 +781,9 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
   static const uint32_t ring_streams = [] { const char* e = getenv("TM_RING_STREAMS"); const int n = e ? atoi(e) : 0; return (uint32_t)(n >= 1 && n <= 4 ? n : 2); }();
   bool use_ring = ring_env != 0 && raw && c.in_pinned && c.out_pinned && ndocs > 0;
   for (uint32_t i = 0; i < nv && use_ring; i++) use_ring = ring_supported(vs[i]);
+  // (the ring's chunks: 48 MiB unless the caller says otherwise - every launch of the match kernel has a ramp and a tail of its own, 1 GiB in
+  // 27.0 ms against 27.6 with 32 MiB chunks and 28.9 with 24; beyond 48 the first results come later for nothing, profiles/r06_h2h.txt)
+  if (use_ring && chunk_default) c.chunk_bytes = chunk_bytes = 48ull << 20;
   // chunks = maximal runs of whole documents of at most `limit` bytes (a longer document is a chunk of its own)
   std::vector<uint32_t>& first = c.first;
   for (uint32_t d = 0; d < ndocs; d++) if (offsets[d + 1] < offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);

@@ -331,6 +331,26 @@ __global__ void k_seg_src(const uint32_t* __restrict__ seg_doc, const uint64_t* 
   seg_src[g] = make_uint4((uint32_t)lo, (uint32_t)(begin - piece_off[lo]), (uint32_t)(piece_off[lo + 1] - begin), 0u);
 }
 
+// k_segments + k_seg_src in one launch, for a chunk of the host-to-host ring (the number of segments is the device's: ctl[0])
+__global__ void k_seg_fill(const uint64_t* __restrict__ doc_seg_start, uint32_t ndocs, const uint64_t* __restrict__ doc_begin, const uint64_t* __restrict__ doc_piece_start,
+                           const uint64_t* __restrict__ piece_off, uint32_t* __restrict__ seg_doc, uint4* __restrict__ seg_src, const uint64_t* __restrict__ ctl) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ctl[0]) return;
+  uint32_t dl = 0, dh = ndocs;   // invariant: start[dl] <= g < start[dh]
+  while (dh - dl > 1) {
+    const uint32_t mid = dl + (dh - dl) / 2;
+    if (doc_seg_start[mid] <= g) dl = mid; else dh = mid;
+  }
+  seg_doc[g] = dl;
+  const uint64_t begin = doc_begin[dl] + (g - doc_seg_start[dl]) * SEG;
+  uint64_t lo = doc_piece_start[dl], hi = doc_piece_start[dl + 1];          // the last piece of the document that begins at or before `begin`
+  while (hi - lo > 1) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (piece_off[mid] <= begin) lo = mid; else hi = mid;
+  }
+  seg_src[g] = make_uint4((uint32_t)lo, (uint32_t)(begin - piece_off[lo]), (uint32_t)(piece_off[lo + 1] - begin), 0u);
+}
+
 constexpr int J_SKIP = NPOS - SEG, J_PLANE = NPOS;     // step C: state (p, fd) lives at word J_SKIP + fd * J_PLANE + p of {D, Db}
 __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const uint8_t* __restrict__ text,
                                                                 const uint64_t* __restrict__ doc_begin,
@@ -1779,23 +1799,21 @@ __global__ void k_chunk_ctl(const unsigned long long* __restrict__ ninfo, uint32
   ctl[4] = ninfo[5];
   ctl[5] = ninfo[0];
 }
-// k_chunk_done, behind K4: the number of ids for the serializer (ctl[2]) and the verdict for the host
-__global__ void k_chunk_done(uint64_t* __restrict__ ctl, const uint64_t* __restrict__ totals, const uint32_t* __restrict__ error_flag, uint64_t out_cap,
-                             uint64_t* __restrict__ h_status) {
-  if (threadIdx.x != 0) return;
+// ids -> enc bytes each, the count worked out on the device (the status word of k_chunk_ctl the id total, the error word); sixteen ids per work-item, 16-byte stores (`out` 16-byte aligned)
+// ... and k_chunk_done's part with it (one launch less behind K4): every work-item works the count out for itself, the first one tells the host
+template <int ENC>
+__global__ __launch_bounds__(256) void k_serialize_ctl(const uint32_t* __restrict__ ids, const uint64_t* __restrict__ ctl, uint8_t* __restrict__ out,
+                                                       const uint64_t* __restrict__ totals, const uint32_t* __restrict__ error_flag, uint64_t out_cap, uint64_t* __restrict__ h_status) {
   uint64_t st = ctl[3];
   const uint64_t ntok = st ? 0ull : totals[1];
   const uint32_t err = *error_flag;
   if (!st && err) st |= RING_ERROR;
   if (!st && ntok > out_cap) st |= RING_OUT_CAP;
-  ctl[2] = st ? 0ull : ntok;
-  h_status[1] = ntok; h_status[2] = ctl[4]; h_status[3] = ctl[0]; h_status[4] = err; h_status[5] = ctl[5];
-  h_status[0] = st;
-}
-// ids -> enc bytes each, the count read on the device (ctl[2]); sixteen ids per work-item, 16-byte stores (`out` 16-byte aligned)
-template <int ENC>
-__global__ __launch_bounds__(256) void k_serialize_ctl(const uint32_t* __restrict__ ids, const uint64_t* __restrict__ ctl, uint8_t* __restrict__ out) {
-  const uint64_t n = ctl[2];
+  const uint64_t n = st ? 0ull : ntok;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    h_status[1] = ntok; h_status[2] = ctl[4]; h_status[3] = ctl[0]; h_status[4] = err; h_status[5] = ctl[5];
+    h_status[0] = st;
+  }
   const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
   if (i0 >= n) return;
   if (i0 + 16u <= n) {
@@ -1847,12 +1865,13 @@ namespace tmh {
 // directly, 11 = the device normalizer packs its text instead of leaving it in the slabs for K1, 12 = group tree of long documents with fan-out 4
 // from 9 segments on (a deep tree on a small document), 13 = a 64 KiB
 // mailbox for the small host <-> device transfers (wraps within a test), 14 = the last member of tm_score_multi gives up after the first
-// meeting of the members (an ERROR path: every member must return).  Nothing else is
+// meeting of the members (an ERROR path: every member must return), 15 = K4's id-staging walk for two-plane rows too, 16 = k_segments and k_seg_src one
+// behind the other for a chunk of the host-to-host ring too (which has them in one launch, k_seg_fill).  Nothing else is
 // reachable in the default build.  With -DTM_DEVEL (tools/ only: results are WRONG) further bits switch
 // phases of K1 off for profiling — 0 no walks at all, 2 no hash probes, 3 no forward-delete probes, 4 no exit maps — bit 9 adds 4 KB
 // of dummy LDS per K1 workgroup, and TM_DBG in the environment sets the initial value.
 #ifndef TM_DEVEL
-constexpr int kDebugMask = 64 | 256 | 1024 | 2048 | 4096 | 8192 | 16384 | 32768;
+constexpr int kDebugMask = 64 | 256 | 1024 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536;
 #define TM_K1_EXTRA_LDS 0
 #define TM_DBG_INITIAL 0
 #endif
@@ -1935,8 +1954,8 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store, bool rezero = f
 // the same scan for up to SCAN1_MAX elements in ONE launch of one workgroup (a run of elements per thread): a server batch or a chunk of the
 // host-to-host pipeline or a server batch scans a few thousand documents / pieces / segments several times, and there the two launches
 // saved per scan are worth more than the parallelism lost
-constexpr int SCAN1_T = 1024;
 constexpr uint64_t SCAN1_MAX = 1u << 14;     // (a single workgroup over 2^17 elements took longer than the two launches it saved)
+template <int SCAN1_T>
 __global__ __launch_bounds__(SCAN1_T) void k_scan_single(const uint32_t* __restrict__ in, uint32_t n, uint64_t* __restrict__ total, uint64_t* __restrict__ out) {
   __shared__ uint64_t s[SCAN1_T];
   const uint32_t per = (n + SCAN1_T) / SCAN1_T;                       // (covers index n, the total slot)
@@ -1958,7 +1977,9 @@ __global__ __launch_bounds__(SCAN1_T) void k_scan_single(const uint32_t* __restr
 }
 
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st) {
-  if (n <= SCAN1_MAX) { TM_LAUNCH(k_scan_single, 1, SCAN1_T, 0, st, in, (uint32_t)n, total, out); return; }
+  static const int scan1 = [] { const char* e = getenv("TM_SCAN1"); return e ? atoi(e) : 1024; }();
+  if (n <= SCAN1_MAX && scan1 == 1024) { TM_LAUNCH(k_scan_single<1024>, 1, 1024, 0, st, in, (uint32_t)n, total, out); return; }
+  if (n <= SCAN1_MAX && scan1 == 256) { TM_LAUNCH(k_scan_single<256>, 1, 256, 0, st, in, (uint32_t)n, total, out); return; }
   uint32_t nblocks = (uint32_t)((n + 1 + SCAN_CH - 1) / SCAN_CH);   // covers index n (the total slot)
   TM_LAUNCH(k_scan_partial, nblocks, SCAN_T, 0, st, in, n, block_sums);
   TM_LAUNCH(k_scan_sums, 1, SCAN_T, 0, st, block_sums, nblocks, total);
@@ -2064,9 +2085,11 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   if (nd > 0) {
     TM_LAUNCH(k_doc_nseg, (nd + 255) / 256, 256, 0, st, b->d_doc_begin, b->d_doc_end, nd, b->d_doc_nseg, (uint32_t)SEG, b->d_error);
     scan_u32(b->d_doc_nseg, nd, b->d_scan_tmp, b->d_totals + 0, b->d_doc_seg_start, st);
-    if (nseg > 0) TM_LAUNCH(k_segments, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_doc_seg_start, nd, nseg, b->d_seg_doc, b->d_ctl);
+    if (nseg > 0 && b->d_ctl && b->text_in_slabs && !(debug_flags() & 65536))
+      TM_LAUNCH(k_seg_fill, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_doc_seg_start, nd, b->d_doc_begin, b->d_doc_piece_start, b->d_piece_off, b->d_seg_doc, b->d_seg_par, b->d_ctl);
+    else if (nseg > 0) TM_LAUNCH(k_segments, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_doc_seg_start, nd, nseg, b->d_seg_doc, b->d_ctl);
     // the text still lies in the normalizer's slabs: where each segment begins in them (in d_seg_par, which K4's parameters take over after K3)
-    if (nseg > 0 && b->text_in_slabs)
+    if (nseg > 0 && b->text_in_slabs && !(b->d_ctl && !(debug_flags() & 65536)))
       TM_LAUNCH(k_seg_src, (uint32_t)((nseg + 255) / 256), 256, 0, st, b->d_seg_doc, b->d_doc_seg_start, b->d_doc_begin, b->d_doc_piece_start, b->d_piece_off, nseg, b->d_seg_par, b->d_ctl);
   }
   mark(1);
@@ -2377,11 +2400,10 @@ int ring_enqueue_tokenize(tm_batch* b, hipStream_t st, uint32_t enc, uint8_t* d_
   if (rc != TM_OK) return rc;
   // (the ids that fit d_bytes: what K4 may store is bounded by out_cap, and the chunk is not taken when it needed more)
   const uint64_t cap_ids = std::min<uint64_t>(b->out_cap, d_bytes_cap / enc);
-  TM_LAUNCH(k_chunk_done, 1, 64, 0, st, b->d_ctl_store, b->d_totals, b->d_error, cap_ids, h_status);
   const uint32_t grid = (uint32_t)((cap_ids / 16 + 1 + 255) / 256);
-  if (enc == 2) TM_LAUNCH(k_serialize_ctl<2>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes);
-  else if (enc == 3) TM_LAUNCH(k_serialize_ctl<3>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes);
-  else TM_LAUNCH(k_serialize_ctl<4>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes);
+  if (enc == 2) TM_LAUNCH(k_serialize_ctl<2>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes, b->d_totals, b->d_error, cap_ids, h_status);
+  else if (enc == 3) TM_LAUNCH(k_serialize_ctl<3>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes, b->d_totals, b->d_error, cap_ids, h_status);
+  else TM_LAUNCH(k_serialize_ctl<4>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes, b->d_totals, b->d_error, cap_ids, h_status);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
 }
