@@ -23,6 +23,11 @@ import time
 
 import numpy as np
 
+# The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 by default); the host-to-host ring wants its four streams
+# on queues of their own (tm_host.hip: 27 ms per GiB with eight queues, 35 with four).  The library asks for eight when it is loaded - but this
+# process initializes the runtime through torch BEFORE the library is loaded, so the variable is set here, as a server's environment would set it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -893,8 +893,8 @@ def test_one_child_chains_in_the_trie():
             assert got.size == exp.size and (got == exp).all() and miss == int(missing[d]), (capcode, d, docs[d][:80])
 
 
-@pytest.mark.parametrize("flags", [0, 32768, 1024])
-def test_walk_with_an_id_per_byte_and_more(flags):
+@pytest.mark.parametrize("flags,wide", [(0, False), (32768, False), (1024, False), (0, True), (32768, True)])
+def test_walk_with_an_id_per_byte_and_more(flags, wide):
     """K4 on texts that emit an id for every byte and, where delete tokens follow, more ids than bytes: the position-staging walk (k_emit_list)
     fills its second phase's rounds (64 slots of a segment per round: up to four and more), runs out of room in front of the byte being read and
     switches a segment to direct stores half way, and meets forward-delete states whose ids it writes itself; flags 32768 / 1024: the id-staging
@@ -904,8 +904,11 @@ def test_walk_with_an_id_per_byte_and_more(flags):
     alphabet = b"qrstuvwx"          # (letters the fuzz vocabulary below has no words of: every one of them is a token of its own)
     toks = [bytes([c]) for c in alphabet + b" D.\n"] + [b" " + bytes([c]) for c in alphabet] + [b"D " + bytes([c]) for c in alphabet[:4]] + [b"qr", b"st", b" qr", b"D qr"]
     toks = list(dict.fromkeys(toks + fuzz_vocab_tokens(rng, 2, 60)))       # + the fuzz vocabulary: its space-prefixed words bring the forward-delete branches
+    if wide:      # more than 65 536 ids: the rows carry u32 ids (round 6: two planes for k_emit_list<true>; one plane of words under hook 15) - 66 000 tokens no text here contains
+        toks += [bytes([0x7F, 0x30 + k % 40, 0x30 + (k // 40) % 40, 0x30 + k // 1600]) for k in range(66_000)]
     img = synth.build_vocab(toks, capcode=2, charset=1, with_unk=True)
     v = tm.Vocab(img)
+    assert (v.n_ids() > 65536) == wide
     orc = Oracle(img)
     docs = []
     for n in (1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 5000):

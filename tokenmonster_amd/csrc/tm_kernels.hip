@@ -131,6 +131,10 @@ __global__ void k_segments(const uint64_t* __restrict__ doc_seg_start, uint32_t 
 
 // narrow T(p,0) rows (vocabularies of at most 65 536 ids): per segment SEG ids (u16), then SEG bytes advance [0..5] | fd' [6] | missing [7]
 constexpr uint64_t R0_NARROW = 3 * SEG;
+// ... and the two-plane form of the larger vocabularies (round 6): SEG ids (u32: id, 0xFFFFFF = none), then the same SEG flag bytes - so that K4's
+// position-staging walk (k_emit_list), which only looks at the flag plane, serves them too.  `narrow` of k_match_branch: 0 = one plane of
+// u32 words (id | advance << 24 | fd' << 30 | missing << 31: the id-staging walks k_emit_tiles<false> / k_score_tiles read these), 1 = u16 + u8, 2 = u32 + u8
+constexpr uint64_t R0_WIDE = 5 * SEG;
 // exit map of a segment as K3 reads it: next entry state [0..7] | #ids << 8, R_INVALID = the entry state cannot occur (k_match_branch, step C)
 __device__ __forceinline__ uint32_t exit_entry(const uint16_t* __restrict__ exit16, const uint32_t* __restrict__ exit_wide, uint64_t idx) {
   const uint32_t x = exit16[idx];
@@ -859,9 +863,12 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
       if (p < seglen) {
         // rows per SEGMENT (not per text position): every store is whole aligned lines.  With at most 65 536 ids a row is two planes, ids
         // (u16) and advance | fd' | missing (u8): 768 instead of 1 024 bytes of the largest stream this kernel writes (r0_narrow_* below)
-        if (narrow) {
+        if (narrow == 1) {
           TM_STREAM_STORE(reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(R0) + g * R0_NARROW) + p, (uint16_t)r0[it]);
           TM_STREAM_STORE(reinterpret_cast<uint8_t*>(R0) + g * R0_NARROW + 2 * SEG + p, (uint8_t)(((r0[it] >> 24) & 63u) | ((r0[it] >> 30) << 6)));
+        } else if (narrow == 2) {
+          TM_STREAM_STORE(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(R0) + g * R0_WIDE) + p, r0[it] & ID_NONE);
+          TM_STREAM_STORE(reinterpret_cast<uint8_t*>(R0) + g * R0_WIDE + 4 * SEG + p, (uint8_t)(((r0[it] >> 24) & 63u) | ((r0[it] >> 30) << 6)));
         } else TM_STREAM_STORE(&R0[g * SEG + p], r0[it]);
         if (!side_ok) TM_STREAM_STORE(&R1[g * SEG + p], r1[it]);   // (rare) too many forward-delete states for the side list
       }
@@ -1167,6 +1174,43 @@ __device__ __forceinline__ void hist_add(unsigned long long* s_w, uint32_t* __re
     if ((uint32_t)old >= HSTICKY) { atomicAdd(&scores[id], adv); return; }          // both ways are hot ids
     if (atomicCAS(&set[way], old, ((unsigned long long)id << 32) | adv) == old) {
       if ((uint32_t)old != 0) atomicAdd(&scores[(uint32_t)(old >> 32)], (uint32_t)old);
+      return;
+    }
+  }
+}
+
+// The same for ids below 65 536 (k_score_list: the two-plane rows), twice as many counters in the same 64 KB and four ways to a set: a counter
+// is ONE word - the id's top four bits | 28 bits of count - in the set its low twelve bits name, so a set is 16 bytes, read with one load, and
+// holds four of the sixteen ids that share it.  (With two ways of {id, count} pairs four ids in ten found no counter: a hot id keeps its way for
+// the whole pass, and 8 192 ids do not fall evenly into 4 096 sets of two - and every miss is a transaction of its own on the way to HBM,
+// 1.9 of the 2.7 ms the histogram cost per GiB: profiles/r06_k4.txt.)  A count cannot run over: 28 bits hold every byte a CU sees in a pass.
+constexpr int H16_SETS = 4096;
+constexpr uint32_t H16_CNT = 0x0FFFFFFFu;
+__device__ __forceinline__ void hist16_add(uint32_t* s_h, uint32_t* __restrict__ scores, uint32_t id, uint32_t adv) {
+  uint32_t* set = s_h + 4u * (id & (uint32_t)(H16_SETS - 1));
+  const uint32_t tag = id >> 12, base_id = id & (uint32_t)(H16_SETS - 1);
+  for (;;) {
+    const uint4 w = *reinterpret_cast<const uint4*>(set);
+    const uint32_t e[4] = {w.x, w.y, w.z, w.w};
+    int way = -1, victim = 0;
+    uint32_t vc = e[0] & H16_CNT;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t c = e[k] & H16_CNT;
+      if (c != 0u && (e[k] >> 28) == tag) way = k;
+      if (c < vc) { vc = c; victim = k; }
+    }
+    if (way >= 0) {
+      const uint32_t old = e[way];
+      // a sticky counter can no longer change hands: plain add (same-address adds of a wavefront are serialised by the LDS, no retries)
+      if ((old & H16_CNT) >= HSTICKY) { atomicAdd(&set[way], adv); return; }
+      if (atomicCAS(&set[way], old, old + adv) == old) return;
+      continue;
+    }
+    if (vc >= HSTICKY) { atomicAdd(&scores[id], adv); return; }          // all four ways are hot ids
+    const uint32_t old = e[victim];
+    if (atomicCAS(&set[victim], old, (tag << 28) | adv) == old) {
+      if (vc != 0u) atomicAdd(&scores[((old >> 28) << 12) | base_id], vc);
       return;
     }
   }
@@ -1481,6 +1525,8 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
 #define TM_K4_TSL 16
 #endif
 constexpr int TSL = TM_K4_TSL, TSLACK_L = 4, TROW_L = SEG + 16;
+// WIDE: the ids of the row are u32 (vocabularies of more than 65 536 ids), else u16
+template <bool WIDE>
 __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
                                                   const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
                                                   uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
@@ -1498,6 +1544,8 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
   const TileSeg t = tile_segment(par, g0 + lane, lane < TSL, nseg);
   constexpr uint32_t SLACK = TSLACK_L;
   const uint8_t* rows_g = reinterpret_cast<const uint8_t*>(R0);
+  typedef typename std::conditional<WIDE, uint32_t, uint16_t>::type idt;
+  constexpr uint64_t RS = WIDE ? R0_WIDE : R0_NARROW, FO = WIDE ? 4 * SEG : 2 * SEG;      // bytes per row, where its flag plane begins
   {
     // lane l fetches the flag bytes of positions 4l .. 4l+3 of every row; all loads before the first LDS write
     uint32_t vb[TSL];
@@ -1506,7 +1554,7 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
       const int ss = s < nv ? s : nv - 1;
       const uint32_t len = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;
       vb[s] = 0u;
-      if (4u * (uint32_t)lane < len) vb[s] = TM_STREAM_LOAD(reinterpret_cast<const uint32_t*>(rows_g + (g0 + (uint64_t)ss) * R0_NARROW + 2 * SEG) + lane);
+      if (4u * (uint32_t)lane < len) vb[s] = TM_STREAM_LOAD(reinterpret_cast<const uint32_t*>(rows_g + (g0 + (uint64_t)ss) * RS + FO) + lane);
     }
 #pragma unroll
     for (int s = 0; s < TSL; s++) *reinterpret_cast<uint32_t*>(&s_m[s][TSLACK_L + 4 * lane]) = vb[s];
@@ -1522,7 +1570,7 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
     uint8_t* rowm = s_m[rl];
     uint32_t* smap = s_side[rl];
     const uint2* __restrict__ sl = side + (g0 + rl) * SIDE_STRIDE;
-    const uint16_t* __restrict__ ids_g = reinterpret_cast<const uint16_t*>(rows_g + (g0 + (uint64_t)(rl < nv ? rl : 0)) * R0_NARROW);
+    const idt* __restrict__ ids_g = reinterpret_cast<const idt*>(rows_g + (g0 + (uint64_t)(rl < nv ? rl : 0)) * RS);
     uint32_t nfd = 0, nmiss = 0;                                       // delete tokens emitted / characters without a token (go :1274)
     // the word of state (p, fd): T(p,1) from the segment's side list, T(p,0) from the flag byte in LDS and the id where it lies (general step only)
     auto word = [&](uint32_t pp, uint32_t f) -> uint32_t {
@@ -1623,7 +1671,7 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
       for (int k = 0; k < 8; k++) {
         const int s = s0 + k, ss = s < nv ? s : nv - 1;
         const uint32_t pp = s_m[s][jj], prev = s_m[s][jp];
-        const uint32_t fetched = reinterpret_cast<const uint16_t*>(rows_g + (g0 + (uint64_t)ss) * R0_NARROW)[pp];
+        const uint32_t fetched = reinterpret_cast<const idt*>(rows_g + (g0 + (uint64_t)ss) * RS)[pp];
         idv[k] = (pp == prev && j != 0u) ? delete_id : fetched;
       }
 #pragma unroll
@@ -1733,6 +1781,165 @@ __global__ __launch_bounds__(WV * 64) void k_score_tiles(const uint32_t* __restr
   __syncthreads();
   for (int j = threadIdx.x; j < HSLOTS; j += WV * 64)
     if ((uint32_t)s_w[j] != 0) atomicAdd(&scores[(uint32_t)(s_w[j] >> 32)], (uint32_t)s_w[j]);
+  if (threadIdx.x == 0) {
+    if (s_ndel) atomicAdd(&scores[delete_id], s_ndel);
+    if (s_ntok) atomicAdd(tokens, s_ntok);
+  }
+}
+
+// K4 of the scoring pass for the two-plane rows (round 6): k_emit_list's position staging instead of k_score_tiles' word staging - only the flag
+// plane of a row is in LDS (272 bytes per segment instead of 1 056), so a workgroup walks 16 wavefronts x 16 chains beside its histogram instead
+// of 11 x 8, and K4's time follows the number of chains a CU walks side by side (profiles/r05_issue_model.txt (3)).
+//   The list has one entry per STEP of the chain: the position the step began at.  The bytes a token covers (trainvocab.go:1109-1162:
+//   scores[id] += length) are the distance to the next entry (to where the chain left the segment, or stopped being staged, for the last one).
+//   A step without a token to fetch from the id plane - a character without a token (:1166-1173), or a forward-delete state, whose token
+//   comes from the side list and is counted by the walk itself - is entered TWICE: equal neighbours say "skip".  Steps that consume no byte
+//   (a forward-delete state may) cannot be listed: from the first of them, as from the first step that finds no room in front of the byte being
+//   read, the chain's tokens are counted by the walk itself.
+template <int WV>
+__global__ __launch_bounds__(WV * 64) void k_score_list(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
+                                                       const uint32_t* __restrict__ R1, const uint8_t* __restrict__ text,
+                                                       const uint4* __restrict__ par, uint64_t nseg, uint32_t delete_id,
+                                                       uint32_t* __restrict__ scores, unsigned long long* __restrict__ tokens,
+                                                       uint32_t* __restrict__ missing_bits, uint32_t* __restrict__ error_flag, uint32_t stage_after) {
+  alignas(16) __shared__ uint8_t s_m[WV][TSL][TROW_L];
+  alignas(16) __shared__ uint32_t s_w[4 * H16_SETS];
+  __shared__ uint32_t s_n[WV][TSL], s_pend[WV][TSL];
+  __shared__ unsigned long long s_ntok;
+  __shared__ uint32_t s_ndel;
+  for (int j = threadIdx.x; j < 4 * H16_SETS; j += WV * 64) s_w[j] = 0u;
+  if (threadIdx.x == 0) { s_ntok = 0; s_ndel = 0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint8_t* rows_g = reinterpret_cast<const uint8_t*>(R0);
+  constexpr uint32_t SLACK = TSLACK_L;
+  uint32_t ntok = 0, ndel = 0;
+  for (uint64_t g0 = ((uint64_t)blockIdx.x * WV + wv) * TSL; g0 < nseg; g0 += (uint64_t)gridDim.x * WV * TSL) {
+    const int nv = (int)(nseg - g0 < (uint64_t)TSL ? nseg - g0 : (uint64_t)TSL);
+    const TileSeg t = tile_segment(par, g0 + lane, lane < TSL, nseg);
+    {
+      uint32_t vb[TSL];
+#pragma unroll
+      for (int s = 0; s < TSL; s++) {
+        const int ss = s < nv ? s : nv - 1;
+        const uint32_t len = s < nv ? (uint32_t)__shfl((int)t.seglen, ss) : 0u;
+        vb[s] = 0u;
+        if (4u * (uint32_t)lane < len) vb[s] = TM_STREAM_LOAD(reinterpret_cast<const uint32_t*>(rows_g + (g0 + (uint64_t)ss) * R0_NARROW + 2 * SEG) + lane);
+      }
+#pragma unroll
+      for (int s = 0; s < TSL; s++) *reinterpret_cast<uint32_t*>(&s_m[wv][s][TSLACK_L + 4 * lane]) = vb[s];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0);
+    }
+    uint32_t staged = 0, pend = 0;
+    {
+      const int rl = lane & (TSL - 1);
+      uint8_t* rowm = s_m[wv][rl];
+      const uint2* __restrict__ sl = side + (g0 + rl) * SIDE_STRIDE;
+      const uint16_t* __restrict__ ids_g = reinterpret_cast<const uint16_t*>(rows_g + (g0 + (uint64_t)(rl < nv ? rl : 0)) * R0_NARROW);
+      const uint32_t seglen = t.have ? t.seglen : 0u;
+      uint32_t p = t.entry >> 1, fd = t.entry & 1u, E = 0, direct = 0, hop = 0;
+      constexpr int GATE_DEAD = -(1 << 24);
+      const int slack0 = (int)SLACK - 2 - (int)stage_after;
+      int gate = p < seglen ? slack0 + (int)p - (int)(fd << 16) : GATE_DEAD;      // as in k_emit_list: >= 0 straight-line step, GATE_DEAD < gate < 0 general step
+      auto note_missing = [&](uint32_t pp) {                               // trainvocab.go:1166-1173: no token for this byte
+        const uint32_t byte = text[t.begin + pp];
+        atomicOr(&missing_bits[byte >> 5], 1u << (byte & 31));
+      };
+      auto fast_step = [&]() __attribute__((always_inline)) {
+        const uint32_t m8 = rowm[SLACK + p];
+        const uint32_t miss = m8 >> 7, fdn = (m8 >> 6) & 1u, adv = m8 & 63u;
+        rowm[E] = (uint8_t)p; rowm[E + 1u] = (uint8_t)p;                   // the step's entry; a second one for a character without a token
+        E += 1u + miss;
+        if (miss) note_missing(p);
+        gate += (int)adv - (int)(fdn << 16) - (int)(1u + miss);
+        ntok += 1u + fdn;                                                  // tokensInText++ (also for a missing byte, :1169) / += 2
+        ndel += fdn;                                                       // scores[deleteToken]++ (:1134,1143,1152)
+        fd = fdn;
+        p += max(adv, 1u);
+        gate = p < seglen ? gate : GATE_DEAD;
+      };
+      for (;;) {
+#ifndef TM_EMU
+        if (gate >= 0) {
+          do fast_step(); while (__builtin_amdgcn_ballot_w64(gate < 0) == 0ull);
+        }
+#else
+        if (__builtin_amdgcn_ballot_w64(gate >= 0) != 0ull) {
+          const bool in = gate >= 0;
+          do { if (in) fast_step(); } while (__builtin_amdgcn_ballot_w64(in && gate < 0) == 0ull);
+        }
+#endif
+        const bool general = (uint32_t)gate > (uint32_t)GATE_DEAD;
+        if (__builtin_amdgcn_ballot_w64(general) != 0ull) {
+          if (general) {
+            uint32_t w;
+            if (fd != 0u) w = side_word(sl, R1, g0 + rl, p);
+            else { const uint32_t m8 = rowm[SLACK + p]; w = (uint32_t)ids_g[p] | ((m8 & 63u) << 24) | ((m8 >> 6) << 30); }      // (only read while its flag byte is intact: E <= p + SLACK - 2 or direct)
+            if (w == R_INVALID || hop > 2u * SEG) { atomicOr(error_flag, 2u); if (direct == 0u) { direct = 1u; staged = E; pend = p; } p = seglen; gate = GATE_DEAD; }
+            else {
+              const uint32_t id = w & ID_NONE, adv = (w >> 24) & 63u, fdn = (w >> 30) & 1u, miss = w >> 31;
+              const bool fits = direct == 0u && slack0 + (int)p - (int)E >= 0 && adv != 0u;
+              if (!fits && direct == 0u) { direct = 1u; staged = E; pend = p; }      // from here on the chain's tokens are counted here
+              ntok += 1u + fdn;
+              ndel += fdn;
+              if (miss) note_missing(p);
+              else if (!fits || fd != 0u) hist16_add(s_w, scores, id, adv);       // a forward-delete state's token is not in the row
+              if (fits) {
+                rowm[E++] = (uint8_t)p;
+                if (fd != 0u || miss) rowm[E++] = (uint8_t)p;                  // "skip": counted above, or nothing to count
+              }
+              fd = fdn;
+              p += adv;
+              hop++;
+              gate = p < seglen ? slack0 + (int)p - (int)E - (int)((fd | direct) << 16) : GATE_DEAD;
+            }
+          }
+        } else if (__builtin_amdgcn_ballot_w64(gate >= 0) == 0ull) break;
+      }
+      if (direct == 0u) { staged = E; pend = p; }
+    }
+    if (lane < TSL) { s_n[wv][lane] = lane < nv ? staged : 0u; s_pend[wv][lane] = pend; }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    // second phase, all 64 lanes: the ids of the listed positions from the id plane, scores[id] += bytes covered through the workgroup's histogram
+    uint32_t nmax = 0;
+#pragma unroll
+    for (int s = 0; s < TSL; s++) nmax = max(nmax, s_n[wv][s]);
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    for (uint32_t j0 = 0; j0 < nmax; j0 += 64u) {
+      const uint32_t j = j0 + (uint32_t)lane, jj = min(j, (uint32_t)TROW_L - 2u), jp = max(jj, 1u) - 1u;
+#pragma unroll 1
+      for (int s0 = 0; s0 < TSL; s0 += 8) {
+        uint32_t idv[8], advv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int s = s0 + k, ss = s < nv ? s : nv - 1;
+          const uint32_t n = s_n[wv][s];
+          const uint32_t pp = s_m[wv][s][jj], prev = s_m[wv][s][jp], nxt = j + 1u < n ? (uint32_t)s_m[wv][s][jj + 1u] : s_pend[wv][s];
+          const bool skip = j >= n || (pp == prev && j != 0u) || (j + 1u < n && pp == nxt);
+          idv[k] = reinterpret_cast<const uint16_t*>(rows_g + (g0 + (uint64_t)ss) * R0_NARROW)[pp];
+          advv[k] = skip ? 0u : nxt - pp;
+        }
+#pragma unroll
+#ifndef TM_SCORE_NOHIST      // (tools/variant_ab.sh: what the walk alone costs - results are WRONG)
+        for (int k = 0; k < 8; k++) if (advv[k] != 0u) hist16_add(s_w, scores, idv[k], advv[k]);
+#else
+        for (int k = 0; k < 8; k++) if (advv[k] == 77u && idv[k] == 0x1234u) atomicAdd(&scores[0], 1u);
+#endif
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  for (int o = 32; o > 0; o >>= 1) { ntok += __shfl_xor(ntok, o); ndel += __shfl_xor(ndel, o); }
+  if (lane == 0) {
+    if (ndel) atomicAdd(&s_ndel, ndel);
+    if (ntok) atomicAdd(&s_ntok, (unsigned long long)ntok);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 4 * H16_SETS; j += WV * 64)
+    if ((s_w[j] & H16_CNT) != 0u) atomicAdd(&scores[((s_w[j] >> 28) << 12) | (uint32_t)(j >> 2)], s_w[j] & H16_CNT);
   if (threadIdx.x == 0) {
     if (s_ndel) atomicAdd(&scores[delete_id], s_ndel);
     if (s_ntok) atomicAdd(tokens, s_ntok);
@@ -1886,6 +2093,9 @@ int debug_flags() {
 
 // T(p,0) rows in the narrow form (u16 id + u8 advance / flags per position) whenever the ids fit
 static bool r0_narrow(const tm_batch* b) { return b->vocab->host.n_ids <= 65536u; }
+// ... k_match_branch's `narrow`: two planes (1: u16 ids, 2: u32 ids) for K4's position-staging walk; one plane of u32 words for the id-staging
+// walks - the scoring pass of a vocabulary of more than 65 536 ids, and test hook 15 on such a vocabulary
+static int r0_mode(const tm_batch* b, bool for_score) { return r0_narrow(b) ? 1 : (for_score || (debug_flags() & 32768)) ? 0 : 2; }
 static uint32_t r0_no_id(const tm_batch* b) { return b->vocab->tables.unk_id != TM_NONE ? b->vocab->tables.unk_id : ID_NONE; }      // what a character without a token emits (go :1269-1276)
 
 uint32_t long_segs() { return (debug_flags() & 4096) ? 8u : LONG_SEGS; }
@@ -1914,6 +2124,11 @@ void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hi
   if (nseg > 0) {
     launch_seg_params(b, st);
     constexpr int WV = SEG <= 256 ? 11 : 5;      // wavefronts of a scoring workgroup: as many tiles as fit the LDS beside the histogram
+    constexpr int WVL = 16;                      // ... of the position-staging form: 16 x 16 chains, 68 KB of flag bytes beside the 64 KB histogram
+    if (r0_narrow(b) && !(debug_flags() & 32768))      // (test hook 15: the word-staging walk for the two-plane rows too)
+      TM_LAUNCH(k_score_list<WVL>, (uint32_t)std::min<uint64_t>((nseg + WVL * TSL - 1) / (WVL * TSL), (uint64_t)n_cu), WVL * 64, 0, st,
+          b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_seg_par, nseg, delete_id, d_hist, d_tokens, d_missing_bits, b->d_error, (debug_flags() & 1024) ? 512u : 0u);
+    else
     TM_LAUNCH(k_score_tiles<WV>, (uint32_t)std::min<uint64_t>((nseg + WV * TS - 1) / (WV * TS), (uint64_t)n_cu), WV * 64, 0, st, 
         b->d_R0, b->d_side, b->d_R1, b->d_text, b->d_seg_par, nseg, delete_id, d_hist, d_tokens, d_missing_bits, b->d_error, r0_narrow(b) ? 1 : 0, r0_no_id(b));
   }
@@ -1938,8 +2153,11 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store, bool rezero = f
   if (nseg > 0) {
     launch_seg_params(b, st);
     const uint32_t stage_after = (debug_flags() & 1024) ? 512u : 0u;
-    if (r0_narrow(b) && !(debug_flags() & 32768))             // (test hook 15: the id-staging form of the walk for the two-plane rows too)
-      TM_LAUNCH(k_emit_list, (uint32_t)((nseg + TSL - 1) / TSL), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
+    if (!(debug_flags() & 32768) && !r0_narrow(b))             // (test hook 15: the id-staging form of the walk instead - for the larger vocabularies over one-plane rows)
+      TM_LAUNCH(k_emit_list<true>, (uint32_t)((nseg + TSL - 1) / TSL), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
+                                                                   b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b), b->d_ctl);
+    else if (!(debug_flags() & 32768))
+      TM_LAUNCH(k_emit_list<false>, (uint32_t)((nseg + TSL - 1) / TSL), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
                                                                    b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b), b->d_ctl);
     else if (r0_narrow(b))
       TM_LAUNCH(k_emit_tiles<true>, (uint32_t)((nseg + TS - 1) / TS), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
@@ -2072,7 +2290,7 @@ int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32
 
 // The pipeline in two halves, so that the scoring pass can look at the exit maps (tm_score_begin) before the entry states of its byte
 // ranges are known (tm_score_finish): pipeline_match = K0 + K1 (+ the group maps of long documents), pipeline_resolve = K3 + scan (+ K4).
-int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
+int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev, bool for_score) {
   const tm_vocab* v = b->vocab;
   { int rc = enter_device(v); if (rc != TM_OK) return rc; }
   b->last_stream = st;
@@ -2096,7 +2314,7 @@ int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev) {
   if (nseg > 0)
     TM_LAUNCH(k_match_branch, (uint32_t)((nseg + WAVES - 1) / WAVES), WAVES * 64, TM_K1_EXTRA_LDS, st, v->tables, b->d_text, b->d_doc_begin, b->d_doc_end,
                                                                                           b->d_doc_vis ? b->d_doc_vis : b->d_doc_end, b->d_seg_doc,
-                                                                                          b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap, b->d_exit16, r0_narrow(b) ? 1 : 0,
+                                                                                          b->d_doc_seg_start, nseg, b->d_R0, b->d_side, b->d_R1, b->d_exitmap, b->d_exit16, r0_mode(b, for_score),
                                                                                           debug_flags(), b->text_in_slabs ? b->d_slab : nullptr, b->d_seg_par, b->d_ctl);
     note_table_use(v, st);
   mark(2);
@@ -2292,7 +2510,7 @@ int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, boo
   hipError_t e = hipSuccess;
   if ((own_text && (e = dalloc(b, &b->d_text, max_bytes + 256)) != hipSuccess) || (e = dalloc(b, &b->d_offsets, 2 * nd1)) != hipSuccess ||
       (e = dalloc(b, &b->d_doc_nseg, nd1)) != hipSuccess || (e = dalloc(b, &b->d_doc_seg_start, nd1 + 1)) != hipSuccess ||
-      (e = dalloc(b, &b->d_seg_doc, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_R0, b->max_segs * SEG)) != hipSuccess || (e = dalloc(b, &b->d_R1, b->max_segs * SEG)) != hipSuccess ||
+      (e = dalloc(b, &b->d_seg_doc, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_R0, b->max_segs * (v->host.n_ids <= 65536u ? SEG : SEG + SEG / 4))) != hipSuccess || (e = dalloc(b, &b->d_R1, b->max_segs * SEG)) != hipSuccess ||
       (e = dalloc(b, &b->d_side, b->max_segs * SIDE_STRIDE)) != hipSuccess ||
       (e = dalloc(b, &b->d_exitmap, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_exit16, b->max_segs * ENT)) != hipSuccess || (e = dalloc(b, &b->d_seg_entry, b->max_segs)) != hipSuccess ||
       (e = dalloc(b, &b->d_seg_tokbase, b->max_segs)) != hipSuccess || (e = dalloc(b, &b->d_seg_par, b->max_segs + 1)) != hipSuccess || (e = dalloc(b, &b->d_doc_ntok, nd1)) != hipSuccess ||

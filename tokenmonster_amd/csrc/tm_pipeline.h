@@ -224,7 +224,7 @@ bool hooks_armed();       // the process was started with TM_TEST_HOOKS in its e
 uint32_t long_segs();    // documents with more segments than this hang under the group tree (LONG_SEGS; 8 under test hook bit 12)
 int build_groups(tm_batch* b, const uint64_t* begin, const uint64_t* end, uint32_t ndocs, hipStream_t st);
 int run_pipeline(tm_batch* b, hipStream_t st, bool timed, float* ms, bool emit);
-int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev);
+int pipeline_match(tm_batch* b, hipStream_t st, hipEvent_t* ev, bool for_score = false);      // for_score: the rows are for the scoring walk (tm_score.hip)
 int pipeline_resolve(tm_batch* b, hipStream_t st, hipEvent_t* ev, int mode);
 void launch_doc_exits(tm_batch* b, uint8_t* d_exits, hipStream_t st);
 // scoring variant of the chain kernel: histogram in HBM (scores | 4 limbs | 256 counters), see tm_score.hip

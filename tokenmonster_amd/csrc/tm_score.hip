@@ -90,7 +90,7 @@ static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
   b->nbytes = d->n;
   b->nseg = nseg;
   { int grc = build_groups(b, be.data(), be.data() + n_strips, n_strips, st); if (grc != TM_OK) return grc; }
-  int rc = pipeline_match(b, st, nullptr);
+  int rc = pipeline_match(b, st, nullptr, true);
   if (rc == TM_OK) d->prepared = true;
   return rc;
 }

@@ -8,7 +8,7 @@
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-declare -A VARIANTS=( [devel]="-DTM_DEVEL" )
+declare -A VARIANTS=( [devel]="-DTM_DEVEL" [nohist]="-DTM_SCORE_NOHIST" )
 case "${1:-}" in
 build)
   for name in "${!VARIANTS[@]}"; do
