@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--config", default=None, help="vocabulary shape (default: englishcode-32000-consistent; score: candidates-65536)")
     ap.add_argument("--tune-mib", type=float, default=0.0, help="tm_vocab_tune the vocabulary on this many MiB of OTHER synthetic text of the same kind before anything is "
                                                                 "timed (off by default: the lines of record are untuned); recorded in config.tables_tuned_on")
-    ap.add_argument("--workload", default="tokenize", choices=["tokenize", "score"],
-                    help="tokenize = BASELINE configs[1] (default); score = trainvocab candidate-scoring pass, configs[4]")
+    ap.add_argument("--workload", default="tokenize", choices=["tokenize", "score", "decode"],
+                    help="tokenize = BASELINE configs[1] (default); score = trainvocab candidate-scoring pass, configs[4]; decode = Decode of the ids of "
+                         "the same corpus, device-resident (SURVEY 8(f) #2: ids in HBM -> text in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hot-path-only", action="store_true", help="input = host-normalized bytes; time only the tokenize pipeline")
     ap.add_argument("--cpu-sample-mb", type=float, default=64.0)
@@ -349,6 +350,130 @@ def bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_f
         dist.destroy_process_group()
 
 
+def bench_decode(args, rank, local_rank, world, vocab, img, kind, capcode, norm_flag, log):
+    """--workload decode: Decode (go/tokenmonster.go:445-550; tokenmonster.cpp:1404-1425) of the ids of the tokenize workload's corpus, device-resident:
+    the timed region starts with the uint32 ids + offsets of the rank's shard in HBM (left there by the tokenizer) and ends with the decoded
+    text in HBM (tm_batch_decode: lengths -> scan -> gather of the tokens' bytes -> capcode decoding).  `value` = decoded bytes of all ranks
+    x K / max-over-ranks wall time.  Documents are sharded by rank, no collective."""
+    import torch
+    import torch.distributed as dist
+    from tokenmonster_amd import _native as N, synth
+    t0 = time.time()
+    raw, roffs = synth.synth_corpus(kind, args.mbytes << 20, seed=0x434F5250 + 2 + 1000 * rank)
+    ndocs = roffs.size - 1
+    batch = C.c_void_p()
+    N.check(N.lib.tm_batch_create(vocab.handle, int(raw.size) + int(raw.size) // 4 + (1 << 20), ndocs, C.byref(batch)))
+    N.check(N.lib.tm_batch_upload_raw(batch, N.ptr(raw), N.ptr(roffs), ndocs))
+    stream = torch.cuda.current_stream().cuda_stream
+    N.check(N.lib.tm_batch_normalize(batch, C.c_void_p(stream)))
+    N.check(N.lib.tm_batch_run(batch, C.c_void_p(stream)))
+    ntok, nmiss = C.c_uint64(), C.c_uint64()
+    N.check(N.lib.tm_batch_totals(batch, C.byref(ntok), C.byref(nmiss)))
+    enc_bytes = int(N.lib.tm_batch_normalized_bytes(batch))
+    log("corpus: %d docs, %.1f MB raw -> %d ids resident in HBM (%.1fs)" % (ndocs, raw.size / 1e6, ntok.value, time.time() - t0))
+    nbytes, host_docs = C.c_uint64(), C.c_uint32()
+
+    def step():
+        N.check(N.lib.tm_batch_decode(batch, 0, C.c_void_p(stream), C.byref(nbytes), C.byref(host_docs)))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    out_bytes = float(nbytes.value)
+    tot = torch.tensor([out_bytes, float(ntok.value)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    all_out = float(tot[0].item())
+    # the stages of one pass by HIP events on the launch stream
+    ms = (C.c_float * 3)()
+    acc = np.zeros(3)
+    for _ in range(3):
+        N.check(N.lib.tm_batch_decode_timed(batch, 0, C.c_void_p(stream), C.byref(nbytes), C.byref(host_docs), ms))
+        acc += np.array(list(ms))
+    acc /= 3
+    stage_ms = {"lengths_scan": round(float(acc[0]), 4), "k_dec_copy": round(float(acc[1]), 4), "k_dec_capcode": round(float(acc[2]), 4)}
+    # algorithmic bytes of each stage: the gather reads 4T of ids and 8T of offsets and writes the encoded text once (the tokens' bytes
+    # come out of a 0.3 MB table that stays in the caches); the capcode decoder reads the encoded text once and writes the decoded text once
+    T, n_enc = float(ntok.value), float(enc_bytes)
+    alg = {"lengths_scan": 4 * T + 4 * T + 4 * T + 8 * T, "k_dec_copy": 4 * T + 8 * T + n_enc, "k_dec_capcode": n_enc + out_bytes}
+    dom = max(stage_ms, key=lambda k: stage_ms[k])
+    achieved = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+    verified, verified_ref = None, None
+    cpu = None
+    if rank == 0:
+        # every document of the timed pass: the decoded text must be the NFD form of the raw text (no capcode, nothing missing) ...
+        ooff = np.zeros(ndocs + 1, dtype=np.uint64)
+        out = np.empty(int(raw.size) + int(raw.size) // 2 + 64, dtype=np.uint8)
+        N.check(N.lib.tm_batch_decoded_download(batch, N.ptr(out), out.size, N.ptr(ooff)))
+        if int(nmiss.value) == 0 and args.verify != 0:
+            plain, poff = synth.normalize_batch(raw, roffs, 0, norm_flag)
+            if int(ooff[-1]) != plain.size or not (ooff == poff).all() or not (out[: plain.size] == plain).all():
+                raise SystemExit("bench.py: the decoded text is not the (NFD) text that was tokenized - number is INVALID")
+            verified = ndocs
+        # ... and, document by document on a sample, what the reference runtime's decode makes of the same ids (also the CPU baseline)
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_bind import Reference, have_ref
+            if have_ref():
+                ids = np.empty(max(int(ntok.value), 1), dtype=np.uint32)
+                toff = np.empty(ndocs + 1, dtype=np.uint64)
+                N.check(N.lib.tm_batch_download(batch, N.ptr(ids), int(ntok.value), N.ptr(toff), None))
+                ref = Reference(img)
+                budget, done, nb = 15.0, 0, 0
+                t1 = time.perf_counter()
+                while done < ndocs and time.perf_counter() - t1 < budget:
+                    for d in range(done, min(done + 512, ndocs)):
+                        txt = ref.decode(ids[int(toff[d]):int(toff[d + 1])])
+                        if txt != out[int(ooff[d]):int(ooff[d + 1])].tobytes():
+                            raise SystemExit("bench.py: document %d decodes differently in the reference runtime - number is INVALID" % d)
+                        nb += len(txt)
+                    done = min(done + 512, ndocs)
+                dt = time.perf_counter() - t1
+                verified_ref = done
+                cpu = {"value": round(nb / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "reference",
+                       "sample": "decode of the first %d documents (%.1f MB of text) of the same id streams by the reference runtime (oracle/_ref, tokenmonster.cpp:1404-1425), "
+                                 "1 thread, %.1f s incl. the Python loop around it; every document compared with the device's text" % (done, nb / 1e6, dt)}
+    if rank == 0:
+        value = all_out * args.steps / elapsed / 1e9
+        e2e_alg = 4 * T + 2 * out_bytes
+        line = {
+            "metric": "GB/s of decoded UTF-8 text, Decode of englishcode-32000 id streams, device-resident", "value": round(value, 4), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s vocabulary shape (synthetic, %d ids); the uint32 ids of %d MiB of raw synthetic mixed text per GPU (%d documents, %d ids) resident in HBM "
+                                   "-> decoded text in HBM (tm_batch_decode: lengths, scan, gather, capcode decoding)" % (args.config, vocab.n_ids(), args.mbytes, ndocs, int(T)),
+                       "ids_per_gpu": int(T), "encoded_bytes_per_gpu": int(n_enc), "decoded_bytes_per_gpu": int(out_bytes), "host_decoded_docs": int(host_docs.value),
+                       "parallelism": "documents sharded by rank, no collective", "rccl_ranks": dist.get_world_size() if world > 1 else 0,
+                       "verified_docs_round_trip": verified, "verified_docs_vs_reference": verified_ref},
+            "stage_ms": stage_ms,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": None, "algorithmic_bytes_per_launch": alg[dom],
+                         "algorithmic_bytes_note": "k_dec_copy: 4T ids + 8T byte offsets read, encoded text written once; k_dec_capcode: encoded text read, decoded text written; "
+                                                   "lengths_scan: ids read, lengths written and read, offsets written",
+                         "whole_pass": {"algorithmic_bytes": e2e_alg, "achieved": round(e2e_alg / (elapsed / args.steps) / 1e9, 3),
+                                        "frac": round(e2e_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6), "note": "4T + 2 N_out over the whole step"}},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    N.lib.tm_batch_free(batch)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def score_prefix(N, vocab, ds, n_ids, n):
     """tm_score over the first n bytes of the resident dataset as one strip -> (scores, tokens_in_text, missing_set)"""
     so, sl = np.array([0], dtype=np.uint64), np.array([n], dtype=np.uint64)
@@ -580,7 +705,7 @@ def main():
     N.check(N.lib.tm_set_device(local_rank))
 
     if args.config is None:
-        args.config = "englishcode-32000-consistent" if args.workload == "tokenize" else "candidates-65536"
+        args.config = "candidates-65536" if args.workload == "score" else "englishcode-32000-consistent"
     kind, vsize, capcode, norm_flag, level, vseed = synth.CONFIGS[args.config]
     t0 = time.time()
     if rank == 0:
@@ -600,6 +725,8 @@ def main():
 
     if args.workload == "score":
         return bench_score(args, rank, local_rank, world, vocab, img, kind, capcode, norm_flag, log)
+    if args.workload == "decode":
+        return bench_decode(args, rank, local_rank, world, vocab, img, kind, capcode, norm_flag, log)
 
     # ---- synthetic corpus shard of this rank ------------------------------------------------------------
     t0 = time.time()

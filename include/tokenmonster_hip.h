@@ -222,15 +222,26 @@ uint64_t tm_batch_device_bytes(const tm_batch* b);
 /* ids of document d = tokens[tok_offsets[d] .. tok_offsets[d+1]).  The gather of reverse[id] (lengths -> scan -> copy)
  * runs on the device; ids >= tm_vocab_n_ids are skipped.  raw != 0: the concatenated token bytes as they are
  * (decode_raw); raw == 0: capcode decoding (javascript/tokenmonster.js:1007-1065) follows — on the device for the documents of a capcode-2
- * UTF-8 vocabulary made of ASCII, the two-byte scripts (U+0080..U+07FF) and the three-byte characters without case (punctuation, CJK, kana,
- * Hangul, symbols); on the host for documents with a letter whose upper-case form has another length, a three-byte letter with case, a
- * four-byte character or malformed UTF-8, and for capcode 1.  tm_decode_host_docs(): how many documents of the calling thread's last tm_decode_batch went to the host decoder.
+ * UTF-8 vocabulary made of ASCII, the two-byte scripts (U+0080..U+07FF), the three-byte characters without case (punctuation, CJK, kana,
+ * Hangul, symbols) and the four-byte characters of blocks that are caseless throughout (emoji, symbols, the ideographs of plane 2); on the
+ * host for documents with a letter whose upper-case form has another length, a three- or four-byte letter with case or malformed UTF-8, and
+ * for capcode 1.  tm_decode_host_docs(): how many documents of the calling thread's last tm_decode_batch went to the host decoder.
  * out_offsets[ndocs+1] is always filled; TM_E_NOSPACE if out_cap is too small (required size in out_offsets[ndocs]).
  * Like the tokenize entry points the call borrows a lane of the vocabulary (its stream, grow-only device arenas and pinned
  * staging): callable concurrently, no allocation in steady state, nothing on the NULL stream. */
 int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* tok_offsets, uint32_t ndocs, int raw,
                     uint8_t* out, uint64_t out_cap, uint64_t* out_offsets);
 uint32_t tm_decode_host_docs(void);
+/* The same on the ids a batch HOLDS after tm_batch_run, device-resident: ids in HBM -> text in HBM, in grow-only buffers of the batch (what
+ * bench.py --workload decode times; a service that detokenizes what it has just tokenized never moves the ids over the host link).
+ * Synchronizes `stream`.  *decoded_bytes: bytes of the documents the device decoded; *host_docs: documents it left to the host decoder
+ * (those are decoded by tm_batch_decoded_download, which returns every document's text in document order - out_offsets[ndocs+1] always
+ * filled, TM_E_NOSPACE with the size required in out_offsets[ndocs] if out_cap is too small). */
+int tm_batch_decode(tm_batch* b, int raw, void* stream, uint64_t* decoded_bytes, uint32_t* host_docs);
+/* ... with HIP events on `stream` around its stages: ms[0] lengths + scan + document offsets, ms[1] the gather of the tokens' bytes
+ * (k_dec_copy), ms[2] capcode decoding (k_dec_capcode; 0 when that is not the device's) - what bench.py's decode line prices its roofline on */
+int tm_batch_decode_timed(tm_batch* b, int raw, void* stream, uint64_t* decoded_bytes, uint32_t* host_docs, float* ms);
+int tm_batch_decoded_download(tm_batch* b, uint8_t* out, uint64_t out_cap, uint64_t* out_offsets);
 
 /* Streaming Decoder (go/tokenmonster.go:552-700 NewDecoder / Decode / DecodeSerialized / Flush; server jobs 5-9): ids arrive a few
  * at a time, a call returns the text that is COMPLETE so far; the bytes of a character that is not (a token may end in the middle of a

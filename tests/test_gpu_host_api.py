@@ -434,3 +434,33 @@ def test_ring_hands_chunks_to_the_exact_path():
         assert (boff == toff * np.uint64(enc)).all() and (bmiss == miss).all()
         assert (_ids_from_bytes(np.asarray(blob), enc) == ids).all()
         assert st["normalized_bytes"] == text.size
+
+
+@pytest.mark.parametrize("capcode", [2, 0])
+def test_resident_decode_equals_the_host_buffer_decode(capcode):
+    """tm_batch_decode: the ids a batch holds decoded where they lie (ids in HBM -> text in HBM, what bench.py --workload decode times) give
+    the text tm_decode_batch gives for the same ids - device-decoded documents and those left to the host decoder alike - and, for a
+    vocabulary with every byte as a token, the NFD form of the raw text back."""
+    from conftest import EMULATED
+    img = synth.synth_vocab(synth.ENGLISHCODE, 3000, capcode=capcode, norm_flag=1, level=3, seed=0x44454344)
+    v = tm.Vocab(img)
+    base_raw, base_off = synth.synth_corpus(synth.ENGLISHCODE, 60_000 if EMULATED else 1_500_000, seed=75)
+    docs = [bytes(base_raw[int(base_off[d]):int(base_off[d + 1])]) for d in range(base_off.size - 1)]
+    docs += ["Découvert À Paris, le CŒUR de l\u2019été: Garçon ÉTÉ".encode(), "中文 と Ελληνικά ЖУК жук".encode(), b"", "I\u0131 \uff21\uff41 mixed CASE".encode(), b"ALL CAPS WORDS HERE and Title Case"]
+    raw = np.frombuffer(b"".join(docs), dtype=np.uint8).copy()
+    roffs = np.zeros(len(docs) + 1, dtype=np.uint64)
+    roffs[1:] = np.cumsum([len(x) for x in docs])
+    text, offs = synth.normalize_batch(raw, roffs, capcode, 1)
+    ids, toff, _ = v.tokenize_packed(text, offs)
+    for raw_mode in (False, True):
+        exp, eoff = v.decode_packed(ids, toff, raw=raw_mode)
+        got, goff, host_docs = v.roundtrip_resident(raw, roffs, raw=raw_mode)
+        assert (goff == eoff).all() and got.tobytes() == exp.tobytes()
+        if capcode == 2 and not raw_mode:
+            assert 1 <= host_docs <= 3                      # (the dotless i / fullwidth letters: upper-case forms the device leaves to the host)
+        else:
+            assert host_docs == 0
+    plain, poff = synth.normalize_batch(raw, roffs, 0, 1)     # NFD without capcode: what Decode gives back (no token is missing in this vocabulary's text)
+    got, goff, _ = v.roundtrip_resident(raw, roffs)
+    if int(v.tokenize_packed(text, offs)[2].sum()) == 0:
+        assert (goff == poff).all() and got.tobytes() == plain.tobytes()

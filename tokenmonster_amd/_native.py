@@ -73,6 +73,9 @@ SIGNATURES = {
     "tm_batch_device_bytes": (C.c_uint64, [vp]),
     "tm_decode_batch": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint64, vp]),
     "tm_decode_host_docs": (C.c_uint32, []),
+    "tm_batch_decode": (C.c_int, [vp, C.c_int, vp, u64p, u32p]),
+    "tm_batch_decode_timed": (C.c_int, [vp, C.c_int, vp, u64p, u32p, f32p]),
+    "tm_batch_decoded_download": (C.c_int, [vp, vp, C.c_uint64, vp]),
     "tm_decoder_new": (C.c_int, [vp, C.POINTER(vp)]),
     "tm_decoder_free": (None, [vp]),
     "tm_decoder_decode": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]),

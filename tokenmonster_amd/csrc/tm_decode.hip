@@ -146,6 +146,17 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
   }
   if (lane == 0) dec_len[d] = host ? DEC_HOST : o - b;
 }
+// out[0] = bytes of the documents the device decoded, out[1] = documents it left to the host decoder (one workgroup)
+__global__ void k_dec_sum(const uint64_t* __restrict__ dec_len, uint32_t ndocs, uint64_t* __restrict__ out) {
+  __shared__ unsigned long long s_bytes, s_host;
+  if (threadIdx.x == 0) { s_bytes = 0; s_host = 0; }
+  __syncthreads();
+  unsigned long long bytes = 0, host = 0;
+  for (uint32_t d = threadIdx.x; d < ndocs; d += blockDim.x) { const uint64_t l = dec_len[d]; if (l == DEC_HOST) host++; else bytes += l; }
+  atomicAdd(&s_bytes, bytes); atomicAdd(&s_host, host);
+  __syncthreads();
+  if (threadIdx.x == 0) { out[0] = s_bytes; out[1] = s_host; }
+}
 }  // namespace tmh
 
 namespace tmh {
@@ -184,3 +195,127 @@ int launch_decode_capcode(const tm_vocab* v, const uint8_t* d_out, const uint64_
   return TM_OK;
 }
 }  // namespace tmh
+
+// ---- device-resident decode of the ids a batch holds -------------------------------------------------------------------------------------------
+// What tm_decode_batch (tm_host.hip) does between its upload and its download, on buffers of the batch: ids in HBM -> text in HBM.  The
+// decode leg of bench.py times this; a caller that keeps token streams on the device (a detokenizing server beside the tokenizing one)
+// gets its text without the ids ever crossing the host link.
+extern "C" {
+
+static int batch_decode(tm_batch* b, int raw, void* stream, uint64_t* decoded_bytes, uint32_t* host_docs, float* ms);
+int tm_batch_decode(tm_batch* b, int raw, void* stream, uint64_t* decoded_bytes, uint32_t* host_docs) { return batch_decode(b, raw, stream, decoded_bytes, host_docs, nullptr); }
+int tm_batch_decode_timed(tm_batch* b, int raw, void* stream, uint64_t* decoded_bytes, uint32_t* host_docs, float* ms) {
+  if (!ms) return set_error(TM_E_INVALID, "null argument");
+  return batch_decode(b, raw, stream, decoded_bytes, host_docs, ms);
+}
+// ms (may be null): HIP events on `stream` around [0] lengths + scan + document offsets, [1] the gather (k_dec_copy), [2] capcode decoding (k_dec_capcode)
+static int batch_decode(tm_batch* b, int raw, void* stream, uint64_t* decoded_bytes, uint32_t* host_docs, float* ms) {
+  if (!b) return set_error(TM_E_INVALID, "null argument");
+  const tm_vocab* v = b->vocab;
+  { int rc = enter_device(v); if (rc != TM_OK) return rc; }
+  { int rc = ensure_output(b); if (rc != TM_OK) return rc; }          // (the ids are all there: the emit stage is repeated if its buffer was too small)
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t nd = b->ndocs;
+  const uint64_t n = nd ? b->last_totals[1] : 0;
+  b->dec_ndocs = nd; b->dec_total = 0; b->dec_capcode = false; b->dec_raw = raw != 0;
+  if (decoded_bytes) *decoded_bytes = 0;
+  if (host_docs) *host_docs = 0;
+  if (ms) ms[0] = ms[1] = ms[2] = 0.f;
+  if (nd == 0) return TM_OK;
+  hipError_t e;
+  if (ms && !b->have_events) {
+    for (auto& ev : b->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    b->have_events = true;
+  }
+  auto mark = [&](int k) { if (ms) (void)hipEventRecord(b->ev[k], st); };
+  auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
+  auto grow = [&](uint8_t** p, uint64_t* cap, uint64_t need) -> hipError_t {
+    if (*cap >= need) return hipSuccess;
+    if (*cap) trace_grow("decode arena", need);
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = need + need / 8 + 4096;
+    return hipMalloc((void**)p, *cap);
+  };
+  const uint64_t sblocks = (n + 1 + SCAN_CH - 1) / SCAN_CH + 2;
+  const uint64_t o_len = 0, o_off = o_len + up((n + 1) * 4), o_sums = o_off + up((n + 2) * 8), o_total = o_sums + up(sblocks * 8), o_doff = o_total + 256,
+                 o_declen = o_doff + up(((uint64_t)nd + 1) * 8), a_bytes = o_declen + up((uint64_t)nd * 8 + 8);
+  if ((e = grow(&b->d_dec_a, &b->dec_a_cap, a_bytes)) != hipSuccess) { b->dec_a_cap = 0; return hip_fail(e, "hipMalloc (decode)"); }
+  uint8_t* A = b->d_dec_a;
+  uint32_t* d_len = (uint32_t*)(A + o_len); uint64_t* d_off = (uint64_t*)(A + o_off); uint64_t* d_sums = (uint64_t*)(A + o_sums); uint64_t* d_total = (uint64_t*)(A + o_total);
+  uint64_t* d_doff = (uint64_t*)(A + o_doff); uint64_t* d_declen = (uint64_t*)(A + o_declen);
+  mark(0);
+  launch_decode_lengths(v, b->d_out, n, b->d_tok_offsets, nd, d_len, d_off, d_sums, d_total, d_doff, st);
+  mark(1);
+  uint64_t total = 0;
+  { int rc = small_d2h(b, &total, d_total, 8, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc; }
+  const uint64_t o_dec = up(total + 16);
+  if ((e = grow(&b->d_dec_b, &b->dec_b_cap, o_dec + up(total + 16))) != hipSuccess) { b->dec_b_cap = 0; return hip_fail(e, "hipMalloc (decode output)"); }
+  mark(2);
+  launch_decode_copy(v, b->d_out, n, d_off, b->d_dec_b, st);
+  mark(3);
+  const bool dev_capcode = !raw && v->host.capcode == 2 && v->host.charset == 1;
+  uint64_t sum[2] = {total, 0};
+  if (dev_capcode) {
+    int rc = launch_decode_capcode(v, b->d_dec_b, d_doff, nd, b->d_dec_b + o_dec, d_declen, st);
+    if (rc != TM_OK) return rc;
+    mark(4);
+    TM_LAUNCH(k_dec_sum, 1, 256, 0, st, d_declen, nd, d_total);            // bytes the device decoded, documents it left to the host
+    if ((rc = small_d2h(b, sum, d_total, 16, st)) != TM_OK) return rc;
+  }
+  { int rc = small_sync(b, st); if (rc != TM_OK) return rc; }
+  if (ms) {
+    (void)hipEventElapsedTime(&ms[0], b->ev[0], b->ev[1]);
+    (void)hipEventElapsedTime(&ms[1], b->ev[2], b->ev[3]);
+    if (dev_capcode) (void)hipEventElapsedTime(&ms[2], b->ev[3], b->ev[4]);
+  }
+  b->dec_total = total; b->dec_o_doff = o_doff; b->dec_o_declen = o_declen; b->dec_o_dec = o_dec; b->dec_capcode = dev_capcode;
+  // (a capcode-1 or UTF-16 vocabulary, or one without capcode that was not asked for the raw form: every document is the host decoder's)
+  const bool all_host = !raw && v->host.capcode != 0 && !dev_capcode;
+  if (decoded_bytes) *decoded_bytes = all_host ? 0 : sum[0];
+  if (host_docs) *host_docs = all_host ? nd : (uint32_t)sum[1];
+  return TM_OK;
+}
+
+int tm_batch_decoded_download(tm_batch* b, uint8_t* out, uint64_t out_cap, uint64_t* out_offsets) {
+  if (!b || !out_offsets) return set_error(TM_E_INVALID, "null argument");
+  const tm_vocab* v = b->vocab;
+  { int rc = enter_device(v); if (rc != TM_OK) return rc; }
+  const uint32_t nd = b->dec_ndocs;
+  out_offsets[0] = 0;
+  if (nd == 0) return TM_OK;
+  hipError_t e;
+  const uint64_t total = b->dec_total;
+  std::vector<uint64_t> doff((size_t)nd + 1), declen(nd, 0);
+  std::vector<uint8_t> enc(total + 16), dec(b->dec_capcode ? total + 16 : 0);
+  if ((e = hipMemcpy(doff.data(), b->d_dec_a + b->dec_o_doff, doff.size() * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
+      (total && (e = hipMemcpy(enc.data(), b->d_dec_b, total, hipMemcpyDeviceToHost)) != hipSuccess)) return hip_fail(e, "D2H decoded bytes");
+  if (b->dec_capcode && ((e = hipMemcpy(declen.data(), b->d_dec_a + b->dec_o_declen, (size_t)nd * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
+                         (total && (e = hipMemcpy(dec.data(), b->d_dec_b + b->dec_o_dec, total, hipMemcpyDeviceToHost)) != hipSuccess))) return hip_fail(e, "D2H decoded text");
+  const bool plain = b->dec_raw || v->host.capcode == 0;      // no capcode to undo: the gathered bytes are the text
+  // the documents the device left alone go through the host decoder, as in tm_decode_batch
+  std::vector<uint32_t> todo;
+  if (!plain) for (uint32_t d = 0; d < nd; d++) if (!b->dec_capcode || declen[d] == DEC_HOST) todo.push_back(d);
+  std::vector<std::vector<uint8_t>> touts;
+  if (!todo.empty()) {
+    std::vector<uint64_t> toff(todo.size() + 1, 0);
+    std::vector<uint8_t> tbytes;
+    for (size_t k = 0; k < todo.size(); k++) { tbytes.insert(tbytes.end(), enc.begin() + doff[todo[k]], enc.begin() + doff[todo[k] + 1]); toff[k + 1] = tbytes.size(); }
+    capcode_decode_batch(tbytes.data(), toff.data(), (uint32_t)todo.size(), v->host.capcode, 0, touts);
+  }
+  std::vector<uint64_t> slot((size_t)nd, DEC_HOST);
+  for (size_t k = 0; k < todo.size(); k++) slot[todo[k]] = k;
+  uint64_t o = 0;
+  for (uint32_t d = 0; d < nd; d++) { out_offsets[d] = o; o += slot[d] != DEC_HOST ? touts[slot[d]].size() : (plain ? doff[d + 1] - doff[d] : declen[d]); }
+  out_offsets[nd] = o;
+  if (o > out_cap) return set_error(TM_E_NOSPACE, "out_cap %llu < %llu required", (unsigned long long)out_cap, (unsigned long long)o);
+  for (uint32_t d = 0; d < nd; d++) {
+    const uint64_t len = out_offsets[d + 1] - out_offsets[d];
+    if (!len) continue;
+    if (slot[d] != DEC_HOST) std::memcpy(out + out_offsets[d], touts[slot[d]].data(), len);
+    else std::memcpy(out + out_offsets[d], (plain ? enc.data() : dec.data()) + doff[d], len);
+  }
+  return TM_OK;
+}
+
+}  // extern "C"

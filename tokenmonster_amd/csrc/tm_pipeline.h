@@ -180,6 +180,13 @@ struct tm_batch {
   // kernels behind the pass are launched over a bound and look the counts up (d_ctl != null; k_chunk_ctl / k_chunk_done, tm_kernels.hip)
   uint64_t* d_ctl_store = nullptr;      // 8 words, allocated on first use
   const uint64_t* d_ctl = nullptr;      // = d_ctl_store while the workspace belongs to a slot of the ring
+  // tm_batch_decode (tm_decode.hip): the ids of this batch decoded where they lie - two grow-only arenas and what the last call left in them
+  uint8_t* d_dec_a = nullptr; uint64_t dec_a_cap = 0;      // lengths, byte offset of every id, scan sums, the documents' offsets and decoded lengths
+  uint8_t* d_dec_b = nullptr; uint64_t dec_b_cap = 0;      // the gathered bytes | the same after capcode decoding
+  uint64_t dec_total = 0, dec_o_doff = 0, dec_o_declen = 0, dec_o_dec = 0;
+  uint32_t dec_ndocs = 0;
+  bool dec_raw = false;                                     // decode_raw: the gathered bytes are the result
+  bool dec_capcode = false;                                 // the capcode decoder ran on the device (else the gathered bytes are the result, or all the host's)
   hipEvent_t ev[TM_NUM_KERNELS + 1] = {};
   bool have_events = false;
 };

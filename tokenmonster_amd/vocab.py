@@ -216,6 +216,33 @@ class Vocab:
             N.check(rc)
             return out[: int(ooff[nd])], ooff
 
+    def roundtrip_resident(self, raw_text, raw_offsets, raw=False):
+        """raw documents -> ids -> text without the ids leaving the device: tm_batch_upload_raw + tm_batch_normalize + tm_batch_run, then
+        tm_batch_decode on the ids the batch holds -> (decoded text u8, offsets u64[D+1], documents the device left to the host decoder)"""
+        raw_text = N.as_u8(raw_text)
+        raw_offsets = np.ascontiguousarray(raw_offsets, dtype=np.uint64)
+        nd = raw_offsets.size - 1
+        b = C.c_void_p()
+        N.check(N.lib.tm_batch_create(self._h, int(raw_text.size * 4 + 16 * nd + 1024), max(nd, 1), C.byref(b)))
+        try:
+            N.check(N.lib.tm_batch_upload_raw(b, N.ptr(raw_text), N.ptr(raw_offsets), nd))
+            N.check(N.lib.tm_batch_normalize(b, None))
+            N.check(N.lib.tm_batch_run(b, None))
+            nbytes, host_docs = C.c_uint64(), C.c_uint32()
+            N.check(N.lib.tm_batch_decode(b, 1 if raw else 0, None, C.byref(nbytes), C.byref(host_docs)))
+            ooff = np.zeros(nd + 1, dtype=np.uint64)
+            cap = int(raw_text.size * 2 + 64)
+            while True:
+                out = np.empty(cap, dtype=np.uint8)
+                rc = N.lib.tm_batch_decoded_download(b, N.ptr(out), cap, N.ptr(ooff))
+                if rc == N.TM_E_NOSPACE:
+                    cap = int(ooff[nd])
+                    continue
+                N.check(rc)
+                return out[: int(ooff[nd])], ooff, int(host_docs.value)
+        finally:
+            N.lib.tm_batch_free(b)
+
     def decode(self, ids):
         """one id sequence -> bytes (python/tokenmonster.py:341 decode)"""
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
