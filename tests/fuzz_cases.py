@@ -114,6 +114,11 @@ def one_norm(seed):
     runs of capitals, digits and apostrophes of every length, also across the 64-byte chunks and 1 KiB pieces of the device pass"""
     rng = np.random.default_rng(seed)
     capcode, flag = (2, int(rng.choice([1, 1, 3, 0]))) if rng.random() < 0.85 else (0, int(rng.choice([1, 3])))
+    # (round 6) every other case: any of the 256 flag values - quotemarks 8, collapse 16, trim 32, leadingspace 64, unixlines 128 and accents 4
+    # go through the device's filter pass (tm_norm.hip: k_pf_*) - over text with runs of blanks, CR LF pairs and curly quotes
+    lossy = rng.random() < 0.5
+    if lossy:
+        flag = int(rng.integers(0, 256))
     toks = [bytes([c]) for c in range(256)]
     v = tm.Vocab(synth.build_vocab(toks, capcode=capcode, charset=1, norm_flag=flag))
     docs = []
@@ -126,6 +131,9 @@ def one_norm(seed):
                 parts.append("".join(rng.choice(NORM_ALPHABET[:30] + LATIN, size=int(rng.integers(1, 40)))))
             elif r < 0.22:
                 parts.append("".join(rng.choice(NORM_ALPHABET[:30] + ASTRAL_HANGUL[int(rng.integers(0, 12)):], size=int(rng.integers(1, 40)))))
+            elif lossy and r < 0.5:
+                parts.append("".join(rng.choice([" ", "  ", "   ", "\r\n", "\r", "\n", "\t", "\u2018", "\u2019", "\u201c", "\u201d", "\u2019s", "a", "B", "é", "É", "x ", " y", "\u0301", "ñ", "1"],
+                                                size=int(rng.integers(1, 30)))))
             elif r < 0.35:
                 parts.append("".join(rng.choice(NORM_ALPHABET[:36], size=int(rng.integers(1, 30)))))
             elif r < 0.55:

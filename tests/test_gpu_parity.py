@@ -435,25 +435,44 @@ def test_match_kernel_stages_the_text_from_the_normalizer_slabs():
     assert nfb == 0 and (goff == eoff).all() and (gtext == etext).all()
 
 
-def test_lossy_normalizer_flags_take_the_host_path_inside_the_device_call():
-    """a vocabulary with accents / quotemarks / collapse / trim / leadingspace / unixlines (training/README.md:110-123): the device
-    normalizer implements NFD and lowercase only, so tm_batch_normalize sends every document through the host normalizer (same
-    call, same outputs) and the raw-text entry points keep working"""
-    for flag in (1 | 8 | 16 | 32 | 128, 2 | 4 | 64):
-        img = synth.synth_vocab(synth.ENGLISHCODE, 1500, capcode=2, norm_flag=1, level=3, seed=3)
-        img = bytes(img[:2]) + bytes([flag]) + bytes(img[3:])
-        v, orc = tm.Vocab(img), Oracle(img)
-        docs = [b"  Hello   World \r\n", "\u201cQuoted\u201d  caf\u00e9  \u2018x\u2019 ".encode(), b"", b"a", b" \t ", b"No leading blank  here"]
-        raw, roffs = synth.synth_corpus(synth.ENGLISHCODE, 100_000, seed=5)
-        docs += [raw[int(roffs[d]):int(roffs[d + 1])].tobytes() for d in range(roffs.size - 1)]
-        text, offs = tm.pack_documents(docs)
-        got, goff, nfb = v.normalize_packed_device(text, offs)
-        assert nfb == len(docs)
-        for d, doc in enumerate(docs):
-            assert got[int(goff[d]):int(goff[d + 1])].tobytes() == synth.normalize(doc, 2, flag)
-        ids = v.tokenize(docs)
-        for d, doc in enumerate(docs):
-            assert ids[d].tolist() == orc.tokenize(synth.normalize(doc, 2, flag))[0].tolist()
+def test_lossy_normalizer_flags_run_on_the_device():
+    """a vocabulary with accents / quotemarks / collapse / trim / leadingspace / unixlines (training/README.md:110-123; the reference's own
+    example is -norm "lowercase collapse trim quotemarks unixlines"): since round 6 a filter pass in front of the normalizer pass does
+    these on the device too (tm_norm.hip: k_pf_*), quirks of the reference's in-place loops included - NO document of ASCII + Latin text
+    goes to the host normalizer, for every one of the 256 flag values, and the bytes are the host normalizer's (= the reference runtime's:
+    tests/test_builder_normalizer.py)."""
+    docs = [b"  Hello   World \r\n", "\u201cQuoted\u201d  caf\u00e9  \u2018x\u2019 ".encode(), b"", b"a", b" \t ", b"No leading blank  here", b"\r\n", b"ab",
+            "a  \u2018b\u2019 c  \u201cd\u201d e".encode(), "x \u2019y  z \u2019w".encode(), "\u2019".encode(), "\u00c9a  \u00f1 \u00fc na\u00efve".encode(), b"  ",
+            b"one  two \r\n three\r\n\r\n  four  ", ("Title Case  And  CAPS \u2018q\u2019 \r\n" * 40).encode()]
+    raw, roffs = synth.synth_corpus(synth.ENGLISHCODE, 60_000, seed=5)
+    docs += [raw[int(roffs[d]):int(roffs[d + 1])].tobytes() for d in range(roffs.size - 1)]
+    text, offs = tm.pack_documents(docs)
+    toks = [bytes([c]) for c in range(256)]
+    for flag in range(256):
+        for capcode in ((2, 0) if flag % 16 == 9 or flag in (255, 254, 4, 6) else (2,)):
+            v = tm.Vocab(synth.build_vocab(toks, capcode=capcode, charset=1, norm_flag=flag))
+            got, goff, nfb = v.normalize_packed_device(text, offs)
+            # (without capcode the normalizer pass keeps lengths: a character that decomposes is the host's; trim + leadingspace cut the last
+            # non-blank BYTE of a text without leading blanks, tokenmonster.cpp:274-277 - half a character in four of these documents: malformed, the host's)
+            assert nfb == 0 or capcode == 0 or ((flag & 96) == 96 and nfb <= 4), (flag, capcode, nfb)
+            exp, eoff = synth.normalize_batch(text, offs, capcode, flag)
+            assert (goff == eoff).all() and got.tobytes() == exp.tobytes(), (flag, capcode)
+    # ... and the ids of a real vocabulary with the reference's example flags (lowercase collapse trim quotemarks unixlines)
+    flag = 2 | 8 | 16 | 32 | 128
+    img = synth.synth_vocab(synth.ENGLISHCODE, 1500, capcode=2, norm_flag=1, level=3, seed=3)
+    img = bytes(img[:2]) + bytes([flag]) + bytes(img[3:])
+    v, orc = tm.Vocab(img), Oracle(img)
+    ids = v.tokenize(docs)
+    for d, doc in enumerate(docs):
+        assert ids[d].tolist() == orc.tokenize(synth.normalize(doc, 2, flag))[0].tolist()
+    # what the filter pass leaves to the host: a three-byte mark under `accents` (the document is normalized from its ORIGINAL bytes)
+    v = tm.Vocab(synth.build_vocab(toks, capcode=2, charset=1, norm_flag=4 | 16 | 32 | 64))
+    odd = ["  a\u20dd  b ".encode(), b"  plain  text ", "e\u0301\ufe0f  x".encode()]
+    t2, o2 = tm.pack_documents(odd)
+    got, goff, nfb = v.normalize_packed_device(t2, o2)
+    assert nfb == 2
+    for d, doc in enumerate(odd):
+        assert got[int(goff[d]):int(goff[d + 1])].tobytes() == synth.normalize(doc, 2, 4 | 16 | 32 | 64)
 
 
 def _utf16(bs):

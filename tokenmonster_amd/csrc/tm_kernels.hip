@@ -2547,7 +2547,7 @@ void tm_batch_free(tm_batch* b) {
                   b->d_seg_tokbase, b->d_seg_par, b->d_doc_ntok, b->d_doc_events, b->d_doc_missing, b->d_doc_fd, b->d_tok_offsets, b->d_scan_tmp, b->d_totals,
                   b->d_out, b->d_groups, b->d_longs, b->d_gmap, b->d_group_entry, b->d_group_base,
                   b->d_raw, b->d_slab, b->d_raw_off, b->d_doc_npiece, b->d_doc_piece_start, b->d_piece_doc, b->d_piece_sum, b->d_piece_carry, b->d_piece_len,
-                  b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids, b->d_two, b->d_ctl_store, b->d_dec_a, b->d_dec_b};
+                  b->d_piece_off, b->d_need_host, b->d_nbegin, b->d_nend, b->d_ninfo, b->d_fb_roff, b->d_fb_noff, b->d_fb_ids, b->d_two, b->d_ctl_store, b->d_dec_a, b->d_dec_b, b->d_rawf, b->d_rawf_off, b->d_pf_piece, b->d_pf_doc, b->d_acc};
   for (void* p : ptrs) (void)hipFree(p);
   if (b->have_events) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
   if (b->aux_stream) (void)hipStreamDestroy(b->aux_stream);

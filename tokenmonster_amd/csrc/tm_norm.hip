@@ -641,6 +641,174 @@ __global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t*
   for (int o = 32; o > 0; o >>= 1) nseg += __shfl_xor(nseg, o);
   if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&ninfo[2], (unsigned long long)nseg);
 }
+// ---- the filter pass in front of the normalizer pass (round 6): the flags that drop and replace BYTES ------------------------------------------
+// quotemarks 8, collapse 16, trim 32, leadingspace 64, unixlines 128 (training/README.md:110-123; tokenmonster.cpp:245-425, 428-462) and what
+// accents 4 (:231-243) does to the two-byte characters, on the device: raw text in, filtered text + new document offsets out, and the
+// normalizer pass (NFD / lowercase / capcode) runs on that.  The host form is tm_normalize.cpp (squeeze, unix_lines, trim_and_lead,
+// remove_marks), fuzzed against the reference runtime for all 256 flag values; this is the same function of the text, stated per byte:
+//   * a space goes when the byte before it in the INPUT is a space; a '\r' goes when a '\n' follows; E2 80 {98,99 | 9C,9D} becomes ' or " -
+//     all local - EXCEPT that the reference compacts in place and looks for the E2 80 in the buffer it is compacting: after exactly ONE
+//     byte has been dropped (and until the next one is) the look-behind finds a byte that was already moved, and the quote stays.  The
+//     offset by which the text has shrunk only grows - one for a dropped byte, two for a replaced quote - so it equals one exactly between the
+//     first single drop of a document and the second, provided no quote was replaced before the first: three numbers per document
+//     (first and second single drop, first quote candidate), found per piece (k_pf_summary) and combined per document (k_pf_doc).
+//     (unixlines WITHOUT collapse is a pass of its own in the reference, into a fresh buffer: no single drops in the loop that follows.)
+//   * trim keeps what lies between the first and the last byte above 32, leadingspace puts a space in front of a first byte that is not
+//     one; together, on a text WITHOUT leading blanks, the reference also cuts the last non-blank byte (:274-277) - kept.
+//   * accents: a two-byte character becomes what NFD-and-drop-Mn leaves of it (nothing, one byte, two bytes: a table from the host's own
+//     function, build_accent_table); whatever else would decompose or is a mark reaches the normalizer pass, whose tables in this mode
+//     refuse it (norm_tables): that document is normalized by the host from its ORIGINAL bytes.
+constexpr uint32_t PF_NONE = 0xFFFFFFFFu;
+struct PfPiece { uint32_t s1, s2, fq, a, z; };      // positions in the document: first / second single drop, first quote candidate (its third byte), first / last byte above 32
+struct PfDoc { uint32_t s1, s2, qb, a, z, zlo; };   // qb: a quote candidate lies before s1; zlo: where the last non-blank OUTPUT byte begins (z, or z - 2 for a replaced quote)
+__device__ __forceinline__ bool pf_isq(uint32_t y) { return y == 0x98u || y == 0x99u || y == 0x9Cu || y == 0x9Du; }
+// the bytes around position base + lane of a document of n bytes at `doc` (0 outside it), for all 64 lanes of a chunk at once: every lane
+// loads its own byte, the two before it and the two behind it come from the neighbouring lanes, and the four bytes either side of the chunk
+// are fetched by the first four lanes (five byte loads per lane were most of what these kernels did)
+struct PfWin { uint32_t p2, p1, x, n1, n2; };
+__device__ __forceinline__ PfWin pf_window(const uint8_t* __restrict__ doc, uint32_t base, int lane, uint32_t n) {
+  const uint32_t i = base + (uint32_t)lane;
+  const uint32_t x = i < n ? doc[i] : 0u;
+  uint32_t edge = 0u;
+  if (lane < 4) {
+    const long long j = lane < 2 ? (long long)base - 2 + lane : (long long)base + 62 + lane;      // base - 2, base - 1, base + 64, base + 65
+    if (j >= 0 && j < (long long)n) edge = doc[j];
+  }
+  const uint32_t em2 = (uint32_t)__shfl((int)edge, 0), em1 = (uint32_t)__shfl((int)edge, 1), ep0 = (uint32_t)__shfl((int)edge, 2), ep1 = (uint32_t)__shfl((int)edge, 3);
+  const uint32_t l1 = (uint32_t)__shfl((int)x, (lane + 63) & 63), l2 = (uint32_t)__shfl((int)x, (lane + 62) & 63);
+  const uint32_t r1 = (uint32_t)__shfl((int)x, (lane + 1) & 63), r2 = (uint32_t)__shfl((int)x, (lane + 2) & 63);
+  PfWin w;
+  w.x = x;
+  w.p1 = lane >= 1 ? l1 : em1;
+  w.p2 = lane >= 2 ? l2 : (lane == 1 ? em1 : em2);
+  w.n1 = lane <= 62 ? r1 : ep0;
+  w.n2 = lane <= 61 ? r2 : (lane == 62 ? ep0 : ep1);
+  return w;
+}
+// is the quote whose third byte lies at t left alone (the in-place quirk above)?
+__device__ __forceinline__ bool pf_suppressed(uint32_t flags, const PfDoc& d, uint32_t t) {
+  return (flags & 16u) && d.s1 < t && t < d.s2 && d.qb == 0u;      // (d.s2 == PF_NONE: no second drop)
+}
+__global__ __launch_bounds__(256) void k_pf_summary(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ piece_doc,
+                                                    const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t flags, PfPiece* __restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t k = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (k >= npieces) return;
+  const uint32_t d = piece_doc[k];
+  const uint64_t db = raw_off[d];
+  const uint32_t n = (uint32_t)(raw_off[d + 1] - db), p0 = (uint32_t)(k - doc_piece_start[d]) * (uint32_t)PIECE, p1e = min(n, p0 + (uint32_t)PIECE);
+  const uint8_t* doc = raw + db;
+  const bool q = flags & 8u, c = flags & 16u, fused = (flags & 16u) && (flags & 128u);
+  PfPiece r{PF_NONE, PF_NONE, PF_NONE, PF_NONE, PF_NONE};
+  for (uint32_t base = p0; base < p1e; base += 64u) {
+    const uint32_t i = base + lane;
+    const bool valid = i < p1e;
+    const PfWin w = pf_window(doc, base, (int)lane, n);
+    const bool single = valid && i > 0u && ((c && w.x == ' ' && w.p1 == ' ') || (fused && w.x == '\n' && w.p1 == '\r'));
+    const bool cand = valid && q && i > 1u && pf_isq(w.x) && w.p1 == 0x80u && w.p2 == 0xE2u;
+    unsigned long long mS = __ballot(single);
+    const unsigned long long mQ = __ballot(cand), mN = __ballot(valid && w.x > 32u);
+    if (mS && r.s1 == PF_NONE) { r.s1 = base + (uint32_t)__builtin_ctzll(mS); mS &= mS - 1ull; }
+    if (mS && r.s2 == PF_NONE) r.s2 = base + (uint32_t)__builtin_ctzll(mS);
+    if (mQ && r.fq == PF_NONE) r.fq = base + (uint32_t)__builtin_ctzll(mQ);
+    if (mN) { if (r.a == PF_NONE) r.a = base + (uint32_t)__builtin_ctzll(mN); r.z = base + 63u - (uint32_t)__builtin_clzll(mN); }
+  }
+  if (lane == 0) out[k] = r;
+}
+__global__ void k_pf_doc(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint64_t* __restrict__ doc_piece_start, uint32_t ndocs, uint32_t flags,
+                         const PfPiece* __restrict__ pieces, PfDoc* __restrict__ out) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= ndocs) return;
+  PfDoc r{PF_NONE, PF_NONE, 0u, PF_NONE, PF_NONE, PF_NONE};
+  uint32_t fq = PF_NONE;
+  for (uint64_t k = doc_piece_start[d]; k < doc_piece_start[d + 1]; k++) {
+    const PfPiece p = pieces[k];
+    if (r.s1 == PF_NONE) { r.s1 = p.s1; r.s2 = p.s2; } else if (r.s2 == PF_NONE) r.s2 = p.s1;
+    if (fq == PF_NONE) fq = p.fq;
+    if (r.a == PF_NONE) r.a = p.a;
+    if (p.z != PF_NONE) r.z = p.z;
+  }
+  r.qb = fq < r.s1 ? 1u : 0u;
+  r.zlo = r.z;
+  if (r.z != PF_NONE && (flags & 8u) && r.z >= 2u) {        // the last non-blank byte is the end of a quote that is replaced: the output byte begins two bytes earlier
+    const uint8_t* doc = raw + raw_off[d];
+    if (pf_isq(doc[r.z]) && doc[r.z - 1u] == 0x80u && doc[r.z - 2u] == 0xE2u && !pf_suppressed(flags, r, r.z)) r.zlo = r.z - 2u;
+  }
+  out[d] = r;
+}
+// what position i of the document emits: *pre - a space in front (leadingspace); returns 0 or 1 and *o, the byte
+__device__ __forceinline__ uint32_t pf_decide(uint32_t flags, const PfDoc& dd, const PfWin& w, uint32_t i, uint32_t n, const uint32_t* __restrict__ acc, uint32_t* pre, uint32_t* o) {
+  *pre = 0u; *o = w.x;
+  const bool q = flags & 8u, c = flags & 16u, u = flags & 128u, trim = flags & 32u, lead = flags & 64u, accents = flags & 4u;
+  // trim / leadingspace: the positions that stay at all, and the one that gets the space
+  uint32_t lo = 0u, hi = n;                                  // [lo, hi) stays
+  bool space_at_lo = false;
+  if (trim) {
+    if (dd.a == PF_NONE) return 0u;                          // blank from end to end: nothing is left
+    if (lead && dd.a == 0u) { if (dd.zlo == 0u) return 0u; hi = dd.zlo; space_at_lo = true; }      // (:274-277: the last non-blank byte goes as well)
+    else { lo = dd.a; hi = dd.z + 1u; space_at_lo = lead; }
+  } else if (lead) space_at_lo = n > 0u;                     // (decided at position 0 below: only in front of a byte that is no space)
+  if (i < lo || i >= hi) return 0u;
+  if (i == lo && space_at_lo && !(lo == 0u && !trim && w.x == ' ')) *pre = 1u;
+  if (c && w.x == ' ' && i > 0u && w.p1 == ' ') return 0u;
+  if (u && w.x == '\r' && i + 1u < n && w.n1 == '\n') return 0u;
+  if (q) {
+    if (w.x == 0xE2u && w.n1 == 0x80u && i + 2u < n && pf_isq(w.n2)) { if (!pf_suppressed(flags, dd, i + 2u)) { *o = w.n2 < 0x9Cu ? '\'' : '"'; return 1u; } }
+    else if (w.x == 0x80u && i >= 1u && w.p1 == 0xE2u && i + 1u < n && pf_isq(w.n1)) { if (!pf_suppressed(flags, dd, i + 1u)) return 0u; }
+    else if (i >= 2u && pf_isq(w.x) && w.p1 == 0x80u && w.p2 == 0xE2u) { if (!pf_suppressed(flags, dd, i)) return 0u; }
+  }
+  if (accents) {
+    // (both halves of the character must have stayed: the cut of trim + leadingspace may have taken the second)
+    if (nm_two_lead(w.x) && i + 1u < hi && nm_cont_byte(w.n1)) {
+      const uint32_t e = acc[nm_two_index(w.x, w.n1)];
+      if ((e & 3u) == 1u) return 0u;
+      if ((e & 3u) >= 2u) *o = (e >> 8) & 0xFFu;
+    } else if (nm_cont_byte(w.x) && i >= lo + 1u && nm_two_lead(w.p1)) {
+      const uint32_t e = acc[nm_two_index(w.p1, w.x)];
+      if ((e & 3u) == 1u || (e & 3u) == 2u) return 0u;
+      if ((e & 3u) == 3u) *o = (e >> 16) & 0xFFu;
+    }
+  }
+  return 1u;
+}
+// EMIT == false: bytes a piece leaves (piece_len); EMIT == true: the bytes themselves, at piece_off
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_pf_pass(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ piece_doc,
+                                                 const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t flags, const PfDoc* __restrict__ docs,
+                                                 const uint32_t* __restrict__ acc, uint32_t* __restrict__ piece_len, const uint64_t* __restrict__ piece_off, uint8_t* __restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t k = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (k >= npieces) return;
+  const uint32_t d = piece_doc[k];
+  const uint64_t db = raw_off[d];
+  const uint32_t n = (uint32_t)(raw_off[d + 1] - db), p0 = (uint32_t)(k - doc_piece_start[d]) * (uint32_t)PIECE, p1e = min(n, p0 + (uint32_t)PIECE);
+  const uint8_t* doc = raw + db;
+  const PfDoc dd = docs[d];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint64_t o = EMIT ? piece_off[k] : 0ull;
+  uint32_t total = 0;
+  for (uint32_t base = p0; base < p1e; base += 64u) {
+    const uint32_t i = base + lane;
+    const bool valid = i < p1e;
+    uint32_t pre = 0, byte = 0, keep = 0;
+    const PfWin w = pf_window(doc, base, (int)lane, n);
+    if (valid) keep = pf_decide(flags, dd, w, i, n, acc, &pre, &byte);
+    const unsigned long long mP = __ballot(pre != 0u), mK = __ballot(keep != 0u);
+    if (EMIT) {
+      const uint64_t at = o + (uint64_t)__popcll(mP & below) + (uint64_t)__popcll(mK & below);
+      if (pre) out[at] = ' ';
+      if (keep) out[at + pre] = (uint8_t)byte;
+      o += (uint64_t)__popcll(mP) + (uint64_t)__popcll(mK);
+    } else total += (uint32_t)__popcll(mP) + (uint32_t)__popcll(mK);
+  }
+  if (!EMIT && lane == 0) piece_len[k] = total;
+}
+// the filtered documents' offsets: a document begins where its first piece does (an empty document has none: where the next one's does)
+__global__ void k_pf_offsets(const uint64_t* __restrict__ piece_off, const uint64_t* __restrict__ doc_piece_start, uint32_t ndocs, uint64_t* __restrict__ new_off) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d <= ndocs) new_off[d] = piece_off[doc_piece_start[d]];
+}
+
 // One side of these two copies is pinned HOST memory, reached over PCIe: that side is accessed in aligned 16-byte units (a byte
 // per lane made a 64-byte request per wavefront), the device side at whatever alignment is left.
 template <bool DST_IS_HOST>
@@ -679,11 +847,16 @@ __global__ void k_place_fallback(const uint8_t* __restrict__ staging, const uint
 namespace {
 // the normalizer's tables for {NFD, lowercase} x {capcode 2 or not}, built once per process from the host normalizer's functions (a few
 // milliseconds of ICU calls: every lane's workspace uploads its own copy)
+// flags: NFD 1, lowercase 2, accents 4.  `accents` (which implies NFD) strips the marks in the filter pass in front of the normalizer pass;
+// what that pass does not handle - a two-byte character that would still decompose or is a non-spacing mark cannot reach this one, a
+// three-byte mark can - has no entry here, so that its document goes to the host normalizer (with its original bytes).
 const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
   static std::mutex mu;
-  static std::vector<uint8_t> cache[8];
+  static std::vector<uint8_t> cache[16];
   std::lock_guard<std::mutex> g(mu);
-  std::vector<uint8_t>& t = cache[(flags & 3u) | (capcode2 ? 4u : 0u)];
+  const bool accents = (flags & 4u) != 0;
+  if (accents) flags |= 1u;
+  std::vector<uint8_t>& t = cache[(flags & 7u) | (capcode2 ? 8u : 0u)];
   if (t.empty()) {
     t.resize(NM_TABLE_BYTES);
     NmTwo* two = reinterpret_cast<NmTwo*>(t.data());
@@ -693,6 +866,13 @@ const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
     build_three_tables(flags & 3u, blk, blk + NM_BLK_WORDS);
     build_four_table(flags & 3u, blk + NM_BLK_WORDS + NM_CP_WORDS);
     blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] = (capcode2 && (flags & 1u)) ? NM_MISC_HANGUL : 0u;      // NFD of the Hangul syllables: by arithmetic, where the pass may change lengths
+    if (accents) {
+      std::vector<uint32_t> acc(NM_TWO_SIZE);
+      build_accent_table(acc.data());
+      for (int k = 0; k < NM_TWO_SIZE; k++) if ((acc[k] & 3u) != 0u || (two[k].a & (NT_DECOMP | NT_DECOMP2))) two[k].a = 0;      // (the filter pass has dealt with the first kind; a decomposition whose mark stays is rare enough for the host)
+      uint32_t* cpt = blk + NM_BLK_WORDS;
+      for (int w = 0; w < NM_CP_WORDS; w++) for (int j = 0; j < 16; j++) if (((cpt[w] >> (2 * j)) & 3u) == 3u) cpt[w] &= ~(3u << (2 * j));      // three-byte marks (a variation selector is Mn): the host
+    }
   }
   return t;
 }
@@ -724,9 +904,10 @@ int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_off
   const uint64_t nbytes = ndocs ? raw_offsets[ndocs] : 0;
   if (ndocs && raw_offsets[0] != 0) return set_error(TM_E_INVALID, "offsets[0] must be 0");
   uint64_t npieces = 0;
+  const uint64_t grows = (b->vocab->host.norm_flag & 64u) ? 1u : 0u;       // leadingspace: the filter pass may put a byte in front of a document
   for (uint32_t d = 0; d < ndocs; d++) {
     if (raw_offsets[d + 1] < raw_offsets[d]) return set_error(TM_E_INVALID, "offsets not monotone at document %u", d);
-    npieces += (raw_offsets[d + 1] - raw_offsets[d] + PIECE - 1) / PIECE;
+    npieces += (raw_offsets[d + 1] - raw_offsets[d] + grows + PIECE - 1) / PIECE;
   }
   { int rc = raw_prepare(b, nbytes, ndocs, npieces, st); if (rc != TM_OK) return rc; }
   hipError_t e;
@@ -764,7 +945,7 @@ int raw_prepare(tm_batch* b, uint64_t nbytes, uint32_t ndocs, uint64_t npieces, 
   if (!b->d_two) {
     // what the vocabulary's flags {NFD, lowercase} do to the two-byte characters U+0080..U+017F, from the host normalizer's own building blocks
     if ((e = hipMalloc((void**)&b->d_two, NM_TABLE_BYTES)) != hipSuccess) return hip_fail(e, "hipMalloc");
-    const std::vector<uint8_t>& tab = norm_tables(b->vocab->host.norm_flag & 3u, b->vocab->host.capcode == 2);
+    const std::vector<uint8_t>& tab = norm_tables(b->vocab->host.norm_flag & 7u, b->vocab->host.capcode == 2);
     int rc = small_h2d(b, b->d_two, tab.data(), NM_TABLE_BYTES, st);
     if (rc != TM_OK) return rc;
   }
@@ -791,7 +972,8 @@ int raw_prepare(tm_batch* b, uint64_t nbytes, uint32_t ndocs, uint64_t npieces, 
 bool raw_upload_replaces_buffers(const tm_batch* b, const uint64_t* raw_offsets, uint32_t ndocs) {
   if (!b || !b->d_raw_off || !b->d_piece_doc) return true;
   uint64_t npieces = 0;
-  for (uint32_t d = 0; d < ndocs; d++) npieces += (raw_offsets[d + 1] - raw_offsets[d] + PIECE - 1) / PIECE;
+  const uint64_t grows = (b->vocab->host.norm_flag & 64u) ? 1u : 0u;       // (as batch_upload_raw_on counts them)
+  for (uint32_t d = 0; d < ndocs; d++) npieces += (raw_offsets[d + 1] - raw_offsets[d] + grows + PIECE - 1) / PIECE;
   return (uint64_t)ndocs + 2 > b->raw_docs_cap || npieces + 2 > b->piece_cap || (npieces + 1) * (uint64_t)SLAB > b->slab_cap;
 }
 
@@ -830,6 +1012,63 @@ static uint32_t norm_grid() {
   return slot;
 }
 
+// The filter pass (k_pf_*, above) on the uploaded text: *R / *RO = the filtered text and its documents' offsets (device), *np = its pieces.
+// One trip to the host of its own (the new offsets: the normalizer pass is launched over the pieces they make).
+static int prefilter(tm_batch* b, hipStream_t st, uint32_t norm_flag, const uint8_t** R, const uint64_t** RO, uint64_t* np_out) {
+  const uint32_t nd = b->raw_docs;
+  hipError_t e;
+  uint64_t np0 = 0;
+  for (uint32_t d = 0; d < nd; d++) {
+    const uint64_t len = b->h_raw_off[d + 1] - b->h_raw_off[d];
+    if (len >= 0xFFFFFFF0ull) return set_error(TM_E_LIMIT, "document %u has %llu bytes: beyond what the filter pass addresses", d, (unsigned long long)len);
+    np0 += (len + PIECE - 1) / PIECE;
+  }
+  const uint64_t out_cap = b->raw_bytes + nd + 256;
+  if ((e = grow(&b->d_rawf, &b->rawf_cap, out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc (filtered text)");
+  if (!b->d_rawf_off || b->rawf_docs_cap < (uint64_t)nd + 2) {
+    (void)hipFree(b->d_rawf_off); (void)hipFree(b->d_pf_doc);
+    b->d_rawf_off = nullptr; b->d_pf_doc = nullptr;
+    b->rawf_docs_cap = (uint64_t)nd + nd / 4 + 16;
+    if ((e = hipMalloc((void**)&b->d_rawf_off, b->rawf_docs_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_pf_doc, b->rawf_docs_cap * sizeof(PfDoc))) != hipSuccess)
+      return hip_fail(e, "hipMalloc (filtered documents)");
+  }
+  { uint8_t* pp = (uint8_t*)b->d_pf_piece; uint64_t cap = b->pf_piece_cap;
+    if ((e = grow(&pp, &cap, (np0 + 1) * sizeof(PfPiece))) != hipSuccess) return hip_fail(e, "hipMalloc (filter pass)");
+    b->d_pf_piece = pp; b->pf_piece_cap = cap; }
+  if ((norm_flag & 4u) && !b->d_acc) {
+    std::vector<uint32_t> acc(NM_TWO_SIZE);
+    build_accent_table(acc.data());
+    if ((e = hipMalloc((void**)&b->d_acc, acc.size() * 4)) != hipSuccess) return hip_fail(e, "hipMalloc");
+    int rc = small_h2d(b, b->d_acc, acc.data(), acc.size() * 4, st);
+    if (rc != TM_OK) return rc;
+  }
+  unsigned long long* ninfo = (unsigned long long*)b->d_ninfo;
+  // the pieces of the ORIGINAL documents
+  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, b->d_raw_off, nd, b->d_doc_npiece, b->d_need_host, ninfo);
+  scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
+  if (np0 > 0) {
+    launch_unit_owner(b->d_doc_piece_start, nd, np0, b->d_piece_doc, st);
+    const uint32_t pgrid = (uint32_t)((np0 + 3) / 4);
+    PfPiece* pieces = (PfPiece*)b->d_pf_piece;
+    PfDoc* docs = (PfDoc*)b->d_pf_doc;
+    TM_LAUNCH(k_pf_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_piece_doc, b->d_doc_piece_start, np0, norm_flag, pieces);
+    TM_LAUNCH(k_pf_doc, (nd + 255) / 256, 256, 0, st, b->d_raw, b->d_raw_off, b->d_doc_piece_start, nd, norm_flag, pieces, docs);
+    TM_LAUNCH(k_pf_pass<false>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_piece_doc, b->d_doc_piece_start, np0, norm_flag, docs, b->d_acc, b->d_piece_len, nullptr, nullptr);
+    scan_u32(b->d_piece_len, np0, b->d_scan_tmp, b->d_totals + 3, b->d_piece_off, st);
+    TM_LAUNCH(k_pf_pass<true>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_piece_doc, b->d_doc_piece_start, np0, norm_flag, docs, b->d_acc, nullptr, b->d_piece_off, b->d_rawf);
+    TM_LAUNCH(k_pf_offsets, (nd + 256) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, nd, b->d_rawf_off);
+  } else (void)hipMemsetAsync(b->d_rawf_off, 0, ((size_t)nd + 1) * 8, st);
+  // the filtered documents' offsets, for the pieces the normalizer pass is launched over
+  std::vector<uint64_t> off((size_t)nd + 1);
+  if ((e = hipMemcpyAsync(off.data(), b->d_rawf_off, off.size() * 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "D2H filtered offsets");
+  uint64_t np = 0;
+  for (uint32_t d = 0; d < nd; d++) np += (off[d + 1] - off[d] + PIECE - 1) / PIECE;
+  if (np + 2 > b->piece_cap || (np + 1) * (uint64_t)SLAB > b->slab_cap * sizeof(b->d_slab[0]) || off[nd] > out_cap)
+    return set_error(TM_E_INTERNAL, "the filter pass left %llu pieces / %llu bytes, the workspace holds %llu pieces", (unsigned long long)np, (unsigned long long)off[nd], (unsigned long long)b->piece_cap);
+  *R = b->d_rawf; *RO = b->d_rawf_off; *np_out = np;
+  return TM_OK;
+}
+
 int tm_batch_normalize(tm_batch* b, void* stream) {
   if (!b) return set_error(TM_E_INVALID, "null argument");
   const tm_vocab* v = b->vocab;
@@ -839,8 +1078,14 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     return set_error(TM_E_INVALID, "normalization flags %u / capcode %u not supported by the normalizer", norm_flag, capcode);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t nd = b->raw_docs;
-  const uint64_t np = b->raw_pieces;
+  uint64_t np = b->raw_pieces;
   hipError_t e;
+  const uint8_t* R = b->d_raw;                 // the text the normalizer pass reads, and its documents: the upload's, or what the filter pass makes of it
+  const uint64_t* RO = b->d_raw_off;
+  if ((norm_flag & ~3u) && nd > 0 && (capcode == 0 || capcode == 2)) {
+    int rc = prefilter(b, st, norm_flag, &R, &RO, &np);
+    if (rc != TM_OK) return rc;
+  }
   b->host_fallback_docs = 0;
   b->d_doc_begin = b->d_nbegin;
   b->d_doc_end = b->d_nend;
@@ -854,7 +1099,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   const uint32_t lower_all = (norm_flag & 2u) ? 1u : 0u;
   unsigned long long* ninfo = (unsigned long long*)b->d_ninfo;
   // piece table
-  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, b->d_raw_off, nd, b->d_doc_npiece, b->d_need_host, ninfo);
+  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, RO, nd, b->d_doc_npiece, b->d_need_host, ninfo);
   scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
   const uint32_t pgrid = (uint32_t)((np + 3) / 4);
   const uint32_t egrid = std::min(pgrid, norm_grid());       // k_norm_emit2: its wavefronts take piece after piece
@@ -874,10 +1119,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   uint64_t pre_bytes = 0;
   if (fast) {
     if (capcode == 2)
-      TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
+      TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
                                                  b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
     else
-      TM_LAUNCH(k_norm_emit<3>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+      TM_LAUNCH(k_norm_emit<3>, pgrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                             nullptr, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
     TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
     scan_u32(b->d_piece_len, np, b->d_scan_tmp, reinterpret_cast<uint64_t*>(ninfo + 5), b->d_piece_off, st);      // (the total lands beside the info words: one copy brings everything)
@@ -913,9 +1158,9 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     }
   }
   if (!fast) {
-    if (np > 0) TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_two, b->d_piece_sum);
+    if (np > 0) TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_two, b->d_piece_sum);
     TM_LAUNCH(k_norm_carry, (nd + 255) / 256, 256, 0, st, b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids,
-                                                    normalize_on_device(capcode, norm_flag) ? 0u : 1u);
+                                                    0u);
     int rc = small_d2h(b, h_info, ninfo, 8, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc;
   }
   const double t1 = now();
@@ -925,10 +1170,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   double f1 = now(), f2 = 0, f3 = 0, f4 = 0;
   // the exact path: the device normalizes its documents with the carries given (one pass into per-piece slabs, lengths on the side) ...
   if (!fast && np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
-    TM_LAUNCH(k_norm_emit2<true>, egrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
+    TM_LAUNCH(k_norm_emit2<true>, egrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
                                               b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
   else if (!fast && np > 0)           // capcode 0, or debug bit 8: the per-lane version of the rules
-    TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+    TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                           b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
   if (!pre) scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
   if (!pre && np > 0 && nf == 0) TM_LAUNCH(k_norm_short, (uint32_t)((np + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, b->d_piece_len, ninfo);
@@ -1001,7 +1246,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
       if (nf > 0 || h_info[6] != 0 || (tm_debug_flags(-1) & 2048)) pack_text(b, st);
     } else {
       // some piece expands beyond its slab (long runs of capitals): exact two-pass path
-      TM_LAUNCH(k_norm_emit<1>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+      TM_LAUNCH(k_norm_emit<1>, pgrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                             b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text, nullptr, b->d_two);
     }
   }
@@ -1037,7 +1282,8 @@ namespace tmh {
 // The host-to-host ring takes a vocabulary whose normalizer pass is the one-pass form (capcode 0 or 2 with flags the device implements)
 bool ring_supported(const tm_vocab* v) {
   const uint32_t capcode = v->host.capcode, norm_flag = v->host.norm_flag;
-  return normalize_supported(capcode, norm_flag) && (capcode == 2 || capcode == 0) && normalize_on_device(capcode, norm_flag) && !(tm_debug_flags(-1) & (256 | 2048));
+  // (a vocabulary with byte-level flags has a filter pass with a trip to the host of its own in front: the lanes' form)
+  return normalize_supported(capcode, norm_flag) && (capcode == 2 || capcode == 0) && (norm_flag & ~3u) == 0 && !(tm_debug_flags(-1) & (256 | 2048));
 }
 // tm_batch_normalize's usual path - ONE pass over the raw text that raw_prepare + the upload have put into the workspace - enqueued on `st`
 // and NOT waited for: what the host would read back stays in d_ninfo, k_chunk_ctl turns it into the control words the kernels behind it

@@ -542,7 +542,8 @@ void build_dec_tables(uint32_t* two, uint32_t* blk, uint32_t* cpt, uint32_t* blk
 // capcode level 1 has no statement in the reference tree: refused rather than guessed
 bool normalize_supported(uint32_t capcode, uint32_t norm_flag) { return (capcode == 0 || capcode == 2) && norm_flag < 256; }
 // what the DEVICE normalizer (tm_norm.hip) does itself; documents of vocabularies with further flags take the host path below
-bool normalize_on_device(uint32_t capcode, uint32_t norm_flag) { return (capcode == 0 || capcode == 2) && (norm_flag & ~3u) == 0; }
+// (round 6: every flag - the byte-level ones and `accents` in a filter pass in front of it, k_pf_pass)
+bool normalize_on_device(uint32_t capcode, uint32_t norm_flag) { return (capcode == 0 || capcode == 2) && norm_flag < 256; }
 
 namespace {
 
@@ -611,6 +612,24 @@ void remove_marks(std::vector<uint8_t>& b) {
 }
 
 }  // namespace
+
+// What flag 4 `accents` (NFD, then every non-spacing mark goes) leaves of the two-byte characters U+0080..U+07FF, for the device's filter pass
+// (tm_norm.hip: k_pf_pass), from the function the host path uses: kind [0..1] - 0 the character stays as it is, 1 nothing is left of it (a
+// non-spacing mark), 2 one byte, 3 two other bytes - | first byte << 8 | second byte << 16.  A character that leaves more than two bytes
+// stays (kind 0): the normalizer pass behind the filter then finds something it may not decompose in this mode and hands the document to the host.
+void build_accent_table(uint32_t* out) {
+  for (int k = 0; k < NM_TWO_SIZE; k++) out[k] = 0;
+  for (uint32_t cp = 0x80; cp < 0x800; cp++) {
+    const uint32_t lead = 0xC0u | (cp >> 6), second = 0x80u | (cp & 0x3Fu);
+    std::vector<uint8_t> t = {(uint8_t)lead, (uint8_t)second};
+    remove_marks(t);
+    uint32_t e = 0;
+    if (t.empty()) e = 1u;
+    else if (t.size() == 1) e = 2u | ((uint32_t)t[0] << 8);
+    else if (t.size() == 2 && (t[0] != lead || t[1] != second)) e = 3u | ((uint32_t)t[0] << 8) | ((uint32_t)t[1] << 16);
+    out[nm_two_index(lead, second)] = e;
+  }
+}
 
 // norm.Normalize + capcode.Encode (go/tokenmonster.go:242-253); flag order as tokenmonster.cpp:428-475
 void normalize_bytes(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_flag, std::vector<uint8_t>& out) {

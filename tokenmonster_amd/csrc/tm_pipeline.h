@@ -140,6 +140,12 @@ struct tm_batch {
   uint32_t* d_group_base = nullptr;
   // raw (un-normalized) input of tm_batch_upload_raw / tm_batch_normalize
   uint8_t* d_raw = nullptr;
+  // the filter pass of a vocabulary with byte-level normalization flags (tm_norm.hip: k_pf_*): the filtered text and its documents
+  uint8_t* d_rawf = nullptr; uint64_t rawf_cap = 0;
+  uint64_t* d_rawf_off = nullptr; uint64_t rawf_docs_cap = 0;
+  void* d_pf_piece = nullptr; uint64_t pf_piece_cap = 0;
+  void* d_pf_doc = nullptr;
+  uint32_t* d_acc = nullptr;             // what `accents` leaves of the two-byte characters
   uint8_t* d_slab = nullptr;            // normalizer: one 2 KiB slab per 1 KiB piece
   uint64_t slab_pieces = 0;             // pieces of the batch that was normalized last (raw_pieces may already count the next upload)
   bool text_in_slabs = false;           // the normalized text of this batch has not been packed into d_text: K1 stages it from the slabs (k_seg_src)
