@@ -167,17 +167,18 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
  * Tokenize (go/tokenmonster.go:242-253: norm.Normalize + capcode.Encode) ON THE DEVICE into the batch's text buffer
  * (max_bytes of tm_batch_create must cover the normalized size, about 1.1x raw with capcode 2).  The device pass handles ASCII, every
  * two-byte script (U+0080..U+07FF: accented Latin, Greek, Cyrillic, Armenian, Hebrew, Arabic ...: NFD, case and capcode from a table the
- * host normalizer fills), the three-byte characters the normalizer leaves alone (General Punctuation, CJK ideographs, most kana,
- * symbols), Hangul syllables (decomposed by arithmetic) and the four-byte characters of caseless, NFD-stable blocks (emoji, symbols, plane-2
- * ideographs); documents with anything else (voiced kana, Latin Extended Additional, cased scripts beyond the BMP, a capital without a
- * lower-case form - U+03D2..U+03D4 -, two combining marks in a row, malformed UTF-8) are normalized by the host normalizer inside the same
- * call; tm_batch_host_fallback_docs reports how many.  (TM_NORM_WG_PER_CU in the environment: the grid of the pass, workgroups per compute
+ * host normalizer fills), Latin Extended Additional under NFD (U+1E00..U+1EFF, what Vietnamese adds: a letter and one or two marks each), the
+ * three-byte characters the normalizer leaves alone (General Punctuation, CJK ideographs, most kana, symbols), Hangul syllables (decomposed
+ * by arithmetic) and the four-byte characters of caseless, NFD-stable blocks (emoji, symbols, plane-2 ideographs); documents with anything
+ * else (voiced kana, cased scripts beyond the BMP, a capital without a lower-case form - U+03D2..U+03D4 -, a combining mark behind a
+ * character that ends in one of its own, malformed UTF-8) are normalized by the host normalizer inside the same call, from their original
+ * bytes; tm_batch_host_fallback_docs reports how many.  (TM_NORM_WG_PER_CU in the environment: the grid of the pass, workgroups per compute
  * unit, default 64 - a tuning knob, profiles/r05_issue_model.txt.)
- * Supported: capcode 0 and 2 (level 1
- * has no statement in the reference tree and is refused), every normalization flag (training/README.md:110-123); the device
- * pass itself implements NFD and lowercase (what the reference's pretrained vocabularies use), a vocabulary with any of the
- * lossy flags accents / quotemarks / collapse / trim / leadingspace / unixlines sends ALL its documents through the (multi-threaded)
- * host normalizer inside this call.  tm_batch_normalize synchronizes `stream`; afterwards tm_batch_run tokenizes the normalized
+ * Supported: capcode 0 and 2 (level 1 has no statement in the reference tree and is refused) and every normalization flag
+ * (training/README.md:110-123) ON THE DEVICE: NFD and lowercase in the pass itself; quotemarks, collapse, trim, leadingspace and unixlines -
+ * and what accents does to the two-byte characters - in a filter pass in front of it that states the reference's in-place loops
+ * (tokenmonster.cpp:245-425) per byte, their quirks included (tm_norm.hip: k_pf_*; one more trip to the host, for the filtered documents'
+ * sizes).  tm_batch_normalize synchronizes `stream`; afterwards tm_batch_run tokenizes the normalized
  * documents.  (Where the normalized text lies between the two calls is the library's business: when every document was normalized on the
  * device it stays in the normalizer's per-piece slabs and the match kernel reads it from there - no packing pass; tm_batch_download_text
  * packs it on request and returns it in document order either way.) */

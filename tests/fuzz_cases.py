@@ -109,6 +109,11 @@ ASTRAL_HANGUL = ["\U0001f600", "\U0001f680", "\U0001f44d\U0001f3fd", "\U0001f1e9
                  "\U0001d15e", "\uac00", "\uac01", "\ud7a3", "\ud55c", "\uad6d", "\uc5b4", "\ubdc1", "\uac12", "\ub2ed", "\u1100", "\u1161", "\u11a8", "\ufe0f"]
 
 
+# round 6: Latin Extended Additional under NFD - a letter and one or two marks per character: the letters Vietnamese adds to Latin-1 / Latin
+# Extended-A, a few of the others of the block, and the ones that stay with the host (a two-byte base: U+1E9B; no decomposition: U+1E9E, U+1EFF)
+VIET = list("ếệềểễấậầẩẫắặằẳẵớợờởỡứựừửữạảịỉọỏụủỳỵỷỹẾỆẤẬẮẶỚỢỨỰẠẢỊỌỤỲỸđĐơƠưƯăĂâêô") + ["\u1e00", "\u1e01", "\u1e9b", "\u1e9e", "\u1eff", "\u1e69", "\u1e08"]
+
+
 def one_norm(seed):
     """the device normalizer (NFD / lowercase + capcode 2; host fallback for what it does not do itself) against the host normalizer:
     runs of capitals, digits and apostrophes of every length, also across the 64-byte chunks and 1 KiB pieces of the device pass"""
@@ -131,6 +136,8 @@ def one_norm(seed):
                 parts.append("".join(rng.choice(NORM_ALPHABET[:30] + LATIN, size=int(rng.integers(1, 40)))))
             elif r < 0.22:
                 parts.append("".join(rng.choice(NORM_ALPHABET[:30] + ASTRAL_HANGUL[int(rng.integers(0, 12)):], size=int(rng.integers(1, 40)))))
+            elif r < 0.27:
+                parts.append("".join(rng.choice(NORM_ALPHABET[:36] + VIET, size=int(rng.integers(1, 40)))))
             elif lossy and r < 0.5:
                 parts.append("".join(rng.choice([" ", "  ", "   ", "\r\n", "\r", "\n", "\t", "\u2018", "\u2019", "\u201c", "\u201d", "\u2019s", "a", "B", "é", "É", "x ", " y", "\u0301", "ñ", "1"],
                                                 size=int(rng.integers(1, 30)))))

@@ -857,6 +857,52 @@ def test_emoji_and_korean_text_stay_on_the_device():
                 assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == unicodedata.normalize("NFD", docs[k].decode()).encode(), docs[k]
 
 
+def test_vietnamese_text_stays_on_the_device():
+    """round 6: Latin Extended Additional (U+1E00..U+1EFF: what Vietnamese is written in beside the two-byte letters) under NFD - a letter and one
+    or two combining marks per character, from a table the host normalizer fills (tm_normalize.cpp: build_lea_table).  One such character used
+    to send its whole document to host ICU.  Bytes == the host normalizer's; >= 99 % of the documents stay on the device; ids of the raw path ==
+    ids of the host-normalized text; the device decoder gives back NFD of the text."""
+    import unicodedata
+    from fuzz_cases import VIET
+    rng = np.random.default_rng(2027)
+    words = ["Việt", "Nam", "tiếng", "Hà", "Nội", "Thành", "phố", "Hồ", "Chí", "Minh", "đường", "Nguyễn", "Huệ", "phở", "bò", "ĐƯỜNG", "TIẾNG", "VIỆT", "người", "được", "những", "trường", "ƯỚC", "Ắt",
+             "hello", "World", "HTTP", "it's", "ớt's", "Ế", "2ế", "x", "I"]
+    docs = []
+    total, target = 0, 120_000 if EMULATED else 3_000_000
+    while total < target:
+        n = int(rng.integers(1, 400))
+        parts = []
+        for _ in range(n):
+            r = rng.random()
+            parts.append(str(rng.choice(words)) if r < 0.8 else "".join(rng.choice(VIET[:60], size=int(rng.integers(1, 6)))))
+            parts.append(str(rng.choice([" ", " ", " ", ", ", ". ", "\n", "'", "1"])))
+        d = "".join(parts)
+        if rng.random() < 0.005:
+            d += str(rng.choice(["\u1e9b", "\u1e9e", "\u1ebf\u0323"]))           # what stays with the host: a two-byte base letter, no decomposition, a further mark behind the character's own
+        docs.append(d.encode())
+        total += len(docs[-1])
+    docs += [("\u1ebf" * 2000).encode(), ("\u1ec6" * 700 + "b").encode(), ("x" * 1022 + "\u1ebf\u1ec7").encode()]
+    raw, offs = tm.pack_documents(docs)
+    for capcode, flag in ((2, 1), (2, 3), (2, 0), (0, 1)):
+        v = tm.Vocab(synth.build_vocab([bytes([c]) for c in range(256)], capcode=capcode, charset=1, norm_flag=flag))
+        got, goff, nfb = v.normalize_packed_device(raw, offs)
+        exp, eoff = synth.normalize_batch(raw, offs, capcode, flag)
+        assert (goff == eoff).all() and got.size == exp.size
+        assert (got == exp).all(), "capcode %d flag %d" % (capcode, flag)
+        if capcode == 2 and (flag & 1):
+            assert nfb <= len(docs) // 100 + 1, "%d of %d documents took the host path (capcode %d flag %d)" % (nfb, len(docs), capcode, flag)
+        if capcode == 2 and flag == 1:
+            ids, toff, miss = v.tokenize_packed(exp, eoff)
+            assert int(miss.sum()) == 0
+            nchk = min(200, len(docs))
+            gotids = v.tokenize(docs[:nchk])
+            for k in range(nchk):
+                assert (gotids[k] == ids[int(toff[k]):int(toff[k + 1])]).all()
+            out, ooff = v.decode_packed(ids[: int(toff[nchk])], np.ascontiguousarray(toff[: nchk + 1]))
+            for k in range(nchk):
+                assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == unicodedata.normalize("NFD", docs[k].decode()).encode(), docs[k]
+
+
 def test_one_child_chains_in_the_trie():
     """round 5: a node below which the trie is a chain of one-child nodes down to the next key is walked in ONE round - the chain's string
     (a record of three table entries, tm_tables.h "tails") against the text - instead of a byte per round, in the plain walk (step A1) and

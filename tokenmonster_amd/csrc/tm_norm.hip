@@ -54,14 +54,15 @@ __device__ __forceinline__ bool nblock(uint32_t cls) { return (cls & NF_BLOCK) !
 struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
 // The normalizer's tables in ONE device buffer (tm_norm_masks.h): NmTwo[NM_TWO_SIZE] | block codes [NM_BLK_WORDS] | code-point codes
 // [NM_CP_WORDS] | block codes of the four-byte characters [NM_BLK4_WORDS] | one word of switches (NM_MISC_*; 16 bytes with its padding).  The 256 work-items of a workgroup stage the entries of U+0080..U+017F (2 KB) and the block codes (256 bytes) in LDS.
-constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t);
+constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea);      // (... | the characters of Latin Extended Additional, read where they lie)
 struct TabLds { NmTwo two[NM_TWO_FAST]; uint32_t blk[NM_BLK_WORDS]; };
 __device__ __forceinline__ NmTabs stage_tabs(TabLds& s, const NmTwo* __restrict__ two) {
   static_assert(NM_TWO_FAST == 256 && NM_BLK_WORDS <= 256, "one entry per work-item");
   const uint32_t* blk = reinterpret_cast<const uint32_t*>(two + NM_TWO_SIZE);
   s.two[threadIdx.x] = two[threadIdx.x];
   if (threadIdx.x < NM_BLK_WORDS) s.blk[threadIdx.x] = blk[threadIdx.x];
-  return NmTabs{s.two, two, s.blk, blk + NM_BLK_WORDS, blk + NM_BLK_WORDS + NM_CP_WORDS, (uint32_t)__builtin_amdgcn_readfirstlane((int)blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS])};
+  return NmTabs{s.two, two, s.blk, blk + NM_BLK_WORDS, blk + NM_BLK_WORDS + NM_CP_WORDS, (uint32_t)__builtin_amdgcn_readfirstlane((int)blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS]),
+                reinterpret_cast<const NmLea*>(blk + NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4)};
 }
 
 // Bytes beyond ASCII are the exception (a dword of plain ASCII never gets here), and what they need is long: kept OUT of line, so that the
@@ -84,9 +85,19 @@ __device__ __noinline__ HighOut emit_high_byte(const uint8_t* r, uint32_t fl, ui
     uint32_t y = 0, mm = 0;
     const uint32_t extra = nm_two_out(e, cont2, (code & 4u) != 0, true, &o.o3, &y, &mm);
     if (extra >= 1u) { o.len1 = extra; o.ysp = y; o.m3 = mm; }
-  } else if (tabs.misc & NM_MISC_HANGUL) {
-    uint32_t hrole, hcp;
-    if (fl != NF_BAD && nm_hangul_role(b, bm1, r[-2], bp1, r[2], &hrole, &hcp)) o.len1 = nm_hangul_out(hcp, hrole, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
+  } else {
+    uint32_t role, idx;
+    if ((tabs.misc & NM_MISC_LEA) && fl != NF_BAD && nm_lea_role(b, bm1, r[-2], bp1, r[2], &role, &idx) && (tabs.lea[idx].a & NT_OK)) {
+      // a letter of Latin Extended Additional (NFD): the letter, its first mark, its second mark or nothing
+      const NmLea e = tabs.lea[idx];
+      if (role == 0u) o.o3 = (code & 4u) ? ((e.a >> 16) & 0xFFu) : ((e.a >> 8) & 0xFFu);
+      else if (role == 1u) { o.len1 = 1u; o.ysp = e.b & 0xFFu; o.o3 = (e.b >> 8) & 0xFFu; }
+      else if (((e.a >> 24) & 3u) == 2u) { o.len1 = 1u; o.ysp = (e.b >> 16) & 0xFFu; o.o3 = e.b >> 24; }
+      else o.len1 = 0xFFu;
+    } else if (tabs.misc & NM_MISC_HANGUL) {
+      uint32_t hrole, hcp;
+      if (fl != NF_BAD && nm_hangul_role(b, bm1, r[-2], bp1, r[2], &hrole, &hcp)) o.len1 = nm_hangul_out(hcp, hrole, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
+    }
   }
   return o;
 }
@@ -368,6 +379,15 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
       // one byte of a Hangul syllable (NFD): its lane emits one of the syllable's jamo - or nothing (tm_norm_masks.h)
       uint32_t hrole, hcp;
       if ((tabs.misc & NM_MISC_HANGUL) && fl != NF_BAD && nm_hangul_role(b, bm1, L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], &hrole, &hcp)) len = nm_hangul_out(hcp, hrole, &o1, &o2, &o3);
+      // ... or of a letter of Latin Extended Additional (NFD): the letter, its first mark, its second mark or nothing
+      uint32_t lrole, lidx;
+      if ((tabs.misc & NM_MISC_LEA) && fl != NF_BAD && nm_lea_role(b, bm1, L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], &lrole, &lidx) && (tabs.lea[lidx].a & NT_OK)) {
+        const NmLea le = tabs.lea[lidx];
+        if (lrole == 0u) o3 = (code & 4u) ? ((le.a >> 16) & 0xFFu) : ((le.a >> 8) & 0xFFu);
+        else if (lrole == 1u) { len = 2u; o2 = le.b & 0xFFu; o3 = (le.b >> 8) & 0xFFu; }
+        else if (((le.a >> 24) & 3u) == 2u) { len = 2u; o2 = (le.b >> 16) & 0xFFu; o3 = le.b >> 24; }
+        else len = 0u;
+      }
     }
     // inclusive prefix sum of len (0..4) over the wavefront: bytes-with-len>=k ballots, counted below the lane
     uint32_t incl = len;
@@ -866,6 +886,12 @@ const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
     build_three_tables(flags & 3u, blk, blk + NM_BLK_WORDS);
     build_four_table(flags & 3u, blk + NM_BLK_WORDS + NM_CP_WORDS);
     blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] = (capcode2 && (flags & 1u)) ? NM_MISC_HANGUL : 0u;      // NFD of the Hangul syllables: by arithmetic, where the pass may change lengths
+    NmLea* lea = reinterpret_cast<NmLea*>(blk + NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4);
+    for (int k = 0; k < NM_LEA_SIZE; k++) lea[k] = NmLea{0, 0};
+    if (capcode2 && (flags & 1u) && !accents) {      // ... and of Latin Extended Additional: a letter and one or two marks (under `accents` the marks would have to go: the host)
+      build_lea_table(flags & 3u, lea);
+      blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] |= NM_MISC_LEA;
+    }
     if (accents) {
       std::vector<uint32_t> acc(NM_TWO_SIZE);
       build_accent_table(acc.data());

@@ -100,8 +100,31 @@ TM_HD bool nm_hangul_role(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uin
   *cp = nm_cp3(lead, b1, b2);
   return nm_hangul(*cp);
 }
+// ---- Latin Extended Additional U+1E00..U+1EFF under NFD (round 6): what Vietnamese is written in beside the two-byte letters --------------------
+// 256 three-byte characters (E1 B8..BB xx) that decompose into an ASCII letter and ONE or TWO two-byte combining marks (ế -> e + U+0302 +
+// U+0301; ớ -> o + U+031B + U+0301), already in canonical order.  One lane per input byte as everywhere: the lane of the first byte takes the
+// letter's role (class, markers, the letter), the second emits the first mark, the third the second mark - or nothing.  A table from the host
+// normalizer's own functions (tm_normalize.cpp: build_lea_table), only with the NFD flag and capcode 2 (NM_MISC_LEA):
+//   a: class of the letter [0..2] | NT_OK [3] | the letter [8..15] | its lower-case form [16..23] | number of marks [24..25]
+//   b: first mark [0..15] | second mark [16..31]
+// An entry without NT_OK (a two-byte base letter: ẛ; no decomposition: ẞ ỿ) leaves the document to the host, as before.
+struct NmLea { uint32_t a, b; };
+constexpr int NM_LEA_SIZE = 256;
+constexpr uint32_t NM_MISC_LEA = 2u;
+// which byte of such a character the byte b between m2 m1 and p1 p2 is (0, 1, 2) and the character's index in the table: false if it is none
+TM_HD bool nm_lea_role(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32_t p2, uint32_t* role, uint32_t* idx) {
+  uint32_t b1, b2;
+  if (b == 0xE1u) { b1 = p1; b2 = p2; *role = 0u; }
+  else if ((b & 0xC0u) != 0x80u) return false;
+  else if (m1 == 0xE1u) { b1 = b; b2 = p1; *role = 1u; }
+  else if (m2 == 0xE1u) { b1 = m1; b2 = b; *role = 2u; }
+  else return false;
+  if (b1 - 0xB8u >= 4u || (b2 & 0xC0u) != 0x80u) return false;
+  *idx = ((b1 & 3u) << 6) | (b2 & 63u);
+  return true;
+}
 // what a kernel knows the tables by: the fast part of the two-byte table and the block table (LDS), the full tables (global memory)
-struct NmTabs { const NmTwo* two_fast; const NmTwo* two_all; const uint32_t* blk; const uint32_t* cp; const uint32_t* blk4; uint32_t misc; };
+struct NmTabs { const NmTwo* two_fast; const NmTwo* two_all; const uint32_t* blk; const uint32_t* cp; const uint32_t* blk4; uint32_t misc; const NmLea* lea; };
 TM_HD NmTwo nm_two_get(const NmTabs& t, uint32_t idx) { return idx < (uint32_t)NM_TWO_FAST ? t.two_fast[idx] : t.two_all[idx]; }
 TM_HD uint32_t nm_three_code(const NmTabs& t, uint32_t cp) {
   const uint32_t bc = (t.blk[cp >> 10] >> (2u * ((cp >> 6) & 15u))) & 3u;
@@ -127,6 +150,8 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
       const uint32_t pa = nm_two_get(tabs, nm_two_index(m2, m1)).a;
       if ((pa & NF_CLASS) == NC_M || (pa & (NT_DECOMP | NT_DECOMP2))) return NF_BAD;
     }
+    // ... the same behind a character of Latin Extended Additional, which ends in a mark of its own
+    if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_LEA) && m3 == 0xE1u && m2 - 0xB8u < 4u && nm_cont_byte(m1) && (tabs.lea[((m2 & 3u) << 6) | (m1 & 63u)].a & NT_OK)) return NF_BAD;
     return a & NF_CLASS;
   }
   if (nm_cont_byte(b) && nm_two_lead(m1)) {
@@ -152,6 +177,10 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
   if (!nm_cont_byte(b1) || !nm_cont_byte(b2)) return NF_BAD;
   if (lead == 0xE2u && nm_punct3(b1, b2)) return ((b1 == 0x80u && b2 == 0x99u) ? (uint32_t)NC_AP : (uint32_t)NC_O) | cont;      // U+2019 is an apostrophe (tokenmonster.js:878)
   const uint32_t cp3 = nm_cp3(lead, b1, b2);
+  if ((tabs.misc & NM_MISC_LEA) && cp3 - 0x1E00u < (uint32_t)NM_LEA_SIZE) {      // a letter and its marks: the first lane is the letter, the others are marks
+    const uint32_t a = tabs.lea[cp3 - 0x1E00u].a;
+    if (a & NT_OK) return cont ? (uint32_t)NC_M : (a & NF_CLASS);
+  }
   const uint32_t code = nm_three_code(tabs, cp3);
   if (code == 0u && (tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp3)) return (uint32_t)NC_LO | cont;       // decomposes, but by arithmetic: nm_hangul_out
   return code == 0u ? (uint32_t)NF_BAD : ((code == 3u ? (uint32_t)NC_M : (code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O)) | cont);      // (3: a combining mark of class 0)

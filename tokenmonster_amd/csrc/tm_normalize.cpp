@@ -423,6 +423,38 @@ void build_two_table(uint32_t norm_flag, NmTwo* out) {
   }
 }
 
+// Latin Extended Additional U+1E00..U+1EFF (tm_norm_masks.h: NmLea): what NFD (+ lowercase) makes of each character, where that is an ASCII
+// letter followed by one or two two-byte combining marks
+void build_lea_table(uint32_t norm_flag, NmLea* out) {
+  for (int k = 0; k < NM_LEA_SIZE; k++) out[k] = NmLea{0, 0};
+  if (!(norm_flag & 1)) return;
+  for (uint32_t cp = 0x1E00; cp < 0x1F00; cp++) {
+    std::vector<uint8_t> t;
+    put_cp(t, cp);
+    nfd_bytes(t);
+    if (norm_flag & 2) lower_bytes(t);
+    if (t.size() != 3 && t.size() != 5) continue;
+    const Cp c1 = next_cp(t.data(), t.size());
+    if (c1.raw || c1.n != 1) continue;
+    const uint8_t k1 = classify(c1);
+    if (!(k1 & kLetter)) continue;
+    bool ok = true;
+    uint32_t marks[2] = {0, 0};
+    const uint32_t nm = (uint32_t)(t.size() - 1) / 2;
+    for (uint32_t j = 0; j < nm && ok; j++) {
+      const Cp cm = next_cp(t.data() + 1 + 2 * j, t.size() - 1 - 2 * j);
+      ok = !cm.raw && cm.n == 2 && (classify(cm) & kMark);
+      marks[j] = (uint32_t)t[1 + 2 * j] | ((uint32_t)t[2 + 2 * j] << 8);
+    }
+    if (!ok) continue;
+    std::vector<uint8_t> low;
+    put_lower(low, c1);
+    if (low.size() != 1) continue;
+    const uint32_t cls = (k1 & kUpper) ? NC_U : (k1 & kLower) ? NC_L : NC_LO;
+    out[cp - 0x1E00] = NmLea{cls | NT_OK | ((uint32_t)t[0] << 8) | ((uint32_t)low[0] << 16) | (nm << 24), marks[0] | (marks[1] << 16)};
+  }
+}
+
 // blk[NM_BLK_WORDS], cp[NM_CP_WORDS]: two bits per block of 64 code points / per code point of U+0000..U+FFFF (tm_norm_masks.h)
 void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cpt) {
   for (int k = 0; k < NM_BLK_WORDS; k++) blk[k] = 0;

@@ -31,7 +31,8 @@ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
 static uint64_t g_margin_ok = 0, g_margin_unknown = 0;
 static NmTwo g_two[2][NM_TWO_SIZE];     // [lower_all]: flags 1 (NFD) and 3 (NFD + lowercase)
 static uint32_t g_blk[2][NM_BLK_WORDS], g_cp[2][NM_CP_WORDS], g_blk4[2][NM_BLK4_WORDS];      // the three- and four-byte characters the pass leaves alone (tm_norm_masks.h)
-static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k], g_blk4[k], NM_MISC_HANGUL}; }
+static NmLea g_lea[2][NM_LEA_SIZE];      // Latin Extended Additional under NFD: a letter + one or two marks (round 6)
+static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k], g_blk4[k], NM_MISC_HANGUL | NM_MISC_LEA, g_lea[k]}; }
 // class byte of every byte of a document as norm_load_piece computes it (bytes outside the document read as 0)
 bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t>& f) {
   const int n = (int)d.size();
@@ -119,6 +120,14 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
       }
       uint32_t hrole, hcp;
       if (fl != NF_BAD && nm_hangul_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &hrole, &hcp)) { len = nm_hangul_out(hcp, hrole, &m3, &ysp, &o3); if (len == 0) continue; }
+      uint32_t lrole, lidx;
+      if (fl != NF_BAD && nm_lea_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &lrole, &lidx) && (g_lea[lower_all ? 1 : 0][lidx].a & NT_OK)) {
+        const NmLea le = g_lea[lower_all ? 1 : 0][lidx];
+        if (lrole == 0u) o3 = (code & 4u) ? ((le.a >> 16) & 0xFFu) : ((le.a >> 8) & 0xFFu);
+        else if (lrole == 1u) { len = 2u; ysp = le.b & 0xFFu; o3 = (le.b >> 8) & 0xFFu; }
+        else if (((le.a >> 24) & 3u) == 2u) { len = 2u; ysp = (le.b >> 16) & 0xFFu; o3 = le.b >> 24; }
+        else continue;
+      }
       if (len == 4) out.push_back('D');
       if (len >= 3) out.push_back((uint8_t)m3);
       if (len >= 2) out.push_back((uint8_t)ysp);
@@ -195,6 +204,10 @@ int main(int argc, char** argv) {
   build_three_tables(3, g_blk[1], g_cp[1]);
   build_four_table(1, g_blk4[0]);
   build_four_table(3, g_blk4[1]);
+  build_lea_table(1, g_lea[0]);
+  build_lea_table(3, g_lea[1]);
+  { int ok = 0, two = 0; for (int k = 0; k < NM_LEA_SIZE; k++) { ok += (g_lea[0][k].a & NT_OK) != 0; two += (g_lea[0][k].a & NT_OK) && ((g_lea[0][k].a >> 24) & 3u) == 2u; }
+    printf("Latin Extended Additional (NFD): %d of %d characters on the device, %d of them with two marks\n", ok, NM_LEA_SIZE, two); }
   { int ok = 0, dec = 0, dec2 = 0; for (int k = 0; k < NM_TWO_SIZE; k++) { ok += (g_two[0][k].a & NT_OK) != 0; dec += (g_two[0][k].a & NT_DECOMP) != 0; dec2 += (g_two[0][k].a & NT_DECOMP2) != 0; }
     int c1 = 0, c2 = 0, mixed = 0;
     for (uint32_t cp = 0x800; cp < 0x10000; cp++) { const uint32_t c = (g_cp[0][cp >> 4] >> (2 * (cp & 15))) & 3u; c1 += c == 1; c2 += c == 2; }
@@ -215,7 +228,9 @@ int main(int argc, char** argv) {
                                     u8"中文文本，测试。Hello世界 ABC中文", u8"こんにちは世界 カタカナ がぎぐ パピプ", u8"한국어 텍스트", u8"가 각 힣 뷁 A가B 가a 1가 '가' 한글Hangul 가\u0301", std::string(1022, 'x') + u8"한국", std::string(1023, 'x') + u8"각", std::string(400, 'x') + std::string(u8"한국어텍스트가나다라마바사") + std::string(u8"아자차카타파하") + std::string(600, 'y'), u8"a\u0301 e\u0301\u0323 o\u0323\u0301 Ắ ǖ", u8"→ ★ ∑ √ ①②③ Ḁḁ ẞ",
                                     std::string(1023, 'x') + u8"й", std::string(1022, 'x') + u8"Йод", std::string(62, 'a') + u8"йй" + std::string(61, 'b') + u8"中文",
                                     u8"Hello 😀 World 🌍🚀 it's 👍🏽 A😀B c😀d 1😀2 '😀' 𝒜𝒷 𠀀𠀁 done", std::string(1021, 'x') + u8"😀Ab", std::string(1022, 'x') + u8"😀" + " Ab", std::string(1023, 'x') + u8"A😀b", std::string(61, 'A') + u8"😀😀" + std::string(70, 'b'),
-                                    u8"𐐀𐐨 Deseret", u8"𝅗𝅥 half note", "\xF0\x9F\x98", "\xF4\x90\x80\x80 beyond", "\xF0\x80\x80\x80 overlong", u8"x😀", u8"I ❤️ U ☺️ 1️⃣ A️b a️B ❤️️", u8"की कि कु हिन्दी HINDI ह"};
+                                    u8"𐐀𐐨 Deseret", u8"𝅗𝅥 half note", "\xF0\x9F\x98", "\xF4\x90\x80\x80 beyond", "\xF0\x80\x80\x80 overlong", u8"x😀", u8"I ❤️ U ☺️ 1️⃣ A️b a️B ❤️️", u8"की कि कु हिन्दी HINDI ह",
+                                    u8"Việt Nam: tiếng Việt, Hà Nội và Thành phố Hồ Chí Minh. ĐƯỜNG Nguyễn Huệ, PHỞ bò; Ắ ắ Ế ế Ộ ộ Ự ự Ỹ ỹ", u8"TIẾNG VIỆT viết HOA và Thường; ớt's Ớt'S 1ế2 'ệ' Ḁḁ ẛ ẞ ỿ ế\u0301 e\u0302\u0301",
+                                    std::string(1022, 'x') + u8"ếệ", std::string(1023, 'x') + u8"Ế" + "b", std::string(1021, 'x') + u8" Ệ" + std::string(40, 'A') + "c", std::string(61, 'A') + u8"ỆỆ" + std::string(70, 'b')};
   for (int lower = 0; lower < 2; lower++) {
     const uint32_t flag = lower ? 3u : 1u;
     for (const auto& s : fixed) { std::vector<uint8_t> d(s.begin(), s.end()); total++; if (!check_doc(d, flag, &skipped)) bad++; }
