@@ -348,8 +348,10 @@ int tm_dataset_upload_sharded(tm_devices* g, const uint8_t* normalized, uint64_t
 uint64_t tm_dataset_set_range(const tm_dataset_set* s, int member, uint64_t* halo_bytes);
 void tm_dataset_set_free(tm_dataset_set* s);
 /* One scoring pass over the WHOLE dataset as one strip (trainvocab.go:909-922), bit-identical to tm_score(v, whole dataset, n_strips = 0) on one
- * device: every member runs tm_score_begin on its range, the 80-entry exit maps are chained on the host into every member's entry state,
- * tm_score_finish completes the ranges, and one all-reduce(sum) of the n_ids + 4 + 256 uint32 histogram words merges them.  Results as tm_score. */
+ * device: every member runs the match kernel on its range, the 80-entry exit maps of all ranges are gathered on every device (ncclAllGather
+ * of 80 bytes per member; peer copies where there is no communicator) and chained there into the member's entry state, the histogram walk
+ * follows on the same stream, and one all-reduce(sum) of the n_ids + 4 + 256 uint32 histogram words merges them: a member's host thread
+ * enqueues its whole half of the pass and waits once.  Results as tm_score. */
 int tm_score_multi(const tm_vocab_set* vs, tm_dataset_set* ds, uint32_t* scores, uint64_t* tokens_in_text, uint8_t missing_set[32]);
 
 #ifdef __cplusplus

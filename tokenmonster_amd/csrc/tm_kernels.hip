@@ -2450,6 +2450,7 @@ int small_sync(tm_batch* b, hipStream_t st) {
 
 int error_from_flag(uint32_t err) {
   if (err == 0) return TM_OK;
+  if (err & 4u) return set_error(TM_E_INPUT, "a byte range of the whole-buffer walk cannot be entered in the state the walk reaches it in (tm_score_multi)");
   if ((err & 1u) == 0u) return set_error(TM_E_INTERNAL, "the emit stage met a transition the match stage never wrote (device error word %u): a fault of this library, not of the input", err);
   return set_error(TM_E_INPUT, "the walk does not advance on this text (a vocabulary / text combination the reference does not terminate on: e.g. one-byte keys beside the delete token in a UTF-16 vocabulary)");
 }

@@ -42,6 +42,7 @@ struct Rccl {
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
@@ -70,11 +71,12 @@ static Rccl& rccl() {
     r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
     r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-    r.ok = r.CommInitAll && r.CommDestroy && r.AllReduce && r.GroupStart && r.GroupEnd && r.GetErrorString;
+    r.ok = r.CommInitAll && r.CommDestroy && r.AllReduce && r.AllGather && r.GroupStart && r.GroupEnd && r.GetErrorString;
   });
   return r;
 }
@@ -90,6 +92,20 @@ struct DeviceKeeper {
   DeviceKeeper& operator=(const DeviceKeeper&) = delete;
 };
 
+// The entry state of member `member`'s byte range from the exit maps of all ranges (ENT bytes each, in member order): the chain the host used
+// to walk between tm_score_begin and tm_score_finish, on the device (round 6) - a member's stream goes from its match kernel through the
+// all-gather of the maps and this kernel straight into its histogram walk, no trip to the host in between.  error bit 2: a range that
+// cannot be entered in the state the walk reaches it in.
+__global__ void k_chain_entry(const uint8_t* __restrict__ all_exits, int member, uint8_t* __restrict__ entry_out, uint32_t* __restrict__ error_word) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t e = 0;
+  for (int k = 0; k < member; k++) {
+    e = all_exits[(size_t)k * ENT + e];
+    if (e >= (uint32_t)ENT) { atomicOr(error_word, 4u); e = 0; break; }
+  }
+  entry_out[0] = (uint8_t)e;
+}
+
 __global__ void k_hist_add(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] += src[i];
@@ -102,6 +118,8 @@ struct tm_devices {
   bool distinct = true;                 // no device appears twice: the members can form an RCCL communicator
   std::vector<hipStream_t> stream;      // one stream per member, for the scoring passes
   std::vector<hipEvent_t> done;         // per member: its half of a pass has been enqueued up to here
+  std::vector<hipEvent_t> begun;        // per member: its match kernel and exit map have been enqueued (the no-RCCL gather of the maps waits for these)
+  std::vector<uint8_t*> d_all_exits;    // per member, on its device: the exit maps of all members' ranges (ENT bytes each)
 #ifndef TM_EMU
   std::vector<ncclComm_t> comm;         // created at the first collective (rccl_ready)
 #endif
@@ -143,9 +161,12 @@ static int open_list(const int* devices, int n, tm_devices** out) {
   }
   g->stream.assign(n, nullptr);
   g->done.assign(n, nullptr);
+  g->begun.assign(n, nullptr);
+  g->d_all_exits.assign(n, nullptr);
   for (int i = 0; i < n; i++) {
     if ((e = hipSetDevice(g->dev[i])) != hipSuccess || (e = hipStreamCreateWithFlags(&g->stream[i], hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&g->begun[i], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipMalloc((void**)&g->d_all_exits[i], (size_t)n * ENT + 16)) != hipSuccess) {
       tm_devices_close(g);
       return hip_fail(e, "tm_devices: stream of a member");
     }
@@ -273,6 +294,8 @@ void tm_devices_close(tm_devices* g) {
     (void)hipSetDevice(g->dev[i]);
     if (g->stream[i]) (void)hipStreamDestroy(g->stream[i]);
     if (g->done[i]) (void)hipEventDestroy(g->done[i]);
+    if (i < g->begun.size() && g->begun[i]) (void)hipEventDestroy(g->begun[i]);
+    if (i < g->d_all_exits.size() && g->d_all_exits[i]) (void)hipFree(g->d_all_exits[i]);
   }
   if (g->d_scratch) { (void)hipSetDevice(g->dev[0]); (void)hipFree(g->d_scratch); }
   delete g;
@@ -413,28 +436,47 @@ int tm_score_multi(const tm_vocab_set* vs, tm_dataset_set* ds, uint32_t* scores,
   std::lock_guard<std::mutex> pass(g->mu);
   const bool use_rccl = rccl_ready(g);
   const uint64_t words = (uint64_t)vs->v[0]->host.n_ids + 4 + 256;
-  std::vector<uint8_t> exits((size_t)nd * ENT, 0xFF);
+  std::vector<uint32_t> h0(words);        // member 0 reads the summed histogram on its own stream, behind the collective
+  uint32_t err0 = 0;
   Meet meet(nd);
-  // Every member's host thread: (1) match kernel over its range -> the range's exit state for all 80 entry states; (2) meet: each chains the
-  // maps of the ranges before its own to its true entry state (dist.resolve_entry is the Python form of the same rule); (3) finish the pass
-  // from that state -> histogram in HBM; (4) ONE all-reduce(sum) of the n_ids + 4 + 256 uint32 words (tm_score.hip's layout: every word is a
-  // plain sum over ranges).  A member without bytes (tiny dataset) runs the same calls on an empty range: identity map, zero histogram.
+  // Every member's host thread ENQUEUES its whole half of the pass and waits once (round 6; the 80 exit states used to make a trip to the host
+  // and back between (1) and (3)): (1) match kernel over its range -> the range's exit state for all 80 entry states; (2) the maps of all
+  // ranges gathered on every device - ncclAllGather of 80 bytes per member, or peer copies where there is no communicator - and chained to
+  // the member's true entry state by k_chain_entry (dist.resolve_entry is the Python form of the same rule); (3) the histogram walk from that
+  // state; (4) ONE all-reduce(sum) of the n_ids + 4 + 256 uint32 words (tm_score.hip's layout: every word is a plain sum over ranges), and
+  // behind it on member 0's stream the copy of the sum to the host.  The members meet (host threads only, nothing is waited for on the
+  // devices) before each collective, so that a member that failed keeps the others out of it.  A member without bytes (tiny dataset) runs
+  // the same calls on an empty range: identity map, zero histogram.
   const int rc = on_members(g, [&](int i) -> int {
     tm_dataset* d = ds->part[i];
     const tm_vocab* v = vs->v[i];
     hipStream_t st = g->stream[i];
-    int r = tm_score_begin(v, d, 0, ds->own[i], ds->continues[i], st, &exits[(size_t)i * ENT]);
+    hipError_t e;
+    int r = score_begin_device(v, d, 0, ds->own[i], ds->continues[i], st);
+    if (r == TM_OK && (e = hipEventRecord(g->begun[i], st)) != hipSuccess) r = hip_fail(e, "hipEventRecord");
     if (!meet.wait(r == TM_OK)) return r;
     // (test hook 14: the last member gives up between the first and the second meeting - every member must come back with its error,
     // nobody may be left waiting at a meeting the others never reach)
     if ((debug_flags() & 16384) && i == nd - 1) r = set_error(TM_E_INPUT, "test hook 14: member %d gives up after the first meeting", i);
-    uint32_t entry = 0;
-    for (int k = 0; k < i && r == TM_OK; k++) {
-      entry = exits[(size_t)k * ENT + entry];
-      if (entry >= (uint32_t)ENT) r = set_error(TM_E_INPUT, "the range of member %d cannot be entered in the state the walk reaches it in", k);
+    if (r == TM_OK) {
+#ifndef TM_EMU
+      if (use_rccl) {
+        (void)hipGetLastError();
+        const ncclResult_t nr = rccl().AllGather(score_exits_device(d), g->d_all_exits[i], (size_t)ENT, ncclUint8, g->comm[i], st);
+        if (nr != ncclSuccess) r = set_error(TM_E_HIP, "ncclAllGather: %s", rccl().GetErrorString(nr));
+      } else
+#endif
+      for (int k = 0; k < nd && r == TM_OK; k++) {
+        if (k != i && (e = hipStreamWaitEvent(st, g->begun[k], 0)) != hipSuccess) { r = hip_fail(e, "hipStreamWaitEvent"); break; }
+        e = g->dev[k] == g->dev[i] ? hipMemcpyAsync(g->d_all_exits[i] + (size_t)k * ENT, score_exits_device(ds->part[k]), ENT, hipMemcpyDeviceToDevice, st)
+                                   : hipMemcpyPeerAsync(g->d_all_exits[i] + (size_t)k * ENT, g->dev[i], score_exits_device(ds->part[k]), g->dev[k], ENT, st);
+        if (e != hipSuccess) r = hip_fail(e, "copy of an exit map");
+      }
     }
-    if (r == TM_OK) r = tm_score_finish(v, d, entry, st, nullptr, 0);
-    hipError_t e;
+    if (r == TM_OK) {
+      TM_LAUNCH(k_chain_entry, 1, 64, 0, st, g->d_all_exits[i], i, score_entry_device(d), score_error_device(d));
+      r = score_finish_device(v, d, st);
+    }
     if (r == TM_OK && (e = hipEventRecord(g->done[i], st)) != hipSuccess) r = hip_fail(e, "hipEventRecord");
     if (!meet.wait(r == TM_OK)) return r;
 #ifndef TM_EMU
@@ -460,15 +502,27 @@ int tm_score_multi(const tm_vocab_set* vs, tm_dataset_set* ds, uint32_t* scores,
         TM_LAUNCH(k_hist_add, (uint32_t)((words + 255) / 256), 256, 0, st, d->d_hist, g->d_scratch, words);
       }
     }
-    if (r == TM_OK && (e = hipStreamSynchronize(st)) != hipSuccess) r = hip_fail(e, "hipStreamSynchronize (scoring pass)");
-    if (r == TM_OK) r = score_check(d);
+    // the sum goes to the host behind the collective, on the same stream: ONE wait per member and pass
+    if (r == TM_OK && i == 0) { r = small_d2h(d->ws, h0.data(), d->d_hist, words * 4, st); if (r == TM_OK) r = small_d2h(d->ws, &err0, d->ws->d_error, 4, st); }
+    if (r == TM_OK) r = i == 0 ? small_sync(d->ws, st) : ((e = hipStreamSynchronize(st)) != hipSuccess ? hip_fail(e, "hipStreamSynchronize (scoring pass)") : TM_OK);
+    if (r == TM_OK) r = i == 0 ? error_from_flag(err0) : score_check(d);
     // nobody frees or reuses a histogram before member 0 has read them all
     meet.wait(r == TM_OK);
     return r;
   });
   if (rc != TM_OK) return rc;
-  (void)hipSetDevice(g->dev[0]);
-  return tm_score_read(vs->v[0], ds->part[0], scores, tokens_in_text, missing_set);
+  const uint32_t n_ids = vs->v[0]->host.n_ids;
+  if (scores) std::memcpy(scores, h0.data(), (size_t)n_ids * 4);
+  if (tokens_in_text) {
+    uint64_t t = 0;
+    for (int k = 0; k < 4; k++) t += (uint64_t)h0[n_ids + k] << (16 * k);
+    *tokens_in_text = t;
+  }
+  if (missing_set) {
+    std::memset(missing_set, 0, 32);
+    for (int k = 0; k < 256; k++) if (h0[n_ids + 4 + k]) missing_set[k >> 3] |= (uint8_t)(1u << (k & 7));
+  }
+  return TM_OK;
 }
 
 }  // extern "C"

@@ -215,6 +215,8 @@ struct tm_dataset {
   uint8_t* d_exits = nullptr;      // per strip: exit state for each of the ENT entry states
   uint32_t strip_cap = 0;
   bool prepared = false;
+  // the strips of the last pass, as the workspace holds them on the device (score_prepare: a pass over the same strips does not upload them again)
+  std::vector<uint64_t> strips_key; const tm_batch* ws_strips_owner = nullptr; bool strips_valid = false;
   // one scoring pass at a time per dataset (it owns ONE workspace); host threads that build and load the next candidates
   // (tm_build_vocab, tm_vocab_load) run beside the pass of the current one
   std::mutex mu;
@@ -280,6 +282,12 @@ int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* 
 int error_from_flag(uint32_t err);
 // tm_score.hip: the error word of the dataset's last pass, once its stream has been synchronized
 int score_check(tm_dataset* d);
+// ... and the two halves of a byte range's pass with the entry state staying on the device (tm_multi.hip)
+int score_begin_device(const tm_vocab* v, tm_dataset* d, uint64_t off, uint64_t len, int continues, hipStream_t st);
+const uint8_t* score_exits_device(const tm_dataset* d);
+uint8_t* score_entry_device(tm_dataset* d);
+uint32_t* score_error_device(tm_dataset* d);
+int score_finish_device(const tm_vocab* v, tm_dataset* d, hipStream_t st);
 // tm_norm.hip
 int batch_upload_raw_on(tm_batch* b, const uint8_t* raw, const uint64_t* raw_offsets, uint32_t ndocs, hipStream_t st);
 // tm_normalize.cpp

@@ -78,7 +78,14 @@ static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
     if ((e = hipMalloc((void**)&d->d_vis, (size_t)d->strip_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&d->d_entry, d->strip_cap)) != hipSuccess ||
         (e = hipMalloc((void**)&d->d_exits, (size_t)d->strip_cap * ENT)) != hipSuccess) { d->strip_cap = 0; return hip_fail(e, "hipMalloc (strips)"); }
   }
-  { int rc = small_h2d(b, b->d_offsets, be.data(), 2ull * n_strips * 8, st);          // (through the pinned mailbox: no pageable copies on this path)
+  // The strips of a training run do not change from pass to pass (one strip: the whole dataset; a member's byte range of tm_score_multi): what
+  // they put on the device - offsets, how far each may look, the group tree of the long ones - is still there from the last pass, and a pass
+  // that finds them unchanged starts its kernels at once (the upload of the tree ends in a wait of its own: 0.1 ms of the 3.7 a member's
+  // share of the 8-GPU pass takes, profiles/r06_score_rank_protocol.json).
+  const bool same_strips = d->strips_valid && d->strips_key == be && d->ws_strips_owner == b;
+  if (!same_strips) {
+    d->strips_valid = false;
+    int rc = small_h2d(b, b->d_offsets, be.data(), 2ull * n_strips * 8, st);          // (through the pinned mailbox: no pageable copies on this path)
     if (rc == TM_OK) rc = small_h2d(b, d->d_vis, be.data() + 2ull * n_strips, (uint64_t)n_strips * 8, st);
     if (rc != TM_OK) return rc; }
   b->d_doc_begin = b->d_offsets;
@@ -89,7 +96,11 @@ static int score_prepare(const tm_vocab* v, tm_dataset* d, const uint64_t* strip
   b->ndocs = n_strips;
   b->nbytes = d->n;
   b->nseg = nseg;
-  { int grc = build_groups(b, be.data(), be.data() + n_strips, n_strips, st); if (grc != TM_OK) return grc; }
+  if (!same_strips) {
+    int grc = build_groups(b, be.data(), be.data() + n_strips, n_strips, st);
+    if (grc != TM_OK) return grc;
+    d->strips_key = be; d->ws_strips_owner = b; d->strips_valid = true;
+  }
   int rc = pipeline_match(b, st, nullptr, true);
   if (rc == TM_OK) d->prepared = true;
   return rc;
@@ -122,6 +133,30 @@ static int score_run(const tm_vocab* v, tm_dataset* d, const uint64_t* strip_off
 }
 
 namespace tmh {
+// The two halves of a byte range's pass WITHOUT a trip to the host between them (tm_multi.hip: tm_score_multi): begin = tm_score_begin up to the
+// exit map on the device; the caller puts the range's entry state into score_entry_device(d) with a kernel on the same stream; finish = the
+// histogram walk from there.  The caller holds no lock of the dataset between the two: tm_score_multi owns its datasets for the pass (tm_devices::mu).
+int score_begin_device(const tm_vocab* v, tm_dataset* d, uint64_t off, uint64_t len, int continues, hipStream_t st) {
+  if (!v || !d) return set_error(TM_E_INVALID, "null argument");
+  if (off > d->n || len > d->n - off) return set_error(TM_E_INVALID, "byte range [%llu, +%llu) outside the dataset of %llu bytes", (unsigned long long)off, (unsigned long long)len, (unsigned long long)d->n);
+  if (continues && len < 64) return set_error(TM_E_INVALID, "a byte range that is followed by more text must be at least 64 bytes long");
+  if (continues == 1 && d->n - (off + len) < 128) return set_error(TM_E_INVALID, "a byte range that is followed by more text needs >= 128 bytes of it behind the range");
+  std::lock_guard<std::mutex> g(d->mu);
+  int rc = score_prepare(v, d, &off, &len, 1, continues != 0, st);
+  if (rc != TM_OK) return rc;
+  launch_doc_exits(d->ws, d->d_exits, st);
+  return TM_OK;
+}
+const uint8_t* score_exits_device(const tm_dataset* d) { return d->d_exits; }
+uint8_t* score_entry_device(tm_dataset* d) { return d->d_entry; }
+uint32_t* score_error_device(tm_dataset* d) { return d->ws->d_error; }
+int score_finish_device(const tm_vocab* v, tm_dataset* d, hipStream_t st) {
+  if (!v || !d) return set_error(TM_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> g(d->mu);
+  if (!d->prepared) return set_error(TM_E_INVALID, "score_finish_device without score_begin_device");
+  d->ws->d_doc_entry = d->d_entry;
+  return score_complete(v, d, nullptr, st);
+}
 int score_check(tm_dataset* d) {
   if (!d || !d->ws) return TM_OK;
   uint32_t err = 0;
