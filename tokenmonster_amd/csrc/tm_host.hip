@@ -151,7 +151,7 @@ static int lane_acquire(const tm_vocab* v, Lane** out) {
 // far socket every doorbell and every completion crosses the inter-socket link: the box-to-box spread of the host-to-host rate in rounds
 // 3 and 4 (27 - 34 GB/s for one library).  The workers of tm_tokenize_pipeline therefore run on the CPUs of the device's node for the length
 // of the call (the calling thread gets its own mask back); TM_NUMA=0 in the environment switches that off.
-struct NumaNear { int node = -1; cpu_set_t cpus; bool usable = false; };
+struct NumaNear { int node = -1; cpu_set_t cpus; bool pin = false; };      // cpus: the node's own list, as the kernel gives it; pin: TM_NUMA has not switched the moving of threads off
 static const NumaNear& numa_near(int device) {
   static std::mutex mu;
   static NumaNear table[64];
@@ -161,9 +161,11 @@ static const NumaNear& numa_near(int device) {
   if (device < 0 || device >= 64 || done[device]) return n;
   done[device] = true;
   CPU_ZERO(&n.cpus);
+  // (the node is read whatever TM_NUMA says: tm_device_numa_node reports it to callers that pin their own feeding threads; TM_NUMA=0 only
+  // keeps THIS library from moving threads)
   const char* off = getenv("TM_NUMA");
   char bdf[64] = {0};
-  if ((off && atoi(off) == 0) || hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return n; }
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return n; }
   for (char* c = bdf; *c; c++) *c = (char)tolower((unsigned char)*c);
   char path[160];
   snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
@@ -173,6 +175,7 @@ static const NumaNear& numa_near(int device) {
   if (fscanf(f, "%d", &node) != 1) node = -1;
   fclose(f);
   if (node < 0) return n;                        // (a one-node host, or a kernel that does not say)
+  n.node = node;
   snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
   if (!(f = fopen(path, "r"))) return n;
   char list[4096] = {0};
@@ -189,21 +192,23 @@ static const NumaNear& numa_near(int device) {
     for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &n.cpus); count++; }
     p = *end == ',' ? end + 1 : end;
   }
-  // only the CPUs this process may use at all (a container's cpuset): an empty intersection leaves everything as it is
-  cpu_set_t mine;
-  if (sched_getaffinity(0, sizeof mine, &mine) == 0) { CPU_AND(&n.cpus, &n.cpus, &mine); count = CPU_COUNT(&n.cpus); }
-  n.node = node;
-  n.usable = count > 0;
+  n.pin = count > 0 && !(off && atoi(off) == 0);
   return n;
 }
-// the calling thread on the CPUs near `device` while the object lives
+// the calling thread on the CPUs near `device` while the object lives - those of them the thread may use at all: the node's list is
+// intersected with the thread's OWN mask at every call (a container's cpuset, a caller's pinning of this thread: what one thread was
+// allowed at the first call says nothing about the next), and a thread that already runs on the node only (a caller's pinned feeder
+// thread) is left exactly where it is
 struct NearDevice {
   cpu_set_t before;
   bool changed = false;
   explicit NearDevice(int device) {
     const NumaNear& n = numa_near(device);
-    if (!n.usable || sched_getaffinity(0, sizeof before, &before) != 0) return;
-    changed = sched_setaffinity(0, sizeof n.cpus, &n.cpus) == 0;
+    if (!n.pin || sched_getaffinity(0, sizeof before, &before) != 0) return;
+    cpu_set_t want;
+    CPU_AND(&want, &n.cpus, &before);
+    if (CPU_COUNT(&want) == 0 || CPU_EQUAL(&want, &before)) return;       // nothing of the node is allowed / the thread is on the node already
+    changed = sched_setaffinity(0, sizeof want, &want) == 0;
   }
   ~NearDevice() { if (changed) (void)sched_setaffinity(0, sizeof before, &before); }
   NearDevice(const NearDevice&) = delete;

@@ -217,9 +217,9 @@ __device__ __forceinline__ int alt_penalty(int flen, uint32_t dS, int len) {
 // address ta) with the chain's string in one go.  Rare - a wavefront meets a handful of them - so all of it sits behind a wave-uniform test at
 // the call sites, and the lanes that are not `on` gather the always-empty entry.  Returns whether the lane's walk now stands on the chain's end
 // node, with *h = the record's header (link format: node | len << 20, value of the end node or 0, its child filter, its base word).
-__device__ __forceinline__ bool tail_compare(const char* __restrict__ tabb, uint32_t idle_off, bool on, uint32_t word, uint32_t ta, int room, uint4* h) {
+__device__ __forceinline__ bool tail_compare(const char* __restrict__ tabb, uint32_t idle_off, uint32_t last_rec, bool on, uint32_t word, uint32_t ta, int room, uint4* h) {
   typedef TM_LDS_SPACE_UNALIGNED uint32_t lds_u32u;
-  const char* rp = tabb + (on ? (size_t)tail_record(word) << 4 : (size_t)idle_off);
+  const char* rp = tabb + (on ? (size_t)min(tail_record(word), last_rec) << 4 : (size_t)idle_off);      // (clamped: tm_tables.h, last_rec)
   *h = *reinterpret_cast<const uint4*>(rp);
   const uint4 s0 = *reinterpret_cast<const uint4*>(rp + 16);
   const int len = (int)tail_len(h->x);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_match_branch(Tables T, const 
         // a round for the walks that stand at the head of a one-child chain (the others wait it out: rare)
         const bool on = k.tw != 0u;
         uint4 h;
-        const bool ok = tail_compare(tabb, idle_off, on, k.tw, TM_LDS_ADDR(w.text) + (uint32_t)(k.tbase + k.depth), k.limit - k.depth, &h);
+        const bool ok = tail_compare(tabb, idle_off, T.last_rec, on, k.tw, TM_LDS_ADDR(w.text) + (uint32_t)(k.tbase + k.depth), k.limit - k.depth, &h);
         if (on) {
           k.tw = 0u;
           if (ok) {

@@ -757,6 +757,7 @@ int tm_normalize(const uint8_t* data, size_t n, uint32_t capcode, uint32_t norm_
   std::vector<uint8_t> o;
   tmh::normalize_bytes(data, n, capcode, norm_flag, o);
   *out = (uint8_t*)std::malloc(o.size() ? o.size() : 1);
+  if (!*out) { *out_n = 0; return tmh::set_error(TM_E_HIP, "out of host memory (%zu bytes)", o.size()); }
   if (!o.empty()) std::memcpy(*out, o.data(), o.size());
   *out_n = o.size();
   return TM_OK;
@@ -771,6 +772,7 @@ int tm_denormalize(const uint8_t* data, size_t n, uint32_t capcode, uint8_t** ou
   else if (capcode == 1) tmh::nocapcode_decode_stream(st, data, n, o);
   else o.assign(data, data + n);
   *out = (uint8_t*)std::malloc(o.size() ? o.size() : 1);
+  if (!*out) { *out_n = 0; return tmh::set_error(TM_E_HIP, "out of host memory (%zu bytes)", o.size()); }
   if (!o.empty()) std::memcpy(*out, o.data(), o.size());
   *out_n = o.size();
   return TM_OK;

@@ -120,6 +120,9 @@ struct Tables {
   uint32_t spl_hint;       // b2 of letter-initial tokens is the forward-delete hint
   uint32_t link_off, direct_off;   // byte offsets of the suffix links / the direct map inside tab
                                    // (the chain records lie behind the suffix links; their entries name them by index: nothing here has to know where)
+  uint32_t last_rec;               // ... except where tab ENDS: the last entry index a chain record may begin at (three entries before the end).  A chain
+                                   // word is an index a walk dereferences as it finds it; the walker clamps it to this, so that a block whose contents
+                                   // do not belong to its description (a stale copy adopted by an importer) reads wrong bytes, not beyond the table.
 };
 
 }  // namespace tmh

@@ -602,6 +602,7 @@ static void set_tables(tm_vocab* v) {
   t.idle_off = hv.idle_off; t.n_da = hv.n_da; t.n_info = hv.n_info; t.max_len = hv.max_len;
   t.off = hv.off; t.bstart = hv.bstart; t.spl_hint = hv.spl_hint; t.link_off = hv.link_off; t.direct_off = hv.direct_off;
   t.has_delete = hv.delete_id != TM_NONE; t.delete_id = hv.delete_id; t.unk_id = hv.unk;
+  t.last_rec = (uint32_t)(v->part_bytes[1] / 16 >= 3 ? v->part_bytes[1] / 16 - 3 : 0);
 }
 
 // "current device" is a property of the calling OS thread; a caller whose threads are not its own (a goroutine under cgo) names the device
