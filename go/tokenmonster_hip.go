@@ -83,7 +83,9 @@ func (hv *HipVocab) Denormalize(b []byte) ([]byte, error) {
 		return nil, err
 	}
 	defer C.tm_free(unsafe.Pointer(out))
-	return C.GoBytes(unsafe.Pointer(out), C.int(n)), nil
+	res := make([]byte, int(n))
+	copy(res, unsafe.Slice((*byte)(unsafe.Pointer(out)), int(n))) // (not C.GoBytes: its length is a C int, and n is a size_t)
+	return res, nil
 }
 
 // LoadHip uploads the vocabulary file that Load (go/tokenmonster.go:2656) reads to `device`.

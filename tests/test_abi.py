@@ -30,6 +30,20 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert not hasattr(lib, n), "libtokenmonster_hip.so still exports the test-support symbol %s" % n
 
 
+def test_every_declared_symbol_has_a_go_binding():
+    """go/*.go (cgo, build tag `hip`) cannot be compiled here - no Go toolchain - but it can be kept in step: every tm_* symbol the public headers
+    declare is called somewhere in it, and it calls nothing the headers do not declare (a renamed or removed entry point shows up here)."""
+    godir = os.path.join(ROOT, "go")
+    src = "".join(open(os.path.join(godir, f)).read() for f in sorted(os.listdir(godir)) if f.endswith(".go"))
+    src = re.sub(r"//[^\n]*", "", src)
+    used = set(re.findall(r"\bC\.(tm_[a-z0-9_]+)\s*\(", src))
+    names = set(declared_symbols("tokenmonster_hip.h") + declared_symbols("tm_build.h"))
+    missing = sorted(names - used)
+    assert not missing, "no Go binding calls %s" % missing
+    unknown = sorted(used - names)
+    assert not unknown, "go/*.go calls %s, which no public header declares" % unknown
+
+
 def test_error_path_without_compute():
     # malformed .vocab is rejected before any device work
     h = C.c_void_p()
