@@ -63,6 +63,7 @@ struct RingSlot {
   uint8_t* h_pin = nullptr;
   uint64_t h_pin_cap = 0, docs_cap = 0;
   hipEvent_t up_done = nullptr, comp_done = nullptr, dl_done = nullptr;
+  const uint8_t* ids_at = nullptr;   // where the packed ids of the chunk in the slot lie (d_bytes, or the workspace's id buffer)
   uint64_t* h_status() const { return reinterpret_cast<uint64_t*>(h_pin); }
   uint64_t* h_roff() const { return reinterpret_cast<uint64_t*>(h_pin + 64); }
   uint64_t* h_toff() const { return reinterpret_cast<uint64_t*>(h_pin + 64 + (docs_cap + 2) * 8); }
@@ -630,7 +631,7 @@ static int pipeline_ring(PipeCall& c, const std::vector<Ring*>& rings) {
         const uint64_t seg_bound = (nb / 100 * slack_pct + 99) / SEG + nd + 1;
         s.h_status()[0] = ~0ull;
         if ((rc = ring_enqueue_normalize(b, cs, seg_bound)) != TM_OK) break;
-        if ((rc = ring_enqueue_tokenize(b, cs, c.enc, s.d_bytes, s.d_bytes_cap, s.h_status())) != TM_OK) break;
+        if ((rc = ring_enqueue_tokenize(b, cs, c.enc, s.d_bytes, s.d_bytes_cap, s.h_status(), &s.ids_at)) != TM_OK) break;
         if ((e = hipEventRecord(s.comp_done, cs)) != hipSuccess) { rc = hip_fail(e, "hipEventRecord"); break; }
         if (trace) fprintf(stderr, "[ring] issue chunk %3zu (%5.1f MiB, %u docs) slot %d at %7.2f ms, %.3f ms of launches\n", k, nb / 1048576.0, nd, si, ti0 - c.t0, now_ms() - ti0);
         issued++;
@@ -702,7 +703,7 @@ static int pipeline_ring(PipeCall& c, const std::vector<Ring*>& rings) {
       const uint64_t out_b = ntok * c.enc;
       const bool fits = (base + ntok) * c.enc <= c.bytes_cap && c.bytes_out;
       hipError_t e = hipSuccess;
-      if (fits && out_b) e = hipMemcpyAsync(c.bytes_out + base * c.enc, s.d_bytes, out_b, hipMemcpyDeviceToHost, r.down);
+      if (fits && out_b) e = hipMemcpyAsync(c.bytes_out + base * c.enc, s.ids_at, out_b, hipMemcpyDeviceToHost, r.down);
       if (e == hipSuccess) e = hipMemcpyAsync(s.h_toff(), s.ws->d_tok_offsets, ((uint64_t)nd + 1) * 8, hipMemcpyDeviceToHost, r.down);
       if (e == hipSuccess && c.missing) e = hipMemcpyAsync(s.h_missing(), s.ws->d_doc_missing, (uint64_t)nd * 4, hipMemcpyDeviceToHost, r.down);
       if (e == hipSuccess) e = hipEventRecord(s.dl_done, r.down);

@@ -1526,7 +1526,9 @@ __global__ __launch_bounds__(64) void k_emit_tiles(const uint32_t* __restrict__ 
 #endif
 constexpr int TSL = TM_K4_TSL, TSLACK_L = 4, TROW_L = SEG + 16;
 // WIDE: the ids of the row are u32 (vocabularies of more than 65 536 ids), else u16
-template <bool WIDE>
+// OUT16: the ids go out as 16 bits each - `out` is the serialized form of go/tokenmonster.go:1545 itself (a chunk of the host-to-host ring with
+// two-byte ids: no serializing pass behind K4, 1.6 GB less traffic per GiB of text)
+template <bool WIDE, bool OUT16 = false>
 __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R0, const uint2* __restrict__ side,
                                                   const uint32_t* __restrict__ R1, const uint4* __restrict__ par, uint64_t nseg,
                                                   uint32_t delete_id, uint64_t out_cap, uint32_t* __restrict__ out,
@@ -1545,6 +1547,8 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
   constexpr uint32_t SLACK = TSLACK_L;
   const uint8_t* rows_g = reinterpret_cast<const uint8_t*>(R0);
   typedef typename std::conditional<WIDE, uint32_t, uint16_t>::type idt;
+  typedef typename std::conditional<OUT16, uint16_t, uint32_t>::type outt;
+  outt* const outp = reinterpret_cast<outt*>(out);
   constexpr uint64_t RS = WIDE ? R0_WIDE : R0_NARROW, FO = WIDE ? 4 * SEG : 2 * SEG;      // bytes per row, where its flag plane begins
   {
     // lane l fetches the flag bytes of positions 4l .. 4l+3 of every row; all loads before the first LDS write
@@ -1625,13 +1629,13 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
             if (fits) {
               if (id != ID_NONE) {
                 // (the id of a forward-delete state is not in the row: it goes out here, and the slot is marked as written)
-                if (fd) { smap[E >> 5] |= 1u << (E & 31u); if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); }
+                if (fd) { smap[E >> 5] |= 1u << (E & 31u); if (t.base + E < out_cap) TM_STREAM_STORE(&outp[t.base + E], (outt)id); }
                 rowm[E++] = (uint8_t)p;
               }
               if (fdn) rowm[E++] = (uint8_t)p;
             } else {
-              if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], id); E++; }
-              if (fdn) { if (t.base + E < out_cap) TM_STREAM_STORE(&out[t.base + E], delete_id); E++; }
+              if (id != ID_NONE) { if (t.base + E < out_cap) TM_STREAM_STORE(&outp[t.base + E], (outt)id); E++; }
+              if (fdn) { if (t.base + E < out_cap) TM_STREAM_STORE(&outp[t.base + E], (outt)delete_id); E++; }
             }
             fd = fdn;
             p += adv;                                                      // (0 is possible: a one-byte alternative of a forward-delete state)
@@ -1679,7 +1683,7 @@ __global__ __launch_bounds__(64) void k_emit_list(const uint32_t* __restrict__ R
         const int s = s0 + k;
         const uint64_t base = s_base[s];
         const bool written = ((s_side[s][jj >> 5] >> (jj & 31u)) & 1u) != 0u;
-        if (j < s_n[s] && !written && base + j < out_cap) TM_STREAM_STORE(&out[base + j], idv[k]);
+        if (j < s_n[s] && !written && base + j < out_cap) TM_STREAM_STORE(&outp[base + j], (outt)idv[k]);
       }
     }
   }
@@ -2006,6 +2010,18 @@ __global__ void k_chunk_ctl(const unsigned long long* __restrict__ ninfo, uint32
   ctl[4] = ninfo[5];
   ctl[5] = ninfo[0];
 }
+// the verdict of a chunk whose ids K4 has packed itself (no k_serialize_ctl behind it)
+__global__ void k_chunk_done(const uint64_t* __restrict__ ctl, const uint64_t* __restrict__ totals, const uint32_t* __restrict__ error_flag, uint64_t out_cap,
+                             uint64_t* __restrict__ h_status) {
+  if (threadIdx.x != 0) return;
+  uint64_t st = ctl[3];
+  const uint64_t ntok = st ? 0ull : totals[1];
+  const uint32_t err = *error_flag;
+  if (!st && err) st |= RING_ERROR;
+  if (!st && ntok > out_cap) st |= RING_OUT_CAP;
+  h_status[1] = ntok; h_status[2] = ctl[4]; h_status[3] = ctl[0]; h_status[4] = err; h_status[5] = ctl[5];
+  h_status[0] = st;
+}
 // ids -> enc bytes each, the count worked out on the device (the status word of k_chunk_ctl the id total, the error word); sixteen ids per work-item, 16-byte stores (`out` 16-byte aligned)
 // ... and k_chunk_done's part with it (one launch less behind K4): every work-item works the count out for itself, the first one tells the host
 template <int ENC>
@@ -2156,6 +2172,9 @@ static void launch_emit(tm_batch* b, hipStream_t st, bool store, bool rezero = f
     if (!(debug_flags() & 32768) && !r0_narrow(b))             // (test hook 15: the id-staging form of the walk instead - for the larger vocabularies over one-plane rows)
       TM_LAUNCH(k_emit_list<true>, (uint32_t)((nseg + TSL - 1) / TSL), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
                                                                    b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b), b->d_ctl);
+    else if (!(debug_flags() & 32768) && store && b->d_out16)      // (a chunk of the ring with two-byte ids: K4 writes the serialized form itself)
+      TM_LAUNCH((k_emit_list<false, true>), (uint32_t)((nseg + TSL - 1) / TSL), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, b->out16_cap,
+                                                                           reinterpret_cast<uint32_t*>(b->d_out16), b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b), b->d_ctl);
     else if (!(debug_flags() & 32768))
       TM_LAUNCH(k_emit_list<false>, (uint32_t)((nseg + TSL - 1) / TSL), 64, 0, st, b->d_R0, b->d_side, b->d_R1, b->d_seg_par, nseg, b->vocab->tables.delete_id, store ? b->out_cap : 0, b->d_out,
                                                                    b->d_error, stage_after, b->d_seg_doc, b->d_doc_fd, b->d_doc_missing, r0_no_id(b), b->d_ctl);
@@ -2612,17 +2631,29 @@ void launch_serialize(const uint32_t* ids, uint64_t n, uint32_t enc, uint8_t* ou
 void launch_chunk_ctl(tm_batch* b, uint64_t seg_bound, hipStream_t st) {
   TM_LAUNCH(k_chunk_ctl, 1, 64, 0, st, (const unsigned long long*)b->d_ninfo, b->ndocs, b->max_bytes, seg_bound, b->d_ctl_store);
 }
-int ring_enqueue_tokenize(tm_batch* b, hipStream_t st, uint32_t enc, uint8_t* d_bytes, uint64_t d_bytes_cap, uint64_t* h_status) {
+int ring_enqueue_tokenize(tm_batch* b, hipStream_t st, uint32_t enc, uint8_t* d_bytes, uint64_t d_bytes_cap, uint64_t* h_status, const uint8_t** ids_at) {
   if (!b->d_ctl) return set_error(TM_E_INTERNAL, "ring_enqueue_tokenize: the workspace has no control words");
-  int rc = pipeline_match(b, st, nullptr);
-  if (rc == TM_OK) rc = pipeline_resolve(b, st, nullptr, 2);
-  if (rc != TM_OK) return rc;
   // (the ids that fit d_bytes: what K4 may store is bounded by out_cap, and the chunk is not taken when it needed more)
   const uint64_t cap_ids = std::min<uint64_t>(b->out_cap, d_bytes_cap / enc);
-  const uint32_t grid = (uint32_t)((cap_ids / 16 + 1 + 255) / 256);
-  if (enc == 2) TM_LAUNCH(k_serialize_ctl<2>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes, b->d_totals, b->d_error, cap_ids, h_status);
-  else if (enc == 3) TM_LAUNCH(k_serialize_ctl<3>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes, b->d_totals, b->d_error, cap_ids, h_status);
-  else TM_LAUNCH(k_serialize_ctl<4>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes, b->d_totals, b->d_error, cap_ids, h_status);
+  // Where the packed ids of the chunk end up.  Two bytes each from a vocabulary of at most 65 536 ids: K4 writes them that way itself
+  // (k_emit_list<false, true>).  Four bytes each: K4's uint32 ids ARE the packed form (an id has 24 bits, go :2089 writes a zero high byte).
+  // Otherwise (three bytes; two bytes cut from wider ids; the id-staging walk of test hook 15) a pass behind K4 packs them.
+  const bool direct16 = enc == 2 && r0_narrow(b) && !(debug_flags() & 32768);
+  const bool direct32 = enc == 4;
+  b->d_out16 = direct16 ? reinterpret_cast<uint16_t*>(d_bytes) : nullptr;
+  b->out16_cap = cap_ids;
+  int rc = pipeline_match(b, st, nullptr);
+  if (rc == TM_OK) rc = pipeline_resolve(b, st, nullptr, 2);
+  b->d_out16 = nullptr;
+  if (rc != TM_OK) return rc;
+  *ids_at = direct32 ? reinterpret_cast<const uint8_t*>(b->d_out) : d_bytes;
+  if (direct16 || direct32) TM_LAUNCH(k_chunk_done, 1, 64, 0, st, b->d_ctl, b->d_totals, b->d_error, cap_ids, h_status);
+  else {
+    const uint32_t grid = (uint32_t)((cap_ids / 16 + 1 + 255) / 256);
+    if (enc == 2) TM_LAUNCH(k_serialize_ctl<2>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes, b->d_totals, b->d_error, cap_ids, h_status);
+    else if (enc == 3) TM_LAUNCH(k_serialize_ctl<3>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes, b->d_totals, b->d_error, cap_ids, h_status);
+    else TM_LAUNCH(k_serialize_ctl<4>, grid, 256, 0, st, b->d_out, b->d_ctl, d_bytes, b->d_totals, b->d_error, cap_ids, h_status);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? TM_OK : hip_fail(e, "kernel launch");
 }

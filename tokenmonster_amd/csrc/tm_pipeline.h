@@ -181,6 +181,8 @@ struct tm_batch {
   uint64_t h_fb_raw_cap = 0, h_fb_norm_cap = 0;
   uint32_t* d_out = nullptr;
   uint64_t out_cap = 0;
+  uint16_t* d_out16 = nullptr;          // set for the length of a launch: K4 writes two-byte ids here instead (a chunk of the ring, launch_emit)
+  uint64_t out16_cap = 0;
   // a chunk of the host-to-host ring (tm_host.hip): what the host would have read back between the stages - the number of segments the normalizer
   // pass left, whether the chunk can be taken on this path at all, the number of ids - stays on the device in these control words, and the
   // kernels behind the pass are launched over a bound and look the counts up (d_ctl != null; k_chunk_ctl / k_chunk_done, tm_kernels.hip)
@@ -265,7 +267,8 @@ int ring_enqueue_normalize(tm_batch* b, hipStream_t st, uint64_t seg_bound);
 void launch_chunk_ctl(tm_batch* b, uint64_t seg_bound, hipStream_t st);
 // K0 .. K4, the ids packed to `enc` bytes into d_bytes (16-byte aligned), and the chunk's verdict written to `h_status` (page-locked host memory, 8 words:
 // status bits, ids, normalized bytes, segments, device error word)
-int ring_enqueue_tokenize(tm_batch* b, hipStream_t st, uint32_t enc, uint8_t* d_bytes, uint64_t d_bytes_cap, uint64_t* h_status);
+// *ids_at: where the packed ids lie when the stream gets there - d_bytes, or the workspace's own id buffer (four-byte ids need no packing)
+int ring_enqueue_tokenize(tm_batch* b, hipStream_t st, uint32_t enc, uint8_t* d_bytes, uint64_t d_bytes_cap, uint64_t* h_status, const uint8_t** ids_at);
 // tm_decode.hip: the stages of a decode on a stream, in buffers of the caller
 constexpr uint64_t DEC_HOST = ~0ull;      // k_dec_capcode's length of a document it leaves to the host decoder (scripts beyond Latin, malformed UTF-8)
 void launch_decode_lengths(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_toff, uint32_t ndocs, uint32_t* d_len, uint64_t* d_off,

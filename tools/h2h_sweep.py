@@ -13,7 +13,7 @@ raw, roffs = synth.synth_corpus(kind, 1024 << 20, seed=0x434F5250 + 2)
 pin_in = tm.PinnedBuffer(raw.size); pin_in.array[:] = raw
 pin_out = tm.PinnedBuffer(raw.size + 4096)
 settings = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or [(4, 32)]
-env = " ".join("%s=%s" % (k, os.environ[k]) for k in ("TM_RING", "TM_RING_SLOTS", "TM_RING_STREAMS", "TM_RING_SLACK", "GPU_MAX_HW_QUEUES") if k in os.environ)
+env = " ".join("%s=%s" % (k, os.environ[k]) for k in ("TM_RING", "TM_RING_SLOTS", "TM_RING_STREAMS", "TM_RING_SLACK", "TM_RING_FIRST_KIB", "TM_RING_RAMP", "GPU_MAX_HW_QUEUES") if k in os.environ)
 for lanes, chunk in settings:
     for _ in range(6):
         v.tokenize_pipeline(pin_in.array, roffs, raw=True, chunk_bytes=chunk << 20, lanes=lanes, out=pin_out.array)
