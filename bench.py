@@ -405,11 +405,12 @@ def bench_decode(args, rank, local_rank, world, vocab, img, kind, capcode, norm_
         N.check(N.lib.tm_batch_decode_timed(batch, 0, C.c_void_p(stream), C.byref(nbytes), C.byref(host_docs), ms))
         acc += np.array(list(ms))
     acc /= 3
-    stage_ms = {"lengths_scan": round(float(acc[0]), 4), "k_dec_copy": round(float(acc[1]), 4), "k_dec_capcode": round(float(acc[2]), 4)}
-    # algorithmic bytes of each stage: the gather reads 4T of ids and 8T of offsets and writes the encoded text once (the tokens' bytes
-    # come out of a 0.3 MB table that stays in the caches); the capcode decoder reads the encoded text once and writes the decoded text once
+    stage_ms = {"tile_lengths_scan": round(float(acc[0]), 4), "k_dec_gather": round(float(acc[1]), 4), "k_dec_capcode": round(float(acc[2]), 4)}
+    # algorithmic bytes of each stage: the byte counts of the tiles read the ids once (4T; the key lengths come out of a table of n_ids + 1 words that
+    # stays in the caches, and what is written is one word per 2048 ids); the gather reads them once more and writes the encoded text once (the keys
+    # come out of a 0.3 MB table); the capcode decoder reads the encoded text once and writes the decoded text once
     T, n_enc = float(ntok.value), float(enc_bytes)
-    alg = {"lengths_scan": 4 * T + 4 * T + 4 * T + 8 * T, "k_dec_copy": 4 * T + 8 * T + n_enc, "k_dec_capcode": n_enc + out_bytes}
+    alg = {"tile_lengths_scan": 4 * T, "k_dec_gather": 4 * T + n_enc, "k_dec_capcode": n_enc + out_bytes}
     dom = max(stage_ms, key=lambda k: stage_ms[k])
     achieved = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
     verified, verified_ref = None, None
@@ -455,15 +456,14 @@ def bench_decode(args, rank, local_rank, world, vocab, img, kind, capcode, norm_
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s vocabulary shape (synthetic, %d ids); the uint32 ids of %d MiB of raw synthetic mixed text per GPU (%d documents, %d ids) resident in HBM "
-                                   "-> decoded text in HBM (tm_batch_decode: lengths, scan, gather, capcode decoding)" % (args.config, vocab.n_ids(), args.mbytes, ndocs, int(T)),
+                                   "-> decoded text in HBM (tm_batch_decode: byte counts of the tiles of ids, scan, gather through LDS, capcode decoding)" % (args.config, vocab.n_ids(), args.mbytes, ndocs, int(T)),
                        "ids_per_gpu": int(T), "encoded_bytes_per_gpu": int(n_enc), "decoded_bytes_per_gpu": int(out_bytes), "host_decoded_docs": int(host_docs.value),
                        "parallelism": "documents sharded by rank, no collective", "rccl_ranks": dist.get_world_size() if world > 1 else 0,
                        "verified_docs_round_trip": verified, "verified_docs_vs_reference": verified_ref},
             "stage_ms": stage_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": None, "algorithmic_bytes_per_launch": alg[dom],
-                         "algorithmic_bytes_note": "k_dec_copy: 4T ids + 8T byte offsets read, encoded text written once; k_dec_capcode: encoded text read, decoded text written; "
-                                                   "lengths_scan: ids read, lengths written and read, offsets written",
+                         "algorithmic_bytes_note": "tile_lengths_scan: 4T ids read; k_dec_gather: 4T ids read, encoded text written once; k_dec_capcode: encoded text read, decoded text written",
                          "whole_pass": {"algorithmic_bytes": e2e_alg, "achieved": round(e2e_alg / (elapsed / args.steps) / 1e9, 3),
                                         "frac": round(e2e_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6), "note": "4T + 2 N_out over the whole step"}},
             "cpu_baseline": cpu,

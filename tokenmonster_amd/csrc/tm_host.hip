@@ -1003,12 +1003,11 @@ int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* t
   hipStream_t st = l->stream;
   hipError_t e = hipSuccess;
   const bool dev_capcode = !raw && v->host.capcode == 2 && v->host.charset == 1 && ndocs > 0;
-  // arena A: ids | document offsets | lengths | byte offset of every id | scan block sums | total | byte offset of every document | decoded lengths
+  // arena A: ids | document offsets | the decode's own words (dec_arena: tiles of ids, byte offset / decoded length of every document)
   auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
-  const uint64_t sblocks = (n + 1 + SCAN_CH - 1) / SCAN_CH + 2;
-  const uint64_t o_tok = 0, o_toff = o_tok + up((n + 1) * 4), o_len = o_toff + up(((uint64_t)ndocs + 1) * 8), o_off = o_len + up((n + 1) * 4),
-                 o_sums = o_off + up((n + 2) * 8), o_total = o_sums + up(sblocks * 8), o_doff = o_total + 256, o_declen = o_doff + up(((uint64_t)ndocs + 1) * 8),
-                 a_bytes = o_declen + up((uint64_t)ndocs * 8 + 8);
+  const uint64_t o_tok = 0, o_toff = o_tok + up((n + 1) * 4);
+  const DecArena a = dec_arena(o_toff + up(((uint64_t)ndocs + 1) * 8), n, ndocs);
+  const uint64_t a_bytes = a.bytes;
   std::vector<uint64_t> doff((size_t)ndocs + 1, 0), declen;
   uint64_t total = 0;
   bool need_raw = !dev_capcode;
@@ -1016,9 +1015,8 @@ int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* t
   do {
     if ((rc = dev_grow(&l->d_dec_a, &l->d_dec_a_cap, a_bytes, "hipMalloc (decode)")) != TM_OK) break;
     uint8_t* A = l->d_dec_a;
-    uint32_t* d_tok = (uint32_t*)(A + o_tok); uint64_t* d_toff = (uint64_t*)(A + o_toff); uint32_t* d_len = (uint32_t*)(A + o_len);
-    uint64_t* d_off = (uint64_t*)(A + o_off); uint64_t* d_sums = (uint64_t*)(A + o_sums); uint64_t* d_total = (uint64_t*)(A + o_total);
-    uint64_t* d_doff = (uint64_t*)(A + o_doff); uint64_t* d_declen = (uint64_t*)(A + o_declen);
+    uint32_t* d_tok = (uint32_t*)(A + o_tok); uint64_t* d_toff = (uint64_t*)(A + o_toff);
+    uint64_t* d_total = (uint64_t*)(A + a.o_total); uint64_t* d_doff = (uint64_t*)(A + a.o_doff); uint64_t* d_declen = (uint64_t*)(A + a.o_declen);
     // ids and offsets through pinned staging (the caller's buffers are pageable Go / Python memory)
     const uint64_t in_bytes = n * 4 + ((uint64_t)ndocs + 1) * 8;
     if ((rc = stage_grow(&l->h_stage_in, &l->h_in_cap, in_bytes)) != TM_OK) break;
@@ -1026,42 +1024,43 @@ int tm_decode_batch(const tm_vocab* v, const uint32_t* tokens, const uint64_t* t
     if (n) std::memcpy(l->h_stage_in + ((uint64_t)ndocs + 1) * 8, tokens, n * 4);
     if ((e = hipMemcpyAsync(d_toff, l->h_stage_in, ((uint64_t)ndocs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
         (n && (e = hipMemcpyAsync(d_tok, l->h_stage_in + ((uint64_t)ndocs + 1) * 8, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess)) { rc = hip_fail(e, "H2D tokens"); break; }
-    launch_decode_lengths(v, d_tok, n, d_toff, ndocs, d_len, d_off, d_sums, d_total, d_doff, st);
-    if ((rc = lane_stage(l, 8 + ((uint64_t)ndocs + 1) * 8)) != TM_OK) break;
-    if ((rc = d2h(l->h_stage, d_total, 8, st, "decode lengths")) != TM_OK || (rc = d2h(l->h_stage + 8, d_doff, ((uint64_t)ndocs + 1) * 8, st, "decode lengths")) != TM_OK) break;
+    launch_decode_lengths(v, d_tok, n, d_toff, ndocs, a, A, st);
+    if ((rc = lane_stage(l, 8)) != TM_OK) break;
+    if ((rc = d2h(l->h_stage, d_total, 8, st, "decode lengths")) != TM_OK) break;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; }
     std::memcpy(&total, l->h_stage, 8);
-    std::memcpy(doff.data(), l->h_stage + 8, doff.size() * 8);
     // arena B: the gathered bytes | the same after capcode decoding (out of place: the host decoder needs the others as they were)
     const uint64_t o_dec = up(total + 16);
     if ((rc = dev_grow(&l->d_dec_b, &l->d_dec_b_cap, o_dec + up(total + 16), "hipMalloc (decode output)")) != TM_OK) break;
     uint8_t* d_out = l->d_dec_b; uint8_t* d_dec = l->d_dec_b + o_dec;
-    launch_decode_copy(v, d_tok, n, d_off, d_out, st);
-    uint64_t h_need = total + 16;
+    launch_decode_copy(v, d_tok, n, d_toff, ndocs, a, A, d_out, st);
     if (dev_capcode) {
-      if ((rc = launch_decode_capcode(v, d_out, d_doff, ndocs, d_dec, d_declen, st)) != TM_OK) break;
+      if ((rc = launch_decode_capcode(v, d_out, d_doff, ndocs, d_dec, d_declen, d_total + 8, st)) != TM_OK) break;
       declen.resize(ndocs);
-      h_need = up((uint64_t)ndocs * 8) + 2 * up(total + 16);
     }
-    if ((rc = lane_stage(l, h_need)) != TM_OK) break;
+    // staging: the documents' byte offsets (they come out of the gather) | decoded lengths | decoded text | gathered bytes
+    const uint64_t s_doff = 0, s_declen = up(((uint64_t)ndocs + 1) * 8), s_text = s_declen + up((uint64_t)ndocs * 8 + 8), s_raw = s_text + up(total + 16);
+    if ((rc = lane_stage(l, s_raw + up(total + 16))) != TM_OK) break;
+    if ((rc = d2h(l->h_stage + s_doff, d_doff, ((uint64_t)ndocs + 1) * 8, st, "decode offsets")) != TM_OK) break;
     if (dev_capcode) {
-      uint8_t* hp = l->h_stage + up((uint64_t)ndocs * 8);
-      if ((rc = d2h(l->h_stage, d_declen, (uint64_t)ndocs * 8, st, "D2H decoded text")) != TM_OK || (rc = d2h(hp, d_dec, total, st, "D2H decoded text")) != TM_OK) break;
+      uint8_t* hp = l->h_stage + s_text;
+      if ((rc = d2h(l->h_stage + s_declen, d_declen, (uint64_t)ndocs * 8, st, "D2H decoded text")) != TM_OK || (rc = d2h(hp, d_dec, total, st, "D2H decoded text")) != TM_OK) break;
       if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; }
-      std::memcpy(declen.data(), l->h_stage, (uint64_t)ndocs * 8);
+      std::memcpy(declen.data(), l->h_stage + s_declen, (uint64_t)ndocs * 8);
       h_dec = hp;
       for (uint32_t d = 0; d < ndocs && !need_raw; d++) need_raw = declen[d] == DEC_HOST;
       if (need_raw) {
-        uint8_t* hr = hp + up(total + 16);
+        uint8_t* hr = l->h_stage + s_raw;
         if ((rc = d2h(hr, d_out, total, st, "D2H decoded bytes")) != TM_OK) break;
         if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; }
         h_raw = hr;
       }
     } else {
-      if ((rc = d2h(l->h_stage, d_out, total, st, "D2H decoded bytes")) != TM_OK) break;
+      if ((rc = d2h(l->h_stage + s_raw, d_out, total, st, "D2H decoded bytes")) != TM_OK) break;
       if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; }
-      h_raw = l->h_stage;
+      h_raw = l->h_stage + s_raw;
     }
+    std::memcpy(doff.data(), l->h_stage + s_doff, doff.size() * 8);
   } while (false);
   if (rc != TM_OK) (void)hipStreamSynchronize(st);      // nothing of this call may still be in flight when the lane goes back
   if (rc == TM_OK) {

@@ -75,6 +75,27 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 #endif
 }
+// The value another lane holds as an operand of this lane's next instruction (a DPP move: no LDS round trip).  ctrl: 0x110 + n = row_shr:n
+// (rows of 16 lanes), 0x138 = wave_shr:1, 0x130 = wave_shl:1, 0x142 / 0x143 = row_bcast:15 / row_bcast:31; rows: which rows of 16 lanes take part.
+// A lane without a source - shifted in from outside its row / the wavefront, or in a row that does not take part - keeps `old`.
+#ifdef TM_EMU
+static inline uint32_t tm_dpp_emu(uint32_t old, uint32_t src, int ctrl, int rows) {
+  const int lane = (int)emu::cur->lane, row = lane >> 4;
+  int from = lane; bool have = false;
+  if (ctrl > 0x110 && ctrl <= 0x11F) { from = lane - (ctrl - 0x110); have = (lane & 15) >= ctrl - 0x110; }
+  else if (ctrl == 0x138) { from = lane - 1; have = lane >= 1; }
+  else if (ctrl == 0x130) { from = lane + 1; have = lane < 63; }
+  else if (ctrl == 0x142) { from = row * 16 - 1; have = row >= 1; }
+  else if (ctrl == 0x143) { from = 31; have = row >= 2; }
+  const uint32_t v = __shfl(src, from & 63);
+  return (have && ((rows >> row) & 1)) ? v : old;
+}
+#define TM_DPP(old, src, ctrl, rows) tm_dpp_emu(old, src, ctrl, rows)
+#define TM_DPP0(src, ctrl) tm_dpp_emu(0u, src, ctrl, 0xF)
+#else
+#define TM_DPP(old, src, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, rows, 0xF, false))
+#define TM_DPP0(src, ctrl) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(src), ctrl, 0xF, 0xF, true))      // all rows; a lane without a source gets 0 (bound_ctrl: no `old` to set up)
+#endif
 // A wavefront's window on global memory: a buffer resource (base and size wave-uniform), so that the range check is the hardware's - a dword
 // load outside [base, base + bytes) returns 0 and costs no branch and no 64-bit compare (offsets are unsigned: "before the window" is
 // outside too).  `bytes` a multiple of 4 and offsets multiples of 4, so that no dword is partly inside.
@@ -82,10 +103,16 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) {
 struct TmWindow { const uint8_t* base; uint32_t bytes; };
 static inline TmWindow tm_window(const void* base, uint32_t bytes) { return TmWindow{(const uint8_t*)base, bytes}; }
 static inline uint32_t tm_window_u32(const TmWindow& w, uint32_t off) { uint32_t v = 0; if (off < w.bytes && w.bytes - off >= 4u) __builtin_memcpy(&v, w.base + off, 4); return v; }
+static inline uint4 tm_window_u128(const TmWindow& w, uint32_t off) { return uint4{tm_window_u32(w, off), tm_window_u32(w, off + 4), tm_window_u32(w, off + 8), tm_window_u32(w, off + 12)}; }
 #else
 typedef __amdgpu_buffer_rsrc_t TmWindow;
 __device__ __forceinline__ TmWindow tm_window(const void* base, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000); }
 __device__ __forceinline__ uint32_t tm_window_u32(TmWindow w, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(w, (int)off, 0, 0); }
+__device__ __forceinline__ uint4 tm_window_u128(TmWindow w, uint32_t off) {      // four dwords, each range-checked by itself
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_amdgcn_raw_buffer_load_b128(w, (int)off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 #endif
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask, uint32_t acc) {      // acc + #set bits of mask below the lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, acc));
@@ -271,10 +298,24 @@ void launch_chunk_ctl(tm_batch* b, uint64_t seg_bound, hipStream_t st);
 int ring_enqueue_tokenize(tm_batch* b, hipStream_t st, uint32_t enc, uint8_t* d_bytes, uint64_t d_bytes_cap, uint64_t* h_status, const uint8_t** ids_at);
 // tm_decode.hip: the stages of a decode on a stream, in buffers of the caller
 constexpr uint64_t DEC_HOST = ~0ull;      // k_dec_capcode's length of a document it leaves to the host decoder (scripts beyond Latin, malformed UTF-8)
-void launch_decode_lengths(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_toff, uint32_t ndocs, uint32_t* d_len, uint64_t* d_off,
-                           uint64_t* d_sums, uint64_t* d_total, uint64_t* d_doff, hipStream_t st);
-void launch_decode_copy(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_off, uint8_t* d_out, hipStream_t st);
-int launch_decode_capcode(const tm_vocab* v, const uint8_t* d_out, const uint64_t* d_doff, uint32_t ndocs, uint8_t* d_dec, uint64_t* d_declen, hipStream_t st);
+// the arena of a decode behind `base` bytes of the caller's own: byte counts of the tiles of ids (tm_decode.hip) | first document of a tile | byte offset of a
+// tile | scan block sums | total | byte offset of every document | decoded length of every document
+struct DecArena { uint64_t ntiles, o_len, o_first, o_off, o_sums, o_total, o_doff, o_declen, bytes; };
+constexpr uint32_t DEC_TILE_IDS = 2048;
+inline DecArena dec_arena(uint64_t base, uint64_t n, uint32_t ndocs) {
+  auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
+  DecArena a;
+  a.ntiles = (n + DEC_TILE_IDS - 1) / DEC_TILE_IDS;
+  const uint64_t sblocks = (a.ntiles + 1 + SCAN_CH - 1) / SCAN_CH + 2;
+  a.o_len = up(base); a.o_first = a.o_len + up((a.ntiles + 1) * 4); a.o_off = a.o_first + up((a.ntiles + 1) * 4); a.o_sums = a.o_off + up((a.ntiles + 2) * 8);
+  a.o_total = a.o_sums + up(sblocks * 8); a.o_doff = a.o_total + 256; a.o_declen = a.o_doff + up(((uint64_t)ndocs + 1) * 8); a.bytes = a.o_declen + up((uint64_t)ndocs * 8 + 8);
+  return a;
+}
+// lengths: the bytes of every tile and their scan (the total at A + a.o_total); copy: the gather itself and the documents' byte offsets (A + a.o_doff)
+void launch_decode_lengths(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_toff, uint32_t ndocs, const DecArena& a, uint8_t* A, hipStream_t st);
+void launch_decode_copy(const tm_vocab* v, const uint32_t* d_tok, uint64_t n, const uint64_t* d_toff, uint32_t ndocs, const DecArena& a, uint8_t* A, uint8_t* d_out, hipStream_t st);
+// d_sums: two words the kernel adds up - bytes the device decoded, documents it left to the host decoder
+int launch_decode_capcode(const tm_vocab* v, const uint8_t* d_out, const uint64_t* d_doff, uint32_t ndocs, uint8_t* d_dec, uint64_t* d_declen, uint64_t* d_sums, hipStream_t st);
 // tm_host.hip: tm_tokenize_pipeline over the lanes of one vocabulary or of its replicas on several devices
 int tokenize_pipeline_on(const tm_vocab* const* vs, uint32_t nv, const uint8_t* text, const uint64_t* offsets, uint32_t ndocs, int raw, uint32_t encoding_length,
                          uint64_t chunk_bytes, uint32_t lanes, uint8_t* bytes_out, uint64_t bytes_cap, uint64_t* byte_offsets, uint32_t* missing,
