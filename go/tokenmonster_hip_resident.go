@@ -509,6 +509,22 @@ func LoadHipCurrent(image []byte) (*HipVocab, error) {
 	}
 	return &HipVocab{h: h, len: int(C.tm_vocab_size(h))}, nil
 }
+
+// LoadHipCurrentSample is LoadHipCurrent with the tables laid out by use from the start (tm_vocab_load_sample): normalizedSample is a few MiB of
+// the text the vocabulary will be used on, as Normalize writes it.  Results are the same; the match kernel is ~5 % faster with 100 000 ids.
+func LoadHipCurrentSample(image []byte, normalizedSample []byte) (*HipVocab, error) {
+	var h *C.tm_vocab
+	var p *C.uint8_t
+	if len(normalizedSample) > 0 {
+		p = (*C.uint8_t)(unsafe.Pointer(&normalizedSample[0]))
+	}
+	if _, err := locked(func() C.int {
+		return C.tm_vocab_load_sample((*C.uint8_t)(unsafe.Pointer(&image[0])), C.size_t(len(image)), p, C.uint64_t(len(normalizedSample)), &h)
+	}); err != nil {
+		return nil, err
+	}
+	return &HipVocab{h: h, len: int(C.tm_vocab_size(h))}, nil
+}
 func UploadDatasetCurrent(normalized []byte) (*HipDataset, error) {
 	var d *C.tm_dataset
 	if _, err := locked(func() C.int { return C.tm_dataset_upload((*C.uint8_t)(unsafe.Pointer(&normalized[0])), C.uint64_t(len(normalized)), &d) }); err != nil {

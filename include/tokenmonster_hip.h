@@ -70,6 +70,10 @@ void tm_vocab_free(tm_vocab* v);
  * unchanged (only internal node numbers move); nothing else of this vocabulary may run meanwhile, and the call waits for what already does.
  * Not for vocabularies made by tm_vocab_block_import (no records).  Cost: about as long as loading the vocabulary + 0.2 s per MiB of sample. */
 int tm_vocab_tune(tm_vocab* v, const uint8_t* normalized_sample, uint64_t n);
+/* tm_vocab_load + tm_vocab_tune in one: the caller hands a sample of normalized text with the file and the tables are built for the device once,
+ * laid out by use from the start (current device; sample_n == 0: plain tm_vocab_load).  Measured on one MI355X, 1 GiB (profiles/r06_tuned_tables.txt):
+ * match kernel -1 % with 32 000 ids (6 MB of tables), -5 % with 100 256 ids (16 MB) and on the 65 536-id scoring pass. */
+int tm_vocab_load_sample(const uint8_t* vocab_file, size_t n, const uint8_t* normalized_sample, uint64_t sample_n, tm_vocab** out);
 /* The device block of a vocabulary from process to process (the data-parallel scoring mode: ONE rank builds a candidate's tables, the others
  * take the finished block - e.g. as the destination of an RCCL broadcast - instead of repeating tm_build_vocab + tm_vocab_load).
  * tm_vocab_block_export describes the block of `v` (plain data: send it as bytes) and returns its device pointer; tm_vocab_block_import makes
@@ -220,8 +224,8 @@ const uint64_t* tm_batch_device_tok_offsets(const tm_batch* b);
 uint64_t tm_batch_device_bytes(const tm_batch* b);
 
 /* ---- decode: Decode / decode_raw (go/tokenmonster.go:445-550; tokenmonster.cpp:1404-1425) ------------------------ */
-/* ids of document d = tokens[tok_offsets[d] .. tok_offsets[d+1]).  The gather of reverse[id] (lengths -> scan -> copy)
- * runs on the device; ids >= tm_vocab_n_ids are skipped.  raw != 0: the concatenated token bytes as they are
+/* ids of document d = tokens[tok_offsets[d] .. tok_offsets[d+1]).  The gather of reverse[id] (byte counts of tiles of 2048 ids -> scan -> gather
+ * through LDS) runs on the device; ids >= tm_vocab_n_ids are skipped.  raw != 0: the concatenated token bytes as they are
  * (decode_raw); raw == 0: capcode decoding (javascript/tokenmonster.js:1007-1065) follows — on the device for the documents of a capcode-2
  * UTF-8 vocabulary made of ASCII, the two-byte scripts (U+0080..U+07FF), the three-byte characters without case (punctuation, CJK, kana,
  * Hangul, symbols) and the four-byte characters of blocks that are caseless throughout (emoji, symbols, the ideographs of plane 2); on the
@@ -239,8 +243,8 @@ uint32_t tm_decode_host_docs(void);
  * (those are decoded by tm_batch_decoded_download, which returns every document's text in document order - out_offsets[ndocs+1] always
  * filled, TM_E_NOSPACE with the size required in out_offsets[ndocs] if out_cap is too small). */
 int tm_batch_decode(tm_batch* b, int raw, void* stream, uint64_t* decoded_bytes, uint32_t* host_docs);
-/* ... with HIP events on `stream` around its stages: ms[0] lengths + scan + document offsets, ms[1] the gather of the tokens' bytes
- * (k_dec_copy), ms[2] capcode decoding (k_dec_capcode; 0 when that is not the device's) - what bench.py's decode line prices its roofline on */
+/* ... with HIP events on `stream` around its stages: ms[0] byte counts of the tiles + scan, ms[1] the gather of the tokens' bytes and the documents'
+ * offsets (k_dec_gather), ms[2] capcode decoding (k_dec_capcode; 0 when that is not the device's) - what bench.py's decode line prices its roofline on */
 int tm_batch_decode_timed(tm_batch* b, int raw, void* stream, uint64_t* decoded_bytes, uint32_t* host_docs, float* ms);
 int tm_batch_decoded_download(tm_batch* b, uint8_t* out, uint64_t out_cap, uint64_t* out_offsets);
 

@@ -366,6 +366,19 @@ def test_tables_laid_out_by_use_give_the_same_results(capcode, charset):
     a, ao = plain.decode_packed(ids0, toff0, raw=True)
     b, bo = tuned.decode_packed(ids0, toff0, raw=True)
     assert (a == b).all() and (ao == bo).all()
+    # tm_vocab_load_sample: the layout by use from the start (also with an empty sample = plain tm_vocab_load)
+    for sample in (b"".join(docs[:40]), b""):
+        v = tm.Vocab(img, sample=np.frombuffer(sample, dtype=np.uint8))
+        got_ids, got_miss = v.tokenize_normalized(docs)
+        assert all(g.size == e.size and (g == e).all() for g, e in zip(got_ids, exp_ids)) and (got_miss == exp_miss).all()
+        s = _score(v, data)
+        assert (s[0] == exp_score[0]).all() and s[1] == exp_score[1] and (s[2] == exp_score[2]).all()
+        assert v.image() == plain.image()
+        b, bo = v.decode_packed(ids0, toff0, raw=True)
+        assert (a == b).all() and (ao == bo).all()
+        v.tune(text(50_000))                    # ... and laid out once more on another sample
+        got_ids, got_miss = v.tokenize_normalized(docs)
+        assert all(g.size == e.size and (g == e).all() for g, e in zip(got_ids, exp_ids)) and (got_miss == exp_miss).all()
 
 
 def _pinned_copy(a):

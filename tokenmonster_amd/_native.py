@@ -33,6 +33,7 @@ SIGNATURES = {
     "tm_device_copy": (C.c_int, [vp, vp, C.c_uint64]),
     "tm_vocab_free": (None, [vp]),
     "tm_vocab_tune": (C.c_int, [vp, vp, C.c_uint64]),
+    "tm_vocab_load_sample": (C.c_int, [vp, C.c_size_t, vp, C.c_uint64, C.POINTER(vp)]),
     "tm_vocab_set_tune": (C.c_int, [vp, vp, C.c_uint64]),
     "tm_vocab_size": (C.c_uint32, [vp]),
     "tm_vocab_n_info": (C.c_uint32, [vp]),

@@ -344,8 +344,11 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
     }
     {
       const size_t first_rec = ((size_t)hv.n_da + 1) + kL2Size + n_nodes;      // in 16-byte entries: double array | empty entry | direct map | links | records
+      // (in the order of the node ids the tables carry: under a layout by use the records of the chains that are taken most lie together)
+      std::vector<uint32_t> by_id(n_nodes);
+      for (uint32_t n = 0; n < n_nodes; n++) by_id[P(n)] = n;
       uint32_t nrec = 0;
-      for (uint32_t n = 0; n < n_nodes; n++)
+      for (uint32_t n : by_id)
         if (depth_of[n] >= 2 && chain[n] >= kTailMin) tailw[n] = kTailFlag | (uint32_t)(first_rec + 3 * (size_t)nrec++);
       n_tail_records = nrec;
     }
@@ -778,6 +781,22 @@ static void count_node_use(const HostVocab& hv, const uint8_t* text, uint64_t n,
   }
 }
 
+// the host tables of hv (in the trie's own numbering) once more, laid out by their use on `sample`
+static int layout_by_use(HostVocab& hv, const Trie& trie, const uint8_t* sample, uint64_t n) {
+  std::vector<uint64_t> use;
+  count_node_use(hv, sample, n, use);
+  // accepting nodes among themselves (they index the rows and space-prefix links too), the others among themselves; ties keep their order
+  std::vector<uint32_t> order(hv.n_nodes), perm(hv.n_nodes);
+  for (uint32_t i = 0; i < hv.n_nodes; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.begin() + hv.n_info, [&](uint32_t a, uint32_t b) { return use[a] > use[b]; });
+  std::stable_sort(order.begin() + hv.n_info, order.end(), [&](uint32_t a, uint32_t b) { return use[a] > use[b]; });
+  for (uint32_t i = 0; i < hv.n_nodes; i++) perm[order[i]] = i;
+  const uint32_t n_da = hv.n_da;
+  int rc = build_tables(hv, trie, &perm);
+  if (rc == TM_OK && hv.n_da != n_da) rc = set_error(TM_E_INTERNAL, "the double array changed size under a renumbering of the nodes");
+  return rc;
+}
+
 extern "C" int tm_vocab_tune(tm_vocab* v, const uint8_t* normalized_sample, uint64_t n) {
   if (!v || (n && !normalized_sample)) return set_error(TM_E_INVALID, "null argument");
   HostVocab& hv = v->host;
@@ -789,25 +808,34 @@ extern "C" int tm_vocab_tune(tm_vocab* v, const uint8_t* normalized_sample, uint
   int rc = build_trie(hv, trie, nullptr);
   if (rc == TM_OK && v->tuned) rc = build_tables(hv, trie);            // count over the trie's own numbering
   if (rc != TM_OK) return rc;
-  std::vector<uint64_t> use;
-  count_node_use(hv, normalized_sample, n, use);
-  // accepting nodes among themselves (they index the rows and space-prefix links too), the others among themselves; ties keep their order
-  std::vector<uint32_t> order(hv.n_nodes), perm(hv.n_nodes);
-  for (uint32_t i = 0; i < hv.n_nodes; i++) order[i] = i;
-  std::stable_sort(order.begin(), order.begin() + hv.n_info, [&](uint32_t a, uint32_t b) { return use[a] > use[b]; });
-  std::stable_sort(order.begin() + hv.n_info, order.end(), [&](uint32_t a, uint32_t b) { return use[a] > use[b]; });
-  for (uint32_t i = 0; i < hv.n_nodes; i++) perm[order[i]] = i;
-  const uint32_t n_da = hv.n_da;
   // The host tables are rewritten in place; whatever goes wrong from here on, host and device must describe the SAME layout when the call
   // returns (a later tm_vocab_block_export, a replica adopting the block or a second tune replays the host's view): on a failure the
   // natural layout is rebuilt and uploaded, and the error of the failed step is what the caller sees.
-  rc = build_tables(hv, trie, &perm);
-  if (rc == TM_OK && hv.n_da != n_da) rc = set_error(TM_E_INTERNAL, "the double array changed size under a renumbering of the nodes");
+  rc = layout_by_use(hv, trie, normalized_sample, n);
   if (rc == TM_OK) rc = reupload_tables(v);
   if (rc == TM_OK) { v->tuned = true; return TM_OK; }
   const std::string keep = last_error();
   if (build_tables(hv, trie) == TM_OK && reupload_tables(v) == TM_OK) v->tuned = false;
   return set_error(rc, "%s", keep.c_str());
+}
+
+// tm_vocab_load with the layout by use from the start: the tables are written for the device once, in the order the sample asks for
+extern "C" int tm_vocab_load_sample(const uint8_t* vocab_file, size_t n, const uint8_t* normalized_sample, uint64_t sample_n, tm_vocab** out) {
+  if (!vocab_file || !out || (sample_n && !normalized_sample)) return set_error(TM_E_INVALID, "null argument");
+  *out = nullptr;
+  auto* v = new tm_vocab();
+  int rc = parse_vocab(vocab_file, n, v->host);
+  if (rc == TM_OK && sample_n) {
+    Trie trie;
+    rc = build_trie(v->host, trie, nullptr);
+    if (rc == TM_OK) rc = layout_by_use(v->host, trie, normalized_sample, sample_n);
+    if (rc == TM_OK) v->tuned = true;
+  }
+  if (rc != TM_OK) { delete v; return rc; }
+  v->host.image.assign(vocab_file, vocab_file + n);
+  if ((rc = upload_tables(v)) != TM_OK) return rc;       // (frees v on failure)
+  *out = v;
+  return TM_OK;
 }
 
 int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* m, void** device_ptr) {

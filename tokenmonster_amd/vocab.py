@@ -30,11 +30,16 @@ class VocabBlock(C.Structure):
 
 
 class Vocab:
-    def __init__(self, image):
+    def __init__(self, image, sample=None):
+        """tm_vocab_load; with `sample` (normalized text the vocabulary will be used on) tm_vocab_load_sample: tables laid out by use from the start"""
         self._image = bytes(image)
         h = C.c_void_p()
         buf = np.frombuffer(self._image, dtype=np.uint8)
-        N.check(N.lib.tm_vocab_load(N.ptr(buf), buf.size, C.byref(h)))
+        if sample is None:
+            N.check(N.lib.tm_vocab_load(N.ptr(buf), buf.size, C.byref(h)))
+        else:
+            data = np.ascontiguousarray(sample, dtype=np.uint8)
+            N.check(N.lib.tm_vocab_load_sample(N.ptr(buf), buf.size, N.ptr(data), data.size, C.byref(h)))
         self._h = h
 
     # ---- the device block from process to process (tm_vocab_block_export / _import: the data-parallel scoring mode) ----

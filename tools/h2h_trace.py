@@ -74,6 +74,34 @@ def analyze(d, head_ms=0.0, win=None):
         cur = max(cur, b)
     gaps.sort(reverse=True)
     print("  idle gaps between kernels: total %.2f ms, largest %s ms" % (sum(gaps) / 1e6, [round(g / 1e6, 2) for g in gaps[:8]]))
+    # the engines side by side, per millisecond of the pass: share of the millisecond in which an upload / a kernel / a download was running
+    def busy_in(iv, a, b):
+        return union([(max(x, a), min(y, b)) for x, y in iv if y > a and x < b]) / max(1, b - a)
+    h2d = [(m[0], m[1]) for m in ml if "HOST_TO_DEVICE" in m[2].upper() or "H2D" in m[2].upper()]
+    d2h = [(m[0], m[1]) for m in ml if "DEVICE_TO_HOST" in m[2].upper() or "D2H" in m[2].upper()]
+    kiv = [(a, b) for a, b, _ in kl]
+    print("  timeline (1 ms bins; tenths of the bin busy: upload | kernels | download):")
+    line_u, line_k, line_d = "", "", ""
+    nb = int((hi - lo) / 1e6) + 1
+    for i in range(nb):
+        a, b = lo + i * 1_000_000, min(hi, lo + (i + 1) * 1_000_000)
+        if b <= a:
+            break
+        f = lambda x: "#" if x >= 0.95 else str(int(x * 10))
+        line_u += f(busy_in(h2d, a, b)); line_k += f(busy_in(kiv, a, b)); line_d += f(busy_in(d2h, a, b))
+    print("    upload   %s\n    kernels  %s\n    download %s" % (line_u, line_k, line_d))
+    # how much of the span two engines run side by side
+    def inter(x, y):
+        ev = sorted([(a, 1, 0) for a, b in x] + [(b, -1, 0) for a, b in x] + [(a, 0, 1) for a, b in y] + [(b, 0, -1) for a, b in y])
+        cx = cy = 0; last = None; tot = 0
+        for t, dx, dy in ev:
+            if last is not None and cx > 0 and cy > 0:
+                tot += t - last
+            cx += dx; cy += dy; last = t
+        return tot
+    span = hi - lo
+    print("  side by side: upload & kernels %.2f ms, kernels & download %.2f ms, upload & download %.2f ms of a span of %.2f ms; kernels busy %.0f %%, upload %.0f %%, download %.0f %%" % (
+        inter(h2d, kiv) / 1e6, inter(kiv, d2h) / 1e6, inter(h2d, d2h) / 1e6, span / 1e6, 100 * union(list(kiv)) / span, 100 * union(list(h2d)) / span, 100 * union(list(d2h)) / span))
     if win:
         # everything the device did between win[0] and win[1] ms of the pass, one line per kernel / copy, with its queue
         ev = [(a, b, "q%s %s" % (kq.get((a, b), "?"), n[-34:])) for a, b, n in kl] + [(m[0], m[1], "      %s %.2f MB" % (m[2][-14:], m[3] / 1e6)) for m in ml]

@@ -132,6 +132,21 @@ int main(int argc, char** argv) {
           while (go) {
             const uint32_t c = at(pos + depth);
             if (!((filt >> (c & 31u)) & 1u)) break;
+            if (is_tail_word(base)) {                                   // a one-child chain (tm_tables.h): one gather of its record, the whole chain or nothing
+              const uint4* r = reinterpret_cast<const uint4*>(tab) + tail_record(base);
+              c_bucket[tail_record(base)]++; c_all[tail_record(base)]++;
+              rounds++; for (int q = 0; q < 4; q++) rounds_c[q]++; for (int q = 0; q < 3; q++) rounds_t[q]++;
+              const int len = (int)tmh::tail_len(r[0].x);
+              const uint8_t* str = reinterpret_cast<const uint8_t*>(r + 1);
+              bool same = depth + len <= limit;
+              for (int k = 0; k < len && same; k++) same = at(pos + depth + k) == str[k];
+              if (!same) break;
+              depth += len; node = link_node(r[0].x);
+              if (r[0].y != 0) bestv = r[0].y;
+              filt = r[0].z; base = r[0].w; chain = 0;
+              go = filt != 0 && depth < limit;
+              continue;
+            }
             const size_t h = (size_t)base + c;
             c_parent[node]++; c_bucket[h]++; c_all[h]++;
             rounds++;
