@@ -208,20 +208,34 @@ __device__ __forceinline__ void dec_scan(uint32_t& s, uint32_t& q) {
 // loop nothing is loaded from global memory but the table entries of characters beyond ASCII, and a lane reads its byte, its neighbours and
 // its class from LDS.  The chunks are aligned like the blocks: the first one of a document may begin with positions that are not the
 // document's, which behave like the ones behind its end.)
-constexpr uint32_t DEC_BLK = 1024, DEC_HALF = 16 + DEC_BLK + 16;
+constexpr uint32_t DEC_BLK = 1024, DEC_HALF = 16 + DEC_BLK + 16, DEC_ILP = 4, DEC_CLASSES = 3;
+constexpr uint64_t DEC_LONG = 16384, DEC_MID = 4096;
+#ifdef TM_EMU
+#define TM_SETPRIO_BY_CLASS(c) ((void)(c))
+#else
+#define TM_SETPRIO_BY_CLASS(c) do { if ((c) == 0u) __builtin_amdgcn_s_setprio(3); else if ((c) == 1u) __builtin_amdgcn_s_setprio(1); } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__ in, const uint64_t* __restrict__ doc_off, uint32_t ndocs,
-                                                      uint8_t* __restrict__ out, uint64_t* __restrict__ dec_len, const uint32_t* __restrict__ tab,
-                                                      unsigned long long* __restrict__ sums) {
+                                                      uint8_t* __restrict__ out, uint64_t* __restrict__ dec_len, const uint32_t* __restrict__ tab) {
   __shared__ uint16_t s_cls[256];
   alignas(16) __shared__ uint8_t s_ring[4][2 * DEC_HALF];
   s_cls[threadIdx.x] = (uint16_t)dec_ascii_class(threadIdx.x);
   __syncthreads();
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t d = blockIdx.x * 4u + wv;
+  // One wavefront per document, and a document is a serial walk: the launch's time is what its longest documents take, so they go first and
+  // run ahead.  The grid is the documents DEC_CLASSES times over: the first third of the workgroups (the ones dispatched first) take only the
+  // documents of DEC_LONG bytes and more - the wavefronts of the others end at once -, the second third those of DEC_MID and more, the last
+  // third the rest; and the wavefront of a long document asks for a higher issue priority than its neighbours on the SIMD (s_setprio), which
+  // keeps it near the speed of a wavefront that is alone (0.5 us per 64-byte chunk against 2.3 when eight share a SIMD evenly).
+  const uint32_t per_class = (ndocs + 3u) / 4u, cls = blockIdx.x / per_class;
+  const uint32_t d = (blockIdx.x - cls * per_class) * 4u + wv;
   if (d >= ndocs) return;
   const uint64_t b = doc_off[d], e = doc_off[d + 1];
-  if (e - b >= 0xFFFFF000ull) { if (lane == 0) { dec_len[d] = DEC_HOST; atomicAdd(&sums[1], 1ull); } return; }
+  const uint32_t mine = e - b >= DEC_LONG ? 0u : (e - b >= DEC_MID ? 1u : 2u);
+  if (mine != cls) return;
+  if (e - b >= 0xFFFFF000ull) { if (lane == 0) dec_len[d] = DEC_HOST; return; }
+  TM_SETPRIO_BY_CLASS(mine);
   const uint64_t wb = b & ~(uint64_t)(DEC_BLK - 1);      // the blocks are aligned in the buffer; positions below are relative to wb
   const uint32_t rb = (uint32_t)(b - wb), re = (uint32_t)(e - wb);
   const TmWindow win = tm_window(in + wb, (re + 3u) & ~3u);
@@ -247,7 +261,68 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t j0 = k == 0 ? rb / 64u : 0u, left = re - k * DEC_BLK, j1 = left >= DEC_BLK ? DEC_BLK / 64u : (left + 63u) / 64u;
-    for (uint32_t j = j0; j < j1; j++) {
+    for (uint32_t jg = j0 & ~(DEC_ILP - 1u); jg < j1 && !host; jg += DEC_ILP) {
+    // DEC_ILP chunks at once when all of them are ASCII: the scans of a chunk do not depend on the chunk before it - only the two carried state
+    // words do, and those are chained through scalar registers between the scans -, so a wavefront has DEC_ILP independent instruction streams
+    // to issue from instead of one chain of ~130 dependent instructions per chunk (what bounded this kernel: profiles/r06_decode_bound.txt)
+    {
+      uint32_t cc[DEC_ILP], ff[DEC_ILP], any = 0;
+#pragma unroll
+      for (uint32_t u = 0; u < DEC_ILP; u++) {
+        const uint32_t at = k * DEC_BLK + 64u * (jg + u) + lane;
+        const bool valid = at >= rb && at < re;
+        uint32_t c = ring[hb + 16u + 64u * (jg + u) + lane];
+        c = valid ? c : 0u;
+        cc[u] = c; any |= c;
+      }
+      if (!__any(any >= 0x80u)) {
+        uint32_t sa[DEC_ILP], qa[DEC_ILP], pv[DEC_ILP];
+#pragma unroll
+        for (uint32_t u = 0; u < DEC_ILP; u++) {
+          const uint32_t at = k * DEC_BLK + 64u * (jg + u) + lane;
+          uint32_t f = s_cls[cc[u]];
+          ff[u] = (at >= rb && at < re) ? f : 0u;
+          sa[u] = (ff[u] >> 1) & 3u; qa[u] = (ff[u] & DC_M) - 1u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < DEC_ILP; u++) dec_scan(sa[u], qa[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < DEC_ILP; u++) {
+          const uint32_t st = sa[u] | (cin1 & ~qa[u]);
+          pv[u] = TM_DPP(cin1, st, 0x138, 0xF);
+          cin1 = read_lane(sa[u], 63) | (cin1 & ~read_lane(qa[u], 63));
+        }
+        uint32_t kept[DEC_ILP], Kk[DEC_ILP];
+#pragma unroll
+        for (uint32_t u = 0; u < DEC_ILP; u++) {
+          const uint32_t f = ff[u], nm = (f >> 8) & ~f & 1u;
+          kept[u] = nm & ~pv[u];
+          Kk[u] = kept[u] & ~(f >> 4);
+          const uint32_t ends_word = ((f >> 3) | ((f >> 4) & kept[u] & ~(pv[u] >> 1)) | (Kk[u] & ~(f >> 5) & ~(f >> 6))) & 1u;
+          sa[u] = ((f >> 3) & 1u) | ((f >> 1) & 2u); qa[u] = (((f >> 2) | Kk[u]) & 1u) | (ends_word << 1);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < DEC_ILP; u++) dec_scan(sa[u], qa[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < DEC_ILP; u++) {
+          const uint32_t st = sa[u] | (cin2 & ~qa[u]);
+          pv[u] = TM_DPP(cin2, st, 0x138, 0xF);
+          cin2 = read_lane(sa[u], 63) | (cin2 & ~read_lane(qa[u], 63));
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < DEC_ILP; u++) {
+          const uint32_t f = ff[u];
+          const uint32_t capS = ((Kk[u] & pv[u]) | (Kk[u] & (f >> 5) & (pv[u] >> 1))) & 1u;
+          const uint32_t oc = cc[u] - ((capS & (f >> 7)) << 5);
+          const unsigned long long km = __ballot(kept[u] != 0u);
+          if (kept[u]) dst[o + mbcnt64(km, 0u)] = (uint8_t)oc;
+          o += (uint32_t)__popcll(km);
+        }
+        continue;
+      }
+    }
+    const uint32_t ja = jg > j0 ? jg : j0, jb = jg + DEC_ILP < j1 ? jg + DEC_ILP : j1;
+    for (uint32_t j = ja; j < jb; j++) {
     const uint32_t pos = k * DEC_BLK + 64u * j;
     const uint32_t at = pos + lane;
     const bool valid = at >= rb && at < re;
@@ -323,10 +398,29 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
     if ((kept_all >> lane) & 1ull) dst[o + mbcnt64(kept_all, 0u)] = (uint8_t)oc;
     o += (uint32_t)__popcll(kept_all);
     }
+    }
     __builtin_amdgcn_wave_barrier();
   }
-  // the decoded length of the document, and what the batch adds up to: sums[0] bytes the device decoded, sums[1] documents it left to the host decoder
-  if (lane == 0) { dec_len[d] = host ? DEC_HOST : (uint64_t)o; if (host) atomicAdd(&sums[1], 1ull); else atomicAdd(&sums[0], (unsigned long long)o); }
+  if (lane == 0) dec_len[d] = host ? DEC_HOST : (uint64_t)o;
+}
+// what the batch adds up to: sums[0] bytes of the documents the device decoded, sums[1] documents it left to the host decoder.  (One workgroup per 2 048
+// documents and two atomic adds per workgroup: an atomic add per DOCUMENT from the decoder itself cost 12 ns each - they all go to one address, and the
+// L2 takes them one after the other -, 3.6 of that kernel's 4.9 ms per GiB: profiles/r06_decode_bound.txt.)
+__global__ __launch_bounds__(256) void k_dec_sum(const uint64_t* __restrict__ dec_len, uint32_t ndocs, unsigned long long* __restrict__ sums) {
+  __shared__ unsigned long long s_b[4], s_h[4];
+  unsigned long long bytes = 0, host = 0;
+  for (uint32_t k = 0; k < 8; k++) {
+    const uint32_t d = blockIdx.x * 2048u + k * 256u + threadIdx.x;
+    if (d < ndocs) { const uint64_t l = dec_len[d]; if (l == DEC_HOST) host++; else bytes += l; }
+  }
+  for (int m = 32; m > 0; m >>= 1) { bytes += __shfl_xor(bytes, m); host += __shfl_xor(host, m); }
+  if ((threadIdx.x & 63u) == 0) { s_b[threadIdx.x >> 6] = bytes; s_h[threadIdx.x >> 6] = host; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long bsum = s_b[0] + s_b[1] + s_b[2] + s_b[3], hsum = s_h[0] + s_h[1] + s_h[2] + s_h[3];
+    if (bsum) atomicAdd(&sums[0], bsum);
+    if (hsum) atomicAdd(&sums[1], hsum);
+  }
 }
 }  // namespace tmh
 
@@ -372,7 +466,10 @@ int launch_decode_capcode(const tm_vocab* v, const uint8_t* d_out, const uint64_
   if (!tab) return set_error(TM_E_HIP, "the decoder's character table could not be placed on device %d", v->device);
   const hipError_t e = hipMemsetAsync(d_sums, 0, 16, st);
   if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
-  if (ndocs) TM_LAUNCH(k_dec_capcode, (ndocs + 3) / 4, 256, 0, st, d_out, d_doff, ndocs, d_dec, d_declen, tab, (unsigned long long*)d_sums);
+  if (ndocs) {
+    TM_LAUNCH(k_dec_capcode, DEC_CLASSES * ((ndocs + 3) / 4), 256, 0, st, d_out, d_doff, ndocs, d_dec, d_declen, tab);
+    TM_LAUNCH(k_dec_sum, (ndocs + 2047) / 2048, 256, 0, st, d_declen, ndocs, (unsigned long long*)d_sums);
+  }
   return TM_OK;
 }
 }  // namespace tmh
