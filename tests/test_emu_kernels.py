@@ -4,7 +4,7 @@ tools/emu compiles the kernel sources of libtokenmonster_hip.so a second time, f
 at every cross-lane operation and barrier: tools/emu/hip/hip_runtime.h), and the -m gpu parity tests run against that library
 in a child process (tests/conftest.py under TM_EMU=1).  This is how a kernel change is checked where no GPU can be had; it says
 nothing about what the gfx950 compiler makes of the code or about speed, and it is no parity claim — those rest on the real
--m gpu run.  The subset below takes about a minute; `TM_EMU=1 python -m pytest tests -m gpu` runs everything (≈ 10 minutes)."""
+-m gpu run.  The subset below takes about two and a half minutes; `TM_EMU=1 python -m pytest tests -m gpu` runs everything (≈ 10 minutes)."""
 import os
 import re
 import subprocess
@@ -13,9 +13,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FAST = ("unit_golden_vector or fuzz_micro_vocab or fuzz_capcode1 or fuzz_utf16 or dense_forward_delete or fallback_paths or "
-        "score_histogram_micro or (score_ranges_of_one_walk and micro) or host_api_edge_cases or golden or capcode_decode or "
-        "normalizer_against_the_host or (against_the_oracle and 1007) or jobs_5_to_9 or stages_the_text or (raw_text_to_ids and 501) or "
-        "(laid_out_by_use and 2-1) or come_and_go")
+        "score_histogram_micro or (score_ranges_of_one_walk and micro) or host_api_edge_cases or golden_fixture_through_hip or "
+        "device_normalizer_equals_reference_js or device_decode_equals_reference_js or capcode_decode or "
+        "normalizer_against_the_host or (against_the_oracle and 1007) or jobs_5_to_9 or (raw_text_to_ids and 501) or come_and_go")
 
 
 def test_emulation_library_exports_the_c_abi():
@@ -35,4 +35,4 @@ def test_gpu_parity_subset_on_the_emulated_device():
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-4000:]
     m = re.search(r"(\d+) passed", out)
-    assert m and int(m.group(1)) >= 32, out[-2000:]
+    assert m and int(m.group(1)) >= 30, out[-2000:]
