@@ -187,6 +187,27 @@ def host_to_host(vocab, raw, roffs, text, offs, ids_expected, log, tm, steps=3, 
     # library's workers run on that node's CPUs for the length of a call (tm_host.hip: NearDevice; TM_NUMA=0 switches it off)
     res["numa"] = {"gpu_node": int(N.lib.tm_device_numa_node(0)), "pinned_input_pages": pages_on_nodes(pin_in.array), "pinned_output_pages": pages_on_nodes(pin_out.array),
                    "worker_threads": "bound to the GPU's node by the library" if os.environ.get("TM_NUMA", "1") != "0" else "left where the scheduler puts them (TM_NUMA=0)"}
+    # what the host link of THIS box gives a plain copy of the same page-locked buffers (the ring cannot be faster than its upload: boxes differ)
+    try:
+        import torch
+        dev_buf = torch.empty(int(raw.size), dtype=torch.uint8, device="cuda")
+        link = {}
+        for name, dst_p, src_p in (("h2d", dev_buf.data_ptr(), pin_in.array.ctypes.data), ("d2h", pin_in.array.ctypes.data, dev_buf.data_ptr())):
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                N.check(N.lib.tm_device_copy(C.c_void_p(dst_p), C.c_void_p(src_p), int(raw.size)))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+            link[name + "_GBps"] = round(raw.size / best / 1e9, 2)
+        link["note"] = "hipMemcpy of the %d MiB page-locked input buffer, best of 3: the floor of a host-to-host pass on this box is raw bytes / h2d" % (raw.size >> 20)
+        res["link"] = link
+        pin_in.array[:] = raw
+        del dev_buf
+    except Exception as ex:      # noqa: BLE001
+        log("link probe failed (%s)" % ex)
     for label, src, dst in (("pinned", pin_in.array, pin_out.array), ("pageable", raw, np.empty(4 * ids_expected + 4096, dtype=np.uint8))):
         # ONE stated setting, `steps` passes after H2H_WARM warm-up passes (benchmark/tokenmonster_bench.go:41-55 times around the whole call).
         # Several, not one: in a fresh process the first five or so calls with four lanes' commands in flight take ~40 ms instead of ~32, each
