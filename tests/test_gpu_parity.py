@@ -596,6 +596,51 @@ def test_decode_matches_reference_and_round_trips():
     assert v.decode_packed(weird, np.array([0, 0, 4], dtype=np.uint64), raw=True)[0].tobytes() == orc.decode_raw(np.array([5, 6], dtype=np.uint32))
 
 
+def test_decode_tiles_blocks_and_length_classes():
+    """round 6's decode: the gather works on tiles of 2 048 ids (a document that begins exactly on a tile, an id count that is a multiple of the tile, ids
+    that do not exist, a tile of 40-byte keys - more than one LDS window), the capcode decoder takes the text through LDS in blocks of 1 KiB aligned
+    in the buffer (characters of two, three and four bytes across every block and chunk boundary, markers as the last byte of a block) and dispatches
+    documents by length class (>= 16 KB, >= 4 KB, shorter; empty ones).  Device == host decoder, byte for byte."""
+    import unicodedata
+    rng = np.random.default_rng(6006)
+    toks = [bytes([c]) for c in range(256)] + [b"D", b"C", b"W", b"the", b" the", b"ing", b"D ", b"x" * 40, b"y" * 39 + b"C", "é".encode(), "ж".encode(), "世".encode(), "😀".encode()]
+    v = tm.Vocab(synth.build_vocab(sorted(set(toks)), capcode=2, charset=1, norm_flag=1))
+    words = ["hello", "World", "HTTP", "it's", "Émile", "ŒUVRE", "Жук", "ЖУК", "世界", "😀", "x", "I", "2nd", "don’t", "NAÏVE", "naïve", " ", "\n", "ß", "ǅ"]
+    def text(n):
+        out, tot = [], 0
+        while tot < n:
+            w = words[int(rng.integers(len(words)))] + (" " if rng.random() < 0.8 else "")
+            out.append(w); tot += len(w.encode())
+        return "".join(out)
+    docs = [text(int(n)) for n in (0, 1, 63, 64, 65, 1023, 1024, 1025, 2047, 2049, 4095, 4097, 16383, 16385, 40_000, 0, 5, 300, 70_000 if not EMULATED else 20_000)]
+    docs += [text(int(n)) for n in rng.integers(0, 3000, size=40)]
+    raw, offs = tm.pack_documents([d.encode() for d in docs])
+    ntext, noff = synth.normalize_batch(raw, offs, 2, 1)
+    ids, toff, miss = v.tokenize_packed(ntext, noff)
+    assert int(miss.sum()) == 0
+    # (a) as tokenized; (b) with ids that do not exist sprinkled in and the id count padded to a multiple of the tile; (c) every document begins on a tile
+    def check(ids_, toff_, expect):
+        out, ooff = v.decode_packed(ids_, toff_)
+        for k, e in enumerate(expect):
+            assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == e, (k, len(e))
+    expect = [unicodedata.normalize("NFD", d).encode() for d in docs]
+    check(ids, toff, expect)
+    bad = np.array([v.n_ids(), 0xFFFFFF, 0xFFFFFFFF], dtype=np.uint32)
+    parts, nt = [], [0]
+    for k in range(len(docs)):
+        t = ids[int(toff[k]):int(toff[k + 1])]
+        t = np.insert(t, rng.integers(0, t.size + 1, size=3), bad) if k % 3 == 0 else t
+        pad = (-(nt[-1] + t.size)) % 2048 if k % 5 == 0 else 0
+        t = np.concatenate([t, np.full(pad, v.n_ids() + 1, dtype=np.uint32)])
+        parts.append(t); nt.append(nt[-1] + t.size)
+    check(np.ascontiguousarray(np.concatenate(parts)), np.array(nt, dtype=np.uint64), expect)
+    # raw decode of a tile of 40-byte keys: 2 048 x 40 bytes = five LDS windows
+    long_ids = v.tokenize_normalized([b"x" * 40 * 3000])[0][0]
+    assert long_ids.size == 3000
+    out, ooff = v.decode_packed(long_ids, np.array([0, 3000], dtype=np.uint64), raw=True)
+    assert out.tobytes() == b"x" * 120_000
+
+
 @pytest.mark.parametrize("name,mbytes", [("englishcode-32000-consistent", 256), ("englishcode-100256-clean", 64), ("code-4096-balanced-nocapcode", 64),
                                          ("english-24000-consistent", 64)])
 def test_full_size_properties(name, mbytes):
