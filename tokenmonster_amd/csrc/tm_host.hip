@@ -56,6 +56,11 @@ struct Lane {
 // ---- the host-to-host ring (tm_tokenize_pipeline on page-locked buffers) ---------------------------------------------------------------------
 // A slot = one chunk in flight: a workspace, the packed ids on the device, and a page-locked block for what goes to and comes from the host
 // beside the bulk data (the chunk's verdict, raw offsets in, id offsets and missing counts out).
+#if defined(__x86_64__) || defined(__i386__)
+#define TM_CPU_RELAX() __builtin_ia32_pause()
+#else
+#define TM_CPU_RELAX() ((void)0)
+#endif
 struct RingSlot {
   tm_batch* ws = nullptr;
   uint8_t* d_bytes = nullptr;
@@ -682,9 +687,26 @@ static int pipeline_ring(PipeCall& c, const std::vector<Ring*>& rings) {
       uint64_t ntok = 0;
       if (si >= 0) {
         RingSlot& s = r.slots[si];
-        hipError_t e = hipEventSynchronize(s.comp_done);
-        if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize (ring chunk)"); c.fail(rc); continue; }
+        // The chunk's verdict is a word in page-locked memory that its last kernel writes (the issuer has set it to ~0): the finisher WATCHES it
+        // instead of sleeping in hipEventSynchronize - on some boxes every other call lost 3.2 ms right there, in the wait for its first chunk
+        // (gpurun_out/r06_probe25: every chunk of a 30.5 ms call lies 3.2 ms behind its place in a 26.9 ms call, from chunk 0 on).  The event
+        // is still asked now and then (a stream that has failed must not be waited for for ever), and the download stream waits for it on the device.
+        hipError_t e = hipSuccess;
+        {
+          const volatile uint64_t* flag = s.h_status();
+          for (uint32_t spin = 1;; spin++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ~0ull) break;
+            if ((spin & 0xFFFu) == 0) {
+              const hipError_t q = hipEventQuery(s.comp_done);
+              if (q == hipSuccess) { if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ~0ull) e = hipEventSynchronize(s.comp_done); break; }
+              if (q != hipErrorNotReady) { e = q; break; }
+            }
+            TM_CPU_RELAX();
+          }
+        }
+        if (e != hipSuccess) { rc = hip_fail(e, "ring chunk"); c.fail(rc); continue; }
         const uint64_t st = s.h_status()[0];
+        if (st == ~0ull) { rc = set_error(TM_E_INTERNAL, "a chunk of the ring ended without its verdict"); c.fail(rc); continue; }
         if (trace) fprintf(stderr, "[ring] chunk %3zu computed at %7.2f ms: status %llu, %llu ids, %llu segments\n", k, now_ms() - c.t0, (unsigned long long)st,
                            (unsigned long long)s.h_status()[1], (unsigned long long)s.h_status()[3]);
         if (st != 0) exact = true; else ntok = s.h_status()[1];
@@ -702,8 +724,8 @@ static int pipeline_ring(PipeCall& c, const std::vector<Ring*>& rings) {
       const uint32_t nd = c.first[k + 1] - c.first[k];
       const uint64_t out_b = ntok * c.enc;
       const bool fits = (base + ntok) * c.enc <= c.bytes_cap && c.bytes_out;
-      hipError_t e = hipSuccess;
-      if (fits && out_b) e = hipMemcpyAsync(c.bytes_out + base * c.enc, s.ids_at, out_b, hipMemcpyDeviceToHost, r.down);
+      hipError_t e = hipStreamWaitEvent(r.down, s.comp_done, 0);
+      if (e == hipSuccess && fits && out_b) e = hipMemcpyAsync(c.bytes_out + base * c.enc, s.ids_at, out_b, hipMemcpyDeviceToHost, r.down);
       if (e == hipSuccess) e = hipMemcpyAsync(s.h_toff(), s.ws->d_tok_offsets, ((uint64_t)nd + 1) * 8, hipMemcpyDeviceToHost, r.down);
       if (e == hipSuccess && c.missing) e = hipMemcpyAsync(s.h_missing(), s.ws->d_doc_missing, (uint64_t)nd * 4, hipMemcpyDeviceToHost, r.down);
       if (e == hipSuccess) e = hipEventRecord(s.dl_done, r.down);

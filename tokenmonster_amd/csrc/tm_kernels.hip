@@ -2020,6 +2020,7 @@ __global__ void k_chunk_done(const uint64_t* __restrict__ ctl, const uint64_t* _
   if (!st && err) st |= RING_ERROR;
   if (!st && ntok > out_cap) st |= RING_OUT_CAP;
   h_status[1] = ntok; h_status[2] = ctl[4]; h_status[3] = ctl[0]; h_status[4] = err; h_status[5] = ctl[5];
+  __threadfence_system();                      // (the host polls the status word: what it says must be there first)
   h_status[0] = st;
 }
 // ids -> enc bytes each, the count worked out on the device (the status word of k_chunk_ctl the id total, the error word); sixteen ids per work-item, 16-byte stores (`out` 16-byte aligned)
@@ -2035,6 +2036,7 @@ __global__ __launch_bounds__(256) void k_serialize_ctl(const uint32_t* __restric
   const uint64_t n = st ? 0ull : ntok;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     h_status[1] = ntok; h_status[2] = ctl[4]; h_status[3] = ctl[0]; h_status[4] = err; h_status[5] = ctl[5];
+    __threadfence_system();
     h_status[0] = st;
   }
   const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;

@@ -160,9 +160,10 @@ template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if 
 template <class T, class U> static inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
 template <class T, class U, class V> static inline T atomicCAS(T* p, U cmp, V v) { T o = *p; if (o == (T)cmp) *p = (T)v; return o; }
 static inline void __threadfence() {}
+static inline void __threadfence_system() {}
 
 // ---- the runtime API the library uses (emu_runtime.cpp) ----------------------------------------------------------------------
-typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInsufficientDriver = 35, hipErrorNoDevice = 100,
+typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorOutOfMemory = 2, hipErrorInsufficientDriver = 35, hipErrorNoDevice = 100,
                hipErrorInvalidDevice = 101 } hipError_t;
 typedef struct emuStream* hipStream_t;
 typedef struct emuEvent* hipEvent_t;
@@ -210,4 +211,5 @@ hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
