@@ -467,6 +467,7 @@ int launch_decode_capcode(const tm_vocab* v, const uint8_t* d_out, const uint64_
   const hipError_t e = hipMemsetAsync(d_sums, 0, 16, st);
   if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
   if (ndocs) {
+    if ((uint64_t)DEC_CLASSES * ((ndocs + 3) / 4) > 0x7FFFFFFFull) return set_error(TM_E_LIMIT, "%u documents in one decode: more than a launch takes (split the batch)", ndocs);
     TM_LAUNCH(k_dec_capcode, DEC_CLASSES * ((ndocs + 3) / 4), 256, 0, st, d_out, d_doff, ndocs, d_dec, d_declen, tab);
     TM_LAUNCH(k_dec_sum, (ndocs + 2047) / 2048, 256, 0, st, d_declen, ndocs, (unsigned long long*)d_sums);
   }
