@@ -694,15 +694,14 @@ __device__ __forceinline__ PfWin pf_window(const uint8_t* __restrict__ doc, uint
     const long long j = lane < 2 ? (long long)base - 2 + lane : (long long)base + 62 + lane;      // base - 2, base - 1, base + 64, base + 65
     if (j >= 0 && j < (long long)n) edge = doc[j];
   }
-  const uint32_t em2 = (uint32_t)__shfl((int)edge, 0), em1 = (uint32_t)__shfl((int)edge, 1), ep0 = (uint32_t)__shfl((int)edge, 2), ep1 = (uint32_t)__shfl((int)edge, 3);
-  const uint32_t l1 = (uint32_t)__shfl((int)x, (lane + 63) & 63), l2 = (uint32_t)__shfl((int)x, (lane + 62) & 63);
-  const uint32_t r1 = (uint32_t)__shfl((int)x, (lane + 1) & 63), r2 = (uint32_t)__shfl((int)x, (lane + 2) & 63);
+  // (the neighbours by DPP moves, the four edge bytes through scalar registers: as eight ds_bpermute this was a third of a pass)
+  const uint32_t em2 = read_lane(edge, 0), em1 = read_lane(edge, 1), ep0 = read_lane(edge, 2), ep1 = read_lane(edge, 3);
   PfWin w;
   w.x = x;
-  w.p1 = lane >= 1 ? l1 : em1;
-  w.p2 = lane >= 2 ? l2 : (lane == 1 ? em1 : em2);
-  w.n1 = lane <= 62 ? r1 : ep0;
-  w.n2 = lane <= 61 ? r2 : (lane == 62 ? ep0 : ep1);
+  w.p1 = TM_DPP(em1, x, 0x138, 0xF);          // wave_shr:1 - the byte of the lane below (lane 0: the byte in front of the chunk)
+  w.p2 = TM_DPP(em2, w.p1, 0x138, 0xF);
+  w.n1 = TM_DPP(ep0, x, 0x130, 0xF);          // wave_shl:1 - the byte of the lane above (lane 63: the byte behind the chunk)
+  w.n2 = TM_DPP(ep1, w.n1, 0x130, 0xF);
   return w;
 }
 // is the quote whose third byte lies at t left alone (the in-place quirk above)?
