@@ -86,7 +86,7 @@ typedef struct tm_vocab_block {
   uint32_t idle_off, n_da, n_info, max_len, off, bstart, spl_hint, link_off, direct_off, delete_id, unk_id;
   uint32_t n_ids, vocab_size, capcode, charset, norm_flag, level, reserve, n_nodes, pad;   /* pad: TM_VOCAB_BLOCK_FORMAT of the exporting build */
 } tm_vocab_block;
-#define TM_VOCAB_BLOCK_FORMAT 5u   /* layout of the device tables inside a block (tm_tables.h); an importer refuses any other */
+#define TM_VOCAB_BLOCK_FORMAT 6u   /* layout of the device tables inside a block (tm_tables.h); an importer refuses any other */
 int tm_vocab_block_export(const tm_vocab* v, tm_vocab_block* meta, void** device_ptr);
 int tm_vocab_block_import(const tm_vocab_block* meta, int device, tm_vocab** out, void** device_ptr);
 /* Synchronous device-to-device copy (also between two devices of the node with peer access), for callers that have no HIP binding of

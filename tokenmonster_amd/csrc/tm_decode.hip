@@ -20,7 +20,7 @@ namespace tmh {
 // The gather works on TILES of DEC_TILE ids, one workgroup each, in two launches with a scan of the tiles' byte counts between them (the
 // byte offset of every id never exists in memory: 12 bytes of traffic per id in the first form of this path, and a byte-by-byte copy by one
 // work-item per id).  k_dec_tile_len: bytes of a tile.  k_dec_doc_tile: the first document whose first id lies in a tile.  k_dec_gather: the
-// lengths once more (two words of the reverse table's offsets per id, L2 hits), their prefix sums inside the tile in LDS, the keys copied into
+// lengths once more (one word of the reverse table per id - place and length packed -, L2 hits), their prefix sums inside the tile in LDS, the keys copied into
 // an LDS window of DEC_WIN bytes - a work-item owns eight consecutive ids, so it writes one run of the window, a dword at a time - and the
 // window written out in 16-byte stores aligned in global memory (partial first / last chunk bytewise: the neighbours' bytes are theirs);
 // the documents that begin in the tile get their byte offset from the same prefix sums.  A tile of more than DEC_WIN bytes (ids of up to
@@ -43,8 +43,8 @@ __device__ __forceinline__ uint32_t dec_load_ids(const uint32_t* __restrict__ to
 #pragma unroll
   for (uint32_t j = 0; j < DEC_PER; j++) {
     const bool ok = id[j] < n_ids;                                                // ids >= n_ids are skipped like the reference does
-    const uint32_t s = ok ? rev_off[id[j]] : 0u, e = ok ? rev_off[id[j] + 1] : 0u;
-    src[j] = s; len[j] = e - s; sum += e - s;
+    const uint32_t pk = ok ? rev_off[id[j]] : 0u;                                 // place | length << 26 (tm_tables.h: kRevPlaceBits)
+    src[j] = pk & ((1u << kRevPlaceBits) - 1u); len[j] = pk >> kRevPlaceBits; sum += pk >> kRevPlaceBits;
   }
   return sum;
 }

@@ -69,6 +69,7 @@ struct HostVocab {
   std::vector<uint4> spl;           // space-prefix links
   std::vector<uint32_t> rev_off;    // n_ids + 1: reverse[id] = rev_bytes[rev_off[id] .. rev_off[id+1])  (last record wins, go :2715)
   std::vector<uint8_t> rev_bytes;
+  std::vector<uint32_t> rev_pack;   // the device's form of rev_off (d_rev_off): place | length << kRevPlaceBits per id (tm_tables.h)
   uint32_t idle_off = 0, n_da = 0, n_nodes = 0, off = 1, bstart = kNone, spl_hint = 0, link_off = 0, direct_off = 0;
 };
 

@@ -35,6 +35,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kNodeBits = 21;
 constexpr uint32_t kNodeMask = (1u << kNodeBits) - 1;
 constexpr uint32_t kHasChildren = 1u << 21;
+constexpr uint32_t kRevPlaceBits = 26;                // reverse table on the device: a key's place in rev_bytes (26 bits: 64 MB) | its length << 26 (keys of at most 40 bytes)
 constexpr uint32_t kMaxNodes = (1u << 20) - 2;       // 20 bits: a link-format entry keeps two depths beside the node id
 constexpr uint32_t kLinkNodeMask = (1u << 20) - 1;
 constexpr uint32_t kL2Size = 65536;

@@ -435,6 +435,12 @@ int build_tables(HostVocab& hv, const Trie& t, const std::vector<uint32_t>* perm
       if (last[id] != kNone) hv.rev_bytes.insert(hv.rev_bytes.end(), hv.keys.begin() + hv.key_off[last[id]], hv.keys.begin() + hv.key_off[last[id] + 1]);
     }
     hv.rev_off[hv.n_ids] = (uint32_t)hv.rev_bytes.size();
+    // ... and as the device reads it: place and length of a key in ONE word (place | length << 26), so that a decode kernel gathers one word per id
+    // and not two (the gathers are what k_dec_tile_len / k_dec_gather wait for)
+    if (hv.rev_bytes.size() >= (1u << kRevPlaceBits)) return set_error(TM_E_LIMIT, "the keys of the reverse table take %zu bytes, more than the device form holds", hv.rev_bytes.size());
+    hv.rev_pack.assign((size_t)hv.n_ids + 1, 0);
+    for (uint32_t id = 0; id < hv.n_ids; id++) hv.rev_pack[id] = hv.rev_off[id] | ((hv.rev_off[id + 1] - hv.rev_off[id]) << kRevPlaceBits);
+    hv.rev_pack[hv.n_ids] = hv.rev_off[hv.n_ids];
   }
   // space-prefix links: x = node reached | continue << 21 | best accepting depth << 22, y = that node's value
   hv.vals.resize(n_info);
@@ -658,7 +664,7 @@ static void table_parts(tm_vocab* v, Part (&parts)[8]) {
   HostVocab& hv = v->host;
   const Part p[8] = {{(void**)&v->d_root, hv.root.data(), 256 * 4, 0}, {(void**)&v->d_tab, hv.tab.data(), hv.tab.size() * sizeof(uint2), 0},
                      {(void**)&v->d_rows, hv.rows.data(), hv.rows.size() * sizeof(Row), 0}, {(void**)&v->d_spl, hv.spl.data(), hv.spl.size() * sizeof(uint4), 0},
-                     {(void**)&v->d_vals, hv.vals.data(), hv.vals.size() * 4, 0}, {(void**)&v->d_rev_off, hv.rev_off.data(), hv.rev_off.size() * 4, 0},
+                     {(void**)&v->d_vals, hv.vals.data(), hv.vals.size() * 4, 0}, {(void**)&v->d_rev_off, hv.rev_pack.data(), hv.rev_pack.size() * 4, 0},
                      {(void**)&v->d_rev_bytes, hv.rev_bytes.data(), hv.rev_bytes.size(), 0}, {(void**)&v->d_begin_byte, hv.begin_byte, 256, 0}};
   for (int k = 0; k < 8; k++) parts[k] = p[k];
 }
