@@ -276,43 +276,43 @@ __global__ __launch_bounds__(256) void k_dec_capcode(const uint8_t* __restrict__
         cc[u] = c; any |= c;
       }
       if (!__any(any >= 0x80u)) {
-        uint32_t sa[DEC_ILP], qa[DEC_ILP], pv[DEC_ILP];
+        // the (set, stop) pairs of the DEC_ILP chunks side by side in ONE register, a byte per chunk: the scan is bitwise, so its six steps serve all
+        // the chunks at once; what a chunk hands to the next - the state behind its lane 63 - is chained through scalar registers behind the scan
+        static_assert(DEC_ILP <= 4, "a byte per chunk");
+        auto chain = [&](uint32_t sp, uint32_t qp, uint32_t& cin) -> uint32_t {
+          const uint32_t S = read_lane(sp, 63), Q = read_lane(qp, 63);
+          uint32_t cinp = 0u, c = cin;
+#pragma unroll
+          for (uint32_t u = 0; u < DEC_ILP; u++) { cinp |= c << (8u * u); c = (((S >> (8u * u)) | (c & ~(Q >> (8u * u)))) & 3u); }
+          cin = c;
+          return TM_DPP(cinp, sp | (cinp & ~qp), 0x138, 0xF);        // the state behind the position before, every chunk in its byte
+        };
+        uint32_t sp = 0u, qp = 0u;
 #pragma unroll
         for (uint32_t u = 0; u < DEC_ILP; u++) {
           const uint32_t at = k * DEC_BLK + 64u * (jg + u) + lane;
           uint32_t f = s_cls[cc[u]];
           ff[u] = (at >= rb && at < re) ? f : 0u;
-          sa[u] = (ff[u] >> 1) & 3u; qa[u] = (ff[u] & DC_M) - 1u;
+          sp |= ((ff[u] >> 1) & 3u) << (8u * u); qp |= (((ff[u] & DC_M) - 1u) & 3u) << (8u * u);
         }
-#pragma unroll
-        for (uint32_t u = 0; u < DEC_ILP; u++) dec_scan(sa[u], qa[u]);
-#pragma unroll
-        for (uint32_t u = 0; u < DEC_ILP; u++) {
-          const uint32_t st = sa[u] | (cin1 & ~qa[u]);
-          pv[u] = TM_DPP(cin1, st, 0x138, 0xF);
-          cin1 = read_lane(sa[u], 63) | (cin1 & ~read_lane(qa[u], 63));
-        }
+        dec_scan(sp, qp);
+        const uint32_t pv1 = chain(sp, qp, cin1);
         uint32_t kept[DEC_ILP], Kk[DEC_ILP];
+        sp = 0u; qp = 0u;
 #pragma unroll
         for (uint32_t u = 0; u < DEC_ILP; u++) {
-          const uint32_t f = ff[u], nm = (f >> 8) & ~f & 1u;
-          kept[u] = nm & ~pv[u];
+          const uint32_t f = ff[u], nm = (f >> 8) & ~f & 1u, pv = pv1 >> (8u * u);
+          kept[u] = nm & ~pv;
           Kk[u] = kept[u] & ~(f >> 4);
-          const uint32_t ends_word = ((f >> 3) | ((f >> 4) & kept[u] & ~(pv[u] >> 1)) | (Kk[u] & ~(f >> 5) & ~(f >> 6))) & 1u;
-          sa[u] = ((f >> 3) & 1u) | ((f >> 1) & 2u); qa[u] = (((f >> 2) | Kk[u]) & 1u) | (ends_word << 1);
+          const uint32_t ends_word = ((f >> 3) | ((f >> 4) & kept[u] & ~(pv >> 1)) | (Kk[u] & ~(f >> 5) & ~(f >> 6))) & 1u;
+          sp |= (((f >> 3) & 1u) | ((f >> 1) & 2u)) << (8u * u); qp |= ((((f >> 2) | Kk[u]) & 1u) | (ends_word << 1)) << (8u * u);
         }
-#pragma unroll
-        for (uint32_t u = 0; u < DEC_ILP; u++) dec_scan(sa[u], qa[u]);
+        dec_scan(sp, qp);
+        const uint32_t pv2 = chain(sp, qp, cin2);
 #pragma unroll
         for (uint32_t u = 0; u < DEC_ILP; u++) {
-          const uint32_t st = sa[u] | (cin2 & ~qa[u]);
-          pv[u] = TM_DPP(cin2, st, 0x138, 0xF);
-          cin2 = read_lane(sa[u], 63) | (cin2 & ~read_lane(qa[u], 63));
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < DEC_ILP; u++) {
-          const uint32_t f = ff[u];
-          const uint32_t capS = ((Kk[u] & pv[u]) | (Kk[u] & (f >> 5) & (pv[u] >> 1))) & 1u;
+          const uint32_t f = ff[u], pv = pv2 >> (8u * u);
+          const uint32_t capS = ((Kk[u] & pv) | (Kk[u] & (f >> 5) & (pv >> 1))) & 1u;
           const uint32_t oc = cc[u] - ((capS & (f >> 7)) << 5);
           const unsigned long long km = __ballot(kept[u] != 0u);
           if (kept[u]) dst[o + mbcnt64(km, 0u)] = (uint8_t)oc;
