@@ -47,6 +47,9 @@ for name, words in WORDS.items():
     text = np.frombuffer(b"".join(docs), dtype=np.uint8)
     n64 = text.size // 64 * 64
     hi = float((text[:n64].reshape(-1, 64) >= 0x80).any(axis=1).mean())
-    print("%-10s %6.1f MB encoded, %3.0f %% of the chunks beyond ASCII, host docs %d of %d: capcode %.3f ms = %.2f ms per GiB of encoded text (gather %.3f)" % (
-        name, enc / 1e6, 100 * hi, hostd.value, nd, acc[2], acc[2] * (1 << 30) / enc, acc[1]), flush=True)
+    # (per GiB of DECODED text: with this byte-level vocabulary the ids of a character beyond ASCII decode to more bytes than the character had - its
+    # single-byte tokens are stored escaped -, so the text the decoder reads is larger than the normalized text by a factor that depends on the script)
+    dec = float(nbytes.value)
+    print("%-18s %6.1f MB normalized -> %6.1f MB decoded, %3.0f %% of the raw chunks beyond ASCII, host docs %d of %d: capcode %.3f ms = %.2f ms per GiB of decoded text (gather %.3f)" % (
+        name, enc / 1e6, dec / 1e6, 100 * hi, hostd.value, nd, acc[2], acc[2] * (1 << 30) / max(dec, 1.0), acc[1]), flush=True)
     N.lib.tm_batch_free(b)
