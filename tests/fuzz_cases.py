@@ -130,6 +130,8 @@ def one_norm(seed):
     for _ in range(int(rng.integers(1, 60))):
         parts = []
         n = int(rng.choice([0, 1, 5, 60, 63, 64, 65, 127, 129, 1000, 1023, 1024, 1025, 2047, 2049, 3100]))
+        if lossy and rng.random() < 0.01:
+            n = int(rng.choice([16383, 16385, 33000]))       # more than one span of the filter pass (tm_norm.hip: PF_SPAN)
         while sum(len(x) for x in parts) < n:
             r = rng.random()
             if r < 0.15:

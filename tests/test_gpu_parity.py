@@ -446,6 +446,10 @@ def test_lossy_normalizer_flags_run_on_the_device():
             b"one  two \r\n three\r\n\r\n  four  ", ("Title Case  And  CAPS \u2018q\u2019 \r\n" * 40).encode()]
     raw, roffs = synth.synth_corpus(synth.ENGLISHCODE, 60_000, seed=5)
     docs += [raw[int(roffs[d]):int(roffs[d + 1])].tobytes() for d in range(roffs.size - 1)]
+    # documents of more than one 16 KiB span of the filter pass (a wavefront per span there, k_pf_long): the single drops, the quotes they
+    # protect, the blanks at both ends and the characters `accents` changes on either side of a span's end
+    docs += [("one  two \u2018q\u2019 \r\n caf\u00e9 " * 3000).encode(), b" \t " * 9000 + "x \u201cy\u201d".encode() * 2000 + b"  z" + b" " * 40000,
+             ("a \u2019b" * 2730 + "  " + "\u2018c\u2019 \u00e9\u00f1" * 5000 + "  d \u201d").encode(), b"Q" + b"abc \r\n" * 2340 + "\u2019".encode() * 9000]
     text, offs = tm.pack_documents(docs)
     toks = [bytes([c]) for c in range(256)]
     for flag in range(256):
@@ -453,8 +457,8 @@ def test_lossy_normalizer_flags_run_on_the_device():
             v = tm.Vocab(synth.build_vocab(toks, capcode=capcode, charset=1, norm_flag=flag))
             got, goff, nfb = v.normalize_packed_device(text, offs)
             # (without capcode the normalizer pass keeps lengths: a character that decomposes is the host's; trim + leadingspace cut the last
-            # non-blank BYTE of a text without leading blanks, tokenmonster.cpp:274-277 - half a character in four of these documents: malformed, the host's)
-            assert nfb == 0 or capcode == 0 or ((flag & 96) == 96 and nfb <= 4), (flag, capcode, nfb)
+            # non-blank BYTE of a text without leading blanks, tokenmonster.cpp:274-277 - half a character in eight of these documents: malformed, the host's)
+            assert nfb == 0 or capcode == 0 or ((flag & 96) == 96 and nfb <= 8), (flag, capcode, nfb)
             exp, eoff = synth.normalize_batch(text, offs, capcode, flag)
             assert (goff == eoff).all() and got.tobytes() == exp.tobytes(), (flag, capcode)
     # ... and the ids of a real vocabulary with the reference's example flags (lowercase collapse trim quotemarks unixlines)

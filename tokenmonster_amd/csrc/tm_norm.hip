@@ -578,12 +578,12 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
 
 
 // pieces per document; clears what the pass writes to on the side (need_host, the info words): no memset commands of their own
-__global__ void k_norm_begin(const uint64_t* __restrict__ raw_off, uint32_t ndocs, uint32_t* __restrict__ doc_npiece, uint8_t* __restrict__ need_host,
+__global__ void k_norm_begin(const uint64_t* __restrict__ rbegin, const uint64_t* __restrict__ rend, uint32_t ndocs, uint32_t* __restrict__ doc_npiece, uint8_t* __restrict__ need_host,
                              unsigned long long* __restrict__ ninfo) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d < 8) ninfo[d] = 0ull;
   if (d < ndocs) {
-    doc_npiece[d] = (uint32_t)((raw_off[d + 1] - raw_off[d] + PIECE - 1) / PIECE);
+    doc_npiece[d] = (uint32_t)((rend[d] - rbegin[d] + PIECE - 1) / PIECE);
     need_host[d] = 0;
   }
 }
@@ -663,7 +663,7 @@ __global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t*
 }
 // ---- the filter pass in front of the normalizer pass (round 6): the flags that drop and replace BYTES ------------------------------------------
 // quotemarks 8, collapse 16, trim 32, leadingspace 64, unixlines 128 (training/README.md:110-123; tokenmonster.cpp:245-425, 428-462) and what
-// accents 4 (:231-243) does to the two-byte characters, on the device: raw text in, filtered text + new document offsets out, and the
+// accents 4 (:231-243) does to the two-byte characters, on the device: raw text in, filtered text + the documents' new ranges out, and the
 // normalizer pass (NFD / lowercase / capcode) runs on that.  The host form is tm_normalize.cpp (squeeze, unix_lines, trim_and_lead,
 // remove_marks), fuzzed against the reference runtime for all 256 flag values; this is the same function of the text, stated per byte:
 //   * a space goes when the byte before it in the INPUT is a space; a '\r' goes when a '\n' follows; E2 80 {98,99 | 9C,9D} becomes ' or " -
@@ -671,161 +671,273 @@ __global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t*
 //     byte has been dropped (and until the next one is) the look-behind finds a byte that was already moved, and the quote stays.  The
 //     offset by which the text has shrunk only grows - one for a dropped byte, two for a replaced quote - so it equals one exactly between the
 //     first single drop of a document and the second, provided no quote was replaced before the first: three numbers per document
-//     (first and second single drop, first quote candidate), found per piece (k_pf_summary) and combined per document (k_pf_doc).
+//     (first and second single drop, first quote candidate).
 //     (unixlines WITHOUT collapse is a pass of its own in the reference, into a fresh buffer: no single drops in the loop that follows.)
 //   * trim keeps what lies between the first and the last byte above 32, leadingspace puts a space in front of a first byte that is not
 //     one; together, on a text WITHOUT leading blanks, the reference also cuts the last non-blank byte (:274-277) - kept.
 //   * accents: a two-byte character becomes what NFD-and-drop-Mn leaves of it (nothing, one byte, two bytes: a table from the host's own
 //     function, build_accent_table); whatever else would decompose or is a mark reaches the normalizer pass, whose tables in this mode
 //     refuse it (norm_tables): that document is normalized by the host from its ORIGINAL bytes.
+// Second form (the first - a piece per wavefront, a byte per lane, three launches that each read the text - took 9 ms per GiB): ONE launch, a
+// wavefront per document, a dword per lane.  The wavefront first looks for the document's numbers - as a rule in its first and last 256
+// bytes: the search for the single drops ends at the second one or at a quote in front of the first, the blanks at either end are short -,
+// then sweeps the text once, 256 bytes per step: the tests are byte-parallel arithmetic on the lane's dword and on the same dword shifted
+// against its neighbours' (DPP moves; the dword behind the step's last is the first of the next step's, which is already under way), a quote is
+// found ONCE, at its first byte, and its other two bytes take their verdict from there, the lane packs the bytes it keeps and writes them
+// with one store (two where it dropped something).  The filtered documents are not packed: document d begins on a 16-byte boundary of its
+// own, PF_GAP bytes further from where it began for every document in front of it (the normalizer pass takes begin and end of a document
+// from two arrays).  A document of more than PF_SPAN bytes (rare) is filtered by a wavefront per span in three launches - numbers per span,
+// sizes per span, bytes - of which the last two skip every other document.
 constexpr uint32_t PF_NONE = 0xFFFFFFFFu;
-struct PfPiece { uint32_t s1, s2, fq, a, z; };      // positions in the document: first / second single drop, first quote candidate (its third byte), first / last byte above 32
+#ifndef TM_PF_SPAN
+#define TM_PF_SPAN 16384u       // (the emulated fuzz also runs with 1024: documents of many spans)
+#endif
+constexpr uint32_t PF_SPAN = TM_PF_SPAN, PF_GAP = 32u;
+static_assert(PF_SPAN % 256u == 0u && PF_SPAN >= (uint32_t)PIECE, "a span is whole steps of the sweep, and the spans' table lives in the pieces' arrays");
+struct PfPiece { uint32_t s1, s2, fq, a, z; };      // of a span; positions in the document: first / second single drop, first quote candidate (its third byte), first / last byte above 32
 struct PfDoc { uint32_t s1, s2, qb, a, z, zlo; };   // qb: a quote candidate lies before s1; zlo: where the last non-blank OUTPUT byte begins (z, or z - 2 for a replaced quote)
+__host__ __device__ __forceinline__ uint64_t pf_out_begin(uint64_t raw_begin, uint32_t d) { return ((raw_begin + 15ull) & ~15ull) + (uint64_t)PF_GAP * d; }
 __device__ __forceinline__ bool pf_isq(uint32_t y) { return y == 0x98u || y == 0x99u || y == 0x9Cu || y == 0x9Du; }
-// the bytes around position base + lane of a document of n bytes at `doc` (0 outside it), for all 64 lanes of a chunk at once: every lane
-// loads its own byte, the two before it and the two behind it come from the neighbouring lanes, and the four bytes either side of the chunk
-// are fetched by the first four lanes (five byte loads per lane were most of what these kernels did)
-struct PfWin { uint32_t p2, p1, x, n1, n2; };
-__device__ __forceinline__ PfWin pf_window(const uint8_t* __restrict__ doc, uint32_t base, int lane, uint32_t n) {
-  const uint32_t i = base + (uint32_t)lane;
-  const uint32_t x = i < n ? doc[i] : 0u;
-  uint32_t edge = 0u;
-  if (lane < 4) {
-    const long long j = lane < 2 ? (long long)base - 2 + lane : (long long)base + 62 + lane;      // base - 2, base - 1, base + 64, base + 65
-    if (j >= 0 && j < (long long)n) edge = doc[j];
-  }
-  // (the neighbours by DPP moves, the four edge bytes through scalar registers: as eight ds_bpermute this was a third of a pass)
-  const uint32_t em2 = read_lane(edge, 0), em1 = read_lane(edge, 1), ep0 = read_lane(edge, 2), ep1 = read_lane(edge, 3);
-  PfWin w;
-  w.x = x;
-  w.p1 = TM_DPP(em1, x, 0x138, 0xF);          // wave_shr:1 - the byte of the lane below (lane 0: the byte in front of the chunk)
-  w.p2 = TM_DPP(em2, w.p1, 0x138, 0xF);
-  w.n1 = TM_DPP(ep0, x, 0x130, 0xF);          // wave_shl:1 - the byte of the lane above (lane 63: the byte behind the chunk)
-  w.n2 = TM_DPP(ep1, w.n1, 0x130, 0xF);
-  return w;
+// four bytes at once: bit 7 of every byte of v that equals the byte c4 holds four times / that is one of 98 99 9C 9D / that is above 32
+__device__ __forceinline__ uint32_t pf_eq(uint32_t v, uint32_t c4) { const uint32_t t = v ^ c4; return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u; }
+__device__ __forceinline__ uint32_t pf_isq4(uint32_t v) { return pf_eq(v & 0xFAFAFAFAu, 0x98989898u); }
+__device__ __forceinline__ uint32_t pf_nb4(uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | v) & 0x80808080u; }
+// the dword at `off` of a document of n bytes behind `win` (a window of (n + 3) & ~3 bytes: the raw text has 256 bytes of room behind its last document): 0 for what lies behind the document
+__device__ __forceinline__ uint32_t pf_load(const TmWindow& win, uint32_t off, uint32_t n) {
+  uint32_t v = tm_window_u32(win, off);
+  const uint32_t rem = n - off;
+  if (rem < 4u) v &= (1u << (8u * rem)) - 1u;
+  return v;
+}
+// position of the first (last) marked byte of the wavefront's 256: `any` = the ballot of m != 0
+__device__ __forceinline__ uint32_t pf_first(unsigned long long any, uint32_t m, uint32_t base) {
+  const int l = __builtin_ctzll(any);
+  return base + 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(read_lane(m, l)) >> 3);
+}
+__device__ __forceinline__ uint32_t pf_last(unsigned long long any, uint32_t m, uint32_t base) {
+  const int l = 63 - __builtin_clzll(any);
+  return base + 4u * (uint32_t)l + ((31u - (uint32_t)__builtin_clz(read_lane(m, l))) >> 3);
 }
 // is the quote whose third byte lies at t left alone (the in-place quirk above)?
 __device__ __forceinline__ bool pf_suppressed(uint32_t flags, const PfDoc& d, uint32_t t) {
   return (flags & 16u) && d.s1 < t && t < d.s2 && d.qb == 0u;      // (d.s2 == PF_NONE: no second drop)
 }
-__global__ __launch_bounds__(256) void k_pf_summary(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ piece_doc,
-                                                    const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t flags, PfPiece* __restrict__ out) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t k = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (k >= npieces) return;
-  const uint32_t d = piece_doc[k];
-  const uint64_t db = raw_off[d];
-  const uint32_t n = (uint32_t)(raw_off[d + 1] - db), p0 = (uint32_t)(k - doc_piece_start[d]) * (uint32_t)PIECE, p1e = min(n, p0 + (uint32_t)PIECE);
-  const uint8_t* doc = raw + db;
-  const bool q = flags & 8u, c = flags & 16u, fused = (flags & 16u) && (flags & 128u);
+// the numbers of the span [rb, re) of a document.  `whole`: the span is the document, and the search for the drops may end at a quote
+// candidate in front of the first of them as well (qb is then 1 whatever follows; spans are combined by positions and need the drops).
+__device__ __forceinline__ PfPiece pf_scan_span(const TmWindow& win, uint32_t n, uint32_t rb, uint32_t re, uint32_t flags, bool whole, uint32_t lane) {
   PfPiece r{PF_NONE, PF_NONE, PF_NONE, PF_NONE, PF_NONE};
-  for (uint32_t base = p0; base < p1e; base += 64u) {
-    const uint32_t i = base + lane;
-    const bool valid = i < p1e;
-    const PfWin w = pf_window(doc, base, (int)lane, n);
-    const bool single = valid && i > 0u && ((c && w.x == ' ' && w.p1 == ' ') || (fused && w.x == '\n' && w.p1 == '\r'));
-    const bool cand = valid && q && i > 1u && pf_isq(w.x) && w.p1 == 0x80u && w.p2 == 0xE2u;
-    unsigned long long mS = __ballot(single);
-    const unsigned long long mQ = __ballot(cand), mN = __ballot(valid && w.x > 32u);
-    if (mS && r.s1 == PF_NONE) { r.s1 = base + (uint32_t)__builtin_ctzll(mS); mS &= mS - 1ull; }
-    if (mS && r.s2 == PF_NONE) r.s2 = base + (uint32_t)__builtin_ctzll(mS);
-    if (mQ && r.fq == PF_NONE) r.fq = base + (uint32_t)__builtin_ctzll(mQ);
-    if (mN) { if (r.a == PF_NONE) r.a = base + (uint32_t)__builtin_ctzll(mN); r.z = base + 63u - (uint32_t)__builtin_clzll(mN); }
-  }
-  if (lane == 0) out[k] = r;
-}
-__global__ void k_pf_doc(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint64_t* __restrict__ doc_piece_start, uint32_t ndocs, uint32_t flags,
-                         const PfPiece* __restrict__ pieces, PfDoc* __restrict__ out) {
-  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= ndocs) return;
-  PfDoc r{PF_NONE, PF_NONE, 0u, PF_NONE, PF_NONE, PF_NONE};
-  uint32_t fq = PF_NONE;
-  for (uint64_t k = doc_piece_start[d]; k < doc_piece_start[d + 1]; k++) {
-    const PfPiece p = pieces[k];
-    if (r.s1 == PF_NONE) { r.s1 = p.s1; r.s2 = p.s2; } else if (r.s2 == PF_NONE) r.s2 = p.s1;
-    if (fq == PF_NONE) fq = p.fq;
-    if (r.a == PF_NONE) r.a = p.a;
-    if (p.z != PF_NONE) r.z = p.z;
-  }
-  r.qb = fq < r.s1 ? 1u : 0u;
-  r.zlo = r.z;
-  if (r.z != PF_NONE && (flags & 8u) && r.z >= 2u) {        // the last non-blank byte is the end of a quote that is replaced: the output byte begins two bytes earlier
-    const uint8_t* doc = raw + raw_off[d];
-    if (pf_isq(doc[r.z]) && doc[r.z - 1u] == 0x80u && doc[r.z - 2u] == 0xE2u && !pf_suppressed(flags, r, r.z)) r.zlo = r.z - 2u;
-  }
-  out[d] = r;
-}
-// what position i of the document emits: *pre - a space in front (leadingspace); returns 0 or 1 and *o, the byte
-__device__ __forceinline__ uint32_t pf_decide(uint32_t flags, const PfDoc& dd, const PfWin& w, uint32_t i, uint32_t n, const uint32_t* __restrict__ acc, uint32_t* pre, uint32_t* o) {
-  *pre = 0u; *o = w.x;
-  const bool q = flags & 8u, c = flags & 16u, u = flags & 128u, trim = flags & 32u, lead = flags & 64u, accents = flags & 4u;
-  // trim / leadingspace: the positions that stay at all, and the one that gets the space
-  uint32_t lo = 0u, hi = n;                                  // [lo, hi) stays
-  bool space_at_lo = false;
-  if (trim) {
-    if (dd.a == PF_NONE) return 0u;                          // blank from end to end: nothing is left
-    if (lead && dd.a == 0u) { if (dd.zlo == 0u) return 0u; hi = dd.zlo; space_at_lo = true; }      // (:274-277: the last non-blank byte goes as well)
-    else { lo = dd.a; hi = dd.z + 1u; space_at_lo = lead; }
-  } else if (lead) space_at_lo = n > 0u;                     // (decided at position 0 below: only in front of a byte that is no space)
-  if (i < lo || i >= hi) return 0u;
-  if (i == lo && space_at_lo && !(lo == 0u && !trim && w.x == ' ')) *pre = 1u;
-  if (c && w.x == ' ' && i > 0u && w.p1 == ' ') return 0u;
-  if (u && w.x == '\r' && i + 1u < n && w.n1 == '\n') return 0u;
-  if (q) {
-    if (w.x == 0xE2u && w.n1 == 0x80u && i + 2u < n && pf_isq(w.n2)) { if (!pf_suppressed(flags, dd, i + 2u)) { *o = w.n2 < 0x9Cu ? '\'' : '"'; return 1u; } }
-    else if (w.x == 0x80u && i >= 1u && w.p1 == 0xE2u && i + 1u < n && pf_isq(w.n1)) { if (!pf_suppressed(flags, dd, i + 1u)) return 0u; }
-    else if (i >= 2u && pf_isq(w.x) && w.p1 == 0x80u && w.p2 == 0xE2u) { if (!pf_suppressed(flags, dd, i)) return 0u; }
-  }
-  if (accents) {
-    // (both halves of the character must have stayed: the cut of trim + leadingspace may have taken the second)
-    if (nm_two_lead(w.x) && i + 1u < hi && nm_cont_byte(w.n1)) {
-      const uint32_t e = acc[nm_two_index(w.x, w.n1)];
-      if ((e & 3u) == 1u) return 0u;
-      if ((e & 3u) >= 2u) *o = (e >> 8) & 0xFFu;
-    } else if (nm_cont_byte(w.x) && i >= lo + 1u && nm_two_lead(w.p1)) {
-      const uint32_t e = acc[nm_two_index(w.p1, w.x)];
-      if ((e & 3u) == 1u || (e & 3u) == 2u) return 0u;
-      if ((e & 3u) == 3u) *o = (e >> 16) & 0xFFu;
+  const bool fused = (flags & 16u) && (flags & 128u), trim = flags & 32u;
+  bool want_s = (flags & 8u) && (flags & 16u), want_a = trim;
+  uint32_t carry = rb >= 4u ? pf_load(win, rb - 4u, n) : 0u;
+#pragma unroll 1
+  for (uint32_t base = rb; base < re && (want_s || want_a); base += 256u) {
+    const uint32_t x = pf_load(win, base + 4u * lane, n);
+    const uint32_t pd = TM_DPP(carry, x, 0x138, 0xF);           // wave_shr:1 - the dword of the lane below (lane 0: the last of the step before)
+    carry = read_lane(x, 63);
+    if (want_s) {
+      const uint32_t p1 = (x << 8) | (pd >> 24), p2 = (x << 16) | (pd >> 16);      // the bytes one / two places in front of the lane's four
+      uint32_t S = pf_eq(x, 0x20202020u) & pf_eq(p1, 0x20202020u);
+      if (fused) S |= pf_eq(x, 0x0A0A0A0Au) & pf_eq(p1, 0x0D0D0D0Du);
+      const uint32_t Q = pf_isq4(x) & pf_eq(p1, 0x80808080u) & pf_eq(p2, 0xE2E2E2E2u);
+      unsigned long long mS = __ballot(S != 0u);
+      while (mS != 0ull && r.s2 == PF_NONE) {
+        const int l = __builtin_ctzll(mS);
+        uint32_t m = read_lane(S, l);
+        const uint32_t pos = base + 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(m) >> 3);
+        if (r.s1 == PF_NONE) r.s1 = pos; else r.s2 = pos;
+        m &= m - 1u;
+        if ((int)lane == l) S = m;
+        if (m == 0u) mS &= mS - 1ull;
+      }
+      const unsigned long long mQ = __ballot(Q != 0u);
+      if (mQ != 0ull && r.fq == PF_NONE) r.fq = pf_first(mQ, Q, base);
+      if (r.s2 != PF_NONE || (whole && r.fq != PF_NONE && (r.s1 == PF_NONE || r.fq < r.s1))) want_s = false;
+    }
+    if (want_a) {
+      const uint32_t N = pf_nb4(x);
+      const unsigned long long mN = __ballot(N != 0u);
+      if (mN != 0ull) { r.a = pf_first(mN, N, base); want_a = false; }
     }
   }
-  return 1u;
-}
-// EMIT == false: bytes a piece leaves (piece_len); EMIT == true: the bytes themselves, at piece_off
-template <bool EMIT>
-__global__ __launch_bounds__(256) void k_pf_pass(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ piece_doc,
-                                                 const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t flags, const PfDoc* __restrict__ docs,
-                                                 const uint32_t* __restrict__ acc, uint32_t* __restrict__ piece_len, const uint64_t* __restrict__ piece_off, uint8_t* __restrict__ out) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t k = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (k >= npieces) return;
-  const uint32_t d = piece_doc[k];
-  const uint64_t db = raw_off[d];
-  const uint32_t n = (uint32_t)(raw_off[d + 1] - db), p0 = (uint32_t)(k - doc_piece_start[d]) * (uint32_t)PIECE, p1e = min(n, p0 + (uint32_t)PIECE);
-  const uint8_t* doc = raw + db;
-  const PfDoc dd = docs[d];
-  const unsigned long long below = (1ull << lane) - 1ull;
-  uint64_t o = EMIT ? piece_off[k] : 0ull;
-  uint32_t total = 0;
-  for (uint32_t base = p0; base < p1e; base += 64u) {
-    const uint32_t i = base + lane;
-    const bool valid = i < p1e;
-    uint32_t pre = 0, byte = 0, keep = 0;
-    const PfWin w = pf_window(doc, base, (int)lane, n);
-    if (valid) keep = pf_decide(flags, dd, w, i, n, acc, &pre, &byte);
-    const unsigned long long mP = __ballot(pre != 0u), mK = __ballot(keep != 0u);
-    if (EMIT) {
-      const uint64_t at = o + (uint64_t)__popcll(mP & below) + (uint64_t)__popcll(mK & below);
-      if (pre) out[at] = ' ';
-      if (keep) out[at + pre] = (uint8_t)byte;
-      o += (uint64_t)__popcll(mP) + (uint64_t)__popcll(mK);
-    } else total += (uint32_t)__popcll(mP) + (uint32_t)__popcll(mK);
+  if (trim && r.a != PF_NONE) {
+#pragma unroll 1
+    for (uint32_t base = rb + ((re - 1u - rb) & ~255u);; base -= 256u) {
+      const uint32_t N = pf_nb4(pf_load(win, base + 4u * lane, n));
+      const unsigned long long mN = __ballot(N != 0u);
+      if (mN != 0ull) { r.z = pf_last(mN, N, base); break; }
+      if (base == rb) break;
+    }
   }
-  if (!EMIT && lane == 0) piece_len[k] = total;
+  return r;
 }
-// the filtered documents' offsets: a document begins where its first piece does (an empty document has none: where the next one's does)
-__global__ void k_pf_offsets(const uint64_t* __restrict__ piece_off, const uint64_t* __restrict__ doc_piece_start, uint32_t ndocs, uint64_t* __restrict__ new_off) {
+// the document's numbers from those of its spans, in order (the numbers of one span: the document's own)
+__device__ __forceinline__ void pf_add_span(PfDoc& r, uint32_t& fq, const PfPiece& p) {
+  if (r.s1 == PF_NONE) { r.s1 = p.s1; r.s2 = p.s2; } else if (r.s2 == PF_NONE) r.s2 = p.s1;
+  if (fq == PF_NONE) fq = p.fq;
+  if (r.a == PF_NONE) r.a = p.a;
+  if (p.z != PF_NONE) r.z = p.z;
+}
+__device__ __forceinline__ void pf_finish(PfDoc& r, uint32_t fq, const uint8_t* __restrict__ doc, uint32_t flags) {
+  r.qb = fq < r.s1 ? 1u : 0u;
+  r.zlo = r.z;
+  // the last non-blank byte is the end of a quote that is replaced: the output byte begins two bytes earlier
+  if (r.z != PF_NONE && (flags & 8u) && r.z >= 2u && pf_isq(doc[r.z]) && doc[r.z - 1u] == 0x80u && doc[r.z - 2u] == 0xE2u && !pf_suppressed(flags, r, r.z)) r.zlo = r.z - 2u;
+}
+// what the span [rb, re) of the document leaves: the number of bytes, and (EMIT) the bytes themselves at `out`
+template <bool EMIT>
+__device__ __forceinline__ uint32_t pf_emit_span(const uint8_t* __restrict__ doc, const TmWindow& win, uint32_t n, uint32_t rb, uint32_t re, uint32_t flags, const PfDoc& dd,
+                                                 const uint32_t* __restrict__ acc, uint8_t* __restrict__ out, uint32_t lane) {
+  const bool q = flags & 8u, c = flags & 16u, u = flags & 128u, trim = flags & 32u, lead = flags & 64u, accents = flags & 4u;
+  // trim / leadingspace: [lo, hi) stays, and a space may go in front of it
+  uint32_t lo = 0u, hi = n;
+  bool pre = false;
+  if (trim) {
+    if (dd.a == PF_NONE) return 0u;                          // blank from end to end: nothing is left
+    if (lead && dd.a == 0u) { if (dd.zlo == 0u) return 0u; hi = dd.zlo; pre = true; }      // (:274-277: the last non-blank byte goes as well)
+    else { lo = dd.a; hi = dd.z + 1u; pre = lead; }
+  } else if (lead) pre = doc[0] != ' ';                      // (n > 0: an empty document has no span)
+  const uint32_t elo = max(lo, rb), ehi = min(hi, re);
+  if (elo >= ehi) return 0u;
+  uint32_t o = 0u;                                           // bytes of the span so far (wave-uniform)
+  if (pre && lo >= rb) { if (EMIT && lane == 0u) out[0] = ' '; o = 1u; }
+  const bool sup_on = q && c && dd.qb == 0u && dd.s1 != PF_NONE;
+  // the sweep begins a dword in front of the first byte that stays: a quote that began there is found where it begins, and the first lane that
+  // matters has its neighbour (nothing of what the sweep looks at lies further back than two bytes)
+  uint32_t base = elo & ~3u;
+  if (base >= 4u) base -= 4u;
+  uint32_t xn = pf_load(win, base + 4u * lane, n), carry = 0u, carry_s = 0u;
+#pragma unroll 1
+  for (; base < ehi; base += 256u) {
+    const uint32_t x = xn, off = base + 4u * lane;
+    xn = pf_load(win, off + 256u, n);
+    const uint32_t pd = TM_DPP(carry, x, 0x138, 0xF);                   // the dword of the lane below (lane 0: the last of the step before)
+    const uint32_t nx = TM_DPP(read_lane(xn, 0), x, 0x130, 0xF);        // the dword of the lane above (lane 63: the first of the next step)
+    carry = read_lane(x, 63);
+    uint32_t D = 0u, y = x;                                              // bit 7 of a byte: it goes; the bytes as they leave
+    if (c) D |= pf_eq(x, 0x20202020u) & pf_eq((x << 8) | (pd >> 24), 0x20202020u);
+    if (u) D |= pf_eq(x, 0x0D0D0D0Du) & pf_eq((x >> 8) | (nx << 24), 0x0A0A0A0Au);
+    if (q) {
+      const uint32_t n1 = (x >> 8) | (nx << 24), n2 = (x >> 16) | (nx << 16);
+      uint32_t S = pf_eq(x, 0xE2E2E2E2u) & pf_eq(n1, 0x80808080u) & pf_isq4(n2);      // a quote begins here
+      if (sup_on && S != 0u) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) { const uint32_t t = off + j + 2u; if (dd.s1 < t && t < dd.s2) S &= ~(0x80u << (8u * j)); }
+      }
+      const uint32_t sp = TM_DPP(carry_s, S, 0x138, 0xF);
+      carry_s = read_lane(S, 63);
+      D |= ((S << 8) | (sp >> 24)) | ((S << 16) | (sp >> 16));           // its second and third byte go
+      const uint32_t full = (S >> 7) * 0xFFu;
+      y = (x & ~full) | ((0x27272727u ^ (((n2 >> 2) & 0x01010101u) * 5u)) & full);      // 98 99 -> ', 9C 9D -> "
+    }
+    if (accents && (x & 0x80808080u) != 0u) {
+      const unsigned long long xx = (unsigned long long)x | ((unsigned long long)nx << 32);
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t b = (x >> (8u * j)) & 0xFFu, i = off + j;
+        if (b < 0x80u) continue;
+        const uint32_t bn = (uint32_t)(xx >> (8u * j + 8u)) & 0xFFu, bp = j ? (x >> (8u * j - 8u)) & 0xFFu : pd >> 24;
+        // (both halves of the character must have stayed: the cut of trim + leadingspace may have taken the second)
+        if (nm_two_lead(b) && i + 1u < hi && nm_cont_byte(bn)) {
+          const uint32_t e = acc[nm_two_index(b, bn)];
+          if ((e & 3u) == 1u) D |= 0x80u << (8u * j);
+          else if ((e & 3u) >= 2u) y = (y & ~(0xFFu << (8u * j))) | (((e >> 8) & 0xFFu) << (8u * j));
+        } else if (nm_cont_byte(b) && i >= lo + 1u && nm_two_lead(bp)) {
+          const uint32_t e = acc[nm_two_index(bp, b)];
+          if ((e & 3u) == 1u || (e & 3u) == 2u) D |= 0x80u << (8u * j);
+          else if ((e & 3u) == 3u) y = (y & ~(0xFFu << (8u * j))) | (((e >> 16) & 0xFFu) << (8u * j));
+        }
+      }
+    }
+    if (base < elo || base + 256u > ehi) {                               // the first and the last step: what lies outside [elo, ehi) goes
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) if (off + j < elo || off + j >= ehi) D |= 0x80u << (8u * j);
+    }
+    // the bytes that stay, packed: w, cnt of them
+    uint32_t w = 0u, s = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) {
+      const uint32_t gone = (D >> (8u * j + 7u)) & 1u;
+      w |= (gone ? 0u : (y >> (8u * j)) & 0xFFu) << s;
+      s += gone ? 0u : 8u;
+    }
+    const uint32_t cnt = s >> 3;
+    const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
+    if (EMIT) {
+      uint8_t* p = out + (o + mbcnt64(b0, 0u) + 2u * mbcnt64(b1, 0u) + 4u * mbcnt64(b2, 0u));
+      if (cnt == 4u) __builtin_memcpy(p, &w, 4);
+      else {
+        if (cnt & 2u) { const uint16_t h = (uint16_t)w; __builtin_memcpy(p, &h, 2); p += 2; w >>= 16; }
+        if (cnt & 1u) *p = (uint8_t)w;
+      }
+    }
+    o += (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+  }
+  return o;
+}
+// A wavefront per span (span_doc null: per document, every document one span or none).  A document that is one span is filtered here from end
+// to end; of a longer one the span's numbers are left for the two kernels below.  rbegin / rend: the filtered document's range in `out`.
+__global__ __launch_bounds__(256) void k_pf_filter(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ span_doc,
+                                                   const uint64_t* __restrict__ doc_span_start, uint64_t nspans, uint32_t flags, const uint32_t* __restrict__ acc,
+                                                   PfPiece* __restrict__ span_sum, uint8_t* __restrict__ out, uint64_t* __restrict__ rbegin, uint64_t* __restrict__ rend) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t k = (uint64_t)blockIdx.x * 4u + (uint64_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (k >= nspans) return;
+  const uint32_t d = span_doc ? span_doc[k] : (uint32_t)k;
+  const uint64_t db = raw_off[d], ob = pf_out_begin(db, d);
+  const uint32_t n = (uint32_t)(raw_off[d + 1] - db);
+  if (n == 0u) { if (lane == 0u) { rbegin[d] = ob; rend[d] = ob; } return; }
+  const uint32_t rb = span_doc ? (uint32_t)(k - doc_span_start[d]) * PF_SPAN : 0u, re = min(n, rb + PF_SPAN);
+  const bool whole = n <= PF_SPAN;
+  const uint8_t* doc = raw + db;
+  const TmWindow win = tm_window(doc, (n + 3u) & ~3u);
+  const PfPiece p = pf_scan_span(win, n, rb, re, flags, whole, lane);
+  if (!whole) { if (lane == 0u) span_sum[k] = p; return; }
+  PfDoc dd{PF_NONE, PF_NONE, 0u, PF_NONE, PF_NONE, PF_NONE};
+  uint32_t fq = PF_NONE;
+  pf_add_span(dd, fq, p);
+  pf_finish(dd, fq, doc, flags);
+  const uint32_t len = pf_emit_span<true>(doc, win, n, rb, re, flags, dd, acc, out + ob, lane);
+  if (lane == 0u) { rbegin[d] = ob; rend[d] = ob + len; }
+}
+// the spans of the documents of more than one: EMIT == false - the document's numbers (left in `docs` by its first span) and the bytes the span
+// leaves (span_len); EMIT == true - the bytes themselves, behind those of the document's spans in front
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_pf_long(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ span_doc,
+                                                 const uint64_t* __restrict__ doc_span_start, uint64_t nspans, uint32_t flags, const uint32_t* __restrict__ acc,
+                                                 const PfPiece* __restrict__ span_sum, PfDoc* __restrict__ docs, uint32_t* __restrict__ span_len,
+                                                 uint8_t* __restrict__ out, uint64_t* __restrict__ rbegin, uint64_t* __restrict__ rend) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t k = (uint64_t)blockIdx.x * 4u + (uint64_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (k >= nspans) return;
+  const uint32_t d = span_doc[k];
+  const uint64_t db = raw_off[d], ob = pf_out_begin(db, d), k0 = doc_span_start[d];
+  const uint32_t n = (uint32_t)(raw_off[d + 1] - db);
+  if (n <= PF_SPAN) return;
+  const uint32_t rb = (uint32_t)(k - k0) * PF_SPAN, re = min(n, rb + PF_SPAN);
+  const uint8_t* doc = raw + db;
+  const TmWindow win = tm_window(doc, (n + 3u) & ~3u);
+  if (!EMIT) {
+    PfDoc dd{PF_NONE, PF_NONE, 0u, PF_NONE, PF_NONE, PF_NONE};
+    uint32_t fq = PF_NONE;
+    for (uint64_t j = k0; j < doc_span_start[d + 1]; j++) pf_add_span(dd, fq, span_sum[j]);
+    pf_finish(dd, fq, doc, flags);
+    const uint32_t len = pf_emit_span<false>(doc, win, n, rb, re, flags, dd, acc, nullptr, lane);
+    if (lane == 0u) { span_len[k] = len; if (k == k0) docs[d] = dd; }
+  } else {
+    const PfDoc dd = docs[d];
+    uint64_t at = 0;
+    for (uint64_t j = k0; j < k; j++) at += span_len[j];
+    const uint32_t len = pf_emit_span<true>(doc, win, n, rb, re, flags, dd, acc, out + ob + at, lane);
+    if (lane == 0u && k + 1 == doc_span_start[d + 1]) { rbegin[d] = ob; rend[d] = ob + at + len; }
+  }
+}
+// spans per document, for a batch with a document of more than one (an empty document has none: its range is written here)
+__global__ void k_pf_begin(const uint64_t* __restrict__ raw_off, uint32_t ndocs, uint32_t* __restrict__ doc_nspan, uint64_t* __restrict__ rbegin, uint64_t* __restrict__ rend) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d <= ndocs) new_off[d] = piece_off[doc_piece_start[d]];
+  if (d >= ndocs) return;
+  const uint64_t db = raw_off[d], n = raw_off[d + 1] - db;
+  doc_nspan[d] = (uint32_t)((n + PF_SPAN - 1) / PF_SPAN);
+  if (n == 0) { rbegin[d] = pf_out_begin(db, d); rend[d] = rbegin[d]; }
 }
 
 // One side of these two copies is pinned HOST memory, reached over PCIe: that side is accessed in aligned 16-byte units (a byte
@@ -1037,29 +1149,34 @@ static uint32_t norm_grid() {
   return slot;
 }
 
-// The filter pass (k_pf_*, above) on the uploaded text: *R / *RO = the filtered text and its documents' offsets (device), *np = its pieces.
-// One trip to the host of its own (the new offsets: the normalizer pass is launched over the pieces they make).
-static int prefilter(tm_batch* b, hipStream_t st, uint32_t norm_flag, const uint8_t** R, const uint64_t** RO, uint64_t* np_out) {
+// The filter pass (k_pf_*, above) on the uploaded text: *R = the filtered text, *RB / *RE = where its documents begin and end (device), *np = its
+// pieces, whose table (k_norm_begin + scan) is made here.  One trip to the host of its own (the piece count: the normalizer pass is launched over it).
+static int prefilter(tm_batch* b, hipStream_t st, uint32_t norm_flag, const uint8_t** R, const uint64_t** RB, const uint64_t** RE, uint64_t* np_out) {
   const uint32_t nd = b->raw_docs;
   hipError_t e;
-  uint64_t np0 = 0;
+  uint64_t nspans = 0;
+  bool any_long = false;
   for (uint32_t d = 0; d < nd; d++) {
     const uint64_t len = b->h_raw_off[d + 1] - b->h_raw_off[d];
-    if (len >= 0xFFFFFFF0ull) return set_error(TM_E_LIMIT, "document %u has %llu bytes: beyond what the filter pass addresses", d, (unsigned long long)len);
-    np0 += (len + PIECE - 1) / PIECE;
+    if (len >= 0xFFFF0000ull) return set_error(TM_E_LIMIT, "document %u has %llu bytes: beyond what the filter pass addresses", d, (unsigned long long)len);
+    nspans += (len + PF_SPAN - 1) / PF_SPAN;
+    any_long = any_long || len > PF_SPAN;
   }
-  const uint64_t out_cap = b->raw_bytes + nd + 256;
+  const uint64_t out_cap = b->raw_bytes + (uint64_t)PF_GAP * nd + 256;
   if ((e = grow(&b->d_rawf, &b->rawf_cap, out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc (filtered text)");
   if (!b->d_rawf_off || b->rawf_docs_cap < (uint64_t)nd + 2) {
     (void)hipFree(b->d_rawf_off); (void)hipFree(b->d_pf_doc);
     b->d_rawf_off = nullptr; b->d_pf_doc = nullptr;
     b->rawf_docs_cap = (uint64_t)nd + nd / 4 + 16;
-    if ((e = hipMalloc((void**)&b->d_rawf_off, b->rawf_docs_cap * 8)) != hipSuccess || (e = hipMalloc((void**)&b->d_pf_doc, b->rawf_docs_cap * sizeof(PfDoc))) != hipSuccess)
+    if ((e = hipMalloc((void**)&b->d_rawf_off, b->rawf_docs_cap * 16)) != hipSuccess || (e = hipMalloc((void**)&b->d_pf_doc, b->rawf_docs_cap * sizeof(PfDoc))) != hipSuccess)
       return hip_fail(e, "hipMalloc (filtered documents)");
   }
-  { uint8_t* pp = (uint8_t*)b->d_pf_piece; uint64_t cap = b->pf_piece_cap;
-    if ((e = grow(&pp, &cap, (np0 + 1) * sizeof(PfPiece))) != hipSuccess) return hip_fail(e, "hipMalloc (filter pass)");
-    b->d_pf_piece = pp; b->pf_piece_cap = cap; }
+  if (any_long) {
+    uint8_t* pp = (uint8_t*)b->d_pf_piece; uint64_t cap = b->pf_piece_cap;
+    if ((e = grow(&pp, &cap, (nspans + 1) * sizeof(PfPiece))) != hipSuccess) return hip_fail(e, "hipMalloc (filter pass)");
+    b->d_pf_piece = pp; b->pf_piece_cap = cap;
+    if (nspans + 2 > b->piece_cap) return set_error(TM_E_INTERNAL, "the filter pass has %llu spans, the workspace holds %llu pieces", (unsigned long long)nspans, (unsigned long long)b->piece_cap);
+  }
   if ((norm_flag & 4u) && !b->d_acc) {
     std::vector<uint32_t> acc(NM_TWO_SIZE);
     build_accent_table(acc.data());
@@ -1067,30 +1184,30 @@ static int prefilter(tm_batch* b, hipStream_t st, uint32_t norm_flag, const uint
     int rc = small_h2d(b, b->d_acc, acc.data(), acc.size() * 4, st);
     if (rc != TM_OK) return rc;
   }
-  unsigned long long* ninfo = (unsigned long long*)b->d_ninfo;
-  // the pieces of the ORIGINAL documents
-  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, b->d_raw_off, nd, b->d_doc_npiece, b->d_need_host, ninfo);
-  scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
-  if (np0 > 0) {
-    launch_unit_owner(b->d_doc_piece_start, nd, np0, b->d_piece_doc, st);
-    const uint32_t pgrid = (uint32_t)((np0 + 3) / 4);
-    PfPiece* pieces = (PfPiece*)b->d_pf_piece;
+  uint64_t* rb = b->d_rawf_off;
+  uint64_t* re = b->d_rawf_off + b->rawf_docs_cap;
+  if (!any_long)
+    TM_LAUNCH(k_pf_filter, (nd + 3) / 4, 256, 0, st, b->d_raw, b->d_raw_off, nullptr, nullptr, (uint64_t)nd, norm_flag, b->d_acc, nullptr, b->d_rawf, rb, re);
+  else {
+    // a document of more than one span: the spans' table (in the arrays the pieces' table takes afterwards), and three launches over it
+    PfPiece* sums = (PfPiece*)b->d_pf_piece;
     PfDoc* docs = (PfDoc*)b->d_pf_doc;
-    TM_LAUNCH(k_pf_summary, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_piece_doc, b->d_doc_piece_start, np0, norm_flag, pieces);
-    TM_LAUNCH(k_pf_doc, (nd + 255) / 256, 256, 0, st, b->d_raw, b->d_raw_off, b->d_doc_piece_start, nd, norm_flag, pieces, docs);
-    TM_LAUNCH(k_pf_pass<false>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_piece_doc, b->d_doc_piece_start, np0, norm_flag, docs, b->d_acc, b->d_piece_len, nullptr, nullptr);
-    scan_u32(b->d_piece_len, np0, b->d_scan_tmp, b->d_totals + 3, b->d_piece_off, st);
-    TM_LAUNCH(k_pf_pass<true>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_piece_doc, b->d_doc_piece_start, np0, norm_flag, docs, b->d_acc, nullptr, b->d_piece_off, b->d_rawf);
-    TM_LAUNCH(k_pf_offsets, (nd + 256) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, nd, b->d_rawf_off);
-  } else (void)hipMemsetAsync(b->d_rawf_off, 0, ((size_t)nd + 1) * 8, st);
-  // the filtered documents' offsets, for the pieces the normalizer pass is launched over
-  std::vector<uint64_t> off((size_t)nd + 1);
-  if ((e = hipMemcpyAsync(off.data(), b->d_rawf_off, off.size() * 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "D2H filtered offsets");
+    const uint32_t sgrid = (uint32_t)((nspans + 3) / 4);
+    TM_LAUNCH(k_pf_begin, (nd + 255) / 256, 256, 0, st, b->d_raw_off, nd, b->d_doc_npiece, rb, re);
+    scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
+    launch_unit_owner(b->d_doc_piece_start, nd, nspans, b->d_piece_doc, st);
+    TM_LAUNCH(k_pf_filter, sgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_piece_doc, b->d_doc_piece_start, nspans, norm_flag, b->d_acc, sums, b->d_rawf, rb, re);
+    TM_LAUNCH(k_pf_long<false>, sgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_piece_doc, b->d_doc_piece_start, nspans, norm_flag, b->d_acc, sums, docs, b->d_piece_len, nullptr, rb, re);
+    TM_LAUNCH(k_pf_long<true>, sgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_piece_doc, b->d_doc_piece_start, nspans, norm_flag, b->d_acc, sums, docs, b->d_piece_len, b->d_rawf, rb, re);
+  }
+  // the pieces of the filtered documents
+  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, rb, re, nd, b->d_doc_npiece, b->d_need_host, (unsigned long long*)b->d_ninfo);
+  scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
   uint64_t np = 0;
-  for (uint32_t d = 0; d < nd; d++) np += (off[d + 1] - off[d] + PIECE - 1) / PIECE;
-  if (np + 2 > b->piece_cap || (np + 1) * (uint64_t)SLAB > b->slab_cap * sizeof(b->d_slab[0]) || off[nd] > out_cap)
-    return set_error(TM_E_INTERNAL, "the filter pass left %llu pieces / %llu bytes, the workspace holds %llu pieces", (unsigned long long)np, (unsigned long long)off[nd], (unsigned long long)b->piece_cap);
-  *R = b->d_rawf; *RO = b->d_rawf_off; *np_out = np;
+  if ((e = hipMemcpyAsync(&np, b->d_totals + 3, 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "D2H filtered piece count");
+  if (np + 2 > b->piece_cap || (np + 1) * (uint64_t)SLAB > b->slab_cap * sizeof(b->d_slab[0]))
+    return set_error(TM_E_INTERNAL, "the filter pass left %llu pieces, the workspace holds %llu", (unsigned long long)np, (unsigned long long)b->piece_cap);
+  *R = b->d_rawf; *RB = rb; *RE = re; *np_out = np;
   return TM_OK;
 }
 
@@ -1106,9 +1223,11 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   uint64_t np = b->raw_pieces;
   hipError_t e;
   const uint8_t* R = b->d_raw;                 // the text the normalizer pass reads, and its documents: the upload's, or what the filter pass makes of it
-  const uint64_t* RO = b->d_raw_off;
-  if ((norm_flag & ~3u) && nd > 0 && (capcode == 0 || capcode == 2)) {
-    int rc = prefilter(b, st, norm_flag, &R, &RO, &np);
+  const uint64_t* RB = b->d_raw_off;
+  const uint64_t* RE = b->d_raw_off + 1;
+  const bool filtered = (norm_flag & ~3u) && nd > 0 && (capcode == 0 || capcode == 2);
+  if (filtered) {
+    int rc = prefilter(b, st, norm_flag, &R, &RB, &RE, &np);
     if (rc != TM_OK) return rc;
   }
   b->host_fallback_docs = 0;
@@ -1124,8 +1243,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   const uint32_t lower_all = (norm_flag & 2u) ? 1u : 0u;
   unsigned long long* ninfo = (unsigned long long*)b->d_ninfo;
   // piece table
-  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, RO, nd, b->d_doc_npiece, b->d_need_host, ninfo);
-  scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
+  if (!filtered) {                             // (the filter pass has made the table of ITS documents' pieces)
+    TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, RB, RE, nd, b->d_doc_npiece, b->d_need_host, ninfo);
+    scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
+  }
   const uint32_t pgrid = (uint32_t)((np + 3) / 4);
   const uint32_t egrid = std::min(pgrid, norm_grid());       // k_norm_emit2: its wavefronts take piece after piece
   if (np > 0) launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
@@ -1144,10 +1265,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   uint64_t pre_bytes = 0;
   if (fast) {
     if (capcode == 2)
-      TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
+      TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
                                                  b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
     else
-      TM_LAUNCH(k_norm_emit<3>, pgrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+      TM_LAUNCH(k_norm_emit<3>, pgrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                             nullptr, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
     TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
     scan_u32(b->d_piece_len, np, b->d_scan_tmp, reinterpret_cast<uint64_t*>(ninfo + 5), b->d_piece_off, st);      // (the total lands beside the info words: one copy brings everything)
@@ -1183,7 +1304,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     }
   }
   if (!fast) {
-    if (np > 0) TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_two, b->d_piece_sum);
+    if (np > 0) TM_LAUNCH(k_norm_summary, pgrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_two, b->d_piece_sum);
     TM_LAUNCH(k_norm_carry, (nd + 255) / 256, 256, 0, st, b->d_piece_sum, b->d_doc_piece_start, nd, b->d_piece_carry, b->d_need_host, ninfo, b->d_fb_ids,
                                                     0u);
     int rc = small_d2h(b, h_info, ninfo, 8, st); if (rc == TM_OK) rc = small_sync(b, st); if (rc != TM_OK) return rc;
@@ -1195,10 +1316,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   double f1 = now(), f2 = 0, f3 = 0, f4 = 0;
   // the exact path: the device normalizes its documents with the carries given (one pass into per-piece slabs, lengths on the side) ...
   if (!fast && np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
-    TM_LAUNCH(k_norm_emit2<true>, egrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
+    TM_LAUNCH(k_norm_emit2<true>, egrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
                                               b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
   else if (!fast && np > 0)           // capcode 0, or debug bit 8: the per-lane version of the rules
-    TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+    TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                           b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
   if (!pre) scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
   if (!pre && np > 0 && nf == 0) TM_LAUNCH(k_norm_short, (uint32_t)((np + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, b->d_piece_len, ninfo);
@@ -1271,7 +1392,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
       if (nf > 0 || h_info[6] != 0 || (tm_debug_flags(-1) & 2048)) pack_text(b, st);
     } else {
       // some piece expands beyond its slab (long runs of capitals): exact two-pass path
-      TM_LAUNCH(k_norm_emit<1>, pgrid, 256, 0, st, R, RO, RO + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+      TM_LAUNCH(k_norm_emit<1>, pgrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
                                             b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text, nullptr, b->d_two);
     }
   }
@@ -1333,7 +1454,7 @@ int ring_enqueue_normalize(tm_batch* b, hipStream_t st, uint64_t seg_bound) {
   (void)hipGetLastError();
   const uint32_t lower_all = (norm_flag & 2u) ? 1u : 0u;
   unsigned long long* ninfo = (unsigned long long*)b->d_ninfo;
-  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, b->d_raw_off, nd, b->d_doc_npiece, b->d_need_host, ninfo);
+  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, b->d_raw_off, b->d_raw_off + 1, nd, b->d_doc_npiece, b->d_need_host, ninfo);
   scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
   const uint32_t pgrid = (uint32_t)((np + 3) / 4);
   const uint32_t egrid = std::min(pgrid, norm_grid());

@@ -35,8 +35,22 @@ for name, words in WORDS.items():
     b = C.c_void_p()
     N.check(N.lib.tm_batch_create(v.handle, int(raw.size) * 2 + (1 << 20), nd, C.byref(b)))
     N.check(N.lib.tm_batch_upload_raw(b, N.ptr(raw), N.ptr(offs), nd))
+    import time
     N.check(N.lib.tm_batch_normalize(b, None)); N.check(N.lib.tm_batch_run(b, None))
+    nt, nm = C.c_uint64(), C.c_uint64()
+    N.check(N.lib.tm_batch_totals(b, C.byref(nt), C.byref(nm)))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        N.check(N.lib.tm_batch_normalize(b, None))
+    t_norm = (time.perf_counter() - t0) / 3 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(3):
+        N.check(N.lib.tm_batch_run(b, None))
+    N.check(N.lib.tm_batch_totals(b, C.byref(nt), C.byref(nm)))
+    t_run = (time.perf_counter() - t0) / 3 * 1e3
     enc = int(N.lib.tm_batch_normalized_bytes(b))
+    print("%-18s tokenize: normalize %.2f ms + K0-K4 %.2f ms per GiB of raw text (%d documents to the host normalizer)" % (
+        name, t_norm * (1 << 30) / raw.size, t_run * (1 << 30) / raw.size, int(N.lib.tm_batch_host_fallback_docs(b))), flush=True)
     nbytes, hostd = C.c_uint64(), C.c_uint32()
     ms = (C.c_float * 3)()
     acc = np.zeros(3)
