@@ -686,14 +686,19 @@ __global__ void k_norm_info(const uint64_t* __restrict__ nbegin, const uint64_t*
 // found ONCE, at its first byte, and its other two bytes take their verdict from there, the lane packs the bytes it keeps and writes them
 // with one store (two where it dropped something).  The filtered documents are not packed: document d begins on a 16-byte boundary of its
 // own, PF_GAP bytes further from where it began for every document in front of it (the normalizer pass takes begin and end of a document
-// from two arrays).  A document of more than PF_SPAN bytes (rare) is filtered by a wavefront per span in three launches - numbers per span,
+// from two arrays).  A document of more than PF_WHOLE bytes (rare) is filtered by a wavefront per span of PF_SPAN in three launches - numbers per span,
 // sizes per span, bytes - of which the last two skip every other document.
 constexpr uint32_t PF_NONE = 0xFFFFFFFFu;
 #ifndef TM_PF_SPAN
-#define TM_PF_SPAN 16384u       // (the emulated fuzz also runs with 1024: documents of many spans)
+#define TM_PF_SPAN 4096u        // (the emulated fuzz also runs with 1024 / 1024: documents of many spans)
 #endif
-constexpr uint32_t PF_SPAN = TM_PF_SPAN, PF_GAP = 32u;
-static_assert(PF_SPAN % 256u == 0u && PF_SPAN >= (uint32_t)PIECE, "a span is whole steps of the sweep, and the spans' table lives in the pieces' arrays");
+#ifndef TM_PF_WHOLE
+#define TM_PF_WHOLE 16384u
+#endif
+// a document of up to PF_WHOLE bytes is one wavefront's; a longer one is cut into spans of PF_SPAN (a span is a wavefront's work from end to end - 16 steps, three times)
+constexpr uint32_t PF_SPAN = TM_PF_SPAN, PF_WHOLE = TM_PF_WHOLE, PF_GAP = 32u;
+static_assert(PF_SPAN % 256u == 0u && PF_SPAN >= (uint32_t)PIECE && PF_WHOLE >= PF_SPAN, "a span is whole steps of the sweep, and the spans' table lives in the pieces' arrays");
+__host__ __device__ __forceinline__ uint32_t pf_spans(uint64_t n) { return n <= PF_WHOLE ? (n ? 1u : 0u) : (uint32_t)((n + PF_SPAN - 1) / PF_SPAN); }
 struct PfPiece { uint32_t s1, s2, fq, a, z; };      // of a span; positions in the document: first / second single drop, first quote candidate (its third byte), first / last byte above 32
 struct PfDoc { uint32_t s1, s2, qb, a, z, zlo; };   // qb: a quote candidate lies before s1; zlo: where the last non-blank OUTPUT byte begins (z, or z - 2 for a replaced quote)
 __host__ __device__ __forceinline__ uint64_t pf_out_begin(uint64_t raw_begin, uint32_t d) { return ((raw_begin + 15ull) & ~15ull) + (uint64_t)PF_GAP * d; }
@@ -886,8 +891,8 @@ __global__ __launch_bounds__(256) void k_pf_filter(const uint8_t* __restrict__ r
   const uint64_t db = raw_off[d], ob = pf_out_begin(db, d);
   const uint32_t n = (uint32_t)(raw_off[d + 1] - db);
   if (n == 0u) { if (lane == 0u) { rbegin[d] = ob; rend[d] = ob; } return; }
-  const uint32_t rb = span_doc ? (uint32_t)(k - doc_span_start[d]) * PF_SPAN : 0u, re = min(n, rb + PF_SPAN);
-  const bool whole = n <= PF_SPAN;
+  const bool whole = n <= PF_WHOLE;
+  const uint32_t rb = span_doc ? (uint32_t)(k - doc_span_start[d]) * PF_SPAN : 0u, re = whole ? n : min(n, rb + PF_SPAN);
   const uint8_t* doc = raw + db;
   const TmWindow win = tm_window(doc, (n + 3u) & ~3u);
   const PfPiece p = pf_scan_span(win, n, rb, re, flags, whole, lane);
@@ -912,7 +917,7 @@ __global__ __launch_bounds__(256) void k_pf_long(const uint8_t* __restrict__ raw
   const uint32_t d = span_doc[k];
   const uint64_t db = raw_off[d], ob = pf_out_begin(db, d), k0 = doc_span_start[d];
   const uint32_t n = (uint32_t)(raw_off[d + 1] - db);
-  if (n <= PF_SPAN) return;
+  if (n <= PF_WHOLE) return;
   const uint32_t rb = (uint32_t)(k - k0) * PF_SPAN, re = min(n, rb + PF_SPAN);
   const uint8_t* doc = raw + db;
   const TmWindow win = tm_window(doc, (n + 3u) & ~3u);
@@ -936,7 +941,7 @@ __global__ void k_pf_begin(const uint64_t* __restrict__ raw_off, uint32_t ndocs,
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ndocs) return;
   const uint64_t db = raw_off[d], n = raw_off[d + 1] - db;
-  doc_nspan[d] = (uint32_t)((n + PF_SPAN - 1) / PF_SPAN);
+  doc_nspan[d] = pf_spans(n);
   if (n == 0) { rbegin[d] = pf_out_begin(db, d); rend[d] = rbegin[d]; }
 }
 
@@ -1159,8 +1164,8 @@ static int prefilter(tm_batch* b, hipStream_t st, uint32_t norm_flag, const uint
   for (uint32_t d = 0; d < nd; d++) {
     const uint64_t len = b->h_raw_off[d + 1] - b->h_raw_off[d];
     if (len >= 0xFFFF0000ull) return set_error(TM_E_LIMIT, "document %u has %llu bytes: beyond what the filter pass addresses", d, (unsigned long long)len);
-    nspans += (len + PF_SPAN - 1) / PF_SPAN;
-    any_long = any_long || len > PF_SPAN;
+    nspans += pf_spans(len);
+    any_long = any_long || len > PF_WHOLE;
   }
   const uint64_t out_cap = b->raw_bytes + (uint64_t)PF_GAP * nd + 256;
   if ((e = grow(&b->d_rawf, &b->rawf_cap, out_cap)) != hipSuccess) return hip_fail(e, "hipMalloc (filtered text)");
