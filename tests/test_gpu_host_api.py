@@ -419,6 +419,39 @@ def test_ring_equals_single_batch():
         N.lib.tm_debug_flags(old)
 
 
+def test_ring_takes_vocabularies_with_byte_level_flags():
+    """A vocabulary with quotemarks / collapse / trim / leadingspace / unixlines / accents (training/README.md:110-123) runs on the ring too: its
+    filter pass (tm_norm.hip: k_pf_*) is enqueued in front of the normalizer pass, which is then launched over the pieces of the RAW documents - a
+    bound - and takes the count of the filtered documents' pieces from the device.  ids == the host normalizer's text through the batch path."""
+    from conftest import EMULATED
+    img0 = synth.synth_vocab(synth.ENGLISHCODE, 3000, capcode=2, norm_flag=1, level=3, seed=0x52494E47)
+    raw0, roffs0 = synth.synth_corpus(synth.ENGLISHCODE, 200_000 if EMULATED else 3_000_000, seed=76)
+    docs = [bytes(raw0[int(roffs0[d]):int(roffs0[d + 1])]) for d in range(roffs0.size - 1)]
+    extra = [b"  Hello   World \r\n", "\u201cQuoted\u201d  caf\u00e9  \u2018x\u2019 ".encode(), b"", b" \t ", b"one  two \r\n three\r\n\r\n  four  ",
+             ("some  plain  words \u2018q\u2019 \r\n" * 40).encode(), ("a \u2019b" * 2730 + "  " + "\u2018c\u2019 \u00e9\u00f1" * 2000 + "  d \u201d x").encode(),
+             b" " * 3000 + b"padded  both   ends\r\n" + b" " * 5000, b"x"]
+    for i, e in enumerate(extra):
+        docs.insert((i * len(docs)) // len(extra), e)
+    raw = np.frombuffer(b"".join(docs), dtype=np.uint8).copy()
+    roffs = np.zeros(len(docs) + 1, dtype=np.uint64)
+    roffs[1:] = np.cumsum([len(x) for x in docs])
+    pin = _pinned_copy(raw)
+    for flag in (2 | 8 | 16 | 32 | 128, 255, 1 | 64, 1 | 4 | 16):
+        img = bytes(img0[:2]) + bytes([flag]) + bytes(img0[3:])
+        v = tm.Vocab(img)
+        text, offs = synth.normalize_batch(raw, roffs, 2, flag)
+        ids, toff, miss = v.tokenize_packed(text, offs)
+        pout = tm.PinnedBuffer(2 * ids.size + 64)
+        for chunk, lanes in ((25_000, 3), (70_000, 2)):
+            blob, boff, bmiss, enc, st = v.tokenize_pipeline(pin.array[: raw.size], roffs, raw=True, chunk_bytes=chunk, lanes=lanes, out=pout.array)
+            # (the long document of marks grows by more than the 25 % the segment kernels of a chunk are launched over when neither accents nor
+            # lowercase shrinks it again, and is then a chunk for the exact path - as without a filter pass)
+            assert st["ring"] == 1 and st["ring_exact_chunks"] <= (0 if flag & 6 else 1) and st["chunks"] > 3, (flag, st)
+            assert st["host_fallback_docs"] == 0 and st["normalized_bytes"] == text.size, (flag, st)
+            assert (boff == toff * np.uint64(enc)).all() and (bmiss == miss).all(), flag
+            assert (_ids_from_bytes(np.asarray(blob), enc) == ids).all(), flag
+
+
 def test_ring_hands_chunks_to_the_exact_path():
     """A chunk the one-pass form of the ring cannot finish by itself - a document for the host normalizer, a document of more than 512 segments,
     text that capcode more than doubles (beyond the bound the segment kernels were launched over) - costs nothing behind its normalizer pass

@@ -625,7 +625,8 @@ static int pipeline_ring(PipeCall& c, const std::vector<Ring*>& rings) {
         uint64_t* lo = s.h_roff();
         uint64_t npieces = 0;
         for (uint32_t d = 0; d <= nd; d++) lo[d] = c.offsets[d0 + d] - b0;
-        for (uint32_t d = 0; d < nd; d++) npieces += (lo[d + 1] - lo[d] + 1023) / 1024;
+        const uint64_t grows = (v->host.norm_flag & 64u) ? 1u : 0u;       // (leadingspace: as batch_upload_raw_on counts them)
+        for (uint32_t d = 0; d < nd; d++) npieces += (lo[d + 1] - lo[d] + grows + 1023) / 1024;
         hipStream_t cs = r.comp[issued % r.comp.size()];
         hipError_t e = hipSuccess;
         const double ti0 = trace ? now_ms() : 0;
@@ -635,7 +636,7 @@ static int pipeline_ring(PipeCall& c, const std::vector<Ring*>& rings) {
             (e = hipEventRecord(s.up_done, r.up)) != hipSuccess || (e = hipStreamWaitEvent(cs, s.up_done, 0)) != hipSuccess) { rc = hip_fail(e, "ring upload"); break; }
         const uint64_t seg_bound = (nb / 100 * slack_pct + 99) / SEG + nd + 1;
         s.h_status()[0] = ~0ull;
-        if ((rc = ring_enqueue_normalize(b, cs, seg_bound)) != TM_OK) break;
+        if ((rc = ring_enqueue_normalize(b, cs, seg_bound, lo)) != TM_OK) break;
         if ((rc = ring_enqueue_tokenize(b, cs, c.enc, s.d_bytes, s.d_bytes_cap, s.h_status(), &s.ids_at)) != TM_OK) break;
         if ((e = hipEventRecord(s.comp_done, cs)) != hipSuccess) { rc = hip_fail(e, "hipEventRecord"); break; }
         if (trace) fprintf(stderr, "[ring] issue chunk %3zu (%5.1f MiB, %u docs) slot %d at %7.2f ms, %.3f ms of launches\n", k, nb / 1048576.0, nd, si, ti0 - c.t0, now_ms() - ti0);

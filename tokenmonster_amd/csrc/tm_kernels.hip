@@ -2131,8 +2131,8 @@ static hipError_t dalloc(tm_batch* b, T** p, uint64_t count) { return batch_allo
 void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32_t ndocs, uint32_t unit, uint32_t* doc_nunits, hipStream_t st) {
   if (ndocs) TM_LAUNCH(k_doc_nseg, (ndocs + 255) / 256, 256, 0, st, doc_begin, doc_end, ndocs, doc_nunits, unit);
 }
-void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st) {
-  if (nunits) TM_LAUNCH(k_segments, (uint32_t)((nunits + 255) / 256), 256, 0, st, doc_unit_start, ndocs, nunits, unit_doc);
+void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st, const uint64_t* count_dev) {
+  if (nunits) TM_LAUNCH(k_segments, (uint32_t)((nunits + 255) / 256), 256, 0, st, doc_unit_start, ndocs, nunits, unit_doc, count_dev);
 }
 static void launch_seg_params(tm_batch* b, hipStream_t st);
 void launch_chain_hist(tm_batch* b, uint32_t delete_id, int n_cu, uint32_t* d_hist, unsigned long long* d_tokens, uint32_t* d_missing_bits,

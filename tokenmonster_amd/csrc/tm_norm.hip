@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
                                                    uint32_t lower_all, const uint8_t* __restrict__ piece_carry,
                                                    uint8_t* __restrict__ need_host, uint32_t* __restrict__ piece_len,
                                                    const uint64_t* __restrict__ piece_off, uint8_t* __restrict__ out,
-                                                   unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two) {
+                                                   unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two,
+                                                   const uint64_t* __restrict__ np_dev) {
   constexpr bool WRITE = MODE != 0;
+  if (np_dev) npieces = min(npieces, np_dev[0]);       // (the ring behind a filter pass: launched over a bound, the count is the device's)
   __shared__ PieceLds s_l[4];
   __shared__ uint8_t s_cls[128];
   __shared__ TabLds s_tab;
@@ -434,8 +436,10 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
                                                     const uint64_t* __restrict__ doc_piece_start, uint64_t npieces, uint32_t lower_all,
                                                     const uint8_t* __restrict__ piece_carry, uint8_t* __restrict__ need_host,
                                                     uint32_t* __restrict__ piece_len, uint8_t* __restrict__ slab,
-                                                    unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two) {
+                                                    unsigned long long* __restrict__ overflow, const NmTwo* __restrict__ two,
+                                                    const uint64_t* __restrict__ np_dev) {
   constexpr int SLAB2 = 2 * PIECE, NCH = PIECE / 64;
+  if (np_dev) npieces = min(npieces, np_dev[0]);       // (the ring behind a filter pass: launched over a bound, the count is the device's)
   __shared__ PieceLds2 s_l[4];
   __shared__ uint8_t s_cls[128];
   __shared__ TabLds s_tab;
@@ -593,9 +597,11 @@ __global__ void k_norm_begin(const uint64_t* __restrict__ rbegin, const uint64_t
 // ... and ninfo[6] counts the pieces that are not the last of their document yet shorter than what a segment looks at (TEXT_LEN): with one
 // of those the text cannot be staged from the slabs by k_match_branch (which looks at two pieces at most) and is packed after all
 __global__ void k_norm_bad(const uint32_t* __restrict__ piece_doc, const uint8_t* __restrict__ need_host, const uint64_t* __restrict__ doc_piece_start, uint64_t npieces,
-                           uint32_t ndocs, uint32_t* __restrict__ piece_len, unsigned long long* __restrict__ ninfo, uint32_t* __restrict__ fb_ids) {
+                           uint32_t ndocs, uint32_t* __restrict__ piece_len, unsigned long long* __restrict__ ninfo, uint32_t* __restrict__ fb_ids,
+                           const uint64_t* __restrict__ np_dev) {
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < npieces) {
+  if (np_dev && k >= np_dev[0]) { if (k < npieces) piece_len[k] = 0; }       // (launched over a bound: what lies behind the device's count is empty)
+  else if (k < npieces) {
     const uint32_t d = piece_doc[k];
     if (need_host[d]) piece_len[k] = 0;
     else if (piece_len[k] < (uint32_t)TEXT_LEN && k + 1 != doc_piece_start[d + 1]) atomicAdd(&ninfo[6], 1ull);
@@ -1154,15 +1160,15 @@ static uint32_t norm_grid() {
   return slot;
 }
 
-// The filter pass (k_pf_*, above) on the uploaded text: *R = the filtered text, *RB / *RE = where its documents begin and end (device), *np = its
-// pieces, whose table (k_norm_begin + scan) is made here.  One trip to the host of its own (the piece count: the normalizer pass is launched over it).
-static int prefilter(tm_batch* b, hipStream_t st, uint32_t norm_flag, const uint8_t** R, const uint64_t** RB, const uint64_t** RE, uint64_t* np_out) {
+// The filter pass (k_pf_*, above) on the uploaded text, enqueued: *R = the filtered text, *RB / *RE = where its documents begin and end (device); the
+// table of its pieces (k_norm_begin + scan) is made here as well, their count is left in d_totals[3].
+static int prefilter_enqueue(tm_batch* b, hipStream_t st, uint32_t norm_flag, const uint64_t* h_raw_off, const uint8_t** R, const uint64_t** RB, const uint64_t** RE) {
   const uint32_t nd = b->raw_docs;
   hipError_t e;
   uint64_t nspans = 0;
   bool any_long = false;
   for (uint32_t d = 0; d < nd; d++) {
-    const uint64_t len = b->h_raw_off[d + 1] - b->h_raw_off[d];
+    const uint64_t len = h_raw_off[d + 1] - h_raw_off[d];
     if (len >= 0xFFFF0000ull) return set_error(TM_E_LIMIT, "document %u has %llu bytes: beyond what the filter pass addresses", d, (unsigned long long)len);
     nspans += pf_spans(len);
     any_long = any_long || len > PF_WHOLE;
@@ -1208,11 +1214,19 @@ static int prefilter(tm_batch* b, hipStream_t st, uint32_t norm_flag, const uint
   // the pieces of the filtered documents
   TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, rb, re, nd, b->d_doc_npiece, b->d_need_host, (unsigned long long*)b->d_ninfo);
   scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
+  *R = b->d_rawf; *RB = rb; *RE = re;
+  return TM_OK;
+}
+// ... for tm_batch_normalize: with one trip to the host of its own (*np = the count of the filtered documents' pieces: the normalizer pass is launched over it)
+static int prefilter(tm_batch* b, hipStream_t st, uint32_t norm_flag, const uint8_t** R, const uint64_t** RB, const uint64_t** RE, uint64_t* np_out) {
+  int rc = prefilter_enqueue(b, st, norm_flag, b->h_raw_off.data(), R, RB, RE);
+  if (rc != TM_OK) return rc;
+  hipError_t e;
   uint64_t np = 0;
   if ((e = hipMemcpyAsync(&np, b->d_totals + 3, 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "D2H filtered piece count");
   if (np + 2 > b->piece_cap || (np + 1) * (uint64_t)SLAB > b->slab_cap * sizeof(b->d_slab[0]))
     return set_error(TM_E_INTERNAL, "the filter pass left %llu pieces, the workspace holds %llu", (unsigned long long)np, (unsigned long long)b->piece_cap);
-  *R = b->d_rawf; *RB = rb; *RE = re; *np_out = np;
+  *np_out = np;
   return TM_OK;
 }
 
@@ -1271,11 +1285,11 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   if (fast) {
     if (capcode == 2)
       TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
-                                                 b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
+                                                 b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two, nullptr);
     else
       TM_LAUNCH(k_norm_emit<3>, pgrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                            nullptr, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
-    TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
+                                            nullptr, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two, nullptr);
+    TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids, nullptr);
     scan_u32(b->d_piece_len, np, b->d_scan_tmp, reinterpret_cast<uint64_t*>(ninfo + 5), b->d_piece_off, st);      // (the total lands beside the info words: one copy brings everything)
     // NO compaction pass here: in the usual case the text stays in the slabs and k_match_branch stages its segments from there (k_seg_src) —
     // packing it was 2.2 GB of traffic and 0.8 ms per GiB; pack_text() below is for the cases that need the packed text after all
@@ -1322,10 +1336,10 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
   // the exact path: the device normalizes its documents with the carries given (one pass into per-piece slabs, lengths on the side) ...
   if (!fast && np > 0 && capcode == 2 && !(tm_debug_flags(-1) & 256))
     TM_LAUNCH(k_norm_emit2<true>, egrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, b->d_piece_carry,
-                                              b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
+                                              b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two, nullptr);
   else if (!fast && np > 0)           // capcode 0, or debug bit 8: the per-lane version of the rules
     TM_LAUNCH(k_norm_emit<2>, pgrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                          b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
+                                          b->d_piece_carry, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two, nullptr);
   if (!pre) scan_u32(b->d_piece_len, np, b->d_scan_tmp, b->d_totals + 2, b->d_piece_off, st);
   if (!pre && np > 0 && nf == 0) TM_LAUNCH(k_norm_short, (uint32_t)((np + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, b->d_piece_len, ninfo);
   if (nf > 0) {
@@ -1398,7 +1412,7 @@ int tm_batch_normalize(tm_batch* b, void* stream) {
     } else {
       // some piece expands beyond its slab (long runs of capitals): exact two-pass path
       TM_LAUNCH(k_norm_emit<1>, pgrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                            b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text, nullptr, b->d_two);
+                                            b->d_piece_carry, b->d_need_host, b->d_piece_len, b->d_piece_off, b->d_text, nullptr, b->d_two, nullptr);
     }
   }
   TM_LAUNCH(k_norm_ranges, (nd + 255) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend);
@@ -1433,14 +1447,16 @@ namespace tmh {
 // The host-to-host ring takes a vocabulary whose normalizer pass is the one-pass form (capcode 0 or 2 with flags the device implements)
 bool ring_supported(const tm_vocab* v) {
   const uint32_t capcode = v->host.capcode, norm_flag = v->host.norm_flag;
-  // (a vocabulary with byte-level flags has a filter pass with a trip to the host of its own in front: the lanes' form)
-  return normalize_supported(capcode, norm_flag) && (capcode == 2 || capcode == 0) && (norm_flag & ~3u) == 0 && !(tm_debug_flags(-1) & (256 | 2048));
+  // (a vocabulary with byte-level flags: the filter pass in front is enqueued like everything else, and the normalizer pass behind it is launched
+  // over the pieces of the RAW documents - a bound: a filtered document is no longer than the raw one, but for the space leadingspace may put in
+  // front, which raw_prepare has counted - and takes the count from the device)
+  return normalize_supported(capcode, norm_flag) && (capcode == 2 || capcode == 0) && !(tm_debug_flags(-1) & (256 | 2048));
 }
 // tm_batch_normalize's usual path - ONE pass over the raw text that raw_prepare + the upload have put into the workspace - enqueued on `st`
 // and NOT waited for: what the host would read back stays in d_ninfo, k_chunk_ctl turns it into the control words the kernels behind it
 // look at (the segments are launched over `seg_bound`), and a chunk the pass cannot finish by itself (documents for the host normalizer, a
 // piece whose margins could not tell, a long document ...) is marked there and run through tm_batch_normalize by the caller afterwards.
-int ring_enqueue_normalize(tm_batch* b, hipStream_t st, uint64_t seg_bound) {
+int ring_enqueue_normalize(tm_batch* b, hipStream_t st, uint64_t seg_bound, const uint64_t* h_raw_off) {
   const tm_vocab* v = b->vocab;
   const uint32_t capcode = v->host.capcode, norm_flag = v->host.norm_flag;
   const uint32_t nd = b->raw_docs;
@@ -1459,18 +1475,28 @@ int ring_enqueue_normalize(tm_batch* b, hipStream_t st, uint64_t seg_bound) {
   (void)hipGetLastError();
   const uint32_t lower_all = (norm_flag & 2u) ? 1u : 0u;
   unsigned long long* ninfo = (unsigned long long*)b->d_ninfo;
-  TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, b->d_raw_off, b->d_raw_off + 1, nd, b->d_doc_npiece, b->d_need_host, ninfo);
-  scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
+  const uint8_t* R = b->d_raw;
+  const uint64_t* RB = b->d_raw_off;
+  const uint64_t* RE = b->d_raw_off + 1;
+  const uint64_t* np_dev = nullptr;             // behind a filter pass np is a bound, and this the count
+  if (norm_flag & ~3u) {
+    int rc = prefilter_enqueue(b, st, norm_flag, h_raw_off, &R, &RB, &RE);
+    if (rc != TM_OK) return rc;
+    np_dev = b->d_totals + 3;
+  } else {
+    TM_LAUNCH(k_norm_begin, (std::max(nd, 8u) + 255) / 256, 256, 0, st, RB, RE, nd, b->d_doc_npiece, b->d_need_host, ninfo);
+    scan_u32(b->d_doc_npiece, nd, b->d_scan_tmp, b->d_totals + 3, b->d_doc_piece_start, st);
+  }
   const uint32_t pgrid = (uint32_t)((np + 3) / 4);
   const uint32_t egrid = std::min(pgrid, norm_grid());
-  launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st);
+  launch_unit_owner(b->d_doc_piece_start, nd, np, b->d_piece_doc, st, np_dev);
   if (capcode == 2)
-    TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
-                                               b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two);
+    TM_LAUNCH(k_norm_emit2<false>, egrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, lower_all, nullptr,
+                                               b->d_need_host, b->d_piece_len, b->d_slab, ninfo + 3, b->d_two, np_dev);
   else
-    TM_LAUNCH(k_norm_emit<3>, pgrid, 256, 0, st, b->d_raw, b->d_raw_off, b->d_raw_off + 1, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
-                                          nullptr, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two);
-  TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids);
+    TM_LAUNCH(k_norm_emit<3>, pgrid, 256, 0, st, R, RB, RE, b->d_piece_doc, b->d_doc_piece_start, np, capcode, lower_all,
+                                          nullptr, b->d_need_host, b->d_piece_len, nullptr, b->d_slab, ninfo + 3, b->d_two, np_dev);
+  TM_LAUNCH(k_norm_bad, (uint32_t)((std::max<uint64_t>(np, nd) + 255) / 256), 256, 0, st, b->d_piece_doc, b->d_need_host, b->d_doc_piece_start, np, nd, b->d_piece_len, ninfo, b->d_fb_ids, np_dev);
   scan_u32(b->d_piece_len, np, b->d_scan_tmp, reinterpret_cast<uint64_t*>(ninfo + 5), b->d_piece_off, st);
   TM_LAUNCH(k_norm_ranges_info, (nd + 255) / 256, 256, 0, st, b->d_piece_off, b->d_doc_piece_start, b->d_need_host, nd, b->d_nbegin, b->d_nend, ninfo, long_segs());
   launch_chunk_ctl(b, b->nseg, st);

@@ -259,7 +259,7 @@ hipError_t batch_alloc_bytes(tm_batch* b, void** p, uint64_t bytes);
 int make_workspace(const tm_vocab* v, uint64_t max_bytes, uint32_t max_docs, bool own_text, bool with_output, tm_batch** out);
 void scan_u32(const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* total, uint64_t* out, hipStream_t st);
 void launch_doc_units(const uint64_t* doc_begin, const uint64_t* doc_end, uint32_t ndocs, uint32_t unit, uint32_t* doc_nunits, hipStream_t st);
-void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st);
+void launch_unit_owner(const uint64_t* doc_unit_start, uint32_t ndocs, uint64_t nunits, uint32_t* unit_doc, hipStream_t st, const uint64_t* count_dev = nullptr);      // count_dev: nunits is a bound, this the count
 // (TM_TRACE: every buffer that is replaced by a larger one after a workspace exists - each is a hipFree, which waits for the whole device)
 inline void trace_grow(const char* what, uint64_t bytes) { static const bool on = getenv("TM_TRACE") != nullptr; if (on) fprintf(stderr, "[grow] %s -> %.2f MB\n", what, bytes / 1048576.0); }
 int reserve_groups(tm_batch* b, uint32_t ngroups, uint32_t nlong);
@@ -290,7 +290,7 @@ constexpr uint32_t RING_HOST_DOCS = 1, RING_LONG_DOCS = 2, RING_UNDECIDED = 4, R
                    RING_ERROR = 128, RING_OUT_CAP = 256;      // status bits of a chunk the ring hands to the exact path instead
 bool ring_supported(const tm_vocab* v);
 int raw_prepare(tm_batch* b, uint64_t nbytes, uint32_t ndocs, uint64_t npieces, hipStream_t st);      // the buffers tm_batch_upload_raw fills, grown to size
-int ring_enqueue_normalize(tm_batch* b, hipStream_t st, uint64_t seg_bound);
+int ring_enqueue_normalize(tm_batch* b, hipStream_t st, uint64_t seg_bound, const uint64_t* h_raw_off);      // h_raw_off: the chunk's document offsets on the host (ndocs + 1)
 void launch_chunk_ctl(tm_batch* b, uint64_t seg_bound, hipStream_t st);
 // K0 .. K4, the ids packed to `enc` bytes into d_bytes (16-byte aligned), and the chunk's verdict written to `h_status` (page-locked host memory, 8 words:
 // status bits, ids, normalized bytes, segments, device error word)
