@@ -172,10 +172,10 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
  * (max_bytes of tm_batch_create must cover the normalized size, about 1.1x raw with capcode 2).  The device pass handles ASCII, every
  * two-byte script (U+0080..U+07FF: accented Latin, Greek, Cyrillic, Armenian, Hebrew, Arabic ...: NFD, case and capcode from a table the
  * host normalizer fills), Latin Extended Additional under NFD (U+1E00..U+1EFF, what Vietnamese adds: a letter and one or two marks each), the
- * three-byte characters the normalizer leaves alone (General Punctuation, CJK ideographs, most kana, symbols), Hangul syllables (decomposed
- * by arithmetic) and the four-byte characters of caseless, NFD-stable blocks (emoji, symbols, plane-2 ideographs); documents with anything
- * else (voiced kana, cased scripts beyond the BMP, a capital without a lower-case form - U+03D2..U+03D4 -, a combining mark behind a
- * character that ends in one of its own, malformed UTF-8) are normalized by the host normalizer inside the same call, from their original
+ * three-byte characters the normalizer leaves alone (General Punctuation, CJK ideographs, kana, symbols), the voiced kana under NFD (a kana and
+ * U+3099 / U+309A each: Japanese text), Hangul syllables (decomposed by arithmetic) and the four-byte characters of caseless, NFD-stable blocks
+ * (emoji, symbols, plane-2 ideographs); documents with anything else (cased scripts beyond the BMP, a capital without a lower-case form -
+ * U+03D2..U+03D4 -, a combining mark of canonical class > 0 of three bytes or behind a character that ends in one of its own, malformed UTF-8) are normalized by the host normalizer inside the same call, from their original
  * bytes; tm_batch_host_fallback_docs reports how many.  (TM_NORM_WG_PER_CU in the environment: the grid of the pass, workgroups per compute
  * unit, default 64 - a tuning knob, profiles/r05_issue_model.txt.)
  * Supported: capcode 0 and 2 (level 1 has no statement in the reference tree and is refused) and every normalization flag

@@ -114,6 +114,10 @@ ASTRAL_HANGUL = ["\U0001f600", "\U0001f680", "\U0001f44d\U0001f3fd", "\U0001f1e9
 VIET = list("ếệềểễấậầẩẫắặằẳẵớợờởỡứựừửữạảịỉọỏụủỳỵỷỹẾỆẤẬẮẶỚỢỨỰẠẢỊỌỤỲỸđĐơƠưƯăĂâêô") + ["\u1e00", "\u1e01", "\u1e9b", "\u1e9e", "\u1eff", "\u1e69", "\u1e08"]
 
 
+# round 6: kana, voiced and not (a voiced kana is a kana and its mark under NFD, on the device), the marks by themselves (the host's), the iteration marks
+KANA = list("あかきくけこさしたなはひまやらわんがぎぐげござじずだぢづでどばびぶべぼぱぴぷぺぽゔゞアカサタハガギグザジダヂヅデドバビブベボパピプペポヴヷヸヹヺヾー") + ["\u3099", "\u309a", "\u0301", "\u4e2d"]
+
+
 def one_norm(seed):
     """the device normalizer (NFD / lowercase + capcode 2; host fallback for what it does not do itself) against the host normalizer:
     runs of capitals, digits and apostrophes of every length, also across the 64-byte chunks and 1 KiB pieces of the device pass"""
@@ -140,6 +144,8 @@ def one_norm(seed):
                 parts.append("".join(rng.choice(NORM_ALPHABET[:30] + ASTRAL_HANGUL[int(rng.integers(0, 12)):], size=int(rng.integers(1, 40)))))
             elif r < 0.27:
                 parts.append("".join(rng.choice(NORM_ALPHABET[:36] + VIET, size=int(rng.integers(1, 40)))))
+            elif r < 0.30:
+                parts.append("".join(rng.choice(NORM_ALPHABET[:30] + KANA, size=int(rng.integers(1, 40)))))
             elif lossy and r < 0.5:
                 parts.append("".join(rng.choice([" ", "  ", "   ", "\r\n", "\r", "\n", "\t", "\u2018", "\u2019", "\u201c", "\u201d", "\u2019s", "a", "B", "é", "É", "x ", " y", "\u0301", "ñ", "1"],
                                                 size=int(rng.integers(1, 30)))))

@@ -143,6 +143,27 @@ for (let i = 0; i < 2000; i++) {
   inputs.push(s);
 }
 
+// round 6, second half: the voiced kana (が -> か + U+3099, ぱ -> は + U+309A, ヴ ヷ ヸ ヹ ヺ ゞ ヾ under NFD) - what Japanese running text is full of;
+// the device normalizer now decomposes them itself.  Appended BEHIND everything else again.
+const kana7 = 'あいうえおかきくけこさしすせそたちつてとなにぬねのはひふへほまみむめもやゆよらりるれろわをんアイウエオカキクケコサシスセソタチツテトハヒフヘホ'.split('');
+const voiced = 'がぎぐげござじずぜぞだぢづでどばびぶべぼぱぴぷぺぽゔゞガギグゲゴザジズゼゾダヂヅデドバビブベボパピプペポヴヷヸヹヺヾ'.split('');
+const jwords = ['です', 'ございます', 'がんばって', 'データ', 'プログラム', 'ヴァイオリン', '日本語', '東京', 'は', 'の', '、', '。', 'Tokyo', 'GPU', 'it', 's', 'ABC'];
+const flavours7 = [
+  () => pick([kana7, voiced, voiced, cjk, lower, upper, [' '], digits, apos]),
+  () => pick([jwords, jwords, [''], [' '], apos, punct, digits, upper]),
+  () => pick([voiced, ['\u3099', '\u309A'], marks, kana7, lower, upper, [" "], apos, digits]),
+  () => pick([voiced, kana7, viet, accented, cyr, syll, emoji, lower, upper, [' '], apos, digits]),
+];
+['がぎぐげご ひらがなの濁点', 'パピプペポ と ばびぶべぼ', 'ヴァイオリンのデータです。', "Aが Bガ'S 1ぱ2 'ぴ'", 'がA ガb GAが', 'か\u3099 は\u309A が\u0301 が\u3099', 'ゞ ヾ ゔ ヷ ヸ ヹ ヺ',
+ 'が', 'ガ', ' が', 'がが', 'aが', 'がa', 'が1', "が'S", 'TOKYOでGPUをつかう'].forEach(s => inputs.push(s));
+for (let i = 0; i < 1200; i++) {
+  const f = flavours7[i % flavours7.length];
+  const n = rnd(rnd(4) === 0 ? 90 : 28);
+  let s = '';
+  for (let k = 0; k < n; k++) s += pick(f());
+  inputs.push(s);
+}
+
 const b64 = s => Buffer.from(s, 'utf8').toString('base64');
 const cases = inputs.map(s => {
   const nfd = s.normalize('NFD');

@@ -463,7 +463,7 @@ def test_ring_hands_chunks_to_the_exact_path():
     base_raw, base_off = synth.synth_corpus(synth.ENGLISHCODE, 150_000, seed=74)
     docs = [bytes(base_raw[int(base_off[d]):int(base_off[d + 1])]) for d in range(base_off.size - 1)]
     n0 = len(docs)
-    docs.insert(n0 // 5, "がぎぐげご ひらがなの濁点はホストの正規化器に行く ".encode() * 20)                          # voiced kana (NFD splits them): host normalizer
+    docs.insert(n0 // 5, "𐐀𐐨 Deseret has case beyond the BMP: the host normalizer's 𐐁𐐩 ".encode() * 20)                              # a cased script of plane 1: host normalizer
     docs.insert(n0 // 2, b"one long document of plain words that goes on and on " * 3200)                               # 170 KB: more than 512 segments
     docs.insert(4 * n0 // 5, b".".join(bytes([65 + int(c)]) for c in rng.integers(0, 26, 9_000)))                        # grows 2.5 x under capcode
     docs.append(b"")

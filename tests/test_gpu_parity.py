@@ -790,15 +790,16 @@ def test_european_text_stays_on_the_device():
 def multilingual_corpus(rng, nbytes):
     """synthetic Russian / Greek / Chinese / Japanese / Hebrew / Arabic running text with English mixed in: two-byte scripts with case
     and decomposing letters (й ё Й, ά ώ), combining marks, CJK ideographs and kana; a few percent of the documents carry what the device
-    leaves to the host (Hangul, voiced kana, emoji, Latin Extended Additional)"""
+    left to the host at one time or still (Hangul, emoji, Latin Extended Additional: the device's by now; a voicing mark by itself, the Greek letters with two marks);
+    the voiced kana of Japanese (が -> か + U+3099 under NFD) are part of the running text: the device's since round 6"""
     ru = "Привет мир Москва Россия Ёжик йод объём СЪЕЗД Киев Санкт-Петербург это русский текст и ещё й ЙОД".split()
     el = "Καλημέρα κόσμε Αθήνα Ελλάδα ΑΘΗΝΑ ά έ ή ί ό ύ ώ Ώρα το και είναι ελληνικό κείμενο".split()
     zh = ["中文", "文本", "测试", "世界", "你好", "数据", "模型", "，", "。", "ABC", "GPU"]
-    ja = ["こんにちは", "世界", "カタカナ", "ひらかな", "テスト", "日本", "の", "は", "、", "。", "Tokyo"]
+    ja = ["こんにちは", "世界", "カタカナ", "ひらかな", "テスト", "日本", "の", "は", "、", "。", "Tokyo", "です", "ございます", "がんばって", "データ", "プログラム", "ヴァイオリン", "ぱぴぷぺぽ"]
     he = "שלום עולם זה טקסט בעברית".split()
     ar = "مرحبا بالعالم هذا نص عربي ١٢٣".split()
     en = "the quick Brown FOX jumps over 13 lazy dogs it's NASA's iPhone".split()
-    host_only = ["한국어", "がぎぐ", "😀", "Ḁḁ", "ΐ"]
+    host_only = ["한국어", "か\u3099", "😀", "Ḁḁ", "ΐ"]
     langs = [ru, el, zh, ja, he, ar]
     docs, total = [], 0
     while total < nbytes:
@@ -849,13 +850,13 @@ def emoji_korean_corpus(rng, nbytes):
     """web-like text: English / French sentences with AT LEAST one emoji per document (four bytes of UTF-8: emoticons, pictographs, a
     skin-tone modifier, flags), Korean running text (Hangul syllables with and without a final consonant) with English mixed in, and
     plane-2 ideographs / hieroglyphs / cuneiform here and there; one document in a hundred carries what still needs the host (a Deseret
-    capital, a musical symbol that decomposes, voiced kana, a mathematical letter); the variation selector U+FE0F behind an emoji and the enclosing
+    capital, a musical symbol that decomposes, a voicing mark by itself, a mathematical letter); the variation selector U+FE0F behind an emoji and the enclosing
     keycap - combining marks of three bytes and canonical class 0 - stay on the device"""
     en = "the quick Brown FOX jumps over 13 lazy dogs it's NASA's iPhone LOL omg so café naïve Über".split()
     ko = "한국어 텍스트 대한민국 서울 값 삶 닭 없다 읽다 가 나 다 라 마 바 사 아 자 차 카 타 파 하 안녕하세요 감사합니다 GPU 토큰".split()
     emoji = ["😀", "😂", "🚀", "🌍", "👍", "👍🏽", "🎉", "🔥", "💯", "🤖", "🦄", "🇰🇷", "🀄", "❤️", "☺️", "1️⃣"]
     astral = ["𠀀", "𠮷", "𓀀", "𒀀"]
-    host_only = ["𐐀", "𝅗𝅥", "がぎ", "𝒜"]         # (mathematical letters: their blocks of 64 code points have unassigned holes, the block table says "mixed")
+    host_only = ["𐐀", "𝅗𝅥", "か\u3099", "𝒜"]         # (mathematical letters: their blocks of 64 code points have unassigned holes, the block table says "mixed")
     docs, total = [], 0
     while total < nbytes:
         n = int(rng.integers(2, 200))
@@ -902,6 +903,47 @@ def test_emoji_and_korean_text_stay_on_the_device():
             import unicodedata
             out, ooff = v.decode_packed(ids[: int(toff[nchk])], np.ascontiguousarray(toff[: nchk + 1]))
             assert N.lib.tm_decode_host_docs() <= max(1, nchk // 20), "%d of %d documents were decoded on the host" % (N.lib.tm_decode_host_docs(), nchk)
+            for k in range(nchk):
+                assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == unicodedata.normalize("NFD", docs[k].decode()).encode(), docs[k]
+
+
+def test_japanese_text_stays_on_the_device():
+    """round 6: the voiced kana (が -> か + U+3099, ぱ -> は + U+309A, ヴ ヷ ヸ ヹ ヺ ゞ ヾ) under NFD - a kana and its mark, from a table the host normalizer
+    fills (tm_normalize.cpp: build_kana_table).  One of them used to send its whole document to host ICU, which is every Japanese document.
+    Bytes == the host normalizer's; with NFD and capcode 2 ALL documents but those with a voicing mark of their own (or a Latin mark behind a
+    voiced kana) stay on the device; ids of the raw path == ids of the host-normalized text; the decoder gives back NFD of the text."""
+    import unicodedata
+    rng = np.random.default_rng(2028)
+    words = ["これは", "日本語", "の", "テキスト", "です", "。", "、", "ございます", "がんばって", "ください", "データ", "プログラム", "ヴァイオリン", "東京", "大学", "で", "GPU", "を", "つかう",
+             "ぱぴぷぺぽ", "ばびぶべぼ", "ザジズゼゾ", "ゞ", "ヾ", "ヷヸヹヺ", "ゔ", "Tokyo", "iPhone", "it's", "2が", "Aガ", "x"]
+    docs, host_docs = [], 0
+    total, target = 0, 120_000 if EMULATED else 3_000_000
+    while total < target:
+        n = int(rng.integers(1, 300))
+        d = "".join(str(rng.choice(words)) + ("" if rng.random() < 0.7 else str(rng.choice([" ", "\n", "'", "1"]))) for _ in range(n))
+        if rng.random() < 0.01:
+            d += str(rng.choice(["か\u3099", "は\u309a", "が\u0301"]))           # what stays with the host: the marks by themselves, a further mark behind the character's own
+            host_docs += 1
+        docs.append(d.encode())
+        total += len(docs[-1])
+    docs += [("が" * 2000).encode(), ("パ" * 341 + "b").encode(), ("x" * 1022 + "がぎ").encode(), ("x" * 1023 + "ヴ").encode()]
+    raw, offs = tm.pack_documents(docs)
+    for capcode, flag in ((2, 1), (2, 3), (2, 0), (0, 1), (2, 1 | 4)):
+        v = tm.Vocab(synth.build_vocab([bytes([c]) for c in range(256)], capcode=capcode, charset=1, norm_flag=flag))
+        got, goff, nfb = v.normalize_packed_device(raw, offs)
+        exp, eoff = synth.normalize_batch(raw, offs, capcode, flag)
+        assert (goff == eoff).all() and got.size == exp.size
+        assert (got == exp).all(), "capcode %d flag %d" % (capcode, flag)
+        if capcode == 2 and flag in (1, 3):
+            assert nfb == host_docs, "%d of %d documents took the host path, %d expected (capcode %d flag %d)" % (nfb, len(docs), host_docs, capcode, flag)
+        if capcode == 2 and flag == 1:
+            ids, toff, miss = v.tokenize_packed(exp, eoff)
+            assert int(miss.sum()) == 0
+            nchk = min(200, len(docs))
+            gotids = v.tokenize(docs[:nchk])
+            for k in range(nchk):
+                assert (gotids[k] == ids[int(toff[k]):int(toff[k + 1])]).all()
+            out, ooff = v.decode_packed(ids[: int(toff[nchk])], np.ascontiguousarray(toff[: nchk + 1]))
             for k in range(nchk):
                 assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == unicodedata.normalize("NFD", docs[k].decode()).encode(), docs[k]
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ bool nblock(uint32_t cls) { return (cls & NF_BLOCK) !
 struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
 // The normalizer's tables in ONE device buffer (tm_norm_masks.h): NmTwo[NM_TWO_SIZE] | block codes [NM_BLK_WORDS] | code-point codes
 // [NM_CP_WORDS] | block codes of the four-byte characters [NM_BLK4_WORDS] | one word of switches (NM_MISC_*; 16 bytes with its padding).  The 256 work-items of a workgroup stage the entries of U+0080..U+017F (2 KB) and the block codes (256 bytes) in LDS.
-constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea);      // (... | the characters of Latin Extended Additional, read where they lie)
+constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea) + NM_KANA_SIZE * sizeof(uint16_t);      // (... | the characters of Latin Extended Additional, read where they lie)
 struct TabLds { NmTwo two[NM_TWO_FAST]; uint32_t blk[NM_BLK_WORDS]; };
 __device__ __forceinline__ NmTabs stage_tabs(TabLds& s, const NmTwo* __restrict__ two) {
   static_assert(NM_TWO_FAST == 256 && NM_BLK_WORDS <= 256, "one entry per work-item");
@@ -94,6 +94,9 @@ __device__ __noinline__ HighOut emit_high_byte(const uint8_t* r, uint32_t fl, ui
       else if (role == 1u) { o.len1 = 1u; o.ysp = e.b & 0xFFu; o.o3 = (e.b >> 8) & 0xFFu; }
       else if (((e.a >> 24) & 3u) == 2u) { o.len1 = 1u; o.ysp = (e.b >> 16) & 0xFFu; o.o3 = e.b >> 24; }
       else o.len1 = 0xFFu;
+    } else if ((tabs.misc & NM_MISC_KANA) && fl != NF_BAD && nm_kana_role(b, bm1, r[-2], bp1, r[2], &role, &idx) && (nm_kana_tab(tabs)[idx] & NK_OK)) {
+      // a voiced kana (NFD): the base kana, the mark, nothing
+      o.len1 = nm_kana_out(nm_kana_tab(tabs)[idx], role, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
     } else if (tabs.misc & NM_MISC_HANGUL) {
       uint32_t hrole, hcp;
       if (fl != NF_BAD && nm_hangul_role(b, bm1, r[-2], bp1, r[2], &hrole, &hcp)) o.len1 = nm_hangul_out(hcp, hrole, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
@@ -390,6 +393,10 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
         else if (((le.a >> 24) & 3u) == 2u) { len = 2u; o2 = (le.b >> 16) & 0xFFu; o3 = le.b >> 24; }
         else len = 0u;
       }
+      // ... or of a voiced kana (NFD): the base kana, the mark, nothing
+      uint32_t krole, kidx;
+      if ((tabs.misc & NM_MISC_KANA) && fl != NF_BAD && nm_kana_role(b, bm1, L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], &krole, &kidx) && (nm_kana_tab(tabs)[kidx] & NK_OK))
+        len = nm_kana_out(nm_kana_tab(tabs)[kidx], krole, &o1, &o2, &o3);
     }
     // inclusive prefix sum of len (0..4) over the wavefront: bytes-with-len>=k ballots, counted below the lane
     uint32_t incl = len;
@@ -1013,6 +1020,12 @@ const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
     if (capcode2 && (flags & 1u) && !accents) {      // ... and of Latin Extended Additional: a letter and one or two marks (under `accents` the marks would have to go: the host)
       build_lea_table(flags & 3u, lea);
       blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] |= NM_MISC_LEA;
+    }
+    uint16_t* kana = reinterpret_cast<uint16_t*>(lea + NM_LEA_SIZE);
+    for (int k = 0; k < NM_KANA_SIZE; k++) kana[k] = 0;
+    if (capcode2 && (flags & 1u) && !accents) {      // ... and of the voiced kana: a kana and its mark
+      build_kana_table(kana);
+      blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] |= NM_MISC_KANA;
     }
     if (accents) {
       std::vector<uint32_t> acc(NM_TWO_SIZE);

@@ -123,8 +123,39 @@ TM_HD bool nm_lea_role(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32
   *idx = ((b1 & 3u) << 6) | (b2 & 63u);
   return true;
 }
+// ---- the voiced kana of U+3040..U+30FF under NFD (round 6): が -> か + U+3099, ぱ -> は + U+309A, ヴ ヷ ヸ ヹ ヺ ゞ ヾ - what sent every Japanese document to the host ----
+// Three bytes in, six out: the lane of the first byte emits the base kana (class LO, a letter without case), the second the combining
+// mark (class M), the third nothing - the scheme of a Latin Extended Additional letter with one mark.  192 entries from the host
+// normalizer's own functions (tm_normalize.cpp: build_kana_table), only with the NFD flag and capcode 2 and without `accents` (NM_MISC_KANA):
+//   NK_OK | NK_SEMI (the mark is U+309A, else U+3099) | low byte of the base kana's code point (it lies in U+30xx like the character)
+// The marks THEMSELVES in a text (canonical class 8: they may have to change places with a neighbour) stay the host's, and so does a two-byte
+// mark right behind a voiced kana.
+constexpr int NM_KANA_SIZE = 192;
+constexpr uint32_t NM_MISC_KANA = 4u, NK_OK = 0x200u, NK_SEMI = 0x100u;
+// which byte of a character of U+3040..U+30FF the byte b between m2 m1 and p1 p2 is (0, 1, 2) and the character's index in the table: false if it is none
+TM_HD bool nm_kana_role(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32_t p2, uint32_t* role, uint32_t* idx) {
+  uint32_t b1, b2;
+  if (b == 0xE3u) { b1 = p1; b2 = p2; *role = 0u; }
+  else if ((b & 0xC0u) != 0x80u) return false;
+  else if (m1 == 0xE3u) { b1 = b; b2 = p1; *role = 1u; }
+  else if (m2 == 0xE3u) { b1 = m1; b2 = b; *role = 2u; }
+  else return false;
+  if (b1 - 0x81u >= 3u || (b2 & 0xC0u) != 0x80u) return false;
+  *idx = ((b1 - 0x81u) << 6) | (b2 & 63u);
+  return true;
+}
+// the bytes the lane of byte number `role` of a voiced kana emits: returns 3 (*o1 *o2 *o3) or 0
+TM_HD uint32_t nm_kana_out(uint32_t e, uint32_t role, uint32_t* o1, uint32_t* o2, uint32_t* o3) {
+  if (role == 2u) return 0u;
+  const uint32_t cp = role == 0u ? 0x3000u | (e & 0xFFu) : ((e & NK_SEMI) ? 0x309Au : 0x3099u);
+  *o1 = 0xE3u; *o2 = 0x80u | ((cp >> 6) & 63u); *o3 = 0x80u | (cp & 63u);
+  return 3u;
+}
 // what a kernel knows the tables by: the fast part of the two-byte table and the block table (LDS), the full tables (global memory)
+// (56 bytes, and no more: the out-of-line classifier takes it by value - in registers; at 64 bytes the compiler passes it through scratch memory)
 struct NmTabs { const NmTwo* two_fast; const NmTwo* two_all; const uint32_t* blk; const uint32_t* cp; const uint32_t* blk4; uint32_t misc; const NmLea* lea; };
+static_assert(sizeof(NmTabs) <= 56, "NmTabs is passed by value to noinline device functions");
+TM_HD const uint16_t* nm_kana_tab(const NmTabs& t) { return reinterpret_cast<const uint16_t*>(t.lea + NM_LEA_SIZE); }      // the kana entries lie behind those of Latin Extended Additional
 TM_HD NmTwo nm_two_get(const NmTabs& t, uint32_t idx) { return idx < (uint32_t)NM_TWO_FAST ? t.two_fast[idx] : t.two_all[idx]; }
 TM_HD uint32_t nm_three_code(const NmTabs& t, uint32_t cp) {
   const uint32_t bc = (t.blk[cp >> 10] >> (2u * ((cp >> 6) & 15u))) & 3u;
@@ -152,6 +183,8 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
     }
     // ... the same behind a character of Latin Extended Additional, which ends in a mark of its own
     if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_LEA) && m3 == 0xE1u && m2 - 0xB8u < 4u && nm_cont_byte(m1) && (tabs.lea[((m2 & 3u) << 6) | (m1 & 63u)].a & NT_OK)) return NF_BAD;
+    // ... and behind a voiced kana
+    if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_KANA) && m3 == 0xE3u && m2 - 0x81u < 3u && nm_cont_byte(m1) && (nm_kana_tab(tabs)[((m2 - 0x81u) << 6) | (m1 & 63u)] & NK_OK)) return NF_BAD;
     return a & NF_CLASS;
   }
   if (nm_cont_byte(b) && nm_two_lead(m1)) {
@@ -181,6 +214,7 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
     const uint32_t a = tabs.lea[cp3 - 0x1E00u].a;
     if (a & NT_OK) return cont ? (uint32_t)NC_M : (a & NF_CLASS);
   }
+  if ((tabs.misc & NM_MISC_KANA) && cp3 - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[cp3 - 0x3040u] & NK_OK)) return cont ? (uint32_t)NC_M : (uint32_t)NC_LO;      // a voiced kana: the kana, its mark, nothing
   const uint32_t code = nm_three_code(tabs, cp3);
   if (code == 0u && (tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp3)) return (uint32_t)NC_LO | cont;       // decomposes, but by arithmetic: nm_hangul_out
   return code == 0u ? (uint32_t)NF_BAD : ((code == 3u ? (uint32_t)NC_M : (code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O)) | cont);      // (3: a combining mark of class 0)

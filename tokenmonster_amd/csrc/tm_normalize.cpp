@@ -455,6 +455,25 @@ void build_lea_table(uint32_t norm_flag, NmLea* out) {
   }
 }
 
+// The voiced kana of U+3040..U+30FF (tm_norm_masks.h: NM_KANA_SIZE): the characters NFD turns into a letter of the same range followed by
+// U+3099 or U+309A
+void build_kana_table(uint16_t* out) {
+  for (int k = 0; k < NM_KANA_SIZE; k++) out[k] = 0;
+  for (uint32_t cp = 0x3040; cp < 0x3040 + (uint32_t)NM_KANA_SIZE; cp++) {
+    std::vector<uint8_t> t;
+    put_cp(t, cp);
+    nfd_bytes(t);
+    if (t.size() != 6) continue;
+    const Cp c1 = next_cp(t.data(), 6);
+    if (c1.raw || c1.n != 3) continue;
+    const Cp c2 = next_cp(t.data() + 3, 3);
+    if (c2.raw || c2.n != 3 || (c2.r != 0x3099 && c2.r != 0x309A) || !(classify(c2) & kMark)) continue;
+    const uint8_t k1 = classify(c1);
+    if (!(k1 & kLetter) || (k1 & (kUpper | kLower)) || (uint32_t)c1.r - 0x3000u >= 0x100u) continue;
+    out[cp - 0x3040] = (uint16_t)(NK_OK | (c2.r == 0x309A ? NK_SEMI : 0u) | ((uint32_t)c1.r & 0xFFu));
+  }
+}
+
 // blk[NM_BLK_WORDS], cp[NM_CP_WORDS]: two bits per block of 64 code points / per code point of U+0000..U+FFFF (tm_norm_masks.h)
 void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cpt) {
   for (int k = 0; k < NM_BLK_WORDS; k++) blk[k] = 0;

@@ -31,8 +31,11 @@ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
 static uint64_t g_margin_ok = 0, g_margin_unknown = 0;
 static NmTwo g_two[2][NM_TWO_SIZE];     // [lower_all]: flags 1 (NFD) and 3 (NFD + lowercase)
 static uint32_t g_blk[2][NM_BLK_WORDS], g_cp[2][NM_CP_WORDS], g_blk4[2][NM_BLK4_WORDS];      // the three- and four-byte characters the pass leaves alone (tm_norm_masks.h)
-static NmLea g_lea[2][NM_LEA_SIZE];      // Latin Extended Additional under NFD: a letter + one or two marks (round 6)
-static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k], g_blk4[k], NM_MISC_HANGUL | NM_MISC_LEA, g_lea[k]}; }
+struct LeaKana { NmLea lea[NM_LEA_SIZE]; uint16_t kana[NM_KANA_SIZE]; };      // (the kana entries lie behind those of Latin Extended Additional: nm_kana_tab)
+static LeaKana g_lk[2];
+#define g_lea_of(k) (g_lk[k].lea)      // Latin Extended Additional under NFD: a letter + one or two marks (round 6)
+#define g_kana (g_lk[0].kana)             // the voiced kana under NFD: a kana + U+3099 / U+309A (round 6)
+static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k], g_blk4[k], NM_MISC_HANGUL | NM_MISC_LEA | NM_MISC_KANA, g_lk[k].lea}; }
 // class byte of every byte of a document as norm_load_piece computes it (bytes outside the document read as 0)
 bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t>& f) {
   const int n = (int)d.size();
@@ -121,13 +124,15 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
       uint32_t hrole, hcp;
       if (fl != NF_BAD && nm_hangul_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &hrole, &hcp)) { len = nm_hangul_out(hcp, hrole, &m3, &ysp, &o3); if (len == 0) continue; }
       uint32_t lrole, lidx;
-      if (fl != NF_BAD && nm_lea_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &lrole, &lidx) && (g_lea[lower_all ? 1 : 0][lidx].a & NT_OK)) {
-        const NmLea le = g_lea[lower_all ? 1 : 0][lidx];
+      if (fl != NF_BAD && nm_lea_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &lrole, &lidx) && (g_lk[lower_all ? 1 : 0].lea[lidx].a & NT_OK)) {
+        const NmLea le = g_lk[lower_all ? 1 : 0].lea[lidx];
         if (lrole == 0u) o3 = (code & 4u) ? ((le.a >> 16) & 0xFFu) : ((le.a >> 8) & 0xFFu);
         else if (lrole == 1u) { len = 2u; ysp = le.b & 0xFFu; o3 = (le.b >> 8) & 0xFFu; }
         else if (((le.a >> 24) & 3u) == 2u) { len = 2u; ysp = (le.b >> 16) & 0xFFu; o3 = le.b >> 24; }
         else continue;
       }
+      uint32_t krole, kidx;
+      if (fl != NF_BAD && nm_kana_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &krole, &kidx) && (g_kana[kidx] & NK_OK)) { len = nm_kana_out(g_kana[kidx], krole, &m3, &ysp, &o3); if (len == 0) continue; }
       if (len == 4) out.push_back('D');
       if (len >= 3) out.push_back((uint8_t)m3);
       if (len >= 2) out.push_back((uint8_t)ysp);
@@ -204,9 +209,11 @@ int main(int argc, char** argv) {
   build_three_tables(3, g_blk[1], g_cp[1]);
   build_four_table(1, g_blk4[0]);
   build_four_table(3, g_blk4[1]);
-  build_lea_table(1, g_lea[0]);
-  build_lea_table(3, g_lea[1]);
-  { int ok = 0, two = 0; for (int k = 0; k < NM_LEA_SIZE; k++) { ok += (g_lea[0][k].a & NT_OK) != 0; two += (g_lea[0][k].a & NT_OK) && ((g_lea[0][k].a >> 24) & 3u) == 2u; }
+  build_lea_table(1, g_lk[0].lea);
+  build_lea_table(3, g_lk[1].lea);
+  build_kana_table(g_lk[0].kana); build_kana_table(g_lk[1].kana);
+  { int ok = 0; for (int k = 0; k < NM_KANA_SIZE; k++) ok += (g_kana[k] & NK_OK) != 0; printf("voiced kana (NFD): %d characters of U+3040..U+30FF on the device\n", ok); }
+  { int ok = 0, two = 0; for (int k = 0; k < NM_LEA_SIZE; k++) { ok += (g_lk[0].lea[k].a & NT_OK) != 0; two += (g_lk[0].lea[k].a & NT_OK) && ((g_lk[0].lea[k].a >> 24) & 3u) == 2u; }
     printf("Latin Extended Additional (NFD): %d of %d characters on the device, %d of them with two marks\n", ok, NM_LEA_SIZE, two); }
   { int ok = 0, dec = 0, dec2 = 0; for (int k = 0; k < NM_TWO_SIZE; k++) { ok += (g_two[0][k].a & NT_OK) != 0; dec += (g_two[0][k].a & NT_DECOMP) != 0; dec2 += (g_two[0][k].a & NT_DECOMP2) != 0; }
     int c1 = 0, c2 = 0, mixed = 0;
@@ -242,7 +249,7 @@ int main(int argc, char** argv) {
       const uint32_t style = rng.below(5);      // 0 mixed, 1 capitals-heavy, 2 digits/apostrophes-heavy, 3 spaces + capitals, 4 long runs
       const bool latin = rng.below(2) != 0;     // half of the documents carry accented Latin letters, a few of them a lot
       // a third of the documents are written in another script: Greek, Cyrillic (with the letters that decompose: й ё ά ...), Hebrew, Arabic,
-      // standalone combining marks, Chinese, Japanese (with voiced kana, which send the document to the host), Korean (Hangul syllables decompose by arithmetic), symbols, four-byte characters
+      // standalone combining marks, Chinese, Japanese (with voiced kana: a kana and its mark), Korean (Hangul syllables decompose by arithmetic), symbols, four-byte characters
       const uint32_t script = rng.below(3) == 0 ? 1 + rng.below(9) : 0;
       const uint32_t latin_share = rng.below(4) == 0 ? 40 : 6;
       while (d.size() < len) {
@@ -258,7 +265,8 @@ int main(int argc, char** argv) {
             case 3: cp = 0x05D0 + rng.below(0x1B); if (rng.below(8) == 0) cp = 0x05B0 + rng.below(0x10); break;   // Hebrew letters, now and then a point
             case 4: cp = 0x0621 + rng.below(0x2A); if (rng.below(8) == 0) cp = 0x064B + rng.below(8); if (rng.below(10) == 0) cp = 0x0660 + rng.below(10); break;   // Arabic, marks, digits
             case 5: cp = rng.below(4) ? 0x4E00 + rng.below(0x5000) : 0x3000 + rng.below(0x40); break;   // Chinese + CJK punctuation
-            case 6: cp = rng.below(3) ? 0x3041 + rng.below(0x56) : (rng.below(2) ? 0x30A1 + rng.below(0x5A) : 0x4E00 + rng.below(0x5000)); break;   // Japanese
+            case 6: cp = rng.below(3) ? 0x3041 + rng.below(0x56) : (rng.below(2) ? 0x30A1 + rng.below(0x5E) : 0x4E00 + rng.below(0x5000));      // Japanese
+                    if (rng.below(14) == 0) cp = rng.below(2) ? 0x3099 + rng.below(2) : 0x0300 + rng.below(4); break;   // ... now and then a voicing mark by itself or a Latin one (the host's behind a voiced kana)
             case 7: cp = rng.below(6) ? 0x0180 + rng.below(0x680) : 0x0300 + rng.below(0x70); break;   // anything two-byte, and stray combining marks
             case 9: {                                                                        // four bytes: emoji and pictographs, plane-2 ideographs, mathematical letters; now and then what the host has to do
               const uint32_t q = rng.below(40);
