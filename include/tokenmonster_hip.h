@@ -174,8 +174,10 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
  * host normalizer fills), Latin Extended Additional under NFD (U+1E00..U+1EFF, what Vietnamese adds: a letter and one or two marks each), the
  * three-byte characters the normalizer leaves alone (General Punctuation, CJK ideographs, kana, symbols), the voiced kana under NFD (a kana and
  * U+3099 / U+309A each: Japanese text), Hangul syllables (decomposed by arithmetic) and the four-byte characters of caseless, NFD-stable blocks
- * (emoji, symbols, plane-2 ideographs); documents with anything else (cased scripts beyond the BMP, a capital without a lower-case form -
- * U+03D2..U+03D4 -, a combining mark of canonical class > 0 of three bytes or behind a character that ends in one of its own, malformed UTF-8) are normalized by the host normalizer inside the same call, from their original
+ * (emoji, symbols, plane-2 ideographs), the three-byte combining marks of U+0800..U+1FFF where they stand in canonical order (virama, nukta, the
+ * Thai tone marks ...: Hindi, Thai) and the three-byte decimal digits; documents with anything else (cased scripts beyond the BMP, a capital
+ * without a lower-case form - U+03D2..U+03D4 -, a three-byte letter that decomposes, marks out of canonical order or behind a character that
+ * ends in one of its own, malformed UTF-8) are normalized by the host normalizer inside the same call, from their original
  * bytes; tm_batch_host_fallback_docs reports how many.  (TM_NORM_WG_PER_CU in the environment: the grid of the pass, workgroups per compute
  * unit, default 64 - a tuning knob, profiles/r05_issue_model.txt.)
  * Supported: capcode 0 and 2 (level 1 has no statement in the reference tree and is refused) and every normalization flag

@@ -118,6 +118,12 @@ VIET = list("·∫ø·ªá·ªÅ·ªÉ·ªÖ·∫•·∫≠·∫ß·∫©·∫´·∫Ø·∫∑·∫±·∫≥·∫µ·ªõ·ª£·ªù·ªü·ª°·ª©·ª±·
 KANA = list("„ÅÇ„Åã„Åç„Åè„Åë„Åì„Åï„Åó„Åü„Å™„ÅØ„Å≤„Åæ„ÇÑ„Çâ„Çè„Çì„Åå„Åé„Åê„Åí„Åî„Åñ„Åò„Åö„Å†„Å¢„Å•„Åß„Å©„Å∞„Å≥„Å∂„Åπ„Åº„Å±„Å¥„Å∑„Å∫„ÅΩ„Çî„Çû„Ç¢„Ç´„Çµ„Çø„Éè„Ç¨„ÇÆ„Ç∞„Ç∂„Ç∏„ÉÄ„ÉÇ„ÉÖ„Éá„Éâ„Éê„Éì„Éñ„Éô„Éú„Éë„Éî„Éó„Éö„Éù„É¥„É∑„É∏„Éπ„É∫„Éæ„Éº") + ["\u3099", "\u309a", "\u0301", "\u4e2d"]
 
 
+# round 6: Devanagari and Thai with their marks of canonical class > 0 (virama 9, nukta 7, the Thai vowels below 103 and tone marks 107: in and out of
+# order), three-byte digits, letters that decompose (the host's), a Latin mark among them
+INDIC_THAI = list("‡§ï‡§ñ‡§ó‡§ú‡§°‡§§‡§®‡§™‡§Æ‡§∞‡§≤‡§µ‡§∏‡§π‡§Ö‡§Ü‡§á‡§è‡§ì") + ["\u093e", "\u093f", "\u0940", "\u0947", "\u094b", "\u094d", "\u094d", "\u093c", "\u0902", "\u0951", "\u0952", "‡•ß", "‡•®", "\u0929", "\u0958"] + \
+             list("‡∏Å‡∏Ç‡∏Ñ‡∏á‡∏à‡∏î‡∏ï‡∏ô‡∏ö‡∏õ‡∏°‡∏¢‡∏£‡∏•‡∏ß‡∏™‡∏´‡∏≠‡∏≤‡πÄ‡πÅ‡πÑ") + ["\u0e31", "\u0e34", "\u0e35", "\u0e38", "\u0e39", "\u0e48", "\u0e49", "\u0e4a", "\u0e4c", "‡πë", "‡πí", "\u09cb", "\u0301"]
+
+
 def one_norm(seed):
     """the device normalizer (NFD / lowercase + capcode 2; host fallback for what it does not do itself) against the host normalizer:
     runs of capitals, digits and apostrophes of every length, also across the 64-byte chunks and 1 KiB pieces of the device pass"""
@@ -146,6 +152,8 @@ def one_norm(seed):
                 parts.append("".join(rng.choice(NORM_ALPHABET[:36] + VIET, size=int(rng.integers(1, 40)))))
             elif r < 0.30:
                 parts.append("".join(rng.choice(NORM_ALPHABET[:30] + KANA, size=int(rng.integers(1, 40)))))
+            elif r < 0.33:
+                parts.append("".join(rng.choice(NORM_ALPHABET[:30] + INDIC_THAI, size=int(rng.integers(1, 40)))))
             elif lossy and r < 0.5:
                 parts.append("".join(rng.choice([" ", "  ", "   ", "\r\n", "\r", "\n", "\t", "\u2018", "\u2019", "\u201c", "\u201d", "\u2019s", "a", "B", "√©", "√â", "x ", " y", "\u0301", "√±", "1"],
                                                 size=int(rng.integers(1, 30)))))

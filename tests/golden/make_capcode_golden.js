@@ -164,6 +164,31 @@ for (let i = 0; i < 1200; i++) {
   inputs.push(s);
 }
 
+// round 6, third part: the three-byte combining marks of canonical class > 0 (virama, nukta, the Thai tone marks and vowels below ...) and the
+// three-byte digits - Hindi and Thai running text, marks in and out of canonical order.  Appended BEHIND everything else again.
+const deva = 'कखगघचछजझटठडढणतथदधनपफबभमयरलवशषसहअआइईउऊएऐओऔ'.split('');
+const devam = ['\u093e', '\u093f', '\u0940', '\u0941', '\u0942', '\u0947', '\u0948', '\u094b', '\u094c', '\u094d', '\u094d', '\u093c', '\u0902', '\u0903', '\u0901', '\u0951', '\u0952'];
+const devad = '०१२३४५६७८९'.split('');
+const thai = 'กขคงจฉชซญดตถทธนบปผฝพฟภมยรลวศษสหอฮะาำเแโใไ'.split('');
+const thaim = ['\u0e31', '\u0e34', '\u0e35', '\u0e36', '\u0e37', '\u0e38', '\u0e39', '\u0e3a', '\u0e47', '\u0e48', '\u0e49', '\u0e4a', '\u0e4b', '\u0e4c'];
+const thaid = '๐๑๒๓๔๕๖๗๘๙'.split('');
+const hwords = ['यह', 'हिन्दी', 'का', 'पाठ', 'है', 'विश्वविद्यालय', 'प्रौद्योगिकी', 'स्वतंत्रता', 'ज\u093cिन्दगी', 'फ\u093cिल्म', 'क्या', 'भारत', 'दिल्ली', 'ภาษาไทย', 'อยู่', 'ที่', 'กรุงเทพมหานคร', 'น้ำ', 'ผู้', 'ใหญ่', 'รู้', 'เรื่อง', 'GPU', 'it', 's', 'ABC', '१२३', '๑๒๓'];
+const flavours8 = [
+  () => pick([deva, deva, devam, devam, devad, lower, upper, [' '], digits, apos]),
+  () => pick([thai, thai, thaim, thaim, thaid, lower, upper, [' '], digits, apos]),
+  () => pick([hwords, hwords, [''], [' '], apos, punct, digits, upper]),
+  () => pick([deva, thai, devam, thaim, marks, ['\u0929', '\u0958', '\u09cb', '\u0bca', '\u0f73', '\u1026'], lower, upper, [' '], apos, digits, devad]),
+];
+['यह हिन्दी का पाठ है।', 'विश्वविद्यालय 2024 में GPU', 'ภาษาไทย อยู่ที่กรุงเทพมหานคร', 'น้ำ ผู้ใหญ่ รู้เรื่อง', "Aक Bก'S 1क्2 'ก่'", 'कA กb १a a१ ๑A', 'क\u094d\u093c क\u093c\u094d', 'ก\u0e48\u0e38 ก\u0e38\u0e48',
+ 'क\u0301 ก\u0301 \u1e09\u0e48 é\u094d', '१२३ ๑๒๓ 1१ १1', 'ໄທ ລາວ ພາສາ', 'བོད་སྐད', 'မြန်မာ', 'ខ្មែរ', 'தமிழ் ಕನ್ನಡ తెలుగు മലയാളം ગુજરાતી ਪੰਜਾਬੀ বাংলা'].forEach(s => inputs.push(s));
+for (let i = 0; i < 1600; i++) {
+  const f = flavours8[i % flavours8.length];
+  const n = rnd(rnd(4) === 0 ? 90 : 28);
+  let s = '';
+  for (let k = 0; k < n; k++) s += pick(f());
+  inputs.push(s);
+}
+
 const b64 = s => Buffer.from(s, 'utf8').toString('base64');
 const cases = inputs.map(s => {
   const nfd = s.normalize('NFD');

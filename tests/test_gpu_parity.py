@@ -948,6 +948,52 @@ def test_japanese_text_stays_on_the_device():
                 assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == unicodedata.normalize("NFD", docs[k].decode()).encode(), docs[k]
 
 
+def test_hindi_and_thai_text_stays_on_the_device():
+    """round 6: the three-byte combining marks of canonical class > 0 (the virama and nukta of the Indic scripts, the tone marks and the vowels below
+    of Thai ...: tm_norm_masks.h, nm_ccc3) stay where they stand under NFD unless they have to change places with a neighbouring mark - decided at the
+    later of two marks from a table of classes the host normalizer fills (tm_normalize.cpp: build_ccc_table).  One virama used to send its document to
+    host ICU, which is every Hindi or Thai document.  Bytes == the host normalizer's; the documents without a letter that decomposes (Bengali's two-part
+    vowels, the nukta letters written as one code point) and without marks out of order stay on the device; ids of the raw path == ids of the
+    host-normalized text; the decoder gives back NFD of the text."""
+    import unicodedata
+    rng = np.random.default_rng(2029)
+    hi = "यह हिन्दी का पाठ है और इसमें कई शब्द हैं जैसे कि विश्वविद्यालय प्रौद्योगिकी स्वतंत्रता ज़िन्दगी फ़िल्म क्या क्यों नहीं भारत दिल्ली मुम्बई १२३ GPU it's".split()
+    th = ["ภาษาไทย", "อยู่", "ที่", "นี่", "กรุงเทพมหานคร", "ประเทศไทย", "สวัสดี", "ครับ", "ค่ะ", "น้ำ", "ผู้", "ใหญ่", "ไม่", "ได้", "เป็น", "คุณ", "รู้", "เรื่อง", "GPU", "Bangkok", "๑๒๓"]
+    other = ["ລາວ", "ພາສາ", "བོད་སྐད", "မြန်မာ", "ខ្មែរ", "ભાષા", "தமிழ்", "ಕನ್ನಡ", "తెలుగు", "മലയാളം"]
+    odd = ["\u0929", "\u09cb", "क\u094d\u093c", "\u0e48\u0e38", "क\u0301", "\u1e09\u0e48"]         # what stays with the host: letters that decompose, marks out of order, a Latin mark among them
+    docs, host_docs = [], 0
+    total, target = 0, 120_000 if EMULATED else 3_000_000
+    while total < target:
+        n = int(rng.integers(1, 300))
+        lang = hi if rng.random() < 0.5 else th
+        d = (" " if lang is hi else "").join(str(rng.choice(lang if rng.random() < 0.93 else other)) for _ in range(n))
+        if rng.random() < 0.01:
+            d += str(rng.choice(odd))
+            host_docs += 1
+        docs.append(d.encode())
+        total += len(docs[-1])
+    docs += [("क्" * 1000).encode(), ("อยู่" * 700 + "b").encode(), ("x" * 1022 + "क्ष").encode(), ("x" * 1021 + "น้ำ").encode()]
+    raw, offs = tm.pack_documents(docs)
+    for capcode, flag in ((2, 1), (2, 3), (2, 0), (0, 1), (2, 1 | 4)):
+        v = tm.Vocab(synth.build_vocab([bytes([c]) for c in range(256)], capcode=capcode, charset=1, norm_flag=flag))
+        got, goff, nfb = v.normalize_packed_device(raw, offs)
+        exp, eoff = synth.normalize_batch(raw, offs, capcode, flag)
+        assert (goff == eoff).all() and got.size == exp.size
+        assert (got == exp).all(), "capcode %d flag %d" % (capcode, flag)
+        if flag in (0, 1, 3):
+            assert nfb <= host_docs, "%d of %d documents took the host path, at most %d expected (capcode %d flag %d)" % (nfb, len(docs), host_docs, capcode, flag)
+        if capcode == 2 and flag == 1:
+            ids, toff, miss = v.tokenize_packed(exp, eoff)
+            assert int(miss.sum()) == 0
+            nchk = min(200, len(docs))
+            gotids = v.tokenize(docs[:nchk])
+            for k in range(nchk):
+                assert (gotids[k] == ids[int(toff[k]):int(toff[k + 1])]).all()
+            out, ooff = v.decode_packed(ids[: int(toff[nchk])], np.ascontiguousarray(toff[: nchk + 1]))
+            for k in range(nchk):
+                assert out[int(ooff[k]):int(ooff[k + 1])].tobytes() == unicodedata.normalize("NFD", docs[k].decode()).encode(), docs[k]
+
+
 def test_vietnamese_text_stays_on_the_device():
     """round 6: Latin Extended Additional (U+1E00..U+1EFF: what Vietnamese is written in beside the two-byte letters) under NFD - a letter and one
     or two combining marks per character, from a table the host normalizer fills (tm_normalize.cpp: build_lea_table).  One such character used

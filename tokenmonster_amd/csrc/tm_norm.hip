@@ -54,7 +54,7 @@ __device__ __forceinline__ bool nblock(uint32_t cls) { return (cls & NF_BLOCK) !
 struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
 // The normalizer's tables in ONE device buffer (tm_norm_masks.h): NmTwo[NM_TWO_SIZE] | block codes [NM_BLK_WORDS] | code-point codes
 // [NM_CP_WORDS] | block codes of the four-byte characters [NM_BLK4_WORDS] | one word of switches (NM_MISC_*; 16 bytes with its padding).  The 256 work-items of a workgroup stage the entries of U+0080..U+017F (2 KB) and the block codes (256 bytes) in LDS.
-constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea) + NM_KANA_SIZE * sizeof(uint16_t);      // (... | the characters of Latin Extended Additional, read where they lie)
+constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea) + NM_KANA_SIZE * sizeof(uint16_t) + NM_CCC_SIZE;      // (... | the characters of Latin Extended Additional, read where they lie)
 struct TabLds { NmTwo two[NM_TWO_FAST]; uint32_t blk[NM_BLK_WORDS]; };
 __device__ __forceinline__ NmTabs stage_tabs(TabLds& s, const NmTwo* __restrict__ two) {
   static_assert(NM_TWO_FAST == 256 && NM_BLK_WORDS <= 256, "one entry per work-item");
@@ -1027,6 +1027,12 @@ const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
       build_kana_table(kana);
       blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] |= NM_MISC_KANA;
     }
+    uint8_t* ccc = reinterpret_cast<uint8_t*>(kana + NM_KANA_SIZE);
+    for (uint32_t k = 0; k < NM_CCC_SIZE; k++) ccc[k] = 0;
+    // ... the three-byte marks of canonical class > 0 (Indic, Thai ...): in place where they stand in order (under NFD without `accents`; without
+    // NFD they are inert, build_three_tables), and the three-byte digits
+    build_ccc_table(flags & 3u, (flags & 1u) && !accents, ccc);
+    blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] |= NM_MISC_CCC;
     if (accents) {
       std::vector<uint32_t> acc(NM_TWO_SIZE);
       build_accent_table(acc.data());

@@ -156,6 +156,18 @@ TM_HD uint32_t nm_kana_out(uint32_t e, uint32_t role, uint32_t* o1, uint32_t* o2
 struct NmTabs { const NmTwo* two_fast; const NmTwo* two_all; const uint32_t* blk; const uint32_t* cp; const uint32_t* blk4; uint32_t misc; const NmLea* lea; };
 static_assert(sizeof(NmTabs) <= 56, "NmTabs is passed by value to noinline device functions");
 TM_HD const uint16_t* nm_kana_tab(const NmTabs& t) { return reinterpret_cast<const uint16_t*>(t.lea + NM_LEA_SIZE); }      // the kana entries lie behind those of Latin Extended Additional
+// ---- three-byte combining marks of canonical class > 0 in U+0800..U+1FFF under NFD (round 6): the virama and nukta of the Indic scripts, the
+// tone marks and the vowels below of Thai and Lao, Tibetan, Myanmar, Khmer ... - what sent every Hindi or Thai document to the host ----------
+// NFD leaves such a mark alone unless it has to change places with a neighbouring mark (canonical ordering), and that is decided where the
+// LATER of two marks stands: a mark of class c behind a character that ends in a mark of class p > c (or in a mark whose class the device
+// does not know: a two-byte one, the last of a decomposition) sends the document to the host; p <= c is in order already.  One byte per code
+// point from the host normalizer's own functions (tm_normalize.cpp: build_ccc_table): the class, 0 = not such a mark.  Only with NM_MISC_CCC
+// (the NFD flag without `accents`; without NFD every mark is inert and build_three_tables says so).  The table lies behind the kana entries.
+// The same table names the decimal digits of the range (NM_CCC_DIGIT: no canonical class is 255) - Devanagari, Bengali, Thai ... digits are
+// class N to capcode like the ASCII and the two-byte ones, whatever the flags.
+constexpr uint32_t NM_CCC_BASE = 0x800u, NM_CCC_SIZE = 0x1800u, NM_MISC_CCC = 8u, NM_CCC_DIGIT = 255u;
+TM_HD const uint8_t* nm_ccc_tab(const NmTabs& t) { return reinterpret_cast<const uint8_t*>(nm_kana_tab(t) + NM_KANA_SIZE); }
+TM_HD uint32_t nm_ccc3(const NmTabs& t, uint32_t cp) { return ((t.misc & NM_MISC_CCC) && cp - NM_CCC_BASE < NM_CCC_SIZE) ? (uint32_t)nm_ccc_tab(t)[cp - NM_CCC_BASE] : 0u; }
 TM_HD NmTwo nm_two_get(const NmTabs& t, uint32_t idx) { return idx < (uint32_t)NM_TWO_FAST ? t.two_fast[idx] : t.two_all[idx]; }
 TM_HD uint32_t nm_three_code(const NmTabs& t, uint32_t cp) {
   const uint32_t bc = (t.blk[cp >> 10] >> (2u * ((cp >> 6) & 15u))) & 3u;
@@ -183,6 +195,8 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
     }
     // ... the same behind a character of Latin Extended Additional, which ends in a mark of its own
     if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_LEA) && m3 == 0xE1u && m2 - 0xB8u < 4u && nm_cont_byte(m1) && (tabs.lea[((m2 & 3u) << 6) | (m1 & 63u)].a & NT_OK)) return NF_BAD;
+    // ... behind a three-byte mark of class > 0 (whose place a two-byte mark of unknown class might have to take)
+    if ((a & NF_CLASS) == NC_M && nm_three_lead(m3) && nm_cont_byte(m2) && nm_cont_byte(m1) && nm_ccc3(tabs, nm_cp3(m3, m2, m1)) - 1u < NM_CCC_DIGIT - 1u) return NF_BAD;
     // ... and behind a voiced kana
     if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_KANA) && m3 == 0xE3u && m2 - 0x81u < 3u && nm_cont_byte(m1) && (nm_kana_tab(tabs)[((m2 - 0x81u) << 6) | (m1 & 63u)] & NK_OK)) return NF_BAD;
     return a & NF_CLASS;
@@ -216,6 +230,25 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
   }
   if ((tabs.misc & NM_MISC_KANA) && cp3 - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[cp3 - 0x3040u] & NK_OK)) return cont ? (uint32_t)NC_M : (uint32_t)NC_LO;      // a voiced kana: the kana, its mark, nothing
   const uint32_t code = nm_three_code(tabs, cp3);
+  if (code == 0u) {
+    const uint32_t c = nm_ccc3(tabs, cp3);
+    if (c == NM_CCC_DIGIT) return (uint32_t)NC_N | cont;
+    if (c != 0u) {                                  // a mark of canonical class c > 0: in place unless the character in front of it ends in a mark that belongs behind it
+      if (!cont) {
+        if (nm_cont_byte(m1) && nm_two_lead(m2)) {
+          const uint32_t pa = nm_two_get(tabs, nm_two_index(m2, m1)).a;
+          if ((pa & NF_CLASS) == NC_M || (pa & (NT_DECOMP | NT_DECOMP2))) return NF_BAD;
+        } else if (nm_cont_byte(m1) && nm_cont_byte(m2) && nm_three_lead(m3)) {
+          const uint32_t pcp = nm_cp3(m3, m2, m1);
+          const uint32_t pc = nm_ccc3(tabs, pcp);
+          if (pc != NM_CCC_DIGIT && pc > c) return NF_BAD;
+          if ((tabs.misc & NM_MISC_LEA) && pcp - 0x1E00u < (uint32_t)NM_LEA_SIZE && (tabs.lea[pcp - 0x1E00u].a & NT_OK)) return NF_BAD;
+          if ((tabs.misc & NM_MISC_KANA) && pcp - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[pcp - 0x3040u] & NK_OK)) return NF_BAD;
+        }
+      }
+      return (uint32_t)NC_M | cont;
+    }
+  }
   if (code == 0u && (tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp3)) return (uint32_t)NC_LO | cont;       // decomposes, but by arithmetic: nm_hangul_out
   return code == 0u ? (uint32_t)NF_BAD : ((code == 3u ? (uint32_t)NC_M : (code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O)) | cont);      // (3: a combining mark of class 0)
 }

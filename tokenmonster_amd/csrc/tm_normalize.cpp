@@ -474,6 +474,26 @@ void build_kana_table(uint16_t* out) {
   }
 }
 
+// The three-byte combining marks of U+0800..U+1FFF with a canonical class > 0 that the flags leave alone (tm_norm_masks.h: NM_CCC_SIZE): the class
+// (marks == false: only the digits, NM_CCC_DIGIT - decimal digits of three bytes, Devanagari to Tai Tham)
+void build_ccc_table(uint32_t norm_flag, bool marks, uint8_t* out) {
+  for (uint32_t k = 0; k < NM_CCC_SIZE; k++) out[k] = 0;
+  for (uint32_t cp = NM_CCC_BASE; cp < NM_CCC_BASE + NM_CCC_SIZE; cp++) {
+    std::vector<uint8_t> in, t;
+    put_cp(in, cp);
+    t = in;
+    if (norm_flag & 1) nfd_bytes(t);
+    if (norm_flag & 2) lower_bytes(t);
+    const Cp c1 = next_cp(in.data(), in.size());
+    if (c1.raw || c1.n != 3 || t != in) continue;
+    std::vector<uint8_t> low;
+    put_lower(low, c1);
+    const int ccc = u_getCombiningClass((UChar32)cp);
+    if (marks && low == in && classify(c1) == kMark && ccc > 0 && ccc < (int)NM_CCC_DIGIT) out[cp - NM_CCC_BASE] = (uint8_t)ccc;
+    else if (low == in && classify(c1) == kDigit) out[cp - NM_CCC_BASE] = (uint8_t)NM_CCC_DIGIT;
+  }
+}
+
 // blk[NM_BLK_WORDS], cp[NM_CP_WORDS]: two bits per block of 64 code points / per code point of U+0000..U+FFFF (tm_norm_masks.h)
 void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cpt) {
   for (int k = 0; k < NM_BLK_WORDS; k++) blk[k] = 0;
@@ -497,7 +517,8 @@ void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cpt) {
         if (t == in && !c1.raw && c1.n == 3 && low == in && !(k1 & (kUpper | kLower | kDigit | kMark))) code = (k1 & kLetter) ? 2u : 1u;
         // a combining mark of class 0 - the variation selectors (U+FE0F behind an emoji), the enclosing keycap, the spacing vowel signs of the
         // Indic scripts ...: canonical ordering never moves it, NFD leaves it alone: class M on the device too (round 5)
-        else if (t == in && !c1.raw && c1.n == 3 && low == in && k1 == kMark && u_getCombiningClass((UChar32)cp) == 0) code = 3u;
+        // (without the NFD flag nothing is ever reordered: every mark is of that kind)
+        else if (t == in && !c1.raw && c1.n == 3 && low == in && k1 == kMark && (u_getCombiningClass((UChar32)cp) == 0 || !(norm_flag & 1))) code = 3u;
       }
       cpt[cp >> 4] |= code << (2u * (cp & 15u));
       if (first == 4) first = code; else if (code != first) same = false;

@@ -31,11 +31,11 @@ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
 static uint64_t g_margin_ok = 0, g_margin_unknown = 0;
 static NmTwo g_two[2][NM_TWO_SIZE];     // [lower_all]: flags 1 (NFD) and 3 (NFD + lowercase)
 static uint32_t g_blk[2][NM_BLK_WORDS], g_cp[2][NM_CP_WORDS], g_blk4[2][NM_BLK4_WORDS];      // the three- and four-byte characters the pass leaves alone (tm_norm_masks.h)
-struct LeaKana { NmLea lea[NM_LEA_SIZE]; uint16_t kana[NM_KANA_SIZE]; };      // (the kana entries lie behind those of Latin Extended Additional: nm_kana_tab)
+struct LeaKana { NmLea lea[NM_LEA_SIZE]; uint16_t kana[NM_KANA_SIZE]; uint8_t ccc[NM_CCC_SIZE]; };      // (the kana entries lie behind those of Latin Extended Additional: nm_kana_tab)
 static LeaKana g_lk[2];
 #define g_lea_of(k) (g_lk[k].lea)      // Latin Extended Additional under NFD: a letter + one or two marks (round 6)
 #define g_kana (g_lk[0].kana)             // the voiced kana under NFD: a kana + U+3099 / U+309A (round 6)
-static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k], g_blk4[k], NM_MISC_HANGUL | NM_MISC_LEA | NM_MISC_KANA, g_lk[k].lea}; }
+static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k], g_blk4[k], NM_MISC_HANGUL | NM_MISC_LEA | NM_MISC_KANA | NM_MISC_CCC, g_lk[k].lea}; }
 // class byte of every byte of a document as norm_load_piece computes it (bytes outside the document read as 0)
 bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t>& f) {
   const int n = (int)d.size();
@@ -212,6 +212,8 @@ int main(int argc, char** argv) {
   build_lea_table(1, g_lk[0].lea);
   build_lea_table(3, g_lk[1].lea);
   build_kana_table(g_lk[0].kana); build_kana_table(g_lk[1].kana);
+  build_ccc_table(1, true, g_lk[0].ccc); build_ccc_table(3, true, g_lk[1].ccc);
+  { int n = 0; for (uint32_t k = 0; k < NM_CCC_SIZE; k++) n += g_lk[0].ccc[k] != 0 && g_lk[0].ccc[k] != NM_CCC_DIGIT; printf("three-byte marks of canonical class > 0 in U+0800..U+1FFF on the device: %d\n", n); }
   { int ok = 0; for (int k = 0; k < NM_KANA_SIZE; k++) ok += (g_kana[k] & NK_OK) != 0; printf("voiced kana (NFD): %d characters of U+3040..U+30FF on the device\n", ok); }
   { int ok = 0, two = 0; for (int k = 0; k < NM_LEA_SIZE; k++) { ok += (g_lk[0].lea[k].a & NT_OK) != 0; two += (g_lk[0].lea[k].a & NT_OK) && ((g_lk[0].lea[k].a >> 24) & 3u) == 2u; }
     printf("Latin Extended Additional (NFD): %d of %d characters on the device, %d of them with two marks\n", ok, NM_LEA_SIZE, two); }
@@ -250,7 +252,7 @@ int main(int argc, char** argv) {
       const bool latin = rng.below(2) != 0;     // half of the documents carry accented Latin letters, a few of them a lot
       // a third of the documents are written in another script: Greek, Cyrillic (with the letters that decompose: й ё ά ...), Hebrew, Arabic,
       // standalone combining marks, Chinese, Japanese (with voiced kana: a kana and its mark), Korean (Hangul syllables decompose by arithmetic), symbols, four-byte characters
-      const uint32_t script = rng.below(3) == 0 ? 1 + rng.below(9) : 0;
+      const uint32_t script = rng.below(3) == 0 ? 1 + rng.below(11) : 0;
       const uint32_t latin_share = rng.below(4) == 0 ? 40 : 6;
       while (d.size() < len) {
         const uint32_t r = rng.below(100);
@@ -268,6 +270,10 @@ int main(int argc, char** argv) {
             case 6: cp = rng.below(3) ? 0x3041 + rng.below(0x56) : (rng.below(2) ? 0x30A1 + rng.below(0x5E) : 0x4E00 + rng.below(0x5000));      // Japanese
                     if (rng.below(14) == 0) cp = rng.below(2) ? 0x3099 + rng.below(2) : 0x0300 + rng.below(4); break;   // ... now and then a voicing mark by itself or a Latin one (the host's behind a voiced kana)
             case 7: cp = rng.below(6) ? 0x0180 + rng.below(0x680) : 0x0300 + rng.below(0x70); break;   // anything two-byte, and stray combining marks
+            case 10: cp = 0x0900 + rng.below(0x80); if (rng.below(5) == 0) cp = rng.below(2) ? 0x094D : (rng.below(2) ? 0x093C : 0x0951 + rng.below(4));      // Devanagari: virama 9, nukta 7, accents 230 / 220 - in and out of order, the letters that decompose
+                     if (rng.below(40) == 0) cp = 0x0300 + rng.below(0x30); if (rng.below(30) == 0) cp = 0x0980 + rng.below(0x80); break;             // ... a Latin mark, Bengali (two-part vowels decompose)
+            case 11: cp = 0x0E01 + rng.below(0x3A); if (rng.below(4) == 0) cp = rng.below(2) ? 0x0E38 + rng.below(3) : 0x0E48 + rng.below(4);                // Thai: vowels below 103, tone marks 107 (อยู่: 103 then 107, in order)
+                     if (rng.below(30) == 0) cp = 0x0EB8 + rng.below(2); if (rng.below(30) == 0) cp = 0x0F71 + rng.below(0x14); if (rng.below(30) == 0) cp = 0x1037 + rng.below(4); break;   // ... Lao, Tibetan, Myanmar marks
             case 9: {                                                                        // four bytes: emoji and pictographs, plane-2 ideographs, mathematical letters; now and then what the host has to do
               const uint32_t q = rng.below(40);
               cp = q < 20 ? 0x1F300 + rng.below(0x700) : q < 28 ? 0x20000 + rng.below(0xA000) : q < 34 ? 0x1D400 + rng.below(0x400) : q < 36 ? 0x10000 + rng.below(0x100) :
