@@ -25,6 +25,7 @@ void build_three_tables(uint32_t norm_flag, uint32_t* blk, uint32_t* cp);    // 
 void build_four_table(uint32_t norm_flag, uint32_t* blk4);                   // NM_BLK4_WORDS words: the blocks of four-byte characters it passes through
 struct NmLea;
 void build_ccc_table(uint32_t norm_flag, bool marks, uint8_t* out);                      // NM_CCC_SIZE entries: canonical class of the three-byte marks of U+0800..U+1FFF that NFD leaves alone (0: not one)
+void build_dec3_table(uint32_t* out);                                        // NM_DEC3_SIZE entries: the three-byte characters of U+0900..U+1BFF that NFD splits in two three-byte ones
 void build_kana_table(uint16_t* out);                                        // NM_KANA_SIZE entries: the voiced kana of U+3040..U+30FF under NFD, a kana + U+3099 / U+309A
 void build_lea_table(uint32_t norm_flag, NmLea* out);                        // NM_LEA_SIZE entries: Latin Extended Additional under NFD, a letter + one or two marks
 void build_accent_table(uint32_t* out);                                      // NM_TWO_SIZE words: what flag 4 `accents` leaves of the two-byte characters (the filter pass)

@@ -54,7 +54,7 @@ __device__ __forceinline__ bool nblock(uint32_t cls) { return (cls & NF_BLOCK) !
 struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
 // The normalizer's tables in ONE device buffer (tm_norm_masks.h): NmTwo[NM_TWO_SIZE] | block codes [NM_BLK_WORDS] | code-point codes
 // [NM_CP_WORDS] | block codes of the four-byte characters [NM_BLK4_WORDS] | one word of switches (NM_MISC_*; 16 bytes with its padding).  The 256 work-items of a workgroup stage the entries of U+0080..U+017F (2 KB) and the block codes (256 bytes) in LDS.
-constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea) + NM_KANA_SIZE * sizeof(uint16_t) + NM_CCC_SIZE;      // (... | the characters of Latin Extended Additional, read where they lie)
+constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea) + NM_KANA_SIZE * sizeof(uint16_t) + NM_CCC_SIZE + NM_DEC3_SIZE * sizeof(uint32_t);      // (... | the characters of Latin Extended Additional, read where they lie)
 struct TabLds { NmTwo two[NM_TWO_FAST]; uint32_t blk[NM_BLK_WORDS]; };
 __device__ __forceinline__ NmTabs stage_tabs(TabLds& s, const NmTwo* __restrict__ two) {
   static_assert(NM_TWO_FAST == 256 && NM_BLK_WORDS <= 256, "one entry per work-item");
@@ -86,20 +86,31 @@ __device__ __noinline__ HighOut emit_high_byte(const uint8_t* r, uint32_t fl, ui
     const uint32_t extra = nm_two_out(e, cont2, (code & 4u) != 0, true, &o.o3, &y, &mm);
     if (extra >= 1u) { o.len1 = extra; o.ysp = y; o.m3 = mm; }
   } else {
-    uint32_t role, idx;
-    if ((tabs.misc & NM_MISC_LEA) && fl != NF_BAD && nm_lea_role(b, bm1, r[-2], bp1, r[2], &role, &idx) && (tabs.lea[idx].a & NT_OK)) {
-      // a letter of Latin Extended Additional (NFD): the letter, its first mark, its second mark or nothing
-      const NmLea e = tabs.lea[idx];
-      if (role == 0u) o.o3 = (code & 4u) ? ((e.a >> 16) & 0xFFu) : ((e.a >> 8) & 0xFFu);
-      else if (role == 1u) { o.len1 = 1u; o.ysp = e.b & 0xFFu; o.o3 = (e.b >> 8) & 0xFFu; }
-      else if (((e.a >> 24) & 3u) == 2u) { o.len1 = 1u; o.ysp = (e.b >> 16) & 0xFFu; o.o3 = e.b >> 24; }
-      else o.len1 = 0xFFu;
-    } else if ((tabs.misc & NM_MISC_KANA) && fl != NF_BAD && nm_kana_role(b, bm1, r[-2], bp1, r[2], &role, &idx) && (nm_kana_tab(tabs)[idx] & NK_OK)) {
-      // a voiced kana (NFD): the base kana, the mark, nothing
-      o.len1 = nm_kana_out(nm_kana_tab(tabs)[idx], role, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
-    } else if (tabs.misc & NM_MISC_HANGUL) {
-      uint32_t hrole, hcp;
-      if (fl != NF_BAD && nm_hangul_role(b, bm1, r[-2], bp1, r[2], &hrole, &hcp)) o.len1 = nm_hangul_out(hcp, hrole, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
+    // a byte of a three-byte character that changes under NFD (one decoding of the character, then by its range - the characters that come here
+    // for nothing, general punctuation and ideographs, leave after four compares)
+    uint32_t role, cp;
+    if (fl != NF_BAD && (tabs.misc & (NM_MISC_LEA | NM_MISC_KANA | NM_MISC_DEC3 | NM_MISC_HANGUL)) && nm_three_role(b, bm1, r[-2], bp1, r[2], &role, &cp)) {
+      if ((tabs.misc & NM_MISC_LEA) && cp - 0x1E00u < (uint32_t)NM_LEA_SIZE) {
+        // a letter of Latin Extended Additional: the letter, its first mark, its second mark or nothing
+        const NmLea e = tabs.lea[cp - 0x1E00u];
+        if (e.a & NT_OK) {
+          if (role == 0u) o.o3 = (code & 4u) ? ((e.a >> 16) & 0xFFu) : ((e.a >> 8) & 0xFFu);
+          else if (role == 1u) { o.len1 = 1u; o.ysp = e.b & 0xFFu; o.o3 = (e.b >> 8) & 0xFFu; }
+          else if (((e.a >> 24) & 3u) == 2u) { o.len1 = 1u; o.ysp = (e.b >> 16) & 0xFFu; o.o3 = e.b >> 24; }
+          else o.len1 = 0xFFu;
+        }
+      } else if ((tabs.misc & NM_MISC_KANA) && cp - 0x3040u < (uint32_t)NM_KANA_SIZE) {
+        // a voiced kana: the base kana, the mark, nothing
+        const uint32_t e = nm_kana_tab(tabs)[cp - 0x3040u];
+        if (e & NK_OK) o.len1 = nm_kana_out(e, role, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
+      } else if ((tabs.misc & NM_MISC_DEC3) && cp - NM_DEC3_BASE < NM_DEC3_SIZE) {
+        // a character NFD splits in two three-byte ones: the first, the second, nothing
+        const uint32_t e = nm_dec3_tab(tabs)[cp - NM_DEC3_BASE];
+        if (e & ND_OK) o.len1 = nm_dec3_out(e, role, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
+      } else if ((tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp)) {
+        // a Hangul syllable: one of its jamo - or nothing
+        o.len1 = nm_hangul_out(cp, role, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
+      }
     }
   }
   return o;
@@ -397,6 +408,10 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
       uint32_t krole, kidx;
       if ((tabs.misc & NM_MISC_KANA) && fl != NF_BAD && nm_kana_role(b, bm1, L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], &krole, &kidx) && (nm_kana_tab(tabs)[kidx] & NK_OK))
         len = nm_kana_out(nm_kana_tab(tabs)[kidx], krole, &o1, &o2, &o3);
+      // ... or of a character NFD splits in two three-byte ones
+      uint32_t drole, dcp;
+      if ((tabs.misc & NM_MISC_DEC3) && fl != NF_BAD && nm_three_role(b, bm1, L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], &drole, &dcp) && (nm_dec3(tabs, dcp) & ND_OK))
+        len = nm_dec3_out(nm_dec3(tabs, dcp), drole, &o1, &o2, &o3);
     }
     // inclusive prefix sum of len (0..4) over the wavefront: bytes-with-len>=k ballots, counted below the lane
     uint32_t incl = len;
@@ -1033,6 +1048,12 @@ const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
     // NFD they are inert, build_three_tables), and the three-byte digits
     build_ccc_table(flags & 3u, (flags & 1u) && !accents, ccc);
     blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] |= NM_MISC_CCC;
+    uint32_t* dec3 = reinterpret_cast<uint32_t*>(ccc + NM_CCC_SIZE);
+    for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) dec3[k] = 0;
+    if (capcode2 && (flags & 1u) && !accents) {      // ... and the three-byte characters NFD splits in two (the two-part vowel signs of Bengali, Tamil ...; the nukta letters)
+      build_dec3_table(dec3);
+      blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] |= NM_MISC_DEC3;
+    }
     if (accents) {
       std::vector<uint32_t> acc(NM_TWO_SIZE);
       build_accent_table(acc.data());

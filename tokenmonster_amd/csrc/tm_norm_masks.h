@@ -167,6 +167,35 @@ TM_HD const uint16_t* nm_kana_tab(const NmTabs& t) { return reinterpret_cast<con
 // class N to capcode like the ASCII and the two-byte ones, whatever the flags.
 constexpr uint32_t NM_CCC_BASE = 0x800u, NM_CCC_SIZE = 0x1800u, NM_MISC_CCC = 8u, NM_CCC_DIGIT = 255u;
 TM_HD const uint8_t* nm_ccc_tab(const NmTabs& t) { return reinterpret_cast<const uint8_t*>(nm_kana_tab(t) + NM_KANA_SIZE); }
+// ---- three-byte characters of U+0900..U+1BFF that NFD splits in TWO three-byte characters (round 6): the two-part vowel signs of Bengali, Tamil,
+// Malayalam, Oriya ... (ো -> ে + া), the nukta letters written as one code point (क़ -> क + ़), Myanmar ဦ, Balinese ... -----------------------------
+// Three bytes in, six out, the scheme of the voiced kana: the lane of the first byte emits the first character (a letter without case, or a mark
+// of class 0), the second the second (a mark), the third nothing.  One word per code point from the host normalizer's own functions
+// (tm_normalize.cpp: build_dec3_table), only with the NFD flag and capcode 2 and without `accents` (NM_MISC_DEC3):
+//   ND_OK | ND_LETTER (the first character is a letter, else a mark) | first - 0x800 [0..12] | second - 0x800 [13..25]
+// A mark of class > 0 behind such a character is compared with the class of its second half like with any other mark (nm_classify_high).
+constexpr uint32_t NM_DEC3_BASE = 0x900u, NM_DEC3_SIZE = 0x1300u, NM_MISC_DEC3 = 16u, ND_OK = 1u << 31, ND_LETTER = 1u << 30;
+TM_HD const uint32_t* nm_dec3_tab(const NmTabs& t) { return reinterpret_cast<const uint32_t*>(nm_ccc_tab(t) + NM_CCC_SIZE); }
+TM_HD uint32_t nm_dec3(const NmTabs& t, uint32_t cp) { return ((t.misc & NM_MISC_DEC3) && cp - NM_DEC3_BASE < NM_DEC3_SIZE) ? nm_dec3_tab(t)[cp - NM_DEC3_BASE] : 0u; }
+// which byte of a three-byte character the byte b between m2 m1 and p1 p2 is (0, 1, 2) and the character: false if it is none
+TM_HD bool nm_three_role(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32_t p2, uint32_t* role, uint32_t* cp) {
+  uint32_t lead, b1, b2;
+  if (nm_three_lead(b)) { lead = b; b1 = p1; b2 = p2; *role = 0u; }
+  else if (!nm_cont_byte(b)) return false;
+  else if (nm_three_lead(m1)) { lead = m1; b1 = b; b2 = p1; *role = 1u; }
+  else if (nm_cont_byte(m1) && nm_three_lead(m2)) { lead = m2; b1 = m1; b2 = b; *role = 2u; }
+  else return false;
+  if (!nm_cont_byte(b1) || !nm_cont_byte(b2)) return false;
+  *cp = nm_cp3(lead, b1, b2);
+  return true;
+}
+// the bytes the lane of byte number `role` of such a character emits: returns 3 (*o1 *o2 *o3) or 0
+TM_HD uint32_t nm_dec3_out(uint32_t e, uint32_t role, uint32_t* o1, uint32_t* o2, uint32_t* o3) {
+  if (role == 2u) return 0u;
+  const uint32_t cp = 0x800u + ((role == 0u ? e : e >> 13) & 0x1FFFu);
+  *o1 = 0xE0u | (cp >> 12); *o2 = 0x80u | ((cp >> 6) & 63u); *o3 = 0x80u | (cp & 63u);
+  return 3u;
+}
 TM_HD uint32_t nm_ccc3(const NmTabs& t, uint32_t cp) { return ((t.misc & NM_MISC_CCC) && cp - NM_CCC_BASE < NM_CCC_SIZE) ? (uint32_t)nm_ccc_tab(t)[cp - NM_CCC_BASE] : 0u; }
 TM_HD NmTwo nm_two_get(const NmTabs& t, uint32_t idx) { return idx < (uint32_t)NM_TWO_FAST ? t.two_fast[idx] : t.two_all[idx]; }
 TM_HD uint32_t nm_three_code(const NmTabs& t, uint32_t cp) {
@@ -197,6 +226,11 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
     if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_LEA) && m3 == 0xE1u && m2 - 0xB8u < 4u && nm_cont_byte(m1) && (tabs.lea[((m2 & 3u) << 6) | (m1 & 63u)].a & NT_OK)) return NF_BAD;
     // ... behind a three-byte mark of class > 0 (whose place a two-byte mark of unknown class might have to take)
     if ((a & NF_CLASS) == NC_M && nm_three_lead(m3) && nm_cont_byte(m2) && nm_cont_byte(m1) && nm_ccc3(tabs, nm_cp3(m3, m2, m1)) - 1u < NM_CCC_DIGIT - 1u) return NF_BAD;
+    // ... behind a three-byte character that ends in a mark of class > 0 of its own (क़)
+    if ((a & NF_CLASS) == NC_M && nm_three_lead(m3) && nm_cont_byte(m2) && nm_cont_byte(m1)) {
+      const uint32_t pe = nm_dec3(tabs, nm_cp3(m3, m2, m1));
+      if ((pe & ND_OK) && nm_ccc3(tabs, 0x800u + ((pe >> 13) & 0x1FFFu)) - 1u < NM_CCC_DIGIT - 1u) return NF_BAD;
+    }
     // ... and behind a voiced kana
     if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_KANA) && m3 == 0xE3u && m2 - 0x81u < 3u && nm_cont_byte(m1) && (nm_kana_tab(tabs)[((m2 - 0x81u) << 6) | (m1 & 63u)] & NK_OK)) return NF_BAD;
     return a & NF_CLASS;
@@ -229,6 +263,8 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
     if (a & NT_OK) return cont ? (uint32_t)NC_M : (a & NF_CLASS);
   }
   if ((tabs.misc & NM_MISC_KANA) && cp3 - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[cp3 - 0x3040u] & NK_OK)) return cont ? (uint32_t)NC_M : (uint32_t)NC_LO;      // a voiced kana: the kana, its mark, nothing
+  { const uint32_t de = nm_dec3(tabs, cp3);       // split in two by NFD: the first character, its mark, nothing
+    if (de & ND_OK) return cont ? (uint32_t)NC_M : ((de & ND_LETTER) ? (uint32_t)NC_LO : (uint32_t)NC_M); }
   const uint32_t code = nm_three_code(tabs, cp3);
   if (code == 0u) {
     const uint32_t c = nm_ccc3(tabs, cp3);
@@ -240,7 +276,8 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
           if ((pa & NF_CLASS) == NC_M || (pa & (NT_DECOMP | NT_DECOMP2))) return NF_BAD;
         } else if (nm_cont_byte(m1) && nm_cont_byte(m2) && nm_three_lead(m3)) {
           const uint32_t pcp = nm_cp3(m3, m2, m1);
-          const uint32_t pc = nm_ccc3(tabs, pcp);
+          const uint32_t pe = nm_dec3(tabs, pcp);      // (a character that is split in two ends in the mark that is its second half)
+          const uint32_t pc = nm_ccc3(tabs, (pe & ND_OK) ? 0x800u + ((pe >> 13) & 0x1FFFu) : pcp);
           if (pc != NM_CCC_DIGIT && pc > c) return NF_BAD;
           if ((tabs.misc & NM_MISC_LEA) && pcp - 0x1E00u < (uint32_t)NM_LEA_SIZE && (tabs.lea[pcp - 0x1E00u].a & NT_OK)) return NF_BAD;
           if ((tabs.misc & NM_MISC_KANA) && pcp - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[pcp - 0x3040u] & NK_OK)) return NF_BAD;

@@ -474,6 +474,30 @@ void build_kana_table(uint16_t* out) {
   }
 }
 
+// The three-byte characters of U+0900..U+1BFF that NFD splits in two three-byte characters (tm_norm_masks.h: NM_DEC3_SIZE): a letter without case
+// or a mark of class 0, NFD-stable by itself, and a mark behind it
+void build_dec3_table(uint32_t* out) {
+  for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) out[k] = 0;
+  for (uint32_t cp = NM_DEC3_BASE; cp < NM_DEC3_BASE + NM_DEC3_SIZE; cp++) {
+    std::vector<uint8_t> t;
+    put_cp(t, cp);
+    nfd_bytes(t);
+    if (t.size() != 6) continue;
+    const Cp c1 = next_cp(t.data(), 6);
+    if (c1.raw || c1.n != 3) continue;
+    const Cp c2 = next_cp(t.data() + 3, 3);
+    if (c2.raw || c2.n != 3 || classify(c2) != kMark) continue;
+    if ((uint32_t)c1.r - 0x800u >= 0x1800u || (uint32_t)c2.r - 0x800u >= 0x1800u) continue;
+    const uint8_t k1 = classify(c1);
+    const bool letter = (k1 & kLetter) && !(k1 & (kUpper | kLower));
+    if (!letter && !(k1 == kMark && u_getCombiningClass((UChar32)c1.r) == 0)) continue;
+    std::vector<uint8_t> low;
+    put_lower(low, c1);
+    if (low.size() != 3 || low[0] != t[0] || low[1] != t[1] || low[2] != t[2]) continue;
+    out[cp - NM_DEC3_BASE] = ND_OK | (letter ? ND_LETTER : 0u) | ((uint32_t)c1.r - 0x800u) | (((uint32_t)c2.r - 0x800u) << 13);
+  }
+}
+
 // The three-byte combining marks of U+0800..U+1FFF with a canonical class > 0 that the flags leave alone (tm_norm_masks.h: NM_CCC_SIZE): the class
 // (marks == false: only the digits, NM_CCC_DIGIT - decimal digits of three bytes, Devanagari to Tai Tham)
 void build_ccc_table(uint32_t norm_flag, bool marks, uint8_t* out) {

@@ -31,11 +31,11 @@ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
 static uint64_t g_margin_ok = 0, g_margin_unknown = 0;
 static NmTwo g_two[2][NM_TWO_SIZE];     // [lower_all]: flags 1 (NFD) and 3 (NFD + lowercase)
 static uint32_t g_blk[2][NM_BLK_WORDS], g_cp[2][NM_CP_WORDS], g_blk4[2][NM_BLK4_WORDS];      // the three- and four-byte characters the pass leaves alone (tm_norm_masks.h)
-struct LeaKana { NmLea lea[NM_LEA_SIZE]; uint16_t kana[NM_KANA_SIZE]; uint8_t ccc[NM_CCC_SIZE]; };      // (the kana entries lie behind those of Latin Extended Additional: nm_kana_tab)
+struct LeaKana { NmLea lea[NM_LEA_SIZE]; uint16_t kana[NM_KANA_SIZE]; uint8_t ccc[NM_CCC_SIZE]; uint32_t dec3[NM_DEC3_SIZE]; };      // (the kana entries lie behind those of Latin Extended Additional: nm_kana_tab)
 static LeaKana g_lk[2];
 #define g_lea_of(k) (g_lk[k].lea)      // Latin Extended Additional under NFD: a letter + one or two marks (round 6)
 #define g_kana (g_lk[0].kana)             // the voiced kana under NFD: a kana + U+3099 / U+309A (round 6)
-static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k], g_blk4[k], NM_MISC_HANGUL | NM_MISC_LEA | NM_MISC_KANA | NM_MISC_CCC, g_lk[k].lea}; }
+static NmTabs tabs_of(bool lower_all) { const int k = lower_all ? 1 : 0; return NmTabs{g_two[k], g_two[k], g_blk[k], g_cp[k], g_blk4[k], NM_MISC_HANGUL | NM_MISC_LEA | NM_MISC_KANA | NM_MISC_CCC | NM_MISC_DEC3, g_lk[k].lea}; }
 // class byte of every byte of a document as norm_load_piece computes it (bytes outside the document read as 0)
 bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t>& f) {
   const int n = (int)d.size();
@@ -133,6 +133,8 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
       }
       uint32_t krole, kidx;
       if (fl != NF_BAD && nm_kana_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &krole, &kidx) && (g_kana[kidx] & NK_OK)) { len = nm_kana_out(g_kana[kidx], krole, &m3, &ysp, &o3); if (len == 0) continue; }
+      uint32_t drole, dcp;
+      if (fl != NF_BAD && nm_three_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &drole, &dcp) && (nm_dec3(tabs_of(lower_all), dcp) & ND_OK)) { len = nm_dec3_out(nm_dec3(tabs_of(lower_all), dcp), drole, &m3, &ysp, &o3); if (len == 0) continue; }
       if (len == 4) out.push_back('D');
       if (len >= 3) out.push_back((uint8_t)m3);
       if (len >= 2) out.push_back((uint8_t)ysp);
@@ -213,6 +215,8 @@ int main(int argc, char** argv) {
   build_lea_table(3, g_lk[1].lea);
   build_kana_table(g_lk[0].kana); build_kana_table(g_lk[1].kana);
   build_ccc_table(1, true, g_lk[0].ccc); build_ccc_table(3, true, g_lk[1].ccc);
+  build_dec3_table(g_lk[0].dec3); build_dec3_table(g_lk[1].dec3);
+  { int n = 0; for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) n += (g_lk[0].dec3[k] & ND_OK) != 0; printf("three-byte characters NFD splits in two, on the device: %d\n", n); }
   { int n = 0; for (uint32_t k = 0; k < NM_CCC_SIZE; k++) n += g_lk[0].ccc[k] != 0 && g_lk[0].ccc[k] != NM_CCC_DIGIT; printf("three-byte marks of canonical class > 0 in U+0800..U+1FFF on the device: %d\n", n); }
   { int ok = 0; for (int k = 0; k < NM_KANA_SIZE; k++) ok += (g_kana[k] & NK_OK) != 0; printf("voiced kana (NFD): %d characters of U+3040..U+30FF on the device\n", ok); }
   { int ok = 0, two = 0; for (int k = 0; k < NM_LEA_SIZE; k++) { ok += (g_lk[0].lea[k].a & NT_OK) != 0; two += (g_lk[0].lea[k].a & NT_OK) && ((g_lk[0].lea[k].a >> 24) & 3u) == 2u; }
