@@ -16,6 +16,10 @@ WORDS = {
     "greek": "και το να είναι από την με για Ο στο που δεν Η θα ΑΘΗΝΑ τους αυτό έχει πολύ".split(),
     "french": "le la les des été où à ça Français ÉTÉ déjà très même être cœur garçon l’homme aujourd’hui".split(),
     "cjk+emoji": "世界 你好 日本語 東京 😀 🎉 こんにちは テスト hello 漢字 中文 👍".split(),
+    "japanese": "これは 日本語 の テキスト です ございます がんばって ください データ プログラム ヴァイオリン 東京 大学 で を つかう ぱぴぷぺぽ ばびぶべぼ Tokyo".split(),
+    "hindi": "यह हिन्दी का पाठ है और इसमें कई शब्द हैं जैसे कि विश्वविद्यालय प्रौद्योगिकी स्वतंत्रता क्या क्यों नहीं भारत दिल्ली मुम्बई १२३".split(),
+    "thai": "ภาษาไทย อยู่ ที่ นี่ กรุงเทพมหานคร ประเทศไทย สวัสดี ครับ ค่ะ น้ำ ผู้ ใหญ่ ไม่ ได้ เป็น คุณ รู้ เรื่อง ๑๒๓".split(),
+    "bengali+tamil": "বাংলাদেশের কোনো হবে বাংলা ভাষা মানুষ কলকাতা தமிழ் மொழி போகிறோம் சென்னை கொண்டு".split(),
     "fr: no U+2019": "le la les des été où à ça Français ÉTÉ déjà très même être cœur garçon homme aujourdhui".split(),
     "fr: accents only": "le la les des été où à ça déjà très même être garçon homme aujourdhui".split(),
     "ascii + U+2019": "le la les des ete ou a ca deja tres meme etre l’homme aujourd’hui".split(),
