@@ -54,22 +54,34 @@ __device__ __forceinline__ bool nblock(uint32_t cls) { return (cls & NF_BLOCK) !
 struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
 // The normalizer's tables in ONE device buffer (tm_norm_masks.h): NmTwo[NM_TWO_SIZE] | block codes [NM_BLK_WORDS] | code-point codes
 // [NM_CP_WORDS] | block codes of the four-byte characters [NM_BLK4_WORDS] | one word of switches (NM_MISC_*; 16 bytes with its padding).  The 256 work-items of a workgroup stage the entries of U+0080..U+017F (2 KB) and the block codes (256 bytes) in LDS.
-constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea) + NM_KANA_SIZE * sizeof(uint16_t) + NM_CCC_SIZE + NM_DEC3_SIZE * sizeof(uint32_t);      // (... | the characters of Latin Extended Additional, read where they lie)
-struct TabLds { NmTwo two[NM_TWO_FAST]; uint32_t blk[NM_BLK_WORDS]; };
+constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea) + NM_KANA_SIZE * sizeof(uint16_t) + NM_CCC_SIZE + (NM_DEC3_SIZE + NM_DEC3_THIRDS) * sizeof(uint32_t);      // (... | the characters of Latin Extended Additional, read where they lie)
+struct TabLds { NmTwo two[NM_TWO_FAST]; uint32_t blk[NM_BLK_WORDS]; uint32_t misc; };
 __device__ __forceinline__ NmTabs stage_tabs(TabLds& s, const NmTwo* __restrict__ two) {
   static_assert(NM_TWO_FAST == 256 && NM_BLK_WORDS <= 256, "one entry per work-item");
   const uint32_t* blk = reinterpret_cast<const uint32_t*>(two + NM_TWO_SIZE);
   s.two[threadIdx.x] = two[threadIdx.x];
   if (threadIdx.x < NM_BLK_WORDS) s.blk[threadIdx.x] = blk[threadIdx.x];
-  return NmTabs{s.two, two, s.blk, blk + NM_BLK_WORDS, blk + NM_BLK_WORDS + NM_CP_WORDS, (uint32_t)__builtin_amdgcn_readfirstlane((int)blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS]),
+  const uint32_t misc = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS]);
+  if (threadIdx.x == 0) s.misc = misc;
+  return NmTabs{s.two, two, s.blk, blk + NM_BLK_WORDS, blk + NM_BLK_WORDS + NM_CP_WORDS, misc,
                 reinterpret_cast<const NmLea*>(blk + NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4)};
+}
+// The out-of-line functions below get the tables as TWO POINTERS - the staged part in LDS, the whole in global memory - and put the NmTabs
+// together themselves: as a 56-byte argument by value it went through scratch memory (a copy per call and lane), and on the device - not on
+// the emulated one - a kernel whose out-of-line callee took a few bytes more of arguments faulted at address 0.
+__device__ __forceinline__ NmTabs tabs_from(const TabLds* s, const NmTwo* __restrict__ two) {
+  const uint32_t* blk = reinterpret_cast<const uint32_t*>(two + NM_TWO_SIZE);
+  return NmTabs{s->two, two, s->blk, blk + NM_BLK_WORDS, blk + NM_BLK_WORDS + NM_CP_WORDS, s->misc, reinterpret_cast<const NmLea*>(blk + NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4)};
 }
 
 // Bytes beyond ASCII are the exception (a dword of plain ASCII never gets here), and what they need is long: kept OUT of line, so that the
 // unrolled loops of the kernels stay short enough for the instruction cache (inlined into every copy of a loop body, the classifier and the
 // two-byte / Hangul output code made k_norm_emit2 57 % larger and 7 % slower on text that has none of these characters).
-__device__ __noinline__ uint32_t classify_high_byte(const uint8_t* raw_x, NmTabs tabs) {
-  return nm_classify_high(raw_x[0], raw_x[-1], raw_x[-2], raw_x[-3], raw_x[1], raw_x[2], raw_x[3], tabs);
+// the character that begins at raw_x, byte x of a staged range of `n` bytes (nm_classify_char; what lies outside the range reads as 0)
+__device__ __noinline__ uint32_t classify_high_char(const uint8_t* raw_x, int x, int n, const TabLds* ts, const NmTwo* two) {
+  const NmTabs tabs = tabs_from(ts, two);
+  return nm_classify_char(raw_x[0], x >= 1 ? raw_x[-1] : 0u, x >= 2 ? raw_x[-2] : 0u, x >= 3 ? raw_x[-3] : 0u, x + 1 < n ? raw_x[1] : 0u, x + 2 < n ? raw_x[2] : 0u,
+                          x + 3 < n ? raw_x[3] : 0u, tabs);
 }
 // what the lane of a byte >= 0x80 emits in k_norm_emit2 (tm_norm_masks.h): the bytes of a two-byte character come from the table - the lead
 // lane its first byte, or the ASCII letter the character decomposes into; the second lane its second byte, or the two bytes of the combining
@@ -77,7 +89,8 @@ __device__ __noinline__ uint32_t classify_high_byte(const uint8_t* raw_x, NmTabs
 // consonant - nothing at all.  In: r = the byte in LDS, fl its class byte, code its rule-table entry; o = {o3, ysp, m3, len1} as the rule
 // table left them.  Returns the same four, len1 = 0xFF for "no byte at all".
 struct HighOut { uint32_t o3, ysp, m3, len1; };
-__device__ __noinline__ HighOut emit_high_byte(const uint8_t* r, uint32_t fl, uint32_t code, HighOut o, NmTabs tabs) {
+__device__ __noinline__ HighOut emit_high_byte(const uint8_t* r, uint32_t fl, uint32_t code, HighOut o, const TabLds* ts, const NmTwo* two) {
+  const NmTabs tabs = tabs_from(ts, two);
   const uint32_t b = r[0], bm1 = r[-1], bp1 = r[1];
   const bool lead2 = nm_two_lead(b), cont2 = nm_cont_byte(b) && nm_two_lead(bm1);
   if (lead2 || cont2) {
@@ -106,7 +119,7 @@ __device__ __noinline__ HighOut emit_high_byte(const uint8_t* r, uint32_t fl, ui
       } else if ((tabs.misc & NM_MISC_DEC3) && cp - NM_DEC3_BASE < NM_DEC3_SIZE) {
         // a character NFD splits in two three-byte ones: the first, the second, nothing
         const uint32_t e = nm_dec3_tab(tabs)[cp - NM_DEC3_BASE];
-        if (e & ND_OK) o.len1 = nm_dec3_out(e, role, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
+        if (e & ND_OK) o.len1 = nm_dec3_out(tabs, e, role, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
       } else if ((tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp)) {
         // a Hangul syllable: one of its jamo - or nothing
         o.len1 = nm_hangul_out(cp, role, &o.m3, &o.ysp, &o.o3) ? 2u : 0xFFu;
@@ -123,7 +136,7 @@ __device__ __noinline__ HighOut emit_high_byte(const uint8_t* r, uint32_t fl, ui
 // 64-bit range tests and exec masks, on a kernel that is bound by its scalar instructions).
 template <typename LDS>
 __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict__ raw, uint64_t rb, uint64_t re, uint64_t pb, int lane,
-                                               const uint8_t* s_cls, const NmTabs& tabs) {
+                                               const uint8_t* s_cls, const TabLds* ts, const NmTwo* __restrict__ two) {
   const uint64_t left = re - pb;
   const uint32_t before = pb != rb ? (uint32_t)PMARGIN : 0u;            // (pb - rb is a multiple of PIECE: the whole margin in front, or none of it)
   const uint32_t after = left > (uint64_t)(PIECE + PMARGIN) ? (uint32_t)(PIECE + PMARGIN) : (uint32_t)left;
@@ -156,7 +169,10 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
   if (__ballot((high & 0x80808080u) != 0u) != 0ull) {
-    // bytes beyond ASCII somewhere in the range (the exception): their dwords again, with the classifier that looks three bytes either way
+    // bytes beyond ASCII somewhere in the range (the exception): their dwords again.  A character is classified ONCE, at its first byte, by the
+    // classifier that looks three bytes either way, and the lane that holds that byte writes the class bytes of the whole character (text in
+    // another script is two- and three-byte characters from end to end: a decoding per byte was most of what the pass took there - 13 - 17 ms
+    // per GiB against 3); every byte beyond ASCII is NF_BAD beforehand, which is what is left of a byte no well-formed character claims.
 #pragma unroll 1
     for (int i = lane; i < PLDS / 4; i += 64) {
       const uint32_t v = reinterpret_cast<const uint32_t*>(L.raw)[i];
@@ -166,12 +182,33 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
         for (int q = 0; q < 4; q++) {
           const int x = 4 * i + q;
           const uint32_t b = (v >> (8 * q)) & 0xFFu;
-          uint32_t fl = 0;                                    // (the three bytes at either end of the staged range are never looked at)
-          if (b < 0x80u) fl = s_cls[b];
-          else if (x >= 3 && x < PLDS - 3) fl = classify_high_byte(L.raw + x, tabs);     // a two-byte character, a three- or four-byte one the pass leaves alone, or NF_BAD
+          const uint32_t fl = b < 0x80u ? (uint32_t)s_cls[b] : ((x >= 3 && x < PLDS - 3) ? (uint32_t)NF_BAD : 0u);      // (the three bytes at either end of the staged range are never looked at)
           f4 |= fl << (8 * q);
         }
         reinterpret_cast<uint32_t*>(L.f)[i] = f4;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll 1
+    for (int i = lane; i < PLDS / 4; i += 64) {
+      const uint32_t v = reinterpret_cast<const uint32_t*>(L.raw)[i];
+      // the bytes >= 0xC0 of the dword, one after the other: a character begins at each (as many trips as the lane with the most of them has -
+      // two in text of three-byte characters, where a loop over the four byte positions makes four calls, each for a third of the lanes)
+      // (this shape and no other: as `for (lm = ...; lm != 0; lm &= lm - 1)` with a `continue` behind the call and a loop over the character's bytes,
+      // k_norm_emit<3> - and only it - came out with wrong class bytes on the device; profiles/r06_scripts_on_device.txt)
+      uint32_t lm = v & (v << 1) & 0x80808080u;
+#pragma unroll 1
+      while (lm != 0u) {
+        const int x = 4 * i + (__builtin_ctz(lm) >> 3);
+        lm &= lm - 1u;
+        const uint32_t r = classify_high_char(L.raw + x, x, PLDS, ts, two);
+        const uint32_t c0 = r & 0xFFu, c1 = (r >> 8) & 0xFFu, nb = c0 == NF_BAD ? 0u : r >> 16;
+        uint8_t* f = L.f + x;
+        if (nb >= 1u && x >= 3 && x < PLDS - 3) f[0] = (uint8_t)c0;
+        if (nb >= 2u && x + 1 >= 3 && x + 1 < PLDS - 3) f[1] = (uint8_t)c1;
+        if (nb >= 3u && x + 2 >= 3 && x + 2 < PLDS - 3) f[2] = (uint8_t)c1;
+        if (nb >= 4u && x + 3 >= 3 && x + 3 < PLDS - 3) f[3] = (uint8_t)c1;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -197,7 +234,7 @@ __global__ __launch_bounds__(256) void k_norm_summary(const uint8_t* __restrict_
   PieceLds& L = s_l[wv];
   const uint32_t d = piece_doc[k];
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, tabs));
+  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, &s_tab, two));
   bool lead_open = true, lead_tl = false, bad = false;
   uint32_t lead_u = 0, trail_u = 0;
   for (int c = 0; c * 64 < m; c++) {
@@ -291,7 +328,7 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
   const uint32_t d = piece_doc[k];
   if (MODE != 3 && need_host[d]) { if (MODE != 1 && lane == 0) piece_len[k] = 0; return; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls, tabs);
+  const int m = norm_load_piece(L, raw, rb, re, pb, lane, s_cls, &s_tab, two);
   uint8_t* dst = MODE == 1 ? out + piece_off[k] : (MODE >= 2 ? out + k * (uint64_t)SLAB : nullptr);
   if (capcode != 2 || MODE == 3) {                          // no capcode: same length, only the lower-case flag applies
     if (MODE != 1 && lane == 0) piece_len[k] = (uint32_t)m;
@@ -411,7 +448,7 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
       // ... or of a character NFD splits in two three-byte ones
       uint32_t drole, dcp;
       if ((tabs.misc & NM_MISC_DEC3) && fl != NF_BAD && nm_three_role(b, bm1, L.raw[x - 2], L.raw[x + 1], L.raw[x + 2], &drole, &dcp) && (nm_dec3(tabs, dcp) & ND_OK))
-        len = nm_dec3_out(nm_dec3(tabs, dcp), drole, &o1, &o2, &o3);
+        len = nm_dec3_out(tabs, nm_dec3(tabs, dcp), drole, &o1, &o2, &o3);
     }
     // inclusive prefix sum of len (0..4) over the wavefront: bytes-with-len>=k ballots, counted below the lane
     uint32_t incl = len;
@@ -481,7 +518,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
   const uint32_t d = piece_doc[k];
   if (CARRY && need_host[d]) { if (lane == 0) piece_len[k] = 0; continue; }
   const uint64_t rb = rbegin[d], re = rend[d], pb = rb + (k - doc_piece_start[d]) * PIECE;
-  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, tabs));
+  const int m = __builtin_amdgcn_readfirstlane(norm_load_piece(L, raw, rb, re, pb, lane, s_cls, &s_tab, two));
   const uint32_t carry = CARRY ? __builtin_amdgcn_readfirstlane((uint32_t)piece_carry[k]) : 0u;
   const int nch = (m + 63) >> 6;
   const uint8_t* fl0 = L.f + PMARGIN + lane;       // class byte of byte (64 c + lane) of the piece = fl0[64 c]; chunk -1 and chunk NCH are the margins
@@ -554,7 +591,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
     uint32_t below = posabs + (uint32_t)lane, n = len1 + 1u;           // first output byte of the lane before the extra bytes of the lanes below it; bytes it emits
     if (__ballot(b >= 0x80u) != 0ull) {
       if (b >= 0x80u) {
-        const HighOut h = emit_high_byte(rc, fl, code, HighOut{o3, ysp, m3, len1}, tabs);
+        const HighOut h = emit_high_byte(rc, fl, code, HighOut{o3, ysp, m3, len1}, &s_tab, two);
         o3 = h.o3; ysp = h.ysp; m3 = h.m3; len1 = h.len1;
       }
       E = ~__ballot(len1 == 0xFFu);
@@ -1049,7 +1086,7 @@ const std::vector<uint8_t>& norm_tables(uint32_t flags, bool capcode2) {
     build_ccc_table(flags & 3u, (flags & 1u) && !accents, ccc);
     blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] |= NM_MISC_CCC;
     uint32_t* dec3 = reinterpret_cast<uint32_t*>(ccc + NM_CCC_SIZE);
-    for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) dec3[k] = 0;
+    for (uint32_t k = 0; k < NM_DEC3_SIZE + NM_DEC3_THIRDS; k++) dec3[k] = 0;
     if (capcode2 && (flags & 1u) && !accents) {      // ... and the three-byte characters NFD splits in two (the two-part vowel signs of Bengali, Tamil ...; the nukta letters)
       build_dec3_table(dec3);
       blk[NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS] |= NM_MISC_DEC3;

@@ -172,10 +172,13 @@ TM_HD const uint8_t* nm_ccc_tab(const NmTabs& t) { return reinterpret_cast<const
 // Three bytes in, six out, the scheme of the voiced kana: the lane of the first byte emits the first character (a letter without case, or a mark
 // of class 0), the second the second (a mark), the third nothing.  One word per code point from the host normalizer's own functions
 // (tm_normalize.cpp: build_dec3_table), only with the NFD flag and capcode 2 and without `accents` (NM_MISC_DEC3):
-//   ND_OK | ND_LETTER (the first character is a letter, else a mark) | first - 0x800 [0..12] | second - 0x800 [13..25]
-// A mark of class > 0 behind such a character is compared with the class of its second half like with any other mark (nm_classify_high).
-constexpr uint32_t NM_DEC3_BASE = 0x900u, NM_DEC3_SIZE = 0x1300u, NM_MISC_DEC3 = 16u, ND_OK = 1u << 31, ND_LETTER = 1u << 30;
+//   ND_OK | ND_LETTER (the first character is a letter, else a mark) | first - 0x800 [0..12] | second - 0x800 [13..25] | [26..29]: 0, or which of
+//   the NM_DEC3_THIRDS words behind the table holds a THIRD character (Kannada ೋ, Sinhala ෝ: three parts - the third lane emits it)
+// A mark of class > 0 behind such a character is compared with the class of its last part like with any other mark (nm_classify_high).
+constexpr uint32_t NM_DEC3_BASE = 0x900u, NM_DEC3_SIZE = 0x1300u, NM_DEC3_THIRDS = 16u, NM_MISC_DEC3 = 16u, ND_OK = 1u << 31, ND_LETTER = 1u << 30;
 TM_HD const uint32_t* nm_dec3_tab(const NmTabs& t) { return reinterpret_cast<const uint32_t*>(nm_ccc_tab(t) + NM_CCC_SIZE); }
+// the last character such an entry ends in (what a mark behind it is compared with)
+TM_HD uint32_t nm_dec3_last(const NmTabs& t, uint32_t e) { const uint32_t k = (e >> 26) & 15u; return k ? nm_dec3_tab(t)[NM_DEC3_SIZE + k] : 0x800u + ((e >> 13) & 0x1FFFu); }
 TM_HD uint32_t nm_dec3(const NmTabs& t, uint32_t cp) { return ((t.misc & NM_MISC_DEC3) && cp - NM_DEC3_BASE < NM_DEC3_SIZE) ? nm_dec3_tab(t)[cp - NM_DEC3_BASE] : 0u; }
 // which byte of a three-byte character the byte b between m2 m1 and p1 p2 is (0, 1, 2) and the character: false if it is none
 TM_HD bool nm_three_role(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint32_t p2, uint32_t* role, uint32_t* cp) {
@@ -190,9 +193,9 @@ TM_HD bool nm_three_role(uint32_t b, uint32_t m1, uint32_t m2, uint32_t p1, uint
   return true;
 }
 // the bytes the lane of byte number `role` of such a character emits: returns 3 (*o1 *o2 *o3) or 0
-TM_HD uint32_t nm_dec3_out(uint32_t e, uint32_t role, uint32_t* o1, uint32_t* o2, uint32_t* o3) {
-  if (role == 2u) return 0u;
-  const uint32_t cp = 0x800u + ((role == 0u ? e : e >> 13) & 0x1FFFu);
+TM_HD uint32_t nm_dec3_out(const NmTabs& t, uint32_t e, uint32_t role, uint32_t* o1, uint32_t* o2, uint32_t* o3) {
+  if (role == 2u && ((e >> 26) & 15u) == 0u) return 0u;
+  const uint32_t cp = role == 2u ? nm_dec3_last(t, e) : 0x800u + ((role == 0u ? e : e >> 13) & 0x1FFFu);
   *o1 = 0xE0u | (cp >> 12); *o2 = 0x80u | ((cp >> 6) & 63u); *o3 = 0x80u | (cp & 63u);
   return 3u;
 }
@@ -229,7 +232,7 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
     // ... behind a three-byte character that ends in a mark of class > 0 of its own (क़)
     if ((a & NF_CLASS) == NC_M && nm_three_lead(m3) && nm_cont_byte(m2) && nm_cont_byte(m1)) {
       const uint32_t pe = nm_dec3(tabs, nm_cp3(m3, m2, m1));
-      if ((pe & ND_OK) && nm_ccc3(tabs, 0x800u + ((pe >> 13) & 0x1FFFu)) - 1u < NM_CCC_DIGIT - 1u) return NF_BAD;
+      if ((pe & ND_OK) && nm_ccc3(tabs, nm_dec3_last(tabs, pe)) - 1u < NM_CCC_DIGIT - 1u) return NF_BAD;
     }
     // ... and behind a voiced kana
     if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_KANA) && m3 == 0xE3u && m2 - 0x81u < 3u && nm_cont_byte(m1) && (nm_kana_tab(tabs)[((m2 - 0x81u) << 6) | (m1 & 63u)] & NK_OK)) return NF_BAD;
@@ -277,7 +280,7 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
         } else if (nm_cont_byte(m1) && nm_cont_byte(m2) && nm_three_lead(m3)) {
           const uint32_t pcp = nm_cp3(m3, m2, m1);
           const uint32_t pe = nm_dec3(tabs, pcp);      // (a character that is split in two ends in the mark that is its second half)
-          const uint32_t pc = nm_ccc3(tabs, (pe & ND_OK) ? 0x800u + ((pe >> 13) & 0x1FFFu) : pcp);
+          const uint32_t pc = nm_ccc3(tabs, (pe & ND_OK) ? nm_dec3_last(tabs, pe) : pcp);
           if (pc != NM_CCC_DIGIT && pc > c) return NF_BAD;
           if ((tabs.misc & NM_MISC_LEA) && pcp - 0x1E00u < (uint32_t)NM_LEA_SIZE && (tabs.lea[pcp - 0x1E00u].a & NT_OK)) return NF_BAD;
           if ((tabs.misc & NM_MISC_KANA) && pcp - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[pcp - 0x3040u] & NK_OK)) return NF_BAD;
@@ -288,6 +291,24 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
   }
   if (code == 0u && (tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp3)) return (uint32_t)NC_LO | cont;       // decomposes, but by arithmetic: nm_hangul_out
   return code == 0u ? (uint32_t)NF_BAD : ((code == 3u ? (uint32_t)NC_M : (code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O)) | cont);      // (3: a combining mark of class 0)
+}
+// The same per CHARACTER, at its first byte b (>= 0xC0): class of the first byte | class of its other bytes << 8 | its length << 16 - what
+// nm_classify_high says of each of its bytes, for one decoding of the character instead of one per byte (a character that is not taken:
+// NF_BAD in both, length 1; the bytes behind it keep the NF_BAD the caller has given every byte beyond ASCII beforehand).
+TM_HD uint32_t nm_classify_char(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m3, uint32_t p1, uint32_t p2, uint32_t p3, const NmTabs& tabs) {
+  const uint32_t cls = nm_classify_high(b, m1, m2, m3, p1, p2, p3, tabs);
+  if (cls == NF_BAD || !(nm_two_lead(b) || nm_three_lead(b) || nm_four_lead(b))) return NF_BAD | (NF_BAD << 8) | (1u << 16);
+  uint32_t cont = cls | NF_CONT, n = 4u;
+  if (nm_two_lead(b)) {
+    n = 2u;
+    if (nm_two_get(tabs, nm_two_index(b, p1)).a & (NT_DECOMP | NT_DECOMP2)) cont = NC_M;            // the second half of a character that decomposes emits the mark
+  } else if (nm_three_lead(b)) {
+    n = 3u;
+    const uint32_t cp3 = nm_cp3(b, p1, p2);                                                          // a letter and its marks (Latin Extended Additional, a voiced kana, a character NFD splits): the other lanes are marks
+    if (((tabs.misc & NM_MISC_LEA) && cp3 - 0x1E00u < (uint32_t)NM_LEA_SIZE && (tabs.lea[cp3 - 0x1E00u].a & NT_OK)) ||
+        ((tabs.misc & NM_MISC_KANA) && cp3 - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[cp3 - 0x3040u] & NK_OK)) || (nm_dec3(tabs, cp3) & ND_OK)) cont = NC_M;
+  }
+  return cls | (cont << 8) | (n << 16);
 }
 // the bytes of a lane that holds one byte of a two-byte character: *o3 = its last output byte; returns how many bytes the lane emits
 // IN FRONT of it: 0, 1 (*y: the second half of a character that decomposes into an ASCII letter and a mark emits the mark) or 2 (*m3 *y:

@@ -477,24 +477,36 @@ void build_kana_table(uint16_t* out) {
 // The three-byte characters of U+0900..U+1BFF that NFD splits in two three-byte characters (tm_norm_masks.h: NM_DEC3_SIZE): a letter without case
 // or a mark of class 0, NFD-stable by itself, and a mark behind it
 void build_dec3_table(uint32_t* out) {
-  for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) out[k] = 0;
+  for (uint32_t k = 0; k < NM_DEC3_SIZE + NM_DEC3_THIRDS; k++) out[k] = 0;
+  uint32_t nthird = 0;
   for (uint32_t cp = NM_DEC3_BASE; cp < NM_DEC3_BASE + NM_DEC3_SIZE; cp++) {
     std::vector<uint8_t> t;
     put_cp(t, cp);
     nfd_bytes(t);
-    if (t.size() != 6) continue;
-    const Cp c1 = next_cp(t.data(), 6);
+    if (t.size() != 6 && t.size() != 9) continue;
+    const Cp c1 = next_cp(t.data(), 3);
     if (c1.raw || c1.n != 3) continue;
-    const Cp c2 = next_cp(t.data() + 3, 3);
-    if (c2.raw || c2.n != 3 || classify(c2) != kMark) continue;
-    if ((uint32_t)c1.r - 0x800u >= 0x1800u || (uint32_t)c2.r - 0x800u >= 0x1800u) continue;
+    bool ok = true;
+    uint32_t parts[3] = {(uint32_t)c1.r, 0, 0};
+    for (size_t j = 1; j < t.size() / 3 && ok; j++) {      // every further part: a mark of three bytes inside the range the tables cover
+      const Cp cj = next_cp(t.data() + 3 * j, 3);
+      ok = !cj.raw && cj.n == 3 && classify(cj) == kMark && (uint32_t)cj.r - 0x800u < 0x1800u;
+      parts[j] = (uint32_t)cj.r;
+    }
+    if (!ok || (uint32_t)c1.r - 0x800u >= 0x1800u) continue;
     const uint8_t k1 = classify(c1);
     const bool letter = (k1 & kLetter) && !(k1 & (kUpper | kLower));
     if (!letter && !(k1 == kMark && u_getCombiningClass((UChar32)c1.r) == 0)) continue;
     std::vector<uint8_t> low;
     put_lower(low, c1);
     if (low.size() != 3 || low[0] != t[0] || low[1] != t[1] || low[2] != t[2]) continue;
-    out[cp - NM_DEC3_BASE] = ND_OK | (letter ? ND_LETTER : 0u) | ((uint32_t)c1.r - 0x800u) | (((uint32_t)c2.r - 0x800u) << 13);
+    uint32_t third = 0;
+    if (t.size() == 9) {                                   // three parts (Kannada U+0CCB, Sinhala U+0DDD): the third in one of the words behind the table
+      if (nthird + 1 >= NM_DEC3_THIRDS) continue;
+      third = ++nthird;
+      out[NM_DEC3_SIZE + third] = parts[2];
+    }
+    out[cp - NM_DEC3_BASE] = ND_OK | (letter ? ND_LETTER : 0u) | (parts[0] - 0x800u) | ((parts[1] - 0x800u) << 13) | (third << 26);
   }
 }
 

@@ -31,7 +31,7 @@ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
 static uint64_t g_margin_ok = 0, g_margin_unknown = 0;
 static NmTwo g_two[2][NM_TWO_SIZE];     // [lower_all]: flags 1 (NFD) and 3 (NFD + lowercase)
 static uint32_t g_blk[2][NM_BLK_WORDS], g_cp[2][NM_CP_WORDS], g_blk4[2][NM_BLK4_WORDS];      // the three- and four-byte characters the pass leaves alone (tm_norm_masks.h)
-struct LeaKana { NmLea lea[NM_LEA_SIZE]; uint16_t kana[NM_KANA_SIZE]; uint8_t ccc[NM_CCC_SIZE]; uint32_t dec3[NM_DEC3_SIZE]; };      // (the kana entries lie behind those of Latin Extended Additional: nm_kana_tab)
+struct LeaKana { NmLea lea[NM_LEA_SIZE]; uint16_t kana[NM_KANA_SIZE]; uint8_t ccc[NM_CCC_SIZE]; uint32_t dec3[NM_DEC3_SIZE + NM_DEC3_THIRDS]; };      // (the kana entries lie behind those of Latin Extended Additional: nm_kana_tab)
 static LeaKana g_lk[2];
 #define g_lea_of(k) (g_lk[k].lea)      // Latin Extended Additional under NFD: a letter + one or two marks (round 6)
 #define g_kana (g_lk[0].kana)             // the voiced kana under NFD: a kana + U+3099 / U+309A (round 6)
@@ -42,12 +42,15 @@ bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t
   auto at = [&](int i) -> uint32_t { return i >= 0 && i < n ? d[i] : 0u; };
   f.assign(n, 0);
   bool ok_all = true;
+  // (as norm_load_piece does it: every byte beyond ASCII NF_BAD, then every character once, at its first byte, for all of its bytes)
+  for (int i = 0; i < n; i++) f[i] = (uint8_t)(d[i] < 0x80u ? ncls_ascii(d[i], lower_all) : (uint32_t)NF_BAD);
   for (int i = 0; i < n; i++) {
-    const uint32_t b = d[i];
-    const uint32_t fl = b < 0x80u ? ncls_ascii(b, lower_all) : nm_classify_high(b, at(i - 1), at(i - 2), at(i - 3), at(i + 1), at(i + 2), at(i + 3), tabs_of(lower_all));
-    if (fl == NF_BAD) ok_all = false;
-    f[i] = (uint8_t)fl;
+    if ((d[i] & 0xC0u) != 0xC0u) continue;
+    const uint32_t r = nm_classify_char(d[i], at(i - 1), at(i - 2), at(i - 3), at(i + 1), at(i + 2), at(i + 3), tabs_of(lower_all));
+    if ((r & 0xFFu) == NF_BAD) continue;
+    for (int j = 0; j < (int)(r >> 16) && i + j < n; j++) f[i + j] = (uint8_t)(j ? (r >> 8) : r);
   }
+  for (int i = 0; i < n; i++) if (f[i] == NF_BAD) ok_all = false;
   return ok_all;
 }
 bool is_block(uint32_t cls) { return (cls & NF_BLOCK) != 0; }
@@ -134,7 +137,7 @@ void emit_piece(const std::vector<uint8_t>& d, const std::vector<uint8_t>& f, in
       uint32_t krole, kidx;
       if (fl != NF_BAD && nm_kana_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &krole, &kidx) && (g_kana[kidx] & NK_OK)) { len = nm_kana_out(g_kana[kidx], krole, &m3, &ysp, &o3); if (len == 0) continue; }
       uint32_t drole, dcp;
-      if (fl != NF_BAD && nm_three_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &drole, &dcp) && (nm_dec3(tabs_of(lower_all), dcp) & ND_OK)) { len = nm_dec3_out(nm_dec3(tabs_of(lower_all), dcp), drole, &m3, &ysp, &o3); if (len == 0) continue; }
+      if (fl != NF_BAD && nm_three_role(b, bm1, rawat(rel - 2), bp1, rawat(rel + 2), &drole, &dcp) && (nm_dec3(tabs_of(lower_all), dcp) & ND_OK)) { len = nm_dec3_out(tabs_of(lower_all), nm_dec3(tabs_of(lower_all), dcp), drole, &m3, &ysp, &o3); if (len == 0) continue; }
       if (len == 4) out.push_back('D');
       if (len >= 3) out.push_back((uint8_t)m3);
       if (len >= 2) out.push_back((uint8_t)ysp);
@@ -216,7 +219,7 @@ int main(int argc, char** argv) {
   build_kana_table(g_lk[0].kana); build_kana_table(g_lk[1].kana);
   build_ccc_table(1, true, g_lk[0].ccc); build_ccc_table(3, true, g_lk[1].ccc);
   build_dec3_table(g_lk[0].dec3); build_dec3_table(g_lk[1].dec3);
-  { int n = 0; for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) n += (g_lk[0].dec3[k] & ND_OK) != 0; printf("three-byte characters NFD splits in two, on the device: %d\n", n); }
+  { int n = 0; for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) n += (g_lk[0].dec3[k] & ND_OK) != 0; int n3 = 0; for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) n3 += ((g_lk[0].dec3[k] >> 26) & 15u) != 0; printf("three-byte characters NFD splits in two or three, on the device: %d (%d of them in three)\n", n, n3); }
   { int n = 0; for (uint32_t k = 0; k < NM_CCC_SIZE; k++) n += g_lk[0].ccc[k] != 0 && g_lk[0].ccc[k] != NM_CCC_DIGIT; printf("three-byte marks of canonical class > 0 in U+0800..U+1FFF on the device: %d\n", n); }
   { int ok = 0; for (int k = 0; k < NM_KANA_SIZE; k++) ok += (g_kana[k] & NK_OK) != 0; printf("voiced kana (NFD): %d characters of U+3040..U+30FF on the device\n", ok); }
   { int ok = 0, two = 0; for (int k = 0; k < NM_LEA_SIZE; k++) { ok += (g_lk[0].lea[k].a & NT_OK) != 0; two += (g_lk[0].lea[k].a & NT_OK) && ((g_lk[0].lea[k].a >> 24) & 3u) == 2u; }
