@@ -51,7 +51,9 @@ __device__ __forceinline__ uint32_t ncls_ascii(uint32_t c, bool lower_all) {
 }
 __device__ __forceinline__ bool nblock(uint32_t cls) { return (cls & NF_BLOCK) != 0; }       // capital, digit, apostrophe, combining mark
 
-struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; };
+// (chg[c]: chunk c of the piece has a byte of a character that the pass CHANGES - a two-byte character, which takes its bytes from the table, or one
+// NFD splits; set by norm_load_piece, looked at by k_norm_emit2, which leaves emit_high_byte alone for a chunk of nothing but inert characters)
+struct PieceLds { alignas(16) uint8_t raw[PLDS]; alignas(4) uint8_t f[PLDS]; uint8_t chg[32]; };
 // The normalizer's tables in ONE device buffer (tm_norm_masks.h): NmTwo[NM_TWO_SIZE] | block codes [NM_BLK_WORDS] | code-point codes
 // [NM_CP_WORDS] | block codes of the four-byte characters [NM_BLK4_WORDS] | one word of switches (NM_MISC_*; 16 bytes with its padding).  The 256 work-items of a workgroup stage the entries of U+0080..U+017F (2 KB) and the block codes (256 bytes) in LDS.
 constexpr size_t NM_TABLE_BYTES = NM_TWO_SIZE * sizeof(NmTwo) + (NM_BLK_WORDS + NM_CP_WORDS + NM_BLK4_WORDS + 4) * sizeof(uint32_t) + NM_LEA_SIZE * sizeof(NmLea) + NM_KANA_SIZE * sizeof(uint16_t) + NM_CCC_SIZE + (NM_DEC3_SIZE + NM_DEC3_THIRDS) * sizeof(uint32_t);      // (... | the characters of Latin Extended Additional, read where they lie)
@@ -157,6 +159,7 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
       high |= v;
     }
   }
+  if (lane < 32) L.chg[lane] = 0;
   // the last dword of the document may be a partial one: its bytes one by one (behind the zero the loop above has put there)
   __builtin_amdgcn_wave_barrier();
   const uint32_t tail = e & 3u;
@@ -203,12 +206,17 @@ __device__ __forceinline__ int norm_load_piece(LDS& L, const uint8_t* __restrict
         const int x = 4 * i + (__builtin_ctz(lm) >> 3);
         lm &= lm - 1u;
         const uint32_t r = classify_high_char(L.raw + x, x, PLDS, ts, two);
-        const uint32_t c0 = r & 0xFFu, c1 = (r >> 8) & 0xFFu, nb = c0 == NF_BAD ? 0u : r >> 16;
+        const uint32_t c0 = r & 0xFFu, c1 = (r >> 8) & 0xFFu, nb = c0 == NF_BAD ? 0u : (r >> 16) & 0xFFu;
         uint8_t* f = L.f + x;
         if (nb >= 1u && x >= 3 && x < PLDS - 3) f[0] = (uint8_t)c0;
         if (nb >= 2u && x + 1 >= 3 && x + 1 < PLDS - 3) f[1] = (uint8_t)c1;
         if (nb >= 3u && x + 2 >= 3 && x + 2 < PLDS - 3) f[2] = (uint8_t)c1;
         if (nb >= 4u && x + 3 >= 3 && x + 3 < PLDS - 3) f[3] = (uint8_t)c1;
+        if ((r >> 24) != 0u && nb != 0u) {                     // a character the pass changes: its chunk(s) of the piece (every writer writes 1)
+          const uint32_t i0 = (uint32_t)(x - PMARGIN), i1 = i0 + nb - 1u;
+          if (i0 < (uint32_t)PIECE) L.chg[i0 >> 6] = 1;
+          if (i1 < (uint32_t)PIECE) L.chg[i1 >> 6] = 1;
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(256) void k_norm_emit(const uint8_t* __restrict__ r
 // and the 'C'/'W' lookahead — are flood fills on the chunk's class ballots, done by the scalar unit; the rule chain is a
 // 2048-entry table in LDS (tm_norm_masks.h; both checked on the CPU by tools/norm_masks_check.cpp); the output is assembled in
 // LDS and leaves for the slab in 16-byte stores.
-struct PieceLds2 { uint8_t raw[PLDS]; uint8_t f[PLDS]; alignas(16) uint8_t out[2 * PIECE + 64]; };   // out: slab image + one dump byte per lane
+struct PieceLds2 { uint8_t raw[PLDS]; uint8_t f[PLDS]; uint8_t chg[32]; alignas(16) uint8_t out[2 * PIECE + 64]; };   // out: slab image + one dump byte per lane
 
 __device__ const NmLut g_norm_lut = nm_make_lut();
 
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(256) void k_norm_emit2(const uint8_t* __restrict__ 
     // the rule.  E = the lanes that emit at least one byte: all, but for the third lane of a Hangul syllable without a final consonant.
     unsigned long long E = ~0ull;
     uint32_t below = posabs + (uint32_t)lane, n = len1 + 1u;           // first output byte of the lane before the extra bytes of the lanes below it; bytes it emits
-    if (__ballot(b >= 0x80u) != 0ull) {
+    if (__ballot(b >= 0x80u) != 0ull && __builtin_amdgcn_readfirstlane((int)L.chg[c]) != 0) {      // (a chunk of nothing but inert characters - punctuation, ideographs, Thai ... - emits its bytes as they are)
       if (b >= 0x80u) {
         const HighOut h = emit_high_byte(rc, fl, code, HighOut{o3, ysp, m3, len1}, &s_tab, two);
         o3 = h.o3; ysp = h.ysp; m3 = h.m3; len1 = h.len1;

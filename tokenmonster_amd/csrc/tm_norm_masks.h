@@ -292,23 +292,25 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
   if (code == 0u && (tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp3)) return (uint32_t)NC_LO | cont;       // decomposes, but by arithmetic: nm_hangul_out
   return code == 0u ? (uint32_t)NF_BAD : ((code == 3u ? (uint32_t)NC_M : (code == 2u ? (uint32_t)NC_LO : (uint32_t)NC_O)) | cont);      // (3: a combining mark of class 0)
 }
-// The same per CHARACTER, at its first byte b (>= 0xC0): class of the first byte | class of its other bytes << 8 | its length << 16 - what
+// The same per CHARACTER, at its first byte b (>= 0xC0): class of the first byte | class of its other bytes << 8 | its length << 16 | (the pass
+// changes its bytes: a two-byte character - they come from the table -, one NFD splits, a Hangul syllable) << 24 - what
 // nm_classify_high says of each of its bytes, for one decoding of the character instead of one per byte (a character that is not taken:
 // NF_BAD in both, length 1; the bytes behind it keep the NF_BAD the caller has given every byte beyond ASCII beforehand).
 TM_HD uint32_t nm_classify_char(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m3, uint32_t p1, uint32_t p2, uint32_t p3, const NmTabs& tabs) {
   const uint32_t cls = nm_classify_high(b, m1, m2, m3, p1, p2, p3, tabs);
   if (cls == NF_BAD || !(nm_two_lead(b) || nm_three_lead(b) || nm_four_lead(b))) return NF_BAD | (NF_BAD << 8) | (1u << 16);
-  uint32_t cont = cls | NF_CONT, n = 4u;
+  uint32_t cont = cls | NF_CONT, n = 4u, changes = 0u;
   if (nm_two_lead(b)) {
-    n = 2u;
+    n = 2u; changes = 1u;
     if (nm_two_get(tabs, nm_two_index(b, p1)).a & (NT_DECOMP | NT_DECOMP2)) cont = NC_M;            // the second half of a character that decomposes emits the mark
   } else if (nm_three_lead(b)) {
     n = 3u;
     const uint32_t cp3 = nm_cp3(b, p1, p2);                                                          // a letter and its marks (Latin Extended Additional, a voiced kana, a character NFD splits): the other lanes are marks
     if (((tabs.misc & NM_MISC_LEA) && cp3 - 0x1E00u < (uint32_t)NM_LEA_SIZE && (tabs.lea[cp3 - 0x1E00u].a & NT_OK)) ||
-        ((tabs.misc & NM_MISC_KANA) && cp3 - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[cp3 - 0x3040u] & NK_OK)) || (nm_dec3(tabs, cp3) & ND_OK)) cont = NC_M;
+        ((tabs.misc & NM_MISC_KANA) && cp3 - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[cp3 - 0x3040u] & NK_OK)) || (nm_dec3(tabs, cp3) & ND_OK)) { cont = NC_M; changes = 1u; }
+    else if ((tabs.misc & NM_MISC_HANGUL) && nm_hangul(cp3)) changes = 1u;
   }
-  return cls | (cont << 8) | (n << 16);
+  return cls | (cont << 8) | (n << 16) | (changes << 24);
 }
 // the bytes of a lane that holds one byte of a two-byte character: *o3 = its last output byte; returns how many bytes the lane emits
 // IN FRONT of it: 0, 1 (*y: the second half of a character that decomposes into an ASCII letter and a mark emits the mark) or 2 (*m3 *y:

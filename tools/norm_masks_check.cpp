@@ -48,7 +48,7 @@ bool classify(const std::vector<uint8_t>& d, bool lower_all, std::vector<uint8_t
     if ((d[i] & 0xC0u) != 0xC0u) continue;
     const uint32_t r = nm_classify_char(d[i], at(i - 1), at(i - 2), at(i - 3), at(i + 1), at(i + 2), at(i + 3), tabs_of(lower_all));
     if ((r & 0xFFu) == NF_BAD) continue;
-    for (int j = 0; j < (int)(r >> 16) && i + j < n; j++) f[i + j] = (uint8_t)(j ? (r >> 8) : r);
+    for (int j = 0; j < (int)((r >> 16) & 0xFFu) && i + j < n; j++) f[i + j] = (uint8_t)(j ? (r >> 8) : r);
   }
   for (int i = 0; i < n; i++) if (f[i] == NF_BAD) ok_all = false;
   return ok_all;
