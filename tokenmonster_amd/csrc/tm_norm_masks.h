@@ -152,9 +152,11 @@ TM_HD uint32_t nm_kana_out(uint32_t e, uint32_t role, uint32_t* o1, uint32_t* o2
   return 3u;
 }
 // what a kernel knows the tables by: the fast part of the two-byte table and the block table (LDS), the full tables (global memory)
-// (56 bytes, and no more: the out-of-line classifier takes it by value - in registers; at 64 bytes the compiler passes it through scratch memory)
+// (The later tables - kana, classes, split characters - are reached from `lea` instead of through pointers of their own: while the out-of-line
+// functions of tm_norm.hip took this struct by value, a 64-byte form of it made the kernels fault on the device.  They now get two pointers and
+// put it together themselves - tm_norm.hip: tabs_from -, and the struct is kept small all the same.)
 struct NmTabs { const NmTwo* two_fast; const NmTwo* two_all; const uint32_t* blk; const uint32_t* cp; const uint32_t* blk4; uint32_t misc; const NmLea* lea; };
-static_assert(sizeof(NmTabs) <= 56, "NmTabs is passed by value to noinline device functions");
+static_assert(sizeof(NmTabs) <= 56, "the later tables are reached from lea");
 TM_HD const uint16_t* nm_kana_tab(const NmTabs& t) { return reinterpret_cast<const uint16_t*>(t.lea + NM_LEA_SIZE); }      // the kana entries lie behind those of Latin Extended Additional
 // ---- three-byte combining marks of canonical class > 0 in U+0800..U+1FFF under NFD (round 6): the virama and nukta of the Indic scripts, the
 // tone marks and the vowels below of Thai and Lao, Tibetan, Myanmar, Khmer ... - what sent every Hindi or Thai document to the host ----------
