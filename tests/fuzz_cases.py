@@ -121,7 +121,7 @@ KANA = list("„ÅÇ„Åã„Åç„Åè„Åë„Åì„Åï„Åó„Åü„Å™„ÅØ„Å≤„Åæ„ÇÑ„Çâ„Çè„Çì„Åå„Åé„Åê„Åí„Åî„
 # round 6: Devanagari and Thai with their marks of canonical class > 0 (virama 9, nukta 7, the Thai vowels below 103 and tone marks 107: in and out of
 # order), three-byte digits, letters that decompose (the host's), a Latin mark among them
 INDIC_THAI = list("‡§ï‡§ñ‡§ó‡§ú‡§°‡§§‡§®‡§™‡§Æ‡§∞‡§≤‡§µ‡§∏‡§π‡§Ö‡§Ü‡§á‡§è‡§ì") + ["\u093e", "\u093f", "\u0940", "\u0947", "\u094b", "\u094d", "\u094d", "\u093c", "\u0902", "\u0951", "\u0952", "‡•ß", "‡•®", "\u0929", "\u0958"] + \
-             list("‡∏Å‡∏Ç‡∏Ñ‡∏á‡∏à‡∏î‡∏ï‡∏ô‡∏ö‡∏õ‡∏°‡∏¢‡∏£‡∏•‡∏ß‡∏™‡∏´‡∏≠‡∏≤‡πÄ‡πÅ‡πÑ") + ["\u0e31", "\u0e34", "\u0e35", "\u0e38", "\u0e39", "\u0e48", "\u0e49", "\u0e4a", "\u0e4c", "‡πë", "‡πí", "\u09cb", "\u0301", "\u09cc", "‡¶ï", "\u0bca", "‡Æ§", "\u0958", "\u095b", "\u0ccb", "\u1026"]
+             list("‡∏Å‡∏Ç‡∏Ñ‡∏á‡∏à‡∏î‡∏ï‡∏ô‡∏ö‡∏õ‡∏°‡∏¢‡∏£‡∏•‡∏ß‡∏™‡∏´‡∏≠‡∏≤‡πÄ‡πÅ‡πÑ") + ["\u0e31", "\u0e34", "\u0e35", "\u0e38", "\u0e39", "\u0e48", "\u0e49", "\u0e4a", "\u0e4c", "‡πë", "‡πí", "\u09cb", "\u0301", "\u09cc", "‡¶ï", "\u0bca", "‡Æ§", "\u0958", "\u095b", "\u0ccb", "\u1026", "·Éê", "·Éë", "·É•", "·¥Ä", "·≤ê"]
 
 
 def one_norm(seed):

@@ -189,6 +189,24 @@ for (let i = 0; i < 1600; i++) {
   inputs.push(s);
 }
 
+// round 6, fourth part: lower-case letters of three bytes (Georgian Mkhedruli, the phonetic extensions) - class L to capcode, nothing changes them;
+// their capitals (Mtavruli) stay the host's.  Appended BEHIND everything else again.
+const geo = 'აბგდევზთიკლმნოპჟრსტუფქღყშჩცძწჭხჯჰ'.split('');
+const gwords = ['საქართველო', 'თბილისი', 'ქართული', 'ენა', 'და', 'არის', 'ᴀ', 'ᴛᴇxᴛ', 'ᲡᲐᲥᲐᲠᲗᲕᲔᲚᲝ', 'Tbilisi', 'GPU', 'it', 's', '2024'];
+const flavours9 = [
+  () => pick([geo, geo, lower, upper, [' '], digits, apos, punct]),
+  () => pick([gwords, gwords, [' '], [' '], apos, punct, digits, upper]),
+  () => pick([geo, ['ᴀ', 'ᴇ', 'ᴛ', 'ᵃ', 'ᶜ', 'Ა', 'Ბ', 'Ꭰ', 'ꭰ'], marks, lower, upper, [' '], apos, digits]),
+];
+['საქართველო არის ქვეყანა.', "Aა Bბ'S 1გ2 'დ'", 'აA აb GAა ააა', 'ქართული ენა 2024 GPU', 'ᴛᴇxᴛ in small caps', 'ა\u0301 ა́ბ', 'ᲡᲐᲥᲐᲠᲗᲕᲔᲚᲝ Mtavruli'].forEach(s => inputs.push(s));
+for (let i = 0; i < 900; i++) {
+  const f = flavours9[i % flavours9.length];
+  const n = rnd(rnd(4) === 0 ? 90 : 28);
+  let s = '';
+  for (let k = 0; k < n; k++) s += pick(f());
+  inputs.push(s);
+}
+
 const b64 = s => Buffer.from(s, 'utf8').toString('base64');
 const cases = inputs.map(s => {
   const nfd = s.normalize('NFD');

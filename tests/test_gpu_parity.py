@@ -960,7 +960,7 @@ def test_hindi_and_thai_text_stays_on_the_device():
     hi = "यह हिन्दी का पाठ है और इसमें कई शब्द हैं जैसे कि विश्वविद्यालय प्रौद्योगिकी स्वतंत्रता ज़िन्दगी फ़िल्म क्या क्यों नहीं भारत दिल्ली मुम्बई १२३ GPU it's".split()
     th = ["ภาษาไทย", "อยู่", "ที่", "นี่", "กรุงเทพมหานคร", "ประเทศไทย", "สวัสดี", "ครับ", "ค่ะ", "น้ำ", "ผู้", "ใหญ่", "ไม่", "ได้", "เป็น", "คุณ", "รู้", "เรื่อง", "GPU", "Bangkok", "๑๒๓"]
     # (... and the characters NFD splits in two or three three-byte ones - Bengali's and Tamil's two-part vowel signs, the nukta letters as one code point, Kannada ೋ and Sinhala ෝ: nm_dec3)
-    other = ["ລາວ", "ພາສາ", "བོད་སྐད", "မြန်မာ", "ខ្មែរ", "ભાષા", "தமிழ்", "ಕನ್ನಡ", "తెలుగు", "മലയാളം", "বাংলাদেশের", "কোনো", "হবে", "மொழி", "போகிறோம்", "കൊല്ലം", "\u0958\u093f\u0932\u093e", "\u095b\u094d\u092f\u093e\u0926\u093e", "ଓଡ଼ିଆ", "ಕೋಲಾರ", "ಯೋಗ", "හෝ", "සිංහල"]
+    other = ["ລາວ", "ພາສາ", "བོད་སྐད", "မြန်မာ", "ខ្មែរ", "ભાષા", "தமிழ்", "ಕನ್ನಡ", "తెలుగు", "മലയാളം", "বাংলাদেশের", "কোনো", "হবে", "மொழி", "போகிறோம்", "കൊല്ലം", "\u0958\u093f\u0932\u093e", "\u095b\u094d\u092f\u093e\u0926\u093e", "ଓଡ଼ିଆ", "ಕೋಲಾರ", "ಯೋಗ", "හෝ", "සිංහල", "საქართველო", "ქართული", "ენა"]      # (... Georgian: lower-case letters of three bytes, class L)
     odd = ["\u0f73", "\u0f75", "क\u094d\u093c", "\u0e48\u0e38", "क\u0301", "\u1e09\u0e48", "\u0958\u0301"]         # what stays with the host: Tibetan vowel signs whose first part is a mark of class > 0, marks out of order, a Latin mark among them
     docs, host_docs = [], 0
     total, target = 0, 120_000 if EMULATED else 3_000_000

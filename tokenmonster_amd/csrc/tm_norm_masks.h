@@ -167,7 +167,8 @@ TM_HD const uint16_t* nm_kana_tab(const NmTabs& t) { return reinterpret_cast<con
 // (the NFD flag without `accents`; without NFD every mark is inert and build_three_tables says so).  The table lies behind the kana entries.
 // The same table names the decimal digits of the range (NM_CCC_DIGIT: no canonical class is 255) - Devanagari, Bengali, Thai ... digits are
 // class N to capcode like the ASCII and the two-byte ones, whatever the flags.
-constexpr uint32_t NM_CCC_BASE = 0x800u, NM_CCC_SIZE = 0x1800u, NM_MISC_CCC = 8u, NM_CCC_DIGIT = 255u;
+// ... and its lower-case letters of three bytes (NM_CCC_LOWER: Georgian, the phonetic extensions ...), class L: nothing ever changes them.
+constexpr uint32_t NM_CCC_BASE = 0x800u, NM_CCC_SIZE = 0x1800u, NM_MISC_CCC = 8u, NM_CCC_DIGIT = 255u, NM_CCC_LOWER = 254u;
 TM_HD const uint8_t* nm_ccc_tab(const NmTabs& t) { return reinterpret_cast<const uint8_t*>(nm_kana_tab(t) + NM_KANA_SIZE); }
 // ---- three-byte characters of U+0900..U+1BFF that NFD splits in TWO three-byte characters (round 6): the two-part vowel signs of Bengali, Tamil,
 // Malayalam, Oriya ... (ো -> ে + া), the nukta letters written as one code point (क़ -> क + ़), Myanmar ဦ, Balinese ... -----------------------------
@@ -230,11 +231,11 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
     // ... the same behind a character of Latin Extended Additional, which ends in a mark of its own
     if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_LEA) && m3 == 0xE1u && m2 - 0xB8u < 4u && nm_cont_byte(m1) && (tabs.lea[((m2 & 3u) << 6) | (m1 & 63u)].a & NT_OK)) return NF_BAD;
     // ... behind a three-byte mark of class > 0 (whose place a two-byte mark of unknown class might have to take)
-    if ((a & NF_CLASS) == NC_M && nm_three_lead(m3) && nm_cont_byte(m2) && nm_cont_byte(m1) && nm_ccc3(tabs, nm_cp3(m3, m2, m1)) - 1u < NM_CCC_DIGIT - 1u) return NF_BAD;
+    if ((a & NF_CLASS) == NC_M && nm_three_lead(m3) && nm_cont_byte(m2) && nm_cont_byte(m1) && nm_ccc3(tabs, nm_cp3(m3, m2, m1)) - 1u < NM_CCC_LOWER - 1u) return NF_BAD;
     // ... behind a three-byte character that ends in a mark of class > 0 of its own (क़)
     if ((a & NF_CLASS) == NC_M && nm_three_lead(m3) && nm_cont_byte(m2) && nm_cont_byte(m1)) {
       const uint32_t pe = nm_dec3(tabs, nm_cp3(m3, m2, m1));
-      if ((pe & ND_OK) && nm_ccc3(tabs, nm_dec3_last(tabs, pe)) - 1u < NM_CCC_DIGIT - 1u) return NF_BAD;
+      if ((pe & ND_OK) && nm_ccc3(tabs, nm_dec3_last(tabs, pe)) - 1u < NM_CCC_LOWER - 1u) return NF_BAD;
     }
     // ... and behind a voiced kana
     if ((a & NF_CLASS) == NC_M && (tabs.misc & NM_MISC_KANA) && m3 == 0xE3u && m2 - 0x81u < 3u && nm_cont_byte(m1) && (nm_kana_tab(tabs)[((m2 - 0x81u) << 6) | (m1 & 63u)] & NK_OK)) return NF_BAD;
@@ -274,6 +275,7 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
   if (code == 0u) {
     const uint32_t c = nm_ccc3(tabs, cp3);
     if (c == NM_CCC_DIGIT) return (uint32_t)NC_N | cont;
+    if (c == NM_CCC_LOWER) return (uint32_t)NC_L | cont;
     if (c != 0u) {                                  // a mark of canonical class c > 0: in place unless the character in front of it ends in a mark that belongs behind it
       if (!cont) {
         if (nm_cont_byte(m1) && nm_two_lead(m2)) {
@@ -283,7 +285,7 @@ TM_HD uint32_t nm_classify_high(uint32_t b, uint32_t m1, uint32_t m2, uint32_t m
           const uint32_t pcp = nm_cp3(m3, m2, m1);
           const uint32_t pe = nm_dec3(tabs, pcp);      // (a character that is split in two ends in the mark that is its second half)
           const uint32_t pc = nm_ccc3(tabs, (pe & ND_OK) ? nm_dec3_last(tabs, pe) : pcp);
-          if (pc != NM_CCC_DIGIT && pc > c) return NF_BAD;
+          if (pc < NM_CCC_LOWER && pc > c) return NF_BAD;
           if ((tabs.misc & NM_MISC_LEA) && pcp - 0x1E00u < (uint32_t)NM_LEA_SIZE && (tabs.lea[pcp - 0x1E00u].a & NT_OK)) return NF_BAD;
           if ((tabs.misc & NM_MISC_KANA) && pcp - 0x3040u < (uint32_t)NM_KANA_SIZE && (nm_kana_tab(tabs)[pcp - 0x3040u] & NK_OK)) return NF_BAD;
         }

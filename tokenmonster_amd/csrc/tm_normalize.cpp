@@ -525,8 +525,10 @@ void build_ccc_table(uint32_t norm_flag, bool marks, uint8_t* out) {
     std::vector<uint8_t> low;
     put_lower(low, c1);
     const int ccc = u_getCombiningClass((UChar32)cp);
-    if (marks && low == in && classify(c1) == kMark && ccc > 0 && ccc < (int)NM_CCC_DIGIT) out[cp - NM_CCC_BASE] = (uint8_t)ccc;
+    if (marks && low == in && classify(c1) == kMark && ccc > 0 && ccc < (int)NM_CCC_LOWER) out[cp - NM_CCC_BASE] = (uint8_t)ccc;
     else if (low == in && classify(c1) == kDigit) out[cp - NM_CCC_BASE] = (uint8_t)NM_CCC_DIGIT;
+    // a lower-case letter of three bytes (Georgian Mkhedruli, the phonetic extensions, small Cherokee ...): capcode and the flags never change one
+    else if (low == in && (classify(c1) & kLower) && !(classify(c1) & (kUpper | kDigit | kMark))) out[cp - NM_CCC_BASE] = (uint8_t)NM_CCC_LOWER;
   }
 }
 

@@ -220,7 +220,7 @@ int main(int argc, char** argv) {
   build_ccc_table(1, true, g_lk[0].ccc); build_ccc_table(3, true, g_lk[1].ccc);
   build_dec3_table(g_lk[0].dec3); build_dec3_table(g_lk[1].dec3);
   { int n = 0; for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) n += (g_lk[0].dec3[k] & ND_OK) != 0; int n3 = 0; for (uint32_t k = 0; k < NM_DEC3_SIZE; k++) n3 += ((g_lk[0].dec3[k] >> 26) & 15u) != 0; printf("three-byte characters NFD splits in two or three, on the device: %d (%d of them in three)\n", n, n3); }
-  { int n = 0; for (uint32_t k = 0; k < NM_CCC_SIZE; k++) n += g_lk[0].ccc[k] != 0 && g_lk[0].ccc[k] != NM_CCC_DIGIT; printf("three-byte marks of canonical class > 0 in U+0800..U+1FFF on the device: %d\n", n); }
+  { int n = 0; for (uint32_t k = 0; k < NM_CCC_SIZE; k++) n += g_lk[0].ccc[k] != 0 && g_lk[0].ccc[k] < NM_CCC_LOWER; printf("three-byte marks of canonical class > 0 in U+0800..U+1FFF on the device: %d\n", n); }
   { int ok = 0; for (int k = 0; k < NM_KANA_SIZE; k++) ok += (g_kana[k] & NK_OK) != 0; printf("voiced kana (NFD): %d characters of U+3040..U+30FF on the device\n", ok); }
   { int ok = 0, two = 0; for (int k = 0; k < NM_LEA_SIZE; k++) { ok += (g_lk[0].lea[k].a & NT_OK) != 0; two += (g_lk[0].lea[k].a & NT_OK) && ((g_lk[0].lea[k].a >> 24) & 3u) == 2u; }
     printf("Latin Extended Additional (NFD): %d of %d characters on the device, %d of them with two marks\n", ok, NM_LEA_SIZE, two); }
@@ -280,7 +280,8 @@ int main(int argc, char** argv) {
             case 10: cp = 0x0900 + rng.below(0x80); if (rng.below(5) == 0) cp = rng.below(2) ? 0x094D : (rng.below(2) ? 0x093C : 0x0951 + rng.below(4));      // Devanagari: virama 9, nukta 7, accents 230 / 220 - in and out of order, the letters that decompose
                      if (rng.below(40) == 0) cp = 0x0300 + rng.below(0x30); if (rng.below(30) == 0) cp = 0x0980 + rng.below(0x80); break;             // ... a Latin mark, Bengali (two-part vowels decompose)
             case 11: cp = 0x0E01 + rng.below(0x3A); if (rng.below(4) == 0) cp = rng.below(2) ? 0x0E38 + rng.below(3) : 0x0E48 + rng.below(4);                // Thai: vowels below 103, tone marks 107 (อยู่: 103 then 107, in order)
-                     if (rng.below(30) == 0) cp = 0x0EB8 + rng.below(2); if (rng.below(30) == 0) cp = 0x0F71 + rng.below(0x14); if (rng.below(30) == 0) cp = 0x1037 + rng.below(4); break;   // ... Lao, Tibetan, Myanmar marks
+                     if (rng.below(30) == 0) cp = 0x0EB8 + rng.below(2); if (rng.below(30) == 0) cp = 0x0F71 + rng.below(0x14); if (rng.below(30) == 0) cp = 0x1037 + rng.below(4);
+                     if (rng.below(12) == 0) cp = rng.below(8) ? 0x10D0 + rng.below(0x2B) : (rng.below(2) ? 0x1D00 + rng.below(0x80) : 0x1C90 + rng.below(0x2B)); break;   // ... Lao, Tibetan, Myanmar marks; Georgian (lower-case letters of three bytes), phonetic extensions, Mtavruli capitals (the host's)
             case 9: {                                                                        // four bytes: emoji and pictographs, plane-2 ideographs, mathematical letters; now and then what the host has to do
               const uint32_t q = rng.below(40);
               cp = q < 20 ? 0x1F300 + rng.below(0x700) : q < 28 ? 0x20000 + rng.below(0xA000) : q < 34 ? 0x1D400 + rng.below(0x400) : q < 36 ? 0x10000 + rng.below(0x100) :
