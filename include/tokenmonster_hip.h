@@ -175,7 +175,7 @@ int tm_batch_upload(tm_batch* b, const uint8_t* text, const uint64_t* offsets, u
  * three-byte characters the normalizer leaves alone (General Punctuation, CJK ideographs, kana, symbols), the voiced kana under NFD (a kana and
  * U+3099 / U+309A each: Japanese text), Hangul syllables (decomposed by arithmetic) and the four-byte characters of caseless, NFD-stable blocks
  * (emoji, symbols, plane-2 ideographs), the three-byte combining marks of U+0800..U+1FFF where they stand in canonical order (virama, nukta, the
- * Thai tone marks ...: Hindi, Thai) and the three-byte decimal digits; documents with anything else (cased scripts beyond the BMP, a capital
+ * Thai tone marks ...: Hindi, Thai) and the three-byte decimal digits and lower-case letters (Georgian); documents with anything else (cased scripts beyond the BMP, a capital
  * without a lower-case form - U+03D2..U+03D4 -, a character of three bytes that NFD splits in three, marks out of canonical order or behind a character that
  * ends in one of its own, malformed UTF-8) are normalized by the host normalizer inside the same call, from their original
  * bytes; tm_batch_host_fallback_docs reports how many.  (TM_NORM_WG_PER_CU in the environment: the grid of the pass, workgroups per compute
